@@ -1,0 +1,232 @@
+"""The reference's own integration tests (tests/*.rs of bacpop/ska.rust), restated engine-agnostically.
+
+Each case takes an engine `E` exposing the mirrored reference API
+(E.Array.build / load / save / align / distance_tsv / nk, E.qual, E.FILTER_*,
+E.QUAL_*, E.sample_name).  tests/test_oracle_golden.py runs them on the CPU
+oracle (pins the oracle); tests/test_gpu_golden.py runs the same cases on the
+HIP path through the C ABI.
+"""
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+IN = os.path.join(HERE, "golden", "input")
+OK = os.path.join(HERE, "golden", "correct")
+
+
+def fin(name):
+    return os.path.join(IN, name)
+
+
+def correct(name):
+    with open(os.path.join(OK, name), "rb") as f:
+        return f.read()
+
+
+def var_hash(aln: bytes):
+    """tests/common/mod.rs:166-189"""
+    lines = aln.decode().splitlines()
+    seqs = [lines[i] for i in range(1, len(lines), 2)]
+    if not seqs:
+        return set()
+    return {tuple(s[c] for s in seqs) for c in range(len(seqs[0]))}
+
+
+def aln_length(aln: bytes):
+    lines = aln.decode().splitlines()
+    return [len(lines[i]) for i in range(1, len(lines), 2)]
+
+
+def matches_path(out: bytes, golden: bytes):
+    """snapbox stdout_matches_path: `[..]` is a within-line wildcard."""
+    o, g = out.decode().split("\n"), golden.decode().split("\n")
+    assert len(o) == len(g), (out, golden)
+    for a, b in zip(o, g):
+        pat = ".*".join(re.escape(x) for x in b.split("[..]"))
+        assert re.fullmatch(pat, a), (a, b)
+
+
+def fasta_inputs(E, files):
+    return [(E.sample_name(f), f, None) for f in files]
+
+
+def rfile(prefix, fastq):
+    if fastq:
+        return [(f"{prefix}_{i}", fin(f"{prefix}_{i}_fwd.fastq.gz"), fin(f"{prefix}_{i}_rev.fastq.gz")) for i in (1, 2)]
+    return [(f"{prefix}_{i}", fin(f"{prefix}_{i}.fa"), None) for i in (1, 2)]
+
+
+def roundtrip(E, arr, tmp_path, name):
+    """`ska build -o x` then a second command loading x.skf: exercise save+load like the CLI tests do."""
+    p = os.path.join(str(tmp_path), name + ".skf")
+    arr.save(p)
+    return E.Array.load(p)
+
+
+# ---------------------------------------------------------------- tests/align.rs
+def case_build_proportion_reads(E, tmp_path):       # align.rs:33-60
+    a = E.Array.build(fasta_inputs(E, [fin("proportion_reads.fa")]), k=17, rc=False, proportion_reads=0.5)
+    a = roundtrip(E, a, tmp_path, "build_proportion_reads")
+    matches_path(a.nk(full_info=True), correct("proportion_reads.stdout"))
+
+
+def case_build_and_align(E, tmp_path):              # align.rs:86-114, basic_align :169-184
+    a = E.Array.build(fasta_inputs(E, [fin("test_1.fa"), fin("test_2.fa")]), k=15)
+    a = roundtrip(E, a, tmp_path, "basic_build")
+    assert var_hash(a.align()) == {("A", "T"), ("C", "T")}
+    b = E.Array.build(fasta_inputs(E, [fin("test_1.fa"), fin("test_2.fa")]))   # `ska align a.fa b.fa` defaults
+    assert var_hash(b.align()) == {("A", "T"), ("C", "T")}
+
+
+def case_long_kmers(E, tmp_path):                   # align.rs:116-167
+    a = E.Array.build(fasta_inputs(E, [fin("test_1.fa"), fin("test_2.fa")]), k=33)
+    a = roundtrip(E, a, tmp_path, "build_k33")
+    assert var_hash(a.align()) == {("C", "T"), ("T", "A")}
+    a = E.Array.load(os.path.join(str(tmp_path), "build_k33.skf"))
+    matches_path(a.nk(), correct("k33.stdout"))
+    try:
+        E.Array.build(fasta_inputs(E, [fin("test_1.fa"), fin("test_2.fa")]), k=65)
+    except Exception:
+        pass
+    else:
+        raise AssertionError("k=65 must fail")
+
+
+def case_filters(E, tmp_path):                      # align.rs:186-347
+    def load():
+        return E.Array.load(fin("merge_k9.skf"))
+    assert set(aln_length(load().align(filter_type=E.FILTER_NONE, ignore_const_gaps=True))) == {38}
+    assert set(aln_length(load().align(filter_type=E.FILTER_NO_AMBIG, filter_ambig_as_missing=True))) == {37}
+    assert var_hash(load().align(filter_type=E.FILTER_NO_CONST)) == {("T", "A"), ("C", "T"), ("S", "G")}
+    assert var_hash(load().align(filter_type=E.FILTER_NO_AMBIG_OR_CONST)) == {("T", "A"), ("C", "T")}
+    assert var_hash(load().align(filter_type=E.FILTER_NO_CONST, mask_ambig=True)) == {("T", "A"), ("C", "T"), ("N", "G")}
+    assert set(aln_length(load().align(filter_type=E.FILTER_NO_CONST, min_freq=0.0))) == {33}
+    assert set(aln_length(load().align(filter_type=E.FILTER_NO_CONST, min_freq=0.0, ignore_const_gaps=True))) == {3}
+    assert set(aln_length(load().align(filter_type=E.FILTER_NO_AMBIG_OR_CONST, min_freq=0.0))) == {32}
+    assert set(aln_length(load().align(filter_type=E.FILTER_NO_AMBIG_OR_CONST, min_freq=0.0, ignore_const_gaps=True))) == {2}
+
+
+def case_parallel_align(E, tmp_path):               # align.rs:349-397
+    d = os.path.join(IN, "par_test")
+    inputs = [(os.path.join(d, f), os.path.join(d, f), None) for f in sorted(os.listdir(d))]
+    s = roundtrip(E, E.Array.build(inputs, k=15, threads=1), tmp_path, "serial_build")
+    p = roundtrip(E, E.Array.build(inputs, k=15, threads=4), tmp_path, "parallel_build")
+    assert var_hash(s.align()) == var_hash(p.align())
+    assert s.nsamples == 45
+
+
+# ---------------------------------------------------------------- tests/fasta_input.rs
+def case_align_n(E, tmp_path):                      # fasta_input.rs:11-32
+    a = E.Array.build(fasta_inputs(E, [fin("N_test_1.fa"), fin("N_test_2.fa")]))
+    a = roundtrip(E, a, tmp_path, "N_test")
+    assert a.align() == correct("align_N.stdout")
+
+
+def case_rev_comp(E, tmp_path):                     # fasta_input.rs:60-154
+    no_rc = E.Array.build(fasta_inputs(E, [fin("test_1.fa"), fin("test_2.fa")]), k=15).align()
+    rc = E.Array.build(fasta_inputs(E, [fin("test_1.fa"), fin("test_2_rc.fa")]), k=15).align()
+    assert var_hash(no_rc) == var_hash(rc)
+    ss = E.Array.build(fasta_inputs(E, [fin("test_1.fa"), fin("test_2_rc.fa")]), k=15, rc=False).align()
+    assert var_hash(ss) == set()
+    k33 = E.Array.build(fasta_inputs(E, [fin("test_1.fa"), fin("test_2.fa")]), k=33, rc=False).align()
+    assert var_hash(k33) == {("T", "A"), ("G", "A")}
+
+
+def case_repeats(E, tmp_path):                      # fasta_input.rs:156-220 (the weed step is next-tier N1)
+    a = E.Array.build(fasta_inputs(E, [fin("dup_test_1.fa"), fin("dup_test_2.fa")]), k=9, rc=False)
+    a = roundtrip(E, a, tmp_path, "dup_ss")
+    assert a.align() == correct("dup_ss.stdout")
+    b = E.Array.build(fasta_inputs(E, [fin("dup_test_1.fa"), fin("dup_test_2.fa")]), k=9)
+    assert roundtrip(E, b, tmp_path, "dup_rc").align() == correct("dup_rc.stdout")
+
+
+def case_palindromes(E, tmp_path):                  # fasta_input.rs:222-291
+    a = E.Array.build(fasta_inputs(E, [fin("palindrome_1.fa"), fin("palindrome_2.fa")]), k=15)
+    assert roundtrip(E, a, tmp_path, "otto").align(filter_type=E.FILTER_NONE) == correct("palindrome.stdout")
+    b = E.Array.build(fasta_inputs(E, [fin("palindrome_1.fa"), fin("palindrome_2.fa")]), k=15, rc=False)
+    assert roundtrip(E, b, tmp_path, "otan").align() == correct("palindrome_norc.stdout")
+    c = E.Array.build(fasta_inputs(E, [fin("palindrome_reps_1.fa"), fin("palindrome_reps_2.fa")]), k=15)
+    assert roundtrip(E, c, tmp_path, "ottootto").align(filter_type=E.FILTER_NONE) == correct("palindrome_reps.stdout")
+
+
+# ---------------------------------------------------------------- tests/fastq_input.rs
+def case_align_fastq(E, tmp_path):                  # fastq_input.rs:11-55
+    r = E.Array.build(rfile("test", True), k=9, q=E.qual(min_count=2, min_qual=2))
+    f = E.Array.build(fasta_inputs(E, [fin("test_1.fa"), fin("test_2.fa")]), k=9)
+    assert var_hash(roundtrip(E, r, tmp_path, "reads").align()) == var_hash(roundtrip(E, f, tmp_path, "fasta_k9").align())
+
+
+def case_count_check(E, tmp_path):                  # fastq_input.rs:57-109
+    c1 = E.Array.build(rfile("test_count", True), k=7, q=E.qual(min_count=1))
+    assert var_hash(c1.align()) == {("C", "W")}
+    c3 = E.Array.build(rfile("test_count", True), k=7, q=E.qual(min_count=3))
+    assert var_hash(c3.align()) == {("C", "T")}
+
+
+def case_count_check_long(E, tmp_path):             # fastq_input.rs:111-192
+    c1 = E.Array.build(rfile("test_long", True), k=63, q=E.qual(min_count=1))
+    assert var_hash(c1.align()) == {("G", "M")}
+    c3 = E.Array.build(rfile("test_long", True), k=63, q=E.qual(min_count=3))
+    h3 = var_hash(roundtrip(E, c3, tmp_path, "reads_k63_c3").align())
+    assert h3 == {("G", "A")}
+    ss = E.Array.build(rfile("test_long", True), k=63, rc=False, q=E.qual(min_count=2))
+    assert var_hash(ss.align()) == h3
+
+
+def case_error_fastq(E, tmp_path):                  # fastq_input.rs:276-470
+    allh = var_hash(E.Array.build(rfile("test", True), k=9, q=E.qual(min_count=3, min_qual=2)).align())
+    assert allh
+    nofilter = E.Array.build(rfile("test_quality", True), k=9, q=E.qual(min_count=5, qual_filter=E.QUAL_NOFILTER))
+    assert var_hash(nofilter.align()) == allh
+    mid = E.Array.build(rfile("test_quality_base", True), k=9,
+                        q=E.qual(min_count=5, qual_filter=E.QUAL_MIDDLE, min_qual=5))
+    assert var_hash(mid.align()) == allh
+    allh = allh - {("C", "T")}                       # "With errors"
+    err = E.Array.build(rfile("test_error", True), k=9, q=E.qual(min_count=5, min_qual=2))
+    assert var_hash(err.align()) == allh
+    qual30 = E.Array.build(rfile("test_quality", True), k=9, q=E.qual(min_count=5, min_qual=30))
+    assert var_hash(qual30.align()) == allh
+    strict = E.Array.build(rfile("test_quality_base", True), k=9,
+                           q=E.qual(min_count=5, min_qual=5, qual_filter=E.QUAL_STRICT))
+    assert var_hash(strict.align()) == allh
+    dflt = E.Array.build(rfile("test_quality_base", True), k=9, q=E.qual(min_count=5))
+    assert var_hash(dflt.align()) == allh
+
+
+# ---------------------------------------------------------------- tests/distance.rs
+def case_basic_dists(E, tmp_path):                  # distance.rs:9-41
+    assert E.Array.load(fin("merge.skf")).distance_tsv() == correct("merge.dist.stdout")
+    assert E.Array.load(fin("merge_k41.skf")).distance_tsv() == correct("merge_k41.dist.stdout")
+
+
+def case_dist_filter(E, tmp_path):                  # distance.rs:44-77
+    assert E.Array.load(fin("merge_k9.skf")).distance_tsv(filt_ambig=False) == correct("merge_k9.dist.stdout")
+    assert E.Array.load(fin("merge_k9.skf")).distance_tsv() == correct("merge_k9_no_ambig.dist.stdout")
+    assert E.Array.load(fin("merge_k9.skf")).distance_tsv(min_freq=1.0) == correct("merge_k9_min_freq.dist.stdout")
+
+
+def case_multisample_dists(E, tmp_path):            # distance.rs:79-129
+    files = ["N_test_1.fa", "N_test_2.fa", "ambig_test_1.fa", "ambig_test_2.fa", "test_1.fa", "test_2.fa"]
+    a = E.Array.build(fasta_inputs(E, [fin(f) for f in files]), k=9)
+    p = os.path.join(str(tmp_path), "multidist.skf")
+    a.save(p)
+    assert E.Array.load(p).distance_tsv() == correct("multidist.stdout")
+    assert E.Array.load(p).distance_tsv(min_freq=0.9) == correct("multidist.minfreq.stdout")
+    assert E.Array.load(p).distance_tsv(filt_ambig=False) == correct("multidist.ambig.stdout")
+    # the fixture written by the Rust binary gives the same tables
+    assert E.Array.load(fin("multidist.skf")).distance_tsv() == correct("multidist.stdout")
+
+
+# ---------------------------------------------------------------- tests/skf_ops.rs (nk part)
+def case_merge_nk(E, tmp_path):                     # skf_ops.rs merge_nk golden: build of test_1/test_2 at k=31
+    a = E.Array.build(fasta_inputs(E, [fin("test_1.fa"), fin("test_2.fa")]), k=31)
+    matches_path(roundtrip(E, a, tmp_path, "merge").nk(), correct("merge_nk.stdout"))
+
+
+def case_dup_ss_nk_shape(E, tmp_path):
+    a = E.Array.build(fasta_inputs(E, [fin("dup_test_1.fa"), fin("dup_test_2.fa")]), k=9, rc=False)
+    out = a.nk(full_info=True).decode()
+    assert "GATT\tAAGG\tK,D\n" in out
+
+
+ALL_CASES = [v for k, v in sorted(globals().items()) if k.startswith("case_")]

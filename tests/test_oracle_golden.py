@@ -1,0 +1,77 @@
+"""Pins the CPU oracle against the reference's own golden vectors."""
+import numpy as np
+import pytest
+
+import golden_cases as G
+import ora
+
+
+@pytest.mark.parametrize("case", G.ALL_CASES, ids=lambda c: c.__name__)
+def test_reference_case(case, tmp_path):
+    case(ora, tmp_path)
+
+
+def _as_map(arr):
+    keys, var, counts = arr.export()
+    return {(int(k["hi"]) << 64) | int(k["lo"]): (bytes(v), int(c)) for k, v, c in zip(keys, var, counts)}
+
+
+@pytest.mark.parametrize("fixture,k,files", [
+    ("merge.skf", 17, ["test_1.fa", "test_2.fa"]),
+    ("merge_k9.skf", 9, ["test_1.fa", "test_2.fa"]),
+    ("merge_k41.skf", 41, ["test_1.fa", "test_2.fa"]),
+    ("multidist.skf", 9, ["N_test_1.fa", "N_test_2.fa", "ambig_test_1.fa", "ambig_test_2.fa", "test_1.fa", "test_2.fa"]),
+])
+def test_skf_fixture_reproduced(fixture, k, files):
+    """The four .skf files written by the Rust binary == our build, as exact {k-mer -> (row, count)} maps."""
+    ref = ora.Array.load(G.fin(fixture))
+    mine = ora.Array.build(G.fasta_inputs(ora, [G.fin(f) for f in files]), k=k)
+    assert ref.k == mine.k == k and ref.rc == mine.rc and ref.k_bits == mine.k_bits
+    assert ref.names == mine.names
+    assert _as_map(ref) == _as_map(mine)
+    assert ref.nkmers == {"merge.skf": 78, "merge_k9.skf": 68, "merge_k41.skf": 43, "multidist.skf": 89}[fixture]
+
+
+def test_skf_roundtrip(tmp_path):
+    for f in ("merge.skf", "merge_k41.skf", "multidist.skf"):
+        a = ora.Array.load(G.fin(f))
+        p = str(tmp_path / f)
+        a.save(p)
+        b = ora.Array.load(p)
+        assert _as_map(a) == _as_map(b) and a.names == b.names and a.version == b.version
+
+
+def test_load_u64_then_u128():
+    # lib.rs:635-661: a k=41 file must fail as u64 and load as u128
+    with pytest.raises(ora.OracleError):
+        ora.Array.load(G.fin("merge_k41.skf"), want_bits=64)
+    assert ora.Array.load(G.fin("merge_k41.skf"), want_bits=128).k_bits == 128
+
+
+def test_sample_names():
+    assert ora.sample_name("/a/b/test_1.fa") == "test_1"
+    assert ora.sample_name("x.fastq.gz") == "x"
+    assert ora.sample_name("dir/x.FASTA") == "x"
+    assert ora.sample_name("dir/x.fa.gz") == "dir/x.fa.gz"
+    assert ora.sample_name("x.fasta.fa") == "x.fasta"
+
+
+def test_end_quirk_q1():
+    """split_kmer.rs:89,121: a (re)start needs idx + k < len (strict)."""
+    k = 7
+    assert len(ora.extract_record(b"ACGTACG", k)[0]) == 0            # L == k -> nothing
+    assert len(ora.extract_record(b"ACGTACGT", k)[0]) == 2           # L == k+1 -> two windows
+    assert len(ora.extract_record(b"ACGTACGTNACGTACG", k)[0]) == 2   # trailing clean run of exactly k dropped
+    assert len(ora.extract_record(b"ACGTACGTNACGTACGA", k)[0]) == 4  # k+1 trailing run kept
+    assert len(ora.extract_record(b"ACGTACGNACGTACGAA", k)[0]) == 4  # run of exactly k before a bad base kept
+
+
+def test_nthash_roll_equals_recompute():
+    rng = np.random.default_rng(0)
+    seq = bytes(rng.choice(list(b"ACGT"), size=200).tolist())
+    for k in (7, 31, 33, 63):
+        for rc in (True, False):
+            _, _, _, h = ora.extract_record(seq, k, rc=rc, qual_bytes=b"I" * len(seq), is_reads=True)
+            for i in (0, 1, 50, len(h) - 2):
+                _, _, _, h1 = ora.extract_record(seq[i:i + k + 1], k, rc=rc, qual_bytes=b"I" * (k + 1), is_reads=True)
+                assert h[i] == h1[0]
