@@ -1,0 +1,157 @@
+/*
+ * skx.h -- C ABI of the MI355X-native split-k-mer engine (libskx.so).
+ *
+ * Drop-in boundary for the build -> merge -> align/distance path of
+ * bacpop/ska.rust v0.5.2.  The reference has no FFI layer; the seam is the
+ * generic Rust API that lib.rs::main calls.  Every entry
+ * point below cites the reference interface it replaces.  Plain pointers and
+ * sizes only; no C++/torch types.  All functions return 0 on success and a
+ * non-zero SKX_E* code on failure (skx_last_error() gives the message, which
+ * matches the reference's panic text where one exists); nothing throws or
+ * longjmps across the boundary.  Handles own host + device memory and are
+ * released by the caller.  There is NO CPU fallback: every compute entry
+ * point fails with SKX_ENODEV when no gfx950 device is usable.
+ */
+#ifndef SKX_H
+#define SKX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SKX_OK        0
+#define SKX_EINVAL    1   /* bad argument (bad k, mismatched k/rc, ...)          */
+#define SKX_EIO       2   /* unreadable / malformed input file                   */
+#define SKX_ENODEV    3   /* no usable HIP device / HIP runtime error            */
+#define SKX_ENOMEM    4
+#define SKX_EEMPTY    5   /* "<file> has no valid sequence" (ska_dict.rs:374)    */
+#define SKX_EUNSUP    6   /* feature not available on the device path            */
+#define SKX_EFORMAT   7   /* .skf decode error (lets a u64 load fall through to u128, lib.rs:635-661) */
+
+/* src/lib.rs QualFilter; src/cli.rs:27-29 defaults (min_count 5, min_qual 20, strict) */
+enum { SKX_QUAL_NOFILTER = 0, SKX_QUAL_MIDDLE = 1, SKX_QUAL_STRICT = 2 };
+/* src/cli.rs FilterType */
+enum { SKX_FILTER_NONE = 0, SKX_FILTER_NO_CONST = 1, SKX_FILTER_NO_AMBIG = 2, SKX_FILTER_NO_AMBIG_OR_CONST = 3 };
+
+/* QualOpts (src/lib.rs; used by merge_ska_dict.rs:354-361, ska_dict.rs:333-341) */
+typedef struct {
+    uint16_t min_count;
+    uint8_t  min_qual;
+    int32_t  qual_filter;
+} skx_qual;
+
+typedef struct { uint64_t lo, hi; } skx_key;   /* split k-mer as the reference encodes it; hi == 0 for k <= 31 */
+
+typedef struct skx_ctx     skx_ctx;      /* one per GPU / process                                   */
+typedef struct skx_dictset skx_dictset;  /* a batch of per-sample SkaDicts, device resident         */
+typedef struct skx_keyset  skx_keyset;   /* sorted unique split k-mers (rows of a merged array)     */
+typedef struct skx_array   skx_array;    /* MergeSkaArray: keys + samples x k-mers middle bases     */
+
+const char *skx_last_error(void);
+const char *skx_version(void);            /* "0.5.2": the ska_version written into .skf files      */
+
+int  skx_ctx_create(int device, skx_ctx **out);
+void skx_ctx_destroy(skx_ctx *ctx);
+int  skx_ctx_sync(skx_ctx *ctx);          /* drain the context's HIP stream                         */
+void *skx_ctx_stream(skx_ctx *ctx);       /* the hipStream_t all kernels of this ctx are launched on */
+
+/* ------------------------------------------------------------------------------------------
+ * Record stream: what the host reader hands to the device in place of needletail's record
+ * iterator (ska_dict.rs:131-153).  Each record's bases (line breaks removed) followed by one
+ * '\n'; `qual` (FASTQ only) has the same layout.  Pointers are host memory unless on_device.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const uint8_t *seq;
+    const uint8_t *qual;      /* NULL for FASTA input */
+    uint64_t       len;       /* bytes in seq (and qual) */
+} skx_stream;
+
+/* SkaDict::new for a batch of samples (ska_dict.rs:333-378; one GPU unit of work per sample,
+ * merge_ska_dict.rs:244,404).  k odd in 5..=63 else SKX_EINVAL "Invalid k-mer length".
+ * A sample without any split k-mer -> SKX_EEMPTY.  FASTQ streams (qual != NULL) apply the
+ * quality rules of split_kmer.rs:66-71,328-339 and the KmerFilter of bloom_filter.rs:116-148. */
+int skx_dictset_build(skx_ctx *ctx, const skx_stream *samples, int n_samples, int on_device,
+                      int k, int rc, const skx_qual *qual, skx_dictset **out);
+/* same, reading FASTA/FASTQ(.gz) files with the library's own reader (needletail replacement).
+ * file2[i] may be NULL.  proportion_reads 0 == None (ska_dict.rs:125-141). */
+int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, const char *const *file2, int n_samples,
+                            int k, int rc, const skx_qual *qual, int threads, double proportion_reads,
+                            skx_dictset **out);
+void skx_dictset_free(skx_dictset *d);
+int  skx_dictset_nsamples(const skx_dictset *d);
+int  skx_dictset_key_bits(const skx_dictset *d);      /* 64 | 128 (lib.rs:592) */
+/* SkaDict::ksize / kmers() (ska_dict.rs:499-512): entry count, then copy-out sorted by key */
+int  skx_dictset_size(skx_dictset *d, int sample, uint64_t *n);
+int  skx_dictset_export(skx_dictset *d, int sample, skx_key *keys, uint8_t *bases, uint64_t cap);
+
+/* ------------------------------------------------------------------------------------------
+ * MergeSkaDict::append/merge + MergeSkaArray::new (merge_ska_dict.rs:77-151,
+ * merge_ska_array.rs:166-186), split so that a multi-GPU host can all-gather key tables
+ * between the two halves:
+ *   skx_keyset_union   : distinct split k-mers over all samples of the dictset
+ *   skx_keyset_device / skx_keyset_from_device / skx_keyset_merge : exchange + combine tables
+ *   skx_array_assemble : rows = keyset, columns = the dictset's samples ('-' where absent)
+ * skx_merge() is the single-GPU composition of the three.
+ * ------------------------------------------------------------------------------------------ */
+int  skx_keyset_union(skx_ctx *ctx, skx_dictset *d, skx_keyset **out);
+int  skx_keyset_size(const skx_keyset *ks, uint64_t *n);
+/* device pointer to n packed 64-bit words per key (1 for k<=31, 2 above), engine order */
+int  skx_keyset_device(skx_keyset *ks, const void **dptr, uint64_t *n_keys, int *words_per_key);
+int  skx_keyset_from_device(skx_ctx *ctx, const void *dptr, uint64_t n_keys, int k, int rc, skx_keyset **out);
+int  skx_keyset_merge(skx_ctx *ctx, skx_keyset *const *sets, int n_sets, skx_keyset **out);
+void skx_keyset_free(skx_keyset *ks);
+int  skx_array_assemble(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows, const char *const *names, skx_array **out);
+int  skx_merge(skx_ctx *ctx, skx_dictset *d, const char *const *names, skx_array **out);
+
+/* build_and_merge (merge_ska_dict.rs:354-417) + MergeSkaArray::new: the `ska build` body */
+int skx_build_and_merge(skx_ctx *ctx, const char *const *names, const char *const *file1, const char *const *file2,
+                        int n_samples, int k, int rc, const skx_qual *qual, int threads, double proportion_reads,
+                        skx_array **out);
+
+/* ------------------------------------------------------------------------------------------ MergeSkaArray */
+void skx_array_free(skx_array *a);
+/* save / load (merge_ska_array.rs:191-204): snappy-frame(CBOR), want_bits 64|128|0 */
+int  skx_array_save(skx_array *a, const char *path);
+int  skx_array_load(skx_ctx *ctx, const char *path, int want_bits, skx_array **out);
+/* construct from host data (row-major [n_rows, n_samples] as in the .skf) */
+int  skx_array_from_host(skx_ctx *ctx, int k, int rc, const char *const *names, int n_samples,
+                         const skx_key *keys, const uint8_t *variants, uint64_t n_rows, const char *version,
+                         skx_array **out);
+typedef struct {
+    int32_t  k, rc, k_bits;
+    uint64_t n_kmers;      /* split_kmers.len() */
+    uint64_t n_rows;       /* variants.nrows()  */
+    uint64_t n_samples;
+} skx_array_info_t;
+int  skx_array_info(const skx_array *a, skx_array_info_t *info);
+const char *skx_array_name(const skx_array *a, uint64_t i);
+const char *skx_array_version(const skx_array *a);
+/* copy-out, rows sorted by key: keys[n_kmers], variants row-major [n_rows, n_samples], counts[n_rows] */
+int  skx_array_export(skx_array *a, skx_key *keys, uint8_t *variants, uint64_t *counts);
+/* n_sample_kmers (merge_ska_array.rs:554-559) */
+int  skx_array_sample_kmers(skx_array *a, int64_t *out);
+/* MergeSkaArray::filter (merge_ska_array.rs:289-402); *removed = its i32 return value */
+int  skx_array_filter(skx_array *a, uint64_t min_count, int filter_ambig_as_missing, int filter_type,
+                      int mask_ambig, int ignore_const_gaps, int update_kmers, int32_t *removed);
+/* write_fasta (merge_ska_array.rs:499-517): ">name\nSEQ\n" per sample to fd */
+int  skx_array_write_fasta(skx_array *a, int fd);
+/* same into a malloc'd buffer (free with skx_free) */
+int  skx_array_fasta(skx_array *a, char **buf, uint64_t *len);
+/* device view of the sample-major middle-base matrix: row s = sample s, pitch bytes apart */
+int  skx_array_device_matrix(skx_array *a, const uint8_t **dptr, uint64_t *pitch, uint64_t *n_rows);
+
+typedef struct { double distance, mismatch_prop; uint64_t match_count, mismatch_count; } skx_dist;
+/* MergeSkaArray::distance (merge_ska_array.rs:416-438,587-632): upper triangle, pairs (i<j) row-major */
+int  skx_array_distance(skx_array *a, double constant, int filt_ambig, skx_dist *out);
+void skx_free(void *p);
+
+/* per-stage device timings of the last call on this ctx (ms; HIP events on the ctx stream) */
+typedef struct { double hist, scatter, dedupe, key_union, assemble, filter, compact, distance; } skx_timings;
+int  skx_ctx_timings(skx_ctx *ctx, skx_timings *t, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,37 @@
+/*
+ * skx_host.h -- host-side mirror of the reference's mode glue for the hot path, above the skx.h C ABI.
+ * Same names, argument meaning and error behaviour as the Rust functions they replace (the reference's
+ * toolchain is absent from this image, so the host side is C++; a Rust host would call skx.h directly and
+ * keep its own generic_modes.rs / io_utils.rs).  Text results are malloc'd; free with skx_free().
+ */
+#ifndef SKX_HOST_H
+#define SKX_HOST_H
+#include "skx.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* generic_modes::apply_filters (generic_modes.rs:112-131): threshold = ceil(n_samples * min_freq), update_kmers = false */
+int skh_apply_filters(skx_array *a, double min_freq, int filter_ambig_as_missing, int filter_type, int ambig_mask,
+                      int ignore_const_gaps, int32_t *removed);
+/* generic_modes::align (generic_modes.rs:22-50): filters then the FASTA alignment */
+int skh_align(skx_array *a, int filter_type, int mask_ambig, int ignore_const_gaps, double min_freq,
+              int filter_ambig_as_missing, char **buf, uint64_t *len);
+/* generic_modes::distance (generic_modes.rs:136-189): two-stage filter, then the long-form TSV with the
+ * VariantDist Display format "{:.2}\t{:.5}\t{}\t{}" (merge_ska_array.rs:57-65) */
+int skh_distance_tsv(skx_array *a, double min_freq, int filt_ambig, char **buf, uint64_t *len);
+/* Display / Debug of MergeSkaArray as `ska nk [--full-info]` prints them (merge_ska_array.rs:649-698, lib.rs:808-827) */
+int skh_nk(skx_array *a, int full_info, char **buf, uint64_t *len);
+/* generic_modes::save_skf (generic_modes.rs:270-283): appends ".skf" unless already there */
+int skh_save_skf(skx_array *a, const char *out_prefix);
+/* io_utils::load_array (io_utils.rs:60-93) + the u64-then-u128 retry of lib.rs:635-661 */
+int skh_load_array(skx_ctx *ctx, const char *const *inputs, int n_inputs, int threads, skx_array **out);
+/* io_utils::read_input_fastas sample-name rule (io_utils.rs:31-46) */
+char *skh_sample_name(const char *path);
+/* the `ska` command line (build | align | distance | nk); returns the process exit code */
+int skh_main(int argc, char **argv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

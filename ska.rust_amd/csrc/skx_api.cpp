@@ -1,0 +1,730 @@
+// skx_api.cpp -- the C ABI (include/skx.h): host orchestration of the gfx950 kernels.
+// No CPU fallback exists: without a usable HIP device every compute entry point fails with SKX_ENODEV.
+#include "skx_internal.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <thread>
+#include <unistd.h>
+
+using namespace skx;
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[1024];
+void skx::set_error(const char *fmt, ...)
+{
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+}
+int skx::hip_fail(hipError_t e, const char *what)
+{
+    set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    return e == hipErrorOutOfMemory ? SKX_ENOMEM : SKX_ENODEV;
+}
+extern "C" const char *skx_last_error(void) { return g_err; }
+extern "C" const char *skx_version(void) { return "0.5.2"; }      // Cargo.toml:3, written as ska_version
+extern "C" void skx_free(void *p) { free(p); }
+
+// ------------------------------------------------------------------------------------------ ctx
+extern "C" int skx_ctx_create(int device, skx_ctx **out)
+{
+    if (!out) { set_error("null out"); return SKX_EINVAL; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) { set_error("no HIP device available (%s); the engine has no CPU path", e == hipSuccess ? "count 0" : hipGetErrorString(e)); return SKX_ENODEV; }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range (%d devices)", device, ndev); return SKX_EINVAL; }
+    SKX_HIP(hipSetDevice(device));
+    skx_ctx *c = new skx_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev[0]) != hipSuccess || hipEventCreate(&c->ev[1]) != hipSuccess) {
+        delete c; set_error("cannot create HIP stream/events"); return SKX_ENODEV;
+    }
+    *out = c;
+    return SKX_OK;
+}
+extern "C" void skx_ctx_destroy(skx_ctx *c)
+{
+    if (!c) return;
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    delete c;
+}
+extern "C" int skx_ctx_sync(skx_ctx *c) { SKX_HIP(hipSetDevice(c->device)); SKX_HIP(hipStreamSynchronize(c->stream)); return SKX_OK; }
+extern "C" void *skx_ctx_stream(skx_ctx *c) { return (void *)c->stream; }
+extern "C" int skx_ctx_timings(skx_ctx *c, skx_timings *t, int reset)
+{
+    if (t) *t = c->tm;
+    if (reset) c->tm = skx_timings{};
+    return SKX_OK;
+}
+
+namespace {
+struct StageTimer {        // HIP-event bracket around one stage on the ctx stream
+    skx_ctx *c; double *slot;
+    StageTimer(skx_ctx *c_, double *s) : c(c_), slot(s) { if (c->timing) (void)hipEventRecord(c->ev[0], c->stream); }
+    ~StageTimer()
+    {
+        if (!c->timing) return;
+        (void)hipEventRecord(c->ev[1], c->stream);
+        (void)hipEventSynchronize(c->ev[1]);
+        float ms = 0; if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) *slot += ms;
+    }
+};
+int check_k(int k)
+{
+    if (k < 5 || k > 63 || (k & 1) == 0) { set_error("Invalid k-mer length"); return SKX_EINVAL; }   // ska_dict.rs:342-344
+    return SKX_OK;
+}
+int ilog2_ceil(uint64_t x) { int l = 0; while ((1ull << l) < x) l++; return l; }
+constexpr uint32_t LDS_TABLE_MAX = 18000;     // slots (+ pad) of 8 B must stay below 160 KiB
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ dictset
+extern "C" void skx_dictset_free(skx_dictset *d) { delete d; }
+extern "C" int skx_dictset_nsamples(const skx_dictset *d) { return d->n; }
+extern "C" int skx_dictset_key_bits(const skx_dictset *d) { return d->key_bits; }
+
+static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *> &seqs, const std::vector<const uint8_t *> &quals,
+                                const std::vector<uint64_t> &lens, int k, int rc, const skx_qual *q, skx_dictset **out)
+{
+    const int n = (int)seqs.size();
+    hipStream_t st = ctx->stream;
+    bool any_qual = false;
+    for (auto p : quals) any_qual |= p != nullptr;
+    if (any_qual && q && q->min_count > 1) { set_error("FASTQ min-count filter (min_count > 1) is not available on the device path yet"); return SKX_EUNSUP; }
+    if (k > 31) { set_error("k > 31 (128-bit split k-mers) is not available on the device path yet"); return SKX_EUNSUP; }
+
+    uint64_t maxlen = 0;
+    for (auto l : lens) maxlen = std::max(maxlen, l);
+    HashParams hp = make_hash_params(k);
+    int logB = std::min({ilog2_ceil((maxlen + 4095) / 4096), hp.bits, MAX_LOGB});
+    if (logB < 0) logB = 0;
+
+    DevBuf<const uint8_t *> d_seqs, d_quals;
+    DevBuf<uint64_t> d_lens;
+    SKX_TRY(d_seqs.alloc(n)); SKX_TRY(d_lens.alloc(n));
+    SKX_HIP(hipMemcpyAsync(d_seqs.p, seqs.data(), n * sizeof(void *), hipMemcpyHostToDevice, st));
+    SKX_HIP(hipMemcpyAsync(d_lens.p, lens.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    if (any_qual) { SKX_TRY(d_quals.alloc(n)); SKX_HIP(hipMemcpyAsync(d_quals.p, quals.data(), n * sizeof(void *), hipMemcpyHostToDevice, st)); }
+    DevBuf<int> d_flag;
+    SKX_TRY(d_flag.alloc(1));
+
+    for (;; logB++) {
+        std::unique_ptr<skx_dictset> d(new skx_dictset());
+        d->ctx = ctx; d->n = n; d->k = k; d->rc = rc; d->logB = logB; d->hp = hp; d->key_bits = 64;
+        const uint64_t nreg = (uint64_t)n << logB;
+        SKX_TRY(d->raw.alloc(nreg)); SKX_TRY(d->ucnt.alloc(nreg)); SKX_TRY(d->off.alloc(nreg + 1));
+        DevBuf<uint32_t> d_cursor, d_max;
+        SKX_TRY(d_cursor.alloc(nreg)); SKX_TRY(d_max.alloc(1));
+        SKX_TRY(d->raw.zero(st)); SKX_TRY(d_cursor.zero(st)); SKX_TRY(d_flag.zero(st));
+
+        ExtractArgs a{};
+        a.seqs = d_seqs.p; a.quals = any_qual ? d_quals.p : nullptr; a.lens = d_lens.p; a.n_samples = n;
+        a.tiles_max = (int)((maxlen + TILE_BASES - 1) / TILE_BASES);
+        a.k = k; a.rc = rc; a.min_qual = q ? q->min_qual : 0; a.qual_filter = q ? q->qual_filter : 0;
+        a.logB = logB; a.hp = hp;
+        { StageTimer t(ctx, &ctx->tm.hist); a.hist = d->raw.p; launch_hist(a, st); }
+        launch_scan_u32(d->raw.p, d->off.p, nreg, d_max.p, st);
+        uint64_t total = 0; uint32_t max_raw = 0;
+        SKX_HIP(hipMemcpyAsync(&total, d->off.p + nreg, 8, hipMemcpyDeviceToHost, st));
+        SKX_HIP(hipMemcpyAsync(&max_raw, d_max.p, 4, hipMemcpyDeviceToHost, st));
+        SKX_HIP(hipStreamSynchronize(st));
+        SKX_TRY(d->words.alloc(total));
+        { StageTimer t(ctx, &ctx->tm.scatter); a.hist = d_cursor.p; a.off = d->off.p; a.words = d->words.p; launch_scatter(a, st); }
+        uint32_t slots = std::max<uint32_t>(1024, (uint32_t)std::min<uint64_t>((uint64_t)max_raw * 3 / 2 + 64, LDS_TABLE_MAX));
+        { StageTimer t(ctx, &ctx->tm.dedupe); launch_dedupe(d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, slots, hp.bits - logB, d_flag.p, st); }
+        int overflow = 0;
+        SKX_HIP(hipMemcpyAsync(&overflow, d_flag.p, 4, hipMemcpyDeviceToHost, st));
+        std::vector<uint32_t> ucnt(nreg);
+        SKX_HIP(hipMemcpyAsync(ucnt.data(), d->ucnt.p, nreg * 4, hipMemcpyDeviceToHost, st));
+        SKX_HIP(hipStreamSynchronize(st));
+        SKX_HIP(hipGetLastError());
+        if (overflow) {
+            if (logB >= std::min(hp.bits, MAX_LOGB)) { set_error("sample too large for the device dictionary (more than %u distinct split k-mers in one of %d buckets)", LDS_TABLE_MAX, 1 << logB); return SKX_EUNSUP; }
+            continue;
+        }
+        d->sample_size.assign(n, 0);
+        for (int s = 0; s < n; s++) for (uint64_t b = 0; b < (1ull << logB); b++) d->sample_size[s] += ucnt[((uint64_t)s << logB) + b];
+        *out = d.release();
+        return SKX_OK;
+    }
+}
+
+extern "C" int skx_dictset_build(skx_ctx *ctx, const skx_stream *samples, int n, int on_device, int k, int rc, const skx_qual *q, skx_dictset **out)
+{
+    if (!ctx || !samples || n <= 0 || !out) { set_error("bad arguments"); return SKX_EINVAL; }
+    SKX_TRY(check_k(k));
+    SKX_HIP(hipSetDevice(ctx->device));
+    std::vector<const uint8_t *> seqs(n), quals(n, nullptr);
+    std::vector<uint64_t> lens(n);
+    std::vector<DevBuf<uint8_t>> own;
+    if (on_device) {
+        for (int i = 0; i < n; i++) {
+            if (((uintptr_t)samples[i].seq & 15) || ((uintptr_t)samples[i].qual & 15)) { set_error("device record streams must be 16-byte aligned"); return SKX_EINVAL; }
+            seqs[i] = samples[i].seq; quals[i] = samples[i].qual; lens[i] = samples[i].len;
+        }
+    } else {
+        own.resize(2 * (size_t)n);
+        for (int i = 0; i < n; i++) {
+            lens[i] = samples[i].len;
+            SKX_TRY(own[2 * i].alloc(samples[i].len + 16));
+            SKX_HIP(hipMemcpyAsync(own[2 * i].p, samples[i].seq, samples[i].len, hipMemcpyHostToDevice, ctx->stream));
+            seqs[i] = own[2 * i].p;
+            if (samples[i].qual) {
+                SKX_TRY(own[2 * i + 1].alloc(samples[i].len + 16));
+                SKX_HIP(hipMemcpyAsync(own[2 * i + 1].p, samples[i].qual, samples[i].len, hipMemcpyHostToDevice, ctx->stream));
+                quals[i] = own[2 * i + 1].p;
+            }
+        }
+    }
+    skx_dictset *d = nullptr;
+    SKX_TRY(dictset_build_device(ctx, seqs, quals, lens, k, rc, q, &d));
+    for (int s = 0; s < n; s++)
+        if (d->sample_size[s] == 0) { set_error("sample %d has no valid sequence", s); delete d; return SKX_EEMPTY; }
+    *out = d;
+    return SKX_OK;
+}
+
+extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, const char *const *file2, int n, int k, int rc,
+                                       const skx_qual *q, int threads, double proportion_reads, skx_dictset **out)
+{
+    if (!ctx || !file1 || n <= 0 || !out) { set_error("bad arguments"); return SKX_EINVAL; }
+    SKX_TRY(check_k(k));
+    std::vector<HostStream> hs(n);
+    std::vector<int> rcodes(n, SKX_OK);
+    std::vector<std::string> errs(n);
+    int nt = std::max(1, std::min(threads, n));
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; t++)
+        pool.emplace_back([&, t]() {
+            for (int i = t; i < n; i += nt) {
+                rcodes[i] = read_sample_stream(file1[i], file2 ? file2[i] : nullptr, proportion_reads, hs[i]);
+                if (rcodes[i] != SKX_OK) errs[i] = skx_last_error();
+            }
+        });
+    for (auto &th : pool) th.join();
+    for (int i = 0; i < n; i++) if (rcodes[i] != SKX_OK) { set_error("%s", errs[i].c_str()); return rcodes[i]; }
+    std::vector<skx_stream> ss(n);
+    for (int i = 0; i < n; i++) { ss[i].seq = hs[i].seq.data(); ss[i].qual = hs[i].is_fastq ? hs[i].qual.data() : nullptr; ss[i].len = hs[i].seq.size(); }
+    skx_dictset *d = nullptr;
+    int r = skx_dictset_build(ctx, ss.data(), n, 0, k, rc, q, &d);
+    if (r == SKX_EEMPTY) {      // "{file} has no valid sequence" (ska_dict.rs:374-376)
+        int bad = 0; sscanf(skx_last_error(), "sample %d", &bad);
+        set_error("%s has no valid sequence", file1[bad]);
+    }
+    if (r != SKX_OK) return r;
+    *out = d;
+    return SKX_OK;
+}
+
+extern "C" int skx_dictset_size(skx_dictset *d, int sample, uint64_t *n)
+{
+    if (!d || sample < 0 || sample >= d->n) { set_error("bad sample index"); return SKX_EINVAL; }
+    *n = d->sample_size[sample];
+    return SKX_OK;
+}
+
+extern "C" int skx_dictset_export(skx_dictset *d, int sample, skx_key *keys, uint8_t *bases, uint64_t cap)
+{
+    if (!d || sample < 0 || sample >= d->n) { set_error("bad sample index"); return SKX_EINVAL; }
+    skx_ctx *ctx = d->ctx; hipStream_t st = ctx->stream;
+    SKX_HIP(hipSetDevice(ctx->device));
+    const uint64_t B = 1ull << d->logB, sz = d->sample_size[sample];
+    if (cap < sz) { set_error("buffer too small"); return SKX_EINVAL; }
+    std::vector<uint64_t> off(B + 1); std::vector<uint32_t> uc(B);
+    SKX_HIP(hipMemcpyAsync(off.data(), d->off.p + ((uint64_t)sample << d->logB), (B + 1) * 8, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipMemcpyAsync(uc.data(), d->ucnt.p + ((uint64_t)sample << d->logB), B * 4, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipStreamSynchronize(st));
+    DevBuf<uint64_t> dk; DevBuf<uint8_t> db;
+    SKX_TRY(dk.alloc(sz)); SKX_TRY(db.alloc(sz));
+    uint64_t w = 0;
+    for (uint64_t b = 0; b < B; b++) { launch_unhash_dict(d->words.p + off[b], uc[b], dk.p + w, db.p + w, d->hp, st); w += uc[b]; }
+    std::vector<uint64_t> hk(sz); std::vector<uint8_t> hb(sz);
+    SKX_HIP(hipMemcpyAsync(hk.data(), dk.p, sz * 8, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipMemcpyAsync(hb.data(), db.p, sz, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipStreamSynchronize(st));
+    std::vector<uint64_t> idx(sz); std::iota(idx.begin(), idx.end(), 0);
+    std::sort(idx.begin(), idx.end(), [&](uint64_t a, uint64_t b2) { return hk[a] < hk[b2]; });
+    for (uint64_t i = 0; i < sz; i++) { if (keys) { keys[i].lo = hk[idx[i]]; keys[i].hi = 0; } if (bases) bases[i] = hb[idx[i]]; }
+    return SKX_OK;
+}
+
+// ------------------------------------------------------------------------------------------ keyset
+extern "C" void skx_keyset_free(skx_keyset *ks) { delete ks; }
+extern "C" int skx_keyset_size(const skx_keyset *ks, uint64_t *n) { *n = ks->total; return SKX_OK; }
+
+static int keyset_finish(skx_keyset *ks)      // scan ncnt -> roff, total, max_rows
+{
+    hipStream_t st = ks->ctx->stream;
+    const uint64_t nsub = 1ull << ks->logN;
+    SKX_TRY(ks->roff.alloc(nsub + 1));
+    DevBuf<uint32_t> d_max; SKX_TRY(d_max.alloc(1));
+    launch_scan_u32(ks->ncnt.p, ks->roff.p, nsub, d_max.p, st);
+    SKX_HIP(hipMemcpyAsync(&ks->total, ks->roff.p + nsub, 8, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipMemcpyAsync(&ks->max_rows, d_max.p, 4, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipStreamSynchronize(st));
+    return SKX_OK;
+}
+
+// union over several dict views (one per source) into one keyset
+static int keyset_union_views(skx_ctx *ctx, const DictView *views, int nviews, int k, int rc, HashParams hp, uint64_t est_hint, skx_keyset **out)
+{
+    hipStream_t st = ctx->stream;
+    DevBuf<int> d_flag; SKX_TRY(d_flag.alloc(1));
+    int min_logN = 0;
+    for (int v = 0; v < nviews; v++) min_logN = std::max(min_logN, views[v].logB);
+    const uint32_t table = 8192, stride = 4096, target = 2500;
+    int logN = std::max(min_logN, std::min(hp.bits, ilog2_ceil((est_hint + target - 1) / target)));
+    for (;; logN++) {
+        std::unique_ptr<skx_keyset> ks(new skx_keyset());
+        ks->ctx = ctx; ks->k = k; ks->rc = rc; ks->logN = logN; ks->hp = hp; ks->stride = stride;
+        const uint64_t nsub = 1ull << logN;
+        SKX_TRY(ks->stage.alloc(nsub * stride)); SKX_TRY(ks->ncnt.alloc(nsub));
+        SKX_TRY(d_flag.zero(st));
+        if (nviews == 1) {
+            launch_union(views[0], logN, ks->stage.p, stride, ks->ncnt.p, table, d_flag.p, st);
+        } else {
+            set_error("multi-source union goes through keyset_merge"); return SKX_EINVAL;
+        }
+        int overflow = 0;
+        SKX_HIP(hipMemcpyAsync(&overflow, d_flag.p, 4, hipMemcpyDeviceToHost, st));
+        SKX_HIP(hipStreamSynchronize(st));
+        SKX_HIP(hipGetLastError());
+        if (overflow) {
+            if (logN >= hp.bits) { set_error("key union overflow"); return SKX_EUNSUP; }
+            continue;
+        }
+        SKX_TRY(keyset_finish(ks.get()));
+        *out = ks.release();
+        return SKX_OK;
+    }
+}
+
+extern "C" int skx_keyset_union(skx_ctx *ctx, skx_dictset *d, skx_keyset **out)
+{
+    if (!ctx || !d || !out) { set_error("bad arguments"); return SKX_EINVAL; }
+    SKX_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    StageTimer t(ctx, &ctx->tm.key_union);
+    DictView v = d->view();
+    // estimate |U| from a thin slice of the hash space (probe sub-buckets of a 2^logP split)
+    uint64_t maxs = 0, sum = 0;
+    for (auto s : d->sample_size) { maxs = std::max(maxs, s); sum += s; }
+    uint64_t est = maxs;
+    if (d->n > 1) {
+        const int logP = std::min(d->hp.bits, std::max(d->logB, ilog2_ceil((sum + 1023) / 1024)));
+        const int probe = (int)std::min<uint64_t>(64, 1ull << logP);
+        DevBuf<uint32_t> d_cnt; DevBuf<int> d_flag;
+        SKX_TRY(d_cnt.alloc(1)); SKX_TRY(d_flag.alloc(1)); SKX_TRY(d_cnt.zero(st)); SKX_TRY(d_flag.zero(st));
+        launch_union_probe(v, logP, probe, d_cnt.p, 8192, d_flag.p, st);
+        uint32_t cnt = 0; int ov = 0;
+        SKX_HIP(hipMemcpyAsync(&cnt, d_cnt.p, 4, hipMemcpyDeviceToHost, st));
+        SKX_HIP(hipMemcpyAsync(&ov, d_flag.p, 4, hipMemcpyDeviceToHost, st));
+        SKX_HIP(hipStreamSynchronize(st));
+        if (!ov) est = std::max<uint64_t>(maxs, (uint64_t)((double)cnt * (double)(1ull << logP) / probe * 1.1));
+        else est = sum;
+    }
+    return keyset_union_views(ctx, &v, 1, d->k, d->rc, d->hp, est, out);
+}
+
+static int keyset_flatten(skx_keyset *ks)
+{
+    if (ks->flat.p) return SKX_OK;
+    SKX_TRY(ks->flat.alloc(ks->total));
+    launch_gather_keys(ks->stage.p, ks->stride, ks->ncnt.p, ks->roff.p, 1 << ks->logN, ks->flat.p, 0, ks->hp, ks->ctx->stream);
+    return SKX_OK;
+}
+
+extern "C" int skx_keyset_device(skx_keyset *ks, const void **dptr, uint64_t *n_keys, int *words_per_key)
+{
+    SKX_HIP(hipSetDevice(ks->ctx->device));
+    SKX_TRY(keyset_flatten(ks));
+    SKX_HIP(hipStreamSynchronize(ks->ctx->stream));
+    *dptr = ks->flat.p; *n_keys = ks->total; if (words_per_key) *words_per_key = 1;
+    return SKX_OK;
+}
+
+// a flat sorted word list viewed as a one-sample, one-bucket dict
+static int keyset_from_flat(skx_ctx *ctx, DevBuf<uint64_t> &&flat, uint64_t n, int k, int rc, skx_keyset **out)
+{
+    std::unique_ptr<skx_keyset> ks(new skx_keyset());
+    ks->ctx = ctx; ks->k = k; ks->rc = rc; ks->hp = make_hash_params(k); ks->logN = -1; ks->total = n;
+    ks->flat = std::move(flat);
+    *out = ks.release();
+    return SKX_OK;
+}
+
+extern "C" int skx_keyset_from_device(skx_ctx *ctx, const void *dptr, uint64_t n_keys, int k, int rc, skx_keyset **out)
+{
+    SKX_TRY(check_k(k));
+    if (k > 31) { set_error("k > 31 not available on the device path yet"); return SKX_EUNSUP; }
+    SKX_HIP(hipSetDevice(ctx->device));
+    DevBuf<uint64_t> flat; SKX_TRY(flat.alloc(n_keys));
+    SKX_HIP(hipMemcpyAsync(flat.p, dptr, n_keys * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    return keyset_from_flat(ctx, std::move(flat), n_keys, k, rc, out);
+}
+
+// union of several keysets: each flat list is a "sample" of a synthetic one-bucket dict
+extern "C" int skx_keyset_merge(skx_ctx *ctx, skx_keyset *const *sets, int n_sets, skx_keyset **out)
+{
+    if (!ctx || !sets || n_sets <= 0 || !out) { set_error("bad arguments"); return SKX_EINVAL; }
+    SKX_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    StageTimer t(ctx, &ctx->tm.key_union);
+    uint64_t total = 0, maxn = 0;
+    for (int i = 0; i < n_sets; i++) {
+        if (sets[i]->k != sets[0]->k) { set_error("K-mer lengths do not match: %d %d", sets[i]->k, sets[0]->k); return SKX_EINVAL; }
+        if (sets[i]->rc != sets[0]->rc) { set_error("Strand use inconsistent"); return SKX_EINVAL; }
+        if (sets[i]->logN >= 0) SKX_TRY(keyset_flatten(sets[i]));
+        total += sets[i]->total; maxn = std::max(maxn, sets[i]->total);
+    }
+    DevBuf<uint64_t> words, off; DevBuf<uint32_t> ucnt;
+    SKX_TRY(words.alloc(total)); SKX_TRY(off.alloc(n_sets + 1)); SKX_TRY(ucnt.alloc(n_sets));
+    std::vector<uint64_t> h_off(n_sets + 1, 0); std::vector<uint32_t> h_cnt(n_sets);
+    for (int i = 0; i < n_sets; i++) {
+        if (sets[i]->total > 0xFFFFFFFFull) { set_error("keyset too large"); return SKX_EUNSUP; }
+        h_cnt[i] = (uint32_t)sets[i]->total; h_off[i + 1] = h_off[i] + sets[i]->total;
+        SKX_HIP(hipMemcpyAsync(words.p + h_off[i], sets[i]->flat.p, sets[i]->total * 8, hipMemcpyDeviceToDevice, st));
+    }
+    SKX_HIP(hipMemcpyAsync(off.p, h_off.data(), (n_sets + 1) * 8, hipMemcpyHostToDevice, st));
+    SKX_HIP(hipMemcpyAsync(ucnt.p, h_cnt.data(), n_sets * 4, hipMemcpyHostToDevice, st));
+    HashParams hp = sets[0]->hp;
+    DictView v{words.p, off.p, ucnt.p, n_sets, 0, hp.bits};
+    int r = keyset_union_views(ctx, &v, 1, sets[0]->k, sets[0]->rc, hp, std::min(total, maxn * 2), out);
+    SKX_HIP(hipStreamSynchronize(st));
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------ array
+extern "C" void skx_array_free(skx_array *a) { delete a; }
+extern "C" const char *skx_array_name(const skx_array *a, uint64_t i) { return i < a->names.size() ? a->names[i].c_str() : ""; }
+extern "C" const char *skx_array_version(const skx_array *a) { return a->version.c_str(); }
+extern "C" int skx_array_info(const skx_array *a, skx_array_info_t *info)
+{
+    info->k = a->k; info->rc = a->rc; info->k_bits = a->k_bits; info->n_kmers = a->n_kmers; info->n_rows = a->n_rows;
+    info->n_samples = a->names.size();
+    return SKX_OK;
+}
+static uint64_t pitch_for(uint64_t cols) { return ((cols + 255) / 256) * 256 + 256; }
+
+extern "C" int skx_array_assemble(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows, const char *const *names, skx_array **out)
+{
+    if (!ctx || !d || !rows || !out) { set_error("bad arguments"); return SKX_EINVAL; }
+    if (rows->k != d->k) { set_error("K-mer lengths do not match: %d %d", d->k, rows->k); return SKX_EINVAL; }      // merge_ska_dict.rs:78-84
+    if (rows->rc != d->rc) { set_error("Strand use inconsistent"); return SKX_EINVAL; }                              // :85-87
+    if (d->n > 65535) { set_error("more than 65535 samples per device array"); return SKX_EUNSUP; }
+    SKX_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::unique_ptr<skx_keyset> rebuilt;
+    if (rows->logN < 0 || rows->logN < d->logB) {      // flat / too coarse: re-slab at a compatible granularity
+        skx_keyset *one[1] = {rows}; skx_keyset *tmp = nullptr;
+        if (rows->logN >= 0) SKX_TRY(keyset_flatten(rows));
+        // reuse the merge path with a minimum logN of the dict's logB
+        DevBuf<uint64_t> off; DevBuf<uint32_t> ucnt;
+        SKX_TRY(off.alloc(2)); SKX_TRY(ucnt.alloc(1));
+        uint64_t h_off[2] = {0, rows->total}; uint32_t h_cnt = (uint32_t)rows->total;
+        SKX_HIP(hipMemcpyAsync(off.p, h_off, 16, hipMemcpyHostToDevice, st));
+        SKX_HIP(hipMemcpyAsync(ucnt.p, &h_cnt, 4, hipMemcpyHostToDevice, st));
+        DictView v{rows->flat.p, off.p, ucnt.p, 1, 0, rows->hp.bits};
+        // force logN >= d->logB by passing a view whose logB is the dict's (single bucket list still valid for logB 0 only)
+        (void)one;
+        uint64_t hint = std::max<uint64_t>(rows->total, (uint64_t)2500 << d->logB);
+        SKX_TRY(keyset_union_views(ctx, &v, 1, rows->k, rows->rc, rows->hp, hint, &tmp));
+        SKX_HIP(hipStreamSynchronize(st));
+        rebuilt.reset(tmp);
+        rows = tmp;
+        if (rows->logN < d->logB) { set_error("internal: keyset granularity"); return SKX_EUNSUP; }
+    }
+    StageTimer t(ctx, &ctx->tm.assemble);
+    std::unique_ptr<skx_array> a(new skx_array());
+    a->ctx = ctx; a->k = d->k; a->rc = d->rc; a->k_bits = d->key_bits; a->hp = d->hp; a->version = skx_version();
+    for (int i = 0; i < d->n; i++) a->names.emplace_back(names && names[i] ? names[i] : "");
+    const uint64_t U = rows->total;
+    a->n_rows = a->n_kmers = U; a->pitch = pitch_for(U); a->engine_order = true;
+    SKX_TRY(a->matrix.alloc((uint64_t)d->n * a->pitch));
+    SKX_TRY(a->present.alloc(U)); SKX_TRY(a->unambig.alloc(U)); SKX_TRY(a->mask.alloc(U)); SKX_TRY(a->keys.alloc(U));
+    DevBuf<int> d_flag; SKX_TRY(d_flag.alloc(1)); SKX_TRY(d_flag.zero(st));
+    if (U) {
+        AssembleArgs aa{};
+        aa.d = d->view(); aa.logN = rows->logN; aa.stage = rows->stage.p; aa.stride = rows->stride; aa.ncnt = rows->ncnt.p; aa.roff = rows->roff.p;
+        aa.matrix = a->matrix.p; aa.pitch = a->pitch; aa.col_present = a->present.p; aa.col_unambig = a->unambig.p; aa.col_mask = a->mask.p;
+        aa.max_rows = rows->max_rows; aa.missing = d_flag.p;
+        launch_assemble(aa, st);
+        launch_gather_keys(rows->stage.p, rows->stride, rows->ncnt.p, rows->roff.p, 1 << rows->logN, a->keys.p, 0, rows->hp, st);
+    }
+    int missing = 0;
+    SKX_HIP(hipMemcpyAsync(&missing, d_flag.p, 4, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipStreamSynchronize(st));
+    SKX_HIP(hipGetLastError());
+    if (missing) { set_error("row keyset does not contain every split k-mer of the samples"); return SKX_EINVAL; }
+    *out = a.release();
+    return SKX_OK;
+}
+
+extern "C" int skx_merge(skx_ctx *ctx, skx_dictset *d, const char *const *names, skx_array **out)
+{
+    skx_keyset *ks = nullptr;
+    SKX_TRY(skx_keyset_union(ctx, d, &ks));
+    int r = skx_array_assemble(ctx, d, ks, names, out);
+    skx_keyset_free(ks);
+    return r;
+}
+
+extern "C" int skx_build_and_merge(skx_ctx *ctx, const char *const *names, const char *const *file1, const char *const *file2, int n,
+                                   int k, int rc, const skx_qual *q, int threads, double proportion_reads, skx_array **out)
+{
+    skx_dictset *d = nullptr;
+    SKX_TRY(skx_dictset_build_files(ctx, file1, file2, n, k, rc, q, threads, proportion_reads, &d));
+    int r = skx_merge(ctx, d, names, out);
+    skx_dictset_free(d);
+    return r;
+}
+
+extern "C" int skx_array_device_matrix(skx_array *a, const uint8_t **dptr, uint64_t *pitch, uint64_t *n_rows)
+{
+    *dptr = a->matrix.p; *pitch = a->pitch; *n_rows = a->n_rows;
+    return SKX_OK;
+}
+
+extern "C" int skx_array_from_host(skx_ctx *ctx, int k, int rc, const char *const *names, int n_samples, const skx_key *keys,
+                                   const uint8_t *variants, uint64_t n_rows, const char *version, skx_array **out)
+{
+    if (!ctx || !out || n_samples <= 0) { set_error("bad arguments"); return SKX_EINVAL; }
+    SKX_TRY(check_k(k));
+    SKX_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::unique_ptr<skx_array> a(new skx_array());
+    a->ctx = ctx; a->k = k; a->rc = rc; a->k_bits = k <= 31 ? 64 : 128; a->hp = make_hash_params(std::min(k, 31));
+    a->version = version ? version : skx_version();
+    for (int i = 0; i < n_samples; i++) a->names.emplace_back(names[i]);
+    a->n_rows = a->n_kmers = n_rows; a->pitch = pitch_for(n_rows); a->engine_order = false;
+    SKX_TRY(a->matrix.alloc((uint64_t)n_samples * a->pitch));
+    SKX_TRY(a->present.alloc(n_rows)); SKX_TRY(a->unambig.alloc(n_rows)); SKX_TRY(a->mask.alloc(n_rows));
+    if (k <= 31) {
+        SKX_TRY(a->keys.alloc(n_rows));
+        std::vector<uint64_t> lo(n_rows);
+        for (uint64_t i = 0; i < n_rows; i++) lo[i] = keys[i].lo;
+        DevBuf<uint64_t> tmp; SKX_TRY(tmp.alloc(n_rows));
+        SKX_HIP(hipMemcpyAsync(tmp.p, lo.data(), n_rows * 8, hipMemcpyHostToDevice, st));
+        launch_hash_keys(tmp.p, a->keys.p, n_rows, a->hp, st);
+        SKX_HIP(hipStreamSynchronize(st));
+    } else {
+        a->host_keys.assign(keys, keys + n_rows);
+    }
+    DevBuf<int> d_bad; SKX_TRY(d_bad.alloc(1)); SKX_TRY(d_bad.zero(st));
+    if (n_rows) {
+        DevBuf<uint8_t> rm; SKX_TRY(rm.alloc(n_rows * (uint64_t)n_samples));
+        SKX_HIP(hipMemcpyAsync(rm.p, variants, n_rows * (uint64_t)n_samples, hipMemcpyHostToDevice, st));
+        SKX_HIP(hipMemsetAsync(a->matrix.p, '-', (uint64_t)n_samples * a->pitch, st));
+        launch_transpose(rm.p, (uint64_t)n_samples, n_rows, (uint64_t)n_samples, a->matrix.p, a->pitch, st);
+        launch_col_stats(a->matrix.p, a->pitch, n_samples, n_rows, a->present.p, a->unambig.p, a->mask.p, d_bad.p, st);
+        SKX_HIP(hipStreamSynchronize(st));
+    }
+    int bad = 0;
+    SKX_HIP(hipMemcpy(&bad, d_bad.p, 4, hipMemcpyDeviceToHost));
+    SKX_HIP(hipGetLastError());
+    if (bad) { set_error("variants contain a byte outside -ACGTMRWSYKVHDBN (not supported on the device path)"); return SKX_EUNSUP; }
+    *out = a.release();
+    return SKX_OK;
+}
+
+extern "C" int skx_array_export(skx_array *a, skx_key *keys, uint8_t *variants, uint64_t *counts)
+{
+    skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
+    SKX_HIP(hipSetDevice(ctx->device));
+    const uint64_t U = a->n_rows, S = a->names.size(), K = a->n_kmers;
+    std::vector<skx_key> hk(K);
+    if (a->k <= 31) {
+        std::vector<uint64_t> w(K);
+        if (K) SKX_HIP(hipMemcpy(w.data(), a->keys.p, K * 8, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < K; i++) { hk[i].lo = hunmix(w[i] >> 4, a->hp); hk[i].hi = 0; }
+    } else hk = a->host_keys;
+    std::vector<uint8_t> rm(U * S);
+    std::vector<uint32_t> pres(U);
+    if (U) {
+        DevBuf<uint8_t> d_rm; SKX_TRY(d_rm.alloc(U * S));
+        launch_transpose(a->matrix.p, a->pitch, S, U, d_rm.p, S, st);
+        SKX_HIP(hipMemcpyAsync(rm.data(), d_rm.p, U * S, hipMemcpyDeviceToHost, st));
+        SKX_HIP(hipMemcpyAsync(pres.data(), a->present.p, U * 4, hipMemcpyDeviceToHost, st));
+        SKX_HIP(hipStreamSynchronize(st));
+    }
+    // rows sorted by key when keys and rows are in step; otherwise stored order
+    std::vector<uint64_t> idx(U); std::iota(idx.begin(), idx.end(), 0);
+    const bool in_step = K == U;
+    if (in_step) std::sort(idx.begin(), idx.end(), [&](uint64_t x, uint64_t y) { return hk[x].hi != hk[y].hi ? hk[x].hi < hk[y].hi : hk[x].lo < hk[y].lo; });
+    if (keys) { if (in_step) for (uint64_t i = 0; i < K; i++) keys[i] = hk[idx[i]]; else std::copy(hk.begin(), hk.end(), keys); }
+    if (variants) for (uint64_t i = 0; i < U; i++) memcpy(variants + i * S, rm.data() + idx[i] * S, S);
+    if (counts) for (uint64_t i = 0; i < U; i++) counts[i] = pres[idx[i]];
+    return SKX_OK;
+}
+
+extern "C" int skx_array_sample_kmers(skx_array *a, int64_t *out)
+{
+    skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
+    SKX_HIP(hipSetDevice(ctx->device));
+    const size_t S = a->names.size();
+    DevBuf<unsigned long long> d; SKX_TRY(d.alloc(S)); SKX_TRY(d.zero(st));
+    launch_row_nonmissing(a->matrix.p, a->pitch, (int)S, a->n_rows, d.p, st);
+    std::vector<unsigned long long> h(S);
+    SKX_HIP(hipMemcpyAsync(h.data(), d.p, S * 8, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipStreamSynchronize(st));
+    for (size_t i = 0; i < S; i++) out[i] = (int64_t)h[i];
+    return SKX_OK;
+}
+
+extern "C" int skx_array_filter(skx_array *a, uint64_t min_count, int filter_ambig_as_missing, int filter_type, int mask_ambig,
+                                int ignore_const_gaps, int update_kmers, int32_t *removed)
+{
+    skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
+    SKX_HIP(hipSetDevice(ctx->device));
+    const uint64_t U = a->n_rows; const size_t S = a->names.size();
+    DevBuf<uint8_t> keep; DevBuf<uint64_t> pos;
+    SKX_TRY(keep.alloc(U)); SKX_TRY(pos.alloc(U + 1));
+    uint64_t kept = 0, silent = 0;
+    {
+        StageTimer t(ctx, &ctx->tm.filter);
+        FilterArgs fa{a->present.p, a->unambig.p, a->mask.p, U, (uint32_t)S, min_count, filter_ambig_as_missing, filter_type, ignore_const_gaps, keep.p};
+        launch_filter_flags(fa, st);
+        launch_scan_u8(keep.p, pos.p, U, st);
+        SKX_HIP(hipMemcpyAsync(&kept, pos.p + U, 8, hipMemcpyDeviceToHost, st));
+        if (filter_ambig_as_missing) {
+            DevBuf<unsigned long long> d_sil; SKX_TRY(d_sil.alloc(1)); SKX_TRY(d_sil.zero(st));
+            launch_count_u8(keep.p, U, 2, d_sil.p, st);
+            unsigned long long s2 = 0;
+            SKX_HIP(hipMemcpyAsync(&s2, d_sil.p, 8, hipMemcpyDeviceToHost, st));
+            SKX_HIP(hipStreamSynchronize(st));
+            silent = s2;
+        }
+        SKX_HIP(hipStreamSynchronize(st));
+    }
+    {
+        StageTimer t(ctx, &ctx->tm.compact);
+        const uint64_t np = pitch_for(kept);
+        DevBuf<uint8_t> nm; DevBuf<uint32_t> p2, u2, m2;
+        SKX_TRY(nm.alloc((uint64_t)S * np)); SKX_TRY(p2.alloc(kept)); SKX_TRY(u2.alloc(kept)); SKX_TRY(m2.alloc(kept));
+        launch_compact_matrix(a->matrix.p, a->pitch, nm.p, np, (int)S, U, keep.p, pos.p, mask_ambig, st);
+        launch_compact_u32(a->present.p, p2.p, U, keep.p, pos.p, st);
+        launch_compact_u32(a->unambig.p, u2.p, U, keep.p, pos.p, st);
+        launch_compact_u32(a->mask.p, m2.p, U, keep.p, pos.p, st);
+        if (mask_ambig) launch_mask_ambig_stats(m2.p, kept, st);
+        // update_counts(true) (merge_ska_array.rs:139-163) rewrites counts AND split_kmers whenever it ran
+        const bool keys_follow = update_kmers || filter_ambig_as_missing;
+        if (a->n_kmers == U && keys_follow) {
+            if (a->k <= 31) {
+                DevBuf<uint64_t> k2; SKX_TRY(k2.alloc(kept));
+                launch_compact_u64(a->keys.p, k2.p, U, keep.p, pos.p, st);
+                a->keys = std::move(k2);
+            } else {
+                std::vector<uint8_t> hkeep(U);
+                SKX_HIP(hipMemcpyAsync(hkeep.data(), keep.p, U, hipMemcpyDeviceToHost, st));
+                SKX_HIP(hipStreamSynchronize(st));
+                std::vector<skx_key> nk; nk.reserve(kept);
+                for (uint64_t i = 0; i < U; i++) if (hkeep[i] == 1) nk.push_back(a->host_keys[i]);
+                a->host_keys.swap(nk);
+            }
+            a->n_kmers = kept;
+        }
+        SKX_HIP(hipStreamSynchronize(st));
+        a->matrix = std::move(nm); a->present = std::move(p2); a->unambig = std::move(u2); a->mask = std::move(m2);
+        a->pitch = np; a->n_rows = kept;
+    }
+    SKX_HIP(hipGetLastError());
+    if (removed) *removed = (int32_t)(U - kept - silent);
+    return SKX_OK;
+}
+
+extern "C" int skx_array_fasta(skx_array *a, char **buf, uint64_t *len)
+{
+    skx_ctx *ctx = a->ctx;
+    SKX_HIP(hipSetDevice(ctx->device));
+    const size_t S = a->names.size(); const uint64_t U = a->n_rows;
+    uint64_t tot = 0;
+    for (auto &nm : a->names) tot += nm.size() + U + 3;
+    char *out = (char *)malloc(tot + 1), *p = out;
+    if (!out) { set_error("out of host memory"); return SKX_ENOMEM; }
+    for (size_t s = 0; s < S; s++) {
+        *p++ = '>'; memcpy(p, a->names[s].data(), a->names[s].size()); p += a->names[s].size(); *p++ = '\n';
+        if (U) { hipError_t e = hipMemcpy(p, a->matrix.p + s * a->pitch, U, hipMemcpyDeviceToHost); if (e != hipSuccess) { free(out); return hip_fail(e, "hipMemcpy"); } }
+        p += U; *p++ = '\n';
+    }
+    *p = 0; *buf = out; *len = (uint64_t)(p - out);
+    return SKX_OK;
+}
+extern "C" int skx_array_write_fasta(skx_array *a, int fd)
+{
+    char *buf = nullptr; uint64_t len = 0;
+    SKX_TRY(skx_array_fasta(a, &buf, &len));
+    uint64_t w = 0;
+    while (w < len) { ssize_t r = write(fd, buf + w, len - w); if (r <= 0) { free(buf); set_error("write failed"); return SKX_EIO; } w += (uint64_t)r; }
+    free(buf);
+    return SKX_OK;
+}
+
+// numerators over 36 of |S1 n S2| / (|S1||S2|) per pair class [2..11] of pair_counts_kernel<false>
+static const int PAIR_CLASS_NUM[10] = {36, 18, 12, 9, 18, 6, 12, 4, 8, 12};
+
+extern "C" int skx_array_distance(skx_array *a, double constant, int filt_ambig, skx_dist *out)
+{
+    skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
+    SKX_HIP(hipSetDevice(ctx->device));
+    const int S = (int)a->names.size(); const uint64_t U = a->n_rows;
+    if (S < 2) return SKX_OK;
+    StageTimer t(ctx, &ctx->tm.distance);
+    const uint64_t wpr = (U + 63) / 64;
+    DevBuf<uint64_t> planes; DevBuf<unsigned long long> cnt;
+    SKX_TRY(planes.alloc(8 * (uint64_t)S * std::max<uint64_t>(wpr, 1)));
+    SKX_TRY(cnt.alloc((uint64_t)S * S * DIST_NCOUNT)); SKX_TRY(cnt.zero(st));
+    launch_build_planes(a->matrix.p, a->pitch, S, U, planes.p, wpr, st);
+    launch_pair_counts(planes.p, S, wpr, filt_ambig, cnt.p, st);
+    std::vector<unsigned long long> h((uint64_t)S * S * DIST_NCOUNT);
+    SKX_HIP(hipMemcpyAsync(h.data(), cnt.p, h.size() * 8, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipStreamSynchronize(st));
+    SKX_HIP(hipGetLastError());
+    uint64_t n = 0;
+    for (int i = 0; i < S; i++)
+        for (int j = i + 1; j < S; j++, n++) {
+            const unsigned long long *c = &h[((uint64_t)i * S + j) * DIST_NCOUNT];
+            double mismatches = (double)c[0], matches = constant, distance;
+            if (filt_ambig) { matches += (double)c[2]; distance = (double)(c[2] - c[3]); }
+            else {
+                unsigned long long m = 0, num = 0;
+                for (int q = 0; q < 10; q++) { m += c[2 + q]; num += c[2 + q] * (unsigned long long)PAIR_CLASS_NUM[q]; }
+                matches += (double)m;
+                distance = (double)(36ull * c[1] - num) / 36.0;
+            }
+            out[n].distance = distance;
+            out[n].mismatch_prop = (matches + mismatches) == 0.0 ? 0.0 : mismatches / (matches + mismatches);
+            out[n].match_count = (uint64_t)matches; out[n].mismatch_count = (uint64_t)mismatches;
+        }
+    return SKX_OK;
+}
+
+// ------------------------------------------------------------------------------------------ .skf
+extern "C" int skx_array_save(skx_array *a, const char *path)
+{
+    SkfData d;
+    d.k = a->k; d.rc = a->rc; d.k_bits = a->k_bits; d.names = a->names; d.version = a->version;
+    const uint64_t U = a->n_rows, S = a->names.size();
+    d.keys.resize(a->n_kmers); d.variants.resize(U * S); d.counts.resize(U); d.n_rows = U;
+    SKX_TRY(skx_array_export(a, d.keys.data(), d.variants.data(), d.counts.data()));
+    return skf_write(path, d);
+}
+extern "C" int skx_array_load(skx_ctx *ctx, const char *path, int want_bits, skx_array **out)
+{
+    SkfData d;
+    SKX_TRY(skf_read(path, d));
+    if (want_bits == 64)       // serde into Vec<u64> fails on wider values; lib.rs:635-661 then retries as u128
+        for (auto &kk : d.keys) if (kk.hi) { set_error("split k-mer does not fit 64 bits"); return SKX_EFORMAT; }
+    std::vector<const char *> names;
+    for (auto &s : d.names) names.push_back(s.c_str());
+    skx_array *a = nullptr;
+    if (d.keys.size() != d.n_rows) { set_error("skf: split_kmers and variants disagree"); return SKX_EFORMAT; }
+    SKX_TRY(skx_array_from_host(ctx, d.k, d.rc, names.data(), (int)names.size(), d.keys.data(), d.variants.data(), d.n_rows, d.version.c_str(), &a));
+    a->k_bits = d.k_bits;
+    *out = a;
+    return SKX_OK;
+}

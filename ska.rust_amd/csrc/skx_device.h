@@ -1,0 +1,143 @@
+// skx_device.h -- launch wrappers of the gfx950 kernels (skx_device.hip) used by the C-ABI layer.
+//
+// Data layout in HBM:
+//   record stream   : bytes, each record's bases followed by '\n' (host reader output)
+//   packed word     : (H(split k-mer) << 4) | base-set mask   [u64 for k<=31]
+//                     H = bijective mix of the 2(k-1)-bit canonical split k-mer; "engine order" == order of H
+//   dictset         : per (sample, bucket) a region of packed words, bucket = top logB bits of H;
+//                     after dedupe the first ucnt words of each region are sorted unique
+//   keyset          : per sub-bucket (top logN bits of H) a slab of sorted unique words (mask bits 0)
+//   array           : sample-major matrix [S][pitch] of ASCII middle bases, '-' == absent
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace skx {
+
+constexpr int TILE_THREADS = 256;
+constexpr int TILE_BASES = 4096;          // window end positions per workgroup
+constexpr int MAX_LOGB = 13;              // buckets per sample <= 8192 (LDS histogram)
+constexpr uint64_t EMPTY64 = ~0ull;
+
+struct HashParams {
+    int bits;          // 2(k-1)
+    int s;             // xorshift distance
+    uint64_t mask;     // (1<<bits)-1
+    uint64_t c1, c2, c1inv, c2inv;
+};
+HashParams make_hash_params(int k);
+__host__ __device__ inline uint64_t hmix(uint64_t x, const HashParams &p)
+{
+    x ^= x >> p.s; x = (x * p.c1) & p.mask;
+    x ^= x >> p.s; x = (x * p.c2) & p.mask;
+    x ^= x >> p.s;
+    return x;
+}
+__host__ __device__ inline uint64_t unxorshift(uint64_t y, int s, int bits)
+{
+    uint64_t x = y;
+    for (int t = s; t < bits; t += s) x ^= y >> t;
+    return x;
+}
+__host__ __device__ inline uint64_t hunmix(uint64_t x, const HashParams &p)
+{
+    x = unxorshift(x, p.s, p.bits); x = (x * p.c2inv) & p.mask;
+    x = unxorshift(x, p.s, p.bits); x = (x * p.c1inv) & p.mask;
+    x = unxorshift(x, p.s, p.bits);
+    return x;
+}
+
+struct ExtractArgs {
+    const uint8_t *const *seqs;   // [n] device pointers to record streams (16-B aligned)
+    const uint8_t *const *quals;  // [n] or nullptr
+    const uint64_t *lens;         // [n]
+    int n_samples;
+    int tiles_max;                // ceil(max len / TILE_BASES)
+    int k, rc;
+    int min_qual, qual_filter;    // FASTQ only
+    int logB;
+    HashParams hp;
+    uint32_t *hist;               // [n << logB] raw window counts (pass 1 out / pass 2 cursors)
+    const uint64_t *off;          // [n << logB] region offsets (pass 2)
+    uint64_t *words;              // dict storage (pass 2)
+};
+
+void launch_hist(const ExtractArgs &a, hipStream_t st);
+void launch_scatter(const ExtractArgs &a, hipStream_t st);
+
+// exclusive scan of u32 counts into u64 offsets (+ total at out[n]); also max of the counts
+void launch_scan_u32(const uint32_t *in, uint64_t *out, uint64_t n, uint32_t *max_out, hipStream_t st);
+
+// in-place sort + dedupe (OR of masks) of every (sample,bucket) region through an order-preserving LDS table
+void launch_dedupe(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_regions,
+                   uint32_t table_slots, int rem_bits, int *overflow, hipStream_t st);
+
+struct DictView {
+    const uint64_t *words; const uint64_t *off; const uint32_t *ucnt;
+    int n_samples, logB, bits;
+};
+// distinct keys per sub-bucket (logN >= logB): slab j at stage + j*stride, count in ncnt[j]
+void launch_union(const DictView &d, int logN, uint64_t *stage, uint32_t stride, uint32_t *ncnt,
+                  uint32_t table_slots, int *overflow, hipStream_t st);
+// estimate |U|: union restricted to `probe` sub-buckets of a 2^logP split; returns distinct count in *cnt
+void launch_union_probe(const DictView &d, int logP, int probe, uint32_t *cnt, uint32_t table_slots, int *overflow,
+                        hipStream_t st);
+
+struct AssembleArgs {
+    DictView d;
+    int logN;                  // sub-buckets of the row keyset
+    const uint64_t *stage;     // row keys: slab j at stage + j*stride
+    uint32_t stride;
+    const uint32_t *ncnt;      // rows per sub-bucket
+    const uint64_t *roff;      // exclusive scan of ncnt (row offset of sub-bucket j)
+    uint8_t *matrix;           // [n_samples][pitch]
+    uint64_t pitch;
+    uint32_t *col_present;     // [U] cells != '-'
+    uint32_t *col_unambig;     // [U] cells in ACGT
+    uint32_t *col_mask;        // [U] bit c set iff IUPAC set-code c (1..15) occurs in the column
+    uint32_t max_rows;         // max ncnt (LDS sizing)
+    int *missing;              // set if a dict key is not among the rows
+};
+void launch_assemble(const AssembleArgs &a, hipStream_t st);
+
+// compact slabs into one array; unhash=1 converts engine-order words back to reference keys
+void launch_gather_keys(const uint64_t *stage, uint32_t stride, const uint32_t *ncnt, const uint64_t *roff, int n_sub,
+                        uint64_t *out, int unhash, HashParams hp, hipStream_t st);
+void launch_hash_keys(const uint64_t *keys, uint64_t *words, uint64_t n, HashParams hp, hipStream_t st);
+void launch_unhash_dict(const uint64_t *words, uint64_t n, uint64_t *keys, uint8_t *bases, HashParams hp, hipStream_t st);
+
+// column statistics of a sample-major matrix (for arrays that did not come from assemble)
+void launch_col_stats(const uint8_t *matrix, uint64_t pitch, int n_samples, uint64_t n_cols, uint32_t *present,
+                      uint32_t *unambig, uint32_t *mask, int *bad_byte, hipStream_t st);
+// MergeSkaArray::filter row rule -> keep flags (u8)
+struct FilterArgs {
+    const uint32_t *present, *unambig, *mask; uint64_t n_cols; uint32_t n_samples;
+    uint64_t min_count; int ambig_as_missing, filter_type, ignore_const_gaps;
+    uint8_t *keep;
+};
+void launch_filter_flags(const FilterArgs &a, hipStream_t st);
+void launch_scan_u8(const uint8_t *flags, uint64_t *pos, uint64_t n, hipStream_t st);   // pos[n] = total
+// out[s][pos[c]] = in[s][c] for kept c (optionally ambiguous -> 'N'); also compacts the stat/key arrays
+void launch_compact_matrix(const uint8_t *in, uint64_t in_pitch, uint8_t *out, uint64_t out_pitch, int n_samples,
+                           uint64_t n_cols, const uint8_t *keep, const uint64_t *pos, int mask_ambig, hipStream_t st);
+void launch_compact_u32(const uint32_t *in, uint32_t *out, uint64_t n, const uint8_t *keep, const uint64_t *pos, hipStream_t st);
+void launch_compact_u64(const uint64_t *in, uint64_t *out, uint64_t n, const uint8_t *keep, const uint64_t *pos, hipStream_t st);
+void launch_mask_ambig_stats(uint32_t *mask, uint64_t n, hipStream_t st);
+void launch_count_u8(const uint8_t *v, uint64_t n, uint8_t value, unsigned long long *out, hipStream_t st);
+// tiled transpose of a byte matrix: in [rows][in_pitch] -> out [cols][out_pitch]
+void launch_transpose(const uint8_t *in, uint64_t in_pitch, uint64_t rows, uint64_t cols, uint8_t *out, uint64_t out_pitch,
+                      hipStream_t st);
+// per-sample count of cells != '-'
+void launch_row_nonmissing(const uint8_t *matrix, uint64_t pitch, int n_samples, uint64_t n_cols, unsigned long long *out,
+                           hipStream_t st);
+
+// ---- distance: bit planes + pair popcounts ----
+// planes[p][s][w]: p in {present, A, C, G, T, sz1, sz2, sz3}, w = 64 columns per word
+void launch_build_planes(const uint8_t *matrix, uint64_t pitch, int n_samples, uint64_t n_cols, uint64_t *planes,
+                         uint64_t words_per_row, hipStream_t st);
+// out[pair][c]: integer pair-class counts, see skx_device.hip
+constexpr int DIST_NCOUNT = 16;
+void launch_pair_counts(const uint64_t *planes, int n_samples, uint64_t words_per_row, int filt_ambig,
+                        unsigned long long *out, hipStream_t st);
+
+}  // namespace skx

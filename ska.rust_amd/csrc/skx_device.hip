@@ -1,0 +1,579 @@
+// skx_device.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the split-k-mer engine.
+//
+// Everything here is HBM-bound integer/byte work (no MFMA): coalesced 16-B loads of the record
+// stream, LDS-staged 2-bit windows, LDS atomics for bucket ranks, order-preserving LDS hash tables
+// for dedupe / set union, popcount bit planes for the pairwise distance.
+//
+// Reference semantics implemented (bacpop/ska.rust v0.5.2, paths relative to its src/):
+//   ska_dict/bit_encoding.rs:30-54   encode_base / valid_base / rc_base
+//   ska_dict/split_kmer.rs:78-217    build + roll_fwd window enumeration, incl. the `idx + k >= len` end rule
+//   ska_dict/split_kmer.rs:281-295   canonical (min of fwd / rc) split k-mer, :144-146 self_palindrome
+//   ska_dict.rs:76-113               per-sample value = IUPAC code of the union of observed middle bases
+//   merge_ska_dict.rs:77-151         samples -> columns, 0/'-' where absent
+//   merge_ska_array.rs:139-186,289-402,416-438,587-632   counts, filter, distance
+#include "skx_device.h"
+
+namespace skx {
+
+// ------------------------------------------------------------------------------------------------
+// hashing: a bijection on `bits`-bit integers so that buckets (top bits) are uniform whatever the
+// genome's composition; "engine order" of keys is the order of H(key).
+// ------------------------------------------------------------------------------------------------
+static uint64_t modinv64(uint64_t c)
+{
+    uint64_t inv = c;                       // correct to 3 bits for odd c
+    for (int i = 0; i < 6; i++) inv *= 2 - c * inv;
+    return inv;
+}
+HashParams make_hash_params(int k)
+{
+    HashParams p;
+    p.bits = 2 * (k - 1);
+    p.s = p.bits / 2 > 0 ? p.bits / 2 : 1;
+    p.mask = p.bits >= 64 ? ~0ull : ((1ull << p.bits) - 1);
+    p.c1 = 0x9E3779B97F4A7C15ull; p.c2 = 0xD6E8FEB86659FD93ull;
+    p.c1inv = modinv64(p.c1); p.c2inv = modinv64(p.c2);
+    return p;
+}
+
+// reverse complement of the low n 2-bit symbols of x (cf. bit_encoding.rs:182-195)
+__device__ static inline uint64_t revcomp2(uint64_t x, int n)
+{
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    x = __builtin_bswap64(x);
+    x ^= 0xAAAAAAAAAAAAAAAAull;
+    return n ? x >> (64 - 2 * n) : 0;
+}
+
+// 16 ASCII bytes -> 2-bit codes (first base most significant), bad-base mask, newline mask (bit j = byte j)
+__device__ static inline void pack16(const uint32_t w[4], uint32_t &code, uint32_t &bad, uint32_t &nl)
+{
+    code = 0; bad = 0; nl = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint32_t x = w[i];
+        uint32_t c = (x >> 1) & 0x03030303u;                       // encode_base per byte
+        code = (code << 8) | ((c * 0x40100401u) >> 24);
+        uint32_t t = (x & 0x0F0F0F0Fu) ^ 0x0E0E0E0Eu;              // low nibble == 14  <=>  !valid_base
+        uint32_t nzt = (t + 0x7F7F7F7Fu) & 0x80808080u;
+        uint32_t u = x ^ 0x0A0A0A0Au;                              // '\n' record terminator
+        uint32_t znl = ~(((u & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | u | 0x7F7F7F7Fu);
+        uint32_t fb = (((~nzt) & 0x80808080u) | znl) >> 7;
+        uint32_t fn = znl >> 7;
+        bad |= (((fb * 0x01020408u) >> 24) & 0xFu) << (4 * i);
+        nl |= (((fn * 0x01020408u) >> 24) & 0xFu) << (4 * i);
+    }
+}
+__device__ static inline uint32_t qualbad16(const uint32_t w[4], int min_qual)
+{
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            uint32_t q = (w[i] >> (8 * b)) & 0xFF;
+            m |= (uint32_t)(((q - 33u) & 0xFFu) <= (uint32_t)min_qual) << (4 * i + b);   // !((q-33) > min_qual), u8 wrap
+        }
+    return m;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1/K2: split k-mer extraction (+ bucket histogram | bucket scatter).  One workgroup = one tile of
+// 4096 window-end positions of one sample; 8 consecutive samples run concurrently, one per XCD
+// (block b -> XCD b%8), so a sample's bucket cursors and partially written lines stay in one L2.
+// ------------------------------------------------------------------------------------------------
+template <bool SCATTER>
+__global__ __launch_bounds__(TILE_THREADS) void extract_kernel(ExtractArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];   // [B] hist (+ [B] chunk bases)
+    __shared__ uint32_t s_code[264];
+    __shared__ uint16_t s_bad[264], s_nl[264], s_qbad[264];
+
+    const int B = 1 << a.logB;
+    const int tid = threadIdx.x;
+    const uint64_t per_group = 8ull * (uint64_t)a.tiles_max;
+    const uint64_t L = blockIdx.x;
+    const int sample = (int)((L / per_group) * 8 + (L % per_group) % 8);
+    const uint64_t tile = (L % per_group) / 8;
+    if (sample >= a.n_samples) return;
+    const uint64_t len = a.lens[sample];
+    const uint64_t T0 = tile * TILE_BASES;
+    if (T0 >= len) return;
+    const uint8_t *seq = a.seqs[sample];
+    const uint8_t *qual = a.quals ? a.quals[sample] : nullptr;
+
+    uint32_t *s_hist = s_dyn;
+    for (int i = tid; i < B; i += TILE_THREADS) s_hist[i] = 0;
+
+    auto load_chunk = [&](int c) {
+        const int64_t p = (int64_t)T0 - 64 + 16 * (int64_t)c;
+        uint32_t w[4], q[4] = {0, 0, 0, 0};
+        if (p >= 0 && (uint64_t)p + 16 <= len) {
+            uint4 v = *reinterpret_cast<const uint4 *>(seq + p);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+            if (qual) { uint4 u = *reinterpret_cast<const uint4 *>(qual + p); q[0] = u.x; q[1] = u.y; q[2] = u.z; q[3] = u.w; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                uint32_t x = 0, y = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    int64_t pos = p + 4 * i + b;
+                    bool in = pos >= 0 && (uint64_t)pos < len;
+                    x |= (uint32_t)(in ? seq[pos] : (uint8_t)'\n') << (8 * b);
+                    if (qual) y |= (uint32_t)(in ? qual[pos] : (uint8_t)'~') << (8 * b);
+                }
+                w[i] = x; q[i] = y;
+            }
+        }
+        uint32_t code, bad, nl;
+        pack16(w, code, bad, nl);
+        uint32_t qb = 0;
+        if (qual) {
+            qb = qualbad16(q, a.min_qual) & ~nl;
+            if (a.qual_filter == 2) bad |= qb;          // QualFilter::Strict (split_kmer.rs:98-101,170-172)
+        }
+        s_code[c] = code; s_bad[c] = (uint16_t)bad; s_nl[c] = (uint16_t)nl; s_qbad[c] = (uint16_t)qb;
+    };
+    load_chunk(tid + 4);
+    if (tid < 4) load_chunk(tid);
+    if (tid == 4) load_chunk(260);
+    __syncthreads();
+
+    // ---- per-thread rolling windows over its 16 positions ----
+    const int k = a.k, h = (k - 1) / 2;
+    const int c = tid + 4;
+    const uint64_t maskk = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1);
+    const uint64_t mask2h = (1ull << (2 * h)) - 1;
+    const uint64_t prev = ((uint64_t)s_code[c - 2] << 32) | s_code[c - 1];
+    const uint32_t cw = s_code[c];
+    const uint32_t bm = s_bad[c];
+    const uint32_t nlx = (uint32_t)s_nl[c] | ((uint32_t)(s_nl[c + 1] & 1u) << 16);
+    const uint32_t badprev = (uint32_t)s_bad[c - 2] | ((uint32_t)s_bad[c - 1] << 16);
+    const uint64_t qb48 = (uint64_t)s_qbad[c - 2] | ((uint64_t)s_qbad[c - 1] << 16) | ((uint64_t)s_qbad[c] << 32);
+    int run = badprev ? __clz(badprev) : 32;                // consecutive good positions ending just before p0
+    uint64_t fwd = prev & ((1ull << (2 * (k - 1))) - 1);    // k-1 bases preceding p0
+    uint64_t rev = revcomp2(fwd, k - 1) << 2;
+    const bool check_mid = qual && a.qual_filter != 0;
+    const int bshift = a.hp.bits + 4 - a.logB;              // word >> bshift == bucket
+
+    uint64_t wv[16];
+    uint32_t vm = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const uint32_t code = (cw >> (30 - 2 * j)) & 3u;
+        fwd = ((fwd << 2) | code) & maskk;
+        rev = (rev >> 2) | ((uint64_t)(code ^ 2u) << (2 * (k - 1)));
+        run = ((bm >> j) & 1u) ? 0 : run + 1;
+        const bool nlnext = (nlx >> (j + 1)) & 1u;
+        // split_kmer.rs:89,121: a (re)start at idx is abandoned when idx + k >= len  <=>  the clean run is
+        // exactly k long and ends at the record's last base
+        bool valid = run >= k && !(nlnext && run == k);
+        if (check_mid) valid = valid && !((qb48 >> (32 + j - h)) & 1ull);   // middle_base_qual, split_kmer.rs:328-339
+        const uint64_t kf = ((fwd >> (2 * h + 2)) << (2 * h)) | (fwd & mask2h);
+        const uint64_t kr = ((rev >> (2 * h + 2)) << (2 * h)) | (rev & mask2h);
+        const uint32_t mf = (uint32_t)(fwd >> (2 * h)) & 3u;
+        uint64_t key = kf; uint32_t m4 = 1u << mf;
+        if (a.rc) {
+            if (kf > kr) { key = kr; m4 = 1u << (mf ^ 2u); }              // canonical = rc (split_kmer.rs:287-291)
+            else if (kf == kr) m4 = (1u << mf) | (1u << (mf ^ 2u));        // self-palindrome -> W / S (ska_dict.rs:85-113)
+        }
+        const uint64_t w = (hmix(key, a.hp) << 4) | m4;
+        wv[j] = w;
+        if (valid) vm |= 1u << j;
+    }
+
+    uint32_t rk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        if ((vm >> j) & 1u) {
+            uint32_t r = atomicAdd(&s_hist[(uint32_t)(wv[j] >> bshift)], 1u);
+            if (SCATTER) rk[j >> 1] |= r << (16 * (j & 1));
+        }
+    __syncthreads();
+    uint32_t *ghist = a.hist + ((uint64_t)sample << a.logB);
+    if (!SCATTER) {
+        for (int i = tid; i < B; i += TILE_THREADS) { uint32_t n = s_hist[i]; if (n) atomicAdd(&ghist[i], n); }
+        return;
+    }
+    uint32_t *s_base = s_dyn + B;
+    for (int i = tid; i < B; i += TILE_THREADS) { uint32_t n = s_hist[i]; s_base[i] = n ? atomicAdd(&ghist[i], n) : 0u; }
+    __syncthreads();
+    const uint64_t *off = a.off + ((uint64_t)sample << a.logB);
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        if ((vm >> j) & 1u) {
+            const uint32_t b = (uint32_t)(wv[j] >> bshift);
+            const uint32_t r = (rk[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+            a.words[off[b] + s_base[b] + r] = wv[j];
+        }
+}
+
+static inline uint64_t extract_grid(const ExtractArgs &a)
+{
+    uint64_t groups = ((uint64_t)a.n_samples + 7) / 8;
+    return groups * 8ull * (uint64_t)a.tiles_max;
+}
+void launch_hist(const ExtractArgs &a, hipStream_t st)
+{
+    uint64_t g = extract_grid(a);
+    if (!g) return;
+    size_t lds = sizeof(uint32_t) << a.logB;
+    hipLaunchKernelGGL(extract_kernel<false>, dim3((unsigned)g), dim3(TILE_THREADS), lds, st, a);
+}
+void launch_scatter(const ExtractArgs &a, hipStream_t st)
+{
+    uint64_t g = extract_grid(a);
+    if (!g) return;
+    size_t lds = 2 * (sizeof(uint32_t) << a.logB);
+    hipLaunchKernelGGL(extract_kernel<true>, dim3((unsigned)g), dim3(TILE_THREADS), lds, st, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// block-wide helpers
+// ------------------------------------------------------------------------------------------------
+__device__ static inline uint32_t wave_incl_scan(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(v, d, 64); if (lane >= d) v += t; }
+    return v;
+}
+// exclusive scan over the block (<= 1024 threads); total returned through *total
+__device__ static inline uint32_t block_excl_scan(uint32_t v, uint32_t *s_tmp /*[17]*/, uint32_t *total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    uint32_t inc = wave_incl_scan(v);
+    if (lane == 63) s_tmp[wv] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t run = 0; for (int i = 0; i < nw; i++) { uint32_t t = s_tmp[i]; s_tmp[i] = run; run += t; } s_tmp[16] = run; }
+    __syncthreads();
+    uint32_t r = s_tmp[wv] + inc - v;
+    if (total) *total = s_tmp[16];
+    __syncthreads();
+    return r;
+}
+
+// single-workgroup exclusive scan u32 -> u64 (n is at most a few million; launch-bound otherwise)
+__global__ __launch_bounds__(1024) void scan_u32_kernel(const uint32_t *in, uint64_t *out, uint64_t n, uint32_t *max_out)
+{
+    __shared__ uint32_t s_tmp[17];
+    __shared__ uint32_t s_max;
+    uint64_t carry = 0;
+    uint32_t mx = 0;
+    if (threadIdx.x == 0) s_max = 0;
+    for (uint64_t base = 0; base < n; base += 4096) {
+        uint32_t v[4]; uint32_t sum = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { uint64_t idx = base + (uint64_t)threadIdx.x * 4 + i; v[i] = idx < n ? in[idx] : 0; sum += v[i]; mx = v[i] > mx ? v[i] : mx; }
+        uint32_t tot;
+        uint32_t ex = block_excl_scan(sum, s_tmp, &tot);
+        uint64_t run = carry + ex;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { uint64_t idx = base + (uint64_t)threadIdx.x * 4 + i; if (idx < n) out[idx] = run; run += v[i]; }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) out[n] = carry;
+    if (max_out) { atomicMax(&s_max, mx); __syncthreads(); if (threadIdx.x == 0) *max_out = s_max; }
+}
+void launch_scan_u32(const uint32_t *in, uint64_t *out, uint64_t n, uint32_t *max_out, hipStream_t st)
+{
+    hipLaunchKernelGGL(scan_u32_kernel, dim3(1), dim3(1024), 0, st, in, out, n, max_out);
+}
+
+__global__ __launch_bounds__(1024) void scan_u8_kernel(const uint8_t *in, uint64_t *out, uint64_t n)
+{
+    __shared__ uint32_t s_tmp[17];
+    uint64_t carry = 0;
+    for (uint64_t base = 0; base < n; base += 8192) {
+        uint32_t v[8]; uint32_t sum = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { uint64_t idx = base + (uint64_t)threadIdx.x * 8 + i; v[i] = idx < n ? (in[idx] == 1) : 0; sum += v[i]; }
+        uint32_t tot;
+        uint32_t ex = block_excl_scan(sum, s_tmp, &tot);
+        uint64_t run = carry + ex;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { uint64_t idx = base + (uint64_t)threadIdx.x * 8 + i; if (idx < n) out[idx] = run; run += v[i]; }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) out[n] = carry;
+}
+void launch_scan_u8(const uint8_t *flags, uint64_t *pos, uint64_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(scan_u8_kernel, dim3(1), dim3(1024), 0, st, flags, pos, n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// order-preserving LDS table: slot = monotone function of the (already uniform) hashed key, linear
+// probing without wrap-around.  Maximal runs of occupied slots are sorted independently and the
+// runs themselves are in key order, so a sorted, duplicate-free emit is O(n).  Slot value 0 == empty
+// (a stored word always has a non-zero base mask in its low 4 bits).
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t TABLE_PAD = 128;
+
+__device__ static inline uint32_t home_slot(uint64_t w, int rem_bits, uint32_t nslots)
+{
+    uint64_t local = rem_bits >= 60 ? (w >> 4) : ((w >> 4) & ((1ull << rem_bits) - 1));
+    uint32_t l32 = rem_bits > 32 ? (uint32_t)(local >> (rem_bits - 32)) : (uint32_t)(local << (32 - rem_bits));
+    if (rem_bits == 0) l32 = 0;
+    return (uint32_t)(((uint64_t)l32 * nslots) >> 32);
+}
+__device__ static inline bool table_insert(unsigned long long *tab, uint32_t total_slots, uint32_t home, uint64_t w)
+{
+    const uint64_t key = w >> 4;
+    for (uint32_t i = home; i < total_slots; ++i) {
+        unsigned long long old = atomicCAS(&tab[i], 0ull, (unsigned long long)w);
+        if (old == 0ull) return true;
+        if ((old >> 4) == key) {
+            if ((old | w) != old) atomicOr(&tab[i], (unsigned long long)(w & 15ull));
+            return true;
+        }
+    }
+    return false;
+}
+// sorted emit of the table; f(idx, word) is called once per distinct key with its rank; returns the count
+template <typename F>
+__device__ static inline uint32_t table_emit_sorted(const unsigned long long *tab, uint32_t total_slots, uint32_t *s_tmp, F f)
+{
+    const uint32_t per = (total_slots + blockDim.x - 1) / blockDim.x;
+    const uint32_t lo = threadIdx.x * per;
+    const uint32_t hi = lo + per < total_slots ? lo + per : total_slots;
+    uint32_t cnt = 0;
+    for (uint32_t i = lo; i < hi; i++) cnt += tab[i] != 0ull;
+    uint32_t total;
+    uint32_t c = block_excl_scan(cnt, s_tmp, &total);
+    for (uint32_t i = lo; i < hi; i++) {
+        const unsigned long long w = tab[i];
+        if (!w) continue;
+        uint32_t gl = 0, lr = 0;
+        for (int64_t j = (int64_t)i - 1; j >= 0; j--) { unsigned long long o = tab[j]; if (!o) break; gl += o > w; }
+        for (uint32_t j = i + 1; j < total_slots; j++) { unsigned long long o = tab[j]; if (!o) break; lr += o < w; }
+        f(c - gl + lr, (uint64_t)w);
+        c++;
+    }
+    return total;
+}
+
+// K3: per (sample,bucket) region: dedupe (OR of base masks) + sort, in place
+__global__ __launch_bounds__(256) void dedupe_kernel(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt,
+                                                     uint32_t nslots, int rem_bits, int *overflow)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_tab[];
+    __shared__ uint32_t s_tmp[17];
+    __shared__ int s_fail;
+    const uint64_t region = blockIdx.x;
+    const uint32_t n = raw[region];
+    if (n == 0) { if (threadIdx.x == 0) ucnt[region] = 0; return; }
+    const uint32_t total_slots = nslots + TABLE_PAD;
+    for (uint32_t i = threadIdx.x; i < total_slots; i += blockDim.x) s_tab[i] = 0ull;
+    if (threadIdx.x == 0) s_fail = 0;
+    __syncthreads();
+    uint64_t *reg = words + off[region];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint64_t w = reg[i];
+        if (!table_insert(s_tab, total_slots, home_slot(w, rem_bits, nslots), w)) s_fail = 1;
+    }
+    __syncthreads();
+    if (s_fail) { if (threadIdx.x == 0) { *overflow = 1; ucnt[region] = 0; } return; }
+    uint32_t total = table_emit_sorted(s_tab, total_slots, s_tmp, [&](uint32_t idx, uint64_t w) { reg[idx] = w; });
+    if (threadIdx.x == 0) ucnt[region] = total;
+}
+void launch_dedupe(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_regions,
+                   uint32_t table_slots, int rem_bits, int *overflow, hipStream_t st)
+{
+    if (!n_regions) return;
+    size_t lds = (size_t)(table_slots + TABLE_PAD) * 8;
+    hipFuncSetAttribute((const void *)dedupe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(dedupe_kernel, dim3((unsigned)n_regions), dim3(256), lds, st, words, off, raw, ucnt, table_slots, rem_bits, overflow);
+}
+
+// first index in [0,n) whose hashed key (word >> 4) is >= x
+__device__ static inline uint32_t lower_bound_words(const uint64_t *reg, uint32_t n, uint64_t x)
+{
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if ((reg[mid] >> 4) < x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__device__ static inline void sub_slice(const DictView &d, int sample, uint64_t j, int logN, const uint64_t *&reg, uint32_t &lo, uint32_t &hi)
+{
+    const int sh = logN - d.logB;
+    const uint64_t b = j >> sh;
+    const uint64_t region = ((uint64_t)sample << d.logB) + b;
+    reg = d.words + d.off[region];
+    const uint32_t n = d.ucnt[region];
+    if (sh == 0) { lo = 0; hi = n; return; }
+    const int rb = d.bits - logN;
+    const uint64_t xlo = j << rb, xhi = (j + 1) << rb;
+    lo = lower_bound_words(reg, n, xlo);
+    hi = ((j + 1) & ((1ull << sh) - 1)) == 0 ? n : lower_bound_words(reg, n, xhi);
+}
+
+// K4: distinct keys of sub-bucket j over all samples -> sorted slab
+template <bool COUNT_ONLY>
+__global__ __launch_bounds__(256) void union_kernel(DictView d, int logN, uint64_t *stage, uint32_t stride, uint32_t *ncnt,
+                                                    uint32_t nslots, int *overflow)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_tab[];
+    __shared__ uint32_t s_tmp[17];
+    __shared__ int s_fail;
+    const uint64_t j = blockIdx.x;
+    const uint32_t total_slots = nslots + TABLE_PAD;
+    for (uint32_t i = threadIdx.x; i < total_slots; i += blockDim.x) s_tab[i] = 0ull;
+    if (threadIdx.x == 0) s_fail = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int rem_bits = d.bits - logN;
+    for (int s = wv; s < d.n_samples; s += nw) {
+        const uint64_t *reg; uint32_t lo, hi;
+        sub_slice(d, s, j, logN, reg, lo, hi);
+        for (uint32_t i = lo + lane; i < hi; i += 64) {
+            const uint64_t w = reg[i];
+            if (!table_insert(s_tab, total_slots, home_slot(w, rem_bits, nslots), w)) s_fail = 1;
+        }
+    }
+    __syncthreads();
+    if (s_fail) { if (threadIdx.x == 0) *overflow = 1; return; }
+    if (COUNT_ONLY) {
+        uint32_t cnt = 0;
+        for (uint32_t i = threadIdx.x; i < total_slots; i += blockDim.x) cnt += s_tab[i] != 0ull;
+        uint32_t tot; block_excl_scan(cnt, s_tmp, &tot);
+        if (threadIdx.x == 0) atomicAdd(ncnt, tot);
+        return;
+    }
+    uint64_t *slab = stage + j * (uint64_t)stride;
+    uint32_t total = table_emit_sorted(s_tab, total_slots, s_tmp, [&](uint32_t idx, uint64_t w) { if (idx < stride) slab[idx] = (w & ~15ull) | 1ull; });
+    if (threadIdx.x == 0) { ncnt[j] = total; if (total > stride) *overflow = 1; }
+}
+void launch_union(const DictView &d, int logN, uint64_t *stage, uint32_t stride, uint32_t *ncnt, uint32_t table_slots,
+                  int *overflow, hipStream_t st)
+{
+    size_t lds = (size_t)(table_slots + TABLE_PAD) * 8;
+    hipFuncSetAttribute((const void *)union_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(union_kernel<false>, dim3(1u << logN), dim3(256), lds, st, d, logN, stage, stride, ncnt, table_slots, overflow);
+}
+void launch_union_probe(const DictView &d, int logP, int probe, uint32_t *cnt, uint32_t table_slots, int *overflow, hipStream_t st)
+{
+    size_t lds = (size_t)(table_slots + TABLE_PAD) * 8;
+    hipFuncSetAttribute((const void *)union_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(union_kernel<true>, dim3((unsigned)probe), dim3(256), lds, st, d, logP, (uint64_t *)nullptr, 0u, cnt, table_slots, overflow);
+}
+
+// IUPAC letter of a base set; bit i of the set == 2-bit code i (A0 C1 T2 G3), cf. bit_encoding.rs:337-368
+__device__ static const char MASK2IUPAC_D[17] = "-ACMTWYHGRSVKDBN";
+
+// K5: rows = key slabs, columns = samples: fill the sample-major matrix + per-row statistics
+__global__ __launch_bounds__(512) void assemble_kernel(AssembleArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    const uint64_t j = blockIdx.x;
+    const uint32_t n = a.ncnt[j];
+    if (n == 0) return;
+    const uint32_t maxr = (a.max_rows + 15u) & ~15u;
+    uint64_t *s_keys = reinterpret_cast<uint64_t *>(s_raw);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_raw + (size_t)maxr * 8);
+    uint32_t *s_msk = s_cnt + maxr;
+    unsigned char *s_rows = reinterpret_cast<unsigned char *>(s_msk + maxr);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const uint64_t *slab = a.stage + j * (uint64_t)a.stride;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { s_keys[i] = slab[i] >> 4; s_cnt[i] = 0; s_msk[i] = 0; }
+    __syncthreads();
+    const uint64_t r0 = a.roff[j];
+    const uint32_t shift = (uint32_t)(r0 & 15u);
+    unsigned char *row = s_rows + (size_t)wv * (maxr + 32u);      // 16-B aligned; cell i lives at row[shift + i]
+    for (int s = wv; s < a.d.n_samples; s += nw) {
+        // fill with '-'
+        for (uint32_t i = lane * 4; i < n + shift + 3; i += 256) *reinterpret_cast<uint32_t *>(row + i) = 0x2D2D2D2Du;
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t *reg; uint32_t lo, hi;
+        sub_slice(a.d, s, j, a.logN, reg, lo, hi);
+        for (uint32_t i = lo + lane; i < hi; i += 64) {
+            const uint64_t w = reg[i];
+            const uint64_t key = w >> 4;
+            uint32_t l = 0, r = n;
+            while (l < r) { uint32_t m = (l + r) >> 1; if (s_keys[m] < key) l = m + 1; else r = m; }
+            if (l < n && s_keys[l] == key) {
+                const uint32_t m4 = (uint32_t)(w & 15u);
+                row[shift + l] = (unsigned char)MASK2IUPAC_D[m4];
+                const uint32_t single = (m4 & (m4 - 1)) == 0;
+                atomicAdd(&s_cnt[l], 1u | (single << 16));
+                atomicOr(&s_msk[l], 1u << m4);
+            } else {
+                *a.missing = 1;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // copy out: global column r0 + i  <-  row[shift + i]; 16-B body, byte head/tail
+        unsigned char *dst = a.matrix + (uint64_t)s * a.pitch + r0;
+        const uint32_t head = (16u - shift) & 15u;
+        const uint32_t h = head < n ? head : n;
+        if ((uint32_t)lane < h) dst[lane] = row[shift + lane];
+        const uint32_t body = (n - h) / 16u;
+        for (uint32_t v = lane; v < body; v += 64) {
+            const uint4 x = *reinterpret_cast<const uint4 *>(row + shift + h + 16u * v);
+            *reinterpret_cast<uint4 *>(dst + h + 16u * v) = x;
+        }
+        const uint32_t done = h + body * 16u;
+        if (done + lane < n) dst[done + lane] = row[shift + done + lane];
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        a.col_present[r0 + i] = s_cnt[i] & 0xFFFFu;
+        a.col_unambig[r0 + i] = s_cnt[i] >> 16;
+        a.col_mask[r0 + i] = s_msk[i];
+    }
+}
+void launch_assemble(const AssembleArgs &a, hipStream_t st)
+{
+    const uint32_t maxr = (a.max_rows + 15u) & ~15u;
+    const int nw = 8;
+    size_t lds = (size_t)maxr * 16 + (size_t)nw * (maxr + 32u);
+    hipFuncSetAttribute((const void *)assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(assemble_kernel, dim3(1u << a.logN), dim3(64 * nw), lds, st, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// key conversions
+// ------------------------------------------------------------------------------------------------
+__global__ void gather_keys_kernel(const uint64_t *stage, uint32_t stride, const uint32_t *ncnt, const uint64_t *roff, uint64_t *out,
+                                   int unhash, HashParams hp)
+{
+    const uint64_t j = blockIdx.x;
+    const uint32_t n = ncnt[j];
+    const uint64_t *slab = stage + j * (uint64_t)stride;
+    uint64_t *dst = out + roff[j];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = unhash ? hunmix(slab[i] >> 4, hp) : slab[i];
+}
+void launch_gather_keys(const uint64_t *stage, uint32_t stride, const uint32_t *ncnt, const uint64_t *roff, int n_sub, uint64_t *out,
+                        int unhash, HashParams hp, hipStream_t st)
+{
+    hipLaunchKernelGGL(gather_keys_kernel, dim3((unsigned)n_sub), dim3(256), 0, st, stage, stride, ncnt, roff, out, unhash, hp);
+}
+__global__ void hash_keys_kernel(const uint64_t *keys, uint64_t *words, uint64_t n, HashParams hp)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        words[i] = (hmix(keys[i], hp) << 4) | 1ull;
+}
+void launch_hash_keys(const uint64_t *keys, uint64_t *words, uint64_t n, HashParams hp, hipStream_t st)
+{
+    if (!n) return;
+    unsigned g = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(hash_keys_kernel, dim3(g), dim3(256), 0, st, keys, words, n, hp);
+}
+__global__ void unhash_dict_kernel(const uint64_t *words, uint64_t n, uint64_t *keys, uint8_t *bases, HashParams hp)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        keys[i] = hunmix(words[i] >> 4, hp);
+        bases[i] = (uint8_t)MASK2IUPAC_D[words[i] & 15u];
+    }
+}
+void launch_unhash_dict(const uint64_t *words, uint64_t n, uint64_t *keys, uint8_t *bases, HashParams hp, hipStream_t st)
+{
+    if (!n) return;
+    unsigned g = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(unhash_dict_kernel, dim3(g), dim3(256), 0, st, words, n, keys, bases, hp);
+}
+
+}  // namespace skx
+#include "skx_device2.inc"

@@ -1,0 +1,98 @@
+// skx_internal.h -- private host-side types shared by the C-ABI translation units.
+#pragma once
+#include "../../include/skx.h"
+#include "skx_device.h"
+#include <string>
+#include <vector>
+
+namespace skx {
+
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what);       // sets the error, returns SKX_ENODEV / SKX_ENOMEM
+
+#define SKX_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return skx::hip_fail(e_, #call); } while (0)
+#define SKX_TRY(call) do { int r_ = (call); if (r_ != SKX_OK) return r_; } while (0)
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr; size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+    ~DevBuf() { release(); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    int alloc(size_t count) {
+        release();
+        if (!count) count = 1;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc"); }
+        n = count; return SKX_OK;
+    }
+    int zero(hipStream_t st) { return p ? (hipMemsetAsync(p, 0, n * sizeof(T), st) == hipSuccess ? SKX_OK : SKX_ENODEV) : SKX_OK; }
+};
+
+}  // namespace skx
+
+struct skx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    skx_timings tm{};
+    bool timing = true;
+};
+
+struct skx_dictset {
+    skx_ctx *ctx = nullptr;
+    int n = 0, k = 0, rc = 0, logB = 0, key_bits = 64;
+    skx::HashParams hp{};
+    skx::DevBuf<uint64_t> words;     // all (sample,bucket) regions
+    skx::DevBuf<uint64_t> off;       // [n<<logB + 1]
+    skx::DevBuf<uint32_t> raw;       // [n<<logB] windows per region
+    skx::DevBuf<uint32_t> ucnt;      // [n<<logB] distinct split k-mers per region
+    std::vector<uint64_t> sample_size;   // SkaDict::ksize per sample
+    skx::DictView view() const { return skx::DictView{words.p, off.p, ucnt.p, n, logB, hp.bits}; }
+};
+
+struct skx_keyset {
+    skx_ctx *ctx = nullptr;
+    int k = 0, rc = 0, logN = 0;
+    skx::HashParams hp{};
+    uint32_t stride = 0, max_rows = 0;
+    uint64_t total = 0;
+    skx::DevBuf<uint64_t> stage;     // slab j at stage + j*stride (sorted, engine order)
+    skx::DevBuf<uint32_t> ncnt;      // [1<<logN]
+    skx::DevBuf<uint64_t> roff;      // [1<<logN + 1]
+    skx::DevBuf<uint64_t> flat;      // lazily built compact copy (engine order words)
+};
+
+struct skx_array {
+    skx_ctx *ctx = nullptr;
+    int k = 0, rc = 0, k_bits = 64;
+    skx::HashParams hp{};
+    std::vector<std::string> names;
+    std::string version;
+    uint64_t n_kmers = 0;            // split_kmers.len()
+    uint64_t n_rows = 0;             // variants.nrows()
+    uint64_t pitch = 0;
+    bool engine_order = false;       // rows sorted by H(key)
+    skx::DevBuf<uint64_t> keys;      // [n_kmers] packed words (H(key)<<4 | 1)
+    skx::DevBuf<uint8_t> matrix;     // [n_samples][pitch], sample-major
+    skx::DevBuf<uint32_t> present, unambig, mask;   // per row statistics
+    // 128-bit keys of arrays loaded from k>31 files are kept on the host (filter/align/distance never touch them)
+    std::vector<skx_key> host_keys;
+};
+
+namespace skx {
+// host reader (fastx.cpp): one sample -> record stream; returns SKX_* and sets the error
+struct HostStream { std::vector<uint8_t> seq, qual; bool is_fastq = false; };
+int read_sample_stream(const char *file1, const char *file2, double proportion_reads, HostStream &out);
+// .skf codec (skf_codec.cpp)
+struct SkfData {
+    int k = 0, rc = 0, k_bits = 64; std::vector<std::string> names; std::string version;
+    std::vector<skx_key> keys; uint64_t n_rows = 0; std::vector<uint8_t> variants; std::vector<uint64_t> counts;
+};
+int skf_read(const char *path, SkfData &out);
+int skf_write(const char *path, const SkfData &in);
+}  // namespace skx

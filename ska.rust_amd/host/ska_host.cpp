@@ -1,0 +1,288 @@
+// ska_host.cpp -- host side above the C ABI: the reference's mode glue for the hot path
+// (generic_modes.rs: align / apply_filters / distance / save_skf; io_utils.rs: read_input_fastas /
+// get_input_list / load_array / set_ostream; cli.rs + lib.rs:557-727,808-827 for build | align | distance | nk).
+// Written in C++ because the image has no Rust toolchain; it only talks to the engine through include/skx.h.
+#include "../../include/skx_host.h"
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <unistd.h>
+#include <vector>
+
+namespace {
+
+void put(std::string &s, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+void put(std::string &s, const char *fmt, ...)
+{
+    char tmp[256];
+    va_list ap; va_start(ap, fmt); int n = vsnprintf(tmp, sizeof tmp, fmt, ap); va_end(ap);
+    if (n < (int)sizeof tmp) { s.append(tmp, (size_t)n); return; }
+    std::vector<char> big((size_t)n + 1);
+    va_start(ap, fmt); vsnprintf(big.data(), big.size(), fmt, ap); va_end(ap);
+    s.append(big.data(), (size_t)n);
+}
+int to_buf(const std::string &s, char **buf, uint64_t *len)
+{
+    char *p = (char *)malloc(s.size() + 1);
+    if (!p) return SKX_ENOMEM;
+    memcpy(p, s.data(), s.size()); p[s.size()] = 0;
+    *buf = p; *len = s.size();
+    return SKX_OK;
+}
+bool ends_with_ci(const std::string &s, const char *suf)
+{
+    size_t m = strlen(suf);
+    if (s.size() < m) return false;
+    for (size_t i = 0; i < m; i++) if (tolower((unsigned char)s[s.size() - m + i]) != suf[i]) return false;
+    return true;
+}
+// Rust `{:?}` of a String
+void rust_debug(std::string &o, const std::string &s)
+{
+    o += '"';
+    for (unsigned char c : s) {
+        if (c == '"') o += "\\\""; else if (c == '\\') o += "\\\\"; else if (c == '\n') o += "\\n";
+        else if (c == '\r') o += "\\r"; else if (c == '\t') o += "\\t";
+        else if (c < 0x20 || c == 0x7f) put(o, "\\u{%x}", c);
+        else o += (char)c;
+    }
+    o += '"';
+}
+}  // namespace
+
+extern "C" char *skh_sample_name(const char *path)
+{
+    // ^.+/(.+)\.(?i:fa|fasta|fastq|fastq\.gz)$  then  ^(.+)\.(?i:...)$  else the whole argument (io_utils.rs:31-46)
+    static const char *exts[] = {".fa", ".fasta", ".fastq", ".fastq.gz"};     // greedy (.+): shortest extension wins
+    const std::string s(path);
+    for (const char *e : exts) {
+        if (!ends_with_ci(s, e)) continue;
+        const size_t stem_end = s.size() - strlen(e);
+        for (size_t i = stem_end; i-- > 1;)
+            if (s[i] == '/' && i + 1 < stem_end) return strdup(s.substr(i + 1, stem_end - i - 1).c_str());
+    }
+    for (const char *e : exts)
+        if (ends_with_ci(s, e) && s.size() > strlen(e)) return strdup(s.substr(0, s.size() - strlen(e)).c_str());
+    return strdup(path);
+}
+
+extern "C" int skh_apply_filters(skx_array *a, double min_freq, int filter_ambig_as_missing, int filter_type, int ambig_mask,
+                                 int ignore_const_gaps, int32_t *removed)
+{
+    skx_array_info_t info; skx_array_info(a, &info);
+    const uint64_t threshold = (uint64_t)std::ceil((double)info.n_samples * min_freq);       // generic_modes.rs:121
+    return skx_array_filter(a, threshold, filter_ambig_as_missing, filter_type, ambig_mask, ignore_const_gaps, /*update_kmers=*/0, removed);
+}
+
+extern "C" int skh_align(skx_array *a, int filter_type, int mask_ambig, int ignore_const_gaps, double min_freq, int filter_ambig_as_missing,
+                         char **buf, uint64_t *len)
+{
+    int32_t removed = 0;
+    int r = skh_apply_filters(a, min_freq, filter_ambig_as_missing, filter_type, mask_ambig, ignore_const_gaps, &removed);
+    if (r != SKX_OK) return r;
+    return skx_array_fasta(a, buf, len);
+}
+
+extern "C" int skh_distance_tsv(skx_array *a, double min_freq, int filt_ambig, char **buf, uint64_t *len)
+{
+    skx_array_info_t info; skx_array_info(a, &info);
+    int32_t removed = 0; int r;
+    if (min_freq * (double)info.n_samples >= 1.0)                                             // generic_modes.rs:149-159
+        if ((r = skh_apply_filters(a, min_freq, 0, SKX_FILTER_NONE, 0, 0, &removed)) != SKX_OK) return r;
+    int32_t constant = 0;
+    if ((r = skh_apply_filters(a, 0.0, 0, SKX_FILTER_NO_CONST, 0, 0, &constant)) != SKX_OK) return r;   // :161-168
+    const uint64_t S = info.n_samples;
+    std::vector<skx_dist> d(S * (S - 1) / 2 + 1);
+    if ((r = skx_array_distance(a, (double)constant, filt_ambig, d.data())) != SKX_OK) return r;
+    std::string out = "Sample1\tSample2\tDistance\tMismatches (proportion)\tMatch count\tMismatch count\n";
+    size_t n = 0;
+    for (uint64_t i = 0; i < S; i++)
+        for (uint64_t j = i + 1; j < S; j++, n++)
+            put(out, "%s\t%s\t%.2f\t%.5f\t%llu\t%llu\n", skx_array_name(a, i), skx_array_name(a, j), d[n].distance, d[n].mismatch_prop,
+                (unsigned long long)d[n].match_count, (unsigned long long)d[n].mismatch_count);
+    return to_buf(out, buf, len);
+}
+
+extern "C" int skh_nk(skx_array *a, int full_info, char **buf, uint64_t *len)
+{
+    skx_array_info_t info; skx_array_info(a, &info);
+    std::string o;
+    put(o, "ska_version=%s\nk=%d\nk_bits=%d\nrc=%s\nk-mers=%llu\nsamples=%llu\n", skx_array_version(a), info.k, info.k_bits,
+        info.rc ? "true" : "false", (unsigned long long)info.n_kmers, (unsigned long long)info.n_samples);
+    o += "sample_names=[";
+    for (uint64_t s = 0; s < info.n_samples; s++) { if (s) o += ", "; rust_debug(o, skx_array_name(a, s)); }
+    o += "]\nsample_kmers=[";
+    std::vector<int64_t> sk(info.n_samples);
+    int r = skx_array_sample_kmers(a, sk.data());
+    if (r != SKX_OK) return r;
+    for (uint64_t s = 0; s < info.n_samples; s++) put(o, "%s%lld", s ? ", " : "", (long long)sk[s]);
+    o += "]\n\n";
+    if (full_info) {
+        std::vector<skx_key> keys(info.n_kmers);
+        std::vector<uint8_t> var(info.n_rows * info.n_samples);
+        if ((r = skx_array_export(a, keys.data(), var.data(), nullptr)) != SKX_OK) return r;
+        const int half = (info.k - 1) / 2;
+        static const char L[] = "ACTG";
+        for (uint64_t row = 0; row < info.n_kmers && row < info.n_rows; row++) {
+            unsigned __int128 key = ((unsigned __int128)keys[row].hi << 64) | keys[row].lo;
+            std::string up(half, 'A'), lo(half, 'A');
+            for (int i = 0; i < half; i++) { lo[half - 1 - i] = L[(int)(key & 3)]; key >>= 2; }
+            for (int i = 0; i < half; i++) { up[half - 1 - i] = L[(int)(key & 3)]; key >>= 2; }
+            o += up; o += '\t'; o += lo; o += '\t';
+            for (uint64_t s = 0; s < info.n_samples; s++) { if (s) o += ','; uint8_t b = var[row * info.n_samples + s]; o += b ? (char)b : '-'; }
+            o += '\n';
+        }
+        o += '\n';
+    }
+    return to_buf(o, buf, len);
+}
+
+extern "C" int skh_save_skf(skx_array *a, const char *out_prefix)
+{
+    std::string p(out_prefix);
+    if (p.size() < 4 || p.compare(p.size() - 4, 4, ".skf") != 0) p += ".skf";           // generic_modes.rs:272-276
+    return skx_array_save(a, p.c_str());
+}
+
+extern "C" int skh_load_array(skx_ctx *ctx, const char *const *inputs, int n_inputs, int threads, skx_array **out)
+{
+    if (n_inputs == 1) {                                                                // io_utils.rs:65-75, lib.rs:635-661
+        int r = skx_array_load(ctx, inputs[0], 64, out);
+        if (r == SKX_OK) return r;
+        return skx_array_load(ctx, inputs[0], 128, out);
+    }
+    // >1 inputs: `ska build` with defaults (k=31, rc, min_count 5, min_qual 20, strict), io_utils.rs:76-92
+    std::vector<char *> names(n_inputs);
+    for (int i = 0; i < n_inputs; i++) names[i] = skh_sample_name(inputs[i]);
+    skx_qual q{5, 20, SKX_QUAL_STRICT};
+    int r = skx_build_and_merge(ctx, names.data(), inputs, nullptr, n_inputs, 31, 1, &q, threads, 0.0, out);
+    for (auto p : names) free(p);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------ CLI
+namespace {
+struct Args {
+    std::vector<std::string> pos;
+    std::vector<std::pair<std::string, std::string>> opt;
+    bool has(const std::string &k) const { for (auto &o : opt) if (o.first == k) return true; return false; }
+    std::string get(const std::string &k, const std::string &d = "") const { for (auto &o : opt) if (o.first == k) return o.second; return d; }
+};
+const char *VALUE_OPTS[] = {"-o", "-k", "-f", "--threads", "--min-count", "--min-qual", "--qual-filter", "--proportion-reads",
+                            "--min-freq", "-m", "--filter", nullptr};
+bool takes_value(const std::string &s) { for (int i = 0; VALUE_OPTS[i]; i++) if (s == VALUE_OPTS[i]) return true; return false; }
+int fail(const char *msg) { fprintf(stderr, "error: %s\n", msg); return 2; }
+int engine_fail() { fprintf(stderr, "error: %s\n", skx_last_error()); return 101; }   // Rust panics exit with 101
+int parse_filter(const std::string &s)
+{
+    if (s == "no-filter") return SKX_FILTER_NONE;
+    if (s == "no-const") return SKX_FILTER_NO_CONST;
+    if (s == "no-ambig") return SKX_FILTER_NO_AMBIG;
+    if (s == "no-ambig-or-const") return SKX_FILTER_NO_AMBIG_OR_CONST;
+    return -1;
+}
+int emit(const std::string &out_path, const char *buf, uint64_t len)                 // io_utils::set_ostream
+{
+    if (out_path.empty()) { fwrite(buf, 1, len, stdout); fflush(stdout); return 0; }
+    FILE *f = fopen(out_path.c_str(), "wb");
+    if (!f) return fail("cannot create output file");
+    fwrite(buf, 1, len, f); fclose(f);
+    return 0;
+}
+}  // namespace
+
+extern "C" int skh_main(int argc, char **argv)
+{
+    fprintf(stderr, "SKA: Split K-mer Analysis (the alignment-free aligner)\n");
+    if (argc < 2) return fail("usage: ska <build|align|distance|nk> ...");
+    const std::string cmd = argv[1];
+    Args a;
+    for (int i = 2; i < argc; i++) {
+        std::string s = argv[i];
+        if (s.size() > 1 && s[0] == '-' && !(s.size() > 1 && isdigit((unsigned char)s[1]))) {
+            if (takes_value(s)) { if (i + 1 >= argc) return fail("missing option value"); a.opt.emplace_back(s, argv[++i]); }
+            else a.opt.emplace_back(s, "");
+        } else a.pos.push_back(s);
+    }
+    int threads = atoi(a.get("--threads", "1").c_str());
+    if (threads < 1) return fail("Threads must be one or higher");
+    skx_ctx *ctx = nullptr;
+    if (skx_ctx_create(0, &ctx) != SKX_OK) return engine_fail();
+    int rcode = 0;
+    skx_array *arr = nullptr;
+    if (cmd == "build") {
+        if (!a.has("-o")) return fail("-o <output> is required");
+        if (a.pos.empty() == !a.has("-f")) return fail("give either sequence files or -f <file_list>");
+        const int k = atoi(a.get("-k", "31").c_str());
+        if (k < 5 || k > 63 || k % 2 == 0) return fail("K-mer must be an odd number between 5 and 63 (inclusive)");   // cli.rs:38-47
+        skx_qual q{5, 20, SKX_QUAL_STRICT};
+        if (a.has("--min-count")) {
+            const std::string mc = a.get("--min-count");
+            if (mc == "auto") return fail("--min-count auto needs the coverage model (`ska cov`), which is outside this engine");
+            char *end; long v = strtol(mc.c_str(), &end, 10);
+            if (*end || v < 1 || v > 65535) return fail("Minimum kmer count must be >= 1");                           // cli.rs:94-108
+            q.min_count = (uint16_t)v;
+        }
+        if (a.has("--min-qual")) q.min_qual = (uint8_t)atoi(a.get("--min-qual").c_str());
+        if (a.has("--qual-filter")) {
+            const std::string f = a.get("--qual-filter");
+            q.qual_filter = f == "no-filter" ? SKX_QUAL_NOFILTER : f == "middle" ? SKX_QUAL_MIDDLE : f == "strict" ? SKX_QUAL_STRICT : -1;
+            if (q.qual_filter < 0) return fail("invalid --qual-filter");
+        }
+        double prop = a.has("--proportion-reads") ? atof(a.get("--proportion-reads").c_str()) : 0.0;
+        std::vector<std::string> names, f1, f2;
+        if (a.has("-f")) {                                                                                            // io_utils.rs:116-146
+            std::ifstream in(a.get("-f"));
+            if (!in) return fail("Unable to open file_list");
+            std::string line;
+            while (std::getline(in, line)) {
+                std::istringstream ls(line); std::vector<std::string> fld; std::string t;
+                while (ls >> t) fld.push_back(t);
+                if (fld.size() < 2 || fld.size() > 3) return fail("Unable to parse line in file_list");
+                names.push_back(fld[0]); f1.push_back(fld[1]); f2.push_back(fld.size() == 3 ? fld[2] : "");
+            }
+        } else
+            for (auto &p : a.pos) { char *n = skh_sample_name(p.c_str()); names.push_back(n); free(n); f1.push_back(p); f2.push_back(""); }
+        std::vector<const char *> cn, c1, c2;
+        for (size_t i = 0; i < names.size(); i++) { cn.push_back(names[i].c_str()); c1.push_back(f1[i].c_str()); c2.push_back(f2[i].empty() ? nullptr : f2[i].c_str()); }
+        if (skx_build_and_merge(ctx, cn.data(), c1.data(), c2.data(), (int)cn.size(), k, !a.has("--single-strand"), &q, threads, prop, &arr) != SKX_OK ||
+            skh_save_skf(arr, a.get("-o").c_str()) != SKX_OK)
+            rcode = engine_fail();
+    } else if (cmd == "align") {
+        if (a.pos.empty()) return fail("input required");
+        std::vector<const char *> in; for (auto &p : a.pos) in.push_back(p.c_str());
+        const int filter = parse_filter(a.get("--filter", "no-const"));
+        if (filter < 0) return fail("invalid --filter");
+        const double mf = atof(a.get("--min-freq", a.get("-m", "0.9")).c_str());
+        if (mf < 0 || mf > 1) return fail("Frequency must be between 0 and 1 (inclusive)");
+        char *buf = nullptr; uint64_t len = 0;
+        if (skh_load_array(ctx, in.data(), (int)in.size(), threads, &arr) != SKX_OK ||
+            skh_align(arr, filter, a.has("--ambig-mask"), a.has("--no-gap-only-sites"), mf, a.has("--filter-ambig-as-missing"), &buf, &len) != SKX_OK)
+            rcode = engine_fail();
+        else { rcode = emit(a.get("-o"), buf, len); skx_free(buf); }
+    } else if (cmd == "distance") {
+        if (a.pos.size() != 1) return fail("one .skf file required");
+        const char *in[1] = {a.pos[0].c_str()};
+        const double mf = atof(a.get("--min-freq", a.get("-m", "0")).c_str());
+        char *buf = nullptr; uint64_t len = 0;
+        if (skh_load_array(ctx, in, 1, 1, &arr) != SKX_OK || skh_distance_tsv(arr, mf, !a.has("--allow-ambiguous"), &buf, &len) != SKX_OK)
+            rcode = engine_fail();
+        else { rcode = emit(a.get("-o"), buf, len); skx_free(buf); }
+    } else if (cmd == "nk") {
+        if (a.pos.size() != 1) return fail("one .skf file required");
+        const char *in[1] = {a.pos[0].c_str()};
+        char *buf = nullptr; uint64_t len = 0;
+        if (skh_load_array(ctx, in, 1, 1, &arr) != SKX_OK || skh_nk(arr, a.has("--full-info"), &buf, &len) != SKX_OK) rcode = engine_fail();
+        else { rcode = emit("", buf, len); skx_free(buf); }
+    } else {
+        rcode = fail("unknown subcommand (this engine provides build, align, distance, nk)");
+    }
+    if (arr) skx_array_free(arr);
+    skx_ctx_destroy(ctx);
+    return rcode;
+}

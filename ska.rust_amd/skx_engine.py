@@ -1,0 +1,458 @@
+"""ctypes binding of the MI355X split-k-mer engine (libskx.so: include/skx.h + include/skx_host.h).
+
+The product path.  It never imports anything from oracle/ and has no CPU
+fallback: if libskx.so is missing or no gfx950 device is usable, every call
+raises.  The Python surface mirrors the reference's Rust API for the hot path
+(SkaDict / build_and_merge / MergeSkaArray / generic_modes), so tests read like
+the reference's own.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libskx.so")
+
+QUAL_NOFILTER, QUAL_MIDDLE, QUAL_STRICT = 0, 1, 2
+FILTER_NONE, FILTER_NO_CONST, FILTER_NO_AMBIG, FILTER_NO_AMBIG_OR_CONST = 0, 1, 2, 3
+OK, EINVAL, EIO, ENODEV, ENOMEM, EEMPTY, EUNSUP, EFORMAT = range(8)
+
+KEY_DT = np.dtype([("lo", "<u8"), ("hi", "<u8")])
+DIST_DT = np.dtype([("distance", "<f8"), ("mismatch_prop", "<f8"), ("match_count", "<u8"), ("mismatch_count", "<u8")])
+
+
+class Qual(C.Structure):
+    _fields_ = [("min_count", C.c_uint16), ("min_qual", C.c_uint8), ("qual_filter", C.c_int32)]
+
+
+class Stream(C.Structure):
+    _fields_ = [("seq", C.c_void_p), ("qual", C.c_void_p), ("len", C.c_uint64)]
+
+
+class ArrayInfo(C.Structure):
+    _fields_ = [("k", C.c_int32), ("rc", C.c_int32), ("k_bits", C.c_int32), ("n_kmers", C.c_uint64),
+                ("n_rows", C.c_uint64), ("n_samples", C.c_uint64)]
+
+
+class Timings(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("hist", "scatter", "dedupe", "key_union", "assemble", "filter", "compact", "distance")]
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[skx {code}] {msg}")
+        self.code = code
+
+
+# every symbol include/skx.h and include/skx_host.h declare
+SYMBOLS = """skx_last_error skx_version skx_ctx_create skx_ctx_destroy skx_ctx_sync skx_ctx_stream skx_dictset_build
+skx_dictset_build_files skx_dictset_free skx_dictset_nsamples skx_dictset_key_bits skx_dictset_size skx_dictset_export
+skx_keyset_union skx_keyset_size skx_keyset_device skx_keyset_from_device skx_keyset_merge skx_keyset_free
+skx_array_assemble skx_merge skx_build_and_merge skx_array_free skx_array_save skx_array_load skx_array_from_host
+skx_array_info skx_array_name skx_array_version skx_array_export skx_array_sample_kmers skx_array_filter
+skx_array_write_fasta skx_array_fasta skx_array_device_matrix skx_array_distance skx_free skx_ctx_timings
+skh_apply_filters skh_align skh_distance_tsv skh_nk skh_save_skf skh_load_array skh_sample_name skh_main""".split()
+
+_lib = None
+
+
+def load_library():
+    """Load libskx.so (no GPU needed for loading); fails loudly when the extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          f"(make -C ska.rust_amd). There is no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    vp, cp, i, d, u64 = C.c_void_p, C.c_char_p, C.c_int, C.c_double, C.c_uint64
+    pp = C.POINTER(vp)
+    lib.skx_last_error.restype = cp
+    lib.skx_version.restype = cp
+    lib.skx_ctx_create.argtypes = [i, pp]
+    lib.skx_ctx_destroy.argtypes = [vp]
+    lib.skx_ctx_sync.argtypes = [vp]
+    lib.skx_ctx_stream.argtypes = [vp]
+    lib.skx_ctx_stream.restype = vp
+    lib.skx_ctx_timings.argtypes = [vp, C.POINTER(Timings), i]
+    lib.skx_dictset_build.argtypes = [vp, C.POINTER(Stream), i, i, i, i, C.POINTER(Qual), pp]
+    lib.skx_dictset_build_files.argtypes = [vp, C.POINTER(cp), C.POINTER(cp), i, i, i, C.POINTER(Qual), i, d, pp]
+    lib.skx_dictset_free.argtypes = [vp]
+    lib.skx_dictset_nsamples.argtypes = [vp]
+    lib.skx_dictset_key_bits.argtypes = [vp]
+    lib.skx_dictset_size.argtypes = [vp, i, C.POINTER(u64)]
+    lib.skx_dictset_export.argtypes = [vp, i, vp, vp, u64]
+    lib.skx_keyset_union.argtypes = [vp, vp, pp]
+    lib.skx_keyset_size.argtypes = [vp, C.POINTER(u64)]
+    lib.skx_keyset_device.argtypes = [vp, pp, C.POINTER(u64), C.POINTER(i)]
+    lib.skx_keyset_from_device.argtypes = [vp, vp, u64, i, i, pp]
+    lib.skx_keyset_merge.argtypes = [vp, pp, i, pp]
+    lib.skx_keyset_free.argtypes = [vp]
+    lib.skx_array_assemble.argtypes = [vp, vp, vp, C.POINTER(cp), pp]
+    lib.skx_merge.argtypes = [vp, vp, C.POINTER(cp), pp]
+    lib.skx_build_and_merge.argtypes = [vp, C.POINTER(cp), C.POINTER(cp), C.POINTER(cp), i, i, i, C.POINTER(Qual), i, d, pp]
+    lib.skx_array_free.argtypes = [vp]
+    lib.skx_array_save.argtypes = [vp, cp]
+    lib.skx_array_load.argtypes = [vp, cp, i, pp]
+    lib.skx_array_from_host.argtypes = [vp, i, i, C.POINTER(cp), i, vp, vp, u64, cp, pp]
+    lib.skx_array_info.argtypes = [vp, C.POINTER(ArrayInfo)]
+    lib.skx_array_name.argtypes = [vp, u64]
+    lib.skx_array_name.restype = cp
+    lib.skx_array_version.argtypes = [vp]
+    lib.skx_array_version.restype = cp
+    lib.skx_array_export.argtypes = [vp, vp, vp, vp]
+    lib.skx_array_sample_kmers.argtypes = [vp, vp]
+    lib.skx_array_filter.argtypes = [vp, u64, i, i, i, i, i, C.POINTER(C.c_int32)]
+    lib.skx_array_write_fasta.argtypes = [vp, i]
+    lib.skx_array_fasta.argtypes = [vp, pp, C.POINTER(u64)]
+    lib.skx_array_device_matrix.argtypes = [vp, pp, C.POINTER(u64), C.POINTER(u64)]
+    lib.skx_array_distance.argtypes = [vp, d, i, vp]
+    lib.skx_free.argtypes = [vp]
+    lib.skh_apply_filters.argtypes = [vp, d, i, i, i, i, C.POINTER(C.c_int32)]
+    lib.skh_align.argtypes = [vp, i, i, i, d, i, pp, C.POINTER(u64)]
+    lib.skh_distance_tsv.argtypes = [vp, d, i, pp, C.POINTER(u64)]
+    lib.skh_nk.argtypes = [vp, i, pp, C.POINTER(u64)]
+    lib.skh_save_skf.argtypes = [vp, cp]
+    lib.skh_load_array.argtypes = [vp, C.POINTER(cp), i, i, pp]
+    lib.skh_sample_name.argtypes = [cp]
+    lib.skh_sample_name.restype = vp
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != OK:
+        raise EngineError(rc, _lib.skx_last_error().decode())
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _take(ptr, n):
+    s = C.string_at(ptr, n.value)
+    _lib.skx_free(ptr)
+    return s
+
+
+def qual(min_count=5, min_qual=20, qual_filter=QUAL_STRICT):
+    return Qual(min_count, min_qual, qual_filter)
+
+
+def sample_name(path):
+    lib = load_library()
+    p = lib.skh_sample_name(path.encode())
+    s = C.string_at(p).decode()
+    lib.skx_free(p)
+    return s
+
+
+class Context:
+    def __init__(self, device=0):
+        lib = load_library()
+        h = C.c_void_p()
+        _check(lib.skx_ctx_create(device, C.byref(h)))
+        self.h = h
+
+    def sync(self):
+        _check(_lib.skx_ctx_sync(self.h))
+
+    @property
+    def stream(self):
+        return _lib.skx_ctx_stream(self.h)
+
+    def timings(self, reset=False):
+        t = Timings()
+        _lib.skx_ctx_timings(self.h, C.byref(t), int(reset))
+        return {n: getattr(t, n) for n, _ in Timings._fields_}
+
+    def close(self):
+        if getattr(self, "h", None):
+            _lib.skx_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("SKX_USE_LOCAL_RANK") else 0)
+    return _default_ctx
+
+
+def record_stream(records):
+    """records: iterable of bytes -> the device record stream (each record + b'\\n')."""
+    return b"".join(bytes(r) + b"\n" for r in records)
+
+
+class DictSet:
+    """A batch of per-sample SkaDicts (ska_dict.rs:56-69), device resident."""
+
+    def __init__(self, handle, ctx):
+        self.h, self.ctx = handle, ctx
+
+    @classmethod
+    def build(cls, streams, k, rc=True, q=None, ctx=None, quals=None):
+        """streams: list of record-stream bytes (host); quals: optional list of quality streams."""
+        ctx = ctx or default_context()
+        q = q or qual()
+        n = len(streams)
+        bufs = [np.frombuffer(s, dtype=np.uint8) for s in streams]
+        qbufs = [np.frombuffer(s, dtype=np.uint8) if s is not None else None for s in (quals or [None] * n)]
+        arr = (Stream * n)()
+        for i in range(n):
+            arr[i].seq = bufs[i].ctypes.data if len(bufs[i]) else None
+            arr[i].qual = qbufs[i].ctypes.data if qbufs[i] is not None else None
+            arr[i].len = len(bufs[i])
+        h = C.c_void_p()
+        _check(_lib.skx_dictset_build(ctx.h, arr, n, 0, k, int(rc), C.byref(q), C.byref(h)))
+        return cls(h, ctx)
+
+    @classmethod
+    def build_device(cls, ptrs, lens, k, rc=True, q=None, ctx=None):
+        """ptrs: device pointers (ints) of 16-B aligned record streams already in HBM."""
+        ctx = ctx or default_context()
+        q = q or qual()
+        n = len(ptrs)
+        arr = (Stream * n)()
+        for i in range(n):
+            arr[i].seq, arr[i].qual, arr[i].len = ptrs[i], None, lens[i]
+        h = C.c_void_p()
+        _check(_lib.skx_dictset_build(ctx.h, arr, n, 1, k, int(rc), C.byref(q), C.byref(h)))
+        return cls(h, ctx)
+
+    @classmethod
+    def from_files(cls, inputs, k, rc=True, q=None, threads=1, proportion_reads=0.0, ctx=None):
+        ctx = ctx or default_context()
+        q = q or qual()
+        n = len(inputs)
+        f1 = (C.c_char_p * n)(*[x[0].encode() for x in inputs])
+        f2 = (C.c_char_p * n)(*[(x[1].encode() if x[1] else None) for x in inputs])
+        h = C.c_void_p()
+        _check(_lib.skx_dictset_build_files(ctx.h, f1, f2, n, k, int(rc), C.byref(q), threads, proportion_reads, C.byref(h)))
+        return cls(h, ctx)
+
+    @property
+    def nsamples(self):
+        return _lib.skx_dictset_nsamples(self.h)
+
+    @property
+    def key_bits(self):
+        return _lib.skx_dictset_key_bits(self.h)
+
+    def size(self, sample):
+        n = C.c_uint64()
+        _check(_lib.skx_dictset_size(self.h, sample, C.byref(n)))
+        return n.value
+
+    def export(self, sample):
+        n = self.size(sample)
+        keys = np.zeros(n, KEY_DT)
+        bases = np.zeros(n, np.uint8)
+        _check(_lib.skx_dictset_export(self.h, sample, _np_ptr(keys), _np_ptr(bases), n))
+        return keys, bases
+
+    def union_keys(self):
+        h = C.c_void_p()
+        _check(_lib.skx_keyset_union(self.ctx.h, self.h, C.byref(h)))
+        return KeySet(h, self.ctx)
+
+    def merge(self, names):
+        n = len(names)
+        nm = (C.c_char_p * n)(*[x.encode() for x in names])
+        h = C.c_void_p()
+        _check(_lib.skx_merge(self.ctx.h, self.h, nm, C.byref(h)))
+        return Array(h, self.ctx)
+
+    def assemble(self, rows, names):
+        n = len(names)
+        nm = (C.c_char_p * n)(*[x.encode() for x in names])
+        h = C.c_void_p()
+        _check(_lib.skx_array_assemble(self.ctx.h, self.h, rows.h, nm, C.byref(h)))
+        return Array(h, self.ctx)
+
+    def free(self):
+        if getattr(self, "h", None):
+            _lib.skx_dictset_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.free()
+
+
+class KeySet:
+    def __init__(self, handle, ctx):
+        self.h, self.ctx = handle, ctx
+
+    def __len__(self):
+        n = C.c_uint64()
+        _check(_lib.skx_keyset_size(self.h, C.byref(n)))
+        return n.value
+
+    def device(self):
+        p, n, w = C.c_void_p(), C.c_uint64(), C.c_int()
+        _check(_lib.skx_keyset_device(self.h, C.byref(p), C.byref(n), C.byref(w)))
+        return p.value, n.value, w.value
+
+    @classmethod
+    def from_device(cls, ptr, n_keys, k, rc=True, ctx=None):
+        ctx = ctx or default_context()
+        h = C.c_void_p()
+        _check(_lib.skx_keyset_from_device(ctx.h, ptr, n_keys, k, int(rc), C.byref(h)))
+        return cls(h, ctx)
+
+    @classmethod
+    def merge(cls, sets, ctx=None):
+        ctx = ctx or sets[0].ctx
+        hs = (C.c_void_p * len(sets))(*[s.h for s in sets])
+        h = C.c_void_p()
+        _check(_lib.skx_keyset_merge(ctx.h, hs, len(sets), C.byref(h)))
+        return cls(h, ctx)
+
+    def free(self):
+        if getattr(self, "h", None):
+            _lib.skx_keyset_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.free()
+
+
+class Array:
+    """MergeSkaArray (merge_ska_array.rs:109-126) on the device."""
+
+    def __init__(self, handle, ctx):
+        self.h, self.ctx = handle, ctx
+
+    @classmethod
+    def build(cls, inputs, k=31, rc=True, q=None, threads=1, proportion_reads=0.0, ctx=None):
+        """inputs: list of (name, file1, file2|None): build_and_merge + MergeSkaArray::new."""
+        ctx = ctx or default_context()
+        q = q or qual()
+        n = len(inputs)
+        names = (C.c_char_p * n)(*[x[0].encode() for x in inputs])
+        f1 = (C.c_char_p * n)(*[x[1].encode() for x in inputs])
+        f2 = (C.c_char_p * n)(*[(x[2].encode() if x[2] else None) for x in inputs])
+        h = C.c_void_p()
+        _check(_lib.skx_build_and_merge(ctx.h, names, f1, f2, n, k, int(rc), C.byref(q), threads, proportion_reads, C.byref(h)))
+        return cls(h, ctx)
+
+    @classmethod
+    def load(cls, path, want_bits=0, ctx=None):
+        ctx = ctx or default_context()
+        h = C.c_void_p()
+        if want_bits:
+            _check(_lib.skx_array_load(ctx.h, path.encode(), want_bits, C.byref(h)))
+        else:
+            p = (C.c_char_p * 1)(path.encode())
+            _check(_lib.skh_load_array(ctx.h, p, 1, 1, C.byref(h)))
+        return cls(h, ctx)
+
+    @classmethod
+    def from_host(cls, k, rc, names, keys, variants, version=None, ctx=None):
+        ctx = ctx or default_context()
+        keys = np.ascontiguousarray(keys, dtype=KEY_DT)
+        variants = np.ascontiguousarray(variants, dtype=np.uint8)
+        n = len(names)
+        nm = (C.c_char_p * n)(*[x.encode() for x in names])
+        h = C.c_void_p()
+        _check(_lib.skx_array_from_host(ctx.h, k, int(rc), nm, n, _np_ptr(keys), _np_ptr(variants), len(keys),
+                                        version.encode() if version else None, C.byref(h)))
+        return cls(h, ctx)
+
+    def save(self, path):
+        _check(_lib.skx_array_save(self.h, path.encode()))
+
+    def save_skf(self, prefix):
+        _check(_lib.skh_save_skf(self.h, prefix.encode()))
+
+    def _info(self):
+        info = ArrayInfo()
+        _check(_lib.skx_array_info(self.h, C.byref(info)))
+        return info
+
+    k = property(lambda s: s._info().k)
+    rc = property(lambda s: bool(s._info().rc))
+    k_bits = property(lambda s: s._info().k_bits)
+    nrows = property(lambda s: s._info().n_rows)
+    nkmers = property(lambda s: s._info().n_kmers)
+    nsamples = property(lambda s: s._info().n_samples)
+    version = property(lambda s: _lib.skx_array_version(s.h).decode())
+
+    @property
+    def names(self):
+        return [_lib.skx_array_name(self.h, i).decode() for i in range(self.nsamples)]
+
+    def export(self):
+        info = self._info()
+        keys = np.zeros(info.n_kmers, KEY_DT)
+        var = np.zeros((info.n_rows, info.n_samples), np.uint8)
+        counts = np.zeros(info.n_rows, np.uint64)
+        _check(_lib.skx_array_export(self.h, _np_ptr(keys), _np_ptr(var), _np_ptr(counts)))
+        return keys, var, counts
+
+    def sample_kmers(self):
+        out = np.zeros(self.nsamples, np.int64)
+        _check(_lib.skx_array_sample_kmers(self.h, _np_ptr(out)))
+        return out
+
+    def filter(self, min_count, filter_ambig_as_missing=False, filter_type=FILTER_NO_CONST, mask_ambig=False,
+               ignore_const_gaps=False, update_kmers=True):
+        r = C.c_int32()
+        _check(_lib.skx_array_filter(self.h, min_count, int(filter_ambig_as_missing), filter_type, int(mask_ambig),
+                                     int(ignore_const_gaps), int(update_kmers), C.byref(r)))
+        return r.value
+
+    def apply_filters(self, min_freq, filter_ambig_as_missing=False, filter_type=FILTER_NO_CONST, ambig_mask=False,
+                      ignore_const_gaps=False):
+        r = C.c_int32()
+        _check(_lib.skh_apply_filters(self.h, min_freq, int(filter_ambig_as_missing), filter_type, int(ambig_mask),
+                                      int(ignore_const_gaps), C.byref(r)))
+        return r.value
+
+    def fasta(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        _check(_lib.skx_array_fasta(self.h, C.byref(p), C.byref(n)))
+        return _take(p, n)
+
+    def device_matrix(self):
+        p, pitch, rows = C.c_void_p(), C.c_uint64(), C.c_uint64()
+        _check(_lib.skx_array_device_matrix(self.h, C.byref(p), C.byref(pitch), C.byref(rows)))
+        return p.value, pitch.value, rows.value
+
+    def nk(self, full_info=False):
+        p, n = C.c_void_p(), C.c_uint64()
+        _check(_lib.skh_nk(self.h, int(full_info), C.byref(p), C.byref(n)))
+        return _take(p, n)
+
+    def distance(self, constant=0.0, filt_ambig=True):
+        s = self.nsamples
+        out = np.zeros(s * (s - 1) // 2, DIST_DT)
+        _check(_lib.skx_array_distance(self.h, constant, int(filt_ambig), _np_ptr(out)))
+        return out
+
+    def distance_tsv(self, min_freq=0.0, filt_ambig=True):
+        p, n = C.c_void_p(), C.c_uint64()
+        _check(_lib.skh_distance_tsv(self.h, min_freq, int(filt_ambig), C.byref(p), C.byref(n)))
+        return _take(p, n)
+
+    def align(self, filter_type=FILTER_NO_CONST, mask_ambig=False, ignore_const_gaps=False, min_freq=0.9,
+              filter_ambig_as_missing=False):
+        p, n = C.c_void_p(), C.c_uint64()
+        _check(_lib.skh_align(self.h, filter_type, int(mask_ambig), int(ignore_const_gaps), min_freq,
+                              int(filter_ambig_as_missing), C.byref(p), C.byref(n)))
+        return _take(p, n)
+
+    def free(self):
+        if getattr(self, "h", None):
+            _lib.skx_array_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.free()

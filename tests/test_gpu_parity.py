@@ -1,0 +1,193 @@
+"""Differential parity: HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs (`-m gpu`).
+Bit-exact: integer split k-mers, byte middle bases, integer counts; distances compared as printed."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_cases as G
+import ora
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    import skx_engine as eng
+    eng.load_library()
+    eng.default_context()
+    return eng
+
+
+def rand_records(rng, n_rec, max_len, alphabet=b"ACGT", p_bad=0.0, lower=False):
+    recs = []
+    for _ in range(n_rec):
+        L = int(rng.integers(0, max_len + 1))
+        s = rng.choice(np.frombuffer(alphabet, dtype=np.uint8), size=L)
+        if p_bad > 0 and L:
+            bad = rng.random(L) < p_bad
+            s = np.where(bad, rng.choice(np.frombuffer(b"NnRYKM-.*", dtype=np.uint8), size=L), s)
+        if lower and L:
+            s = np.where(rng.random(L) < 0.2, s | 0x20, s)
+        recs.append(s.astype(np.uint8).tobytes())
+    return recs
+
+
+def oracle_dict(recs, k, rc):
+    d = ora.Dict.new(k, rc)
+    for r in recs:
+        d.add_record(r)
+    return d
+
+
+def check_dicts(E, samples, k, rc):
+    ds = E.DictSet.build([E.record_stream(r) for r in samples], k, rc)
+    for i, recs in enumerate(samples):
+        ok, ob = oracle_dict(recs, k, rc).export()
+        gk, gb = ds.export(i)
+        assert len(gk) == len(ok), (k, rc, i, len(gk), len(ok))
+        assert np.array_equal(gk["lo"], ok["lo"]) and np.array_equal(gk["hi"], ok["hi"])
+        assert np.array_equal(gb, ob)
+    return ds
+
+
+@pytest.mark.parametrize("k", [5, 7, 9, 15, 17, 21, 31])
+@pytest.mark.parametrize("rc", [True, False])
+def test_dict_random(E, k, rc):
+    rng = np.random.default_rng(100 + k)
+    samples = [rand_records(rng, 6, 3000) + [b"ACGT" * 3] for _ in range(3)]
+    check_dicts(E, samples, k, rc)
+
+
+@pytest.mark.parametrize("k", [7, 15, 31])
+def test_dict_adversarial(E, k):
+    """N runs, IUPAC letters, '-', lowercase, records of length k-1 / k / k+1, clean runs of exactly k at the
+    record end (split_kmer.rs:89 quirk), homopolymers (palindromes when rc) and tile-boundary straddlers."""
+    rng = np.random.default_rng(7 * k)
+    base = rand_records(rng, 4, 9000, p_bad=0.01, lower=True)
+    core = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=k + 1).tolist())
+    edge = [core[:k - 1], core[:k], core[:k + 1], b"N" + core[:k], core[:k] + b"N", core[:k] + b"N" + core[:k],
+            core[:k + 1] + b"N" + core[:k + 1], b"A" * (3 * k), b"AT" * (2 * k), b"ACGT" * k, b"", b"N" * 50,
+            b"acgtn" * 20, bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=4096 - k // 2).tolist()),
+            bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=8200).tolist())]
+    for rc in (True, False):
+        check_dicts(E, [base + edge, edge + base, [core[:k + 1]]], k, rc)
+
+
+def test_dict_larger_genome(E):
+    """~300 kbp related samples: many tiles and buckets, exercises cross-tile halos."""
+    import synth
+    anc = synth.ancestor(300_000, seed=3)
+    streams = [synth.sample_stream(anc, i, 4, private_snps=40, shared_snps=10, seed=3) for i in range(4)]
+    ds = E.DictSet.build([s.tobytes() for s in streams], 31, True)
+    for i, s in enumerate(streams):
+        recs = s.tobytes().split(b"\n")[:-1]
+        ok, ob = oracle_dict(recs, 31, True).export()
+        gk, gb = ds.export(i)
+        assert np.array_equal(gk["lo"], ok["lo"]) and np.array_equal(gb, ob)
+
+
+def as_map(keys, var, counts):
+    return {(int(k["hi"]) << 64) | int(k["lo"]): (bytes(v), int(c)) for k, v, c in zip(keys, var, counts)}
+
+
+def build_both(E, samples, k, rc):
+    names = [f"s{i}" for i in range(len(samples))]
+    ds = E.DictSet.build([E.record_stream(r) for r in samples], k, rc)
+    ga = ds.merge(names)
+    oa = ora.Array.from_dicts([oracle_dict(r, k, rc) for r in samples], names)
+    return ga, oa
+
+
+@pytest.mark.parametrize("k,rc", [(9, True), (15, False), (31, True)])
+def test_merge_array(E, k, rc):
+    rng = np.random.default_rng(k)
+    anc = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=5000).tolist())
+    samples = []
+    for i in range(7):
+        s = bytearray(anc)
+        for p in rng.integers(0, len(s), size=25):
+            s[p] = b"ACGT"[rng.integers(0, 4)]
+        samples.append([bytes(s[:2500]), bytes(s[2500:])] + rand_records(rng, 1, 300))
+    ga, oa = build_both(E, samples, k, rc)
+    assert ga.names == oa.names and ga.nkmers == oa.nkmers
+    assert as_map(*ga.export()) == as_map(*oa.export())
+    assert list(ga.sample_kmers()) == [int(x) for x in (oa.export()[1] != ord("-")).sum(axis=0)]
+
+
+FILTERS = [(ft, amb, mask, gaps) for ft in range(4) for amb in (False, True) for mask in (False, True) for gaps in (False, True)]
+
+
+@pytest.mark.parametrize("min_freq", [0.0, 0.5, 0.9, 1.0])
+def test_filter_and_align(E, min_freq):
+    rng = np.random.default_rng(5)
+    anc = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=3000).tolist())
+    samples = []
+    for i in range(6):
+        s = bytearray(anc)
+        for p in rng.integers(0, len(s), size=30):
+            s[p] = b"ACGT"[rng.integers(0, 4)]
+        if i % 2:
+            s = s[:2000]           # missing k-mers
+        samples.append([bytes(s), bytes(s[100:400])])   # repeats -> ambiguity codes
+    for ft, amb, mask, gaps in FILTERS:
+        ga, oa = build_both(E, samples, 9, True)
+        g = ga.align(filter_type=ft, mask_ambig=mask, ignore_const_gaps=gaps, min_freq=min_freq, filter_ambig_as_missing=amb)
+        o = oa.align(filter_type=ft, mask_ambig=mask, ignore_const_gaps=gaps, min_freq=min_freq, filter_ambig_as_missing=amb)
+        assert G.aln_length(g) == G.aln_length(o), (ft, amb, mask, gaps)
+        assert sorted(zip(*[l for l in g.decode().splitlines()[1::2]])) == sorted(zip(*[l for l in o.decode().splitlines()[1::2]]))
+    # removed-row counts of MergeSkaArray::filter
+    for ft, amb, mask, gaps in FILTERS[::3]:
+        ga, oa = build_both(E, samples, 9, True)
+        assert ga.filter(3, amb, ft, mask, gaps, True) == oa.filter(3, amb, ft, mask, gaps, True)
+        assert as_map(*ga.export()) == as_map(*oa.export())
+
+
+@pytest.mark.parametrize("filt_ambig", [True, False])
+def test_distance(E, filt_ambig):
+    rng = np.random.default_rng(11)
+    anc = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=4000).tolist())
+    samples = []
+    for i in range(9):
+        s = bytearray(anc)
+        for p in rng.integers(0, len(s), size=40):
+            s[p] = b"ACGT"[rng.integers(0, 4)]
+        samples.append([bytes(s[: 4000 - 150 * i]), bytes(s[50:500])])
+    ga, oa = build_both(E, samples, 9, True)
+    for mf in (0.0, 0.6):
+        ga, oa = build_both(E, samples, 9, True)
+        assert ga.distance_tsv(min_freq=mf, filt_ambig=filt_ambig) == oa.distance_tsv(min_freq=mf, filt_ambig=filt_ambig)
+
+
+def test_skf_written_by_engine_is_read_by_oracle(E, tmp_path):
+    a = E.Array.build(G.fasta_inputs(E, [G.fin("test_1.fa"), G.fin("test_2.fa")]), k=17)
+    p = str(tmp_path / "e.skf")
+    a.save(p)
+    o = ora.Array.load(p)
+    ref = ora.Array.load(G.fin("merge.skf"))
+    assert as_map(*o.export()) == as_map(*ref.export()) and o.names == ref.names
+
+
+def test_keyset_exchange_equals_single_merge(E):
+    """Section 8e: union of per-shard key tables, then per-shard assemble == one merge of everything."""
+    rng = np.random.default_rng(2)
+    anc = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=6000).tolist())
+    samples = []
+    for i in range(6):
+        s = bytearray(anc)
+        for p in rng.integers(0, len(s), size=20):
+            s[p] = b"ACGT"[rng.integers(0, 4)]
+        samples.append([bytes(s)])
+    names = [f"s{i}" for i in range(6)]
+    whole = E.DictSet.build([E.record_stream(r) for r in samples], 15, True).merge(names)
+    shards = [E.DictSet.build([E.record_stream(r) for r in samples[a:b]], 15, True) for a, b in ((0, 2), (2, 6))]
+    keysets = [s.union_keys() for s in shards]
+    rows = E.KeySet.merge(keysets)
+    assert len(rows) == whole.nkmers
+    wk, wv, _ = whole.export()
+    col = 0
+    for s, (a, b) in zip(shards, ((0, 2), (2, 6))):
+        part = s.assemble(rows, names[a:b])
+        pk, pv, _ = part.export()
+        assert np.array_equal(pk["lo"], wk["lo"]) and np.array_equal(pv, wv[:, a:b])
+        col += b - a
