@@ -117,8 +117,8 @@ int  skx_array_save(skx_array *a, const char *path);
 int  skx_array_load(skx_ctx *ctx, const char *path, int want_bits, skx_array **out);
 /* construct from host data (row-major [n_rows, n_samples] as in the .skf) */
 int  skx_array_from_host(skx_ctx *ctx, int k, int rc, const char *const *names, int n_samples,
-                         const skx_key *keys, const uint8_t *variants, uint64_t n_rows, const char *version,
-                         skx_array **out);
+                         const skx_key *keys, const uint8_t *variants, const uint64_t *variant_count /* NULL: recount */,
+                         uint64_t n_rows, const char *version, skx_array **out);
 typedef struct {
     int32_t  k, rc, k_bits;
     uint64_t n_kmers;      /* split_kmers.len() */
@@ -141,6 +141,12 @@ int  skx_array_write_fasta(skx_array *a, int fd);
 int  skx_array_fasta(skx_array *a, char **buf, uint64_t *len);
 /* device view of the sample-major middle-base matrix: row s = sample s, pitch bytes apart */
 int  skx_array_device_matrix(skx_array *a, const uint8_t **dptr, uint64_t *pitch, uint64_t *n_rows);
+
+/* multi-GPU column slabs: device views of the per-row statistics the filter reads
+ * (cells != '-', cells in ACGT, set of IUPAC codes present, stored variant_count; u32 each, n_rows long) so that
+ * the host can reduce them across ranks, and the global sample count the gap test must use */
+int  skx_array_device_stats(skx_array *a, uint32_t **present, uint32_t **unambig, uint32_t **mask, uint32_t **variant_count);
+int  skx_array_set_total_samples(skx_array *a, uint64_t total_samples);
 
 typedef struct { double distance, mismatch_prop; uint64_t match_count, mismatch_count; } skx_dist;
 /* MergeSkaArray::distance (merge_ska_array.rs:416-438,587-632): upper triangle, pairs (i<j) row-major */

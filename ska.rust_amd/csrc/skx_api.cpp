@@ -28,9 +28,20 @@ extern "C" const char *skx_last_error(void) { return g_err; }
 extern "C" const char *skx_version(void) { return "0.5.2"; }      // Cargo.toml:3, written as ska_version
 extern "C" void skx_free(void *p) { free(p); }
 
+// nothing may unwind across the C boundary
+template <typename F>
+static int skx_guarded(F &&f) noexcept
+{
+    try { return f(); }
+    catch (const std::bad_alloc &) { set_error("out of host memory"); return SKX_ENOMEM; }
+    catch (const std::exception &e) { set_error("internal error: %s", e.what()); return SKX_EINVAL; }
+    catch (...) { set_error("internal error"); return SKX_EINVAL; }
+}
+
 // ------------------------------------------------------------------------------------------ ctx
 extern "C" int skx_ctx_create(int device, skx_ctx **out)
 {
+    return skx_guarded([&]() -> int {
     if (!out) { set_error("null out"); return SKX_EINVAL; }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -45,6 +56,7 @@ extern "C" int skx_ctx_create(int device, skx_ctx **out)
     }
     *out = c;
     return SKX_OK;
+    });
 }
 extern "C" void skx_ctx_destroy(skx_ctx *c)
 {
@@ -57,9 +69,11 @@ extern "C" int skx_ctx_sync(skx_ctx *c) { SKX_HIP(hipSetDevice(c->device)); SKX_
 extern "C" void *skx_ctx_stream(skx_ctx *c) { return (void *)c->stream; }
 extern "C" int skx_ctx_timings(skx_ctx *c, skx_timings *t, int reset)
 {
+    return skx_guarded([&]() -> int {
     if (t) *t = c->tm;
     if (reset) c->tm = skx_timings{};
     return SKX_OK;
+    });
 }
 
 namespace {
@@ -156,6 +170,7 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
 
 extern "C" int skx_dictset_build(skx_ctx *ctx, const skx_stream *samples, int n, int on_device, int k, int rc, const skx_qual *q, skx_dictset **out)
 {
+    return skx_guarded([&]() -> int {
     if (!ctx || !samples || n <= 0 || !out) { set_error("bad arguments"); return SKX_EINVAL; }
     SKX_TRY(check_k(k));
     SKX_HIP(hipSetDevice(ctx->device));
@@ -187,11 +202,13 @@ extern "C" int skx_dictset_build(skx_ctx *ctx, const skx_stream *samples, int n,
         if (d->sample_size[s] == 0) { set_error("sample %d has no valid sequence", s); delete d; return SKX_EEMPTY; }
     *out = d;
     return SKX_OK;
+    });
 }
 
 extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, const char *const *file2, int n, int k, int rc,
                                        const skx_qual *q, int threads, double proportion_reads, skx_dictset **out)
 {
+    return skx_guarded([&]() -> int {
     if (!ctx || !file1 || n <= 0 || !out) { set_error("bad arguments"); return SKX_EINVAL; }
     SKX_TRY(check_k(k));
     std::vector<HostStream> hs(n);
@@ -219,17 +236,21 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
     if (r != SKX_OK) return r;
     *out = d;
     return SKX_OK;
+    });
 }
 
 extern "C" int skx_dictset_size(skx_dictset *d, int sample, uint64_t *n)
 {
+    return skx_guarded([&]() -> int {
     if (!d || sample < 0 || sample >= d->n) { set_error("bad sample index"); return SKX_EINVAL; }
     *n = d->sample_size[sample];
     return SKX_OK;
+    });
 }
 
 extern "C" int skx_dictset_export(skx_dictset *d, int sample, skx_key *keys, uint8_t *bases, uint64_t cap)
 {
+    return skx_guarded([&]() -> int {
     if (!d || sample < 0 || sample >= d->n) { set_error("bad sample index"); return SKX_EINVAL; }
     skx_ctx *ctx = d->ctx; hipStream_t st = ctx->stream;
     SKX_HIP(hipSetDevice(ctx->device));
@@ -251,6 +272,7 @@ extern "C" int skx_dictset_export(skx_dictset *d, int sample, skx_key *keys, uin
     std::sort(idx.begin(), idx.end(), [&](uint64_t a, uint64_t b2) { return hk[a] < hk[b2]; });
     for (uint64_t i = 0; i < sz; i++) { if (keys) { keys[i].lo = hk[idx[i]]; keys[i].hi = 0; } if (bases) bases[i] = hb[idx[i]]; }
     return SKX_OK;
+    });
 }
 
 // ------------------------------------------------------------------------------------------ keyset
@@ -306,6 +328,7 @@ static int keyset_union_views(skx_ctx *ctx, const DictView *views, int nviews, i
 
 extern "C" int skx_keyset_union(skx_ctx *ctx, skx_dictset *d, skx_keyset **out)
 {
+    return skx_guarded([&]() -> int {
     if (!ctx || !d || !out) { set_error("bad arguments"); return SKX_EINVAL; }
     SKX_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -329,6 +352,7 @@ extern "C" int skx_keyset_union(skx_ctx *ctx, skx_dictset *d, skx_keyset **out)
         else est = sum;
     }
     return keyset_union_views(ctx, &v, 1, d->k, d->rc, d->hp, est, out);
+    });
 }
 
 static int keyset_flatten(skx_keyset *ks)
@@ -341,11 +365,13 @@ static int keyset_flatten(skx_keyset *ks)
 
 extern "C" int skx_keyset_device(skx_keyset *ks, const void **dptr, uint64_t *n_keys, int *words_per_key)
 {
+    return skx_guarded([&]() -> int {
     SKX_HIP(hipSetDevice(ks->ctx->device));
     SKX_TRY(keyset_flatten(ks));
     SKX_HIP(hipStreamSynchronize(ks->ctx->stream));
     *dptr = ks->flat.p; *n_keys = ks->total; if (words_per_key) *words_per_key = 1;
     return SKX_OK;
+    });
 }
 
 // a flat sorted word list viewed as a one-sample, one-bucket dict
@@ -360,17 +386,20 @@ static int keyset_from_flat(skx_ctx *ctx, DevBuf<uint64_t> &&flat, uint64_t n, i
 
 extern "C" int skx_keyset_from_device(skx_ctx *ctx, const void *dptr, uint64_t n_keys, int k, int rc, skx_keyset **out)
 {
+    return skx_guarded([&]() -> int {
     SKX_TRY(check_k(k));
     if (k > 31) { set_error("k > 31 not available on the device path yet"); return SKX_EUNSUP; }
     SKX_HIP(hipSetDevice(ctx->device));
     DevBuf<uint64_t> flat; SKX_TRY(flat.alloc(n_keys));
     SKX_HIP(hipMemcpyAsync(flat.p, dptr, n_keys * 8, hipMemcpyDeviceToDevice, ctx->stream));
     return keyset_from_flat(ctx, std::move(flat), n_keys, k, rc, out);
+    });
 }
 
 // union of several keysets: each flat list is a "sample" of a synthetic one-bucket dict
 extern "C" int skx_keyset_merge(skx_ctx *ctx, skx_keyset *const *sets, int n_sets, skx_keyset **out)
 {
+    return skx_guarded([&]() -> int {
     if (!ctx || !sets || n_sets <= 0 || !out) { set_error("bad arguments"); return SKX_EINVAL; }
     SKX_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -397,6 +426,7 @@ extern "C" int skx_keyset_merge(skx_ctx *ctx, skx_keyset *const *sets, int n_set
     int r = keyset_union_views(ctx, &v, 1, sets[0]->k, sets[0]->rc, hp, std::min(total, maxn * 2), out);
     SKX_HIP(hipStreamSynchronize(st));
     return r;
+    });
 }
 
 // ------------------------------------------------------------------------------------------ array
@@ -405,14 +435,17 @@ extern "C" const char *skx_array_name(const skx_array *a, uint64_t i) { return i
 extern "C" const char *skx_array_version(const skx_array *a) { return a->version.c_str(); }
 extern "C" int skx_array_info(const skx_array *a, skx_array_info_t *info)
 {
+    return skx_guarded([&]() -> int {
     info->k = a->k; info->rc = a->rc; info->k_bits = a->k_bits; info->n_kmers = a->n_kmers; info->n_rows = a->n_rows;
     info->n_samples = a->names.size();
     return SKX_OK;
+    });
 }
 static uint64_t pitch_for(uint64_t cols) { return ((cols + 255) / 256) * 256 + 256; }
 
 extern "C" int skx_array_assemble(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows, const char *const *names, skx_array **out)
 {
+    return skx_guarded([&]() -> int {
     if (!ctx || !d || !rows || !out) { set_error("bad arguments"); return SKX_EINVAL; }
     if (rows->k != d->k) { set_error("K-mer lengths do not match: %d %d", d->k, rows->k); return SKX_EINVAL; }      // merge_ska_dict.rs:78-84
     if (rows->rc != d->rc) { set_error("Strand use inconsistent"); return SKX_EINVAL; }                              // :85-87
@@ -446,7 +479,7 @@ extern "C" int skx_array_assemble(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows
     const uint64_t U = rows->total;
     a->n_rows = a->n_kmers = U; a->pitch = pitch_for(U); a->engine_order = true;
     SKX_TRY(a->matrix.alloc((uint64_t)d->n * a->pitch));
-    SKX_TRY(a->present.alloc(U)); SKX_TRY(a->unambig.alloc(U)); SKX_TRY(a->mask.alloc(U)); SKX_TRY(a->keys.alloc(U));
+    SKX_TRY(a->present.alloc(U)); SKX_TRY(a->unambig.alloc(U)); SKX_TRY(a->mask.alloc(U)); SKX_TRY(a->keys.alloc(U)); SKX_TRY(a->vcount.alloc(U));
     DevBuf<int> d_flag; SKX_TRY(d_flag.alloc(1)); SKX_TRY(d_flag.zero(st));
     if (U) {
         AssembleArgs aa{};
@@ -455,6 +488,7 @@ extern "C" int skx_array_assemble(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows
         aa.max_rows = rows->max_rows; aa.missing = d_flag.p;
         launch_assemble(aa, st);
         launch_gather_keys(rows->stage.p, rows->stride, rows->ncnt.p, rows->roff.p, 1 << rows->logN, a->keys.p, 0, rows->hp, st);
+        SKX_HIP(hipMemcpyAsync(a->vcount.p, a->present.p, U * 4, hipMemcpyDeviceToDevice, st));     // merge_ska_array.rs:172
     }
     int missing = 0;
     SKX_HIP(hipMemcpyAsync(&missing, d_flag.p, 4, hipMemcpyDeviceToHost, st));
@@ -463,36 +497,54 @@ extern "C" int skx_array_assemble(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows
     if (missing) { set_error("row keyset does not contain every split k-mer of the samples"); return SKX_EINVAL; }
     *out = a.release();
     return SKX_OK;
+    });
 }
 
 extern "C" int skx_merge(skx_ctx *ctx, skx_dictset *d, const char *const *names, skx_array **out)
 {
+    return skx_guarded([&]() -> int {
     skx_keyset *ks = nullptr;
     SKX_TRY(skx_keyset_union(ctx, d, &ks));
     int r = skx_array_assemble(ctx, d, ks, names, out);
     skx_keyset_free(ks);
     return r;
+    });
 }
 
 extern "C" int skx_build_and_merge(skx_ctx *ctx, const char *const *names, const char *const *file1, const char *const *file2, int n,
                                    int k, int rc, const skx_qual *q, int threads, double proportion_reads, skx_array **out)
 {
+    return skx_guarded([&]() -> int {
     skx_dictset *d = nullptr;
     SKX_TRY(skx_dictset_build_files(ctx, file1, file2, n, k, rc, q, threads, proportion_reads, &d));
     int r = skx_merge(ctx, d, names, out);
     skx_dictset_free(d);
     return r;
+    });
 }
 
 extern "C" int skx_array_device_matrix(skx_array *a, const uint8_t **dptr, uint64_t *pitch, uint64_t *n_rows)
 {
+    return skx_guarded([&]() -> int {
     *dptr = a->matrix.p; *pitch = a->pitch; *n_rows = a->n_rows;
     return SKX_OK;
+    });
 }
 
-extern "C" int skx_array_from_host(skx_ctx *ctx, int k, int rc, const char *const *names, int n_samples, const skx_key *keys,
-                                   const uint8_t *variants, uint64_t n_rows, const char *version, skx_array **out)
+extern "C" int skx_array_device_stats(skx_array *a, uint32_t **present, uint32_t **unambig, uint32_t **mask, uint32_t **variant_count)
 {
+    if (present) *present = a->present.p;
+    if (unambig) *unambig = a->unambig.p;
+    if (mask) *mask = a->mask.p;
+    if (variant_count) *variant_count = a->vcount.p;
+    return SKX_OK;
+}
+extern "C" int skx_array_set_total_samples(skx_array *a, uint64_t total) { a->total_samples = total; return SKX_OK; }
+
+extern "C" int skx_array_from_host(skx_ctx *ctx, int k, int rc, const char *const *names, int n_samples, const skx_key *keys,
+                                   const uint8_t *variants, const uint64_t *variant_count, uint64_t n_rows, const char *version, skx_array **out)
+{
+    return skx_guarded([&]() -> int {
     if (!ctx || !out || n_samples <= 0) { set_error("bad arguments"); return SKX_EINVAL; }
     SKX_TRY(check_k(k));
     SKX_HIP(hipSetDevice(ctx->device));
@@ -503,7 +555,7 @@ extern "C" int skx_array_from_host(skx_ctx *ctx, int k, int rc, const char *cons
     for (int i = 0; i < n_samples; i++) a->names.emplace_back(names[i]);
     a->n_rows = a->n_kmers = n_rows; a->pitch = pitch_for(n_rows); a->engine_order = false;
     SKX_TRY(a->matrix.alloc((uint64_t)n_samples * a->pitch));
-    SKX_TRY(a->present.alloc(n_rows)); SKX_TRY(a->unambig.alloc(n_rows)); SKX_TRY(a->mask.alloc(n_rows));
+    SKX_TRY(a->present.alloc(n_rows)); SKX_TRY(a->unambig.alloc(n_rows)); SKX_TRY(a->mask.alloc(n_rows)); SKX_TRY(a->vcount.alloc(n_rows));
     if (k <= 31) {
         SKX_TRY(a->keys.alloc(n_rows));
         std::vector<uint64_t> lo(n_rows);
@@ -522,6 +574,12 @@ extern "C" int skx_array_from_host(skx_ctx *ctx, int k, int rc, const char *cons
         SKX_HIP(hipMemsetAsync(a->matrix.p, '-', (uint64_t)n_samples * a->pitch, st));
         launch_transpose(rm.p, (uint64_t)n_samples, n_rows, (uint64_t)n_samples, a->matrix.p, a->pitch, st);
         launch_col_stats(a->matrix.p, a->pitch, n_samples, n_rows, a->present.p, a->unambig.p, a->mask.p, d_bad.p, st);
+        if (variant_count) {
+            std::vector<uint32_t> vc(n_rows);
+            for (uint64_t i = 0; i < n_rows; i++) vc[i] = (uint32_t)variant_count[i];
+            SKX_HIP(hipMemcpyAsync(a->vcount.p, vc.data(), n_rows * 4, hipMemcpyHostToDevice, st));
+            SKX_HIP(hipStreamSynchronize(st));
+        } else SKX_HIP(hipMemcpyAsync(a->vcount.p, a->present.p, n_rows * 4, hipMemcpyDeviceToDevice, st));
         SKX_HIP(hipStreamSynchronize(st));
     }
     int bad = 0;
@@ -530,10 +588,12 @@ extern "C" int skx_array_from_host(skx_ctx *ctx, int k, int rc, const char *cons
     if (bad) { set_error("variants contain a byte outside -ACGTMRWSYKVHDBN (not supported on the device path)"); return SKX_EUNSUP; }
     *out = a.release();
     return SKX_OK;
+    });
 }
 
 extern "C" int skx_array_export(skx_array *a, skx_key *keys, uint8_t *variants, uint64_t *counts)
 {
+    return skx_guarded([&]() -> int {
     skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
     SKX_HIP(hipSetDevice(ctx->device));
     const uint64_t U = a->n_rows, S = a->names.size(), K = a->n_kmers;
@@ -549,7 +609,7 @@ extern "C" int skx_array_export(skx_array *a, skx_key *keys, uint8_t *variants, 
         DevBuf<uint8_t> d_rm; SKX_TRY(d_rm.alloc(U * S));
         launch_transpose(a->matrix.p, a->pitch, S, U, d_rm.p, S, st);
         SKX_HIP(hipMemcpyAsync(rm.data(), d_rm.p, U * S, hipMemcpyDeviceToHost, st));
-        SKX_HIP(hipMemcpyAsync(pres.data(), a->present.p, U * 4, hipMemcpyDeviceToHost, st));
+        SKX_HIP(hipMemcpyAsync(pres.data(), a->vcount.p, U * 4, hipMemcpyDeviceToHost, st));
         SKX_HIP(hipStreamSynchronize(st));
     }
     // rows sorted by key when keys and rows are in step; otherwise stored order
@@ -560,10 +620,12 @@ extern "C" int skx_array_export(skx_array *a, skx_key *keys, uint8_t *variants, 
     if (variants) for (uint64_t i = 0; i < U; i++) memcpy(variants + i * S, rm.data() + idx[i] * S, S);
     if (counts) for (uint64_t i = 0; i < U; i++) counts[i] = pres[idx[i]];
     return SKX_OK;
+    });
 }
 
 extern "C" int skx_array_sample_kmers(skx_array *a, int64_t *out)
 {
+    return skx_guarded([&]() -> int {
     skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
     SKX_HIP(hipSetDevice(ctx->device));
     const size_t S = a->names.size();
@@ -574,11 +636,13 @@ extern "C" int skx_array_sample_kmers(skx_array *a, int64_t *out)
     SKX_HIP(hipStreamSynchronize(st));
     for (size_t i = 0; i < S; i++) out[i] = (int64_t)h[i];
     return SKX_OK;
+    });
 }
 
 extern "C" int skx_array_filter(skx_array *a, uint64_t min_count, int filter_ambig_as_missing, int filter_type, int mask_ambig,
                                 int ignore_const_gaps, int update_kmers, int32_t *removed)
 {
+    return skx_guarded([&]() -> int {
     skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
     SKX_HIP(hipSetDevice(ctx->device));
     const uint64_t U = a->n_rows; const size_t S = a->names.size();
@@ -587,7 +651,7 @@ extern "C" int skx_array_filter(skx_array *a, uint64_t min_count, int filter_amb
     uint64_t kept = 0, silent = 0;
     {
         StageTimer t(ctx, &ctx->tm.filter);
-        FilterArgs fa{a->present.p, a->unambig.p, a->mask.p, U, (uint32_t)S, min_count, filter_ambig_as_missing, filter_type, ignore_const_gaps, keep.p};
+        FilterArgs fa{a->vcount.p, a->present.p, a->unambig.p, a->mask.p, U, (uint32_t)(a->total_samples ? a->total_samples : S), min_count, filter_ambig_as_missing, filter_type, ignore_const_gaps, keep.p};
         launch_filter_flags(fa, st);
         launch_scan_u8(keep.p, pos.p, U, st);
         SKX_HIP(hipMemcpyAsync(&kept, pos.p + U, 8, hipMemcpyDeviceToHost, st));
@@ -604,12 +668,14 @@ extern "C" int skx_array_filter(skx_array *a, uint64_t min_count, int filter_amb
     {
         StageTimer t(ctx, &ctx->tm.compact);
         const uint64_t np = pitch_for(kept);
-        DevBuf<uint8_t> nm; DevBuf<uint32_t> p2, u2, m2;
-        SKX_TRY(nm.alloc((uint64_t)S * np)); SKX_TRY(p2.alloc(kept)); SKX_TRY(u2.alloc(kept)); SKX_TRY(m2.alloc(kept));
+        DevBuf<uint8_t> nm; DevBuf<uint32_t> p2, u2, m2, v2;
+        SKX_TRY(nm.alloc((uint64_t)S * np)); SKX_TRY(p2.alloc(kept)); SKX_TRY(u2.alloc(kept)); SKX_TRY(m2.alloc(kept)); SKX_TRY(v2.alloc(kept));
         launch_compact_matrix(a->matrix.p, a->pitch, nm.p, np, (int)S, U, keep.p, pos.p, mask_ambig, st);
         launch_compact_u32(a->present.p, p2.p, U, keep.p, pos.p, st);
         launch_compact_u32(a->unambig.p, u2.p, U, keep.p, pos.p, st);
         launch_compact_u32(a->mask.p, m2.p, U, keep.p, pos.p, st);
+        // update_counts(true) rewrites variant_count with the unambiguous counts (merge_ska_array.rs:139-163)
+        launch_compact_u32(filter_ambig_as_missing ? a->unambig.p : a->vcount.p, v2.p, U, keep.p, pos.p, st);
         if (mask_ambig) launch_mask_ambig_stats(m2.p, kept, st);
         // update_counts(true) (merge_ska_array.rs:139-163) rewrites counts AND split_kmers whenever it ran
         const bool keys_follow = update_kmers || filter_ambig_as_missing;
@@ -629,16 +695,18 @@ extern "C" int skx_array_filter(skx_array *a, uint64_t min_count, int filter_amb
             a->n_kmers = kept;
         }
         SKX_HIP(hipStreamSynchronize(st));
-        a->matrix = std::move(nm); a->present = std::move(p2); a->unambig = std::move(u2); a->mask = std::move(m2);
+        a->matrix = std::move(nm); a->present = std::move(p2); a->unambig = std::move(u2); a->mask = std::move(m2); a->vcount = std::move(v2);
         a->pitch = np; a->n_rows = kept;
     }
     SKX_HIP(hipGetLastError());
     if (removed) *removed = (int32_t)(U - kept - silent);
     return SKX_OK;
+    });
 }
 
 extern "C" int skx_array_fasta(skx_array *a, char **buf, uint64_t *len)
 {
+    return skx_guarded([&]() -> int {
     skx_ctx *ctx = a->ctx;
     SKX_HIP(hipSetDevice(ctx->device));
     const size_t S = a->names.size(); const uint64_t U = a->n_rows;
@@ -653,15 +721,18 @@ extern "C" int skx_array_fasta(skx_array *a, char **buf, uint64_t *len)
     }
     *p = 0; *buf = out; *len = (uint64_t)(p - out);
     return SKX_OK;
+    });
 }
 extern "C" int skx_array_write_fasta(skx_array *a, int fd)
 {
+    return skx_guarded([&]() -> int {
     char *buf = nullptr; uint64_t len = 0;
     SKX_TRY(skx_array_fasta(a, &buf, &len));
     uint64_t w = 0;
     while (w < len) { ssize_t r = write(fd, buf + w, len - w); if (r <= 0) { free(buf); set_error("write failed"); return SKX_EIO; } w += (uint64_t)r; }
     free(buf);
     return SKX_OK;
+    });
 }
 
 // numerators over 36 of |S1 n S2| / (|S1||S2|) per pair class [2..11] of pair_counts_kernel<false>
@@ -669,6 +740,7 @@ static const int PAIR_CLASS_NUM[10] = {36, 18, 12, 9, 18, 6, 12, 4, 8, 12};
 
 extern "C" int skx_array_distance(skx_array *a, double constant, int filt_ambig, skx_dist *out)
 {
+    return skx_guarded([&]() -> int {
     skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
     SKX_HIP(hipSetDevice(ctx->device));
     const int S = (int)a->names.size(); const uint64_t U = a->n_rows;
@@ -701,20 +773,24 @@ extern "C" int skx_array_distance(skx_array *a, double constant, int filt_ambig,
             out[n].match_count = (uint64_t)matches; out[n].mismatch_count = (uint64_t)mismatches;
         }
     return SKX_OK;
+    });
 }
 
 // ------------------------------------------------------------------------------------------ .skf
 extern "C" int skx_array_save(skx_array *a, const char *path)
 {
+    return skx_guarded([&]() -> int {
     SkfData d;
     d.k = a->k; d.rc = a->rc; d.k_bits = a->k_bits; d.names = a->names; d.version = a->version;
     const uint64_t U = a->n_rows, S = a->names.size();
     d.keys.resize(a->n_kmers); d.variants.resize(U * S); d.counts.resize(U); d.n_rows = U;
     SKX_TRY(skx_array_export(a, d.keys.data(), d.variants.data(), d.counts.data()));
     return skf_write(path, d);
+    });
 }
 extern "C" int skx_array_load(skx_ctx *ctx, const char *path, int want_bits, skx_array **out)
 {
+    return skx_guarded([&]() -> int {
     SkfData d;
     SKX_TRY(skf_read(path, d));
     if (want_bits == 64)       // serde into Vec<u64> fails on wider values; lib.rs:635-661 then retries as u128
@@ -723,8 +799,10 @@ extern "C" int skx_array_load(skx_ctx *ctx, const char *path, int want_bits, skx
     for (auto &s : d.names) names.push_back(s.c_str());
     skx_array *a = nullptr;
     if (d.keys.size() != d.n_rows) { set_error("skf: split_kmers and variants disagree"); return SKX_EFORMAT; }
-    SKX_TRY(skx_array_from_host(ctx, d.k, d.rc, names.data(), (int)names.size(), d.keys.data(), d.variants.data(), d.n_rows, d.version.c_str(), &a));
+    SKX_TRY(skx_array_from_host(ctx, d.k, d.rc, names.data(), (int)names.size(), d.keys.data(), d.variants.data(),
+                                d.counts.size() == d.n_rows ? d.counts.data() : nullptr, d.n_rows, d.version.c_str(), &a));
     a->k_bits = d.k_bits;
     *out = a;
     return SKX_OK;
+    });
 }

@@ -111,7 +111,7 @@ void launch_col_stats(const uint8_t *matrix, uint64_t pitch, int n_samples, uint
                       uint32_t *unambig, uint32_t *mask, int *bad_byte, hipStream_t st);
 // MergeSkaArray::filter row rule -> keep flags (u8)
 struct FilterArgs {
-    const uint32_t *present, *unambig, *mask; uint64_t n_cols; uint32_t n_samples;
+    const uint32_t *vcount, *present, *unambig, *mask; uint64_t n_cols; uint32_t n_samples;
     uint64_t min_count; int ambig_as_missing, filter_type, ignore_const_gaps;
     uint8_t *keep;
 };

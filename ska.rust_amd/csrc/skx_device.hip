@@ -156,7 +156,7 @@ __global__ __launch_bounds__(TILE_THREADS) void extract_kernel(ExtractArgs a)
     uint64_t fwd = prev & ((1ull << (2 * (k - 1))) - 1);    // k-1 bases preceding p0
     uint64_t rev = revcomp2(fwd, k - 1) << 2;
     const bool check_mid = qual && a.qual_filter != 0;
-    const int bshift = a.hp.bits + 4 - a.logB;              // word >> bshift == bucket
+    const int bshift = a.hp.bits - a.logB;                  // (word >> 4) >> bshift == bucket (two steps: bshift + 4 may be 64)
 
     uint64_t wv[16];
     uint32_t vm = 0;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(TILE_THREADS) void extract_kernel(ExtractArgs a)
 #pragma unroll
     for (int j = 0; j < 16; j++)
         if ((vm >> j) & 1u) {
-            uint32_t r = atomicAdd(&s_hist[(uint32_t)(wv[j] >> bshift)], 1u);
+            uint32_t r = atomicAdd(&s_hist[(uint32_t)((wv[j] >> 4) >> bshift)], 1u);
             if (SCATTER) rk[j >> 1] |= r << (16 * (j & 1));
         }
     __syncthreads();
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(TILE_THREADS) void extract_kernel(ExtractArgs a)
 #pragma unroll
     for (int j = 0; j < 16; j++)
         if ((vm >> j) & 1u) {
-            const uint32_t b = (uint32_t)(wv[j] >> bshift);
+            const uint32_t b = (uint32_t)((wv[j] >> 4) >> bshift);
             const uint32_t r = (rk[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
             a.words[off[b] + s_base[b] + r] = wv[j];
         }

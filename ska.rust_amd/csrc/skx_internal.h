@@ -76,10 +76,12 @@ struct skx_array {
     uint64_t n_kmers = 0;            // split_kmers.len()
     uint64_t n_rows = 0;             // variants.nrows()
     uint64_t pitch = 0;
+    uint64_t total_samples = 0;      // samples over all ranks when this array is one column slab (0: names.size())
     bool engine_order = false;       // rows sorted by H(key)
     skx::DevBuf<uint64_t> keys;      // [n_kmers] packed words (H(key)<<4 | 1)
     skx::DevBuf<uint8_t> matrix;     // [n_samples][pitch], sample-major
-    skx::DevBuf<uint32_t> present, unambig, mask;   // per row statistics
+    skx::DevBuf<uint32_t> present, unambig, mask;   // per row statistics of the matrix
+    skx::DevBuf<uint32_t> vcount;                   // variant_count as the reference stores it (merge_ska_array.rs:121)
     // 128-bit keys of arrays loaded from k>31 files are kept on the host (filter/align/distance never touch them)
     std::vector<skx_key> host_keys;
 };

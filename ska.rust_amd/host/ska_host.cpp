@@ -53,6 +53,13 @@ void rust_debug(std::string &o, const std::string &s)
     }
     o += '"';
 }
+template <typename F>
+int skx_guarded(F &&f) noexcept
+{
+    try { return f(); }
+    catch (const std::bad_alloc &) { return SKX_ENOMEM; }
+    catch (...) { return SKX_EINVAL; }
+}
 }  // namespace
 
 extern "C" char *skh_sample_name(const char *path)
@@ -74,22 +81,27 @@ extern "C" char *skh_sample_name(const char *path)
 extern "C" int skh_apply_filters(skx_array *a, double min_freq, int filter_ambig_as_missing, int filter_type, int ambig_mask,
                                  int ignore_const_gaps, int32_t *removed)
 {
+    return skx_guarded([&]() -> int {
     skx_array_info_t info; skx_array_info(a, &info);
     const uint64_t threshold = (uint64_t)std::ceil((double)info.n_samples * min_freq);       // generic_modes.rs:121
     return skx_array_filter(a, threshold, filter_ambig_as_missing, filter_type, ambig_mask, ignore_const_gaps, /*update_kmers=*/0, removed);
+    });
 }
 
 extern "C" int skh_align(skx_array *a, int filter_type, int mask_ambig, int ignore_const_gaps, double min_freq, int filter_ambig_as_missing,
                          char **buf, uint64_t *len)
 {
+    return skx_guarded([&]() -> int {
     int32_t removed = 0;
     int r = skh_apply_filters(a, min_freq, filter_ambig_as_missing, filter_type, mask_ambig, ignore_const_gaps, &removed);
     if (r != SKX_OK) return r;
     return skx_array_fasta(a, buf, len);
+    });
 }
 
 extern "C" int skh_distance_tsv(skx_array *a, double min_freq, int filt_ambig, char **buf, uint64_t *len)
 {
+    return skx_guarded([&]() -> int {
     skx_array_info_t info; skx_array_info(a, &info);
     int32_t removed = 0; int r;
     if (min_freq * (double)info.n_samples >= 1.0)                                             // generic_modes.rs:149-159
@@ -106,10 +118,12 @@ extern "C" int skh_distance_tsv(skx_array *a, double min_freq, int filt_ambig, c
             put(out, "%s\t%s\t%.2f\t%.5f\t%llu\t%llu\n", skx_array_name(a, i), skx_array_name(a, j), d[n].distance, d[n].mismatch_prop,
                 (unsigned long long)d[n].match_count, (unsigned long long)d[n].mismatch_count);
     return to_buf(out, buf, len);
+    });
 }
 
 extern "C" int skh_nk(skx_array *a, int full_info, char **buf, uint64_t *len)
 {
+    return skx_guarded([&]() -> int {
     skx_array_info_t info; skx_array_info(a, &info);
     std::string o;
     put(o, "ska_version=%s\nk=%d\nk_bits=%d\nrc=%s\nk-mers=%llu\nsamples=%llu\n", skx_array_version(a), info.k, info.k_bits,
@@ -140,17 +154,21 @@ extern "C" int skh_nk(skx_array *a, int full_info, char **buf, uint64_t *len)
         o += '\n';
     }
     return to_buf(o, buf, len);
+    });
 }
 
 extern "C" int skh_save_skf(skx_array *a, const char *out_prefix)
 {
+    return skx_guarded([&]() -> int {
     std::string p(out_prefix);
     if (p.size() < 4 || p.compare(p.size() - 4, 4, ".skf") != 0) p += ".skf";           // generic_modes.rs:272-276
     return skx_array_save(a, p.c_str());
+    });
 }
 
 extern "C" int skh_load_array(skx_ctx *ctx, const char *const *inputs, int n_inputs, int threads, skx_array **out)
 {
+    return skx_guarded([&]() -> int {
     if (n_inputs == 1) {                                                                // io_utils.rs:65-75, lib.rs:635-661
         int r = skx_array_load(ctx, inputs[0], 64, out);
         if (r == SKX_OK) return r;
@@ -163,6 +181,7 @@ extern "C" int skh_load_array(skx_ctx *ctx, const char *const *inputs, int n_inp
     int r = skx_build_and_merge(ctx, names.data(), inputs, nullptr, n_inputs, 31, 1, &q, threads, 0.0, out);
     for (auto p : names) free(p);
     return r;
+    });
 }
 
 // ------------------------------------------------------------------------------------------ CLI

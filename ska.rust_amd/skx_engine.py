@@ -51,7 +51,7 @@ skx_dictset_build_files skx_dictset_free skx_dictset_nsamples skx_dictset_key_bi
 skx_keyset_union skx_keyset_size skx_keyset_device skx_keyset_from_device skx_keyset_merge skx_keyset_free
 skx_array_assemble skx_merge skx_build_and_merge skx_array_free skx_array_save skx_array_load skx_array_from_host
 skx_array_info skx_array_name skx_array_version skx_array_export skx_array_sample_kmers skx_array_filter
-skx_array_write_fasta skx_array_fasta skx_array_device_matrix skx_array_distance skx_free skx_ctx_timings
+skx_array_write_fasta skx_array_fasta skx_array_device_matrix skx_array_device_stats skx_array_set_total_samples skx_array_distance skx_free skx_ctx_timings
 skh_apply_filters skh_align skh_distance_tsv skh_nk skh_save_skf skh_load_array skh_sample_name skh_main""".split()
 
 _lib = None
@@ -95,7 +95,7 @@ def load_library():
     lib.skx_array_free.argtypes = [vp]
     lib.skx_array_save.argtypes = [vp, cp]
     lib.skx_array_load.argtypes = [vp, cp, i, pp]
-    lib.skx_array_from_host.argtypes = [vp, i, i, C.POINTER(cp), i, vp, vp, u64, cp, pp]
+    lib.skx_array_from_host.argtypes = [vp, i, i, C.POINTER(cp), i, vp, vp, vp, u64, cp, pp]
     lib.skx_array_info.argtypes = [vp, C.POINTER(ArrayInfo)]
     lib.skx_array_name.argtypes = [vp, u64]
     lib.skx_array_name.restype = cp
@@ -107,6 +107,8 @@ def load_library():
     lib.skx_array_write_fasta.argtypes = [vp, i]
     lib.skx_array_fasta.argtypes = [vp, pp, C.POINTER(u64)]
     lib.skx_array_device_matrix.argtypes = [vp, pp, C.POINTER(u64), C.POINTER(u64)]
+    lib.skx_array_device_stats.argtypes = [vp, pp, pp, pp, pp]
+    lib.skx_array_set_total_samples.argtypes = [vp, u64]
     lib.skx_array_distance.argtypes = [vp, d, i, vp]
     lib.skx_free.argtypes = [vp]
     lib.skh_apply_filters.argtypes = [vp, d, i, i, i, i, C.POINTER(C.c_int32)]
@@ -355,14 +357,15 @@ class Array:
         return cls(h, ctx)
 
     @classmethod
-    def from_host(cls, k, rc, names, keys, variants, version=None, ctx=None):
+    def from_host(cls, k, rc, names, keys, variants, counts=None, version=None, ctx=None):
         ctx = ctx or default_context()
         keys = np.ascontiguousarray(keys, dtype=KEY_DT)
         variants = np.ascontiguousarray(variants, dtype=np.uint8)
         n = len(names)
         nm = (C.c_char_p * n)(*[x.encode() for x in names])
         h = C.c_void_p()
-        _check(_lib.skx_array_from_host(ctx.h, k, int(rc), nm, n, _np_ptr(keys), _np_ptr(variants), len(keys),
+        counts = np.ascontiguousarray(counts, dtype=np.uint64) if counts is not None else None
+        _check(_lib.skx_array_from_host(ctx.h, k, int(rc), nm, n, _np_ptr(keys), _np_ptr(variants), _np_ptr(counts), len(keys),
                                         version.encode() if version else None, C.byref(h)))
         return cls(h, ctx)
 
@@ -425,6 +428,14 @@ class Array:
         p, pitch, rows = C.c_void_p(), C.c_uint64(), C.c_uint64()
         _check(_lib.skx_array_device_matrix(self.h, C.byref(p), C.byref(pitch), C.byref(rows)))
         return p.value, pitch.value, rows.value
+
+    def device_stats(self):
+        p = [C.c_void_p() for _ in range(4)]
+        _check(_lib.skx_array_device_stats(self.h, *[C.byref(x) for x in p]))
+        return [x.value for x in p]
+
+    def set_total_samples(self, total):
+        _check(_lib.skx_array_set_total_samples(self.h, total))
 
     def nk(self, full_info=False):
         p, n = C.c_void_p(), C.c_uint64()
