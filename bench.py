@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--genomes", type=int, default=1000, help="samples per GPU")
     ap.add_argument("--genome-len", type=int, default=5_000_000)
     ap.add_argument("-k", type=int, default=31)
-    ap.add_argument("--cpu-genomes", type=int, default=16, help="size of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-genomes", type=int, default=4, help="size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--check", action="store_true", help="verify a subsample of the result against the CPU oracle")
     return ap.parse_args()
 
@@ -110,8 +110,14 @@ def main():
     total_bases = int(sum(lens))
     torch.cuda.synchronize()
 
+    host_ms = {"build": 0.0, "merge": 0.0, "align": 0.0, "free": 0.0}
+
     def step():
+        t_a = time.perf_counter()
         ds = E.DictSet.build_device(ptrs, lens, args.k, True, ctx=ctx)
+        ctx.sync()
+        t_b = time.perf_counter()
+        host_ms["build"] += (t_b - t_a) * 1e3
         if world == 1:
             arr = ds.merge(names)
         else:
@@ -130,17 +136,25 @@ def main():
             skdist.as_tensor(pv, U, "<i4", dev).copy_(tp)
             torch.cuda.synchronize()
             arr.set_total_samples(n_total)
+        ctx.sync()
+        t_c = time.perf_counter()
+        host_ms["merge"] += (t_c - t_b) * 1e3
         info = (arr.nrows, arr.nsamples)
         removed = arr.apply_filters(0.9, False, E.FILTER_NO_CONST, False, False)      # ska align defaults
         ctx.sync()
+        t_d = time.perf_counter()
+        host_ms["align"] += (t_d - t_c) * 1e3
         out = (info[0], arr.nrows, removed)
         ds.free()
+        host_ms["free"] += (time.perf_counter() - t_d) * 1e3
         return arr, out
 
     for _ in range(args.warmup):
         arr, _ = step()
         arr.free()
     ctx.timings(reset=True)
+    for kk in host_ms:
+        host_ms[kk] = 0.0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -197,6 +211,7 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": scatter_ms},
             "stage_ms_per_step": {k: v / steps for k, v in tm.items()},
+            "host_wall_ms_per_step": {k: v / steps for k, v in host_ms.items()},
         }
         if check:
             res["check"] = check

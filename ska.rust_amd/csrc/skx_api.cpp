@@ -6,8 +6,11 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <numeric>
+#include <unordered_map>
 #include <thread>
 #include <unistd.h>
 
@@ -27,6 +30,54 @@ int skx::hip_fail(hipError_t e, const char *what)
 extern "C" const char *skx_last_error(void) { return g_err; }
 extern "C" const char *skx_version(void) { return "0.5.2"; }      // Cargo.toml:3, written as ska_version
 extern "C" void skx_free(void *p) { free(p); }
+
+// ------------------------------------------------------------------------------------------ device memory cache
+namespace {
+struct DevCache {
+    std::mutex mu;
+    std::multimap<size_t, void *> free_blocks;          // size -> block
+    std::unordered_map<void *, size_t> live;            // block -> size
+    size_t cached_bytes = 0;
+} g_cache;
+}
+void *skx::dev_alloc(size_t bytes, hipError_t *err)
+{
+    bytes = (bytes + 255) & ~(size_t)255;
+    {
+        std::lock_guard<std::mutex> lk(g_cache.mu);
+        auto it = g_cache.free_blocks.lower_bound(bytes);
+        if (it != g_cache.free_blocks.end() && it->first <= bytes + bytes / 4 + (1u << 20)) {
+            void *p = it->second; size_t sz = it->first;
+            g_cache.free_blocks.erase(it); g_cache.cached_bytes -= sz; g_cache.live[p] = sz;
+            return p;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {                                // out of memory: drop the cache and retry once
+        (void)hipGetLastError();
+        skx::dev_trim();
+        e = hipMalloc(&p, bytes);
+    }
+    if (e != hipSuccess) { if (err) *err = e; return nullptr; }
+    std::lock_guard<std::mutex> lk(g_cache.mu);
+    g_cache.live[p] = bytes;
+    return p;
+}
+void skx::dev_free(void *p)
+{
+    std::lock_guard<std::mutex> lk(g_cache.mu);
+    auto it = g_cache.live.find(p);
+    if (it == g_cache.live.end()) { (void)hipFree(p); return; }
+    g_cache.free_blocks.emplace(it->second, p); g_cache.cached_bytes += it->second;
+    g_cache.live.erase(it);
+}
+void skx::dev_trim()
+{
+    std::lock_guard<std::mutex> lk(g_cache.mu);
+    for (auto &kv : g_cache.free_blocks) (void)hipFree(kv.second);
+    g_cache.free_blocks.clear(); g_cache.cached_bytes = 0;
+}
 
 // nothing may unwind across the C boundary
 template <typename F>
@@ -63,6 +114,7 @@ extern "C" void skx_ctx_destroy(skx_ctx *c)
     if (!c) return;
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    skx::dev_trim();
     delete c;
 }
 extern "C" int skx_ctx_sync(skx_ctx *c) { SKX_HIP(hipSetDevice(c->device)); SKX_HIP(hipStreamSynchronize(c->stream)); return SKX_OK; }
@@ -95,6 +147,7 @@ int check_k(int k)
 }
 int ilog2_ceil(uint64_t x) { int l = 0; while ((1ull << l) < x) l++; return l; }
 constexpr uint32_t LDS_TABLE_MAX = 18000;     // slots (+ pad) of 8 B must stay below 160 KiB
+constexpr uint32_t LDS_SORT_MAX = 13312;      // words of the per-region counting sort (12 B each)
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ dictset
@@ -149,8 +202,9 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
         SKX_HIP(hipStreamSynchronize(st));
         SKX_TRY(d->words.alloc(total));
         { StageTimer t(ctx, &ctx->tm.scatter); a.hist = d_cursor.p; a.off = d->off.p; a.words = d->words.p; launch_scatter(a, st); }
-        uint32_t slots = std::max<uint32_t>(1024, (uint32_t)std::min<uint64_t>((uint64_t)max_raw * 3 / 2 + 64, LDS_TABLE_MAX));
-        { StageTimer t(ctx, &ctx->tm.dedupe); launch_dedupe(d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, slots, hp.bits - logB, d_flag.p, st); }
+        // LDS capacity (words) of the per-region counting sort: 12 B per word, <= 160 KiB
+        uint32_t cap = std::max<uint32_t>(512, (uint32_t)std::min<uint64_t>(((uint64_t)max_raw + 255) / 256 * 256, LDS_SORT_MAX));
+        { StageTimer t(ctx, &ctx->tm.dedupe); launch_dedupe_mb(d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, cap, hp.bits - logB, d_flag.p, st); }
         int overflow = 0;
         SKX_HIP(hipMemcpyAsync(&overflow, d_flag.p, 4, hipMemcpyDeviceToHost, st));
         std::vector<uint32_t> ucnt(nreg);
@@ -158,7 +212,7 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
         SKX_HIP(hipStreamSynchronize(st));
         SKX_HIP(hipGetLastError());
         if (overflow) {
-            if (logB >= std::min(hp.bits, MAX_LOGB)) { set_error("sample too large for the device dictionary (more than %u distinct split k-mers in one of %d buckets)", LDS_TABLE_MAX, 1 << logB); return SKX_EUNSUP; }
+            if (logB >= std::min(hp.bits, MAX_LOGB)) { set_error("sample too large for the device dictionary (more than %u split k-mer occurrences in one of %d buckets)", LDS_SORT_MAX, 1 << logB); return SKX_EUNSUP; }
             continue;
         }
         d->sample_size.assign(n, 0);
@@ -472,7 +526,6 @@ extern "C" int skx_array_assemble(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows
         rows = tmp;
         if (rows->logN < d->logB) { set_error("internal: keyset granularity"); return SKX_EUNSUP; }
     }
-    StageTimer t(ctx, &ctx->tm.assemble);
     std::unique_ptr<skx_array> a(new skx_array());
     a->ctx = ctx; a->k = d->k; a->rc = d->rc; a->k_bits = d->key_bits; a->hp = d->hp; a->version = skx_version();
     for (int i = 0; i < d->n; i++) a->names.emplace_back(names && names[i] ? names[i] : "");
@@ -486,7 +539,7 @@ extern "C" int skx_array_assemble(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows
         aa.d = d->view(); aa.logN = rows->logN; aa.stage = rows->stage.p; aa.stride = rows->stride; aa.ncnt = rows->ncnt.p; aa.roff = rows->roff.p;
         aa.matrix = a->matrix.p; aa.pitch = a->pitch; aa.col_present = a->present.p; aa.col_unambig = a->unambig.p; aa.col_mask = a->mask.p;
         aa.max_rows = rows->max_rows; aa.missing = d_flag.p;
-        launch_assemble(aa, st);
+        { StageTimer t(ctx, &ctx->tm.assemble); launch_assemble(aa, st); }
         launch_gather_keys(rows->stage.p, rows->stride, rows->ncnt.p, rows->roff.p, 1 << rows->logN, a->keys.p, 0, rows->hp, st);
         SKX_HIP(hipMemcpyAsync(a->vcount.p, a->present.p, U * 4, hipMemcpyDeviceToDevice, st));     // merge_ska_array.rs:172
     }

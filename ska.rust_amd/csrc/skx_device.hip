@@ -282,26 +282,43 @@ void launch_scan_u32(const uint32_t *in, uint64_t *out, uint64_t n, uint32_t *ma
     hipLaunchKernelGGL(scan_u32_kernel, dim3(1), dim3(1024), 0, st, in, out, n, max_out);
 }
 
-__global__ __launch_bounds__(1024) void scan_u8_kernel(const uint8_t *in, uint64_t *out, uint64_t n)
+// multi-block exclusive scan of (flag == 1): per-block sums -> single-block scan of the sums -> apply
+constexpr int SCAN8_PER_BLOCK = 8192;
+__global__ __launch_bounds__(1024) void scan_u8_sums_kernel(const uint8_t *in, uint64_t n, uint32_t *sums)
 {
     __shared__ uint32_t s_tmp[17];
-    uint64_t carry = 0;
-    for (uint64_t base = 0; base < n; base += 8192) {
-        uint32_t v[8]; uint32_t sum = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) { uint64_t idx = base + (uint64_t)threadIdx.x * 8 + i; v[i] = idx < n ? (in[idx] == 1) : 0; sum += v[i]; }
-        uint32_t tot;
-        uint32_t ex = block_excl_scan(sum, s_tmp, &tot);
-        uint64_t run = carry + ex;
-#pragma unroll
-        for (int i = 0; i < 8; i++) { uint64_t idx = base + (uint64_t)threadIdx.x * 8 + i; if (idx < n) out[idx] = run; run += v[i]; }
-        carry += tot;
-    }
-    if (threadIdx.x == 0) out[n] = carry;
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN8_PER_BLOCK + (uint64_t)threadIdx.x * 8;
+    uint32_t sum = 0;
+    if (base + 8 <= n) { uint64_t v = *reinterpret_cast<const uint64_t *>(in + base); for (int i = 0; i < 8; i++) sum += ((v >> (8 * i)) & 0xFF) == 1; }
+    else for (int i = 0; i < 8; i++) sum += (base + i < n) && in[base + i] == 1;
+    uint32_t tot; block_excl_scan(sum, s_tmp, &tot);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(1024) void scan_u8_apply_kernel(const uint8_t *in, uint64_t n, const uint64_t *block_off, uint64_t *out)
+{
+    __shared__ uint32_t s_tmp[17];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN8_PER_BLOCK + (uint64_t)threadIdx.x * 8;
+    uint32_t v[8]; uint32_t sum = 0;
+    for (int i = 0; i < 8; i++) { v[i] = (base + i < n) && in[base + i] == 1; sum += v[i]; }
+    uint32_t ex = block_excl_scan(sum, s_tmp, nullptr);
+    uint64_t run = block_off[blockIdx.x] + ex;
+    for (int i = 0; i < 8; i++) { if (base + i < n) out[base + i] = run; run += v[i]; }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == blockDim.x - 1) out[n] = run;
 }
 void launch_scan_u8(const uint8_t *flags, uint64_t *pos, uint64_t n, hipStream_t st)
 {
-    hipLaunchKernelGGL(scan_u8_kernel, dim3(1), dim3(1024), 0, st, flags, pos, n);
+    // scratch for the block sums lives at the tail of `pos` is not possible (u64 semantics), so use a small static pool
+    static uint32_t *d_sums = nullptr; static uint64_t *d_offs = nullptr; static uint64_t cap = 0;
+    const uint64_t nb = (n + SCAN8_PER_BLOCK - 1) / SCAN8_PER_BLOCK;
+    if (nb == 0) { (void)hipMemsetAsync(pos, 0, 8, st); return; }
+    if (nb > cap) {
+        if (d_sums) { (void)hipFree(d_sums); (void)hipFree(d_offs); }
+        cap = nb * 2 + 1024;
+        (void)hipMalloc((void **)&d_sums, cap * 4); (void)hipMalloc((void **)&d_offs, (cap + 1) * 8);
+    }
+    hipLaunchKernelGGL(scan_u8_sums_kernel, dim3((unsigned)nb), dim3(1024), 0, st, flags, n, d_sums);
+    hipLaunchKernelGGL(scan_u32_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)d_sums, d_offs, nb, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(scan_u8_apply_kernel, dim3((unsigned)nb), dim3(1024), 0, st, flags, n, (const uint64_t *)d_offs, pos);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -323,7 +340,8 @@ __device__ static inline bool table_insert(unsigned long long *tab, uint32_t tot
 {
     const uint64_t key = w >> 4;
     for (uint32_t i = home; i < total_slots; ++i) {
-        unsigned long long old = atomicCAS(&tab[i], 0ull, (unsigned long long)w);
+        unsigned long long old = tab[i];
+        if (old == 0ull) old = atomicCAS(&tab[i], 0ull, (unsigned long long)w);
         if (old == 0ull) return true;
         if ((old >> 4) == key) {
             if ((old | w) != old) atomicOr(&tab[i], (unsigned long long)(w & 15ull));
@@ -388,6 +406,80 @@ void launch_dedupe(uint64_t *words, const uint64_t *off, const uint32_t *raw, ui
     hipLaunchKernelGGL(dedupe_kernel, dim3((unsigned)n_regions), dim3(256), lds, st, words, off, raw, ucnt, table_slots, rem_bits, overflow);
 }
 
+// K3 (fast path): counting sort of a region into micro-buckets of ~2-4 words by the next hash bits, then a tiny
+// per-thread insertion sort with duplicate folding (OR of base masks).  No CAS loops, no data-dependent probe
+// chains: cost is O(n) LDS operations per region whatever the duplication level.
+__global__ __launch_bounds__(256) void dedupe_mb_kernel(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt,
+                                                        uint32_t cap, int rem_bits, int *overflow)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
+    __shared__ uint32_t s_tmp[17];
+    const uint64_t region = blockIdx.x;
+    const uint32_t n = raw[region];
+    if (n == 0) { if (threadIdx.x == 0) ucnt[region] = 0; return; }
+    if (n > cap) { if (threadIdx.x == 0) { *overflow = 1; ucnt[region] = 0; } return; }
+    uint64_t *s_elem = reinterpret_cast<uint64_t *>(s_mem);                 // [cap]
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_mem + (size_t)cap * 8); // [M] counts -> cursors -> unique counts
+    uint32_t *s_start = s_cnt + cap / 2;                                     // [M] micro-bucket starts
+    int logM = 31 - __clz(n) - 1;                                            // ~2..4 words per micro-bucket
+    if (logM < 0) logM = 0;
+    if (logM > rem_bits) logM = rem_bits;
+    while ((1u << logM) > cap / 2) logM--;
+    const uint32_t M = 1u << logM;
+    const int mshift = rem_bits - logM;                                      // micro-bucket = local >> mshift
+    const uint64_t lmask = rem_bits >= 60 ? ~0ull : ((1ull << rem_bits) - 1);
+    uint64_t *reg = words + off[region];
+    for (uint32_t i = threadIdx.x; i < M; i += blockDim.x) s_cnt[i] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&s_cnt[(uint32_t)(((reg[i] >> 4) & lmask) >> mshift)], 1u);
+    __syncthreads();
+    // exclusive scan of the counts (each thread owns R consecutive micro-buckets)
+    const uint32_t R = (M + blockDim.x - 1) / blockDim.x;
+    const uint32_t m0 = threadIdx.x * R, m1 = m0 + R < M ? m0 + R : M;
+    uint32_t sum = 0;
+    for (uint32_t m = m0; m < m1; m++) sum += s_cnt[m];
+    uint32_t run = block_excl_scan(sum, s_tmp, nullptr);
+    for (uint32_t m = m0; m < m1; m++) { uint32_t c = s_cnt[m]; s_start[m] = run; s_cnt[m] = run; run += c; }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint64_t w = reg[i];
+        s_elem[atomicAdd(&s_cnt[(uint32_t)(((w >> 4) & lmask) >> mshift)], 1u)] = w;
+    }
+    __syncthreads();
+    // per micro-bucket: insertion sort with duplicate folding, in place; s_cnt[m] <- distinct count
+    uint32_t usum = 0;
+    for (uint32_t m = m0; m < m1; m++) {
+        const uint32_t b = s_start[m], e = s_cnt[m];
+        uint32_t u = 0;
+        for (uint32_t i = b; i < e; i++) {
+            const uint64_t w = s_elem[i], key = w >> 4;
+            uint32_t p = u;
+            while (p > 0 && (s_elem[b + p - 1] >> 4) > key) p--;
+            if (p > 0 && (s_elem[b + p - 1] >> 4) == key) { s_elem[b + p - 1] |= w & 15ull; continue; }
+            for (uint32_t q = u; q > p; q--) s_elem[b + q] = s_elem[b + q - 1];
+            s_elem[b + p] = w;
+            u++;
+        }
+        s_cnt[m] = u; usum += u;
+    }
+    uint32_t total;
+    uint32_t o = block_excl_scan(usum, s_tmp, &total);
+    for (uint32_t m = m0; m < m1; m++) {
+        const uint32_t b = s_start[m], u = s_cnt[m];
+        for (uint32_t i = 0; i < u; i++) reg[o + i] = s_elem[b + i];
+        o += u;
+    }
+    if (threadIdx.x == 0) ucnt[region] = total;
+}
+void launch_dedupe_mb(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_regions, uint32_t cap,
+                      int rem_bits, int *overflow, hipStream_t st)
+{
+    if (!n_regions) return;
+    size_t lds = (size_t)cap * 8 + (size_t)cap * 4;       // elements + two u32 arrays of cap/2
+    hipFuncSetAttribute((const void *)dedupe_mb_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(dedupe_mb_kernel, dim3((unsigned)n_regions), dim3(256), lds, st, words, off, raw, ucnt, cap, rem_bits, overflow);
+}
+
 // first index in [0,n) whose hashed key (word >> 4) is >= x
 __device__ static inline uint32_t lower_bound_words(const uint64_t *reg, uint32_t n, uint64_t x)
 {
@@ -424,12 +516,18 @@ __global__ __launch_bounds__(256) void union_kernel(DictView d, int logN, uint64
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int rem_bits = d.bits - logN;
-    for (int s = wv; s < d.n_samples; s += nw) {
-        const uint64_t *reg; uint32_t lo, hi;
-        sub_slice(d, s, j, logN, reg, lo, hi);
-        for (uint32_t i = lo + lane; i < hi; i += 64) {
-            const uint64_t w = reg[i];
-            if (!table_insert(s_tab, total_slots, home_slot(w, rem_bits, nslots), w)) s_fail = 1;
+    // every lane binary-searches the slice of one sample; the wave then streams the 64 slices one after another
+    for (int s0 = wv * 64; s0 < d.n_samples; s0 += nw * 64) {
+        const uint64_t *my_reg = nullptr; uint32_t my_lo = 0, my_hi = 0;
+        if (s0 + lane < d.n_samples) sub_slice(d, s0 + lane, j, logN, my_reg, my_lo, my_hi);
+        const int cnt = d.n_samples - s0 < 64 ? d.n_samples - s0 : 64;
+        for (int t = 0; t < cnt; t++) {
+            const uint64_t *reg = reinterpret_cast<const uint64_t *>(__shfl((unsigned long long)my_reg, t, 64));
+            const uint32_t lo = __shfl(my_lo, t, 64), hi = __shfl(my_hi, t, 64);
+            for (uint32_t i = lo + lane; i < hi; i += 64) {
+                const uint64_t w = reg[i];
+                if (!table_insert(s_tab, total_slots, home_slot(w, rem_bits, nslots), w)) s_fail = 1;
+            }
         }
     }
     __syncthreads();

@@ -13,6 +13,12 @@ int hip_fail(hipError_t e, const char *what);       // sets the error, returns S
 #define SKX_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return skx::hip_fail(e_, #call); } while (0)
 #define SKX_TRY(call) do { int r_ = (call); if (r_ != SKX_OK) return r_; } while (0)
 
+// caching device allocator (per process): freed blocks are kept and reused for later requests of a similar size,
+// so steady-state batches do not go through hipMalloc/hipFree (which map/unmap tens of GB and cost seconds)
+void *dev_alloc(size_t bytes, hipError_t *err);
+void dev_free(void *p);
+void dev_trim();                                   // release every cached block
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr; size_t n = 0;
@@ -22,12 +28,13 @@ struct DevBuf {
     DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
     DevBuf &operator=(DevBuf &&o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
     ~DevBuf() { release(); }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    void release() { if (p) dev_free(p); p = nullptr; n = 0; }
     int alloc(size_t count) {
         release();
         if (!count) count = 1;
-        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
-        if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc"); }
+        hipError_t e = hipSuccess;
+        p = (T *)dev_alloc(count * sizeof(T), &e);
+        if (!p) return hip_fail(e, "hipMalloc");
         n = count; return SKX_OK;
     }
     int zero(hipStream_t st) { return p ? (hipMemsetAsync(p, 0, n * sizeof(T), st) == hipSuccess ? SKX_OK : SKX_ENODEV) : SKX_OK; }
