@@ -168,7 +168,7 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
     uint64_t maxlen = 0;
     for (auto l : lens) maxlen = std::max(maxlen, l);
     HashParams hp = make_hash_params(k);
-    int logB = std::min({ilog2_ceil((maxlen + 4095) / 4096), hp.bits, MAX_LOGB});
+    int logB = std::min({ilog2_ceil((maxlen + 4095) / 4096), hp.bits, MAX_LOGB});      // ~2-4 k windows per bucket
     if (logB < 0) logB = 0;
 
     DevBuf<const uint8_t *> d_seqs, d_quals;
@@ -180,30 +180,48 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
     DevBuf<int> d_flag;
     SKX_TRY(d_flag.alloc(1));
 
-    for (;; logB++) {
+    bool exact = false;        // single pass with fixed-capacity regions first; exact two-pass layout if a region overflows
+    for (;;) {
         std::unique_ptr<skx_dictset> d(new skx_dictset());
         d->ctx = ctx; d->n = n; d->k = k; d->rc = rc; d->logB = logB; d->hp = hp; d->key_bits = 64;
         const uint64_t nreg = (uint64_t)n << logB;
         SKX_TRY(d->raw.alloc(nreg)); SKX_TRY(d->ucnt.alloc(nreg)); SKX_TRY(d->off.alloc(nreg + 1));
-        DevBuf<uint32_t> d_cursor, d_max;
-        SKX_TRY(d_cursor.alloc(nreg)); SKX_TRY(d_max.alloc(1));
-        SKX_TRY(d->raw.zero(st)); SKX_TRY(d_cursor.zero(st)); SKX_TRY(d_flag.zero(st));
+        SKX_TRY(d->raw.zero(st)); SKX_TRY(d_flag.zero(st));
 
         ExtractArgs a{};
         a.seqs = d_seqs.p; a.quals = any_qual ? d_quals.p : nullptr; a.lens = d_lens.p; a.n_samples = n;
-        a.tiles_max = (int)((maxlen + TILE_BASES - 1) / TILE_BASES);
+        a.tiles_max = (int)((maxlen + extract_tile_bases(logB) - 1) / extract_tile_bases(logB));
         a.k = k; a.rc = rc; a.min_qual = q ? q->min_qual : 0; a.qual_filter = q ? q->qual_filter : 0;
-        a.logB = logB; a.hp = hp;
-        { StageTimer t(ctx, &ctx->tm.hist); a.hist = d->raw.p; launch_hist(a, st); }
-        launch_scan_u32(d->raw.p, d->off.p, nreg, d_max.p, st);
-        uint64_t total = 0; uint32_t max_raw = 0;
-        SKX_HIP(hipMemcpyAsync(&total, d->off.p + nreg, 8, hipMemcpyDeviceToHost, st));
-        SKX_HIP(hipMemcpyAsync(&max_raw, d_max.p, 4, hipMemcpyDeviceToHost, st));
-        SKX_HIP(hipStreamSynchronize(st));
-        SKX_TRY(d->words.alloc(total));
-        { StageTimer t(ctx, &ctx->tm.scatter); a.hist = d_cursor.p; a.off = d->off.p; a.words = d->words.p; launch_scatter(a, st); }
+        a.logB = logB; a.hp = hp; a.overflow = d_flag.p;
+        uint32_t lds_cap;
+        if (!exact) {
+            // hashed buckets are Poisson around len/B: 20 % + 256 words of head-room covers ordinary repeat content
+            const uint64_t mean = (maxlen >> logB) + 1;
+            const uint32_t region_cap = (uint32_t)std::min<uint64_t>(((mean + mean / 5 + 256) + 63) / 64 * 64, 0x7FFFFFFFull);
+            launch_fill_offsets(d->off.p, nreg, region_cap, st);
+            SKX_TRY(d->words.alloc(nreg * (uint64_t)region_cap));
+            { StageTimer t(ctx, &ctx->tm.scatter); a.hist = d->raw.p; a.off = d->off.p; a.words = d->words.p; a.capacity = region_cap; launch_scatter(a, st); }
+            int over = 0;
+            SKX_HIP(hipMemcpyAsync(&over, d_flag.p, 4, hipMemcpyDeviceToHost, st));
+            SKX_HIP(hipStreamSynchronize(st));
+            if (over) { exact = true; continue; }
+            lds_cap = region_cap;
+        } else {
+            DevBuf<uint32_t> d_cursor, d_max;
+            SKX_TRY(d_cursor.alloc(nreg)); SKX_TRY(d_max.alloc(1)); SKX_TRY(d_cursor.zero(st));
+            { StageTimer t(ctx, &ctx->tm.hist); a.hist = d->raw.p; launch_hist(a, st); }
+            launch_scan_u32(d->raw.p, d->off.p, nreg, d_max.p, st);
+            uint64_t total = 0; uint32_t max_raw = 0;
+            SKX_HIP(hipMemcpyAsync(&total, d->off.p + nreg, 8, hipMemcpyDeviceToHost, st));
+            SKX_HIP(hipMemcpyAsync(&max_raw, d_max.p, 4, hipMemcpyDeviceToHost, st));
+            SKX_HIP(hipStreamSynchronize(st));
+            SKX_TRY(d->words.alloc(total));
+            { StageTimer t(ctx, &ctx->tm.scatter); a.hist = d_cursor.p; a.off = d->off.p; a.words = d->words.p; a.capacity = 0xFFFFFFFFu; launch_scatter(a, st); }
+            lds_cap = max_raw;
+        }
         // LDS capacity (words) of the per-region counting sort: 12 B per word, <= 160 KiB
-        uint32_t cap = std::max<uint32_t>(512, (uint32_t)std::min<uint64_t>(((uint64_t)max_raw + 255) / 256 * 256, LDS_SORT_MAX));
+        uint32_t cap = std::max<uint32_t>(512, (uint32_t)std::min<uint64_t>(((uint64_t)lds_cap + 255) / 256 * 256, LDS_SORT_MAX));
+        SKX_TRY(d_flag.zero(st));
         { StageTimer t(ctx, &ctx->tm.dedupe); launch_dedupe_mb(d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, cap, hp.bits - logB, d_flag.p, st); }
         int overflow = 0;
         SKX_HIP(hipMemcpyAsync(&overflow, d_flag.p, 4, hipMemcpyDeviceToHost, st));
@@ -213,6 +231,7 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
         SKX_HIP(hipGetLastError());
         if (overflow) {
             if (logB >= std::min(hp.bits, MAX_LOGB)) { set_error("sample too large for the device dictionary (more than %u split k-mer occurrences in one of %d buckets)", LDS_SORT_MAX, 1 << logB); return SKX_EUNSUP; }
+            logB++;
             continue;
         }
         d->sample_size.assign(n, 0);

@@ -14,37 +14,36 @@
 
 namespace skx {
 
-constexpr int TILE_THREADS = 256;
-constexpr int TILE_BASES = 4096;          // window end positions per workgroup
+int extract_tile_bases(int logB);         // window end positions per workgroup of the extraction kernels (16 per thread)
 constexpr int MAX_LOGB = 13;              // buckets per sample <= 8192 (LDS histogram)
 constexpr uint64_t EMPTY64 = ~0ull;
 
+// H: a 3-round Feistel bijection on the 2(k-1)-bit split k-mer (upper arm | lower arm), 32-bit arithmetic only.
+// Its top bits are uniform whatever the genome's composition, so hash buckets are balanced; "engine order" of
+// keys is the numeric order of H(key).
 struct HashParams {
     int bits;          // 2(k-1)
-    int s;             // xorshift distance
-    uint64_t mask;     // (1<<bits)-1
-    uint64_t c1, c2, c1inv, c2inv;
+    int hb;            // bits / 2 = k-1 (<= 30 on the 64-bit path)
+    uint32_t hmask;    // (1<<hb)-1
+    uint32_t c[4];     // odd round multipliers
 };
 HashParams make_hash_params(int k);
+__host__ __device__ inline uint32_t hround(uint32_t v, uint32_t c, int hb) { return (v * c) >> (32 - hb); }
+__host__ __device__ inline void hmix_halves(uint32_t &L, uint32_t &R, const HashParams &p)
+{
+    L ^= hround(R, p.c[0], p.hb); R ^= hround(L, p.c[1], p.hb); L ^= hround(R, p.c[2], p.hb);
+}
 __host__ __device__ inline uint64_t hmix(uint64_t x, const HashParams &p)
 {
-    x ^= x >> p.s; x = (x * p.c1) & p.mask;
-    x ^= x >> p.s; x = (x * p.c2) & p.mask;
-    x ^= x >> p.s;
-    return x;
-}
-__host__ __device__ inline uint64_t unxorshift(uint64_t y, int s, int bits)
-{
-    uint64_t x = y;
-    for (int t = s; t < bits; t += s) x ^= y >> t;
-    return x;
+    uint32_t L = (uint32_t)(x >> p.hb), R = (uint32_t)x & p.hmask;
+    hmix_halves(L, R, p);
+    return ((uint64_t)L << p.hb) | R;
 }
 __host__ __device__ inline uint64_t hunmix(uint64_t x, const HashParams &p)
 {
-    x = unxorshift(x, p.s, p.bits); x = (x * p.c2inv) & p.mask;
-    x = unxorshift(x, p.s, p.bits); x = (x * p.c1inv) & p.mask;
-    x = unxorshift(x, p.s, p.bits);
-    return x;
+    uint32_t L = (uint32_t)(x >> p.hb), R = (uint32_t)x & p.hmask;
+    L ^= hround(R, p.c[2], p.hb); R ^= hround(L, p.c[1], p.hb); L ^= hround(R, p.c[0], p.hb);
+    return ((uint64_t)L << p.hb) | R;
 }
 
 struct ExtractArgs {
@@ -60,12 +59,17 @@ struct ExtractArgs {
     uint32_t *hist;               // [n << logB] raw window counts (pass 1 out / pass 2 cursors)
     const uint64_t *off;          // [n << logB] region offsets (pass 2)
     uint64_t *words;              // dict storage (pass 2)
+    uint32_t capacity;            // words per region (pass 2): ranks beyond it are dropped and *overflow is set
+    int *overflow;
+    int debug_mode;               // profiling aid (SKX_SCATTER_MODE): 1 = no stores, 2 = no global atomics/stores
 };
 
 void launch_hist(const ExtractArgs &a, hipStream_t st);
 void launch_scatter(const ExtractArgs &a, hipStream_t st);
 
 // exclusive scan of u32 counts into u64 offsets (+ total at out[n]); also max of the counts
+// off[r] = r * capacity (fixed-capacity regions of the single-pass path)
+void launch_fill_offsets(uint64_t *off, uint64_t n, uint32_t capacity, hipStream_t st);
 void launch_scan_u32(const uint32_t *in, uint64_t *out, uint64_t n, uint32_t *max_out, hipStream_t st);
 
 // in-place sort + dedupe (OR of masks) of every (sample,bucket) region through an order-preserving LDS table

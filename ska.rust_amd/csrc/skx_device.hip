@@ -12,6 +12,7 @@
 //   merge_ska_dict.rs:77-151         samples -> columns, 0/'-' where absent
 //   merge_ska_array.rs:139-186,289-402,416-438,587-632   counts, filter, distance
 #include "skx_device.h"
+#include <cstdlib>
 
 namespace skx {
 
@@ -19,31 +20,23 @@ namespace skx {
 // hashing: a bijection on `bits`-bit integers so that buckets (top bits) are uniform whatever the
 // genome's composition; "engine order" of keys is the order of H(key).
 // ------------------------------------------------------------------------------------------------
-static uint64_t modinv64(uint64_t c)
-{
-    uint64_t inv = c;                       // correct to 3 bits for odd c
-    for (int i = 0; i < 6; i++) inv *= 2 - c * inv;
-    return inv;
-}
 HashParams make_hash_params(int k)
 {
     HashParams p;
     p.bits = 2 * (k - 1);
-    p.s = p.bits / 2 > 0 ? p.bits / 2 : 1;
-    p.mask = p.bits >= 64 ? ~0ull : ((1ull << p.bits) - 1);
-    p.c1 = 0x9E3779B97F4A7C15ull; p.c2 = 0xD6E8FEB86659FD93ull;
-    p.c1inv = modinv64(p.c1); p.c2inv = modinv64(p.c2);
+    p.hb = k - 1;
+    p.hmask = p.hb >= 32 ? ~0u : ((1u << p.hb) - 1);
+    p.c[0] = 0x9E3779B1u; p.c[1] = 0x85EBCA6Bu; p.c[2] = 0xC2B2AE35u; p.c[3] = 0x27D4EB2Fu;
     return p;
 }
 
-// reverse complement of the low n 2-bit symbols of x (cf. bit_encoding.rs:182-195)
-__device__ static inline uint64_t revcomp2(uint64_t x, int n)
+// reverse complement of an arm of n (<= 16) 2-bit symbols (cf. bit_encoding.rs:182-195)
+__device__ static inline uint32_t revcomp_arm(uint32_t x, int n)
 {
-    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
-    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
-    x = __builtin_bswap64(x);
-    x ^= 0xAAAAAAAAAAAAAAAAull;
-    return n ? x >> (64 - 2 * n) : 0;
+    x = __builtin_bitreverse32(x);
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    x ^= 0xAAAAAAAAu;
+    return n ? x >> (32 - 2 * n) : 0;
 }
 
 // 16 ASCII bytes -> 2-bit codes (first base most significant), bad-base mask, newline mask (bit j = byte j)
@@ -83,14 +76,30 @@ __device__ static inline uint32_t qualbad16(const uint32_t w[4], int min_qual)
 // 4096 window-end positions of one sample; 8 consecutive samples run concurrently, one per XCD
 // (block b -> XCD b%8), so a sample's bucket cursors and partially written lines stay in one L2.
 // ------------------------------------------------------------------------------------------------
-template <bool SCATTER>
-__global__ __launch_bounds__(TILE_THREADS) void extract_kernel(ExtractArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];   // [B] hist (+ [B] chunk bases)
-    __shared__ uint32_t s_code[264];
-    __shared__ uint16_t s_bad[264], s_nl[264], s_qbad[264];
+// forward declaration (defined with the block-wide helpers below)
+__device__ static inline uint32_t block_excl_scan(uint32_t v, uint32_t *s_tmp, uint32_t *total);
 
+// LDS carve (dynamic, 16-B aligned): [B+4] hist -> local starts (+ a dummy counter for invalid windows) | [B] global
+// chunk bases | codes+masks, later aliased by the staging buffer.  16 window-end positions per thread.  The tile's
+// words are staged bucket-by-bucket in ROUNDS passes so that the copy-out writes every (tile, bucket) chunk with
+// adjacent lanes (few, wide L2 write requests) while the staging buffer stays small enough for 2-3 workgroups per CU.
+template <bool SCATTER, int TILE, int ROUNDS>
+__global__ __launch_bounds__(TILE / 16) void extract_kernel(ExtractArgs a)
+{
+    constexpr int NT = TILE / 16;
+    constexpr int NCHUNK = TILE / 16 + 5;                              // 4 halo chunks before, 1 after
+    constexpr uint32_t STAGE_CAP = (uint32_t)(TILE / ROUNDS + TILE / (4 * ROUNDS));
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int B = 1 << a.logB;
+    uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_raw);            // [B] + dummy at [B]
+    uint32_t *s_base = s_hist + B + 4;
+    uint32_t *s_tmp = s_base + B;                                      // [20] block-scan scratch
+    unsigned char *s_rest = reinterpret_cast<unsigned char *>(s_tmp + 20);
+    uint32_t *s_code = reinterpret_cast<uint32_t *>(s_rest);
+    uint16_t *s_bad = reinterpret_cast<uint16_t *>(s_code + NCHUNK + 3);
+    uint16_t *s_nl = s_bad + NCHUNK + 3, *s_qbad = s_nl + NCHUNK + 3;
+    uint64_t *s_stage = reinterpret_cast<uint64_t *>(s_rest);           // aliases the code arrays once they are dead
+
     const int tid = threadIdx.x;
     const uint64_t per_group = 8ull * (uint64_t)a.tiles_max;
     const uint64_t L = blockIdx.x;
@@ -98,15 +107,13 @@ __global__ __launch_bounds__(TILE_THREADS) void extract_kernel(ExtractArgs a)
     const uint64_t tile = (L % per_group) / 8;
     if (sample >= a.n_samples) return;
     const uint64_t len = a.lens[sample];
-    const uint64_t T0 = tile * TILE_BASES;
+    const uint64_t T0 = tile * TILE;
     if (T0 >= len) return;
     const uint8_t *seq = a.seqs[sample];
     const uint8_t *qual = a.quals ? a.quals[sample] : nullptr;
 
-    uint32_t *s_hist = s_dyn;
-    for (int i = tid; i < B; i += TILE_THREADS) s_hist[i] = 0;
-
-    auto load_chunk = [&](int c) {
+    for (int i = tid; i < B + 4; i += NT) s_hist[i] = 0;
+    for (int c = tid; c < NCHUNK; c += NT) {
         const int64_t p = (int64_t)T0 - 64 + 16 * (int64_t)c;
         uint32_t w[4], q[4] = {0, 0, 0, 0};
         if (p >= 0 && (uint64_t)p + 16 <= len) {
@@ -135,99 +142,164 @@ __global__ __launch_bounds__(TILE_THREADS) void extract_kernel(ExtractArgs a)
             if (a.qual_filter == 2) bad |= qb;          // QualFilter::Strict (split_kmer.rs:98-101,170-172)
         }
         s_code[c] = code; s_bad[c] = (uint16_t)bad; s_nl[c] = (uint16_t)nl; s_qbad[c] = (uint16_t)qb;
-    };
-    load_chunk(tid + 4);
-    if (tid < 4) load_chunk(tid);
-    if (tid == 4) load_chunk(260);
+    }
     __syncthreads();
 
-    // ---- per-thread rolling windows over its 16 positions ----
     const int k = a.k, h = (k - 1) / 2;
     const int c = tid + 4;
-    const uint64_t maskk = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1);
-    const uint64_t mask2h = (1ull << (2 * h)) - 1;
-    const uint64_t prev = ((uint64_t)s_code[c - 2] << 32) | s_code[c - 1];
+    // ---- which of my 16 windows exist: bit i of the 48-bit fields <-> position p0 - 32 + i ----
+    // G = good positions; W[i] = all of the k positions ending at i are good (doubling + binary decomposition of k);
+    // split_kmer.rs:89,121: a (re)start at idx is abandoned when idx + k >= len  <=>  the clean run is exactly k long
+    // (position i-k is bad) and ends at the record's last base (position i+1 is the terminator)
+    const uint64_t G = ~((uint64_t)s_bad[c - 2] | ((uint64_t)s_bad[c - 1] << 16) | ((uint64_t)s_bad[c] << 32)) & 0xFFFFFFFFFFFFull;
+    uint64_t Wk = ~0ull;
+    {
+        uint64_t A = G; int offset = 0, span = 1;
+        // A covers `span` positions; consume the bits of k from the least significant upwards
+        for (int bit = 0; bit < 6; bit++) {
+            if ((k >> bit) & 1) { Wk &= A << offset; offset += span; }
+            A &= A << span; span <<= 1;
+        }
+    }
+    const uint64_t NL = ((uint64_t)s_nl[c] << 32) | ((uint64_t)(s_nl[c + 1] & 1u) << 48);
+    const uint64_t exact = Wk & ~(G << k);
+    uint64_t V = Wk & ~(exact & (NL >> 1));
+    if (qual && a.qual_filter != 0)                                          // middle_base_qual, split_kmer.rs:328-339
+        V &= ~((((uint64_t)s_qbad[c - 2] | ((uint64_t)s_qbad[c - 1] << 16) | ((uint64_t)s_qbad[c] << 32))) << h);
+    const uint32_t vm = (uint32_t)(V >> 32) & 0xFFFFu;
+
+    // ---- rolling split k-mer over my 16 positions; arms are <= 30 bits, all 32-bit arithmetic ----
+    const uint32_t am = (1u << (2 * h)) - 1;                                  // arm mask (h <= 15)
+    const uint64_t prev = ((uint64_t)s_code[c - 2] << 32) | s_code[c - 1];    // 32 bases before p0, first base most significant
+    // window ending at p0-1: upper arm | middle | lower arm  (split_kmer.rs:104-116)
+    uint32_t lower = (uint32_t)prev & am;
+    uint32_t mid = (uint32_t)(prev >> (2 * h)) & 3u;
+    uint32_t upper = (uint32_t)(prev >> (2 * h + 2)) & am;
+    uint32_t rc_upper = revcomp_arm(lower, h), rc_lower = revcomp_arm(upper, h), rc_mid = mid ^ 2u;   // :149-153
+    const int hb = a.hp.hb;
+    const int bshift = a.hp.bits - a.logB;                  // (word >> 4) >> bshift == bucket
     const uint32_t cw = s_code[c];
-    const uint32_t bm = s_bad[c];
-    const uint32_t nlx = (uint32_t)s_nl[c] | ((uint32_t)(s_nl[c + 1] & 1u) << 16);
-    const uint32_t badprev = (uint32_t)s_bad[c - 2] | ((uint32_t)s_bad[c - 1] << 16);
-    const uint64_t qb48 = (uint64_t)s_qbad[c - 2] | ((uint64_t)s_qbad[c - 1] << 16) | ((uint64_t)s_qbad[c] << 32);
-    int run = badprev ? __clz(badprev) : 32;                // consecutive good positions ending just before p0
-    uint64_t fwd = prev & ((1ull << (2 * (k - 1))) - 1);    // k-1 bases preceding p0
-    uint64_t rev = revcomp2(fwd, k - 1) << 2;
-    const bool check_mid = qual && a.qual_filter != 0;
-    const int bshift = a.hp.bits - a.logB;                  // (word >> 4) >> bshift == bucket (two steps: bshift + 4 may be 64)
+    const uint32_t rcflag = a.rc ? ~0u : 0u;
 
     uint64_t wv[16];
-    uint32_t vm = 0;
+    uint32_t rk[16];                                         // (bucket << 16) | rank within the tile's bucket; bucket 0xFFFF = no window
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const uint32_t code = (cw >> (30 - 2 * j)) & 3u;
-        fwd = ((fwd << 2) | code) & maskk;
-        rev = (rev >> 2) | ((uint64_t)(code ^ 2u) << (2 * (k - 1)));
-        run = ((bm >> j) & 1u) ? 0 : run + 1;
-        const bool nlnext = (nlx >> (j + 1)) & 1u;
-        // split_kmer.rs:89,121: a (re)start at idx is abandoned when idx + k >= len  <=>  the clean run is
-        // exactly k long and ends at the record's last base
-        bool valid = run >= k && !(nlnext && run == k);
-        if (check_mid) valid = valid && !((qb48 >> (32 + j - h)) & 1ull);   // middle_base_qual, split_kmer.rs:328-339
-        const uint64_t kf = ((fwd >> (2 * h + 2)) << (2 * h)) | (fwd & mask2h);
-        const uint64_t kr = ((rev >> (2 * h + 2)) << (2 * h)) | (rev & mask2h);
-        const uint32_t mf = (uint32_t)(fwd >> (2 * h)) & 3u;
-        uint64_t key = kf; uint32_t m4 = 1u << mf;
-        if (a.rc) {
-            if (kf > kr) { key = kr; m4 = 1u << (mf ^ 2u); }              // canonical = rc (split_kmer.rs:287-291)
-            else if (kf == kr) m4 = (1u << mf) | (1u << (mf ^ 2u));        // self-palindrome -> W / S (ska_dict.rs:85-113)
-        }
-        const uint64_t w = (hmix(key, a.hp) << 4) | m4;
+        // roll_fwd (split_kmer.rs:199-213)
+        upper = ((upper << 2) | mid) & am;
+        mid = lower >> (2 * h - 2);
+        lower = ((lower << 2) | code) & am;
+        rc_lower = (rc_lower >> 2) | (rc_mid << (2 * h - 2));
+        rc_mid = mid ^ 2u;
+        rc_upper = (rc_upper >> 2) | ((code ^ 2u) << (2 * h - 2));
+        // canonical = min(fwd, rc) (split_kmer.rs:281-295); equal arms = self-palindrome -> both middles (ska_dict.rs:85-113)
+        const bool gt = (upper != rc_upper ? upper > rc_upper : lower > rc_lower) && rcflag;
+        const bool eq = (upper == rc_upper) && (lower == rc_lower) && rcflag;
+        uint32_t hl = gt ? rc_upper : upper, hr = gt ? rc_lower : lower;
+        const uint32_t m4 = (1u << (gt ? rc_mid : mid)) | (eq ? (1u << rc_mid) : 0u);
+        hmix_halves(hl, hr, a.hp);
+        const uint64_t w = ((uint64_t)hl << (hb + 4)) | ((uint64_t)hr << 4) | m4;
         wv[j] = w;
-        if (valid) vm |= 1u << j;
+        const bool valid = (vm >> j) & 1u;
+        const uint32_t bk = valid ? (uint32_t)((w >> 4) >> bshift) : (uint32_t)B;
+        const uint32_t r = atomicAdd(&s_hist[bk], 1u);
+        rk[j] = ((valid ? bk : 0xFFFFu) << 16) | (r & 0xFFFFu);
     }
-
-    uint32_t rk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < 16; j++)
-        if ((vm >> j) & 1u) {
-            uint32_t r = atomicAdd(&s_hist[(uint32_t)((wv[j] >> 4) >> bshift)], 1u);
-            if (SCATTER) rk[j >> 1] |= r << (16 * (j & 1));
-        }
-    __syncthreads();
+    __syncthreads();                                        // also: the code arrays are dead from here on
     uint32_t *ghist = a.hist + ((uint64_t)sample << a.logB);
     if (!SCATTER) {
-        for (int i = tid; i < B; i += TILE_THREADS) { uint32_t n = s_hist[i]; if (n) atomicAdd(&ghist[i], n); }
+        for (int i = tid; i < B; i += NT) { uint32_t n = s_hist[i]; if (n) atomicAdd(&ghist[i], n); }
         return;
     }
-    uint32_t *s_base = s_dyn + B;
-    for (int i = tid; i < B; i += TILE_THREADS) { uint32_t n = s_hist[i]; s_base[i] = n ? atomicAdd(&ghist[i], n) : 0u; }
+    if (a.debug_mode == 2) return;
+    // reserve one chunk per non-empty bucket in the sample's region (global cursor); counts -> local starts
+    const int R = (B + NT - 1) / NT;
+    const int b0 = tid * R < B ? tid * R : B, b1 = b0 + R < B ? b0 + R : B;
+    uint32_t lsum = 0;
+    for (int b = b0; b < b1; b++) { const uint32_t n = s_hist[b]; s_base[b] = n ? atomicAdd(&ghist[b], n) : 0u; lsum += n; }
+    uint32_t total;
+    uint32_t lrun = block_excl_scan(lsum, s_tmp, &total);
+    // s_hist: counts -> local starts; s_base: chunk base -> (chunk base - local start), so that a staged word at local
+    // index i lands at region offset s_base[b] + i
+    for (int b = b0; b < b1; b++) { const uint32_t n = s_hist[b]; s_hist[b] = lrun; s_base[b] -= lrun; lrun += n; }
+    if (tid == 0) s_hist[B] = total;                        // sentinel: start of the (non-existent) bucket B
     __syncthreads();
+    if (a.debug_mode == 1) return;
     const uint64_t *off = a.off + ((uint64_t)sample << a.logB);
+    const bool fixed = a.capacity != 0xFFFFFFFFu;           // fixed-capacity regions: offsets are arithmetic
+    const uint64_t reg0 = ((uint64_t)sample << a.logB) * a.capacity;
+    bool dropped = false;
+    uint32_t unstaged_mask = 0;                             // rounds whose words did not fit the staging buffer (skewed tile)
+#pragma unroll 1
+    for (int q = 0; q < ROUNDS; q++) {
+        const uint32_t qb0 = (uint32_t)(((uint64_t)B * q) / ROUNDS), qb1 = (uint32_t)(((uint64_t)B * (q + 1)) / ROUNDS);
+        const uint32_t e0 = s_hist[qb0], e1 = s_hist[qb1];
+        if (e1 - e0 > STAGE_CAP) { unstaged_mask |= 1u << q; continue; }     // uniform
 #pragma unroll
-    for (int j = 0; j < 16; j++)
-        if ((vm >> j) & 1u) {
-            const uint32_t b = (uint32_t)((wv[j] >> 4) >> bshift);
-            const uint32_t r = (rk[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-            a.words[off[b] + s_base[b] + r] = wv[j];
+        for (int j = 0; j < 16; j++) {
+            const uint32_t b = rk[j] >> 16;
+            if (b >= qb0 && b < qb1) s_stage[s_hist[b] - e0 + (rk[j] & 0xFFFFu)] = wv[j];
         }
+        __syncthreads();
+        for (uint32_t i = tid; i < e1 - e0; i += NT) {
+            const uint64_t w = s_stage[i];
+            const uint32_t b = (uint32_t)((w >> 4) >> bshift);
+            const uint32_t r = s_base[b] + e0 + i;
+            if (a.debug_mode == 4) continue;                                                           // profiling: staging only
+            if (r < a.capacity) a.words[(fixed ? reg0 + (uint64_t)b * a.capacity : off[b]) + r] = w; else dropped = true;
+        }
+        __syncthreads();
+    }
+    if (unstaged_mask) {                                    // rare: direct 8-B stores, one element at a time
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t b = rk[j] >> 16;
+            if (b < (uint32_t)B && ((unstaged_mask >> ((uint64_t)b * ROUNDS / B)) & 1u)) {
+                const uint32_t r = s_base[b] + s_hist[b] + (rk[j] & 0xFFFFu);
+                if (r < a.capacity) a.words[off[b] + r] = wv[j]; else dropped = true;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (dropped) *a.overflow = 1;
 }
 
-static inline uint64_t extract_grid(const ExtractArgs &a)
+template <int TILE, int ROUNDS>
+static inline size_t extract_lds(const ExtractArgs &a, bool scatter)
 {
-    uint64_t groups = ((uint64_t)a.n_samples + 7) / 8;
-    return groups * 8ull * (uint64_t)a.tiles_max;
+    size_t codes = (size_t)(TILE / 16 + 8) * 10 + 64;
+    size_t stage = scatter ? (size_t)(TILE / ROUNDS + TILE / (4 * ROUNDS)) * 8 : 0;
+    return ((size_t)8 << a.logB) + 16 + 80 + (stage > codes ? stage : codes);
 }
-void launch_hist(const ExtractArgs &a, hipStream_t st)
+template <bool SCATTER, int TILE, int ROUNDS>
+static void launch_extract_t(const ExtractArgs &a, hipStream_t st)
 {
-    uint64_t g = extract_grid(a);
+    const uint64_t g = (((uint64_t)a.n_samples + 7) / 8) * 8ull * (uint64_t)a.tiles_max;
     if (!g) return;
-    size_t lds = sizeof(uint32_t) << a.logB;
-    hipLaunchKernelGGL(extract_kernel<false>, dim3((unsigned)g), dim3(TILE_THREADS), lds, st, a);
+    const size_t lds = extract_lds<TILE, ROUNDS>(a, SCATTER);
+    hipFuncSetAttribute((const void *)extract_kernel<SCATTER, TILE, ROUNDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((extract_kernel<SCATTER, TILE, ROUNDS>), dim3((unsigned)g), dim3(TILE / 16), lds, st, a);
 }
-void launch_scatter(const ExtractArgs &a, hipStream_t st)
+static int g_extract_variant = -1;
+static int extract_variant()
 {
-    uint64_t g = extract_grid(a);
-    if (!g) return;
-    size_t lds = 2 * (sizeof(uint32_t) << a.logB);
-    hipLaunchKernelGGL(extract_kernel<true>, dim3((unsigned)g), dim3(TILE_THREADS), lds, st, a);
+    if (g_extract_variant < 0) { const char *e = getenv("SKX_EXTRACT_VARIANT"); g_extract_variant = e ? atoi(e) : 0; }
+    return g_extract_variant;
+}
+template <bool SCATTER>
+static void launch_extract(const ExtractArgs &a, hipStream_t st)
+{
+    if (extract_tile_bases(a.logB) == 16384) launch_extract_t<SCATTER, 16384, 2>(a, st);
+    else launch_extract_t<SCATTER, 8192, 2>(a, st);
+}
+int extract_tile_bases(int logB) { return (logB <= 11 && extract_variant() == 0) ? 16384 : 8192; }
+void launch_hist(const ExtractArgs &a, hipStream_t st) { launch_extract<false>(a, st); }
+void launch_scatter(const ExtractArgs &a0, hipStream_t st)
+{
+    ExtractArgs a = a0;
+    if (const char *e = getenv("SKX_SCATTER_MODE")) a.debug_mode = atoi(e);
+    launch_extract<true>(a, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -276,6 +348,14 @@ __global__ __launch_bounds__(1024) void scan_u32_kernel(const uint32_t *in, uint
     }
     if (threadIdx.x == 0) out[n] = carry;
     if (max_out) { atomicMax(&s_max, mx); __syncthreads(); if (threadIdx.x == 0) *max_out = s_max; }
+}
+__global__ void fill_offsets_kernel(uint64_t *off, uint64_t n, uint32_t capacity)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= n; i += (uint64_t)gridDim.x * blockDim.x) off[i] = i * capacity;
+}
+void launch_fill_offsets(uint64_t *off, uint64_t n, uint32_t capacity, hipStream_t st)
+{
+    hipLaunchKernelGGL(fill_offsets_kernel, dim3(1024), dim3(256), 0, st, off, n, capacity);
 }
 void launch_scan_u32(const uint32_t *in, uint64_t *out, uint64_t n, uint32_t *max_out, hipStream_t st)
 {

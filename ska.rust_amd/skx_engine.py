@@ -170,7 +170,7 @@ class Context:
         return {n: getattr(t, n) for n, _ in Timings._fields_}
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and _lib is not None:
             _lib.skx_ctx_destroy(self.h)
             self.h = None
 
@@ -280,7 +280,7 @@ class DictSet:
         return Array(h, self.ctx)
 
     def free(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and _lib is not None:
             _lib.skx_dictset_free(self.h)
             self.h = None
 
@@ -318,7 +318,7 @@ class KeySet:
         return cls(h, ctx)
 
     def free(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and _lib is not None:
             _lib.skx_keyset_free(self.h)
             self.h = None
 
@@ -461,7 +461,7 @@ class Array:
         return _take(p, n)
 
     def free(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and _lib is not None:
             _lib.skx_array_free(self.h)
             self.h = None
 
