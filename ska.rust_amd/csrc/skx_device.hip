@@ -489,15 +489,16 @@ void launch_dedupe(uint64_t *words, const uint64_t *off, const uint32_t *raw, ui
 // K3 (fast path): counting sort of a region into micro-buckets of ~2-4 words by the next hash bits, then a tiny
 // per-thread insertion sort with duplicate folding (OR of base masks).  No CAS loops, no data-dependent probe
 // chains: cost is O(n) LDS operations per region whatever the duplication level.
+template <int ITEMS>
 __global__ __launch_bounds__(256) void dedupe_mb_kernel(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt,
-                                                        uint32_t cap, int rem_bits, int *overflow)
+                                                        uint32_t cap, int rem_bits, int *overflow, int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
     __shared__ uint32_t s_tmp[17];
     const uint64_t region = blockIdx.x;
     const uint32_t n = raw[region];
     if (n == 0) { if (threadIdx.x == 0) ucnt[region] = 0; return; }
-    if (n > cap) { if (threadIdx.x == 0) { *overflow = 1; ucnt[region] = 0; } return; }
+    if (n > cap || n > 256u * ITEMS) { if (threadIdx.x == 0) { *overflow = 1; ucnt[region] = 0; } return; }
     uint64_t *s_elem = reinterpret_cast<uint64_t *>(s_mem);                 // [cap]
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_mem + (size_t)cap * 8); // [M] counts -> cursors -> unique counts
     uint32_t *s_start = s_cnt + cap / 2;                                     // [M] micro-bucket starts
@@ -509,55 +510,109 @@ __global__ __launch_bounds__(256) void dedupe_mb_kernel(uint64_t *words, const u
     const int mshift = rem_bits - logM;                                      // micro-bucket = local >> mshift
     const uint64_t lmask = rem_bits >= 60 ? ~0ull : ((1ull << rem_bits) - 1);
     uint64_t *reg = words + off[region];
-    for (uint32_t i = threadIdx.x; i < M; i += blockDim.x) s_cnt[i] = 0;
+    // the whole region goes into registers with all loads in flight at once (word 0 never occurs: base masks are non-zero)
+    uint64_t e[ITEMS];
+#pragma unroll
+    for (int t = 0; t < ITEMS; t++) { const uint32_t i = threadIdx.x + 256u * t; e[t] = i < n ? reg[i] : 0ull; }
+    for (uint32_t i = threadIdx.x; i < M; i += 256) s_cnt[i] = 0;
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&s_cnt[(uint32_t)(((reg[i] >> 4) & lmask) >> mshift)], 1u);
+#pragma unroll
+    for (int t = 0; t < ITEMS; t++) if (e[t]) atomicAdd(&s_cnt[(uint32_t)(((e[t] >> 4) & lmask) >> mshift)], 1u);
     __syncthreads();
+    if (dbg == 1) return;
     // exclusive scan of the counts (each thread owns R consecutive micro-buckets)
-    const uint32_t R = (M + blockDim.x - 1) / blockDim.x;
-    const uint32_t m0 = threadIdx.x * R, m1 = m0 + R < M ? m0 + R : M;
+    const uint32_t R = (M + 255) / 256;
+    const uint32_t m0 = threadIdx.x * R < M ? threadIdx.x * R : M, m1 = m0 + R < M ? m0 + R : M;
     uint32_t sum = 0;
     for (uint32_t m = m0; m < m1; m++) sum += s_cnt[m];
     uint32_t run = block_excl_scan(sum, s_tmp, nullptr);
     for (uint32_t m = m0; m < m1; m++) { uint32_t c = s_cnt[m]; s_start[m] = run; s_cnt[m] = run; run += c; }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint64_t w = reg[i];
-        s_elem[atomicAdd(&s_cnt[(uint32_t)(((w >> 4) & lmask) >> mshift)], 1u)] = w;
+    uint32_t pos[ITEMS];
+#pragma unroll
+    for (int t = 0; t < ITEMS; t++) {
+        pos[t] = 0;
+        if (e[t]) { pos[t] = atomicAdd(&s_cnt[(uint32_t)(((e[t] >> 4) & lmask) >> mshift)], 1u); s_elem[pos[t]] = e[t]; }
+    }
+    if (threadIdx.x == 0) s_start[M] = n;
+    __syncthreads();
+    if (dbg == 2) return;
+    // rank every word inside its micro-bucket (all words in parallel, 4 LDS reads in flight per step): sorted position =
+    // start + #smaller keys + #equal keys at lower positions; equal keys also fold their base masks together
+    // position-ordered from here on (p = tid + 256 t): neighbouring lanes touch neighbouring LDS words, so the random-bank
+    // conflicts of the scatter above do not come back.  Rank of a word inside its micro-bucket = #smaller keys + #equal
+    // keys at lower positions; equal keys also fold their base masks together.
+    uint32_t npos[ITEMS];
+#pragma unroll
+    for (int t = 0; t < ITEMS; t++) {
+        const uint32_t p = threadIdx.x + 256u * t;
+        npos[t] = 0; e[t] = 0;
+        if (p >= n) continue;
+        const uint64_t w0 = s_elem[p], key = w0 >> 4;
+        const uint32_t m = (uint32_t)((key & lmask) >> mshift);
+        const uint32_t b = s_start[m], eend = s_start[m + 1];
+        uint32_t less = 0, eqb = 0, mor = (uint32_t)w0 & 15u;
+        for (uint32_t j = b; j < eend; j++) {
+            const uint64_t w = s_elem[j], kj = w >> 4;
+            less += kj < key;
+            const bool iseq = kj == key;
+            eqb += iseq && j < p;
+            mor |= iseq ? (uint32_t)w & 15u : 0u;
+        }
+        npos[t] = b + less + eqb;
+        e[t] = (w0 & ~15ull) | mor;
     }
     __syncthreads();
-    // per micro-bucket: insertion sort with duplicate folding, in place; s_cnt[m] <- distinct count
-    uint32_t usum = 0;
-    for (uint32_t m = m0; m < m1; m++) {
-        const uint32_t b = s_start[m], e = s_cnt[m];
-        uint32_t u = 0;
-        for (uint32_t i = b; i < e; i++) {
-            const uint64_t w = s_elem[i], key = w >> 4;
-            uint32_t p = u;
-            while (p > 0 && (s_elem[b + p - 1] >> 4) > key) p--;
-            if (p > 0 && (s_elem[b + p - 1] >> 4) == key) { s_elem[b + p - 1] |= w & 15ull; continue; }
-            for (uint32_t q = u; q > p; q--) s_elem[b + q] = s_elem[b + q - 1];
-            s_elem[b + p] = w;
-            u++;
-        }
-        s_cnt[m] = u; usum += u;
+#pragma unroll
+    for (int t = 0; t < ITEMS; t++) if (e[t]) s_elem[npos[t]] = e[t];
+    __syncthreads();
+    if (dbg == 3) return;
+    // keep the first word of every run of equal keys; compaction index from wave ballots + a tiny per-row table
+    uint32_t *s_rows = s_cnt;                               // [ITEMS][4] leaders per (row, wave); counters are dead now
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t flags = 0, below[ITEMS];
+#pragma unroll
+    for (int t = 0; t < ITEMS; t++) {
+        const uint32_t p = threadIdx.x + 256u * t;
+        bool lead = false;
+        if (p < n) { e[t] = s_elem[p]; lead = p == 0 || (s_elem[p - 1] >> 4) != (e[t] >> 4); }
+        const unsigned long long bal = __ballot(lead);
+        below[t] = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lead) flags |= 1u << t;
+        if (lane == 0) s_rows[t * 4 + wv] = __popcll(bal);
     }
-    uint32_t total;
-    uint32_t o = block_excl_scan(usum, s_tmp, &total);
-    for (uint32_t m = m0; m < m1; m++) {
-        const uint32_t b = s_start[m], u = s_cnt[m];
-        for (uint32_t i = 0; i < u; i++) reg[o + i] = s_elem[b + i];
-        o += u;
+    __syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (int t = 0; t < ITEMS; t++) {
+        uint32_t rowsum = 0, before = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { const uint32_t c = s_rows[t * 4 + w]; before += w < wv ? c : 0u; rowsum += c; }
+        if ((flags >> t) & 1u) reg[base + before + below[t]] = e[t];
+        base += rowsum;
     }
+    const uint32_t total = base;
     if (threadIdx.x == 0) ucnt[region] = total;
+}
+template <int ITEMS>
+static void launch_dedupe_items(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_regions, uint32_t cap,
+                                int rem_bits, int *overflow, size_t lds, hipStream_t st)
+{
+    hipFuncSetAttribute((const void *)dedupe_mb_kernel<ITEMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const char *e = getenv("SKX_DEDUPE_MODE");
+    hipLaunchKernelGGL(dedupe_mb_kernel<ITEMS>, dim3((unsigned)n_regions), dim3(256), lds, st, words, off, raw, ucnt, cap, rem_bits, overflow, e ? atoi(e) : 0);
 }
 void launch_dedupe_mb(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_regions, uint32_t cap,
                       int rem_bits, int *overflow, hipStream_t st)
 {
     if (!n_regions) return;
-    size_t lds = (size_t)cap * 8 + (size_t)cap * 4;       // elements + two u32 arrays of cap/2
-    hipFuncSetAttribute((const void *)dedupe_mb_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(dedupe_mb_kernel, dim3((unsigned)n_regions), dim3(256), lds, st, words, off, raw, ucnt, cap, rem_bits, overflow);
+    size_t lds = (size_t)cap * 8 + (size_t)cap * 4 + 16;  // elements + two u32 arrays of cap/2 (+ sentinel)
+    const uint32_t items = (cap + 255) / 256;
+    if (items <= 4) launch_dedupe_items<4>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, lds, st);
+    else if (items <= 8) launch_dedupe_items<8>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, lds, st);
+    else if (items <= 14) launch_dedupe_items<14>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, lds, st);
+    else if (items <= 24) launch_dedupe_items<24>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, lds, st);
+    else launch_dedupe_items<52>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, lds, st);
 }
 
 // first index in [0,n) whose hashed key (word >> 4) is >= x
