@@ -638,7 +638,7 @@ __device__ static inline void sub_slice(const DictView &d, int sample, uint64_t 
 
 // K4: distinct keys of sub-bucket j over all samples -> sorted slab
 template <bool COUNT_ONLY>
-__global__ __launch_bounds__(256) void union_kernel(DictView d, int logN, uint64_t *stage, uint32_t stride, uint32_t *ncnt,
+__global__ __launch_bounds__(1024) void union_kernel(DictView d, int logN, uint64_t *stage, uint32_t stride, uint32_t *ncnt,
                                                     uint32_t nslots, int *overflow)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_tab[];
@@ -683,13 +683,13 @@ void launch_union(const DictView &d, int logN, uint64_t *stage, uint32_t stride,
 {
     size_t lds = (size_t)(table_slots + TABLE_PAD) * 8;
     hipFuncSetAttribute((const void *)union_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(union_kernel<false>, dim3(1u << logN), dim3(256), lds, st, d, logN, stage, stride, ncnt, table_slots, overflow);
+    hipLaunchKernelGGL(union_kernel<false>, dim3(1u << logN), dim3(1024), lds, st, d, logN, stage, stride, ncnt, table_slots, overflow);
 }
 void launch_union_probe(const DictView &d, int logP, int probe, uint32_t *cnt, uint32_t table_slots, int *overflow, hipStream_t st)
 {
     size_t lds = (size_t)(table_slots + TABLE_PAD) * 8;
     hipFuncSetAttribute((const void *)union_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(union_kernel<true>, dim3((unsigned)probe), dim3(256), lds, st, d, logP, (uint64_t *)nullptr, 0u, cnt, table_slots, overflow);
+    hipLaunchKernelGGL(union_kernel<true>, dim3((unsigned)probe), dim3(1024), lds, st, d, logP, (uint64_t *)nullptr, 0u, cnt, table_slots, overflow);
 }
 
 // IUPAC letter of a base set; bit i of the set == 2-bit code i (A0 C1 T2 G3), cf. bit_encoding.rs:337-368
@@ -714,41 +714,48 @@ __global__ __launch_bounds__(512) void assemble_kernel(AssembleArgs a)
     const uint64_t r0 = a.roff[j];
     const uint32_t shift = (uint32_t)(r0 & 15u);
     unsigned char *row = s_rows + (size_t)wv * (maxr + 32u);      // 16-B aligned; cell i lives at row[shift + i]
-    for (int s = wv; s < a.d.n_samples; s += nw) {
-        // fill with '-'
-        for (uint32_t i = lane * 4; i < n + shift + 3; i += 256) *reinterpret_cast<uint32_t *>(row + i) = 0x2D2D2D2Du;
-        __builtin_amdgcn_wave_barrier();
-        const uint64_t *reg; uint32_t lo, hi;
-        sub_slice(a.d, s, j, a.logN, reg, lo, hi);
-        for (uint32_t i = lo + lane; i < hi; i += 64) {
-            const uint64_t w = reg[i];
-            const uint64_t key = w >> 4;
-            uint32_t l = 0, r = n;
-            while (l < r) { uint32_t m = (l + r) >> 1; if (s_keys[m] < key) l = m + 1; else r = m; }
-            if (l < n && s_keys[l] == key) {
-                const uint32_t m4 = (uint32_t)(w & 15u);
-                row[shift + l] = (unsigned char)MASK2IUPAC_D[m4];
-                const uint32_t single = (m4 & (m4 - 1)) == 0;
-                atomicAdd(&s_cnt[l], 1u | (single << 16));
-                atomicOr(&s_msk[l], 1u << m4);
-            } else {
-                *a.missing = 1;
+    // every lane binary-searches the slice of one sample (64 searches in flight); the wave then handles the slices in turn
+    for (int sbase = wv * 64; sbase < a.d.n_samples; sbase += nw * 64) {
+        const uint64_t *my_reg = nullptr; uint32_t my_lo = 0, my_hi = 0;
+        if (sbase + lane < a.d.n_samples) sub_slice(a.d, sbase + lane, j, a.logN, my_reg, my_lo, my_hi);
+        const int cnt = a.d.n_samples - sbase < 64 ? a.d.n_samples - sbase : 64;
+        for (int t = 0; t < cnt; t++) {
+            const int s = sbase + t;
+            const uint64_t *reg = reinterpret_cast<const uint64_t *>(__shfl((unsigned long long)my_reg, t, 64));
+            const uint32_t lo = __shfl(my_lo, t, 64), hi = __shfl(my_hi, t, 64);
+            // fill with '-'
+            for (uint32_t i = lane * 4; i < n + shift + 3; i += 256) *reinterpret_cast<uint32_t *>(row + i) = 0x2D2D2D2Du;
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t i = lo + lane; i < hi; i += 64) {
+                const uint64_t w = reg[i];
+                const uint64_t key = w >> 4;
+                uint32_t l = 0, r = n;
+                while (l < r) { uint32_t m = (l + r) >> 1; if (s_keys[m] < key) l = m + 1; else r = m; }
+                if (l < n && s_keys[l] == key) {
+                    const uint32_t m4 = (uint32_t)(w & 15u);
+                    row[shift + l] = (unsigned char)MASK2IUPAC_D[m4];
+                    const uint32_t single = (m4 & (m4 - 1)) == 0;
+                    atomicAdd(&s_cnt[l], 1u | (single << 16));
+                    atomicOr(&s_msk[l], 1u << m4);
+                } else {
+                    *a.missing = 1;
+                }
             }
+            __builtin_amdgcn_wave_barrier();
+            // copy out: global column r0 + i  <-  row[shift + i]; 16-B body, byte head/tail
+            unsigned char *dst = a.matrix + (uint64_t)s * a.pitch + r0;
+            const uint32_t head = (16u - shift) & 15u;
+            const uint32_t h = head < n ? head : n;
+            if ((uint32_t)lane < h) dst[lane] = row[shift + lane];
+            const uint32_t body = (n - h) / 16u;
+            for (uint32_t v = lane; v < body; v += 64) {
+                const uint4 x = *reinterpret_cast<const uint4 *>(row + shift + h + 16u * v);
+                *reinterpret_cast<uint4 *>(dst + h + 16u * v) = x;
+            }
+            const uint32_t done = h + body * 16u;
+            if (done + lane < n) dst[done + lane] = row[shift + done + lane];
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
-        // copy out: global column r0 + i  <-  row[shift + i]; 16-B body, byte head/tail
-        unsigned char *dst = a.matrix + (uint64_t)s * a.pitch + r0;
-        const uint32_t head = (16u - shift) & 15u;
-        const uint32_t h = head < n ? head : n;
-        if ((uint32_t)lane < h) dst[lane] = row[shift + lane];
-        const uint32_t body = (n - h) / 16u;
-        for (uint32_t v = lane; v < body; v += 64) {
-            const uint4 x = *reinterpret_cast<const uint4 *>(row + shift + h + 16u * v);
-            *reinterpret_cast<uint4 *>(dst + h + 16u * v) = x;
-        }
-        const uint32_t done = h + body * 16u;
-        if (done + lane < n) dst[done + lane] = row[shift + done + lane];
-        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
