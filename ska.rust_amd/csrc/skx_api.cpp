@@ -147,7 +147,8 @@ int check_k(int k)
 }
 int ilog2_ceil(uint64_t x) { int l = 0; while ((1ull << l) < x) l++; return l; }
 constexpr uint32_t LDS_TABLE_MAX = 18000;     // slots (+ pad) of 8 B must stay below 160 KiB
-constexpr uint32_t LDS_SORT_MAX = 13312;      // words of the per-region counting sort (12 B each)
+constexpr uint32_t LDS_SORT_MAX = 6144;       // words per region of the counting sort (24 per thread in registers)
+constexpr uint32_t LDS_SORT_MAX_WIDE = 4096;  // 128-bit path (16 per thread)
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ dictset
@@ -163,12 +164,14 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
     bool any_qual = false;
     for (auto p : quals) any_qual |= p != nullptr;
     if (any_qual && q && q->min_count > 1) { set_error("FASTQ min-count filter (min_count > 1) is not available on the device path yet"); return SKX_EUNSUP; }
-    if (k > 31) { set_error("k > 31 (128-bit split k-mers) is not available on the device path yet"); return SKX_EUNSUP; }
-
+    const bool wide = k > 31;                                   // lib.rs:592: u64 for k <= 31, u128 above
     uint64_t maxlen = 0;
     for (auto l : lens) maxlen = std::max(maxlen, l);
-    HashParams hp = make_hash_params(k);
-    int logB = std::min({ilog2_ceil((maxlen + 4095) / 4096), hp.bits, MAX_LOGB});      // ~2-4 k windows per bucket
+    HashParams hp = make_hash_params(std::min(k, 31));
+    WideHash wh = make_wide_hash(k);
+    const int key_bits_used = 2 * (k - 1);
+    const uint64_t per_region = wide ? 2048 : 4096;                                           // target windows per bucket (upper bound)
+    int logB = std::min({ilog2_ceil((maxlen + per_region - 1) / per_region), key_bits_used, MAX_LOGB});
     if (logB < 0) logB = 0;
 
     DevBuf<const uint8_t *> d_seqs, d_quals;
@@ -183,24 +186,27 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
     bool exact = false;        // single pass with fixed-capacity regions first; exact two-pass layout if a region overflows
     for (;;) {
         std::unique_ptr<skx_dictset> d(new skx_dictset());
-        d->ctx = ctx; d->n = n; d->k = k; d->rc = rc; d->logB = logB; d->hp = hp; d->key_bits = 64;
+        d->ctx = ctx; d->n = n; d->k = k; d->rc = rc; d->logB = logB; d->hp = hp; d->wh = wh; d->key_bits = wide ? 128 : 64;
+        const int wpk = wide ? 2 : 1;
+        const int tile_bases = wide ? extract_tile_bases_wide() : extract_tile_bases(logB);
         const uint64_t nreg = (uint64_t)n << logB;
         SKX_TRY(d->raw.alloc(nreg)); SKX_TRY(d->ucnt.alloc(nreg)); SKX_TRY(d->off.alloc(nreg + 1));
         SKX_TRY(d->raw.zero(st)); SKX_TRY(d_flag.zero(st));
 
         ExtractArgs a{};
         a.seqs = d_seqs.p; a.quals = any_qual ? d_quals.p : nullptr; a.lens = d_lens.p; a.n_samples = n;
-        a.tiles_max = (int)((maxlen + extract_tile_bases(logB) - 1) / extract_tile_bases(logB));
+        a.tiles_max = (int)((maxlen + tile_bases - 1) / tile_bases);
         a.k = k; a.rc = rc; a.min_qual = q ? q->min_qual : 0; a.qual_filter = q ? q->qual_filter : 0;
-        a.logB = logB; a.hp = hp; a.overflow = d_flag.p;
+        a.logB = logB; a.hp = hp; a.wh = wh; a.overflow = d_flag.p;
         uint32_t lds_cap;
         if (!exact) {
             // hashed buckets are Poisson around len/B: 20 % + 256 words of head-room covers ordinary repeat content
             const uint64_t mean = (maxlen >> logB) + 1;
             const uint32_t region_cap = (uint32_t)std::min<uint64_t>(((mean + mean / 5 + 256) + 63) / 64 * 64, 0x7FFFFFFFull);
             launch_fill_offsets(d->off.p, nreg, region_cap, st);
-            SKX_TRY(d->words.alloc(nreg * (uint64_t)region_cap));
-            { StageTimer t(ctx, &ctx->tm.scatter); a.hist = d->raw.p; a.off = d->off.p; a.words = d->words.p; a.capacity = region_cap; launch_scatter(a, st); }
+            SKX_TRY(d->words.alloc(nreg * (uint64_t)region_cap * wpk));
+            { StageTimer t(ctx, &ctx->tm.scatter); a.hist = d->raw.p; a.off = d->off.p; a.words = d->words.p; a.capacity = region_cap;
+              if (wide) launch_scatter_wide(a, st); else launch_scatter(a, st); }
             int over = 0;
             SKX_HIP(hipMemcpyAsync(&over, d_flag.p, 4, hipMemcpyDeviceToHost, st));
             SKX_HIP(hipStreamSynchronize(st));
@@ -209,20 +215,23 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
         } else {
             DevBuf<uint32_t> d_cursor, d_max;
             SKX_TRY(d_cursor.alloc(nreg)); SKX_TRY(d_max.alloc(1)); SKX_TRY(d_cursor.zero(st));
-            { StageTimer t(ctx, &ctx->tm.hist); a.hist = d->raw.p; launch_hist(a, st); }
+            { StageTimer t(ctx, &ctx->tm.hist); a.hist = d->raw.p; if (wide) launch_hist_wide(a, st); else launch_hist(a, st); }
             launch_scan_u32(d->raw.p, d->off.p, nreg, d_max.p, st);
             uint64_t total = 0; uint32_t max_raw = 0;
             SKX_HIP(hipMemcpyAsync(&total, d->off.p + nreg, 8, hipMemcpyDeviceToHost, st));
             SKX_HIP(hipMemcpyAsync(&max_raw, d_max.p, 4, hipMemcpyDeviceToHost, st));
             SKX_HIP(hipStreamSynchronize(st));
-            SKX_TRY(d->words.alloc(total));
-            { StageTimer t(ctx, &ctx->tm.scatter); a.hist = d_cursor.p; a.off = d->off.p; a.words = d->words.p; a.capacity = 0xFFFFFFFFu; launch_scatter(a, st); }
+            SKX_TRY(d->words.alloc(total * wpk));
+            { StageTimer t(ctx, &ctx->tm.scatter); a.hist = d_cursor.p; a.off = d->off.p; a.words = d->words.p; a.capacity = 0xFFFFFFFFu;
+              if (wide) launch_scatter_wide(a, st); else launch_scatter(a, st); }
             lds_cap = max_raw;
         }
         // LDS capacity (words) of the per-region counting sort: 12 B per word, <= 160 KiB
-        uint32_t cap = std::max<uint32_t>(512, (uint32_t)std::min<uint64_t>(((uint64_t)lds_cap + 255) / 256 * 256, LDS_SORT_MAX));
+        uint32_t cap = std::max<uint32_t>(512, (uint32_t)std::min<uint64_t>(((uint64_t)lds_cap + 255) / 256 * 256, wide ? LDS_SORT_MAX_WIDE : LDS_SORT_MAX));
         SKX_TRY(d_flag.zero(st));
-        { StageTimer t(ctx, &ctx->tm.dedupe); launch_dedupe_mb(d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, cap, hp.bits - logB, d_flag.p, st); }
+        { StageTimer t(ctx, &ctx->tm.dedupe);
+          if (wide) launch_dedupe_wide((u128 *)d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, cap, key_bits_used - logB, d_flag.p, st);
+          else launch_dedupe_mb(d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, cap, hp.bits - logB, d_flag.p, st); }
         int overflow = 0;
         SKX_HIP(hipMemcpyAsync(&overflow, d_flag.p, 4, hipMemcpyDeviceToHost, st));
         std::vector<uint32_t> ucnt(nreg);
@@ -230,7 +239,7 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
         SKX_HIP(hipStreamSynchronize(st));
         SKX_HIP(hipGetLastError());
         if (overflow) {
-            if (logB >= std::min(hp.bits, MAX_LOGB)) { set_error("sample too large for the device dictionary (more than %u split k-mer occurrences in one of %d buckets)", LDS_SORT_MAX, 1 << logB); return SKX_EUNSUP; }
+            if (logB >= std::min(key_bits_used, MAX_LOGB)) { set_error("sample too large for the device dictionary (more than %u split k-mer occurrences in one of %d buckets)", LDS_SORT_MAX, 1 << logB); return SKX_EUNSUP; }
             logB++;
             continue;
         }
@@ -333,17 +342,30 @@ extern "C" int skx_dictset_export(skx_dictset *d, int sample, skx_key *keys, uin
     SKX_HIP(hipMemcpyAsync(off.data(), d->off.p + ((uint64_t)sample << d->logB), (B + 1) * 8, hipMemcpyDeviceToHost, st));
     SKX_HIP(hipMemcpyAsync(uc.data(), d->ucnt.p + ((uint64_t)sample << d->logB), B * 4, hipMemcpyDeviceToHost, st));
     SKX_HIP(hipStreamSynchronize(st));
-    DevBuf<uint64_t> dk; DevBuf<uint8_t> db;
-    SKX_TRY(dk.alloc(sz)); SKX_TRY(db.alloc(sz));
-    uint64_t w = 0;
-    for (uint64_t b = 0; b < B; b++) { launch_unhash_dict(d->words.p + off[b], uc[b], dk.p + w, db.p + w, d->hp, st); w += uc[b]; }
-    std::vector<uint64_t> hk(sz); std::vector<uint8_t> hb(sz);
-    SKX_HIP(hipMemcpyAsync(hk.data(), dk.p, sz * 8, hipMemcpyDeviceToHost, st));
-    SKX_HIP(hipMemcpyAsync(hb.data(), db.p, sz, hipMemcpyDeviceToHost, st));
-    SKX_HIP(hipStreamSynchronize(st));
+    std::vector<skx_key> hk(sz); std::vector<uint8_t> hb(sz);
+    static const char M2I[17] = "-ACMTWYHGRSVKDBN";
+    const int wpk = d->wide() ? 2 : 1;
+    {
+        std::vector<uint64_t> raw((size_t)sz * wpk);
+        uint64_t w = 0;
+        for (uint64_t b = 0; b < B; b++) {
+            if (uc[b]) SKX_HIP(hipMemcpyAsync(raw.data() + w * wpk, d->words.p + off[b] * wpk, (size_t)uc[b] * 8 * wpk, hipMemcpyDeviceToHost, st));
+            w += uc[b];
+        }
+        SKX_HIP(hipStreamSynchronize(st));
+        for (uint64_t i = 0; i < sz; i++) {
+            if (d->wide()) {
+                const u128 word = ((u128)raw[2 * i + 1] << 64) | raw[2 * i];
+                const u128 key = hunmix_w(word >> 4, d->wh);
+                hk[i].lo = (uint64_t)key; hk[i].hi = (uint64_t)(key >> 64); hb[i] = (uint8_t)M2I[(unsigned)word & 15u];
+            } else {
+                hk[i].lo = hunmix(raw[i] >> 4, d->hp); hk[i].hi = 0; hb[i] = (uint8_t)M2I[raw[i] & 15u];
+            }
+        }
+    }
     std::vector<uint64_t> idx(sz); std::iota(idx.begin(), idx.end(), 0);
-    std::sort(idx.begin(), idx.end(), [&](uint64_t a, uint64_t b2) { return hk[a] < hk[b2]; });
-    for (uint64_t i = 0; i < sz; i++) { if (keys) { keys[i].lo = hk[idx[i]]; keys[i].hi = 0; } if (bases) bases[i] = hb[idx[i]]; }
+    std::sort(idx.begin(), idx.end(), [&](uint64_t a, uint64_t b2) { return hk[a].hi != hk[b2].hi ? hk[a].hi < hk[b2].hi : hk[a].lo < hk[b2].lo; });
+    for (uint64_t i = 0; i < sz; i++) { if (keys) keys[i] = hk[idx[i]]; if (bases) bases[i] = hb[idx[i]]; }
     return SKX_OK;
     });
 }
@@ -368,20 +390,24 @@ static int keyset_finish(skx_keyset *ks)      // scan ncnt -> roff, total, max_r
 // union over several dict views (one per source) into one keyset
 static int keyset_union_views(skx_ctx *ctx, const DictView *views, int nviews, int k, int rc, HashParams hp, uint64_t est_hint, skx_keyset **out)
 {
+    const bool wide = k > 31;
+    const WideHash wh = make_wide_hash(k);
+    const int kbits = 2 * (k - 1);
     hipStream_t st = ctx->stream;
     DevBuf<int> d_flag; SKX_TRY(d_flag.alloc(1));
     int min_logN = 0;
     for (int v = 0; v < nviews; v++) min_logN = std::max(min_logN, views[v].logB);
-    const uint32_t table = 8192, stride = 4096, target = 2500;
-    int logN = std::max(min_logN, std::min(hp.bits, ilog2_ceil((est_hint + target - 1) / target)));
+    const uint32_t table = wide ? 4096 : 8192, stride = wide ? 2048 : 4096, target = wide ? 1200 : 2500;
+    int logN = std::max(min_logN, std::min(kbits, ilog2_ceil((est_hint + target - 1) / target)));
     for (;; logN++) {
         std::unique_ptr<skx_keyset> ks(new skx_keyset());
-        ks->ctx = ctx; ks->k = k; ks->rc = rc; ks->logN = logN; ks->hp = hp; ks->stride = stride;
+        ks->ctx = ctx; ks->k = k; ks->rc = rc; ks->logN = logN; ks->hp = hp; ks->wh = wh; ks->wide = wide; ks->stride = stride;
         const uint64_t nsub = 1ull << logN;
-        SKX_TRY(ks->stage.alloc(nsub * stride)); SKX_TRY(ks->ncnt.alloc(nsub));
+        SKX_TRY(ks->stage.alloc(nsub * stride * ks->wpk())); SKX_TRY(ks->ncnt.alloc(nsub));
         SKX_TRY(d_flag.zero(st));
         if (nviews == 1) {
-            launch_union(views[0], logN, ks->stage.p, stride, ks->ncnt.p, table, d_flag.p, st);
+            if (wide) launch_union_wide(views[0], logN, (u128 *)ks->stage.p, stride, ks->ncnt.p, table, d_flag.p, st);
+            else launch_union(views[0], logN, ks->stage.p, stride, ks->ncnt.p, table, d_flag.p, st);
         } else {
             set_error("multi-source union goes through keyset_merge"); return SKX_EINVAL;
         }
@@ -390,7 +416,7 @@ static int keyset_union_views(skx_ctx *ctx, const DictView *views, int nviews, i
         SKX_HIP(hipStreamSynchronize(st));
         SKX_HIP(hipGetLastError());
         if (overflow) {
-            if (logN >= hp.bits) { set_error("key union overflow"); return SKX_EUNSUP; }
+            if (logN >= kbits) { set_error("key union overflow"); return SKX_EUNSUP; }
             continue;
         }
         SKX_TRY(keyset_finish(ks.get()));
@@ -412,11 +438,12 @@ extern "C" int skx_keyset_union(skx_ctx *ctx, skx_dictset *d, skx_keyset **out)
     for (auto s : d->sample_size) { maxs = std::max(maxs, s); sum += s; }
     uint64_t est = maxs;
     if (d->n > 1) {
-        const int logP = std::min(d->hp.bits, std::max(d->logB, ilog2_ceil((sum + 1023) / 1024)));
+        const int logP = std::min(2 * (d->k - 1), std::max(d->logB, ilog2_ceil((sum + 1023) / 1024)));
         const int probe = (int)std::min<uint64_t>(64, 1ull << logP);
         DevBuf<uint32_t> d_cnt; DevBuf<int> d_flag;
         SKX_TRY(d_cnt.alloc(1)); SKX_TRY(d_flag.alloc(1)); SKX_TRY(d_cnt.zero(st)); SKX_TRY(d_flag.zero(st));
-        launch_union_probe(v, logP, probe, d_cnt.p, 8192, d_flag.p, st);
+        if (d->wide()) launch_union_probe_wide(v, logP, probe, d_cnt.p, 4096, d_flag.p, st);
+        else launch_union_probe(v, logP, probe, d_cnt.p, 8192, d_flag.p, st);
         uint32_t cnt = 0; int ov = 0;
         SKX_HIP(hipMemcpyAsync(&cnt, d_cnt.p, 4, hipMemcpyDeviceToHost, st));
         SKX_HIP(hipMemcpyAsync(&ov, d_flag.p, 4, hipMemcpyDeviceToHost, st));
@@ -431,8 +458,9 @@ extern "C" int skx_keyset_union(skx_ctx *ctx, skx_dictset *d, skx_keyset **out)
 static int keyset_flatten(skx_keyset *ks)
 {
     if (ks->flat.p) return SKX_OK;
-    SKX_TRY(ks->flat.alloc(ks->total));
-    launch_gather_keys(ks->stage.p, ks->stride, ks->ncnt.p, ks->roff.p, 1 << ks->logN, ks->flat.p, 0, ks->hp, ks->ctx->stream);
+    SKX_TRY(ks->flat.alloc(ks->total * ks->wpk()));
+    if (ks->wide) launch_gather_keys_wide((const u128 *)ks->stage.p, ks->stride, ks->ncnt.p, ks->roff.p, 1 << ks->logN, (u128 *)ks->flat.p, ks->ctx->stream);
+    else launch_gather_keys(ks->stage.p, ks->stride, ks->ncnt.p, ks->roff.p, 1 << ks->logN, ks->flat.p, 0, ks->hp, ks->ctx->stream);
     return SKX_OK;
 }
 
@@ -442,7 +470,7 @@ extern "C" int skx_keyset_device(skx_keyset *ks, const void **dptr, uint64_t *n_
     SKX_HIP(hipSetDevice(ks->ctx->device));
     SKX_TRY(keyset_flatten(ks));
     SKX_HIP(hipStreamSynchronize(ks->ctx->stream));
-    *dptr = ks->flat.p; *n_keys = ks->total; if (words_per_key) *words_per_key = 1;
+    *dptr = ks->flat.p; *n_keys = ks->total; if (words_per_key) *words_per_key = ks->wpk();
     return SKX_OK;
     });
 }
@@ -451,7 +479,7 @@ extern "C" int skx_keyset_device(skx_keyset *ks, const void **dptr, uint64_t *n_
 static int keyset_from_flat(skx_ctx *ctx, DevBuf<uint64_t> &&flat, uint64_t n, int k, int rc, skx_keyset **out)
 {
     std::unique_ptr<skx_keyset> ks(new skx_keyset());
-    ks->ctx = ctx; ks->k = k; ks->rc = rc; ks->hp = make_hash_params(k); ks->logN = -1; ks->total = n;
+    ks->ctx = ctx; ks->k = k; ks->rc = rc; ks->hp = make_hash_params(std::min(k, 31)); ks->wh = make_wide_hash(k); ks->wide = k > 31; ks->logN = -1; ks->total = n;
     ks->flat = std::move(flat);
     *out = ks.release();
     return SKX_OK;
@@ -461,10 +489,10 @@ extern "C" int skx_keyset_from_device(skx_ctx *ctx, const void *dptr, uint64_t n
 {
     return skx_guarded([&]() -> int {
     SKX_TRY(check_k(k));
-    if (k > 31) { set_error("k > 31 not available on the device path yet"); return SKX_EUNSUP; }
     SKX_HIP(hipSetDevice(ctx->device));
-    DevBuf<uint64_t> flat; SKX_TRY(flat.alloc(n_keys));
-    SKX_HIP(hipMemcpyAsync(flat.p, dptr, n_keys * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    const int wpk = k > 31 ? 2 : 1;
+    DevBuf<uint64_t> flat; SKX_TRY(flat.alloc(n_keys * wpk));
+    SKX_HIP(hipMemcpyAsync(flat.p, dptr, n_keys * 8 * wpk, hipMemcpyDeviceToDevice, ctx->stream));
     return keyset_from_flat(ctx, std::move(flat), n_keys, k, rc, out);
     });
 }
@@ -485,17 +513,18 @@ extern "C" int skx_keyset_merge(skx_ctx *ctx, skx_keyset *const *sets, int n_set
         total += sets[i]->total; maxn = std::max(maxn, sets[i]->total);
     }
     DevBuf<uint64_t> words, off; DevBuf<uint32_t> ucnt;
-    SKX_TRY(words.alloc(total)); SKX_TRY(off.alloc(n_sets + 1)); SKX_TRY(ucnt.alloc(n_sets));
+    const int wpk = sets[0]->wpk();
+    SKX_TRY(words.alloc(total * wpk)); SKX_TRY(off.alloc(n_sets + 1)); SKX_TRY(ucnt.alloc(n_sets));
     std::vector<uint64_t> h_off(n_sets + 1, 0); std::vector<uint32_t> h_cnt(n_sets);
     for (int i = 0; i < n_sets; i++) {
         if (sets[i]->total > 0xFFFFFFFFull) { set_error("keyset too large"); return SKX_EUNSUP; }
         h_cnt[i] = (uint32_t)sets[i]->total; h_off[i + 1] = h_off[i] + sets[i]->total;
-        SKX_HIP(hipMemcpyAsync(words.p + h_off[i], sets[i]->flat.p, sets[i]->total * 8, hipMemcpyDeviceToDevice, st));
+        SKX_HIP(hipMemcpyAsync(words.p + h_off[i] * wpk, sets[i]->flat.p, sets[i]->total * 8 * wpk, hipMemcpyDeviceToDevice, st));
     }
     SKX_HIP(hipMemcpyAsync(off.p, h_off.data(), (n_sets + 1) * 8, hipMemcpyHostToDevice, st));
     SKX_HIP(hipMemcpyAsync(ucnt.p, h_cnt.data(), n_sets * 4, hipMemcpyHostToDevice, st));
     HashParams hp = sets[0]->hp;
-    DictView v{words.p, off.p, ucnt.p, n_sets, 0, hp.bits};
+    DictView v{words.p, off.p, ucnt.p, n_sets, 0, 2 * (sets[0]->k - 1)};
     int r = keyset_union_views(ctx, &v, 1, sets[0]->k, sets[0]->rc, hp, std::min(total, maxn * 2), out);
     SKX_HIP(hipStreamSynchronize(st));
     return r;
@@ -535,7 +564,7 @@ extern "C" int skx_array_assemble(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows
         uint64_t h_off[2] = {0, rows->total}; uint32_t h_cnt = (uint32_t)rows->total;
         SKX_HIP(hipMemcpyAsync(off.p, h_off, 16, hipMemcpyHostToDevice, st));
         SKX_HIP(hipMemcpyAsync(ucnt.p, &h_cnt, 4, hipMemcpyHostToDevice, st));
-        DictView v{rows->flat.p, off.p, ucnt.p, 1, 0, rows->hp.bits};
+        DictView v{rows->flat.p, off.p, ucnt.p, 1, 0, 2 * (rows->k - 1)};
         // force logN >= d->logB by passing a view whose logB is the dict's (single bucket list still valid for logB 0 only)
         (void)one;
         uint64_t hint = std::max<uint64_t>(rows->total, (uint64_t)2500 << d->logB);
@@ -546,20 +575,21 @@ extern "C" int skx_array_assemble(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows
         if (rows->logN < d->logB) { set_error("internal: keyset granularity"); return SKX_EUNSUP; }
     }
     std::unique_ptr<skx_array> a(new skx_array());
-    a->ctx = ctx; a->k = d->k; a->rc = d->rc; a->k_bits = d->key_bits; a->hp = d->hp; a->version = skx_version();
+    a->ctx = ctx; a->k = d->k; a->rc = d->rc; a->k_bits = d->key_bits; a->hp = d->hp; a->wh = d->wh; a->version = skx_version();
     for (int i = 0; i < d->n; i++) a->names.emplace_back(names && names[i] ? names[i] : "");
     const uint64_t U = rows->total;
     a->n_rows = a->n_kmers = U; a->pitch = pitch_for(U); a->engine_order = true;
     SKX_TRY(a->matrix.alloc((uint64_t)d->n * a->pitch));
-    SKX_TRY(a->present.alloc(U)); SKX_TRY(a->unambig.alloc(U)); SKX_TRY(a->mask.alloc(U)); SKX_TRY(a->keys.alloc(U)); SKX_TRY(a->vcount.alloc(U));
+    SKX_TRY(a->present.alloc(U)); SKX_TRY(a->unambig.alloc(U)); SKX_TRY(a->mask.alloc(U)); SKX_TRY(a->keys.alloc(U * rows->wpk())); SKX_TRY(a->vcount.alloc(U));
     DevBuf<int> d_flag; SKX_TRY(d_flag.alloc(1)); SKX_TRY(d_flag.zero(st));
     if (U) {
         AssembleArgs aa{};
         aa.d = d->view(); aa.logN = rows->logN; aa.stage = rows->stage.p; aa.stride = rows->stride; aa.ncnt = rows->ncnt.p; aa.roff = rows->roff.p;
         aa.matrix = a->matrix.p; aa.pitch = a->pitch; aa.col_present = a->present.p; aa.col_unambig = a->unambig.p; aa.col_mask = a->mask.p;
         aa.max_rows = rows->max_rows; aa.missing = d_flag.p;
-        { StageTimer t(ctx, &ctx->tm.assemble); launch_assemble(aa, st); }
-        launch_gather_keys(rows->stage.p, rows->stride, rows->ncnt.p, rows->roff.p, 1 << rows->logN, a->keys.p, 0, rows->hp, st);
+        { StageTimer t(ctx, &ctx->tm.assemble); if (rows->wide) launch_assemble_wide(aa, st); else launch_assemble(aa, st); }
+        if (rows->wide) launch_gather_keys_wide((const u128 *)rows->stage.p, rows->stride, rows->ncnt.p, rows->roff.p, 1 << rows->logN, (u128 *)a->keys.p, st);
+        else launch_gather_keys(rows->stage.p, rows->stride, rows->ncnt.p, rows->roff.p, 1 << rows->logN, a->keys.p, 0, rows->hp, st);
         SKX_HIP(hipMemcpyAsync(a->vcount.p, a->present.p, U * 4, hipMemcpyDeviceToDevice, st));     // merge_ska_array.rs:172
     }
     int missing = 0;
@@ -622,7 +652,7 @@ extern "C" int skx_array_from_host(skx_ctx *ctx, int k, int rc, const char *cons
     SKX_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     std::unique_ptr<skx_array> a(new skx_array());
-    a->ctx = ctx; a->k = k; a->rc = rc; a->k_bits = k <= 31 ? 64 : 128; a->hp = make_hash_params(std::min(k, 31));
+    a->ctx = ctx; a->k = k; a->rc = rc; a->k_bits = k <= 31 ? 64 : 128; a->hp = make_hash_params(std::min(k, 31)); a->wh = make_wide_hash(k);
     a->version = version ? version : skx_version();
     for (int i = 0; i < n_samples; i++) a->names.emplace_back(names[i]);
     a->n_rows = a->n_kmers = n_rows; a->pitch = pitch_for(n_rows); a->engine_order = false;
@@ -674,7 +704,15 @@ extern "C" int skx_array_export(skx_array *a, skx_key *keys, uint8_t *variants, 
         std::vector<uint64_t> w(K);
         if (K) SKX_HIP(hipMemcpy(w.data(), a->keys.p, K * 8, hipMemcpyDeviceToHost));
         for (uint64_t i = 0; i < K; i++) { hk[i].lo = hunmix(w[i] >> 4, a->hp); hk[i].hi = 0; }
-    } else hk = a->host_keys;
+    } else if (!a->host_keys.empty() || K == 0) hk = a->host_keys;
+    else {
+        std::vector<uint64_t> w(2 * K);
+        SKX_HIP(hipMemcpy(w.data(), a->keys.p, K * 16, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < K; i++) {
+            const u128 key = hunmix_w((((u128)w[2 * i + 1] << 64) | w[2 * i]) >> 4, a->wh);
+            hk[i].lo = (uint64_t)key; hk[i].hi = (uint64_t)(key >> 64);
+        }
+    }
     std::vector<uint8_t> rm(U * S);
     std::vector<uint32_t> pres(U);
     if (U) {
@@ -755,6 +793,10 @@ extern "C" int skx_array_filter(skx_array *a, uint64_t min_count, int filter_amb
             if (a->k <= 31) {
                 DevBuf<uint64_t> k2; SKX_TRY(k2.alloc(kept));
                 launch_compact_u64(a->keys.p, k2.p, U, keep.p, pos.p, st);
+                a->keys = std::move(k2);
+            } else if (a->host_keys.empty()) {
+                DevBuf<uint64_t> k2; SKX_TRY(k2.alloc(kept * 2));
+                launch_compact_u128(a->keys.p, k2.p, U, keep.p, pos.p, st);
                 a->keys = std::move(k2);
             } else {
                 std::vector<uint8_t> hkeep(U);

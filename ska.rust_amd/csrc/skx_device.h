@@ -46,6 +46,28 @@ __host__ __device__ inline uint64_t hunmix(uint64_t x, const HashParams &p)
     return ((uint64_t)L << p.hb) | R;
 }
 
+// ---- 128-bit path (k > 31): arms of up to 62 bits, packed word = (H(key) << 4) | mask in 128 bits ----
+typedef unsigned __int128 u128;
+struct WideHash { int bits, hb; uint64_t hmask; uint64_t c[3]; };
+WideHash make_wide_hash(int k);
+__host__ __device__ inline uint64_t hround64(uint64_t v, uint64_t c, int hb) { return (v * c) >> (64 - hb); }
+__host__ __device__ inline void hmix_halves_w(uint64_t &L, uint64_t &R, const WideHash &p)
+{
+    L ^= hround64(R, p.c[0], p.hb); R ^= hround64(L, p.c[1], p.hb); L ^= hround64(R, p.c[2], p.hb);
+}
+__host__ __device__ inline u128 hunmix_w(u128 x, const WideHash &p)
+{
+    uint64_t L = (uint64_t)(x >> p.hb), R = (uint64_t)x & p.hmask;
+    L ^= hround64(R, p.c[2], p.hb); R ^= hround64(L, p.c[1], p.hb); L ^= hround64(R, p.c[0], p.hb);
+    return ((u128)L << p.hb) | R;
+}
+__host__ __device__ inline u128 hmix_w(u128 x, const WideHash &p)
+{
+    uint64_t L = (uint64_t)(x >> p.hb), R = (uint64_t)x & p.hmask;
+    hmix_halves_w(L, R, p);
+    return ((u128)L << p.hb) | R;
+}
+
 struct ExtractArgs {
     const uint8_t *const *seqs;   // [n] device pointers to record streams (16-B aligned)
     const uint8_t *const *quals;  // [n] or nullptr
@@ -56,6 +78,7 @@ struct ExtractArgs {
     int min_qual, qual_filter;    // FASTQ only
     int logB;
     HashParams hp;
+    WideHash wh;                  // k > 31
     uint32_t *hist;               // [n << logB] raw window counts (pass 1 out / pass 2 cursors)
     const uint64_t *off;          // [n << logB] region offsets (pass 2)
     uint64_t *words;              // dict storage (pass 2)
@@ -80,7 +103,7 @@ void launch_dedupe_mb(uint64_t *words, const uint64_t *off, const uint32_t *raw,
                       uint32_t cap, int rem_bits, int *overflow, hipStream_t st);
 
 struct DictView {
-    const uint64_t *words; const uint64_t *off; const uint32_t *ucnt;
+    const uint64_t *words; const uint64_t *off; const uint32_t *ucnt;   // wide: words are u128 (2 x u64), off in elements
     int n_samples, logB, bits;
 };
 // distinct keys per sub-bucket (logN >= logB): slab j at stage + j*stride, count in ncnt[j]
@@ -129,6 +152,7 @@ void launch_compact_matrix(const uint8_t *in, uint64_t in_pitch, uint8_t *out, u
                            uint64_t n_cols, const uint8_t *keep, const uint64_t *pos, int mask_ambig, hipStream_t st);
 void launch_compact_u32(const uint32_t *in, uint32_t *out, uint64_t n, const uint8_t *keep, const uint64_t *pos, hipStream_t st);
 void launch_compact_u64(const uint64_t *in, uint64_t *out, uint64_t n, const uint8_t *keep, const uint64_t *pos, hipStream_t st);
+void launch_compact_u128(const uint64_t *in, uint64_t *out, uint64_t n, const uint8_t *keep, const uint64_t *pos, hipStream_t st);
 void launch_mask_ambig_stats(uint32_t *mask, uint64_t n, hipStream_t st);
 void launch_count_u8(const uint8_t *v, uint64_t n, uint8_t value, unsigned long long *out, hipStream_t st);
 // tiled transpose of a byte matrix: in [rows][in_pitch] -> out [cols][out_pitch]
@@ -146,5 +170,18 @@ void launch_build_planes(const uint8_t *matrix, uint64_t pitch, int n_samples, u
 constexpr int DIST_NCOUNT = 16;
 void launch_pair_counts(const uint64_t *planes, int n_samples, uint64_t words_per_row, int filt_ambig,
                         unsigned long long *out, hipStream_t st);
+
+// ---- wide (k > 31) launchers: same roles as their 64-bit counterparts; word pointers address u128 elements ----
+void launch_hist_wide(const ExtractArgs &a, hipStream_t st);
+void launch_scatter_wide(const ExtractArgs &a, hipStream_t st);
+int extract_tile_bases_wide();
+void launch_dedupe_wide(u128 *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_regions, uint32_t cap,
+                        int rem_bits, int *overflow, hipStream_t st);
+void launch_union_wide(const DictView &d, int logN, u128 *stage, uint32_t stride, uint32_t *ncnt, uint32_t table_slots, int *overflow,
+                       hipStream_t st);
+void launch_union_probe_wide(const DictView &d, int logP, int probe, uint32_t *cnt, uint32_t table_slots, int *overflow, hipStream_t st);
+void launch_assemble_wide(const AssembleArgs &a, hipStream_t st);      // a.stage addresses u128 slabs
+void launch_gather_keys_wide(const u128 *stage, uint32_t stride, const uint32_t *ncnt, const uint64_t *roff, int n_sub, u128 *out,
+                             hipStream_t st);
 
 }  // namespace skx

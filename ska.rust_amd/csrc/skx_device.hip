@@ -611,8 +611,7 @@ void launch_dedupe_mb(uint64_t *words, const uint64_t *off, const uint32_t *raw,
     if (items <= 4) launch_dedupe_items<4>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, lds, st);
     else if (items <= 8) launch_dedupe_items<8>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, lds, st);
     else if (items <= 14) launch_dedupe_items<14>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, lds, st);
-    else if (items <= 24) launch_dedupe_items<24>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, lds, st);
-    else launch_dedupe_items<52>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, lds, st);
+    else launch_dedupe_items<24>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, lds, st);     // host keeps regions <= 6144 words
 }
 
 // first index in [0,n) whose hashed key (word >> 4) is >= x
@@ -817,3 +816,4 @@ void launch_unhash_dict(const uint64_t *words, uint64_t n, uint64_t *keys, uint8
 
 }  // namespace skx
 #include "skx_device2.inc"
+#include "skx_device_wide.inc"

@@ -54,18 +54,23 @@ struct skx_dictset {
     skx_ctx *ctx = nullptr;
     int n = 0, k = 0, rc = 0, logB = 0, key_bits = 64;
     skx::HashParams hp{};
-    skx::DevBuf<uint64_t> words;     // all (sample,bucket) regions
+    skx::WideHash wh{};              // k > 31
+    bool wide() const { return key_bits == 128; }
+    skx::DevBuf<uint64_t> words;     // all (sample,bucket) regions (2 x u64 per word when wide)
     skx::DevBuf<uint64_t> off;       // [n<<logB + 1]
     skx::DevBuf<uint32_t> raw;       // [n<<logB] windows per region
     skx::DevBuf<uint32_t> ucnt;      // [n<<logB] distinct split k-mers per region
     std::vector<uint64_t> sample_size;   // SkaDict::ksize per sample
-    skx::DictView view() const { return skx::DictView{words.p, off.p, ucnt.p, n, logB, hp.bits}; }
+    skx::DictView view() const { return skx::DictView{words.p, off.p, ucnt.p, n, logB, wide() ? wh.bits : hp.bits}; }
 };
 
 struct skx_keyset {
     skx_ctx *ctx = nullptr;
     int k = 0, rc = 0, logN = 0;
     skx::HashParams hp{};
+    skx::WideHash wh{};
+    bool wide = false;               // k > 31: 2 x u64 per key
+    int wpk() const { return wide ? 2 : 1; }
     uint32_t stride = 0, max_rows = 0;
     uint64_t total = 0;
     skx::DevBuf<uint64_t> stage;     // slab j at stage + j*stride (sorted, engine order)
@@ -85,7 +90,8 @@ struct skx_array {
     uint64_t pitch = 0;
     uint64_t total_samples = 0;      // samples over all ranks when this array is one column slab (0: names.size())
     bool engine_order = false;       // rows sorted by H(key)
-    skx::DevBuf<uint64_t> keys;      // [n_kmers] packed words (H(key)<<4 | 1)
+    skx::WideHash wh{};
+    skx::DevBuf<uint64_t> keys;      // [n_kmers] packed words (H(key)<<4 | 1); 2 x u64 per key when k > 31 and built on the device
     skx::DevBuf<uint8_t> matrix;     // [n_samples][pitch], sample-major
     skx::DevBuf<uint32_t> present, unambig, mask;   // per row statistics of the matrix
     skx::DevBuf<uint32_t> vcount;                   // variant_count as the reference stores it (merge_ska_array.rs:121)

@@ -51,7 +51,7 @@ def check_dicts(E, samples, k, rc):
     return ds
 
 
-@pytest.mark.parametrize("k", [5, 7, 9, 15, 17, 21, 31])
+@pytest.mark.parametrize("k", [5, 7, 9, 15, 17, 21, 31, 33, 41, 55, 63])
 @pytest.mark.parametrize("rc", [True, False])
 def test_dict_random(E, k, rc):
     rng = np.random.default_rng(100 + k)
@@ -59,7 +59,7 @@ def test_dict_random(E, k, rc):
     check_dicts(E, samples, k, rc)
 
 
-@pytest.mark.parametrize("k", [7, 15, 31])
+@pytest.mark.parametrize("k", [7, 15, 31, 33, 47, 63])
 def test_dict_adversarial(E, k):
     """N runs, IUPAC letters, '-', lowercase, records of length k-1 / k / k+1, clean runs of exactly k at the
     record end (split_kmer.rs:89 quirk), homopolymers (palindromes when rc) and tile-boundary straddlers."""
@@ -74,17 +74,18 @@ def test_dict_adversarial(E, k):
         check_dicts(E, [base + edge, edge + base, [core[:k + 1]]], k, rc)
 
 
-def test_dict_larger_genome(E):
+@pytest.mark.parametrize("k", [31, 41])
+def test_dict_larger_genome(E, k):
     """~300 kbp related samples: many tiles and buckets, exercises cross-tile halos."""
     import synth
     anc = synth.ancestor(300_000, seed=3)
     streams = [synth.sample_stream(anc, i, 4, private_snps=40, shared_snps=10, seed=3) for i in range(4)]
-    ds = E.DictSet.build([s.tobytes() for s in streams], 31, True)
+    ds = E.DictSet.build([s.tobytes() for s in streams], k, True)
     for i, s in enumerate(streams):
         recs = s.tobytes().split(b"\n")[:-1]
-        ok, ob = oracle_dict(recs, 31, True).export()
+        ok, ob = oracle_dict(recs, k, True).export()
         gk, gb = ds.export(i)
-        assert np.array_equal(gk["lo"], ok["lo"]) and np.array_equal(gb, ob)
+        assert np.array_equal(gk["lo"], ok["lo"]) and np.array_equal(gk["hi"], ok["hi"]) and np.array_equal(gb, ob)
 
 
 def as_map(keys, var, counts):
@@ -99,7 +100,7 @@ def build_both(E, samples, k, rc):
     return ga, oa
 
 
-@pytest.mark.parametrize("k,rc", [(9, True), (15, False), (31, True)])
+@pytest.mark.parametrize("k,rc", [(9, True), (15, False), (31, True), (33, True), (41, False), (63, True)])
 def test_merge_array(E, k, rc):
     rng = np.random.default_rng(k)
     anc = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=5000).tolist())
@@ -168,7 +169,8 @@ def test_skf_written_by_engine_is_read_by_oracle(E, tmp_path):
     assert as_map(*o.export()) == as_map(*ref.export()) and o.names == ref.names
 
 
-def test_keyset_exchange_equals_single_merge(E):
+@pytest.mark.parametrize("k", [15, 41])
+def test_keyset_exchange_equals_single_merge(E, k):
     """Section 8e: union of per-shard key tables, then per-shard assemble == one merge of everything."""
     rng = np.random.default_rng(2)
     anc = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=6000).tolist())
@@ -179,8 +181,8 @@ def test_keyset_exchange_equals_single_merge(E):
             s[p] = b"ACGT"[rng.integers(0, 4)]
         samples.append([bytes(s)])
     names = [f"s{i}" for i in range(6)]
-    whole = E.DictSet.build([E.record_stream(r) for r in samples], 15, True).merge(names)
-    shards = [E.DictSet.build([E.record_stream(r) for r in samples[a:b]], 15, True) for a, b in ((0, 2), (2, 6))]
+    whole = E.DictSet.build([E.record_stream(r) for r in samples], k, True).merge(names)
+    shards = [E.DictSet.build([E.record_stream(r) for r in samples[a:b]], k, True) for a, b in ((0, 2), (2, 6))]
     keysets = [s.union_keys() for s in shards]
     rows = E.KeySet.merge(keysets)
     assert len(rows) == whole.nkmers
@@ -189,5 +191,5 @@ def test_keyset_exchange_equals_single_merge(E):
     for s, (a, b) in zip(shards, ((0, 2), (2, 6))):
         part = s.assemble(rows, names[a:b])
         pk, pv, _ = part.export()
-        assert np.array_equal(pk["lo"], wk["lo"]) and np.array_equal(pv, wv[:, a:b])
+        assert np.array_equal(pk["lo"], wk["lo"]) and np.array_equal(pk["hi"], wk["hi"]) and np.array_equal(pv, wv[:, a:b])
         col += b - a
