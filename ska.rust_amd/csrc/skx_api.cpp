@@ -163,7 +163,36 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
     hipStream_t st = ctx->stream;
     bool any_qual = false;
     for (auto p : quals) any_qual |= p != nullptr;
-    if (any_qual && q && q->min_count > 1) { set_error("FASTQ min-count filter (min_count > 1) is not available on the device path yet"); return SKX_EUNSUP; }
+    if (any_qual) {
+        // reads: per-sample quality gates + KmerFilter (skx_reads.hip); the dictset is then one sorted region per sample
+        const bool wide_r = k > 31;
+        const int wpk_r = wide_r ? 2 : 1;
+        std::vector<DevBuf<uint64_t>> lists(n);
+        std::vector<uint64_t> sizes(n, 0), offs(n + 1, 0);
+        for (int s = 0; s < n; s++) {
+            skx_qual qs = q ? *q : skx_qual{5, 20, SKX_QUAL_STRICT};
+            if (!quals[s]) { qs.min_count = 0; qs.qual_filter = SKX_QUAL_NOFILTER; }        // FASTA sample in a mixed batch: no filtering
+            SKX_TRY(reads_sample_dict(ctx, seqs[s], quals[s], lens[s], k, rc, qs, lists[s], &sizes[s]));
+            if (sizes[s] > 0xFFFFFFFFull) { set_error("sample too large"); return SKX_EUNSUP; }
+            offs[s + 1] = offs[s] + sizes[s];
+        }
+        std::unique_ptr<skx_dictset> d(new skx_dictset());
+        d->ctx = ctx; d->n = n; d->k = k; d->rc = rc; d->logB = 0; d->hp = make_hash_params(std::min(k, 31)); d->wh = make_wide_hash(k);
+        d->key_bits = wide_r ? 128 : 64;
+        SKX_TRY(d->words.alloc(offs[n] * wpk_r)); SKX_TRY(d->off.alloc(n + 1)); SKX_TRY(d->raw.alloc(n)); SKX_TRY(d->ucnt.alloc(n));
+        std::vector<uint32_t> uc(n);
+        for (int s = 0; s < n; s++) {
+            uc[s] = (uint32_t)sizes[s];
+            if (sizes[s]) SKX_HIP(hipMemcpyAsync(d->words.p + offs[s] * wpk_r, lists[s].p, sizes[s] * 8 * wpk_r, hipMemcpyDeviceToDevice, st));
+        }
+        SKX_HIP(hipMemcpyAsync(d->off.p, offs.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
+        SKX_HIP(hipMemcpyAsync(d->ucnt.p, uc.data(), n * 4, hipMemcpyHostToDevice, st));
+        SKX_HIP(hipMemcpyAsync(d->raw.p, uc.data(), n * 4, hipMemcpyHostToDevice, st));
+        SKX_HIP(hipStreamSynchronize(st));
+        d->sample_size = sizes;
+        *out = d.release();
+        return SKX_OK;
+    }
     const bool wide = k > 31;                                   // lib.rs:592: u64 for k <= 31, u128 above
     uint64_t maxlen = 0;
     for (auto l : lens) maxlen = std::max(maxlen, l);

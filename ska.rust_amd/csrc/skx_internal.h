@@ -103,6 +103,9 @@ namespace skx {
 // host reader (fastx.cpp): one sample -> record stream; returns SKX_* and sets the error
 struct HostStream { std::vector<uint8_t> seq, qual; bool is_fastq = false; };
 int read_sample_stream(const char *file1, const char *file2, double proportion_reads, HostStream &out);
+// FASTQ sample -> sorted unique packed words (skx_reads.hip)
+int reads_sample_dict(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t len, int k, int rc, const skx_qual &q,
+                      DevBuf<uint64_t> &out_words, uint64_t *n_out);
 // .skf codec (skf_codec.cpp)
 struct SkfData {
     int k = 0, rc = 0, k_bits = 64; std::vector<std::string> names; std::string version;

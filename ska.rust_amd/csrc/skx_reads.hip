@@ -1,0 +1,297 @@
+// skx_reads.hip -- the FASTQ side of SkaDict::new (ska_dict.rs:118-180 with is_reads): quality gates of
+// split_kmer.rs:66-71,328-339, ntHash of the whole k-mer (nthash.rs:35-76) and an exact, order-free evaluation of
+// KmerFilter::filter (bloom_filter.rs:62-148) -- blocked bloom (5-bit fingerprint in one of 3 145 728 u64 words) in front
+// of a HashMap<u64,u16> that passes a k-mer exactly when its count reaches min_count.
+//
+// The reference's filter is sequential and order dependent only through bloom false positives.  Per distinct hash h
+// (SURVEY.md A.6), with occurrences t_1 < t_2 < ... in stream order (file 1 then file 2):
+//   FP(h)  <=>  fp(h) is a subset of OR{ fp(g) : loc(g) == loc(h), first(g) < first(h) }
+//   min_count == 2 : every occurrence passes except t_1, which passes iff FP(h)
+//   min_count >= 3 : exactly the (min_count - FP(h))-th occurrence passes
+// so the device evaluates it with a stable sort by hash, a sort of the distinct hashes by (bloom word, first
+// occurrence) and a segmented prefix-OR.  Sorts/scans are rocPRIM device primitives (plain library calls on the
+// reads-only side path); everything specific to the path is hand-written below.
+#include <cstring>
+#include "skx_internal.h"
+#include <rocprim/rocprim.hpp>
+
+namespace skx {
+
+__device__ static const uint64_t NT_H[4] = {0x3c8bfbb395c60474ull, 0x3193c18562a02b4cull, 0x295549f54be24456ull, 0x20323ed082572324ull};
+__device__ static const uint64_t NT_RC[4] = {0x295549f54be24456ull, 0x20323ed082572324ull, 0x3c8bfbb395c60474ull, 0x3193c18562a02b4cull};
+__device__ static inline uint64_t rotl64d(uint64_t x, unsigned r) { r &= 63; return r ? (x << r) | (x >> (64 - r)) : x; }
+
+struct ReadsArgs {
+    const uint8_t *seq, *qual; uint64_t len;
+    int k, rc, min_qual, qual_filter;
+    HashParams hp; WideHash wh;
+    uint64_t *hash; uint64_t *wlo; uint64_t *whi; uint8_t *flag;
+};
+
+// one thread per window-end position; the window is rebuilt from its k bytes (O(k) per position: this is the reads-only
+// path, simplicity over speed)
+__global__ __launch_bounds__(256) void reads_windows_kernel(ReadsArgs a)
+{
+    __shared__ uint8_t s_seq[256 + 80], s_q[256 + 80];
+    const uint64_t p0 = (uint64_t)blockIdx.x * 256;
+    const int k = a.k, h = (k - 1) / 2;
+    // tile covers positions [p0 - 64, p0 + 256 + 2)
+    for (int i = threadIdx.x; i < 256 + 66; i += 256) {
+        const int64_t pos = (int64_t)p0 - 64 + i;
+        const bool in = pos >= 0 && (uint64_t)pos < a.len;
+        s_seq[i] = in ? a.seq[pos] : (uint8_t)'\n';
+        s_q[i] = (in && a.qual) ? a.qual[pos] : (uint8_t)'~';
+    }
+    __syncthreads();
+    const uint64_t p = p0 + threadIdx.x;
+    if (p >= a.len) return;
+    const int e = 64 + threadIdx.x;                       // tile index of the window's last base
+    auto qbad = [&](int i) { return a.qual && (uint8_t)(s_q[i] - 33) <= (uint8_t)a.min_qual; };     // !((q-33) > min_qual)
+    auto bad = [&](int i) { const uint8_t b = s_seq[i]; return (b & 0xF) == 14 || b == '\n' || (a.qual_filter == 2 && qbad(i)); };
+    bool valid = true;
+    u128 upper = 0, lower = 0, rc_upper = 0, rc_lower = 0;
+    uint32_t mid = 0;
+    uint64_t fh = 0, rh = 0;
+    for (int i = 0; i < k; i++) {
+        const int ti = e - (k - 1) + i;
+        valid = valid && !bad(ti);
+        const uint32_t c = (s_seq[ti] >> 1) & 3u;
+        if (i < h) upper = (upper << 2) | c; else if (i == h) mid = c; else lower = (lower << 2) | c;
+        fh ^= rotl64d(NT_H[c], (unsigned)(k - 1 - i));
+        rh ^= rotl64d(NT_RC[c], (unsigned)i);
+    }
+    for (int i = 0; i < h; i++) {
+        rc_upper = (rc_upper << 2) | (((s_seq[e - i] >> 1) & 3u) ^ 2u);               // reverse complement of the lower arm
+        rc_lower = (rc_lower << 2) | (((s_seq[e - (k - 1) + h - 1 - i] >> 1) & 3u) ^ 2u);   // ... of the upper arm
+    }
+    // split_kmer.rs:89,121: a clean run of exactly k ending at the record's last base is never started
+    if (s_seq[e + 1] == '\n') valid = valid && !bad(e - k);
+    // middle_base_qual (split_kmer.rs:328-339): Middle and Strict gate on the middle base
+    const bool midq_ok = !(a.qual && a.qual_filter != 0 && qbad(e - h));
+    uint32_t m4 = 1u << mid;
+    u128 hl = upper, hr = lower;
+    if (a.rc) {
+        const bool gt = upper != rc_upper ? upper > rc_upper : lower > rc_lower;
+        if (gt) { hl = rc_upper; hr = rc_lower; m4 = 1u << (mid ^ 2u); }
+        else if (upper == rc_upper && lower == rc_lower) m4 |= 1u << (mid ^ 2u);
+    }
+    u128 w;
+    if (k <= 31) { uint32_t L = (uint32_t)hl, R = (uint32_t)hr; hmix_halves(L, R, a.hp); w = ((u128)L << (a.hp.hb + 4)) | ((u128)R << 4) | m4; }
+    else { uint64_t L = (uint64_t)hl, R = (uint64_t)hr; hmix_halves_w(L, R, a.wh); w = ((u128)L << (a.wh.hb + 4)) | ((u128)R << 4) | m4; }
+    a.hash[p] = a.rc ? (fh < rh ? fh : rh) : fh;
+    a.wlo[p] = (uint64_t)w;
+    if (a.whi) a.whi[p] = (uint64_t)(w >> 64);
+    a.flag[p] = valid && midq_ok;                          // the `&&` of ska_dict.rs:155-157: the count filter is not touched otherwise
+}
+
+__global__ void gather_u64_kernel(const uint64_t *src, const uint32_t *idx, uint64_t *dst, uint64_t n)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[idx[i]];
+}
+__global__ void iota_u32_kernel(uint32_t *v, uint64_t n)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) v[i] = (uint32_t)i;
+}
+// head[i] = first occurrence of its hash in the hash-sorted order; startpos[i] = i at heads else 0 (for a max-scan)
+__global__ void heads_kernel(const uint64_t *hs, uint32_t *head, uint32_t *startpos, uint64_t n)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const bool hd = i == 0 || hs[i] != hs[i - 1];
+        head[i] = hd; startpos[i] = hd ? (uint32_t)i : 0u;
+    }
+}
+// bloom word and fingerprint (bloom_filter.rs:50-74): loc = (cheap_mix(h) * buf_size) >> 64, fp = 5 bits of h
+__device__ static inline uint64_t bloom_loc(uint64_t h) { const uint64_t m = (h ^ (h >> 31)) * 0x85D059AA333121CFull; return (uint64_t)(((u128)m * 3145728ull) >> 64); }
+__device__ static inline uint64_t bloom_fp(uint64_t h)
+{
+    return (1ull << (h & 63)) | (1ull << ((h >> 6) & 63)) | (1ull << ((h >> 12) & 63)) | (1ull << ((h >> 18) & 63)) | (1ull << ((h >> 24) & 63));
+}
+// per distinct hash (group id = gsum[i]-1 at its head): composite key (loc << 32 | first occurrence) and fingerprint
+__global__ void distinct_kernel(const uint64_t *hs, const uint32_t *ts, const uint32_t *head, const uint32_t *gsum, uint64_t *ckey, uint32_t *gidx,
+                                uint64_t *dhash, uint64_t n)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        if (head[i]) { const uint32_t g = gsum[i] - 1; ckey[g] = (bloom_loc(hs[i]) << 32) | ts[i]; gidx[g] = g; dhash[g] = hs[i]; }
+}
+__global__ void fp_prepare_kernel(const uint64_t *cks, const uint32_t *gs, const uint64_t *dhash, uint32_t *lockey, uint64_t *fpv, uint64_t n)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        lockey[i] = (uint32_t)(cks[i] >> 32); fpv[i] = bloom_fp(dhash[gs[i]]);
+    }
+}
+__global__ void fp_decide_kernel(const uint32_t *gs, const uint64_t *fpv, const uint64_t *prev, uint8_t *FP, uint64_t n)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        FP[gs[i]] = (fpv[i] & ~prev[i]) == 0;
+}
+// KmerFilter::filter verdict per occurrence (occurrence number j is 1-based inside its hash group)
+__global__ void accept_kernel(const uint32_t *gsum, const uint32_t *start, const uint8_t *FP, uint8_t *acc, int min_count, uint64_t n)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t j = (uint32_t)i - start[i] + 1, fpos = FP[gsum[i] - 1];
+        acc[i] = min_count == 2 ? (j >= 2 || fpos) : (j == (uint32_t)min_count - fpos);
+    }
+}
+// sorted words -> unique words with OR-ed masks
+__global__ void word_heads_kernel(const uint64_t *lo, const uint64_t *hi, uint32_t *head, uint64_t n)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        head[i] = i == 0 || (lo[i] >> 4) != (lo[i - 1] >> 4) || (hi && hi[i] != hi[i - 1]);
+}
+__global__ void word_fold_kernel(const uint64_t *lo, const uint64_t *hi, const uint32_t *head, const uint32_t *hsum, uint64_t *out, int wpk, uint64_t n)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (!head[i]) continue;
+        uint64_t w = lo[i];
+        for (uint64_t j = i + 1; j < n && !head[j]; j++) w |= lo[j] & 15ull;
+        const uint64_t o = hsum[i] - 1;
+        out[o * wpk] = w;
+        if (wpk == 2) out[o * 2 + 1] = hi[i];
+    }
+}
+
+struct BitOr64 { __host__ __device__ uint64_t operator()(uint64_t a, uint64_t b) const { return a | b; } };
+
+namespace {
+inline unsigned grid_for(uint64_t n) { uint64_t g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 65535 ? 65535 : g)); }
+struct Temp {             // rocPRIM scratch, grown on demand
+    DevBuf<uint8_t> buf;
+    int need(size_t bytes) { if (bytes > buf.n) return buf.alloc(bytes + bytes / 4 + 256); return SKX_OK; }
+};
+#define RP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail(e_, #call); } while (0)
+
+template <typename K, typename V>
+int sort_pairs(Temp &tmp, const K *kin, K *kout, const V *vin, V *vout, uint64_t n, hipStream_t st)
+{
+    size_t bytes = 0;
+    RP(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0, sizeof(K) * 8, st));
+    SKX_TRY(tmp.need(bytes));
+    RP(rocprim::radix_sort_pairs(tmp.buf.p, bytes, kin, kout, vin, vout, n, 0, sizeof(K) * 8, st));
+    return SKX_OK;
+}
+template <typename T, typename Op>
+int incl_scan(Temp &tmp, const T *in, T *out, uint64_t n, Op op, hipStream_t st)
+{
+    size_t bytes = 0;
+    RP(rocprim::inclusive_scan(nullptr, bytes, in, out, n, op, st));
+    SKX_TRY(tmp.need(bytes));
+    RP(rocprim::inclusive_scan(tmp.buf.p, bytes, in, out, n, op, st));
+    return SKX_OK;
+}
+// indices (or values) of the flagged items; returns the count
+template <typename In, typename Out>
+int select_flagged(Temp &tmp, In in, const uint8_t *flags, Out *out, uint64_t n, uint64_t *count, hipStream_t st)
+{
+    DevBuf<size_t> d_cnt; SKX_TRY(d_cnt.alloc(1));
+    size_t bytes = 0;
+    RP(rocprim::select(nullptr, bytes, in, flags, out, d_cnt.p, n, st));
+    SKX_TRY(tmp.need(bytes));
+    RP(rocprim::select(tmp.buf.p, bytes, in, flags, out, d_cnt.p, n, st));
+    size_t c = 0;
+    RP(hipMemcpyAsync(&c, d_cnt.p, sizeof c, hipMemcpyDeviceToHost, st));
+    RP(hipStreamSynchronize(st));
+    *count = c;
+    return SKX_OK;
+}
+}  // namespace
+
+// One FASTQ sample -> its SkaDict as a sorted (engine order) list of unique packed words.
+int reads_sample_dict(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t len, int k, int rc, const skx_qual &q,
+                      DevBuf<uint64_t> &out_words, uint64_t *n_out)
+{
+    hipStream_t st = ctx->stream;
+    const bool wide = k > 31;
+    const int wpk = wide ? 2 : 1;
+    *n_out = 0;
+    if (len == 0) return SKX_OK;
+    if (len > 0xFFFFFFF0ull) { set_error("FASTQ sample longer than 4 G bases"); return SKX_EUNSUP; }
+    Temp tmp;
+    DevBuf<uint64_t> hash, wlo, whi; DevBuf<uint8_t> flag;
+    SKX_TRY(hash.alloc(len)); SKX_TRY(wlo.alloc(len)); SKX_TRY(flag.alloc(len));
+    if (wide) SKX_TRY(whi.alloc(len));
+    ReadsArgs ra{d_seq, d_qual, len, k, rc, q.min_qual, q.qual_filter, make_hash_params(k < 31 ? k : 31), make_wide_hash(k),
+                 hash.p, wlo.p, wide ? whi.p : nullptr, flag.p};
+    hipLaunchKernelGGL(reads_windows_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, ra);
+
+    // candidate windows in stream order
+    DevBuf<uint32_t> idx; SKX_TRY(idx.alloc(len));
+    uint64_t m = 0;
+    SKX_TRY(select_flagged(tmp, rocprim::counting_iterator<uint32_t>(0), flag.p, idx.p, len, &m, st));
+    if (m == 0) return SKX_OK;
+
+    DevBuf<uint32_t> acc_t;            // stream positions of the windows that enter the dictionary
+    uint64_t m2 = 0;
+    if (q.min_count <= 1) {            // KmerFilter: 0 | 1 => no filtering
+        acc_t = std::move(idx); m2 = m;
+    } else {
+        DevBuf<uint64_t> hk, hs; DevBuf<uint32_t> ts;
+        SKX_TRY(hk.alloc(m)); SKX_TRY(hs.alloc(m)); SKX_TRY(ts.alloc(m));
+        hipLaunchKernelGGL(gather_u64_kernel, dim3(grid_for(m)), dim3(256), 0, st, hash.p, idx.p, hk.p, m);
+        SKX_TRY(sort_pairs(tmp, hk.p, hs.p, idx.p, ts.p, m, st));                        // stable: occurrences stay in stream order
+        DevBuf<uint32_t> head, startpos, gsum, start;
+        SKX_TRY(head.alloc(m)); SKX_TRY(startpos.alloc(m)); SKX_TRY(gsum.alloc(m)); SKX_TRY(start.alloc(m));
+        hipLaunchKernelGGL(heads_kernel, dim3(grid_for(m)), dim3(256), 0, st, hs.p, head.p, startpos.p, m);
+        SKX_TRY(incl_scan(tmp, head.p, gsum.p, m, rocprim::plus<uint32_t>(), st));
+        SKX_TRY(incl_scan(tmp, startpos.p, start.p, m, rocprim::maximum<uint32_t>(), st));
+        uint32_t nd = 0;
+        RP(hipMemcpyAsync(&nd, gsum.p + (m - 1), 4, hipMemcpyDeviceToHost, st));
+        RP(hipStreamSynchronize(st));
+        DevBuf<uint64_t> ckey, cks, dhash, fpv, prev; DevBuf<uint32_t> gidx, gs, lockey; DevBuf<uint8_t> FP;
+        SKX_TRY(ckey.alloc(nd)); SKX_TRY(cks.alloc(nd)); SKX_TRY(dhash.alloc(nd)); SKX_TRY(fpv.alloc(nd)); SKX_TRY(prev.alloc(nd));
+        SKX_TRY(gidx.alloc(nd)); SKX_TRY(gs.alloc(nd)); SKX_TRY(lockey.alloc(nd)); SKX_TRY(FP.alloc(nd));
+        hipLaunchKernelGGL(distinct_kernel, dim3(grid_for(m)), dim3(256), 0, st, hs.p, ts.p, head.p, gsum.p, ckey.p, gidx.p, dhash.p, m);
+        SKX_TRY(sort_pairs(tmp, ckey.p, cks.p, gidx.p, gs.p, nd, st));
+        hipLaunchKernelGGL(fp_prepare_kernel, dim3(grid_for(nd)), dim3(256), 0, st, cks.p, gs.p, dhash.p, lockey.p, fpv.p, (uint64_t)nd);
+        {
+            size_t bytes = 0;
+            RP(rocprim::exclusive_scan_by_key(nullptr, bytes, lockey.p, fpv.p, prev.p, (uint64_t)0, nd, BitOr64(),
+                                              rocprim::equal_to<uint32_t>(), st));
+            SKX_TRY(tmp.need(bytes));
+            RP(rocprim::exclusive_scan_by_key(tmp.buf.p, bytes, lockey.p, fpv.p, prev.p, (uint64_t)0, nd, BitOr64(),
+                                              rocprim::equal_to<uint32_t>(), st));
+        }
+        hipLaunchKernelGGL(fp_decide_kernel, dim3(grid_for(nd)), dim3(256), 0, st, gs.p, fpv.p, prev.p, FP.p, (uint64_t)nd);
+        DevBuf<uint8_t> acc; SKX_TRY(acc.alloc(m));
+        hipLaunchKernelGGL(accept_kernel, dim3(grid_for(m)), dim3(256), 0, st, gsum.p, start.p, FP.p, acc.p, (int)q.min_count, m);
+        SKX_TRY(acc_t.alloc(m));
+        SKX_TRY(select_flagged(tmp, ts.p, acc.p, acc_t.p, m, &m2, st));
+        if (m2 == 0) return SKX_OK;
+    }
+
+    // accepted windows -> sorted unique packed words
+    DevBuf<uint64_t> alo, ahi, slo, shi;
+    SKX_TRY(alo.alloc(m2)); SKX_TRY(slo.alloc(m2));
+    hipLaunchKernelGGL(gather_u64_kernel, dim3(grid_for(m2)), dim3(256), 0, st, wlo.p, acc_t.p, alo.p, m2);
+    if (!wide) {
+        size_t bytes = 0;
+        RP(rocprim::radix_sort_keys(nullptr, bytes, alo.p, slo.p, m2, 0, 64, st));
+        SKX_TRY(tmp.need(bytes));
+        RP(rocprim::radix_sort_keys(tmp.buf.p, bytes, alo.p, slo.p, m2, 0, 64, st));
+    } else {
+        // 128-bit order = stable sort by the low word, then stable sort by the high word
+        SKX_TRY(ahi.alloc(m2)); SKX_TRY(shi.alloc(m2));
+        hipLaunchKernelGGL(gather_u64_kernel, dim3(grid_for(m2)), dim3(256), 0, st, whi.p, acc_t.p, ahi.p, m2);
+        DevBuf<uint32_t> i0, i1, i2; DevBuf<uint64_t> t1, t2;
+        SKX_TRY(i0.alloc(m2)); SKX_TRY(i1.alloc(m2)); SKX_TRY(i2.alloc(m2)); SKX_TRY(t1.alloc(m2)); SKX_TRY(t2.alloc(m2));
+        hipLaunchKernelGGL(iota_u32_kernel, dim3(grid_for(m2)), dim3(256), 0, st, i0.p, m2);
+        SKX_TRY(sort_pairs(tmp, alo.p, t1.p, i0.p, i1.p, m2, st));                         // by low word
+        hipLaunchKernelGGL(gather_u64_kernel, dim3(grid_for(m2)), dim3(256), 0, st, ahi.p, i1.p, t2.p, m2);
+        SKX_TRY(sort_pairs(tmp, t2.p, shi.p, i1.p, i2.p, m2, st));                          // then by high word (stable)
+        hipLaunchKernelGGL(gather_u64_kernel, dim3(grid_for(m2)), dim3(256), 0, st, alo.p, i2.p, slo.p, m2);
+    }
+    DevBuf<uint32_t> whead, whsum;
+    SKX_TRY(whead.alloc(m2)); SKX_TRY(whsum.alloc(m2));
+    hipLaunchKernelGGL(word_heads_kernel, dim3(grid_for(m2)), dim3(256), 0, st, slo.p, wide ? shi.p : nullptr, whead.p, m2);
+    SKX_TRY(incl_scan(tmp, whead.p, whsum.p, m2, rocprim::plus<uint32_t>(), st));
+    uint32_t nu = 0;
+    RP(hipMemcpyAsync(&nu, whsum.p + (m2 - 1), 4, hipMemcpyDeviceToHost, st));
+    RP(hipStreamSynchronize(st));
+    SKX_TRY(out_words.alloc((uint64_t)nu * wpk));
+    hipLaunchKernelGGL(word_fold_kernel, dim3(grid_for(m2)), dim3(256), 0, st, slo.p, wide ? shi.p : nullptr, whead.p, whsum.p, out_words.p, wpk, m2);
+    RP(hipStreamSynchronize(st));
+    RP(hipGetLastError());
+    *n_out = nu;
+    return SKX_OK;
+}
+
+}  // namespace skx

@@ -193,3 +193,53 @@ def test_keyset_exchange_equals_single_merge(E, k):
         pk, pv, _ = part.export()
         assert np.array_equal(pk["lo"], wk["lo"]) and np.array_equal(pk["hi"], wk["hi"]) and np.array_equal(pv, wv[:, a:b])
         col += b - a
+
+
+def _write_fastq(path, reads, quals):
+    with open(path, "wb") as f:
+        for i, (r, q) in enumerate(zip(reads, quals)):
+            f.write(b"@r%d\n" % i + r + b"\n+\n" + q + b"\n")
+
+
+@pytest.fixture(scope="module")
+def fastq_pair(tmp_path_factory):
+    """~10 M read bases with 2 % substitution errors: millions of distinct k-mers, so the blocked bloom filter of
+    bloom_filter.rs produces false positives and the order-dependent part of KmerFilter is exercised."""
+    rng = np.random.default_rng(42)
+    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=300_000)
+    comp = np.zeros(256, dtype=np.uint8)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    n_reads, L = 34_000, 150
+    d = tmp_path_factory.mktemp("fq")
+    paths = []
+    for tag in ("fwd", "rev"):
+        starts = rng.integers(0, len(genome) - L, size=n_reads)
+        reads, quals = [], []
+        for s in starts:
+            r = genome[s:s + L].copy()
+            if tag == "rev":
+                r = comp[r[::-1]]
+            err = rng.random(L) < 0.02
+            r[err] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(err.sum()))
+            if rng.random() < 0.01:
+                r[rng.integers(0, L)] = ord("N")
+            q = rng.choice(np.frombuffer(b"#+5?I", dtype=np.uint8), size=L, p=[0.02, 0.03, 0.05, 0.2, 0.7])
+            reads.append(r.tobytes())
+            quals.append(q.tobytes())
+        p = str(d / f"s_{tag}.fastq")
+        _write_fastq(p, reads, quals)
+        paths.append(p)
+    return paths
+
+
+@pytest.mark.parametrize("k,min_count,qf,min_qual", [(31, 1, 2, 20), (31, 2, 2, 20), (31, 3, 2, 20), (31, 5, 0, 20), (21, 4, 1, 10),
+                                                     (41, 2, 2, 20), (41, 3, 1, 5)])
+def test_fastq_kmer_filter(E, fastq_pair, k, min_count, qf, min_qual):
+    f1, f2 = fastq_pair
+    og = ora.Dict.from_files(k, f1, f2, True, ora.qual(min_count, min_qual, qf))
+    ds = E.DictSet.from_files([(f1, f2)], k, True, E.qual(min_count, min_qual, qf))
+    ok, ob = og.export()
+    gk, gb = ds.export(0)
+    assert len(gk) == len(ok) and len(ok) > 1000
+    assert np.array_equal(gk["lo"], ok["lo"]) and np.array_equal(gk["hi"], ok["hi"]) and np.array_equal(gb, ob)
