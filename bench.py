@@ -198,6 +198,12 @@ def main():
         scatter_ms = tm["scatter"] / steps
         algo_bytes = 10.0 * total_bases
         achieved = algo_bytes / (scatter_ms * 1e-3) / 1e9 if scatter_ms > 0 else 0.0
+        traffic = None       # HBM bytes per launch from the PMC passes recorded in profiles/ (FETCH_SIZE x2 + WRITE_SIZE), scaled per base
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_extract.json")))
+            traffic = (pmc["read_bytes_per_base"] + pmc["write_bytes_per_base"]) * total_bases
+        except Exception:
+            pass
         res = {
             "metric": "genomes/sec ska build+align, 1 000x5 Mbp k=31; bit-exact vs CPU",
             "value": n_total * steps / dt, "unit": "genomes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -209,7 +215,7 @@ def main():
                        "rows_U": shape[0], "rows_kept": shape[1], "parallelism": f"samples sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": "extract_kernel<true> (split k-mer extraction + bucket scatter)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": scatter_ms},
+                         "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": scatter_ms},
             "stage_ms_per_step": {k: v / steps for k, v in tm.items()},
             "host_wall_ms_per_step": {k: v / steps for k, v in host_ms.items()},
         }
