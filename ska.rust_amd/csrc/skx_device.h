@@ -127,6 +127,7 @@ struct AssembleArgs {
     uint32_t *col_mask;        // [U] bit c set iff IUPAC set-code c (1..15) occurs in the column
     uint32_t max_rows;         // max ncnt (LDS sizing)
     int *missing;              // set if a dict key is not among the rows
+    int debug_mode;            // profiling aid (SKX_ASM_MODE)
 };
 void launch_assemble(const AssembleArgs &a, hipStream_t st);
 

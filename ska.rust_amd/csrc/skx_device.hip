@@ -213,16 +213,27 @@ __global__ __launch_bounds__(TILE / 16) void extract_kernel(ExtractArgs a)
         return;
     }
     if (a.debug_mode == 2) return;
-    // reserve one chunk per non-empty bucket in the sample's region (global cursor); counts -> local starts
+    // reserve one chunk per non-empty bucket in the sample's region (global cursor); the returned bases are not needed
+    // until the copy-out, so the atomics stay in flight behind the block scan and the first staging pass
+    constexpr int RMAX = (8192 * 16 + TILE - 1) / TILE;     // buckets per thread at most (B <= 8192)
     const int R = (B + NT - 1) / NT;
     const int b0 = tid * R < B ? tid * R : B, b1 = b0 + R < B ? b0 + R : B;
-    uint32_t lsum = 0;
-    for (int b = b0; b < b1; b++) { const uint32_t n = s_hist[b]; s_base[b] = n ? atomicAdd(&ghist[b], n) : 0u; lsum += n; }
+    uint32_t gb[RMAX], lsum = 0;
+#pragma unroll
+    for (int r = 0; r < RMAX; r++) {
+        gb[r] = 0;
+        if (b0 + r < b1) { const uint32_t n = s_hist[b0 + r]; if (n) gb[r] = atomicAdd(&ghist[b0 + r], n); lsum += n; }
+    }
     uint32_t total;
     uint32_t lrun = block_excl_scan(lsum, s_tmp, &total);
-    // s_hist: counts -> local starts; s_base: chunk base -> (chunk base - local start), so that a staged word at local
+    // s_hist: counts -> local starts; s_base (written later): chunk base - local start, so that a staged word at local
     // index i lands at region offset s_base[b] + i
-    for (int b = b0; b < b1; b++) { const uint32_t n = s_hist[b]; s_hist[b] = lrun; s_base[b] -= lrun; lrun += n; }
+    uint32_t lst[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; r++) {
+        lst[r] = lrun;
+        if (b0 + r < b1) { const uint32_t n = s_hist[b0 + r]; s_hist[b0 + r] = lrun; lrun += n; }
+    }
     if (tid == 0) s_hist[B] = total;                        // sentinel: start of the (non-existent) bucket B
     __syncthreads();
     if (a.debug_mode == 1) return;
@@ -230,6 +241,7 @@ __global__ __launch_bounds__(TILE / 16) void extract_kernel(ExtractArgs a)
     const bool fixed = a.capacity != 0xFFFFFFFFu;           // fixed-capacity regions: offsets are arithmetic
     const uint64_t reg0 = ((uint64_t)sample << a.logB) * a.capacity;
     bool dropped = false;
+    bool bases_written = false;
     uint32_t unstaged_mask = 0;                             // rounds whose words did not fit the staging buffer (skewed tile)
 #pragma unroll 1
     for (int q = 0; q < ROUNDS; q++) {
@@ -240,6 +252,11 @@ __global__ __launch_bounds__(TILE / 16) void extract_kernel(ExtractArgs a)
         for (int j = 0; j < 16; j++) {
             const uint32_t b = rk[j] >> 16;
             if (b >= qb0 && b < qb1) s_stage[s_hist[b] - e0 + (rk[j] & 0xFFFFu)] = wv[j];
+        }
+        if (!bases_written) {                                   // first use of the cursor atomics' results
+#pragma unroll
+            for (int r = 0; r < RMAX; r++) if (b0 + r < b1) s_base[b0 + r] = gb[r] - lst[r];
+            bases_written = true;
         }
         __syncthreads();
         for (uint32_t i = tid; i < e1 - e0; i += NT) {
@@ -252,6 +269,11 @@ __global__ __launch_bounds__(TILE / 16) void extract_kernel(ExtractArgs a)
         __syncthreads();
     }
     if (unstaged_mask) {                                    // rare: direct 8-B stores, one element at a time
+        if (!bases_written) {
+#pragma unroll
+            for (int r = 0; r < RMAX; r++) if (b0 + r < b1) s_base[b0 + r] = gb[r] - lst[r];
+        }
+        __syncthreads();
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const uint32_t b = rk[j] >> 16;
@@ -658,9 +680,13 @@ __global__ __launch_bounds__(1024) void union_kernel(DictView d, int logN, uint6
         for (int t = 0; t < cnt; t++) {
             const uint64_t *reg = reinterpret_cast<const uint64_t *>(__shfl((unsigned long long)my_reg, t, 64));
             const uint32_t lo = __shfl(my_lo, t, 64), hi = __shfl(my_hi, t, 64);
-            for (uint32_t i = lo + lane; i < hi; i += 64) {
-                const uint64_t w = reg[i];
-                if (!table_insert(s_tab, total_slots, home_slot(w, rem_bits, nslots), w)) s_fail = 1;
+            for (uint32_t i0 = lo; i0 < hi; i0 += 512) {
+                uint64_t wq[8];                               // 8 words per lane in flight per memory round trip
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const uint32_t i = i0 + 64u * u + lane; wq[u] = i < hi ? reg[i] : 0ull; }
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (wq[u] && !table_insert(s_tab, total_slots, home_slot(wq[u], rem_bits, nslots), wq[u])) s_fail = 1;
             }
         }
     }
@@ -693,6 +719,13 @@ void launch_union_probe(const DictView &d, int logP, int probe, uint32_t *cnt, u
 
 // IUPAC letter of a base set; bit i of the set == 2-bit code i (A0 C1 T2 G3), cf. bit_encoding.rs:337-368
 __device__ static const char MASK2IUPAC_D[17] = "-ACMTWYHGRSVKDBN";
+// the same table as two 64-bit immediates (pure ALU: a __device__ array lookup would be a global-memory gather per cell)
+__device__ static inline unsigned char mask2iupac(uint32_t m4)
+{
+    const uint64_t lo = 0x485957544D43412Dull;      // "-ACMTWYH"
+    const uint64_t hi = 0x4E42444B56535247ull;      // "GRSVKDBN"
+    return (unsigned char)(((m4 & 8u) ? hi : lo) >> (8u * (m4 & 7u)));
+}
 
 // K5: rows = key slabs, columns = samples: fill the sample-major matrix + per-row statistics
 __global__ __launch_bounds__(512) void assemble_kernel(AssembleArgs a)
@@ -705,10 +738,25 @@ __global__ __launch_bounds__(512) void assemble_kernel(AssembleArgs a)
     uint64_t *s_keys = reinterpret_cast<uint64_t *>(s_raw);
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_raw + (size_t)maxr * 8);
     uint32_t *s_msk = s_cnt + maxr;
-    unsigned char *s_rows = reinterpret_cast<unsigned char *>(s_msk + maxr);
+    uint32_t *s_idx = s_msk + maxr;                                   // [maxr/2 + 2] row index by the next hash bits
+    unsigned char *s_rows = reinterpret_cast<unsigned char *>(s_idx + maxr / 2 + 4);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const uint64_t *slab = a.stage + j * (uint64_t)a.stride;
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { s_keys[i] = slab[i] >> 4; s_cnt[i] = 0; s_msk[i] = 0; }
+    __syncthreads();
+    // direct index: rows are uniform in the sub-bucket's hash range, so the next logI bits of the key select ~2 rows
+    const int rem = a.d.bits - a.logN;
+    int logI = 31 - __clz(n | 1u);                                    // ~n/2..n index cells
+    if (logI > rem) logI = rem;
+    while ((1u << logI) > maxr / 2) logI--;
+    const uint32_t nidx = 1u << logI;
+    const uint64_t lmask = rem >= 60 ? ~0ull : ((1ull << rem) - 1);
+    for (uint32_t b = threadIdx.x; b <= nidx; b += blockDim.x) {
+        uint32_t l = 0, r = n;
+        if (b == nidx) l = n;
+        else { const uint64_t x = ((uint64_t)b) << (rem - logI); while (l < r) { uint32_t m = (l + r) >> 1; if ((s_keys[m] & lmask) < x) l = m + 1; else r = m; } }
+        s_idx[b] = l;
+    }
     __syncthreads();
     const uint64_t r0 = a.roff[j];
     const uint32_t shift = (uint32_t)(r0 & 15u);
@@ -718,30 +766,60 @@ __global__ __launch_bounds__(512) void assemble_kernel(AssembleArgs a)
         const uint64_t *my_reg = nullptr; uint32_t my_lo = 0, my_hi = 0;
         if (sbase + lane < a.d.n_samples) sub_slice(a.d, sbase + lane, j, a.logN, my_reg, my_lo, my_hi);
         const int cnt = a.d.n_samples - sbase < 64 ? a.d.n_samples - sbase : 64;
+        // software pipeline over the 64 slices: the first 512 words of slice t+1 are in flight while slice t is looked up
+        uint64_t nq[8];
+        {
+            const uint64_t *reg0 = reinterpret_cast<const uint64_t *>(__shfl((unsigned long long)my_reg, 0, 64));
+            const uint32_t lo0 = __shfl(my_lo, 0, 64), hi0 = __shfl(my_hi, 0, 64);
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const uint32_t i = lo0 + 64u * u + lane; nq[u] = i < hi0 ? reg0[i] : 0ull; }
+        }
         for (int t = 0; t < cnt; t++) {
             const int s = sbase + t;
             const uint64_t *reg = reinterpret_cast<const uint64_t *>(__shfl((unsigned long long)my_reg, t, 64));
             const uint32_t lo = __shfl(my_lo, t, 64), hi = __shfl(my_hi, t, 64);
+            uint64_t wq[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) wq[u] = nq[u];
+            {
+                const int tn = t + 1 < cnt ? t + 1 : t;
+                const uint64_t *regn = reinterpret_cast<const uint64_t *>(__shfl((unsigned long long)my_reg, tn, 64));
+                const uint32_t lon = __shfl(my_lo, tn, 64), hin = t + 1 < cnt ? __shfl(my_hi, tn, 64) : 0u;
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const uint32_t i = lon + 64u * u + lane; nq[u] = i < hin ? regn[i] : 0ull; }
+            }
             // fill with '-'
             for (uint32_t i = lane * 4; i < n + shift + 3; i += 256) *reinterpret_cast<uint32_t *>(row + i) = 0x2D2D2D2Du;
             __builtin_amdgcn_wave_barrier();
-            for (uint32_t i = lo + lane; i < hi; i += 64) {
-                const uint64_t w = reg[i];
-                const uint64_t key = w >> 4;
-                uint32_t l = 0, r = n;
-                while (l < r) { uint32_t m = (l + r) >> 1; if (s_keys[m] < key) l = m + 1; else r = m; }
-                if (l < n && s_keys[l] == key) {
-                    const uint32_t m4 = (uint32_t)(w & 15u);
-                    row[shift + l] = (unsigned char)MASK2IUPAC_D[m4];
-                    const uint32_t single = (m4 & (m4 - 1)) == 0;
-                    atomicAdd(&s_cnt[l], 1u | (single << 16));
-                    atomicOr(&s_msk[l], 1u << m4);
-                } else {
-                    *a.missing = 1;
+            if (!(a.debug_mode & 2))
+            for (uint32_t i0 = lo; i0 < hi; i0 += 512) {
+                if (i0 != lo) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { const uint32_t i = i0 + 64u * u + lane; wq[u] = i < hi ? reg[i] : 0ull; }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint64_t w = wq[u];
+                    if (!w) continue;
+                    const uint64_t key = w >> 4;
+                    const uint32_t ib = (uint32_t)((key & lmask) >> (rem - logI));
+                    uint32_t l = s_idx[ib];
+                    const uint32_t le = s_idx[ib + 1];
+                    while (l < le && s_keys[l] < key) l++;
+                    if (l < le && s_keys[l] == key) {
+                        const uint32_t m4 = (uint32_t)(w & 15u);
+                        row[shift + l] = mask2iupac(m4);
+                        const uint32_t single = (m4 & (m4 - 1)) == 0;
+                        atomicAdd(&s_cnt[l], 1u | (single << 16));
+                        atomicOr(&s_msk[l], 1u << m4);
+                    } else {
+                        *a.missing = 1;
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
             // copy out: global column r0 + i  <-  row[shift + i]; 16-B body, byte head/tail
+            if (a.debug_mode & 1) continue;
             unsigned char *dst = a.matrix + (uint64_t)s * a.pitch + r0;
             const uint32_t head = (16u - shift) & 15u;
             const uint32_t h = head < n ? head : n;
@@ -763,11 +841,13 @@ __global__ __launch_bounds__(512) void assemble_kernel(AssembleArgs a)
         a.col_mask[r0 + i] = s_msk[i];
     }
 }
-void launch_assemble(const AssembleArgs &a, hipStream_t st)
+void launch_assemble(const AssembleArgs &a0, hipStream_t st)
 {
+    AssembleArgs a = a0;
+    if (const char *e = getenv("SKX_ASM_MODE")) a.debug_mode = atoi(e);
     const uint32_t maxr = (a.max_rows + 15u) & ~15u;
     const int nw = 8;
-    size_t lds = (size_t)maxr * 16 + (size_t)nw * (maxr + 32u);
+    size_t lds = (size_t)maxr * 16 + ((size_t)maxr / 2 + 4) * 4 + (size_t)nw * (maxr + 32u);
     hipFuncSetAttribute((const void *)assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(assemble_kernel, dim3(1u << a.logN), dim3(64 * nw), lds, st, a);
 }
@@ -804,7 +884,7 @@ __global__ void unhash_dict_kernel(const uint64_t *words, uint64_t n, uint64_t *
 {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         keys[i] = hunmix(words[i] >> 4, hp);
-        bases[i] = (uint8_t)MASK2IUPAC_D[words[i] & 15u];
+        bases[i] = mask2iupac((uint32_t)words[i] & 15u);
     }
 }
 void launch_unhash_dict(const uint64_t *words, uint64_t n, uint64_t *keys, uint8_t *bases, HashParams hp, hipStream_t st)
