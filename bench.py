@@ -72,13 +72,17 @@ def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("SKX_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))   # override: ranks sharing one GPU in tests
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a gfx950 GPU: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("SKX_BENCH_BACKEND", "nccl")      # "gloo" lets two ranks share one GPU in tests
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import dist as skdist
     import skx_engine as E

@@ -123,7 +123,8 @@ typedef struct {
     int32_t  k, rc, k_bits;
     uint64_t n_kmers;      /* split_kmers.len() */
     uint64_t n_rows;       /* variants.nrows()  */
-    uint64_t n_samples;
+    uint64_t n_samples;    /* columns held by this array                                  */
+    uint64_t total_samples;/* samples over all ranks when this array is one column slab (== n_samples otherwise) */
 } skx_array_info_t;
 int  skx_array_info(const skx_array *a, skx_array_info_t *info);
 const char *skx_array_name(const skx_array *a, uint64_t i);

@@ -569,6 +569,7 @@ extern "C" int skx_array_info(const skx_array *a, skx_array_info_t *info)
     return skx_guarded([&]() -> int {
     info->k = a->k; info->rc = a->rc; info->k_bits = a->k_bits; info->n_kmers = a->n_kmers; info->n_rows = a->n_rows;
     info->n_samples = a->names.size();
+    info->total_samples = a->total_samples ? a->total_samples : a->names.size();
     return SKX_OK;
     });
 }

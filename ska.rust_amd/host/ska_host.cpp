@@ -83,7 +83,7 @@ extern "C" int skh_apply_filters(skx_array *a, double min_freq, int filter_ambig
 {
     return skx_guarded([&]() -> int {
     skx_array_info_t info; skx_array_info(a, &info);
-    const uint64_t threshold = (uint64_t)std::ceil((double)info.n_samples * min_freq);       // generic_modes.rs:121
+    const uint64_t threshold = (uint64_t)std::ceil((double)info.total_samples * min_freq);   // generic_modes.rs:121 (nsamples() over all slabs)
     return skx_array_filter(a, threshold, filter_ambig_as_missing, filter_type, ambig_mask, ignore_const_gaps, /*update_kmers=*/0, removed);
     });
 }

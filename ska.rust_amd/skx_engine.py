@@ -32,7 +32,7 @@ class Stream(C.Structure):
 
 class ArrayInfo(C.Structure):
     _fields_ = [("k", C.c_int32), ("rc", C.c_int32), ("k_bits", C.c_int32), ("n_kmers", C.c_uint64),
-                ("n_rows", C.c_uint64), ("n_samples", C.c_uint64)]
+                ("n_rows", C.c_uint64), ("n_samples", C.c_uint64), ("total_samples", C.c_uint64)]
 
 
 class Timings(C.Structure):
