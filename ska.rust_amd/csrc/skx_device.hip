@@ -83,10 +83,11 @@ __device__ static inline uint32_t block_excl_scan(uint32_t v, uint32_t *s_tmp, u
 // chunk bases | codes+masks, later aliased by the staging buffer.  16 window-end positions per thread.  The tile's
 // words are staged bucket-by-bucket in ROUNDS passes so that the copy-out writes every (tile, bucket) chunk with
 // adjacent lanes (few, wide L2 write requests) while the staging buffer stays small enough for 2-3 workgroups per CU.
-template <bool SCATTER, int TILE, int ROUNDS>
-__global__ __launch_bounds__(TILE / 16) void extract_kernel(ExtractArgs a)
+template <bool SCATTER, int TILE, int ROUNDS, int PPT>
+__global__ __launch_bounds__(TILE / PPT) void extract_kernel(ExtractArgs a)
 {
-    constexpr int NT = TILE / 16;
+    constexpr int NT = TILE / PPT;
+    constexpr int NCH = PPT / 16;                                      // 16-base chunks per thread
     constexpr int NCHUNK = TILE / 16 + 5;                              // 4 halo chunks before, 1 after
     constexpr uint32_t STAGE_CAP = (uint32_t)(TILE / ROUNDS + TILE / (4 * ROUNDS));
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -146,31 +147,10 @@ __global__ __launch_bounds__(TILE / 16) void extract_kernel(ExtractArgs a)
     __syncthreads();
 
     const int k = a.k, h = (k - 1) / 2;
-    const int c = tid + 4;
-    // ---- which of my 16 windows exist: bit i of the 48-bit fields <-> position p0 - 32 + i ----
-    // G = good positions; W[i] = all of the k positions ending at i are good (doubling + binary decomposition of k);
-    // split_kmer.rs:89,121: a (re)start at idx is abandoned when idx + k >= len  <=>  the clean run is exactly k long
-    // (position i-k is bad) and ends at the record's last base (position i+1 is the terminator)
-    const uint64_t G = ~((uint64_t)s_bad[c - 2] | ((uint64_t)s_bad[c - 1] << 16) | ((uint64_t)s_bad[c] << 32)) & 0xFFFFFFFFFFFFull;
-    uint64_t Wk = ~0ull;
-    {
-        uint64_t A = G; int offset = 0, span = 1;
-        // A covers `span` positions; consume the bits of k from the least significant upwards
-        for (int bit = 0; bit < 6; bit++) {
-            if ((k >> bit) & 1) { Wk &= A << offset; offset += span; }
-            A &= A << span; span <<= 1;
-        }
-    }
-    const uint64_t NL = ((uint64_t)s_nl[c] << 32) | ((uint64_t)(s_nl[c + 1] & 1u) << 48);
-    const uint64_t exact = Wk & ~(G << k);
-    uint64_t V = Wk & ~(exact & (NL >> 1));
-    if (qual && a.qual_filter != 0)                                          // middle_base_qual, split_kmer.rs:328-339
-        V &= ~((((uint64_t)s_qbad[c - 2] | ((uint64_t)s_qbad[c - 1] << 16) | ((uint64_t)s_qbad[c] << 32))) << h);
-    const uint32_t vm = (uint32_t)(V >> 32) & 0xFFFFu;
-
-    // ---- rolling split k-mer over my 16 positions; arms are <= 30 bits, all 32-bit arithmetic ----
+    const int c0 = tid * NCH + 4;
+    // ---- rolling split k-mer over my PPT positions; arms are <= 30 bits, all 32-bit arithmetic ----
     const uint32_t am = (1u << (2 * h)) - 1;                                  // arm mask (h <= 15)
-    const uint64_t prev = ((uint64_t)s_code[c - 2] << 32) | s_code[c - 1];    // 32 bases before p0, first base most significant
+    const uint64_t prev = ((uint64_t)s_code[c0 - 2] << 32) | s_code[c0 - 1];  // 32 bases before p0, first base most significant
     // window ending at p0-1: upper arm | middle | lower arm  (split_kmer.rs:104-116)
     uint32_t lower = (uint32_t)prev & am;
     uint32_t mid = (uint32_t)(prev >> (2 * h)) & 3u;
@@ -178,33 +158,56 @@ __global__ __launch_bounds__(TILE / 16) void extract_kernel(ExtractArgs a)
     uint32_t rc_upper = revcomp_arm(lower, h), rc_lower = revcomp_arm(upper, h), rc_mid = mid ^ 2u;   // :149-153
     const int hb = a.hp.hb;
     const int bshift = a.hp.bits - a.logB;                  // (word >> 4) >> bshift == bucket
-    const uint32_t cw = s_code[c];
     const uint32_t rcflag = a.rc ? ~0u : 0u;
 
-    uint64_t wv[16];
-    uint32_t rk[16];                                         // (bucket << 16) | rank within the tile's bucket; bucket 0xFFFF = no window
+    uint64_t wv[PPT];
+    uint32_t rk[PPT];                                       // (bucket << 16) | rank within the tile's bucket; bucket 0xFFFF = no window
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const uint32_t code = (cw >> (30 - 2 * j)) & 3u;
-        // roll_fwd (split_kmer.rs:199-213)
-        upper = ((upper << 2) | mid) & am;
-        mid = lower >> (2 * h - 2);
-        lower = ((lower << 2) | code) & am;
-        rc_lower = (rc_lower >> 2) | (rc_mid << (2 * h - 2));
-        rc_mid = mid ^ 2u;
-        rc_upper = (rc_upper >> 2) | ((code ^ 2u) << (2 * h - 2));
-        // canonical = min(fwd, rc) (split_kmer.rs:281-295); equal arms = self-palindrome -> both middles (ska_dict.rs:85-113)
-        const bool gt = (upper != rc_upper ? upper > rc_upper : lower > rc_lower) && rcflag;
-        const bool eq = (upper == rc_upper) && (lower == rc_lower) && rcflag;
-        uint32_t hl = gt ? rc_upper : upper, hr = gt ? rc_lower : lower;
-        const uint32_t m4 = (1u << (gt ? rc_mid : mid)) | (eq ? (1u << rc_mid) : 0u);
-        hmix_halves(hl, hr, a.hp);
-        const uint64_t w = ((uint64_t)hl << (hb + 4)) | ((uint64_t)hr << 4) | m4;
-        wv[j] = w;
-        const bool valid = (vm >> j) & 1u;
-        const uint32_t bk = valid ? (uint32_t)((w >> 4) >> bshift) : (uint32_t)B;
-        const uint32_t r = atomicAdd(&s_hist[bk], 1u);
-        rk[j] = ((valid ? bk : 0xFFFFu) << 16) | (r & 0xFFFFu);
+    for (int half = 0; half < NCH; half++) {
+        const int c = c0 + half;
+        // which of these 16 windows exist: bit i of the 48-bit fields <-> position (chunk start) - 32 + i.
+        // G = good positions; W[i] = all of the k positions ending at i are good (doubling + binary decomposition of k);
+        // split_kmer.rs:89,121: a (re)start at idx is abandoned when idx + k >= len  <=>  the clean run is exactly k long
+        // (position i-k is bad) and ends at the record's last base (position i+1 is the terminator)
+        const uint64_t G = ~((uint64_t)s_bad[c - 2] | ((uint64_t)s_bad[c - 1] << 16) | ((uint64_t)s_bad[c] << 32)) & 0xFFFFFFFFFFFFull;
+        uint64_t Wk = ~0ull;
+        {
+            uint64_t A = G; int offset = 0, span = 1;
+            for (int bit = 0; bit < 6; bit++) {
+                if ((k >> bit) & 1) { Wk &= A << offset; offset += span; }
+                A &= A << span; span <<= 1;
+            }
+        }
+        const uint64_t NL = ((uint64_t)s_nl[c] << 32) | ((uint64_t)(s_nl[c + 1] & 1u) << 48);
+        const uint64_t exact = Wk & ~(G << k);
+        uint64_t V = Wk & ~(exact & (NL >> 1));
+        if (qual && a.qual_filter != 0)                                          // middle_base_qual, split_kmer.rs:328-339
+            V &= ~((((uint64_t)s_qbad[c - 2] | ((uint64_t)s_qbad[c - 1] << 16) | ((uint64_t)s_qbad[c] << 32))) << h);
+        const uint32_t vm = (uint32_t)(V >> 32) & 0xFFFFu;
+        const uint32_t cw = s_code[c];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t code = (cw >> (30 - 2 * j)) & 3u;
+            // roll_fwd (split_kmer.rs:199-213)
+            upper = ((upper << 2) | mid) & am;
+            mid = lower >> (2 * h - 2);
+            lower = ((lower << 2) | code) & am;
+            rc_lower = (rc_lower >> 2) | (rc_mid << (2 * h - 2));
+            rc_mid = mid ^ 2u;
+            rc_upper = (rc_upper >> 2) | ((code ^ 2u) << (2 * h - 2));
+            // canonical = min(fwd, rc) (split_kmer.rs:281-295); equal arms = self-palindrome -> both middles (ska_dict.rs:85-113)
+            const bool gt = (upper != rc_upper ? upper > rc_upper : lower > rc_lower) && rcflag;
+            const bool eq = (upper == rc_upper) && (lower == rc_lower) && rcflag;
+            uint32_t hl = gt ? rc_upper : upper, hr = gt ? rc_lower : lower;
+            const uint32_t m4 = (1u << (gt ? rc_mid : mid)) | (eq ? (1u << rc_mid) : 0u);
+            hmix_halves(hl, hr, a.hp);
+            const uint64_t w = ((uint64_t)hl << (hb + 4)) | ((uint64_t)hr << 4) | m4;
+            wv[16 * half + j] = w;
+            const bool valid = (vm >> j) & 1u;
+            const uint32_t bk = valid ? (uint32_t)((w >> 4) >> bshift) : (uint32_t)B;
+            const uint32_t r = atomicAdd(&s_hist[bk], 1u);
+            rk[16 * half + j] = ((valid ? bk : 0xFFFFu) << 16) | (r & 0xFFFFu);
+        }
     }
     __syncthreads();                                        // also: the code arrays are dead from here on
     uint32_t *ghist = a.hist + ((uint64_t)sample << a.logB);
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(TILE / 16) void extract_kernel(ExtractArgs a)
     if (a.debug_mode == 2) return;
     // reserve one chunk per non-empty bucket in the sample's region (global cursor); the returned bases are not needed
     // until the copy-out, so the atomics stay in flight behind the block scan and the first staging pass
-    constexpr int RMAX = (8192 * 16 + TILE - 1) / TILE;     // buckets per thread at most (B <= 8192)
+    constexpr int RMAX = (8192 + NT - 1) / NT;              // buckets per thread at most (B <= 8192)
     const int R = (B + NT - 1) / NT;
     const int b0 = tid * R < B ? tid * R : B, b1 = b0 + R < B ? b0 + R : B;
     uint32_t gb[RMAX], lsum = 0;
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(TILE / 16) void extract_kernel(ExtractArgs a)
         const uint32_t e0 = s_hist[qb0], e1 = s_hist[qb1];
         if (e1 - e0 > STAGE_CAP) { unstaged_mask |= 1u << q; continue; }     // uniform
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
+        for (int j = 0; j < PPT; j++) {
             const uint32_t b = rk[j] >> 16;
             if (b >= qb0 && b < qb1) s_stage[s_hist[b] - e0 + (rk[j] & 0xFFFFu)] = wv[j];
         }
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(TILE / 16) void extract_kernel(ExtractArgs a)
         }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
+        for (int j = 0; j < PPT; j++) {
             const uint32_t b = rk[j] >> 16;
             if (b < (uint32_t)B && ((unstaged_mask >> ((uint64_t)b * ROUNDS / B)) & 1u)) {
                 const uint32_t r = s_base[b] + s_hist[b] + (rk[j] & 0xFFFFu);
@@ -294,14 +297,14 @@ static inline size_t extract_lds(const ExtractArgs &a, bool scatter)
     size_t stage = scatter ? (size_t)(TILE / ROUNDS + TILE / (4 * ROUNDS)) * 8 : 0;
     return ((size_t)8 << a.logB) + 16 + 80 + (stage > codes ? stage : codes);
 }
-template <bool SCATTER, int TILE, int ROUNDS>
+template <bool SCATTER, int TILE, int ROUNDS, int PPT>
 static void launch_extract_t(const ExtractArgs &a, hipStream_t st)
 {
     const uint64_t g = (((uint64_t)a.n_samples + 7) / 8) * 8ull * (uint64_t)a.tiles_max;
     if (!g) return;
     const size_t lds = extract_lds<TILE, ROUNDS>(a, SCATTER);
-    hipFuncSetAttribute((const void *)extract_kernel<SCATTER, TILE, ROUNDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((extract_kernel<SCATTER, TILE, ROUNDS>), dim3((unsigned)g), dim3(TILE / 16), lds, st, a);
+    hipFuncSetAttribute((const void *)extract_kernel<SCATTER, TILE, ROUNDS, PPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((extract_kernel<SCATTER, TILE, ROUNDS, PPT>), dim3((unsigned)g), dim3(TILE / PPT), lds, st, a);
 }
 static int g_extract_variant = -1;
 static int extract_variant()
@@ -312,10 +315,12 @@ static int extract_variant()
 template <bool SCATTER>
 static void launch_extract(const ExtractArgs &a, hipStream_t st)
 {
-    if (extract_tile_bases(a.logB) == 16384) launch_extract_t<SCATTER, 16384, 2>(a, st);
-    else launch_extract_t<SCATTER, 8192, 2>(a, st);
+    if (extract_tile_bases(a.logB) == 16384) {
+        if (extract_variant() == 2) launch_extract_t<SCATTER, 16384, 4, 32>(a, st);     // 512 threads x 32 positions, 2 WGs per CU
+        else launch_extract_t<SCATTER, 16384, 2, 16>(a, st);
+    } else launch_extract_t<SCATTER, 8192, 2, 16>(a, st);
 }
-int extract_tile_bases(int logB) { return (logB <= 11 && extract_variant() == 0) ? 16384 : 8192; }
+int extract_tile_bases(int logB) { return (logB <= 11 && extract_variant() != 1) ? 16384 : 8192; }
 void launch_hist(const ExtractArgs &a, hipStream_t st) { launch_extract<false>(a, st); }
 void launch_scatter(const ExtractArgs &a0, hipStream_t st)
 {

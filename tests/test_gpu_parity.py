@@ -243,3 +243,49 @@ def test_fastq_kmer_filter(E, fastq_pair, k, min_count, qf, min_qual):
     gk, gb = ds.export(0)
     assert len(gk) == len(ok) and len(ok) > 1000
     assert np.array_equal(gk["lo"], ok["lo"]) and np.array_equal(gk["hi"], ok["hi"]) and np.array_equal(gb, ob)
+
+
+# ---- failure behaviour (the reference panics; the C ABI returns codes with the same message text) ----
+def test_error_codes(E, tmp_path):
+    with pytest.raises(E.EngineError) as ei:                                   # ska_dict.rs:342-344
+        E.DictSet.build([b"ACGTACGTACGT\n"], 6, True)
+    assert ei.value.code == E.EINVAL and "Invalid k-mer length" in str(ei.value)
+    with pytest.raises(E.EngineError) as ei:
+        E.DictSet.build([b"ACGTACGTACGT\n"], 65, True)
+    assert ei.value.code == E.EINVAL
+    with pytest.raises(E.EngineError) as ei:                                   # ska_dict.rs:374-376
+        E.DictSet.build([b"ACGTACGTACGTACGTACGTACGTACGTACGTAAA\n", b"NNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNN\n"], 31, True)
+    assert ei.value.code == E.EEMPTY and "no valid sequence" in str(ei.value)
+    p = str(tmp_path / "empty.fa")
+    open(p, "w").close()
+    with pytest.raises(E.EngineError) as ei:                                   # ska_dict.rs:131-132
+        E.Array.build([("e", p, None)], k=15)
+    assert ei.value.code == E.EIO and "Invalid path/file" in str(ei.value)
+    with pytest.raises(E.EngineError):
+        E.Array.build([("e", str(tmp_path / "missing.fa"), None)], k=15)
+    with pytest.raises(E.EngineError) as ei:                                   # not a .skf
+        E.Array.load(G.fin("test_1.fa"))
+    assert ei.value.code == E.EFORMAT
+    # merge_ska_dict.rs:78-87: k / strand mismatches between the two halves of a merge
+    a = E.DictSet.build([b"ACGTTGCAAGGCTTAACCGGTTAAGC\n"], 9, True)
+    b = E.DictSet.build([b"ACGTTGCAAGGCTTAACCGGTTAAGC\n"], 11, True)
+    with pytest.raises(E.EngineError) as ei:
+        a.assemble(b.union_keys(), ["x"])
+    assert "K-mer lengths do not match" in str(ei.value)
+    c = E.DictSet.build([b"ACGTTGCAAGGCTTAACCGGTTAAGC\n"], 9, False)
+    with pytest.raises(E.EngineError) as ei:
+        a.assemble(c.union_keys(), ["x"])
+    assert "Strand use inconsistent" in str(ei.value)
+
+
+def test_ragged_and_tiny_inputs(E):
+    """empty records, a sample that is one k+1 record, single-sample arrays, k=5 (8-bit keys)."""
+    samples = [[b"", b"ACGTAC", b"", b"ACGTACGT" * 3], [b"ACGTAC"], [b"TTTTTTGACCA", b""]]
+    check_dicts(E, samples, 5, True)
+    check_dicts(E, [samples[0], samples[2]], 7, False)
+    ga, oa = build_both(E, [[b"ACGTACGTTGCA" * 4]], 9, True)
+    assert as_map(*ga.export()) == as_map(*oa.export())
+    g = ga.align(filter_type=E.FILTER_NONE, min_freq=0.0).decode().splitlines()
+    o = oa.align(filter_type=ora.FILTER_NONE, min_freq=0.0).decode().splitlines()
+    assert g[0] == o[0] and sorted(g[1]) == sorted(o[1])
+    assert ga.nk(True).decode().split("\n")[0].startswith("ska_version=")
