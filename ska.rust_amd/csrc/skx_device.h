@@ -18,7 +18,7 @@ int extract_tile_bases(int logB);         // window end positions per workgroup 
 constexpr int MAX_LOGB = 13;              // buckets per sample <= 8192 (LDS histogram)
 constexpr uint64_t EMPTY64 = ~0ull;
 
-// H: a 3-round Feistel bijection on the 2(k-1)-bit split k-mer (upper arm | lower arm), 32-bit arithmetic only.
+// H: a 2-round Feistel bijection on the 2(k-1)-bit split k-mer (upper arm | lower arm), 32-bit arithmetic only.
 // Its top bits are uniform whatever the genome's composition, so hash buckets are balanced; "engine order" of
 // keys is the numeric order of H(key).
 struct HashParams {
@@ -31,7 +31,7 @@ HashParams make_hash_params(int k);
 __host__ __device__ inline uint32_t hround(uint32_t v, uint32_t c, int hb) { return (v * c) >> (32 - hb); }
 __host__ __device__ inline void hmix_halves(uint32_t &L, uint32_t &R, const HashParams &p)
 {
-    L ^= hround(R, p.c[0], p.hb); R ^= hround(L, p.c[1], p.hb); L ^= hround(R, p.c[2], p.hb);
+    L ^= hround(R, p.c[0], p.hb); R ^= hround(L, p.c[1], p.hb);
 }
 __host__ __device__ inline uint64_t hmix(uint64_t x, const HashParams &p)
 {
@@ -42,7 +42,7 @@ __host__ __device__ inline uint64_t hmix(uint64_t x, const HashParams &p)
 __host__ __device__ inline uint64_t hunmix(uint64_t x, const HashParams &p)
 {
     uint32_t L = (uint32_t)(x >> p.hb), R = (uint32_t)x & p.hmask;
-    L ^= hround(R, p.c[2], p.hb); R ^= hround(L, p.c[1], p.hb); L ^= hround(R, p.c[0], p.hb);
+    R ^= hround(L, p.c[1], p.hb); L ^= hround(R, p.c[0], p.hb);
     return ((uint64_t)L << p.hb) | R;
 }
 

@@ -146,6 +146,7 @@ __global__ __launch_bounds__(TILE / PPT) void extract_kernel(ExtractArgs a)
     }
     __syncthreads();
 
+    if (a.debug_mode == 5) return;
     const int k = a.k, h = (k - 1) / 2;
     const int c0 = tid * NCH + 4;
     // ---- rolling split k-mer over my PPT positions; arms are <= 30 bits, all 32-bit arithmetic ----
@@ -159,6 +160,8 @@ __global__ __launch_bounds__(TILE / PPT) void extract_kernel(ExtractArgs a)
     const int hb = a.hp.hb;
     const int bshift = a.hp.bits - a.logB;                  // (word >> 4) >> bshift == bucket
     const uint32_t rcflag = a.rc ? ~0u : 0u;
+    const bool top_from_hl = a.logB <= hb;                  // bucket = top logB bits of H = top bits of the hashed upper arm
+    const int top_shift = top_from_hl ? hb - a.logB : 0;
 
     uint64_t wv[PPT];
     uint32_t rk[PPT];                                       // (bucket << 16) | rank within the tile's bucket; bucket 0xFFFF = no window
@@ -196,16 +199,17 @@ __global__ __launch_bounds__(TILE / PPT) void extract_kernel(ExtractArgs a)
             rc_mid = mid ^ 2u;
             rc_upper = (rc_upper >> 2) | ((code ^ 2u) << (2 * h - 2));
             // canonical = min(fwd, rc) (split_kmer.rs:281-295); equal arms = self-palindrome -> both middles (ska_dict.rs:85-113)
-            const bool gt = (upper != rc_upper ? upper > rc_upper : lower > rc_lower) && rcflag;
-            const bool eq = (upper == rc_upper) && (lower == rc_lower) && rcflag;
+            const uint64_t kf = ((uint64_t)upper << 32) | lower, kr = ((uint64_t)rc_upper << 32) | rc_lower;   // one 64-bit compare each
+            const bool gt = kf > kr && rcflag;
+            const bool eq = kf == kr && rcflag;
             uint32_t hl = gt ? rc_upper : upper, hr = gt ? rc_lower : lower;
             const uint32_t m4 = (1u << (gt ? rc_mid : mid)) | (eq ? (1u << rc_mid) : 0u);
             hmix_halves(hl, hr, a.hp);
             const uint64_t w = ((uint64_t)hl << (hb + 4)) | ((uint64_t)hr << 4) | m4;
             wv[16 * half + j] = w;
             const bool valid = (vm >> j) & 1u;
-            const uint32_t bk = valid ? (uint32_t)((w >> 4) >> bshift) : (uint32_t)B;
-            const uint32_t r = atomicAdd(&s_hist[bk], 1u);
+            const uint32_t bk = valid ? (top_from_hl ? hl >> top_shift : (uint32_t)((w >> 4) >> bshift)) : (uint32_t)B;
+            const uint32_t r = a.debug_mode == 6 ? (uint32_t)(w >> 40) : atomicAdd(&s_hist[bk], 1u);
             rk[16 * half + j] = ((valid ? bk : 0xFFFFu) << 16) | (r & 0xFFFFu);
         }
     }
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(TILE / PPT) void extract_kernel(ExtractArgs a)
         for (int i = tid; i < B; i += NT) { uint32_t n = s_hist[i]; if (n) atomicAdd(&ghist[i], n); }
         return;
     }
-    if (a.debug_mode == 2) return;
+    if (a.debug_mode == 2 || a.debug_mode == 6) { if (rk[3] == 0x12345u && wv[5] == 77) *a.overflow = 1; return; }
     // reserve one chunk per non-empty bucket in the sample's region (global cursor); the returned bases are not needed
     // until the copy-out, so the atomics stay in flight behind the block scan and the first staging pass
     constexpr int RMAX = (8192 + NT - 1) / NT;              // buckets per thread at most (B <= 8192)
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(TILE / PPT) void extract_kernel(ExtractArgs a)
     for (int q = 0; q < ROUNDS; q++) {
         const uint32_t qb0 = (uint32_t)(((uint64_t)B * q) / ROUNDS), qb1 = (uint32_t)(((uint64_t)B * (q + 1)) / ROUNDS);
         const uint32_t e0 = s_hist[qb0], e1 = s_hist[qb1];
-        if (e1 - e0 > STAGE_CAP) { unstaged_mask |= 1u << q; continue; }     // uniform
+        if (e1 - e0 > STAGE_CAP || a.debug_mode == 7) { unstaged_mask |= 1u << q; continue; }     // uniform
 #pragma unroll
         for (int j = 0; j < PPT; j++) {
             const uint32_t b = rk[j] >> 16;
