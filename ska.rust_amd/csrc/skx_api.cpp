@@ -413,6 +413,8 @@ static int keyset_finish(skx_keyset *ks)      // scan ncnt -> roff, total, max_r
     SKX_HIP(hipMemcpyAsync(&ks->total, ks->roff.p + nsub, 8, hipMemcpyDeviceToHost, st));
     SKX_HIP(hipMemcpyAsync(&ks->max_rows, d_max.p, 4, hipMemcpyDeviceToHost, st));
     SKX_HIP(hipStreamSynchronize(st));
+    if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] keyset: logN=%d sub-buckets=%llu rows=%llu mean=%.1f max=%u\n", ks->logN, (unsigned long long)nsub,
+                                 (unsigned long long)ks->total, (double)ks->total / (double)nsub, ks->max_rows);
     return SKX_OK;
 }
 

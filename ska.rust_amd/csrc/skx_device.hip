@@ -110,17 +110,21 @@ __global__ __launch_bounds__(TILE / PPT) void extract_kernel(ExtractArgs a)
     const uint64_t len = a.lens[sample];
     const uint64_t T0 = tile * TILE;
     if (T0 >= len) return;
-    const uint8_t *seq = a.seqs[sample];
-    const uint8_t *qual = a.quals ? a.quals[sample] : nullptr;
+    // record streams live in HBM: explicit global address space (a pointer fetched from memory is generic -> flat_load)
+    typedef const uint8_t __attribute__((address_space(1))) *gbytes_t;
+    gbytes_t seq = (gbytes_t)(uintptr_t)a.seqs[sample];
+    gbytes_t qual = a.quals ? (gbytes_t)(uintptr_t)a.quals[sample] : (gbytes_t)0;
 
     for (int i = tid; i < B + 4; i += NT) s_hist[i] = 0;
     for (int c = tid; c < NCHUNK; c += NT) {
         const int64_t p = (int64_t)T0 - 64 + 16 * (int64_t)c;
         uint32_t w[4], q[4] = {0, 0, 0, 0};
         if (p >= 0 && (uint64_t)p + 16 <= len) {
-            uint4 v = *reinterpret_cast<const uint4 *>(seq + p);
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            typedef const u32x4 __attribute__((address_space(1))) *gvec_t;
+            const u32x4 v = *(gvec_t)(seq + p);
             w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-            if (qual) { uint4 u = *reinterpret_cast<const uint4 *>(qual + p); q[0] = u.x; q[1] = u.y; q[2] = u.z; q[3] = u.w; }
+            if (qual) { const u32x4 u = *(gvec_t)(qual + p); q[0] = u.x; q[1] = u.y; q[2] = u.z; q[3] = u.w; }
         } else {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -645,9 +649,15 @@ void launch_dedupe_mb(uint64_t *words, const uint64_t *off, const uint32_t *raw,
     else launch_dedupe_items<24>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, lds, st);     // host keeps regions <= 6144 words
 }
 
+// pointers that reach a kernel inside an argument struct are generic (flat_load: slower, and it also ticks the LDS
+// counter); dictionary words only ever live in HBM, so read them through an explicit global-address-space pointer
+typedef const uint64_t __attribute__((address_space(1))) *gwords_t;
+__device__ static inline gwords_t as_global(const uint64_t *p) { return (gwords_t)(uintptr_t)p; }
+
 // first index in [0,n) whose hashed key (word >> 4) is >= x
-__device__ static inline uint32_t lower_bound_words(const uint64_t *reg, uint32_t n, uint64_t x)
+__device__ static inline uint32_t lower_bound_words(const uint64_t *reg_, uint32_t n, uint64_t x)
 {
+    gwords_t reg = as_global(reg_);
     uint32_t lo = 0, hi = n;
     while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if ((reg[mid] >> 4) < x) lo = mid + 1; else hi = mid; }
     return lo;
@@ -687,10 +697,10 @@ __global__ __launch_bounds__(1024) void union_kernel(DictView d, int logN, uint6
         if (s0 + lane < d.n_samples) sub_slice(d, s0 + lane, j, logN, my_reg, my_lo, my_hi);
         const int cnt = d.n_samples - s0 < 64 ? d.n_samples - s0 : 64;
         for (int t = 0; t < cnt; t++) {
-            const uint64_t *reg = reinterpret_cast<const uint64_t *>(__shfl((unsigned long long)my_reg, t, 64));
+            gwords_t reg = as_global(reinterpret_cast<const uint64_t *>(__shfl((unsigned long long)my_reg, t, 64)));
             const uint32_t lo = __shfl(my_lo, t, 64), hi = __shfl(my_hi, t, 64);
             for (uint32_t i0 = lo; i0 < hi; i0 += 512) {
-                uint64_t wq[8];                               // 8 words per lane in flight per memory round trip
+                uint64_t wq[8];                               // 8 words per lane in flight per memory round trip (clamped, branch-free)
 #pragma unroll
                 for (int u = 0; u < 8; u++) { const uint32_t i = i0 + 64u * u + lane; wq[u] = i < hi ? reg[i] : 0ull; }
 #pragma unroll
@@ -770,46 +780,34 @@ __global__ __launch_bounds__(512) void assemble_kernel(AssembleArgs a)
     const uint64_t r0 = a.roff[j];
     const uint32_t shift = (uint32_t)(r0 & 15u);
     unsigned char *row = s_rows + (size_t)wv * (maxr + 32u);      // 16-B aligned; cell i lives at row[shift + i]
-    // every lane binary-searches the slice of one sample (64 searches in flight); the wave then handles the slices in turn
+    // every lane binary-searches the slice of one sample (64 searches in flight); the wave then handles the slices in turn.
+    // Slices are addressed as offsets from the kernel-argument pointer (global address space, no flat loads) and read
+    // with clamped, branch-free loads so that 8 words per lane are in flight per memory round trip.
+    const uint64_t *wbase = a.d.words;
     for (int sbase = wv * 64; sbase < a.d.n_samples; sbase += nw * 64) {
-        const uint64_t *my_reg = nullptr; uint32_t my_lo = 0, my_hi = 0;
-        if (sbase + lane < a.d.n_samples) sub_slice(a.d, sbase + lane, j, a.logN, my_reg, my_lo, my_hi);
-        const int cnt = a.d.n_samples - sbase < 64 ? a.d.n_samples - sbase : 64;
-        // software pipeline over the 64 slices: the first 512 words of slice t+1 are in flight while slice t is looked up
-        uint64_t nq[8];
-        {
-            const uint64_t *reg0 = reinterpret_cast<const uint64_t *>(__shfl((unsigned long long)my_reg, 0, 64));
-            const uint32_t lo0 = __shfl(my_lo, 0, 64), hi0 = __shfl(my_hi, 0, 64);
-#pragma unroll
-            for (int u = 0; u < 8; u++) { const uint32_t i = lo0 + 64u * u + lane; nq[u] = i < hi0 ? reg0[i] : 0ull; }
+        uint64_t my_off = 0; uint32_t my_lo = 0, my_hi = 0;
+        if (sbase + lane < a.d.n_samples) {
+            const uint64_t *my_reg = nullptr;
+            sub_slice(a.d, sbase + lane, j, a.logN, my_reg, my_lo, my_hi);
+            my_off = (uint64_t)(my_reg - wbase);
         }
+        const int cnt = a.d.n_samples - sbase < 64 ? a.d.n_samples - sbase : 64;
         for (int t = 0; t < cnt; t++) {
             const int s = sbase + t;
-            const uint64_t *reg = reinterpret_cast<const uint64_t *>(__shfl((unsigned long long)my_reg, t, 64));
+            gwords_t reg = as_global(wbase + __shfl((unsigned long long)my_off, t, 64));
             const uint32_t lo = __shfl(my_lo, t, 64), hi = __shfl(my_hi, t, 64);
-            uint64_t wq[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) wq[u] = nq[u];
-            {
-                const int tn = t + 1 < cnt ? t + 1 : t;
-                const uint64_t *regn = reinterpret_cast<const uint64_t *>(__shfl((unsigned long long)my_reg, tn, 64));
-                const uint32_t lon = __shfl(my_lo, tn, 64), hin = t + 1 < cnt ? __shfl(my_hi, tn, 64) : 0u;
-#pragma unroll
-                for (int u = 0; u < 8; u++) { const uint32_t i = lon + 64u * u + lane; nq[u] = i < hin ? regn[i] : 0ull; }
-            }
             // fill with '-'
             for (uint32_t i = lane * 4; i < n + shift + 3; i += 256) *reinterpret_cast<uint32_t *>(row + i) = 0x2D2D2D2Du;
             __builtin_amdgcn_wave_barrier();
             if (!(a.debug_mode & 2))
             for (uint32_t i0 = lo; i0 < hi; i0 += 512) {
-                if (i0 != lo) {
+                uint64_t wq[8];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) { const uint32_t i = i0 + 64u * u + lane; wq[u] = i < hi ? reg[i] : 0ull; }
-                }
+                for (int u = 0; u < 8; u++) { const uint32_t i = i0 + 64u * u + lane; wq[u] = i < hi ? reg[i] : 0ull; }
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const uint64_t w = wq[u];
-                    if (!w) continue;
+                    if (i0 + 64u * u + lane >= hi) continue;
                     const uint64_t key = w >> 4;
                     const uint32_t ib = (uint32_t)((key & lmask) >> (rem - logI));
                     uint32_t l = s_idx[ib];
@@ -817,10 +815,9 @@ __global__ __launch_bounds__(512) void assemble_kernel(AssembleArgs a)
                     while (l < le && s_keys[l] < key) l++;
                     if (l < le && s_keys[l] == key) {
                         const uint32_t m4 = (uint32_t)(w & 15u);
-                        row[shift + l] = mask2iupac(m4);
+                        if (!(a.debug_mode & 8)) row[shift + l] = mask2iupac(m4);
                         const uint32_t single = (m4 & (m4 - 1)) == 0;
-                        atomicAdd(&s_cnt[l], 1u | (single << 16));
-                        atomicOr(&s_msk[l], 1u << m4);
+                        if (!(a.debug_mode & 4)) { atomicAdd(&s_cnt[l], 1u | (single << 16)); atomicOr(&s_msk[l], 1u << m4); }
                     } else {
                         *a.missing = 1;
                     }
