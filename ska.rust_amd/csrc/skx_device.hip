@@ -311,7 +311,7 @@ static void launch_extract_t(const ExtractArgs &a, hipStream_t st)
     const uint64_t g = (((uint64_t)a.n_samples + 7) / 8) * 8ull * (uint64_t)a.tiles_max;
     if (!g) return;
     const size_t lds = extract_lds<TILE, ROUNDS>(a, SCATTER);
-    hipFuncSetAttribute((const void *)extract_kernel<SCATTER, TILE, ROUNDS, PPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)extract_kernel<SCATTER, TILE, ROUNDS, PPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((extract_kernel<SCATTER, TILE, ROUNDS, PPT>), dim3((unsigned)g), dim3(TILE / PPT), lds, st, a);
 }
 static int g_extract_variant = -1;
@@ -517,7 +517,7 @@ void launch_dedupe(uint64_t *words, const uint64_t *off, const uint32_t *raw, ui
 {
     if (!n_regions) return;
     size_t lds = (size_t)(table_slots + TABLE_PAD) * 8;
-    hipFuncSetAttribute((const void *)dedupe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)dedupe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(dedupe_kernel, dim3((unsigned)n_regions), dim3(256), lds, st, words, off, raw, ucnt, table_slots, rem_bits, overflow);
 }
 
@@ -633,7 +633,7 @@ template <int ITEMS>
 static void launch_dedupe_items(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_regions, uint32_t cap,
                                 int rem_bits, int *overflow, size_t lds, hipStream_t st)
 {
-    hipFuncSetAttribute((const void *)dedupe_mb_kernel<ITEMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)dedupe_mb_kernel<ITEMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const char *e = getenv("SKX_DEDUPE_MODE");
     hipLaunchKernelGGL(dedupe_mb_kernel<ITEMS>, dim3((unsigned)n_regions), dim3(256), lds, st, words, off, raw, ucnt, cap, rem_bits, overflow, e ? atoi(e) : 0);
 }
@@ -726,13 +726,13 @@ void launch_union(const DictView &d, int logN, uint64_t *stage, uint32_t stride,
                   int *overflow, hipStream_t st)
 {
     size_t lds = (size_t)(table_slots + TABLE_PAD) * 8;
-    hipFuncSetAttribute((const void *)union_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)union_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(union_kernel<false>, dim3(1u << logN), dim3(1024), lds, st, d, logN, stage, stride, ncnt, table_slots, overflow);
 }
 void launch_union_probe(const DictView &d, int logP, int probe, uint32_t *cnt, uint32_t table_slots, int *overflow, hipStream_t st)
 {
     size_t lds = (size_t)(table_slots + TABLE_PAD) * 8;
-    hipFuncSetAttribute((const void *)union_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)union_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(union_kernel<true>, dim3((unsigned)probe), dim3(1024), lds, st, d, logP, (uint64_t *)nullptr, 0u, cnt, table_slots, overflow);
 }
 
@@ -854,7 +854,7 @@ void launch_assemble(const AssembleArgs &a0, hipStream_t st)
     const uint32_t maxr = (a.max_rows + 15u) & ~15u;
     const int nw = 8;
     size_t lds = (size_t)maxr * 16 + ((size_t)maxr / 2 + 4) * 4 + (size_t)nw * (maxr + 32u);
-    hipFuncSetAttribute((const void *)assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(assemble_kernel, dim3(1u << a.logN), dim3(64 * nw), lds, st, a);
 }
 
