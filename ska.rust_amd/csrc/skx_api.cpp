@@ -263,6 +263,13 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
           else launch_dedupe_mb(d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, cap, hp.bits - logB, d_flag.p, st); }
         int overflow = 0;
         SKX_HIP(hipMemcpyAsync(&overflow, d_flag.p, 4, hipMemcpyDeviceToHost, st));
+        SKX_HIP(hipStreamSynchronize(st));
+        if (!wide && overflow == 2) {
+            // regions beyond the counting sort's capacity (repeat-rich buckets): table-based dedupe, only distinct keys must fit
+            SKX_TRY(d_flag.zero(st));
+            { StageTimer t(ctx, &ctx->tm.dedupe); launch_dedupe(d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, LDS_TABLE_MAX, hp.bits - logB, d_flag.p, cap, st); }
+            SKX_HIP(hipMemcpyAsync(&overflow, d_flag.p, 4, hipMemcpyDeviceToHost, st));
+        }
         std::vector<uint32_t> ucnt(nreg);
         SKX_HIP(hipMemcpyAsync(ucnt.data(), d->ucnt.p, nreg * 4, hipMemcpyDeviceToHost, st));
         SKX_HIP(hipStreamSynchronize(st));

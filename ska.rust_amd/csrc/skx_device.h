@@ -97,7 +97,7 @@ void launch_scan_u32(const uint32_t *in, uint64_t *out, uint64_t n, uint32_t *ma
 
 // in-place sort + dedupe (OR of masks) of every (sample,bucket) region through an order-preserving LDS table
 void launch_dedupe(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_regions,
-                   uint32_t table_slots, int rem_bits, int *overflow, hipStream_t st);
+                   uint32_t table_slots, int rem_bits, int *overflow, uint32_t min_n, hipStream_t st);
 
 void launch_dedupe_mb(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_regions,
                       uint32_t cap, int rem_bits, int *overflow, hipStream_t st);

@@ -489,14 +489,17 @@ __device__ static inline uint32_t table_emit_sorted(const unsigned long long *ta
 }
 
 // K3: per (sample,bucket) region: dedupe (OR of base masks) + sort, in place
+// K3 (fallback for regions larger than the counting sort's LDS capacity, i.e. heavy repeat content: tandem repeats,
+// homopolymers): duplicates collapse on insertion, so only the number of DISTINCT keys has to fit.
 __global__ __launch_bounds__(256) void dedupe_kernel(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt,
-                                                     uint32_t nslots, int rem_bits, int *overflow)
+                                                     uint32_t nslots, int rem_bits, int *overflow, uint32_t min_n)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_tab[];
     __shared__ uint32_t s_tmp[17];
     __shared__ int s_fail;
     const uint64_t region = blockIdx.x;
     const uint32_t n = raw[region];
+    if (n <= min_n) return;                                  // handled by the counting-sort kernel
     if (n == 0) { if (threadIdx.x == 0) ucnt[region] = 0; return; }
     const uint32_t total_slots = nslots + TABLE_PAD;
     for (uint32_t i = threadIdx.x; i < total_slots; i += blockDim.x) s_tab[i] = 0ull;
@@ -513,12 +516,12 @@ __global__ __launch_bounds__(256) void dedupe_kernel(uint64_t *words, const uint
     if (threadIdx.x == 0) ucnt[region] = total;
 }
 void launch_dedupe(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_regions,
-                   uint32_t table_slots, int rem_bits, int *overflow, hipStream_t st)
+                   uint32_t table_slots, int rem_bits, int *overflow, uint32_t min_n, hipStream_t st)
 {
     if (!n_regions) return;
     size_t lds = (size_t)(table_slots + TABLE_PAD) * 8;
     (void)hipFuncSetAttribute((const void *)dedupe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(dedupe_kernel, dim3((unsigned)n_regions), dim3(256), lds, st, words, off, raw, ucnt, table_slots, rem_bits, overflow);
+    hipLaunchKernelGGL(dedupe_kernel, dim3((unsigned)n_regions), dim3(256), lds, st, words, off, raw, ucnt, table_slots, rem_bits, overflow, min_n);
 }
 
 // K3 (fast path): counting sort of a region into micro-buckets of ~2-4 words by the next hash bits, then a tiny
@@ -533,7 +536,7 @@ __global__ __launch_bounds__(256) void dedupe_mb_kernel(uint64_t *words, const u
     const uint64_t region = blockIdx.x;
     const uint32_t n = raw[region];
     if (n == 0) { if (threadIdx.x == 0) ucnt[region] = 0; return; }
-    if (n > cap || n > 256u * ITEMS) { if (threadIdx.x == 0) { *overflow = 1; ucnt[region] = 0; } return; }
+    if (n > cap || n > 256u * ITEMS) { if (threadIdx.x == 0) atomicOr(overflow, 2); return; }      // left to dedupe_kernel
     uint64_t *s_elem = reinterpret_cast<uint64_t *>(s_mem);                 // [cap]
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_mem + (size_t)cap * 8); // [M] counts -> cursors -> unique counts
     uint32_t *s_start = s_cnt + cap / 2;                                     // [M] micro-bucket starts

@@ -289,3 +289,16 @@ def test_ragged_and_tiny_inputs(E):
     o = oa.align(filter_type=ora.FILTER_NONE, min_freq=0.0).decode().splitlines()
     assert g[0] == o[0] and sorted(g[1]) == sorted(o[1])
     assert ga.nk(True).decode().split("\n")[0].startswith("ska_version=")
+
+
+def test_repeat_rich_sample(E):
+    """Tandem repeats / homopolymers put tens of thousands of identical split k-mers into one hash bucket: the region
+    overflows the fixed-capacity layout (-> exact histogram pass) and the counting sort (-> table dedupe)."""
+    rng = np.random.default_rng(9)
+    rnd = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=150_000).tolist())
+    recs = [rnd[:60_000] + b"AT" * 12_000 + rnd[60_000:90_000], b"A" * 20_000 + rnd[90_000:], b"GATTACA" * 5_000, b"ACGT" * 9_000]
+    for k, rc in ((31, True), (15, False)):
+        ds = check_dicts(E, [recs, [rnd]], k, rc)
+        ga = ds.merge(["rep", "rnd"])
+        oa = ora.Array.from_dicts([oracle_dict(recs, k, rc), oracle_dict([rnd], k, rc)], ["rep", "rnd"])
+        assert as_map(*ga.export()) == as_map(*oa.export())
