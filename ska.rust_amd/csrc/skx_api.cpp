@@ -435,8 +435,7 @@ static int keyset_union_views(skx_ctx *ctx, const DictView *views, int nviews, i
     DevBuf<int> d_flag; SKX_TRY(d_flag.alloc(1));
     int min_logN = 0;
     for (int v = 0; v < nviews; v++) min_logN = std::max(min_logN, views[v].logB);
-    uint32_t table = wide ? 4096 : 8192, stride = wide ? 2048 : 4096, target = wide ? 1200 : 2500;
-    if (const char *e = getenv("SKX_ROW_TARGET")) target = (uint32_t)atoi(e);
+    const uint32_t table = wide ? 4096 : 8192, stride = wide ? 2048 : 4096, target = wide ? 1200 : 2500;
     int logN = std::max(min_logN, std::min(kbits, ilog2_ceil((est_hint + target - 1) / target)));
     for (;; logN++) {
         std::unique_ptr<skx_keyset> ks(new skx_keyset());

@@ -84,7 +84,6 @@ struct ExtractArgs {
     uint64_t *words;              // dict storage (pass 2)
     uint32_t capacity;            // words per region (pass 2): ranks beyond it are dropped and *overflow is set
     int *overflow;
-    int debug_mode;               // profiling aid (SKX_SCATTER_MODE): 1 = no stores, 2 = no global atomics/stores
 };
 
 void launch_hist(const ExtractArgs &a, hipStream_t st);
@@ -127,7 +126,6 @@ struct AssembleArgs {
     uint32_t *col_mask;        // [U] bit c set iff IUPAC set-code c (1..15) occurs in the column
     uint32_t max_rows;         // max ncnt (LDS sizing)
     int *missing;              // set if a dict key is not among the rows
-    int debug_mode;            // profiling aid (SKX_ASM_MODE)
 };
 void launch_assemble(const AssembleArgs &a, hipStream_t st);
 

@@ -150,7 +150,6 @@ __global__ __launch_bounds__(TILE / PPT) void extract_kernel(ExtractArgs a)
     }
     __syncthreads();
 
-    if (a.debug_mode == 5) return;
     const int k = a.k, h = (k - 1) / 2;
     const int c0 = tid * NCH + 4;
     // ---- rolling split k-mer over my PPT positions; arms are <= 30 bits, all 32-bit arithmetic ----
@@ -213,7 +212,7 @@ __global__ __launch_bounds__(TILE / PPT) void extract_kernel(ExtractArgs a)
             wv[16 * half + j] = w;
             const bool valid = (vm >> j) & 1u;
             const uint32_t bk = valid ? (top_from_hl ? hl >> top_shift : (uint32_t)((w >> 4) >> bshift)) : (uint32_t)B;
-            const uint32_t r = a.debug_mode == 6 ? (uint32_t)(w >> 40) : atomicAdd(&s_hist[bk], 1u);
+            const uint32_t r = atomicAdd(&s_hist[bk], 1u);
             rk[16 * half + j] = ((valid ? bk : 0xFFFFu) << 16) | (r & 0xFFFFu);
         }
     }
@@ -223,7 +222,6 @@ __global__ __launch_bounds__(TILE / PPT) void extract_kernel(ExtractArgs a)
         for (int i = tid; i < B; i += NT) { uint32_t n = s_hist[i]; if (n) atomicAdd(&ghist[i], n); }
         return;
     }
-    if (a.debug_mode == 2 || a.debug_mode == 6) { if (rk[3] == 0x12345u && wv[5] == 77) *a.overflow = 1; return; }
     // reserve one chunk per non-empty bucket in the sample's region (global cursor); the returned bases are not needed
     // until the copy-out, so the atomics stay in flight behind the block scan and the first staging pass
     constexpr int RMAX = (8192 + NT - 1) / NT;              // buckets per thread at most (B <= 8192)
@@ -247,7 +245,6 @@ __global__ __launch_bounds__(TILE / PPT) void extract_kernel(ExtractArgs a)
     }
     if (tid == 0) s_hist[B] = total;                        // sentinel: start of the (non-existent) bucket B
     __syncthreads();
-    if (a.debug_mode == 1) return;
     const uint64_t *off = a.off + ((uint64_t)sample << a.logB);
     const bool fixed = a.capacity != 0xFFFFFFFFu;           // fixed-capacity regions: offsets are arithmetic
     const uint64_t reg0 = ((uint64_t)sample << a.logB) * a.capacity;
@@ -258,7 +255,7 @@ __global__ __launch_bounds__(TILE / PPT) void extract_kernel(ExtractArgs a)
     for (int q = 0; q < ROUNDS; q++) {
         const uint32_t qb0 = (uint32_t)(((uint64_t)B * q) / ROUNDS), qb1 = (uint32_t)(((uint64_t)B * (q + 1)) / ROUNDS);
         const uint32_t e0 = s_hist[qb0], e1 = s_hist[qb1];
-        if (e1 - e0 > STAGE_CAP || a.debug_mode == 7) { unstaged_mask |= 1u << q; continue; }     // uniform
+        if (e1 - e0 > STAGE_CAP) { unstaged_mask |= 1u << q; continue; }     // uniform
 #pragma unroll
         for (int j = 0; j < PPT; j++) {
             const uint32_t b = rk[j] >> 16;
@@ -274,7 +271,6 @@ __global__ __launch_bounds__(TILE / PPT) void extract_kernel(ExtractArgs a)
             const uint64_t w = s_stage[i];
             const uint32_t b = (uint32_t)((w >> 4) >> bshift);
             const uint32_t r = s_base[b] + e0 + i;
-            if (a.debug_mode == 4) continue;                                                           // profiling: staging only
             if (r < a.capacity) a.words[(fixed ? reg0 + (uint64_t)b * a.capacity : off[b]) + r] = w; else dropped = true;
         }
         __syncthreads();
@@ -314,28 +310,16 @@ static void launch_extract_t(const ExtractArgs &a, hipStream_t st)
     (void)hipFuncSetAttribute((const void *)extract_kernel<SCATTER, TILE, ROUNDS, PPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((extract_kernel<SCATTER, TILE, ROUNDS, PPT>), dim3((unsigned)g), dim3(TILE / PPT), lds, st, a);
 }
-static int g_extract_variant = -1;
-static int extract_variant()
-{
-    if (g_extract_variant < 0) { const char *e = getenv("SKX_EXTRACT_VARIANT"); g_extract_variant = e ? atoi(e) : 0; }
-    return g_extract_variant;
-}
 template <bool SCATTER>
 static void launch_extract(const ExtractArgs &a, hipStream_t st)
 {
-    if (extract_tile_bases(a.logB) == 16384) {
-        if (extract_variant() == 2) launch_extract_t<SCATTER, 16384, 4, 32>(a, st);     // 512 threads x 32 positions, 2 WGs per CU
-        else launch_extract_t<SCATTER, 16384, 2, 16>(a, st);
-    } else launch_extract_t<SCATTER, 8192, 2, 16>(a, st);
+    // 16 384 positions x 1 024 threads while the two [B] LDS arrays leave room for the staging buffer, else half of that
+    if (extract_tile_bases(a.logB) == 16384) launch_extract_t<SCATTER, 16384, 2, 16>(a, st);
+    else launch_extract_t<SCATTER, 8192, 2, 16>(a, st);
 }
-int extract_tile_bases(int logB) { return (logB <= 11 && extract_variant() != 1) ? 16384 : 8192; }
+int extract_tile_bases(int logB) { return logB <= 11 ? 16384 : 8192; }
 void launch_hist(const ExtractArgs &a, hipStream_t st) { launch_extract<false>(a, st); }
-void launch_scatter(const ExtractArgs &a0, hipStream_t st)
-{
-    ExtractArgs a = a0;
-    if (const char *e = getenv("SKX_SCATTER_MODE")) a.debug_mode = atoi(e);
-    launch_extract<true>(a, st);
-}
+void launch_scatter(const ExtractArgs &a, hipStream_t st) { launch_extract<true>(a, st); }
 
 // ------------------------------------------------------------------------------------------------
 // block-wide helpers
@@ -529,7 +513,7 @@ void launch_dedupe(uint64_t *words, const uint64_t *off, const uint32_t *raw, ui
 // chains: cost is O(n) LDS operations per region whatever the duplication level.
 template <int ITEMS>
 __global__ __launch_bounds__(256) void dedupe_mb_kernel(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt,
-                                                        uint32_t cap, int rem_bits, int *overflow, int dbg)
+                                                        uint32_t cap, int rem_bits, int *overflow)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
     __shared__ uint32_t s_tmp[17];
@@ -557,7 +541,6 @@ __global__ __launch_bounds__(256) void dedupe_mb_kernel(uint64_t *words, const u
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) if (e[t]) atomicAdd(&s_cnt[(uint32_t)(((e[t] >> 4) & lmask) >> mshift)], 1u);
     __syncthreads();
-    if (dbg == 1) return;
     // exclusive scan of the counts (each thread owns R consecutive micro-buckets)
     const uint32_t R = (M + 255) / 256;
     const uint32_t m0 = threadIdx.x * R < M ? threadIdx.x * R : M, m1 = m0 + R < M ? m0 + R : M;
@@ -574,7 +557,6 @@ __global__ __launch_bounds__(256) void dedupe_mb_kernel(uint64_t *words, const u
     }
     if (threadIdx.x == 0) s_start[M] = n;
     __syncthreads();
-    if (dbg == 2) return;
     // rank every word inside its micro-bucket (all words in parallel, 4 LDS reads in flight per step): sorted position =
     // start + #smaller keys + #equal keys at lower positions; equal keys also fold their base masks together
     // position-ordered from here on (p = tid + 256 t): neighbouring lanes touch neighbouring LDS words, so the random-bank
@@ -604,7 +586,6 @@ __global__ __launch_bounds__(256) void dedupe_mb_kernel(uint64_t *words, const u
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) if (e[t]) s_elem[npos[t]] = e[t];
     __syncthreads();
-    if (dbg == 3) return;
     // keep the first word of every run of equal keys; compaction index from wave ballots + a tiny per-row table
     uint32_t *s_rows = s_cnt;                               // [ITEMS][4] leaders per (row, wave); counters are dead now
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -637,8 +618,7 @@ static void launch_dedupe_items(uint64_t *words, const uint64_t *off, const uint
                                 int rem_bits, int *overflow, size_t lds, hipStream_t st)
 {
     (void)hipFuncSetAttribute((const void *)dedupe_mb_kernel<ITEMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const char *e = getenv("SKX_DEDUPE_MODE");
-    hipLaunchKernelGGL(dedupe_mb_kernel<ITEMS>, dim3((unsigned)n_regions), dim3(256), lds, st, words, off, raw, ucnt, cap, rem_bits, overflow, e ? atoi(e) : 0);
+    hipLaunchKernelGGL(dedupe_mb_kernel<ITEMS>, dim3((unsigned)n_regions), dim3(256), lds, st, words, off, raw, ucnt, cap, rem_bits, overflow);
 }
 void launch_dedupe_mb(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_regions, uint32_t cap,
                       int rem_bits, int *overflow, hipStream_t st)
@@ -740,8 +720,7 @@ void launch_union_probe(const DictView &d, int logP, int probe, uint32_t *cnt, u
 }
 
 // IUPAC letter of a base set; bit i of the set == 2-bit code i (A0 C1 T2 G3), cf. bit_encoding.rs:337-368
-__device__ static const char MASK2IUPAC_D[17] = "-ACMTWYHGRSVKDBN";
-// the same table as two 64-bit immediates (pure ALU: a __device__ array lookup would be a global-memory gather per cell)
+// IUPAC letter of a base set as two 64-bit immediates (pure ALU: a __device__ array lookup would be a global gather per cell)
 __device__ static inline unsigned char mask2iupac(uint32_t m4)
 {
     const uint64_t lo = 0x485957544D43412Dull;      // "-ACMTWYH"
@@ -802,7 +781,6 @@ __global__ __launch_bounds__(512) void assemble_kernel(AssembleArgs a)
             // fill with '-'
             for (uint32_t i = lane * 4; i < n + shift + 3; i += 256) *reinterpret_cast<uint32_t *>(row + i) = 0x2D2D2D2Du;
             __builtin_amdgcn_wave_barrier();
-            if (!(a.debug_mode & 2))
             for (uint32_t i0 = lo; i0 < hi; i0 += 512) {
                 uint64_t wq[8];
 #pragma unroll
@@ -818,9 +796,10 @@ __global__ __launch_bounds__(512) void assemble_kernel(AssembleArgs a)
                     while (l < le && s_keys[l] < key) l++;
                     if (l < le && s_keys[l] == key) {
                         const uint32_t m4 = (uint32_t)(w & 15u);
-                        if (!(a.debug_mode & 8)) row[shift + l] = mask2iupac(m4);
+                        row[shift + l] = mask2iupac(m4);
                         const uint32_t single = (m4 & (m4 - 1)) == 0;
-                        if (!(a.debug_mode & 4)) { atomicAdd(&s_cnt[l], 1u | (single << 16)); atomicOr(&s_msk[l], 1u << m4); }
+                        atomicAdd(&s_cnt[l], 1u | (single << 16));
+                        atomicOr(&s_msk[l], 1u << m4);
                     } else {
                         *a.missing = 1;
                     }
@@ -828,7 +807,6 @@ __global__ __launch_bounds__(512) void assemble_kernel(AssembleArgs a)
             }
             __builtin_amdgcn_wave_barrier();
             // copy out: global column r0 + i  <-  row[shift + i]; 16-B body, byte head/tail
-            if (a.debug_mode & 1) continue;
             unsigned char *dst = a.matrix + (uint64_t)s * a.pitch + r0;
             const uint32_t head = (16u - shift) & 15u;
             const uint32_t h = head < n ? head : n;
@@ -850,10 +828,8 @@ __global__ __launch_bounds__(512) void assemble_kernel(AssembleArgs a)
         a.col_mask[r0 + i] = s_msk[i];
     }
 }
-void launch_assemble(const AssembleArgs &a0, hipStream_t st)
+void launch_assemble(const AssembleArgs &a, hipStream_t st)
 {
-    AssembleArgs a = a0;
-    if (const char *e = getenv("SKX_ASM_MODE")) a.debug_mode = atoi(e);
     const uint32_t maxr = (a.max_rows + 15u) & ~15u;
     const int nw = 8;
     size_t lds = (size_t)maxr * 16 + ((size_t)maxr / 2 + 4) * 4 + (size_t)nw * (maxr + 32u);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Kernel micro-benchmark: dictionary build (extract+scatter, dedupe) on random genomes generated on the GPU.
-usage: kbench.py [n_genomes] [genome_len] [reps]   (honours SKX_SCATTER_MODE / SKX_EXTRACT_VARIANT)"""
+usage: kbench.py [n_genomes] [genome_len] [reps]"""
 import os
 import sys
 
