@@ -43,12 +43,19 @@ def parse():
     return ap.parse_args()
 
 
+def private_snps(n_total):
+    """500 private SNPs per sample up to 1 000 samples (configs 2-3), 100 beyond (config 4), so that the
+    rows x samples matrix of the sharded runs stays within one GPU's HBM."""
+    return 500 if n_total <= 1000 else 100
+
+
 def cpu_baseline(args, anc, n_total):
     """Oracle build_and_merge + align on a bounded sample of the same workload, timed on the host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import ora
     import synth
     n = args.cpu_genomes
+    priv = private_snps(n_total)
     cores = os.cpu_count() or 1
     want = max(1, min(cores, 1 + n // 10))
     threads = 1 << int(np.floor(np.log2(want)))          # merge_ska_dict.rs:384-385
@@ -56,7 +63,7 @@ def cpu_baseline(args, anc, n_total):
         inputs = []
         for i in range(n):
             p = os.path.join(td, f"g{i}.fa")
-            synth.to_fasta(synth.sample_stream(anc, i, n_total), p)
+            synth.to_fasta(synth.sample_stream(anc, i, n_total, private_snps=priv), p)
             inputs.append((f"g{i}", p, None))
         t0 = time.perf_counter()
         arr = ora.Array.build(inputs, k=args.k, rc=True, threads=threads)
@@ -77,7 +84,12 @@ def main():
         raise SystemExit("bench.py needs a gfx950 GPU: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded = world > 1 or os.environ.get("SKX_BENCH_FORCE_SHARDED") == "1"     # the override runs the exchange path at world size 1
+    if sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("SKX_BENCH_BACKEND", "nccl")      # "gloo" lets two ranks share one GPU in tests
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -98,7 +110,7 @@ def main():
     lens, offs, tot = [], [], 0
     streams = []
     for i in range(G):
-        s = synth.sample_stream(anc, lo + i, n_total)
+        s = synth.sample_stream(anc, lo + i, n_total, private_snps=private_snps(n_total))
         streams.append(s)
         offs.append(tot)
         lens.append(len(s))
@@ -122,7 +134,7 @@ def main():
         ctx.sync()
         t_b = time.perf_counter()
         host_ms["build"] += (t_b - t_a) * 1e3
-        if world == 1:
+        if not sharded:
             arr = ds.merge(names)
         else:
             ks = ds.union_keys()
@@ -159,7 +171,7 @@ def main():
     ctx.timings(reset=True)
     for kk in host_ms:
         host_ms[kk] = 0.0
-    if world > 1:
+    if sharded:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -169,11 +181,11 @@ def main():
             last.free()
         last, shape = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if sharded:
         dist.barrier()
     dt = time.perf_counter() - t0
     tm = ctx.timings()
-    if world > 1:
+    if sharded:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -186,7 +198,7 @@ def main():
         od = []
         for i in range(nchk):
             d = ora.Dict.new(args.k, True)
-            for rec in synth.sample_stream(anc, lo + i, n_total).tobytes().split(b"\n")[:-1]:
+            for rec in synth.sample_stream(anc, lo + i, n_total, private_snps=private_snps(n_total)).tobytes().split(b"\n")[:-1]:
                 d.add_record(rec)
             od.append(d)
         ds = E.DictSet.build_device(ptrs[:nchk], lens[:nchk], args.k, True, ctx=ctx)
@@ -215,8 +227,8 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"ska build + ska align, {G} synthetic {args.genome_len} bp assemblies per GPU, k={args.k}, "
                                    f"inputs resident in HBM (BASELINE.json configs[2])",
-                       "samples_per_gpu": G, "genome_len": args.genome_len, "k": args.k,
-                       "rows_U": shape[0], "rows_kept": shape[1], "parallelism": f"samples sharded x{world}"},
+                       "samples_per_gpu": G, "private_snps": private_snps(n_total), "genome_len": args.genome_len, "k": args.k,
+                       "rows_U": shape[0], "rows_kept": shape[1], "parallelism": f"samples sharded x{world}" + (" (key-table all-gather path)" if sharded else "")},
             "roofline": {"bound": "hbm", "kernel": "extract_kernel<true> (split k-mer extraction + bucket scatter)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": scatter_ms},
@@ -228,7 +240,7 @@ def main():
         if world == 1 and args.cpu_genomes > 0:
             res["cpu_baseline"] = cpu_baseline(args, anc, n_total)
         print(json.dumps(res))
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 
