@@ -94,17 +94,23 @@ void launch_scatter(const ExtractArgs &a, hipStream_t st);
 void launch_fill_offsets(uint64_t *off, uint64_t n, uint32_t capacity, hipStream_t st);
 void launch_scan_u32(const uint32_t *in, uint64_t *out, uint64_t n, uint32_t *max_out, hipStream_t st);
 
+constexpr int SUBIDX = 16;     // sub-ranges indexed per (sample, bucket) region
 // in-place sort + dedupe (OR of masks) of every (sample,bucket) region through an order-preserving LDS table
 void launch_dedupe(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_regions,
-                   uint32_t table_slots, int rem_bits, int *overflow, uint32_t min_n, hipStream_t st);
+                   uint32_t table_slots, int rem_bits, int *overflow, uint32_t min_n, uint16_t *sidx, int sb, hipStream_t st);
 
 void launch_dedupe_mb(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_regions,
-                      uint32_t cap, int rem_bits, int *overflow, hipStream_t st);
+                      uint32_t cap, int rem_bits, int *overflow, uint16_t *sidx, int sb, hipStream_t st);
 
 struct DictView {
     const uint64_t *words; const uint64_t *off; const uint32_t *ucnt;   // wide: words are u128 (2 x u64), off in elements
     int n_samples, logB, bits;
+    // optional sub-index written by the dedupe kernels: sidx[region * 16 + s] = first word of the region whose next
+    // `sb` hash bits (below the bucket bits) are >= s.  Turns the per-(sample, sub-bucket) slice search of the union and
+    // assemble kernels into two independent loads (nullptr: binary search).
+    const uint16_t *sidx = nullptr; int sb = 0;
 };
+
 // distinct keys per sub-bucket (logN >= logB): slab j at stage + j*stride, count in ncnt[j]
 void launch_union(const DictView &d, int logN, uint64_t *stage, uint32_t stride, uint32_t *ncnt,
                   uint32_t table_slots, int *overflow, hipStream_t st);

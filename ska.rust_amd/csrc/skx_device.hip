@@ -428,12 +428,26 @@ void launch_scan_u8(const uint8_t *flags, uint64_t *pos, uint64_t n, hipStream_t
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t TABLE_PAD = 128;
 
+// bits [sh, sh + popcount(mask)) of a packed word.  HI: the caller guarantees sh >= 32 (field in the upper half): two
+// 32-bit operations instead of a quarter-rate 64-bit shift.  (A run-time test of the uniform sh inside the unrolled
+// loops makes the compiler unswitch them and triples the register count.)
+template <bool HI>
+__device__ static inline uint32_t word_field(uint64_t w, int sh, uint32_t mask)
+{
+    return HI ? ((uint32_t)(w >> 32) >> (sh - 32)) & mask : (uint32_t)(w >> sh) & mask;
+}
+
 __device__ static inline uint32_t home_slot(uint64_t w, int rem_bits, uint32_t nslots)
 {
-    uint64_t local = rem_bits >= 60 ? (w >> 4) : ((w >> 4) & ((1ull << rem_bits) - 1));
-    uint32_t l32 = rem_bits > 32 ? (uint32_t)(local >> (rem_bits - 32)) : (uint32_t)(local << (32 - rem_bits));
-    if (rem_bits == 0) l32 = 0;
-    return (uint32_t)(((uint64_t)l32 * nslots) >> 32);
+    // l32 = the top 32 of the word's rem_bits local hash bits (word bits [rem_bits - 28, rem_bits + 4)), left-aligned when fewer
+    uint32_t l32;
+    if (rem_bits >= 32) {
+        const int sh = rem_bits - 28;                          // 4..32, wave-uniform: one v_alignbit instead of a 64-bit shift
+        l32 = sh >= 32 ? (uint32_t)(w >> 32) : __builtin_amdgcn_alignbit((uint32_t)(w >> 32), (uint32_t)w, (uint32_t)sh);
+    } else {
+        l32 = rem_bits == 0 ? 0u : (uint32_t)(((w >> 4) & ((1ull << rem_bits) - 1)) << (32 - rem_bits));
+    }
+    return __umulhi(l32, nslots);
 }
 __device__ static inline bool table_insert(unsigned long long *tab, uint32_t total_slots, uint32_t home, uint64_t w)
 {
@@ -476,15 +490,17 @@ __device__ static inline uint32_t table_emit_sorted(const unsigned long long *ta
 // K3 (fallback for regions larger than the counting sort's LDS capacity, i.e. heavy repeat content: tandem repeats,
 // homopolymers): duplicates collapse on insertion, so only the number of DISTINCT keys has to fit.
 __global__ __launch_bounds__(256) void dedupe_kernel(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt,
-                                                     uint32_t nslots, int rem_bits, int *overflow, uint32_t min_n)
+                                                     uint32_t nslots, int rem_bits, int *overflow, uint32_t min_n, uint16_t *sidx, int sb)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_tab[];
     __shared__ uint32_t s_tmp[17];
+    __shared__ uint32_t s_sub[SUBIDX];
     __shared__ int s_fail;
     const uint64_t region = blockIdx.x;
     const uint32_t n = raw[region];
     if (n <= min_n) return;                                  // handled by the counting-sort kernel
-    if (n == 0) { if (threadIdx.x == 0) ucnt[region] = 0; return; }
+    if (n == 0) { if (threadIdx.x == 0) ucnt[region] = 0; if (threadIdx.x < SUBIDX) sidx[region * SUBIDX + threadIdx.x] = 0; return; }
+    if (threadIdx.x < SUBIDX) s_sub[threadIdx.x] = 0xFFFFFFFFu;
     const uint32_t total_slots = nslots + TABLE_PAD;
     for (uint32_t i = threadIdx.x; i < total_slots; i += blockDim.x) s_tab[i] = 0ull;
     if (threadIdx.x == 0) s_fail = 0;
@@ -495,25 +511,35 @@ __global__ __launch_bounds__(256) void dedupe_kernel(uint64_t *words, const uint
         if (!table_insert(s_tab, total_slots, home_slot(w, rem_bits, nslots), w)) s_fail = 1;
     }
     __syncthreads();
-    if (s_fail) { if (threadIdx.x == 0) { *overflow = 1; ucnt[region] = 0; } return; }
-    uint32_t total = table_emit_sorted(s_tab, total_slots, s_tmp, [&](uint32_t idx, uint64_t w) { reg[idx] = w; });
+    if (s_fail) { if (threadIdx.x == 0) { *overflow = 1; ucnt[region] = 0; } if (threadIdx.x < SUBIDX) sidx[region * SUBIDX + threadIdx.x] = 0; return; }
+    const uint64_t lmask = rem_bits >= 60 ? ~0ull : ((1ull << rem_bits) - 1);
+    uint32_t total = table_emit_sorted(s_tab, total_slots, s_tmp, [&](uint32_t idx, uint64_t w) {
+        reg[idx] = w;
+        atomicMin(&s_sub[sb ? (uint32_t)(((w >> 4) & lmask) >> (rem_bits - sb)) : 0u], idx);
+    });
     if (threadIdx.x == 0) ucnt[region] = total;
+    __syncthreads();
+    if (threadIdx.x < SUBIDX) {                              // first word of sub-range s = first set entry at or above s
+        uint32_t v = total;
+        for (int s2 = SUBIDX - 1; s2 >= (int)threadIdx.x; s2--) if (s_sub[s2] != 0xFFFFFFFFu) v = s_sub[s2];
+        sidx[region * SUBIDX + threadIdx.x] = (uint16_t)v;
+    }
 }
 void launch_dedupe(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_regions,
-                   uint32_t table_slots, int rem_bits, int *overflow, uint32_t min_n, hipStream_t st)
+                   uint32_t table_slots, int rem_bits, int *overflow, uint32_t min_n, uint16_t *sidx, int sb, hipStream_t st)
 {
     if (!n_regions) return;
     size_t lds = (size_t)(table_slots + TABLE_PAD) * 8;
     (void)hipFuncSetAttribute((const void *)dedupe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(dedupe_kernel, dim3((unsigned)n_regions), dim3(256), lds, st, words, off, raw, ucnt, table_slots, rem_bits, overflow, min_n);
+    hipLaunchKernelGGL(dedupe_kernel, dim3((unsigned)n_regions), dim3(256), lds, st, words, off, raw, ucnt, table_slots, rem_bits, overflow, min_n, sidx, sb);
 }
 
 // K3 (fast path): counting sort of a region into micro-buckets of ~2-4 words by the next hash bits, then a tiny
 // per-thread insertion sort with duplicate folding (OR of base masks).  No CAS loops, no data-dependent probe
 // chains: cost is O(n) LDS operations per region whatever the duplication level.
-template <int ITEMS>
+template <int ITEMS, bool HI>
 __global__ __launch_bounds__(256) void dedupe_mb_kernel(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt,
-                                                        uint32_t cap, int rem_bits, int *overflow)
+                                                        uint32_t cap, int rem_bits, int *overflow, uint16_t *sidx, int sb)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
     __shared__ uint32_t s_tmp[17];
@@ -529,8 +555,7 @@ __global__ __launch_bounds__(256) void dedupe_mb_kernel(uint64_t *words, const u
     if (logM > rem_bits) logM = rem_bits;
     while ((1u << logM) > cap / 2) logM--;
     const uint32_t M = 1u << logM;
-    const int mshift = rem_bits - logM;                                      // micro-bucket = local >> mshift
-    const uint64_t lmask = rem_bits >= 60 ? ~0ull : ((1ull << rem_bits) - 1);
+    const int mshift = rem_bits - logM + 4;                                  // micro-bucket = word_field<HI>(w, mshift, M - 1)
     uint64_t *reg = words + off[region];
     // the whole region goes into registers with all loads in flight at once (word 0 never occurs: base masks are non-zero)
     uint64_t e[ITEMS];
@@ -539,7 +564,7 @@ __global__ __launch_bounds__(256) void dedupe_mb_kernel(uint64_t *words, const u
     for (uint32_t i = threadIdx.x; i < M; i += 256) s_cnt[i] = 0;
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < ITEMS; t++) if (e[t]) atomicAdd(&s_cnt[(uint32_t)(((e[t] >> 4) & lmask) >> mshift)], 1u);
+    for (int t = 0; t < ITEMS; t++) if (e[t]) atomicAdd(&s_cnt[word_field<HI>(e[t], mshift, M - 1)], 1u);
     __syncthreads();
     // exclusive scan of the counts (each thread owns R consecutive micro-buckets)
     const uint32_t R = (M + 255) / 256;
@@ -553,7 +578,7 @@ __global__ __launch_bounds__(256) void dedupe_mb_kernel(uint64_t *words, const u
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) {
         pos[t] = 0;
-        if (e[t]) { pos[t] = atomicAdd(&s_cnt[(uint32_t)(((e[t] >> 4) & lmask) >> mshift)], 1u); s_elem[pos[t]] = e[t]; }
+        if (e[t]) { pos[t] = atomicAdd(&s_cnt[word_field<HI>(e[t], mshift, M - 1)], 1u); s_elem[pos[t]] = e[t]; }
     }
     if (threadIdx.x == 0) s_start[M] = n;
     __syncthreads();
@@ -569,7 +594,7 @@ __global__ __launch_bounds__(256) void dedupe_mb_kernel(uint64_t *words, const u
         npos[t] = 0; e[t] = 0;
         if (p >= n) continue;
         const uint64_t w0 = s_elem[p], key = w0 >> 4;
-        const uint32_t m = (uint32_t)((key & lmask) >> mshift);
+        const uint32_t m = word_field<HI>(w0, mshift, M - 1);
         const uint32_t b = s_start[m], eend = s_start[m + 1];
         uint32_t less = 0, eqb = 0, mor = (uint32_t)w0 & 15u;
         for (uint32_t j = b; j < eend; j++) {
@@ -589,12 +614,21 @@ __global__ __launch_bounds__(256) void dedupe_mb_kernel(uint64_t *words, const u
     // keep the first word of every run of equal keys; compaction index from wave ballots + a tiny per-row table
     uint32_t *s_rows = s_cnt;                               // [ITEMS][4] leaders per (row, wave); counters are dead now
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t flags = 0, below[ITEMS];
+    uint32_t flags = 0, sflags = 0, below[ITEMS];
+    const int subshift = rem_bits - sb + 4;                 // sub-range of a word = its next sb hash bits
+    const uint32_t submask = (1u << sb) - 1;
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) {
         const uint32_t p = threadIdx.x + 256u * t;
         bool lead = false;
-        if (p < n) { e[t] = s_elem[p]; lead = p == 0 || (s_elem[p - 1] >> 4) != (e[t] >> 4); }
+        if (p < n) {
+            e[t] = s_elem[p];
+            // one XOR with the predecessor answers both questions: keys differ <=> a bit above the base mask differs;
+            // new sub-range <=> a bit at or above subshift differs (all words of a region agree above rem_bits + 4)
+            const uint64_t x = p ? s_elem[p - 1] ^ e[t] : ~0ull;
+            lead = x > 15ull;
+            if (HI ? (uint32_t)(x >> 32) >= (1u << (subshift - 32)) : x >= (1ull << subshift)) sflags |= 1u << t;
+        }
         const unsigned long long bal = __ballot(lead);
         below[t] = __popcll(bal & ((1ull << lane) - 1ull));
         if (lead) flags |= 1u << t;
@@ -608,6 +642,9 @@ __global__ __launch_bounds__(256) void dedupe_mb_kernel(uint64_t *words, const u
 #pragma unroll
         for (int w = 0; w < 4; w++) { const uint32_t c = s_rows[t * 4 + w]; before += w < wv ? c : 0u; rowsum += c; }
         if ((flags >> t) & 1u) reg[base + before + below[t]] = e[t];
+        // first word of a new sub-range: record where it starts (sub-ranges without words keep the 0xFFFF the host
+        // pre-filled; readers take the next recorded start)
+        if ((sflags >> t) & 1u) sidx[region * SUBIDX + word_field<false>(e[t], subshift, submask)] = (uint16_t)(base + before + below[t]);
         base += rowsum;
     }
     const uint32_t total = base;
@@ -615,21 +652,28 @@ __global__ __launch_bounds__(256) void dedupe_mb_kernel(uint64_t *words, const u
 }
 template <int ITEMS>
 static void launch_dedupe_items(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_regions, uint32_t cap,
-                                int rem_bits, int *overflow, size_t lds, hipStream_t st)
+                                int rem_bits, int *overflow, uint16_t *sidx, int sb, size_t lds, hipStream_t st)
 {
-    (void)hipFuncSetAttribute((const void *)dedupe_mb_kernel<ITEMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(dedupe_mb_kernel<ITEMS>, dim3((unsigned)n_regions), dim3(256), lds, st, words, off, raw, ucnt, cap, rem_bits, overflow);
+    // every field the kernel extracts (micro-bucket, sub-range) starts at bit rem_bits + 4 - (<= log2 cap) or higher
+    int lc = 0; while ((1u << lc) < cap) lc++;
+    if (rem_bits + 4 - lc >= 32 && rem_bits + 4 - sb >= 32) {
+        (void)hipFuncSetAttribute((const void *)dedupe_mb_kernel<ITEMS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((dedupe_mb_kernel<ITEMS, true>), dim3((unsigned)n_regions), dim3(256), lds, st, words, off, raw, ucnt, cap, rem_bits, overflow, sidx, sb);
+    } else {
+        (void)hipFuncSetAttribute((const void *)dedupe_mb_kernel<ITEMS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((dedupe_mb_kernel<ITEMS, false>), dim3((unsigned)n_regions), dim3(256), lds, st, words, off, raw, ucnt, cap, rem_bits, overflow, sidx, sb);
+    }
 }
 void launch_dedupe_mb(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_regions, uint32_t cap,
-                      int rem_bits, int *overflow, hipStream_t st)
+                      int rem_bits, int *overflow, uint16_t *sidx, int sb, hipStream_t st)
 {
     if (!n_regions) return;
     size_t lds = (size_t)cap * 8 + (size_t)cap * 4 + 16;  // elements + two u32 arrays of cap/2 (+ sentinel)
     const uint32_t items = (cap + 255) / 256;
-    if (items <= 4) launch_dedupe_items<4>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, lds, st);
-    else if (items <= 8) launch_dedupe_items<8>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, lds, st);
-    else if (items <= 14) launch_dedupe_items<14>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, lds, st);
-    else launch_dedupe_items<24>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, lds, st);     // host keeps regions <= 6144 words
+    if (items <= 4) launch_dedupe_items<4>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);
+    else if (items <= 8) launch_dedupe_items<8>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);
+    else if (items <= 14) launch_dedupe_items<14>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);
+    else launch_dedupe_items<24>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);     // host keeps regions <= 6144 words
 }
 
 // pointers that reach a kernel inside an argument struct are generic (flat_load: slower, and it also ticks the LDS
@@ -637,14 +681,14 @@ void launch_dedupe_mb(uint64_t *words, const uint64_t *off, const uint32_t *raw,
 typedef const uint64_t __attribute__((address_space(1))) *gwords_t;
 __device__ static inline gwords_t as_global(const uint64_t *p) { return (gwords_t)(uintptr_t)p; }
 
-// first index in [0,n) whose hashed key (word >> 4) is >= x
-__device__ static inline uint32_t lower_bound_words(const uint64_t *reg_, uint32_t n, uint64_t x)
+// first index in [lo,hi) whose hashed key (word >> 4) is >= x
+__device__ static inline uint32_t lower_bound_words(const uint64_t *reg_, uint32_t lo, uint32_t hi, uint64_t x)
 {
     gwords_t reg = as_global(reg_);
-    uint32_t lo = 0, hi = n;
     while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if ((reg[mid] >> 4) < x) lo = mid + 1; else hi = mid; }
     return lo;
 }
+// slice [lo,hi) of sample's region that belongs to sub-bucket j of a 2^logN split (logN >= logB)
 __device__ static inline void sub_slice(const DictView &d, int sample, uint64_t j, int logN, const uint64_t *&reg, uint32_t &lo, uint32_t &hi)
 {
     const int sh = logN - d.logB;
@@ -653,15 +697,38 @@ __device__ static inline void sub_slice(const DictView &d, int sample, uint64_t 
     reg = d.words + d.off[region];
     const uint32_t n = d.ucnt[region];
     if (sh == 0) { lo = 0; hi = n; return; }
+    const uint32_t jj = (uint32_t)(j & ((1ull << sh) - 1)), last = (1u << sh) - 1;
     const int rb = d.bits - logN;
     const uint64_t xlo = j << rb, xhi = (j + 1) << rb;
-    lo = lower_bound_words(reg, n, xlo);
-    hi = ((j + 1) & ((1ull << sh) - 1)) == 0 ? n : lower_bound_words(reg, n, xhi);
+    if (d.sidx) {
+        // the dedupe kernels left the starts of the region's 2^sb sub-ranges: direct look-up, or a short search inside one
+        typedef const uint16_t __attribute__((address_space(1))) *gidx_t;
+        gidx_t ix = (gidx_t)(uintptr_t)(d.sidx + region * SUBIDX);
+        // start of sub-range a = first recorded start at or above a (0xFFFF: no word there), else the region's end
+        auto start_of = [&](uint32_t a) -> uint32_t {
+            for (; a < (1u << d.sb); a++) { const uint32_t v = ix[a]; if (v != 0xFFFFu) return v; }
+            return n;
+        };
+        if (sh <= d.sb) {
+            lo = start_of(jj << (d.sb - sh));
+            hi = jj == last ? n : start_of((jj + 1) << (d.sb - sh));
+            return;
+        }
+        if (d.sb > 0) {
+            const uint32_t c = jj >> (sh - d.sb);
+            const uint32_t a0 = start_of(c), a1 = start_of(c + 1);
+            lo = lower_bound_words(reg, a0, a1, xlo);
+            hi = ((jj + 1) & ((1u << (sh - d.sb)) - 1)) == 0 ? a1 : lower_bound_words(reg, lo, a1, xhi);
+            return;
+        }
+    }
+    lo = lower_bound_words(reg, 0, n, xlo);
+    hi = jj == last ? n : lower_bound_words(reg, lo, n, xhi);
 }
 
 // K4: distinct keys of sub-bucket j over all samples -> sorted slab
 template <bool COUNT_ONLY>
-__global__ __launch_bounds__(1024) void union_kernel(DictView d, int logN, uint64_t *stage, uint32_t stride, uint32_t *ncnt,
+__global__ __launch_bounds__(1024, 8) void union_kernel(DictView d, int logN, uint64_t *stage, uint32_t stride, uint32_t *ncnt,
                                                     uint32_t nslots, int *overflow)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_tab[];
@@ -790,7 +857,7 @@ __global__ __launch_bounds__(512) void assemble_kernel(AssembleArgs a)
                     const uint64_t w = wq[u];
                     if (i0 + 64u * u + lane >= hi) continue;
                     const uint64_t key = w >> 4;
-                    const uint32_t ib = (uint32_t)((key & lmask) >> (rem - logI));
+                    const uint32_t ib = word_field<false>(w, rem - logI + 4, nidx - 1);
                     uint32_t l = s_idx[ib];
                     const uint32_t le = s_idx[ib + 1];
                     while (l < le && s_keys[l] < key) l++;

@@ -60,8 +60,10 @@ struct skx_dictset {
     skx::DevBuf<uint64_t> off;       // [n<<logB + 1]
     skx::DevBuf<uint32_t> raw;       // [n<<logB] windows per region
     skx::DevBuf<uint32_t> ucnt;      // [n<<logB] distinct split k-mers per region
+    skx::DevBuf<uint16_t> sidx;      // [n<<logB][16] sub-index of every region (narrow keys, device-built dictionaries)
+    int sb = 0;
     std::vector<uint64_t> sample_size;   // SkaDict::ksize per sample
-    skx::DictView view() const { return skx::DictView{words.p, off.p, ucnt.p, n, logB, wide() ? wh.bits : hp.bits}; }
+    skx::DictView view() const { return skx::DictView{words.p, off.p, ucnt.p, n, logB, wide() ? wh.bits : hp.bits, sidx.p, sb}; }
 };
 
 struct skx_keyset {

@@ -302,3 +302,18 @@ def test_repeat_rich_sample(E):
         ga = ds.merge(["rep", "rnd"])
         oa = ora.Array.from_dicts([oracle_dict(recs, k, rc), oracle_dict([rnd], k, rc)], ["rep", "rnd"])
         assert as_map(*ga.export()) == as_map(*oa.export())
+
+
+def test_unrelated_samples_fine_split(E):
+    """Unrelated genomes: the union is ~32x one sample, so the row keyset is split much finer (2^6 sub-buckets per
+    dictionary bucket) than the 16-entry sub-index the dedupe kernel leaves per region -> bracketed slice search."""
+    rng = np.random.default_rng(77)
+    samples = [[bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=100_000).tolist())] for _ in range(32)]
+    ga, oa = build_both(E, samples, 31, True)
+    assert ga.nkmers == oa.nkmers
+    gk, gv, gc = ga.export()
+    ok, ov, oc = oa.export()
+    go, oo = np.argsort(gk["lo"], kind="stable"), np.argsort(ok["lo"], kind="stable")
+    assert np.array_equal(gk["lo"][go], ok["lo"][oo])
+    assert np.array_equal(np.asarray(gv)[go], np.asarray(ov)[oo])
+    assert np.array_equal(np.asarray(gc)[go], np.asarray(oc)[oo])
