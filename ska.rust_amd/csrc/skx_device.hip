@@ -537,8 +537,8 @@ void launch_dedupe(uint64_t *words, const uint64_t *off, const uint32_t *raw, ui
 // K3 (fast path): counting sort of a region into micro-buckets of ~2-4 words by the next hash bits, then a tiny
 // per-thread insertion sort with duplicate folding (OR of base masks).  No CAS loops, no data-dependent probe
 // chains: cost is O(n) LDS operations per region whatever the duplication level.
-template <int ITEMS, bool HI>
-__global__ __launch_bounds__(256) void dedupe_mb_kernel(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt,
+template <int ITEMS, bool HI, int NT>
+__global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt,
                                                         uint32_t cap, int rem_bits, int *overflow, uint16_t *sidx, int sb)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) void dedupe_mb_kernel(uint64_t *words, const u
     const uint64_t region = blockIdx.x;
     const uint32_t n = raw[region];
     if (n == 0) { if (threadIdx.x == 0) ucnt[region] = 0; return; }
-    if (n > cap || n > 256u * ITEMS) { if (threadIdx.x == 0) atomicOr(overflow, 2); return; }      // left to dedupe_kernel
+    if (n > cap || n > (uint32_t)NT * ITEMS) { if (threadIdx.x == 0) atomicOr(overflow, 2); return; }      // left to dedupe_kernel
     uint64_t *s_elem = reinterpret_cast<uint64_t *>(s_mem);                 // [cap]
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_mem + (size_t)cap * 8); // [M] counts -> cursors -> unique counts
     uint32_t *s_start = s_cnt + cap / 2;                                     // [M] micro-bucket starts
@@ -560,14 +560,14 @@ __global__ __launch_bounds__(256) void dedupe_mb_kernel(uint64_t *words, const u
     // the whole region goes into registers with all loads in flight at once (word 0 never occurs: base masks are non-zero)
     uint64_t e[ITEMS];
 #pragma unroll
-    for (int t = 0; t < ITEMS; t++) { const uint32_t i = threadIdx.x + 256u * t; e[t] = i < n ? reg[i] : 0ull; }
-    for (uint32_t i = threadIdx.x; i < M; i += 256) s_cnt[i] = 0;
+    for (int t = 0; t < ITEMS; t++) { const uint32_t i = threadIdx.x + (uint32_t)NT * t; e[t] = i < n ? reg[i] : 0ull; }
+    for (uint32_t i = threadIdx.x; i < M; i += NT) s_cnt[i] = 0;
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) if (e[t]) atomicAdd(&s_cnt[word_field<HI>(e[t], mshift, M - 1)], 1u);
     __syncthreads();
     // exclusive scan of the counts (each thread owns R consecutive micro-buckets)
-    const uint32_t R = (M + 255) / 256;
+    const uint32_t R = (M + NT - 1) / NT;
     const uint32_t m0 = threadIdx.x * R < M ? threadIdx.x * R : M, m1 = m0 + R < M ? m0 + R : M;
     uint32_t sum = 0;
     for (uint32_t m = m0; m < m1; m++) sum += s_cnt[m];
@@ -584,26 +584,40 @@ __global__ __launch_bounds__(256) void dedupe_mb_kernel(uint64_t *words, const u
     __syncthreads();
     // rank every word inside its micro-bucket (all words in parallel, 4 LDS reads in flight per step): sorted position =
     // start + #smaller keys + #equal keys at lower positions; equal keys also fold their base masks together
-    // position-ordered from here on (p = tid + 256 t): neighbouring lanes touch neighbouring LDS words, so the random-bank
+    // position-ordered from here on (p = tid + NT t): neighbouring lanes touch neighbouring LDS words, so the random-bank
     // conflicts of the scatter above do not come back.  Rank of a word inside its micro-bucket = #smaller keys + #equal
     // keys at lower positions; equal keys also fold their base masks together.
     uint32_t npos[ITEMS];
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) {
-        const uint32_t p = threadIdx.x + 256u * t;
+        const uint32_t p = threadIdx.x + (uint32_t)NT * t;
         npos[t] = 0; e[t] = 0;
         if (p >= n) continue;
-        const uint64_t w0 = s_elem[p], key = w0 >> 4;
+        const uint64_t w0 = s_elem[p], w0lo = w0 & ~15ull;
         const uint32_t m = word_field<HI>(w0, mshift, M - 1);
         const uint32_t b = s_start[m], eend = s_start[m + 1];
+        // key_j < key  <=>  w_j < (w0 & ~15);  key_j == key  <=>  (w_j ^ w0) < 16: no 64-bit shifts (quarter rate) in the loop.
+        // Fast path: count the smaller keys and notice whether the key occurs again; only then (rare) order the equal
+        // keys by position and fold their base masks.
         uint32_t less = 0, eqb = 0, mor = (uint32_t)w0 & 15u;
-        for (uint32_t j = b; j < eend; j++) {
-            const uint64_t w = s_elem[j], kj = w >> 4;
-            less += kj < key;
-            const bool iseq = kj == key;
-            eqb += iseq && j < p;
-            mor |= iseq ? (uint32_t)w & 15u : 0u;
-        }
+        bool dup = false;
+        auto step = [&](uint32_t j, uint64_t w, bool valid) {
+            const uint64_t x = w ^ w0;
+            less += valid && w < w0lo;
+            dup |= valid && j != p && (((uint32_t)(x >> 32) | ((uint32_t)x >> 4)) == 0u);
+        };
+        // micro-buckets hold ~2.4 words: the first four slots are straight-line code (reads past the bucket stay inside
+        // the LDS carve and are masked), longer buckets finish in a loop
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) step(b + u, s_elem[b + u], b + u < eend);
+        for (uint32_t j = b + 4; j < eend; j++) step(j, s_elem[j], true);
+        if (dup)
+            for (uint32_t j = b; j < eend; j++) {
+                const uint64_t w = s_elem[j];
+                const bool iseq = ((w ^ w0) >> 4) == 0ull;
+                eqb += iseq && j < p;
+                mor |= iseq ? (uint32_t)w & 15u : 0u;
+            }
         npos[t] = b + less + eqb;
         e[t] = (w0 & ~15ull) | mor;
     }
@@ -612,14 +626,15 @@ __global__ __launch_bounds__(256) void dedupe_mb_kernel(uint64_t *words, const u
     for (int t = 0; t < ITEMS; t++) if (e[t]) s_elem[npos[t]] = e[t];
     __syncthreads();
     // keep the first word of every run of equal keys; compaction index from wave ballots + a tiny per-row table
-    uint32_t *s_rows = s_cnt;                               // [ITEMS][4] leaders per (row, wave); counters are dead now
+    constexpr int NW = NT / 64;
+    uint32_t *s_rows = s_cnt;                               // [ITEMS][NW] leaders per (row, wave); counters are dead now
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t flags = 0, sflags = 0, below[ITEMS];
     const int subshift = rem_bits - sb + 4;                 // sub-range of a word = its next sb hash bits
     const uint32_t submask = (1u << sb) - 1;
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) {
-        const uint32_t p = threadIdx.x + 256u * t;
+        const uint32_t p = threadIdx.x + (uint32_t)NT * t;
         bool lead = false;
         if (p < n) {
             e[t] = s_elem[p];
@@ -630,38 +645,45 @@ __global__ __launch_bounds__(256) void dedupe_mb_kernel(uint64_t *words, const u
             if (HI ? (uint32_t)(x >> 32) >= (1u << (subshift - 32)) : x >= (1ull << subshift)) sflags |= 1u << t;
         }
         const unsigned long long bal = __ballot(lead);
-        below[t] = __popcll(bal & ((1ull << lane) - 1ull));
+        below[t] = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
         if (lead) flags |= 1u << t;
-        if (lane == 0) s_rows[t * 4 + wv] = __popcll(bal);
+        if (lane == 0) s_rows[t * NW + wv] = __popcll(bal);
     }
     __syncthreads();
-    uint32_t base = 0;
+    // counts per (row, wave) -> exclusive prefix in output order (one wave, entries i and i + 64), total at [ITEMS * 4]
+    if (wv == 0) {
+        constexpr int NE = ITEMS * NW;
+        const uint32_t a = lane < NE ? s_rows[lane] : 0u, b2 = lane + 64 < NE ? s_rows[lane + 64] : 0u;
+        const uint32_t ia = wave_incl_scan(a), ta = __shfl(ia, 63, 64);
+        const uint32_t ib = NE > 64 ? wave_incl_scan(b2) : 0u;
+        if (lane < NE) s_rows[lane] = ia - a;
+        if (NE > 64 && lane + 64 < NE) s_rows[lane + 64] = ta + ib - b2;
+        if (lane == 63) s_rows[NE] = ta + (NE > 64 ? ib : 0u);
+    }
+    __syncthreads();
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) {
-        uint32_t rowsum = 0, before = 0;
-#pragma unroll
-        for (int w = 0; w < 4; w++) { const uint32_t c = s_rows[t * 4 + w]; before += w < wv ? c : 0u; rowsum += c; }
-        if ((flags >> t) & 1u) reg[base + before + below[t]] = e[t];
+        if (!((flags >> t) & 1u)) continue;
+        const uint32_t o = s_rows[t * NW + wv] + below[t];
+        reg[o] = e[t];
         // first word of a new sub-range: record where it starts (sub-ranges without words keep the 0xFFFF the host
         // pre-filled; readers take the next recorded start)
-        if ((sflags >> t) & 1u) sidx[region * SUBIDX + word_field<false>(e[t], subshift, submask)] = (uint16_t)(base + before + below[t]);
-        base += rowsum;
+        if ((sflags >> t) & 1u) sidx[region * SUBIDX + word_field<false>(e[t], subshift, submask)] = (uint16_t)o;
     }
-    const uint32_t total = base;
-    if (threadIdx.x == 0) ucnt[region] = total;
+    if (threadIdx.x == 0) ucnt[region] = s_rows[ITEMS * NW];
 }
-template <int ITEMS>
+template <int ITEMS, int NT>
 static void launch_dedupe_items(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_regions, uint32_t cap,
                                 int rem_bits, int *overflow, uint16_t *sidx, int sb, size_t lds, hipStream_t st)
 {
     // every field the kernel extracts (micro-bucket, sub-range) starts at bit rem_bits + 4 - (<= log2 cap) or higher
     int lc = 0; while ((1u << lc) < cap) lc++;
     if (rem_bits + 4 - lc >= 32 && rem_bits + 4 - sb >= 32) {
-        (void)hipFuncSetAttribute((const void *)dedupe_mb_kernel<ITEMS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((dedupe_mb_kernel<ITEMS, true>), dim3((unsigned)n_regions), dim3(256), lds, st, words, off, raw, ucnt, cap, rem_bits, overflow, sidx, sb);
+        (void)hipFuncSetAttribute((const void *)dedupe_mb_kernel<ITEMS, true, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((dedupe_mb_kernel<ITEMS, true, NT>), dim3((unsigned)n_regions), dim3(NT), lds, st, words, off, raw, ucnt, cap, rem_bits, overflow, sidx, sb);
     } else {
-        (void)hipFuncSetAttribute((const void *)dedupe_mb_kernel<ITEMS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((dedupe_mb_kernel<ITEMS, false>), dim3((unsigned)n_regions), dim3(256), lds, st, words, off, raw, ucnt, cap, rem_bits, overflow, sidx, sb);
+        (void)hipFuncSetAttribute((const void *)dedupe_mb_kernel<ITEMS, false, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((dedupe_mb_kernel<ITEMS, false, NT>), dim3((unsigned)n_regions), dim3(NT), lds, st, words, off, raw, ucnt, cap, rem_bits, overflow, sidx, sb);
     }
 }
 void launch_dedupe_mb(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_regions, uint32_t cap,
@@ -669,11 +691,11 @@ void launch_dedupe_mb(uint64_t *words, const uint64_t *off, const uint32_t *raw,
 {
     if (!n_regions) return;
     size_t lds = (size_t)cap * 8 + (size_t)cap * 4 + 16;  // elements + two u32 arrays of cap/2 (+ sentinel)
-    const uint32_t items = (cap + 255) / 256;
-    if (items <= 4) launch_dedupe_items<4>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);
-    else if (items <= 8) launch_dedupe_items<8>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);
-    else if (items <= 14) launch_dedupe_items<14>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);
-    else launch_dedupe_items<24>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);     // host keeps regions <= 6144 words
+    // The kernel is bound by its chain of LDS round trips and barriers, not by a throughput limit: 512 threads with half
+    // the words each finish a region sooner and put twice the waves on a CU (the LDS footprint fixes 4 regions per CU).
+    if (cap <= 512u * 4) launch_dedupe_items<4, 512>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);
+    else if (cap <= 512u * 7) launch_dedupe_items<7, 512>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);
+    else launch_dedupe_items<12, 512>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);     // host keeps regions <= 6144 words
 }
 
 // pointers that reach a kernel inside an argument struct are generic (flat_load: slower, and it also ticks the LDS
