@@ -818,7 +818,7 @@ __device__ static inline unsigned char mask2iupac(uint32_t m4)
 }
 
 // K5: rows = key slabs, columns = samples: fill the sample-major matrix + per-row statistics
-__global__ __launch_bounds__(512) void assemble_kernel(AssembleArgs a)
+__global__ __launch_bounds__(512, 8) void assemble_kernel(AssembleArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const uint64_t j = blockIdx.x;
@@ -827,12 +827,12 @@ __global__ __launch_bounds__(512) void assemble_kernel(AssembleArgs a)
     const uint32_t maxr = (a.max_rows + 15u) & ~15u;
     uint64_t *s_keys = reinterpret_cast<uint64_t *>(s_raw);
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_raw + (size_t)maxr * 8);
-    uint32_t *s_msk = s_cnt + maxr;
-    uint32_t *s_idx = s_msk + maxr;                                   // [maxr/2 + 2] row index by the next hash bits
+    uint32_t *s_msk = s_cnt + maxr;                                   // [maxr/2] 16-bit code sets, two rows per word
+    uint32_t *s_idx = s_msk + maxr / 2;                                   // [maxr/2 + 2] row index by the next hash bits
     unsigned char *s_rows = reinterpret_cast<unsigned char *>(s_idx + maxr / 2 + 4);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const uint64_t *slab = a.stage + j * (uint64_t)a.stride;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { s_keys[i] = slab[i] >> 4; s_cnt[i] = 0; s_msk[i] = 0; }
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { s_keys[i] = slab[i] >> 4; s_cnt[i] = 0; if (!(i & 1u)) s_msk[i >> 1] = 0; }
     __syncthreads();
     // direct index: rows are uniform in the sub-bucket's hash range, so the next logI bits of the key select ~2 rows
     const int rem = a.d.bits - a.logN;
@@ -888,7 +888,7 @@ __global__ __launch_bounds__(512) void assemble_kernel(AssembleArgs a)
                         row[shift + l] = mask2iupac(m4);
                         const uint32_t single = (m4 & (m4 - 1)) == 0;
                         atomicAdd(&s_cnt[l], 1u | (single << 16));
-                        atomicOr(&s_msk[l], 1u << m4);
+                        atomicOr(&s_msk[l >> 1], (1u << m4) << (16u * (l & 1u)));
                     } else {
                         *a.missing = 1;
                     }
@@ -914,14 +914,14 @@ __global__ __launch_bounds__(512) void assemble_kernel(AssembleArgs a)
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
         a.col_present[r0 + i] = s_cnt[i] & 0xFFFFu;
         a.col_unambig[r0 + i] = s_cnt[i] >> 16;
-        a.col_mask[r0 + i] = s_msk[i];
+        a.col_mask[r0 + i] = (s_msk[i >> 1] >> (16u * (i & 1u))) & 0xFFFFu;
     }
 }
 void launch_assemble(const AssembleArgs &a, hipStream_t st)
 {
     const uint32_t maxr = (a.max_rows + 15u) & ~15u;
     const int nw = 8;
-    size_t lds = (size_t)maxr * 16 + ((size_t)maxr / 2 + 4) * 4 + (size_t)nw * (maxr + 32u);
+    size_t lds = (size_t)maxr * 14 + ((size_t)maxr / 2 + 4) * 4 + (size_t)nw * (maxr + 32u);
     (void)hipFuncSetAttribute((const void *)assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(assemble_kernel, dim3(1u << a.logN), dim3(64 * nw), lds, st, a);
 }
