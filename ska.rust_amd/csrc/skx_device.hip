@@ -764,10 +764,13 @@ __global__ __launch_bounds__(1024, 8) void union_kernel(DictView d, int logN, ui
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int rem_bits = d.bits - logN;
     // every lane binary-searches the slice of one sample; the wave then streams the 64 slices one after another
-    for (int s0 = wv * 64; s0 < d.n_samples; s0 += nw * 64) {
+    // samples are dealt evenly to the waves (a few hundred samples would otherwise leave most waves idle)
+    const int per = (d.n_samples + nw - 1) / nw;
+    const int wend = (wv + 1) * per < d.n_samples ? (wv + 1) * per : d.n_samples;
+    for (int s0 = wv * per; s0 < wend; s0 += 64) {
         const uint64_t *my_reg = nullptr; uint32_t my_lo = 0, my_hi = 0;
-        if (s0 + lane < d.n_samples) sub_slice(d, s0 + lane, j, logN, my_reg, my_lo, my_hi);
-        const int cnt = d.n_samples - s0 < 64 ? d.n_samples - s0 : 64;
+        const int cnt = wend - s0 < 64 ? wend - s0 : 64;
+        if (lane < cnt) sub_slice(d, s0 + lane, j, logN, my_reg, my_lo, my_hi);
         for (int t = 0; t < cnt; t++) {
             gwords_t reg = as_global(reinterpret_cast<const uint64_t *>(__shfl((unsigned long long)my_reg, t, 64)));
             const uint32_t lo = __shfl(my_lo, t, 64), hi = __shfl(my_hi, t, 64);
@@ -855,14 +858,16 @@ __global__ __launch_bounds__(512, 8) void assemble_kernel(AssembleArgs a)
     // Slices are addressed as offsets from the kernel-argument pointer (global address space, no flat loads) and read
     // with clamped, branch-free loads so that 8 words per lane are in flight per memory round trip.
     const uint64_t *wbase = a.d.words;
-    for (int sbase = wv * 64; sbase < a.d.n_samples; sbase += nw * 64) {
+    const int per = (a.d.n_samples + nw - 1) / nw;                 // samples are dealt evenly to the waves
+    const int wend = (wv + 1) * per < a.d.n_samples ? (wv + 1) * per : a.d.n_samples;
+    for (int sbase = wv * per; sbase < wend; sbase += 64) {
         uint64_t my_off = 0; uint32_t my_lo = 0, my_hi = 0;
-        if (sbase + lane < a.d.n_samples) {
+        const int cnt = wend - sbase < 64 ? wend - sbase : 64;
+        if (lane < cnt) {
             const uint64_t *my_reg = nullptr;
             sub_slice(a.d, sbase + lane, j, a.logN, my_reg, my_lo, my_hi);
             my_off = (uint64_t)(my_reg - wbase);
         }
-        const int cnt = a.d.n_samples - sbase < 64 ? a.d.n_samples - sbase : 64;
         for (int t = 0; t < cnt; t++) {
             const int s = sbase + t;
             gwords_t reg = as_global(wbase + __shfl((unsigned long long)my_off, t, 64));
