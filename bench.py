@@ -49,6 +49,19 @@ def private_snps(n_total):
     return 500 if n_total <= 1000 else 100
 
 
+def other_kernels(tm, steps, n_bases, n_distinct, rows, rows_kept, n_samples):
+    """HBM rate of the remaining stages against SURVEY.md 8d's algorithmic bytes (W + 1 = 9 B per dictionary entry,
+    P ~ N windows, D = sum of distinct split k-mers per sample, U rows, U' rows kept)."""
+    out = []
+    for name, ms, nbytes in (
+            ("per-sample dedup (dedupe_mb_kernel)", tm["dedupe"] / steps, 9.0 * (n_bases + n_distinct)),
+            ("merge (union_kernel + assemble_kernel)", (tm["key_union"] + tm["assemble"]) / steps, 9.0 * n_distinct + rows * (8.0 + n_samples)),
+            ("filter + compaction", (tm["filter"] + tm["compact"]) / steps, rows * (8.0 + n_samples) + rows_kept * float(n_samples))):
+        gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out.append({"stage": name, "ms": ms, "algorithmic_bytes": nbytes, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
+    return out
+
+
 def cpu_baseline(args, anc, n_total):
     """Oracle build_and_merge + align on a bounded sample of the same workload, timed on the host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -209,6 +222,11 @@ def main():
             ok &= bool(np.array_equal(gk["lo"], okk["lo"]) and np.array_equal(gb, ob))
         check = {"dicts_equal_oracle": ok, "samples_checked": nchk}
 
+    n_distinct = None
+    if rank == 0:                      # sum of the per-sample dictionary sizes (untimed): the D of SURVEY.md 8d's per-stage bytes
+        ds = E.DictSet.build_device(ptrs, lens, args.k, True, ctx=ctx)
+        n_distinct = int(sum(ds.size(i) for i in range(G)))
+        ds.free()
     if rank == 0:
         steps = max(args.steps, 1)
         scatter_ms = tm["scatter"] / steps
@@ -233,6 +251,7 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": scatter_ms},
             "stage_ms_per_step": {k: v / steps for k, v in tm.items()},
+            "other_kernels": other_kernels(tm, steps, total_bases, n_distinct, shape[0], shape[1], G),
             "host_wall_ms_per_step": {k: v / steps for k, v in host_ms.items()},
         }
         if check:

@@ -542,6 +542,132 @@ static void update_counts(ora_array *a, int filter_ambig_as_missing)
     a->nrows = w; a->nk = w;
 }
 
+/* ---- skf life-cycle: `ska merge` / `ska delete` / `ska weed` ------------------------------------ */
+
+/* generic_modes::merge (generic_modes.rs:90-106): to_dict (merge_ska_array.rs:208-222) + MergeSkaDict::extend
+ * (merge_ska_dict.rs:160-193) folded over the inputs + MergeSkaArray::new (merge_ska_array.rs:166-186).  Rows of the
+ * result = union of the inputs' split k-mers (sorted by key here; the reference's order is the hash map's), columns = the
+ * inputs' samples in order, absent = '-', variant_count = #cells that are neither 0 nor '-' (:172). */
+ora_array *ora_array_merge(const ora_array *const *in, int n)
+{
+    if (n <= 0) { ora_set_error("no input arrays"); return NULL; }
+    size_t tot_rows = 0, S = 0;
+    for (int i = 0; i < n; i++) {
+        if (in[i]->k != in[0]->k) { ora_set_error("K-mer lengths do not match: %d %d", in[i]->k, in[0]->k); return NULL; }   /* :169-171 */
+        if (in[i]->rc != in[0]->rc) { ora_set_error("Strand use inconsistent"); return NULL; }                                /* :172-174 */
+        if (in[i]->nk != in[i]->nrows) { ora_set_error("array keys and rows are out of step"); return NULL; }
+        tot_rows += in[i]->nrows; S += in[i]->ns;
+    }
+    /* all (key, source, row) triples sorted by key: one output row per distinct key */
+    typedef struct { ora_key k; uint32_t src, rid; } ksr;
+    ksr *p = (ksr *)malloc((tot_rows ? tot_rows : 1) * sizeof *p);
+    size_t w = 0;
+    for (int i = 0; i < n; i++) for (size_t r = 0; r < in[i]->nrows; r++) { p[w].k = in[i]->keys[r]; p[w].src = (uint32_t)i; p[w].rid = (uint32_t)r; w++; }
+    /* stable insertion of the source index into the comparison keeps equal keys grouped; order inside a group is free */
+    for (size_t gap = tot_rows / 2; gap > 0; gap /= 2)          /* shell sort: no dependence on qsort_r */
+        for (size_t i = gap; i < tot_rows; i++) {
+            ksr t = p[i]; size_t j = i;
+            while (j >= gap && cmp_key(&p[j - gap].k, &t.k) > 0) { p[j] = p[j - gap]; j -= gap; }
+            p[j] = t;
+        }
+    size_t U = 0;
+    for (size_t i = 0; i < tot_rows; i++) if (i == 0 || cmp_key(&p[i].k, &p[i - 1].k) != 0) U++;
+    ora_array *a = (ora_array *)calloc(1, sizeof *a);
+    a->k = in[0]->k; a->rc = in[0]->rc; a->k_bits = in[0]->k_bits; a->nk = a->nrows = U; a->ns = S;
+    a->keys = (ora_key *)malloc((U ? U : 1) * sizeof(ora_key));
+    a->var = (uint8_t *)malloc(U * S + 1); memset(a->var, '-', U * S + 1);
+    a->counts = (uint64_t *)calloc(U ? U : 1, 8);
+    a->names = (char **)malloc(S * sizeof(char *));
+    size_t *col0 = (size_t *)malloc(n * sizeof(size_t)), c = 0;
+    for (int i = 0; i < n; i++) { col0[i] = c; for (size_t s = 0; s < in[i]->ns; s++) a->names[c++] = strdup(in[i]->names[s]); }
+    a->version = strdup(in[0]->version ? in[0]->version : "");
+    size_t row = (size_t)-1;
+    for (size_t i = 0; i < tot_rows; i++) {
+        if (i == 0 || cmp_key(&p[i].k, &p[i - 1].k) != 0) { row++; a->keys[row] = p[i].k; }
+        const ora_array *src = in[p[i].src];
+        memcpy(a->var + row * S + col0[p[i].src], src->var + (size_t)p[i].rid * src->ns, src->ns);
+    }
+    for (size_t r = 0; r < U; r++) { uint64_t cnt = 0; for (size_t s = 0; s < S; s++) { uint8_t b = a->var[r * S + s]; cnt += b != 0 && b != '-'; } a->counts[r] = cnt; }
+    free(p); free(col0);
+    return a;
+}
+
+/* MergeSkaArray::delete_samples (merge_ska_array.rs:231-271): 0 on success, -1 + error text where the reference panics */
+int ora_array_delete_samples(ora_array *a, const char *const *del_names, int n_del)
+{
+    if (n_del <= 0 || (size_t)n_del == a->ns) { ora_set_error("Invalid number of samples to remove"); return -1; }      /* :232-234 */
+    /* a name set: duplicates in the request collapse, every name must match one column (first match, :243-249) */
+    uint8_t *drop = (uint8_t *)calloc(a->ns, 1), *found = (uint8_t *)calloc(n_del, 1);
+    for (int d = 0; d < n_del; d++) {
+        int dup = 0;
+        for (int e = 0; e < d; e++) if (!strcmp(del_names[e], del_names[d])) { dup = 1; found[d] = 1; }
+        if (dup) continue;
+        for (size_t s = 0; s < a->ns; s++) if (!drop[s] && !strcmp(a->names[s], del_names[d])) { drop[s] = 1; found[d] = 1; break; }
+    }
+    for (int d = 0; d < n_del; d++) if (!found[d]) { ora_set_error("Could not find sample(s): {\"%s\"}", del_names[d]); free(drop); free(found); return -1; }   /* :252-254 */
+    size_t S = a->ns, S2 = 0;
+    for (size_t s = 0; s < S; s++) S2 += !drop[s];
+    uint8_t *nv = (uint8_t *)malloc(a->nrows * S2 + 1);
+    for (size_t r = 0; r < a->nrows; r++) { size_t c = 0; for (size_t s = 0; s < S; s++) if (!drop[s]) nv[r * S2 + c++] = a->var[r * S + s]; }
+    size_t c = 0;
+    for (size_t s = 0; s < S; s++) { if (drop[s]) free(a->names[s]); else a->names[c++] = a->names[s]; }
+    free(a->var); a->var = nv; a->ns = S2;
+    free(drop); free(found);
+    update_counts(a, 0);                                                                                                  /* :270 */
+    return 0;
+}
+
+/* MergeSkaArray::weed (merge_ska_array.rs:452-487) with the split k-mers of a RefSka (ska_ref.rs:189-262, kmer_iter :541):
+ * every canonical split k-mer of the weed FASTA's records, whatever its middle base = the keys of the file's SkaDict */
+int ora_array_weed(ora_array *a, const ora_key *weed_keys, size_t n_weed, int reverse)
+{
+    if (a->nk != a->nrows) { ora_set_error("array keys and rows are out of step"); return -1; }
+    ora_key *wk = (ora_key *)malloc((n_weed ? n_weed : 1) * sizeof *wk);
+    memcpy(wk, weed_keys, n_weed * sizeof *wk);
+    for (size_t gap = n_weed / 2; gap > 0; gap /= 2)
+        for (size_t i = gap; i < n_weed; i++) { ora_key t = wk[i]; size_t j = i; while (j >= gap && cmp_key(&wk[j - gap], &t) > 0) { wk[j] = wk[j - gap]; j -= gap; } wk[j] = t; }
+    size_t S = a->ns, w = 0;
+    for (size_t r = 0; r < a->nrows; r++) {
+        size_t lo = 0, hi = n_weed;
+        while (lo < hi) { size_t mid = (lo + hi) / 2; if (cmp_key(&wk[mid], &a->keys[r]) < 0) lo = mid + 1; else hi = mid; }
+        const int found = lo < n_weed && cmp_key(&wk[lo], &a->keys[r]) == 0;
+        if ((!reverse && !found) || (reverse && found)) {                                                                 /* :468 */
+            if (w != r) { memmove(a->var + w * S, a->var + r * S, S); a->keys[w] = a->keys[r]; a->counts[w] = a->counts[r]; }
+            w++;
+        }
+    }
+    a->nrows = a->nk = w;
+    free(wk);
+    return 0;
+}
+
+/* generic_modes::weed (generic_modes.rs:207-262): weed file (FASTA only, RefSka::new) then the optional filter with a
+ * FLOOR threshold and update_kmers = true */
+int ora_weed(ora_array *a, const char *weed_fasta, int reverse, double min_freq, int filter_ambig_as_missing, int filter_type,
+             int ambig_mask, int ignore_const_gaps)
+{
+    if (weed_fasta) {
+        ora_fastx peek;                                                                                                   /* ska_ref.rs:206-208 */
+        if (ora_fastx_read(weed_fasta, &peek)) return -1;
+        const int fq = peek.is_fastq;
+        ora_fastx_free(&peek);
+        if (fq) { ora_set_error("Cannot create reference from FASTQ files"); return -1; }
+        ora_qual q = {1, 0, 0};
+        ora_dict *d = ora_dict_from_files(a->k, a->rc, weed_fasta, NULL, &q, 0.0);
+        if (!d) return -1;
+        size_t n = ora_dict_size(d);
+        ora_key *keys = (ora_key *)malloc((n ? n : 1) * sizeof *keys); uint8_t *bases = (uint8_t *)malloc(n ? n : 1);
+        ora_dict_export_sorted(d, keys, bases);
+        int r = ora_array_weed(a, keys, n, reverse);
+        free(keys); free(bases); ora_dict_free(d);
+        if (r) return r;
+    }
+    const size_t thr = (size_t)floor((double)a->ns * min_freq);                                                           /* :249 */
+    if (thr > 0 || filter_type != 0 || ambig_mask || ignore_const_gaps)
+        ora_array_filter(a, thr, filter_ambig_as_missing, filter_type, ambig_mask, ignore_const_gaps, 1);
+    return 0;
+}
+
 /* filter (merge_ska_array.rs:289-402) */
 int32_t ora_array_filter(ora_array *a, size_t min_count, int filter_ambig_as_missing, int filter_type,
                          int mask_ambig, int ignore_const_gaps, int update_kmers)

@@ -103,6 +103,17 @@ char *ora_array_fasta(const ora_array *a, size_t *len);
 /* Display / Debug (`ska nk`, merge_ska_array.rs:649-698) exactly as main prints them */
 char *ora_array_nk(const ora_array *a, int full_info, size_t *len);
 
+/* ---- skf life-cycle ---- */
+/* generic_modes::merge (generic_modes.rs:90-106) = to_dict + MergeSkaDict::extend (merge_ska_dict.rs:160-193) + ::new */
+ora_array *ora_array_merge(const ora_array *const *in, int n);
+/* MergeSkaArray::delete_samples (merge_ska_array.rs:231-271); -1 + ora_last_error() where the reference panics */
+int ora_array_delete_samples(ora_array *a, const char *const *del_names, int n_del);
+/* MergeSkaArray::weed (merge_ska_array.rs:452-487) against a key list (RefSka::kmer_iter, ska_ref.rs:541) */
+int ora_array_weed(ora_array *a, const ora_key *weed_keys, size_t n_weed, int reverse);
+/* generic_modes::weed (generic_modes.rs:207-262): optional weed FASTA, then the filter with a floor() threshold */
+int ora_weed(ora_array *a, const char *weed_fasta, int reverse, double min_freq, int filter_ambig_as_missing, int filter_type,
+             int ambig_mask, int ignore_const_gaps);
+
 typedef struct { double distance, mismatch_prop; uint64_t match_count, mismatch_count; } ora_dist;
 /* MergeSkaArray::distance (merge_ska_array.rs:416-438,587-632): upper triangle, (i<j) row-major */
 void ora_array_distance(const ora_array *a, double constant, int filt_ambig, ora_dist *out);

@@ -229,4 +229,82 @@ def case_dup_ss_nk_shape(E, tmp_path):
     assert "GATT\tAAGG\tK,D\n" in out
 
 
+def _must_fail(fn):
+    try:
+        fn()
+    except Exception:
+        return
+    raise AssertionError("the reference panics here")
+
+
+def _merge_delete(E, tmp_path, k, del_list):        # shared body of skf_ops.rs:11-83 and :85-161
+    t1 = roundtrip(E, E.Array.build(fasta_inputs(E, [fin("test_1.fa")]), k=k), tmp_path, "test_1")
+    t2 = roundtrip(E, E.Array.build(fasta_inputs(E, [fin("test_2.fa")]), k=k), tmp_path, "test_2")
+    m = roundtrip(E, E.Array.merge([t1, t2]), tmp_path, "merge")
+    assert m.names == ["test_1", "test_2"] and m.k == k
+    # removing a sample that is not there panics (merge_ska_array.rs:252-254)
+    _must_fail(lambda: E.Array.load(os.path.join(str(tmp_path), "merge.skf")).delete_samples(del_list))
+    # delete test_2: nk must equal the single-sample build's
+    m.delete_samples(["test_2"])
+    d = roundtrip(E, m, tmp_path, "merge_delete")
+    assert d.nk() == t1.nk()
+    assert d.nk(full_info=True).decode().split("\n")[:9] == t1.nk(full_info=True).decode().split("\n")[:9]
+    return t1, t2
+
+
+def case_merge_delete(E, tmp_path):                 # skf_ops.rs:11-83
+    t1, t2 = _merge_delete(E, tmp_path, 31, ["test_3"])
+    matches_path(E.Array.load(os.path.join(str(tmp_path), "merge.skf")).nk(), correct("merge_nk.stdout"))
+    # merging is the same as building both together
+    both = E.Array.build(fasta_inputs(E, [fin("test_1.fa"), fin("test_2.fa")]), k=31)
+    assert sorted(E.Array.merge([t1, t2]).nk(full_info=True).decode().split("\n")) == sorted(both.nk(full_info=True).decode().split("\n"))
+    # delete preconditions (merge_ska_array.rs:232-234)
+    _must_fail(lambda: E.Array.merge([t1, t2]).delete_samples([]))
+    _must_fail(lambda: E.Array.merge([t1, t2]).delete_samples(["test_1", "test_2"]))
+    # merge preconditions (merge_ska_dict.rs:169-174)
+    _must_fail(lambda: E.Array.merge([t1, E.Array.build(fasta_inputs(E, [fin("test_2.fa")]), k=17)]))
+    _must_fail(lambda: E.Array.merge([t1, E.Array.build(fasta_inputs(E, [fin("test_2.fa")]), k=31, rc=False)]))
+
+
+def case_merge_delete_u128(E, tmp_path):            # skf_ops.rs:85-161
+    with open(fin("missing_delete.txt")) as f:
+        names = [ln.split()[0] for ln in f if ln.strip()]
+    _merge_delete(E, tmp_path, 41, names)
+
+
+def case_weed(E, tmp_path):                         # skf_ops.rs:163-290
+    def load(name):                                 # every CLI step of the reference test starts from the file
+        return E.Array.load(os.path.join(str(tmp_path), name + ".skf"))
+    # the weed FASTA's split k-mers go; default min_freq 0.9 -> floor(2 * 0.9) = 1 (generic_modes.rs:249)
+    a = E.Array.load(fin("merge.skf"))
+    a.weed(fin("weed.fa"))
+    roundtrip(E, a, tmp_path, "weeded")
+    assert load("weeded").align() == correct("weed_align.stdout")
+    # a second pass without a weed file: filter no-const, min_freq 1
+    a = load("weeded")
+    a.weed(None, min_freq=1.0, filter_type=E.FILTER_NO_CONST)
+    matches_path(roundtrip(E, a, tmp_path, "weeded2").nk(full_info=True), correct("weed_nk.stdout"))
+    # masking ambiguous sites
+    b = E.Array.load(fin("merge_k9.skf"))
+    b.weed(None, ambig_mask=True)
+    matches_path(roundtrip(E, b, tmp_path, "weed_k9").nk(), correct("weed_nk_k9.stdout"))
+    # keep rather than weed
+    c = E.Array.load(fin("merge.skf"))
+    c.weed(fin("weed.fa"), reverse=True)
+    assert roundtrip(E, c, tmp_path, "weed_rev").align() == correct("weed_align_reverse.stdout")
+    # longer k-mers (u128)
+    d = roundtrip(E, E.Array.build(fasta_inputs(E, [fin("test_1.fa"), fin("test_2.fa")]), k=41), tmp_path, "build_k41")
+    d.weed(None, min_freq=1.0, filter_type=E.FILTER_NO_AMBIG_OR_CONST)
+    matches_path(roundtrip(E, d, tmp_path, "weed_k41").nk(full_info=True), correct("weed_nk_k41.stdout"))
+    # a FASTQ weed file is refused (ska_ref.rs:206-208)
+    _must_fail(lambda: E.Array.load(fin("merge.skf")).weed(fin("test_1_fwd.fastq.gz")))
+
+
+def case_repeats_weed(E, tmp_path):                 # fasta_input.rs:156-220, the weed step
+    a = E.Array.build(fasta_inputs(E, [fin("dup_test_1.fa"), fin("dup_test_2.fa")]), k=9, rc=False)
+    a = roundtrip(E, a, tmp_path, "dup_ss")
+    a.weed(None, filter_type=E.FILTER_NO_CONST, min_freq=1.0)
+    matches_path(roundtrip(E, a, tmp_path, "dup_ss_w").nk(full_info=True), correct("dup_ss_nk.stdout"))
+
+
 ALL_CASES = [v for k, v in sorted(globals().items()) if k.startswith("case_")]

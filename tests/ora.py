@@ -84,6 +84,11 @@ def _load():
     lib.ora_distance_tsv.argtypes = [vp, d, i, C.POINTER(sz)]
     lib.ora_align_fasta.restype = vp
     lib.ora_align_fasta.argtypes = [vp, i, i, i, d, i, C.POINTER(sz)]
+    lib.ora_array_merge.restype = vp
+    lib.ora_array_merge.argtypes = [C.POINTER(vp), i]
+    lib.ora_array_delete_samples.argtypes = [vp, C.POINTER(cp), i]
+    lib.ora_array_weed.argtypes = [vp, vp, sz, i]
+    lib.ora_weed.argtypes = [vp, cp, i, d, i, i, i, i]
     lib.ora_timers_get.argtypes = [C.POINTER(Timers), i]
     lib.ora_sample_name.restype = vp
     lib.ora_sample_name.argtypes = [cp]
@@ -257,6 +262,28 @@ class Array:
         n = C.c_size_t()
         return _take(lib.ora_align_fasta(self.h, filter_type, int(mask_ambig), int(ignore_const_gaps), min_freq,
                                          int(filter_ambig_as_missing), C.byref(n)), n.value)
+
+    # ---- skf life-cycle (ska merge / delete / weed) ----
+    @classmethod
+    def merge(cls, arrays):
+        hs = (C.c_void_p * len(arrays))(*[a.h for a in arrays])
+        return cls(lib.ora_array_merge(hs, len(arrays)))
+
+    def delete_samples(self, names):
+        nm = (C.c_char_p * len(names))(*[x.encode() for x in names])
+        if lib.ora_array_delete_samples(self.h, nm, len(names)):
+            raise _err()
+
+    def weed_keys(self, keys, reverse=False):
+        keys = np.ascontiguousarray(keys, KEY_DT)
+        if lib.ora_array_weed(self.h, _np_ptr(keys), len(keys), int(reverse)):
+            raise _err()
+
+    def weed(self, weed_fasta=None, reverse=False, min_freq=0.9, filter_ambig_as_missing=False, filter_type=FILTER_NONE,
+             ambig_mask=False, ignore_const_gaps=False):
+        if lib.ora_weed(self.h, weed_fasta.encode() if weed_fasta else None, int(reverse), min_freq,
+                        int(filter_ambig_as_missing), filter_type, int(ambig_mask), int(ignore_const_gaps)):
+            raise _err()
 
     def __del__(self):
         if getattr(self, "h", None):
