@@ -154,6 +154,26 @@ typedef struct { double distance, mismatch_prop; uint64_t match_count, mismatch_
 int  skx_array_distance(skx_array *a, double constant, int filt_ambig, skx_dist *out);
 void skx_free(void *p);
 
+/* ---- .skf life-cycle: `ska merge`, `ska delete`, `ska weed` ---- */
+/* generic_modes::merge (generic_modes.rs:90-106) = MergeSkaArray::to_dict (merge_ska_array.rs:208-222) +
+ * MergeSkaDict::extend (merge_ska_dict.rs:160-193) folded over the inputs + MergeSkaArray::new (:166-186): rows = union of
+ * the inputs' split k-mers, columns = their samples in order, absent cells '-'.  SKX_EINVAL with the reference's panic
+ * texts "K-mer lengths do not match: a b" / "Strand use inconsistent". */
+int  skx_array_merge(skx_ctx *ctx, skx_array *const *arrays, int n_arrays, skx_array **out);
+/* MergeSkaArray::delete_samples (merge_ska_array.rs:231-271) incl. update_counts(false): rows no remaining sample has are
+ * dropped.  SKX_EINVAL "Invalid number of samples to remove" / "Could not find sample(s): {..}" where it panics. */
+int  skx_array_delete_samples(skx_array *a, const char *const *names, int n_names);
+/* MergeSkaArray::weed (merge_ska_array.rs:452-487): rows whose split k-mer is (reverse: is not) in `weed` are removed;
+ * `weed` = the split k-mers of the weed FASTA (RefSka::new + kmer_iter, ska_ref.rs:189-262,541), i.e. the key set of its
+ * dictionary: skx_dictset_build_files (1 sample) -> skx_keyset_union. */
+int  skx_array_weed(skx_array *a, skx_keyset *weed, int reverse, uint64_t *removed);
+/* RefSka::new + kmer_iter (ska_ref.rs:189-262,541) for `ska weed`: the split k-mers of a FASTA file as a key set;
+ * SKX_EINVAL "Cannot create reference from FASTQ files" (ska_ref.rs:206-208), SKX_EEMPTY "<file> has no valid sequence" */
+int  skx_keyset_from_fasta(skx_ctx *ctx, const char *path, int k, int rc, skx_keyset **out);
+/* the context an array lives on; and a way for host glue above the ABI to leave its message in skx_last_error() */
+skx_ctx *skx_array_ctx(const skx_array *a);
+void skx_set_last_error(const char *msg);
+
 /* per-stage device timings of the last call on this ctx (ms; HIP events on the ctx stream) */
 typedef struct { double hist, scatter, dedupe, key_union, assemble, filter, compact, distance; } skx_timings;
 int  skx_ctx_timings(skx_ctx *ctx, skx_timings *t, int reset);

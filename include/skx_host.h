@@ -26,9 +26,18 @@ int skh_nk(skx_array *a, int full_info, char **buf, uint64_t *len);
 int skh_save_skf(skx_array *a, const char *out_prefix);
 /* io_utils::load_array (io_utils.rs:60-93) + the u64-then-u128 retry of lib.rs:635-661 */
 int skh_load_array(skx_ctx *ctx, const char *const *inputs, int n_inputs, int threads, skx_array **out);
+/* generic_modes::merge (generic_modes.rs:90-106): first file decides u64/u128 (lib.rs:728-741), the others must load as the
+ * same type ("Failed to load input file (inconsistent k-mer lengths?)"); saved through save_skf (".skf" appended) */
+int skh_merge(skx_ctx *ctx, const char *const *skf_files, int n_files, const char *out_prefix);
+/* generic_modes::delete (generic_modes.rs:192-210): delete_samples then save (".skf" appended unless present) */
+int skh_delete(skx_array *a, const char *const *names, int n_names, const char *out_file);
+/* generic_modes::weed (generic_modes.rs:213-267): optional weed FASTA (FASTQ refused, ska_ref.rs:206-208), then the filter
+ * with threshold floor(n_samples * min_freq) and update_kmers = true when anything is asked for; out_file NULL = no save */
+int skh_weed(skx_array *a, const char *weed_file, int reverse, double min_freq, int filter_ambig_as_missing, int filter_type,
+             int ambig_mask, int ignore_const_gaps, const char *out_file);
 /* io_utils::read_input_fastas sample-name rule (io_utils.rs:31-46) */
 char *skh_sample_name(const char *path);
-/* the `ska` command line (build | align | distance | nk); returns the process exit code */
+/* the `ska` command line (build | align | distance | nk | merge | delete | weed); returns the process exit code */
 int skh_main(int argc, char **argv);
 
 #ifdef __cplusplus

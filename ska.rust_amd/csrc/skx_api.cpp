@@ -734,13 +734,11 @@ extern "C" int skx_array_from_host(skx_ctx *ctx, int k, int rc, const char *cons
     });
 }
 
-extern "C" int skx_array_export(skx_array *a, skx_key *keys, uint8_t *variants, uint64_t *counts)
+// split k-mers of an array as the reference stores them (hash undone), in the array's row order
+static int array_host_keys(skx_array *a, std::vector<skx_key> &hk)
 {
-    return skx_guarded([&]() -> int {
-    skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
-    SKX_HIP(hipSetDevice(ctx->device));
-    const uint64_t U = a->n_rows, S = a->names.size(), K = a->n_kmers;
-    std::vector<skx_key> hk(K);
+    const uint64_t K = a->n_kmers;
+    hk.assign(K, skx_key{0, 0});
     if (a->k <= 31) {
         std::vector<uint64_t> w(K);
         if (K) SKX_HIP(hipMemcpy(w.data(), a->keys.p, K * 8, hipMemcpyDeviceToHost));
@@ -754,6 +752,17 @@ extern "C" int skx_array_export(skx_array *a, skx_key *keys, uint8_t *variants, 
             hk[i].lo = (uint64_t)key; hk[i].hi = (uint64_t)(key >> 64);
         }
     }
+    return SKX_OK;
+}
+
+extern "C" int skx_array_export(skx_array *a, skx_key *keys, uint8_t *variants, uint64_t *counts)
+{
+    return skx_guarded([&]() -> int {
+    skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
+    SKX_HIP(hipSetDevice(ctx->device));
+    const uint64_t U = a->n_rows, S = a->names.size(), K = a->n_kmers;
+    std::vector<skx_key> hk;
+    SKX_TRY(array_host_keys(a, hk));
     std::vector<uint8_t> rm(U * S);
     std::vector<uint32_t> pres(U);
     if (U) {
@@ -790,6 +799,52 @@ extern "C" int skx_array_sample_kmers(skx_array *a, int64_t *out)
     });
 }
 
+// shared tail of filter / weed / delete_samples: rows with keep == 1 survive (pos = exclusive scan of keep)
+static int array_compact(skx_array *a, DevBuf<uint8_t> &keep, DevBuf<uint64_t> &pos, uint64_t kept, int mask_ambig, bool vcount_from_unambig,
+                         bool keys_follow)
+{
+    skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
+    const uint64_t U = a->n_rows; const size_t S = a->names.size();
+    const bool filter_ambig_as_missing = vcount_from_unambig;
+    {
+        StageTimer t(ctx, &ctx->tm.compact);
+        const uint64_t np = pitch_for(kept);
+        DevBuf<uint8_t> nm; DevBuf<uint32_t> p2, u2, m2, v2;
+        SKX_TRY(nm.alloc((uint64_t)S * np)); SKX_TRY(p2.alloc(kept)); SKX_TRY(u2.alloc(kept)); SKX_TRY(m2.alloc(kept)); SKX_TRY(v2.alloc(kept));
+        launch_compact_matrix(a->matrix.p, a->pitch, nm.p, np, (int)S, U, keep.p, pos.p, mask_ambig, st);
+        launch_compact_u32(a->present.p, p2.p, U, keep.p, pos.p, st);
+        launch_compact_u32(a->unambig.p, u2.p, U, keep.p, pos.p, st);
+        launch_compact_u32(a->mask.p, m2.p, U, keep.p, pos.p, st);
+        // update_counts(true) rewrites variant_count with the unambiguous counts (merge_ska_array.rs:139-163)
+        launch_compact_u32(filter_ambig_as_missing ? a->unambig.p : a->vcount.p, v2.p, U, keep.p, pos.p, st);
+        if (mask_ambig) launch_mask_ambig_stats(m2.p, kept, st);
+        // update_counts(true) (merge_ska_array.rs:139-163) rewrites counts AND split_kmers whenever it ran
+        if (a->n_kmers == U && keys_follow) {
+            if (a->k <= 31) {
+                DevBuf<uint64_t> k2; SKX_TRY(k2.alloc(kept));
+                launch_compact_u64(a->keys.p, k2.p, U, keep.p, pos.p, st);
+                a->keys = std::move(k2);
+            } else if (a->host_keys.empty()) {
+                DevBuf<uint64_t> k2; SKX_TRY(k2.alloc(kept * 2));
+                launch_compact_u128(a->keys.p, k2.p, U, keep.p, pos.p, st);
+                a->keys = std::move(k2);
+            } else {
+                std::vector<uint8_t> hkeep(U);
+                SKX_HIP(hipMemcpyAsync(hkeep.data(), keep.p, U, hipMemcpyDeviceToHost, st));
+                SKX_HIP(hipStreamSynchronize(st));
+                std::vector<skx_key> nk; nk.reserve(kept);
+                for (uint64_t i = 0; i < U; i++) if (hkeep[i] == 1) nk.push_back(a->host_keys[i]);
+                a->host_keys.swap(nk);
+            }
+            a->n_kmers = kept;
+        }
+        SKX_HIP(hipStreamSynchronize(st));
+        a->matrix = std::move(nm); a->present = std::move(p2); a->unambig = std::move(u2); a->mask = std::move(m2); a->vcount = std::move(v2);
+        a->pitch = np; a->n_rows = kept;
+    }
+    return SKX_OK;
+}
+
 extern "C" int skx_array_filter(skx_array *a, uint64_t min_count, int filter_ambig_as_missing, int filter_type, int mask_ambig,
                                 int ignore_const_gaps, int update_kmers, int32_t *removed)
 {
@@ -816,46 +871,199 @@ extern "C" int skx_array_filter(skx_array *a, uint64_t min_count, int filter_amb
         }
         SKX_HIP(hipStreamSynchronize(st));
     }
-    {
-        StageTimer t(ctx, &ctx->tm.compact);
-        const uint64_t np = pitch_for(kept);
-        DevBuf<uint8_t> nm; DevBuf<uint32_t> p2, u2, m2, v2;
-        SKX_TRY(nm.alloc((uint64_t)S * np)); SKX_TRY(p2.alloc(kept)); SKX_TRY(u2.alloc(kept)); SKX_TRY(m2.alloc(kept)); SKX_TRY(v2.alloc(kept));
-        launch_compact_matrix(a->matrix.p, a->pitch, nm.p, np, (int)S, U, keep.p, pos.p, mask_ambig, st);
-        launch_compact_u32(a->present.p, p2.p, U, keep.p, pos.p, st);
-        launch_compact_u32(a->unambig.p, u2.p, U, keep.p, pos.p, st);
-        launch_compact_u32(a->mask.p, m2.p, U, keep.p, pos.p, st);
-        // update_counts(true) rewrites variant_count with the unambiguous counts (merge_ska_array.rs:139-163)
-        launch_compact_u32(filter_ambig_as_missing ? a->unambig.p : a->vcount.p, v2.p, U, keep.p, pos.p, st);
-        if (mask_ambig) launch_mask_ambig_stats(m2.p, kept, st);
-        // update_counts(true) (merge_ska_array.rs:139-163) rewrites counts AND split_kmers whenever it ran
-        const bool keys_follow = update_kmers || filter_ambig_as_missing;
-        if (a->n_kmers == U && keys_follow) {
-            if (a->k <= 31) {
-                DevBuf<uint64_t> k2; SKX_TRY(k2.alloc(kept));
-                launch_compact_u64(a->keys.p, k2.p, U, keep.p, pos.p, st);
-                a->keys = std::move(k2);
-            } else if (a->host_keys.empty()) {
-                DevBuf<uint64_t> k2; SKX_TRY(k2.alloc(kept * 2));
-                launch_compact_u128(a->keys.p, k2.p, U, keep.p, pos.p, st);
-                a->keys = std::move(k2);
-            } else {
-                std::vector<uint8_t> hkeep(U);
-                SKX_HIP(hipMemcpyAsync(hkeep.data(), keep.p, U, hipMemcpyDeviceToHost, st));
-                SKX_HIP(hipStreamSynchronize(st));
-                std::vector<skx_key> nk; nk.reserve(kept);
-                for (uint64_t i = 0; i < U; i++) if (hkeep[i] == 1) nk.push_back(a->host_keys[i]);
-                a->host_keys.swap(nk);
-            }
-            a->n_kmers = kept;
-        }
-        SKX_HIP(hipStreamSynchronize(st));
-        a->matrix = std::move(nm); a->present = std::move(p2); a->unambig = std::move(u2); a->mask = std::move(m2); a->vcount = std::move(v2);
-        a->pitch = np; a->n_rows = kept;
-    }
+    SKX_TRY(array_compact(a, keep, pos, kept, mask_ambig, filter_ambig_as_missing != 0, update_kmers || filter_ambig_as_missing));
     SKX_HIP(hipGetLastError());
     if (removed) *removed = (int32_t)(U - kept - silent);
     return SKX_OK;
+    });
+}
+
+// ------------------------------------------------------------------------------------------ skf life-cycle (N1)
+static bool key_less(const skx_key &x, const skx_key &y) { return x.hi != y.hi ? x.hi < y.hi : x.lo < y.lo; }
+static bool key_eq(const skx_key &x, const skx_key &y) { return x.hi == y.hi && x.lo == y.lo; }
+
+// flags -> scan -> compaction with the keys following the rows
+static int array_keep_rows(skx_array *a, DevBuf<uint8_t> &keep, uint64_t *removed)
+{
+    hipStream_t st = a->ctx->stream;
+    const uint64_t U = a->n_rows;
+    DevBuf<uint64_t> pos; SKX_TRY(pos.alloc(U + 1));
+    uint64_t kept = 0;
+    launch_scan_u8(keep.p, pos.p, U, st);
+    SKX_HIP(hipMemcpyAsync(&kept, pos.p + U, 8, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipStreamSynchronize(st));
+    SKX_TRY(array_compact(a, keep, pos, kept, 0, false, true));
+    SKX_HIP(hipGetLastError());
+    if (removed) *removed = U - kept;
+    return SKX_OK;
+}
+
+extern "C" skx_ctx *skx_array_ctx(const skx_array *a) { return a->ctx; }
+extern "C" void skx_set_last_error(const char *msg) { set_error("%s", msg ? msg : ""); }
+
+// RefSka::new(k, file, rc, ..) + kmer_iter (ska_ref.rs:189-262,541) as `ska weed` uses it: the canonical split k-mers of every
+// record of a FASTA file, whatever their middle bases = the key set of the file's dictionary
+extern "C" int skx_keyset_from_fasta(skx_ctx *ctx, const char *path, int k, int rc, skx_keyset **out)
+{
+    return skx_guarded([&]() -> int {
+    if (!ctx || !path || !out) { set_error("bad arguments"); return SKX_EINVAL; }
+    SKX_TRY(check_k(k));
+    HostStream hs;
+    SKX_TRY(read_sample_stream(path, nullptr, 0.0, hs));
+    if (hs.is_fastq) { set_error("Cannot create reference from FASTQ files"); return SKX_EINVAL; }                                // ska_ref.rs:206-208
+    skx_stream ss; ss.seq = hs.seq.data(); ss.qual = nullptr; ss.len = hs.seq.size();
+    skx_dictset *d = nullptr;
+    int r = skx_dictset_build(ctx, &ss, 1, 0, k, rc, nullptr, &d);
+    if (r == SKX_EEMPTY) set_error("%s has no valid sequence", path);                                                             // ska_ref.rs:255-257
+    if (r != SKX_OK) return r;
+    r = skx_keyset_union(ctx, d, out);
+    skx_dictset_free(d);
+    return r;
+    });
+}
+
+extern "C" int skx_array_merge(skx_ctx *ctx, skx_array *const *in, int n, skx_array **out)
+{
+    return skx_guarded([&]() -> int {
+    if (!ctx || !in || n <= 0 || !out) { set_error("bad arguments"); return SKX_EINVAL; }
+    SKX_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    uint64_t tot = 0; size_t S = 0;
+    for (int i = 0; i < n; i++) {
+        if (in[i]->k != in[0]->k) { set_error("K-mer lengths do not match: %d %d", in[i]->k, in[0]->k); return SKX_EINVAL; }     // merge_ska_dict.rs:169-171
+        if (in[i]->rc != in[0]->rc) { set_error("Strand use inconsistent"); return SKX_EINVAL; }                                  // :172-174
+        if (in[i]->n_kmers != in[i]->n_rows) { set_error("split k-mers and variants are out of step (filtered without update_kmers)"); return SKX_EINVAL; }
+        tot += in[i]->n_rows; S += in[i]->names.size();
+    }
+    if (S > 65535) { set_error("more than 65535 samples per device array"); return SKX_EUNSUP; }
+    std::unique_ptr<skx_array> a(new skx_array());
+    a->ctx = ctx; a->k = in[0]->k; a->rc = in[0]->rc; a->k_bits = in[0]->k_bits; a->hp = in[0]->hp; a->wh = in[0]->wh; a->version = skx_version();
+    for (int i = 0; i < n; i++) for (auto &nm : in[i]->names) a->names.push_back(nm);                                             // :177
+    // rows of the result = distinct split k-mers over all inputs; idx[i][r] = result row of row r of input i
+    std::vector<DevBuf<uint32_t>> idx(n);
+    uint64_t U = 0;
+    if (a->k <= 31) {
+        DevBuf<uint64_t> all, rows; SKX_TRY(all.alloc(tot));
+        uint64_t o = 0;
+        for (int i = 0; i < n; i++) { if (in[i]->n_rows) SKX_HIP(hipMemcpyAsync(all.p + o, in[i]->keys.p, in[i]->n_rows * 8, hipMemcpyDeviceToDevice, st)); o += in[i]->n_rows; }
+        SKX_TRY(sort_unique_words(all.p, tot, rows, &U, st));
+        for (int i = 0; i < n; i++) { SKX_TRY(idx[i].alloc(in[i]->n_rows)); launch_lookup_rows(in[i]->keys.p, in[i]->n_rows, rows.p, U, idx[i].p, st); }
+        SKX_TRY(a->keys.alloc(U));
+        if (U) SKX_HIP(hipMemcpyAsync(a->keys.p, rows.p, U * 8, hipMemcpyDeviceToDevice, st));
+        SKX_HIP(hipStreamSynchronize(st));
+        a->engine_order = true;
+    } else {
+        // 128-bit keys of loaded arrays live on the host: the row set is a host sort, the matrix work stays on the device
+        std::vector<std::vector<skx_key>> hk(n);
+        std::vector<skx_key> all; all.reserve(tot);
+        for (int i = 0; i < n; i++) { SKX_TRY(array_host_keys(in[i], hk[i])); all.insert(all.end(), hk[i].begin(), hk[i].end()); }
+        std::sort(all.begin(), all.end(), key_less);
+        all.erase(std::unique(all.begin(), all.end(), key_eq), all.end());
+        U = all.size();
+        for (int i = 0; i < n; i++) {
+            std::vector<uint32_t> h(hk[i].size());
+            for (size_t r = 0; r < hk[i].size(); r++) h[r] = (uint32_t)(std::lower_bound(all.begin(), all.end(), hk[i][r], key_less) - all.begin());
+            SKX_TRY(idx[i].alloc(h.size()));
+            if (!h.empty()) SKX_HIP(hipMemcpyAsync(idx[i].p, h.data(), h.size() * 4, hipMemcpyHostToDevice, st));
+            SKX_HIP(hipStreamSynchronize(st));
+        }
+        a->host_keys.swap(all);
+        a->engine_order = false;
+    }
+    if (U > 0xFFFFFFF0ull) { set_error("too many rows"); return SKX_EUNSUP; }
+    a->n_rows = a->n_kmers = U; a->pitch = pitch_for(U);
+    SKX_TRY(a->matrix.alloc((uint64_t)S * a->pitch));
+    SKX_TRY(a->present.alloc(U)); SKX_TRY(a->unambig.alloc(U)); SKX_TRY(a->mask.alloc(U)); SKX_TRY(a->vcount.alloc(U));
+    SKX_HIP(hipMemsetAsync(a->matrix.p, '-', (uint64_t)S * a->pitch, st));                                                        // absent = 0 -> '-' (merge_ska_array.rs:175)
+    size_t c0 = 0;
+    for (int i = 0; i < n; i++) {
+        launch_scatter_rows(in[i]->matrix.p, in[i]->pitch, (int)in[i]->names.size(), a->matrix.p + c0 * a->pitch, a->pitch, idx[i].p, in[i]->n_rows, st);
+        c0 += in[i]->names.size();
+    }
+    DevBuf<int> d_bad; SKX_TRY(d_bad.alloc(1)); SKX_TRY(d_bad.zero(st));
+    if (U) {
+        launch_col_stats(a->matrix.p, a->pitch, (int)S, U, a->present.p, a->unambig.p, a->mask.p, d_bad.p, st);
+        SKX_HIP(hipMemcpyAsync(a->vcount.p, a->present.p, U * 4, hipMemcpyDeviceToDevice, st));                                   // :172
+    }
+    SKX_HIP(hipStreamSynchronize(st));
+    SKX_HIP(hipGetLastError());
+    *out = a.release();
+    return SKX_OK;
+    });
+}
+
+extern "C" int skx_array_delete_samples(skx_array *a, const char *const *del_names, int n_del)
+{
+    return skx_guarded([&]() -> int {
+    if (!a) { set_error("bad arguments"); return SKX_EINVAL; }
+    skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
+    SKX_HIP(hipSetDevice(ctx->device));
+    const size_t S = a->names.size();
+    if (n_del <= 0 || (size_t)n_del == S) { set_error("Invalid number of samples to remove"); return SKX_EINVAL; }                // merge_ska_array.rs:232-234
+    if (a->n_kmers != a->n_rows) { set_error("split k-mers and variants are out of step (filtered without update_kmers)"); return SKX_EINVAL; }
+    // the request is a set of names; each must match a column (first match wins, :243-249)
+    std::vector<std::string> want;
+    for (int d = 0; d < n_del; d++) if (std::find(want.begin(), want.end(), del_names[d]) == want.end()) want.emplace_back(del_names[d]);
+    std::vector<char> drop(S, 0);
+    for (auto &w : want) {
+        bool found = false;
+        for (size_t s = 0; s < S && !found; s++) if (!drop[s] && a->names[s] == w) { drop[s] = 1; found = true; }
+        if (!found) { set_error("Could not find sample(s): {\"%s\"}", w.c_str()); return SKX_EINVAL; }                           // :252-254
+    }
+    std::vector<std::string> names2;
+    for (size_t s = 0; s < S; s++) if (!drop[s]) names2.push_back(a->names[s]);
+    const size_t S2 = names2.size();
+    if (S2 == 0) { set_error("Invalid number of samples to remove"); return SKX_EINVAL; }
+    const uint64_t U = a->n_rows;
+    DevBuf<uint8_t> nm; SKX_TRY(nm.alloc((uint64_t)S2 * a->pitch));
+    size_t c = 0;
+    for (size_t s = 0; s < S; s++) if (!drop[s]) { SKX_HIP(hipMemcpyAsync(nm.p + c * a->pitch, a->matrix.p + s * a->pitch, a->pitch, hipMemcpyDeviceToDevice, st)); c++; }
+    SKX_HIP(hipStreamSynchronize(st));
+    a->matrix = std::move(nm); a->names.swap(names2); a->total_samples = 0;
+    // update_counts(false) (:139-163,270): recount, drop the rows no remaining sample has
+    DevBuf<int> d_bad; SKX_TRY(d_bad.alloc(1)); SKX_TRY(d_bad.zero(st));
+    DevBuf<uint8_t> keep; SKX_TRY(keep.alloc(U));
+    if (U) {
+        launch_col_stats(a->matrix.p, a->pitch, (int)S2, U, a->present.p, a->unambig.p, a->mask.p, d_bad.p, st);
+        SKX_HIP(hipMemcpyAsync(a->vcount.p, a->present.p, U * 4, hipMemcpyDeviceToDevice, st));
+        launch_nonzero_flags(a->present.p, U, keep.p, st);
+    }
+    return array_keep_rows(a, keep, nullptr);
+    });
+}
+
+extern "C" int skx_array_weed(skx_array *a, skx_keyset *weed, int reverse, uint64_t *removed)
+{
+    return skx_guarded([&]() -> int {
+    if (!a || !weed) { set_error("bad arguments"); return SKX_EINVAL; }
+    skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
+    SKX_HIP(hipSetDevice(ctx->device));
+    if (weed->k != a->k) { set_error("K-mer lengths do not match: %d %d", weed->k, a->k); return SKX_EINVAL; }
+    if (weed->rc != a->rc) { set_error("Strand use inconsistent"); return SKX_EINVAL; }
+    if (a->n_kmers != a->n_rows) { set_error("split k-mers and variants are out of step (filtered without update_kmers)"); return SKX_EINVAL; }
+    const uint64_t U = a->n_rows;
+    if (weed->logN >= 0) SKX_TRY(keyset_flatten(weed));
+    DevBuf<uint8_t> keep; SKX_TRY(keep.alloc(U));
+    if (a->k <= 31) {
+        DevBuf<uint32_t> idx; SKX_TRY(idx.alloc(U));
+        launch_lookup_rows(a->keys.p, U, weed->flat.p, weed->total, idx.p, st);
+        launch_member_flags(idx.p, U, reverse, keep.p, st);                                                                       // merge_ska_array.rs:468
+        SKX_HIP(hipStreamSynchronize(st));
+    } else {
+        std::vector<uint64_t> w(2 * weed->total);
+        if (weed->total) SKX_HIP(hipMemcpy(w.data(), weed->flat.p, weed->total * 16, hipMemcpyDeviceToHost));
+        std::vector<skx_key> wk(weed->total), hk;
+        for (uint64_t i = 0; i < weed->total; i++) {
+            const u128 key = hunmix_w((((u128)w[2 * i + 1] << 64) | w[2 * i]) >> 4, weed->wh);
+            wk[i].lo = (uint64_t)key; wk[i].hi = (uint64_t)(key >> 64);
+        }
+        std::sort(wk.begin(), wk.end(), key_less);
+        SKX_TRY(array_host_keys(a, hk));
+        std::vector<uint8_t> h(U);
+        for (uint64_t r = 0; r < U; r++) { const bool found = std::binary_search(wk.begin(), wk.end(), hk[r], key_less); h[r] = (uint8_t)(reverse ? found : !found); }
+        if (U) SKX_HIP(hipMemcpy(keep.p, h.data(), U, hipMemcpyHostToDevice));
+    }
+    return array_keep_rows(a, keep, removed);
     });
 }
 

@@ -189,4 +189,11 @@ void launch_assemble_wide(const AssembleArgs &a, hipStream_t st);      // a.stag
 void launch_gather_keys_wide(const u128 *stage, uint32_t stride, const uint32_t *ncnt, const uint64_t *roff, int n_sub, u128 *out,
                              hipStream_t st);
 
+// ---- row-set operations for `ska merge` / `ska weed` / `ska delete` (skx_setops.hip)
+void launch_lookup_rows(const uint64_t *words, uint64_t n, const uint64_t *sorted, uint64_t m, uint32_t *idx, hipStream_t st);
+void launch_member_flags(const uint32_t *idx, uint64_t n, int reverse, uint8_t *keep, hipStream_t st);
+void launch_scatter_rows(const uint8_t *src, uint64_t src_pitch, int n_samples, uint8_t *dst, uint64_t dst_pitch, const uint32_t *idx,
+                         uint64_t n, hipStream_t st);
+void launch_nonzero_flags(const uint32_t *v, uint64_t n, uint8_t *keep, hipStream_t st);
+
 }  // namespace skx

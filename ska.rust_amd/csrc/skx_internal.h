@@ -108,6 +108,8 @@ int read_sample_stream(const char *file1, const char *file2, double proportion_r
 // FASTQ sample -> sorted unique packed words (skx_reads.hip)
 int reads_sample_dict(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t len, int k, int rc, const skx_qual &q,
                       DevBuf<uint64_t> &out_words, uint64_t *n_out);
+// sorted duplicate-free copy of packed words (skx_setops.hip)
+int sort_unique_words(const uint64_t *in, uint64_t n, DevBuf<uint64_t> &out, uint64_t *n_out, hipStream_t st);
 // .skf codec (skf_codec.cpp)
 struct SkfData {
     int k = 0, rc = 0, k_bits = 64; std::vector<std::string> names; std::string version;

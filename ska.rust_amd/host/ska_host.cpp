@@ -53,6 +53,13 @@ void rust_debug(std::string &o, const std::string &s)
     }
     o += '"';
 }
+void skx_set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+void skx_set_error(const char *fmt, ...)
+{
+    char tmp[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(tmp, sizeof tmp, fmt, ap); va_end(ap);
+    skx_set_last_error(tmp);
+}
 template <typename F>
 int skx_guarded(F &&f) noexcept
 {
@@ -184,6 +191,65 @@ extern "C" int skh_load_array(skx_ctx *ctx, const char *const *inputs, int n_inp
     });
 }
 
+extern "C" int skh_merge(skx_ctx *ctx, const char *const *skf_files, int n_files, const char *out_prefix)
+{
+    return skx_guarded([&]() -> int {
+    if (n_files < 2) { skx_set_error("Need at least two files to merge"); return SKX_EINVAL; }                    // lib.rs:729-731
+    std::vector<skx_array *> arrs(n_files, nullptr);
+    auto cleanup = [&]() { for (auto p : arrs) if (p) skx_array_free(p); };
+    int bits = 64;
+    if (skx_array_load(ctx, skf_files[0], 64, &arrs[0]) != SKX_OK) {
+        bits = 128;
+        if (skx_array_load(ctx, skf_files[0], 128, &arrs[0]) != SKX_OK) { skx_set_error("Could not read input file: %s", skf_files[0]); return SKX_EIO; }
+    }
+    for (int i = 1; i < n_files; i++)
+        if (skx_array_load(ctx, skf_files[i], bits, &arrs[i]) != SKX_OK) {                                        // generic_modes.rs:99-100
+            cleanup(); skx_set_error("Failed to load input file (inconsistent k-mer lengths?): %s", skf_files[i]); return SKX_EINVAL;
+        }
+    skx_array *m = nullptr;
+    int r = skx_array_merge(ctx, arrs.data(), n_files, &m);
+    cleanup();
+    if (r != SKX_OK) return r;
+    r = skh_save_skf(m, out_prefix);
+    skx_array_free(m);
+    return r;
+    });
+}
+
+extern "C" int skh_delete(skx_array *a, const char *const *names, int n_names, const char *out_file)
+{
+    return skx_guarded([&]() -> int {
+    int r = skx_array_delete_samples(a, names, n_names);
+    if (r != SKX_OK) return r;
+    return skh_save_skf(a, out_file);                                                                             // generic_modes.rs:200-209 (same suffix rule)
+    });
+}
+
+extern "C" int skh_weed(skx_array *a, const char *weed_file, int reverse, double min_freq, int filter_ambig_as_missing, int filter_type,
+                        int ambig_mask, int ignore_const_gaps, const char *out_file)
+{
+    return skx_guarded([&]() -> int {
+    skx_array_info_t info; skx_array_info(a, &info);
+    if (weed_file) {
+        // RefSka::new(k, file, rc, ..) (generic_modes.rs:222-235): FASTA only; its split k-mers = the keys of the file's dictionary
+        skx_keyset *ks = nullptr;
+        int r = skx_keyset_from_fasta(skx_array_ctx(a), weed_file, info.k, info.rc, &ks);
+        if (r != SKX_OK) return r;
+        uint64_t removed = 0;
+        r = skx_array_weed(a, ks, reverse, &removed);
+        skx_keyset_free(ks);
+        if (r != SKX_OK) return r;
+    }
+    const uint64_t threshold = (uint64_t)std::floor((double)info.n_samples * min_freq);                           // generic_modes.rs:249
+    if (threshold > 0 || filter_type != SKX_FILTER_NONE || ambig_mask || ignore_const_gaps) {
+        int32_t removed = 0;
+        int r = skx_array_filter(a, threshold, filter_ambig_as_missing, filter_type, ambig_mask, ignore_const_gaps, /*update_kmers=*/1, &removed);
+        if (r != SKX_OK) return r;
+    }
+    return out_file ? skx_array_save(a, out_file) : SKX_OK;                                                       // :263-266 (no suffix rule here)
+    });
+}
+
 // ------------------------------------------------------------------------------------------ CLI
 namespace {
 struct Args {
@@ -193,7 +259,7 @@ struct Args {
     std::string get(const std::string &k, const std::string &d = "") const { for (auto &o : opt) if (o.first == k) return o.second; return d; }
 };
 const char *VALUE_OPTS[] = {"-o", "-k", "-f", "--threads", "--min-count", "--min-qual", "--qual-filter", "--proportion-reads",
-                            "--min-freq", "-m", "--filter", nullptr};
+                            "--min-freq", "-m", "--filter", "-s", "--skf-file", nullptr};
 bool takes_value(const std::string &s) { for (int i = 0; VALUE_OPTS[i]; i++) if (s == VALUE_OPTS[i]) return true; return false; }
 int fail(const char *msg) { fprintf(stderr, "error: %s\n", msg); return 2; }
 int engine_fail() { fprintf(stderr, "error: %s\n", skx_last_error()); return 101; }   // Rust panics exit with 101
@@ -218,7 +284,7 @@ int emit(const std::string &out_path, const char *buf, uint64_t len)            
 extern "C" int skh_main(int argc, char **argv)
 {
     fprintf(stderr, "SKA: Split K-mer Analysis (the alignment-free aligner)\n");
-    if (argc < 2) return fail("usage: ska <build|align|distance|nk> ...");
+    if (argc < 2) return fail("usage: ska <build|align|distance|nk|merge|delete|weed> ...");
     const std::string cmd = argv[1];
     Args a;
     for (int i = 2; i < argc; i++) {
@@ -298,8 +364,39 @@ extern "C" int skh_main(int argc, char **argv)
         char *buf = nullptr; uint64_t len = 0;
         if (skh_load_array(ctx, in, 1, 1, &arr) != SKX_OK || skh_nk(arr, a.has("--full-info"), &buf, &len) != SKX_OK) rcode = engine_fail();
         else { rcode = emit("", buf, len); skx_free(buf); }
+    } else if (cmd == "merge") {                                                                                  // cli.rs Merge, lib.rs:728-741
+        if (!a.has("-o")) return fail("-o <output> is required");
+        std::vector<const char *> in; for (auto &p : a.pos) in.push_back(p.c_str());
+        if (skh_merge(ctx, in.data(), (int)in.size(), a.get("-o").c_str()) != SKX_OK) rcode = engine_fail();
+    } else if (cmd == "delete") {                                                                                 // cli.rs Delete, lib.rs:742-759
+        const std::string skf = a.get("-s", a.get("--skf-file"));
+        if (skf.empty()) return fail("-s <skf_file> is required");
+        if (a.pos.empty() == !a.has("-f")) return fail("give either sample names or -f <file_list>");
+        std::vector<std::string> names;
+        if (a.has("-f")) {                                                                                        // io_utils::get_input_list: first column
+            std::ifstream in(a.get("-f"));
+            if (!in) return fail("Unable to open file_list");
+            std::string line;
+            while (std::getline(in, line)) { std::istringstream ls(line); std::string t; if (ls >> t) names.push_back(t); }
+        } else names = a.pos;
+        std::vector<const char *> cn; for (auto &n : names) cn.push_back(n.c_str());
+        const char *in[1] = {skf.c_str()};
+        const std::string out = a.get("-o", skf);
+        if (skh_load_array(ctx, in, 1, 1, &arr) != SKX_OK || skh_delete(arr, cn.data(), (int)cn.size(), out.c_str()) != SKX_OK) rcode = engine_fail();
+    } else if (cmd == "weed") {                                                                                   // cli.rs Weed, lib.rs:760-806
+        if (a.pos.empty() || a.pos.size() > 2) return fail("usage: ska weed <skf_file> [weed_file]");
+        const int filter = parse_filter(a.get("--filter", "no-filter"));
+        if (filter < 0) return fail("invalid --filter");
+        const double mf = atof(a.get("--min-freq", a.get("-m", "0.9")).c_str());
+        if (mf < 0 || mf > 1) return fail("Frequency must be between 0 and 1 (inclusive)");
+        const char *in[1] = {a.pos[0].c_str()};
+        const std::string out = a.get("-o", a.pos[0]);
+        if (skh_load_array(ctx, in, 1, 1, &arr) != SKX_OK ||
+            skh_weed(arr, a.pos.size() == 2 ? a.pos[1].c_str() : nullptr, a.has("--reverse"), mf, a.has("--filter-ambig-as-missing"), filter,
+                     a.has("--ambig-mask"), a.has("--no-gap-only-sites"), out.c_str()) != SKX_OK)
+            rcode = engine_fail();
     } else {
-        rcode = fail("unknown subcommand (this engine provides build, align, distance, nk)");
+        rcode = fail("unknown subcommand (this engine provides build, align, distance, nk, merge, delete, weed)");
     }
     if (arr) skx_array_free(arr);
     skx_ctx_destroy(ctx);

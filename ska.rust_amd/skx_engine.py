@@ -52,7 +52,8 @@ skx_keyset_union skx_keyset_size skx_keyset_device skx_keyset_from_device skx_ke
 skx_array_assemble skx_merge skx_build_and_merge skx_array_free skx_array_save skx_array_load skx_array_from_host
 skx_array_info skx_array_name skx_array_version skx_array_export skx_array_sample_kmers skx_array_filter
 skx_array_write_fasta skx_array_fasta skx_array_device_matrix skx_array_device_stats skx_array_set_total_samples skx_array_distance skx_free skx_ctx_timings
-skh_apply_filters skh_align skh_distance_tsv skh_nk skh_save_skf skh_load_array skh_sample_name skh_main""".split()
+skx_array_merge skx_array_delete_samples skx_array_weed skx_keyset_from_fasta skx_array_ctx skx_set_last_error
+skh_apply_filters skh_align skh_distance_tsv skh_nk skh_save_skf skh_load_array skh_sample_name skh_main skh_merge skh_delete skh_weed""".split()
 
 _lib = None
 
@@ -117,6 +118,16 @@ def load_library():
     lib.skh_nk.argtypes = [vp, i, pp, C.POINTER(u64)]
     lib.skh_save_skf.argtypes = [vp, cp]
     lib.skh_load_array.argtypes = [vp, C.POINTER(cp), i, i, pp]
+    lib.skx_array_merge.argtypes = [vp, pp, i, pp]
+    lib.skx_array_delete_samples.argtypes = [vp, C.POINTER(cp), i]
+    lib.skx_array_weed.argtypes = [vp, vp, i, C.POINTER(u64)]
+    lib.skx_keyset_from_fasta.argtypes = [vp, cp, i, i, pp]
+    lib.skx_array_ctx.argtypes = [vp]
+    lib.skx_array_ctx.restype = vp
+    lib.skx_set_last_error.argtypes = [cp]
+    lib.skh_merge.argtypes = [vp, C.POINTER(cp), i, cp]
+    lib.skh_delete.argtypes = [vp, C.POINTER(cp), i, cp]
+    lib.skh_weed.argtypes = [vp, cp, i, d, i, i, i, i, cp]
     lib.skh_sample_name.argtypes = [cp]
     lib.skh_sample_name.restype = vp
     _lib = lib
@@ -310,6 +321,14 @@ class KeySet:
         return cls(h, ctx)
 
     @classmethod
+    def from_fasta(cls, path, k, rc=True, ctx=None):
+        """RefSka::new + kmer_iter (ska_ref.rs:189-262,541): the split k-mers of a FASTA file (what `ska weed` removes)."""
+        ctx = ctx or default_context()
+        h = C.c_void_p()
+        _check(_lib.skx_keyset_from_fasta(ctx.h, path.encode(), k, int(rc), C.byref(h)))
+        return cls(h, ctx)
+
+    @classmethod
     def merge(cls, sets, ctx=None):
         ctx = ctx or sets[0].ctx
         hs = (C.c_void_p * len(sets))(*[s.h for s in sets])
@@ -355,6 +374,29 @@ class Array:
             p = (C.c_char_p * 1)(path.encode())
             _check(_lib.skh_load_array(ctx.h, p, 1, 1, C.byref(h)))
         return cls(h, ctx)
+
+    # ---- .skf life-cycle: ska merge / delete / weed (generic_modes.rs:90-106,192-267) ----
+    @classmethod
+    def merge(cls, arrays, ctx=None):
+        ctx = ctx or arrays[0].ctx
+        hs = (C.c_void_p * len(arrays))(*[a.h for a in arrays])
+        h = C.c_void_p()
+        _check(_lib.skx_array_merge(ctx.h, hs, len(arrays), C.byref(h)))
+        return cls(h, ctx)
+
+    def delete_samples(self, names):
+        nm = (C.c_char_p * max(len(names), 1))(*[x.encode() for x in names])
+        _check(_lib.skx_array_delete_samples(self.h, nm, len(names)))
+
+    def weed_keys(self, keyset, reverse=False):
+        r = C.c_uint64()
+        _check(_lib.skx_array_weed(self.h, keyset.h, int(reverse), C.byref(r)))
+        return r.value
+
+    def weed(self, weed_fasta=None, reverse=False, min_freq=0.9, filter_ambig_as_missing=False, filter_type=FILTER_NONE,
+             ambig_mask=False, ignore_const_gaps=False):
+        _check(_lib.skh_weed(self.h, weed_fasta.encode() if weed_fasta else None, int(reverse), min_freq, int(filter_ambig_as_missing),
+                             filter_type, int(ambig_mask), int(ignore_const_gaps), None))
 
     @classmethod
     def from_host(cls, k, rc, names, keys, variants, counts=None, version=None, ctx=None):

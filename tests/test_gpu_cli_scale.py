@@ -50,6 +50,61 @@ def test_cli_build_align_distance_nk(tmp_path):
     assert rc != 0
 
 
+def test_cli_merge_delete_weed(tmp_path):
+    """tests/skf_ops.rs through the `ska` executable: merge_delete (:11-83), merge_delete_u128 (:85-161), weed (:163-290)."""
+    import shutil
+    wd = str(tmp_path)
+    for k in ("31", "41"):
+        for t in ("test_1", "test_2"):
+            rc, out, err = ska("build", G.fin(t + ".fa"), "-o", t, "-k", k, cwd=wd)
+            assert rc == 0, err
+        rc, out, err = ska("merge", "test_1.skf", "test_2.skf", "-o", "merge", cwd=wd)
+        assert rc == 0 and os.path.exists(os.path.join(wd, "merge.skf")), err
+        rc, out, err = ska("nk", "merge.skf", cwd=wd)
+        if k == "31":
+            G.matches_path(out, G.correct("merge_nk.stdout"))
+        rc, out, err = ska("delete", "-s", "merge.skf", "test_3", cwd=wd)                       # not there -> panic
+        assert rc != 0 and b"Could not find sample" in err
+        rc, out, err = ska("delete", "-s", "merge.skf", "-f", G.fin("missing_delete.txt"), cwd=wd)
+        assert rc != 0
+        rc, nk1, err = ska("nk", "test_1.skf", cwd=wd)
+        rc, out, err = ska("delete", "-s", "merge.skf", "-o", "merge_delete", "test_2", cwd=wd)
+        assert rc == 0, err
+        rc, out, err = ska("nk", "merge_delete.skf", cwd=wd)
+        assert rc == 0 and out == nk1
+        rc, out, err = ska("delete", "-s", "merge.skf", "test_2", cwd=wd)                       # in place
+        assert rc == 0, err
+        rc, out, err = ska("nk", "merge.skf", cwd=wd)
+        assert out == nk1
+    rc, out, err = ska("merge", "test_1.skf", "-o", "x", cwd=wd)
+    assert rc != 0                                                                             # lib.rs:729-731
+    # weed
+    shutil.copy(G.fin("merge.skf"), os.path.join(wd, "merge.skf"))
+    rc, out, err = ska("weed", "merge.skf", G.fin("weed.fa"), cwd=wd)
+    assert rc == 0, err
+    rc, out, err = ska("align", "merge.skf", cwd=wd)
+    assert out == G.correct("weed_align.stdout")
+    rc, out, err = ska("weed", "merge.skf", "--filter", "no-const", "--min-freq", "1", cwd=wd)
+    assert rc == 0, err
+    rc, out, err = ska("nk", "merge.skf", "--full-info", cwd=wd)
+    G.matches_path(out, G.correct("weed_nk.stdout"))
+    shutil.copy(G.fin("merge_k9.skf"), os.path.join(wd, "merge_k9.skf"))
+    rc, out, err = ska("weed", "merge_k9.skf", "--ambig-mask", cwd=wd)
+    assert rc == 0, err
+    rc, out, err = ska("nk", "merge_k9.skf", cwd=wd)
+    G.matches_path(out, G.correct("weed_nk_k9.stdout"))
+    shutil.copy(G.fin("merge.skf"), os.path.join(wd, "merge.skf"))
+    rc, out, err = ska("weed", "merge.skf", G.fin("weed.fa"), "--reverse", "-o", "kept.skf", cwd=wd)
+    assert rc == 0, err
+    rc, out, err = ska("align", "kept.skf", cwd=wd)
+    assert out == G.correct("weed_align_reverse.stdout")
+    rc, out, err = ska("build", "-o", "build_k41", "-k", "41", G.fin("test_1.fa"), G.fin("test_2.fa"), cwd=wd)
+    rc, out, err = ska("weed", "build_k41.skf", "--filter", "no-ambig-or-const", "--min-freq", "1", cwd=wd)
+    assert rc == 0, err
+    rc, out, err = ska("nk", "build_k41.skf", "--full-info", cwd=wd)
+    G.matches_path(out, G.correct("weed_nk_k41.stdout"))
+
+
 @pytest.fixture(scope="module")
 def big():
     """BASELINE.json configs[1] shape, reduced to 24 samples so that the oracle spot checks stay in seconds."""

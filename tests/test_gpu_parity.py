@@ -317,3 +317,92 @@ def test_unrelated_samples_fine_split(E):
     assert np.array_equal(gk["lo"][go], ok["lo"][oo])
     assert np.array_equal(np.asarray(gv)[go], np.asarray(ov)[oo])
     assert np.array_equal(np.asarray(gc)[go], np.asarray(oc)[oo])
+
+
+def _related_samples(rng, n, length=4000, snps=30):
+    anc = bytearray(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=length).tolist())
+    out = []
+    for _ in range(n):
+        s = bytearray(anc)
+        for p in rng.integers(0, length, size=snps):
+            s[p] = b"ACGT"[rng.integers(0, 4)]
+        out.append([bytes(s[: length // 2]), bytes(s[length // 2:])])
+    return bytes(anc), out
+
+
+@pytest.mark.parametrize("k,rc", [(15, True), (31, True), (31, False), (41, True)])
+def test_skf_lifecycle_merge_delete_weed(E, k, rc, tmp_path):
+    """`ska merge` / `ska delete` / `ska weed` on the device vs the oracle's restatement (generic_modes.rs:90-106,192-267),
+    for arrays in engine order (just built) and in file order (loaded), 64- and 128-bit keys."""
+    rng = np.random.default_rng(500 + k)
+    anc, samples = _related_samples(rng, 5)
+    names = [f"s{i}" for i in range(5)]
+
+    def both(idx):
+        ds = E.DictSet.build([E.record_stream(samples[i]) for i in idx], k, rc)
+        ga = ds.merge([names[i] for i in idx])
+        oa = ora.Array.from_dicts([oracle_dict(samples[i], k, rc) for i in idx], [names[i] for i in idx])
+        return ga, oa
+
+    g1, o1 = both([0, 1, 2])
+    g2, o2 = both([3, 4])
+    for via_file in (False, True):
+        a1, a2 = g1, g2
+        if via_file:
+            p1, p2 = str(tmp_path / "a1.skf"), str(tmp_path / "a2.skf")
+            g1.save(p1), g2.save(p2)
+            a1, a2 = E.Array.load(p1), E.Array.load(p2)
+        gm, om = E.Array.merge([a1, a2]), ora.Array.merge([o1, o2])
+        assert gm.names == om.names == names and gm.nkmers == om.nkmers
+        assert as_map(*gm.export()) == as_map(*om.export())
+        assert list(gm.sample_kmers()) == [int(x) for x in (om.export()[1] != ord("-")).sum(axis=0)]
+        # merging is building everything together
+        gall, oall = both([0, 1, 2, 3, 4])
+        assert as_map(*gm.export()) == as_map(*gall.export())
+        # delete two samples (one from each input); rows only they had disappear
+        gm.delete_samples(["s1", "s3"]), om.delete_samples(["s1", "s3"])
+        assert gm.names == om.names == ["s0", "s2", "s4"]
+        assert as_map(*gm.export()) == as_map(*om.export())
+        # weed: a stretch of the ancestor plus something foreign, both directions, with and without the follow-up filter
+        wf = str(tmp_path / "weed.fa")
+        with open(wf, "wb") as f:
+            f.write(b">w1\n" + anc[500:1500] + b"\n>w2\n" + bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=300).tolist()) + b"\n")
+        for reverse, kw in ((False, {}), (True, dict(min_freq=1.0, filter_type=E.FILTER_NO_CONST)), (False, dict(ambig_mask=True, min_freq=0.0))):
+            gw, ow = E.Array.merge([a1, a2]), ora.Array.merge([o1, o2])
+            okw = {("filter_type" if kk == "filter_type" else kk): (vv if kk != "filter_type" else ora.FILTER_NO_CONST) for kk, vv in kw.items()}
+            gw.weed(wf, reverse=reverse, **kw), ow.weed(wf, reverse=reverse, **okw)
+            assert gw.nkmers == ow.nkmers and 0 < gw.nkmers
+            assert as_map(*gw.export()) == as_map(*ow.export())
+    # weed with a key set taken straight from a FASTA (RefSka::new): count of removed rows
+    ks = E.KeySet.from_fasta(wf, k, rc)
+    gw = E.Array.merge([g1, g2])
+    before = gw.nkmers
+    removed = gw.weed_keys(ks)
+    assert removed == before - gw.nkmers and removed > 0
+
+
+def test_skf_lifecycle_errors(E, tmp_path):
+    rng = np.random.default_rng(3)
+    _, samples = _related_samples(rng, 2, length=600, snps=5)
+    a = E.DictSet.build([E.record_stream(samples[0])], 31, True).merge(["a"])
+    b17 = E.DictSet.build([E.record_stream(samples[1])], 17, True).merge(["b"])
+    bss = E.DictSet.build([E.record_stream(samples[1])], 31, False).merge(["b"])
+    b = E.DictSet.build([E.record_stream(samples[1])], 31, True).merge(["b"])
+    with pytest.raises(E.EngineError, match="K-mer lengths do not match"):
+        E.Array.merge([a, b17])
+    with pytest.raises(E.EngineError, match="Strand use inconsistent"):
+        E.Array.merge([a, bss])
+    m = E.Array.merge([a, b])
+    with pytest.raises(E.EngineError, match="Invalid number of samples to remove"):
+        m.delete_samples([])
+    with pytest.raises(E.EngineError, match="Invalid number of samples to remove"):
+        m.delete_samples(["a", "b"])
+    with pytest.raises(E.EngineError, match="Could not find sample"):
+        m.delete_samples(["zzz"])
+    with pytest.raises(E.EngineError, match="Cannot create reference from FASTQ"):
+        m.weed(G.fin("test_1_fwd.fastq.gz"))
+    # filtered for output only (update_kmers = false): keys and rows are out of step, set operations refuse
+    m.apply_filters(0.0, filter_type=E.FILTER_NO_CONST)
+    if m.nkmers != m.nrows:
+        with pytest.raises(E.EngineError, match="out of step"):
+            m.delete_samples(["a"])
