@@ -79,17 +79,16 @@ __device__ static inline uint32_t qualbad16(const uint32_t w[4], int min_qual)
 // forward declaration (defined with the block-wide helpers below)
 __device__ static inline uint32_t block_excl_scan(uint32_t v, uint32_t *s_tmp, uint32_t *total);
 
-// LDS carve (dynamic, 16-B aligned): [B+4] hist -> local starts (+ a dummy counter for invalid windows) | [B] global
-// chunk bases | codes+masks, later aliased by the staging buffer.  16 window-end positions per thread.  The tile's
-// words are staged bucket-by-bucket in ROUNDS passes so that the copy-out writes every (tile, bucket) chunk with
-// adjacent lanes (few, wide L2 write requests) while the staging buffer stays small enough for 2-3 workgroups per CU.
-template <bool SCATTER, int TILE, int ROUNDS, int PPT>
+// LDS carve (dynamic, 16-B aligned): [B+4] hist -> local starts (+ a dummy counter for invalid windows) | [B] chunk
+// bases | codes+masks, later aliased by the staging buffer.  16 window-end positions per thread.  The tile's words are
+// staged in bucket order (one pass: TILE words = 128 KB) so that the copy-out writes every (tile, bucket) chunk with
+// adjacent lanes (few, wide L2 write requests).  HI: the bucket bits of a packed word lie in its upper half.
+template <bool SCATTER, int TILE, bool HI, int PPT>
 __global__ __launch_bounds__(TILE / PPT) void extract_kernel(ExtractArgs a)
 {
     constexpr int NT = TILE / PPT;
     constexpr int NCH = PPT / 16;                                      // 16-base chunks per thread
     constexpr int NCHUNK = TILE / 16 + 5;                              // 4 halo chunks before, 1 after
-    constexpr uint32_t STAGE_CAP = (uint32_t)(TILE / ROUNDS + TILE / (4 * ROUNDS));
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int B = 1 << a.logB;
     uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_raw);            // [B] + dummy at [B]
@@ -223,7 +222,7 @@ __global__ __launch_bounds__(TILE / PPT) void extract_kernel(ExtractArgs a)
         return;
     }
     // reserve one chunk per non-empty bucket in the sample's region (global cursor); the returned bases are not needed
-    // until the copy-out, so the atomics stay in flight behind the block scan and the first staging pass
+    // until the copy-out, so the atomics stay in flight behind the block scan and the staging pass
     constexpr int RMAX = (8192 + NT - 1) / NT;              // buckets per thread at most (B <= 8192)
     const int R = (B + NT - 1) / NT;
     const int b0 = tid * R < B ? tid * R : B, b1 = b0 + R < B ? b0 + R : B;
@@ -235,87 +234,69 @@ __global__ __launch_bounds__(TILE / PPT) void extract_kernel(ExtractArgs a)
     }
     uint32_t total;
     uint32_t lrun = block_excl_scan(lsum, s_tmp, &total);
-    // s_hist: counts -> local starts; s_base (written later): chunk base - local start, so that a staged word at local
-    // index i lands at region offset s_base[b] + i
-    uint32_t lst[RMAX];
+    // s_hist: counts -> local starts (position of the bucket's first word in the staging buffer)
 #pragma unroll
-    for (int r = 0; r < RMAX; r++) {
-        lst[r] = lrun;
+    for (int r = 0; r < RMAX; r++)
         if (b0 + r < b1) { const uint32_t n = s_hist[b0 + r]; s_hist[b0 + r] = lrun; lrun += n; }
-    }
     if (tid == 0) s_hist[B] = total;                        // sentinel: start of the (non-existent) bucket B
     __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PPT; j++) {
+        const uint32_t b = rk[j] >> 16;
+        if (b < (uint32_t)B) s_stage[s_hist[b] + (rk[j] & 0xFFFFu)] = wv[j];
+    }
+    // first use of the cursor atomics' results.  A staged word at index i goes to word s_base[bucket] + i of the sample's
+    // span of the word buffer: s_base = region offset inside the span + chunk base - local start (all 32-bit; the span
+    // starts at a wave-uniform 64-bit base, so the store is base + 32-bit offset)
     const uint64_t *off = a.off + ((uint64_t)sample << a.logB);
     const bool fixed = a.capacity != 0xFFFFFFFFu;           // fixed-capacity regions: offsets are arithmetic
-    const uint64_t reg0 = ((uint64_t)sample << a.logB) * a.capacity;
+    const uint64_t span0 = fixed ? ((uint64_t)sample << a.logB) * a.capacity : off[0];
+    const uint32_t span_last = fixed ? (uint32_t)(((uint64_t)a.capacity << a.logB) - 1) : (uint32_t)(off[B] - off[0] - 1);
     bool dropped = false;
-    bool bases_written = false;
-    uint32_t unstaged_mask = 0;                             // rounds whose words did not fit the staging buffer (skewed tile)
-#pragma unroll 1
-    for (int q = 0; q < ROUNDS; q++) {
-        const uint32_t qb0 = (uint32_t)(((uint64_t)B * q) / ROUNDS), qb1 = (uint32_t)(((uint64_t)B * (q + 1)) / ROUNDS);
-        const uint32_t e0 = s_hist[qb0], e1 = s_hist[qb1];
-        if (e1 - e0 > STAGE_CAP) { unstaged_mask |= 1u << q; continue; }     // uniform
 #pragma unroll
-        for (int j = 0; j < PPT; j++) {
-            const uint32_t b = rk[j] >> 16;
-            if (b >= qb0 && b < qb1) s_stage[s_hist[b] - e0 + (rk[j] & 0xFFFFu)] = wv[j];
+    for (int r = 0; r < RMAX; r++)
+        if (b0 + r < b1) {
+            const uint32_t b = (uint32_t)(b0 + r), start = s_hist[b], n = s_hist[b + 1] - start;
+            if (n && gb[r] + n > a.capacity) dropped = true;                  // the region is full: the host falls back to exact offsets
+            s_base[b] = (fixed ? b * a.capacity : (uint32_t)(off[b] - off[0])) + gb[r] - start;
         }
-        if (!bases_written) {                                   // first use of the cursor atomics' results
-#pragma unroll
-            for (int r = 0; r < RMAX; r++) if (b0 + r < b1) s_base[b0 + r] = gb[r] - lst[r];
-            bases_written = true;
-        }
-        __syncthreads();
-        for (uint32_t i = tid; i < e1 - e0; i += NT) {
-            const uint64_t w = s_stage[i];
-            const uint32_t b = (uint32_t)((w >> 4) >> bshift);
-            const uint32_t r = s_base[b] + e0 + i;
-            if (r < a.capacity) a.words[(fixed ? reg0 + (uint64_t)b * a.capacity : off[b]) + r] = w; else dropped = true;
-        }
-        __syncthreads();
-    }
-    if (unstaged_mask) {                                    // rare: direct 8-B stores, one element at a time
-        if (!bases_written) {
-#pragma unroll
-            for (int r = 0; r < RMAX; r++) if (b0 + r < b1) s_base[b0 + r] = gb[r] - lst[r];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < PPT; j++) {
-            const uint32_t b = rk[j] >> 16;
-            if (b < (uint32_t)B && ((unstaged_mask >> ((uint64_t)b * ROUNDS / B)) & 1u)) {
-                const uint32_t r = s_base[b] + s_hist[b] + (rk[j] & 0xFFFFu);
-                if (r < a.capacity) a.words[off[b] + r] = wv[j]; else dropped = true;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+    __syncthreads();
+    typedef uint64_t __attribute__((address_space(1))) *gout_t;
+    gout_t out = (gout_t)(uintptr_t)(a.words + span0);
+    const int bsh_hi = a.hp.bits + 4 - 32 - a.logB;          // HI: bucket = upper half >> bsh_hi
+    for (uint32_t i = tid; i < total; i += NT) {
+        const uint64_t w = s_stage[i];
+        const uint32_t b = HI ? (uint32_t)(w >> 32) >> bsh_hi : (uint32_t)((w >> 4) >> bshift);
+        uint32_t r = s_base[b] + i;
+        r = r < span_last ? r : span_last;                                    // an overflowing chunk must not leave the sample's span
+        out[r] = w;
     }
     if (dropped) *a.overflow = 1;
 }
 
-template <int TILE, int ROUNDS>
+template <int TILE>
 static inline size_t extract_lds(const ExtractArgs &a, bool scatter)
 {
     size_t codes = (size_t)(TILE / 16 + 8) * 10 + 64;
-    size_t stage = scatter ? (size_t)(TILE / ROUNDS + TILE / (4 * ROUNDS)) * 8 : 0;
+    size_t stage = scatter ? (size_t)TILE * 8 : 0;
     return ((size_t)8 << a.logB) + 16 + 80 + (stage > codes ? stage : codes);
 }
-template <bool SCATTER, int TILE, int ROUNDS, int PPT>
+template <bool SCATTER, int TILE, bool HI, int PPT>
 static void launch_extract_t(const ExtractArgs &a, hipStream_t st)
 {
     const uint64_t g = (((uint64_t)a.n_samples + 7) / 8) * 8ull * (uint64_t)a.tiles_max;
     if (!g) return;
-    const size_t lds = extract_lds<TILE, ROUNDS>(a, SCATTER);
-    (void)hipFuncSetAttribute((const void *)extract_kernel<SCATTER, TILE, ROUNDS, PPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((extract_kernel<SCATTER, TILE, ROUNDS, PPT>), dim3((unsigned)g), dim3(TILE / PPT), lds, st, a);
+    const size_t lds = extract_lds<TILE>(a, SCATTER);
+    (void)hipFuncSetAttribute((const void *)extract_kernel<SCATTER, TILE, HI, PPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((extract_kernel<SCATTER, TILE, HI, PPT>), dim3((unsigned)g), dim3(TILE / PPT), lds, st, a);
 }
 template <bool SCATTER>
 static void launch_extract(const ExtractArgs &a, hipStream_t st)
 {
     // 16 384 positions x 1 024 threads while the two [B] LDS arrays leave room for the staging buffer, else half of that
-    if (extract_tile_bases(a.logB) == 16384) launch_extract_t<SCATTER, 16384, 2, 16>(a, st);
-    else launch_extract_t<SCATTER, 8192, 2, 16>(a, st);
+    const bool hi = a.hp.bits + 4 - 32 - a.logB >= 0;
+    if (extract_tile_bases(a.logB) == 16384) { if (hi) launch_extract_t<SCATTER, 16384, true, 16>(a, st); else launch_extract_t<SCATTER, 16384, false, 16>(a, st); }
+    else { if (hi) launch_extract_t<SCATTER, 8192, true, 16>(a, st); else launch_extract_t<SCATTER, 8192, false, 16>(a, st); }
 }
 int extract_tile_bases(int logB) { return logB <= 11 ? 16384 : 8192; }
 void launch_hist(const ExtractArgs &a, hipStream_t st) { launch_extract<false>(a, st); }
