@@ -568,15 +568,24 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
     // position-ordered from here on (p = tid + NT t): neighbouring lanes touch neighbouring LDS words, so the random-bank
     // conflicts of the scatter above do not come back.  Rank of a word inside its micro-bucket = #smaller keys + #equal
     // keys at lower positions; equal keys also fold their base masks together.
-    uint32_t npos[ITEMS];
+    // The three dependent LDS reads per word (the word, its micro-bucket's bounds, the bucket's first slots) are issued
+    // for all of the thread's words at once, stage by stage, so a thread waits for three round trips instead of 3 x ITEMS.
+    uint32_t npos[ITEMS], bb[ITEMS], ee[ITEMS];
+#pragma unroll
+    for (int t = 0; t < ITEMS; t++) { const uint32_t p = threadIdx.x + (uint32_t)NT * t; e[t] = s_elem[p < n ? p : n - 1]; }
+#pragma unroll
+    for (int t = 0; t < ITEMS; t++) asm volatile("" : "+v"(e[t]));
+#pragma unroll
+    for (int t = 0; t < ITEMS; t++) { const uint32_t m = word_field<HI>(e[t], mshift, M - 1); bb[t] = s_start[m]; ee[t] = s_start[m + 1]; }
+#pragma unroll
+    for (int t = 0; t < ITEMS; t++) asm volatile("" : "+v"(bb[t]), "+v"(ee[t]));
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) {
         const uint32_t p = threadIdx.x + (uint32_t)NT * t;
-        npos[t] = 0; e[t] = 0;
-        if (p >= n) continue;
-        const uint64_t w0 = s_elem[p], w0lo = w0 & ~15ull;
-        const uint32_t m = word_field<HI>(w0, mshift, M - 1);
-        const uint32_t b = s_start[m], eend = s_start[m + 1];
+        npos[t] = 0;
+        if (p >= n) { e[t] = 0; continue; }
+        const uint64_t w0 = e[t], w0lo = w0 & ~15ull;
+        const uint32_t b = bb[t], eend = ee[t];
         // key_j < key  <=>  w_j < (w0 & ~15);  key_j == key  <=>  (w_j ^ w0) < 16: no 64-bit shifts (quarter rate) in the loop.
         // Fast path: count the smaller keys and notice whether the key occurs again; only then (rare) order the equal
         // keys by position and fold their base masks.
@@ -589,8 +598,13 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
         };
         // micro-buckets hold ~2.4 words: the first four slots are straight-line code (reads past the bucket stay inside
         // the LDS carve and are masked), longer buckets finish in a loop
+        uint64_t wq[4];
 #pragma unroll
-        for (uint32_t u = 0; u < 4; u++) step(b + u, s_elem[b + u], b + u < eend);
+        for (uint32_t u = 0; u < 4; u++) wq[u] = s_elem[b + u];              // four reads in flight, whatever the bucket's size
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) asm volatile("" : "+v"(wq[u]));      // (keeps the compiler from sinking each read into its own branch)
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) step(b + u, wq[u], b + u < eend);
         for (uint32_t j = b + 4; j < eend; j++) step(j, s_elem[j], true);
         if (dup)
             for (uint32_t j = b; j < eend; j++) {
