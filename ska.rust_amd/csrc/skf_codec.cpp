@@ -4,21 +4,66 @@
 //   map(8){ k, rc, names[], split_kmers[] (u128 > 2^64-1 as tag-2 bignum), variants{v:1, dim:[U,S], data[]},
 //           variant_count[], ska_version, k_bits }
 // Chunks are written snappy-compressed (type 0x00) with masked CRC-32C so files are loadable by the real `ska`.
+//
+// the reference encodes and decodes the whole array serially in memory (2 B of CBOR per matrix cell).
+// Here both directions stream: the CBOR text exists only as 32 MB super-blocks, whose 64 KB snappy chunks are
+// (de)compressed and checksummed by a team of host threads, and the U x S matrix is pulled from / pushed to the caller in
+// row blocks (the device gathers / transposes them), so neither the 2UxS-byte CBOR nor a host copy of the matrix is ever
+// materialised.
 #include "skx_internal.h"
+#include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 
 namespace skx {
 namespace {
 
-// ---------------------------------------------------------------- CRC-32C (Castagnoli), slice-by-1
+// ---------------------------------------------------------------- CRC-32C (Castagnoli), slice-by-8
 struct Crc32c {
-    uint32_t t[256];
-    Crc32c() { for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1) ? 0x82F63B78u : 0); t[i] = c; } }
-    uint32_t operator()(const uint8_t *p, size_t n) const { uint32_t c = ~0u; while (n--) c = t[(c ^ *p++) & 0xFF] ^ (c >> 8); return ~c; }
+    uint32_t t[8][256];
+    Crc32c()
+    {
+        for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1) ? 0x82F63B78u : 0); t[0][i] = c; }
+        for (uint32_t i = 0; i < 256; i++) for (int s = 1; s < 8; s++) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xFF];
+    }
+    uint32_t operator()(const uint8_t *p, size_t n) const
+    {
+        uint32_t c = ~0u;
+        while (n >= 8) {
+            uint64_t v; memcpy(&v, p, 8);
+            v ^= c;
+            c = t[7][v & 0xFF] ^ t[6][(v >> 8) & 0xFF] ^ t[5][(v >> 16) & 0xFF] ^ t[4][(v >> 24) & 0xFF] ^
+                t[3][(v >> 32) & 0xFF] ^ t[2][(v >> 40) & 0xFF] ^ t[1][(v >> 48) & 0xFF] ^ t[0][v >> 56];
+            p += 8; n -= 8;
+        }
+        while (n--) c = t[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+        return ~c;
+    }
 };
 const Crc32c crc32c;
 inline uint32_t mask_crc(uint32_t c) { return ((c >> 15) | (c << 17)) + 0xa282ead8u; }
+
+constexpr size_t CHUNK = 65536;                 // uncompressed bytes per snappy-frame chunk (the format's maximum)
+constexpr size_t SUPER = 512 * CHUNK;           // bytes of CBOR in flight per direction
+
+int n_workers(int threads)
+{
+    if (threads <= 0) { threads = (int)std::thread::hardware_concurrency(); if (threads <= 0) threads = 4; }
+    return std::min(threads, 64);
+}
+template <typename F>
+void parallel_for(size_t n, int threads, F &&f)      // f(i) for i in [0, n), dynamic distribution
+{
+    if (n == 0) return;
+    const int nt = (int)std::min<size_t>((size_t)threads, n);
+    if (nt <= 1) { for (size_t i = 0; i < n; i++) f(i); return; }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; t++) pool.emplace_back([&]() { for (size_t i; (i = next.fetch_add(1)) < n;) f(i); });
+    for (auto &th : pool) th.join();
+}
 
 // ---------------------------------------------------------------- snappy block (format_description.txt)
 void put_varint(std::vector<uint8_t> &o, uint32_t v) { while (v >= 0x80) { o.push_back((uint8_t)(v | 0x80)); v >>= 7; } o.push_back((uint8_t)v); }
@@ -45,6 +90,7 @@ void snappy_compress_block(const uint8_t *in, size_t n, std::vector<uint8_t> &o)
     static thread_local uint16_t table[1 << 14];
     memset(table, 0, sizeof table);
     auto load32 = [&](size_t i) { uint32_t v; memcpy(&v, in + i, 4); return v; };
+    auto load64 = [&](size_t i) { uint64_t v; memcpy(&v, in + i, 8); return v; };
     auto hash = [&](uint32_t v) { return (v * 0x1e35a7bdu) >> 18; };
     size_t lit = 0, i = 1;
     const size_t limit = n - 4;
@@ -54,7 +100,13 @@ void snappy_compress_block(const uint8_t *in, size_t n, std::vector<uint8_t> &o)
         table[h] = (uint16_t)i;
         if (cand < i && load32(cand) == cur) {
             size_t len = 4;
+            while (i + len + 8 <= n) {                                  // extend 8 bytes at a time
+                const uint64_t x = load64(cand + len) ^ load64(i + len);
+                if (x) { len += (size_t)__builtin_ctzll(x) >> 3; goto done; }
+                len += 8;
+            }
             while (i + len < n && in[cand + len] == in[i + len]) len++;
+        done:
             put_literal(o, in + lit, i - lit);
             put_copy(o, i - cand, len);
             i += len; lit = i;
@@ -62,12 +114,20 @@ void snappy_compress_block(const uint8_t *in, size_t n, std::vector<uint8_t> &o)
     }
     put_literal(o, in + lit, n - lit);
 }
-bool snappy_uncompress_block(const uint8_t *in, size_t n, std::vector<uint8_t> &out)
+// uncompressed length announced by a compressed block (0xFFFFFFFF: malformed)
+uint32_t snappy_ulen(const uint8_t *in, size_t n, size_t *hdr)
 {
     size_t i = 0; uint32_t ulen = 0; int sh = 0;
-    for (;;) { if (i >= n || sh > 28) return false; uint8_t b = in[i++]; ulen |= (uint32_t)(b & 0x7F) << sh; sh += 7; if (!(b & 0x80)) break; }
-    const size_t base = out.size();
-    out.reserve(base + ulen);
+    for (;;) { if (i >= n || sh > 28) return 0xFFFFFFFFu; uint8_t b = in[i++]; ulen |= (uint32_t)(b & 0x7F) << sh; sh += 7; if (!(b & 0x80)) break; }
+    if (hdr) *hdr = i;
+    return ulen;
+}
+// decompress into out[0 .. ulen) (caller sized it from snappy_ulen)
+bool snappy_uncompress_block(const uint8_t *in, size_t n, uint8_t *out, size_t ulen)
+{
+    size_t i = 0;
+    if (snappy_ulen(in, n, &i) != ulen) return false;
+    size_t o = 0;
     while (i < n) {
         const uint8_t tag = in[i++];
         size_t len, off;
@@ -75,18 +135,149 @@ bool snappy_uncompress_block(const uint8_t *in, size_t n, std::vector<uint8_t> &
             len = tag >> 2;
             if (len >= 60) { size_t nb = len - 59; if (i + nb > n) return false; len = 0; for (size_t k = 0; k < nb; k++) len |= (size_t)in[i + k] << (8 * k); i += nb; }
             len++;
-            if (i + len > n) return false;
-            out.insert(out.end(), in + i, in + i + len); i += len;
+            if (i + len > n || o + len > ulen) return false;
+            memcpy(out + o, in + i, len); i += len; o += len;
             continue;
         }
         if ((tag & 3) == 1) { if (i >= n) return false; len = ((tag >> 2) & 7) + 4; off = ((size_t)(tag >> 5) << 8) | in[i++]; }
         else if ((tag & 3) == 2) { if (i + 2 > n) return false; len = (tag >> 2) + 1; off = in[i] | ((size_t)in[i + 1] << 8); i += 2; }
         else { if (i + 4 > n) return false; len = (tag >> 2) + 1; off = in[i] | ((size_t)in[i + 1] << 8) | ((size_t)in[i + 2] << 16) | ((size_t)in[i + 3] << 24); i += 4; }
-        if (!off || off > out.size() - base) return false;
-        for (size_t k = 0; k < len; k++) out.push_back(out[out.size() - off]);
+        if (!off || off > o || o + len > ulen) return false;
+        if (off >= len) memcpy(out + o, out + o - off, len);
+        else for (size_t k = 0; k < len; k++) out[o + k] = out[o + k - off];     // overlapping run
+        o += len;
     }
-    return out.size() - base == ulen;
+    return o == ulen;
 }
+
+// ---------------------------------------------------------------- snappy frame, streaming
+// Writer side: CBOR bytes are appended; every full super-block is cut into 64 KB chunks that the team compresses.
+struct FrameWriter {
+    FILE *f = nullptr; int threads = 1; bool ok = true;
+    std::vector<uint8_t> cur;
+    std::vector<std::vector<uint8_t>> comp;
+    bool open(const char *path, int nthreads)
+    {
+        threads = nthreads; f = fopen(path, "wb");
+        if (!f) return false;
+        cur.reserve(SUPER + CHUNK);
+        ok = fwrite("\xff\x06\x00\x00sNaPpY", 1, 10, f) == 10;
+        return ok;
+    }
+    void emit(size_t nbytes)                        // compress + write cur[0 .. nbytes), keep the rest
+    {
+        const size_t nch = (nbytes + CHUNK - 1) / CHUNK;
+        if (comp.size() < nch) comp.resize(nch);
+        std::vector<uint32_t> crc(nch);
+        parallel_for(nch, threads, [&](size_t c) {
+            const size_t off = c * CHUNK, n = std::min(CHUNK, nbytes - off);
+            comp[c].clear();
+            snappy_compress_block(cur.data() + off, n, comp[c]);
+            crc[c] = mask_crc(crc32c(cur.data() + off, n));
+        });
+        for (size_t c = 0; c < nch && ok; c++) {
+            const size_t off = c * CHUNK, n = std::min(CHUNK, nbytes - off);
+            const bool raw = comp[c].size() >= n - n / 8;           // snap's rule of thumb: store incompressible chunks raw
+            const uint8_t *payload = raw ? cur.data() + off : comp[c].data();
+            const size_t plen = raw ? n : comp[c].size(), clen = plen + 4;
+            uint8_t hdr[8] = {(uint8_t)(raw ? 1 : 0), (uint8_t)clen, (uint8_t)(clen >> 8), (uint8_t)(clen >> 16),
+                              (uint8_t)crc[c], (uint8_t)(crc[c] >> 8), (uint8_t)(crc[c] >> 16), (uint8_t)(crc[c] >> 24)};
+            ok = fwrite(hdr, 1, 8, f) == 8 && fwrite(payload, 1, plen, f) == plen;
+        }
+        cur.erase(cur.begin(), cur.begin() + (ptrdiff_t)nbytes);
+    }
+    void append(const uint8_t *p, size_t n)
+    {
+        while (n) {
+            if (cur.size() >= SUPER) emit(cur.size() / CHUNK * CHUNK);
+            const size_t take = std::min(n, SUPER - cur.size());
+            cur.insert(cur.end(), p, p + take); p += take; n -= take;
+        }
+    }
+    uint8_t *grow(size_t n)                          // room for n more bytes at the end of the pending buffer (n <= SUPER)
+    {
+        if (cur.size() + n > SUPER) emit(cur.size() / CHUNK * CHUNK);
+        const size_t at = cur.size();
+        cur.resize(at + n);
+        return cur.data() + at;
+    }
+    bool close()
+    {
+        if (f) { if (ok && !cur.empty()) emit(cur.size()); ok = (fclose(f) == 0) && ok; f = nullptr; }
+        return ok;
+    }
+    ~FrameWriter() { if (f) fclose(f); }
+};
+
+// Reader side: the compressed file is read whole (it is small next to the CBOR it expands to), its chunk directory is
+// scanned once, and super-blocks of chunks are decompressed + checked by the team on demand.
+struct FrameReader {
+    std::vector<uint8_t> raw;
+    struct Chunk { size_t off, len; uint32_t ulen, crc; bool compressed; };
+    std::vector<Chunk> chunks;
+    size_t next_chunk = 0; int threads = 1;
+    std::vector<uint8_t> buf; size_t pos = 0;       // decoded bytes not yet consumed: buf[pos ..)
+    const char *err = nullptr;
+
+    bool open(const char *path, int nthreads)
+    {
+        threads = nthreads;
+        FILE *f = fopen(path, "rb");
+        if (!f) { err = "open"; return false; }
+        fseek(f, 0, SEEK_END); const long sz = ftell(f); fseek(f, 0, SEEK_SET);
+        if (sz < 0) { fclose(f); err = "open"; return false; }
+        raw.resize((size_t)sz);
+        const bool rd = sz == 0 || fread(raw.data(), 1, (size_t)sz, f) == (size_t)sz;
+        fclose(f);
+        if (!rd) { err = "open"; return false; }
+        size_t i = 0; bool seen = false;
+        while (i < raw.size()) {
+            if (i + 4 > raw.size()) { err = "skf: truncated frame"; return false; }
+            const uint8_t type = raw[i]; const size_t len = raw[i + 1] | ((size_t)raw[i + 2] << 8) | ((size_t)raw[i + 3] << 16);
+            i += 4;
+            if (i + len > raw.size()) { err = "skf: truncated frame"; return false; }
+            if (type == 0xff) { if (len != 6 || memcmp(&raw[i], "sNaPpY", 6)) { err = "skf: not a snappy stream"; return false; } seen = true; }
+            else if (type <= 0x01) {
+                if (!seen || len < 4) { err = "skf: bad chunk"; return false; }
+                Chunk c; c.off = i + 4; c.len = len - 4; c.compressed = type == 0x00; memcpy(&c.crc, &raw[i], 4);
+                c.ulen = c.compressed ? snappy_ulen(&raw[c.off], c.len, nullptr) : (uint32_t)c.len;
+                if (c.ulen == 0xFFFFFFFFu || c.ulen > CHUNK) { err = "skf: corrupt snappy block"; return false; }
+                chunks.push_back(c);
+            } else if (type < 0x80) { err = "skf: unsupported chunk type"; return false; }
+            i += len;
+        }
+        if (!seen) { err = "skf: not a snappy stream"; return false; }
+        return true;
+    }
+    size_t avail() const { return buf.size() - pos; }
+    const uint8_t *data() const { return buf.data() + pos; }
+    void consume(size_t n) { pos += n; }
+    // make at least `need` bytes available (fewer only at end of stream); decodes up to one super-block more
+    bool fill(size_t need)
+    {
+        while (avail() < need && next_chunk < chunks.size()) {
+            if (pos) { buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)pos); pos = 0; }
+            size_t last = next_chunk, add = 0;
+            while (last < chunks.size() && add < SUPER) add += chunks[last++].ulen;
+            const size_t base = buf.size();
+            buf.resize(base + add);
+            std::vector<size_t> at(last - next_chunk);
+            size_t o = base;
+            for (size_t c = next_chunk; c < last; c++) { at[c - next_chunk] = o; o += chunks[c].ulen; }
+            std::atomic<int> bad{0};
+            parallel_for(last - next_chunk, threads, [&](size_t j) {
+                const Chunk &c = chunks[next_chunk + j];
+                uint8_t *dst = buf.data() + at[j];
+                if (c.compressed) { if (!snappy_uncompress_block(&raw[c.off], c.len, dst, c.ulen)) { bad = 1; return; } }
+                else memcpy(dst, &raw[c.off], c.len);
+                if (mask_crc(crc32c(dst, c.ulen)) != c.crc) bad = 2;
+            });
+            if (bad) { err = bad == 1 ? "skf: corrupt snappy block" : "skf: checksum mismatch"; return false; }
+            next_chunk = last;
+        }
+        return true;
+    }
+};
 
 // ---------------------------------------------------------------- CBOR (RFC 8949, definite lengths only)
 struct Writer {
@@ -101,29 +292,49 @@ struct Writer {
         else { b.push_back(m | 27); for (int s = 56; s >= 0; s -= 8) b.push_back((uint8_t)(v >> s)); }
     }
     void text(const std::string &s) { head(3, s.size()); b.insert(b.end(), s.begin(), s.end()); }
+    void key(const skx_key &kk)
+    {
+        if (!kk.hi) { head(0, kk.lo); return; }
+        uint8_t be[16]; int nb = 0;
+        for (int s = 56; s >= 0; s -= 8) { uint8_t x = (uint8_t)(kk.hi >> s); if (nb || x) be[nb++] = x; }
+        for (int s = 56; s >= 0; s -= 8) be[nb++] = (uint8_t)(kk.lo >> s);
+        head(6, 2); head(2, (uint64_t)nb); b.insert(b.end(), be, be + nb);
+    }
 };
+// pull parser over the frame reader
 struct Reader {
-    const uint8_t *p; size_t n, i = 0; bool ok = true;
+    FrameReader &fr; bool ok = true;
+    explicit Reader(FrameReader &r) : fr(r) {}
+    bool need(size_t n) { if (fr.avail() < n && !fr.fill(n)) return ok = false; if (fr.avail() < n) return ok = false; return true; }
     bool head(int &major, uint64_t &v)
     {
-        if (i >= n) return ok = false;
-        uint8_t c = p[i++]; major = c >> 5; uint8_t ai = c & 31;
-        if (ai < 24) { v = ai; return true; }
-        int nb = ai == 24 ? 1 : ai == 25 ? 2 : ai == 26 ? 4 : ai == 27 ? 8 : 0;
-        if (!nb || i + nb > n) return ok = false;
-        v = 0; for (int k = 0; k < nb; k++) v = (v << 8) | p[i++];
+        if (!need(1)) return false;
+        const uint8_t c = fr.data()[0]; major = c >> 5; const uint8_t ai = c & 31;
+        if (ai < 24) { v = ai; fr.consume(1); return true; }
+        const int nb = ai == 24 ? 1 : ai == 25 ? 2 : ai == 26 ? 4 : ai == 27 ? 8 : 0;
+        if (!nb || !need(1 + (size_t)nb)) return ok = false;
+        v = 0; for (int k = 0; k < nb; k++) v = (v << 8) | fr.data()[1 + k];
+        fr.consume(1 + (size_t)nb);
         return true;
     }
     uint64_t uint() { int m; uint64_t v = 0; if (!head(m, v) || m != 0) ok = false; return v; }
     uint64_t array() { int m; uint64_t v = 0; if (!head(m, v) || m != 4) ok = false; return v; }
-    std::string text() { int m; uint64_t v = 0; if (!head(m, v) || m != 3 || i + v > n) { ok = false; return {}; } std::string s((const char *)p + i, v); i += v; return s; }
+    std::string text()
+    {
+        int m; uint64_t v = 0;
+        if (!head(m, v) || m != 3 || v > (1u << 20) || !need(v)) { ok = false; return {}; }
+        std::string s((const char *)fr.data(), v); fr.consume(v);
+        return s;
+    }
+    bool boolean() { if (!need(1)) return false; const uint8_t c = fr.data()[0]; if (c != 0xf4 && c != 0xf5) { ok = false; return false; } fr.consume(1); return c == 0xf5; }
     skx_key key()
     {
         skx_key k{0, 0}; int m; uint64_t v;
         if (!head(m, v)) return k;
         if (m == 0) { k.lo = v; return k; }
-        if (m == 6 && v == 2 && head(m, v) && m == 2 && v <= 16 && i + v <= n) {
-            unsigned __int128 x = 0; for (uint64_t t = 0; t < v; t++) x = (x << 8) | p[i++];
+        if (m == 6 && v == 2 && head(m, v) && m == 2 && v <= 16 && need(v)) {
+            unsigned __int128 x = 0; for (uint64_t t = 0; t < v; t++) x = (x << 8) | fr.data()[t];
+            fr.consume(v);
             k.lo = (uint64_t)x; k.hi = (uint64_t)(x >> 64); return k;
         }
         ok = false; return k;
@@ -132,112 +343,160 @@ struct Reader {
 
 }  // namespace
 
-int skf_read(const char *path, SkfData &d)
+int skf_read_stream(const char *path, SkfMeta &m, std::vector<skx_key> &keys, std::vector<uint64_t> &counts,
+                    const std::function<int(uint64_t, uint64_t)> &begin_rows, const RowSink &sink, int threads)
 {
-    FILE *f = fopen(path, "rb");
-    if (!f) { set_error("cannot open %s", path); return SKX_EIO; }
-    std::vector<uint8_t> raw;
-    uint8_t tmp[1 << 16]; size_t r;
-    while ((r = fread(tmp, 1, sizeof tmp, f)) > 0) raw.insert(raw.end(), tmp, tmp + r);
-    fclose(f);
-    // --- snappy frame
-    std::vector<uint8_t> cbor;
-    size_t i = 0; bool seen = false;
-    while (i < raw.size()) {
-        if (i + 4 > raw.size()) { set_error("skf: truncated frame"); return SKX_EFORMAT; }
-        const uint8_t type = raw[i]; const size_t len = raw[i + 1] | ((size_t)raw[i + 2] << 8) | ((size_t)raw[i + 3] << 16);
-        i += 4;
-        if (i + len > raw.size()) { set_error("skf: truncated frame"); return SKX_EFORMAT; }
-        if (type == 0xff) { if (len != 6 || memcmp(&raw[i], "sNaPpY", 6)) { set_error("skf: not a snappy stream"); return SKX_EFORMAT; } seen = true; }
-        else if (type <= 0x01) {
-            if (!seen || len < 4) { set_error("skf: bad chunk"); return SKX_EFORMAT; }
-            uint32_t want; memcpy(&want, &raw[i], 4);
-            const size_t before = cbor.size();
-            if (type == 0x00) { if (!snappy_uncompress_block(&raw[i + 4], len - 4, cbor)) { set_error("skf: corrupt snappy block"); return SKX_EFORMAT; } }
-            else cbor.insert(cbor.end(), raw.begin() + i + 4, raw.begin() + i + len);
-            if (mask_crc(crc32c(cbor.data() + before, cbor.size() - before)) != want) { set_error("skf: checksum mismatch"); return SKX_EFORMAT; }
-        } else if (type < 0x80) { set_error("skf: unsupported chunk type %u", type); return SKX_EFORMAT; }
-        i += len;
+    threads = n_workers(threads);
+    FrameReader fr;
+    if (!fr.open(path, threads)) {
+        if (fr.err && !strcmp(fr.err, "open")) { set_error("cannot open %s", path); return SKX_EIO; }
+        set_error("%s", fr.err ? fr.err : "skf: read failed"); return SKX_EFORMAT;
     }
-    if (!seen) { set_error("skf: not a snappy stream"); return SKX_EFORMAT; }
-    // --- CBOR struct
-    Reader rd{cbor.data(), cbor.size()};
-    int m; uint64_t nf = 0;
-    if (!rd.head(m, nf) || m != 5) { set_error("skf: CBOR decode failed"); return SKX_EFORMAT; }
+    Reader rd(fr);
+    int mj; uint64_t nf = 0;
+    if (!rd.head(mj, nf) || mj != 5) { set_error("%s", fr.err ? fr.err : "skf: CBOR decode failed"); return SKX_EFORMAT; }
     uint64_t dim0 = 0, dim1 = 0; bool have_var = false;
     for (uint64_t fidx = 0; fidx < nf && rd.ok; fidx++) {
         const std::string name = rd.text();
-        if (name == "k") d.k = (int)rd.uint();
-        else if (name == "rc") { if (rd.i < rd.n && (rd.p[rd.i] == 0xf4 || rd.p[rd.i] == 0xf5)) d.rc = rd.p[rd.i++] == 0xf5; else rd.ok = false; }
-        else if (name == "names") { uint64_t n = rd.array(); for (uint64_t j = 0; j < n && rd.ok; j++) d.names.push_back(rd.text()); }
-        else if (name == "split_kmers") { uint64_t n = rd.array(); d.keys.reserve(n); for (uint64_t j = 0; j < n && rd.ok; j++) d.keys.push_back(rd.key()); }
+        if (name == "k") m.k = (int)rd.uint();
+        else if (name == "rc") m.rc = rd.boolean();
+        else if (name == "names") { uint64_t n = rd.array(); for (uint64_t j = 0; j < n && rd.ok; j++) m.names.push_back(rd.text()); }
+        else if (name == "split_kmers") { uint64_t n = rd.array(); if (n > (1ull << 40)) rd.ok = false; else keys.reserve(n); for (uint64_t j = 0; j < n && rd.ok; j++) keys.push_back(rd.key()); }
         else if (name == "variants") {
-            uint64_t n3 = 0; if (!rd.head(m, n3) || m != 5) rd.ok = false;
+            uint64_t n3 = 0; if (!rd.head(mj, n3) || mj != 5) rd.ok = false;
             for (uint64_t g = 0; g < n3 && rd.ok; g++) {
                 const std::string sub = rd.text();
                 if (sub == "v") rd.uint();
                 else if (sub == "dim") { if (rd.array() != 2) rd.ok = false; dim0 = rd.uint(); dim1 = rd.uint(); }
-                else if (sub == "data") { uint64_t n = rd.array(); d.variants.resize(n); for (uint64_t j = 0; j < n && rd.ok; j++) d.variants[j] = (uint8_t)rd.uint(); have_var = true; }
+                else if (sub == "data") {
+                    const uint64_t n = rd.array();
+                    if (!rd.ok || n != dim0 * dim1) { rd.ok = false; break; }          // ndarray serde writes dim before data
+                    m.n_rows = dim0;
+                    int r = begin_rows(dim0, dim1);
+                    if (r != SKX_OK) return r;
+                    // cells are CBOR uints: one byte below 24, else 0x18 + the byte (every base letter): the usual case is
+                    // extracted by the whole team, two bytes per cell; anything else falls back to the generic decoder
+                    const uint64_t S = dim1;
+                    const uint64_t block_rows = S ? std::max<uint64_t>(1, (16u << 20) / S) : 1;
+                    std::vector<uint8_t> rows;
+                    uint64_t row0 = 0;
+                    while (row0 < dim0 && rd.ok) {
+                        const uint64_t nr = std::min(block_rows, dim0 - row0), cells = nr * S;
+                        rows.resize(cells);
+                        uint64_t done = 0;
+                        while (done < cells && rd.ok) {
+                            if (fr.avail() < 2 && !rd.need(1)) break;
+                            const uint64_t can = std::min<uint64_t>(cells - done, fr.avail() / 2);
+                            const uint8_t *src = fr.data();
+                            uint64_t fast = 0;
+                            if (can >= 4096) {
+                                const size_t parts = (size_t)std::min<uint64_t>((uint64_t)threads, can / 4096);
+                                const uint64_t per = can / parts;
+                                std::atomic<int> odd{0};
+                                parallel_for(parts, threads, [&](size_t pt) {
+                                    const uint64_t a = pt * per, b = pt + 1 == parts ? can : a + per;
+                                    uint8_t bad = 0;
+                                    for (uint64_t c = a; c < b; c++) { bad |= (uint8_t)(src[2 * c] ^ 0x18); rows[done + c] = src[2 * c + 1]; }
+                                    if (bad) odd = 1;
+                                });
+                                if (!odd) fast = can;
+                            }
+                            if (fast) { fr.consume(2 * fast); done += fast; continue; }
+                            // generic cell by cell (also the tail of a block)
+                            const uint64_t lim = std::min<uint64_t>(cells - done, std::max<uint64_t>(can, 1));
+                            for (uint64_t c = 0; c < lim && rd.ok; c++) rows[done + c] = (uint8_t)rd.uint();
+                            done += lim;
+                        }
+                        if (!rd.ok) break;
+                        r = sink(row0, nr, rows.data());
+                        if (r != SKX_OK) return r;
+                        row0 += nr;
+                    }
+                    have_var = rd.ok;
+                }
                 else rd.ok = false;
             }
         }
-        else if (name == "variant_count") { uint64_t n = rd.array(); d.counts.resize(n); for (uint64_t j = 0; j < n && rd.ok; j++) d.counts[j] = rd.uint(); }
-        else if (name == "ska_version") d.version = rd.text();
-        else if (name == "k_bits") d.k_bits = (int)rd.uint();
+        else if (name == "variant_count") { uint64_t n = rd.array(); if (n > (1ull << 40)) rd.ok = false; else counts.resize(n); for (uint64_t j = 0; j < n && rd.ok; j++) counts[j] = rd.uint(); }
+        else if (name == "ska_version") m.version = rd.text();
+        else if (name == "k_bits") m.k_bits = (int)rd.uint();
         else rd.ok = false;
     }
-    if (!rd.ok || !have_var || dim0 * dim1 != d.variants.size() || dim1 != d.names.size()) { set_error("skf: CBOR decode failed"); return SKX_EFORMAT; }
-    d.n_rows = dim0;
+    if (!rd.ok || !have_var || dim1 != m.names.size()) { set_error("%s", fr.err ? fr.err : "skf: CBOR decode failed"); return SKX_EFORMAT; }
     return SKX_OK;
 }
 
-int skf_write(const char *path, const SkfData &d)
+int skf_write_stream(const char *path, const SkfMeta &m, const std::vector<skx_key> &keys, const std::vector<uint64_t> &counts,
+                     const RowFetch &fetch, int threads)
 {
+    threads = n_workers(threads);
+    FrameWriter fw;
+    if (!fw.open(path, threads)) { set_error("cannot create %s", path); return SKX_EIO; }
+    const uint64_t S = m.names.size(), U = m.n_rows;
     Writer w;
-    const uint64_t S = d.names.size();
-    w.b.reserve(d.variants.size() * 2 + d.keys.size() * 12 + 1024);
+    auto flush = [&]() { fw.append(w.b.data(), w.b.size()); w.b.clear(); };
     w.head(5, 8);
-    w.text("k"); w.head(0, (uint64_t)d.k);
-    w.text("rc"); w.b.push_back(d.rc ? 0xf5 : 0xf4);
-    w.text("names"); w.head(4, S); for (auto &s : d.names) w.text(s);
-    w.text("split_kmers"); w.head(4, d.keys.size());
-    for (auto &kk : d.keys) {
-        if (!kk.hi) w.head(0, kk.lo);
-        else {
-            uint8_t be[16]; int nb = 0;
-            for (int s = 56; s >= 0; s -= 8) { uint8_t b = (uint8_t)(kk.hi >> s); if (nb || b) be[nb++] = b; }
-            for (int s = 56; s >= 0; s -= 8) be[nb++] = (uint8_t)(kk.lo >> s);
-            w.head(6, 2); w.head(2, (uint64_t)nb); w.b.insert(w.b.end(), be, be + nb);
-        }
-    }
+    w.text("k"); w.head(0, (uint64_t)m.k);
+    w.text("rc"); w.b.push_back(m.rc ? 0xf5 : 0xf4);
+    w.text("names"); w.head(4, S); for (auto &s : m.names) w.text(s);
+    w.text("split_kmers"); w.head(4, keys.size());
+    for (size_t i = 0; i < keys.size(); i++) { w.key(keys[i]); if (w.b.size() >= (1u << 20)) flush(); }
     w.text("variants"); w.head(5, 3);
     w.text("v"); w.head(0, 1);
-    w.text("dim"); w.head(4, 2); w.head(0, d.n_rows); w.head(0, S);
-    w.text("data"); w.head(4, d.variants.size());
-    for (uint8_t v : d.variants) { if (v < 24) w.b.push_back(v); else { w.b.push_back(0x18); w.b.push_back(v); } }
-    w.text("variant_count"); w.head(4, d.counts.size()); for (uint64_t c : d.counts) w.head(0, c);
-    w.text("ska_version"); w.text(d.version);
-    w.text("k_bits"); w.head(0, (uint64_t)d.k_bits);
-
-    FILE *f = fopen(path, "wb");
-    if (!f) { set_error("cannot create %s", path); return SKX_EIO; }
-    bool ok = fwrite("\xff\x06\x00\x00sNaPpY", 1, 10, f) == 10;
-    std::vector<uint8_t> blk;
-    for (size_t off = 0; off < w.b.size() && ok; off += 65536) {
-        const size_t n = std::min<size_t>(65536, w.b.size() - off);
-        blk.clear();
-        snappy_compress_block(w.b.data() + off, n, blk);
-        const bool raw = blk.size() >= n - n / 8;           // snap's rule of thumb: store incompressible chunks raw
-        const uint8_t *payload = raw ? w.b.data() + off : blk.data();
-        const size_t plen = raw ? n : blk.size(), clen = plen + 4;
-        const uint32_t crc = mask_crc(crc32c(w.b.data() + off, n));
-        uint8_t hdr[8] = {(uint8_t)(raw ? 1 : 0), (uint8_t)clen, (uint8_t)(clen >> 8), (uint8_t)(clen >> 16),
-                          (uint8_t)crc, (uint8_t)(crc >> 8), (uint8_t)(crc >> 16), (uint8_t)(crc >> 24)};
-        ok = fwrite(hdr, 1, 8, f) == 8 && fwrite(payload, 1, plen, f) == plen;
+    w.text("dim"); w.head(4, 2); w.head(0, U); w.head(0, S);
+    w.text("data"); w.head(4, U * S);
+    flush();
+    const uint64_t block_rows = S ? std::max<uint64_t>(1, std::min<uint64_t>((16u << 20) / S, SUPER / (2 * S) ? SUPER / (2 * S) : 1)) : 1;
+    std::vector<uint8_t> rows;
+    for (uint64_t row0 = 0; row0 < U && fw.ok; row0 += block_rows) {
+        const uint64_t nr = std::min(block_rows, U - row0), cells = nr * S;
+        rows.resize(cells);
+        int r = fetch(row0, nr, rows.data());
+        if (r != SKX_OK) return r;
+        if (2 * cells <= SUPER) {
+            // every cell the engine holds is a letter or '-' (>= 24): two bytes per cell, written in place by the team
+            uint8_t *dst = fw.grow(2 * cells);
+            const size_t parts = (size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)threads, cells / 65536));
+            const uint64_t per = cells / parts;
+            std::atomic<int> small{0};
+            parallel_for(parts, threads, [&](size_t pt) {
+                const uint64_t a = pt * per, b = pt + 1 == parts ? cells : a + per;
+                uint8_t lo = 0xFF;
+                for (uint64_t c = a; c < b; c++) { const uint8_t v = rows[c]; lo = std::min(lo, v); dst[2 * c] = 0x18; dst[2 * c + 1] = v; }
+                if (lo < 24) small = 1;
+            });
+            if (!small) continue;
+            fw.cur.resize(fw.cur.size() - 2 * cells);       // a value below 24 is a single byte: redo this block generically
+        }
+        for (uint64_t c = 0; c < cells; c++) { w.head(0, rows[c]); if (w.b.size() >= (1u << 20)) flush(); }
+        flush();
     }
-    ok = (fclose(f) == 0) && ok;
-    if (!ok) { set_error("short write %s", path); return SKX_EIO; }
+    w.text("variant_count"); w.head(4, counts.size());
+    for (size_t i = 0; i < counts.size(); i++) { w.head(0, counts[i]); if (w.b.size() >= (1u << 20)) flush(); }
+    w.text("ska_version"); w.text(m.version);
+    w.text("k_bits"); w.head(0, (uint64_t)m.k_bits);
+    flush();
+    if (!fw.close()) { set_error("short write %s", path); return SKX_EIO; }
     return SKX_OK;
+}
+
+// whole-array forms (small inputs, tests)
+int skf_read(const char *path, SkfData &d)
+{
+    SkfMeta m; uint64_t S = 0;
+    int r = skf_read_stream(path, m, d.keys, d.counts,
+                            [&](uint64_t U, uint64_t cols) { S = cols; d.variants.resize(U * S); return SKX_OK; },
+                            [&](uint64_t row0, uint64_t nr, const uint8_t *src) { memcpy(d.variants.data() + row0 * S, src, nr * S); return SKX_OK; }, 0);
+    if (r != SKX_OK) return r;
+    d.k = m.k; d.rc = m.rc; d.k_bits = m.k_bits; d.names = m.names; d.version = m.version; d.n_rows = m.n_rows;
+    return SKX_OK;
+}
+int skf_write(const char *path, const SkfData &d)
+{
+    SkfMeta m; m.k = d.k; m.rc = d.rc; m.k_bits = d.k_bits; m.names = d.names; m.version = d.version; m.n_rows = d.n_rows;
+    const uint64_t S = d.names.size();
+    return skf_write_stream(path, m, d.keys, d.counts,
+                            [&](uint64_t row0, uint64_t nr, uint8_t *dst) { memcpy(dst, d.variants.data() + row0 * S, nr * S); return SKX_OK; }, 0);
 }
 
 }  // namespace skx

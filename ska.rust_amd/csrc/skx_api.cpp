@@ -1140,32 +1140,96 @@ extern "C" int skx_array_distance(skx_array *a, double constant, int filt_ambig,
 }
 
 // ------------------------------------------------------------------------------------------ .skf
+// MergeSkaArray::save (merge_ska_array.rs:191-199), streamed: rows go out in the array's own order (the
+// order of H for arrays built here, the file's order for loaded ones; the reference's order is its hash map's), one
+// transposed row block at a time, so the host never holds the U x S matrix or its 2-bytes-per-cell CBOR text.
 extern "C" int skx_array_save(skx_array *a, const char *path)
 {
     return skx_guarded([&]() -> int {
-    SkfData d;
-    d.k = a->k; d.rc = a->rc; d.k_bits = a->k_bits; d.names = a->names; d.version = a->version;
+    skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
+    SKX_HIP(hipSetDevice(ctx->device));
     const uint64_t U = a->n_rows, S = a->names.size();
-    d.keys.resize(a->n_kmers); d.variants.resize(U * S); d.counts.resize(U); d.n_rows = U;
-    SKX_TRY(skx_array_export(a, d.keys.data(), d.variants.data(), d.counts.data()));
-    return skf_write(path, d);
+    SkfMeta m; m.k = a->k; m.rc = a->rc; m.k_bits = a->k_bits; m.names = a->names; m.version = a->version; m.n_rows = U;
+    std::vector<skx_key> keys;
+    SKX_TRY(array_host_keys(a, keys));
+    std::vector<uint32_t> vc(U);
+    if (U) SKX_HIP(hipMemcpy(vc.data(), a->vcount.p, U * 4, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> counts(vc.begin(), vc.end());
+    DevBuf<uint8_t> d_blk;
+    uint64_t blk_cap = 0;
+    auto fetch = [&](uint64_t row0, uint64_t nr, uint8_t *dst) -> int {
+        if (nr * S > blk_cap) { blk_cap = nr * S; SKX_TRY(d_blk.alloc(blk_cap)); }
+        launch_transpose(a->matrix.p + row0, a->pitch, S, nr, d_blk.p, S, st);          // [S][nr] slice -> [nr][S]
+        SKX_HIP(hipMemcpyAsync(dst, d_blk.p, nr * S, hipMemcpyDeviceToHost, st));
+        SKX_HIP(hipStreamSynchronize(st));
+        return SKX_OK;
+    };
+    return skf_write_stream(path, m, keys, counts, fetch, 0);
     });
 }
+
+// MergeSkaArray::load (merge_ska_array.rs:201-204), streamed: row blocks are transposed into the sample-major matrix as
+// they are decoded
 extern "C" int skx_array_load(skx_ctx *ctx, const char *path, int want_bits, skx_array **out)
 {
     return skx_guarded([&]() -> int {
-    SkfData d;
-    SKX_TRY(skf_read(path, d));
+    if (!ctx || !path || !out) { set_error("bad arguments"); return SKX_EINVAL; }
+    SKX_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::unique_ptr<skx_array> a(new skx_array());
+    a->ctx = ctx;
+    SkfMeta m; std::vector<skx_key> keys; std::vector<uint64_t> counts;
+    DevBuf<uint8_t> d_blk; uint64_t blk_cap = 0, S = 0;
+    auto begin_rows = [&](uint64_t U, uint64_t cols) -> int {
+        S = cols;
+        if (S == 0 || S > 65535) { set_error("skf: unsupported number of samples"); return SKX_EFORMAT; }
+        a->n_rows = U; a->pitch = pitch_for(U);
+        SKX_TRY(a->matrix.alloc(S * a->pitch));
+        SKX_HIP(hipMemsetAsync(a->matrix.p, '-', S * a->pitch, st));
+        return SKX_OK;
+    };
+    auto sink = [&](uint64_t row0, uint64_t nr, const uint8_t *src) -> int {
+        if (nr * S > blk_cap) { blk_cap = nr * S; SKX_TRY(d_blk.alloc(blk_cap)); }
+        SKX_HIP(hipMemcpyAsync(d_blk.p, src, nr * S, hipMemcpyHostToDevice, st));
+        launch_transpose(d_blk.p, S, nr, S, a->matrix.p + row0, a->pitch, st);          // [nr][S] -> columns row0.. of [S][pitch]
+        SKX_HIP(hipStreamSynchronize(st));                                                // src is reused by the decoder
+        return SKX_OK;
+    };
+    SKX_TRY(skf_read_stream(path, m, keys, counts, begin_rows, sink, 0));
+    SKX_TRY(check_k(m.k));
     if (want_bits == 64)       // serde into Vec<u64> fails on wider values; lib.rs:635-661 then retries as u128
-        for (auto &kk : d.keys) if (kk.hi) { set_error("split k-mer does not fit 64 bits"); return SKX_EFORMAT; }
-    std::vector<const char *> names;
-    for (auto &s : d.names) names.push_back(s.c_str());
-    skx_array *a = nullptr;
-    if (d.keys.size() != d.n_rows) { set_error("skf: split_kmers and variants disagree"); return SKX_EFORMAT; }
-    SKX_TRY(skx_array_from_host(ctx, d.k, d.rc, names.data(), (int)names.size(), d.keys.data(), d.variants.data(),
-                                d.counts.size() == d.n_rows ? d.counts.data() : nullptr, d.n_rows, d.version.c_str(), &a));
-    a->k_bits = d.k_bits;
-    *out = a;
+        for (auto &kk : keys) if (kk.hi) { set_error("split k-mer does not fit 64 bits"); return SKX_EFORMAT; }
+    const uint64_t U = a->n_rows;
+    if (keys.size() != U) { set_error("skf: split_kmers and variants disagree"); return SKX_EFORMAT; }
+    a->k = m.k; a->rc = m.rc; a->k_bits = m.k_bits; a->hp = make_hash_params(std::min(m.k, 31)); a->wh = make_wide_hash(m.k);
+    a->version = m.version.empty() ? skx_version() : m.version; a->names = m.names;
+    a->n_kmers = U; a->engine_order = false;
+    SKX_TRY(a->present.alloc(U)); SKX_TRY(a->unambig.alloc(U)); SKX_TRY(a->mask.alloc(U)); SKX_TRY(a->vcount.alloc(U));
+    if (m.k <= 31) {
+        SKX_TRY(a->keys.alloc(U));
+        std::vector<uint64_t> lo(U);
+        for (uint64_t i = 0; i < U; i++) lo[i] = keys[i].lo;
+        DevBuf<uint64_t> tmp; SKX_TRY(tmp.alloc(U));
+        if (U) SKX_HIP(hipMemcpyAsync(tmp.p, lo.data(), U * 8, hipMemcpyHostToDevice, st));
+        launch_hash_keys(tmp.p, a->keys.p, U, a->hp, st);
+        SKX_HIP(hipStreamSynchronize(st));
+    } else a->host_keys.swap(keys);
+    DevBuf<int> d_bad; SKX_TRY(d_bad.alloc(1)); SKX_TRY(d_bad.zero(st));
+    if (U) {
+        launch_col_stats(a->matrix.p, a->pitch, (int)S, U, a->present.p, a->unambig.p, a->mask.p, d_bad.p, st);
+        if (counts.size() == U) {
+            std::vector<uint32_t> vc(U);
+            for (uint64_t i = 0; i < U; i++) vc[i] = (uint32_t)counts[i];
+            SKX_HIP(hipMemcpyAsync(a->vcount.p, vc.data(), U * 4, hipMemcpyHostToDevice, st));
+            SKX_HIP(hipStreamSynchronize(st));
+        } else SKX_HIP(hipMemcpyAsync(a->vcount.p, a->present.p, U * 4, hipMemcpyDeviceToDevice, st));
+    }
+    int bad = 0;
+    SKX_HIP(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipStreamSynchronize(st));
+    SKX_HIP(hipGetLastError());
+    if (bad) { set_error("variants contain a byte outside -ACGTMRWSYKVHDBN (not supported on the device path)"); return SKX_EUNSUP; }
+    *out = a.release();
     return SKX_OK;
     });
 }

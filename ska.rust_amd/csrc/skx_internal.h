@@ -2,6 +2,7 @@
 #pragma once
 #include "../../include/skx.h"
 #include "skx_device.h"
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -117,4 +118,13 @@ struct SkfData {
 };
 int skf_read(const char *path, SkfData &out);
 int skf_write(const char *path, const SkfData &in);
+// streaming forms: the matrix moves in row blocks (row-major [nrows][n_samples]), the snappy chunks are
+// (de)compressed by `threads` host threads (0 = all cores)
+struct SkfMeta { int k = 0, rc = 0, k_bits = 64; std::vector<std::string> names; std::string version; uint64_t n_rows = 0; };
+typedef std::function<int(uint64_t row0, uint64_t nrows, uint8_t *dst)> RowFetch;
+typedef std::function<int(uint64_t row0, uint64_t nrows, const uint8_t *src)> RowSink;
+int skf_write_stream(const char *path, const SkfMeta &m, const std::vector<skx_key> &keys, const std::vector<uint64_t> &counts,
+                     const RowFetch &fetch, int threads);
+int skf_read_stream(const char *path, SkfMeta &m, std::vector<skx_key> &keys, std::vector<uint64_t> &counts,
+                    const std::function<int(uint64_t n_rows, uint64_t n_samples)> &begin_rows, const RowSink &sink, int threads);
 }  // namespace skx
