@@ -406,3 +406,33 @@ def test_skf_lifecycle_errors(E, tmp_path):
     if m.nkmers != m.nrows:
         with pytest.raises(E.EngineError, match="out of step"):
             m.delete_samples(["a"])
+
+
+def test_skf_stream_codec_integrity(E, tmp_path):
+    """The streaming codec: a multi-super-block file round-trips (engine -> engine, engine -> oracle, oracle -> engine),
+    and a flipped byte / a truncated file is an error (masked CRC-32C per chunk), never a silently different array."""
+    rng = np.random.default_rng(11)
+    _, samples = _related_samples(rng, 40, length=60_000, snps=300)
+    names = [f"s{i}" for i in range(40)]
+    ga = E.DictSet.build([E.record_stream(s) for s in samples], 31, True).merge(names)      # ~0.4 M rows x 40: > one 32 MB super-block of CBOR
+    p = str(tmp_path / "big.skf")
+    ga.save(p)
+    ref = as_map(*ga.export())
+    assert as_map(*E.Array.load(p).export()) == ref
+    oa = ora.Array.load(p)
+    assert oa.names == names and as_map(*oa.export()) == ref
+    p2 = str(tmp_path / "big_oracle.skf")
+    oa.save(p2)                                                                              # uncompressed chunks (type 0x01)
+    assert as_map(*E.Array.load(p2).export()) == ref
+    raw = bytearray(open(p, "rb").read())
+    bad = bytearray(raw)
+    bad[len(bad) // 2] ^= 0x40
+    open(str(tmp_path / "flip.skf"), "wb").write(bad)
+    with pytest.raises(E.EngineError):
+        E.Array.load(str(tmp_path / "flip.skf"), want_bits=64)
+    open(str(tmp_path / "cut.skf"), "wb").write(raw[: len(raw) * 2 // 3])
+    with pytest.raises(E.EngineError):
+        E.Array.load(str(tmp_path / "cut.skf"), want_bits=64)
+    open(str(tmp_path / "junk.skf"), "wb").write(b"not a snappy stream at all")
+    with pytest.raises(E.EngineError):
+        E.Array.load(str(tmp_path / "junk.skf"), want_bits=64)
