@@ -6,7 +6,7 @@
 // Chunks are written snappy-compressed (type 0x00) with masked CRC-32C so files are loadable by the real `ska`.
 //
 // the reference encodes and decodes the whole array serially in memory (2 B of CBOR per matrix cell).
-// Here both directions stream: the CBOR text exists only as 32 MB super-blocks, whose 64 KB snappy chunks are
+// Here both directions stream: the CBOR text exists only as 128 MB super-blocks, whose 64 KB snappy chunks are
 // (de)compressed and checksummed by a team of host threads, and the U x S matrix is pulled from / pushed to the caller in
 // row blocks (the device gathers / transposes them), so neither the 2UxS-byte CBOR nor a host copy of the matrix is ever
 // materialised.
@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -46,7 +47,13 @@ const Crc32c crc32c;
 inline uint32_t mask_crc(uint32_t c) { return ((c >> 15) | (c << 17)) + 0xa282ead8u; }
 
 constexpr size_t CHUNK = 65536;                 // uncompressed bytes per snappy-frame chunk (the format's maximum)
-constexpr size_t SUPER = 512 * CHUNK;           // bytes of CBOR in flight per direction
+// bytes of CBOR in flight per direction: 128 MB (thread teams are forked per super-block); SKX_SKF_BLOCK_MB trades memory for forks
+static size_t super_bytes()
+{
+    static const size_t v = [] { const char *e = getenv("SKX_SKF_BLOCK_MB"); long mb = e ? atol(e) : 128; if (mb < 1) mb = 1; if (mb > 4096) mb = 4096; return (size_t)mb * 16 * CHUNK; }();
+    return v;
+}
+#define SUPER (super_bytes())
 
 int n_workers(int threads)
 {
@@ -377,7 +384,7 @@ int skf_read_stream(const char *path, SkfMeta &m, std::vector<skx_key> &keys, st
                     // cells are CBOR uints: one byte below 24, else 0x18 + the byte (every base letter): the usual case is
                     // extracted by the whole team, two bytes per cell; anything else falls back to the generic decoder
                     const uint64_t S = dim1;
-                    const uint64_t block_rows = S ? std::max<uint64_t>(1, (16u << 20) / S) : 1;
+                    const uint64_t block_rows = S ? std::max<uint64_t>(1, (uint64_t)(SUPER / 2) / S) : 1;
                     std::vector<uint8_t> rows;
                     uint64_t row0 = 0;
                     while (row0 < dim0 && rd.ok) {
@@ -446,7 +453,7 @@ int skf_write_stream(const char *path, const SkfMeta &m, const std::vector<skx_k
     w.text("dim"); w.head(4, 2); w.head(0, U); w.head(0, S);
     w.text("data"); w.head(4, U * S);
     flush();
-    const uint64_t block_rows = S ? std::max<uint64_t>(1, std::min<uint64_t>((16u << 20) / S, SUPER / (2 * S) ? SUPER / (2 * S) : 1)) : 1;
+    const uint64_t block_rows = S ? std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)(SUPER / 2) / S, SUPER / (2 * S) ? SUPER / (2 * S) : 1)) : 1;
     std::vector<uint8_t> rows;
     for (uint64_t row0 = 0; row0 < U && fw.ok; row0 += block_rows) {
         const uint64_t nr = std::min(block_rows, U - row0), cells = nr * S;

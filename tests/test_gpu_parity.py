@@ -411,10 +411,11 @@ def test_skf_lifecycle_errors(E, tmp_path):
 def test_skf_stream_codec_integrity(E, tmp_path):
     """The streaming codec: a multi-super-block file round-trips (engine -> engine, engine -> oracle, oracle -> engine),
     and a flipped byte / a truncated file is an error (masked CRC-32C per chunk), never a silently different array."""
+    os.environ["SKX_SKF_BLOCK_MB"] = "4"       # read once, at the codec's first use: many super-blocks in this test
     rng = np.random.default_rng(11)
     _, samples = _related_samples(rng, 40, length=60_000, snps=300)
     names = [f"s{i}" for i in range(40)]
-    ga = E.DictSet.build([E.record_stream(s) for s in samples], 31, True).merge(names)      # ~0.4 M rows x 40: > one 32 MB super-block of CBOR
+    ga = E.DictSet.build([E.record_stream(s) for s in samples], 31, True).merge(names)      # ~0.4 M rows x 40: 33 MB of CBOR
     p = str(tmp_path / "big.skf")
     ga.save(p)
     ref = as_map(*ga.export())
