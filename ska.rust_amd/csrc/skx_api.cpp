@@ -1111,9 +1111,9 @@ extern "C" int skx_array_distance(skx_array *a, double constant, int filt_ambig,
     StageTimer t(ctx, &ctx->tm.distance);
     const uint64_t wpr = (U + 63) / 64;
     DevBuf<uint64_t> planes; DevBuf<unsigned long long> cnt;
-    SKX_TRY(planes.alloc(8 * (uint64_t)S * std::max<uint64_t>(wpr, 1)));
+    SKX_TRY(planes.alloc((filt_ambig ? 4 : 8) * (uint64_t)S * std::max<uint64_t>(wpr, 1)));
     SKX_TRY(cnt.alloc((uint64_t)S * S * DIST_NCOUNT)); SKX_TRY(cnt.zero(st));
-    launch_build_planes(a->matrix.p, a->pitch, S, U, planes.p, wpr, st);
+    launch_build_planes(a->matrix.p, a->pitch, S, U, planes.p, wpr, filt_ambig, st);
     launch_pair_counts(planes.p, S, wpr, filt_ambig, cnt.p, st);
     std::vector<unsigned long long> h((uint64_t)S * S * DIST_NCOUNT);
     SKX_HIP(hipMemcpyAsync(h.data(), cnt.p, h.size() * 8, hipMemcpyDeviceToHost, st));

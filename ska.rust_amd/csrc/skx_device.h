@@ -169,8 +169,8 @@ void launch_row_nonmissing(const uint8_t *matrix, uint64_t pitch, int n_samples,
 
 // ---- distance: bit planes + pair popcounts ----
 // planes[p][s][w]: p in {present, A, C, G, T, sz1, sz2, sz3}, w = 64 columns per word
-void launch_build_planes(const uint8_t *matrix, uint64_t pitch, int n_samples, uint64_t n_cols, uint64_t *planes,
-                         uint64_t words_per_row, hipStream_t st);
+void launch_build_planes(const uint8_t *matrix, uint64_t pitch, int n_samples, uint64_t n_cols, uint64_t *planes, uint64_t wpr, int filt,
+                         hipStream_t st);
 // out[pair][c]: integer pair-class counts, see skx_device.hip
 constexpr int DIST_NCOUNT = 16;
 void launch_pair_counts(const uint64_t *planes, int n_samples, uint64_t words_per_row, int filt_ambig,
