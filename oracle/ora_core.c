@@ -219,8 +219,14 @@ size_t ora_extract_record(const uint8_t *seq, size_t len, const uint8_t *qual, i
                           int qual_filter, int is_reads, ora_key *keys, uint8_t *mid, uint8_t *flags,
                           uint64_t *hashes, size_t cap)
 {
-    if (k <= 31) return extract_record_64(seq, len, qual, k, rc, min_qual, qual_filter, is_reads, keys, mid, flags, hashes, cap);
-    return extract_record_128(seq, len, qual, k, rc, min_qual, qual_filter, is_reads, keys, mid, flags, hashes, cap);
+    if (k <= 31) return extract_record_64(seq, len, qual, k, rc, min_qual, qual_filter, is_reads, keys, mid, flags, hashes, NULL, cap);
+    return extract_record_128(seq, len, qual, k, rc, min_qual, qual_filter, is_reads, keys, mid, flags, hashes, NULL, cap);
+}
+/* the same enumeration with get_middle_pos() of every window (RefSka::new, ska_ref.rs:215-246) */
+size_t extract_record_pos(const uint8_t *seq, size_t len, int k, int rc, ora_key *keys, uint8_t *flags, size_t *pos, size_t cap)
+{
+    if (k <= 31) return extract_record_64(seq, len, NULL, k, rc, 0, ORA_QUAL_NOFILTER, 0, keys, NULL, flags, NULL, pos, cap);
+    return extract_record_128(seq, len, NULL, k, rc, 0, ORA_QUAL_NOFILTER, 0, keys, NULL, flags, NULL, pos, cap);
 }
 
 /* ------------------------------------------------------------- SkaDict */

@@ -31,7 +31,7 @@ void ora_fastx_free(ora_fastx *f) { free(f->recs); free(f->arena); memset(f, 0, 
 static void push(ora_fastx *f, size_t *cap, const uint8_t *seq, size_t len, const uint8_t *qual)
 {
     if (f->n == *cap) { *cap = *cap ? *cap * 2 : 64; f->recs = (ora_rec *)realloc(f->recs, *cap * sizeof(ora_rec)); }
-    f->recs[f->n].seq = seq; f->recs[f->n].len = len; f->recs[f->n].qual = qual; f->n++;
+    f->recs[f->n].seq = seq; f->recs[f->n].len = len; f->recs[f->n].qual = qual; f->recs[f->n].id = NULL; f->recs[f->n].id_len = 0; f->n++;
 }
 
 int ora_fastx_read(const char *path, ora_fastx *out)
@@ -46,7 +46,10 @@ int ora_fastx_read(const char *path, ora_fastx *out)
         out->is_fastq = 0;
         while (i < n) {
             if (b[i] != '>') { ora_set_error("Invalid FASTA/Q record"); ora_fastx_free(out); return -1; }
+            const size_t id0 = i + 1;
             while (i < n && b[i] != '\n') i++;          /* header line */
+            size_t id1 = i;
+            if (id1 > id0 && b[id1 - 1] == '\r') id1--;
             if (i < n) i++;
             /* sequence: up to the next line that starts with '>' ; compact in place */
             size_t w = i, s0 = i;
@@ -56,6 +59,7 @@ int ora_fastx_read(const char *path, ora_fastx *out)
                 if (c != '\n' && c != '\r') b[w++] = c;
             }
             push(out, &cap, b + s0, w - s0, NULL);
+            out->recs[out->n - 1].id = b + id0; out->recs[out->n - 1].id_len = id1 - id0;
         }
     } else if (b[0] == '@') {
         out->is_fastq = 1;

@@ -11,7 +11,7 @@ typedef unsigned __int128 u128;
 void ora_set_error(const char *fmt, ...);
 
 /* ---- FASTX (needletail 0.5 behaviour used at ska_dict.rs:131-153,356-366) ---- */
-typedef struct { const uint8_t *seq; size_t len; const uint8_t *qual; } ora_rec;
+typedef struct { const uint8_t *seq; size_t len; const uint8_t *qual; const uint8_t *id; size_t id_len; } ora_rec;   /* id: header line without '>' */
 typedef struct { ora_rec *recs; size_t n; int is_fastq; uint8_t *arena; } ora_fastx;
 int  ora_fastx_read(const char *path, ora_fastx *out);   /* 0 ok */
 void ora_fastx_free(ora_fastx *f);
@@ -35,4 +35,6 @@ uint8_t *ora_snappy_frame_encode(const uint8_t *in, size_t len, size_t *out_len)
 uint32_t ora_crc32c(const uint8_t *p, size_t n);
 
 double ora_now(void);
+/* SplitKmer enumeration of one record with get_middle_pos() of every window (ora_core.c) */
+size_t extract_record_pos(const uint8_t *seq, size_t len, int k, int rc, ora_key *keys, uint8_t *flags, size_t *pos, size_t cap);
 #endif

@@ -282,7 +282,7 @@ static void SFX(dict_add_record)(SFX(kmap) *m, ora_kmer_filter *filt, const uint
 /* known-answer enumeration for ora_extract_record */
 static size_t SFX(extract_record)(const uint8_t *seq, size_t len, const uint8_t *qual, int k, int rc,
                                   int min_qual, int qual_filter, int is_reads, ora_key *keys, uint8_t *mid,
-                                  uint8_t *flags, uint64_t *hashes, size_t cap)
+                                  uint8_t *flags, uint64_t *hashes, size_t *pos, size_t cap)
 {
     SFX(splitkmer) it; size_t n = 0;
     if (!SFX(sk_new)(&it, seq, len, qual, k, rc, (uint8_t)min_qual, qual_filter, is_reads)) return 0;
@@ -303,6 +303,7 @@ static size_t SFX(extract_record)(const uint8_t *seq, size_t len, const uint8_t 
             if (flags) flags[n] = (uint8_t)((is_rc ? ORA_F_IS_RC : 0) | (SFX(sk_self_palindrome)(&it) ? ORA_F_PALIN : 0) |
                                             (SFX(sk_middle_base_qual)(&it) ? ORA_F_MIDQ_OK : 0));
             if (hashes) hashes[n] = is_reads ? ora_nthash_curr(&it.hash_gen) : 0;
+            if (pos) pos[n] = it.index - (size_t)((k + 1) / 2 - 1);         /* get_middle_pos, split_kmer.rs:322-325 */
         }
         n++;
         more = SFX(sk_roll_fwd)(&it);

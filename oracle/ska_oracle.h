@@ -114,6 +114,17 @@ int ora_array_weed(ora_array *a, const ora_key *weed_keys, size_t n_weed, int re
 int ora_weed(ora_array *a, const char *weed_fasta, int reverse, double min_freq, int filter_ambig_as_missing, int filter_type,
              int ambig_mask, int ignore_const_gaps);
 
+/* ---- `ska map` ---- */
+typedef struct ora_ref ora_ref;
+/* RefSka::new (ska_ref.rs:189-311): split k-mers + middle positions of a reference FASTA, optional repeat coordinates */
+ora_ref *ora_ref_new(int k, const char *fasta, int rc, int ambig_mask, int repeat_mask);
+/* generic_modes::map's to_dict + RefSka::map (generic_modes.rs:56-67, ska_ref.rs:508-533) */
+int ora_ref_map(ora_ref *r, const ora_array *a);
+/* write_aln / write_vcf (ska_ref.rs:622-765, aln_writer.rs, idx_check.rs) into malloc'd text */
+char *ora_ref_write_aln(ora_ref *r, size_t *len);
+char *ora_ref_write_vcf(ora_ref *r, size_t *len);
+void ora_ref_free(ora_ref *r);
+
 typedef struct { double distance, mismatch_prop; uint64_t match_count, mismatch_count; } ora_dist;
 /* MergeSkaArray::distance (merge_ska_array.rs:416-438,587-632): upper triangle, (i<j) row-major */
 void ora_array_distance(const ora_array *a, double constant, int filt_ambig, ora_dist *out);

@@ -806,6 +806,11 @@ static int array_compact(skx_array *a, DevBuf<uint8_t> &keep, DevBuf<uint64_t> &
     skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
     const uint64_t U = a->n_rows; const size_t S = a->names.size();
     const bool filter_ambig_as_missing = vcount_from_unambig;
+    if (kept == U && !mask_ambig) {                 // nothing goes: no 2 x U x S bytes of traffic, no second matrix
+        if (filter_ambig_as_missing && U) SKX_HIP(hipMemcpyAsync(a->vcount.p, a->unambig.p, U * 4, hipMemcpyDeviceToDevice, st));
+        SKX_HIP(hipStreamSynchronize(st));
+        return SKX_OK;
+    }
     {
         StageTimer t(ctx, &ctx->tm.compact);
         const uint64_t np = pitch_for(kept);

@@ -89,6 +89,14 @@ def _load():
     lib.ora_array_delete_samples.argtypes = [vp, C.POINTER(cp), i]
     lib.ora_array_weed.argtypes = [vp, vp, sz, i]
     lib.ora_weed.argtypes = [vp, cp, i, d, i, i, i, i]
+    lib.ora_ref_new.restype = vp
+    lib.ora_ref_new.argtypes = [i, cp, i, i, i]
+    lib.ora_ref_map.argtypes = [vp, vp]
+    lib.ora_ref_write_aln.restype = vp
+    lib.ora_ref_write_aln.argtypes = [vp, C.POINTER(sz)]
+    lib.ora_ref_write_vcf.restype = vp
+    lib.ora_ref_write_vcf.argtypes = [vp, C.POINTER(sz)]
+    lib.ora_ref_free.argtypes = [vp]
     lib.ora_timers_get.argtypes = [C.POINTER(Timers), i]
     lib.ora_sample_name.restype = vp
     lib.ora_sample_name.argtypes = [cp]
@@ -284,6 +292,23 @@ class Array:
         if lib.ora_weed(self.h, weed_fasta.encode() if weed_fasta else None, int(reverse), min_freq,
                         int(filter_ambig_as_missing), filter_type, int(ambig_mask), int(ignore_const_gaps)):
             raise _err()
+
+    # ---- ska map (generic_modes.rs:56-84) ----
+    def map(self, reference, fmt="aln", ambig_mask=False, repeat_mask=False):
+        """RefSka::new(k, reference, rc, ambig_mask, repeat_mask) + map + write_aln | write_vcf -> text"""
+        r = lib.ora_ref_new(self.k, reference.encode(), int(self.rc), int(ambig_mask), int(repeat_mask))
+        if not r:
+            raise _err()
+        try:
+            if lib.ora_ref_map(r, self.h):
+                raise _err()
+            n = C.c_size_t()
+            p = (lib.ora_ref_write_vcf if fmt == "vcf" else lib.ora_ref_write_aln)(r, C.byref(n))
+            if not p:
+                raise _err()
+            return _take(p, n.value)
+        finally:
+            lib.ora_ref_free(r)
 
     def __del__(self):
         if getattr(self, "h", None):
