@@ -170,6 +170,12 @@ int  skx_array_weed(skx_array *a, skx_keyset *weed, int reverse, uint64_t *remov
 /* RefSka::new + kmer_iter (ska_ref.rs:189-262,541) for `ska weed`: the split k-mers of a FASTA file as a key set;
  * SKX_EINVAL "Cannot create reference from FASTQ files" (ska_ref.rs:206-208), SKX_EEMPTY "<file> has no valid sequence" */
 int  skx_keyset_from_fasta(skx_ctx *ctx, const char *path, int k, int rc, skx_keyset **out);
+/* ---- `ska map` ----
+ * generic_modes::map (generic_modes.rs:56-84) = RefSka::new(k, reference, rc, ambig_mask, repeat_mask) (ska_ref.rs:189-311)
+ * + RefSka::map (:508-533) + write_aln (format 0, :622-645, AlnWriter aln_writer.rs) | write_vcf (format 1, :648-765).
+ * The text is malloc'd (skx_free).  Errors where the reference panics: "Cannot create reference from FASTQ files",
+ * "<file> has no valid sequence" (SKX_EEMPTY), "No split k-mers mapped to reference". */
+int  skx_array_map(skx_array *a, const char *reference_fasta, int ambig_mask, int repeat_mask, int format, int threads, char **buf, uint64_t *len);
 /* the context an array lives on; and a way for host glue above the ABI to leave its message in skx_last_error() */
 skx_ctx *skx_array_ctx(const skx_array *a);
 void skx_set_last_error(const char *msg);

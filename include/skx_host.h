@@ -37,7 +37,7 @@ int skh_weed(skx_array *a, const char *weed_file, int reverse, double min_freq, 
              int ambig_mask, int ignore_const_gaps, const char *out_file);
 /* io_utils::read_input_fastas sample-name rule (io_utils.rs:31-46) */
 char *skh_sample_name(const char *path);
-/* the `ska` command line (build | align | distance | nk | merge | delete | weed); returns the process exit code */
+/* the `ska` command line (build | align | map | distance | nk | merge | delete | weed); returns the process exit code */
 int skh_main(int argc, char **argv);
 
 #ifdef __cplusplus

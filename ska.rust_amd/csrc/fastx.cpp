@@ -40,8 +40,9 @@ static int parse_fasta(const std::vector<uint8_t> &b, size_t step, HostStream &o
     out.seq.reserve(out.seq.size() + b.size());
     while (p < end) {
         const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));     // header line
-        p = nl ? nl + 1 : end;
         const bool keep = rec % step == 0;
+        if (keep) { const uint8_t *q = p + 1, *he = nl ? nl : end; while (q < he && *q != ' ' && *q != '\t' && *q != '\r') q++; out.ids.emplace_back((const char *)p + 1, (size_t)(q - p - 1)); }
+        p = nl ? nl + 1 : end;
         while (p < end && *p != '>') {                                                // sequence lines
             nl = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
             const uint8_t *le = nl ? nl : end;
@@ -87,7 +88,7 @@ int read_sample_stream(const char *file1, const char *file2, double proportion_r
 {
     size_t step = 1;
     if (proportion_reads > 0.0) { step = (size_t)std::llround(1.0 / proportion_reads); if (step == 0) step = 1; }
-    out.seq.clear(); out.qual.clear();
+    out.seq.clear(); out.qual.clear(); out.ids.clear();
     std::vector<uint8_t> buf;
     SKX_TRY(slurp(file1, buf));
     if (buf[0] == '@') out.is_fastq = true;

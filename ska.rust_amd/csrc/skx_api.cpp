@@ -2,6 +2,7 @@
 // No CPU fallback exists: without a usable HIP device every compute entry point fails with SKX_ENODEV.
 #include "skx_internal.h"
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1140,6 +1141,179 @@ extern "C" int skx_array_distance(skx_array *a, double constant, int filt_ambig,
             out[n].mismatch_prop = (matches + mismatches) == 0.0 ? 0.0 : mismatches / (matches + mismatches);
             out[n].match_count = (uint64_t)matches; out[n].mismatch_count = (uint64_t)mismatches;
         }
+    return SKX_OK;
+    });
+}
+
+// ------------------------------------------------------------------------------------------ ska map (N3)
+// generic_modes::map (generic_modes.rs:56-84): RefSka::new(k, reference, rc, ambig_mask, repeat_mask) (ska_ref.rs:189-311), map
+// (:508-533), write_aln | write_vcf (:622-765).  Device: reference windows, look-up of every window's split k-mer in the array,
+// gather of the mapped rows (reverse-complemented where the reference strand is not the canonical one), one AlnWriter state
+// machine per sample.  Host: record bookkeeping, repeat coordinates, text.
+extern "C" int skx_array_map(skx_array *a, const char *reference, int ambig_mask, int repeat_mask, int format, int threads, char **buf, uint64_t *len)
+{
+    return skx_guarded([&]() -> int {
+    if (!a || !reference || !buf || !len) { set_error("bad arguments"); return SKX_EINVAL; }
+    skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
+    SKX_HIP(hipSetDevice(ctx->device));
+    const int k = a->k, h = (k - 1) / 2, S = (int)a->names.size();
+    if (a->n_kmers != a->n_rows) { set_error("split k-mers and variants are out of step (filtered without update_kmers)"); return SKX_EINVAL; }
+    HostStream hs;
+    SKX_TRY(read_sample_stream(reference, nullptr, 0.0, hs));
+    if (hs.is_fastq) { set_error("Cannot create reference from FASTQ files"); return SKX_EINVAL; }                                // ska_ref.rs:206-208
+    const uint64_t L = hs.seq.size();
+    if (L > 0xFFFFFFF0ull) { set_error("reference longer than 4 G bases"); return SKX_EUNSUP; }
+    // chromosomes: start in the record stream, length, offset in the concatenated output
+    std::vector<uint64_t> cstart, clen, coff;
+    { uint64_t b0 = 0, off = 0; for (uint64_t i = 0; i < L; i++) if (hs.seq[i] == '\n') { cstart.push_back(b0); clen.push_back(i - b0); coff.push_back(off); off += i - b0; b0 = i + 1; } }
+    const size_t n_chrom = cstart.size();
+    uint64_t total = 0; for (auto l : clen) total += l;
+    DevBuf<uint8_t> d_seq; SKX_TRY(d_seq.alloc(L + 16));
+    SKX_HIP(hipMemcpyAsync(d_seq.p, hs.seq.data(), L, hipMemcpyHostToDevice, st));
+    DevBuf<uint64_t> wlo, whi; DevBuf<uint8_t> flag;
+    SKX_TRY(ref_windows(ctx, d_seq.p, L, k, a->rc, wlo, whi, flag));
+    std::vector<uint8_t> hflag(L);
+    std::vector<uint64_t> hlo(L), hhi;
+    SKX_HIP(hipMemcpyAsync(hflag.data(), flag.p, L, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipMemcpyAsync(hlo.data(), wlo.p, L * 8, hipMemcpyDeviceToHost, st));
+    if (k > 31) { hhi.resize(L); SKX_HIP(hipMemcpyAsync(hhi.data(), whi.p, L * 8, hipMemcpyDeviceToHost, st)); }
+    SKX_HIP(hipStreamSynchronize(st));
+    uint64_t n_windows = 0; for (uint64_t p = 0; p < L; p++) n_windows += hflag[p] != 0;
+    if (n_windows == 0) { set_error("%s has no valid sequence", reference); return SKX_EEMPTY; }                                  // ska_ref.rs:255-257
+    auto chrom_of = [&](uint64_t sp) { return (size_t)(std::upper_bound(cstart.begin(), cstart.end(), sp) - cstart.begin()) - 1; };
+    // repeat coordinates (ska_ref.rs:259-293): every window whose split k-mer occurs more than once in the reference
+    std::vector<uint64_t> repeat;
+    if (repeat_mask) {
+        std::vector<std::pair<skx_key, uint64_t>> ks; ks.reserve(n_windows);
+        for (uint64_t p = 0; p < L; p++) if (hflag[p]) ks.push_back({skx_key{hlo[p] >> 4, k > 31 ? hhi[p] : 0}, p});
+        std::vector<uint8_t> rep(L, 0);
+        std::sort(ks.begin(), ks.end(), [](const std::pair<skx_key, uint64_t> &x, const std::pair<skx_key, uint64_t> &y) { return key_less(x.first, y.first); });
+        for (size_t i = 0; i < ks.size();) { size_t j = i; while (j < ks.size() && key_eq(ks[j].first, ks[i].first)) j++; if (j - i > 1) for (size_t q = i; q < j; q++) rep[ks[q].second] = 1; i = j; }
+        uint64_t last_chrom = 0, last_end = 0, chrom_offset = 0;
+        for (uint64_t p = 0; p < L; p++) {
+            if (!hflag[p]) continue;
+            const size_t c = chrom_of(p - h);
+            if (c > last_chrom) { chrom_offset += clen[last_chrom]; last_chrom = c; }
+            if (!rep[p]) continue;
+            const uint64_t pos = p - h - cstart[c], start = pos - h + chrom_offset, end = pos + h + chrom_offset;
+            for (uint64_t x = (start > last_end || start == 0) ? start : last_end + 1; x < end + 1; x++) repeat.push_back(x);
+            last_chrom = c; last_end = end;
+        }
+    }
+    // look-up
+    DevBuf<uint32_t> row; DevBuf<uint8_t> is_rc;
+    SKX_TRY(row.alloc(L)); SKX_TRY(is_rc.alloc(L));
+    if (k <= 31) {
+        DevBuf<uint64_t> sorted; DevBuf<uint32_t> perm;
+        const uint64_t *skeys = a->keys.p; const uint32_t *sperm = nullptr;
+        if (!a->engine_order) { SKX_TRY(sort_words_perm(a->keys.p, a->n_rows, sorted, perm, st)); skeys = sorted.p; sperm = perm.p; }
+        launch_map_lookup(wlo.p, flag.p, d_seq.p, L, h, skeys, sperm, a->n_rows, row.p, is_rc.p, st);
+        SKX_HIP(hipStreamSynchronize(st));
+    } else {
+        std::vector<skx_key> ak; SKX_TRY(array_host_keys(a, ak));
+        std::vector<uint32_t> order(ak.size()); std::iota(order.begin(), order.end(), 0u);
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key_less(ak[x], ak[y]); });
+        std::vector<uint32_t> hrow(L, 0xFFFFFFFFu); std::vector<uint8_t> hrc(L, 0);
+        for (uint64_t p = 0; p < L; p++) {
+            if (!hflag[p]) continue;
+            const u128 key = hunmix_w((((u128)hhi[p] << 64) | hlo[p]) >> 4, a->wh);
+            const skx_key kk{(uint64_t)key, (uint64_t)(key >> 64)};
+            auto it = std::lower_bound(order.begin(), order.end(), kk, [&](uint32_t x, const skx_key &v) { return key_less(ak[x], v); });
+            if (it != order.end() && key_eq(ak[*it], kk)) hrow[p] = *it;
+            hrc[p] = ((uint32_t)hlo[p] & 15u) == (1u << ((((uint32_t)hs.seq[p - h] >> 1) & 3u) ^ 2u));
+        }
+        SKX_HIP(hipMemcpy(row.p, hrow.data(), L * 4, hipMemcpyHostToDevice));
+        SKX_HIP(hipMemcpy(is_rc.p, hrc.data(), L, hipMemcpyHostToDevice));
+    }
+    DevBuf<uint32_t> mapped; uint64_t M = 0;
+    SKX_TRY(select_mapped(row.p, L, mapped, &M, st));
+    if (M == 0) { set_error("No split k-mers mapped to reference"); return SKX_EINVAL; }                                          // ska_ref.rs:553-555
+    std::vector<uint32_t> hm(M), mpos(M), mchrom(M);
+    SKX_HIP(hipMemcpy(hm.data(), mapped.p, M * 4, hipMemcpyDeviceToHost));
+    for (uint64_t m = 0; m < M; m++) { const uint64_t mid = (uint64_t)hm[m] - h; const size_t c = chrom_of(mid); mchrom[m] = (uint32_t)c; mpos[m] = (uint32_t)(mid - cstart[c]); }
+    DevBuf<uint32_t> d_mpos, d_mchrom; DevBuf<uint64_t> d_cstart, d_clen, d_coff, d_rep;
+    SKX_TRY(d_mpos.alloc(M)); SKX_TRY(d_mchrom.alloc(M)); SKX_TRY(d_cstart.alloc(n_chrom)); SKX_TRY(d_clen.alloc(n_chrom)); SKX_TRY(d_coff.alloc(n_chrom));
+    SKX_TRY(d_rep.alloc(repeat.size() + 1));
+    SKX_HIP(hipMemcpyAsync(d_mpos.p, mpos.data(), M * 4, hipMemcpyHostToDevice, st));
+    SKX_HIP(hipMemcpyAsync(d_mchrom.p, mchrom.data(), M * 4, hipMemcpyHostToDevice, st));
+    SKX_HIP(hipMemcpyAsync(d_cstart.p, cstart.data(), n_chrom * 8, hipMemcpyHostToDevice, st));
+    SKX_HIP(hipMemcpyAsync(d_clen.p, clen.data(), n_chrom * 8, hipMemcpyHostToDevice, st));
+    SKX_HIP(hipMemcpyAsync(d_coff.p, coff.data(), n_chrom * 8, hipMemcpyHostToDevice, st));
+    if (!repeat.empty()) SKX_HIP(hipMemcpyAsync(d_rep.p, repeat.data(), repeat.size() * 8, hipMemcpyHostToDevice, st));
+    const uint64_t mpitch = (M + 255) / 256 * 256, opitch = (total + 255) / 256 * 256 + 256;
+    DevBuf<uint8_t> mv, out;
+    SKX_TRY(mv.alloc((uint64_t)S * mpitch)); SKX_TRY(out.alloc((uint64_t)S * opitch));
+    SKX_HIP(hipMemsetAsync(out.p, '-', (uint64_t)S * opitch, st));
+    launch_gather_mapped(a->matrix.p, a->pitch, S, mapped.p, row.p, is_rc.p, M, mv.p, mpitch, st);
+    MapWriteArgs wa{mv.p, mpitch, M, d_mpos.p, d_mchrom.p, d_seq.p, d_cstart.p, d_clen.p, d_coff.p, (int)n_chrom, (uint64_t)h, ambig_mask,
+                    d_rep.p, (uint64_t)repeat.size(), out.p, opitch, S};
+    launch_aln_write(wa, st);
+    std::vector<uint8_t> aln((uint64_t)S * opitch);
+    SKX_HIP(hipMemcpyAsync(aln.data(), out.p, aln.size(), hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipStreamSynchronize(st));
+    SKX_HIP(hipGetLastError());
+    // ---- text
+    std::string o;
+    if (format == 0) {                                                                                                             // write_aln, ska_ref.rs:622-645
+        o.reserve((uint64_t)S * (total + 64));
+        for (int s = 0; s < S; s++) { o += '>'; o += a->names[s]; o += '\n'; o.append((const char *)aln.data() + (uint64_t)s * opitch, total); o += '\n'; }
+    } else {                                                                                                                       // write_vcf, :648-765
+        o += "##fileformat=VCFv4.4\n";
+        for (size_t c = 0; c < n_chrom; c++) { o += "##contig=<ID="; o += hs.ids[c]; o += ">\n"; }
+        o += "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT";
+        for (int s = 0; s < S; s++) { o += '\t'; o += a->names[s]; }
+        o += '\n';
+        auto vbase = [](uint8_t b) { return (b == 'A' || b == 'C' || b == 'G' || b == 'T') ? (char)b : 'N'; };                    // u8_to_base, :137-146
+        const uint64_t BLK = 4096;
+        const uint64_t nblk = (total + BLK - 1) / BLK;
+        std::vector<std::string> parts(nblk);
+        int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency(); if (nt < 1) nt = 1; if (nt > 64) nt = 64;
+        std::atomic<uint64_t> next{0};
+        auto work = [&]() {
+            std::vector<uint8_t> col((uint64_t)S * BLK);
+            std::vector<int> gt(S);
+            for (uint64_t b; (b = next.fetch_add(1)) < nblk;) {
+                const uint64_t x0 = b * BLK, nx = std::min(BLK, total - x0);
+                for (int s = 0; s < S; s++) memcpy(col.data() + (uint64_t)s * BLK, aln.data() + (uint64_t)s * opitch + x0, nx);
+                std::string &t = parts[b];
+                for (uint64_t i = 0; i < nx; i++) {
+                    const uint64_t idx = x0 + i;
+                    const size_t c = (size_t)(std::upper_bound(coff.begin(), coff.end(), idx) - coff.begin()) - 1;               // IdxCheck (idx_check.rs)
+                    const uint64_t pos = idx - coff[c];
+                    const uint8_t ref_base = hs.seq[cstart[c] + pos];
+                    char alts[5]; int n_alt = 0; bool variant = false;
+                    for (int s = 0; s < S; s++) {
+                        const uint8_t mb = col[(uint64_t)s * BLK + i];
+                        if (mb == ref_base) gt[s] = 0;
+                        else if (mb == '-') { variant = true; gt[s] = -1; }
+                        else {
+                            variant = true;
+                            const char ab = vbase(mb);
+                            int at = -1;
+                            for (int q = 0; q < n_alt; q++) if (alts[q] == ab) at = q;
+                            if (at < 0) { alts[n_alt] = ab; at = n_alt++; }
+                            gt[s] = at + 1;
+                        }
+                    }
+                    if (!variant) continue;
+                    t += hs.ids[c]; t += '\t'; t += std::to_string(pos + 1); t += "\t.\t"; t += vbase(ref_base); t += '\t';
+                    if (!n_alt) t += '.';
+                    for (int q = 0; q < n_alt; q++) { if (q) t += ','; t += alts[q]; }
+                    t += "\t.\t.\t.\tGT";
+                    for (int s = 0; s < S; s++) { t += '\t'; if (gt[s] < 0) t += '.'; else t += std::to_string(gt[s]); }
+                    t += '\n';
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nt; t++) pool.emplace_back(work);
+        for (auto &th : pool) th.join();
+        for (auto &p : parts) o += p;
+    }
+    char *mem = (char *)malloc(o.size() + 1);
+    if (!mem) return SKX_ENOMEM;
+    memcpy(mem, o.data(), o.size()); mem[o.size()] = 0;
+    *buf = mem; *len = o.size();
     return SKX_OK;
     });
 }

@@ -196,4 +196,19 @@ void launch_scatter_rows(const uint8_t *src, uint64_t src_pitch, int n_samples, 
                          uint64_t n, hipStream_t st);
 void launch_nonzero_flags(const uint32_t *v, uint64_t n, uint8_t *keep, hipStream_t st);
 
+// ---- `ska map` (skx_reads.hip)
+struct MapWriteArgs {
+    const uint8_t *mv; uint64_t mpitch, M;            // mapped variants, sample-major [n_samples][mpitch]
+    const uint32_t *m_pos, *m_chrom;                  // middle position inside its chromosome / chromosome of mapped window m
+    const uint8_t *stream; const uint64_t *cstart, *clen, *coff; int n_chrom;   // reference record stream, per chromosome: start in the stream, length, offset in the output
+    uint64_t half; int ambig_mask;
+    const uint64_t *repeat; uint64_t n_repeat;        // output coordinates to mask (repeat_coors)
+    uint8_t *out; uint64_t opitch; int n_samples;     // pseudoalignments [n_samples][opitch], pre-filled with '-'
+};
+void launch_map_lookup(const uint64_t *wlo, const uint8_t *flag, const uint8_t *seq, uint64_t len, int h, const uint64_t *sorted,
+                       const uint32_t *perm, uint64_t U, uint32_t *row, uint8_t *is_rc, hipStream_t st);
+void launch_gather_mapped(const uint8_t *matrix, uint64_t pitch, int n_samples, const uint32_t *mapped, const uint32_t *row, const uint8_t *is_rc,
+                          uint64_t M, uint8_t *mv, uint64_t mpitch, hipStream_t st);
+void launch_aln_write(const MapWriteArgs &a, hipStream_t st);
+
 }  // namespace skx

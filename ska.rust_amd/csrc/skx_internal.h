@@ -104,11 +104,15 @@ struct skx_array {
 
 namespace skx {
 // host reader (fastx.cpp): one sample -> record stream; returns SKX_* and sets the error
-struct HostStream { std::vector<uint8_t> seq, qual; bool is_fastq = false; };
+struct HostStream { std::vector<uint8_t> seq, qual; bool is_fastq = false; std::vector<std::string> ids; };   // ids: FASTA record ids (header up to white space)
 int read_sample_stream(const char *file1, const char *file2, double proportion_reads, HostStream &out);
 // FASTQ sample -> sorted unique packed words (skx_reads.hip)
 int reads_sample_dict(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t len, int k, int rc, const skx_qual &q,
                       DevBuf<uint64_t> &out_words, uint64_t *n_out);
+// `ska map` helpers (skx_reads.hip)
+int ref_windows(skx_ctx *ctx, const uint8_t *d_seq, uint64_t len, int k, int rc, DevBuf<uint64_t> &wlo, DevBuf<uint64_t> &whi, DevBuf<uint8_t> &flag);
+int select_mapped(const uint32_t *row, uint64_t len, DevBuf<uint32_t> &mapped, uint64_t *m, hipStream_t st);
+int sort_words_perm(const uint64_t *words, uint64_t n, DevBuf<uint64_t> &sorted, DevBuf<uint32_t> &perm, hipStream_t st);
 // sorted duplicate-free copy of packed words (skx_setops.hip)
 int sort_unique_words(const uint64_t *in, uint64_t n, DevBuf<uint64_t> &out, uint64_t *n_out, hipStream_t st);
 // .skf codec (skf_codec.cpp)

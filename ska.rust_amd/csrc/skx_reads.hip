@@ -294,4 +294,145 @@ int reads_sample_dict(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual,
     return SKX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// `ska map`: RefSka::new + map + AlnWriter (ska_ref.rs:189-311,508-583, aln_writer.rs) on the device.
+// The reference genome goes through the same per-position window kernel as reads (no quality stream): every window-end
+// position p of the record stream gets its packed word and a validity flag, in stream (= position) order.
+// ------------------------------------------------------------------------------------------------
+int ref_windows(skx_ctx *ctx, const uint8_t *d_seq, uint64_t len, int k, int rc, DevBuf<uint64_t> &wlo, DevBuf<uint64_t> &whi, DevBuf<uint8_t> &flag)
+{
+    const bool wide = k > 31;
+    DevBuf<uint64_t> hash;
+    SKX_TRY(hash.alloc(len)); SKX_TRY(wlo.alloc(len)); SKX_TRY(flag.alloc(len));
+    if (wide) SKX_TRY(whi.alloc(len));
+    ReadsArgs ra{d_seq, nullptr, len, k, rc, 0, 0, make_hash_params(k < 31 ? k : 31), make_wide_hash(k), hash.p, wlo.p, wide ? whi.p : nullptr, flag.p};
+    hipLaunchKernelGGL(reads_windows_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream, ra);
+    return SKX_OK;
+}
+
+// row of the array holding each reference window's split k-mer (0xFFFFFFFF: none / no window), and whether the reference
+// strand is the reverse complement of the canonical form (RefKmer::rc): then the canonical middle base is the complement of
+// the forward one, i.e. the word's base mask is exactly 1 << (mid ^ 2)
+__global__ __launch_bounds__(256) void map_lookup_kernel(const uint64_t *wlo, const uint8_t *flag, const uint8_t *seq, uint64_t len, int h,
+                                                        const uint64_t *sorted, const uint32_t *perm, uint64_t U, uint32_t *row, uint8_t *is_rc)
+{
+    const uint64_t p = blockIdx.x * 256ull + threadIdx.x;
+    if (p >= len) return;
+    uint32_t r = 0xFFFFFFFFu; uint8_t rcf = 0;
+    if (flag[p]) {
+        const uint64_t w = wlo[p], key = w >> 4;
+        uint64_t lo = 0, hi = U;
+        while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if ((sorted[mid] >> 4) < key) lo = mid + 1; else hi = mid; }
+        if (lo < U && (sorted[lo] >> 4) == key) r = perm ? perm[lo] : (uint32_t)lo;
+        const uint32_t mid_code = (seq[p - h] >> 1) & 3u;
+        rcf = ((uint32_t)w & 15u) == (1u << (mid_code ^ 2u));
+    }
+    row[p] = r; is_rc[p] = rcf;
+}
+void launch_map_lookup(const uint64_t *wlo, const uint8_t *flag, const uint8_t *seq, uint64_t len, int h, const uint64_t *sorted,
+                       const uint32_t *perm, uint64_t U, uint32_t *row, uint8_t *is_rc, hipStream_t st)
+{
+    if (!len) return;
+    hipLaunchKernelGGL(map_lookup_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, wlo, flag, seq, len, h, sorted, perm, U, row, is_rc);
+}
+__global__ void row_found_kernel(const uint32_t *row, uint8_t *found, uint64_t n)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) found[i] = row[i] != 0xFFFFFFFFu;
+}
+// stream positions of the mapped windows, in order
+int select_mapped(const uint32_t *row, uint64_t len, DevBuf<uint32_t> &mapped, uint64_t *m, hipStream_t st)
+{
+    Temp tmp; DevBuf<uint8_t> found;
+    SKX_TRY(found.alloc(len)); SKX_TRY(mapped.alloc(len));
+    hipLaunchKernelGGL(row_found_kernel, dim3(grid_for(len)), dim3(256), 0, st, row, found.p, len);
+    return select_flagged(tmp, rocprim::counting_iterator<uint32_t>(0), found.p, mapped.p, len, m, st);
+}
+// sorted copy of unsorted array keys with the permutation back to rows (arrays loaded from a file keep the file's order)
+int sort_words_perm(const uint64_t *words, uint64_t n, DevBuf<uint64_t> &sorted, DevBuf<uint32_t> &perm, hipStream_t st)
+{
+    Temp tmp; DevBuf<uint32_t> iota;
+    SKX_TRY(sorted.alloc(n)); SKX_TRY(perm.alloc(n)); SKX_TRY(iota.alloc(n));
+    if (!n) return SKX_OK;
+    hipLaunchKernelGGL(iota_u32_kernel, dim3(grid_for(n)), dim3(256), 0, st, iota.p, n);
+    return sort_pairs(tmp, words, sorted.p, iota.p, perm.p, n, st);
+}
+
+// RC_IUPAC (bit_encoding.rs:475-510)
+__device__ static inline uint8_t rc_iupac(uint8_t b)
+{
+    switch (b | 0x20) {
+    case 'a': return 'T'; case 'b': return 'V'; case 'c': return 'G'; case 'd': return 'H'; case 'g': return 'C';
+    case 'h': return 'D'; case 'k': return 'M'; case 'm': return 'K'; case 'n': return 'N'; case 'r': return 'Y';
+    case 's': return 'S'; case 't': return 'A'; case 'v': return 'B'; case 'w': return 'W'; case 'y': return 'R';
+    default: return '-';
+    }
+}
+// mapped_variants, sample-major: mv[s][m] = (rc ? RC_IUPAC : id)(matrix[s][row of mapped window m])   (ska_ref.rs:519-530)
+__global__ __launch_bounds__(256) void gather_mapped_kernel(const uint8_t *matrix, uint64_t pitch, const uint32_t *mapped, const uint32_t *row,
+                                                           const uint8_t *is_rc, uint64_t M, uint8_t *mv, uint64_t mpitch)
+{
+    const uint64_t m = blockIdx.x * 256ull + threadIdx.x;
+    if (m >= M) return;
+    const uint64_t s = blockIdx.y;
+    const uint32_t p = mapped[m];
+    const uint8_t b = matrix[s * pitch + row[p]];
+    mv[s * mpitch + m] = is_rc[p] ? rc_iupac(b) : b;
+}
+void launch_gather_mapped(const uint8_t *matrix, uint64_t pitch, int n_samples, const uint32_t *mapped, const uint32_t *row, const uint8_t *is_rc,
+                          uint64_t M, uint8_t *mv, uint64_t mpitch, hipStream_t st)
+{
+    if (!M || !n_samples) return;
+    hipLaunchKernelGGL(gather_mapped_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)n_samples), dim3(256), 0, st, matrix, pitch, mapped, row, is_rc, M, mv, mpitch);
+}
+
+// AlnWriter (aln_writer.rs), one sample per thread: the writer is a sequential state machine over the mapped positions
+// (next_pos / last_mapped / last_written), so it is run as such; samples are independent (the reference's par_iter).
+__device__ static inline bool is_ambiguous_d(uint8_t b) { b |= 0x20; return !(b == 'a' || b == 'c' || b == 'g' || b == 't' || b == 'u' || b == ('-' | 0x20)); }
+__global__ __launch_bounds__(64) void aln_write_kernel(MapWriteArgs a)
+{
+    const uint64_t s = blockIdx.x * 64ull + threadIdx.x;
+    if (s >= (uint64_t)a.n_samples) return;
+    const uint8_t *mv = a.mv + s * a.mpitch;
+    uint8_t *out = a.out + s * a.opitch;
+    uint64_t next_pos = a.half, curr_chrom = 0, last_mapped = 0, last_written = 0, chrom_offset = 0;
+    auto refb = [&](uint64_t chrom, uint64_t x) { return a.stream[a.cstart[chrom] + x]; };
+    auto fill_fwd = [&](uint64_t maximum) {                                            // aln_writer.rs:78-92
+        if (last_written > 0) {
+            const uint64_t lm = last_mapped + a.half, overhang = lm > last_written ? lm - last_written : 0;
+            const uint64_t start = last_written + 1;
+            uint64_t end = start + overhang; if (end > maximum) end = maximum;
+            if (end > start) { for (uint64_t x = start; x < end; x++) out[x + chrom_offset] = refb(curr_chrom, x); last_written = end; }
+        }
+    };
+    auto fill_contig = [&]() {                                                          // :95-101
+        const uint64_t len = a.clen[curr_chrom];
+        fill_fwd(len);
+        chrom_offset += len; curr_chrom += 1; next_pos = a.half;
+    };
+    for (uint64_t m = 0; m < a.M; m++) {                                                // write_split_kmer, :105-137
+        const uint8_t base = mv[m];
+        if (base == '-') continue;                                                       // ska_ref.rs:574
+        const uint64_t mapped_pos = a.m_pos[m], mapped_chrom = a.m_chrom[m];
+        while (mapped_chrom > curr_chrom) fill_contig();
+        if (mapped_pos < next_pos) last_mapped = mapped_pos;
+        else {
+            if (mapped_pos > next_pos) fill_fwd(mapped_pos - a.half);
+            for (uint64_t x = mapped_pos - a.half; x < mapped_pos; x++) out[x + chrom_offset] = refb(curr_chrom, x);
+            next_pos = mapped_pos + a.half + 1; last_mapped = mapped_pos; last_written = mapped_pos;
+        }
+    }
+    while (curr_chrom < (uint64_t)a.n_chrom) fill_contig();                             // finalise, :140-158
+    for (uint64_t m = 0; m < a.M; m++) {                                                // the middle bases go in last
+        const uint8_t base = mv[m];
+        if (base == '-') continue;
+        out[a.m_pos[m] + a.coff[a.m_chrom[m]]] = (a.ambig_mask && is_ambiguous_d(base)) ? (uint8_t)'N' : base;
+    }
+    for (uint64_t i = 0; i < a.n_repeat; i++) { const uint64_t x = a.repeat[i]; if (out[x] != '-') out[x] = 'N'; }
+}
+void launch_aln_write(const MapWriteArgs &a, hipStream_t st)
+{
+    if (!a.n_samples) return;
+    hipLaunchKernelGGL(aln_write_kernel, dim3((unsigned)((a.n_samples + 63) / 64)), dim3(64), 0, st, a);
+}
+
 }  // namespace skx

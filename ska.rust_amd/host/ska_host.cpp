@@ -259,7 +259,7 @@ struct Args {
     std::string get(const std::string &k, const std::string &d = "") const { for (auto &o : opt) if (o.first == k) return o.second; return d; }
 };
 const char *VALUE_OPTS[] = {"-o", "-k", "-f", "--threads", "--min-count", "--min-qual", "--qual-filter", "--proportion-reads",
-                            "--min-freq", "-m", "--filter", "-s", "--skf-file", nullptr};
+                            "--min-freq", "-m", "--filter", "-s", "--skf-file", "--format", nullptr};
 bool takes_value(const std::string &s) { for (int i = 0; VALUE_OPTS[i]; i++) if (s == VALUE_OPTS[i]) return true; return false; }
 int fail(const char *msg) { fprintf(stderr, "error: %s\n", msg); return 2; }
 int engine_fail() { fprintf(stderr, "error: %s\n", skx_last_error()); return 101; }   // Rust panics exit with 101
@@ -284,7 +284,7 @@ int emit(const std::string &out_path, const char *buf, uint64_t len)            
 extern "C" int skh_main(int argc, char **argv)
 {
     fprintf(stderr, "SKA: Split K-mer Analysis (the alignment-free aligner)\n");
-    if (argc < 2) return fail("usage: ska <build|align|distance|nk|merge|delete|weed> ...");
+    if (argc < 2) return fail("usage: ska <build|align|map|distance|nk|merge|delete|weed> ...");
     const std::string cmd = argv[1];
     Args a;
     for (int i = 2; i < argc; i++) {
@@ -364,6 +364,16 @@ extern "C" int skh_main(int argc, char **argv)
         char *buf = nullptr; uint64_t len = 0;
         if (skh_load_array(ctx, in, 1, 1, &arr) != SKX_OK || skh_nk(arr, a.has("--full-info"), &buf, &len) != SKX_OK) rcode = engine_fail();
         else { rcode = emit("", buf, len); skx_free(buf); }
+    } else if (cmd == "map") {                                                                                    // cli.rs Map, lib.rs:663-709
+        if (a.pos.size() < 2) return fail("usage: ska map <reference.fa> <input.skf | sequence files...> [-o out] [-f aln|vcf]");
+        const std::string fmt = a.get("--format", a.has("-f") ? a.get("-f") : "aln");                             // -f is the format here, not a file list
+        if (fmt != "aln" && fmt != "vcf") return fail("invalid --format (aln | vcf)");
+        std::vector<const char *> in; for (size_t i = 1; i < a.pos.size(); i++) in.push_back(a.pos[i].c_str());
+        char *buf = nullptr; uint64_t len = 0;
+        if (skh_load_array(ctx, in.data(), (int)in.size(), threads, &arr) != SKX_OK ||
+            skx_array_map(arr, a.pos[0].c_str(), a.has("--ambig-mask"), a.has("--repeat-mask"), fmt == "vcf", threads, &buf, &len) != SKX_OK)
+            rcode = engine_fail();
+        else { rcode = emit(a.get("-o"), buf, len); skx_free(buf); }
     } else if (cmd == "merge") {                                                                                  // cli.rs Merge, lib.rs:728-741
         if (!a.has("-o")) return fail("-o <output> is required");
         std::vector<const char *> in; for (auto &p : a.pos) in.push_back(p.c_str());
@@ -396,7 +406,7 @@ extern "C" int skh_main(int argc, char **argv)
                      a.has("--ambig-mask"), a.has("--no-gap-only-sites"), out.c_str()) != SKX_OK)
             rcode = engine_fail();
     } else {
-        rcode = fail("unknown subcommand (this engine provides build, align, distance, nk, merge, delete, weed)");
+        rcode = fail("unknown subcommand (this engine provides build, align, map, distance, nk, merge, delete, weed)");
     }
     if (arr) skx_array_free(arr);
     skx_ctx_destroy(ctx);

@@ -52,7 +52,7 @@ skx_keyset_union skx_keyset_size skx_keyset_device skx_keyset_from_device skx_ke
 skx_array_assemble skx_merge skx_build_and_merge skx_array_free skx_array_save skx_array_load skx_array_from_host
 skx_array_info skx_array_name skx_array_version skx_array_export skx_array_sample_kmers skx_array_filter
 skx_array_write_fasta skx_array_fasta skx_array_device_matrix skx_array_device_stats skx_array_set_total_samples skx_array_distance skx_free skx_ctx_timings
-skx_array_merge skx_array_delete_samples skx_array_weed skx_keyset_from_fasta skx_array_ctx skx_set_last_error
+skx_array_merge skx_array_delete_samples skx_array_weed skx_keyset_from_fasta skx_array_ctx skx_set_last_error skx_array_map
 skh_apply_filters skh_align skh_distance_tsv skh_nk skh_save_skf skh_load_array skh_sample_name skh_main skh_merge skh_delete skh_weed""".split()
 
 _lib = None
@@ -122,6 +122,7 @@ def load_library():
     lib.skx_array_delete_samples.argtypes = [vp, C.POINTER(cp), i]
     lib.skx_array_weed.argtypes = [vp, vp, i, C.POINTER(u64)]
     lib.skx_keyset_from_fasta.argtypes = [vp, cp, i, i, pp]
+    lib.skx_array_map.argtypes = [vp, cp, i, i, i, i, pp, C.POINTER(u64)]
     lib.skx_array_ctx.argtypes = [vp]
     lib.skx_array_ctx.restype = vp
     lib.skx_set_last_error.argtypes = [cp]
@@ -387,6 +388,12 @@ class Array:
     def delete_samples(self, names):
         nm = (C.c_char_p * max(len(names), 1))(*[x.encode() for x in names])
         _check(_lib.skx_array_delete_samples(self.h, nm, len(names)))
+
+    def map(self, reference, fmt="aln", ambig_mask=False, repeat_mask=False, threads=0):
+        """generic_modes::map: RefSka::new + map + write_aln | write_vcf -> text (generic_modes.rs:56-84)."""
+        p, n = C.c_void_p(), C.c_uint64()
+        _check(_lib.skx_array_map(self.h, reference.encode(), int(ambig_mask), int(repeat_mask), 1 if fmt == "vcf" else 0, threads, C.byref(p), C.byref(n)))
+        return _take(p, n)
 
     def weed_keys(self, keyset, reverse=False):
         r = C.c_uint64()

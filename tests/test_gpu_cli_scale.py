@@ -105,6 +105,24 @@ def test_cli_merge_delete_weed(tmp_path):
     G.matches_path(out, G.correct("weed_nk_k41.stdout"))
 
 
+def test_cli_map(tmp_path):
+    """tests/map.rs through the `ska` executable."""
+    wd = str(tmp_path)
+    rc, out, err = ska("map", G.fin("test_ref.fa"), G.fin("merge.skf"), cwd=wd)
+    assert rc == 0 and out == G.correct("map_aln.stdout"), err
+    rc, out, err = ska("map", G.fin("test_ref.fa"), G.fin("merge.skf"), "-f", "vcf", cwd=wd)
+    assert rc == 0, err
+    G.matches_path(out, G.correct("map_vcf.stdout"))
+    rc, out, err = ska("map", G.fin("test_ref.fa"), G.fin("merge_k9.skf"), "--ambig-mask", cwd=wd)
+    assert out == G.correct("map_aln_k9_filter.stdout")
+    rc, out, err = ska("map", G.fin("test_ref_two_chrom_repeats.fa"), G.fin("merge_k9.skf"), "--repeat-mask", "--format", "vcf", cwd=wd)
+    G.matches_path(out, G.correct("map_vcf_two_chrom.masked.stdout"))
+    rc, out, err = ska("map", G.fin("test_ref.fa"), G.fin("test_1.fa"), G.fin("indel_test.fa"), "-o", "map.aln", cwd=wd)      # sequence files: built on the fly
+    assert rc == 0 and open(os.path.join(wd, "map.aln"), "rb").read() == G.correct("map_aln_indels.stdout"), err
+    rc, out, err = ska("map", G.fin("test_ref.fa"), G.fin("merge_k41.skf"), cwd=wd)
+    assert out == G.correct("map_aln_k41.stdout")
+
+
 @pytest.fixture(scope="module")
 def big():
     """BASELINE.json configs[1] shape, reduced to 24 samples so that the oracle spot checks stay in seconds."""

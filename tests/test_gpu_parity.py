@@ -437,3 +437,44 @@ def test_skf_stream_codec_integrity(E, tmp_path):
     open(str(tmp_path / "junk.skf"), "wb").write(b"not a snappy stream at all")
     with pytest.raises(E.EngineError):
         E.Array.load(str(tmp_path / "junk.skf"), want_bits=64)
+
+
+@pytest.mark.parametrize("k,rc", [(15, True), (31, True), (31, False), (41, True)])
+def test_map_vs_oracle(E, k, rc, tmp_path):
+    """`ska map` (RefSka::new + map + AlnWriter + VCF, ska_ref.rs) on the device vs the oracle: multi-chromosome reference with
+    N runs, lower case, a repeated block and a contig shorter than k; arrays in engine order and in file order; all flag
+    combinations; text compared byte for byte."""
+    rng = np.random.default_rng(900 + k)
+    anc, samples = _related_samples(rng, 4, length=6000, snps=40)
+    names = [f"s{i}" for i in range(4)]
+    ga, oa = build_both(E, samples, k, rc)
+    ref = bytearray(anc)
+    ref[700:720] = b"N" * 20
+    ref[1500:1600] = bytes(ref[1500:1600]).lower()
+    rep = bytes(ref[2000:2200])
+    chroms = [bytes(ref[:3000]), b"ACGTACG", bytes(ref[3000:]) + rep, bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=500).tolist())]
+    rp = str(tmp_path / "ref.fa")
+    with open(rp, "wb") as f:
+        for i, c in enumerate(chroms):
+            f.write(b">chr%d some description\n" % i)
+            for o in range(0, len(c), 70):
+                f.write(c[o:o + 70] + b"\n")
+    p = str(tmp_path / "a.skf")
+    ga.save(p)
+    for arr in (ga, E.Array.load(p)):
+        for fmt in ("aln", "vcf"):
+            for ambig_mask in (False, True):
+                for repeat_mask in (False, True):
+                    g = arr.map(rp, fmt=fmt, ambig_mask=ambig_mask, repeat_mask=repeat_mask)
+                    o = oa.map(rp, fmt=fmt, ambig_mask=ambig_mask, repeat_mask=repeat_mask)
+                    assert g == o, (fmt, ambig_mask, repeat_mask)
+    with pytest.raises(E.EngineError, match="Cannot create reference from FASTQ"):
+        ga.map(G.fin("test_1_fwd.fastq.gz"))
+    far = str(tmp_path / "far.fa")
+    open(far, "wb").write(b">x\n" + bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=400).tolist()) + b"\n")
+    with pytest.raises(E.EngineError, match="No split k-mers mapped"):
+        ga.map(far)
+    tiny = str(tmp_path / "tiny.fa")
+    open(tiny, "wb").write(b">x\nACGT\n")
+    with pytest.raises(E.EngineError, match="has no valid sequence"):
+        ga.map(tiny)
