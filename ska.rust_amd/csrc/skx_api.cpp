@@ -1231,22 +1231,33 @@ extern "C" int skx_array_map(skx_array *a, const char *reference, int ambig_mask
     std::vector<uint32_t> hm(M), mpos(M), mchrom(M);
     SKX_HIP(hipMemcpy(hm.data(), mapped.p, M * 4, hipMemcpyDeviceToHost));
     for (uint64_t m = 0; m < M; m++) { const uint64_t mid = (uint64_t)hm[m] - h; const size_t c = chrom_of(mid); mchrom[m] = (uint32_t)c; mpos[m] = (uint32_t)(mid - cstart[c]); }
-    DevBuf<uint32_t> d_mpos, d_mchrom; DevBuf<uint64_t> d_cstart, d_clen, d_coff, d_rep;
-    SKX_TRY(d_mpos.alloc(M)); SKX_TRY(d_mchrom.alloc(M)); SKX_TRY(d_cstart.alloc(n_chrom)); SKX_TRY(d_clen.alloc(n_chrom)); SKX_TRY(d_coff.alloc(n_chrom));
-    SKX_TRY(d_rep.alloc(repeat.size() + 1));
+    // per chromosome: its range in the mapped list; the reference with the chromosomes concatenated (= output coordinates)
+    std::vector<uint64_t> mlo(n_chrom, 0), mhi(n_chrom, 0);
+    for (uint64_t m = 0; m < M; m++) { const uint32_t c = mchrom[m]; if (mhi[c] == 0) mlo[c] = m; mhi[c] = m + 1; }
+    std::vector<uint8_t> refcat; refcat.reserve(total + 8);
+    for (size_t c = 0; c < n_chrom; c++) refcat.insert(refcat.end(), hs.seq.begin() + (ptrdiff_t)cstart[c], hs.seq.begin() + (ptrdiff_t)(cstart[c] + clen[c]));
+    refcat.resize(total + 8, '-');
+    DevBuf<uint32_t> d_mpos, d_mchrom, d_pres, d_first, d_last; DevBuf<uint64_t> d_clen, d_coff, d_rep, d_mlo, d_mhi; DevBuf<uint8_t> d_refcat;
+    const uint64_t ppitch = (total + 31) / 32 + 4;
+    SKX_TRY(d_mpos.alloc(M)); SKX_TRY(d_mchrom.alloc(M)); SKX_TRY(d_clen.alloc(n_chrom)); SKX_TRY(d_coff.alloc(n_chrom));
+    SKX_TRY(d_mlo.alloc(n_chrom)); SKX_TRY(d_mhi.alloc(n_chrom)); SKX_TRY(d_rep.alloc(repeat.size() + 1)); SKX_TRY(d_refcat.alloc(total + 8));
+    SKX_TRY(d_pres.alloc((uint64_t)S * ppitch)); SKX_TRY(d_first.alloc((uint64_t)S * n_chrom)); SKX_TRY(d_last.alloc((uint64_t)S * n_chrom));
+    SKX_TRY(d_pres.zero(st));
     SKX_HIP(hipMemcpyAsync(d_mpos.p, mpos.data(), M * 4, hipMemcpyHostToDevice, st));
     SKX_HIP(hipMemcpyAsync(d_mchrom.p, mchrom.data(), M * 4, hipMemcpyHostToDevice, st));
-    SKX_HIP(hipMemcpyAsync(d_cstart.p, cstart.data(), n_chrom * 8, hipMemcpyHostToDevice, st));
     SKX_HIP(hipMemcpyAsync(d_clen.p, clen.data(), n_chrom * 8, hipMemcpyHostToDevice, st));
     SKX_HIP(hipMemcpyAsync(d_coff.p, coff.data(), n_chrom * 8, hipMemcpyHostToDevice, st));
+    SKX_HIP(hipMemcpyAsync(d_mlo.p, mlo.data(), n_chrom * 8, hipMemcpyHostToDevice, st));
+    SKX_HIP(hipMemcpyAsync(d_mhi.p, mhi.data(), n_chrom * 8, hipMemcpyHostToDevice, st));
+    SKX_HIP(hipMemcpyAsync(d_refcat.p, refcat.data(), total + 8, hipMemcpyHostToDevice, st));
     if (!repeat.empty()) SKX_HIP(hipMemcpyAsync(d_rep.p, repeat.data(), repeat.size() * 8, hipMemcpyHostToDevice, st));
     const uint64_t mpitch = (M + 255) / 256 * 256, opitch = (total + 255) / 256 * 256 + 256;
     DevBuf<uint8_t> mv, out;
     SKX_TRY(mv.alloc((uint64_t)S * mpitch)); SKX_TRY(out.alloc((uint64_t)S * opitch));
     SKX_HIP(hipMemsetAsync(out.p, '-', (uint64_t)S * opitch, st));
     launch_gather_mapped(a->matrix.p, a->pitch, S, mapped.p, row.p, is_rc.p, M, mv.p, mpitch, st);
-    MapWriteArgs wa{mv.p, mpitch, M, d_mpos.p, d_mchrom.p, d_seq.p, d_cstart.p, d_clen.p, d_coff.p, (int)n_chrom, (uint64_t)h, ambig_mask,
-                    d_rep.p, (uint64_t)repeat.size(), out.p, opitch, S};
+    MapWriteArgs wa{mv.p, mpitch, M, d_mpos.p, d_mchrom.p, d_mlo.p, d_mhi.p, d_refcat.p, total, d_clen.p, d_coff.p, (int)n_chrom, (uint64_t)h, ambig_mask,
+                    d_rep.p, (uint64_t)repeat.size(), out.p, opitch, S, d_pres.p, ppitch, d_first.p, d_last.p};
     launch_aln_write(wa, st);
     std::vector<uint8_t> aln((uint64_t)S * opitch);
     SKX_HIP(hipMemcpyAsync(aln.data(), out.p, aln.size(), hipMemcpyDeviceToHost, st));

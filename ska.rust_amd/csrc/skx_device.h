@@ -200,10 +200,14 @@ void launch_nonzero_flags(const uint32_t *v, uint64_t n, uint8_t *keep, hipStrea
 struct MapWriteArgs {
     const uint8_t *mv; uint64_t mpitch, M;            // mapped variants, sample-major [n_samples][mpitch]
     const uint32_t *m_pos, *m_chrom;                  // middle position inside its chromosome / chromosome of mapped window m
-    const uint8_t *stream; const uint64_t *cstart, *clen, *coff; int n_chrom;   // reference record stream, per chromosome: start in the stream, length, offset in the output
+    const uint64_t *mlo, *mhi;                        // per chromosome: its range in the mapped list
+    const uint8_t *refcat; uint64_t total;            // reference bases, chromosomes concatenated (= output coordinates)
+    const uint64_t *clen, *coff; int n_chrom;         // per chromosome: length, offset in the output
     uint64_t half; int ambig_mask;
     const uint64_t *repeat; uint64_t n_repeat;        // output coordinates to mask (repeat_coors)
     uint8_t *out; uint64_t opitch; int n_samples;     // pseudoalignments [n_samples][opitch], pre-filled with '-'
+    uint32_t *pres; uint64_t ppitch;                  // presence bits of the middle bases [n_samples][ppitch] (zeroed, >= total/32 + 3 words)
+    uint32_t *first, *last;                           // [n_samples][n_chrom] scratch
 };
 void launch_map_lookup(const uint64_t *wlo, const uint8_t *flag, const uint8_t *seq, uint64_t len, int h, const uint64_t *sorted,
                        const uint32_t *perm, uint64_t U, uint32_t *row, uint8_t *is_rc, hipStream_t st);

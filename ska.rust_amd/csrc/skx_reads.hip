@@ -385,54 +385,113 @@ void launch_gather_mapped(const uint8_t *matrix, uint64_t pitch, int n_samples, 
     hipLaunchKernelGGL(gather_mapped_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)n_samples), dim3(256), 0, st, matrix, pitch, mapped, row, is_rc, M, mv, mpitch);
 }
 
-// AlnWriter (aln_writer.rs), one sample per thread: the writer is a sequential state machine over the mapped positions
-// (next_pos / last_mapped / last_written), so it is run as such; samples are independent (the reference's par_iter).
+// AlnWriter (aln_writer.rs) without its sequential walk.  Per sample and chromosome the writer's output is
+//   out[x] = the (masked) middle base            where a split k-mer with a non-'-' base of this sample is mapped at x
+//          = the reference base                  where such a position lies within `half` of x (write_split_kmer's left flank
+//                                                + fill_fwd_bases' right overhang tile exactly the union of [p - half, p + half])
+//          = '-'                                 elsewhere,
+// plus one artefact that has to be kept for parity: last_mapped / last_written are not reset at a chromosome change, so
+// the first fill_fwd_bases of the next chromosome can copy reference bases at the previous chromosome's trailing
+// coordinates.  After a chromosome with mapped positions that stale state is (lm, min(lm + half + 1, len)) whatever the
+// walk did, so it is reproduced from the first / last mapped position per (sample, chromosome) by one short loop per sample.
 __device__ static inline bool is_ambiguous_d(uint8_t b) { b |= 0x20; return !(b == 'a' || b == 'c' || b == 'g' || b == 't' || b == 'u' || b == ('-' | 0x20)); }
-__global__ __launch_bounds__(64) void aln_write_kernel(MapWriteArgs a)
+
+// pass 1: middle bases + presence bits
+__global__ __launch_bounds__(256) void map_mid_kernel(MapWriteArgs a)
+{
+    const uint64_t m = blockIdx.x * 256ull + threadIdx.x;
+    if (m >= a.M) return;
+    const uint64_t s = blockIdx.y;
+    const uint8_t base = a.mv[s * a.mpitch + m];
+    if (base == '-') return;                                                            // ska_ref.rs:574
+    const uint64_t x = a.m_pos[m] + a.coff[a.m_chrom[m]];
+    a.out[s * a.opitch + x] = (a.ambig_mask && is_ambiguous_d(base)) ? (uint8_t)'N' : base;
+    atomicOr(&a.pres[s * a.ppitch + (x >> 5)], 1u << (x & 31));
+}
+// first / last present mapped position per (sample, chromosome); mlo/mhi = range of the chromosome in the mapped list
+__global__ __launch_bounds__(64) void map_ends_kernel(MapWriteArgs a)
+{
+    const uint64_t i = blockIdx.x * 64ull + threadIdx.x;
+    if (i >= (uint64_t)a.n_samples * a.n_chrom) return;
+    const uint64_t s = i / a.n_chrom, c = i % a.n_chrom;
+    const uint8_t *mv = a.mv + s * a.mpitch;
+    uint32_t first = 0xFFFFFFFFu, last = 0xFFFFFFFFu;
+    for (uint64_t m = a.mlo[c]; m < a.mhi[c]; m++) if (mv[m] != '-') { first = a.m_pos[m]; break; }
+    if (first != 0xFFFFFFFFu) for (uint64_t m = a.mhi[c]; m-- > a.mlo[c];) if (mv[m] != '-') { last = a.m_pos[m]; break; }
+    a.first[i] = first; a.last[i] = last;
+}
+// pass 2: flanks.  4 output positions per thread; the presence bits of [x - half, x + half] come from three 32-bit words
+__global__ __launch_bounds__(256) void map_flank_kernel(MapWriteArgs a)
+{
+    const uint64_t x0 = (blockIdx.x * 256ull + threadIdx.x) * 4;
+    if (x0 >= a.total) return;
+    const uint64_t s = blockIdx.y;
+    const uint32_t *pres = a.pres + s * a.ppitch;
+    uint8_t *out = a.out + s * a.opitch;
+    // chromosome of x0 (upper_bound on the output offsets)
+    int lo = 0, hi = a.n_chrom;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.coff[mid] <= x0) lo = mid + 1; else hi = mid; }
+    int c = lo - 1;
+    uint32_t o4 = *reinterpret_cast<const uint32_t *>(out + x0);
+    const uint32_t r4 = *reinterpret_cast<const uint32_t *>(a.refcat + x0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint64_t x = x0 + i;
+        if (x >= a.total) break;
+        while (c + 1 < a.n_chrom && a.coff[c + 1] <= x) c++;
+        if ((pres[x >> 5] >> (x & 31)) & 1u) continue;                                   // a middle base
+        const uint64_t cb = a.coff[c], ce = cb + a.clen[c];                              // chromosome bounds in output coordinates
+        const uint64_t wl = x >= cb + a.half ? x - a.half : cb, wh = x + a.half < ce ? x + a.half : ce - 1;
+        const uint64_t wi = wl >> 5; const uint32_t sh = (uint32_t)(wl & 31);
+        const uint64_t ab = (uint64_t)pres[wi] | ((uint64_t)pres[wi + 1] << 32);
+        uint64_t v = ab >> sh;
+        if (sh) v |= (uint64_t)pres[wi + 2] << (64 - sh);
+        const uint32_t nb = (uint32_t)(wh - wl + 1);                                     // <= 63
+        if (v & ((1ull << nb) - 1ull)) o4 = (o4 & ~(0xFFu << (8 * i))) | (((r4 >> (8 * i)) & 0xFFu) << (8 * i));
+    }
+    *reinterpret_cast<uint32_t *>(out + x0) = o4;
+}
+// the stale-state artefact at chromosome changes (see above) + repeat masking; one thread per sample, loops over chromosomes
+__global__ __launch_bounds__(64) void map_stale_kernel(MapWriteArgs a)
 {
     const uint64_t s = blockIdx.x * 64ull + threadIdx.x;
     if (s >= (uint64_t)a.n_samples) return;
-    const uint8_t *mv = a.mv + s * a.mpitch;
+    const uint32_t *pres = a.pres + s * a.ppitch;
     uint8_t *out = a.out + s * a.opitch;
-    uint64_t next_pos = a.half, curr_chrom = 0, last_mapped = 0, last_written = 0, chrom_offset = 0;
-    auto refb = [&](uint64_t chrom, uint64_t x) { return a.stream[a.cstart[chrom] + x]; };
-    auto fill_fwd = [&](uint64_t maximum) {                                            // aln_writer.rs:78-92
-        if (last_written > 0) {
-            const uint64_t lm = last_mapped + a.half, overhang = lm > last_written ? lm - last_written : 0;
-            const uint64_t start = last_written + 1;
+    uint64_t lw = 0, lm = 0;                                                              // last_written, last_mapped
+    for (int c = 0; c < a.n_chrom; c++) {
+        const uint32_t first = a.first[s * a.n_chrom + c], last = a.last[s * a.n_chrom + c];
+        const uint64_t len = a.clen[c], cb = a.coff[c];
+        // the fill_fwd_bases that runs with the previous chromosome's state: before the first write (only if it is beyond
+        // next_pos = half), or at the end of a chromosome without any write
+        const bool has = first != 0xFFFFFFFFu;
+        const uint64_t maximum = has ? (uint64_t)first - a.half : len;
+        if (lw > 0 && (!has || (uint64_t)first > a.half)) {
+            const uint64_t overhang = lm + a.half > lw ? lm + a.half - lw : 0, start = lw + 1;
             uint64_t end = start + overhang; if (end > maximum) end = maximum;
-            if (end > start) { for (uint64_t x = start; x < end; x++) out[x + chrom_offset] = refb(curr_chrom, x); last_written = end; }
+            if (end > start) {
+                for (uint64_t x = start; x < end; x++) { const uint64_t X = cb + x; if (!((pres[X >> 5] >> (X & 31)) & 1u)) out[X] = a.refcat[X]; }
+                lw = end;
+            }
         }
-    };
-    auto fill_contig = [&]() {                                                          // :95-101
-        const uint64_t len = a.clen[curr_chrom];
-        fill_fwd(len);
-        chrom_offset += len; curr_chrom += 1; next_pos = a.half;
-    };
-    for (uint64_t m = 0; m < a.M; m++) {                                                // write_split_kmer, :105-137
-        const uint8_t base = mv[m];
-        if (base == '-') continue;                                                       // ska_ref.rs:574
-        const uint64_t mapped_pos = a.m_pos[m], mapped_chrom = a.m_chrom[m];
-        while (mapped_chrom > curr_chrom) fill_contig();
-        if (mapped_pos < next_pos) last_mapped = mapped_pos;
-        else {
-            if (mapped_pos > next_pos) fill_fwd(mapped_pos - a.half);
-            for (uint64_t x = mapped_pos - a.half; x < mapped_pos; x++) out[x + chrom_offset] = refb(curr_chrom, x);
-            next_pos = mapped_pos + a.half + 1; last_mapped = mapped_pos; last_written = mapped_pos;
-        }
+        if (has) { lm = last; lw = (uint64_t)last + a.half + 1 < len ? (uint64_t)last + a.half + 1 : len; }
     }
-    while (curr_chrom < (uint64_t)a.n_chrom) fill_contig();                             // finalise, :140-158
-    for (uint64_t m = 0; m < a.M; m++) {                                                // the middle bases go in last
-        const uint8_t base = mv[m];
-        if (base == '-') continue;
-        out[a.m_pos[m] + a.coff[a.m_chrom[m]]] = (a.ambig_mask && is_ambiguous_d(base)) ? (uint8_t)'N' : base;
-    }
-    for (uint64_t i = 0; i < a.n_repeat; i++) { const uint64_t x = a.repeat[i]; if (out[x] != '-') out[x] = 'N'; }
+}
+__global__ __launch_bounds__(256) void map_repeat_kernel(MapWriteArgs a)
+{
+    const uint64_t i = blockIdx.x * 256ull + threadIdx.x;
+    if (i >= a.n_repeat) return;
+    uint8_t *o = a.out + (uint64_t)blockIdx.y * a.opitch + a.repeat[i];
+    if (*o != '-') *o = 'N';                                                             // aln_writer.rs:150-154
 }
 void launch_aln_write(const MapWriteArgs &a, hipStream_t st)
 {
-    if (!a.n_samples) return;
-    hipLaunchKernelGGL(aln_write_kernel, dim3((unsigned)((a.n_samples + 63) / 64)), dim3(64), 0, st, a);
+    if (!a.n_samples || !a.total) return;
+    hipLaunchKernelGGL(map_mid_kernel, dim3((unsigned)((a.M + 255) / 256), (unsigned)a.n_samples), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(map_ends_kernel, dim3((unsigned)(((uint64_t)a.n_samples * a.n_chrom + 63) / 64)), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(map_flank_kernel, dim3((unsigned)(((a.total + 3) / 4 + 255) / 256), (unsigned)a.n_samples), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(map_stale_kernel, dim3((unsigned)((a.n_samples + 63) / 64)), dim3(64), 0, st, a);
+    if (a.n_repeat) hipLaunchKernelGGL(map_repeat_kernel, dim3((unsigned)((a.n_repeat + 255) / 256), (unsigned)a.n_samples), dim3(256), 0, st, a);
 }
 
 }  // namespace skx
