@@ -291,6 +291,16 @@ def test_ragged_and_tiny_inputs(E):
     assert ga.nk(True).decode().split("\n")[0].startswith("ska_version=")
 
 
+def test_repeat_rich_tiny_wide_sample(E):
+    """k > 31 with fewer buckets than staging rounds and one bucket holding most of a tile (poly-A + a short random tail):
+    the words of that bucket go out through the unstaged path of the 128-bit scatter kernel."""
+    rng = np.random.default_rng(17)
+    tail = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=600).tolist())
+    for k in (33, 41, 63):
+        check_dicts(E, [[b"A" * 3300 + tail], [tail + b"AT" * 1500]], k, True)
+        check_dicts(E, [[b"C" * 3900]], k, False)
+
+
 def test_repeat_rich_sample(E):
     """Tandem repeats / homopolymers put tens of thousands of identical split k-mers into one hash bucket: the region
     overflows the fixed-capacity layout (-> exact histogram pass) and the counting sort (-> table dedupe)."""
