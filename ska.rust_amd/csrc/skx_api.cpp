@@ -200,7 +200,7 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
     HashParams hp = make_hash_params(std::min(k, 31));
     WideHash wh = make_wide_hash(k);
     const int key_bits_used = 2 * (k - 1);
-    const uint64_t per_region = wide ? 2048 : 4096;                                           // target windows per bucket (upper bound)
+    const uint64_t per_region = 4096;                                           // target windows per bucket (upper bound)
     int logB = std::min({ilog2_ceil((maxlen + per_region - 1) / per_region), key_bits_used, MAX_LOGB});
     if (logB < 0) logB = 0;
 
