@@ -221,7 +221,7 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
         const int tile_bases = wide ? extract_tile_bases_wide() : extract_tile_bases(logB);
         const uint64_t nreg = (uint64_t)n << logB;
         SKX_TRY(d->raw.alloc(nreg)); SKX_TRY(d->ucnt.alloc(nreg)); SKX_TRY(d->off.alloc(nreg + 1));
-        if (!wide) { SKX_TRY(d->sidx.alloc(nreg * skx::SUBIDX)); d->sb = std::min(4, hp.bits - logB); }
+        SKX_TRY(d->sidx.alloc(nreg * skx::SUBIDX)); d->sb = std::min(4, (wide ? key_bits_used : hp.bits) - logB);
         SKX_TRY(d->raw.zero(st)); SKX_TRY(d_flag.zero(st));
 
         ExtractArgs a{};
@@ -260,9 +260,9 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
         // LDS capacity (words) of the per-region counting sort: 12 B per word, <= 160 KiB
         uint32_t cap = std::max<uint32_t>(512, (uint32_t)std::min<uint64_t>(((uint64_t)lds_cap + 255) / 256 * 256, wide ? LDS_SORT_MAX_WIDE : LDS_SORT_MAX));
         SKX_TRY(d_flag.zero(st));
-        if (!wide) SKX_HIP(hipMemsetAsync(d->sidx.p, 0xFF, nreg * skx::SUBIDX * sizeof(uint16_t), st));     // 0xFFFF = sub-range without words
+        SKX_HIP(hipMemsetAsync(d->sidx.p, 0xFF, nreg * skx::SUBIDX * sizeof(uint16_t), st));     // 0xFFFF = sub-range without words
         { StageTimer t(ctx, &ctx->tm.dedupe);
-          if (wide) launch_dedupe_wide((u128 *)d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, cap, key_bits_used - logB, d_flag.p, st);
+          if (wide) launch_dedupe_wide((u128 *)d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, cap, key_bits_used - logB, d_flag.p, d->sidx.p, d->sb, st);
           else launch_dedupe_mb(d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, cap, hp.bits - logB, d_flag.p, d->sidx.p, d->sb, st); }
         int overflow = 0;
         SKX_HIP(hipMemcpyAsync(&overflow, d_flag.p, 4, hipMemcpyDeviceToHost, st));

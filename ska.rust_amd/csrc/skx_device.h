@@ -181,7 +181,7 @@ void launch_hist_wide(const ExtractArgs &a, hipStream_t st);
 void launch_scatter_wide(const ExtractArgs &a, hipStream_t st);
 int extract_tile_bases_wide();
 void launch_dedupe_wide(u128 *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_regions, uint32_t cap,
-                        int rem_bits, int *overflow, hipStream_t st);
+                        int rem_bits, int *overflow, uint16_t *sidx, int sb, hipStream_t st);
 void launch_union_wide(const DictView &d, int logN, u128 *stage, uint32_t stride, uint32_t *ncnt, uint32_t table_slots, int *overflow,
                        hipStream_t st);
 void launch_union_probe_wide(const DictView &d, int logP, int probe, uint32_t *cnt, uint32_t table_slots, int *overflow, hipStream_t st);
