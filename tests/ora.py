@@ -34,8 +34,11 @@ def build_lib():
 
 
 def _load():
-    if not os.path.exists(_LIB):
-        build_lib()
+    try:
+        build_lib()                      # no-op when up to date; rebuilds a stale checker after a source change
+    except Exception:
+        if not os.path.exists(_LIB):
+            raise
     lib = C.CDLL(_LIB)
     vp, sz, i, d, cp = C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_char_p
     lib.ora_last_error.restype = cp
