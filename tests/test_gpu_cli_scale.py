@@ -196,3 +196,54 @@ def test_distance_many_samples(big):
     ga = E.DictSet.build(small, 31, True).merge(names[:12])
     oa = ora.Array.from_dicts(dicts, names[:12])
     assert ga.distance_tsv(filt_ambig=False) == oa.distance_tsv(filt_ambig=False)
+
+
+def test_full_size_lifecycle_and_map(big, tmp_path):
+    """BASELINE-size genomes through the .skf life-cycle and `ska map`, checked by size-independent properties and an oracle
+    spot check: merge(build(A), build(B)) == build(A + B); delete(merge, B) == build(A); save -> load round trip;
+    weed(x, ancestor) + weed(x, ancestor, reverse) partition the rows; map of two samples == the oracle's."""
+    import synth
+    E, streams, names = big
+    A, B = list(range(0, 6)), list(range(6, 10))
+    dsA = E.DictSet.build([streams[i].tobytes() for i in A], 31, True)
+    dsB = E.DictSet.build([streams[i].tobytes() for i in B], 31, True)
+    dsAB = E.DictSet.build([streams[i].tobytes() for i in A + B], 31, True)
+    a, b, ab = dsA.merge([names[i] for i in A]), dsB.merge([names[i] for i in B]), dsAB.merge([names[i] for i in A + B])
+    m = E.Array.merge([a, b])
+    mk, mv, mc = m.export()
+    wk, wv, wc = ab.export()
+    assert m.names == ab.names and np.array_equal(mk["lo"], wk["lo"]) and np.array_equal(mv, wv) and np.array_equal(mc, wc)
+    # streaming codec at this size, then delete
+    p = str(tmp_path / "m.skf")
+    m.save(p)
+    m2 = E.Array.load(p)
+    lk, lv, lc = m2.export()
+    assert np.array_equal(lk["lo"], wk["lo"]) and np.array_equal(lv, wv) and np.array_equal(lc, wc)
+    m2.delete_samples([names[i] for i in B])
+    dk, dv, dc = m2.export()
+    ak, av, ac = a.export()
+    assert m2.names == a.names and np.array_equal(dk["lo"], ak["lo"]) and np.array_equal(dv, av) and np.array_equal(dc, ac)
+    # weed with the ancestor's split k-mers: the two directions partition the rows
+    anc = synth.ancestor(5_000_000, seed=1)
+    ref = str(tmp_path / "anc.fa")
+    synth.to_fasta(np.concatenate([anc, np.array([10], np.uint8)]), ref)
+    ks = E.KeySet.from_fasta(ref, 31, True)
+    w1, w2 = E.Array.merge([a, b]), E.Array.merge([a, b])
+    r1, r2 = w1.weed_keys(ks), w2.weed_keys(ks, reverse=True)
+    assert r1 + r2 == len(wk) and w1.nkmers + w2.nkmers == len(wk) and w2.nkmers == r1
+    k1, k2 = w1.export()[0]["lo"], w2.export()[0]["lo"]
+    assert len(np.intersect1d(k1, k2)) == 0 and np.array_equal(np.sort(np.concatenate([k1, k2])), wk["lo"])
+    # map two samples onto the ancestor == oracle
+    two = E.DictSet.build([streams[0].tobytes(), streams[9].tobytes()], 31, True).merge(["g0", "g9"])
+    dicts = []
+    for s in (streams[0], streams[9]):
+        d = ora.Dict.new(31, True)
+        for rec in s.tobytes().split(b"\n")[:-1]:
+            d.add_record(rec)
+        dicts.append(d)
+    otwo = ora.Array.from_dicts(dicts, ["g0", "g9"])
+    g = two.map(ref)
+    assert g == otwo.map(ref)
+    seqs = g.split(b"\n")[1::2]
+    assert [len(x) for x in seqs] == [5_000_000, 5_000_000] and seqs[0].count(b"-") < 50_000
+    assert two.map(ref, fmt="vcf") == otwo.map(ref, fmt="vcf")
