@@ -125,6 +125,14 @@ char *ora_ref_write_aln(ora_ref *r, size_t *len);
 char *ora_ref_write_vcf(ora_ref *r, size_t *len);
 void ora_ref_free(ora_ref *r);
 
+/* ---- `ska cov` / --min-count auto (coverage.rs) ---- */
+/* occurrence-count histogram of the split k-mers of a FASTQ pair: hist[c-1] = #split k-mers seen c times (c <= 1000) */
+int ora_cov_histogram(const char *fq1, const char *fq2, int k, int rc, uint32_t hist[1000]);
+/* two-component Poisson mixture fit (argmin BFGS restated) + find_cutoff on a truncated histogram; -1 if not converged */
+int ora_cov_fit(const double *counts, size_t n, double *w0, double *c, size_t *cutoff);
+/* the whole subcommand: plot_hist text (malloc'd) and the cutoff */
+char *ora_cov(const char *fq1, const char *fq2, int k, int rc, size_t *len, size_t *cutoff);
+
 typedef struct { double distance, mismatch_prop; uint64_t match_count, mismatch_count; } ora_dist;
 /* MergeSkaArray::distance (merge_ska_array.rs:416-438,587-632): upper triangle, (i<j) row-major */
 void ora_array_distance(const ora_array *a, double constant, int filt_ambig, ora_dist *out);

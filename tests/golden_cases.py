@@ -359,4 +359,22 @@ def case_map_n(E, tmp_path):                        # fasta_input.rs:34-58
     assert a.map(fin("test_ref.fa")) == correct("map_N.stdout")
 
 
+# ---------------------------------------------------------------- coverage.rs unit test + fastq_input.rs cov_check
+COV_EXAMPLE = [44633459, 950672, 104410, 44137, 24170, 21232, 21699, 24145, 30696, 39210, 49878, 63683, 77690, 95147, 112416, 130307,
+               146531, 160932, 175130, 185113, 193149, 197468, 199189, 198235, 192150, 185565, 176362, 165455, 152487, 139495, 127036,
+               112803, 103080, 90425, 80637, 70960, 62698, 54949, 46744, 41240, 35591, 30025, 25856, 22105, 19405, 16668, 14780, 12620,
+               11074, 9807, 8517, 7731, 7112, 6846, 6126, 5696, 5233, 4779, 4288, 3873, 3519, 3406, 2994, 2859, 2650, 2394, 2376, 2260,
+               2233, 2050, 1859, 1863, 1792, 1777, 1773, 1738, 1648]
+
+
+def case_cov(E, tmp_path):
+    w0, c, cutoff = E.cov_fit(COV_EXAMPLE)                                      # coverage.rs:369-385: the reference's known answer
+    assert cutoff == 9 and 0.9 < w0 < 0.93 and 25.5 < c < 26.5
+    text, cut = E.cov(fin("test_1_fwd.fastq.gz"), fin("test_1_rev.fastq.gz"), k=9)       # fastq_input.rs:474-510: runs
+    assert text.startswith(b"Count\tK_mers\tMixture_density\tComponent\n") and cut >= 1
+    text, cut = E.cov(fin("test_long_1_fwd.fastq.gz"), fin("test_long_1_rev.fastq.gz"), k=33)
+    assert text.startswith(b"Count\t")
+    _must_fail(lambda: E.cov(fin("test_1.fa"), fin("test_2.fa"), k=9))              # FASTA is refused
+
+
 ALL_CASES = [v for k, v in sorted(globals().items()) if k.startswith("case_")]

@@ -100,6 +100,10 @@ def _load():
     lib.ora_ref_write_vcf.restype = vp
     lib.ora_ref_write_vcf.argtypes = [vp, C.POINTER(sz)]
     lib.ora_ref_free.argtypes = [vp]
+    lib.ora_cov_histogram.argtypes = [cp, cp, i, i, vp]
+    lib.ora_cov_fit.argtypes = [vp, sz, C.POINTER(d), C.POINTER(d), C.POINTER(sz)]
+    lib.ora_cov.restype = vp
+    lib.ora_cov.argtypes = [cp, cp, i, i, C.POINTER(sz), C.POINTER(sz)]
     lib.ora_timers_get.argtypes = [C.POINTER(Timers), i]
     lib.ora_sample_name.restype = vp
     lib.ora_sample_name.argtypes = [cp]
@@ -317,6 +321,31 @@ class Array:
         if getattr(self, "h", None):
             lib.ora_array_free(self.h)
             self.h = None
+
+
+def cov_histogram(fq1, fq2, k=31, rc=True):
+    h = np.zeros(1000, np.uint32)
+    if lib.ora_cov_histogram(fq1.encode(), fq2.encode(), k, int(rc), _np_ptr(h)):
+        raise _err()
+    return h
+
+
+def cov_fit(counts):
+    """coverage.rs fit_histogram on an already truncated histogram -> (w0, c, cutoff)"""
+    c = np.ascontiguousarray(counts, np.float64)
+    w0, cc, cut = C.c_double(), C.c_double(), C.c_size_t()
+    if lib.ora_cov_fit(_np_ptr(c), len(c), C.byref(w0), C.byref(cc), C.byref(cut)):
+        raise _err()
+    return w0.value, cc.value, cut.value
+
+
+def cov(fq1, fq2, k=31, rc=True):
+    """`ska cov`: (plot_hist text, cutoff)"""
+    n, cut = C.c_size_t(), C.c_size_t()
+    p = lib.ora_cov(fq1.encode(), fq2.encode(), k, int(rc), C.byref(n), C.byref(cut))
+    if not p:
+        raise _err()
+    return _take(p, n.value), cut.value
 
 
 def sample_name(path):
