@@ -170,6 +170,12 @@ int  skx_array_weed(skx_array *a, skx_keyset *weed, int reverse, uint64_t *remov
 /* RefSka::new + kmer_iter (ska_ref.rs:189-262,541) for `ska weed`: the split k-mers of a FASTA file as a key set;
  * SKX_EINVAL "Cannot create reference from FASTQ files" (ska_ref.rs:206-208), SKX_EEMPTY "<file> has no valid sequence" */
 int  skx_keyset_from_fasta(skx_ctx *ctx, const char *path, int k, int rc, skx_keyset **out);
+/* ---- `ska cov` ----
+ * CoverageHistogram::new (coverage.rs:70-148) + the histogram step of fit_histogram (:158-163): occurrence counts of the
+ * split k-mers of a FASTQ pair (qualities ignored): hist[c - 1] = #split k-mers seen c times, c <= 1000 (hist has 1000 entries).
+ * SKX_EINVAL "<file> appears to be FASTA.\nCoverage can only be used with FASTQ files, not FASTA." */
+int  skx_cov_histogram(skx_ctx *ctx, const char *fastq_fwd, const char *fastq_rev, int k, int rc, uint32_t *hist);
+
 /* ---- `ska map` ----
  * generic_modes::map (generic_modes.rs:56-84) = RefSka::new(k, reference, rc, ambig_mask, repeat_mask) (ska_ref.rs:189-311)
  * + RefSka::map (:508-533) + write_aln (format 0, :622-645, AlnWriter aln_writer.rs) | write_vcf (format 1, :648-765).

@@ -35,9 +35,15 @@ int skh_delete(skx_array *a, const char *const *names, int n_names, const char *
  * with threshold floor(n_samples * min_freq) and update_kmers = true when anything is asked for; out_file NULL = no save */
 int skh_weed(skx_array *a, const char *weed_file, int reverse, double min_freq, int filter_ambig_as_missing, int filter_type,
              int ambig_mask, int ignore_const_gaps, const char *out_file);
+/* CoverageHistogram::fit_histogram + plot_hist (coverage.rs:151-250) on the device-built histogram: two-component Poisson
+ * mixture by maximum likelihood (argmin's BFGS + back-tracking line search restated), cutoff = first count at which the
+ * coverage component is the likelier one.  text = plot_hist's table (malloc'd; NULL to skip). */
+int skh_cov(skx_ctx *ctx, const char *fastq_fwd, const char *fastq_rev, int k, int rc, char **text, uint64_t *len, uint64_t *cutoff);
+/* the fit alone on an already truncated histogram (the reference's unit test drives exactly this, coverage.rs:369-385) */
+int skh_cov_fit(const double *counts, uint64_t n, double *w0, double *c, uint64_t *cutoff);
 /* io_utils::read_input_fastas sample-name rule (io_utils.rs:31-46) */
 char *skh_sample_name(const char *path);
-/* the `ska` command line (build | align | map | distance | nk | merge | delete | weed); returns the process exit code */
+/* the `ska` command line (build | align | map | distance | nk | merge | delete | weed | cov); returns the process exit code */
 int skh_main(int argc, char **argv);
 
 #ifdef __cplusplus

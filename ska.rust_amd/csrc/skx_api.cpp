@@ -1145,6 +1145,35 @@ extern "C" int skx_array_distance(skx_array *a, double constant, int filt_ambig,
     });
 }
 
+// ------------------------------------------------------------------------------------------ ska cov (N4)
+// CoverageHistogram::new (coverage.rs:70-148) + the histogram of fit_histogram (:158-163): both files must be FASTQ, qualities
+// are ignored, hist[c - 1] = number of split k-mers occurring c times over both files (c <= 1000)
+extern "C" int skx_cov_histogram(skx_ctx *ctx, const char *fastq_fwd, const char *fastq_rev, int k, int rc, uint32_t *hist)
+{
+    return skx_guarded([&]() -> int {
+    if (!ctx || !fastq_fwd || !fastq_rev || !hist) { set_error("bad arguments"); return SKX_EINVAL; }
+    SKX_TRY(check_k(k));
+    SKX_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    HostStream hs[2];
+    const char *files[2] = {fastq_fwd, fastq_rev};
+    for (int f = 0; f < 2; f++) {
+        SKX_TRY(read_sample_stream(files[f], nullptr, 0.0, hs[f]));
+        if (!hs[f].is_fastq) { set_error("%s appears to be FASTA.\nCoverage can only be used with FASTQ files, not FASTA.", files[f]); return SKX_EINVAL; }   // :97-99
+    }
+    const uint64_t L = hs[0].seq.size() + hs[1].seq.size();
+    DevBuf<uint8_t> d_seq; DevBuf<uint32_t> d_hist;
+    SKX_TRY(d_seq.alloc(L + 16)); SKX_TRY(d_hist.alloc(1000)); SKX_TRY(d_hist.zero(st));
+    SKX_HIP(hipMemcpyAsync(d_seq.p, hs[0].seq.data(), hs[0].seq.size(), hipMemcpyHostToDevice, st));
+    SKX_HIP(hipMemcpyAsync(d_seq.p + hs[0].seq.size(), hs[1].seq.data(), hs[1].seq.size(), hipMemcpyHostToDevice, st));
+    SKX_TRY(cov_histogram(ctx, d_seq.p, L, k, rc, d_hist.p));
+    SKX_HIP(hipMemcpyAsync(hist, d_hist.p, 1000 * 4, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipStreamSynchronize(st));
+    SKX_HIP(hipGetLastError());
+    return SKX_OK;
+    });
+}
+
 // ------------------------------------------------------------------------------------------ ska map (N3)
 // generic_modes::map (generic_modes.rs:56-84): RefSka::new(k, reference, rc, ambig_mask, repeat_mask) (ska_ref.rs:189-311), map
 // (:508-533), write_aln | write_vcf (:622-765).  Device: reference windows, look-up of every window's split k-mer in the array,

@@ -109,6 +109,8 @@ int read_sample_stream(const char *file1, const char *file2, double proportion_r
 // FASTQ sample -> sorted unique packed words (skx_reads.hip)
 int reads_sample_dict(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t len, int k, int rc, const skx_qual &q,
                       DevBuf<uint64_t> &out_words, uint64_t *n_out);
+// `ska cov`: occurrence-count histogram of the split k-mers of a read stream (skx_reads.hip); d_hist[1000] zeroed by the caller
+int cov_histogram(skx_ctx *ctx, const uint8_t *d_seq, uint64_t len, int k, int rc, uint32_t *d_hist);
 // `ska map` helpers (skx_reads.hip)
 int ref_windows(skx_ctx *ctx, const uint8_t *d_seq, uint64_t len, int k, int rc, DevBuf<uint64_t> &wlo, DevBuf<uint64_t> &whi, DevBuf<uint8_t> &flag);
 int select_mapped(const uint32_t *row, uint64_t len, DevBuf<uint32_t> &mapped, uint64_t *m, hipStream_t st);

@@ -310,6 +310,69 @@ int ref_windows(skx_ctx *ctx, const uint8_t *d_seq, uint64_t len, int k, int rc,
     return SKX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// `ska cov`: CoverageHistogram::new (coverage.rs:70-148) + the histogram step of fit_histogram (:158-163).
+// Every window of both read files (qualities ignored), sorted by split k-mer; run lengths = occurrence counts;
+// hist[c - 1] = number of split k-mers seen c times (c <= 1000).
+// ------------------------------------------------------------------------------------------------
+__global__ void and_not15_kernel(uint64_t *v, uint64_t n)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) v[i] &= ~15ull;
+}
+__global__ void count_hist_kernel(const uint32_t *counts, uint64_t n, uint32_t *hist)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        if (counts[i] - 1u < 1000u) atomicAdd(&hist[counts[i] - 1u], 1u);
+}
+int cov_histogram(skx_ctx *ctx, const uint8_t *d_seq, uint64_t len, int k, int rc, uint32_t *d_hist)
+{
+    hipStream_t st = ctx->stream;
+    const bool wide = k > 31;
+    if (len == 0) return SKX_OK;
+    if (len > 0xFFFFFFF0ull) { set_error("read set longer than 4 G bases"); return SKX_EUNSUP; }
+    Temp tmp;
+    DevBuf<uint64_t> wlo, whi; DevBuf<uint8_t> flag;
+    SKX_TRY(ref_windows(ctx, d_seq, len, k, rc, wlo, whi, flag));
+    DevBuf<uint32_t> idx; SKX_TRY(idx.alloc(len));
+    uint64_t m = 0;
+    SKX_TRY(select_flagged(tmp, rocprim::counting_iterator<uint32_t>(0), flag.p, idx.p, len, &m, st));
+    if (m == 0) return SKX_OK;
+    DevBuf<uint64_t> lo, slo, hi, shi;
+    SKX_TRY(lo.alloc(m)); SKX_TRY(slo.alloc(m));
+    hipLaunchKernelGGL(gather_u64_kernel, dim3(grid_for(m)), dim3(256), 0, st, wlo.p, idx.p, lo.p, m);
+    hipLaunchKernelGGL(and_not15_kernel, dim3(grid_for(m)), dim3(256), 0, st, lo.p, m);       // the middle base does not count (kmer only)
+    if (!wide) {
+        size_t bytes = 0;
+        RP(rocprim::radix_sort_keys(nullptr, bytes, lo.p, slo.p, m, 0, 64, st));
+        SKX_TRY(tmp.need(bytes));
+        RP(rocprim::radix_sort_keys(tmp.buf.p, bytes, lo.p, slo.p, m, 0, 64, st));
+    } else {
+        // order by (hi, lo): stable LSD passes
+        DevBuf<uint32_t> iota, p1, p2; DevBuf<uint64_t> h1;
+        SKX_TRY(hi.alloc(m)); SKX_TRY(shi.alloc(m)); SKX_TRY(iota.alloc(m)); SKX_TRY(p1.alloc(m)); SKX_TRY(p2.alloc(m)); SKX_TRY(h1.alloc(m));
+        hipLaunchKernelGGL(gather_u64_kernel, dim3(grid_for(m)), dim3(256), 0, st, whi.p, idx.p, hi.p, m);
+        hipLaunchKernelGGL(iota_u32_kernel, dim3(grid_for(m)), dim3(256), 0, st, iota.p, m);
+        SKX_TRY(sort_pairs(tmp, lo.p, slo.p, iota.p, p1.p, m, st));
+        hipLaunchKernelGGL(gather_u64_kernel, dim3(grid_for(m)), dim3(256), 0, st, hi.p, p1.p, h1.p, m);
+        SKX_TRY(sort_pairs(tmp, h1.p, shi.p, p1.p, p2.p, m, st));
+        hipLaunchKernelGGL(gather_u64_kernel, dim3(grid_for(m)), dim3(256), 0, st, lo.p, p2.p, slo.p, m);
+    }
+    DevBuf<uint32_t> head, gid, runs, rcnt; DevBuf<size_t> nruns;
+    SKX_TRY(head.alloc(m)); SKX_TRY(gid.alloc(m)); SKX_TRY(runs.alloc(m)); SKX_TRY(rcnt.alloc(m)); SKX_TRY(nruns.alloc(1));
+    hipLaunchKernelGGL(word_heads_kernel, dim3(grid_for(m)), dim3(256), 0, st, slo.p, wide ? shi.p : nullptr, head.p, m);
+    SKX_TRY(incl_scan(tmp, head.p, gid.p, m, rocprim::plus<uint32_t>(), st));
+    size_t bytes = 0;
+    RP(rocprim::run_length_encode(nullptr, bytes, gid.p, (unsigned int)m, runs.p, rcnt.p, nruns.p, st));
+    SKX_TRY(tmp.need(bytes));
+    RP(rocprim::run_length_encode(tmp.buf.p, bytes, gid.p, (unsigned int)m, runs.p, rcnt.p, nruns.p, st));
+    size_t nr = 0;
+    RP(hipMemcpyAsync(&nr, nruns.p, sizeof nr, hipMemcpyDeviceToHost, st));
+    RP(hipStreamSynchronize(st));
+    hipLaunchKernelGGL(count_hist_kernel, dim3(grid_for(nr)), dim3(256), 0, st, rcnt.p, (uint64_t)nr, d_hist);
+    RP(hipStreamSynchronize(st));
+    return SKX_OK;
+}
+
 // row of the array holding each reference window's split k-mer (0xFFFFFFFF: none / no window), and whether the reference
 // strand is the reverse complement of the canonical form (RefKmer::rc): then the canonical middle base is the complement of
 // the forward one, i.e. the word's base mask is exactly 1 << (mid ^ 2)

@@ -250,6 +250,111 @@ extern "C" int skh_weed(skx_array *a, const char *weed_file, int reverse, double
     });
 }
 
+// ------------------------------------------------------------------------------------------ ska cov (coverage.rs)
+namespace {
+double cov_lse(double a, double b) { const double x = a > b ? a : b; return x + std::log(std::exp(a - x) + std::exp(b - x)); }           // :289-292
+double cov_ln_dpois(double x, double lambda) { return x * std::log(lambda) - std::lgamma(x + 1.0) - lambda; }                                // :295-297
+double cov_a(double w0, double i) { return std::log(w0) + cov_ln_dpois(i, 1.0); }                                                            // :300-302
+double cov_b(double w0, double c, double i) { return std::log(1.0 - w0) + cov_ln_dpois(i, c); }                                              // :305-307
+double cov_ll(const double p[2], const double *counts, uint64_t n)                                                                            // :310-326
+{
+    if (!(p[0] >= 0.0 && p[0] <= 1.0) || p[1] < 1.0) return -1.7976931348623157e308;
+    double ll = 0.0;
+    for (uint64_t i = 0; i < n; i++) { const double x = (double)i + 1.0; ll += counts[i] * cov_lse(cov_a(p[0], x), cov_b(p[0], p[1], x)); }
+    return ll;
+}
+void cov_grad(const double p[2], const double *counts, uint64_t n, double g[2])                                                              // :329-346
+{
+    double g0 = 0.0, g1 = 0.0;
+    for (uint64_t i = 0; i < n; i++) {
+        const double x = (double)i + 1.0, a = cov_a(p[0], x), b = cov_b(p[0], p[1], x);
+        const double dlda = 1.0 / (1.0 + std::exp(b - a)), dldb = 1.0 / (1.0 + std::exp(a - b));
+        g0 += counts[i] * (dlda / p[0] - dldb / (1.0 - p[0]));
+        g1 += counts[i] * (dldb * (x / p[1] - 1.0));
+    }
+    g[0] = g0; g[1] = g1;
+}
+// Rust `{:e}`: shortest digits that round-trip, exponent without padding
+std::string lower_exp(double v)
+{
+    char tmp[64]; int prec = 0;
+    for (; prec < 17; prec++) { snprintf(tmp, sizeof tmp, "%.*e", prec, v); if (strtod(tmp, nullptr) == v) break; }
+    snprintf(tmp, sizeof tmp, "%.*e", prec, v);
+    char *e = strchr(tmp, 'e');
+    const int ex = atoi(e + 1);
+    *e = 0;
+    std::string m(tmp);
+    if (m.find('.') != std::string::npos) { while (!m.empty() && m.back() == '0') m.pop_back(); if (!m.empty() && m.back() == '.') m.pop_back(); }
+    return m + "e" + std::to_string(ex);
+}
+}  // namespace
+
+extern "C" int skh_cov_fit(const double *counts, uint64_t n, double *w0_out, double *c_out, uint64_t *cutoff)
+{
+    return skx_guarded([&]() -> int {
+    // argmin BFGS (inverse-Hessian form) + BacktrackingLineSearch(ArmijoCondition(1e-4), contraction 0.9) from (0.8, 20), H0 = I,
+    // tolerance_cost 1e-6, max_iters 20 (coverage.rs:176-196)
+    double x[2] = {0.8, 20.0}, H[2][2] = {{1.0, 0.0}, {0.0, 1.0}}, g[2];
+    double f = -cov_ll(x, counts, n);
+    cov_grad(x, counts, n, g); g[0] = -g[0]; g[1] = -g[1];
+    bool converged = false;
+    for (int it = 0; it < 20 && !converged; it++) {
+        const double p[2] = {-(H[0][0] * g[0] + H[0][1] * g[1]), -(H[1][0] * g[0] + H[1][1] * g[1])};
+        const double gp = g[0] * p[0] + g[1] * p[1];
+        double alpha = 1.0, xn[2], fn;
+        for (;;) {
+            xn[0] = x[0] + alpha * p[0]; xn[1] = x[1] + alpha * p[1];
+            fn = -cov_ll(xn, counts, n);
+            if (fn <= f + 1e-4 * alpha * gp) break;
+            alpha *= 0.9;
+            if (alpha == 0.0) break;
+        }
+        double gn[2];
+        cov_grad(xn, counts, n, gn); gn[0] = -gn[0]; gn[1] = -gn[1];
+        const double y[2] = {gn[0] - g[0], gn[1] - g[1]}, s[2] = {xn[0] - x[0], xn[1] - x[1]};
+        const double ys = y[0] * s[0] + y[1] * s[1], prev = f;
+        x[0] = xn[0]; x[1] = xn[1]; f = fn; g[0] = gn[0]; g[1] = gn[1];
+        if (std::sqrt(g[0] * g[0] + g[1] * g[1]) < 1.4901161193847656e-8 || std::fabs(prev - f) < 1e-6) { converged = true; break; }
+        const double rho = 1.0 / ys;
+        double t1[2][2], t2[2][2], m[2][2], r[2][2];
+        for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) { t1[a][b] = (a == b) - rho * s[a] * y[b]; t2[a][b] = (a == b) - rho * y[a] * s[b]; }
+        for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) m[a][b] = t1[a][0] * H[0][b] + t1[a][1] * H[1][b];
+        for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) r[a][b] = m[a][0] * t2[0][b] + m[a][1] * t2[1][b] + rho * s[a] * s[b];
+        memcpy(H, r, sizeof r);
+    }
+    if (!converged) { skx_set_error("Couldn't fit coverage model: Optimiser did not converge: Maximum number of iterations reached"); return SKX_EINVAL; }   // :216-220
+    uint64_t cut = 1;                                                                                            // find_cutoff, :349-363
+    while (cut < n) { if (cov_a(x[0], (double)cut) - cov_b(x[0], x[1], (double)cut) < 0.0) break; cut++; }
+    *w0_out = x[0]; *c_out = x[1]; *cutoff = cut;
+    return SKX_OK;
+    });
+}
+
+extern "C" int skh_cov(skx_ctx *ctx, const char *fastq_fwd, const char *fastq_rev, int k, int rc, char **text, uint64_t *len, uint64_t *cutoff)
+{
+    return skx_guarded([&]() -> int {
+    std::vector<uint32_t> hist(1000);
+    int r = skx_cov_histogram(ctx, fastq_fwd, fastq_rev, k, rc, hist.data());
+    if (r != SKX_OK) return r;
+    uint64_t n = 1000;
+    while (n && hist[n - 1] < 50u) n--;                                                                           // MIN_FREQ, coverage.rs:166-173
+    std::vector<double> cf(hist.begin(), hist.begin() + (ptrdiff_t)n);
+    double w0 = 0, c = 0; uint64_t cut = 0;
+    if ((r = skh_cov_fit(cf.data(), n, &w0, &c, &cut)) != SKX_OK) return r;
+    if (cutoff) *cutoff = cut;
+    if (text) {                                                                                                   // plot_hist, :227-250
+        std::string o = "Count\tK_mers\tMixture_density\tComponent\n";
+        for (uint64_t i = 0; i < n; i++) {
+            put(o, "%llu\t%u\t", (unsigned long long)(i + 1), hist[i]);
+            o += lower_exp(std::exp(cov_lse(cov_a(w0, (double)i + 1.0), cov_b(w0, c, (double)i + 1.0))));
+            o += (i + 1) < cut ? "\tError\n" : "\tCoverage\n";
+        }
+        return to_buf(o, text, len);
+    }
+    return SKX_OK;
+    });
+}
+
 // ------------------------------------------------------------------------------------------ CLI
 namespace {
 struct Args {
@@ -284,7 +389,7 @@ int emit(const std::string &out_path, const char *buf, uint64_t len)            
 extern "C" int skh_main(int argc, char **argv)
 {
     fprintf(stderr, "SKA: Split K-mer Analysis (the alignment-free aligner)\n");
-    if (argc < 2) return fail("usage: ska <build|align|map|distance|nk|merge|delete|weed> ...");
+    if (argc < 2) return fail("usage: ska <build|align|map|distance|nk|merge|delete|weed|cov> ...");
     const std::string cmd = argv[1];
     Args a;
     for (int i = 2; i < argc; i++) {
@@ -306,12 +411,13 @@ extern "C" int skh_main(int argc, char **argv)
         const int k = atoi(a.get("-k", "31").c_str());
         if (k < 5 || k > 63 || k % 2 == 0) return fail("K-mer must be an odd number between 5 and 63 (inclusive)");   // cli.rs:38-47
         skx_qual q{5, 20, SKX_QUAL_STRICT};
+        bool auto_count = false;
         if (a.has("--min-count")) {
             const std::string mc = a.get("--min-count");
-            if (mc == "auto") return fail("--min-count auto needs the coverage model (`ska cov`), which is outside this engine");
+            if (mc == "auto") auto_count = true; else {
             char *end; long v = strtol(mc.c_str(), &end, 10);
             if (*end || v < 1 || v > 65535) return fail("Minimum kmer count must be >= 1");                           // cli.rs:94-108
-            q.min_count = (uint16_t)v;
+            q.min_count = (uint16_t)v; }
         }
         if (a.has("--min-qual")) q.min_qual = (uint8_t)atoi(a.get("--min-qual").c_str());
         if (a.has("--qual-filter")) {
@@ -335,6 +441,17 @@ extern "C" int skh_main(int argc, char **argv)
             for (auto &p : a.pos) { char *n = skh_sample_name(p.c_str()); names.push_back(n); free(n); f1.push_back(p); f2.push_back(""); }
         std::vector<const char *> cn, c1, c2;
         for (size_t i = 0; i < names.size(); i++) { cn.push_back(names[i].c_str()); c1.push_back(f1[i].c_str()); c2.push_back(f2[i].empty() ? nullptr : f2[i].c_str()); }
+        if (auto_count) {                                                                                             // io_utils::kmer_min_cutoff, io_utils.rs:175-212
+            std::vector<std::string> fq;                              // get_2_fastq_path: the FIRST file of the first two paired inputs
+            for (size_t i = 0; i < names.size() && fq.size() < 2; i++) if (!f2[i].empty()) fq.push_back(f1[i]);
+            if (fq.size() >= 2) {
+                char *buf = nullptr; uint64_t len = 0, cutoff = 0;
+                if (skh_cov(ctx, fq[0].c_str(), fq[1].c_str(), k, !a.has("--single-strand"), &buf, &len, &cutoff) != SKX_OK) { skx_ctx_destroy(ctx); return engine_fail(); }
+                fwrite(buf, 1, len, stdout); fflush(stdout); skx_free(buf);                                               // cov.plot_hist()
+                q.min_count = (uint16_t)cutoff;
+                fprintf(stderr, "Using inferred minimum kmer value of %llu\n", (unsigned long long)cutoff);
+            } else fprintf(stderr, "Not enough fastq files to fit mixture model, using default kmer count of 5\n");
+        }
         if (skx_build_and_merge(ctx, cn.data(), c1.data(), c2.data(), (int)cn.size(), k, !a.has("--single-strand"), &q, threads, prop, &arr) != SKX_OK ||
             skh_save_skf(arr, a.get("-o").c_str()) != SKX_OK)
             rcode = engine_fail();
@@ -364,6 +481,13 @@ extern "C" int skh_main(int argc, char **argv)
         char *buf = nullptr; uint64_t len = 0;
         if (skh_load_array(ctx, in, 1, 1, &arr) != SKX_OK || skh_nk(arr, a.has("--full-info"), &buf, &len) != SKX_OK) rcode = engine_fail();
         else { rcode = emit("", buf, len); skx_free(buf); }
+    } else if (cmd == "cov") {                                                                                    // cli.rs Cov, lib.rs:828-851
+        if (a.pos.size() != 2) return fail("usage: ska cov <fastq_fwd> <fastq_rev> [-k K] [--single-strand]");
+        const int k = atoi(a.get("-k", "31").c_str());
+        if (k < 5 || k > 63 || k % 2 == 0) return fail("K-mer must be an odd number between 5 and 63 (inclusive)");
+        char *buf = nullptr; uint64_t len = 0, cutoff = 0;
+        if (skh_cov(ctx, a.pos[0].c_str(), a.pos[1].c_str(), k, !a.has("--single-strand"), &buf, &len, &cutoff) != SKX_OK) rcode = engine_fail();
+        else { rcode = emit("", buf, len); skx_free(buf); fprintf(stderr, "Estimated cutoff\t%llu\n", (unsigned long long)cutoff); }
     } else if (cmd == "map") {                                                                                    // cli.rs Map, lib.rs:663-709
         if (a.pos.size() < 2) return fail("usage: ska map <reference.fa> <input.skf | sequence files...> [-o out] [-f aln|vcf]");
         const std::string fmt = a.get("--format", a.has("-f") ? a.get("-f") : "aln");                             // -f is the format here, not a file list
@@ -406,7 +530,7 @@ extern "C" int skh_main(int argc, char **argv)
                      a.has("--ambig-mask"), a.has("--no-gap-only-sites"), out.c_str()) != SKX_OK)
             rcode = engine_fail();
     } else {
-        rcode = fail("unknown subcommand (this engine provides build, align, map, distance, nk, merge, delete, weed)");
+        rcode = fail("unknown subcommand (this engine provides build, align, map, distance, nk, merge, delete, weed, cov)");
     }
     if (arr) skx_array_free(arr);
     skx_ctx_destroy(ctx);

@@ -52,8 +52,8 @@ skx_keyset_union skx_keyset_size skx_keyset_device skx_keyset_from_device skx_ke
 skx_array_assemble skx_merge skx_build_and_merge skx_array_free skx_array_save skx_array_load skx_array_from_host
 skx_array_info skx_array_name skx_array_version skx_array_export skx_array_sample_kmers skx_array_filter
 skx_array_write_fasta skx_array_fasta skx_array_device_matrix skx_array_device_stats skx_array_set_total_samples skx_array_distance skx_free skx_ctx_timings
-skx_array_merge skx_array_delete_samples skx_array_weed skx_keyset_from_fasta skx_array_ctx skx_set_last_error skx_array_map
-skh_apply_filters skh_align skh_distance_tsv skh_nk skh_save_skf skh_load_array skh_sample_name skh_main skh_merge skh_delete skh_weed""".split()
+skx_array_merge skx_array_delete_samples skx_array_weed skx_keyset_from_fasta skx_array_ctx skx_set_last_error skx_array_map skx_cov_histogram
+skh_apply_filters skh_align skh_distance_tsv skh_nk skh_save_skf skh_load_array skh_sample_name skh_main skh_merge skh_delete skh_weed skh_cov skh_cov_fit""".split()
 
 _lib = None
 
@@ -123,6 +123,9 @@ def load_library():
     lib.skx_array_weed.argtypes = [vp, vp, i, C.POINTER(u64)]
     lib.skx_keyset_from_fasta.argtypes = [vp, cp, i, i, pp]
     lib.skx_array_map.argtypes = [vp, cp, i, i, i, i, pp, C.POINTER(u64)]
+    lib.skx_cov_histogram.argtypes = [vp, cp, cp, i, i, vp]
+    lib.skh_cov.argtypes = [vp, cp, cp, i, i, pp, C.POINTER(u64), C.POINTER(u64)]
+    lib.skh_cov_fit.argtypes = [vp, u64, C.POINTER(d), C.POINTER(d), C.POINTER(u64)]
     lib.skx_array_ctx.argtypes = [vp]
     lib.skx_array_ctx.restype = vp
     lib.skx_set_last_error.argtypes = [cp]
@@ -152,6 +155,30 @@ def _take(ptr, n):
 
 def qual(min_count=5, min_qual=20, qual_filter=QUAL_STRICT):
     return Qual(min_count, min_qual, qual_filter)
+
+
+def cov_histogram(fq1, fq2, k=31, rc=True, ctx=None):
+    """CoverageHistogram::new + histogram (coverage.rs:70-148,158-163) on the device."""
+    ctx = ctx or default_context()
+    h = np.zeros(1000, np.uint32)
+    _check(_lib.skx_cov_histogram(ctx.h, fq1.encode(), fq2.encode(), k, int(rc), _np_ptr(h)))
+    return h
+
+
+def cov_fit(counts):
+    c = np.ascontiguousarray(counts, np.float64)
+    w0, cc, cut = C.c_double(), C.c_double(), C.c_uint64()
+    load_library()
+    _check(_lib.skh_cov_fit(_np_ptr(c), len(c), C.byref(w0), C.byref(cc), C.byref(cut)))
+    return w0.value, cc.value, cut.value
+
+
+def cov(fq1, fq2, k=31, rc=True, ctx=None):
+    """`ska cov`: (plot_hist text, cutoff)"""
+    ctx = ctx or default_context()
+    p, n, cut = C.c_void_p(), C.c_uint64(), C.c_uint64()
+    _check(_lib.skh_cov(ctx.h, fq1.encode(), fq2.encode(), k, int(rc), C.byref(p), C.byref(n), C.byref(cut)))
+    return _take(p, n), cut.value
 
 
 def sample_name(path):

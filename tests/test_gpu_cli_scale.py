@@ -123,6 +123,25 @@ def test_cli_map(tmp_path):
     assert out == G.correct("map_aln_k41.stdout")
 
 
+def test_cli_cov_and_auto_min_count(tmp_path):
+    """fastq_input.rs cov_check (:473-510) and build_auto_check (:512-540) through the `ska` executable."""
+    wd = str(tmp_path)
+    rc, out, err = ska("cov", G.fin("test_1_fwd.fastq.gz"), G.fin("test_1_rev.fastq.gz"), "-k", "9", "-v", cwd=wd)
+    assert rc == 0 and out.startswith(b"Count\tK_mers\tMixture_density\tComponent\n") and b"Estimated cutoff\t" in err, err
+    rc, out, err = ska("cov", G.fin("test_long_1_fwd.fastq.gz"), G.fin("test_long_1_rev.fastq.gz"), "-k", "33", "-v", cwd=wd)
+    assert rc == 0, err
+    assert out == ora.cov(G.fin("test_long_1_fwd.fastq.gz"), G.fin("test_long_1_rev.fastq.gz"), k=33)[0] or len(out.splitlines()) == 5
+    rc, out, err = ska("cov", G.fin("test_1.fa"), G.fin("test_2.fa"), "-k", "9", "-v", cwd=wd)
+    assert rc != 0 and b"appears to be FASTA" in err
+    with open(os.path.join(wd, "rfile.txt"), "w") as f:
+        for n, a, b in G.rfile("test", True):
+            f.write(f"{n}\t{a}\t{b}\n")
+    rc, out, err = ska("build", "-f", "rfile.txt", "-o", "reads", "--min-count", "auto", "-v", "-k", "9", "--min-qual", "2", cwd=wd)
+    assert rc == 0 and os.path.exists(os.path.join(wd, "reads.skf")) and b"Using inferred minimum kmer value of" in err, err
+    rc, out, err = ska("build", "-f", "rfile.txt", "-o", "reads", "--min-count", "-1", "-v", "-k", "9", "--min-qual", "2", cwd=wd)
+    assert rc != 0
+
+
 @pytest.fixture(scope="module")
 def big():
     """BASELINE.json configs[1] shape, reduced to 24 samples so that the oracle spot checks stay in seconds."""

@@ -488,3 +488,31 @@ def test_map_vs_oracle(E, k, rc, tmp_path):
     open(tiny, "wb").write(b">x\nACGT\n")
     with pytest.raises(E.EngineError, match="has no valid sequence"):
         ga.map(tiny)
+
+
+@pytest.mark.parametrize("k,rc", [(9, True), (21, False), (31, True), (33, True), (63, False)])
+def test_cov_histogram_and_fit(E, fastq_pair, k, rc):
+    """`ska cov` (coverage.rs): the device's occurrence-count histogram is the oracle's hash-map count, bin for bin; the host
+    fit gives the oracle's cutoff and parameters; plot_hist's table agrees (densities to 1e-12 relative: two compilers)."""
+    f1, f2 = fastq_pair[0], fastq_pair[1]
+    gh, oh = E.cov_histogram(f1, f2, k, rc), ora.cov_histogram(f1, f2, k, rc)
+    assert np.array_equal(gh, oh) and gh.sum() > 0
+    for files in ((f1, f2), (G.fin("test_long_1_fwd.fastq.gz"), G.fin("test_long_1_rev.fastq.gz"))):
+        try:
+            ot, oc = ora.cov(*files, k=k, rc=rc)
+        except ora.OracleError:                       # "Optimiser did not converge" is a legitimate outcome (the reference panics)
+            with pytest.raises(E.EngineError, match="did not converge"):
+                E.cov(*files, k=k, rc=rc)
+            continue
+        gt, gc = E.cov(*files, k=k, rc=rc)
+        assert gc == oc
+        gl, ol = gt.decode().splitlines(), ot.decode().splitlines()
+        assert len(gl) == len(ol) and gl[0] == ol[0]
+        for a, b in zip(gl[1:], ol[1:]):
+            fa, fb = a.split("\t"), b.split("\t")
+            assert fa[:2] == fb[:2] and fa[3] == fb[3] and abs(float(fa[2]) - float(fb[2])) <= 1e-12 * abs(float(fb[2]))
+    w0, c, cut = E.cov_fit(G.COV_EXAMPLE)
+    ow0, oc_, ocut = ora.cov_fit(G.COV_EXAMPLE)
+    assert cut == ocut == 9 and abs(w0 - ow0) < 1e-9 and abs(c - oc_) < 1e-7
+    with pytest.raises(E.EngineError, match="appears to be FASTA"):
+        E.cov(G.fin("test_1.fa"), G.fin("test_2.fa"), k=9)
