@@ -3,6 +3,7 @@
 #include "skx_internal.h"
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -336,6 +337,7 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
     std::vector<int> rcodes(n, SKX_OK);
     std::vector<std::string> errs(n);
     int nt = std::max(1, std::min(threads, n));
+    const auto t_read0 = std::chrono::steady_clock::now();
     std::vector<std::thread> pool;
     for (int t = 0; t < nt; t++)
         pool.emplace_back([&, t]() {
@@ -345,11 +347,14 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
             }
         });
     for (auto &th : pool) th.join();
+    if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] build_files: %d samples read + parsed by %d threads in %.2f s\n", n, nt, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_read0).count());
     for (int i = 0; i < n; i++) if (rcodes[i] != SKX_OK) { set_error("%s", errs[i].c_str()); return rcodes[i]; }
     std::vector<skx_stream> ss(n);
     for (int i = 0; i < n; i++) { ss[i].seq = hs[i].seq.data(); ss[i].qual = hs[i].is_fastq ? hs[i].qual.data() : nullptr; ss[i].len = hs[i].seq.size(); }
     skx_dictset *d = nullptr;
+    const auto t_dev0 = std::chrono::steady_clock::now();
     int r = skx_dictset_build(ctx, ss.data(), n, 0, k, rc, q, &d);
+    if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] build_files: H2D + dictionaries in %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_dev0).count());
     if (r == SKX_EEMPTY) {      // "{file} has no valid sequence" (ska_dict.rs:374-376)
         int bad = 0; sscanf(skx_last_error(), "sample %d", &bad);
         set_error("%s has no valid sequence", file1[bad]);
