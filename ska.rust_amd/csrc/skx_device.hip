@@ -766,15 +766,21 @@ __global__ __launch_bounds__(1024, 8) void union_kernel(DictView d, int logN, ui
         const uint64_t *my_reg = nullptr; uint32_t my_lo = 0, my_hi = 0;
         const int cnt = wend - s0 < 64 ? wend - s0 : 64;
         if (lane < cnt) sub_slice(d, s0 + lane, j, logN, my_reg, my_lo, my_hi);
-        for (int t = 0; t < cnt; t++) {
-            gwords_t reg = as_global(reinterpret_cast<const uint64_t *>(__shfl((unsigned long long)my_reg, t, 64)));
-            const uint32_t lo = __shfl(my_lo, t, 64), hi = __shfl(my_hi, t, 64);
-            for (uint32_t i0 = lo; i0 < hi; i0 += 512) {
-                uint64_t wq[8];                               // 8 words per lane in flight per memory round trip (clamped, branch-free)
+        // the two halves of the wave stream two samples' slices at once: twice the loads in flight per wave
+        const int half = lane >> 5, hl = lane & 31;
+        for (int t = 0; t < cnt; t += 2) {
+            const int src = t + half < cnt ? t + half : t;                 // odd count: the upper half idles on the last round
+            gwords_t reg = as_global(reinterpret_cast<const uint64_t *>(__shfl((unsigned long long)my_reg, src, 64)));
+            const uint32_t lo = __shfl(my_lo, src, 64), hi_s = __shfl(my_hi, src, 64);        // (shuffles outside any lane-dependent branch)
+            const uint32_t hi = t + half < cnt ? hi_s : lo;
+            const uint32_t other_lo = __shfl(lo, lane ^ 32, 64), other_hi = __shfl(hi, lane ^ 32, 64);
+            const uint32_t span = hi - lo > other_hi - other_lo ? hi - lo : other_hi - other_lo;     // wave-uniform trip count
+            for (uint32_t o = 0; o < span; o += 320) {
+                uint64_t wq[10];
 #pragma unroll
-                for (int u = 0; u < 8; u++) { const uint32_t i = i0 + 64u * u + lane; wq[u] = i < hi ? reg[i] : 0ull; }
+                for (int u = 0; u < 10; u++) { const uint32_t i = lo + o + 32u * u + hl; wq[u] = i < hi ? reg[i] : 0ull; }
 #pragma unroll
-                for (int u = 0; u < 8; u++)
+                for (int u = 0; u < 10; u++)
                     if (wq[u] && !table_insert(s_tab, total_slots, home_slot(wq[u], rem_bits, nslots), wq[u])) s_fail = 1;
             }
         }
