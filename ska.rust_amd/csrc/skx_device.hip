@@ -530,11 +530,10 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
     if (n > cap || n > (uint32_t)NT * ITEMS) { if (threadIdx.x == 0) atomicOr(overflow, 2); return; }      // left to dedupe_kernel
     uint64_t *s_elem = reinterpret_cast<uint64_t *>(s_mem);                 // [cap]
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_mem + (size_t)cap * 8); // [M] counts -> cursors -> unique counts
-    uint32_t *s_start = s_cnt + cap / 2;                                     // [M] micro-bucket starts
-    int logM = 31 - __clz(n) - 1;                                            // ~2..4 words per micro-bucket
+    int logM = 31 - __clz(n);                                                // ~1..2 words per micro-bucket
     if (logM < 0) logM = 0;
     if (logM > rem_bits) logM = rem_bits;
-    while ((1u << logM) > cap / 2) logM--;
+    while ((1u << logM) > cap) logM--;
     const uint32_t M = 1u << logM;
     const int mshift = rem_bits - logM + 4;                                  // micro-bucket = word_field<HI>(w, mshift, M - 1)
     uint64_t *reg = words + off[region];
@@ -553,7 +552,7 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
     uint32_t sum = 0;
     for (uint32_t m = m0; m < m1; m++) sum += s_cnt[m];
     uint32_t run = block_excl_scan(sum, s_tmp, nullptr);
-    for (uint32_t m = m0; m < m1; m++) { uint32_t c = s_cnt[m]; s_start[m] = run; s_cnt[m] = run; run += c; }
+    for (uint32_t m = m0; m < m1; m++) { uint32_t c = s_cnt[m]; s_cnt[m] = run; run += c; }      // start of m; the scatter below turns it into its end = start of m + 1
     __syncthreads();
     uint32_t pos[ITEMS];
 #pragma unroll
@@ -561,7 +560,6 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
         pos[t] = 0;
         if (e[t]) { pos[t] = atomicAdd(&s_cnt[word_field<HI>(e[t], mshift, M - 1)], 1u); s_elem[pos[t]] = e[t]; }
     }
-    if (threadIdx.x == 0) s_start[M] = n;
     __syncthreads();
     // rank every word inside its micro-bucket (all words in parallel, 4 LDS reads in flight per step): sorted position =
     // start + #smaller keys + #equal keys at lower positions; equal keys also fold their base masks together
@@ -576,7 +574,7 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) asm volatile("" : "+v"(e[t]));
 #pragma unroll
-    for (int t = 0; t < ITEMS; t++) { const uint32_t m = word_field<HI>(e[t], mshift, M - 1); bb[t] = s_start[m]; ee[t] = s_start[m + 1]; }
+    for (int t = 0; t < ITEMS; t++) { const uint32_t m = word_field<HI>(e[t], mshift, M - 1); bb[t] = m ? s_cnt[m - 1] : 0u; ee[t] = s_cnt[m]; }
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) asm volatile("" : "+v"(bb[t]), "+v"(ee[t]));
 #pragma unroll
@@ -596,16 +594,17 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
             less += valid && w < w0lo;
             dup |= valid && j != p && (((uint32_t)(x >> 32) | ((uint32_t)x >> 4)) == 0u);
         };
-        // micro-buckets hold ~2.4 words: the first four slots are straight-line code (reads past the bucket stay inside
-        // the LDS carve and are masked), longer buckets finish in a loop
-        uint64_t wq[4];
+        // the first slots are straight-line code (reads past the bucket stay inside the LDS carve and are masked), longer
+        // buckets finish in a loop
+        constexpr uint32_t NS = 4;                                             // micro-buckets hold ~1.2 words on average
+        uint64_t wq[NS];
 #pragma unroll
-        for (uint32_t u = 0; u < 4; u++) wq[u] = s_elem[b + u];              // four reads in flight, whatever the bucket's size
+        for (uint32_t u = 0; u < NS; u++) wq[u] = s_elem[b + u];             // reads in flight whatever the bucket's size
 #pragma unroll
-        for (uint32_t u = 0; u < 4; u++) asm volatile("" : "+v"(wq[u]));      // (keeps the compiler from sinking each read into its own branch)
+        for (uint32_t u = 0; u < NS; u++) asm volatile("" : "+v"(wq[u]));     // (keeps the compiler from sinking each read into its own branch)
 #pragma unroll
-        for (uint32_t u = 0; u < 4; u++) step(b + u, wq[u], b + u < eend);
-        for (uint32_t j = b + 4; j < eend; j++) step(j, s_elem[j], true);
+        for (uint32_t u = 0; u < NS; u++) step(b + u, wq[u], b + u < eend);
+        for (uint32_t j = b + NS; j < eend; j++) step(j, s_elem[j], true);
         if (dup)
             for (uint32_t j = b; j < eend; j++) {
                 const uint64_t w = s_elem[j];
