@@ -529,7 +529,7 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
     if (n == 0) { if (threadIdx.x == 0) ucnt[region] = 0; return; }
     if (n > cap || n > (uint32_t)NT * ITEMS) { if (threadIdx.x == 0) atomicOr(overflow, 2); return; }      // left to dedupe_kernel
     uint64_t *s_elem = reinterpret_cast<uint64_t *>(s_mem);                 // [cap]
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_mem + (size_t)cap * 8); // [M] counts -> cursors -> unique counts
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_mem + (size_t)cap * 8) + 1;   // [-1] = 0 | [M] counts -> cursors (= bucket ends) -> leader counts
     int logM = 31 - __clz(n);                                                // ~1..2 words per micro-bucket
     if (logM < 0) logM = 0;
     if (logM > rem_bits) logM = rem_bits;
@@ -542,6 +542,7 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) { const uint32_t i = threadIdx.x + (uint32_t)NT * t; e[t] = i < n ? reg[i] : 0ull; }
     for (uint32_t i = threadIdx.x; i < M; i += NT) s_cnt[i] = 0;
+    if (threadIdx.x == 0) s_cnt[-1] = 0;                                     // end of the bucket before the first
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) if (e[t]) atomicAdd(&s_cnt[word_field<HI>(e[t], mshift, M - 1)], 1u);
@@ -574,7 +575,7 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) asm volatile("" : "+v"(e[t]));
 #pragma unroll
-    for (int t = 0; t < ITEMS; t++) { const uint32_t m = word_field<HI>(e[t], mshift, M - 1); bb[t] = m ? s_cnt[m - 1] : 0u; ee[t] = s_cnt[m]; }
+    for (int t = 0; t < ITEMS; t++) { const uint32_t m = word_field<HI>(e[t], mshift, M - 1); bb[t] = s_cnt[(int)m - 1]; ee[t] = s_cnt[m]; }
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) asm volatile("" : "+v"(bb[t]), "+v"(ee[t]));
 #pragma unroll
@@ -621,7 +622,7 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
     __syncthreads();
     // keep the first word of every run of equal keys; compaction index from wave ballots + a tiny per-row table
     constexpr int NW = NT / 64;
-    uint32_t *s_rows = s_cnt;                               // [ITEMS][NW] leaders per (row, wave); counters are dead now
+    uint32_t *s_rows = s_cnt;                               // [ITEMS][NW] leaders per (row, wave); the cursors are dead now
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t flags = 0, sflags = 0, below[ITEMS];
     const int subshift = rem_bits - sb + 4;                 // sub-range of a word = its next sb hash bits
