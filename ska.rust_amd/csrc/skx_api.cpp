@@ -201,7 +201,9 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
     HashParams hp = make_hash_params(std::min(k, 31));
     WideHash wh = make_wide_hash(k);
     const int key_bits_used = 2 * (k - 1);
-    const uint64_t per_region = 4096;                                           // target windows per bucket (upper bound)
+    // windows per bucket (upper bound): the 64-bit dedupe sorts up to 6 144 words per region in LDS and the regions get 20 % + 256
+    // words of head-room, so 4 900 is the largest mean that fits -- and the largest buckets give the scatter its widest chunks
+    const uint64_t per_region = wide ? 4096 : 4900;
     int logB = std::min({ilog2_ceil((maxlen + per_region - 1) / per_region), key_bits_used, MAX_LOGB});
     if (logB < 0) logB = 0;
 

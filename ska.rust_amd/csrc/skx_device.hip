@@ -293,12 +293,13 @@ static void launch_extract_t(const ExtractArgs &a, hipStream_t st)
 template <bool SCATTER>
 static void launch_extract(const ExtractArgs &a, hipStream_t st)
 {
-    // 16 384 positions x 1 024 threads while the two [B] LDS arrays leave room for the staging buffer, else half of that
     const bool hi = a.hp.bits + 4 - 32 - a.logB >= 0;
     if (extract_tile_bases(a.logB) == 16384) { if (hi) launch_extract_t<SCATTER, 16384, true, 16>(a, st); else launch_extract_t<SCATTER, 16384, false, 16>(a, st); }
     else { if (hi) launch_extract_t<SCATTER, 8192, true, 16>(a, st); else launch_extract_t<SCATTER, 8192, false, 16>(a, st); }
 }
-int extract_tile_bases(int logB) { return logB <= 11 ? 16384 : 8192; }
+// 8 192 positions x 512 threads (two workgroups per CU) while a (tile, bucket) chunk still averages >= 8 words, 16 384 x 1 024
+// (one per CU) for 2 048 buckets, 8 192 again when the two [B] LDS arrays leave no room for the larger staging buffer
+int extract_tile_bases(int logB) { return logB == 11 ? 16384 : 8192; }
 void launch_hist(const ExtractArgs &a, hipStream_t st) { launch_extract<false>(a, st); }
 void launch_scatter(const ExtractArgs &a, hipStream_t st) { launch_extract<true>(a, st); }
 
@@ -690,7 +691,7 @@ void launch_dedupe_mb(uint64_t *words, const uint64_t *off, const uint32_t *raw,
     // the words each finish a region sooner and put twice the waves on a CU (the LDS footprint fixes 4 regions per CU).
     if (cap <= 512u * 4) launch_dedupe_items<4, 512>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);
     else if (cap <= 512u * 7) launch_dedupe_items<7, 512>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);
-    else launch_dedupe_items<12, 512>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);     // host keeps regions <= 6144 words
+    else launch_dedupe_items<6, 1024>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);    // host keeps regions <= 6144 words
 }
 
 // pointers that reach a kernel inside an argument struct are generic (flat_load: slower, and it also ticks the LDS
