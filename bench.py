@@ -227,6 +227,7 @@ def main():
         ds = E.DictSet.build_device(ptrs, lens, args.k, True, ctx=ctx)
         n_distinct = int(sum(ds.size(i) for i in range(G)))
         ds.free()
+    res = None
     if rank == 0:
         steps = max(args.steps, 1)
         scatter_ms = tm["scatter"] / steps
@@ -258,9 +259,18 @@ def main():
             res["check"] = check
         if world == 1 and args.cpu_genomes > 0:
             res["cpu_baseline"] = cpu_baseline(args, anc, n_total)
-        print(json.dumps(res))
     if sharded:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner through C stdio, which is flushed at exit: push it out first so that the
+        # JSON line is the last line of stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":
