@@ -11,9 +11,14 @@
  * Parity pinning: the real `ska` binary cannot be built in this image (no
  * Rust toolchain, unvendored deps), so the restatement is pinned against the
  * reference's own committed fixtures (tests/golden/): the four .skf files
- * written by the Rust binary, every *.dist.stdout / nk / align golden and the
- * inline expectations of tests/{align,fasta_input,fastq_input,distance}.rs.
- * See tests/test_oracle_golden.py.
+ * written by the Rust binary, every *.dist.stdout / nk / align golden, the
+ * inline expectations of tests/{align,fasta_input,fastq_input,distance}.rs,
+ * the skf_ops.rs goldens (merge / delete / weed) and the 19 map_* goldens of
+ * tests/map.rs.  See tests/test_oracle_golden.py.
+ * One part is pinned only by a single known answer: the mixture fit of
+ * `ska cov` (ora_cov.c) restates the argmin crate's optimiser, which is not in
+ * /root/reference; the reference's unit-test vector (coverage.rs:369-385 ->
+ * cutoff 9) is reproduced, nothing else constrains its iterates.
  */
 #ifndef SKA_ORACLE_H
 #define SKA_ORACLE_H
