@@ -348,9 +348,11 @@ static uint32_t SFX(mdict_new_row)(SFX(mdict) *m)
     uint32_t r = (uint32_t)((m->n_chunks - 1) * ORA_MROWS + m->rows_in_last++);
     return r + 1;
 }
+/* the merged map hashes with another seed than the per-sample maps (hashbrown gives every map its own RandomState):
+ * feeding a linear-probing table in the slot order of a table with the SAME hash degenerates into long probe runs */
 static uint32_t *SFX(mdict_slot)(SFX(mdict) *m, KT key, int *found)
 {
-    size_t mask = m->cap - 1, i = (size_t)SFX(khash)(key) & mask;
+    size_t mask = m->cap - 1, i = (size_t)((SFX(khash)(key ^ (KT)0x5851F42D4C957F2DULL) * 0x9E3779B97F4A7C15ULL) >> 20) & mask;
     for (;;) {
         if (!m->rowid[i]) { m->keys[i] = key; *found = 0; return &m->rowid[i]; }
         if (m->keys[i] == key) { *found = 1; return &m->rowid[i]; }
