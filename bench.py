@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--genomes", type=int, default=1000, help="samples per GPU")
     ap.add_argument("--genome-len", type=int, default=5_000_000)
     ap.add_argument("-k", type=int, default=31)
-    ap.add_argument("--cpu-genomes", type=int, default=16, help="size of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-genomes", type=int, default=64, help="size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--check", action="store_true", help="verify a subsample of the result against the CPU oracle")
     return ap.parse_args()
 
