@@ -26,6 +26,7 @@ def test_bench_json_keys_and_oracle_use():
     src = open(os.path.join(ROOT, "bench.py")).read()
     tree = ast.parse(src)
     keys = {k.value for node in ast.walk(tree) if isinstance(node, ast.Dict) for k in node.keys if isinstance(k, ast.Constant) and isinstance(k.value, str)}
+    keys |= {n.slice.value for n in ast.walk(tree) if isinstance(n, ast.Subscript) and isinstance(n.slice, ast.Constant) and isinstance(n.slice.value, str)}
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "workload", "roofline", "bound", "achieved", "peak", "frac", "traffic", "cpu_baseline", "cores", "kind", "sample"):
         assert k in keys, k
