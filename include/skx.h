@@ -105,7 +105,11 @@ void skx_keyset_free(skx_keyset *ks);
 int  skx_array_assemble(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows, const char *const *names, skx_array **out);
 int  skx_merge(skx_ctx *ctx, skx_dictset *d, const char *const *names, skx_array **out);
 
-/* build_and_merge (merge_ska_dict.rs:354-417) + MergeSkaArray::new: the `ska build` body */
+/* build_and_merge (merge_ska_dict.rs:354-417) + MergeSkaArray::new: the `ska build` body.
+ * When the samples' dictionaries do not fit in free device memory together (estimate from the file sizes, 60 % of free
+ * HBM; SKX_BUILD_BATCH_MB overrides the budget), consecutive batches of samples are built and joined by the
+ * skx_array_merge row-set path; a batch that still runs out of memory is halved and retried.  Same rows, columns and
+ * sample order as a single batch. */
 int skx_build_and_merge(skx_ctx *ctx, const char *const *names, const char *const *file1, const char *const *file2,
                         int n_samples, int k, int rc, const skx_qual *qual, int threads, double proportion_reads,
                         skx_array **out);

@@ -14,6 +14,7 @@
 #include <numeric>
 #include <unordered_map>
 #include <thread>
+#include <sys/stat.h>
 #include <unistd.h>
 
 using namespace skx;
@@ -662,15 +663,75 @@ extern "C" int skx_merge(skx_ctx *ctx, skx_dictset *d, const char *const *names,
     });
 }
 
+// ---- `ska build` on more samples than fit in HBM at once ---------------------------------------------------------------
+// The per-sample dictionaries are the large transient (8-byte packed words, raw and deduplicated, per input base); the
+// array that survives is 1 byte per (row, sample).  A batch of samples whose dictionaries fit is built and merged into
+// an array, the batch arrays are then joined by the `ska merge` row-set path (skx_array_merge): the result has the same
+// rows and columns as one big batch (merge_ska_dict.rs:354-417 builds the same union through its tree of appends).
+static uint64_t sample_device_bytes(const char *f1, const char *f2, bool wide)
+{
+    uint64_t bases = 0;
+    for (const char *f : {f1, f2}) {
+        if (!f) continue;
+        struct stat sb;
+        if (stat(f, &sb) != 0) continue;                       // the reader reports a missing file
+        const size_t L = strlen(f);
+        const bool gz = L > 3 && !strcmp(f + L - 3, ".gz");
+        bases += (uint64_t)sb.st_size * (gz ? 5u : 1u);        // upper estimate: FASTQ text holds about half as many bases
+    }
+    return bases * (wide ? 44u : 24u) + (8u << 20);            // sequence + raw regions (with slack) + deduplicated words
+}
+static uint64_t cached_device_bytes() { std::lock_guard<std::mutex> lk(g_cache.mu); return g_cache.cached_bytes; }
+static uint64_t build_budget_bytes(skx_ctx *ctx)
+{
+    if (const char *e = getenv("SKX_BUILD_BATCH_MB")) return (uint64_t)std::max(1.0, atof(e)) << 20;
+    size_t fr = 0, tot = 0;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) return ~0ull;
+    return (uint64_t)(fr + cached_device_bytes()) / 10 * 6;
+}
+static int build_range(skx_ctx *ctx, const char *const *names, const char *const *file1, const char *const *file2, int lo, int hi,
+                       int k, int rc, const skx_qual *q, int threads, double proportion_reads, std::vector<skx_array *> &parts)
+{
+    skx_dictset *d = nullptr;
+    skx_array *a = nullptr;
+    int r = skx_dictset_build_files(ctx, file1 + lo, file2 ? file2 + lo : nullptr, hi - lo, k, rc, q, threads, proportion_reads, &d);
+    if (r == SKX_OK) { r = skx_merge(ctx, d, names + lo, &a); skx_dictset_free(d); }
+    if (r == SKX_ENOMEM && hi - lo > 1) {                      // the estimate was too low: halve the batch
+        dev_trim();
+        const int mid = lo + (hi - lo) / 2;
+        SKX_TRY(build_range(ctx, names, file1, file2, lo, mid, k, rc, q, threads, proportion_reads, parts));
+        return build_range(ctx, names, file1, file2, mid, hi, k, rc, q, threads, proportion_reads, parts);
+    }
+    if (r != SKX_OK) return r;
+    parts.push_back(a);
+    return SKX_OK;
+}
+
 extern "C" int skx_build_and_merge(skx_ctx *ctx, const char *const *names, const char *const *file1, const char *const *file2, int n,
                                    int k, int rc, const skx_qual *q, int threads, double proportion_reads, skx_array **out)
 {
     return skx_guarded([&]() -> int {
-    skx_dictset *d = nullptr;
-    SKX_TRY(skx_dictset_build_files(ctx, file1, file2, n, k, rc, q, threads, proportion_reads, &d));
-    int r = skx_merge(ctx, d, names, out);
-    skx_dictset_free(d);
-    return r;
+    if (!ctx || !names || !file1 || n <= 0 || !out) { set_error("bad arguments"); return SKX_EINVAL; }
+    SKX_TRY(check_k(k));
+    const uint64_t budget = build_budget_bytes(ctx);
+    std::vector<skx_array *> parts;
+    struct Drop { std::vector<skx_array *> &v; ~Drop() { for (auto *a : v) skx_array_free(a); } } drop{parts};
+    int r = SKX_OK, lo = 0;
+    while (lo < n && r == SKX_OK) {
+        uint64_t need = 0;
+        int hi = lo;
+        while (hi < n) {
+            const uint64_t s = sample_device_bytes(file1[hi], file2 ? file2[hi] : nullptr, k > 31);
+            if (hi > lo && need + s > budget) break;
+            need += s; hi++;
+        }
+        if (getenv("SKX_DEBUG") && (lo || hi < n)) fprintf(stderr, "[skx] build: samples %d..%d as one batch (estimate %.1f MB of %.1f MB)\n", lo, hi - 1, need / 1048576.0, budget / 1048576.0);
+        r = build_range(ctx, names, file1, file2, lo, hi, k, rc, q, threads, proportion_reads, parts);
+        lo = hi;
+    }
+    if (r != SKX_OK) return r;
+    if (parts.size() == 1) { *out = parts[0]; parts.clear(); return SKX_OK; }
+    return skx_array_merge(ctx, parts.data(), (int)parts.size(), out);
     });
 }
 

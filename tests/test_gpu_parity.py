@@ -516,3 +516,36 @@ def test_cov_histogram_and_fit(E, fastq_pair, k, rc):
     assert cut == ocut == 9 and abs(w0 - ow0) < 1e-9 and abs(c - oc_) < 1e-7
     with pytest.raises(E.EngineError, match="appears to be FASTA"):
         E.cov(G.fin("test_1.fa"), G.fin("test_2.fa"), k=9)
+
+
+@pytest.mark.parametrize("k,rc,batch_mb", [(31, True, 1), (31, False, 20), (41, True, 20), (15, True, 30)])
+def test_build_in_batches_equals_one_batch(E, k, rc, batch_mb, tmp_path, monkeypatch, capfd):
+    """`ska build` on more samples than the device-memory budget admits at once: batches of samples are built and joined by
+    the `ska merge` row-set path; rows, columns, names and counts must equal the single-batch build and the oracle's."""
+    rng = np.random.default_rng(900 + k + batch_mb)
+    _, samples = _related_samples(rng, 9, length=6000, snps=40)
+    samples[4] = samples[4] + rand_records(rng, 2, 500)
+    inputs = []
+    for i, recs in enumerate(samples):
+        p = tmp_path / f"b{i}.fa"
+        p.write_bytes(b"".join(b">r%d\n%s\n" % (j, r) for j, r in enumerate(recs)))
+        inputs.append((f"s{i}", str(p), None))
+    monkeypatch.delenv("SKX_BUILD_BATCH_MB", raising=False)
+    one = E.Array.build(inputs, k=k, rc=rc, threads=2)
+    monkeypatch.setenv("SKX_BUILD_BATCH_MB", str(batch_mb))        # 8 MB fixed + 24 B/base per sample: 1 -> one sample per batch
+    monkeypatch.setenv("SKX_DEBUG", "1")
+    capfd.readouterr()
+    many = E.Array.build(inputs, k=k, rc=rc, threads=2)
+    n_batches = capfd.readouterr().err.count("as one batch")
+    assert n_batches == {1: 9, 20: 5, 30: 3}[batch_mb]
+    monkeypatch.delenv("SKX_BUILD_BATCH_MB")
+    monkeypatch.delenv("SKX_DEBUG")
+    oa = ora.Array.from_dicts([oracle_dict(r, k, rc) for r in samples], [x[0] for x in inputs])
+    assert many.names == one.names == oa.names and many.nkmers == one.nkmers == oa.nkmers
+    m = as_map(*many.export())
+    assert m == as_map(*one.export()) and m == as_map(*oa.export())
+    assert list(many.sample_kmers()) == list(one.sample_kmers())
+    # the joined array goes on through filter + align like any other
+    f1, f2, f3 = (a.align(filter_type=1, min_freq=0.8) for a in (many, one, oa))
+    cols = lambda t: sorted(zip(*[l for l in t.decode().splitlines()[1::2]]))
+    assert cols(f1) == cols(f2) == cols(f3)
