@@ -166,8 +166,10 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
     hipStream_t st = ctx->stream;
     bool any_qual = false;
     for (auto p : quals) any_qual |= p != nullptr;
-    if (any_qual) {
-        // reads: per-sample quality gates + KmerFilter (skx_reads.hip); the dictset is then one sorted region per sample
+    // reads: per-sample quality gates + KmerFilter (skx_reads.hip); the dictset is then one sorted region per sample.  The same
+    // sort-based path takes assemblies too large for the bucketed one (more than 2^MAX_LOGB regions' worth of windows: a 40 Mbp
+    // sample and up, to 4 Gbp), with the filters switched off.
+    auto build_sorted = [&]() -> int {
         const bool wide_r = k > 31;
         const int wpk_r = wide_r ? 2 : 1;
         std::vector<DevBuf<uint64_t>> lists(n);
@@ -195,7 +197,7 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
         d->sample_size = sizes;
         *out = d.release();
         return SKX_OK;
-    }
+    };
     const bool wide = k > 31;                                   // lib.rs:592: u64 for k <= 31, u128 above
     uint64_t maxlen = 0;
     for (auto l : lens) maxlen = std::max(maxlen, l);
@@ -205,6 +207,7 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
     // windows per bucket (upper bound): the 64-bit dedupe sorts up to 6 144 words per region in LDS and the regions get 20 % + 256
     // words of head-room, so 4 900 is the largest mean that fits -- and the largest buckets give the scatter its widest chunks
     const uint64_t per_region = wide ? 4096 : 4900;
+    if (any_qual || maxlen > (per_region << MAX_LOGB)) return build_sorted();
     int logB = std::min({ilog2_ceil((maxlen + per_region - 1) / per_region), key_bits_used, MAX_LOGB});
     if (logB < 0) logB = 0;
 
@@ -282,7 +285,7 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
         SKX_HIP(hipStreamSynchronize(st));
         SKX_HIP(hipGetLastError());
         if (overflow) {
-            if (logB >= std::min(key_bits_used, MAX_LOGB)) { set_error("sample too large for the device dictionary (more than %u split k-mer occurrences in one of %d buckets)", LDS_SORT_MAX, 1 << logB); return SKX_EUNSUP; }
+            if (logB >= std::min(key_bits_used, MAX_LOGB)) return build_sorted();      // repeat content beyond every region size: sort instead
             logB++;
             continue;
         }

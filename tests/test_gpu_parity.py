@@ -549,3 +549,36 @@ def test_build_in_batches_equals_one_batch(E, k, rc, batch_mb, tmp_path, monkeyp
     f1, f2, f3 = (a.align(filter_type=1, min_freq=0.8) for a in (many, one, oa))
     cols = lambda t: sorted(zip(*[l for l in t.decode().splitlines()[1::2]]))
     assert cols(f1) == cols(f2) == cols(f3)
+
+
+def _sorted_export(arr):
+    keys, var, counts = arr.export()
+    order = np.lexsort((keys["lo"], keys["hi"]))
+    return keys["hi"][order], keys["lo"][order], np.asarray(var)[order], np.asarray(counts)[order]
+
+
+@pytest.mark.parametrize("k,length", [(31, 41_000_000), (41, 34_000_000)])
+def test_oversize_assembly_takes_the_sorted_path(E, k, length):
+    """An assembly with more windows than 2^13 bucket regions hold (40.1 Mbp at k <= 31, 33.5 Mbp above) is built by the
+    sort-based path the read sets use, filters off; its dictionary, and an array merged with an ordinary sample, must equal
+    the oracle's."""
+    rng = np.random.default_rng(k)
+    g = rng.integers(0, 4, size=length, dtype=np.uint8)
+    big = np.frombuffer(b"ACGT", dtype=np.uint8)[g]
+    small = big[: 1_000_000].copy()
+    small[rng.integers(0, len(small), size=300)] = ord("A")
+    samples = [[big[: length // 2].tobytes(), big[length // 2:].tobytes()], [small.tobytes()]]
+    ds = E.DictSet.build([E.record_stream(r) for r in samples], k, True)
+    ods = [oracle_dict(r, k, True) for r in samples]
+    for i in range(2):
+        ok, ob = ods[i].export()
+        gk, gb = ds.export(i)
+        assert len(gk) == len(ok)
+        assert np.array_equal(gk["lo"], ok["lo"]) and np.array_equal(gk["hi"], ok["hi"]) and np.array_equal(gb, ob)
+    if k > 31:
+        return                 # the merged-array half once is enough for the suite's running time
+    ga = ds.merge(["big", "small"])
+    oa = ora.Array.from_dicts(ods, ["big", "small"])
+    assert ga.nkmers == oa.nkmers
+    for x, y in zip(_sorted_export(ga), _sorted_export(oa)):
+        assert np.array_equal(x, y)
