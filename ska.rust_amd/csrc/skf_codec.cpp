@@ -11,12 +11,17 @@
 // row blocks (the device gathers / transposes them), so neither the 2UxS-byte CBOR nor a host copy of the matrix is ever
 // materialised.
 #include "skx_internal.h"
+#include <chrono>
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace skx {
 namespace {
@@ -55,10 +60,20 @@ static size_t super_bytes()
 }
 #define SUPER (super_bytes())
 
+// does the device take a data section of this many bytes?  SKX_SKF_DEVICE = 0 never, 1 whenever a whole chunk lies inside,
+// default: from 1 MB up (below that the host codec is as fast as the launches)
+bool device_section(uint64_t bytes)
+{
+    const char *e = getenv("SKX_SKF_DEVICE");
+    if (e && *e == '0') return false;
+    if (e && *e == '1') return bytes >= CHUNK;
+    return bytes >= (1u << 20);
+}
 int n_workers(int threads)
 {
     if (threads <= 0) { threads = (int)std::thread::hardware_concurrency(); if (threads <= 0) threads = 4; }
-    return std::min(threads, 64);
+    static const int cap = [] { const char *e = getenv("SKX_SKF_THREADS"); const int v = e ? atoi(e) : 64; return v > 0 ? v : 64; }();
+    return std::min(threads, cap);
 }
 template <typename F>
 void parallel_for(size_t n, int threads, F &&f)      // f(i) for i in [0, n), dynamic distribution
@@ -161,6 +176,7 @@ bool snappy_uncompress_block(const uint8_t *in, size_t n, uint8_t *out, size_t u
 // Writer side: CBOR bytes are appended; every full super-block is cut into 64 KB chunks that the team compresses.
 struct FrameWriter {
     FILE *f = nullptr; int threads = 1; bool ok = true;
+    uint64_t total = 0;                             // uncompressed bytes taken so far (written + pending)
     std::vector<uint8_t> cur;
     std::vector<std::vector<uint8_t>> comp;
     bool open(const char *path, int nthreads)
@@ -193,8 +209,10 @@ struct FrameWriter {
         }
         cur.erase(cur.begin(), cur.begin() + (ptrdiff_t)nbytes);
     }
+    void flush_all() { if (!cur.empty()) emit(cur.size()); }      // only at a multiple of CHUNK, or at the end
     void append(const uint8_t *p, size_t n)
     {
+        total += n;
         while (n) {
             if (cur.size() >= SUPER) emit(cur.size() / CHUNK * CHUNK);
             const size_t take = std::min(n, SUPER - cur.size());
@@ -204,6 +222,7 @@ struct FrameWriter {
     uint8_t *grow(size_t n)                          // room for n more bytes at the end of the pending buffer (n <= SUPER)
     {
         if (cur.size() + n > SUPER) emit(cur.size() / CHUNK * CHUNK);
+        total += n;
         const size_t at = cur.size();
         cur.resize(at + n);
         return cur.data() + at;
@@ -218,25 +237,49 @@ struct FrameWriter {
 
 // Reader side: the compressed file is read whole (it is small next to the CBOR it expands to), its chunk directory is
 // scanned once, and super-blocks of chunks are decompressed + checked by the team on demand.
+// the compressed file, mapped (no copy: the chunks are read by the decoders -- or copied to the device -- straight from the page cache)
+struct Mapped {
+    const uint8_t *p = nullptr; size_t n = 0;
+    ~Mapped() { if (p && n) munmap((void *)p, n); }
+    bool open(const char *path)
+    {
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat sb;
+        if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { ::close(fd); return false; }
+        n = (size_t)sb.st_size;
+        if (n) { void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0); if (m == MAP_FAILED) { ::close(fd); n = 0; return false; } p = (const uint8_t *)m; }
+        ::close(fd);
+        return true;
+    }
+    size_t size() const { return n; }
+    const uint8_t *data() const { return p; }
+    const uint8_t &operator[](size_t i) const { return p[i]; }
+};
 struct FrameReader {
-    std::vector<uint8_t> raw;
-    struct Chunk { size_t off, len; uint32_t ulen, crc; bool compressed; };
+    Mapped raw;
+    typedef SkfChunk Chunk;
     std::vector<Chunk> chunks;
     size_t next_chunk = 0; int threads = 1;
     std::vector<uint8_t> buf; size_t pos = 0;       // decoded bytes not yet consumed: buf[pos ..)
+    uint64_t ubase = 0, total_ulen = 0;             // stream offset of buf[0]; length of the whole uncompressed stream
+    uint64_t upos() const { return ubase + pos; }
+    bool seek(uint64_t u)                           // continue reading at stream offset u
+    {
+        if (u > total_ulen) return false;
+        size_t lo = 0, hi = chunks.size();
+        while (lo < hi) { const size_t mid = (lo + hi) / 2; if (chunks[mid].uoff + chunks[mid].ulen <= u) lo = mid + 1; else hi = mid; }
+        buf.clear(); pos = 0; next_chunk = lo;
+        ubase = lo < chunks.size() ? chunks[lo].uoff : total_ulen;
+        if (u > ubase) { if (!fill((size_t)(u - ubase))) return false; pos = (size_t)(u - ubase); }
+        return true;
+    }
     const char *err = nullptr;
 
     bool open(const char *path, int nthreads)
     {
         threads = nthreads;
-        FILE *f = fopen(path, "rb");
-        if (!f) { err = "open"; return false; }
-        fseek(f, 0, SEEK_END); const long sz = ftell(f); fseek(f, 0, SEEK_SET);
-        if (sz < 0) { fclose(f); err = "open"; return false; }
-        raw.resize((size_t)sz);
-        const bool rd = sz == 0 || fread(raw.data(), 1, (size_t)sz, f) == (size_t)sz;
-        fclose(f);
-        if (!rd) { err = "open"; return false; }
+        if (!raw.open(path)) { err = "open"; return false; }
         size_t i = 0; bool seen = false;
         while (i < raw.size()) {
             if (i + 4 > raw.size()) { err = "skf: truncated frame"; return false; }
@@ -249,6 +292,7 @@ struct FrameReader {
                 Chunk c; c.off = i + 4; c.len = len - 4; c.compressed = type == 0x00; memcpy(&c.crc, &raw[i], 4);
                 c.ulen = c.compressed ? snappy_ulen(&raw[c.off], c.len, nullptr) : (uint32_t)c.len;
                 if (c.ulen == 0xFFFFFFFFu || c.ulen > CHUNK) { err = "skf: corrupt snappy block"; return false; }
+                c.uoff = total_ulen; total_ulen += c.ulen;
                 chunks.push_back(c);
             } else if (type < 0x80) { err = "skf: unsupported chunk type"; return false; }
             i += len;
@@ -260,10 +304,13 @@ struct FrameReader {
     const uint8_t *data() const { return buf.data() + pos; }
     void consume(size_t n) { pos += n; }
     // make at least `need` bytes available (fewer only at end of stream); decodes up to one super-block more
+    double fill_secs = 0;
     bool fill(size_t need)
     {
+        const auto t_f0 = std::chrono::steady_clock::now();
+        struct Acc { double &a; std::chrono::steady_clock::time_point t; ~Acc() { a += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); } } acc{fill_secs, t_f0};
         while (avail() < need && next_chunk < chunks.size()) {
-            if (pos) { buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)pos); pos = 0; }
+            if (pos) { buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)pos); ubase += pos; pos = 0; }
             size_t last = next_chunk, add = 0;
             while (last < chunks.size() && add < SUPER) add += chunks[last++].ulen;
             const size_t base = buf.size();
@@ -351,11 +398,18 @@ struct Reader {
 }  // namespace
 
 int skf_read_stream(const char *path, SkfMeta &m, std::vector<skx_key> &keys, std::vector<uint64_t> &counts,
-                    const std::function<int(uint64_t, uint64_t)> &begin_rows, const RowSink &sink, int threads)
+                    const std::function<int(uint64_t, uint64_t)> &begin_rows, const RowSink &sink, int threads, const DevDecode *dev)
 {
     threads = n_workers(threads);
     FrameReader fr;
-    if (!fr.open(path, threads)) {
+    const bool dbg = getenv("SKX_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const auto t_open = now();
+    const bool opened = fr.open(path, threads);
+    if (dbg) fprintf(stderr, "[skx] load: file read + chunk directory in %.2f s\n", secs(t_open, now()));
+    auto t_mark = now();
+    if (!opened) {
         if (fr.err && !strcmp(fr.err, "open")) { set_error("cannot open %s", path); return SKX_EIO; }
         set_error("%s", fr.err ? fr.err : "skf: read failed"); return SKX_EFORMAT;
     }
@@ -368,7 +422,39 @@ int skf_read_stream(const char *path, SkfMeta &m, std::vector<skx_key> &keys, st
         if (name == "k") m.k = (int)rd.uint();
         else if (name == "rc") m.rc = rd.boolean();
         else if (name == "names") { uint64_t n = rd.array(); for (uint64_t j = 0; j < n && rd.ok; j++) m.names.push_back(rd.text()); }
-        else if (name == "split_kmers") { uint64_t n = rd.array(); if (n > (1ull << 40)) rd.ok = false; else keys.reserve(n); for (uint64_t j = 0; j < n && rd.ok; j++) keys.push_back(rd.key()); }
+        else if (name == "split_kmers") {
+            uint64_t n = rd.array();
+            if (n > (1ull << 40)) { rd.ok = false; continue; }
+            keys.resize(n);
+            // nearly every 64-bit split k-mer is a 9-byte uint (0x1b + 8 bytes): whole runs of those are decoded by the team,
+            // anything else one at a time by the generic parser
+            uint64_t j = 0;
+            while (j < n && rd.ok) {
+                const uint64_t can = std::min<uint64_t>(n - j, fr.avail() / 9);
+                if (can >= 4096) {
+                    const uint8_t *src = fr.data();
+                    const size_t parts = (size_t)std::min<uint64_t>((uint64_t)threads, can / 1024);
+                    const uint64_t per = can / parts;
+                    std::atomic<int> other{0};
+                    parallel_for(parts, threads, [&](size_t pt) {
+                        const uint64_t a = pt * per, b = pt + 1 == parts ? can : a + per;
+                        uint8_t bad = 0;
+                        for (uint64_t c = a; c < b; c++) {
+                            const uint8_t *q = src + 9 * c;
+                            bad |= (uint8_t)(q[0] ^ 0x1b);
+                            uint64_t v; memcpy(&v, q + 1, 8);
+                            keys[j + c] = skx_key{__builtin_bswap64(v), 0};
+                        }
+                        if (bad) other = 1;
+                    });
+                    if (!other) { fr.consume(9 * can); j += can; continue; }
+                    for (uint64_t c = 0; c < can && rd.ok; c++) keys[j + c] = rd.key();         // a run with shorter / wider keys in it
+                    j += can;
+                    continue;
+                }
+                keys[j++] = rd.key();
+            }
+        }
         else if (name == "variants") {
             uint64_t n3 = 0; if (!rd.head(mj, n3) || mj != 5) rd.ok = false;
             for (uint64_t g = 0; g < n3 && rd.ok; g++) {
@@ -387,6 +473,17 @@ int skf_read_stream(const char *path, SkfMeta &m, std::vector<skx_key> &keys, st
                     const uint64_t block_rows = S ? std::max<uint64_t>(1, (uint64_t)(SUPER / 2) / S) : 1;
                     std::vector<uint8_t> rows;
                     uint64_t row0 = 0;
+                    if (dev && device_section(2 * n) && fr.upos() + 2 * n <= fr.total_ulen) {
+                        // the whole section on the device: compressed chunks in, sample-major matrix out
+                        const uint64_t upos = fr.upos();
+                        if (dbg) fprintf(stderr, "[skx] load: header + split k-mers parsed in %.2f s (%.2f s of it decompressing their chunks)\n", secs(t_mark, now()), fr.fill_secs);
+                        t_mark = now();
+                        r = (*dev)(fr.raw.data(), fr.chunks.data(), fr.chunks.size(), upos, dim0, dim1);
+                        if (dbg) fprintf(stderr, "[skx] load: data section in %.2f s\n", secs(t_mark, now()));
+                        t_mark = now();
+                        if (r == SKX_OK) { if (!fr.seek(upos + 2 * n)) rd.ok = false; row0 = dim0; }
+                        else if (r != SKF_NOT_TAKEN) return r;
+                    }
                     while (row0 < dim0 && rd.ok) {
                         const uint64_t nr = std::min(block_rows, dim0 - row0), cells = nr * S;
                         rows.resize(cells);
@@ -434,12 +531,16 @@ int skf_read_stream(const char *path, SkfMeta &m, std::vector<skx_key> &keys, st
 }
 
 int skf_write_stream(const char *path, const SkfMeta &m, const std::vector<skx_key> &keys, const std::vector<uint64_t> &counts,
-                     const RowFetch &fetch, int threads)
+                     const RowFetch &fetch, int threads, const DevEncode *dev)
 {
     threads = n_workers(threads);
     FrameWriter fw;
     if (!fw.open(path, threads)) { set_error("cannot create %s", path); return SKX_EIO; }
     const uint64_t S = m.names.size(), U = m.n_rows;
+    const bool dbg = getenv("SKX_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    auto t_mark = now();
     Writer w;
     auto flush = [&]() { fw.append(w.b.data(), w.b.size()); w.b.clear(); };
     w.head(5, 8);
@@ -447,15 +548,56 @@ int skf_write_stream(const char *path, const SkfMeta &m, const std::vector<skx_k
     w.text("rc"); w.b.push_back(m.rc ? 0xf5 : 0xf4);
     w.text("names"); w.head(4, S); for (auto &s : m.names) w.text(s);
     w.text("split_kmers"); w.head(4, keys.size());
-    for (size_t i = 0; i < keys.size(); i++) { w.key(keys[i]); if (w.b.size() >= (1u << 20)) flush(); }
+    flush();
+    for (size_t i0 = 0; i0 < keys.size(); i0 += (4u << 20)) {              // slices of the list are encoded by the team, then appended in order
+        const size_t cnt = std::min<size_t>(4u << 20, keys.size() - i0), parts = std::max<size_t>(1, std::min<size_t>((size_t)threads, cnt / 4096));
+        std::vector<Writer> ws(parts);
+        parallel_for(parts, threads, [&](size_t pt) {
+            const size_t a = i0 + cnt * pt / parts, b = i0 + cnt * (pt + 1) / parts;
+            ws[pt].b.reserve((b - a) * 9 + 32);
+            for (size_t i = a; i < b; i++) ws[pt].key(keys[i]);
+        });
+        for (auto &x : ws) fw.append(x.b.data(), x.b.size());
+    }
     w.text("variants"); w.head(5, 3);
     w.text("v"); w.head(0, 1);
     w.text("dim"); w.head(4, 2); w.head(0, U); w.head(0, S);
     w.text("data"); w.head(4, U * S);
     flush();
+    if (dbg) fprintf(stderr, "[skx] save: header + split k-mers encoded in %.2f s\n", secs(t_mark, now()));
+    t_mark = now();
     const uint64_t block_rows = S ? std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)(SUPER / 2) / S, SUPER / (2 * S) ? SUPER / (2 * S) : 1)) : 1;
     std::vector<uint8_t> rows;
-    for (uint64_t row0 = 0; row0 < U && fw.ok; row0 += block_rows) {
+    uint64_t first_row = 0;
+    if (dev && S && device_section(2 * U * S)) {
+        // whole 64 KB chunks inside the section are produced on the device; the ragged ends (< 64 KB each) here
+        const uint64_t upos = fw.total, bytes = 2 * U * S;
+        const uint64_t A = (upos + CHUNK - 1) / CHUNK * CHUNK, Z = (upos + bytes) / CHUNK * CHUNK;
+        auto host_bytes = [&](uint64_t b0, uint64_t b1) -> int {           // section bytes [b0, b1)
+            if (b0 >= b1) return SKX_OK;
+            const uint64_t c0 = b0 / 2, c1 = (b1 + 1) / 2, r0 = c0 / S, r1 = (c1 - 1) / S;
+            rows.resize((r1 - r0 + 1) * S);
+            int r = fetch(r0, r1 - r0 + 1, rows.data());
+            if (r != SKX_OK) return r;
+            std::vector<uint8_t> tmp(b1 - b0);
+            for (uint64_t q = b0; q < b1; q++) tmp[q - b0] = (q & 1) ? rows[(q >> 1) - r0 * S] : 0x18;
+            fw.append(tmp.data(), tmp.size());
+            return SKX_OK;
+        };
+        if (Z > A) {
+            int r = host_bytes(0, A - upos);
+            if (r != SKX_OK) return r;
+            fw.flush_all();
+            if (!fw.ok) { set_error("short write %s", path); return SKX_EIO; }
+            r = (*dev)(fw.f, upos, A, (Z - A) / CHUNK);
+            if (r != SKX_OK) return r;
+            fw.total = Z;
+            r = host_bytes(Z - upos, bytes);
+            if (r != SKX_OK) return r;
+            first_row = U;
+        }
+    }
+    for (uint64_t row0 = first_row; row0 < U && fw.ok; row0 += block_rows) {
         const uint64_t nr = std::min(block_rows, U - row0), cells = nr * S;
         rows.resize(cells);
         int r = fetch(row0, nr, rows.data());
@@ -473,17 +615,20 @@ int skf_write_stream(const char *path, const SkfMeta &m, const std::vector<skx_k
                 if (lo < 24) small = 1;
             });
             if (!small) continue;
-            fw.cur.resize(fw.cur.size() - 2 * cells);       // a value below 24 is a single byte: redo this block generically
+            fw.cur.resize(fw.cur.size() - 2 * cells); fw.total -= 2 * cells;       // a value below 24 is a single byte: redo this block generically
         }
         for (uint64_t c = 0; c < cells; c++) { w.head(0, rows[c]); if (w.b.size() >= (1u << 20)) flush(); }
         flush();
     }
+    if (dbg) fprintf(stderr, "[skx] save: data section in %.2f s\n", secs(t_mark, now()));
+    t_mark = now();
     w.text("variant_count"); w.head(4, counts.size());
     for (size_t i = 0; i < counts.size(); i++) { w.head(0, counts[i]); if (w.b.size() >= (1u << 20)) flush(); }
     w.text("ska_version"); w.text(m.version);
     w.text("k_bits"); w.head(0, (uint64_t)m.k_bits);
     flush();
     if (!fw.close()) { set_error("short write %s", path); return SKX_EIO; }
+    if (dbg) fprintf(stderr, "[skx] save: counts + close in %.2f s\n", secs(t_mark, now()));
     return SKX_OK;
 }
 

@@ -1430,6 +1430,13 @@ extern "C" int skx_array_map(skx_array *a, const char *reference, int ambig_mask
 }
 
 // ------------------------------------------------------------------------------------------ .skf
+// 64 KB chunks per launch of the device codec (512 MB of CBOR; SKX_SKF_GROUP_CHUNKS overrides, tests use small groups)
+static uint64_t skf_group_chunks()
+{
+    const char *e = getenv("SKX_SKF_GROUP_CHUNKS");
+    const long v = e ? atol(e) : 8192;
+    return (uint64_t)std::max<long>(1, std::min<long>(v, 1 << 20));
+}
 // MergeSkaArray::save (merge_ska_array.rs:191-199), streamed: rows go out in the array's own order (the
 // order of H for arrays built here, the file's order for loaded ones; the reference's order is its hash map's), one
 // transposed row block at a time, so the host never holds the U x S matrix or its 2-bytes-per-cell CBOR text.
@@ -1441,7 +1448,9 @@ extern "C" int skx_array_save(skx_array *a, const char *path)
     const uint64_t U = a->n_rows, S = a->names.size();
     SkfMeta m; m.k = a->k; m.rc = a->rc; m.k_bits = a->k_bits; m.names = a->names; m.version = a->version; m.n_rows = U;
     std::vector<skx_key> keys;
+    const auto t_k0 = std::chrono::steady_clock::now();
     SKX_TRY(array_host_keys(a, keys));
+    if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] save: keys to host in %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_k0).count());
     std::vector<uint32_t> vc(U);
     if (U) SKX_HIP(hipMemcpy(vc.data(), a->vcount.p, U * 4, hipMemcpyDeviceToHost));
     std::vector<uint64_t> counts(vc.begin(), vc.end());
@@ -1454,7 +1463,53 @@ extern "C" int skx_array_save(skx_array *a, const char *path)
         SKX_HIP(hipStreamSynchronize(st));
         return SKX_OK;
     };
-    return skf_write_stream(path, m, keys, counts, fetch, 0);
+    // the data section on the device (skx_snappy.hip): groups of 64 KB chunks -> row-major cells -> finished frame chunks
+    struct Pinned { uint8_t *p = nullptr; size_t cap = 0; ~Pinned() { if (p) (void)hipHostFree(p); }
+                    int need(size_t n) { if (n <= cap) return SKX_OK; if (p) (void)hipHostFree(p); p = nullptr; cap = 0;
+                                         if (hipHostMalloc((void **)&p, n, hipHostMallocDefault) != hipSuccess) { p = nullptr; return SKX_ENOMEM; } cap = n; return SKX_OK; } } pin[2];
+    const DevEncode dev_encode = [&](FILE *f, uint64_t upos, uint64_t uoff0, uint64_t n_chunks) -> int {
+        const uint64_t G = skf_group_chunks();
+        if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] save: %llu chunks of the data section encoded on the device\n", (unsigned long long)n_chunks);
+        DevBuf<uint8_t> d_cells, d_slots, d_dense; DevBuf<uint32_t> d_sizes; DevBuf<uint64_t> d_off;
+        SKX_TRY(d_slots.alloc(std::min(G, n_chunks) * (uint64_t)SKF_SLOT)); SKX_TRY(d_sizes.alloc(std::min(G, n_chunks))); SKX_TRY(d_off.alloc(std::min(G, n_chunks)));
+        std::vector<uint32_t> sizes; std::vector<uint64_t> off;
+        uint64_t cells_cap = 0, dense_cap = 0;
+        // the file write of one group runs beside the device work of the next (two pinned buffers)
+        struct Writer { std::thread th; bool ok = true; void join() { if (th.joinable()) th.join(); } ~Writer() { join(); } } wr;
+        int flip = 0;
+        for (uint64_t g0 = 0; g0 < n_chunks; g0 += G, flip ^= 1) {
+            const uint64_t ng = std::min(G, n_chunks - g0);
+            const uint64_t rel_lo = uoff0 + g0 * 65536ull - upos, rel_hi = rel_lo + ng * 65536ull;        // section bytes of this group
+            const uint64_t c_lo = rel_lo >> 1, c_hi = ((rel_hi - 1) >> 1) + 1;
+            const uint64_t r0 = c_lo / S, r1 = (c_hi - 1) / S + 1, nr = r1 - r0;
+            if (nr * S + 16 > cells_cap) { cells_cap = nr * S + 16; SKX_TRY(d_cells.alloc(cells_cap)); }
+            launch_transpose(a->matrix.p + r0, a->pitch, S, nr, d_cells.p, S, st);                          // [S][nr] slice -> [nr][S]
+            SKX_TRY(launch_skf_encode_cells(ctx->device, d_cells.p, r0 * S, upos, uoff0 + g0 * 65536ull, (uint32_t)ng, d_slots.p, d_sizes.p, st));
+            sizes.resize(ng); off.resize(ng);
+            SKX_HIP(hipMemcpyAsync(sizes.data(), d_sizes.p, ng * 4, hipMemcpyDeviceToHost, st));
+            SKX_HIP(hipStreamSynchronize(st));
+            uint64_t total = 0;
+            for (uint64_t c = 0; c < ng; c++) { off[c] = total; total += sizes[c]; }
+            if (total > dense_cap) { dense_cap = total + total / 4; SKX_TRY(d_dense.alloc(dense_cap)); }
+            SKX_TRY(pin[flip].need(total));
+            SKX_HIP(hipMemcpyAsync(d_off.p, off.data(), ng * 8, hipMemcpyHostToDevice, st));
+            launch_skf_gather(d_slots.p, d_sizes.p, d_off.p, (uint32_t)ng, d_dense.p, st);
+            SKX_HIP(hipMemcpyAsync(pin[flip].p, d_dense.p, total, hipMemcpyDeviceToHost, st));
+            SKX_HIP(hipStreamSynchronize(st));
+            SKX_HIP(hipGetLastError());
+            wr.join();
+            if (!wr.ok) break;
+            const uint8_t *buf = pin[flip].p;
+            wr.th = std::thread([&wr, buf, total, f]() { wr.ok = fwrite(buf, 1, total, f) == total; });
+        }
+        wr.join();
+        if (!wr.ok) { set_error("short write %s", path); return SKX_EIO; }
+        return SKX_OK;
+    };
+    const auto t_w0 = std::chrono::steady_clock::now();
+    const int r = skf_write_stream(path, m, keys, counts, fetch, 0, &dev_encode);
+    if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] save: stream written in %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_w0).count());
+    return r;
     });
 }
 
@@ -1485,7 +1540,61 @@ extern "C" int skx_array_load(skx_ctx *ctx, const char *path, int want_bits, skx
         SKX_HIP(hipStreamSynchronize(st));                                                // src is reused by the decoder
         return SKX_OK;
     };
-    SKX_TRY(skf_read_stream(path, m, keys, counts, begin_rows, sink, 0));
+    // the data section on the device: groups of compressed chunks -> row-major cells -> transposed into the matrix
+    const DevDecode dev_decode = [&](const uint8_t *file, const SkfChunk *ch, size_t nch, uint64_t upos, uint64_t U, uint64_t cols) -> int {
+        if (!U || !cols) return SKF_NOT_TAKEN;
+        const uint64_t uend = upos + 2 * U * cols, G = skf_group_chunks();
+        size_t c0 = 0, c1 = nch;
+        { size_t lo = 0, hi = nch; while (lo < hi) { const size_t mid = (lo + hi) / 2; if (ch[mid].uoff + ch[mid].ulen <= upos) lo = mid + 1; else hi = mid; } c0 = lo; }
+        { size_t lo = c0, hi = nch; while (lo < hi) { const size_t mid = (lo + hi) / 2; if (ch[mid].uoff < uend) lo = mid + 1; else hi = mid; } c1 = lo; }
+        if (c0 >= c1) return SKF_NOT_TAKEN;
+        if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] load: %zu chunks of the data section decoded on the device\n", c1 - c0);
+        DevBuf<uint8_t> d_src, d_cells[2]; DevBuf<SnapChunk> d_chunks; DevBuf<int> d_status;
+        SKX_TRY(d_status.alloc(1)); SKX_TRY(d_status.zero(st));
+        const uint64_t cells_cap = std::min<uint64_t>(G, c1 - c0) * 32768ull + cols + 64;
+        SKX_TRY(d_cells[0].alloc(cells_cap)); SKX_TRY(d_cells[1].alloc(cells_cap)); SKX_TRY(d_chunks.alloc(std::min<uint64_t>(G, c1 - c0)));
+        std::vector<SnapChunk> tab;
+        uint64_t src_cap = 0, row_lo = 0, have_hi = 0;          // rows < row_lo are in the matrix; cells [row_lo * cols, have_hi) wait in the current buffer
+        int cur = 0;
+        for (size_t g0 = c0; g0 < c1; g0 += G) {
+            const size_t g1 = std::min<size_t>(c1, g0 + G);
+            const size_t f_lo = ch[g0].off, f_hi = ch[g1 - 1].off + ch[g1 - 1].len;
+            if (f_hi - f_lo + 512 > src_cap) { src_cap = f_hi - f_lo + 512; SKX_TRY(d_src.alloc(src_cap)); }      // + the decoder's read-ahead window
+            tab.resize(g1 - g0);
+            for (size_t c = g0; c < g1; c++) tab[c - g0] = SnapChunk{ch[c].off - f_lo, ch[c].uoff, (uint32_t)ch[c].len, ch[c].ulen, ch[c].crc, ch[c].compressed ? 1u : 0u};
+            SKX_HIP(hipMemcpyAsync(d_src.p, file + f_lo, f_hi - f_lo, hipMemcpyHostToDevice, st));
+            SKX_HIP(hipMemcpyAsync(d_chunks.p, tab.data(), tab.size() * sizeof(SnapChunk), hipMemcpyHostToDevice, st));
+            const uint64_t base_cell = (row_lo * cols) & ~7ull;
+            SKX_TRY(launch_skf_decode_cells(ctx->device, d_src.p, d_chunks.p, (uint32_t)(g1 - g0), upos, uend, d_cells[cur].p, base_cell, d_status.p, st));
+            // cells this group delivered: value bytes (odd section offsets) below the end of its last chunk
+            const uint64_t s_hi = std::min(ch[g1 - 1].uoff + ch[g1 - 1].ulen, uend);
+            have_hi = (s_hi - upos) >> 1;
+            const uint64_t row_done = g1 == c1 ? U : have_hi / cols;
+            const uint8_t *in = d_cells[cur].p + (row_lo * cols - base_cell);
+            for (uint64_t r = row_lo; r < row_done; r += 4000000ull) {                          // grid.y of the transpose: 65 535 tiles of 64 rows
+                const uint64_t nr = std::min<uint64_t>(4000000ull, row_done - r);
+                launch_transpose(in + (r - row_lo) * cols, cols, nr, cols, a->matrix.p + r, a->pitch, st);
+            }
+            if (g1 < c1) {                                                                      // the unfinished row moves to the other buffer
+                const uint64_t nb = (row_done * cols) & ~7ull, left = have_hi - row_done * cols;
+                if (left) SKX_HIP(hipMemcpyAsync(d_cells[cur ^ 1].p + (row_done * cols - nb), d_cells[cur].p + (row_done * cols - base_cell), left, hipMemcpyDeviceToDevice, st));
+            }
+            SKX_HIP(hipStreamSynchronize(st));                                                   // tab / d_src are reused
+            row_lo = row_done; cur ^= 1;
+        }
+        int status = 0;
+        SKX_HIP(hipMemcpy(&status, d_status.p, 4, hipMemcpyDeviceToHost));
+        SKX_HIP(hipGetLastError());
+        if (status == 3) {                                                                       // cells that are not (0x18, byte): the generic decoder's case
+            SKX_HIP(hipMemsetAsync(a->matrix.p, '-', cols * a->pitch, st));
+            return SKF_NOT_TAKEN;
+        }
+        if (status) { set_error(status == 2 ? "skf: checksum mismatch" : "skf: corrupt snappy block"); return SKX_EFORMAT; }
+        return SKX_OK;
+    };
+    const auto t_r0 = std::chrono::steady_clock::now();
+    SKX_TRY(skf_read_stream(path, m, keys, counts, begin_rows, sink, 0, &dev_decode));
+    if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] load: stream read in %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_r0).count());
     SKX_TRY(check_k(m.k));
     if (want_bits == 64)       // serde into Vec<u64> fails on wider values; lib.rs:635-661 then retries as u128
         for (auto &kk : keys) if (kk.hi) { set_error("split k-mer does not fit 64 bits"); return SKX_EFORMAT; }

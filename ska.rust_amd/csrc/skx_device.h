@@ -163,6 +163,14 @@ void launch_count_u8(const uint8_t *v, uint64_t n, uint8_t value, unsigned long 
 // tiled transpose of a byte matrix: in [rows][in_pitch] -> out [cols][out_pitch]
 void launch_transpose(const uint8_t *in, uint64_t in_pitch, uint64_t rows, uint64_t cols, uint8_t *out, uint64_t out_pitch,
                       hipStream_t st);
+// .skf data section on the device (skx_snappy.hip): one snappy-frame chunk per wavefront
+struct SnapChunk { uint64_t src_off, uoff; uint32_t src_len, ulen, crc, compressed; };   // where its bytes are, where its output belongs
+constexpr uint32_t SKF_SLOT = 8 + 65536;                                                  // frame header + largest payload
+int launch_skf_decode_cells(int device, const uint8_t *src, const SnapChunk *chunks, uint32_t n_chunks, uint64_t upos, uint64_t uend,
+                            uint8_t *cells, uint64_t base_cell, int *status, hipStream_t st);
+int launch_skf_encode_cells(int device, const uint8_t *cells, uint64_t base_cell, uint64_t upos, uint64_t uoff0, uint32_t n_chunks,
+                            uint8_t *slots, uint32_t *sizes, hipStream_t st);
+void launch_skf_gather(const uint8_t *slots, const uint32_t *sizes, const uint64_t *off, uint32_t n_chunks, uint8_t *dense, hipStream_t st);
 // per-sample count of cells != '-'
 void launch_row_nonmissing(const uint8_t *matrix, uint64_t pitch, int n_samples, uint64_t n_cols, unsigned long long *out,
                            hipStream_t st);

@@ -2,6 +2,7 @@
 #pragma once
 #include "../../include/skx.h"
 #include "skx_device.h"
+#include <cstdio>
 #include <functional>
 #include <string>
 #include <vector>
@@ -129,8 +130,17 @@ int skf_write(const char *path, const SkfData &in);
 struct SkfMeta { int k = 0, rc = 0, k_bits = 64; std::vector<std::string> names; std::string version; uint64_t n_rows = 0; };
 typedef std::function<int(uint64_t row0, uint64_t nrows, uint8_t *dst)> RowFetch;
 typedef std::function<int(uint64_t row0, uint64_t nrows, const uint8_t *src)> RowSink;
+// Optional device hooks for the `variants` data section (2 bytes per cell; skx_snappy.hip).  Decode: the compressed file image,
+// its chunk directory (uoff = offset of the chunk's output in the uncompressed stream) and the section's start; SKX_OK = the
+// matrix is filled, SKF_NOT_TAKEN = use the host path.  Encode: write the finished frame chunks covering stream bytes
+// [uoff0, uoff0 + n_chunks * 64 KB) to f.
+struct SkfChunk { size_t off, len; uint32_t ulen, crc; bool compressed; uint64_t uoff; };
+constexpr int SKF_NOT_TAKEN = -1000;
+typedef std::function<int(const uint8_t *file, const SkfChunk *chunks, size_t n_chunks, uint64_t upos, uint64_t n_rows, uint64_t n_samples)> DevDecode;
+typedef std::function<int(FILE *f, uint64_t upos, uint64_t uoff0, uint64_t n_chunks)> DevEncode;
 int skf_write_stream(const char *path, const SkfMeta &m, const std::vector<skx_key> &keys, const std::vector<uint64_t> &counts,
-                     const RowFetch &fetch, int threads);
+                     const RowFetch &fetch, int threads, const DevEncode *dev = nullptr);
 int skf_read_stream(const char *path, SkfMeta &m, std::vector<skx_key> &keys, std::vector<uint64_t> &counts,
-                    const std::function<int(uint64_t n_rows, uint64_t n_samples)> &begin_rows, const RowSink &sink, int threads);
+                    const std::function<int(uint64_t n_rows, uint64_t n_samples)> &begin_rows, const RowSink &sink, int threads,
+                    const DevDecode *dev = nullptr);
 }  // namespace skx

@@ -418,10 +418,19 @@ def test_skf_lifecycle_errors(E, tmp_path):
             m.delete_samples(["a"])
 
 
-def test_skf_stream_codec_integrity(E, tmp_path):
+SKF_MODES = {"host": {"SKX_SKF_DEVICE": "0"}, "device": {"SKX_SKF_DEVICE": "1"},
+             "device_small_groups": {"SKX_SKF_DEVICE": "1", "SKX_SKF_GROUP_CHUNKS": "3"}}
+
+
+@pytest.mark.parametrize("mode", list(SKF_MODES))
+def test_skf_stream_codec_integrity(E, tmp_path, mode, monkeypatch):
     """The streaming codec: a multi-super-block file round-trips (engine -> engine, engine -> oracle, oracle -> engine),
-    and a flipped byte / a truncated file is an error (masked CRC-32C per chunk), never a silently different array."""
+    and a flipped byte / a truncated file is an error (masked CRC-32C per chunk), never a silently different array.
+    Once with the `variants` section on the host thread team, once on the device (snappy + CRC-32C + CBOR cells in
+    skx_snappy.hip), once on the device in groups of 3 chunks (rows straddle groups)."""
     os.environ["SKX_SKF_BLOCK_MB"] = "4"       # read once, at the codec's first use: many super-blocks in this test
+    for kk, vv in SKF_MODES[mode].items():
+        monkeypatch.setenv(kk, vv)
     rng = np.random.default_rng(11)
     _, samples = _related_samples(rng, 40, length=60_000, snps=300)
     names = [f"s{i}" for i in range(40)]
@@ -430,6 +439,9 @@ def test_skf_stream_codec_integrity(E, tmp_path):
     ga.save(p)
     ref = as_map(*ga.export())
     assert as_map(*E.Array.load(p).export()) == ref
+    monkeypatch.setenv("SKX_SKF_DEVICE", "1" if mode == "host" else "0")                   # written one way, read the other
+    assert as_map(*E.Array.load(p).export()) == ref
+    monkeypatch.setenv("SKX_SKF_DEVICE", SKF_MODES[mode]["SKX_SKF_DEVICE"])
     oa = ora.Array.load(p)
     assert oa.names == names and as_map(*oa.export()) == ref
     p2 = str(tmp_path / "big_oracle.skf")
@@ -582,3 +594,31 @@ def test_oversize_assembly_takes_the_sorted_path(E, k, length):
     assert ga.nkmers == oa.nkmers
     for x, y in zip(_sorted_export(ga), _sorted_export(oa)):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("n_samples,pad", [(1, ""), (2, "x"), (3, ""), (7, "yy"), (33, "z")])
+def test_skf_device_codec_alignments(E, tmp_path, n_samples, pad, monkeypatch):
+    """The device codec for every parity / alignment of the data section inside the stream (the section starts wherever the
+    names and split k-mers end; rows are n_samples cells, chunks 65 536 bytes): device-written files are read by the host
+    codec and the oracle, host-written ones by the device, in groups of 2 chunks."""
+    rng = np.random.default_rng(40 + n_samples)
+    _, samples = _related_samples(rng, n_samples, length=90_000, snps=200)
+    names = [f"s{i}{pad}" for i in range(n_samples)]
+    ga = E.DictSet.build([E.record_stream(s) for s in samples], 31, True).merge(names)
+    rows = _sorted_export(ga)
+    files = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SKX_SKF_DEVICE", mode)
+        monkeypatch.setenv("SKX_SKF_GROUP_CHUNKS", "2")
+        files[mode] = str(tmp_path / f"w{mode}.skf")
+        ga.save(files[mode])
+    for written in ("0", "1"):
+        for read in ("0", "1"):
+            monkeypatch.setenv("SKX_SKF_DEVICE", read)
+            back = E.Array.load(files[written])
+            assert back.names == names
+            for x, y in zip(_sorted_export(back), rows):
+                assert np.array_equal(x, y), (written, read)
+        oa = ora.Array.load(files[written])
+        for x, y in zip(_sorted_export(oa), rows):
+            assert np.array_equal(x, y), written

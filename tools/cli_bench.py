@@ -30,6 +30,8 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") els
         t0 = time.perf_counter()
         r = subprocess.run([SKA, *args], cwd=td, capture_output=True)
         assert r.returncode == 0, r.stderr[-500:]
+        if os.environ.get("SKX_DEBUG"):
+            sys.stderr.write("".join(l + "\n" for l in r.stderr.decode().splitlines() if l.startswith("[skx]")))
         return time.perf_counter() - t0, r.stdout
 
     tb, _ = run("build", "-f", "list.txt", "-o", "all", "-k", "31", "--threads", threads)
