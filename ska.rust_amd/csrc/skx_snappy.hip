@@ -311,29 +311,40 @@ __global__ __launch_bounds__(64) void skf_encode_cells_kernel(const uint8_t *__r
         const uint32_t g = r * 64 + lane;
         const uint4 q = *(const uint4 *)(s_in + 16 * g);
         const uint32_t prev = g ? ((const uint32_t *)s_in)[4 * g - 1] : 0u;
-        bool same = q.x == ((prev >> 16) | (q.x << 16)) && q.y == ((q.x >> 16) | (q.y << 16)) && q.z == ((q.y >> 16) | (q.z << 16)) &&
-                    q.w == ((q.z >> 16) | (q.w << 16));
-        if (g == 0) same = false;
+        // bit i of mm: byte i of the granule differs from the byte two back
+        auto nz = [](uint32_t d) -> uint32_t {
+            uint32_t t = (((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u;
+            return ((t >> 7) & 1u) | ((t >> 14) & 2u) | ((t >> 21) & 4u) | ((t >> 28) & 8u);
+        };
+        uint32_t mm = nz(q.x ^ ((prev >> 16) | (q.x << 16))) | (nz(q.y ^ ((q.x >> 16) | (q.y << 16))) << 4) |
+                      (nz(q.z ^ ((q.y >> 16) | (q.z << 16))) << 8) | (nz(q.w ^ ((q.z >> 16) | (q.w << 16))) << 12);
+        if (g == 0) mm |= 3u;                                                       // nothing to copy from yet
+        const bool same = mm == 0u;
         const uint64_t m = __ballot(same);
         // maximal runs of repeating granules become copies of up to 64 bytes (the longest a snappy copy can be); runs restart at
-        // the round's first granule
+        // the round's first granule.  A granule that does not repeat: copy up to its first differing byte, the differing
+        // span as a literal, copy after it.
         const uint64_t below = (1ull << lane) - 1ull;
         const uint64_t zb = ~m & below, za = ~m & ~(below | (1ull << lane));
         const uint32_t start = zb ? 64u - (uint32_t)__clzll(zb) : 0u, end = za ? (uint32_t)__ffsll((long long)za) - 1u : 64u;
         const uint32_t ncopy = (same && ((lane - start) & 3u) == 0u) ? min(4u, end - lane) : 0u;      // granules covered by this lane's copy
-        const uint32_t sz = same ? (ncopy ? 3u : 0u) : 17u;
-        const uint64_t m3 = __ballot(sz == 3u), m17 = __ballot(sz == 17u);
-        const uint32_t my = pos + 3u * (uint32_t)__popcll(m3 & below) + 17u * (uint32_t)__popcll(m17 & below);
-        const uint32_t total = 3u * (uint32_t)__popcll(m3) + 17u * (uint32_t)__popcll(m17);
-        if (pos + total > RAW_LIMIT) { raw = true; break; }
-        if (sz == 3u) {
-            out[my] = (uint8_t)(((16u * ncopy - 1u) << 2) | 2u);                                  // copy, 2-byte offset
-            out[my + 1] = 2; out[my + 2] = 0;
-        } else if (sz == 17u) {
-            out[my] = (uint8_t)((16 - 1) << 2);                                                  // literal of 16
-            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        const uint32_t first = same ? 0u : (uint32_t)__ffs((int)mm) - 1u, last = same ? 0u : 31u - (uint32_t)__clz((int)mm);
+        const uint32_t lit = last - first + 1u, tail = 15u - last;
+        const uint32_t sz = same ? (ncopy ? 3u : 0u) : ((first ? 3u : 0u) + 1u + lit + (tail ? 3u : 0u));
+        uint32_t inc = sz;
 #pragma unroll
-            for (int j = 0; j < 16; j++) out[my + 1 + j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d); if ((int)lane >= d) inc += t; }
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        if (pos + total > RAW_LIMIT) { raw = true; break; }
+        uint32_t o = pos + inc - sz;
+        if (same) {
+            if (ncopy) { out[o] = (uint8_t)(((16u * ncopy - 1u) << 2) | 2u); out[o + 1] = 2; out[o + 2] = 0; }      // copy, 2-byte offset
+        } else {
+            if (first) { out[o] = (uint8_t)(((first - 1u) << 2) | 2u); out[o + 1] = 2; out[o + 2] = 0; o += 3; }
+            out[o++] = (uint8_t)((lit - 1u) << 2);                                                           // literal
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+            for (uint32_t j = first; j <= last; j++) out[o++] = (uint8_t)(w[j >> 2] >> (8u * (j & 3u)));
+            if (tail) { out[o] = (uint8_t)(((tail - 1u) << 2) | 2u); out[o + 1] = 2; out[o + 2] = 0; }
         }
         pos += total;
     }
