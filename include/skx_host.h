@@ -17,6 +17,8 @@ int skh_apply_filters(skx_array *a, double min_freq, int filter_ambig_as_missing
 /* generic_modes::align (generic_modes.rs:22-50): filters then the FASTA alignment */
 int skh_align(skx_array *a, int filter_type, int mask_ambig, int ignore_const_gaps, double min_freq,
               int filter_ambig_as_missing, char **buf, uint64_t *len);
+int skh_align_fd(skx_array *a, int filter_type, int mask_ambig, int ignore_const_gaps, double min_freq,
+                 int filter_ambig_as_missing, int fd);   /* the same, streamed to a file descriptor */
 /* generic_modes::distance (generic_modes.rs:136-189): two-stage filter, then the long-form TSV with the
  * VariantDist Display format "{:.2}\t{:.5}\t{}\t{}" (merge_ska_array.rs:57-65) */
 int skh_distance_tsv(skx_array *a, double min_freq, int filt_ambig, char **buf, uint64_t *len);

@@ -339,28 +339,46 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
     return skx_guarded([&]() -> int {
     if (!ctx || !file1 || n <= 0 || !out) { set_error("bad arguments"); return SKX_EINVAL; }
     SKX_TRY(check_k(k));
-    std::vector<HostStream> hs(n);
+    // Every reader thread parses a file and sends its record stream to the device itself (a synchronous copy from pageable
+    // memory on the thread's own stream): the uploads of some samples run beside the parsing of others, and the host copy
+    // of a sample is gone as soon as it is on the device.
     std::vector<int> rcodes(n, SKX_OK);
     std::vector<std::string> errs(n);
+    std::vector<DevBuf<uint8_t>> d_seq(n), d_qual(n);
+    std::vector<skx_stream> ss(n);
     int nt = std::max(1, std::min(threads, n));
     const auto t_read0 = std::chrono::steady_clock::now();
     std::vector<std::thread> pool;
+    std::atomic<int> next{0};
     for (int t = 0; t < nt; t++)
-        pool.emplace_back([&, t]() {
-            for (int i = t; i < n; i += nt) {
-                rcodes[i] = read_sample_stream(file1[i], file2 ? file2[i] : nullptr, proportion_reads, hs[i]);
-                if (rcodes[i] != SKX_OK) errs[i] = skx_last_error();
+        pool.emplace_back([&]() {
+            (void)hipSetDevice(ctx->device);
+            hipStream_t up_st = nullptr;
+            if (hipStreamCreateWithFlags(&up_st, hipStreamNonBlocking) != hipSuccess) up_st = nullptr;
+            struct Drop { hipStream_t s; ~Drop() { if (s) (void)hipStreamDestroy(s); } } drop{up_st};
+            for (int i; (i = next.fetch_add(1)) < n;) {
+                HostStream h;
+                rcodes[i] = read_sample_stream(file1[i], file2 ? file2[i] : nullptr, proportion_reads, h);
+                if (rcodes[i] != SKX_OK) { errs[i] = skx_last_error(); continue; }
+                const size_t len = h.seq.size();
+                auto up = [&](DevBuf<uint8_t> &dst, const std::vector<uint8_t> &src) -> int {
+                    SKX_TRY(dst.alloc(len + 16));
+                    if (len) { SKX_HIP(hipMemcpyAsync(dst.p, src.data(), len, hipMemcpyHostToDevice, up_st)); SKX_HIP(hipStreamSynchronize(up_st)); }
+                    return SKX_OK;
+                };
+                rcodes[i] = up(d_seq[i], h.seq);
+                if (rcodes[i] == SKX_OK && h.is_fastq) rcodes[i] = up(d_qual[i], h.qual);
+                if (rcodes[i] != SKX_OK) { errs[i] = skx_last_error(); continue; }
+                ss[i].seq = d_seq[i].p; ss[i].qual = h.is_fastq ? d_qual[i].p : nullptr; ss[i].len = len;
             }
         });
     for (auto &th : pool) th.join();
-    if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] build_files: %d samples read + parsed by %d threads in %.2f s\n", n, nt, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_read0).count());
+    if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] build_files: %d samples read, parsed and sent to the device by %d threads in %.2f s\n", n, nt, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_read0).count());
     for (int i = 0; i < n; i++) if (rcodes[i] != SKX_OK) { set_error("%s", errs[i].c_str()); return rcodes[i]; }
-    std::vector<skx_stream> ss(n);
-    for (int i = 0; i < n; i++) { ss[i].seq = hs[i].seq.data(); ss[i].qual = hs[i].is_fastq ? hs[i].qual.data() : nullptr; ss[i].len = hs[i].seq.size(); }
     skx_dictset *d = nullptr;
     const auto t_dev0 = std::chrono::steady_clock::now();
-    int r = skx_dictset_build(ctx, ss.data(), n, 0, k, rc, q, &d);
-    if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] build_files: H2D + dictionaries in %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_dev0).count());
+    int r = skx_dictset_build(ctx, ss.data(), n, 1, k, rc, q, &d);
+    if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] build_files: dictionaries in %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_dev0).count());
     if (r == SKX_EEMPTY) {      // "{file} has no valid sequence" (ska_dict.rs:374-376)
         int bad = 0; sscanf(skx_last_error(), "sample %d", &bad);
         set_error("%s has no valid sequence", file1[bad]);
@@ -698,7 +716,14 @@ static int build_range(skx_ctx *ctx, const char *const *names, const char *const
     skx_dictset *d = nullptr;
     skx_array *a = nullptr;
     int r = skx_dictset_build_files(ctx, file1 + lo, file2 ? file2 + lo : nullptr, hi - lo, k, rc, q, threads, proportion_reads, &d);
-    if (r == SKX_OK) { r = skx_merge(ctx, d, names + lo, &a); skx_dictset_free(d); }
+    if (r == SKX_OK) {
+        const auto t0 = std::chrono::steady_clock::now();
+        r = skx_merge(ctx, d, names + lo, &a);
+        const auto t1 = std::chrono::steady_clock::now();
+        skx_dictset_free(d);
+        if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] build: merge into the array %.2f s, dictionaries released %.2f s\n", std::chrono::duration<double>(t1 - t0).count(),
+                                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
+    }
     if (r == SKX_ENOMEM && hi - lo > 1) {                      // the estimate was too low: halve the batch
         dev_trim();
         const int mid = lo + (hi - lo) / 2;
@@ -1163,14 +1188,42 @@ extern "C" int skx_array_fasta(skx_array *a, char **buf, uint64_t *len)
     return SKX_OK;
     });
 }
+// write_fasta (merge_ska_array.rs:507-520) streamed to a file descriptor: batches of samples (header + row + newline, ~64 MB)
+// come off the device into one of two pinned buffers while a writer thread puts the previous batch out; no copy of the
+// alignment is held on the host.
 extern "C" int skx_array_write_fasta(skx_array *a, int fd)
 {
     return skx_guarded([&]() -> int {
-    char *buf = nullptr; uint64_t len = 0;
-    SKX_TRY(skx_array_fasta(a, &buf, &len));
-    uint64_t w = 0;
-    while (w < len) { ssize_t r = write(fd, buf + w, len - w); if (r <= 0) { free(buf); set_error("write failed"); return SKX_EIO; } w += (uint64_t)r; }
-    free(buf);
+    skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
+    SKX_HIP(hipSetDevice(ctx->device));
+    const size_t S = a->names.size(); const uint64_t U = a->n_rows;
+    size_t max_rec = 0;
+    for (auto &nm : a->names) max_rec = std::max<size_t>(max_rec, nm.size() + U + 3);
+    const size_t cap = std::max<size_t>(max_rec, 64u << 20);
+    struct Pinned { char *p = nullptr; ~Pinned() { if (p) (void)hipHostFree(p); } } pin[2];
+    for (auto &b : pin) if (hipHostMalloc((void **)&b.p, cap, hipHostMallocDefault) != hipSuccess) { b.p = nullptr; set_error("out of host memory"); return SKX_ENOMEM; }
+    struct Writer { std::thread th; bool ok = true; void join() { if (th.joinable()) th.join(); } ~Writer() { join(); } } wr;
+    int flip = 0;
+    for (size_t s = 0; s < S;) {
+        char *buf = pin[flip].p; size_t used = 0;
+        while (s < S && used + a->names[s].size() + U + 3 <= cap) {
+            const std::string &nm = a->names[s];
+            buf[used++] = '>'; memcpy(buf + used, nm.data(), nm.size()); used += nm.size(); buf[used++] = '\n';
+            if (U) SKX_HIP(hipMemcpyAsync(buf + used, a->matrix.p + s * a->pitch, U, hipMemcpyDeviceToHost, st));
+            used += U; buf[used++] = '\n';
+            s++;
+        }
+        SKX_HIP(hipStreamSynchronize(st));
+        wr.join();
+        if (!wr.ok) break;
+        wr.th = std::thread([&wr, buf, used, fd]() {
+            size_t w = 0;
+            while (w < used) { const ssize_t r = write(fd, buf + w, used - w); if (r <= 0) { wr.ok = false; return; } w += (size_t)r; }
+        });
+        flip ^= 1;
+    }
+    wr.join();
+    if (!wr.ok) { set_error("write failed"); return SKX_EIO; }
     return SKX_OK;
     });
 }
@@ -1549,7 +1602,8 @@ extern "C" int skx_array_load(skx_ctx *ctx, const char *path, int want_bits, skx
         { size_t lo = c0, hi = nch; while (lo < hi) { const size_t mid = (lo + hi) / 2; if (ch[mid].uoff < uend) lo = mid + 1; else hi = mid; } c1 = lo; }
         if (c0 >= c1) return SKF_NOT_TAKEN;
         if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] load: %zu chunks of the data section decoded on the device\n", c1 - c0);
-        DevBuf<uint8_t> d_src, d_cells[2]; DevBuf<SnapChunk> d_chunks; DevBuf<int> d_status;
+        DevBuf<uint8_t> d_src, d_cells[2], d_scratch; DevBuf<SnapChunk> d_chunks; DevBuf<int> d_status;
+        SKX_TRY(d_scratch.alloc(std::min<uint64_t>(G, c1 - c0) * 65536ull + 16));
         SKX_TRY(d_status.alloc(1)); SKX_TRY(d_status.zero(st));
         const uint64_t cells_cap = std::min<uint64_t>(G, c1 - c0) * 32768ull + cols + 64;
         SKX_TRY(d_cells[0].alloc(cells_cap)); SKX_TRY(d_cells[1].alloc(cells_cap)); SKX_TRY(d_chunks.alloc(std::min<uint64_t>(G, c1 - c0)));
@@ -1565,7 +1619,7 @@ extern "C" int skx_array_load(skx_ctx *ctx, const char *path, int want_bits, skx
             SKX_HIP(hipMemcpyAsync(d_src.p, file + f_lo, f_hi - f_lo, hipMemcpyHostToDevice, st));
             SKX_HIP(hipMemcpyAsync(d_chunks.p, tab.data(), tab.size() * sizeof(SnapChunk), hipMemcpyHostToDevice, st));
             const uint64_t base_cell = (row_lo * cols) & ~7ull;
-            SKX_TRY(launch_skf_decode_cells(ctx->device, d_src.p, d_chunks.p, (uint32_t)(g1 - g0), upos, uend, d_cells[cur].p, base_cell, d_status.p, st));
+            SKX_TRY(launch_skf_decode_cells(ctx->device, d_src.p, d_chunks.p, (uint32_t)(g1 - g0), upos, uend, d_scratch.p, d_cells[cur].p, base_cell, d_status.p, st));
             // cells this group delivered: value bytes (odd section offsets) below the end of its last chunk
             const uint64_t s_hi = std::min(ch[g1 - 1].uoff + ch[g1 - 1].ulen, uend);
             have_hi = (s_hi - upos) >> 1;

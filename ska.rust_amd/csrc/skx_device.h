@@ -167,7 +167,7 @@ void launch_transpose(const uint8_t *in, uint64_t in_pitch, uint64_t rows, uint6
 struct SnapChunk { uint64_t src_off, uoff; uint32_t src_len, ulen, crc, compressed; };   // where its bytes are, where its output belongs
 constexpr uint32_t SKF_SLOT = 8 + 65536;                                                  // frame header + largest payload
 int launch_skf_decode_cells(int device, const uint8_t *src, const SnapChunk *chunks, uint32_t n_chunks, uint64_t upos, uint64_t uend,
-                            uint8_t *cells, uint64_t base_cell, int *status, hipStream_t st);
+                            uint8_t *scratch /* n_chunks x 64 KB */, uint8_t *cells, uint64_t base_cell, int *status, hipStream_t st);
 int launch_skf_encode_cells(int device, const uint8_t *cells, uint64_t base_cell, uint64_t upos, uint64_t uoff0, uint32_t n_chunks,
                             uint8_t *slots, uint32_t *sizes, hipStream_t st);
 void launch_skf_gather(const uint8_t *slots, const uint32_t *sizes, const uint64_t *off, uint32_t n_chunks, uint8_t *dense, hipStream_t st);

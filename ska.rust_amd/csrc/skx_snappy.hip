@@ -4,9 +4,9 @@
 // matrix: U x S cells, each a CBOR uint of two bytes (0x18, base letter), cut by the snappy frame format into independent
 // 64 KB chunks.  That section never has to exist on the host:
 //   load: the compressed chunks go to the device as they are in the file; one wavefront per chunk decodes the snappy
-//         block into LDS (any valid element stream: literals, 1/2/4-byte-offset copies, overlapping copies), checks the
-//         chunk's CRC-32C, checks the 0x18 prefixes and writes the cell bytes row-major for the transpose into the
-//         sample-major matrix;
+//         block (any valid element stream: literals, 1/2/4-byte-offset copies, overlapping copies) -- a sequential walk,
+//         so it runs with many wavefronts per CU and no LDS -- then a workgroup per chunk checks the chunk's CRC-32C and
+//         the 0x18 prefixes and writes the cell bytes row-major for the transpose into the sample-major matrix;
 //   save: one wavefront per chunk builds the chunk's CBOR bytes in LDS from row-major cells, encodes them as snappy
 //         elements (16-byte granules that repeat the bytes two back become copies, 64-byte runs one copy; the rest
 //         literals -- a valid stream for any decoder, ~20x on real arrays), computes the CRC-32C and leaves a finished
@@ -23,11 +23,11 @@ namespace {
 constexpr uint32_t SNAP_CHUNK = 65536;
 constexpr uint32_t CRC_POLY = 0x82F63B78u;                 // CRC-32C (Castagnoli), reflected
 constexpr uint32_t CRC_SEG = 1028;                         // bytes per lane: 257 dwords, so the 64 lanes start in 64 different LDS banks
-constexpr uint32_t SRC_LDS = 8192;                         // compressed chunks up to this size are staged in LDS
-constexpr uint32_t LDS_BYTES = SNAP_CHUNK + 4096 + SRC_LDS + 272;      // + the read-ahead of the 256-byte source window
 
 __device__ uint32_t g_crc_tab[1024];                       // slice-by-4 tables
 __device__ uint32_t g_crc_shift[64];                       // x^(8 * bytes after lane i's segment) for a full 64 KB chunk
+constexpr uint32_t CRC_SEG4 = 260;                         // the same for a 256-thread workgroup: 65 dwords per thread
+__device__ uint32_t g_crc_shift4[256];
 
 inline uint32_t h_gf_mul(uint32_t a, uint32_t b)
 {
@@ -52,6 +52,9 @@ int upload_tables(int device)
     for (uint32_t i = 0; i < 64; i++) { const uint64_t end = std::min<uint64_t>((uint64_t)(i + 1) * CRC_SEG, SNAP_CHUNK); shift[i] = h_xpow_bytes(SNAP_CHUNK - end); }
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_crc_tab), tab, sizeof tab) != hipSuccess) return SKX_ENODEV;
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_crc_shift), shift, sizeof shift) != hipSuccess) return SKX_ENODEV;
+    uint32_t shift4[256];
+    for (uint32_t i = 0; i < 256; i++) { const uint64_t end = std::min<uint64_t>((uint64_t)(i + 1) * CRC_SEG4, SNAP_CHUNK); shift4[i] = h_xpow_bytes(SNAP_CHUNK - end); }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_crc_shift4), shift4, sizeof shift4) != hipSuccess) return SKX_ENODEV;
     if (device >= 0 && device < 64) done[device] = true;
     return SKX_OK;
 }
@@ -91,23 +94,49 @@ __device__ inline uint32_t wave_crc32c(const uint8_t *s_buf, const uint32_t *s_t
     for (int d = 1; d < 64; d <<= 1) c ^= __shfl_xor(c, d);
     return c;
 }
+// the same by a 256-thread workgroup (260-byte segments); s_red: 4 words of LDS.  Contains two barriers.
+__device__ inline uint32_t block_crc32c(const uint8_t *s_buf, const uint32_t *s_tab, uint32_t n, uint32_t tid, uint32_t *s_red)
+{
+    const uint32_t a = min(tid * CRC_SEG4, n), b = min(a + CRC_SEG4, n);
+    uint32_t c = 0xFFFFFFFFu;
+    uint32_t i = a;
+    for (; i + 4 <= b; i += 4) {
+        c ^= *(const uint32_t *)(s_buf + i);
+        c = s_tab[768 + (c & 0xFF)] ^ s_tab[512 + ((c >> 8) & 0xFF)] ^ s_tab[256 + ((c >> 16) & 0xFF)] ^ s_tab[c >> 24];
+    }
+    for (; i < b; i++) c = s_tab[(c ^ s_buf[i]) & 0xFF] ^ (c >> 8);
+    c = ~c;
+    if (a == b) c = 0;
+    const uint32_t w = n == SNAP_CHUNK ? g_crc_shift4[tid] : xpow_bytes(n - b);
+    c = gf_mul(w, c);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) c ^= __shfl_xor(c, d);
+    if ((tid & 63u) == 0) s_red[tid >> 6] = c;
+    __syncthreads();
+    c = s_red[0] ^ s_red[1] ^ s_red[2] ^ s_red[3];
+    __syncthreads();
+    return c;
+}
 __device__ inline uint32_t mask_crc(uint32_t c) { return ((c >> 15) | (c << 17)) + 0xa282ead8u; }
 }  // namespace
 
-// One snappy block -> s_out (LDS), by one wavefront.  The element stream is walked from registers: the wavefront holds a
-// 256-byte window of the source, one dword per lane, and a tag with its (up to four) trailing bytes is two v_readlane away.
-// Copies are one lane per byte (a snappy copy is at most 64 bytes long).  The copy this data is full of -- offset 2, the
-// (0x18, base) pair repeated -- needs no read at all: the pair is kept in two scalars and the lanes write it out.
-template <bool STAGED>
-__device__ __forceinline__ int snappy_block_to_lds(const uint8_t *s_src, const uint8_t *in, uint32_t a0, uint32_t n_in, uint32_t ulen, uint8_t *s_out,
-                                                   uint32_t lane)
+// One snappy block -> out (global memory), by one wavefront.  The element stream is walked from registers: the wavefront holds
+// a 256-byte window of the source, one dword per lane, and a tag with its (up to four) trailing bytes is two v_readlane away.
+// A single wavefront issues an instruction every few cycles at best, so the walk is made cheap per element and run by many
+// wavefronts at once (no LDS, few registers):
+//   * the copy this data is full of -- offset 2, the (0x18, base) pair repeated -- reads nothing: the last two output bytes
+//     are carried in a scalar and the lanes write them out;
+//   * literals come from the source;
+//   * any other copy reads output this wavefront wrote earlier through memory: an agent-scope fence first, then one lane per
+//     byte (a snappy copy is at most 64 bytes long; one that overlaps its own output repeats its last `off` bytes).
+__device__ __forceinline__ int snappy_block_to_global(const uint8_t *__restrict__ in, uint32_t n_in, uint32_t ulen, uint8_t *out, uint32_t lane)
 {
-    const uint32_t *lds4 = (const uint32_t *)s_src;
-    const uint32_t *__restrict__ glb4 = (const uint32_t *)(in - a0);
-    uint32_t wbase = 0, win = STAGED ? lds4[lane] : glb4[lane];
+    const uint32_t a0 = (uint32_t)((uintptr_t)in & 3u);
+    const uint32_t *__restrict__ src4 = (const uint32_t *)(in - a0);
+    uint32_t wbase = 0, win = src4[lane];
     auto fetch = [&](uint32_t ip) -> uint64_t {                        // source bytes ip .. ip+4 in the low 40 bits
         const uint32_t abs = a0 + ip;
-        if (abs - wbase > 244u) { wbase = abs & ~3u; win = STAGED ? lds4[(wbase >> 2) + lane] : glb4[(wbase >> 2) + lane]; }
+        if (abs - wbase > 244u) { wbase = abs & ~3u; win = src4[(wbase >> 2) + lane]; }
         const uint32_t idx = abs - wbase, l = idx >> 2;
         const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)win, (int)l), hi = (uint32_t)__builtin_amdgcn_readlane((int)win, (int)l + 1);
         return (((uint64_t)hi << 32) | lo) >> (8u * (idx & 3u));
@@ -123,17 +152,23 @@ __device__ __forceinline__ int snappy_block_to_lds(const uint8_t *s_src, const u
         }
         if (v != ulen) return 1;
     }
-    uint32_t pair = 0;                                                  // out[op-2] | out[op-1] << 8 once op >= 2 (pair_ok)
+    uint32_t pair = 0;                                                  // out[op-2] | out[op-1] << 8 when pair_ok
     bool pair_ok = false;
+    volatile uint8_t *vout = out;
     while (ip < n_in) {
         const uint64_t x = fetch(ip);
         const uint32_t tag = (uint32_t)x & 0xFFu, type = tag & 3u;
         const uint32_t ext = (uint32_t)(x >> 8);                      // the four bytes after the tag
-        if (((uint32_t)x & 0x00FFFF03u) == 0x00000202u && pair_ok) {   // copy, 2-byte offset == 2: the hot element
+        if (((uint32_t)x & 0x00FFFF03u) == 0x00000202u && op >= 2) {   // copy, 2-byte offset == 2: the hot element
             const uint32_t len = (tag >> 2) + 1;
             if (ip + 3 > n_in || len > ulen - op) return 1;
-            if (lane < len) s_out[op + lane] = (uint8_t)(pair >> (8u * (lane & 1u)));
-            __builtin_amdgcn_wave_barrier();
+            if (!pair_ok) {
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+                const uint32_t t = lane < 2 ? vout[op - 2 + lane] : 0u;
+                pair = (uint32_t)__builtin_amdgcn_readlane((int)t, 0) | ((uint32_t)__builtin_amdgcn_readlane((int)t, 1) << 8);
+                pair_ok = true;
+            }
+            if (lane < len) out[op + lane] = (uint8_t)(pair >> (8u * (lane & 1u)));
             if (len & 1u) pair = (pair >> 8) | ((pair & 0xFFu) << 8);
             op += len; ip += 3;
             continue;
@@ -150,79 +185,77 @@ __device__ __forceinline__ int snappy_block_to_lds(const uint8_t *s_src, const u
                 len += 1;
             }
             if (len > n_in - ip || len > ulen - op) return 1;
-            if (STAGED) for (uint32_t j = lane; j < len; j += 64) s_out[op + j] = s_src[a0 + ip + j];
-            else for (uint32_t j = lane; j < len; j += 64) s_out[op + j] = in[ip + j];
-            __builtin_amdgcn_wave_barrier();                           // LDS operations of a wavefront complete in order; keep the compiler from reordering
+            for (uint32_t j = lane; j < len; j += 64) out[op + j] = in[ip + j];
             ip += len; op += len;
+            if (len >= 2) { pair = (uint32_t)fetch(ip - 2) & 0xFFFFu; pair_ok = true; }
+            else if (pair_ok) pair = (pair >> 8) | (((uint32_t)fetch(ip - 1) & 0xFFu) << 8);
+            continue;
+        }
+        uint32_t len, off;
+        if (type == 1) {
+            if (ip + 2 > n_in) return 1;
+            len = 4 + ((tag >> 2) & 7u); off = ((tag >> 5) << 8) | (ext & 0xFFu); ip += 2;
+        } else if (type == 2) {
+            if (ip + 3 > n_in) return 1;
+            len = (tag >> 2) + 1; off = ext & 0xFFFFu; ip += 3;
         } else {
-            uint32_t len, off;
-            if (type == 1) {
-                if (ip + 2 > n_in) return 1;
-                len = 4 + ((tag >> 2) & 7u); off = ((tag >> 5) << 8) | (ext & 0xFFu); ip += 2;
-            } else if (type == 2) {
-                if (ip + 3 > n_in) return 1;
-                len = (tag >> 2) + 1; off = ext & 0xFFFFu; ip += 3;
-            } else {
-                if (ip + 5 > n_in) return 1;
-                len = (tag >> 2) + 1; off = ext; ip += 5;
-            }
-            if (off == 0 || off > op || len > ulen - op) return 1;
-            // one lane per byte; a copy that overlaps its own output repeats the last `off` bytes
-            uint32_t back = lane;
-            if (off < len) back = (off & (off - 1u)) ? lane % off : (lane & (off - 1u));
-            uint8_t v = 0;
-            if (lane < len) v = s_out[op - off + back];
-            __builtin_amdgcn_wave_barrier();
-            if (lane < len) s_out[op + lane] = v;
-            __builtin_amdgcn_wave_barrier();
-            op += len;
+            if (ip + 5 > n_in) return 1;
+            len = (tag >> 2) + 1; off = ext; ip += 5;
         }
-        // the last two output bytes, for the hot element
-        pair_ok = op >= 2;
-        if (pair_ok) {
-            const uint32_t t = lane < 2 ? s_out[op - 2 + lane] : 0u;
-            pair = (uint32_t)__builtin_amdgcn_readlane((int)t, 0) | ((uint32_t)__builtin_amdgcn_readlane((int)t, 1) << 8);
-        }
+        if (off == 0 || off > op || len > ulen - op) return 1;
+        uint32_t back = lane;
+        if (off < len) back = (off & (off - 1u)) ? lane % off : (lane & (off - 1u));
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");             // this wavefront's earlier stores, visible to its loads
+        uint32_t v = 0;
+        if (lane < len) v = vout[op - off + back];
+        if (lane < len) out[op + lane] = (uint8_t)v;
+        op += len;
+        if (len >= 2) { pair = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)len - 2) | ((uint32_t)__builtin_amdgcn_readlane((int)v, (int)len - 1) << 8); pair_ok = true; }
+        else if (pair_ok) pair = (pair >> 8) | ((uint32_t)__builtin_amdgcn_readlane((int)v, 0) << 8);
     }
     return op == ulen ? 0 : 1;
 }
 
 // ---------------------------------------------------------------------------------------------------------------- load
 // status: 0 ok, 1 corrupt snappy block, 2 checksum mismatch, 3 a cell that is not (0x18, byte)
-__global__ __launch_bounds__(64) void skf_decode_cells_kernel(const uint8_t *__restrict__ src, const SnapChunk *__restrict__ chunks,
-                                                              uint64_t upos, uint64_t uend, uint8_t *__restrict__ cells, uint64_t base_cell,
-                                                              int *status)
+// Step 1: chunk -> scratch[chunk * 64 KB ..): four chunks per workgroup, one per wavefront.
+__global__ __launch_bounds__(256) void skf_decode_kernel(const uint8_t *__restrict__ src, const SnapChunk *__restrict__ chunks, uint32_t n_chunks,
+                                                        uint8_t *__restrict__ scratch, int *status)
+{
+    const uint32_t lane = threadIdx.x & 63u, ci = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (ci >= n_chunks) return;
+    const SnapChunk c = chunks[ci];
+    const uint8_t *in = src + c.src_off;
+    uint8_t *out = scratch + (uint64_t)ci * SNAP_CHUNK;
+    int err = 0;
+    if (c.ulen > SNAP_CHUNK) err = 1;
+    else if (!c.compressed) {
+        if (c.src_len != c.ulen) err = 1;
+        else for (uint32_t i = lane; i < c.ulen; i += 64) out[i] = in[i];
+    } else err = snappy_block_to_global(in, c.src_len, c.ulen, out, lane);
+    if (err && lane == 0) atomicMax(status, err);
+}
+
+// Step 2: a workgroup per chunk: CRC-32C, 0x18 prefixes, cell bytes to their row-major place.
+__global__ __launch_bounds__(256) void skf_cells_kernel(const uint8_t *__restrict__ scratch, const SnapChunk *__restrict__ chunks, uint64_t upos, uint64_t uend,
+                                                       uint8_t *__restrict__ cells, uint64_t base_cell, int *status)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
     uint8_t *s_out = s_mem;
     uint32_t *s_tab = (uint32_t *)(s_mem + SNAP_CHUNK);
-    uint8_t *s_src = s_mem + SNAP_CHUNK + 4096;
-    const uint32_t lane = threadIdx.x;
+    uint32_t *s_red = s_tab + 1024;
+    const uint32_t tid = threadIdx.x;
     const SnapChunk c = chunks[blockIdx.x];
-    for (uint32_t i = lane; i < 1024; i += 64) s_tab[i] = g_crc_tab[i];
-    const uint8_t *in = src + c.src_off;
-    const uint32_t n_in = c.src_len, ulen = c.ulen;
-    const uint32_t a0 = (uint32_t)((uintptr_t)in & 3u);
-    const bool staged = n_in <= SRC_LDS;
-    if (staged) {
-        const uint32_t *in4 = (const uint32_t *)(in - a0);
-        const uint32_t nd = (a0 + n_in + 3) >> 2;
-        for (uint32_t i = lane; i < nd; i += 64) ((uint32_t *)s_src)[i] = in4[i];
+    const uint32_t ulen = c.ulen;
+    if (ulen > SNAP_CHUNK) return;                                      // step 1 has flagged it
+    for (uint32_t i = tid; i < 1024; i += 256) s_tab[i] = g_crc_tab[i];
+    {
+        const uint4 *g = (const uint4 *)(scratch + (uint64_t)blockIdx.x * SNAP_CHUNK);
+        for (uint32_t i = tid; i < (ulen + 15) / 16; i += 256) ((uint4 *)s_out)[i] = g[i];
     }
     __syncthreads();
-    int err = 0;
-    if (!c.compressed) {
-        if (n_in != ulen || ulen > SNAP_CHUNK) err = 1;
-        else if (staged) for (uint32_t i = lane; i < ulen; i += 64) s_out[i] = s_src[a0 + i];
-        else for (uint32_t i = lane; i < ulen; i += 64) s_out[i] = in[i];
-    } else if (staged) err = snappy_block_to_lds<true>(s_src, in, a0, n_in, ulen, s_out, lane);
-    else err = snappy_block_to_lds<false>(s_src, in, a0, n_in, ulen, s_out, lane);
-    __syncthreads();
-    if (!err) {
-        const uint32_t crc = mask_crc(wave_crc32c(s_out, s_tab, ulen, lane));
-        if (crc != c.crc) err = 2;
-    }
-    if (err) { if (lane == 0) atomicMax(status, err); return; }
+    const uint32_t crc = mask_crc(block_crc32c(s_out, s_tab, ulen, tid, s_red));
+    if (crc != c.crc) { if (tid == 0) atomicMax(status, 2); return; }
 
     // the part of this chunk inside the data section [upos, uend): chunk-local bytes [lo, hi)
     const uint64_t uoff = c.uoff;
@@ -233,20 +266,20 @@ __global__ __launch_bounds__(64) void skf_decode_cells_kernel(const uint8_t *__r
     {
         const uint32_t d0 = (lo + 3) >> 2, d1 = hi >> 2;
         const uint32_t mask = vpar ? 0x00FF00FFu : 0xFF00FF00u, want = vpar ? 0x00180018u : 0x18001800u;
-        for (uint32_t d = d0 + lane; d < d1; d += 64) odd |= (((const uint32_t *)s_out)[d] & mask) != want;
-        if (lane < 8) {                                               // the ragged ends, byte by byte
-            const uint32_t e0 = lane < 4 ? lo + lane : (max(d1, d0) << 2) + (lane - 4);
-            const uint32_t lim = lane < 4 ? min(d0 << 2, hi) : hi;
+        for (uint32_t d = d0 + tid; d < d1; d += 256) odd |= (((const uint32_t *)s_out)[d] & mask) != want;
+        if (tid < 8) {                                                // the ragged ends, byte by byte
+            const uint32_t e0 = tid < 4 ? lo + tid : (max(d1, d0) << 2) + (tid - 4);
+            const uint32_t lim = tid < 4 ? min(d0 << 2, hi) : hi;
             if (e0 >= lo && e0 < lim && (e0 & 1u) != vpar) odd |= s_out[e0] != 0x18;
         }
     }
-    if (__ballot(odd)) { if (lane == 0) atomicMax(status, 3); return; }
+    if (__syncthreads_or(odd)) { if (tid == 0) atomicMax(status, 3); return; }
     const uint32_t b0 = lo + (((lo & 1u) != vpar) ? 1u : 0u);         // first value byte
     if (b0 >= hi) return;
     const uint64_t ci_lo = (uoff + b0 - upos) >> 1;
     const uint64_t count = ((uint64_t)(hi - b0) + 1) >> 1;
     const uint64_t rel_lo = ci_lo - base_cell, rel_hi = rel_lo + count;
-    for (uint64_t w = (rel_lo & ~7ull) + 8ull * lane; w < rel_hi; w += 512) {
+    for (uint64_t w = (rel_lo & ~7ull) + 8ull * tid; w < rel_hi; w += 2048) {
         if (w >= rel_lo && w + 8 <= rel_hi) {
             const uint8_t *p = s_out + b0 + 2 * (uint32_t)(w - rel_lo);
             uint64_t v = 0;
@@ -262,13 +295,15 @@ __global__ __launch_bounds__(64) void skf_decode_cells_kernel(const uint8_t *__r
     }
 }
 
-int launch_skf_decode_cells(int device, const uint8_t *src, const SnapChunk *chunks, uint32_t n_chunks, uint64_t upos, uint64_t uend, uint8_t *cells,
-                            uint64_t base_cell, int *status, hipStream_t st)
+int launch_skf_decode_cells(int device, const uint8_t *src, const SnapChunk *chunks, uint32_t n_chunks, uint64_t upos, uint64_t uend, uint8_t *scratch,
+                            uint8_t *cells, uint64_t base_cell, int *status, hipStream_t st)
 {
     if (!n_chunks) return SKX_OK;
     SKX_TRY(upload_tables(device));
-    (void)hipFuncSetAttribute((const void *)skf_decode_cells_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-    hipLaunchKernelGGL(skf_decode_cells_kernel, dim3(n_chunks), dim3(64), LDS_BYTES, st, src, chunks, upos, uend, cells, base_cell, status);
+    const uint32_t lds = SNAP_CHUNK + 4096 + 16;
+    (void)hipFuncSetAttribute((const void *)skf_cells_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(skf_decode_kernel, dim3((n_chunks + 3) / 4), dim3(256), 0, st, src, chunks, n_chunks, scratch, status);
+    hipLaunchKernelGGL(skf_cells_kernel, dim3(n_chunks), dim3(256), lds, st, scratch, chunks, upos, uend, cells, base_cell, status);
     return SKX_OK;
 }
 

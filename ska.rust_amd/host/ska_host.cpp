@@ -8,9 +8,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <fstream>
 #include <sstream>
 #include <string>
+#include <fcntl.h>
 #include <unistd.h>
 #include <vector>
 
@@ -103,6 +105,17 @@ extern "C" int skh_align(skx_array *a, int filter_type, int mask_ambig, int igno
     int r = skh_apply_filters(a, min_freq, filter_ambig_as_missing, filter_type, mask_ambig, ignore_const_gaps, &removed);
     if (r != SKX_OK) return r;
     return skx_array_fasta(a, buf, len);
+    });
+}
+
+// the same, written straight to a file descriptor (the alignment of a large array is never held on the host)
+extern "C" int skh_align_fd(skx_array *a, int filter_type, int mask_ambig, int ignore_const_gaps, double min_freq, int filter_ambig_as_missing, int fd)
+{
+    return skx_guarded([&]() -> int {
+    int32_t removed = 0;
+    int r = skh_apply_filters(a, min_freq, filter_ambig_as_missing, filter_type, mask_ambig, ignore_const_gaps, &removed);
+    if (r != SKX_OK) return r;
+    return skx_array_write_fasta(a, fd);
     });
 }
 
@@ -401,8 +414,12 @@ extern "C" int skh_main(int argc, char **argv)
     }
     int threads = atoi(a.get("--threads", "1").c_str());
     if (threads < 1) return fail("Threads must be one or higher");
+    const auto t_main = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_main).count(); };
+    const bool dbg = getenv("SKX_DEBUG") != nullptr;
     skx_ctx *ctx = nullptr;
     if (skx_ctx_create(0, &ctx) != SKX_OK) return engine_fail();
+    if (dbg) fprintf(stderr, "[skx] main: device context after %.2f s\n", since());
     int rcode = 0;
     skx_array *arr = nullptr;
     if (cmd == "build") {
@@ -462,11 +479,12 @@ extern "C" int skh_main(int argc, char **argv)
         if (filter < 0) return fail("invalid --filter");
         const double mf = atof(a.get("--min-freq", a.get("-m", "0.9")).c_str());
         if (mf < 0 || mf > 1) return fail("Frequency must be between 0 and 1 (inclusive)");
-        char *buf = nullptr; uint64_t len = 0;
+        int fd = 1;                                                                                               // io_utils::set_ostream: stdout or -o
+        if (a.has("-o")) { fd = open(a.get("-o").c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644); if (fd < 0) return fail("cannot create output file"); }
         if (skh_load_array(ctx, in.data(), (int)in.size(), threads, &arr) != SKX_OK ||
-            skh_align(arr, filter, a.has("--ambig-mask"), a.has("--no-gap-only-sites"), mf, a.has("--filter-ambig-as-missing"), &buf, &len) != SKX_OK)
+            skh_align_fd(arr, filter, a.has("--ambig-mask"), a.has("--no-gap-only-sites"), mf, a.has("--filter-ambig-as-missing"), fd) != SKX_OK)
             rcode = engine_fail();
-        else { rcode = emit(a.get("-o"), buf, len); skx_free(buf); }
+        if (fd != 1) close(fd);
     } else if (cmd == "distance") {
         if (a.pos.size() != 1) return fail("one .skf file required");
         const char *in[1] = {a.pos[0].c_str()};
@@ -532,7 +550,9 @@ extern "C" int skh_main(int argc, char **argv)
     } else {
         rcode = fail("unknown subcommand (this engine provides build, align, map, distance, nk, merge, delete, weed, cov)");
     }
+    if (dbg) fprintf(stderr, "[skx] main: %s done after %.2f s\n", cmd.c_str(), since());
     if (arr) skx_array_free(arr);
     skx_ctx_destroy(ctx);
+    if (dbg) fprintf(stderr, "[skx] main: device memory released after %.2f s\n", since());
     return rcode;
 }

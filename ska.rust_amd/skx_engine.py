@@ -53,7 +53,7 @@ skx_array_assemble skx_merge skx_build_and_merge skx_array_free skx_array_save s
 skx_array_info skx_array_name skx_array_version skx_array_export skx_array_sample_kmers skx_array_filter
 skx_array_write_fasta skx_array_fasta skx_array_device_matrix skx_array_device_stats skx_array_set_total_samples skx_array_distance skx_free skx_ctx_timings
 skx_array_merge skx_array_delete_samples skx_array_weed skx_keyset_from_fasta skx_array_ctx skx_set_last_error skx_array_map skx_cov_histogram
-skh_apply_filters skh_align skh_distance_tsv skh_nk skh_save_skf skh_load_array skh_sample_name skh_main skh_merge skh_delete skh_weed skh_cov skh_cov_fit""".split()
+skh_apply_filters skh_align skh_align_fd skh_distance_tsv skh_nk skh_save_skf skh_load_array skh_sample_name skh_main skh_merge skh_delete skh_weed skh_cov skh_cov_fit""".split()
 
 _lib = None
 
@@ -499,6 +499,10 @@ class Array:
         p, n = C.c_void_p(), C.c_uint64()
         _check(_lib.skx_array_fasta(self.h, C.byref(p), C.byref(n)))
         return _take(p, n)
+
+    def write_fasta(self, fd):
+        """write_fasta streamed to a file descriptor (merge_ska_array.rs:507-520)."""
+        _check(_lib.skx_array_write_fasta(self.h, int(fd)))
 
     def device_matrix(self):
         p, pitch, rows = C.c_void_p(), C.c_uint64(), C.c_uint64()

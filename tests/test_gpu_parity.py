@@ -629,3 +629,20 @@ def test_skf_device_codec_alignments(E, tmp_path, n_samples, pad, monkeypatch):
         oa = ora.Array.load(files[written])
         for x, y in zip(_sorted_export(oa), rows):
             assert np.array_equal(x, y), written
+
+
+def test_write_fasta_streamed_equals_buffer(E, tmp_path):
+    """skx_array_write_fasta (pinned double buffers + writer thread) puts out exactly the text skx_array_fasta builds."""
+    rng = np.random.default_rng(77)
+    _, samples = _related_samples(rng, 9, length=20_000, snps=150)
+    names = [f"sample_{i}" * (1 + i % 3) for i in range(9)]
+    ga = E.DictSet.build([E.record_stream(s) for s in samples], 31, True).merge(names)
+    ga.apply_filters(0.5, False, E.FILTER_NO_CONST, False, False)
+    want = ga.fasta()
+    p = tmp_path / "aln.fa"
+    fd = os.open(str(p), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    try:
+        ga.write_fasta(fd)
+    finally:
+        os.close(fd)
+    assert p.read_bytes() == want and want.count(b">") == 9
