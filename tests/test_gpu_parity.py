@@ -646,3 +646,155 @@ def test_write_fasta_streamed_equals_buffer(E, tmp_path):
     finally:
         os.close(fd)
     assert p.read_bytes() == want and want.count(b">") == 9
+
+
+# ---- a snappy frame re-encoder for the decoder test: every element type the format has, chosen at random -------------------
+def _crc32c_table():
+    tab = []
+    for i in range(256):
+        c = i
+        for _ in range(8):
+            c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+        tab.append(c)
+    return tab
+
+
+_CRC_TAB = _crc32c_table()
+
+
+def _masked_crc32c(data):
+    c = 0xFFFFFFFF
+    for b in data:
+        c = _CRC_TAB[(c ^ b) & 0xFF] ^ (c >> 8)
+    c ^= 0xFFFFFFFF
+    return (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def _snappy_decode(block):
+    n, shift, ip = 0, 0, 0
+    while True:
+        b = block[ip]; ip += 1
+        n |= (b & 0x7F) << shift; shift += 7
+        if not b & 0x80:
+            break
+    out = bytearray()
+    while ip < len(block):
+        tag = block[ip]; ip += 1
+        t = tag & 3
+        if t == 0:
+            ln = (tag >> 2) + 1
+            if ln > 60:
+                nb = ln - 60
+                ln = int.from_bytes(block[ip:ip + nb], "little") + 1; ip += nb
+            out += block[ip:ip + ln]; ip += ln
+            continue
+        if t == 1:
+            ln, off = 4 + ((tag >> 2) & 7), ((tag >> 5) << 8) | block[ip]; ip += 1
+        elif t == 2:
+            ln, off = (tag >> 2) + 1, int.from_bytes(block[ip:ip + 2], "little"); ip += 2
+        else:
+            ln, off = (tag >> 2) + 1, int.from_bytes(block[ip:ip + 4], "little"); ip += 4
+        for _ in range(ln):
+            out.append(out[-off])
+    assert len(out) == n
+    return bytes(out)
+
+
+def _snappy_encode_random(data, rng, one_literal=False):
+    n = len(data)
+    out = bytearray()
+    v = n
+    while True:
+        out.append((v & 0x7F) | (0x80 if v >> 7 else 0)); v >>= 7
+        if not v:
+            break
+
+    def literal(lo, hi):
+        ln = hi - lo
+        if ln <= 60:
+            out.append((ln - 1) << 2)
+        else:
+            nb = 1 if ln - 1 < 256 else (2 if ln - 1 < 65536 else 3)
+            if rng.random() < 0.2 and nb < 4:
+                nb += 1                                   # a wider length field than needed is still valid
+            out.append((59 + nb) << 2); out.extend((ln - 1).to_bytes(nb, "little"))
+        out.extend(data[lo:hi])
+
+    if one_literal:
+        literal(0, n)
+        return bytes(out)
+    offs = [1, 2, 3, 4, 5, 7, 8, 16, 63, 64, 65, 100, 1000, 2046, 2047, 2048, 5000, 40000, 65535]
+    i = 0
+    while i < n:
+        best_len, best_off = 0, 0
+        for off in rng.choice(offs, size=6, replace=False):
+            off = int(off)
+            if off > i:
+                continue
+            ln = 0
+            while ln < 64 and i + ln < n and data[i + ln] == data[i + ln - off]:
+                ln += 1
+            if ln > best_len:
+                best_len, best_off = ln, off
+        if best_len >= 1 and rng.random() < 0.9:
+            ln = int(rng.integers(1, best_len + 1)) if rng.random() < 0.3 else best_len
+            kinds = [2, 4] if best_off < 65536 else [4]
+            if 4 <= ln <= 11 and best_off < 2048:
+                kinds.append(1)
+            kind = int(rng.choice(kinds))
+            if kind == 1:
+                out.append(1 | ((ln - 4) << 2) | ((best_off >> 8) << 5)); out.append(best_off & 0xFF)
+            elif kind == 2:
+                out.append(2 | ((ln - 1) << 2)); out.extend(best_off.to_bytes(2, "little"))
+            else:
+                out.append(3 | ((ln - 1) << 2)); out.extend(best_off.to_bytes(4, "little"))
+            i += ln
+        else:
+            ln = min(n - i, int(rng.choice([1, 2, 3, 17, 60, 61, 64, 200, 300])))
+            literal(i, i + ln)
+            i += ln
+    return bytes(out)
+
+
+def _reencode_skf(raw, rng):
+    """snappy frame -> the same stream, every compressed chunk re-encoded with random (valid) elements."""
+    assert raw[:10] == b"\xff\x06\x00\x00sNaPpY"
+    out = bytearray(raw[:10])
+    i, k = 10, 0
+    while i < len(raw):
+        typ, ln = raw[i], int.from_bytes(raw[i + 1:i + 4], "little")
+        body = raw[i + 4:i + 4 + ln]
+        i += 4 + ln
+        assert typ in (0, 1)
+        data = _snappy_decode(body[4:]) if typ == 0 else bytes(body[4:])
+        assert _masked_crc32c(data) == int.from_bytes(body[:4], "little")
+        enc = _snappy_encode_random(data, rng, one_literal=(k in (2, 8)))
+        assert _snappy_decode(enc) == data
+        out += b"\x00" + (len(enc) + 4).to_bytes(3, "little") + _masked_crc32c(data).to_bytes(4, "little") + enc
+        k += 1
+    return bytes(out)
+
+
+def test_skf_device_decoder_takes_any_valid_element_stream(E, tmp_path, monkeypatch):
+    """Files written by other snappy encoders (the reference's `snap` crate) hold whatever elements their match finder
+    chose.  Here every chunk of a file is re-encoded with elements drawn at random from all the format has -- literals with
+    0-4 length bytes, copies with 1/2/4-byte offsets, copies overlapping their own output at odd offsets -- and must load on
+    the device path to the same array."""
+    rng = np.random.default_rng(123)
+    _, samples = _related_samples(rng, 5, length=40_000, snps=300)
+    names = [f"s{i}" for i in range(5)]
+    ga = E.DictSet.build([E.record_stream(s) for s in samples], 31, True).merge(names)
+    rows = _sorted_export(ga)
+    monkeypatch.setenv("SKX_SKF_DEVICE", "0")
+    p = str(tmp_path / "host.skf")
+    ga.save(p)
+    re = _reencode_skf(open(p, "rb").read(), rng)
+    p2 = str(tmp_path / "random_elements.skf")
+    open(p2, "wb").write(re)
+    for mode, group in (("1", "2"), ("1", "8192"), ("0", "8192")):
+        monkeypatch.setenv("SKX_SKF_DEVICE", mode)
+        monkeypatch.setenv("SKX_SKF_GROUP_CHUNKS", group)
+        back = E.Array.load(p2)
+        assert back.names == names
+        for x, y in zip(_sorted_export(back), rows):
+            assert np.array_equal(x, y), (mode, group)
