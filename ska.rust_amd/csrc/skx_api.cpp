@@ -1200,12 +1200,19 @@ extern "C" int skx_array_write_fasta(skx_array *a, int fd)
     size_t max_rec = 0;
     for (auto &nm : a->names) max_rec = std::max<size_t>(max_rec, nm.size() + U + 3);
     const size_t cap = std::max<size_t>(max_rec, 64u << 20);
-    struct Pinned { char *p = nullptr; ~Pinned() { if (p) (void)hipHostFree(p); } } pin[2];
-    for (auto &b : pin) if (hipHostMalloc((void **)&b.p, cap, hipHostMallocDefault) != hipSuccess) { b.p = nullptr; set_error("out of host memory"); return SKX_ENOMEM; }
-    struct Writer { std::thread th; bool ok = true; void join() { if (th.joinable()) th.join(); } ~Writer() { join(); } } wr;
-    int flip = 0;
-    for (size_t s = 0; s < S;) {
-        char *buf = pin[flip].p; size_t used = 0;
+    // a regular file takes several batches at once (pwrite at known offsets); a pipe takes them in order
+    struct stat sb;
+    const bool regular = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
+    off_t pos = regular ? lseek(fd, 0, SEEK_CUR) : 0;
+    const int NB = regular && pos >= 0 ? 6 : 2;
+    struct Slot { char *p = nullptr; std::thread th; ~Slot() { if (th.joinable()) th.join(); if (p) (void)hipHostFree(p); } } slot[6];
+    for (int b = 0; b < NB; b++) if (hipHostMalloc((void **)&slot[b].p, cap, hipHostMallocDefault) != hipSuccess) { slot[b].p = nullptr; set_error("out of host memory"); return SKX_ENOMEM; }
+    std::atomic<bool> ok{true};
+    int cur = 0, last = -1;
+    for (size_t s = 0; s < S && ok;) {
+        Slot &sl = slot[cur];
+        if (sl.th.joinable()) sl.th.join();
+        char *buf = sl.p; size_t used = 0;
         while (s < S && used + a->names[s].size() + U + 3 <= cap) {
             const std::string &nm = a->names[s];
             buf[used++] = '>'; memcpy(buf + used, nm.data(), nm.size()); used += nm.size(); buf[used++] = '\n';
@@ -1214,16 +1221,22 @@ extern "C" int skx_array_write_fasta(skx_array *a, int fd)
             s++;
         }
         SKX_HIP(hipStreamSynchronize(st));
-        wr.join();
-        if (!wr.ok) break;
-        wr.th = std::thread([&wr, buf, used, fd]() {
+        if (NB == 2 && last >= 0 && slot[last].th.joinable()) slot[last].th.join();          // keep the order on a pipe
+        const off_t at = pos;
+        const bool positioned = NB > 2;
+        sl.th = std::thread([&ok, buf, used, fd, at, positioned]() {
             size_t w = 0;
-            while (w < used) { const ssize_t r = write(fd, buf + w, used - w); if (r <= 0) { wr.ok = false; return; } w += (size_t)r; }
+            while (w < used) {
+                const ssize_t r = positioned ? pwrite(fd, buf + w, used - w, at + (off_t)w) : write(fd, buf + w, used - w);
+                if (r <= 0) { ok = false; return; }
+                w += (size_t)r;
+            }
         });
-        flip ^= 1;
+        pos += (off_t)used; last = cur; cur = (cur + 1) % NB;
     }
-    wr.join();
-    if (!wr.ok) { set_error("write failed"); return SKX_EIO; }
+    for (int b = 0; b < NB; b++) if (slot[b].th.joinable()) slot[b].th.join();
+    if (!ok) { set_error("write failed"); return SKX_EIO; }
+    if (NB > 2) (void)lseek(fd, pos, SEEK_SET);
     return SKX_OK;
     });
 }
