@@ -83,8 +83,11 @@ __device__ static inline uint32_t block_excl_scan(uint32_t v, uint32_t *s_tmp, u
 // bases | codes+masks, later aliased by the staging buffer.  16 window-end positions per thread.  The tile's words are
 // staged in bucket order (one pass: TILE words = 128 KB) so that the copy-out writes every (tile, bucket) chunk with
 // adjacent lanes (few, wide L2 write requests).  HI: the bucket bits of a packed word lie in its upper half.
-template <bool SCATTER, int TILE, bool HI, int PPT>
-__global__ __launch_bounds__(TILE / PPT) void extract_kernel(ExtractArgs a)
+// SPLIT: the staging buffer holds half a tile at a time (the lower half of the bucket space, then the upper half), so a
+// 12 288-position tile needs 57 KB of LDS instead of 105 KB and two 768-thread workgroups share a CU (85-VGPR cap), with
+// the same (tile, bucket) chunks in the word buffer as single-pass staging would write.
+template <bool SCATTER, int TILE, bool HI, int PPT, bool SPLIT, int RMAX>
+__global__ __launch_bounds__(TILE / PPT, SPLIT ? 6 : 1) void extract_kernel(ExtractArgs a)
 {
     constexpr int NT = TILE / PPT;
     constexpr int NCH = PPT / 16;                                      // 16-base chunks per thread
@@ -223,8 +226,7 @@ __global__ __launch_bounds__(TILE / PPT) void extract_kernel(ExtractArgs a)
     }
     // reserve one chunk per non-empty bucket in the sample's region (global cursor); the returned bases are not needed
     // until the copy-out, so the atomics stay in flight behind the block scan and the staging pass
-    constexpr int RMAX = (8192 + NT - 1) / NT;              // buckets per thread at most (B <= 8192)
-    const int R = (B + NT - 1) / NT;
+    const int R = (B + NT - 1) / NT;                        // buckets per thread (<= RMAX: the launcher picks RMAX from logB)
     const int b0 = tid * R < B ? tid * R : B, b1 = b0 + R < B ? b0 + R : B;
     uint32_t gb[RMAX], lsum = 0;
 #pragma unroll
@@ -240,10 +242,15 @@ __global__ __launch_bounds__(TILE / PPT) void extract_kernel(ExtractArgs a)
         if (b0 + r < b1) { const uint32_t n = s_hist[b0 + r]; s_hist[b0 + r] = lrun; lrun += n; }
     if (tid == 0) s_hist[B] = total;                        // sentinel: start of the (non-existent) bucket B
     __syncthreads();
+    constexpr uint32_t HALF = SPLIT ? TILE / 2 : TILE;      // staged words per round
+    const int bsh_hi = a.hp.bits + 4 - 32 - a.logB;          // HI: bucket = upper half >> bsh_hi
+    uint32_t sidx_[SPLIT ? PPT : 1];                        // SPLIT: the staged index of my words (0xFFFFFFFF = no window), kept for round two
 #pragma unroll
     for (int j = 0; j < PPT; j++) {
         const uint32_t b = rk[j] >> 16;
-        if (b < (uint32_t)B) s_stage[s_hist[b] + (rk[j] & 0xFFFFu)] = wv[j];
+        const uint32_t idx = b < (uint32_t)B ? s_hist[b] + (rk[j] & 0xFFFFu) : 0xFFFFFFFFu;
+        if (SPLIT) sidx_[j] = idx;
+        if (idx < HALF) s_stage[idx] = wv[j];
     }
     // first use of the cursor atomics' results.  A staged word at index i goes to word s_base[bucket] + i of the sample's
     // span of the word buffer: s_base = region offset inside the span + chunk base - local start (all 32-bit; the span
@@ -263,43 +270,63 @@ __global__ __launch_bounds__(TILE / PPT) void extract_kernel(ExtractArgs a)
     __syncthreads();
     typedef uint64_t __attribute__((address_space(1))) *gout_t;
     gout_t out = (gout_t)(uintptr_t)(a.words + span0);
-    const int bsh_hi = a.hp.bits + 4 - 32 - a.logB;          // HI: bucket = upper half >> bsh_hi
-    for (uint32_t i = tid; i < total; i += NT) {
+    const uint32_t end0 = total < HALF ? total : HALF;
+    for (uint32_t i = tid; i < end0; i += NT) {
         const uint64_t w = s_stage[i];
         const uint32_t b = HI ? (uint32_t)(w >> 32) >> bsh_hi : (uint32_t)((w >> 4) >> bshift);
         uint32_t r = s_base[b] + i;
         r = r < span_last ? r : span_last;                                    // an overflowing chunk must not leave the sample's span
         out[r] = w;
     }
+    if (SPLIT && total > HALF) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PPT; j++) if (sidx_[j] != 0xFFFFFFFFu && sidx_[j] >= HALF) s_stage[sidx_[j] - HALF] = wv[j];
+        __syncthreads();
+        for (uint32_t i = HALF + tid; i < total; i += NT) {
+            const uint64_t w = s_stage[i - HALF];
+            const uint32_t b = HI ? (uint32_t)(w >> 32) >> bsh_hi : (uint32_t)((w >> 4) >> bshift);
+            uint32_t r = s_base[b] + i;
+            r = r < span_last ? r : span_last;
+            out[r] = w;
+        }
+    }
     if (dropped) *a.overflow = 1;
 }
 
-template <int TILE>
+template <int TILE, bool SPLIT>
 static inline size_t extract_lds(const ExtractArgs &a, bool scatter)
 {
     size_t codes = (size_t)(TILE / 16 + 8) * 10 + 64;
-    size_t stage = scatter ? (size_t)TILE * 8 : 0;
+    size_t stage = scatter ? (size_t)TILE * (SPLIT ? 4 : 8) : 0;
     return ((size_t)8 << a.logB) + 16 + 80 + (stage > codes ? stage : codes);
 }
-template <bool SCATTER, int TILE, bool HI, int PPT>
+template <bool SCATTER, int TILE, bool HI, int PPT, bool SPLIT, int RMAX>
 static void launch_extract_t(const ExtractArgs &a, hipStream_t st)
 {
     const uint64_t g = (((uint64_t)a.n_samples + 7) / 8) * 8ull * (uint64_t)a.tiles_max;
     if (!g) return;
-    const size_t lds = extract_lds<TILE>(a, SCATTER);
-    (void)hipFuncSetAttribute((const void *)extract_kernel<SCATTER, TILE, HI, PPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((extract_kernel<SCATTER, TILE, HI, PPT>), dim3((unsigned)g), dim3(TILE / PPT), lds, st, a);
+    const size_t lds = extract_lds<TILE, SPLIT>(a, SCATTER);
+    (void)hipFuncSetAttribute((const void *)extract_kernel<SCATTER, TILE, HI, PPT, SPLIT, RMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((extract_kernel<SCATTER, TILE, HI, PPT, SPLIT, RMAX>), dim3((unsigned)g), dim3(TILE / PPT), lds, st, a);
 }
 template <bool SCATTER>
 static void launch_extract(const ExtractArgs &a, hipStream_t st)
 {
     const bool hi = a.hp.bits + 4 - 32 - a.logB >= 0;
-    if (extract_tile_bases(a.logB) == 16384) { if (hi) launch_extract_t<SCATTER, 16384, true, 16>(a, st); else launch_extract_t<SCATTER, 16384, false, 16>(a, st); }
-    else { if (hi) launch_extract_t<SCATTER, 8192, true, 16>(a, st); else launch_extract_t<SCATTER, 8192, false, 16>(a, st); }
+    if (a.logB <= 10) {          // 12 288 positions x 768 threads, half-tile staging: two workgroups per CU, 12-word chunks
+        if (hi) launch_extract_t<SCATTER, 12288, true, 16, SCATTER, 2>(a, st); else launch_extract_t<SCATTER, 12288, false, 16, SCATTER, 2>(a, st);
+    } else if (a.logB == 11) {   // 16 384 x 1 024, one workgroup per CU
+        if (hi) launch_extract_t<SCATTER, 16384, true, 16, false, 2>(a, st); else launch_extract_t<SCATTER, 16384, false, 16, false, 2>(a, st);
+    } else {                     // 8 192 x 512 (4 096 / 8 192 buckets: the histogram dominates the LDS)
+        if (hi) launch_extract_t<SCATTER, 8192, true, 16, false, 16>(a, st); else launch_extract_t<SCATTER, 8192, false, 16, false, 16>(a, st);
+    }
 }
-// 8 192 positions x 512 threads (two workgroups per CU) while a (tile, bucket) chunk still averages >= 8 words, 16 384 x 1 024
-// (one per CU) for 2 048 buckets, 8 192 again when the two [B] LDS arrays leave no room for the larger staging buffer
-int extract_tile_bases(int logB) { return logB == 11 ? 16384 : 8192; }
+// Tile sizes.  What HBM delivers for this kernel's writes depends on the size of the (tile, bucket) chunk (tools/scatter_bw.hip:
+// 3.5 TB/s for 64-byte pieces, 5.2 TB/s from 128 bytes up, 5.7 TB/s streaming), so the tile is as large as two resident
+// workgroups allow: 1 024-bucket samples get 12 288 positions (12-word chunks) with the staging buffer holding half a tile
+// at a time (57 KB of LDS, 77 VGPRs x 768 threads); 2 048-bucket samples 16 384 positions with one workgroup per CU.
+int extract_tile_bases(int logB) { return logB <= 10 ? 12288 : (logB == 11 ? 16384 : 8192); }
 void launch_hist(const ExtractArgs &a, hipStream_t st) { launch_extract<false>(a, st); }
 void launch_scatter(const ExtractArgs &a, hipStream_t st) { launch_extract<true>(a, st); }
 
