@@ -316,17 +316,19 @@ static void launch_extract(const ExtractArgs &a, hipStream_t st)
     const bool hi = a.hp.bits + 4 - 32 - a.logB >= 0;
     if (a.logB <= 10) {          // 12 288 positions x 768 threads, half-tile staging: two workgroups per CU, 12-word chunks
         if (hi) launch_extract_t<SCATTER, 12288, true, 16, SCATTER, 2>(a, st); else launch_extract_t<SCATTER, 12288, false, 16, SCATTER, 2>(a, st);
-    } else if (a.logB == 11) {   // 16 384 x 1 024, one workgroup per CU
-        if (hi) launch_extract_t<SCATTER, 16384, true, 16, false, 2>(a, st); else launch_extract_t<SCATTER, 16384, false, 16, false, 2>(a, st);
-    } else {                     // 8 192 x 512 (4 096 / 8 192 buckets: the histogram dominates the LDS)
-        if (hi) launch_extract_t<SCATTER, 8192, true, 16, false, 16>(a, st); else launch_extract_t<SCATTER, 8192, false, 16, false, 16>(a, st);
+    } else if (a.logB == 11) {   // the same with three buckets per thread (6-word chunks; the wider cursor array costs 3 VGPRs and a small spill)
+        if (hi) launch_extract_t<SCATTER, 12288, true, 16, SCATTER, 4>(a, st); else launch_extract_t<SCATTER, 12288, false, 16, SCATTER, 4>(a, st);
+    } else {                     // 8 192 x 512, half-tile staging (4 096 / 8 192 buckets: the histogram takes 32 / 64 KB of the LDS; 2-word
+                                 // chunks -- 300 x 15 Mbp: 49 ms against 63 ms unsplit, either way 4 x the time per base of a 5 Mbp sample)
+        if (hi) launch_extract_t<SCATTER, 8192, true, 16, SCATTER, 16>(a, st); else launch_extract_t<SCATTER, 8192, false, 16, SCATTER, 16>(a, st);
     }
 }
 // Tile sizes.  What HBM delivers for this kernel's writes depends on the size of the (tile, bucket) chunk (tools/scatter_bw.hip:
 // 3.5 TB/s for 64-byte pieces, 5.2 TB/s from 128 bytes up, 5.7 TB/s streaming), so the tile is as large as two resident
 // workgroups allow: 1 024-bucket samples get 12 288 positions (12-word chunks) with the staging buffer holding half a tile
-// at a time (57 KB of LDS, 77 VGPRs x 768 threads); 2 048-bucket samples 16 384 positions with one workgroup per CU.
-int extract_tile_bases(int logB) { return logB <= 10 ? 12288 : (logB == 11 ? 16384 : 8192); }
+// at a time (57 KB of LDS, 77 VGPRs x 768 threads), and so do 2 048-bucket samples (6-word chunks, but two workgroups: 15.6 ms
+// against 18.2 ms with 16 384-position tiles and one workgroup, 800 x 6 Mbp).
+int extract_tile_bases(int logB) { return logB <= 11 ? 12288 : 8192; }
 void launch_hist(const ExtractArgs &a, hipStream_t st) { launch_extract<false>(a, st); }
 void launch_scatter(const ExtractArgs &a, hipStream_t st) { launch_extract<true>(a, st); }
 
