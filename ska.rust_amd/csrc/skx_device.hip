@@ -73,7 +73,7 @@ __device__ static inline uint32_t qualbad16(const uint32_t w[4], int min_qual)
 
 // ------------------------------------------------------------------------------------------------
 // K1/K2: split k-mer extraction (+ bucket histogram | bucket scatter).  One workgroup = one tile of
-// 4096 window-end positions of one sample; 8 consecutive samples run concurrently, one per XCD
+// TILE window-end positions of one sample; 8 consecutive samples run concurrently, one per XCD
 // (block b -> XCD b%8), so a sample's bucket cursors and partially written lines stay in one L2.
 // ------------------------------------------------------------------------------------------------
 // forward declaration (defined with the block-wide helpers below)
@@ -81,8 +81,8 @@ __device__ static inline uint32_t block_excl_scan(uint32_t v, uint32_t *s_tmp, u
 
 // LDS carve (dynamic, 16-B aligned): [B+4] hist -> local starts (+ a dummy counter for invalid windows) | [B] chunk
 // bases | codes+masks, later aliased by the staging buffer.  16 window-end positions per thread.  The tile's words are
-// staged in bucket order (one pass: TILE words = 128 KB) so that the copy-out writes every (tile, bucket) chunk with
-// adjacent lanes (few, wide L2 write requests).  HI: the bucket bits of a packed word lie in its upper half.
+// staged in bucket order (TILE words, or half of them at a time: SPLIT) so that the copy-out writes every (tile, bucket)
+// chunk with adjacent lanes (few, wide L2 write requests).  HI: the bucket bits of a packed word lie in its upper half.
 // SPLIT: the staging buffer holds half a tile at a time (the lower half of the bucket space, then the upper half), so a
 // 12 288-position tile needs 57 KB of LDS instead of 105 KB and two 768-thread workgroups share a CU (85-VGPR cap), with
 // the same (tile, bucket) chunks in the word buffer as single-pass staging would write.
