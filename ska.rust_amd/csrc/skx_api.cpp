@@ -1,4 +1,5 @@
-// skx_api.cpp -- the C ABI (include/skx.h): host orchestration of the gfx950 kernels.
+// skx_api.cpp -- the C ABI (include/skx.h): host orchestration of the gfx950 kernels for build -> merge -> filter -> distance and the
+// .skf life-cycle operations (cov / map / .skf files: skx_api_io.cpp).
 // No CPU fallback exists: without a usable HIP device every compute entry point fails with SKX_ENODEV.
 #include "skx_internal.h"
 #include <algorithm>
@@ -82,14 +83,10 @@ void skx::dev_trim()
     g_cache.free_blocks.clear(); g_cache.cached_bytes = 0;
 }
 
-// nothing may unwind across the C boundary
-template <typename F>
-static int skx_guarded(F &&f) noexcept
+int skx::check_k(int k)
 {
-    try { return f(); }
-    catch (const std::bad_alloc &) { set_error("out of host memory"); return SKX_ENOMEM; }
-    catch (const std::exception &e) { set_error("internal error: %s", e.what()); return SKX_EINVAL; }
-    catch (...) { set_error("internal error"); return SKX_EINVAL; }
+    if (k < 5 || k > 63 || (k & 1) == 0) { set_error("Invalid k-mer length"); return SKX_EINVAL; }   // ska_dict.rs:342-344
+    return SKX_OK;
 }
 
 // ------------------------------------------------------------------------------------------ ctx
@@ -143,11 +140,6 @@ struct StageTimer {        // HIP-event bracket around one stage on the ctx stre
         float ms = 0; if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) *slot += ms;
     }
 };
-int check_k(int k)
-{
-    if (k < 5 || k > 63 || (k & 1) == 0) { set_error("Invalid k-mer length"); return SKX_EINVAL; }   // ska_dict.rs:342-344
-    return SKX_OK;
-}
 int ilog2_ceil(uint64_t x) { int l = 0; while ((1ull << l) < x) l++; return l; }
 constexpr uint32_t LDS_TABLE_MAX = 18000;     // slots (+ pad) of 8 B must stay below 160 KiB
 constexpr uint32_t LDS_SORT_MAX = 6144;       // words per region of the counting sort (24 per thread in registers)
@@ -614,7 +606,6 @@ extern "C" int skx_array_info(const skx_array *a, skx_array_info_t *info)
     return SKX_OK;
     });
 }
-static uint64_t pitch_for(uint64_t cols) { return ((cols + 255) / 256) * 256 + 256; }
 
 extern "C" int skx_array_assemble(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows, const char *const *names, skx_array **out)
 {
@@ -832,7 +823,7 @@ extern "C" int skx_array_from_host(skx_ctx *ctx, int k, int rc, const char *cons
 }
 
 // split k-mers of an array as the reference stores them (hash undone), in the array's row order
-static int array_host_keys(skx_array *a, std::vector<skx_key> &hk)
+int skx::array_host_keys(skx_array *a, std::vector<skx_key> &hk)
 {
     const uint64_t K = a->n_kmers;
     hk.assign(K, skx_key{0, 0});
@@ -981,8 +972,6 @@ extern "C" int skx_array_filter(skx_array *a, uint64_t min_count, int filter_amb
 }
 
 // ------------------------------------------------------------------------------------------ skf life-cycle (N1)
-static bool key_less(const skx_key &x, const skx_key &y) { return x.hi != y.hi ? x.hi < y.hi : x.lo < y.lo; }
-static bool key_eq(const skx_key &x, const skx_key &y) { return x.hi == y.hi && x.lo == y.lo; }
 
 // flags -> scan -> compaction with the keys following the rows
 static int array_keep_rows(skx_array *a, DevBuf<uint8_t> &keep, uint64_t *removed)
@@ -1282,420 +1271,3 @@ extern "C" int skx_array_distance(skx_array *a, double constant, int filt_ambig,
     });
 }
 
-// ------------------------------------------------------------------------------------------ ska cov (N4)
-// CoverageHistogram::new (coverage.rs:70-148) + the histogram of fit_histogram (:158-163): both files must be FASTQ, qualities
-// are ignored, hist[c - 1] = number of split k-mers occurring c times over both files (c <= 1000)
-extern "C" int skx_cov_histogram(skx_ctx *ctx, const char *fastq_fwd, const char *fastq_rev, int k, int rc, uint32_t *hist)
-{
-    return skx_guarded([&]() -> int {
-    if (!ctx || !fastq_fwd || !fastq_rev || !hist) { set_error("bad arguments"); return SKX_EINVAL; }
-    SKX_TRY(check_k(k));
-    SKX_HIP(hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
-    HostStream hs[2];
-    const char *files[2] = {fastq_fwd, fastq_rev};
-    for (int f = 0; f < 2; f++) {
-        SKX_TRY(read_sample_stream(files[f], nullptr, 0.0, hs[f]));
-        if (!hs[f].is_fastq) { set_error("%s appears to be FASTA.\nCoverage can only be used with FASTQ files, not FASTA.", files[f]); return SKX_EINVAL; }   // :97-99
-    }
-    const uint64_t L = hs[0].seq.size() + hs[1].seq.size();
-    DevBuf<uint8_t> d_seq; DevBuf<uint32_t> d_hist;
-    SKX_TRY(d_seq.alloc(L + 16)); SKX_TRY(d_hist.alloc(1000)); SKX_TRY(d_hist.zero(st));
-    SKX_HIP(hipMemcpyAsync(d_seq.p, hs[0].seq.data(), hs[0].seq.size(), hipMemcpyHostToDevice, st));
-    SKX_HIP(hipMemcpyAsync(d_seq.p + hs[0].seq.size(), hs[1].seq.data(), hs[1].seq.size(), hipMemcpyHostToDevice, st));
-    SKX_TRY(cov_histogram(ctx, d_seq.p, L, k, rc, d_hist.p));
-    SKX_HIP(hipMemcpyAsync(hist, d_hist.p, 1000 * 4, hipMemcpyDeviceToHost, st));
-    SKX_HIP(hipStreamSynchronize(st));
-    SKX_HIP(hipGetLastError());
-    return SKX_OK;
-    });
-}
-
-// ------------------------------------------------------------------------------------------ ska map (N3)
-// generic_modes::map (generic_modes.rs:56-84): RefSka::new(k, reference, rc, ambig_mask, repeat_mask) (ska_ref.rs:189-311), map
-// (:508-533), write_aln | write_vcf (:622-765).  Device: reference windows, look-up of every window's split k-mer in the array,
-// gather of the mapped rows (reverse-complemented where the reference strand is not the canonical one), one AlnWriter state
-// machine per sample.  Host: record bookkeeping, repeat coordinates, text.
-extern "C" int skx_array_map(skx_array *a, const char *reference, int ambig_mask, int repeat_mask, int format, int threads, char **buf, uint64_t *len)
-{
-    return skx_guarded([&]() -> int {
-    if (!a || !reference || !buf || !len) { set_error("bad arguments"); return SKX_EINVAL; }
-    skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
-    SKX_HIP(hipSetDevice(ctx->device));
-    const int k = a->k, h = (k - 1) / 2, S = (int)a->names.size();
-    if (a->n_kmers != a->n_rows) { set_error("split k-mers and variants are out of step (filtered without update_kmers)"); return SKX_EINVAL; }
-    HostStream hs;
-    SKX_TRY(read_sample_stream(reference, nullptr, 0.0, hs));
-    if (hs.is_fastq) { set_error("Cannot create reference from FASTQ files"); return SKX_EINVAL; }                                // ska_ref.rs:206-208
-    const uint64_t L = hs.seq.size();
-    if (L > 0xFFFFFFF0ull) { set_error("reference longer than 4 G bases"); return SKX_EUNSUP; }
-    // chromosomes: start in the record stream, length, offset in the concatenated output
-    std::vector<uint64_t> cstart, clen, coff;
-    { uint64_t b0 = 0, off = 0; for (uint64_t i = 0; i < L; i++) if (hs.seq[i] == '\n') { cstart.push_back(b0); clen.push_back(i - b0); coff.push_back(off); off += i - b0; b0 = i + 1; } }
-    const size_t n_chrom = cstart.size();
-    uint64_t total = 0; for (auto l : clen) total += l;
-    DevBuf<uint8_t> d_seq; SKX_TRY(d_seq.alloc(L + 16));
-    SKX_HIP(hipMemcpyAsync(d_seq.p, hs.seq.data(), L, hipMemcpyHostToDevice, st));
-    DevBuf<uint64_t> wlo, whi; DevBuf<uint8_t> flag;
-    SKX_TRY(ref_windows(ctx, d_seq.p, L, k, a->rc, wlo, whi, flag));
-    std::vector<uint8_t> hflag(L);
-    std::vector<uint64_t> hlo(L), hhi;
-    SKX_HIP(hipMemcpyAsync(hflag.data(), flag.p, L, hipMemcpyDeviceToHost, st));
-    SKX_HIP(hipMemcpyAsync(hlo.data(), wlo.p, L * 8, hipMemcpyDeviceToHost, st));
-    if (k > 31) { hhi.resize(L); SKX_HIP(hipMemcpyAsync(hhi.data(), whi.p, L * 8, hipMemcpyDeviceToHost, st)); }
-    SKX_HIP(hipStreamSynchronize(st));
-    uint64_t n_windows = 0; for (uint64_t p = 0; p < L; p++) n_windows += hflag[p] != 0;
-    if (n_windows == 0) { set_error("%s has no valid sequence", reference); return SKX_EEMPTY; }                                  // ska_ref.rs:255-257
-    auto chrom_of = [&](uint64_t sp) { return (size_t)(std::upper_bound(cstart.begin(), cstart.end(), sp) - cstart.begin()) - 1; };
-    // repeat coordinates (ska_ref.rs:259-293): every window whose split k-mer occurs more than once in the reference
-    std::vector<uint64_t> repeat;
-    if (repeat_mask) {
-        std::vector<std::pair<skx_key, uint64_t>> ks; ks.reserve(n_windows);
-        for (uint64_t p = 0; p < L; p++) if (hflag[p]) ks.push_back({skx_key{hlo[p] >> 4, k > 31 ? hhi[p] : 0}, p});
-        std::vector<uint8_t> rep(L, 0);
-        std::sort(ks.begin(), ks.end(), [](const std::pair<skx_key, uint64_t> &x, const std::pair<skx_key, uint64_t> &y) { return key_less(x.first, y.first); });
-        for (size_t i = 0; i < ks.size();) { size_t j = i; while (j < ks.size() && key_eq(ks[j].first, ks[i].first)) j++; if (j - i > 1) for (size_t q = i; q < j; q++) rep[ks[q].second] = 1; i = j; }
-        uint64_t last_chrom = 0, last_end = 0, chrom_offset = 0;
-        for (uint64_t p = 0; p < L; p++) {
-            if (!hflag[p]) continue;
-            const size_t c = chrom_of(p - h);
-            if (c > last_chrom) { chrom_offset += clen[last_chrom]; last_chrom = c; }
-            if (!rep[p]) continue;
-            const uint64_t pos = p - h - cstart[c], start = pos - h + chrom_offset, end = pos + h + chrom_offset;
-            for (uint64_t x = (start > last_end || start == 0) ? start : last_end + 1; x < end + 1; x++) repeat.push_back(x);
-            last_chrom = c; last_end = end;
-        }
-    }
-    // look-up
-    DevBuf<uint32_t> row; DevBuf<uint8_t> is_rc;
-    SKX_TRY(row.alloc(L)); SKX_TRY(is_rc.alloc(L));
-    if (k <= 31) {
-        DevBuf<uint64_t> sorted; DevBuf<uint32_t> perm;
-        const uint64_t *skeys = a->keys.p; const uint32_t *sperm = nullptr;
-        if (!a->engine_order) { SKX_TRY(sort_words_perm(a->keys.p, a->n_rows, sorted, perm, st)); skeys = sorted.p; sperm = perm.p; }
-        launch_map_lookup(wlo.p, flag.p, d_seq.p, L, h, skeys, sperm, a->n_rows, row.p, is_rc.p, st);
-        SKX_HIP(hipStreamSynchronize(st));
-    } else {
-        std::vector<skx_key> ak; SKX_TRY(array_host_keys(a, ak));
-        std::vector<uint32_t> order(ak.size()); std::iota(order.begin(), order.end(), 0u);
-        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key_less(ak[x], ak[y]); });
-        std::vector<uint32_t> hrow(L, 0xFFFFFFFFu); std::vector<uint8_t> hrc(L, 0);
-        for (uint64_t p = 0; p < L; p++) {
-            if (!hflag[p]) continue;
-            const u128 key = hunmix_w((((u128)hhi[p] << 64) | hlo[p]) >> 4, a->wh);
-            const skx_key kk{(uint64_t)key, (uint64_t)(key >> 64)};
-            auto it = std::lower_bound(order.begin(), order.end(), kk, [&](uint32_t x, const skx_key &v) { return key_less(ak[x], v); });
-            if (it != order.end() && key_eq(ak[*it], kk)) hrow[p] = *it;
-            hrc[p] = ((uint32_t)hlo[p] & 15u) == (1u << ((((uint32_t)hs.seq[p - h] >> 1) & 3u) ^ 2u));
-        }
-        SKX_HIP(hipMemcpy(row.p, hrow.data(), L * 4, hipMemcpyHostToDevice));
-        SKX_HIP(hipMemcpy(is_rc.p, hrc.data(), L, hipMemcpyHostToDevice));
-    }
-    DevBuf<uint32_t> mapped; uint64_t M = 0;
-    SKX_TRY(select_mapped(row.p, L, mapped, &M, st));
-    if (M == 0) { set_error("No split k-mers mapped to reference"); return SKX_EINVAL; }                                          // ska_ref.rs:553-555
-    std::vector<uint32_t> hm(M), mpos(M), mchrom(M);
-    SKX_HIP(hipMemcpy(hm.data(), mapped.p, M * 4, hipMemcpyDeviceToHost));
-    for (uint64_t m = 0; m < M; m++) { const uint64_t mid = (uint64_t)hm[m] - h; const size_t c = chrom_of(mid); mchrom[m] = (uint32_t)c; mpos[m] = (uint32_t)(mid - cstart[c]); }
-    // per chromosome: its range in the mapped list; the reference with the chromosomes concatenated (= output coordinates)
-    std::vector<uint64_t> mlo(n_chrom, 0), mhi(n_chrom, 0);
-    for (uint64_t m = 0; m < M; m++) { const uint32_t c = mchrom[m]; if (mhi[c] == 0) mlo[c] = m; mhi[c] = m + 1; }
-    std::vector<uint8_t> refcat; refcat.reserve(total + 8);
-    for (size_t c = 0; c < n_chrom; c++) refcat.insert(refcat.end(), hs.seq.begin() + (ptrdiff_t)cstart[c], hs.seq.begin() + (ptrdiff_t)(cstart[c] + clen[c]));
-    refcat.resize(total + 8, '-');
-    DevBuf<uint32_t> d_mpos, d_mchrom, d_pres, d_first, d_last; DevBuf<uint64_t> d_clen, d_coff, d_rep, d_mlo, d_mhi; DevBuf<uint8_t> d_refcat;
-    const uint64_t ppitch = (total + 31) / 32 + 4;
-    SKX_TRY(d_mpos.alloc(M)); SKX_TRY(d_mchrom.alloc(M)); SKX_TRY(d_clen.alloc(n_chrom)); SKX_TRY(d_coff.alloc(n_chrom));
-    SKX_TRY(d_mlo.alloc(n_chrom)); SKX_TRY(d_mhi.alloc(n_chrom)); SKX_TRY(d_rep.alloc(repeat.size() + 1)); SKX_TRY(d_refcat.alloc(total + 8));
-    SKX_TRY(d_pres.alloc((uint64_t)S * ppitch)); SKX_TRY(d_first.alloc((uint64_t)S * n_chrom)); SKX_TRY(d_last.alloc((uint64_t)S * n_chrom));
-    SKX_TRY(d_pres.zero(st));
-    SKX_HIP(hipMemcpyAsync(d_mpos.p, mpos.data(), M * 4, hipMemcpyHostToDevice, st));
-    SKX_HIP(hipMemcpyAsync(d_mchrom.p, mchrom.data(), M * 4, hipMemcpyHostToDevice, st));
-    SKX_HIP(hipMemcpyAsync(d_clen.p, clen.data(), n_chrom * 8, hipMemcpyHostToDevice, st));
-    SKX_HIP(hipMemcpyAsync(d_coff.p, coff.data(), n_chrom * 8, hipMemcpyHostToDevice, st));
-    SKX_HIP(hipMemcpyAsync(d_mlo.p, mlo.data(), n_chrom * 8, hipMemcpyHostToDevice, st));
-    SKX_HIP(hipMemcpyAsync(d_mhi.p, mhi.data(), n_chrom * 8, hipMemcpyHostToDevice, st));
-    SKX_HIP(hipMemcpyAsync(d_refcat.p, refcat.data(), total + 8, hipMemcpyHostToDevice, st));
-    if (!repeat.empty()) SKX_HIP(hipMemcpyAsync(d_rep.p, repeat.data(), repeat.size() * 8, hipMemcpyHostToDevice, st));
-    const uint64_t mpitch = (M + 255) / 256 * 256, opitch = (total + 255) / 256 * 256 + 256;
-    DevBuf<uint8_t> mv, out;
-    SKX_TRY(mv.alloc((uint64_t)S * mpitch)); SKX_TRY(out.alloc((uint64_t)S * opitch));
-    SKX_HIP(hipMemsetAsync(out.p, '-', (uint64_t)S * opitch, st));
-    launch_gather_mapped(a->matrix.p, a->pitch, S, mapped.p, row.p, is_rc.p, M, mv.p, mpitch, st);
-    MapWriteArgs wa{mv.p, mpitch, M, d_mpos.p, d_mchrom.p, d_mlo.p, d_mhi.p, d_refcat.p, total, d_clen.p, d_coff.p, (int)n_chrom, (uint64_t)h, ambig_mask,
-                    d_rep.p, (uint64_t)repeat.size(), out.p, opitch, S, d_pres.p, ppitch, d_first.p, d_last.p};
-    launch_aln_write(wa, st);
-    std::vector<uint8_t> aln((uint64_t)S * opitch);
-    SKX_HIP(hipMemcpyAsync(aln.data(), out.p, aln.size(), hipMemcpyDeviceToHost, st));
-    SKX_HIP(hipStreamSynchronize(st));
-    SKX_HIP(hipGetLastError());
-    // ---- text
-    std::string o;
-    if (format == 0) {                                                                                                             // write_aln, ska_ref.rs:622-645
-        o.reserve((uint64_t)S * (total + 64));
-        for (int s = 0; s < S; s++) { o += '>'; o += a->names[s]; o += '\n'; o.append((const char *)aln.data() + (uint64_t)s * opitch, total); o += '\n'; }
-    } else {                                                                                                                       // write_vcf, :648-765
-        o += "##fileformat=VCFv4.4\n";
-        for (size_t c = 0; c < n_chrom; c++) { o += "##contig=<ID="; o += hs.ids[c]; o += ">\n"; }
-        o += "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT";
-        for (int s = 0; s < S; s++) { o += '\t'; o += a->names[s]; }
-        o += '\n';
-        auto vbase = [](uint8_t b) { return (b == 'A' || b == 'C' || b == 'G' || b == 'T') ? (char)b : 'N'; };                    // u8_to_base, :137-146
-        const uint64_t BLK = 4096;
-        const uint64_t nblk = (total + BLK - 1) / BLK;
-        std::vector<std::string> parts(nblk);
-        int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency(); if (nt < 1) nt = 1; if (nt > 64) nt = 64;
-        std::atomic<uint64_t> next{0};
-        auto work = [&]() {
-            std::vector<uint8_t> col((uint64_t)S * BLK);
-            std::vector<int> gt(S);
-            for (uint64_t b; (b = next.fetch_add(1)) < nblk;) {
-                const uint64_t x0 = b * BLK, nx = std::min(BLK, total - x0);
-                for (int s = 0; s < S; s++) memcpy(col.data() + (uint64_t)s * BLK, aln.data() + (uint64_t)s * opitch + x0, nx);
-                std::string &t = parts[b];
-                for (uint64_t i = 0; i < nx; i++) {
-                    const uint64_t idx = x0 + i;
-                    const size_t c = (size_t)(std::upper_bound(coff.begin(), coff.end(), idx) - coff.begin()) - 1;               // IdxCheck (idx_check.rs)
-                    const uint64_t pos = idx - coff[c];
-                    const uint8_t ref_base = hs.seq[cstart[c] + pos];
-                    char alts[5]; int n_alt = 0; bool variant = false;
-                    for (int s = 0; s < S; s++) {
-                        const uint8_t mb = col[(uint64_t)s * BLK + i];
-                        if (mb == ref_base) gt[s] = 0;
-                        else if (mb == '-') { variant = true; gt[s] = -1; }
-                        else {
-                            variant = true;
-                            const char ab = vbase(mb);
-                            int at = -1;
-                            for (int q = 0; q < n_alt; q++) if (alts[q] == ab) at = q;
-                            if (at < 0) { alts[n_alt] = ab; at = n_alt++; }
-                            gt[s] = at + 1;
-                        }
-                    }
-                    if (!variant) continue;
-                    t += hs.ids[c]; t += '\t'; t += std::to_string(pos + 1); t += "\t.\t"; t += vbase(ref_base); t += '\t';
-                    if (!n_alt) t += '.';
-                    for (int q = 0; q < n_alt; q++) { if (q) t += ','; t += alts[q]; }
-                    t += "\t.\t.\t.\tGT";
-                    for (int s = 0; s < S; s++) { t += '\t'; if (gt[s] < 0) t += '.'; else t += std::to_string(gt[s]); }
-                    t += '\n';
-                }
-            }
-        };
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nt; t++) pool.emplace_back(work);
-        for (auto &th : pool) th.join();
-        for (auto &p : parts) o += p;
-    }
-    char *mem = (char *)malloc(o.size() + 1);
-    if (!mem) return SKX_ENOMEM;
-    memcpy(mem, o.data(), o.size()); mem[o.size()] = 0;
-    *buf = mem; *len = o.size();
-    return SKX_OK;
-    });
-}
-
-// ------------------------------------------------------------------------------------------ .skf
-// 64 KB chunks per launch of the device codec (512 MB of CBOR; SKX_SKF_GROUP_CHUNKS overrides, tests use small groups)
-static uint64_t skf_group_chunks()
-{
-    const char *e = getenv("SKX_SKF_GROUP_CHUNKS");
-    const long v = e ? atol(e) : 8192;
-    return (uint64_t)std::max<long>(1, std::min<long>(v, 1 << 20));
-}
-// MergeSkaArray::save (merge_ska_array.rs:191-199), streamed: rows go out in the array's own order (the
-// order of H for arrays built here, the file's order for loaded ones; the reference's order is its hash map's), one
-// transposed row block at a time, so the host never holds the U x S matrix or its 2-bytes-per-cell CBOR text.
-extern "C" int skx_array_save(skx_array *a, const char *path)
-{
-    return skx_guarded([&]() -> int {
-    skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
-    SKX_HIP(hipSetDevice(ctx->device));
-    const uint64_t U = a->n_rows, S = a->names.size();
-    SkfMeta m; m.k = a->k; m.rc = a->rc; m.k_bits = a->k_bits; m.names = a->names; m.version = a->version; m.n_rows = U;
-    std::vector<skx_key> keys;
-    const auto t_k0 = std::chrono::steady_clock::now();
-    SKX_TRY(array_host_keys(a, keys));
-    if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] save: keys to host in %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_k0).count());
-    std::vector<uint32_t> vc(U);
-    if (U) SKX_HIP(hipMemcpy(vc.data(), a->vcount.p, U * 4, hipMemcpyDeviceToHost));
-    std::vector<uint64_t> counts(vc.begin(), vc.end());
-    DevBuf<uint8_t> d_blk;
-    uint64_t blk_cap = 0;
-    auto fetch = [&](uint64_t row0, uint64_t nr, uint8_t *dst) -> int {
-        if (nr * S > blk_cap) { blk_cap = nr * S; SKX_TRY(d_blk.alloc(blk_cap)); }
-        launch_transpose(a->matrix.p + row0, a->pitch, S, nr, d_blk.p, S, st);          // [S][nr] slice -> [nr][S]
-        SKX_HIP(hipMemcpyAsync(dst, d_blk.p, nr * S, hipMemcpyDeviceToHost, st));
-        SKX_HIP(hipStreamSynchronize(st));
-        return SKX_OK;
-    };
-    // the data section on the device (skx_snappy.hip): groups of 64 KB chunks -> row-major cells -> finished frame chunks
-    struct Pinned { uint8_t *p = nullptr; size_t cap = 0; ~Pinned() { if (p) (void)hipHostFree(p); }
-                    int need(size_t n) { if (n <= cap) return SKX_OK; if (p) (void)hipHostFree(p); p = nullptr; cap = 0;
-                                         if (hipHostMalloc((void **)&p, n, hipHostMallocDefault) != hipSuccess) { p = nullptr; return SKX_ENOMEM; } cap = n; return SKX_OK; } } pin[2];
-    const DevEncode dev_encode = [&](FILE *f, uint64_t upos, uint64_t uoff0, uint64_t n_chunks) -> int {
-        const uint64_t G = skf_group_chunks();
-        if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] save: %llu chunks of the data section encoded on the device\n", (unsigned long long)n_chunks);
-        DevBuf<uint8_t> d_cells, d_slots, d_dense; DevBuf<uint32_t> d_sizes; DevBuf<uint64_t> d_off;
-        SKX_TRY(d_slots.alloc(std::min(G, n_chunks) * (uint64_t)SKF_SLOT)); SKX_TRY(d_sizes.alloc(std::min(G, n_chunks))); SKX_TRY(d_off.alloc(std::min(G, n_chunks)));
-        std::vector<uint32_t> sizes; std::vector<uint64_t> off;
-        uint64_t cells_cap = 0, dense_cap = 0;
-        // the file write of one group runs beside the device work of the next (two pinned buffers)
-        struct Writer { std::thread th; bool ok = true; void join() { if (th.joinable()) th.join(); } ~Writer() { join(); } } wr;
-        int flip = 0;
-        for (uint64_t g0 = 0; g0 < n_chunks; g0 += G, flip ^= 1) {
-            const uint64_t ng = std::min(G, n_chunks - g0);
-            const uint64_t rel_lo = uoff0 + g0 * 65536ull - upos, rel_hi = rel_lo + ng * 65536ull;        // section bytes of this group
-            const uint64_t c_lo = rel_lo >> 1, c_hi = ((rel_hi - 1) >> 1) + 1;
-            const uint64_t r0 = c_lo / S, r1 = (c_hi - 1) / S + 1, nr = r1 - r0;
-            if (nr * S + 16 > cells_cap) { cells_cap = nr * S + 16; SKX_TRY(d_cells.alloc(cells_cap)); }
-            launch_transpose(a->matrix.p + r0, a->pitch, S, nr, d_cells.p, S, st);                          // [S][nr] slice -> [nr][S]
-            SKX_TRY(launch_skf_encode_cells(ctx->device, d_cells.p, r0 * S, upos, uoff0 + g0 * 65536ull, (uint32_t)ng, d_slots.p, d_sizes.p, st));
-            sizes.resize(ng); off.resize(ng);
-            SKX_HIP(hipMemcpyAsync(sizes.data(), d_sizes.p, ng * 4, hipMemcpyDeviceToHost, st));
-            SKX_HIP(hipStreamSynchronize(st));
-            uint64_t total = 0;
-            for (uint64_t c = 0; c < ng; c++) { off[c] = total; total += sizes[c]; }
-            if (total > dense_cap) { dense_cap = total + total / 4; SKX_TRY(d_dense.alloc(dense_cap)); }
-            SKX_TRY(pin[flip].need(total));
-            SKX_HIP(hipMemcpyAsync(d_off.p, off.data(), ng * 8, hipMemcpyHostToDevice, st));
-            launch_skf_gather(d_slots.p, d_sizes.p, d_off.p, (uint32_t)ng, d_dense.p, st);
-            SKX_HIP(hipMemcpyAsync(pin[flip].p, d_dense.p, total, hipMemcpyDeviceToHost, st));
-            SKX_HIP(hipStreamSynchronize(st));
-            SKX_HIP(hipGetLastError());
-            wr.join();
-            if (!wr.ok) break;
-            const uint8_t *buf = pin[flip].p;
-            wr.th = std::thread([&wr, buf, total, f]() { wr.ok = fwrite(buf, 1, total, f) == total; });
-        }
-        wr.join();
-        if (!wr.ok) { set_error("short write %s", path); return SKX_EIO; }
-        return SKX_OK;
-    };
-    const auto t_w0 = std::chrono::steady_clock::now();
-    const int r = skf_write_stream(path, m, keys, counts, fetch, 0, &dev_encode);
-    if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] save: stream written in %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_w0).count());
-    return r;
-    });
-}
-
-// MergeSkaArray::load (merge_ska_array.rs:201-204), streamed: row blocks are transposed into the sample-major matrix as
-// they are decoded
-extern "C" int skx_array_load(skx_ctx *ctx, const char *path, int want_bits, skx_array **out)
-{
-    return skx_guarded([&]() -> int {
-    if (!ctx || !path || !out) { set_error("bad arguments"); return SKX_EINVAL; }
-    SKX_HIP(hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
-    std::unique_ptr<skx_array> a(new skx_array());
-    a->ctx = ctx;
-    SkfMeta m; std::vector<skx_key> keys; std::vector<uint64_t> counts;
-    DevBuf<uint8_t> d_blk; uint64_t blk_cap = 0, S = 0;
-    auto begin_rows = [&](uint64_t U, uint64_t cols) -> int {
-        S = cols;
-        if (S == 0 || S > 65535) { set_error("skf: unsupported number of samples"); return SKX_EFORMAT; }
-        a->n_rows = U; a->pitch = pitch_for(U);
-        SKX_TRY(a->matrix.alloc(S * a->pitch));
-        SKX_HIP(hipMemsetAsync(a->matrix.p, '-', S * a->pitch, st));
-        return SKX_OK;
-    };
-    auto sink = [&](uint64_t row0, uint64_t nr, const uint8_t *src) -> int {
-        if (nr * S > blk_cap) { blk_cap = nr * S; SKX_TRY(d_blk.alloc(blk_cap)); }
-        SKX_HIP(hipMemcpyAsync(d_blk.p, src, nr * S, hipMemcpyHostToDevice, st));
-        launch_transpose(d_blk.p, S, nr, S, a->matrix.p + row0, a->pitch, st);          // [nr][S] -> columns row0.. of [S][pitch]
-        SKX_HIP(hipStreamSynchronize(st));                                                // src is reused by the decoder
-        return SKX_OK;
-    };
-    // the data section on the device: groups of compressed chunks -> row-major cells -> transposed into the matrix
-    const DevDecode dev_decode = [&](const uint8_t *file, const SkfChunk *ch, size_t nch, uint64_t upos, uint64_t U, uint64_t cols) -> int {
-        if (!U || !cols) return SKF_NOT_TAKEN;
-        const uint64_t uend = upos + 2 * U * cols, G = skf_group_chunks();
-        size_t c0 = 0, c1 = nch;
-        { size_t lo = 0, hi = nch; while (lo < hi) { const size_t mid = (lo + hi) / 2; if (ch[mid].uoff + ch[mid].ulen <= upos) lo = mid + 1; else hi = mid; } c0 = lo; }
-        { size_t lo = c0, hi = nch; while (lo < hi) { const size_t mid = (lo + hi) / 2; if (ch[mid].uoff < uend) lo = mid + 1; else hi = mid; } c1 = lo; }
-        if (c0 >= c1) return SKF_NOT_TAKEN;
-        if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] load: %zu chunks of the data section decoded on the device\n", c1 - c0);
-        DevBuf<uint8_t> d_src, d_cells[2], d_scratch; DevBuf<SnapChunk> d_chunks; DevBuf<int> d_status;
-        SKX_TRY(d_scratch.alloc(std::min<uint64_t>(G, c1 - c0) * 65536ull + 16));
-        SKX_TRY(d_status.alloc(1)); SKX_TRY(d_status.zero(st));
-        const uint64_t cells_cap = std::min<uint64_t>(G, c1 - c0) * 32768ull + cols + 64;
-        SKX_TRY(d_cells[0].alloc(cells_cap)); SKX_TRY(d_cells[1].alloc(cells_cap)); SKX_TRY(d_chunks.alloc(std::min<uint64_t>(G, c1 - c0)));
-        std::vector<SnapChunk> tab;
-        uint64_t src_cap = 0, row_lo = 0, have_hi = 0;          // rows < row_lo are in the matrix; cells [row_lo * cols, have_hi) wait in the current buffer
-        int cur = 0;
-        for (size_t g0 = c0; g0 < c1; g0 += G) {
-            const size_t g1 = std::min<size_t>(c1, g0 + G);
-            const size_t f_lo = ch[g0].off, f_hi = ch[g1 - 1].off + ch[g1 - 1].len;
-            if (f_hi - f_lo + 512 > src_cap) { src_cap = f_hi - f_lo + 512; SKX_TRY(d_src.alloc(src_cap)); }      // + the decoder's read-ahead window
-            tab.resize(g1 - g0);
-            for (size_t c = g0; c < g1; c++) tab[c - g0] = SnapChunk{ch[c].off - f_lo, ch[c].uoff, (uint32_t)ch[c].len, ch[c].ulen, ch[c].crc, ch[c].compressed ? 1u : 0u};
-            SKX_HIP(hipMemcpyAsync(d_src.p, file + f_lo, f_hi - f_lo, hipMemcpyHostToDevice, st));
-            SKX_HIP(hipMemcpyAsync(d_chunks.p, tab.data(), tab.size() * sizeof(SnapChunk), hipMemcpyHostToDevice, st));
-            const uint64_t base_cell = (row_lo * cols) & ~7ull;
-            SKX_TRY(launch_skf_decode_cells(ctx->device, d_src.p, d_chunks.p, (uint32_t)(g1 - g0), upos, uend, d_scratch.p, d_cells[cur].p, base_cell, d_status.p, st));
-            // cells this group delivered: value bytes (odd section offsets) below the end of its last chunk
-            const uint64_t s_hi = std::min(ch[g1 - 1].uoff + ch[g1 - 1].ulen, uend);
-            have_hi = (s_hi - upos) >> 1;
-            const uint64_t row_done = g1 == c1 ? U : have_hi / cols;
-            const uint8_t *in = d_cells[cur].p + (row_lo * cols - base_cell);
-            for (uint64_t r = row_lo; r < row_done; r += 4000000ull) {                          // grid.y of the transpose: 65 535 tiles of 64 rows
-                const uint64_t nr = std::min<uint64_t>(4000000ull, row_done - r);
-                launch_transpose(in + (r - row_lo) * cols, cols, nr, cols, a->matrix.p + r, a->pitch, st);
-            }
-            if (g1 < c1) {                                                                      // the unfinished row moves to the other buffer
-                const uint64_t nb = (row_done * cols) & ~7ull, left = have_hi - row_done * cols;
-                if (left) SKX_HIP(hipMemcpyAsync(d_cells[cur ^ 1].p + (row_done * cols - nb), d_cells[cur].p + (row_done * cols - base_cell), left, hipMemcpyDeviceToDevice, st));
-            }
-            SKX_HIP(hipStreamSynchronize(st));                                                   // tab / d_src are reused
-            row_lo = row_done; cur ^= 1;
-        }
-        int status = 0;
-        SKX_HIP(hipMemcpy(&status, d_status.p, 4, hipMemcpyDeviceToHost));
-        SKX_HIP(hipGetLastError());
-        if (status == 3) {                                                                       // cells that are not (0x18, byte): the generic decoder's case
-            SKX_HIP(hipMemsetAsync(a->matrix.p, '-', cols * a->pitch, st));
-            return SKF_NOT_TAKEN;
-        }
-        if (status) { set_error(status == 2 ? "skf: checksum mismatch" : "skf: corrupt snappy block"); return SKX_EFORMAT; }
-        return SKX_OK;
-    };
-    const auto t_r0 = std::chrono::steady_clock::now();
-    SKX_TRY(skf_read_stream(path, m, keys, counts, begin_rows, sink, 0, &dev_decode));
-    if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] load: stream read in %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_r0).count());
-    SKX_TRY(check_k(m.k));
-    if (want_bits == 64)       // serde into Vec<u64> fails on wider values; lib.rs:635-661 then retries as u128
-        for (auto &kk : keys) if (kk.hi) { set_error("split k-mer does not fit 64 bits"); return SKX_EFORMAT; }
-    const uint64_t U = a->n_rows;
-    if (keys.size() != U) { set_error("skf: split_kmers and variants disagree"); return SKX_EFORMAT; }
-    a->k = m.k; a->rc = m.rc; a->k_bits = m.k_bits; a->hp = make_hash_params(std::min(m.k, 31)); a->wh = make_wide_hash(m.k);
-    a->version = m.version.empty() ? skx_version() : m.version; a->names = m.names;
-    a->n_kmers = U; a->engine_order = false;
-    SKX_TRY(a->present.alloc(U)); SKX_TRY(a->unambig.alloc(U)); SKX_TRY(a->mask.alloc(U)); SKX_TRY(a->vcount.alloc(U));
-    if (m.k <= 31) {
-        SKX_TRY(a->keys.alloc(U));
-        std::vector<uint64_t> lo(U);
-        for (uint64_t i = 0; i < U; i++) lo[i] = keys[i].lo;
-        DevBuf<uint64_t> tmp; SKX_TRY(tmp.alloc(U));
-        if (U) SKX_HIP(hipMemcpyAsync(tmp.p, lo.data(), U * 8, hipMemcpyHostToDevice, st));
-        launch_hash_keys(tmp.p, a->keys.p, U, a->hp, st);
-        SKX_HIP(hipStreamSynchronize(st));
-    } else a->host_keys.swap(keys);
-    DevBuf<int> d_bad; SKX_TRY(d_bad.alloc(1)); SKX_TRY(d_bad.zero(st));
-    if (U) {
-        launch_col_stats(a->matrix.p, a->pitch, (int)S, U, a->present.p, a->unambig.p, a->mask.p, d_bad.p, st);
-        if (counts.size() == U) {
-            std::vector<uint32_t> vc(U);
-            for (uint64_t i = 0; i < U; i++) vc[i] = (uint32_t)counts[i];
-            SKX_HIP(hipMemcpyAsync(a->vcount.p, vc.data(), U * 4, hipMemcpyHostToDevice, st));
-            SKX_HIP(hipStreamSynchronize(st));
-        } else SKX_HIP(hipMemcpyAsync(a->vcount.p, a->present.p, U * 4, hipMemcpyDeviceToDevice, st));
-    }
-    int bad = 0;
-    SKX_HIP(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, st));
-    SKX_HIP(hipStreamSynchronize(st));
-    SKX_HIP(hipGetLastError());
-    if (bad) { set_error("variants contain a byte outside -ACGTMRWSYKVHDBN (not supported on the device path)"); return SKX_EUNSUP; }
-    *out = a.release();
-    return SKX_OK;
-    });
-}

@@ -4,6 +4,8 @@
 #include "skx_device.h"
 #include <cstdio>
 #include <functional>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -144,3 +146,22 @@ int skf_read_stream(const char *path, SkfMeta &m, std::vector<skx_key> &keys, st
                     const std::function<int(uint64_t n_rows, uint64_t n_samples)> &begin_rows, const RowSink &sink, int threads,
                     const DevDecode *dev = nullptr);
 }  // namespace skx
+
+// helpers shared by the ABI translation units (skx_api.cpp, skx_api_io.cpp)
+namespace skx {
+int check_k(int k);                                                  // "Invalid k-mer length" (ska_dict.rs:342-344)
+int array_host_keys(skx_array *a, std::vector<skx_key> &hk);         // the array's split k-mers as the reference stores them, in row order
+inline uint64_t pitch_for(uint64_t cols) { return ((cols + 255) / 256) * 256 + 256; }
+inline bool key_less(const skx_key &x, const skx_key &y) { return x.hi != y.hi ? x.hi < y.hi : x.lo < y.lo; }
+inline bool key_eq(const skx_key &x, const skx_key &y) { return x.hi == y.hi && x.lo == y.lo; }
+}  // namespace skx
+// nothing may unwind across the C boundary
+template <typename F>
+inline int skx_guarded(F &&f) noexcept
+{
+    try { return f(); }
+    catch (const std::bad_alloc &) { skx::set_error("out of host memory"); return SKX_ENOMEM; }
+    catch (const std::exception &e) { skx::set_error("internal error: %s", e.what()); return SKX_EINVAL; }
+    catch (...) { skx::set_error("internal error"); return SKX_EINVAL; }
+}
+

@@ -8,5 +8,5 @@ if [ ${#args[@]} -gt 0 ]; then sed "${args[@]}" csrc/skx_device.hip > csrc/_v.hi
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -c csrc/_v.hip -o build/_v.o
 rm csrc/_v.hip
 mkdir -p ../ab
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../ab/libskx_$name.so build/_v.o build/skx_reads.o build/skx_setops.o build/skx_snappy.o build/skx_api.o build/fastx.o build/skf_codec.o build/ska_host.o -lz -lpthread
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../ab/libskx_$name.so build/_v.o build/skx_reads.o build/skx_setops.o build/skx_snappy.o build/skx_api.o build/skx_api_io.o build/fastx.o build/skf_codec.o build/ska_host.o -lz -lpthread
 echo built ab/libskx_$name.so
