@@ -716,10 +716,11 @@ void launch_dedupe_mb(uint64_t *words, const uint64_t *off, const uint32_t *raw,
 {
     if (!n_regions) return;
     size_t lds = (size_t)cap * 8 + (size_t)cap * 4 + 16;  // elements + two u32 arrays of cap/2 (+ sentinel)
-    // The kernel is bound by its chain of LDS round trips and barriers, not by a throughput limit: 512 threads with half
-    // the words each finish a region sooner and put twice the waves on a CU (the LDS footprint fixes 4 regions per CU).
+    // 512 threads while three regions (<= 4 096 words, 49 KB) share a CU; beyond that the LDS footprint fixes two regions per
+    // CU and 1 024 threads keep 32 waves on it (800 x 6 Mbp, 3 840-word regions: <6, 1024> 26.4 ms, <8, 512> 20.9 ms).
     if (cap <= 512u * 4) launch_dedupe_items<4, 512>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);
     else if (cap <= 512u * 7) launch_dedupe_items<7, 512>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);
+    else if (cap <= 512u * 8) launch_dedupe_items<8, 512>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);
     else launch_dedupe_items<6, 1024>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);    // host keeps regions <= 6144 words
 }
 
