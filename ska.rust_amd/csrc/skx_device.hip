@@ -721,6 +721,7 @@ void launch_dedupe_mb(uint64_t *words, const uint64_t *off, const uint32_t *raw,
     if (cap <= 512u * 4) launch_dedupe_items<4, 512>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);
     else if (cap <= 512u * 7) launch_dedupe_items<7, 512>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);
     else if (cap <= 512u * 8) launch_dedupe_items<8, 512>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);
+    else if (cap <= 1024u * 5) launch_dedupe_items<5, 1024>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);
     else launch_dedupe_items<6, 1024>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);    // host keeps regions <= 6144 words
 }
 
