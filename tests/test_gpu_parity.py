@@ -798,3 +798,19 @@ def test_skf_device_decoder_takes_any_valid_element_stream(E, tmp_path, monkeypa
         assert back.names == names
         for x, y in zip(_sorted_export(back), rows):
             assert np.array_equal(x, y), (mode, group)
+
+
+@pytest.mark.parametrize("length", [2_000_000, 5_000_000, 6_000_000, 6_600_000, 12_000_000, 25_000_000])
+def test_dict_every_bucket_configuration(E, length):
+    """One sample per bucket count / kernel configuration (512, 1 024, 2 048 x 2 dedupe shapes, 4 096, 8 192 buckets: tile size,
+    half-tile staging, cursor array and dedupe instantiation all change with it), dictionary bit-exact against the oracle."""
+    rng = np.random.default_rng(length % 1000 + 7)
+    g = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=length, dtype=np.uint8)]
+    g[rng.integers(0, length, size=50)] = ord("N")                       # a few window breaks
+    cut = length // 3
+    recs = [g[:cut].tobytes(), g[cut:].tobytes()]
+    ds = E.DictSet.build([E.record_stream(recs)], 31, True)
+    ok, ob = oracle_dict(recs, 31, True).export()
+    gk, gb = ds.export(0)
+    assert len(gk) == len(ok)
+    assert np.array_equal(gk["lo"], ok["lo"]) and np.array_equal(gk["hi"], ok["hi"]) and np.array_equal(gb, ob)
