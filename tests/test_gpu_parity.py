@@ -800,8 +800,9 @@ def test_skf_device_decoder_takes_any_valid_element_stream(E, tmp_path, monkeypa
             assert np.array_equal(x, y), (mode, group)
 
 
-@pytest.mark.parametrize("length", [2_000_000, 5_000_000, 6_000_000, 6_600_000, 12_000_000, 25_000_000])
-def test_dict_every_bucket_configuration(E, length):
+@pytest.mark.parametrize("k,length", [(31, 2_000_000), (31, 5_000_000), (31, 6_000_000), (31, 6_600_000), (31, 12_000_000), (31, 25_000_000),
+                                      (41, 2_000_000), (41, 5_000_000), (41, 12_000_000)])
+def test_dict_every_bucket_configuration(E, k, length):
     """One sample per bucket count / kernel configuration (512, 1 024, 2 048 x 2 dedupe shapes, 4 096, 8 192 buckets: tile size,
     half-tile staging, cursor array and dedupe instantiation all change with it), dictionary bit-exact against the oracle."""
     rng = np.random.default_rng(length % 1000 + 7)
@@ -809,8 +810,8 @@ def test_dict_every_bucket_configuration(E, length):
     g[rng.integers(0, length, size=50)] = ord("N")                       # a few window breaks
     cut = length // 3
     recs = [g[:cut].tobytes(), g[cut:].tobytes()]
-    ds = E.DictSet.build([E.record_stream(recs)], 31, True)
-    ok, ob = oracle_dict(recs, 31, True).export()
+    ds = E.DictSet.build([E.record_stream(recs)], k, True)
+    ok, ob = oracle_dict(recs, k, True).export()
     gk, gb = ds.export(0)
     assert len(gk) == len(ok)
     assert np.array_equal(gk["lo"], ok["lo"]) and np.array_equal(gk["hi"], ok["hi"]) and np.array_equal(gb, ob)
