@@ -28,60 +28,107 @@ struct ReadsArgs {
     uint64_t *hash; uint64_t *wlo; uint64_t *whi; uint8_t *flag;
 };
 
-// one thread per window-end position; the window is rebuilt from its k bytes (O(k) per position: this is the reads-only
-// path, simplicity over speed)
-__global__ __launch_bounds__(256) void reads_windows_kernel(ReadsArgs a)
+// Eight consecutive window-end positions per thread: the state of the window before the first one is built from its k
+// bytes, the rest roll (arms, reverse-complement arms, both ntHash strands, the length of the clean run).  The workgroup's
+// 2 048 results per array go through one LDS buffer, array after array, position-major (row stride 264: conflict-free both
+// ways), and leave as contiguous 16 KB pieces -- a per-thread store of its own 64 bytes per array would cost one L2
+// request per 8 bytes, and parking all three arrays at once would leave two workgroups per CU.
+constexpr int RW_PPT = 8, RW_NT = 256, RW_TILE = RW_PPT * RW_NT, RW_STRIDE = RW_NT + 8;
+__device__ static inline uint64_t nt_pick(uint32_t c, uint64_t t0, uint64_t t1, uint64_t t2, uint64_t t3)
 {
-    __shared__ uint8_t s_seq[256 + 80], s_q[256 + 80];
-    const uint64_t p0 = (uint64_t)blockIdx.x * 256;
+    return (c & 2u) ? ((c & 1u) ? t3 : t2) : ((c & 1u) ? t1 : t0);
+}
+__global__ __launch_bounds__(RW_NT) void reads_windows_kernel(ReadsArgs a)
+{
+    __shared__ uint8_t s_seq[RW_TILE + 80], s_q[RW_TILE + 80], s_flag[RW_TILE];
+    __shared__ uint64_t s_out[RW_PPT * RW_STRIDE];
+    uint64_t o_hash[RW_PPT], o_lo[RW_PPT], o_hi[RW_PPT];
+    const uint64_t p0 = (uint64_t)blockIdx.x * RW_TILE;
     const int k = a.k, h = (k - 1) / 2;
-    // tile covers positions [p0 - 64, p0 + 256 + 2)
-    for (int i = threadIdx.x; i < 256 + 66; i += 256) {
+    // tile covers positions [p0 - 64, p0 + RW_TILE + 2)
+    for (int i = threadIdx.x; i < RW_TILE + 66; i += RW_NT) {
         const int64_t pos = (int64_t)p0 - 64 + i;
         const bool in = pos >= 0 && (uint64_t)pos < a.len;
         s_seq[i] = in ? a.seq[pos] : (uint8_t)'\n';
         s_q[i] = (in && a.qual) ? a.qual[pos] : (uint8_t)'~';
     }
     __syncthreads();
-    const uint64_t p = p0 + threadIdx.x;
-    if (p >= a.len) return;
-    const int e = 64 + threadIdx.x;                       // tile index of the window's last base
     auto qbad = [&](int i) { return a.qual && (uint8_t)(s_q[i] - 33) <= (uint8_t)a.min_qual; };     // !((q-33) > min_qual)
     auto bad = [&](int i) { const uint8_t b = s_seq[i]; return (b & 0xF) == 14 || b == '\n' || (a.qual_filter == 2 && qbad(i)); };
-    bool valid = true;
-    u128 upper = 0, lower = 0, rc_upper = 0, rc_lower = 0;
-    uint32_t mid = 0;
-    uint64_t fh = 0, rh = 0;
-    for (int i = 0; i < k; i++) {
-        const int ti = e - (k - 1) + i;
-        valid = valid && !bad(ti);
-        const uint32_t c = (s_seq[ti] >> 1) & 3u;
-        if (i < h) upper = (upper << 2) | c; else if (i == h) mid = c; else lower = (lower << 2) | c;
-        fh ^= rotl64d(NT_H[c], (unsigned)(k - 1 - i));
-        rh ^= rotl64d(NT_RC[c], (unsigned)i);
+    auto code = [&](int i) -> uint32_t { return (s_seq[i] >> 1) & 3u; };
+    const uint64_t pstart = p0 + (uint64_t)threadIdx.x * RW_PPT;
+    const int e0 = 64 + (int)threadIdx.x * RW_PPT;        // tile index of my first window's last base
+    if (pstart < a.len) {
+        const uint64_t am = (1ull << (2 * h)) - 1;        // arm mask (h <= 31)
+        const uint64_t H0 = NT_H[0], H1 = NT_H[1], H2 = NT_H[2], H3 = NT_H[3], R0 = NT_RC[0], R1 = NT_RC[1], R2 = NT_RC[2], R3 = NT_RC[3];
+        // the window ending one position before my first
+        uint64_t upper = 0, lower = 0, rc_upper = 0, rc_lower = 0, fh = 0, rh = 0;
+        uint32_t mid = 0;
+        const int e = e0 - 1;
+        for (int i = 0; i < k; i++) {
+            const uint32_t c = code(e - (k - 1) + i);
+            if (i < h) upper = (upper << 2) | c; else if (i == h) mid = c; else lower = (lower << 2) | c;
+            fh ^= rotl64d(nt_pick(c, H0, H1, H2, H3), (unsigned)(k - 1 - i));
+            rh ^= rotl64d(nt_pick(c, R0, R1, R2, R3), (unsigned)i);
+        }
+        for (int i = 0; i < h; i++) {
+            rc_upper = (rc_upper << 2) | (code(e - i) ^ 2u);                       // reverse complement of the lower arm
+            rc_lower = (rc_lower << 2) | (code(e - (k - 1) + h - 1 - i) ^ 2u);     // ... of the upper arm
+        }
+        uint32_t rc_mid = mid ^ 2u;
+        uint32_t run = 0;                                  // clean bases ending at e, counted up to k + 1
+        for (int t = e; t >= e - k && !bad(t); t--) run++;
+#pragma unroll
+        for (int j = 0; j < RW_PPT; j++) {
+            const int ej = e0 + j;
+            const uint32_t c = code(ej), cout = code(ej - k);
+            // roll_fwd (split_kmer.rs:199-213)
+            upper = ((upper << 2) | mid) & am;
+            mid = (uint32_t)(lower >> (2 * h - 2));
+            lower = ((lower << 2) | c) & am;
+            rc_lower = (rc_lower >> 2) | ((uint64_t)rc_mid << (2 * h - 2));
+            rc_mid = mid ^ 2u;
+            rc_upper = (rc_upper >> 2) | ((uint64_t)(c ^ 2u) << (2 * h - 2));
+            // ntHash of the whole k-mer, both strands (nthash.rs:35-76)
+            fh = rotl64d(fh, 1) ^ rotl64d(nt_pick(cout, H0, H1, H2, H3), (unsigned)k) ^ nt_pick(c, H0, H1, H2, H3);
+            rh = rotl64d(rh ^ nt_pick(cout, R0, R1, R2, R3), 63) ^ rotl64d(nt_pick(c, R0, R1, R2, R3), (unsigned)(k - 1));
+            run = bad(ej) ? 0u : min(run + 1u, (uint32_t)k + 1u);
+            // split_kmer.rs:89,121: a clean run of exactly k ending at the record's last base is never started
+            bool valid = run >= (uint32_t)k;
+            if (s_seq[ej + 1] == '\n') valid = valid && run > (uint32_t)k;
+            // middle_base_qual (split_kmer.rs:328-339): Middle and Strict gate on the middle base
+            const bool midq_ok = !(a.qual && a.qual_filter != 0 && qbad(ej - h));
+            uint32_t m4 = 1u << mid;
+            uint64_t hl = upper, hr = lower;
+            if (a.rc) {
+                const bool gt = upper != rc_upper ? upper > rc_upper : lower > rc_lower;
+                if (gt) { hl = rc_upper; hr = rc_lower; m4 = 1u << (mid ^ 2u); }
+                else if (upper == rc_upper && lower == rc_lower) m4 |= 1u << (mid ^ 2u);
+            }
+            u128 w;
+            if (k <= 31) { uint32_t L = (uint32_t)hl, R = (uint32_t)hr; hmix_halves(L, R, a.hp); w = ((u128)L << (a.hp.hb + 4)) | ((u128)R << 4) | m4; }
+            else { uint64_t L = hl, R = hr; hmix_halves_w(L, R, a.wh); w = ((u128)L << (a.wh.hb + 4)) | ((u128)R << 4) | m4; }
+            o_hash[j] = a.rc ? (fh < rh ? fh : rh) : fh;
+            o_lo[j] = (uint64_t)w;
+            o_hi[j] = (uint64_t)(w >> 64);
+            s_flag[threadIdx.x * RW_PPT + j] = valid && midq_ok;            // the `&&` of ska_dict.rs:155-157: the count filter is not touched otherwise
+        }
     }
-    for (int i = 0; i < h; i++) {
-        rc_upper = (rc_upper << 2) | (((s_seq[e - i] >> 1) & 3u) ^ 2u);               // reverse complement of the lower arm
-        rc_lower = (rc_lower << 2) | (((s_seq[e - (k - 1) + h - 1 - i] >> 1) & 3u) ^ 2u);   // ... of the upper arm
-    }
-    // split_kmer.rs:89,121: a clean run of exactly k ending at the record's last base is never started
-    if (s_seq[e + 1] == '\n') valid = valid && !bad(e - k);
-    // middle_base_qual (split_kmer.rs:328-339): Middle and Strict gate on the middle base
-    const bool midq_ok = !(a.qual && a.qual_filter != 0 && qbad(e - h));
-    uint32_t m4 = 1u << mid;
-    u128 hl = upper, hr = lower;
-    if (a.rc) {
-        const bool gt = upper != rc_upper ? upper > rc_upper : lower > rc_lower;
-        if (gt) { hl = rc_upper; hr = rc_lower; m4 = 1u << (mid ^ 2u); }
-        else if (upper == rc_upper && lower == rc_lower) m4 |= 1u << (mid ^ 2u);
-    }
-    u128 w;
-    if (k <= 31) { uint32_t L = (uint32_t)hl, R = (uint32_t)hr; hmix_halves(L, R, a.hp); w = ((u128)L << (a.hp.hb + 4)) | ((u128)R << 4) | m4; }
-    else { uint64_t L = (uint64_t)hl, R = (uint64_t)hr; hmix_halves_w(L, R, a.wh); w = ((u128)L << (a.wh.hb + 4)) | ((u128)R << 4) | m4; }
-    a.hash[p] = a.rc ? (fh < rh ? fh : rh) : fh;
-    a.wlo[p] = (uint64_t)w;
-    if (a.whi) a.whi[p] = (uint64_t)(w >> 64);
-    a.flag[p] = valid && midq_ok;                          // the `&&` of ska_dict.rs:155-157: the count filter is not touched otherwise
+    const uint64_t left = a.len - p0 < (uint64_t)RW_TILE ? a.len - p0 : (uint64_t)RW_TILE;
+    const bool mine = pstart < a.len;
+    auto put = [&](const uint64_t (&v)[RW_PPT], uint64_t *dst) {       // my eight values -> LDS -> the array, contiguously
+        if (mine) {
+#pragma unroll
+            for (int j = 0; j < RW_PPT; j++) s_out[j * RW_STRIDE + (int)threadIdx.x] = v[j];
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < left; i += RW_NT) dst[p0 + i] = s_out[(int)(i % RW_PPT) * RW_STRIDE + (int)(i / RW_PPT)];
+        __syncthreads();
+    };
+    put(o_hash, a.hash);
+    put(o_lo, a.wlo);
+    if (a.whi) put(o_hi, a.whi);
+    for (uint32_t i = threadIdx.x; i < left; i += RW_NT) a.flag[p0 + i] = s_flag[i];
 }
 
 __global__ void gather_u64_kernel(const uint64_t *src, const uint32_t *idx, uint64_t *dst, uint64_t n)
@@ -211,7 +258,7 @@ int reads_sample_dict(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual,
     if (wide) SKX_TRY(whi.alloc(len));
     ReadsArgs ra{d_seq, d_qual, len, k, rc, q.min_qual, q.qual_filter, make_hash_params(k < 31 ? k : 31), make_wide_hash(k),
                  hash.p, wlo.p, wide ? whi.p : nullptr, flag.p};
-    hipLaunchKernelGGL(reads_windows_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, ra);
+    hipLaunchKernelGGL(reads_windows_kernel, dim3((unsigned)((len + RW_TILE - 1) / RW_TILE)), dim3(RW_NT), 0, st, ra);
 
     // candidate windows in stream order
     DevBuf<uint32_t> idx; SKX_TRY(idx.alloc(len));
@@ -306,7 +353,7 @@ int ref_windows(skx_ctx *ctx, const uint8_t *d_seq, uint64_t len, int k, int rc,
     SKX_TRY(hash.alloc(len)); SKX_TRY(wlo.alloc(len)); SKX_TRY(flag.alloc(len));
     if (wide) SKX_TRY(whi.alloc(len));
     ReadsArgs ra{d_seq, nullptr, len, k, rc, 0, 0, make_hash_params(k < 31 ? k : 31), make_wide_hash(k), hash.p, wlo.p, wide ? whi.p : nullptr, flag.p};
-    hipLaunchKernelGGL(reads_windows_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream, ra);
+    hipLaunchKernelGGL(reads_windows_kernel, dim3((unsigned)((len + RW_TILE - 1) / RW_TILE)), dim3(RW_NT), 0, ctx->stream, ra);
     return SKX_OK;
 }
 
