@@ -161,7 +161,7 @@ def main():
             pp, pu, pm, pv = arr.device_stats()
             U = arr.nrows
             tp, tu, tm = (skdist.as_tensor(x, U, "<i4", dev) for x in (pp, pu, pm))
-            skdist.reduce_row_stats(tp, tu, tm)
+            skdist.reduce_row_stats(tp, tu, tm, total_samples=n_total)
             skdist.as_tensor(pv, U, "<i4", dev).copy_(tp)
             torch.cuda.synchronize()
             arr.set_total_samples(n_total)

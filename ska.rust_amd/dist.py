@@ -38,18 +38,32 @@ def allgather_tables(local: torch.Tensor, group=None):
     return [parts[r][: sizes[r]] for r in range(world)]
 
 
-def reduce_row_stats(present: torch.Tensor, unambig: torch.Tensor, mask: torch.Tensor, group=None):
-    """Global per-row statistics from per-rank column slabs: counts add, code masks OR.
-    NCCL has no bitwise reduction, so the masks are all-gathered and OR-ed locally."""
-    dist.all_reduce(present, op=dist.ReduceOp.SUM, group=group)
-    dist.all_reduce(unambig, op=dist.ReduceOp.SUM, group=group)
+def reduce_row_stats(present: torch.Tensor, unambig: torch.Tensor, mask: torch.Tensor, group=None, total_samples=None):
+    """Global per-row statistics from per-rank column slabs: counts add, code masks OR (in place).
+    NCCL has no bitwise reduction, so the 16-bit code sets are all-gathered (two bytes per row) and OR-ed locally.  When the whole
+    job has fewer than 65 536 samples (`total_samples`), both counts travel in one all-reduce, 16 bits each."""
     world = dist.get_world_size(group)
-    parts = [torch.empty_like(mask) for _ in range(world)]
-    dist.all_gather(parts, mask, group=group)
-    acc = parts[0]
+    if total_samples is not None and 0 < total_samples <= 0xFFFF:
+        packed = present + (unambig << 16)
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        present.copy_(packed & 0xFFFF)
+        unambig.copy_((packed >> 16) & 0xFFFF)
+    else:
+        dist.all_reduce(present, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(unambig, op=dist.ReduceOp.SUM, group=group)
+    m8 = mask.to(torch.int16).view(torch.uint8)             # 16 code bits per row, sent as bytes (neither backend moves int16)
+    if dist.get_backend(group) == "gloo":
+        parts = [torch.empty_like(m8) for _ in range(world)]
+        dist.all_gather(parts, m8, group=group)
+    else:
+        out = torch.empty(world * m8.numel(), dtype=torch.uint8, device=m8.device)
+        dist.all_gather_into_tensor(out, m8, group=group)
+        parts = [out[r * m8.numel():(r + 1) * m8.numel()] for r in range(world)]
+    acc = parts[0].clone()
     for p in parts[1:]:
-        acc = torch.bitwise_or(acc, p)
-    mask.copy_(acc)
+        acc |= p
+    acc = acc.view(torch.int16)
+    mask.copy_(acc.to(torch.int32) & 0xFFFF)
     return present, unambig, mask
 
 

@@ -29,7 +29,7 @@ def _samples(n=6, L=4000, seed=3):
     return out
 
 
-def _worker(rank, world, port, tmp):
+def _worker(rank, world, port, tmp, packed):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import dist as skdist
@@ -59,17 +59,18 @@ def _worker(rank, world, port, tmp):
         if i:
             mask |= ((slab == c).any(axis=1).astype(np.int32) << i)
     mask = torch.from_numpy(mask)
-    skdist.reduce_row_stats(present, unambig, mask)
+    skdist.reduce_row_stats(present, unambig, mask, total_samples=len(_samples()) if packed else None)
     np.savez(os.path.join(tmp, f"r{rank}.npz"), rows=rows, present=present.numpy(), unambig=unambig.numpy(), mask=mask.numpy(),
              lo=lo, hi=hi, slab=slab)
     dist.destroy_process_group()
 
 
-def test_sharded_exchange_matches_single_merge(tmp_path):
+@pytest.mark.parametrize("packed", [False, True])          # counts in two all-reduces | both in one (16 bits each)
+def test_sharded_exchange_matches_single_merge(tmp_path, packed):
     import ora
     world = 2
-    port = 29500 + (os.getpid() % 1000)
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    port = 29500 + (os.getpid() % 1000) + (500 if packed else 0)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), packed), nprocs=world, join=True)
     samples = _samples()
     names = [f"s{i}" for i in range(len(samples))]
     dicts = []
@@ -86,6 +87,11 @@ def test_sharded_exchange_matches_single_merge(tmp_path):
         assert np.array_equal(p["unambig"], np.isin(fv, list(b"ACGT")).sum(axis=1))
     assert np.array_equal(np.concatenate([p["slab"] for p in parts], axis=1), fv)   # column slabs tile the matrix
     assert np.array_equal(parts[0]["mask"], parts[1]["mask"])
+    want = np.zeros(len(fk), np.int32)
+    for i, c in enumerate(b"-ACMTWYHGRSVKDBN"):
+        if i:
+            want |= (fv == c).any(axis=1).astype(np.int32) << i
+    assert np.array_equal(parts[0]["mask"], want)                              # OR of the ranks' code sets == the full matrix's
     assert [(int(p["lo"]), int(p["hi"])) for p in parts] == [(0, 3), (3, 6)]
 
 
