@@ -190,6 +190,12 @@ int  skx_array_map(skx_array *a, const char *reference_fasta, int ambig_mask, in
 skx_ctx *skx_array_ctx(const skx_array *a);
 void skx_set_last_error(const char *msg);
 
+/* wall-clock phases of the host-side path (file reading + upload, .skf codec, FASTA writer ...), accumulated per name since the
+ * last reset: a JSON object {"phase": seconds, ...} in first-use order (malloc'd, skx_free).  The reference has no counterpart;
+ * bench.py's end_to_end leg and SKX_DEBUG read them.  skx_phase_add lets host glue above the ABI record its own phases. */
+int  skx_phases_json(char **buf, uint64_t *len, int reset);
+void skx_phase_add(const char *name, double seconds);
+
 /* per-stage device timings of the last call on this ctx (ms; HIP events on the ctx stream) */
 typedef struct { double hist, scatter, dedupe, key_union, assemble, filter, compact, distance; } skx_timings;
 int  skx_ctx_timings(skx_ctx *ctx, skx_timings *t, int reset);

@@ -402,12 +402,11 @@ int skf_read_stream(const char *path, SkfMeta &m, std::vector<skx_key> &keys, st
 {
     threads = n_workers(threads);
     FrameReader fr;
-    const bool dbg = getenv("SKX_DEBUG") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     const auto t_open = now();
     const bool opened = fr.open(path, threads);
-    if (dbg) fprintf(stderr, "[skx] load: file read + chunk directory in %.2f s\n", secs(t_open, now()));
+    phase_add("load.map_file_chunk_directory", secs(t_open, now()));
     auto t_mark = now();
     if (!opened) {
         if (fr.err && !strcmp(fr.err, "open")) { set_error("cannot open %s", path); return SKX_EIO; }
@@ -476,10 +475,10 @@ int skf_read_stream(const char *path, SkfMeta &m, std::vector<skx_key> &keys, st
                     if (dev && device_section(2 * n) && fr.upos() + 2 * n <= fr.total_ulen) {
                         // the whole section on the device: compressed chunks in, sample-major matrix out
                         const uint64_t upos = fr.upos();
-                        if (dbg) fprintf(stderr, "[skx] load: header + split k-mers parsed in %.2f s (%.2f s of it decompressing their chunks)\n", secs(t_mark, now()), fr.fill_secs);
+                        phase_add("load.header_split_kmers", secs(t_mark, now()));
                         t_mark = now();
                         r = (*dev)(fr.raw.data(), fr.chunks.data(), fr.chunks.size(), upos, dim0, dim1);
-                        if (dbg) fprintf(stderr, "[skx] load: data section in %.2f s\n", secs(t_mark, now()));
+                        phase_add("load.data_section_device", secs(t_mark, now()));
                         t_mark = now();
                         if (r == SKX_OK) { if (!fr.seek(upos + 2 * n)) rd.ok = false; row0 = dim0; }
                         else if (r != SKF_NOT_TAKEN) return r;
@@ -537,7 +536,6 @@ int skf_write_stream(const char *path, const SkfMeta &m, const std::vector<skx_k
     FrameWriter fw;
     if (!fw.open(path, threads)) { set_error("cannot create %s", path); return SKX_EIO; }
     const uint64_t S = m.names.size(), U = m.n_rows;
-    const bool dbg = getenv("SKX_DEBUG") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     auto t_mark = now();
@@ -564,7 +562,7 @@ int skf_write_stream(const char *path, const SkfMeta &m, const std::vector<skx_k
     w.text("dim"); w.head(4, 2); w.head(0, U); w.head(0, S);
     w.text("data"); w.head(4, U * S);
     flush();
-    if (dbg) fprintf(stderr, "[skx] save: header + split k-mers encoded in %.2f s\n", secs(t_mark, now()));
+    phase_add("save.header_split_kmers", secs(t_mark, now()));
     t_mark = now();
     const uint64_t block_rows = S ? std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)(SUPER / 2) / S, SUPER / (2 * S) ? SUPER / (2 * S) : 1)) : 1;
     std::vector<uint8_t> rows;
@@ -620,7 +618,7 @@ int skf_write_stream(const char *path, const SkfMeta &m, const std::vector<skx_k
         for (uint64_t c = 0; c < cells; c++) { w.head(0, rows[c]); if (w.b.size() >= (1u << 20)) flush(); }
         flush();
     }
-    if (dbg) fprintf(stderr, "[skx] save: data section in %.2f s\n", secs(t_mark, now()));
+    phase_add("save.data_section", secs(t_mark, now()));
     t_mark = now();
     w.text("variant_count"); w.head(4, counts.size());
     for (size_t i = 0; i < counts.size(); i++) { w.head(0, counts[i]); if (w.b.size() >= (1u << 20)) flush(); }
@@ -628,7 +626,7 @@ int skf_write_stream(const char *path, const SkfMeta &m, const std::vector<skx_k
     w.text("k_bits"); w.head(0, (uint64_t)m.k_bits);
     flush();
     if (!fw.close()) { set_error("short write %s", path); return SKX_EIO; }
-    if (dbg) fprintf(stderr, "[skx] save: counts + close in %.2f s\n", secs(t_mark, now()));
+    phase_add("save.counts_close", secs(t_mark, now()));
     return SKX_OK;
 }
 

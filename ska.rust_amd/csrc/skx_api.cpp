@@ -15,6 +15,8 @@
 #include <numeric>
 #include <unordered_map>
 #include <thread>
+#include <cerrno>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -32,27 +34,67 @@ int skx::hip_fail(hipError_t e, const char *what)
     return e == hipErrorOutOfMemory ? SKX_ENOMEM : SKX_ENODEV;
 }
 extern "C" const char *skx_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------ phases
+namespace {
+struct Phases { std::mutex mu; std::vector<std::pair<std::string, double>> v; } g_phases;
+}
+void skx::phase_add(const char *name, double secs)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_phases.mu);
+        bool found = false;
+        for (auto &p : g_phases.v) if (p.first == name) { p.second += secs; found = true; break; }
+        if (!found) g_phases.v.emplace_back(name, secs);
+    }
+    if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] %-28s %.3f s\n", name, secs);
+}
+extern "C" void skx_phase_add(const char *name, double seconds) { if (name) skx::phase_add(name, seconds); }
+extern "C" int skx_phases_json(char **buf, uint64_t *len, int reset)
+{
+    return skx_guarded([&]() -> int {
+    std::string o = "{";
+    {
+        std::lock_guard<std::mutex> lk(g_phases.mu);
+        for (size_t i = 0; i < g_phases.v.size(); i++) {
+            char tmp[64]; snprintf(tmp, sizeof tmp, "%.6f", g_phases.v[i].second);
+            o += (i ? ", \"" : "\"") + g_phases.v[i].first + "\": " + tmp;
+        }
+        if (reset) g_phases.v.clear();
+    }
+    o += "}";
+    char *p = (char *)malloc(o.size() + 1);
+    if (!p) { set_error("out of host memory"); return SKX_ENOMEM; }
+    memcpy(p, o.c_str(), o.size() + 1);
+    *buf = p; if (len) *len = o.size();
+    return SKX_OK;
+    });
+}
 extern "C" const char *skx_version(void) { return "0.5.2"; }      // Cargo.toml:3, written as ska_version
 extern "C" void skx_free(void *p) { free(p); }
 
 // ------------------------------------------------------------------------------------------ device memory cache
 namespace {
+// one pool per device: a block is only ever handed back to a request made while its own device is current
 struct DevCache {
     std::mutex mu;
-    std::multimap<size_t, void *> free_blocks;          // size -> block
-    std::unordered_map<void *, size_t> live;            // block -> size
+    std::map<int, std::multimap<size_t, void *>> free_blocks;      // device -> size -> block
+    std::unordered_map<void *, std::pair<size_t, int>> live;       // block -> (size, device)
     size_t cached_bytes = 0;
 } g_cache;
+int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
 }
 void *skx::dev_alloc(size_t bytes, hipError_t *err)
 {
     bytes = (bytes + 255) & ~(size_t)255;
+    const int dev = current_device();
     {
         std::lock_guard<std::mutex> lk(g_cache.mu);
-        auto it = g_cache.free_blocks.lower_bound(bytes);
-        if (it != g_cache.free_blocks.end() && it->first <= bytes + bytes / 4 + (1u << 20)) {
+        auto &pool = g_cache.free_blocks[dev];
+        auto it = pool.lower_bound(bytes);
+        if (it != pool.end() && it->first <= bytes + bytes / 4 + (1u << 20)) {
             void *p = it->second; size_t sz = it->first;
-            g_cache.free_blocks.erase(it); g_cache.cached_bytes -= sz; g_cache.live[p] = sz;
+            pool.erase(it); g_cache.cached_bytes -= sz; g_cache.live[p] = {sz, dev};
             return p;
         }
     }
@@ -63,9 +105,9 @@ void *skx::dev_alloc(size_t bytes, hipError_t *err)
         skx::dev_trim();
         e = hipMalloc(&p, bytes);
     }
-    if (e != hipSuccess) { if (err) *err = e; return nullptr; }
+    if (e != hipSuccess) { (void)hipGetLastError(); if (err) *err = e; return nullptr; }
     std::lock_guard<std::mutex> lk(g_cache.mu);
-    g_cache.live[p] = bytes;
+    g_cache.live[p] = {bytes, dev};
     return p;
 }
 void skx::dev_free(void *p)
@@ -73,13 +115,13 @@ void skx::dev_free(void *p)
     std::lock_guard<std::mutex> lk(g_cache.mu);
     auto it = g_cache.live.find(p);
     if (it == g_cache.live.end()) { (void)hipFree(p); return; }
-    g_cache.free_blocks.emplace(it->second, p); g_cache.cached_bytes += it->second;
+    g_cache.free_blocks[it->second.second].emplace(it->second.first, p); g_cache.cached_bytes += it->second.first;
     g_cache.live.erase(it);
 }
 void skx::dev_trim()
 {
     std::lock_guard<std::mutex> lk(g_cache.mu);
-    for (auto &kv : g_cache.free_blocks) (void)hipFree(kv.second);
+    for (auto &pool : g_cache.free_blocks) for (auto &kv : pool.second) (void)hipFree(kv.second);      // hipFree takes a block of any device
     g_cache.free_blocks.clear(); g_cache.cached_bytes = 0;
 }
 
@@ -365,12 +407,12 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
             }
         });
     for (auto &th : pool) th.join();
-    if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] build_files: %d samples read, parsed and sent to the device by %d threads in %.2f s\n", n, nt, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_read0).count());
+    phase_add("build.read_parse_upload", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_read0).count());
     for (int i = 0; i < n; i++) if (rcodes[i] != SKX_OK) { set_error("%s", errs[i].c_str()); return rcodes[i]; }
     skx_dictset *d = nullptr;
     const auto t_dev0 = std::chrono::steady_clock::now();
     int r = skx_dictset_build(ctx, ss.data(), n, 1, k, rc, q, &d);
-    if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] build_files: dictionaries in %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_dev0).count());
+    phase_add("build.dictionaries", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_dev0).count());
     if (r == SKX_EEMPTY) {      // "{file} has no valid sequence" (ska_dict.rs:374-376)
         int bad = 0; sscanf(skx_last_error(), "sample %d", &bad);
         set_error("%s has no valid sequence", file1[bad]);
@@ -555,6 +597,7 @@ extern "C" int skx_keyset_from_device(skx_ctx *ctx, const void *dptr, uint64_t n
     const int wpk = k > 31 ? 2 : 1;
     DevBuf<uint64_t> flat; SKX_TRY(flat.alloc(n_keys * wpk));
     SKX_HIP(hipMemcpyAsync(flat.p, dptr, n_keys * 8 * wpk, hipMemcpyDeviceToDevice, ctx->stream));
+    SKX_HIP(hipStreamSynchronize(ctx->stream));          // the caller may free or reuse dptr as soon as this returns
     return keyset_from_flat(ctx, std::move(flat), n_keys, k, rc, out);
     });
 }
@@ -693,7 +736,15 @@ static uint64_t sample_device_bytes(const char *f1, const char *f2, bool wide)
     }
     return bases * (wide ? 44u : 24u) + (8u << 20);            // sequence + raw regions (with slack) + deduplicated words
 }
-static uint64_t cached_device_bytes() { std::lock_guard<std::mutex> lk(g_cache.mu); return g_cache.cached_bytes; }
+static uint64_t cached_device_bytes()        // of the current device
+{
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lk(g_cache.mu);
+    uint64_t n = 0;
+    auto it = g_cache.free_blocks.find(dev);
+    if (it != g_cache.free_blocks.end()) for (auto &kv : it->second) n += kv.first;
+    return n;
+}
 static uint64_t build_budget_bytes(skx_ctx *ctx)
 {
     if (const char *e = getenv("SKX_BUILD_BATCH_MB")) return (uint64_t)std::max(1.0, atof(e)) << 20;
@@ -712,8 +763,8 @@ static int build_range(skx_ctx *ctx, const char *const *names, const char *const
         r = skx_merge(ctx, d, names + lo, &a);
         const auto t1 = std::chrono::steady_clock::now();
         skx_dictset_free(d);
-        if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] build: merge into the array %.2f s, dictionaries released %.2f s\n", std::chrono::duration<double>(t1 - t0).count(),
-                                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
+        phase_add("build.merge", std::chrono::duration<double>(t1 - t0).count());
+        phase_add("build.release_dictionaries", std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
     }
     if (r == SKX_ENOMEM && hi - lo > 1) {                      // the estimate was too low: halve the batch
         dev_trim();
@@ -952,7 +1003,9 @@ extern "C" int skx_array_filter(skx_array *a, uint64_t min_count, int filter_amb
         StageTimer t(ctx, &ctx->tm.filter);
         FilterArgs fa{a->vcount.p, a->present.p, a->unambig.p, a->mask.p, U, (uint32_t)(a->total_samples ? a->total_samples : S), min_count, filter_ambig_as_missing, filter_type, ignore_const_gaps, keep.p};
         launch_filter_flags(fa, st);
-        launch_scan_u8(keep.p, pos.p, U, st);
+        DevBuf<uint32_t> sc_sums; DevBuf<uint64_t> sc_offs;
+        SKX_TRY(sc_sums.alloc(scan_u8_blocks(U))); SKX_TRY(sc_offs.alloc(scan_u8_blocks(U) + 1));
+        launch_scan_u8(keep.p, pos.p, U, sc_sums.p, sc_offs.p, st);
         SKX_HIP(hipMemcpyAsync(&kept, pos.p + U, 8, hipMemcpyDeviceToHost, st));
         if (filter_ambig_as_missing) {
             DevBuf<unsigned long long> d_sil; SKX_TRY(d_sil.alloc(1)); SKX_TRY(d_sil.zero(st));
@@ -980,7 +1033,9 @@ static int array_keep_rows(skx_array *a, DevBuf<uint8_t> &keep, uint64_t *remove
     const uint64_t U = a->n_rows;
     DevBuf<uint64_t> pos; SKX_TRY(pos.alloc(U + 1));
     uint64_t kept = 0;
-    launch_scan_u8(keep.p, pos.p, U, st);
+    DevBuf<uint32_t> sc_sums; DevBuf<uint64_t> sc_offs;
+    SKX_TRY(sc_sums.alloc(scan_u8_blocks(U))); SKX_TRY(sc_offs.alloc(scan_u8_blocks(U) + 1));
+    launch_scan_u8(keep.p, pos.p, U, sc_sums.p, sc_offs.p, st);
     SKX_HIP(hipMemcpyAsync(&kept, pos.p + U, 8, hipMemcpyDeviceToHost, st));
     SKX_HIP(hipStreamSynchronize(st));
     SKX_TRY(array_compact(a, keep, pos, kept, 0, false, true));
@@ -1189,14 +1244,17 @@ extern "C" int skx_array_write_fasta(skx_array *a, int fd)
     size_t max_rec = 0;
     for (auto &nm : a->names) max_rec = std::max<size_t>(max_rec, nm.size() + U + 3);
     const size_t cap = std::max<size_t>(max_rec, 64u << 20);
-    // a regular file takes several batches at once (pwrite at known offsets); a pipe takes them in order
+    // a regular file takes several batches at once (pwrite at known offsets); a pipe takes them in order, and so does a
+    // descriptor opened with O_APPEND (`ska align x.skf >> out.aln`): Linux pwrite ignores the offset there and appends
     struct stat sb;
     const bool regular = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
+    const int fl = fcntl(fd, F_GETFL);
+    const bool append = fl >= 0 && (fl & O_APPEND);
     off_t pos = regular ? lseek(fd, 0, SEEK_CUR) : 0;
-    const int NB = regular && pos >= 0 ? 6 : 2;
+    const int NB = regular && !append && pos >= 0 ? 6 : 2;
+    std::atomic<bool> ok{true};                 // declared before the slots: their destructors join writers that store to it
     struct Slot { char *p = nullptr; std::thread th; ~Slot() { if (th.joinable()) th.join(); if (p) (void)hipHostFree(p); } } slot[6];
     for (int b = 0; b < NB; b++) if (hipHostMalloc((void **)&slot[b].p, cap, hipHostMallocDefault) != hipSuccess) { slot[b].p = nullptr; set_error("out of host memory"); return SKX_ENOMEM; }
-    std::atomic<bool> ok{true};
     int cur = 0, last = -1;
     for (size_t s = 0; s < S && ok;) {
         Slot &sl = slot[cur];
@@ -1217,6 +1275,7 @@ extern "C" int skx_array_write_fasta(skx_array *a, int fd)
             size_t w = 0;
             while (w < used) {
                 const ssize_t r = positioned ? pwrite(fd, buf + w, used - w, at + (off_t)w) : write(fd, buf + w, used - w);
+                if (r < 0 && errno == EINTR) continue;
                 if (r <= 0) { ok = false; return; }
                 w += (size_t)r;
             }

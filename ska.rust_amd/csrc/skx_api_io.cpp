@@ -244,11 +244,12 @@ extern "C" int skx_array_save(skx_array *a, const char *path)
     skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
     SKX_HIP(hipSetDevice(ctx->device));
     const uint64_t U = a->n_rows, S = a->names.size();
+    if (a->n_kmers != a->n_rows) { set_error("split k-mers and variants are out of step (filtered without update_kmers): such an array cannot be loaded back"); return SKX_EINVAL; }
     SkfMeta m; m.k = a->k; m.rc = a->rc; m.k_bits = a->k_bits; m.names = a->names; m.version = a->version; m.n_rows = U;
     std::vector<skx_key> keys;
     const auto t_k0 = std::chrono::steady_clock::now();
     SKX_TRY(array_host_keys(a, keys));
-    if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] save: keys to host in %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_k0).count());
+    phase_add("save.keys_to_host", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_k0).count());
     std::vector<uint32_t> vc(U);
     if (U) SKX_HIP(hipMemcpy(vc.data(), a->vcount.p, U * 4, hipMemcpyDeviceToHost));
     std::vector<uint64_t> counts(vc.begin(), vc.end());
@@ -306,7 +307,7 @@ extern "C" int skx_array_save(skx_array *a, const char *path)
     };
     const auto t_w0 = std::chrono::steady_clock::now();
     const int r = skf_write_stream(path, m, keys, counts, fetch, 0, &dev_encode);
-    if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] save: stream written in %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_w0).count());
+    phase_add("save.total_stream", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_w0).count());
     return r;
     });
 }
@@ -393,7 +394,8 @@ extern "C" int skx_array_load(skx_ctx *ctx, const char *path, int want_bits, skx
     };
     const auto t_r0 = std::chrono::steady_clock::now();
     SKX_TRY(skf_read_stream(path, m, keys, counts, begin_rows, sink, 0, &dev_decode));
-    if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] load: stream read in %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_r0).count());
+    phase_add("load.total_stream", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_r0).count());
+    PhaseTimer t_fin("load.keys_upload_stats");
     SKX_TRY(check_k(m.k));
     if (want_bits == 64)       // serde into Vec<u64> fails on wider values; lib.rs:635-661 then retries as u128
         for (auto &kk : keys) if (kk.hi) { set_error("split k-mer does not fit 64 bits"); return SKX_EFORMAT; }

@@ -151,7 +151,8 @@ struct FilterArgs {
     uint8_t *keep;
 };
 void launch_filter_flags(const FilterArgs &a, hipStream_t st);
-void launch_scan_u8(const uint8_t *flags, uint64_t *pos, uint64_t n, hipStream_t st);   // pos[n] = total
+uint64_t scan_u8_blocks(uint64_t n);      // scratch of launch_scan_u8: sums[blocks] u32 + offs[blocks + 1] u64, owned by the caller
+void launch_scan_u8(const uint8_t *flags, uint64_t *pos, uint64_t n, uint32_t *sums, uint64_t *offs, hipStream_t st);   // pos[n] = total
 // out[s][pos[c]] = in[s][c] for kept c (optionally ambiguous -> 'N'); also compacts the stat/key arrays
 void launch_compact_matrix(const uint8_t *in, uint64_t in_pitch, uint8_t *out, uint64_t out_pitch, int n_samples,
                            uint64_t n_cols, const uint8_t *keep, const uint64_t *pos, int mask_ambig, hipStream_t st);

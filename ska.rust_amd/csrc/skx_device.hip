@@ -415,20 +415,15 @@ __global__ __launch_bounds__(1024) void scan_u8_apply_kernel(const uint8_t *in, 
     for (int i = 0; i < 8; i++) { if (base + i < n) out[base + i] = run; run += v[i]; }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == blockDim.x - 1) out[n] = run;
 }
-void launch_scan_u8(const uint8_t *flags, uint64_t *pos, uint64_t n, hipStream_t st)
+uint64_t scan_u8_blocks(uint64_t n) { return (n + SCAN8_PER_BLOCK - 1) / SCAN8_PER_BLOCK; }
+// scratch (caller-owned, on the stream's device): sums[scan_u8_blocks(n)] u32, offs[scan_u8_blocks(n) + 1] u64
+void launch_scan_u8(const uint8_t *flags, uint64_t *pos, uint64_t n, uint32_t *sums, uint64_t *offs, hipStream_t st)
 {
-    // scratch for the block sums lives at the tail of `pos` is not possible (u64 semantics), so use a small static pool
-    static uint32_t *d_sums = nullptr; static uint64_t *d_offs = nullptr; static uint64_t cap = 0;
-    const uint64_t nb = (n + SCAN8_PER_BLOCK - 1) / SCAN8_PER_BLOCK;
+    const uint64_t nb = scan_u8_blocks(n);
     if (nb == 0) { (void)hipMemsetAsync(pos, 0, 8, st); return; }
-    if (nb > cap) {
-        if (d_sums) { (void)hipFree(d_sums); (void)hipFree(d_offs); }
-        cap = nb * 2 + 1024;
-        (void)hipMalloc((void **)&d_sums, cap * 4); (void)hipMalloc((void **)&d_offs, (cap + 1) * 8);
-    }
-    hipLaunchKernelGGL(scan_u8_sums_kernel, dim3((unsigned)nb), dim3(1024), 0, st, flags, n, d_sums);
-    hipLaunchKernelGGL(scan_u32_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)d_sums, d_offs, nb, (uint32_t *)nullptr);
-    hipLaunchKernelGGL(scan_u8_apply_kernel, dim3((unsigned)nb), dim3(1024), 0, st, flags, n, (const uint64_t *)d_offs, pos);
+    hipLaunchKernelGGL(scan_u8_sums_kernel, dim3((unsigned)nb), dim3(1024), 0, st, flags, n, sums);
+    hipLaunchKernelGGL(scan_u32_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)sums, offs, nb, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(scan_u8_apply_kernel, dim3((unsigned)nb), dim3(1024), 0, st, flags, n, (const uint64_t *)offs, pos);
 }
 
 // ------------------------------------------------------------------------------------------------

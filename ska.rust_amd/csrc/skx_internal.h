@@ -2,6 +2,7 @@
 #pragma once
 #include "../../include/skx.h"
 #include "skx_device.h"
+#include <chrono>
 #include <cstdio>
 #include <functional>
 #include <new>
@@ -16,6 +17,16 @@ int hip_fail(hipError_t e, const char *what);       // sets the error, returns S
 
 #define SKX_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return skx::hip_fail(e_, #call); } while (0)
 #define SKX_TRY(call) do { int r_ = (call); if (r_ != SKX_OK) return r_; } while (0)
+
+// wall-clock phases of the host path (file reading, uploads, codec, writers): accumulated per name in first-use order, printed
+// as they are recorded when SKX_DEBUG is set, returned as JSON by skx_phases_json (bench.py's end_to_end leg reads them)
+void phase_add(const char *name, double secs);
+struct PhaseTimer {
+    const char *name; std::chrono::steady_clock::time_point t0;
+    explicit PhaseTimer(const char *n) : name(n), t0(std::chrono::steady_clock::now()) {}
+    double stop() { double s = 0; if (name) { s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); phase_add(name, s); name = nullptr; } return s; }
+    ~PhaseTimer() { stop(); }
+};
 
 // caching device allocator (per process): freed blocks are kept and reused for later requests of a similar size,
 // so steady-state batches do not go through hipMalloc/hipFree (which map/unmap tens of GB and cost seconds)

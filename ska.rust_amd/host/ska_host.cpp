@@ -62,6 +62,12 @@ void skx_set_error(const char *fmt, ...)
     va_list ap; va_start(ap, fmt); vsnprintf(tmp, sizeof tmp, fmt, ap); va_end(ap);
     skx_set_last_error(tmp);
 }
+struct Phase {       // wall-clock phase recorded through the ABI (skx_phase_add)
+    const char *name; std::chrono::steady_clock::time_point t0;
+    explicit Phase(const char *n) : name(n), t0(std::chrono::steady_clock::now()) {}
+    void stop() { if (name) { skx_phase_add(name, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); name = nullptr; } }
+    ~Phase() { stop(); }
+};
 template <typename F>
 int skx_guarded(F &&f) noexcept
 {
@@ -113,8 +119,11 @@ extern "C" int skh_align_fd(skx_array *a, int filter_type, int mask_ambig, int i
 {
     return skx_guarded([&]() -> int {
     int32_t removed = 0;
+    Phase pf("align.filter");
     int r = skh_apply_filters(a, min_freq, filter_ambig_as_missing, filter_type, mask_ambig, ignore_const_gaps, &removed);
+    pf.stop();
     if (r != SKX_OK) return r;
+    Phase pw("align.write_fasta");
     return skx_array_write_fasta(a, fd);
     });
 }
@@ -191,8 +200,8 @@ extern "C" int skh_load_array(skx_ctx *ctx, const char *const *inputs, int n_inp
     return skx_guarded([&]() -> int {
     if (n_inputs == 1) {                                                                // io_utils.rs:65-75, lib.rs:635-661
         int r = skx_array_load(ctx, inputs[0], 64, out);
-        if (r == SKX_OK) return r;
-        return skx_array_load(ctx, inputs[0], 128, out);
+        if (r != SKX_EFORMAT) return r;                                                 // only "does not fit u64" falls through to u128; a missing
+        return skx_array_load(ctx, inputs[0], 128, out);                                // or corrupt file keeps its own message
     }
     // >1 inputs: `ska build` with defaults (k=31, rc, min_count 5, min_qual 20, strict), io_utils.rs:76-92
     std::vector<char *> names(n_inputs);
@@ -419,7 +428,7 @@ extern "C" int skh_main(int argc, char **argv)
     const bool dbg = getenv("SKX_DEBUG") != nullptr;
     skx_ctx *ctx = nullptr;
     if (skx_ctx_create(0, &ctx) != SKX_OK) return engine_fail();
-    if (dbg) fprintf(stderr, "[skx] main: device context after %.2f s\n", since());
+    skx_phase_add("main.device_context", since());
     int rcode = 0;
     skx_array *arr = nullptr;
     if (cmd == "build") {
@@ -550,9 +559,15 @@ extern "C" int skh_main(int argc, char **argv)
     } else {
         rcode = fail("unknown subcommand (this engine provides build, align, map, distance, nk, merge, delete, weed, cov)");
     }
-    if (dbg) fprintf(stderr, "[skx] main: %s done after %.2f s\n", cmd.c_str(), since());
+    const double t_done = since();
+    if (dbg) fprintf(stderr, "[skx] main: %s done after %.2f s\n", cmd.c_str(), t_done);
     if (arr) skx_array_free(arr);
     skx_ctx_destroy(ctx);
-    if (dbg) fprintf(stderr, "[skx] main: device memory released after %.2f s\n", since());
+    skx_phase_add("main.release_device", since() - t_done);
+    skx_phase_add("main.total", since());
+    if (const char *pp = getenv("SKX_PHASES")) {                  // phase table of this invocation as JSON (bench.py's end_to_end leg)
+        char *js = nullptr; uint64_t jl = 0;
+        if (skx_phases_json(&js, &jl, 0) == SKX_OK) { if (FILE *f = fopen(pp, "w")) { fwrite(js, 1, jl, f); fputc('\n', f); fclose(f); } skx_free(js); }
+    }
     return rcode;
 }

@@ -68,10 +68,22 @@ def sample_stream(anc, index, n_samples, private_snps=500, shared_snps=50, seed=
 
 
 def to_fasta(stream, path, width=60):
-    """Write a record stream as a wrapped multi-FASTA file."""
-    data = stream.tobytes()
+    """Write a record stream as a wrapped multi-FASTA file (one reshape per contig, no per-line Python work)."""
+    ends = np.flatnonzero(stream == 10)
+    parts = []
+    a = 0
+    for i, b in enumerate(ends):
+        rec = stream[a:b]
+        a = b + 1
+        parts.append(np.frombuffer(b">contig_%d\n" % i, dtype=np.uint8))
+        full = len(rec) // width
+        if full:
+            lines = np.empty((full, width + 1), dtype=np.uint8)
+            lines[:, :width] = rec[:full * width].reshape(full, width)
+            lines[:, width] = 10
+            parts.append(lines.reshape(-1))
+        if len(rec) > full * width:
+            parts.append(rec[full * width:])
+            parts.append(np.frombuffer(b"\n", dtype=np.uint8))
     with open(path, "wb") as f:
-        for i, rec in enumerate(data.split(b"\n")[:-1]):
-            f.write(b">contig_%d\n" % i)
-            for o in range(0, len(rec), width):
-                f.write(rec[o:o + width] + b"\n")
+        f.write(np.concatenate(parts).tobytes() if parts else b"")
