@@ -52,7 +52,7 @@ skx_keyset_union skx_keyset_size skx_keyset_device skx_keyset_from_device skx_ke
 skx_array_assemble skx_merge skx_build_and_merge skx_array_free skx_array_save skx_array_load skx_array_from_host
 skx_array_info skx_array_name skx_array_version skx_array_export skx_array_sample_kmers skx_array_filter
 skx_array_write_fasta skx_array_fasta skx_array_device_matrix skx_array_device_stats skx_array_set_total_samples skx_array_distance skx_free skx_ctx_timings
-skx_array_merge skx_array_delete_samples skx_array_weed skx_keyset_from_fasta skx_array_ctx skx_set_last_error skx_array_map skx_cov_histogram
+skx_array_merge skx_array_delete_samples skx_array_weed skx_keyset_from_fasta skx_array_ctx skx_set_last_error skx_array_map skx_cov_histogram skx_phases_json skx_phase_add
 skh_apply_filters skh_align skh_align_fd skh_distance_tsv skh_nk skh_save_skf skh_load_array skh_sample_name skh_main skh_merge skh_delete skh_weed skh_cov skh_cov_fit""".split()
 
 _lib = None
@@ -134,6 +134,9 @@ def load_library():
     lib.skh_weed.argtypes = [vp, cp, i, d, i, i, i, i, cp]
     lib.skh_sample_name.argtypes = [cp]
     lib.skh_sample_name.restype = vp
+    lib.skx_phases_json.argtypes = [pp, C.POINTER(u64), i]
+    lib.skx_phase_add.argtypes = [cp, d]
+    lib.skx_phase_add.restype = None
     _lib = lib
     return lib
 
@@ -179,6 +182,14 @@ def cov(fq1, fq2, k=31, rc=True, ctx=None):
     p, n, cut = C.c_void_p(), C.c_uint64(), C.c_uint64()
     _check(_lib.skh_cov(ctx.h, fq1.encode(), fq2.encode(), k, int(rc), C.byref(p), C.byref(n), C.byref(cut)))
     return _take(p, n), cut.value
+
+
+def phases(reset=False):
+    """Wall-clock phases of the host path recorded since the last reset: {name: seconds} in first-use order."""
+    import json
+    buf, n = C.c_void_p(), C.c_uint64()
+    _check(_lib.skx_phases_json(C.byref(buf), C.byref(n), int(reset)))
+    return json.loads(_take(buf, n))
 
 
 def sample_name(path):
