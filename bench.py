@@ -39,8 +39,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "ska.rust_amd"))
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
+
+# torch is imported inside main(), after the end-to-end leg: a parent process that has loaded the HIP runtime is a second client
+# of the GPU driver, and with one alive the first large device allocation of every ska process it starts takes 2.2 s longer
+# (measured: tools/seq_probe.py, profiles/r02_seq_probe.log) -- a user's shell is not such a process
+torch = None
+dist = None
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -227,27 +231,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("SKX_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))   # override: ranks sharing one GPU in tests
-    if not torch.cuda.is_available():
+    if not os.path.exists("/dev/kfd"):
         raise SystemExit("bench.py needs a gfx950 GPU: the engine has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     sharded = world > 1 or os.environ.get("SKX_BENCH_FORCE_SHARDED") == "1"     # the override runs the exchange path at world size 1
-    if sharded:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        backend = os.environ.get("SKX_BENCH_BACKEND", "nccl")      # "gloo" lets two ranks share one GPU in tests
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-
-    import dist as skdist
-    import skx_engine as E
     import synth
-    E.load_library()
-    ctx = E.Context(local_rank)
 
     G = args.genomes
     n_total = G * world
@@ -269,6 +256,35 @@ def main():
         offs.append(tot)
         lens.append(len(s))
         tot += (len(s) + 255) // 256 * 256
+    # The end-to-end leg goes first, before this process opens the device: the ska executable then finds the GPU as a fresh login
+    # would (device memory that another process has just released is wiped by the driver before it is handed out again, at
+    # ~20 GB/s on this box -- DESIGN.md section 8 -- so a leg that follows 80 GB of this process's own buffers would be charged
+    # for them)
+    e2e = None
+    if want_files and not args.no_e2e:
+        e2e = end_to_end(args, files, td)
+    global torch, dist
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a gfx950 GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        backend = os.environ.get("SKX_BENCH_BACKEND", "nccl")      # "gloo" lets two ranks share one GPU in tests
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    import dist as skdist
+    import skx_engine as E
+    E.load_library()
+    ctx = E.Context(local_rank)
     pool = torch.empty(tot + 256, dtype=torch.uint8, device=dev)
     for i, s in enumerate(streams):
         pool[offs[i]:offs[i] + lens[i]] = torch.from_numpy(s).to(dev, non_blocking=False)
@@ -386,8 +402,8 @@ def main():
             del pool
             torch.cuda.empty_cache()
             try:
-                if not args.no_e2e:
-                    res["end_to_end"] = end_to_end(args, files, td)
+                if e2e is not None:
+                    res["end_to_end"] = e2e
                 oarr = oaln = None
                 if args.cpu_genomes > 0:
                     res["cpu_baseline"], oarr, oaln = cpu_baseline(args, files, n_total, td)

@@ -424,7 +424,9 @@ int skf_read_stream(const char *path, SkfMeta &m, std::vector<skx_key> &keys, st
         else if (name == "split_kmers") {
             uint64_t n = rd.array();
             if (n > (1ull << 40)) { rd.ok = false; continue; }
-            keys.resize(n);
+            phase_add("load.dbg_before_keys", secs(t_mark, now()));
+            { const auto tq = now(); keys.resize(n); phase_add("load.dbg_keys_resize", secs(tq, now())); }
+            double team_s = 0, generic_s = 0; uint64_t generic_n = 0;
             // nearly every 64-bit split k-mer is a 9-byte uint (0x1b + 8 bytes): whole runs of those are decoded by the team,
             // anything else one at a time by the generic parser
             uint64_t j = 0;
@@ -435,6 +437,7 @@ int skf_read_stream(const char *path, SkfMeta &m, std::vector<skx_key> &keys, st
                     const size_t parts = (size_t)std::min<uint64_t>((uint64_t)threads, can / 1024);
                     const uint64_t per = can / parts;
                     std::atomic<int> other{0};
+                    const auto tq = now();
                     parallel_for(parts, threads, [&](size_t pt) {
                         const uint64_t a = pt * per, b = pt + 1 == parts ? can : a + per;
                         uint8_t bad = 0;
@@ -446,13 +449,16 @@ int skf_read_stream(const char *path, SkfMeta &m, std::vector<skx_key> &keys, st
                         }
                         if (bad) other = 1;
                     });
+                    team_s += secs(tq, now());
                     if (!other) { fr.consume(9 * can); j += can; continue; }
                     for (uint64_t c = 0; c < can && rd.ok; c++) keys[j + c] = rd.key();         // a run with shorter / wider keys in it
                     j += can;
                     continue;
                 }
-                keys[j++] = rd.key();
+                { const auto tq = now(); keys[j++] = rd.key(); generic_s += secs(tq, now()); generic_n++; }
             }
+            phase_add("load.dbg_keys_team", team_s); phase_add("load.dbg_keys_generic", generic_s); phase_add("load.dbg_fill", fr.fill_secs);
+            if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] generic keys %llu\n", (unsigned long long)generic_n);
         }
         else if (name == "variants") {
             uint64_t n3 = 0; if (!rd.head(mj, n3) || mj != 5) rd.ok = false;

@@ -17,6 +17,7 @@
 #include <thread>
 #include <cerrno>
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -373,24 +374,74 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
     return skx_guarded([&]() -> int {
     if (!ctx || !file1 || n <= 0 || !out) { set_error("bad arguments"); return SKX_EINVAL; }
     SKX_TRY(check_k(k));
-    // Every reader thread parses a file and sends its record stream to the device itself (a synchronous copy from pageable
-    // memory on the thread's own stream): the uploads of some samples run beside the parsing of others, and the host copy
-    // of a sample is gone as soon as it is on the device.
+    // Reader threads.  A plain (uncompressed, single-file) FASTA sample is not parsed on the host at all: its bytes are read
+    // into pinned memory and uploaded as they are, and the device strips headers and line breaks (skx_parse.hip) -- the host
+    // side of an assembly is one read() and one asynchronous copy.  FASTQ, .gz and two-file samples are parsed by the host
+    // reader (fastx.cpp) and uploaded as record streams.  Either way the uploads of some samples run beside the reading of
+    // others, each thread on its own stream.
     std::vector<int> rcodes(n, SKX_OK);
     std::vector<std::string> errs(n);
     std::vector<DevBuf<uint8_t>> d_seq(n), d_qual(n);
+    std::vector<uint64_t> raw_len(n, 0), slot_off(n, 0), slot_len(n, 0);
+    std::vector<char> is_raw(n, 0);
     std::vector<skx_stream> ss(n);
-    int nt = std::max(1, std::min(threads, n));
+    size_t step = 1;
+    if (proportion_reads > 0.0) { step = (size_t)std::llround(1.0 / proportion_reads); if (step == 0) step = 1; }
+    const bool device_parse = step == 1 && !getenv("SKX_HOST_PARSE");
     const auto t_read0 = std::chrono::steady_clock::now();
+    // one device buffer for all raw texts and one for all record streams (a slot per single-file sample, sized from stat):
+    // two allocations whatever the number of samples
+    DevBuf<uint8_t> raw_all, out_all;
+    if (device_parse) {
+        uint64_t tot = 0;
+        for (int i = 0; i < n; i++) {
+            struct stat sb;
+            if ((file2 && file2[i]) || stat(file1[i], &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 1) continue;
+            slot_off[i] = tot; slot_len[i] = ((uint64_t)sb.st_size + 64 + 255) & ~255ull;
+            tot += slot_len[i];
+        }
+        if (tot) { SKX_HIP(hipSetDevice(ctx->device)); SKX_TRY(raw_all.alloc(tot)); SKX_TRY(out_all.alloc(tot)); }
+    }
+    int nt = std::max(1, std::min(threads, n));
     std::vector<std::thread> pool;
     std::atomic<int> next{0};
+    constexpr size_t PIN = 8u << 20;
     for (int t = 0; t < nt; t++)
         pool.emplace_back([&]() {
             (void)hipSetDevice(ctx->device);
             hipStream_t up_st = nullptr;
             if (hipStreamCreateWithFlags(&up_st, hipStreamNonBlocking) != hipSuccess) up_st = nullptr;
-            struct Drop { hipStream_t s; ~Drop() { if (s) (void)hipStreamDestroy(s); } } drop{up_st};
+            struct Drop { hipStream_t s; uint8_t *pin; ~Drop() { if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } if (pin) (void)hipHostFree(pin); } } drop{up_st, nullptr};
+            // raw upload of a plain FASTA file: SKX_OK (taken), SKF_NOT_TAKEN (use the host reader), or an error
+            auto raw_upload = [&](int i) -> int {
+                if (!slot_len[i]) return SKF_NOT_TAKEN;
+                const int fd = ::open(file1[i], O_RDONLY);
+                if (fd < 0) return SKF_NOT_TAKEN;                                    // the host reader reports it
+                struct Close { int fd; ~Close() { ::close(fd); } } cl{fd};
+                if (!drop.pin && hipHostMalloc((void **)&drop.pin, PIN, hipHostMallocDefault) != hipSuccess) { drop.pin = nullptr; set_error("out of host memory"); return SKX_ENOMEM; }
+                const uint64_t cap = slot_len[i] - 64;                               // the size stat reported
+                uint8_t *dst = raw_all.p + slot_off[i];
+                uint64_t off = 0;
+                while (off < cap) {
+                    const size_t want = (size_t)std::min<uint64_t>(PIN, cap - off);
+                    size_t got = 0;
+                    while (got < want) { const ssize_t r = read(fd, drop.pin + got, want - got); if (r < 0 && errno == EINTR) continue; if (r <= 0) break; got += (size_t)r; }
+                    if (got == 0) break;                                               // the file shrank under us: what was read is the file
+                    if (off == 0 && drop.pin[0] != '>') return SKF_NOT_TAKEN;          // FASTQ ('@'), gzip (1f 8b), anything else: the host reader's
+                    SKX_HIP(hipMemcpyAsync(dst + off, drop.pin, got, hipMemcpyHostToDevice, up_st));
+                    SKX_HIP(hipStreamSynchronize(up_st));                              // the pinned buffer is reused; the copy is ~20x faster than the read
+                    off += got;
+                }
+                if (off == 0) return SKF_NOT_TAKEN;
+                raw_len[i] = off; is_raw[i] = 1;
+                return SKX_OK;
+            };
             for (int i; (i = next.fetch_add(1)) < n;) {
+                if (device_parse && up_st) {
+                    const int r = raw_upload(i);
+                    if (r == SKX_OK) continue;
+                    if (r != SKF_NOT_TAKEN) { rcodes[i] = r; errs[i] = skx_last_error(); continue; }
+                }
                 HostStream h;
                 rcodes[i] = read_sample_stream(file1[i], file2 ? file2[i] : nullptr, proportion_reads, h);
                 if (rcodes[i] != SKX_OK) { errs[i] = skx_last_error(); continue; }
@@ -407,8 +458,43 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
             }
         });
     for (auto &th : pool) th.join();
-    phase_add("build.read_parse_upload", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_read0).count());
+    phase_add("build.read_upload", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_read0).count());
     for (int i = 0; i < n; i++) if (rcodes[i] != SKX_OK) { set_error("%s", errs[i].c_str()); return rcodes[i]; }
+    // the raw FASTA texts -> record streams, all files in one set of launches
+    {
+        PhaseTimer t_parse("build.device_fasta_parse");
+        SKX_HIP(hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
+        std::vector<int> idx;
+        for (int i = 0; i < n; i++) if (is_raw[i]) idx.push_back(i);
+        const int m = (int)idx.size();
+        if (m) {
+            std::vector<const uint8_t *> h_raw(m); std::vector<uint8_t *> h_out(m); std::vector<uint64_t> h_len(m), h_base(m + 1, 0);
+            for (int j = 0; j < m; j++) {
+                const int i = idx[j];
+                h_raw[j] = raw_all.p + slot_off[i]; h_out[j] = out_all.p + slot_off[i]; h_len[j] = raw_len[i];
+                h_base[j + 1] = h_base[j] + fasta_parse_tiles(raw_len[i]);
+            }
+            const uint64_t tiles = h_base[m];
+            std::vector<uint32_t> h_tf(tiles);
+            for (int j = 0; j < m; j++) std::fill(h_tf.begin() + (ptrdiff_t)h_base[j], h_tf.begin() + (ptrdiff_t)h_base[j + 1], (uint32_t)j);
+            DevBuf<const uint8_t *> g_raw; DevBuf<uint8_t *> g_out; DevBuf<uint64_t> g_len, g_outlen, g_base, g_off, g_sum; DevBuf<uint32_t> g_tf; DevBuf<uint8_t> g_kind;
+            SKX_TRY(g_raw.alloc(m)); SKX_TRY(g_out.alloc(m)); SKX_TRY(g_len.alloc(m)); SKX_TRY(g_outlen.alloc(m)); SKX_TRY(g_base.alloc(m + 1));
+            SKX_TRY(g_off.alloc(tiles)); SKX_TRY(g_sum.alloc(tiles)); SKX_TRY(g_tf.alloc(tiles)); SKX_TRY(g_kind.alloc(tiles));
+            SKX_HIP(hipMemcpyAsync(g_raw.p, h_raw.data(), m * sizeof(void *), hipMemcpyHostToDevice, st));
+            SKX_HIP(hipMemcpyAsync(g_out.p, h_out.data(), m * sizeof(void *), hipMemcpyHostToDevice, st));
+            SKX_HIP(hipMemcpyAsync(g_len.p, h_len.data(), m * 8, hipMemcpyHostToDevice, st));
+            SKX_HIP(hipMemcpyAsync(g_base.p, h_base.data(), (m + 1) * 8, hipMemcpyHostToDevice, st));
+            if (tiles) SKX_HIP(hipMemcpyAsync(g_tf.p, h_tf.data(), tiles * 4, hipMemcpyHostToDevice, st));
+            launch_fasta_parse(g_raw.p, g_len.p, g_out.p, g_outlen.p, g_tf.p, g_base.p, tiles, g_sum.p, g_off.p, g_kind.p, m, st);
+            std::vector<uint64_t> h_outlen(m);
+            SKX_HIP(hipMemcpyAsync(h_outlen.data(), g_outlen.p, m * 8, hipMemcpyDeviceToHost, st));
+            SKX_HIP(hipStreamSynchronize(st));
+            SKX_HIP(hipGetLastError());
+            for (int j = 0; j < m; j++) { const int i = idx[j]; ss[i].seq = out_all.p + slot_off[i]; ss[i].qual = nullptr; ss[i].len = h_outlen[j]; }
+        }
+        raw_all.release();
+    }
     skx_dictset *d = nullptr;
     const auto t_dev0 = std::chrono::steady_clock::now();
     int r = skx_dictset_build(ctx, ss.data(), n, 1, k, rc, q, &d);
@@ -1232,34 +1318,72 @@ extern "C" int skx_array_fasta(skx_array *a, char **buf, uint64_t *len)
     return SKX_OK;
     });
 }
-// write_fasta (merge_ska_array.rs:507-520) streamed to a file descriptor: batches of samples (header + row + newline, ~64 MB)
-// come off the device into one of two pinned buffers while a writer thread puts the previous batch out; no copy of the
-// alignment is held on the host.
+// write_fasta (merge_ska_array.rs:507-520) streamed to a file descriptor: batches of samples (header + row + newline) come off
+// the device into pinned buffers; no copy of the alignment is held on the host.
+//  * regular file opened read-write: the file is sized up front and mapped, and every batch is copied into the mapping by
+//    several threads at once (page-cache pages of one file are filled in parallel; write()/pwrite() on one inode are serialised
+//    by the kernel, which is what bounded the first version: 4.9 GB in 1.0 s);
+//  * regular file, write-only: several batches in flight with pwrite at known offsets;
+//  * pipe, or a descriptor opened with O_APPEND (`ska align x.skf >> out.aln`: Linux pwrite ignores the offset there and
+//    appends): batches in order through write().
 extern "C" int skx_array_write_fasta(skx_array *a, int fd)
 {
     return skx_guarded([&]() -> int {
     skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
     SKX_HIP(hipSetDevice(ctx->device));
     const size_t S = a->names.size(); const uint64_t U = a->n_rows;
-    size_t max_rec = 0;
-    for (auto &nm : a->names) max_rec = std::max<size_t>(max_rec, nm.size() + U + 3);
-    const size_t cap = std::max<size_t>(max_rec, 64u << 20);
-    // a regular file takes several batches at once (pwrite at known offsets); a pipe takes them in order, and so does a
-    // descriptor opened with O_APPEND (`ska align x.skf >> out.aln`): Linux pwrite ignores the offset there and appends
+    size_t max_rec = 0; uint64_t total = 0;
+    for (auto &nm : a->names) { max_rec = std::max<size_t>(max_rec, nm.size() + U + 3); total += nm.size() + U + 3; }
     struct stat sb;
     const bool regular = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
     const int fl = fcntl(fd, F_GETFL);
     const bool append = fl >= 0 && (fl & O_APPEND);
     off_t pos = regular ? lseek(fd, 0, SEEK_CUR) : 0;
-    const int NB = regular && !append && pos >= 0 ? 6 : 2;
+    // ---- mapped output
+    uint8_t *map = nullptr; size_t map_len = 0, map_skew = 0;
+    if (regular && !append && pos >= 0 && fl >= 0 && (fl & O_ACCMODE) == O_RDWR && total && !getenv("SKX_NO_MMAP_OUTPUT")) {
+        const long pg = sysconf(_SC_PAGESIZE);
+        map_skew = (size_t)(pos % pg);
+        if (ftruncate(fd, pos + (off_t)total) == 0) {
+            map_len = total + map_skew;
+            void *m = mmap(nullptr, map_len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, pos - (off_t)map_skew);
+            if (m != MAP_FAILED) map = (uint8_t *)m; else map_len = 0;
+        }
+    }
+    struct Unmap { uint8_t *&p; size_t &n; ~Unmap() { if (p) munmap(p, n); } } unmap{map, map_len};
+    // the file's pages are allocated by fallocate before the copies start (allocating a page-cache page inside a page fault
+    // costs ~1 us and does not scale over the threads of one file; fallocate does ~12 GB/s on tmpfs, and copies that run beside
+    // it contend with it: 4.9 GB in 0.8 s this way, 1.0 s with the copies chasing the allocation, 1.0-1.4 s through
+    // write()/pwrite() -- tools/fasta_knobs.py); the first batches come off the device meanwhile
+    std::atomic<uint64_t> backed{0};
+    struct Joiner { std::thread th; ~Joiner() { if (th.joinable()) th.join(); } } falloc;
+    if (map) falloc.th = std::thread([&backed, fd, pos, total]() {
+        constexpr uint64_t STEP = 256ull << 20;
+        for (uint64_t o = 0; o < total; o += STEP) {
+            (void)posix_fallocate(fd, pos + (off_t)o, (off_t)std::min(STEP, total - o));      // on failure the page faults do the allocation
+        }
+        backed.store(~0ull, std::memory_order_release);
+    });
+    const size_t cap = std::max<size_t>(max_rec, map ? (32u << 20) : (64u << 20));
+    auto knob = [](const char *name, int dflt) { const char *e = getenv(name); const int v = e ? atoi(e) : 0; return v > 0 ? v : dflt; };
+    const int NB = map ? std::min(6, knob("SKX_FASTA_NB", 4)) : (regular && !append && pos >= 0 ? 6 : 2);
+    const int KT = map ? knob("SKX_FASTA_KT", 4) : 1;                   // copier threads per batch (mapped output)
+
     std::atomic<bool> ok{true};                 // declared before the slots: their destructors join writers that store to it
-    struct Slot { char *p = nullptr; std::thread th; ~Slot() { if (th.joinable()) th.join(); if (p) (void)hipHostFree(p); } } slot[6];
-    for (int b = 0; b < NB; b++) if (hipHostMalloc((void **)&slot[b].p, cap, hipHostMallocDefault) != hipSuccess) { slot[b].p = nullptr; set_error("out of host memory"); return SKX_ENOMEM; }
+    struct Slot { char *p = nullptr; std::vector<std::thread> th; void join() { for (auto &t : th) if (t.joinable()) t.join(); th.clear(); }
+                  ~Slot() { join(); if (p) (void)hipHostFree(p); } } slot[6];
+    { PhaseTimer t_pin("fasta.pinned_buffers");
+      for (int b = 0; b < NB; b++) if (hipHostMalloc((void **)&slot[b].p, cap, hipHostMallocDefault) != hipSuccess) { slot[b].p = nullptr; set_error("out of host memory"); return SKX_ENOMEM; } }
     int cur = 0, last = -1;
+    double t_join = 0, t_d2h = 0;
+    auto clk = [] { return std::chrono::steady_clock::now(); };
+    auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    uint64_t done = 0;                          // bytes of the alignment handed to writers so far
     for (size_t s = 0; s < S && ok;) {
         Slot &sl = slot[cur];
-        if (sl.th.joinable()) sl.th.join();
+        { const auto t0 = clk(); sl.join(); t_join += sec(t0, clk()); }
         char *buf = sl.p; size_t used = 0;
+        const auto t1 = clk();
         while (s < S && used + a->names[s].size() + U + 3 <= cap) {
             const std::string &nm = a->names[s];
             buf[used++] = '>'; memcpy(buf + used, nm.data(), nm.size()); used += nm.size(); buf[used++] = '\n';
@@ -1268,23 +1392,36 @@ extern "C" int skx_array_write_fasta(skx_array *a, int fd)
             s++;
         }
         SKX_HIP(hipStreamSynchronize(st));
-        if (NB == 2 && last >= 0 && slot[last].th.joinable()) slot[last].th.join();          // keep the order on a pipe
-        const off_t at = pos;
-        const bool positioned = NB > 2;
-        sl.th = std::thread([&ok, buf, used, fd, at, positioned]() {
-            size_t w = 0;
-            while (w < used) {
-                const ssize_t r = positioned ? pwrite(fd, buf + w, used - w, at + (off_t)w) : write(fd, buf + w, used - w);
-                if (r < 0 && errno == EINTR) continue;
-                if (r <= 0) { ok = false; return; }
-                w += (size_t)r;
+        t_d2h += sec(t1, clk());
+        if (map) {
+            uint8_t *dst = map + map_skew + done;
+            for (int t = 0; t < KT; t++) {
+                const size_t lo = used * (size_t)t / KT, hi = used * (size_t)(t + 1) / KT;
+                sl.th.emplace_back([dst, buf, lo, hi, &backed]() {
+                    while (backed.load(std::memory_order_acquire) != ~0ull) usleep(100);
+                    memcpy(dst + lo, buf + lo, hi - lo);
+                });
             }
-        });
-        pos += (off_t)used; last = cur; cur = (cur + 1) % NB;
+        } else {
+            if (NB == 2 && last >= 0) slot[last].join();                                     // keep the order on a pipe
+            const off_t at = pos + (off_t)done;
+            const bool positioned = NB > 2;
+            sl.th.emplace_back([&ok, buf, used, fd, at, positioned]() {
+                size_t w = 0;
+                while (w < used) {
+                    const ssize_t r = positioned ? pwrite(fd, buf + w, used - w, at + (off_t)w) : write(fd, buf + w, used - w);
+                    if (r < 0 && errno == EINTR) continue;
+                    if (r <= 0) { ok = false; return; }
+                    w += (size_t)r;
+                }
+            });
+        }
+        done += used; last = cur; cur = (cur + 1) % NB;
     }
-    for (int b = 0; b < NB; b++) if (slot[b].th.joinable()) slot[b].th.join();
+    { const auto t0 = clk(); for (int b = 0; b < NB; b++) slot[b].join(); t_join += sec(t0, clk()); }
+    phase_add("fasta.device_to_pinned", t_d2h); phase_add("fasta.wait_for_writers", t_join);
     if (!ok) { set_error("write failed"); return SKX_EIO; }
-    if (NB > 2) (void)lseek(fd, pos, SEEK_SET);
+    if (map || NB > 2) (void)lseek(fd, pos + (off_t)done, SEEK_SET);
     return SKX_OK;
     });
 }

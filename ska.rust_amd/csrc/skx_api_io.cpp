@@ -328,7 +328,7 @@ extern "C" int skx_array_load(skx_ctx *ctx, const char *path, int want_bits, skx
         S = cols;
         if (S == 0 || S > 65535) { set_error("skf: unsupported number of samples"); return SKX_EFORMAT; }
         a->n_rows = U; a->pitch = pitch_for(U);
-        SKX_TRY(a->matrix.alloc(S * a->pitch));
+        { PhaseTimer t_al("load.matrix_alloc"); SKX_TRY(a->matrix.alloc(S * a->pitch)); }
         SKX_HIP(hipMemsetAsync(a->matrix.p, '-', S * a->pitch, st));
         return SKX_OK;
     };

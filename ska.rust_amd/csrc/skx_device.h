@@ -198,6 +198,11 @@ void launch_assemble_wide(const AssembleArgs &a, hipStream_t st);      // a.stag
 void launch_gather_keys_wide(const u128 *stage, uint32_t stride, const uint32_t *ncnt, const uint64_t *roff, int n_sub, u128 *out,
                              hipStream_t st);
 
+// ---- FASTA text -> record stream (skx_parse.hip): tiles of 16 KB; scratch per tile: 8 B summary, 8 B offset, 1 B kind
+uint64_t fasta_parse_tiles(uint64_t len);
+void launch_fasta_parse(const uint8_t *const *raw, const uint64_t *rawlen, uint8_t *const *out, uint64_t *outlen, const uint32_t *tile_file,
+                        const uint64_t *tile_base, uint64_t n_tiles, void *summary, uint64_t *tile_off, uint8_t *tile_kind, int n, hipStream_t st);
+
 // ---- row-set operations for `ska merge` / `ska weed` / `ska delete` (skx_setops.hip)
 void launch_lookup_rows(const uint64_t *words, uint64_t n, const uint64_t *sorted, uint64_t m, uint32_t *idx, hipStream_t st);
 void launch_member_flags(const uint32_t *idx, uint64_t n, int reverse, uint8_t *keep, hipStream_t st);

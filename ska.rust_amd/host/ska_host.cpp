@@ -489,7 +489,7 @@ extern "C" int skh_main(int argc, char **argv)
         const double mf = atof(a.get("--min-freq", a.get("-m", "0.9")).c_str());
         if (mf < 0 || mf > 1) return fail("Frequency must be between 0 and 1 (inclusive)");
         int fd = 1;                                                                                               // io_utils::set_ostream: stdout or -o
-        if (a.has("-o")) { fd = open(a.get("-o").c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644); if (fd < 0) return fail("cannot create output file"); }
+        if (a.has("-o")) { fd = open(a.get("-o").c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644)   /* read-write: the writer maps the file */; if (fd < 0) return fail("cannot create output file"); }
         if (skh_load_array(ctx, in.data(), (int)in.size(), threads, &arr) != SKX_OK ||
             skh_align_fd(arr, filter, a.has("--ambig-mask"), a.has("--no-gap-only-sites"), mf, a.has("--filter-ambig-as-missing"), fd) != SKX_OK)
             rcode = engine_fail();
