@@ -6,6 +6,8 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <deque>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -389,6 +391,25 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
     if (proportion_reads > 0.0) { step = (size_t)std::llround(1.0 / proportion_reads); if (step == 0) step = 1; }
     const bool device_parse = step == 1 && !getenv("SKX_HOST_PARSE");
     const auto t_read0 = std::chrono::steady_clock::now();
+    const int nt = std::max(1, std::min({threads, n, 32}));      // 5 GB of FASTA text: 0.43 / 0.24 / 0.24 / 0.32 s with 8 / 16 / 32 / 64 readers (tools/read_knobs.py)
+    // Raw path plumbing: reader threads make no HIP calls at all (creating a stream or a pinned buffer per thread serialises in
+    // the runtime: 64 threads spent 0.28 s each waiting for theirs).  They read() file pieces into the slots of ONE pinned ring;
+    // a single uploader issues the copies on one stream and recycles the slots.  The ring is pinned by a helper thread while
+    // this one sizes and allocates the device buffers.
+    constexpr size_t SLOT = 8u << 20;
+    const int n_slots = std::max(4, std::min(2 * nt, 32));
+    struct Ring {
+        uint8_t *base = nullptr; std::mutex mu; std::condition_variable cv_free, cv_work;
+        std::vector<int> free_slots; struct Req { int slot; uint8_t *dst; size_t bytes; }; std::deque<Req> work; int readers_left = 0; bool failed = false;
+        ~Ring() { if (base) (void)hipHostFree(base); }
+    } ring;
+    std::thread pin_thread;
+    std::atomic<int> pin_rc{-1};
+    if (device_parse) pin_thread = std::thread([&]() {
+        (void)hipSetDevice(ctx->device);
+        pin_rc = hipHostMalloc((void **)&ring.base, (size_t)n_slots * SLOT, hipHostMallocDefault) == hipSuccess ? 0 : 1;
+    });
+    struct JoinPin { std::thread &t; ~JoinPin() { if (t.joinable()) t.join(); } } join_pin{pin_thread};
     // one device buffer for all raw texts and one for all record streams (a slot per single-file sample, sized from stat):
     // two allocations whatever the number of samples
     DevBuf<uint8_t> raw_all, out_all;
@@ -401,35 +422,78 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
             tot += slot_len[i];
         }
         if (tot) { SKX_HIP(hipSetDevice(ctx->device)); SKX_TRY(raw_all.alloc(tot)); SKX_TRY(out_all.alloc(tot)); }
+        pin_thread.join();
+        phase_add("build.alloc_text_pin_ring", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_read0).count());
+        if (pin_rc != 0) { ring.base = nullptr; }                                 // no pinned memory: every sample takes the host reader
+        else for (int b = 0; b < n_slots; b++) ring.free_slots.push_back(b);
     }
-    int nt = std::max(1, std::min(threads, n));
+    const bool raw_ok = device_parse && ring.base && raw_all.p;
+    ring.readers_left = nt;
+    // uploader: copies queued pieces on one stream, a batch at a time, and returns their slots
+    std::vector<std::thread> uploaders;
+    const int n_up = getenv("SKX_UPLOADERS") ? std::max(1, atoi(getenv("SKX_UPLOADERS"))) : 2;      // two streams keep both copy engines busy
+    if (raw_ok) for (int u = 0; u < n_up; u++) uploaders.emplace_back([&]() {
+        (void)hipSetDevice(ctx->device);
+        hipStream_t up = nullptr;
+        if (hipStreamCreateWithFlags(&up, hipStreamNonBlocking) != hipSuccess) up = nullptr;
+        std::vector<Ring::Req> batch;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(ring.mu);
+                ring.cv_work.wait(lk, [&] { return !ring.work.empty() || ring.readers_left == 0; });
+                if (ring.work.empty() && ring.readers_left == 0) break;
+                const size_t take = std::max<size_t>(1, ring.work.size() / 2);          // leave work for the other uploader
+                batch.assign(ring.work.begin(), ring.work.begin() + (ptrdiff_t)take); ring.work.erase(ring.work.begin(), ring.work.begin() + (ptrdiff_t)take);
+            }
+            bool bad = false;
+            for (auto &r : batch) bad |= hipMemcpyAsync(r.dst, ring.base + (size_t)r.slot * SLOT, r.bytes, hipMemcpyHostToDevice, up) != hipSuccess;
+            bad |= hipStreamSynchronize(up) != hipSuccess;
+            {
+                std::lock_guard<std::mutex> lk(ring.mu);
+                if (bad) ring.failed = true;
+                for (auto &r : batch) ring.free_slots.push_back(r.slot);
+            }
+            ring.cv_free.notify_all();
+        }
+        if (up) (void)hipStreamDestroy(up);
+    });
     std::vector<std::thread> pool;
     std::atomic<int> next{0};
-    constexpr size_t PIN = 8u << 20;
     for (int t = 0; t < nt; t++)
         pool.emplace_back([&]() {
-            (void)hipSetDevice(ctx->device);
-            hipStream_t up_st = nullptr;
-            if (hipStreamCreateWithFlags(&up_st, hipStreamNonBlocking) != hipSuccess) up_st = nullptr;
-            struct Drop { hipStream_t s; uint8_t *pin; ~Drop() { if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } if (pin) (void)hipHostFree(pin); } } drop{up_st, nullptr};
+            struct Leave { Ring &r; ~Leave() { { std::lock_guard<std::mutex> lk(r.mu); r.readers_left--; } r.cv_work.notify_all(); } } leave{ring};
+            hipStream_t up_st = nullptr;                                             // host-reader path only, created on first use
+            struct Drop { hipStream_t &s; ~Drop() { if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } } } drop{up_st};
             // raw upload of a plain FASTA file: SKX_OK (taken), SKF_NOT_TAKEN (use the host reader), or an error
             auto raw_upload = [&](int i) -> int {
                 if (!slot_len[i]) return SKF_NOT_TAKEN;
                 const int fd = ::open(file1[i], O_RDONLY);
                 if (fd < 0) return SKF_NOT_TAKEN;                                    // the host reader reports it
                 struct Close { int fd; ~Close() { ::close(fd); } } cl{fd};
-                if (!drop.pin && hipHostMalloc((void **)&drop.pin, PIN, hipHostMallocDefault) != hipSuccess) { drop.pin = nullptr; set_error("out of host memory"); return SKX_ENOMEM; }
                 const uint64_t cap = slot_len[i] - 64;                               // the size stat reported
                 uint8_t *dst = raw_all.p + slot_off[i];
                 uint64_t off = 0;
                 while (off < cap) {
-                    const size_t want = (size_t)std::min<uint64_t>(PIN, cap - off);
+                    int slot;
+                    {
+                        std::unique_lock<std::mutex> lk(ring.mu);
+                        ring.cv_free.wait(lk, [&] { return !ring.free_slots.empty() || ring.failed; });
+                        if (ring.failed) { set_error("upload of the sequence files failed"); return SKX_ENODEV; }
+                        slot = ring.free_slots.back(); ring.free_slots.pop_back();
+                    }
+                    uint8_t *buf = ring.base + (size_t)slot * SLOT;
+                    const size_t want = (size_t)std::min<uint64_t>(SLOT, cap - off);
                     size_t got = 0;
-                    while (got < want) { const ssize_t r = read(fd, drop.pin + got, want - got); if (r < 0 && errno == EINTR) continue; if (r <= 0) break; got += (size_t)r; }
-                    if (got == 0) break;                                               // the file shrank under us: what was read is the file
-                    if (off == 0 && drop.pin[0] != '>') return SKF_NOT_TAKEN;          // FASTQ ('@'), gzip (1f 8b), anything else: the host reader's
-                    SKX_HIP(hipMemcpyAsync(dst + off, drop.pin, got, hipMemcpyHostToDevice, up_st));
-                    SKX_HIP(hipStreamSynchronize(up_st));                              // the pinned buffer is reused; the copy is ~20x faster than the read
+                    while (got < want) { const ssize_t r = read(fd, buf + got, want - got); if (r < 0 && errno == EINTR) continue; if (r <= 0) break; got += (size_t)r; }
+                    const bool not_fasta = off == 0 && got && buf[0] != '>';         // FASTQ ('@'), gzip (1f 8b), anything else: the host reader's
+                    if (got == 0 || not_fasta) {
+                        { std::lock_guard<std::mutex> lk(ring.mu); ring.free_slots.push_back(slot); }
+                        ring.cv_free.notify_one();
+                        if (not_fasta) return SKF_NOT_TAKEN;
+                        break;                                                         // the file shrank under us: what was read is the file
+                    }
+                    { std::lock_guard<std::mutex> lk(ring.mu); ring.work.push_back({slot, dst + off, got}); }
+                    ring.cv_work.notify_one();
                     off += got;
                 }
                 if (off == 0) return SKF_NOT_TAKEN;
@@ -437,7 +501,7 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
                 return SKX_OK;
             };
             for (int i; (i = next.fetch_add(1)) < n;) {
-                if (device_parse && up_st) {
+                if (raw_ok) {
                     const int r = raw_upload(i);
                     if (r == SKX_OK) continue;
                     if (r != SKF_NOT_TAKEN) { rcodes[i] = r; errs[i] = skx_last_error(); continue; }
@@ -445,6 +509,7 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
                 HostStream h;
                 rcodes[i] = read_sample_stream(file1[i], file2 ? file2[i] : nullptr, proportion_reads, h);
                 if (rcodes[i] != SKX_OK) { errs[i] = skx_last_error(); continue; }
+                if (!up_st) { (void)hipSetDevice(ctx->device); if (hipStreamCreateWithFlags(&up_st, hipStreamNonBlocking) != hipSuccess) up_st = nullptr; }
                 const size_t len = h.seq.size();
                 auto up = [&](DevBuf<uint8_t> &dst, const std::vector<uint8_t> &src) -> int {
                     SKX_TRY(dst.alloc(len + 16));
@@ -458,7 +523,9 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
             }
         });
     for (auto &th : pool) th.join();
+    for (auto &u : uploaders) u.join();
     phase_add("build.read_upload", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_read0).count());
+    if (ring.failed) { set_error("upload of the sequence files failed"); return SKX_ENODEV; }
     for (int i = 0; i < n; i++) if (rcodes[i] != SKX_OK) { set_error("%s", errs[i].c_str()); return rcodes[i]; }
     // the raw FASTA texts -> record streams, all files in one set of launches
     {
