@@ -119,6 +119,16 @@ void skx_array_free(skx_array *a);
 /* save / load (merge_ska_array.rs:191-204): snappy-frame(CBOR), want_bits 64|128|0 */
 int  skx_array_save(skx_array *a, const char *path);
 int  skx_array_load(skx_ctx *ctx, const char *path, int want_bits, skx_array **out);
+/* load + filter in one pass over the file (the body of `ska align x.skf` and `ska distance x.skf`): the same array as
+ * skx_array_load followed by generic_modes::apply_filters (generic_modes.rs:112-131: threshold ceil(n_samples * min_freq),
+ * update_kmers = false), or -- two_stage != 0 -- by the two filters of generic_modes::distance (generic_modes.rs:149-168: NoFilter
+ * at ceil(n_samples * min_freq) when min_freq * n_samples >= 1, then NoConst at 0; *constant = rows the second one removed).
+ * Rows are filtered as they come off the decoder, so the unfiltered rows x samples matrix never exists on the device and the
+ * split k-mer list is not decoded (the resulting array has no keys: save / merge / weed / map on it fail with SKX_EINVAL).
+ * Files the one-pass reader does not take (k > 31, unusual field order, stored counts that differ from the rows) go through
+ * skx_array_load + skx_array_filter inside the call. */
+typedef struct { double min_freq; int32_t filter_ambig_as_missing, filter_type, mask_ambig, ignore_const_gaps, two_stage; } skx_filter_spec;
+int  skx_array_load_filtered(skx_ctx *ctx, const char *path, const skx_filter_spec *f, skx_array **out, int64_t *removed, int64_t *constant);
 /* construct from host data (row-major [n_rows, n_samples] as in the .skf) */
 int  skx_array_from_host(skx_ctx *ctx, int k, int rc, const char *const *names, int n_samples,
                          const skx_key *keys, const uint8_t *variants, const uint64_t *variant_count /* NULL: recount */,

@@ -19,6 +19,12 @@ int skh_align(skx_array *a, int filter_type, int mask_ambig, int ignore_const_ga
               int filter_ambig_as_missing, char **buf, uint64_t *len);
 int skh_align_fd(skx_array *a, int filter_type, int mask_ambig, int ignore_const_gaps, double min_freq,
                  int filter_ambig_as_missing, int fd);   /* the same, streamed to a file descriptor */
+/* `ska align <inputs>` (lib.rs:617-662 = io_utils::load_array + generic_modes::align): one .skf input goes through the engine's
+ * one-pass load + filter (skx_array_load_filtered), several sequence files through build_and_merge with the CLI defaults */
+int skh_align_inputs_fd(skx_ctx *ctx, const char *const *inputs, int n_inputs, int threads, int filter_type, int mask_ambig, int ignore_const_gaps,
+                        double min_freq, int filter_ambig_as_missing, int fd);
+/* `ska distance <skf>` (lib.rs:710-727 = load + generic_modes::distance), same one-pass load */
+int skh_distance_skf_tsv(skx_ctx *ctx, const char *skf_file, double min_freq, int filt_ambig, char **buf, uint64_t *len);
 /* generic_modes::distance (generic_modes.rs:136-189): two-stage filter, then the long-form TSV with the
  * VariantDist Display format "{:.2}\t{:.5}\t{}\t{}" (merge_ska_array.rs:57-65) */
 int skh_distance_tsv(skx_array *a, double min_freq, int filt_ambig, char **buf, uint64_t *len);

@@ -248,7 +248,7 @@ struct Mapped {
         struct stat sb;
         if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { ::close(fd); return false; }
         n = (size_t)sb.st_size;
-        if (n) { void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0); if (m == MAP_FAILED) { ::close(fd); n = 0; return false; } p = (const uint8_t *)m; }
+        if (n) { void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);   /* one call maps every page: the chunk walk below touches them all */ if (m == MAP_FAILED) { ::close(fd); n = 0; return false; } p = (const uint8_t *)m; }
         ::close(fd);
         return true;
     }
@@ -305,6 +305,7 @@ struct FrameReader {
     void consume(size_t n) { pos += n; }
     // make at least `need` bytes available (fewer only at end of stream); decodes up to one super-block more
     double fill_secs = 0;
+    size_t fill_limit = 0;                          // decoded bytes per fill (0: one super-block); small when only a header is wanted
     bool fill(size_t need)
     {
         const auto t_f0 = std::chrono::steady_clock::now();
@@ -312,7 +313,8 @@ struct FrameReader {
         while (avail() < need && next_chunk < chunks.size()) {
             if (pos) { buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)pos); ubase += pos; pos = 0; }
             size_t last = next_chunk, add = 0;
-            while (last < chunks.size() && add < SUPER) add += chunks[last++].ulen;
+            const size_t lim = fill_limit ? std::max(fill_limit, need) : SUPER;
+            while (last < chunks.size() && add < lim) add += chunks[last++].ulen;
             const size_t base = buf.size();
             buf.resize(base + add);
             std::vector<size_t> at(last - next_chunk);
@@ -532,6 +534,91 @@ int skf_read_stream(const char *path, SkfMeta &m, std::vector<skx_key> &keys, st
         else rd.ok = false;
     }
     if (!rd.ok || !have_var || dim1 != m.names.size()) { set_error("%s", fr.err ? fr.err : "skf: CBOR decode failed"); return SKX_EFORMAT; }
+    return SKX_OK;
+}
+
+// ---------------------------------------------------------------- layout-only open (the streaming load of `ska align x.skf`)
+struct SkfFile::Impl { FrameReader fr; };
+SkfFile::SkfFile() : impl(new Impl()) {}
+SkfFile::~SkfFile() { delete impl; }
+const uint8_t *SkfFile::file() const { return impl->fr.raw.data(); }
+const SkfChunk *SkfFile::chunks() const { return impl->fr.chunks.data(); }
+size_t SkfFile::n_chunks() const { return impl->fr.chunks.size(); }
+// Header, then the split k-mer list is stepped over without being decoded: it is U uints, 9 bytes each unless a key is below
+// 2^32 (then the bytes at +9U are not the "variants" field and the caller takes the general reader).
+int SkfFile::open(const char *path)
+{
+    FrameReader &fr = impl->fr;
+    PhaseTimer t_open("load.map_file_chunk_directory");
+    const bool opened = fr.open(path, n_workers(0));
+    t_open.stop();
+    if (!opened) {
+        if (fr.err && !strcmp(fr.err, "open")) { set_error("cannot open %s", path); return SKX_EIO; }
+        set_error("%s", fr.err ? fr.err : "skf: read failed"); return SKX_EFORMAT;
+    }
+    PhaseTimer t_hdr("load.header");
+    fr.fill_limit = 1u << 20;
+    Reader rd(fr);
+    int mj; uint64_t nf = 0;
+    if (!rd.head(mj, nf) || mj != 5 || nf != 8) return SKF_NOT_TAKEN;
+    if (rd.text() != "k") return SKF_NOT_TAKEN;
+    m.k = (int)rd.uint();
+    if (rd.text() != "rc") return SKF_NOT_TAKEN;
+    m.rc = rd.boolean();
+    if (rd.text() != "names") return SKF_NOT_TAKEN;
+    { const uint64_t n = rd.array(); if (!rd.ok || n > 65535) return SKF_NOT_TAKEN; for (uint64_t j = 0; j < n && rd.ok; j++) m.names.push_back(rd.text()); }
+    if (!rd.ok || rd.text() != "split_kmers") return SKF_NOT_TAKEN;
+    n_keys = rd.array();
+    if (!rd.ok || n_keys > (1ull << 40)) return SKF_NOT_TAKEN;
+    upos_keys = fr.upos();
+    if (!fr.seek(upos_keys + 9 * n_keys)) return SKF_NOT_TAKEN;
+    rd.ok = true;
+    if (rd.text() != "variants" || !rd.ok) return SKF_NOT_TAKEN;
+    uint64_t n3 = 0;
+    if (!rd.head(mj, n3) || mj != 5 || n3 != 3) return SKF_NOT_TAKEN;
+    if (rd.text() != "v") return SKF_NOT_TAKEN;
+    rd.uint();
+    if (rd.text() != "dim" || rd.array() != 2) return SKF_NOT_TAKEN;
+    const uint64_t d0 = rd.uint(), d1 = rd.uint();
+    if (rd.text() != "data") return SKF_NOT_TAKEN;
+    const uint64_t nd = rd.array();
+    if (!rd.ok || d0 != n_keys || d1 != m.names.size() || nd != d0 * d1) return SKF_NOT_TAKEN;
+    m.n_rows = d0;
+    upos_data = fr.upos();
+    if (upos_data + 2 * nd > fr.total_ulen) return SKF_NOT_TAKEN;
+    return SKX_OK;
+}
+// what follows the data section: variant_count, ska_version, k_bits
+int SkfFile::read_tail(std::vector<uint32_t> &counts)
+{
+    FrameReader &fr = impl->fr;
+    PhaseTimer t("load.variant_counts");
+    fr.fill_limit = 0;
+    if (!fr.seek(upos_data + 2 * m.n_rows * (uint64_t)m.names.size())) { set_error("skf: CBOR decode failed"); return SKX_EFORMAT; }
+    Reader rd(fr);
+    if (rd.text() != "variant_count") { set_error("skf: CBOR decode failed"); return SKX_EFORMAT; }
+    const uint64_t n = rd.array();
+    if (!rd.ok || n != m.n_rows) { set_error("skf: CBOR decode failed"); return SKX_EFORMAT; }
+    counts.resize(n);
+    // 1 to 3 bytes per count while the samples number below 65 536: straight from the decoded bytes when a run is fully buffered
+    uint64_t j = 0;
+    while (j < n && rd.ok) {
+        const uint8_t *p = fr.data(); const size_t av = fr.avail(); size_t o = 0;
+        while (j < n && o + 3 <= av) {
+            const uint8_t c = p[o];
+            if (c < 24) { counts[j++] = c; o += 1; }
+            else if (c == 24) { counts[j++] = p[o + 1]; o += 2; }
+            else if (c == 25) { counts[j++] = ((uint32_t)p[o + 1] << 8) | p[o + 2]; o += 3; }
+            else break;
+        }
+        fr.consume(o);
+        if (j < n) { const uint64_t v = rd.uint(); if (v > 0xFFFFFFFFull) rd.ok = false; counts[j++] = (uint32_t)v; }
+    }
+    if (!rd.ok || rd.text() != "ska_version") { set_error("skf: CBOR decode failed"); return SKX_EFORMAT; }
+    m.version = rd.text();
+    if (!rd.ok || rd.text() != "k_bits") { set_error("skf: CBOR decode failed"); return SKX_EFORMAT; }
+    m.k_bits = (int)rd.uint();
+    if (!rd.ok) { set_error("skf: CBOR decode failed"); return SKX_EFORMAT; }
     return SKX_OK;
 }
 

@@ -1029,6 +1029,7 @@ extern "C" int skx_array_from_host(skx_ctx *ctx, int k, int rc, const char *cons
 // split k-mers of an array as the reference stores them (hash undone), in the array's row order
 int skx::array_host_keys(skx_array *a, std::vector<skx_key> &hk)
 {
+    if (a->keys_absent) { set_error("this array was loaded without its split k-mers (skx_array_load_filtered)"); return SKX_EINVAL; }
     const uint64_t K = a->n_kmers;
     hk.assign(K, skx_key{0, 0});
     if (a->k <= 31) {
@@ -1231,7 +1232,7 @@ extern "C" int skx_array_merge(skx_ctx *ctx, skx_array *const *in, int n, skx_ar
     for (int i = 0; i < n; i++) {
         if (in[i]->k != in[0]->k) { set_error("K-mer lengths do not match: %d %d", in[i]->k, in[0]->k); return SKX_EINVAL; }     // merge_ska_dict.rs:169-171
         if (in[i]->rc != in[0]->rc) { set_error("Strand use inconsistent"); return SKX_EINVAL; }                                  // :172-174
-        if (in[i]->n_kmers != in[i]->n_rows) { set_error("split k-mers and variants are out of step (filtered without update_kmers)"); return SKX_EINVAL; }
+        if (in[i]->n_kmers != in[i]->n_rows || in[i]->keys_absent) { set_error("split k-mers and variants are out of step (filtered without update_kmers)"); return SKX_EINVAL; }
         tot += in[i]->n_rows; S += in[i]->names.size();
     }
     if (S > 65535) { set_error("more than 65535 samples per device array"); return SKX_EUNSUP; }
@@ -1299,7 +1300,7 @@ extern "C" int skx_array_delete_samples(skx_array *a, const char *const *del_nam
     SKX_HIP(hipSetDevice(ctx->device));
     const size_t S = a->names.size();
     if (n_del <= 0 || (size_t)n_del == S) { set_error("Invalid number of samples to remove"); return SKX_EINVAL; }                // merge_ska_array.rs:232-234
-    if (a->n_kmers != a->n_rows) { set_error("split k-mers and variants are out of step (filtered without update_kmers)"); return SKX_EINVAL; }
+    if (a->n_kmers != a->n_rows || a->keys_absent) { set_error("split k-mers and variants are out of step (filtered without update_kmers)"); return SKX_EINVAL; }
     // the request is a set of names; each must match a column (first match wins, :243-249)
     std::vector<std::string> want;
     for (int d = 0; d < n_del; d++) if (std::find(want.begin(), want.end(), del_names[d]) == want.end()) want.emplace_back(del_names[d]);
@@ -1339,7 +1340,7 @@ extern "C" int skx_array_weed(skx_array *a, skx_keyset *weed, int reverse, uint6
     SKX_HIP(hipSetDevice(ctx->device));
     if (weed->k != a->k) { set_error("K-mer lengths do not match: %d %d", weed->k, a->k); return SKX_EINVAL; }
     if (weed->rc != a->rc) { set_error("Strand use inconsistent"); return SKX_EINVAL; }
-    if (a->n_kmers != a->n_rows) { set_error("split k-mers and variants are out of step (filtered without update_kmers)"); return SKX_EINVAL; }
+    if (a->n_kmers != a->n_rows || a->keys_absent) { set_error("split k-mers and variants are out of step (filtered without update_kmers)"); return SKX_EINVAL; }
     const uint64_t U = a->n_rows;
     if (weed->logN >= 0) SKX_TRY(keyset_flatten(weed));
     DevBuf<uint8_t> keep; SKX_TRY(keep.alloc(U));

@@ -55,7 +55,7 @@ extern "C" int skx_array_map(skx_array *a, const char *reference, int ambig_mask
     skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
     SKX_HIP(hipSetDevice(ctx->device));
     const int k = a->k, h = (k - 1) / 2, S = (int)a->names.size();
-    if (a->n_kmers != a->n_rows) { set_error("split k-mers and variants are out of step (filtered without update_kmers)"); return SKX_EINVAL; }
+    if (a->n_kmers != a->n_rows || a->keys_absent) { set_error("split k-mers and variants are out of step (filtered without update_kmers)"); return SKX_EINVAL; }
     HostStream hs;
     SKX_TRY(read_sample_stream(reference, nullptr, 0.0, hs));
     if (hs.is_fastq) { set_error("Cannot create reference from FASTQ files"); return SKX_EINVAL; }                                // ska_ref.rs:206-208
@@ -244,7 +244,7 @@ extern "C" int skx_array_save(skx_array *a, const char *path)
     skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
     SKX_HIP(hipSetDevice(ctx->device));
     const uint64_t U = a->n_rows, S = a->names.size();
-    if (a->n_kmers != a->n_rows) { set_error("split k-mers and variants are out of step (filtered without update_kmers): such an array cannot be loaded back"); return SKX_EINVAL; }
+    if (a->n_kmers != a->n_rows || a->keys_absent) { set_error("split k-mers and variants are out of step (filtered without update_kmers): such an array cannot be loaded back"); return SKX_EINVAL; }
     SkfMeta m; m.k = a->k; m.rc = a->rc; m.k_bits = a->k_bits; m.names = a->names; m.version = a->version; m.n_rows = U;
     std::vector<skx_key> keys;
     const auto t_k0 = std::chrono::steady_clock::now();
@@ -429,6 +429,174 @@ extern "C" int skx_array_load(skx_ctx *ctx, const char *path, int want_bits, skx
     SKX_HIP(hipStreamSynchronize(st));
     SKX_HIP(hipGetLastError());
     if (bad) { set_error("variants contain a byte outside -ACGTMRWSYKVHDBN (not supported on the device path)"); return SKX_EUNSUP; }
+    *out = a.release();
+    return SKX_OK;
+    });
+}
+
+// ------------------------------------------------------------------------------------------ load + filter in one pass
+// `ska align x.skf` / `ska distance x.skf` (generic_modes.rs:22-50,136-189 on io_utils::load_array's single-file branch).  The
+// general form -- skx_array_load, then the filter(s) -- holds the unfiltered rows x samples matrix (22.6 GB for 1 000 x 5 Mbp) only
+// to drop four fifths of its rows.  Here each group of rows leaves the decoder row-major, gets its statistics and its filter
+// verdict, and only the kept rows are transposed into the (small) sample-major matrix.  The filter's min_count test reads the
+// file's variant_count, which is stored AFTER the matrix: the pass runs on the count the rows imply (what every writer stores)
+// while a host thread parses the stored list, and a mismatch sends the file through the general path instead.
+static int load_then_filter(skx_ctx *ctx, const char *path, const skx_filter_spec *f, skx_array **out, int64_t *removed, int64_t *constant)
+{
+    skx_array *a = nullptr;
+    int r = skx_array_load(ctx, path, 64, &a);
+    if (r == SKX_EFORMAT) r = skx_array_load(ctx, path, 128, &a);
+    if (r != SKX_OK) return r;
+    const uint64_t S = a->names.size();
+    int32_t rem = 0, cst = 0;
+    if (f->two_stage) {
+        if (f->min_freq * (double)S >= 1.0) r = skx_array_filter(a, (uint64_t)std::ceil((double)S * f->min_freq), 0, SKX_FILTER_NONE, 0, 0, 0, &rem);
+        if (r == SKX_OK) r = skx_array_filter(a, 0, 0, SKX_FILTER_NO_CONST, 0, 0, 0, &cst);
+    } else
+        r = skx_array_filter(a, (uint64_t)std::ceil((double)S * f->min_freq), f->filter_ambig_as_missing, f->filter_type, f->mask_ambig, f->ignore_const_gaps, 0, &rem);
+    if (r != SKX_OK) { skx_array_free(a); return r; }
+    if (removed) *removed = rem;
+    if (constant) *constant = cst;
+    *out = a;
+    return SKX_OK;
+}
+
+extern "C" int skx_array_load_filtered(skx_ctx *ctx, const char *path, const skx_filter_spec *f, skx_array **out, int64_t *removed, int64_t *constant)
+{
+    return skx_guarded([&]() -> int {
+    if (!ctx || !path || !f || !out) { set_error("bad arguments"); return SKX_EINVAL; }
+    if (getenv("SKX_NO_STREAM_LOAD")) return load_then_filter(ctx, path, f, out, removed, constant);
+    SKX_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    SkfFile sf;
+    {
+        const int r = sf.open(path);
+        if (r == SKF_NOT_TAKEN) return load_then_filter(ctx, path, f, out, removed, constant);
+        if (r != SKX_OK) return r;
+    }
+    const uint64_t U = sf.m.n_rows, S = sf.m.names.size();
+    if (!U || !S || sf.m.k > 31) return load_then_filter(ctx, path, f, out, removed, constant);
+    SKX_TRY(check_k(sf.m.k));
+    // the stored counts, parsed beside the device work
+    std::vector<uint32_t> counts; int tail_rc = SKX_OK; std::string tail_err;
+    std::thread tail([&]() { tail_rc = sf.read_tail(counts); if (tail_rc != SKX_OK) tail_err = skx_last_error(); });
+    struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join_tail{tail};
+
+    const uint64_t upos = sf.upos_data, uend = upos + 2 * U * S, G = skf_group_chunks();
+    const SkfChunk *ch = sf.chunks(); const size_t nch = sf.n_chunks(); const uint8_t *file = sf.file();
+    size_t c0 = 0, c1 = nch;
+    { size_t lo = 0, hi = nch; while (lo < hi) { const size_t mid = (lo + hi) / 2; if (ch[mid].uoff + ch[mid].ulen <= upos) lo = mid + 1; else hi = mid; } c0 = lo; }
+    { size_t lo = c0, hi = nch; while (lo < hi) { const size_t mid = (lo + hi) / 2; if (ch[mid].uoff < uend) lo = mid + 1; else hi = mid; } c1 = lo; }
+    if (c0 >= c1) return load_then_filter(ctx, path, f, out, removed, constant);
+
+    std::unique_ptr<skx_array> a(new skx_array());
+    a->ctx = ctx; a->k = sf.m.k; a->rc = sf.m.rc; a->hp = make_hash_params(std::min(sf.m.k, 31)); a->wh = make_wide_hash(sf.m.k);
+    a->names = sf.m.names; a->engine_order = false; a->keys_absent = true; a->n_kmers = U;
+    const uint64_t thr = f->two_stage ? (f->min_freq * (double)S >= 1.0 ? (uint64_t)std::ceil((double)S * f->min_freq) : 0) : (uint64_t)std::ceil((double)S * f->min_freq);
+
+    PhaseTimer t_data("load.stream_decode_filter");
+    DevBuf<uint8_t> d_src, d_cells[2], d_scratch, keep; DevBuf<SnapChunk> d_chunks; DevBuf<int> d_status, d_bad;
+    DevBuf<uint32_t> present, unambig, mask, sc_sums; DevBuf<uint64_t> pos, sc_offs;
+    const uint64_t gmax = std::min<uint64_t>(G, c1 - c0);
+    SKX_TRY(d_scratch.alloc(gmax * 65536ull + 16));
+    SKX_TRY(d_status.alloc(1)); SKX_TRY(d_status.zero(st)); SKX_TRY(d_bad.alloc(1)); SKX_TRY(d_bad.zero(st));
+    const uint64_t cells_cap = gmax * 32768ull + S + 64, rows_cap = gmax * 32768ull / S + 2;
+    SKX_TRY(d_cells[0].alloc(cells_cap)); SKX_TRY(d_cells[1].alloc(cells_cap)); SKX_TRY(d_chunks.alloc(gmax));
+    SKX_TRY(present.alloc(U)); SKX_TRY(unambig.alloc(U)); SKX_TRY(mask.alloc(U)); SKX_TRY(keep.alloc(U));
+    SKX_TRY(pos.alloc(rows_cap + 1)); SKX_TRY(sc_sums.alloc(scan_u8_blocks(rows_cap) + 1)); SKX_TRY(sc_offs.alloc(scan_u8_blocks(rows_cap) + 2));
+    // kept rows: capacity grows when a file keeps more than the first guess (a quarter of its rows)
+    uint64_t cap = pitch_for(std::max<uint64_t>(U / 4, 1024)), kept = 0;
+    SKX_TRY(a->matrix.alloc(S * cap));
+    std::vector<SnapChunk> tab;
+    uint64_t src_cap = 0, row_lo = 0, have_hi = 0;
+    int cur = 0;
+    for (size_t g0 = c0; g0 < c1; g0 += G) {
+        const size_t g1 = std::min<size_t>(c1, g0 + G);
+        const size_t f_lo = ch[g0].off, f_hi = ch[g1 - 1].off + ch[g1 - 1].len;
+        if (f_hi - f_lo + 512 > src_cap) { src_cap = f_hi - f_lo + 512; SKX_TRY(d_src.alloc(src_cap)); }
+        tab.resize(g1 - g0);
+        for (size_t c = g0; c < g1; c++) tab[c - g0] = SnapChunk{ch[c].off - f_lo, ch[c].uoff, (uint32_t)ch[c].len, ch[c].ulen, ch[c].crc, ch[c].compressed ? 1u : 0u};
+        SKX_HIP(hipMemcpyAsync(d_src.p, file + f_lo, f_hi - f_lo, hipMemcpyHostToDevice, st));
+        SKX_HIP(hipMemcpyAsync(d_chunks.p, tab.data(), tab.size() * sizeof(SnapChunk), hipMemcpyHostToDevice, st));
+        const uint64_t base_cell = (row_lo * S) & ~7ull;
+        SKX_TRY(launch_skf_decode_cells(ctx->device, d_src.p, d_chunks.p, (uint32_t)(g1 - g0), upos, uend, d_scratch.p, d_cells[cur].p, base_cell, d_status.p, st));
+        const uint64_t s_hi = std::min(ch[g1 - 1].uoff + ch[g1 - 1].ulen, uend);
+        have_hi = (s_hi - upos) >> 1;
+        const uint64_t row_done = g1 == c1 ? U : have_hi / S;
+        const uint8_t *in = d_cells[cur].p + (row_lo * S - base_cell);
+        const uint64_t nr = row_done - row_lo;
+        uint64_t gk = 0;
+        if (nr) {
+            launch_row_stats_rm(in, S, nr, present.p + row_lo, unambig.p + row_lo, mask.p + row_lo, d_bad.p, st);
+            FilterArgs fa{present.p + row_lo, present.p + row_lo, unambig.p + row_lo, mask.p + row_lo, nr, (uint32_t)S, thr, f->two_stage ? 0 : f->filter_ambig_as_missing,
+                          f->two_stage ? SKX_FILTER_NO_CONST : f->filter_type, f->two_stage ? 0 : f->ignore_const_gaps, keep.p + row_lo, f->two_stage};
+            launch_filter_flags(fa, st);
+            launch_scan_u8(keep.p + row_lo, pos.p, nr, sc_sums.p, sc_offs.p, st);
+            SKX_HIP(hipMemcpyAsync(&gk, pos.p + nr, 8, hipMemcpyDeviceToHost, st));
+        }
+        if (g1 < c1) {                                                                      // the unfinished row moves to the other buffer
+            const uint64_t nb = (row_done * S) & ~7ull, left = have_hi - row_done * S;
+            if (left) SKX_HIP(hipMemcpyAsync(d_cells[cur ^ 1].p + (row_done * S - nb), d_cells[cur].p + (row_done * S - base_cell), left, hipMemcpyDeviceToDevice, st));
+        }
+        SKX_HIP(hipStreamSynchronize(st));                                                   // gk; tab / d_src are reused
+        if (kept + gk > cap - 256) {                                                        // more rows survive than guessed: a wider matrix
+            const uint64_t ncap = pitch_for(std::max((kept + gk) * 2, cap * 2));
+            DevBuf<uint8_t> nm; SKX_TRY(nm.alloc(S * ncap));
+            if (kept) SKX_HIP(hipMemcpy2DAsync(nm.p, ncap, a->matrix.p, cap, kept, S, hipMemcpyDeviceToDevice, st));
+            SKX_HIP(hipStreamSynchronize(st));
+            a->matrix = std::move(nm); cap = ncap;
+        }
+        if (gk) launch_compact_rm(in, S, nr, keep.p + row_lo, pos.p, a->matrix.p, cap, kept, f->two_stage ? 0 : f->mask_ambig, st);
+        kept += gk;
+        row_lo = row_done; cur ^= 1;
+    }
+    int status = 0, bad = 0;
+    SKX_HIP(hipMemcpyAsync(&status, d_status.p, 4, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipStreamSynchronize(st));
+    SKX_HIP(hipGetLastError());
+    t_data.stop();
+    if (status == 3) { tail.join(); a.reset(); return load_then_filter(ctx, path, f, out, removed, constant); }    // cells that are not (0x18, byte)
+    if (status) { set_error(status == 2 ? "skf: checksum mismatch" : "skf: corrupt snappy block"); return SKX_EFORMAT; }
+    if (bad) { set_error("variants contain a byte outside -ACGTMRWSYKVHDBN (not supported on the device path)"); return SKX_EUNSUP; }
+    // the stored counts: must be what the rows imply for the verdicts above to stand
+    tail.join();
+    if (tail_rc != SKX_OK) { set_error("%s", tail_err.c_str()); return tail_rc; }
+    PhaseTimer t_fin("load.counts_check_statistics");
+    DevBuf<uint32_t> d_counts; SKX_TRY(d_counts.alloc(U));
+    SKX_HIP(hipMemcpyAsync(d_counts.p, counts.data(), U * 4, hipMemcpyHostToDevice, st));
+    if (!(f->filter_ambig_as_missing && !f->two_stage)) {                                   // update_counts(true) ignores the stored counts
+        SKX_TRY(d_status.zero(st));
+        launch_differ_u32(d_counts.p, present.p, U, d_status.p, st);
+        int differ = 0;
+        SKX_HIP(hipMemcpyAsync(&differ, d_status.p, 4, hipMemcpyDeviceToHost, st));
+        SKX_HIP(hipStreamSynchronize(st));
+        if (differ) { a.reset(); return load_then_filter(ctx, path, f, out, removed, constant); }
+    }
+    // statistics of the kept rows, in row order
+    unsigned long long n_silent = 0, n_const = 0;
+    {
+        DevBuf<unsigned long long> d_cnt; SKX_TRY(d_cnt.alloc(2)); SKX_TRY(d_cnt.zero(st));
+        launch_count_u8(keep.p, U, 2, d_cnt.p, st); launch_count_u8(keep.p, U, 3, d_cnt.p + 1, st);
+        unsigned long long h[2] = {0, 0};
+        SKX_HIP(hipMemcpyAsync(h, d_cnt.p, 16, hipMemcpyDeviceToHost, st));
+        DevBuf<uint64_t> gpos; DevBuf<uint32_t> s2; DevBuf<uint64_t> o2;
+        SKX_TRY(gpos.alloc(U + 1)); SKX_TRY(s2.alloc(scan_u8_blocks(U) + 1)); SKX_TRY(o2.alloc(scan_u8_blocks(U) + 2));
+        launch_scan_u8(keep.p, gpos.p, U, s2.p, o2.p, st);
+        SKX_TRY(a->present.alloc(kept)); SKX_TRY(a->unambig.alloc(kept)); SKX_TRY(a->mask.alloc(kept)); SKX_TRY(a->vcount.alloc(kept));
+        launch_compact_u32(present.p, a->present.p, U, keep.p, gpos.p, st);
+        launch_compact_u32(unambig.p, a->unambig.p, U, keep.p, gpos.p, st);
+        launch_compact_u32(mask.p, a->mask.p, U, keep.p, gpos.p, st);
+        launch_compact_u32((f->filter_ambig_as_missing && !f->two_stage) ? unambig.p : d_counts.p, a->vcount.p, U, keep.p, gpos.p, st);
+        if (f->mask_ambig && !f->two_stage) launch_mask_ambig_stats(a->mask.p, kept, st);
+        SKX_HIP(hipStreamSynchronize(st));
+        n_silent = h[0]; n_const = h[1];
+    }
+    SKX_HIP(hipGetLastError());
+    a->k_bits = sf.m.k_bits; a->version = sf.m.version.empty() ? skx_version() : sf.m.version;
+    a->n_rows = kept; a->pitch = cap;
+    if (removed) *removed = (int64_t)(U - kept - n_silent - n_const);
+    if (constant) *constant = (int64_t)n_const;
     *out = a.release();
     return SKX_OK;
     });

@@ -149,8 +149,13 @@ struct FilterArgs {
     const uint32_t *vcount, *present, *unambig, *mask; uint64_t n_cols; uint32_t n_samples;
     uint64_t min_count; int ambig_as_missing, filter_type, ignore_const_gaps;
     uint8_t *keep;
+    int two_stage = 0;         // generic_modes::distance's pair of filters in one pass: keep = 3 marks a row its second stage removes
 };
 void launch_filter_flags(const FilterArgs &a, hipStream_t st);
+// streaming load: statistics of row-major rows (S cells each), and their kept rows into the sample-major matrix at col0 + pos[r]
+void launch_row_stats_rm(const uint8_t *cells, uint64_t S, uint64_t nr, uint32_t *present, uint32_t *unambig, uint32_t *mask, int *bad_byte, hipStream_t st);
+void launch_compact_rm(const uint8_t *cells, uint64_t S, uint64_t nr, const uint8_t *keep, const uint64_t *pos, uint8_t *out, uint64_t pitch,
+                       uint64_t col0, int mask_ambig, hipStream_t st);
 uint64_t scan_u8_blocks(uint64_t n);      // scratch of launch_scan_u8: sums[blocks] u32 + offs[blocks + 1] u64, owned by the caller
 void launch_scan_u8(const uint8_t *flags, uint64_t *pos, uint64_t n, uint32_t *sums, uint64_t *offs, hipStream_t st);   // pos[n] = total
 // out[s][pos[c]] = in[s][c] for kept c (optionally ambiguous -> 'N'); also compacts the stat/key arrays
@@ -161,6 +166,7 @@ void launch_compact_u64(const uint64_t *in, uint64_t *out, uint64_t n, const uin
 void launch_compact_u128(const uint64_t *in, uint64_t *out, uint64_t n, const uint8_t *keep, const uint64_t *pos, hipStream_t st);
 void launch_mask_ambig_stats(uint32_t *mask, uint64_t n, hipStream_t st);
 void launch_count_u8(const uint8_t *v, uint64_t n, uint8_t value, unsigned long long *out, hipStream_t st);
+void launch_differ_u32(const uint32_t *a, const uint32_t *b, uint64_t n, int *flag, hipStream_t st);      // *flag = 1 if a[i] != b[i] anywhere
 // tiled transpose of a byte matrix: in [rows][in_pitch] -> out [cols][out_pitch]
 void launch_transpose(const uint8_t *in, uint64_t in_pitch, uint64_t rows, uint64_t cols, uint8_t *out, uint64_t out_pitch,
                       hipStream_t st);

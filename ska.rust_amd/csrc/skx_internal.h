@@ -114,6 +114,7 @@ struct skx_array {
     skx::DevBuf<uint32_t> vcount;                   // variant_count as the reference stores it (merge_ska_array.rs:121)
     // 128-bit keys of arrays loaded from k>31 files are kept on the host (filter/align/distance never touch them)
     std::vector<skx_key> host_keys;
+    bool keys_absent = false;        // loaded through skx_array_load_filtered: the split k-mer list was stepped over
 };
 
 namespace skx {
@@ -151,6 +152,17 @@ struct SkfChunk { size_t off, len; uint32_t ulen, crc; bool compressed; uint64_t
 constexpr int SKF_NOT_TAKEN = -1000;
 typedef std::function<int(const uint8_t *file, const SkfChunk *chunks, size_t n_chunks, uint64_t upos, uint64_t n_rows, uint64_t n_samples)> DevDecode;
 typedef std::function<int(FILE *f, uint64_t upos, uint64_t uoff0, uint64_t n_chunks)> DevEncode;
+// layout-only view of a .skf for the streaming load (`ska align x.skf`, `ska distance x.skf`): header parsed, the split k-mer
+// list stepped over, the data section located; SKF_NOT_TAKEN when the file does not have the usual shape (the general reader's)
+struct SkfFile {
+    struct Impl; Impl *impl;
+    SkfMeta m; uint64_t n_keys = 0, upos_keys = 0, upos_data = 0;
+    SkfFile(); ~SkfFile();
+    SkfFile(const SkfFile &) = delete; SkfFile &operator=(const SkfFile &) = delete;
+    int open(const char *path);
+    int read_tail(std::vector<uint32_t> &counts);           // variant_count + ska_version + k_bits (fills m.version / m.k_bits)
+    const uint8_t *file() const; const SkfChunk *chunks() const; size_t n_chunks() const;
+};
 int skf_write_stream(const char *path, const SkfMeta &m, const std::vector<skx_key> &keys, const std::vector<uint64_t> &counts,
                      const RowFetch &fetch, int threads, const DevEncode *dev = nullptr);
 int skf_read_stream(const char *path, SkfMeta &m, std::vector<skx_key> &keys, std::vector<uint64_t> &counts,

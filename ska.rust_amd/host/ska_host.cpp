@@ -150,6 +150,55 @@ extern "C" int skh_distance_tsv(skx_array *a, double min_freq, int filt_ambig, c
     });
 }
 
+static int distance_table(skx_array *a, double constant, int filt_ambig, char **buf, uint64_t *len)
+{
+    skx_array_info_t info; skx_array_info(a, &info);
+    const uint64_t S = info.n_samples;
+    std::vector<skx_dist> d(S * (S - 1) / 2 + 1);
+    int r;
+    if ((r = skx_array_distance(a, constant, filt_ambig, d.data())) != SKX_OK) return r;
+    std::string out = "Sample1\tSample2\tDistance\tMismatches (proportion)\tMatch count\tMismatch count\n";
+    size_t n = 0;
+    for (uint64_t i = 0; i < S; i++)
+        for (uint64_t j = i + 1; j < S; j++, n++)
+            put(out, "%s\t%s\t%.2f\t%.5f\t%llu\t%llu\n", skx_array_name(a, i), skx_array_name(a, j), d[n].distance, d[n].mismatch_prop,
+                (unsigned long long)d[n].match_count, (unsigned long long)d[n].mismatch_count);
+    return to_buf(out, buf, len);
+}
+
+extern "C" int skh_distance_skf_tsv(skx_ctx *ctx, const char *skf_file, double min_freq, int filt_ambig, char **buf, uint64_t *len)
+{
+    return skx_guarded([&]() -> int {
+    skx_filter_spec fs{min_freq, 0, SKX_FILTER_NO_CONST, 0, 0, 1};
+    skx_array *a = nullptr; int64_t removed = 0, constant = 0;
+    int r = skx_array_load_filtered(ctx, skf_file, &fs, &a, &removed, &constant);
+    if (r != SKX_OK) return r;
+    r = distance_table(a, (double)constant, filt_ambig, buf, len);
+    skx_array_free(a);
+    return r;
+    });
+}
+
+extern "C" int skh_align_inputs_fd(skx_ctx *ctx, const char *const *inputs, int n_inputs, int threads, int filter_type, int mask_ambig, int ignore_const_gaps,
+                                   double min_freq, int filter_ambig_as_missing, int fd)
+{
+    return skx_guarded([&]() -> int {
+    skx_array *a = nullptr; int r;
+    if (n_inputs == 1) {
+        skx_filter_spec fs{min_freq, filter_ambig_as_missing, filter_type, mask_ambig, ignore_const_gaps, 0};
+        int64_t removed = 0;
+        if ((r = skx_array_load_filtered(ctx, inputs[0], &fs, &a, &removed, nullptr)) != SKX_OK) return r;
+        Phase pw("align.write_fasta");
+        r = skx_array_write_fasta(a, fd);
+    } else {
+        if ((r = skh_load_array(ctx, inputs, n_inputs, threads, &a)) != SKX_OK) return r;
+        r = skh_align_fd(a, filter_type, mask_ambig, ignore_const_gaps, min_freq, filter_ambig_as_missing, fd);
+    }
+    skx_array_free(a);
+    return r;
+    });
+}
+
 extern "C" int skh_nk(skx_array *a, int full_info, char **buf, uint64_t *len)
 {
     return skx_guarded([&]() -> int {
@@ -490,8 +539,8 @@ extern "C" int skh_main(int argc, char **argv)
         if (mf < 0 || mf > 1) return fail("Frequency must be between 0 and 1 (inclusive)");
         int fd = 1;                                                                                               // io_utils::set_ostream: stdout or -o
         if (a.has("-o")) { fd = open(a.get("-o").c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644)   /* read-write: the writer maps the file */; if (fd < 0) return fail("cannot create output file"); }
-        if (skh_load_array(ctx, in.data(), (int)in.size(), threads, &arr) != SKX_OK ||
-            skh_align_fd(arr, filter, a.has("--ambig-mask"), a.has("--no-gap-only-sites"), mf, a.has("--filter-ambig-as-missing"), fd) != SKX_OK)
+        if (skh_align_inputs_fd(ctx, in.data(), (int)in.size(), threads, filter, a.has("--ambig-mask"), a.has("--no-gap-only-sites"), mf,
+                                a.has("--filter-ambig-as-missing"), fd) != SKX_OK)
             rcode = engine_fail();
         if (fd != 1) close(fd);
     } else if (cmd == "distance") {
@@ -499,7 +548,8 @@ extern "C" int skh_main(int argc, char **argv)
         const char *in[1] = {a.pos[0].c_str()};
         const double mf = atof(a.get("--min-freq", a.get("-m", "0")).c_str());
         char *buf = nullptr; uint64_t len = 0;
-        if (skh_load_array(ctx, in, 1, 1, &arr) != SKX_OK || skh_distance_tsv(arr, mf, !a.has("--allow-ambiguous"), &buf, &len) != SKX_OK)
+        (void)in;
+        if (skh_distance_skf_tsv(ctx, a.pos[0].c_str(), mf, !a.has("--allow-ambiguous"), &buf, &len) != SKX_OK)
             rcode = engine_fail();
         else { rcode = emit(a.get("-o"), buf, len); skx_free(buf); }
     } else if (cmd == "nk") {

@@ -30,6 +30,11 @@ class Stream(C.Structure):
     _fields_ = [("seq", C.c_void_p), ("qual", C.c_void_p), ("len", C.c_uint64)]
 
 
+class FilterSpec(C.Structure):
+    _fields_ = [("min_freq", C.c_double), ("filter_ambig_as_missing", C.c_int32), ("filter_type", C.c_int32), ("mask_ambig", C.c_int32),
+                ("ignore_const_gaps", C.c_int32), ("two_stage", C.c_int32)]
+
+
 class ArrayInfo(C.Structure):
     _fields_ = [("k", C.c_int32), ("rc", C.c_int32), ("k_bits", C.c_int32), ("n_kmers", C.c_uint64),
                 ("n_rows", C.c_uint64), ("n_samples", C.c_uint64), ("total_samples", C.c_uint64)]
@@ -52,8 +57,8 @@ skx_keyset_union skx_keyset_size skx_keyset_device skx_keyset_from_device skx_ke
 skx_array_assemble skx_merge skx_build_and_merge skx_array_free skx_array_save skx_array_load skx_array_from_host
 skx_array_info skx_array_name skx_array_version skx_array_export skx_array_sample_kmers skx_array_filter
 skx_array_write_fasta skx_array_fasta skx_array_device_matrix skx_array_device_stats skx_array_set_total_samples skx_array_distance skx_free skx_ctx_timings
-skx_array_merge skx_array_delete_samples skx_array_weed skx_keyset_from_fasta skx_array_ctx skx_set_last_error skx_array_map skx_cov_histogram skx_phases_json skx_phase_add
-skh_apply_filters skh_align skh_align_fd skh_distance_tsv skh_nk skh_save_skf skh_load_array skh_sample_name skh_main skh_merge skh_delete skh_weed skh_cov skh_cov_fit""".split()
+skx_array_merge skx_array_delete_samples skx_array_weed skx_keyset_from_fasta skx_array_ctx skx_set_last_error skx_array_map skx_cov_histogram skx_phases_json skx_phase_add skx_array_load_filtered
+skh_apply_filters skh_align skh_align_fd skh_distance_tsv skh_nk skh_save_skf skh_load_array skh_sample_name skh_main skh_merge skh_delete skh_weed skh_cov skh_cov_fit skh_align_inputs_fd skh_distance_skf_tsv""".split()
 
 _lib = None
 
@@ -134,6 +139,9 @@ def load_library():
     lib.skh_weed.argtypes = [vp, cp, i, d, i, i, i, i, cp]
     lib.skh_sample_name.argtypes = [cp]
     lib.skh_sample_name.restype = vp
+    lib.skx_array_load_filtered.argtypes = [vp, cp, C.POINTER(FilterSpec), pp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.skh_align_inputs_fd.argtypes = [vp, C.POINTER(cp), i, i, i, i, i, d, i, i]
+    lib.skh_distance_skf_tsv.argtypes = [vp, cp, d, i, pp, C.POINTER(u64)]
     lib.skx_phases_json.argtypes = [pp, C.POINTER(u64), i]
     lib.skx_phase_add.argtypes = [cp, d]
     lib.skx_phase_add.restype = None
@@ -415,6 +423,16 @@ class Array:
         return cls(h, ctx)
 
     # ---- .skf life-cycle: ska merge / delete / weed (generic_modes.rs:90-106,192-267) ----
+    @classmethod
+    def load_filtered(cls, path, min_freq=0.9, filter_ambig_as_missing=False, filter_type=FILTER_NO_CONST, mask_ambig=False, ignore_const_gaps=False,
+                      two_stage=False, ctx=None):
+        """skx_array_load_filtered: load + apply_filters (or distance's two filters) in one pass -> (array, removed, constant)"""
+        ctx = ctx or default_context()
+        fs = FilterSpec(min_freq, int(filter_ambig_as_missing), filter_type, int(mask_ambig), int(ignore_const_gaps), int(two_stage))
+        h, rem, cst = C.c_void_p(), C.c_int64(), C.c_int64()
+        _check(_lib.skx_array_load_filtered(ctx.h, path.encode(), C.byref(fs), C.byref(h), C.byref(rem), C.byref(cst)))
+        return cls(h, ctx), rem.value, cst.value
+
     @classmethod
     def merge(cls, arrays, ctx=None):
         ctx = ctx or arrays[0].ctx
