@@ -860,6 +860,100 @@ extern "C" int skx_array_assemble(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows
     });
 }
 
+// ---- lazily held arrays -------------------------------------------------------------------------------------------------
+static AssembleArgs lazy_args(skx_array *a, int *d_flag)
+{
+    AssembleArgs aa{};
+    skx_keyset *rows = a->lazy_rows;
+    aa.d = a->lazy_dict->view(); aa.logN = rows->logN; aa.stage = rows->stage.p; aa.stride = rows->stride; aa.ncnt = rows->ncnt.p; aa.roff = rows->roff.p;
+    aa.matrix = nullptr; aa.pitch = 0; aa.col_present = a->present.p; aa.col_unambig = a->unambig.p; aa.col_mask = a->mask.p;
+    aa.max_rows = rows->max_rows; aa.missing = d_flag;
+    return aa;
+}
+// takes ownership of d and rows (also on failure)
+static int array_make_lazy(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows, const char *const *names, skx_array **out)
+{
+    std::unique_ptr<skx_array> a(new skx_array());
+    a->lazy_dict = d; a->lazy_rows = rows;
+    hipStream_t st = ctx->stream;
+    a->ctx = ctx; a->k = d->k; a->rc = d->rc; a->k_bits = d->key_bits; a->hp = d->hp; a->wh = d->wh; a->version = skx_version();
+    for (int i = 0; i < d->n; i++) a->names.emplace_back(names && names[i] ? names[i] : "");
+    const uint64_t U = rows->total;
+    a->n_rows = a->n_kmers = U; a->pitch = 0; a->engine_order = true; a->stats_ready = false;
+    SKX_TRY(a->present.alloc(U)); SKX_TRY(a->unambig.alloc(U)); SKX_TRY(a->mask.alloc(U)); SKX_TRY(a->keys.alloc(U)); SKX_TRY(a->vcount.alloc(U));
+    if (U) launch_gather_keys(rows->stage.p, rows->stride, rows->ncnt.p, rows->roff.p, 1 << rows->logN, a->keys.p, 0, rows->hp, st);
+    SKX_HIP(hipStreamSynchronize(st));
+    *out = a.release();
+    return SKX_OK;
+}
+static int lazy_check_missing(skx_array *a, DevBuf<int> &d_flag)
+{
+    int missing = 0;
+    SKX_HIP(hipMemcpyAsync(&missing, d_flag.p, 4, hipMemcpyDeviceToHost, a->ctx->stream));
+    SKX_HIP(hipStreamSynchronize(a->ctx->stream));
+    SKX_HIP(hipGetLastError());
+    if (missing) { set_error("row keyset does not contain every split k-mer of the samples"); return SKX_EINVAL; }
+    return SKX_OK;
+}
+int skx::array_lazy_stats(skx_array *a)
+{
+    if (!a->lazy() || a->stats_ready) return SKX_OK;
+    skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
+    SKX_HIP(hipSetDevice(ctx->device));
+    DevBuf<int> d_flag; SKX_TRY(d_flag.alloc(1)); SKX_TRY(d_flag.zero(st));
+    if (a->n_rows) {
+        AssembleArgs aa = lazy_args(a, d_flag.p);
+        { StageTimer t(ctx, &ctx->tm.assemble); launch_assemble(aa, st, 1); }
+        SKX_HIP(hipMemcpyAsync(a->vcount.p, a->present.p, a->n_rows * 4, hipMemcpyDeviceToDevice, st));     // merge_ska_array.rs:172
+    }
+    SKX_TRY(lazy_check_missing(a, d_flag));
+    a->stats_ready = true;
+    return SKX_OK;
+}
+int skx::array_materialize(skx_array *a)
+{
+    if (!a->lazy()) return SKX_OK;
+    skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
+    SKX_HIP(hipSetDevice(ctx->device));
+    const uint64_t U = a->n_rows; const size_t S = a->names.size();
+    a->pitch = pitch_for(U);
+    SKX_TRY(a->matrix.alloc((uint64_t)S * a->pitch));
+    DevBuf<int> d_flag; SKX_TRY(d_flag.alloc(1)); SKX_TRY(d_flag.zero(st));
+    if (U) {
+        AssembleArgs aa = lazy_args(a, d_flag.p);
+        aa.matrix = a->matrix.p; aa.pitch = a->pitch;
+        { StageTimer t(ctx, &ctx->tm.assemble); launch_assemble(aa, st, 0); }
+        if (!a->stats_ready) SKX_HIP(hipMemcpyAsync(a->vcount.p, a->present.p, U * 4, hipMemcpyDeviceToDevice, st));
+    }
+    SKX_TRY(lazy_check_missing(a, d_flag));
+    a->stats_ready = true;
+    a->drop_lazy();
+    return SKX_OK;
+}
+int skx::array_lazy_window(skx_array *a, uint64_t r0, uint64_t nr, DevBuf<uint8_t> &buf, const uint8_t **win, uint64_t *wpitch)
+{
+    skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
+    skx_keyset *rows = a->lazy_rows;
+    if (rows->h_roff.empty()) {
+        rows->h_roff.resize((1ull << rows->logN) + 1);
+        SKX_HIP(hipMemcpy(rows->h_roff.data(), rows->roff.p, rows->h_roff.size() * 8, hipMemcpyDeviceToHost));
+    }
+    const auto &ro = rows->h_roff;
+    const uint64_t j0 = (uint64_t)(std::upper_bound(ro.begin(), ro.end(), r0) - ro.begin()) - 1;                // sub-bucket holding row r0
+    const uint64_t j1 = (uint64_t)(std::lower_bound(ro.begin(), ro.end(), r0 + nr) - ro.begin());                // first sub-bucket past the last row
+    const uint64_t c0 = ro[j0] & ~15ull, span = ro[j1] - c0;                                                     // 16-B aligned window start
+    const uint64_t wp = pitch_for(span);
+    const size_t S = a->names.size();
+    if (buf.n < S * wp) SKX_TRY(buf.alloc(S * wp));
+    DevBuf<int> d_flag; SKX_TRY(d_flag.alloc(1)); SKX_TRY(d_flag.zero(st));
+    AssembleArgs aa = lazy_args(a, d_flag.p);
+    aa.matrix = buf.p; aa.pitch = wp; aa.j_base = (uint32_t)j0; aa.col_base = c0;
+    { StageTimer t(ctx, &ctx->tm.assemble); launch_assemble(aa, st, 0, (uint32_t)(j1 - j0)); }
+    SKX_TRY(lazy_check_missing(a, d_flag));
+    *win = buf.p + (r0 - c0); *wpitch = wp;
+    return SKX_OK;
+}
+
 extern "C" int skx_merge(skx_ctx *ctx, skx_dictset *d, const char *const *names, skx_array **out)
 {
     return skx_guarded([&]() -> int {
@@ -913,7 +1007,14 @@ static int build_range(skx_ctx *ctx, const char *const *names, const char *const
     int r = skx_dictset_build_files(ctx, file1 + lo, file2 ? file2 + lo : nullptr, hi - lo, k, rc, q, threads, proportion_reads, &d);
     if (r == SKX_OK) {
         const auto t0 = std::chrono::steady_clock::now();
-        r = skx_merge(ctx, d, names + lo, &a);
+        if (!d->wide() && !getenv("SKX_EAGER_ARRAY")) {
+            // rows now, cells on demand: the array keeps the dictionaries (see skx_array::lazy_dict)
+            skx_keyset *ks = nullptr;
+            r = skx_keyset_union(ctx, d, &ks);
+            if (r == SKX_OK) r = array_make_lazy(ctx, d, ks, names + lo, &a); else skx_dictset_free(d);
+            d = nullptr;
+        } else
+            r = skx_merge(ctx, d, names + lo, &a);
         const auto t1 = std::chrono::steady_clock::now();
         skx_dictset_free(d);
         phase_add("build.merge", std::chrono::duration<double>(t1 - t0).count());
@@ -961,6 +1062,7 @@ extern "C" int skx_build_and_merge(skx_ctx *ctx, const char *const *names, const
 extern "C" int skx_array_device_matrix(skx_array *a, const uint8_t **dptr, uint64_t *pitch, uint64_t *n_rows)
 {
     return skx_guarded([&]() -> int {
+    SKX_TRY(array_materialize(a));
     *dptr = a->matrix.p; *pitch = a->pitch; *n_rows = a->n_rows;
     return SKX_OK;
     });
@@ -968,6 +1070,7 @@ extern "C" int skx_array_device_matrix(skx_array *a, const uint8_t **dptr, uint6
 
 extern "C" int skx_array_device_stats(skx_array *a, uint32_t **present, uint32_t **unambig, uint32_t **mask, uint32_t **variant_count)
 {
+    { const int r = skx_guarded([&]() -> int { return array_materialize(a); }); if (r != SKX_OK) return r; }
     if (present) *present = a->present.p;
     if (unambig) *unambig = a->unambig.p;
     if (mask) *mask = a->mask.p;
@@ -1053,6 +1156,7 @@ extern "C" int skx_array_export(skx_array *a, skx_key *keys, uint8_t *variants, 
     return skx_guarded([&]() -> int {
     skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
     SKX_HIP(hipSetDevice(ctx->device));
+    SKX_TRY(array_materialize(a));
     const uint64_t U = a->n_rows, S = a->names.size(), K = a->n_kmers;
     std::vector<skx_key> hk;
     SKX_TRY(array_host_keys(a, hk));
@@ -1082,6 +1186,7 @@ extern "C" int skx_array_sample_kmers(skx_array *a, int64_t *out)
     skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
     SKX_HIP(hipSetDevice(ctx->device));
     const size_t S = a->names.size();
+    if (a->lazy()) { for (size_t i = 0; i < S; i++) out[i] = (int64_t)a->lazy_dict->sample_size[i]; return SKX_OK; }      // a sample's cells = its dictionary
     DevBuf<unsigned long long> d; SKX_TRY(d.alloc(S)); SKX_TRY(d.zero(st));
     launch_row_nonmissing(a->matrix.p, a->pitch, (int)S, a->n_rows, d.p, st);
     std::vector<unsigned long long> h(S);
@@ -1109,7 +1214,15 @@ static int array_compact(skx_array *a, DevBuf<uint8_t> &keep, DevBuf<uint64_t> &
         const uint64_t np = pitch_for(kept);
         DevBuf<uint8_t> nm; DevBuf<uint32_t> p2, u2, m2, v2;
         SKX_TRY(nm.alloc((uint64_t)S * np)); SKX_TRY(p2.alloc(kept)); SKX_TRY(u2.alloc(kept)); SKX_TRY(m2.alloc(kept)); SKX_TRY(v2.alloc(kept));
-        launch_compact_matrix(a->matrix.p, a->pitch, nm.p, np, (int)S, U, keep.p, pos.p, mask_ambig, st);
+        if (a->lazy()) {
+            // the kept rows are assembled straight from the dictionaries: the unfiltered matrix is never written
+            DevBuf<int> d_flag; SKX_TRY(d_flag.alloc(1)); SKX_TRY(d_flag.zero(st));
+            AssembleArgs aa = lazy_args(a, d_flag.p);
+            aa.matrix = nm.p; aa.pitch = np; aa.keep = keep.p; aa.kpos = pos.p; aa.mask_ambig = mask_ambig;
+            { StageTimer t2(ctx, &ctx->tm.assemble); launch_assemble(aa, st, 2); }
+            SKX_TRY(lazy_check_missing(a, d_flag));
+        } else
+            launch_compact_matrix(a->matrix.p, a->pitch, nm.p, np, (int)S, U, keep.p, pos.p, mask_ambig, st);
         launch_compact_u32(a->present.p, p2.p, U, keep.p, pos.p, st);
         launch_compact_u32(a->unambig.p, u2.p, U, keep.p, pos.p, st);
         launch_compact_u32(a->mask.p, m2.p, U, keep.p, pos.p, st);
@@ -1139,6 +1252,7 @@ static int array_compact(skx_array *a, DevBuf<uint8_t> &keep, DevBuf<uint64_t> &
         SKX_HIP(hipStreamSynchronize(st));
         a->matrix = std::move(nm); a->present = std::move(p2); a->unambig = std::move(u2); a->mask = std::move(m2); a->vcount = std::move(v2);
         a->pitch = np; a->n_rows = kept;
+        a->drop_lazy();
     }
     return SKX_OK;
 }
@@ -1150,6 +1264,7 @@ extern "C" int skx_array_filter(skx_array *a, uint64_t min_count, int filter_amb
     skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
     SKX_HIP(hipSetDevice(ctx->device));
     const uint64_t U = a->n_rows; const size_t S = a->names.size();
+    SKX_TRY(array_lazy_stats(a));
     DevBuf<uint8_t> keep; DevBuf<uint64_t> pos;
     SKX_TRY(keep.alloc(U)); SKX_TRY(pos.alloc(U + 1));
     uint64_t kept = 0, silent = 0;
@@ -1229,6 +1344,7 @@ extern "C" int skx_array_merge(skx_ctx *ctx, skx_array *const *in, int n, skx_ar
     SKX_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     uint64_t tot = 0; size_t S = 0;
+    for (int i = 0; i < n; i++) SKX_TRY(array_materialize(in[i]));
     for (int i = 0; i < n; i++) {
         if (in[i]->k != in[0]->k) { set_error("K-mer lengths do not match: %d %d", in[i]->k, in[0]->k); return SKX_EINVAL; }     // merge_ska_dict.rs:169-171
         if (in[i]->rc != in[0]->rc) { set_error("Strand use inconsistent"); return SKX_EINVAL; }                                  // :172-174
@@ -1298,6 +1414,7 @@ extern "C" int skx_array_delete_samples(skx_array *a, const char *const *del_nam
     if (!a) { set_error("bad arguments"); return SKX_EINVAL; }
     skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
     SKX_HIP(hipSetDevice(ctx->device));
+    SKX_TRY(array_materialize(a));
     const size_t S = a->names.size();
     if (n_del <= 0 || (size_t)n_del == S) { set_error("Invalid number of samples to remove"); return SKX_EINVAL; }                // merge_ska_array.rs:232-234
     if (a->n_kmers != a->n_rows || a->keys_absent) { set_error("split k-mers and variants are out of step (filtered without update_kmers)"); return SKX_EINVAL; }
@@ -1338,6 +1455,7 @@ extern "C" int skx_array_weed(skx_array *a, skx_keyset *weed, int reverse, uint6
     if (!a || !weed) { set_error("bad arguments"); return SKX_EINVAL; }
     skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
     SKX_HIP(hipSetDevice(ctx->device));
+    SKX_TRY(array_materialize(a));
     if (weed->k != a->k) { set_error("K-mer lengths do not match: %d %d", weed->k, a->k); return SKX_EINVAL; }
     if (weed->rc != a->rc) { set_error("Strand use inconsistent"); return SKX_EINVAL; }
     if (a->n_kmers != a->n_rows || a->keys_absent) { set_error("split k-mers and variants are out of step (filtered without update_kmers)"); return SKX_EINVAL; }
@@ -1372,6 +1490,7 @@ extern "C" int skx_array_fasta(skx_array *a, char **buf, uint64_t *len)
     return skx_guarded([&]() -> int {
     skx_ctx *ctx = a->ctx;
     SKX_HIP(hipSetDevice(ctx->device));
+    SKX_TRY(array_materialize(a));
     const size_t S = a->names.size(); const uint64_t U = a->n_rows;
     uint64_t tot = 0;
     for (auto &nm : a->names) tot += nm.size() + U + 3;
@@ -1399,6 +1518,7 @@ extern "C" int skx_array_write_fasta(skx_array *a, int fd)
     return skx_guarded([&]() -> int {
     skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
     SKX_HIP(hipSetDevice(ctx->device));
+    SKX_TRY(array_materialize(a));
     const size_t S = a->names.size(); const uint64_t U = a->n_rows;
     size_t max_rec = 0; uint64_t total = 0;
     for (auto &nm : a->names) { max_rec = std::max<size_t>(max_rec, nm.size() + U + 3); total += nm.size() + U + 3; }
@@ -1502,6 +1622,7 @@ extern "C" int skx_array_distance(skx_array *a, double constant, int filt_ambig,
     return skx_guarded([&]() -> int {
     skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
     SKX_HIP(hipSetDevice(ctx->device));
+    SKX_TRY(array_materialize(a));
     const int S = (int)a->names.size(); const uint64_t U = a->n_rows;
     if (S < 2) return SKX_OK;
     StageTimer t(ctx, &ctx->tm.distance);

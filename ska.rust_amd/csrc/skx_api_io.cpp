@@ -56,6 +56,7 @@ extern "C" int skx_array_map(skx_array *a, const char *reference, int ambig_mask
     SKX_HIP(hipSetDevice(ctx->device));
     const int k = a->k, h = (k - 1) / 2, S = (int)a->names.size();
     if (a->n_kmers != a->n_rows || a->keys_absent) { set_error("split k-mers and variants are out of step (filtered without update_kmers)"); return SKX_EINVAL; }
+    SKX_TRY(array_materialize(a));
     HostStream hs;
     SKX_TRY(read_sample_stream(reference, nullptr, 0.0, hs));
     if (hs.is_fastq) { set_error("Cannot create reference from FASTQ files"); return SKX_EINVAL; }                                // ska_ref.rs:206-208
@@ -250,14 +251,23 @@ extern "C" int skx_array_save(skx_array *a, const char *path)
     const auto t_k0 = std::chrono::steady_clock::now();
     SKX_TRY(array_host_keys(a, keys));
     phase_add("save.keys_to_host", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_k0).count());
+    SKX_TRY(array_lazy_stats(a));              // a lazily held array: the stored counts come from a statistics-only pass
     std::vector<uint32_t> vc(U);
     if (U) SKX_HIP(hipMemcpy(vc.data(), a->vcount.p, U * 4, hipMemcpyDeviceToHost));
     std::vector<uint64_t> counts(vc.begin(), vc.end());
-    DevBuf<uint8_t> d_blk;
+    DevBuf<uint8_t> d_blk, d_win;
     uint64_t blk_cap = 0;
+    // rows [r0, r0 + nr) sample-major: a slice of the matrix, or -- lazily held array -- a window assembled for the occasion
+    auto rows_view = [&](uint64_t r0, uint64_t nr, const uint8_t **p, uint64_t *pitch) -> int {
+        if (a->lazy()) return array_lazy_window(a, r0, nr, d_win, p, pitch);
+        *p = a->matrix.p + r0; *pitch = a->pitch;
+        return SKX_OK;
+    };
     auto fetch = [&](uint64_t row0, uint64_t nr, uint8_t *dst) -> int {
         if (nr * S > blk_cap) { blk_cap = nr * S; SKX_TRY(d_blk.alloc(blk_cap)); }
-        launch_transpose(a->matrix.p + row0, a->pitch, S, nr, d_blk.p, S, st);          // [S][nr] slice -> [nr][S]
+        const uint8_t *src; uint64_t sp;
+        SKX_TRY(rows_view(row0, nr, &src, &sp));
+        launch_transpose(src, sp, S, nr, d_blk.p, S, st);                                // [S][nr] slice -> [nr][S]
         SKX_HIP(hipMemcpyAsync(dst, d_blk.p, nr * S, hipMemcpyDeviceToHost, st));
         SKX_HIP(hipStreamSynchronize(st));
         return SKX_OK;
@@ -282,7 +292,9 @@ extern "C" int skx_array_save(skx_array *a, const char *path)
             const uint64_t c_lo = rel_lo >> 1, c_hi = ((rel_hi - 1) >> 1) + 1;
             const uint64_t r0 = c_lo / S, r1 = (c_hi - 1) / S + 1, nr = r1 - r0;
             if (nr * S + 16 > cells_cap) { cells_cap = nr * S + 16; SKX_TRY(d_cells.alloc(cells_cap)); }
-            launch_transpose(a->matrix.p + r0, a->pitch, S, nr, d_cells.p, S, st);                          // [S][nr] slice -> [nr][S]
+            const uint8_t *src; uint64_t sp;
+            SKX_TRY(rows_view(r0, nr, &src, &sp));
+            launch_transpose(src, sp, S, nr, d_cells.p, S, st);                                             // [S][nr] slice -> [nr][S]
             SKX_TRY(launch_skf_encode_cells(ctx->device, d_cells.p, r0 * S, upos, uoff0 + g0 * 65536ull, (uint32_t)ng, d_slots.p, d_sizes.p, st));
             sizes.resize(ng); off.resize(ng);
             SKX_HIP(hipMemcpyAsync(sizes.data(), d_sizes.p, ng * 4, hipMemcpyDeviceToHost, st));

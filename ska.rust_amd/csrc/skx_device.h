@@ -132,8 +132,13 @@ struct AssembleArgs {
     uint32_t *col_mask;        // [U] bit c set iff IUPAC set-code c (1..15) occurs in the column
     uint32_t max_rows;         // max ncnt (LDS sizing)
     int *missing;              // set if a dict key is not among the rows
+    uint32_t j_base = 0;       // first sub-bucket of this launch
+    uint64_t col_base = 0;     // mode 0: output column of row r is r - col_base (a window of rows in a small buffer)
+    const uint8_t *keep = nullptr; const uint64_t *kpos = nullptr;    // mode 2: row flags (1 = kept) and their exclusive scan [U + 1]
+    int mask_ambig = 0;        // mode 2: ambiguous cells are written as 'N' (MergeSkaArray::filter's ambig_mask)
 };
-void launch_assemble(const AssembleArgs &a, hipStream_t st);
+// mode 0: matrix + statistics; 1: statistics only; 2: kept rows only (64-bit keys; the k > 31 kernel has mode 0 alone)
+void launch_assemble(const AssembleArgs &a, hipStream_t st, int mode = 0, uint32_t n_blocks = 0);
 
 // compact slabs into one array; unhash=1 converts engine-order words back to reference keys
 void launch_gather_keys(const uint64_t *stage, uint32_t stride, const uint32_t *ncnt, const uint64_t *roff, int n_sub,

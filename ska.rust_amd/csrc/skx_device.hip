@@ -848,22 +848,37 @@ __device__ static inline unsigned char mask2iupac(uint32_t m4)
     return (unsigned char)(((m4 & 8u) ? hi : lo) >> (8u * (m4 & 7u)));
 }
 
-// K5: rows = key slabs, columns = samples: fill the sample-major matrix + per-row statistics
+// K5: rows = key slabs, columns = samples: fill the sample-major matrix + per-row statistics.
+// MODE 0: matrix + statistics (columns land at roff[j] - col_base: a window of sub-buckets can be assembled into a small
+//         buffer, which is how a lazily held array is streamed into a .skf without ever existing in full);
+// MODE 1: statistics only (the filter of a lazily held array decides from these);
+// MODE 2: kept rows only -- keep[] / kpos[] (flags and their exclusive scan over all rows) select the rows, which land at
+//         column kpos[row]: the filtered array is written directly, the unfiltered one never is.
+template <int MODE>
 __global__ __launch_bounds__(512, 8) void assemble_kernel(AssembleArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    const uint64_t j = blockIdx.x;
+    const uint64_t j = (uint64_t)blockIdx.x + a.j_base;
     const uint32_t n = a.ncnt[j];
     if (n == 0) return;
     const uint32_t maxr = (a.max_rows + 15u) & ~15u;
     uint64_t *s_keys = reinterpret_cast<uint64_t *>(s_raw);
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_raw + (size_t)maxr * 8);
+    uint16_t *s_map = reinterpret_cast<uint16_t *>(s_cnt);                // MODE 2: row -> kept slot (0xFFFF: dropped); no counts in that mode
     uint32_t *s_msk = s_cnt + maxr;                                   // [maxr/2] 16-bit code sets, two rows per word
     uint32_t *s_idx = s_msk + maxr / 2;                                   // [maxr/2 + 2] row index by the next hash bits
     unsigned char *s_rows = reinterpret_cast<unsigned char *>(s_idx + maxr / 2 + 4);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const uint64_t *slab = a.stage + j * (uint64_t)a.stride;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { s_keys[i] = slab[i] >> 4; s_cnt[i] = 0; if (!(i & 1u)) s_msk[i >> 1] = 0; }
+    const uint64_t r0 = a.roff[j];
+    const uint64_t k0 = MODE == 2 ? a.kpos[r0] : 0;
+    const uint32_t nout = MODE == 2 ? (uint32_t)(a.kpos[r0 + n] - k0) : n;      // cells every sample writes for this sub-bucket
+    if (MODE == 2 && nout == 0) return;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        s_keys[i] = slab[i] >> 4;
+        if (MODE == 2) s_map[i] = a.keep[r0 + i] == 1 ? (uint16_t)(a.kpos[r0 + i] - k0) : (uint16_t)0xFFFF;
+        else { s_cnt[i] = 0; if (!(i & 1u)) s_msk[i >> 1] = 0; }
+    }
     __syncthreads();
     // direct index: rows are uniform in the sub-bucket's hash range, so the next logI bits of the key select ~2 rows
     const int rem = a.d.bits - a.logN;
@@ -879,8 +894,8 @@ __global__ __launch_bounds__(512, 8) void assemble_kernel(AssembleArgs a)
         s_idx[b] = l;
     }
     __syncthreads();
-    const uint64_t r0 = a.roff[j];
-    const uint32_t shift = (uint32_t)(r0 & 15u);
+    const uint64_t ocol = MODE == 2 ? k0 : r0 - a.col_base;           // first output column of this sub-bucket
+    const uint32_t shift = (uint32_t)(ocol & 15u);
     unsigned char *row = s_rows + (size_t)wv * (maxr + 32u);      // 16-B aligned; cell i lives at row[shift + i]
     // every lane binary-searches the slice of one sample (64 searches in flight); the wave then handles the slices in turn.
     // Slices are addressed as offsets from the kernel-argument pointer (global address space, no flat loads) and read
@@ -900,9 +915,11 @@ __global__ __launch_bounds__(512, 8) void assemble_kernel(AssembleArgs a)
             const int s = sbase + t;
             gwords_t reg = as_global(wbase + __shfl((unsigned long long)my_off, t, 64));
             const uint32_t lo = __shfl(my_lo, t, 64), hi = __shfl(my_hi, t, 64);
-            // fill with '-'
-            for (uint32_t i = lane * 4; i < n + shift + 3; i += 256) *reinterpret_cast<uint32_t *>(row + i) = 0x2D2D2D2Du;
-            __builtin_amdgcn_wave_barrier();
+            if (MODE != 1) {
+                // fill with '-'
+                for (uint32_t i = lane * 4; i < nout + shift + 3; i += 256) *reinterpret_cast<uint32_t *>(row + i) = 0x2D2D2D2Du;
+                __builtin_amdgcn_wave_barrier();
+            }
             for (uint32_t i0 = lo; i0 < hi; i0 += 512) {
                 uint64_t wq[8];
 #pragma unroll
@@ -918,31 +935,37 @@ __global__ __launch_bounds__(512, 8) void assemble_kernel(AssembleArgs a)
                     while (l < le && s_keys[l] < key) l++;
                     if (l < le && s_keys[l] == key) {
                         const uint32_t m4 = (uint32_t)(w & 15u);
-                        row[shift + l] = mask2iupac(m4);
-                        const uint32_t single = (m4 & (m4 - 1)) == 0;
-                        atomicAdd(&s_cnt[l], 1u | (single << 16));
-                        atomicOr(&s_msk[l >> 1], (1u << m4) << (16u * (l & 1u)));
+                        if (MODE == 0) row[shift + l] = mask2iupac(m4);
+                        if (MODE == 2) { const uint32_t o = s_map[l]; if (o != 0xFFFFu) row[shift + o] = (a.mask_ambig && (m4 & (m4 - 1))) ? (unsigned char)'N' : mask2iupac(m4); }
+                        if (MODE != 2) {
+                            const uint32_t single = (m4 & (m4 - 1)) == 0;
+                            atomicAdd(&s_cnt[l], 1u | (single << 16));
+                            atomicOr(&s_msk[l >> 1], (1u << m4) << (16u * (l & 1u)));
+                        }
                     } else {
                         *a.missing = 1;
                     }
                 }
             }
-            __builtin_amdgcn_wave_barrier();
-            // copy out: global column r0 + i  <-  row[shift + i]; 16-B body, byte head/tail
-            unsigned char *dst = a.matrix + (uint64_t)s * a.pitch + r0;
-            const uint32_t head = (16u - shift) & 15u;
-            const uint32_t h = head < n ? head : n;
-            if ((uint32_t)lane < h) dst[lane] = row[shift + lane];
-            const uint32_t body = (n - h) / 16u;
-            for (uint32_t v = lane; v < body; v += 64) {
-                const uint4 x = *reinterpret_cast<const uint4 *>(row + shift + h + 16u * v);
-                *reinterpret_cast<uint4 *>(dst + h + 16u * v) = x;
+            if (MODE != 1) {
+                __builtin_amdgcn_wave_barrier();
+                // copy out: output column ocol + i  <-  row[shift + i]; 16-B body, byte head/tail
+                unsigned char *dst = a.matrix + (uint64_t)s * a.pitch + ocol;
+                const uint32_t head = (16u - shift) & 15u;
+                const uint32_t h = head < nout ? head : nout;
+                if ((uint32_t)lane < h) dst[lane] = row[shift + lane];
+                const uint32_t body = (nout - h) / 16u;
+                for (uint32_t v = lane; v < body; v += 64) {
+                    const uint4 x = *reinterpret_cast<const uint4 *>(row + shift + h + 16u * v);
+                    *reinterpret_cast<uint4 *>(dst + h + 16u * v) = x;
+                }
+                const uint32_t done = h + body * 16u;
+                if (done + lane < nout) dst[done + lane] = row[shift + done + lane];
+                __builtin_amdgcn_wave_barrier();
             }
-            const uint32_t done = h + body * 16u;
-            if (done + lane < n) dst[done + lane] = row[shift + done + lane];
-            __builtin_amdgcn_wave_barrier();
         }
     }
+    if (MODE == 2) return;
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
         a.col_present[r0 + i] = s_cnt[i] & 0xFFFFu;
@@ -950,13 +973,20 @@ __global__ __launch_bounds__(512, 8) void assemble_kernel(AssembleArgs a)
         a.col_mask[r0 + i] = (s_msk[i >> 1] >> (16u * (i & 1u))) & 0xFFFFu;
     }
 }
-void launch_assemble(const AssembleArgs &a, hipStream_t st)
+template <int MODE>
+static void launch_assemble_t(const AssembleArgs &a, uint32_t n_blocks, hipStream_t st)
 {
     const uint32_t maxr = (a.max_rows + 15u) & ~15u;
     const int nw = 8;
-    size_t lds = (size_t)maxr * 14 + ((size_t)maxr / 2 + 4) * 4 + (size_t)nw * (maxr + 32u);
-    (void)hipFuncSetAttribute((const void *)assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(assemble_kernel, dim3(1u << a.logN), dim3(64 * nw), lds, st, a);
+    size_t lds = (size_t)maxr * 14 + ((size_t)maxr / 2 + 4) * 4 + (MODE == 1 ? 0 : (size_t)nw * (maxr + 32u));
+    (void)hipFuncSetAttribute((const void *)assemble_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(assemble_kernel<MODE>, dim3(n_blocks), dim3(64 * nw), lds, st, a);
+}
+// sub-buckets [a.j_base, a.j_base + n_blocks); n_blocks = 0: all of them
+void launch_assemble(const AssembleArgs &a, hipStream_t st, int mode, uint32_t n_blocks)
+{
+    if (!n_blocks) n_blocks = (1u << a.logN) - a.j_base;
+    if (mode == 0) launch_assemble_t<0>(a, n_blocks, st); else if (mode == 1) launch_assemble_t<1>(a, n_blocks, st); else launch_assemble_t<2>(a, n_blocks, st);
 }
 
 // ------------------------------------------------------------------------------------------------

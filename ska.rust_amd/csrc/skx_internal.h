@@ -94,6 +94,7 @@ struct skx_keyset {
     skx::DevBuf<uint32_t> ncnt;      // [1<<logN]
     skx::DevBuf<uint64_t> roff;      // [1<<logN + 1]
     skx::DevBuf<uint64_t> flat;      // lazily built compact copy (engine order words)
+    std::vector<uint64_t> h_roff;    // host copy of roff (windows of a lazily held array)
 };
 
 struct skx_array {
@@ -115,6 +116,15 @@ struct skx_array {
     // 128-bit keys of arrays loaded from k>31 files are kept on the host (filter/align/distance never touch them)
     std::vector<skx_key> host_keys;
     bool keys_absent = false;        // loaded through skx_array_load_filtered: the split k-mer list was stepped over
+    // Lazily held (the build path, 64-bit keys): rows, keys and names are known but the rows x samples matrix has not been
+    // assembled; the dictionaries and the row keyset are kept instead.  `ska build` streams such an array into its .skf window
+    // by window and `ska align *.fa` filters it before any cell is written, so neither ever holds the unfiltered matrix;
+    // every other operation assembles it first (skx::array_materialize).
+    skx_dictset *lazy_dict = nullptr; skx_keyset *lazy_rows = nullptr;
+    bool stats_ready = true;         // present / unambig / mask / vcount filled (lazy arrays get them from a statistics-only pass)
+    bool lazy() const { return lazy_dict != nullptr; }
+    void drop_lazy() { delete lazy_dict; delete lazy_rows; lazy_dict = nullptr; lazy_rows = nullptr; }
+    ~skx_array() { drop_lazy(); }
 };
 
 namespace skx {
@@ -174,6 +184,10 @@ int skf_read_stream(const char *path, SkfMeta &m, std::vector<skx_key> &keys, st
 namespace skx {
 int check_k(int k);                                                  // "Invalid k-mer length" (ska_dict.rs:342-344)
 int array_host_keys(skx_array *a, std::vector<skx_key> &hk);         // the array's split k-mers as the reference stores them, in row order
+int array_materialize(skx_array *a);                                 // a lazily held array gets its matrix (no-op otherwise)
+int array_lazy_stats(skx_array *a);                                  // a lazily held array gets its per-row statistics
+// rows [r0, r0 + nr) of a lazily held array as a sample-major window: cell (s, r) at win + s * wpitch + (r - r0)
+int array_lazy_window(skx_array *a, uint64_t r0, uint64_t nr, DevBuf<uint8_t> &buf, const uint8_t **win, uint64_t *wpitch);
 inline uint64_t pitch_for(uint64_t cols) { return ((cols + 255) / 256) * 256 + 256; }
 inline bool key_less(const skx_key &x, const skx_key &y) { return x.hi != y.hi ? x.hi < y.hi : x.lo < y.lo; }
 inline bool key_eq(const skx_key &x, const skx_key &y) { return x.hi == y.hi && x.lo == y.lo; }

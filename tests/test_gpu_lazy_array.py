@@ -1,0 +1,112 @@
+"""Lazily held arrays (`-m gpu`): skx_build_and_merge returns rows + dictionaries, not a matrix.  `ska build` streams such an
+array into its .skf window by window, `ska align *.fa` filters it before any cell is written; every other operation assembles
+the matrix first.  All of them must give what the eagerly assembled array (SKX_EAGER_ARRAY=1) and the oracle give."""
+import os
+
+import numpy as np
+import pytest
+
+import ora
+
+pytestmark = pytest.mark.gpu
+FILTERS = [(ft, amb, mask, gaps) for ft in range(4) for amb in (False, True) for mask in (False, True) for gaps in (False, True)]
+
+
+@pytest.fixture(scope="module")
+def E():
+    import skx_engine as eng
+    eng.load_library()
+    eng.default_context()
+    return eng
+
+
+def _files(tmp_path, n=9, length=60_000, snps=120, seed=3):
+    rng = np.random.default_rng(seed)
+    anc = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=length)]
+    inputs = []
+    for i in range(n):
+        s = anc.copy()
+        pos = rng.integers(0, length, size=snps)
+        s[pos] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=snps)]
+        if i % 3 == 2:
+            s = s[: length * 2 // 3]                            # missing k-mers
+        seq = s.tobytes()
+        if i % 4 == 1:
+            seq = seq + b"\n>rep\n" + seq[1000:1400]            # a repeat with changed flanks -> ambiguity codes
+            seq = seq[:1200] + b"T" + seq[1201:]
+        p = tmp_path / f"s{i}.fa"
+        with open(p, "wb") as f:
+            f.write(b">c0\n" + seq[: len(seq) // 2] + b"\n>c1\n" + seq[len(seq) // 2:] + b"\n")
+        inputs.append((f"s{i}", str(p), None))
+    return inputs
+
+
+def _sorted(arr):
+    k, v, c = arr.export()
+    o = np.argsort(k["lo"], kind="stable")
+    return k["lo"][o], v[o], c[o]
+
+
+def test_lazy_save_streams_the_same_file_rows(E, tmp_path, monkeypatch):
+    inputs = _files(tmp_path)
+    oa = ora.Array.build(inputs, k=31)
+    want = _sorted(oa)
+    monkeypatch.setenv("SKX_SKF_DEVICE", "1")
+    monkeypatch.setenv("SKX_SKF_GROUP_CHUNKS", "2")              # several windows
+    lazy = E.Array.build(inputs, k=31, threads=3)
+    assert list(lazy.sample_kmers()) == [int(x) for x in (oa.export()[1] != ord("-")).sum(axis=0)]      # answered from the dictionaries
+    p = str(tmp_path / "lazy.skf")
+    lazy.save(p)                                                 # still lazy: windows
+    back = ora.Array.load(p)
+    for x, y in zip(_sorted(back), want):
+        assert np.array_equal(x, y)
+    monkeypatch.setenv("SKX_SKF_DEVICE", "0")                    # host codec: rows fetched block by block
+    p2 = str(tmp_path / "lazy_host.skf")
+    E.Array.build(inputs, k=31, threads=3).save(p2)
+    for x, y in zip(_sorted(ora.Array.load(p2)), want):
+        assert np.array_equal(x, y)
+    # and the materialised array is the same array
+    for x, y in zip(_sorted(lazy), want):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("min_freq", [0.0, 0.5, 0.9, 1.0])
+def test_lazy_filter_writes_only_kept_rows(E, tmp_path, monkeypatch, min_freq):
+    inputs = _files(tmp_path, n=7, length=30_000, seed=11)
+    for ft, amb, mask, gaps in FILTERS:
+        lazy = E.Array.build(inputs, k=15, threads=2)
+        g = lazy.align(filter_type=ft, mask_ambig=mask, ignore_const_gaps=gaps, min_freq=min_freq, filter_ambig_as_missing=amb)
+        monkeypatch.setenv("SKX_EAGER_ARRAY", "1")
+        eager = E.Array.build(inputs, k=15, threads=2)
+        monkeypatch.delenv("SKX_EAGER_ARRAY")
+        e = eager.align(filter_type=ft, mask_ambig=mask, ignore_const_gaps=gaps, min_freq=min_freq, filter_ambig_as_missing=amb)
+        assert g == e, (ft, amb, mask, gaps)                     # same engine order either way: byte-identical
+        oa = ora.Array.build(inputs, k=15)
+        o = oa.align(filter_type=ft, mask_ambig=mask, ignore_const_gaps=gaps, min_freq=min_freq, filter_ambig_as_missing=amb)
+        assert sorted(zip(*g.decode().splitlines()[1::2])) == sorted(zip(*o.decode().splitlines()[1::2])), (ft, amb, mask, gaps)
+
+
+def test_lazy_filter_then_export_and_counts(E, tmp_path):
+    inputs = _files(tmp_path, n=6, length=25_000, seed=21)
+    for ft, amb, mask, gaps in FILTERS[::5]:
+        lazy = E.Array.build(inputs, k=21, threads=2)
+        oa = ora.Array.build(inputs, k=21)
+        assert lazy.filter(3, amb, ft, mask, gaps, True) == oa.filter(3, amb, ft, mask, gaps, True)
+        for x, y in zip(_sorted(lazy), _sorted(oa)):
+            assert np.array_equal(x, y), (ft, amb, mask, gaps)
+
+
+def test_lazy_array_other_operations_materialise(E, tmp_path):
+    inputs = _files(tmp_path, n=5, length=20_000, seed=31)
+    oa = ora.Array.build(inputs, k=31)
+    assert E.Array.build(inputs, k=31).distance_tsv() == ora.Array.build(inputs, k=31).distance_tsv()
+    assert E.Array.build(inputs, k=31).nk(full_info=True) == oa.nk(full_info=True)
+    a = E.Array.build(inputs, k=31)
+    a.delete_samples(["s1", "s3"])
+    o = ora.Array.build(inputs, k=31)
+    o.delete_samples(["s1", "s3"])
+    for x, y in zip(_sorted(a), _sorted(o)):
+        assert np.array_equal(x, y)
+    m = E.Array.merge([E.Array.build(inputs[:2], k=31), E.Array.build(inputs[2:], k=31)])
+    for x, y in zip(_sorted(m), _sorted(oa)):
+        assert np.array_equal(x, y)

@@ -27,5 +27,8 @@ tb,pb=run(["build","-f","list.txt","-o","all","-k","31","--threads",thr],"b.json
 if mode=="sleep": time.sleep(4)
 align_args=["align","all.skf","-o","aln.fa"] + (["--threads",thr] if mode!="nothreads" else [])
 ta,pa=run(align_args,"a.json")
-print({k:v for k,v in pa.items() if k.startswith("fasta")}); print(mode, "build %.2f align %.2f"%(tb,ta), "matrix_alloc", pa.get("load.matrix_alloc"), "hdr", pa.get("load.header_split_kmers"), "ctx", pa.get("main.device_context"), "fasta", pa.get("align.write_fasta"))
+
+print(mode, "build %.2f align %.2f" % (tb, ta))
+print(" build:", {k: round(v, 3) for k, v in pb.items()})
+print(" align:", {k: round(v, 3) for k, v in pa.items()})
 import shutil; shutil.rmtree(td)
