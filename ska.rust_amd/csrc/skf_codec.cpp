@@ -248,8 +248,23 @@ struct Mapped {
         struct stat sb;
         if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { ::close(fd); return false; }
         n = (size_t)sb.st_size;
-        if (n) { void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);   /* one call maps every page: the chunk walk below touches them all */ if (m == MAP_FAILED) { ::close(fd); n = 0; return false; } p = (const uint8_t *)m; }
+        if (n) { void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0); if (m == MAP_FAILED) { ::close(fd); n = 0; return false; } p = (const uint8_t *)m; }
         ::close(fd);
+        // the chunk walk touches every page of the file (a chunk of this data is about one page long): map them from several
+        // threads first instead of taking 700 000 faults one after another (2.8 GB: 0.15-0.27 s -> measured in profiles/)
+        if (n >= (64u << 20)) {
+            const int T = 8;
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; t++) th.emplace_back([this, t, T]() {
+                const size_t a = n / T * t, b = t + 1 == T ? n : n / T * (t + 1);
+#ifdef MADV_POPULATE_READ
+                if (madvise((void *)(p + (a & ~(size_t)4095)), b - (a & ~(size_t)4095), MADV_POPULATE_READ) == 0) return;
+#endif
+                volatile uint8_t sink = 0;
+                for (size_t o = a; o < b; o += 4096) sink = sink + p[o];
+            });
+            for (auto &x : th) x.join();
+        }
         return true;
     }
     size_t size() const { return n; }
@@ -623,7 +638,7 @@ int SkfFile::read_tail(std::vector<uint32_t> &counts)
 }
 
 int skf_write_stream(const char *path, const SkfMeta &m, const std::vector<skx_key> &keys, const std::vector<uint64_t> &counts,
-                     const RowFetch &fetch, int threads, const DevEncode *dev)
+                     const RowFetch &fetch, int threads, const DevEncode *dev, const SkfFastSections *fast)
 {
     threads = n_workers(threads);
     FrameWriter fw;
@@ -638,9 +653,11 @@ int skf_write_stream(const char *path, const SkfMeta &m, const std::vector<skx_k
     w.text("k"); w.head(0, (uint64_t)m.k);
     w.text("rc"); w.b.push_back(m.rc ? 0xf5 : 0xf4);
     w.text("names"); w.head(4, S); for (auto &s : m.names) w.text(s);
-    w.text("split_kmers"); w.head(4, keys.size());
+    const bool fast_keys = fast && fast->keys_cbor;
+    w.text("split_kmers"); w.head(4, fast_keys ? fast->n_keys : keys.size());
     flush();
-    for (size_t i0 = 0; i0 < keys.size(); i0 += (4u << 20)) {              // slices of the list are encoded by the team, then appended in order
+    if (fast_keys) fw.append(fast->keys_cbor, fast->keys_cbor_len);
+    for (size_t i0 = 0; !fast_keys && i0 < keys.size(); i0 += (4u << 20)) {              // slices of the list are encoded by the team, then appended in order
         const size_t cnt = std::min<size_t>(4u << 20, keys.size() - i0), parts = std::max<size_t>(1, std::min<size_t>((size_t)threads, cnt / 4096));
         std::vector<Writer> ws(parts);
         parallel_for(parts, threads, [&](size_t pt) {
@@ -713,8 +730,21 @@ int skf_write_stream(const char *path, const SkfMeta &m, const std::vector<skx_k
     }
     phase_add("save.data_section", secs(t_mark, now()));
     t_mark = now();
-    w.text("variant_count"); w.head(4, counts.size());
-    for (size_t i = 0; i < counts.size(); i++) { w.head(0, counts[i]); if (w.b.size() >= (1u << 20)) flush(); }
+    if (fast && fast->counts32) {
+        w.text("variant_count"); w.head(4, fast->n_counts);
+        flush();
+        const size_t cnt = fast->n_counts, parts = std::max<size_t>(1, std::min<size_t>((size_t)threads, cnt / 65536));
+        std::vector<Writer> ws(parts);
+        parallel_for(parts, threads, [&](size_t pt) {
+            const size_t a = cnt * pt / parts, b = cnt * (pt + 1) / parts;
+            ws[pt].b.reserve((b - a) * 3 + 16);
+            for (size_t i = a; i < b; i++) ws[pt].head(0, fast->counts32[i]);
+        });
+        for (auto &x : ws) fw.append(x.b.data(), x.b.size());
+    } else {
+        w.text("variant_count"); w.head(4, counts.size());
+        for (size_t i = 0; i < counts.size(); i++) { w.head(0, counts[i]); if (w.b.size() >= (1u << 20)) flush(); }
+    }
     w.text("ska_version"); w.text(m.version);
     w.text("k_bits"); w.head(0, (uint64_t)m.k_bits);
     flush();

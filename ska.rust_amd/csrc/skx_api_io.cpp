@@ -247,14 +247,32 @@ extern "C" int skx_array_save(skx_array *a, const char *path)
     const uint64_t U = a->n_rows, S = a->names.size();
     if (a->n_kmers != a->n_rows || a->keys_absent) { set_error("split k-mers and variants are out of step (filtered without update_kmers): such an array cannot be loaded back"); return SKX_EINVAL; }
     SkfMeta m; m.k = a->k; m.rc = a->rc; m.k_bits = a->k_bits; m.names = a->names; m.version = a->version; m.n_rows = U;
+    // split k-mers: 64-bit keys held on the device leave as finished CBOR (9 bytes each) through a pinned buffer; wider ones, keys
+    // kept on the host and lists with a key below 2^32 (shorter minimal form) are encoded by the host team
     std::vector<skx_key> keys;
+    SkfFastSections fast;
+    struct PinnedBuf { uint8_t *p = nullptr; ~PinnedBuf() { if (p) (void)hipHostFree(p); } } pin_keys, pin_counts;
     const auto t_k0 = std::chrono::steady_clock::now();
-    SKX_TRY(array_host_keys(a, keys));
+    if (a->k <= 31 && a->keys.p && U && !a->keys_absent && a->n_kmers == U && !getenv("SKX_SKF_HOST_KEYS")) {
+        DevBuf<uint8_t> d_kc; DevBuf<int> d_short;
+        SKX_TRY(d_kc.alloc(9 * U + 64)); SKX_TRY(d_short.alloc(1)); SKX_TRY(d_short.zero(st));
+        launch_keys_cbor(a->keys.p, U, a->hp, d_kc.p, d_short.p, st);
+        if (hipHostMalloc((void **)&pin_keys.p, 9 * U + 64, hipHostMallocDefault) != hipSuccess) { pin_keys.p = nullptr; set_error("out of host memory"); return SKX_ENOMEM; }
+        int is_short = 0;
+        SKX_HIP(hipMemcpyAsync(pin_keys.p, d_kc.p, 9 * U, hipMemcpyDeviceToHost, st));
+        SKX_HIP(hipMemcpyAsync(&is_short, d_short.p, 4, hipMemcpyDeviceToHost, st));
+        SKX_HIP(hipStreamSynchronize(st));
+        if (!is_short) { fast.keys_cbor = pin_keys.p; fast.keys_cbor_len = 9 * U; fast.n_keys = U; }
+    }
+    if (!fast.keys_cbor) SKX_TRY(array_host_keys(a, keys));
     phase_add("save.keys_to_host", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_k0).count());
     SKX_TRY(array_lazy_stats(a));              // a lazily held array: the stored counts come from a statistics-only pass
-    std::vector<uint32_t> vc(U);
-    if (U) SKX_HIP(hipMemcpy(vc.data(), a->vcount.p, U * 4, hipMemcpyDeviceToHost));
-    std::vector<uint64_t> counts(vc.begin(), vc.end());
+    std::vector<uint64_t> counts;
+    if (U) {
+        if (hipHostMalloc((void **)&pin_counts.p, U * 4, hipHostMallocDefault) != hipSuccess) { pin_counts.p = nullptr; set_error("out of host memory"); return SKX_ENOMEM; }
+        SKX_HIP(hipMemcpy(pin_counts.p, a->vcount.p, U * 4, hipMemcpyDeviceToHost));
+        fast.counts32 = (const uint32_t *)pin_counts.p; fast.n_counts = U;
+    }
     DevBuf<uint8_t> d_blk, d_win;
     uint64_t blk_cap = 0;
     // rows [r0, r0 + nr) sample-major: a slice of the matrix, or -- lazily held array -- a window assembled for the occasion
@@ -318,7 +336,7 @@ extern "C" int skx_array_save(skx_array *a, const char *path)
         return SKX_OK;
     };
     const auto t_w0 = std::chrono::steady_clock::now();
-    const int r = skf_write_stream(path, m, keys, counts, fetch, 0, &dev_encode);
+    const int r = skf_write_stream(path, m, keys, counts, fetch, 0, &dev_encode, &fast);
     phase_add("save.total_stream", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_w0).count());
     return r;
     });

@@ -144,6 +144,8 @@ void launch_assemble(const AssembleArgs &a, hipStream_t st, int mode = 0, uint32
 void launch_gather_keys(const uint64_t *stage, uint32_t stride, const uint32_t *ncnt, const uint64_t *roff, int n_sub,
                         uint64_t *out, int unhash, HashParams hp, hipStream_t st);
 void launch_hash_keys(const uint64_t *keys, uint64_t *words, uint64_t n, HashParams hp, hipStream_t st);
+// packed words -> the .skf's split k-mer list (9 bytes of CBOR per key, out padded to 9 n + 16); *short_key = 1 if a key needs fewer
+void launch_keys_cbor(const uint64_t *words, uint64_t n, HashParams hp, uint8_t *out, int *short_key, hipStream_t st);
 void launch_unhash_dict(const uint64_t *words, uint64_t n, uint64_t *keys, uint8_t *bases, HashParams hp, hipStream_t st);
 
 // column statistics of a sample-major matrix (for arrays that did not come from assemble)

@@ -1006,6 +1006,30 @@ void launch_gather_keys(const uint64_t *stage, uint32_t stride, const uint32_t *
 {
     hipLaunchKernelGGL(gather_keys_kernel, dim3((unsigned)n_sub), dim3(256), 0, st, stage, stride, ncnt, roff, out, unhash, hp);
 }
+// split k-mers as the .skf stores them: CBOR uints, 0x1b + 8 big-endian bytes each (a key below 2^32 has a shorter minimal form:
+// *short_key is set and the host encodes the list instead).  256 keys per workgroup through LDS, written as dwords.
+__global__ __launch_bounds__(256) void keys_cbor_kernel(const uint64_t *words, uint64_t n, HashParams hp, uint8_t *out, int *short_key)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_b[256 * 9 + 12];
+    const uint64_t i0 = (uint64_t)blockIdx.x * 256, i = i0 + threadIdx.x;
+    if (i < n) {
+        const uint64_t key = hunmix(words[i] >> 4, hp);
+        if (key <= 0xFFFFFFFFull) *short_key = 1;
+        uint8_t *p = s_b + 9 * threadIdx.x;
+        p[0] = 0x1b;
+#pragma unroll
+        for (int b = 0; b < 8; b++) p[1 + b] = (uint8_t)(key >> (56 - 8 * b));
+    }
+    __syncthreads();
+    const uint32_t nb = (uint32_t)((n - i0 < 256 ? n - i0 : 256) * 9);
+    uint8_t *dst = out + i0 * 9;                                   // 2304 i0: dword aligned
+    for (uint32_t v = threadIdx.x; v < (nb + 3) / 4; v += 256) reinterpret_cast<uint32_t *>(dst)[v] = reinterpret_cast<const uint32_t *>(s_b)[v];   // the buffer is padded past 9 n
+}
+void launch_keys_cbor(const uint64_t *words, uint64_t n, HashParams hp, uint8_t *out, int *short_key, hipStream_t st)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(keys_cbor_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, words, n, hp, out, short_key);
+}
 __global__ void hash_keys_kernel(const uint64_t *keys, uint64_t *words, uint64_t n, HashParams hp)
 {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)

@@ -173,8 +173,11 @@ struct SkfFile {
     int read_tail(std::vector<uint32_t> &counts);           // variant_count + ska_version + k_bits (fills m.version / m.k_bits)
     const uint8_t *file() const; const SkfChunk *chunks() const; size_t n_chunks() const;
 };
+// optional shortcuts of skf_write_stream: the split k-mer list already as CBOR bytes (the device writes 9-byte uints), the counts
+// as 32-bit values (encoded by the thread team); when set, `keys` / `counts` are ignored
+struct SkfFastSections { const uint8_t *keys_cbor = nullptr; uint64_t keys_cbor_len = 0, n_keys = 0; const uint32_t *counts32 = nullptr; uint64_t n_counts = 0; };
 int skf_write_stream(const char *path, const SkfMeta &m, const std::vector<skx_key> &keys, const std::vector<uint64_t> &counts,
-                     const RowFetch &fetch, int threads, const DevEncode *dev = nullptr);
+                     const RowFetch &fetch, int threads, const DevEncode *dev = nullptr, const SkfFastSections *fast = nullptr);
 int skf_read_stream(const char *path, SkfMeta &m, std::vector<skx_key> &keys, std::vector<uint64_t> &counts,
                     const std::function<int(uint64_t n_rows, uint64_t n_samples)> &begin_rows, const RowSink &sink, int threads,
                     const DevDecode *dev = nullptr);
