@@ -150,6 +150,10 @@ int  skx_array_sample_kmers(skx_array *a, int64_t *out);
 /* MergeSkaArray::filter (merge_ska_array.rs:289-402); *removed = its i32 return value */
 int  skx_array_filter(skx_array *a, uint64_t min_count, int filter_ambig_as_missing, int filter_type,
                       int mask_ambig, int ignore_const_gaps, int update_kmers, int32_t *removed);
+/* Optional hint before skx_array_load_filtered: the array about to be loaded will be written with skx_array_write_fasta to `fd` (a
+ * regular file opened read-write, at its current offset).  The engine then allocates the file's pages while the rows are still
+ * being read -- page allocation, not copying, is what bounds a 5 GB alignment on tmpfs.  No effect on the bytes written. */
+int  skx_ctx_expect_output(skx_ctx *ctx, int fd);
 /* write_fasta (merge_ska_array.rs:499-517): ">name\nSEQ\n" per sample to fd */
 int  skx_array_write_fasta(skx_array *a, int fd);
 /* same into a malloc'd buffer (free with skx_free) */

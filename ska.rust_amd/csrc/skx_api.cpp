@@ -134,6 +134,51 @@ int skx::check_k(int k)
     return SKX_OK;
 }
 
+// ------------------------------------------------------------------------------------------ output page allocation
+skx::Preallocator::Preallocator(int fd_, off_t base_) : fd(fd_), base(base_)
+{
+    th = std::thread([this]() {
+        constexpr uint64_t STEP = 256ull << 20;
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [this] { return stop || done < target; });
+            if (stop && done >= target) return;
+            const uint64_t o = done, n = std::min(STEP, target - done);
+            lk.unlock();
+            (void)posix_fallocate(fd, base + (off_t)o, (off_t)n);          // on failure the writer's page faults do the allocation
+            lk.lock();
+            done = o + n;
+            cv.notify_all();
+        }
+    });
+}
+skx::Preallocator::~Preallocator() { { std::lock_guard<std::mutex> lk(mu); stop = true; target = done; } cv.notify_all(); if (th.joinable()) th.join(); }
+void skx::Preallocator::raise(uint64_t bytes) { { std::lock_guard<std::mutex> lk(mu); if (bytes > target) target = bytes; } cv.notify_all(); }
+void skx::Preallocator::finish(uint64_t bytes)
+{
+    std::unique_lock<std::mutex> lk(mu);
+    if (bytes > target) target = bytes;
+    cv.notify_all();
+    cv.wait(lk, [&] { return done >= bytes; });
+}
+// a regular file, opened read-write and not in append mode, can be written through a mapping
+bool skx::mappable_output_fd(int fd, off_t *pos)
+{
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) return false;
+    const int fl = fcntl(fd, F_GETFL);
+    if (fl < 0 || (fl & O_APPEND) || (fl & O_ACCMODE) != O_RDWR) return false;
+    *pos = lseek(fd, 0, SEEK_CUR);
+    return *pos >= 0;
+}
+extern "C" int skx_ctx_expect_output(skx_ctx *ctx, int fd)
+{
+    if (!ctx) return SKX_EINVAL;
+    off_t pos;
+    ctx->expect_fd = (fd >= 0 && mappable_output_fd(fd, &pos) && !getenv("SKX_NO_MMAP_OUTPUT")) ? fd : -1;
+    return SKX_OK;
+}
+
 // ------------------------------------------------------------------------------------------ ctx
 extern "C" int skx_ctx_create(int device, skx_ctx **out)
 {
@@ -1543,15 +1588,15 @@ extern "C" int skx_array_write_fasta(skx_array *a, int fd)
     // costs ~1 us and does not scale over the threads of one file; fallocate does ~12 GB/s on tmpfs, and copies that run beside
     // it contend with it: 4.9 GB in 0.8 s this way, 1.0 s with the copies chasing the allocation, 1.0-1.4 s through
     // write()/pwrite() -- tools/fasta_knobs.py); the first batches come off the device meanwhile
-    std::atomic<uint64_t> backed{0};
+    std::shared_ptr<Preallocator> pre;
+    std::atomic<bool> backed{false};
     struct Joiner { std::thread th; ~Joiner() { if (th.joinable()) th.join(); } } falloc;
-    if (map) falloc.th = std::thread([&backed, fd, pos, total]() {
-        constexpr uint64_t STEP = 256ull << 20;
-        for (uint64_t o = 0; o < total; o += STEP) {
-            (void)posix_fallocate(fd, pos + (off_t)o, (off_t)std::min(STEP, total - o));      // on failure the page faults do the allocation
-        }
-        backed.store(~0ull, std::memory_order_release);
-    });
+    if (map) {
+        if (a->prealloc && a->prealloc->fd == fd && a->prealloc->base == pos) pre = a->prealloc;      // started while the rows were being read
+        else pre = std::make_shared<Preallocator>(fd, pos);
+        a->prealloc.reset();
+        falloc.th = std::thread([&backed, pre, total]() { pre->finish(total); backed.store(true, std::memory_order_release); });
+    }
     const size_t cap = std::max<size_t>(max_rec, map ? (32u << 20) : (64u << 20));
     auto knob = [](const char *name, int dflt) { const char *e = getenv(name); const int v = e ? atoi(e) : 0; return v > 0 ? v : dflt; };
     const int NB = map ? std::min(6, knob("SKX_FASTA_NB", 4)) : (regular && !append && pos >= 0 ? 6 : 2);
@@ -1586,7 +1631,7 @@ extern "C" int skx_array_write_fasta(skx_array *a, int fd)
             for (int t = 0; t < KT; t++) {
                 const size_t lo = used * (size_t)t / KT, hi = used * (size_t)(t + 1) / KT;
                 sl.th.emplace_back([dst, buf, lo, hi, &backed]() {
-                    while (backed.load(std::memory_order_acquire) != ~0ull) usleep(100);
+                    while (!backed.load(std::memory_order_acquire)) usleep(100);
                     memcpy(dst + lo, buf + lo, hi - lo);
                 });
             }

@@ -540,6 +540,14 @@ extern "C" int skx_array_load_filtered(skx_ctx *ctx, const char *path, const skx
     std::vector<SnapChunk> tab;
     uint64_t src_cap = 0, row_lo = 0, have_hi = 0;
     int cur = 0;
+    // the alignment's destination, when the caller announced it: its pages are allocated as the kept rows accumulate
+    uint64_t name_bytes = 0;
+    for (auto &nm : a->names) name_bytes += nm.size() + 3;
+    if (ctx->expect_fd >= 0 && !f->two_stage) {
+        off_t opos;
+        if (mappable_output_fd(ctx->expect_fd, &opos)) a->prealloc = std::make_shared<Preallocator>(ctx->expect_fd, opos);
+    }
+    ctx->expect_fd = -1;
     for (size_t g0 = c0; g0 < c1; g0 += G) {
         const size_t g1 = std::min<size_t>(c1, g0 + G);
         const size_t f_lo = ch[g0].off, f_hi = ch[g1 - 1].off + ch[g1 - 1].len;
@@ -556,6 +564,7 @@ extern "C" int skx_array_load_filtered(skx_ctx *ctx, const char *path, const skx
         const uint8_t *in = d_cells[cur].p + (row_lo * S - base_cell);
         const uint64_t nr = row_done - row_lo;
         uint64_t gk = 0;
+        if (a->prealloc && kept) a->prealloc->raise(name_bytes + S * kept);
         if (nr) {
             launch_row_stats_rm(in, S, nr, present.p + row_lo, unambig.p + row_lo, mask.p + row_lo, d_bad.p, st);
             FilterArgs fa{present.p + row_lo, present.p + row_lo, unambig.p + row_lo, mask.p + row_lo, nr, (uint32_t)S, thr, f->two_stage ? 0 : f->filter_ambig_as_missing,

@@ -4,8 +4,13 @@
 #include "skx_device.h"
 #include <chrono>
 #include <cstdio>
+#include <condition_variable>
 #include <functional>
+#include <memory>
+#include <mutex>
 #include <new>
+#include <thread>
+#include <sys/types.h>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -57,7 +62,22 @@ struct DevBuf {
 
 }  // namespace skx
 
+namespace skx {
+// allocates the page-cache pages of a file range ahead of the writer (posix_fallocate in steps on its own thread): the target can
+// be raised while the data that will fill the range is still being produced
+struct Preallocator {
+    int fd; off_t base;
+    std::mutex mu; std::condition_variable cv; uint64_t target = 0, done = 0; bool stop = false;
+    std::thread th;
+    Preallocator(int fd_, off_t base_);
+    ~Preallocator();
+    void raise(uint64_t bytes);            // pages of [base, base + bytes) wanted
+    void finish(uint64_t bytes);           // raise, then wait until they are there
+};
+}  // namespace skx
+
 struct skx_ctx {
+    int expect_fd = -1;              // skx_ctx_expect_output: where the next alignment goes (pages allocated while its rows are read)
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
@@ -116,6 +136,7 @@ struct skx_array {
     // 128-bit keys of arrays loaded from k>31 files are kept on the host (filter/align/distance never touch them)
     std::vector<skx_key> host_keys;
     bool keys_absent = false;        // loaded through skx_array_load_filtered: the split k-mer list was stepped over
+    std::shared_ptr<skx::Preallocator> prealloc;   // output pages being allocated for skx_array_write_fasta (skx_ctx_expect_output)
     // Lazily held (the build path, 64-bit keys): rows, keys and names are known but the rows x samples matrix has not been
     // assembled; the dictionaries and the row keyset are kept instead.  `ska build` streams such an array into its .skf window
     // by window and `ska align *.fa` filters it before any cell is written, so neither ever holds the unfiltered matrix;
@@ -186,6 +207,7 @@ int skf_read_stream(const char *path, SkfMeta &m, std::vector<skx_key> &keys, st
 // helpers shared by the ABI translation units (skx_api.cpp, skx_api_io.cpp)
 namespace skx {
 int check_k(int k);                                                  // "Invalid k-mer length" (ska_dict.rs:342-344)
+bool mappable_output_fd(int fd, off_t *pos);                         // regular file, read-write, not O_APPEND: can be written through a mapping
 int array_host_keys(skx_array *a, std::vector<skx_key> &hk);         // the array's split k-mers as the reference stores them, in row order
 int array_materialize(skx_array *a);                                 // a lazily held array gets its matrix (no-op otherwise)
 int array_lazy_stats(skx_array *a);                                  // a lazily held array gets its per-row statistics
