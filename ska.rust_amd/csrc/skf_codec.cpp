@@ -241,7 +241,7 @@ struct FrameWriter {
 struct Mapped {
     const uint8_t *p = nullptr; size_t n = 0;
     ~Mapped() { if (p && n) munmap((void *)p, n); }
-    bool open(const char *path)
+    bool open(const char *path, bool populate = true)
     {
         const int fd = ::open(path, O_RDONLY);
         if (fd < 0) return false;
@@ -252,7 +252,7 @@ struct Mapped {
         ::close(fd);
         // the chunk walk touches every page of the file (a chunk of this data is about one page long): map them from several
         // threads first instead of taking 700 000 faults one after another (2.8 GB: 0.15-0.27 s -> measured in profiles/)
-        if (n >= (64u << 20)) {
+        if (populate && n >= (64u << 20)) {
             const int T = 8;
             std::vector<std::thread> th;
             for (int t = 0; t < T; t++) th.emplace_back([this, t, T]() {
@@ -279,23 +279,50 @@ struct FrameReader {
     std::vector<uint8_t> buf; size_t pos = 0;       // decoded bytes not yet consumed: buf[pos ..)
     uint64_t ubase = 0, total_ulen = 0;             // stream offset of buf[0]; length of the whole uncompressed stream
     uint64_t upos() const { return ubase + pos; }
+    // The chunk walk can run on its own thread (open_async): `chunks` is reserved up front, so published entries never move, and
+    // readers wait for the entries they need -- the device starts decoding the first rows while the walk is still far from the
+    // end of the file.  walk_state: 0 finished, 1 running, 2 failed (err says why).
+    std::atomic<size_t> n_pub{0};
+    std::atomic<int> walk_state{0};
+    std::thread walker;
+    ~FrameReader() { if (walker.joinable()) walker.join(); }
+    size_t published() const { return n_pub.load(std::memory_order_acquire); }
+    bool walking() const { return walk_state.load(std::memory_order_acquire) == 1; }
+    bool wait_for(size_t idx)                       // chunk idx published?  (false: the walk ended before it)
+    {
+        for (;;) {
+            if (published() > idx) return true;
+            if (!walking()) return published() > idx;
+            usleep(50);
+        }
+    }
+    bool wait_covering(uint64_t u)                  // until a published chunk ends beyond stream offset u, or the walk is over
+    {
+        for (;;) {
+            const size_t n = published();
+            if (n && chunks[n - 1].uoff + chunks[n - 1].ulen > u) return true;
+            if (!walking()) { const size_t m = published(); return m && chunks[m - 1].uoff + chunks[m - 1].ulen > u; }
+            usleep(50);
+        }
+    }
     bool seek(uint64_t u)                           // continue reading at stream offset u
     {
-        if (u > total_ulen) return false;
-        size_t lo = 0, hi = chunks.size();
+        (void)wait_covering(u);
+        if (!walking() && u > total_ulen) return false;
+        size_t lo = 0, hi = published();
+        const size_t n = hi;
         while (lo < hi) { const size_t mid = (lo + hi) / 2; if (chunks[mid].uoff + chunks[mid].ulen <= u) lo = mid + 1; else hi = mid; }
         buf.clear(); pos = 0; next_chunk = lo;
-        ubase = lo < chunks.size() ? chunks[lo].uoff : total_ulen;
+        ubase = lo < n ? chunks[lo].uoff : total_ulen;
         if (u > ubase) { if (!fill((size_t)(u - ubase))) return false; pos = (size_t)(u - ubase); }
         return true;
     }
     const char *err = nullptr;
 
-    bool open(const char *path, int nthreads)
+    bool walk()                                     // the file's chunk directory; publishes as it goes
     {
-        threads = nthreads;
-        if (!raw.open(path)) { err = "open"; return false; }
-        size_t i = 0; bool seen = false;
+        size_t i = 0; bool seen = false; uint64_t tot = 0;
+        const size_t cap = chunks.capacity();
         while (i < raw.size()) {
             if (i + 4 > raw.size()) { err = "skf: truncated frame"; return false; }
             const uint8_t type = raw[i]; const size_t len = raw[i + 1] | ((size_t)raw[i + 2] << 8) | ((size_t)raw[i + 3] << 16);
@@ -307,12 +334,33 @@ struct FrameReader {
                 Chunk c; c.off = i + 4; c.len = len - 4; c.compressed = type == 0x00; memcpy(&c.crc, &raw[i], 4);
                 c.ulen = c.compressed ? snappy_ulen(&raw[c.off], c.len, nullptr) : (uint32_t)c.len;
                 if (c.ulen == 0xFFFFFFFFu || c.ulen > CHUNK) { err = "skf: corrupt snappy block"; return false; }
-                c.uoff = total_ulen; total_ulen += c.ulen;
+                c.uoff = tot; tot += c.ulen;
+                if (cap && chunks.size() == cap) { err = "skf: more chunks than reserved"; return false; }       // asynchronous walk: entries must not move
                 chunks.push_back(c);
+                if ((chunks.size() & 255u) == 0) n_pub.store(chunks.size(), std::memory_order_release);
             } else if (type < 0x80) { err = "skf: unsupported chunk type"; return false; }
             i += len;
         }
         if (!seen) { err = "skf: not a snappy stream"; return false; }
+        total_ulen = tot;
+        n_pub.store(chunks.size(), std::memory_order_release);
+        return true;
+    }
+    bool open(const char *path, int nthreads)
+    {
+        threads = nthreads;
+        if (!raw.open(path)) { err = "open"; return false; }
+        const bool ok = walk();
+        n_pub.store(chunks.size(), std::memory_order_release);
+        return ok;
+    }
+    bool open_async(const char *path, int nthreads)
+    {
+        threads = nthreads;
+        if (!raw.open(path, false)) { err = "open"; return false; }
+        chunks.reserve(raw.size() / 512 + 4096);         // virtual until used; a chunk of 64 KB rarely compresses below 3 KB
+        walk_state.store(1, std::memory_order_release);
+        walker = std::thread([this]() { const bool ok = walk(); walk_state.store(ok ? 0 : 2, std::memory_order_release); });
         return true;
     }
     size_t avail() const { return buf.size() - pos; }
@@ -325,11 +373,13 @@ struct FrameReader {
     {
         const auto t_f0 = std::chrono::steady_clock::now();
         struct Acc { double &a; std::chrono::steady_clock::time_point t; ~Acc() { a += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); } } acc{fill_secs, t_f0};
-        while (avail() < need && next_chunk < chunks.size()) {
+        while (avail() < need && wait_for(next_chunk)) {
             if (pos) { buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)pos); ubase += pos; pos = 0; }
             size_t last = next_chunk, add = 0;
             const size_t lim = fill_limit ? std::max(fill_limit, need) : SUPER;
-            while (last < chunks.size() && add < lim) add += chunks[last++].ulen;
+            if (!fill_limit && walking()) (void)wait_for(next_chunk + SUPER / CHUNK);      // a whole super-block's chunks, if they are coming
+            const size_t n_now = published();
+            while (last < n_now && add < lim) add += chunks[last++].ulen;
             const size_t base = buf.size();
             buf.resize(base + add);
             std::vector<size_t> at(last - next_chunk);
@@ -558,19 +608,30 @@ SkfFile::SkfFile() : impl(new Impl()) {}
 SkfFile::~SkfFile() { delete impl; }
 const uint8_t *SkfFile::file() const { return impl->fr.raw.data(); }
 const SkfChunk *SkfFile::chunks() const { return impl->fr.chunks.data(); }
-size_t SkfFile::n_chunks() const { return impl->fr.chunks.size(); }
+size_t SkfFile::n_chunks() const { return impl->fr.published(); }
+bool SkfFile::wait_chunk(size_t idx) { return impl->fr.wait_for(idx); }
+int SkfFile::walk_result()
+{
+    FrameReader &fr = impl->fr;
+    while (fr.walking()) usleep(50);
+    if (fr.walk_state.load() == 2) { set_error("%s", fr.err ? fr.err : "skf: read failed"); return SKX_EFORMAT; }
+    if (upos_data + 2 * m.n_rows * (uint64_t)m.names.size() > fr.total_ulen) { set_error("skf: truncated frame"); return SKX_EFORMAT; }
+    return SKX_OK;
+}
+size_t SkfFile::chunk_of(uint64_t u)
+{
+    FrameReader &fr = impl->fr;
+    (void)fr.wait_covering(u);
+    size_t lo = 0, hi = fr.published();
+    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (fr.chunks[mid].uoff + fr.chunks[mid].ulen <= u) lo = mid + 1; else hi = mid; }
+    return lo;
+}
 // Header, then the split k-mer list is stepped over without being decoded: it is U uints, 9 bytes each unless a key is below
 // 2^32 (then the bytes at +9U are not the "variants" field and the caller takes the general reader).
 int SkfFile::open(const char *path)
 {
     FrameReader &fr = impl->fr;
-    PhaseTimer t_open("load.map_file_chunk_directory");
-    const bool opened = fr.open(path, n_workers(0));
-    t_open.stop();
-    if (!opened) {
-        if (fr.err && !strcmp(fr.err, "open")) { set_error("cannot open %s", path); return SKX_EIO; }
-        set_error("%s", fr.err ? fr.err : "skf: read failed"); return SKX_EFORMAT;
-    }
+    if (!fr.open_async(path, n_workers(0))) { set_error("cannot open %s", path); return SKX_EIO; }      // the chunk walk runs beside everything below
     PhaseTimer t_hdr("load.header");
     fr.fill_limit = 1u << 20;
     Reader rd(fr);
@@ -600,8 +661,7 @@ int SkfFile::open(const char *path)
     if (!rd.ok || d0 != n_keys || d1 != m.names.size() || nd != d0 * d1) return SKF_NOT_TAKEN;
     m.n_rows = d0;
     upos_data = fr.upos();
-    if (upos_data + 2 * nd > fr.total_ulen) return SKF_NOT_TAKEN;
-    return SKX_OK;
+    return SKX_OK;                                   // whether the stream really holds 2 nd more bytes: walk_result()
 }
 // what follows the data section: variant_count, ska_version, k_bits
 int SkfFile::read_tail(std::vector<uint32_t> &counts)

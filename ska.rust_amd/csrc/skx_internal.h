@@ -192,7 +192,10 @@ struct SkfFile {
     SkfFile(const SkfFile &) = delete; SkfFile &operator=(const SkfFile &) = delete;
     int open(const char *path);
     int read_tail(std::vector<uint32_t> &counts);           // variant_count + ska_version + k_bits (fills m.version / m.k_bits)
-    const uint8_t *file() const; const SkfChunk *chunks() const; size_t n_chunks() const;
+    const uint8_t *file() const; const SkfChunk *chunks() const;
+    // the chunk directory is filled in by a walker thread: entries below n_chunks() are final and never move
+    size_t n_chunks() const; bool wait_chunk(size_t idx); size_t chunk_of(uint64_t stream_offset);
+    int walk_result();                                      // waits for the walk: SKX_OK, or the file's framing error
 };
 // optional shortcuts of skf_write_stream: the split k-mer list already as CBOR bytes (the device writes 9-byte uints), the counts
 // as 32-bit values (encoded by the thread team); when set, `keys` / `counts` are ignored
