@@ -1201,16 +1201,19 @@ extern "C" int skx_array_export(skx_array *a, skx_key *keys, uint8_t *variants, 
     return skx_guarded([&]() -> int {
     skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
     SKX_HIP(hipSetDevice(ctx->device));
-    SKX_TRY(array_materialize(a));
+    if (variants) SKX_TRY(array_materialize(a)); else SKX_TRY(array_lazy_stats(a));
     const uint64_t U = a->n_rows, S = a->names.size(), K = a->n_kmers;
     std::vector<skx_key> hk;
     SKX_TRY(array_host_keys(a, hk));
-    std::vector<uint8_t> rm(U * S);
+    std::vector<uint8_t> rm(variants ? U * S : 0);              // keys / counts alone (variants == NULL) never move the matrix
     std::vector<uint32_t> pres(U);
     if (U) {
-        DevBuf<uint8_t> d_rm; SKX_TRY(d_rm.alloc(U * S));
-        launch_transpose(a->matrix.p, a->pitch, S, U, d_rm.p, S, st);
-        SKX_HIP(hipMemcpyAsync(rm.data(), d_rm.p, U * S, hipMemcpyDeviceToHost, st));
+        if (variants) {
+            DevBuf<uint8_t> d_rm; SKX_TRY(d_rm.alloc(U * S));
+            launch_transpose(a->matrix.p, a->pitch, S, U, d_rm.p, S, st);
+            SKX_HIP(hipMemcpyAsync(rm.data(), d_rm.p, U * S, hipMemcpyDeviceToHost, st));
+            SKX_HIP(hipStreamSynchronize(st));
+        }
         SKX_HIP(hipMemcpyAsync(pres.data(), a->vcount.p, U * 4, hipMemcpyDeviceToHost, st));
         SKX_HIP(hipStreamSynchronize(st));
     }

@@ -471,6 +471,23 @@ extern "C" int skh_main(int argc, char **argv)
             else a.opt.emplace_back(s, "");
         } else a.pos.push_back(s);
     }
+    {   // clap rejects what a subcommand does not declare (cli.rs:109-330); -v / --verbose is global (cli.rs:103-104)
+        static const struct { const char *cmd; const char *flags; } KNOWN[] = {
+            {"build", " -o -k -f --proportion-reads --single-strand --min-count --min-qual --qual-filter --threads "},
+            {"align", " -o -m --min-freq --filter-ambig-as-missing --filter --ambig-mask --no-gap-only-sites --threads "},
+            {"map", " -o -f --format --ambig-mask --repeat-mask --threads "},
+            {"distance", " -o -m --min-freq --allow-ambiguous --threads "},
+            {"merge", " -o "}, {"delete", " -s --skf-file -o -f "},
+            {"weed", " -o --reverse -m --min-freq --filter-ambig-as-missing --filter --ambig-mask --no-gap-only-sites "},
+            {"nk", " --full-info "}, {"cov", " -k --single-strand "}};
+        for (auto &kc : KNOWN)
+            if (cmd == kc.cmd)
+                for (auto &o : a.opt)
+                    if (o.first != "-v" && o.first != "--verbose" && !strstr(kc.flags, (" " + o.first + " ").c_str())) {
+                        fprintf(stderr, "error: unexpected argument '%s' found\n\nUsage: ska %s [OPTIONS]\n\nFor more information, try '--help'.\n", o.first.c_str(), cmd.c_str());
+                        return 2;
+                    }
+    }
     int threads = atoi(a.get("--threads", "1").c_str());
     if (threads < 1) return fail("Threads must be one or higher");
     const auto t_main = std::chrono::steady_clock::now();

@@ -506,6 +506,14 @@ class Array:
         _check(_lib.skx_array_export(self.h, _np_ptr(keys), _np_ptr(var), _np_ptr(counts)))
         return keys, var, counts
 
+    def export_keys(self):
+        """split k-mers (sorted) and their counts without moving the matrix"""
+        info = self._info()
+        keys = np.zeros(info.n_kmers, KEY_DT)
+        counts = np.zeros(info.n_rows, np.uint64)
+        _check(_lib.skx_array_export(self.h, _np_ptr(keys), None, _np_ptr(counts)))
+        return keys, counts
+
     def sample_kmers(self):
         out = np.zeros(self.nsamples, np.int64)
         _check(_lib.skx_array_sample_kmers(self.h, _np_ptr(out)))

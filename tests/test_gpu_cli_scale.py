@@ -266,3 +266,48 @@ def test_full_size_lifecycle_and_map(big, tmp_path):
     seqs = g.split(b"\n")[1::2]
     assert [len(x) for x in seqs] == [5_000_000, 5_000_000] and seqs[0].count(b"-") < 50_000
     assert two.map(ref, fmt="vcf") == otwo.map(ref, fmt="vcf")
+
+
+def test_cli_rejects_unknown_flags_like_clap(tmp_path):
+    """cli.rs:109-330: an argument a subcommand does not declare is an error (exit code 2), not a silently ignored boolean."""
+    wd = str(tmp_path)
+    for args in (["build", "-o", "x", "--no-such-flag", G.fin("test_1.fa"), G.fin("test_2.fa")],
+                 ["align", G.fin("merge.skf"), "--allow-ambiguous"],            # a `distance` flag
+                 ["distance", G.fin("merge.skf"), "--filter", "no-const"],      # an `align` flag
+                 ["nk", G.fin("merge.skf"), "--threads", "2"],
+                 ["merge", G.fin("merge.skf"), G.fin("merge_k9.skf"), "-o", "m", "--reverse"]):
+        rc, out, err = ska(*args, cwd=wd)
+        assert rc == 2 and b"unexpected argument" in err, (args, rc, err[-200:])
+    rc, out, err = ska("align", G.fin("merge.skf"), "-v", cwd=wd)               # the global flag stays accepted everywhere
+    assert rc == 0
+
+
+def test_builds_are_deterministic(tmp_path, monkeypatch):
+    """Rows are kept in the order of H(key) whatever the path that produced them: two runs, a build forced into several batches
+    (joined by the merge row-set path) and an eagerly assembled array all write the same .skf bytes and the same nk listing."""
+    import synth
+    wd = str(tmp_path)
+    anc = synth.ancestor(150_000, seed=3)
+    files = []
+    for i in range(10):
+        p = os.path.join(wd, f"d{i}.fa")
+        synth.to_fasta(synth.sample_stream(anc, i, 10, private_snps=40, shared_snps=10, seed=3), p)
+        files.append(p)
+    outs = {}
+    for tag, env in (("a", {}), ("b", {}), ("batched", {"SKX_BUILD_BATCH_MB": "8"}), ("eager", {"SKX_EAGER_ARRAY": "1"}), ("host_parse", {"SKX_HOST_PARSE": "1"})):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        rc, out, err = ska("build", "-o", tag, "-k", "31", "--threads", "3", *files, cwd=wd)
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        assert rc == 0, err
+        rc, nk, err = ska("nk", tag + ".skf", "--full-info", cwd=wd)
+        assert rc == 0, err
+        outs[tag] = (open(os.path.join(wd, tag + ".skf"), "rb").read(), nk)
+    for tag in ("b", "batched", "eager", "host_parse"):
+        assert outs[tag][0] == outs["a"][0], tag
+        assert outs[tag][1] == outs["a"][1], tag
+    # and the alignment of the file is the alignment of the single-invocation form, byte for byte
+    rc, a1, err = ska("align", "a.skf", cwd=wd)
+    rc2, a2, err2 = ska("align", "--threads", "2", *files, cwd=wd)
+    assert rc == 0 and rc2 == 0 and a1 == a2

@@ -1,0 +1,160 @@
+"""BASELINE.json configs[1] and configs[2] at their full sizes (`-m gpu`): 100 and 1 000 synthetic 5 Mbp assemblies, k = 31.
+The oracle cannot build 1 000 samples in test time, so config 3 is pinned by (a) oracle dictionaries of samples spread over the
+set, (b) the oracle's merged array on a 64-sample subset built from the same files, (c) exact sharded == unsharded equality of the
+whole array on the device, (d) size-independent properties of the filter / alignment.  Config 2 goes through the `ska` executable:
+its 100-sample .skf is read by the oracle and must be the oracle's own array, row for row."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import ora
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SKA = os.path.join(ROOT, "ska.rust_amd", "ska")
+
+
+@pytest.fixture(scope="module")
+def E():
+    import torch                    # before the engine: torch brings its own copy of the HIP runtime, and the copy loaded second finds no GPU
+    torch.cuda.init()
+    import skx_engine as eng
+    eng.load_library()
+    eng.default_context()
+    return eng
+
+
+def _shm(tmp_path_factory):
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    import tempfile
+    return tempfile.mkdtemp(prefix="skx_full_", dir=base)
+
+
+def _sorted(arr):
+    k, v, c = arr.export()
+    o = np.argsort(k["lo"], kind="stable")
+    return k["lo"][o], v[o], c[o]
+
+
+@pytest.fixture(scope="module")
+def thousand(tmp_path_factory):
+    import shutil
+    import synth
+    td = _shm(tmp_path_factory)
+    anc = synth.ancestor(5_000_000, seed=1)
+    n = 1000
+    files = []
+    for i in range(n):
+        p = os.path.join(td, f"g{i}.fa")
+        synth.to_fasta(synth.sample_stream(anc, i, n), p)
+        files.append(p)
+    yield td, files
+    shutil.rmtree(td, ignore_errors=True)
+
+
+def test_config3_thousand_assemblies(E, thousand):
+    import torch
+    import dist as skdist
+    td, files = thousand
+    n = len(files)
+    names = [f"g{i}" for i in range(n)]
+    dev = torch.device("cuda", 0)
+    whole_ds = E.DictSet.from_files([(f, None) for f in files], 31, True, threads=32)
+    # (a) dictionaries of 8 samples spread over the set (index 9 mod 10 = reverse-complemented by the generator)
+    for i in (0, 9, 199, 333, 500, 509, 777, 999):
+        ok, ob = ora.Dict.from_files(31, files[i]).export()
+        gk, gb = whole_ds.export(i)
+        assert np.array_equal(gk["lo"], ok["lo"]) and np.array_equal(gb, ob), i
+    whole = whole_ds.merge(names)
+    U = whole.nrows
+    assert 20_000_000 < U < 26_000_000
+    assert [int(x) for x in whole.sample_kmers()] == [whole_ds.size(i) for i in range(n)]
+    # (b) the oracle's merged array on a 64-sample subset (every 16th sample, so the subset spans the whole tree), same files
+    sub = list(range(0, n, 16))[:64]
+    sub_inputs = [(names[i], files[i], None) for i in sub]
+    oa = ora.Array.build(sub_inputs, k=31, threads=8)
+    ga = E.Array.build(sub_inputs, k=31, threads=16)
+    for x, y in zip(_sorted(ga), _sorted(oa)):
+        assert np.array_equal(x, y)
+    # ... and the whole array restricted to those samples is that array: rows any of them has, in key order
+    wkeys, wcounts = whole.export_keys()
+    p, pitch, rows = whole.device_matrix()
+    assert rows == U
+    mat = skdist.as_tensor(p, n * pitch, "|u1", dev).view(n, pitch)[:, :U]
+    sub_mat = mat[torch.tensor(sub, device=dev)]                                    # [64][U], engine (hash) order
+    present = (sub_mat != ord("-")).any(dim=0)
+    assert len(wkeys) == U and int(wcounts.sum()) == sum(whole_ds.size(i) for i in range(n))
+    # the two arrays hold the same rows: compared as multisets of rows through a 64-bit row hash (the whole array is in hash
+    # order, the oracle's in key order)
+    sub_rows = sub_mat[:, present].t().contiguous().cpu().numpy()                   # [rows of the subset][samples of the subset]
+    w = np.random.default_rng(5).integers(1, 1 << 62, size=len(sub), dtype=np.uint64) | np.uint64(1)
+    ha = np.sort(sub_rows.astype(np.uint64) @ w)
+    hb = np.sort(_sorted(oa)[1].astype(np.uint64) @ w)
+    assert len(ha) == len(hb) and np.array_equal(ha, hb)
+    # (c) sharded == unsharded, exactly: two shards exchange key tables, fill their column slabs; slabs tile the whole matrix
+    half = n // 2
+    shards = [E.DictSet.from_files([(f, None) for f in files[lo:hi]], 31, True, threads=32) for lo, hi in ((0, half), (half, n))]
+    rows_ks = E.KeySet.merge([s.union_keys() for s in shards])
+    assert len(rows_ks) == U
+    wp = [skdist.as_tensor(x, U, "<i4", dev) for x in whole.device_stats()[:3]]
+    acc = [torch.zeros(U, dtype=torch.int32, device=dev) for _ in range(2)]
+    accm = torch.zeros(U, dtype=torch.int32, device=dev)
+    for s, (lo, hi) in zip(shards, ((0, half), (half, n))):
+        part = s.assemble(rows_ks, names[lo:hi])
+        pp, ppitch, prow = part.device_matrix()
+        assert prow == U
+        pm = skdist.as_tensor(pp, (hi - lo) * ppitch, "|u1", dev).view(hi - lo, ppitch)[:, :U]
+        assert torch.equal(pm, mat[lo:hi])
+        st = [skdist.as_tensor(x, U, "<i4", dev) for x in part.device_stats()[:3]]
+        acc[0] += st[0]; acc[1] += st[1]; accm |= st[2]
+        part.free(); s.free()
+    assert torch.equal(acc[0], wp[0]) and torch.equal(acc[1], wp[1]) and torch.equal(accm, wp[2])
+    # (d) the default `ska align` filter at full size: idempotent, every kept column varies and is present in >= 900 samples
+    removed = whole.apply_filters(0.9)
+    kept = whole.nrows
+    assert removed == U - kept and 4_000_000 < kept < 6_000_000
+    assert whole.apply_filters(0.9) == 0 and whole.nrows == kept
+    p, pitch, rows = whole.device_matrix()
+    fm = skdist.as_tensor(p, n * pitch, "|u1", dev).view(n, pitch)[:, :kept]
+    assert bool((fm != fm[0]).any(dim=0).all())
+    assert bool(((fm != ord("-")).sum(dim=0) >= 900).all())
+    whole_ds.free()
+
+
+def test_config2_hundred_assemblies_through_the_executable(E, thousand):
+    td, files = thousand
+    import synth
+    # config 2 is its own data set (100 samples: a shallower tree than the first 100 of 1 000)
+    anc = synth.ancestor(5_000_000, seed=1)
+    n = 100
+    sub = os.path.join(td, "c2")
+    os.makedirs(sub, exist_ok=True)
+    fl = []
+    for i in range(n):
+        p = os.path.join(sub, f"h{i}.fa")
+        synth.to_fasta(synth.sample_stream(anc, i, n), p)
+        fl.append(p)
+    with open(os.path.join(sub, "list.txt"), "w") as f:
+        for i, p in enumerate(fl):
+            f.write(f"h{i}\t{p}\n")
+    r = subprocess.run([SKA, "build", "-f", "list.txt", "-o", "c2", "-k", "31", "--threads", "32"], cwd=sub, capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-400:]
+    got = ora.Array.load(os.path.join(sub, "c2.skf"))                       # the oracle reads the engine's file
+    want = ora.Array.build([(f"h{i}", p, None) for i, p in enumerate(fl)], k=31, threads=8)
+    assert got.names == want.names and got.k == 31 and got.rc and got.version == "0.5.2"
+    for x, y in zip(_sorted(got), _sorted(want)):
+        assert np.array_equal(x, y)
+    # and `ska align` of that file is the oracle's alignment, column for column
+    r = subprocess.run([SKA, "align", "c2.skf", "-o", "c2.aln"], cwd=sub, capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-400:]
+    g = open(os.path.join(sub, "c2.aln"), "rb").read()
+    o = want.align(min_freq=0.9)
+
+    def cols(aln):
+        rws = aln.split(b"\n")[1::2]
+        m = np.frombuffer(b"".join(rws), dtype=np.uint8).reshape(len(rws), -1)
+        return m[:, np.lexsort(m[::-1])]
+    assert g.split(b"\n")[0::2][:n] == o.split(b"\n")[0::2][:n]
+    assert np.array_equal(cols(g), cols(o))
