@@ -297,6 +297,7 @@ def main():
     torch.cuda.synchronize()
 
     host_ms = {"build": 0.0, "merge": 0.0, "align": 0.0, "free": 0.0}
+    xch = {"key_table_allgather_s": 0.0, "key_table_allgather_bytes_per_rank": 0, "row_stats_s": 0.0, "row_stats_bytes_per_rank": 0}     # sharded runs: the exchanges
 
     def step():
         t_a = time.perf_counter()
@@ -308,19 +309,25 @@ def main():
             arr = ds.merge(names)
         else:
             ks = ds.union_keys()
-            p, n, _ = ks.device()
+            p, n, wpk = ks.device()                  # wpk 64-bit words per key (2 for k > 31)
             ctx.sync()
-            tables = skdist.allgather_tables(skdist.as_tensor(p, n, "<i8", dev))
+            t_x = time.perf_counter()
+            tables = skdist.allgather_tables(skdist.as_tensor(p, n * wpk, "<i8", dev))
             torch.cuda.synchronize()
-            sets = [E.KeySet.from_device(t.data_ptr(), t.numel(), args.k, True, ctx=ctx) for t in tables]
+            xch["key_table_allgather_s"] += time.perf_counter() - t_x
+            xch["key_table_allgather_bytes_per_rank"] = int(sum(t.numel() for t in tables) * 8)
+            sets = [E.KeySet.from_device(t.data_ptr(), t.numel() // wpk, args.k, True, ctx=ctx) for t in tables]
             rows = E.KeySet.merge(sets, ctx=ctx)
             arr = ds.assemble(rows, names)
             pp, pu, pm, pv = arr.device_stats()
             U = arr.nrows
             tp, tu, tm = (skdist.as_tensor(x, U, "<i4", dev) for x in (pp, pu, pm))
+            t_x = time.perf_counter()
             skdist.reduce_row_stats(tp, tu, tm, total_samples=n_total)
             skdist.as_tensor(pv, U, "<i4", dev).copy_(tp)
             torch.cuda.synchronize()
+            xch["row_stats_s"] += time.perf_counter() - t_x
+            xch["row_stats_bytes_per_rank"] = int(U * (4 + 2 * world))
             arr.set_total_samples(n_total)
         ctx.sync()
         t_c = time.perf_counter()
@@ -341,6 +348,7 @@ def main():
     ctx.timings(reset=True)
     for kk in host_ms:
         host_ms[kk] = 0.0
+    xch["key_table_allgather_s"] = xch["row_stats_s"] = 0.0
     if sharded:
         dist.barrier()
     torch.cuda.synchronize()
@@ -394,6 +402,10 @@ def main():
             "other_kernels": other_kernels(tm, steps, total_bases, n_distinct, shape[0], shape[1], G),
             "host_wall_ms_per_step": {k: v / steps for k, v in host_ms.items()},
         }
+        if sharded:
+            res["exchange_per_step_rank0"] = {"key_table_allgather_ms": xch["key_table_allgather_s"] / steps * 1e3, "key_table_allgather_bytes": xch["key_table_allgather_bytes_per_rank"],
+                                              "row_stats_ms": xch["row_stats_s"] / steps * 1e3, "row_stats_bytes": xch["row_stats_bytes_per_rank"],
+                                              "what": "one all-gather of the per-rank key tables + the reduction of the per-row filter statistics; nothing else crosses xGMI"}
         res["roofline"]["traffic_source"] = "profiles/pmc_extract.json: FETCH_SIZE x 2 + WRITE_SIZE of a separate --pmc run of this kernel, scaled per base (not measured in this run)"
         if world == 1:
             # the legs below run outside the timed region; the bench's own device buffers go first (the ska executable gets the GPU)

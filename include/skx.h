@@ -170,6 +170,14 @@ int  skx_array_set_total_samples(skx_array *a, uint64_t total_samples);
 typedef struct { double distance, mismatch_prop; uint64_t match_count, mismatch_count; } skx_dist;
 /* MergeSkaArray::distance (merge_ska_array.rs:416-438,587-632): upper triangle, pairs (i<j) row-major */
 int  skx_array_distance(skx_array *a, double constant, int filt_ambig, skx_dist *out);
+/* The two halves of skx_array_distance, so that a multi-GPU host can exchange the bit planes between them (SURVEY.md 8e:
+ * "tile the pair matrix over ranks"): every rank builds the planes of its own samples over the (globally filtered) rows, the
+ * planes are all-gathered (plane-major: planes[p][sample][word], 4 planes with filt_ambig, 8 without), and each rank
+ * finishes a band of first samples [i_lo, i_hi) against every later sample -- `out` = those pairs, (i, j > i) row-major, in the
+ * arithmetic of merge_ska_array.rs:596-631.  i_lo must be a multiple of 32.  The planes pointer stays valid while the array lives. */
+int  skx_array_distance_planes(skx_array *a, int filt_ambig, const void **planes, uint64_t *words_per_row, int *n_planes);
+int  skx_planes_distance(skx_ctx *ctx, const void *planes, int n_samples, uint64_t words_per_row, int filt_ambig, double constant,
+                         int i_lo, int i_hi, skx_dist *out);
 void skx_free(void *p);
 
 /* ---- .skf life-cycle: `ska merge`, `ska delete`, `ska weed` ---- */

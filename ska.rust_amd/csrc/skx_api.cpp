@@ -1580,7 +1580,8 @@ extern "C" int skx_array_write_fasta(skx_array *a, int fd)
     if (regular && !append && pos >= 0 && fl >= 0 && (fl & O_ACCMODE) == O_RDWR && total && !getenv("SKX_NO_MMAP_OUTPUT")) {
         const long pg = sysconf(_SC_PAGESIZE);
         map_skew = (size_t)(pos % pg);
-        if (ftruncate(fd, pos + (off_t)total) == 0) {
+        // the file is only ever grown: several writers (one per GPU) may each hold a window of the same file
+        if ((off_t)sb.st_size >= pos + (off_t)total || ftruncate(fd, pos + (off_t)total) == 0) {
             map_len = total + map_skew;
             void *m = mmap(nullptr, map_len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, pos - (off_t)map_skew);
             if (m != MAP_FAILED) map = (uint8_t *)m; else map_len = 0;
@@ -1665,29 +1666,13 @@ extern "C" int skx_array_write_fasta(skx_array *a, int fd)
 // numerators over 36 of |S1 n S2| / (|S1||S2|) per pair class [2..11] of pair_counts_kernel<false>
 static const int PAIR_CLASS_NUM[10] = {36, 18, 12, 9, 18, 6, 12, 4, 8, 12};
 
-extern "C" int skx_array_distance(skx_array *a, double constant, int filt_ambig, skx_dist *out)
+// pair-class counts -> VariantDist (merge_ska_array.rs:596-631), pairs (i in [i_lo, i_hi), j > i) row-major; h rows are relative to i_lo
+static void finish_pairs(const unsigned long long *h, int S, int i_lo, int i_hi, double constant, int filt_ambig, skx_dist *out)
 {
-    return skx_guarded([&]() -> int {
-    skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
-    SKX_HIP(hipSetDevice(ctx->device));
-    SKX_TRY(array_materialize(a));
-    const int S = (int)a->names.size(); const uint64_t U = a->n_rows;
-    if (S < 2) return SKX_OK;
-    StageTimer t(ctx, &ctx->tm.distance);
-    const uint64_t wpr = (U + 63) / 64;
-    DevBuf<uint64_t> planes; DevBuf<unsigned long long> cnt;
-    SKX_TRY(planes.alloc((filt_ambig ? 4 : 8) * (uint64_t)S * std::max<uint64_t>(wpr, 1)));
-    SKX_TRY(cnt.alloc((uint64_t)S * S * DIST_NCOUNT)); SKX_TRY(cnt.zero(st));
-    launch_build_planes(a->matrix.p, a->pitch, S, U, planes.p, wpr, filt_ambig, st);
-    launch_pair_counts(planes.p, S, wpr, filt_ambig, cnt.p, st);
-    std::vector<unsigned long long> h((uint64_t)S * S * DIST_NCOUNT);
-    SKX_HIP(hipMemcpyAsync(h.data(), cnt.p, h.size() * 8, hipMemcpyDeviceToHost, st));
-    SKX_HIP(hipStreamSynchronize(st));
-    SKX_HIP(hipGetLastError());
     uint64_t n = 0;
-    for (int i = 0; i < S; i++)
+    for (int i = i_lo; i < i_hi; i++)
         for (int j = i + 1; j < S; j++, n++) {
-            const unsigned long long *c = &h[((uint64_t)i * S + j) * DIST_NCOUNT];
+            const unsigned long long *c = &h[((uint64_t)(i - i_lo) * S + j) * DIST_NCOUNT];
             double mismatches = (double)c[0], matches = constant, distance;
             if (filt_ambig) { matches += (double)c[2]; distance = (double)(c[2] - c[3]); }
             else {
@@ -1700,6 +1685,67 @@ extern "C" int skx_array_distance(skx_array *a, double constant, int filt_ambig,
             out[n].mismatch_prop = (matches + mismatches) == 0.0 ? 0.0 : mismatches / (matches + mismatches);
             out[n].match_count = (uint64_t)matches; out[n].mismatch_count = (uint64_t)mismatches;
         }
+}
+static int planes_distance(skx_ctx *ctx, const uint64_t *planes, int S, uint64_t wpr, int filt_ambig, double constant, int i_lo, int i_hi, skx_dist *out)
+{
+    hipStream_t st = ctx->stream;
+    if (S < 2 || i_lo >= i_hi) return SKX_OK;
+    const uint64_t rows = (uint64_t)(i_hi - i_lo);
+    DevBuf<unsigned long long> cnt;
+    SKX_TRY(cnt.alloc(rows * S * DIST_NCOUNT)); SKX_TRY(cnt.zero(st));
+    launch_pair_counts(planes, S, wpr, filt_ambig, cnt.p, st, i_lo, i_hi);
+    std::vector<unsigned long long> h(rows * S * DIST_NCOUNT);
+    SKX_HIP(hipMemcpyAsync(h.data(), cnt.p, h.size() * 8, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipStreamSynchronize(st));
+    SKX_HIP(hipGetLastError());
+    finish_pairs(h.data(), S, i_lo, i_hi, constant, filt_ambig, out);
+    return SKX_OK;
+}
+
+extern "C" int skx_array_distance_planes(skx_array *a, int filt_ambig, const void **planes, uint64_t *words_per_row, int *n_planes)
+{
+    return skx_guarded([&]() -> int {
+    if (!a || !planes || !words_per_row) { set_error("bad arguments"); return SKX_EINVAL; }
+    skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
+    SKX_HIP(hipSetDevice(ctx->device));
+    SKX_TRY(array_materialize(a));
+    const int S = (int)a->names.size(); const uint64_t U = a->n_rows;
+    const uint64_t wpr = std::max<uint64_t>((U + 63) / 64, 1);
+    const int np = filt_ambig ? 4 : 8;
+    SKX_TRY(a->planes.alloc((uint64_t)np * S * wpr));
+    if (U == 0) SKX_TRY(a->planes.zero(st));
+    launch_build_planes(a->matrix.p, a->pitch, S, U, a->planes.p, wpr, filt_ambig, st);
+    SKX_HIP(hipStreamSynchronize(st));
+    SKX_HIP(hipGetLastError());
+    *planes = a->planes.p; *words_per_row = wpr; if (n_planes) *n_planes = np;
+    return SKX_OK;
+    });
+}
+extern "C" int skx_planes_distance(skx_ctx *ctx, const void *planes, int n_samples, uint64_t words_per_row, int filt_ambig, double constant,
+                                   int i_lo, int i_hi, skx_dist *out)
+{
+    return skx_guarded([&]() -> int {
+    if (!ctx || !planes || !out || n_samples < 0 || i_lo < 0 || i_hi > n_samples || (i_lo % 32)) { set_error("bad arguments (i_lo must be a multiple of 32)"); return SKX_EINVAL; }
+    SKX_HIP(hipSetDevice(ctx->device));
+    StageTimer t(ctx, &ctx->tm.distance);
+    return planes_distance(ctx, (const uint64_t *)planes, n_samples, words_per_row, filt_ambig, constant, i_lo, i_hi, out);
+    });
+}
+
+extern "C" int skx_array_distance(skx_array *a, double constant, int filt_ambig, skx_dist *out)
+{
+    return skx_guarded([&]() -> int {
+    skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
+    SKX_HIP(hipSetDevice(ctx->device));
+    SKX_TRY(array_materialize(a));
+    const int S = (int)a->names.size(); const uint64_t U = a->n_rows;
+    if (S < 2) return SKX_OK;
+    StageTimer t(ctx, &ctx->tm.distance);
+    const uint64_t wpr = (U + 63) / 64;
+    DevBuf<uint64_t> planes;
+    SKX_TRY(planes.alloc((filt_ambig ? 4 : 8) * (uint64_t)S * std::max<uint64_t>(wpr, 1)));
+    launch_build_planes(a->matrix.p, a->pitch, S, U, planes.p, wpr, filt_ambig, st);
+    SKX_TRY(planes_distance(ctx, planes.p, S, wpr, filt_ambig, constant, 0, S, out));
     return SKX_OK;
     });
 }

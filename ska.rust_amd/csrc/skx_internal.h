@@ -135,6 +135,7 @@ struct skx_array {
     skx::DevBuf<uint32_t> vcount;                   // variant_count as the reference stores it (merge_ska_array.rs:121)
     // 128-bit keys of arrays loaded from k>31 files are kept on the host (filter/align/distance never touch them)
     std::vector<skx_key> host_keys;
+    skx::DevBuf<uint64_t> planes;    // bit planes of the distance sweep (skx_array_distance_planes)
     bool keys_absent = false;        // loaded through skx_array_load_filtered: the split k-mer list was stepped over
     std::shared_ptr<skx::Preallocator> prealloc;   // output pages being allocated for skx_array_write_fasta (skx_ctx_expect_output)
     // Lazily held (the build path, 64-bit keys): rows, keys and names are known but the rows x samples matrix has not been
