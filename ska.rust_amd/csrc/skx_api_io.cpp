@@ -533,7 +533,8 @@ extern "C" int skx_array_load_filtered(skx_ctx *ctx, const char *path, const skx
     SKX_TRY(present.alloc(U)); SKX_TRY(unambig.alloc(U)); SKX_TRY(mask.alloc(U)); SKX_TRY(keep.alloc(U));
     SKX_TRY(pos.alloc(rows_cap + 1)); SKX_TRY(sc_sums.alloc(scan_u8_blocks(rows_cap) + 1)); SKX_TRY(sc_offs.alloc(scan_u8_blocks(rows_cap) + 2));
     // kept rows: capacity grows when a file keeps more than the first guess (a quarter of its rows)
-    uint64_t cap = pitch_for(std::max<uint64_t>(U / 4, 1024)), kept = 0;
+    // (`ska distance` without --min-freq keeps every row that varies -- nearly all of them: sized for that from the start)
+    uint64_t cap = pitch_for(f->two_stage && thr <= 1 ? U : std::max<uint64_t>(U / 4, 1024)), kept = 0;
     SKX_TRY(a->matrix.alloc(S * cap));
     std::vector<SnapChunk> tab;
     uint64_t src_cap = 0, row_lo = 0, have_hi = 0;

@@ -156,7 +156,8 @@ static int distance_table(skx_array *a, double constant, int filt_ambig, char **
     const uint64_t S = info.n_samples;
     std::vector<skx_dist> d(S * (S - 1) / 2 + 1);
     int r;
-    if ((r = skx_array_distance(a, constant, filt_ambig, d.data())) != SKX_OK) return r;
+    { Phase pd("distance.pair_sweep"); if ((r = skx_array_distance(a, constant, filt_ambig, d.data())) != SKX_OK) return r; }
+    Phase pt("distance.table_text");
     std::string out = "Sample1\tSample2\tDistance\tMismatches (proportion)\tMatch count\tMismatch count\n";
     size_t n = 0;
     for (uint64_t i = 0; i < S; i++)
