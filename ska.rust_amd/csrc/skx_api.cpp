@@ -280,6 +280,71 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
         *out = d.release();
         return SKX_OK;
     };
+    // The same samples through the engine's own kernels (skx_reads2.hip): the windows that pass the gates and the count filter
+    // come back as packed words, which go into (sample, bucket) regions like an assembly's and through the same dedupe kernel
+    // -- sorted, folded, sub-indexed regions, so union / assemble treat reads and assemblies alike.  A sample the partition
+    // kernels do not take (or regions the LDS sort cannot hold) sends the batch to the sort-based form above.
+    auto build_bucketed_reads = [&]() -> int {
+        const bool wide_r = k > 31;
+        const int wpk_r = wide_r ? 2 : 1, kbits = 2 * (k - 1);
+        std::vector<DevBuf<uint64_t>> wl(n), wh2(n);
+        std::vector<uint64_t> cnt(n, 0);
+        uint64_t maxn = 0;
+        for (int s = 0; s < n; s++) {
+            skx_qual qs = q ? *q : skx_qual{5, 20, SKX_QUAL_STRICT};
+            if (!quals[s]) { qs.min_count = 0; qs.qual_filter = SKX_QUAL_NOFILTER; }        // FASTA sample in a mixed batch: no filtering
+            const int r = reads_sample_words(ctx, seqs[s], quals[s], lens[s], k, rc, qs, wl[s], wh2[s], &cnt[s]);
+            if (r != SKX_OK) return r;                                                       // SKF_NOT_TAKEN included
+            maxn = std::max(maxn, cnt[s]);
+        }
+        const uint64_t per = wide_r ? 2500 : 3500, lds_max = wide_r ? LDS_SORT_MAX_WIDE : LDS_SORT_MAX;
+        int logB = std::min({ilog2_ceil((maxn + per - 1) / per), kbits, MAX_LOGB});
+        if (logB < 0) logB = 0;
+        std::unique_ptr<skx_dictset> d(new skx_dictset());
+        d->ctx = ctx; d->n = n; d->k = k; d->rc = rc; d->logB = logB; d->hp = make_hash_params(std::min(k, 31)); d->wh = make_wide_hash(k);
+        d->key_bits = wide_r ? 128 : 64;
+        const uint64_t nreg = (uint64_t)n << logB;
+        SKX_TRY(d->raw.alloc(nreg)); SKX_TRY(d->ucnt.alloc(nreg)); SKX_TRY(d->off.alloc(nreg + 1)); SKX_TRY(d->sidx.alloc(nreg * skx::SUBIDX));
+        d->sb = std::min(4, kbits - logB);
+        SKX_TRY(d->raw.zero(st));
+        for (int s = 0; s < n; s++) launch_words_regions(true, wl[s].p, wide_r ? wh2[s].p : nullptr, cnt[s], kbits, logB, (uint64_t)s << logB, d->raw.p, nullptr, nullptr, nullptr, st);
+        DevBuf<uint32_t> d_max, cursor; SKX_TRY(d_max.alloc(1)); SKX_TRY(cursor.alloc(nreg)); SKX_TRY(cursor.zero(st));
+        launch_scan_u32(d->raw.p, d->off.p, nreg, d_max.p, st);
+        uint64_t total = 0; uint32_t max_raw = 0;
+        SKX_HIP(hipMemcpyAsync(&total, d->off.p + nreg, 8, hipMemcpyDeviceToHost, st));
+        SKX_HIP(hipMemcpyAsync(&max_raw, d_max.p, 4, hipMemcpyDeviceToHost, st));
+        SKX_HIP(hipStreamSynchronize(st));
+        if (max_raw > lds_max) { if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] reads: region of %u words, batch left to the sort-based form\n", max_raw); return SKF_NOT_TAKEN; }   // e.g. min_count 2 on deep reads: every repeat occurrence is a word
+        SKX_TRY(d->words.alloc(std::max<uint64_t>(total, 1) * wpk_r));
+        for (int s = 0; s < n; s++) {
+            launch_words_regions(false, wl[s].p, wide_r ? wh2[s].p : nullptr, cnt[s], kbits, logB, (uint64_t)s << logB, nullptr, d->off.p, cursor.p, d->words.p, st);
+            wl[s].release(); wh2[s].release();
+        }
+        const uint32_t cap = std::max<uint32_t>(512, (uint32_t)std::min<uint64_t>(((uint64_t)max_raw + 255) / 256 * 256, lds_max));
+        DevBuf<int> d_flag2; SKX_TRY(d_flag2.alloc(1)); SKX_TRY(d_flag2.zero(st));
+        SKX_HIP(hipMemsetAsync(d->sidx.p, 0xFF, nreg * skx::SUBIDX * sizeof(uint16_t), st));
+        { StageTimer t(ctx, &ctx->tm.dedupe);
+          if (wide_r) launch_dedupe_wide((u128 *)d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, cap, kbits - logB, d_flag2.p, d->sidx.p, d->sb, st);
+          else launch_dedupe_mb(d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, cap, d->hp.bits - logB, d_flag2.p, d->sidx.p, d->sb, st); }
+        int overflow = 0;
+        std::vector<uint32_t> ucnt(nreg);
+        SKX_HIP(hipMemcpyAsync(&overflow, d_flag2.p, 4, hipMemcpyDeviceToHost, st));
+        SKX_HIP(hipMemcpyAsync(ucnt.data(), d->ucnt.p, nreg * 4, hipMemcpyDeviceToHost, st));
+        SKX_HIP(hipStreamSynchronize(st));
+        SKX_HIP(hipGetLastError());
+        if (overflow) { if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] reads: dedupe overflow, batch left to the sort-based form\n"); return SKF_NOT_TAKEN; }
+        d->sample_size.assign(n, 0);
+        for (int s = 0; s < n; s++) for (uint64_t b = 0; b < (1ull << logB); b++) d->sample_size[s] += ucnt[((uint64_t)s << logB) + b];
+        *out = d.release();
+        return SKX_OK;
+    };
+    auto build_reads = [&]() -> int {
+        if (!getenv("SKX_READS_SORT")) {
+            const int r = build_bucketed_reads();
+            if (r != SKF_NOT_TAKEN) return r;
+        }
+        return build_sorted();
+    };
     const bool wide = k > 31;                                   // lib.rs:592: u64 for k <= 31, u128 above
     uint64_t maxlen = 0;
     for (auto l : lens) maxlen = std::max(maxlen, l);
@@ -289,7 +354,7 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
     // windows per bucket (upper bound): the 64-bit dedupe sorts up to 6 144 words per region in LDS and the regions get 20 % + 256
     // words of head-room, so 4 900 is the largest mean that fits -- and the largest buckets give the scatter its widest chunks
     const uint64_t per_region = wide ? 4096 : 4900;
-    if (any_qual || maxlen > (per_region << MAX_LOGB)) return build_sorted();
+    if (any_qual || maxlen > (per_region << MAX_LOGB)) return build_reads();
     int logB = std::min({ilog2_ceil((maxlen + per_region - 1) / per_region), key_bits_used, MAX_LOGB});
     if (logB < 0) logB = 0;
 
@@ -367,7 +432,7 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
         SKX_HIP(hipStreamSynchronize(st));
         SKX_HIP(hipGetLastError());
         if (overflow) {
-            if (logB >= std::min(key_bits_used, MAX_LOGB)) return build_sorted();      // repeat content beyond every region size: sort instead
+            if (logB >= std::min(key_bits_used, MAX_LOGB)) return build_reads();       // repeat content beyond every region size
             logB++;
             continue;
         }

@@ -26,6 +26,7 @@ struct ReadsArgs {
     int k, rc, min_qual, qual_filter;
     HashParams hp; WideHash wh;
     uint64_t *hash; uint64_t *wlo; uint64_t *whi; uint8_t *flag;
+    unsigned long long *n_valid;      // optional: [256] counters, slot blockIdx % 256 += windows that pass the gates (one hot counter costs 2 ms)
 };
 
 // Eight consecutive window-end positions per thread: the state of the window before the first one is built from its k
@@ -128,7 +129,12 @@ __global__ __launch_bounds__(RW_NT) void reads_windows_kernel(ReadsArgs a)
     put(o_hash, a.hash);
     put(o_lo, a.wlo);
     if (a.whi) put(o_hi, a.whi);
-    for (uint32_t i = threadIdx.x; i < left; i += RW_NT) a.flag[p0 + i] = s_flag[i];
+    uint32_t nv = 0;
+    for (uint32_t i = threadIdx.x; i < left; i += RW_NT) { a.flag[p0 + i] = s_flag[i]; nv += s_flag[i]; }
+    if (a.n_valid) {
+        for (int d = 32; d; d >>= 1) nv += __shfl_down(nv, d, 64);
+        if ((threadIdx.x & 63) == 0 && nv) atomicAdd(a.n_valid + (blockIdx.x & 255u), (unsigned long long)nv);
+    }
 }
 
 __global__ void gather_u64_kernel(const uint64_t *src, const uint32_t *idx, uint64_t *dst, uint64_t n)
@@ -241,6 +247,19 @@ int select_flagged(Temp &tmp, In in, const uint8_t *flags, Out *out, uint64_t n,
     return SKX_OK;
 }
 }  // namespace
+
+// the window pass alone: per window-end position its ntHash, packed word and whether it passes the quality gates
+int reads_windows(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t len, int k, int rc, const skx_qual &q, DevBuf<uint64_t> &hash,
+                  DevBuf<uint64_t> &wlo, DevBuf<uint64_t> &whi, DevBuf<uint8_t> &flag, unsigned long long *d_n_valid)
+{
+    const bool wide = k > 31;
+    SKX_TRY(hash.alloc(len)); SKX_TRY(wlo.alloc(len)); SKX_TRY(flag.alloc(len));
+    if (wide) SKX_TRY(whi.alloc(len));
+    ReadsArgs ra{d_seq, d_qual, len, k, rc, q.min_qual, q.qual_filter, make_hash_params(k < 31 ? k : 31), make_wide_hash(k),
+                 hash.p, wlo.p, wide ? whi.p : nullptr, flag.p, d_n_valid};
+    hipLaunchKernelGGL(reads_windows_kernel, dim3((unsigned)((len + RW_TILE - 1) / RW_TILE)), dim3(RW_NT), 0, ctx->stream, ra);
+    return SKX_OK;
+}
 
 // One FASTQ sample -> its SkaDict as a sorted (engine order) list of unique packed words.
 int reads_sample_dict(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t len, int k, int rc, const skx_qual &q,

@@ -1,0 +1,425 @@
+// skx_reads2.hip -- KmerFilter (bloom_filter.rs:35-148) for a whole FASTQ sample with the engine's own kernels: the windows of
+// the sample are partitioned by bloom word and every partition is evaluated in LDS.  (skx_reads.hip holds the first form, a
+// chain of rocPRIM sorts / scans / selections; it remains as the fallback for samples this form does not take.)
+//
+// What the reference computes per k-mer hash h, with occurrences t_1 < t_2 < ... in stream order:
+//   FP(h)  <=>  fp(h) is a subset of OR{ fp(g) : loc(g) == loc(h), first(g) < first(h) }          (the blocked bloom's false positive)
+//   min_count == 2 : every occurrence passes except t_1, which passes iff FP(h)
+//   min_count >= 3 : exactly the (min_count - FP(h))-th occurrence passes
+// loc(h) = (mix(h) * 3 145 728) >> 64 with mix a bijection (bloom_filter.rs:50-58,72-74), so ordering the windows by m = mix(h)
+// groups equal hashes AND equal bloom words: one partition by loc serves both.  3 145 728 = 32 768 x 96, so a final partition is
+// exactly 96 consecutive bloom words (~5 500 windows of a 50x isolate) -- no bloom word straddles two partitions.
+//   rs_scatter_kernel<24576,128> : windows (hash, position) -> 128 coarse partitions   (tiles of 4 096, chunks of ~23 records)
+//   rs_scatter_kernel<96,256>    : each coarse partition -> 256 final ones
+//   rs_groups_kernel             : a final partition in LDS: counting sort by m into micro-buckets, rank by (m, position),
+//                                  hash groups, bloom-word groups, FP, verdict per occurrence -> positions that pass
+//   words_* kernels              : passing positions -> packed words -> (sample, bucket) regions of a dictset, which the
+//                                  assemblies' dedupe_mb_kernel sorts / folds (so reads get sub-indexed regions too)
+#include "skx_internal.h"
+#include <algorithm>
+
+namespace skx {
+
+constexpr uint64_t BLOOM_WORDS = 3145728ull;                           // bloom_filter.rs:93-97
+constexpr uint64_t MIX_C = 0x85D059AA333121CFull, MIX_CINV = 0x756de8dbb3c2452full;      // MIX_C * MIX_CINV == 1 (mod 2^64)
+__device__ static inline uint64_t mixh(uint64_t h) { return (h ^ (h >> 31)) * MIX_C; }               // cheap_mix
+__device__ static inline uint64_t unmixh(uint64_t m) { const uint64_t x = m * MIX_CINV; return x ^ (x >> 31) ^ (x >> 62); }
+__device__ static inline uint32_t loc_of(uint64_t m) { return (uint32_t)__umul64hi(m, BLOOM_WORDS); }
+__device__ static inline uint64_t bloom_fp5(uint64_t h)                  // bloom_filter.rs:62-68
+{
+    return (1ull << (h & 63)) | (1ull << ((h >> 6) & 63)) | (1ull << ((h >> 12) & 63)) | (1ull << ((h >> 18) & 63)) | (1ull << ((h >> 24) & 63));
+}
+
+// ---------------------------------------------------------------------------------------------------------- partition
+constexpr int RS_TILE = 4096, RS_NT = 512, RS_PER = RS_TILE / RS_NT;
+struct RsArgs {
+    const uint64_t *src_h; const uint32_t *src_t; const uint8_t *flag;      // FROM_POS: hash[p], flag[p], t = p; else records of source partitions
+    const uint32_t *src_cnt; uint64_t src_cap, n_pos;
+    uint64_t *dst_h; uint32_t *dst_t; uint32_t *dst_cnt; uint64_t dst_cap;   // destination partition (src * FAN + sub) holds dst_cap records
+    int *overflow;
+};
+template <int DIV, int FAN, bool FROM_POS>
+__global__ __launch_bounds__(RS_NT) void rs_scatter_kernel(RsArgs a)
+{
+    __shared__ uint32_t s_hist[FAN], s_lbase[FAN + 1], s_gbase[FAN];
+    __shared__ uint64_t s_h[RS_TILE];
+    __shared__ uint32_t s_t[RS_TILE];
+    const uint32_t src = FROM_POS ? 0u : blockIdx.y;
+    const uint64_t n = FROM_POS ? a.n_pos : (uint64_t)a.src_cnt[src];
+    const uint64_t i0 = (uint64_t)blockIdx.x * RS_TILE;
+    if (i0 >= n) return;
+    const uint64_t sbase = FROM_POS ? 0 : (uint64_t)src * a.src_cap;
+    for (int i = threadIdx.x; i < FAN; i += RS_NT) s_hist[i] = 0;
+    __syncthreads();
+    uint64_t h[RS_PER]; uint32_t t[RS_PER], rk[RS_PER];
+#pragma unroll
+    for (int j = 0; j < RS_PER; j++) {
+        const uint64_t i = i0 + threadIdx.x + (uint64_t)RS_NT * j;
+        const bool valid = i < n && (!FROM_POS || a.flag[i]);
+        h[j] = valid ? a.src_h[sbase + i] : 0ull;
+        t[j] = FROM_POS ? (uint32_t)i : (valid ? a.src_t[sbase + i] : 0u);
+        rk[j] = 0xFFFFFFFFu;
+        if (valid) { const uint32_t sub = (loc_of(mixh(h[j])) / (uint32_t)DIV) % (uint32_t)FAN; rk[j] = (sub << 16) | atomicAdd(&s_hist[sub], 1u); }
+    }
+    __syncthreads();
+    // one cursor reservation per non-empty destination; local starts by a serial walk of the (<= 256) counters in one wave
+    for (int b = threadIdx.x; b < FAN; b += RS_NT) {
+        const uint32_t nb = s_hist[b];
+        uint32_t g = 0;
+        if (nb) { g = atomicAdd(&a.dst_cnt[(uint64_t)src * FAN + b], nb); if ((uint64_t)g + nb > a.dst_cap) *a.overflow = 1; }
+        s_gbase[b] = g;
+    }
+    if (threadIdx.x < 64) {
+        constexpr int PERL = (FAN + 63) / 64;
+        uint32_t c[PERL], sum = 0;
+#pragma unroll
+        for (int u = 0; u < PERL; u++) { const int b = threadIdx.x * PERL + u; c[u] = b < FAN ? s_hist[b] : 0u; sum += c[u]; }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(inc, d, 64); if ((int)threadIdx.x >= d) inc += y; }
+        uint32_t run = inc - sum;
+#pragma unroll
+        for (int u = 0; u < PERL; u++) { const int b = threadIdx.x * PERL + u; if (b < FAN) s_lbase[b] = run; run += c[u]; }
+        if (threadIdx.x == 63) s_lbase[FAN] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RS_PER; j++)
+        if (rk[j] != 0xFFFFFFFFu) { const uint32_t o = s_lbase[rk[j] >> 16] + (rk[j] & 0xFFFFu); s_h[o] = h[j]; s_t[o] = t[j]; }
+    __syncthreads();
+    const uint32_t total = s_lbase[FAN];
+    for (uint32_t i = threadIdx.x; i < total; i += RS_NT) {
+        const uint64_t hh = s_h[i];
+        const uint32_t sub = (loc_of(mixh(hh)) / (uint32_t)DIV) % (uint32_t)FAN;
+        const uint64_t r = (uint64_t)s_gbase[sub] + (i - s_lbase[sub]);
+        if (r < a.dst_cap) { const uint64_t o = ((uint64_t)src * FAN + sub) * a.dst_cap + r; a.dst_h[o] = hh; a.dst_t[o] = s_t[i]; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------- one partition in LDS
+// WPP = bloom words per final partition: 48 (65 536 partitions; samples of up to ~200 M windows) or 12 (262 144 partitions).
+// 1 024 threads x 4 records, 69 KB of LDS: two workgroups per CU.
+constexpr int RG_NT = 1024, RG_ITEMS = 4, RG_CAP = RG_NT * RG_ITEMS, RG_MB = 48 * 64;       // micro-bucket = (bloom word, top bits of the fraction)
+struct RgArgs { const uint64_t *h; const uint32_t *t; const uint32_t *cnt; uint64_t cap; int min_count; uint32_t *out_t; unsigned long long *out_n; int *overflow; unsigned long long *dbg; };
+#define RG_MARK(i) do { if (a.dbg && threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&a.dbg[i], now_ - t_mark); t_mark = now_; } } while (0)
+template <int WPP>
+__device__ static inline uint32_t micro_of(uint64_t m, uint32_t loc0, uint32_t &loc_rel)
+{
+    constexpr int FB = WPP == 48 ? 6 : 8;                        // 48 x 64 = 12 x 256 = 3 072 micro-buckets
+    const uint64_t frac = m * BLOOM_WORDS;                       // low 64 bits of the 128-bit product whose high part is the bloom word
+    loc_rel = loc_of(m) - loc0;
+    return loc_rel * (1u << FB) + (uint32_t)(frac >> (64 - FB));
+}
+template <int WPP>
+__global__ __launch_bounds__(RG_NT) void rs_groups_kernel(RgArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
+    uint64_t *s_m = reinterpret_cast<uint64_t *>(s_mem);                  // [RG_CAP] mix(hash) sorted; then, at group heads, the hash's bloom fingerprint
+    uint32_t *s_t = reinterpret_cast<uint32_t *>(s_m + RG_CAP);            // [RG_CAP] stream position
+    uint32_t *s_cnt = s_t + RG_CAP + 1;                                    // [-1] = 0 | [RG_MB] counts -> cursors (= micro-bucket ends)
+    uint8_t *s_loc = reinterpret_cast<uint8_t *>(s_cnt + RG_MB + 1);       // [RG_CAP] bloom word inside the partition (0..47)
+    __shared__ uint32_t s_tmp[17];
+    __shared__ unsigned long long s_gb;
+    const uint64_t region = blockIdx.x;
+    const uint32_t n = a.cnt[region];
+    if (n == 0) return;
+    if (n > (uint32_t)RG_CAP || n > a.cap) { if (threadIdx.x == 0) *a.overflow = 1; return; }
+    const uint64_t base = region * a.cap;
+    const uint32_t loc0 = (uint32_t)region * (uint32_t)WPP;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long t_mark = __builtin_readcyclecounter();
+    uint64_t e_m[RG_ITEMS]; uint32_t e_t[RG_ITEMS], e_mb[RG_ITEMS];
+#pragma unroll
+    for (int j = 0; j < RG_ITEMS; j++) {
+        const uint32_t p = threadIdx.x + (uint32_t)RG_NT * j;
+        e_m[j] = 0; e_t[j] = 0; e_mb[j] = 0xFFFFFFFFu;
+        if (p < n) { e_m[j] = mixh(a.h[base + p]); e_t[j] = a.t[base + p]; uint32_t lr; e_mb[j] = micro_of<WPP>(e_m[j], loc0, lr); }
+    }
+    for (uint32_t i = threadIdx.x; i < (uint32_t)RG_MB; i += RG_NT) s_cnt[i] = 0;
+    if (threadIdx.x == 0) s_cnt[-1] = 0;
+    __syncthreads();
+    RG_MARK(0);
+#pragma unroll
+    for (int j = 0; j < RG_ITEMS; j++) if (e_mb[j] != 0xFFFFFFFFu) atomicAdd(&s_cnt[e_mb[j]], 1u);
+    __syncthreads();
+    auto block_excl_scan = [&](uint32_t v, uint32_t &total) -> uint32_t {       // over the 1 024 threads
+        uint32_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(inc, d, 64); if (lane >= d) inc += y; }
+        __syncthreads();
+        if (lane == 63) s_tmp[wv] = inc;
+        __syncthreads();
+        uint32_t pre = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < RG_NT / 64; w++) { const uint32_t c = s_tmp[w]; if (w < wv) pre += c; tot += c; }
+        total = tot;
+        return pre + inc - v;
+    };
+    {   // exclusive scan of the counts: 3 consecutive micro-buckets per thread
+        constexpr uint32_t R = RG_MB / RG_NT;
+        const uint32_t m0 = threadIdx.x * R;
+        uint32_t sum = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < R; u++) sum += s_cnt[m0 + u];
+        uint32_t tot;
+        uint32_t run = block_excl_scan(sum, tot);
+#pragma unroll
+        for (uint32_t u = 0; u < R; u++) { const uint32_t c = s_cnt[m0 + u]; s_cnt[m0 + u] = run; run += c; }      // start; the scatter turns it into the end
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RG_ITEMS; j++)
+        if (e_mb[j] != 0xFFFFFFFFu) { const uint32_t o = atomicAdd(&s_cnt[e_mb[j]], 1u); s_m[o] = e_m[j]; s_t[o] = e_t[j]; }
+    __syncthreads();
+    RG_MARK(1);
+    // rank inside the micro-bucket by (m, position): positions are unique, so there are no ties
+    uint32_t npos[RG_ITEMS];
+#pragma unroll
+    for (int j = 0; j < RG_ITEMS; j++) {
+        const uint32_t p = threadIdx.x + (uint32_t)RG_NT * j;
+        npos[j] = 0xFFFFFFFFu;
+        if (p >= n) continue;
+        const uint64_t m = s_m[p]; const uint32_t tt = s_t[p];
+        uint32_t lr; const uint32_t mb = micro_of<WPP>(m, loc0, lr);
+        const uint32_t b = s_cnt[(int)mb - 1], e = s_cnt[mb];
+        uint32_t less = 0;
+        for (uint32_t q = b; q < e; q += 8) {                                  // eight independent LDS reads in flight per step (a k-mer of a 50x isolate
+            uint64_t mq[8]; uint32_t tq[8];                                      // fills its micro-bucket with ~35 records)
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) { const uint32_t qq = q + u < e ? q + u : e - 1; mq[u] = s_m[qq]; tq[u] = s_t[qq]; }
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) less += (q + u < e) && (mq[u] < m || (mq[u] == m && tq[u] < tt));
+        }
+        npos[j] = b + less; e_m[j] = m; e_t[j] = tt; e_mb[j] = lr;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RG_ITEMS; j++) if (npos[j] != 0xFFFFFFFFu) { s_m[npos[j]] = e_m[j]; s_t[npos[j]] = e_t[j]; }
+    __syncthreads();
+    // group heads (first = earliest occurrence of a hash): marked in s_loc, their s_m entry becomes the hash's bloom fingerprint,
+    // and their positions go into a compact list, so that everything below runs one lane per GROUP with short, similar loops
+    // (scanning the records themselves cost ~100 cycles of LDS latency per step in a few divergent lanes: 75 k of 110 k cycles)
+    bool is_head[RG_ITEMS]; uint64_t fpv[RG_ITEMS];
+#pragma unroll
+    for (int j = 0; j < RG_ITEMS; j++) {
+        const uint32_t p = threadIdx.x + (uint32_t)RG_NT * j;
+        is_head[j] = false; fpv[j] = 0;
+        if (p >= n) continue;
+        const uint64_t m = s_m[p];
+        is_head[j] = p == 0 || s_m[p - 1] != m;
+        fpv[j] = bloom_fp5(unmixh(m));
+        uint32_t lr; (void)micro_of<WPP>(m, loc0, lr);
+        s_loc[p] = (uint8_t)lr;
+    }
+    __syncthreads();
+    uint16_t *s_hidx = reinterpret_cast<uint16_t *>(s_cnt - 1);             // [heads + 1] positions of the group heads, in order (the cursors are dead)
+    uint32_t n_heads = 0;
+#pragma unroll
+    for (int j = 0; j < RG_ITEMS; j++) {
+        const uint32_t p = threadIdx.x + (uint32_t)RG_NT * j;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(is_head[j] ? 1u : 0u, tot);
+        if (is_head[j]) { s_m[p] = fpv[j]; s_hidx[n_heads + ex] = (uint16_t)p; }
+        n_heads += tot;
+    }
+    if (threadIdx.x == 0) s_hidx[n_heads] = (uint16_t)n;
+    __syncthreads();
+    RG_MARK(2);
+    // per group: size, FP where it can change the verdict (bloom fingerprints of the hashes of the same bloom word first seen
+    // earlier), and what the group emits
+    const uint32_t mc = (uint32_t)a.min_count;
+    uint32_t g_p[RG_ITEMS], g_occ[RG_ITEMS], g_emit[RG_ITEMS], g_fp = 0, mine = 0;
+#pragma unroll
+    for (int j = 0; j < RG_ITEMS; j++) {
+        const uint32_t kh = threadIdx.x + (uint32_t)RG_NT * j;
+        g_p[j] = 0; g_occ[j] = 0; g_emit[j] = 0;
+        if (kh >= n_heads) continue;
+        const uint32_t p = s_hidx[kh], occ = (uint32_t)s_hidx[kh + 1] - p;
+        uint32_t fpos = 0;
+        if (mc == 2 || occ + 1 >= mc) {               // a smaller group passes nothing whatever its FP (occurrence number <= occ < min_count - 1)
+            const uint8_t lc = s_loc[p]; const uint32_t tp = s_t[p];
+            uint64_t seen = 0;
+            for (int kk = (int)kh - 1; kk >= 0; kk--) { const uint32_t q = s_hidx[kk]; if (s_loc[q] != lc) break; if (s_t[q] < tp) seen |= s_m[q]; }
+            for (uint32_t kk = kh + 1; kk < n_heads; kk++) { const uint32_t q = s_hidx[kk]; if (s_loc[q] != lc) break; if (s_t[q] < tp) seen |= s_m[q]; }
+            fpos = (s_m[p] & ~seen) == 0;
+        }
+        g_p[j] = p; g_occ[j] = occ; g_fp |= fpos << j;
+        g_emit[j] = mc == 2 ? occ - 1 + fpos : (occ >= mc - fpos ? 1u : 0u);
+        mine += g_emit[j];
+    }
+    RG_MARK(3);
+    uint32_t total;
+    const uint32_t ex = block_excl_scan(mine, total);
+    if (threadIdx.x == 0) s_gb = total ? atomicAdd(a.out_n, (unsigned long long)total) : 0ull;
+    __syncthreads();
+    RG_MARK(4);
+    unsigned long long o = s_gb + ex;
+#pragma unroll
+    for (int j = 0; j < RG_ITEMS; j++) {
+        if (!g_emit[j]) continue;
+        const uint32_t p = g_p[j], fpos = (g_fp >> j) & 1u;
+        if (mc == 2) { for (uint32_t u = fpos ? 0u : 1u; u < g_occ[j]; u++) a.out_t[o++] = s_t[p + u]; }      // every occurrence but the first; the first iff FP
+        else a.out_t[o++] = s_t[p + (mc - fpos) - 1];                                                          // exactly the (min_count - FP)-th
+    }
+    RG_MARK(5);
+}
+
+// ---------------------------------------------------------------------------------------------------------- small kernels
+// flagged positions -> their packed words (no count filter: min_count <= 1, FASTA samples, oversize assemblies)
+__global__ __launch_bounds__(256) void words_from_flags_kernel(const uint8_t *flag, const uint64_t *wlo, const uint64_t *whi, uint64_t n, uint64_t *out_lo, uint64_t *out_hi,
+                                                               unsigned long long *out_n)
+{
+    __shared__ uint32_t s_w[4]; __shared__ unsigned long long s_b;
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool f = i < n && flag[i];
+    const unsigned long long bal = __ballot(f);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) s_w[wv] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t t = 0; for (int w = 0; w < 4; w++) { const uint32_t c = s_w[w]; s_w[w] = t; t += c; } s_b = t ? atomicAdd(out_n, (unsigned long long)t) : 0ull; }
+    __syncthreads();
+    if (f) {
+        const unsigned long long o = s_b + s_w[wv] + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        out_lo[o] = wlo[i]; if (whi) out_hi[o] = whi[i];
+    }
+}
+__global__ void words_gather_kernel(const uint32_t *pos, uint64_t n, const uint64_t *wlo, const uint64_t *whi, uint64_t *out_lo, uint64_t *out_hi)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t p = pos[i];
+        out_lo[i] = wlo[p]; if (whi) out_hi[i] = whi[p];
+    }
+}
+// bucket of a packed word: top logB bits of its hash H (word = H << 4 | mask, H of `bits` bits; wide: hi:lo is the 128-bit word)
+__device__ static inline uint32_t word_bucket(uint64_t lo, uint64_t hi, int bits, int logB, bool wide)
+{
+    if (logB == 0) return 0u;
+    const int sh = bits + 4 - logB;                               // bucket = word >> sh
+    if (!wide) return (uint32_t)(lo >> sh);
+    return sh >= 64 ? (uint32_t)(hi >> (sh - 64)) : (uint32_t)((hi << (64 - sh)) | (lo >> sh));
+}
+// COUNT: raw[region] += words of the region; else: words into their regions through the cursors (exact offsets, so nothing can
+// overflow).  A workgroup takes 4 096 words, ranks them per bucket in an LDS histogram and touches every global counter once.
+constexpr int WR_NT = 1024, WR_PER = 4;
+template <bool COUNT>
+__global__ __launch_bounds__(WR_NT) void words_regions_kernel(const uint64_t *in_lo, const uint64_t *in_hi, uint64_t n, int bits, int logB, uint64_t region0,
+                                                              uint32_t *raw, const uint64_t *off, uint32_t *cursor, uint64_t *words)
+{
+    extern __shared__ uint32_t s_bin[];                              // [2^logB] counts, then the workgroup's first slot in each region
+    const bool wide = in_hi != nullptr;
+    const uint32_t B = 1u << logB;
+    for (uint32_t i = threadIdx.x; i < B; i += WR_NT) s_bin[i] = 0;
+    __syncthreads();
+    uint64_t lo[WR_PER], hi[WR_PER]; uint32_t rk[WR_PER], bk[WR_PER];
+#pragma unroll
+    for (int j = 0; j < WR_PER; j++) {
+        const uint64_t i = (uint64_t)blockIdx.x * (WR_NT * WR_PER) + threadIdx.x + (uint64_t)WR_NT * j;
+        bk[j] = 0xFFFFFFFFu; lo[j] = hi[j] = 0; rk[j] = 0;
+        if (i < n) { lo[j] = in_lo[i]; hi[j] = wide ? in_hi[i] : 0ull; bk[j] = word_bucket(lo[j], hi[j], bits, logB, wide); rk[j] = atomicAdd(&s_bin[bk[j]], 1u); }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < B; b += WR_NT) {
+        const uint32_t c = s_bin[b];
+        if (c) s_bin[b] = COUNT ? atomicAdd(&raw[region0 + b], c) : atomicAdd(&cursor[region0 + b], c);
+    }
+    if (COUNT) return;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < WR_PER; j++) {
+        if (bk[j] == 0xFFFFFFFFu) continue;
+        const uint64_t o = off[region0 + bk[j]] + s_bin[bk[j]] + rk[j];
+        if (wide) { words[2 * o] = lo[j]; words[2 * o + 1] = hi[j]; } else words[o] = lo[j];
+    }
+}
+
+static inline unsigned grid_of(uint64_t n, unsigned per = 256) { uint64_t g = (n + per - 1) / per; return (unsigned)(g < 1 ? 1 : (g > 262144 ? 262144 : g)); }
+
+void launch_words_regions(bool count, const uint64_t *in_lo, const uint64_t *in_hi, uint64_t n, int bits, int logB, uint64_t region0, uint32_t *raw,
+                          const uint64_t *off, uint32_t *cursor, uint64_t *words, hipStream_t st)
+{
+    if (!n) return;
+    const unsigned g = (unsigned)((n + WR_NT * WR_PER - 1) / (WR_NT * WR_PER));
+    const size_t lds = (size_t)4 << logB;
+    if (count) hipLaunchKernelGGL(words_regions_kernel<true>, dim3(g), dim3(WR_NT), lds, st, in_lo, in_hi, n, bits, logB, region0, raw, off, cursor, words);
+    else hipLaunchKernelGGL(words_regions_kernel<false>, dim3(g), dim3(WR_NT), lds, st, in_lo, in_hi, n, bits, logB, region0, raw, off, cursor, words);
+}
+
+// One FASTQ / oversize sample -> the packed words of the windows that enter its dictionary (unsorted, duplicates included).
+// SKF_NOT_TAKEN: the sample is left to the first form (partition overflow: a hash far more frequent than a partition holds).
+int reads_sample_words(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t len, int k, int rc, const skx_qual &q,
+                       DevBuf<uint64_t> &out_lo, DevBuf<uint64_t> &out_hi, uint64_t *n_out)
+{
+    hipStream_t st = ctx->stream;
+    const bool wide = k > 31;
+    *n_out = 0;
+    if (len == 0) return SKX_OK;
+    if (len > 0xFFFFFFF0ull) { set_error("FASTQ sample longer than 4 G bases"); return SKX_EUNSUP; }
+    DevBuf<uint64_t> wlo, whi, hash; DevBuf<uint8_t> flag;
+    DevBuf<unsigned long long> d_n; DevBuf<int> d_over;            // d_n[0]: positions / words that leave; d_n[1 .. 257): gated windows (spread counters)
+    SKX_TRY(d_n.alloc(257)); SKX_TRY(d_n.zero(st)); SKX_TRY(d_over.alloc(1)); SKX_TRY(d_over.zero(st));
+    SKX_TRY(reads_windows(ctx, d_seq, d_qual, len, k, rc, q, hash, wlo, whi, flag, d_n.p + 1));
+    unsigned long long n_acc = 0;
+    if (q.min_count <= 1) {                                        // KmerFilter: 0 | 1 => every gated window enters
+        SKX_TRY(out_lo.alloc(len)); if (wide) SKX_TRY(out_hi.alloc(len));
+        hipLaunchKernelGGL(words_from_flags_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, (const uint8_t *)flag.p, (const uint64_t *)wlo.p,
+                           wide ? (const uint64_t *)whi.p : (const uint64_t *)nullptr, len, out_lo.p, wide ? out_hi.p : (uint64_t *)nullptr, d_n.p);
+        SKX_HIP(hipMemcpyAsync(&n_acc, d_n.p, 8, hipMemcpyDeviceToHost, st));
+        SKX_HIP(hipStreamSynchronize(st));
+        SKX_HIP(hipGetLastError());
+        *n_out = n_acc;
+        return SKX_OK;
+    }
+    // two partition passes (coarse, then 256 final partitions each); capacities from the number of gated windows, hashes being uniform
+    unsigned long long n_win = 0, parts[256];                      // counted by the window kernel
+    SKX_HIP(hipMemcpyAsync(parts, d_n.p + 1, sizeof parts, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipStreamSynchronize(st));
+    for (auto c : parts) n_win += c;
+    if (n_win == 0) return SKX_OK;
+    // partition sizes vary more than a Poisson count: the ~35 occurrences of a k-mer of a 50x isolate move together
+    // (sigma ~ sqrt(35 x mean)); half the mean + 1 024 records of head-room covers that
+    const bool fine = (n_win / 65536) * 3 / 2 + 1024 > (uint64_t)RG_CAP;                  // > ~134 M windows: 262 144 partitions of 12 bloom words
+    const uint64_t n_part = fine ? 262144 : 65536, fan1 = n_part / 256;
+    const uint64_t cap1 = n_win / fan1 + n_win / (fan1 * 16) + 16384, cap2 = (n_win / n_part) * 3 / 2 + 1024;
+    if (cap2 > (uint64_t)RG_CAP) return SKF_NOT_TAKEN;                                     // beyond ~530 M windows
+    DevBuf<uint64_t> h1, h2; DevBuf<uint32_t> t1, t2, c1, c2, acc_t;
+    SKX_TRY(h1.alloc(fan1 * cap1)); SKX_TRY(t1.alloc(fan1 * cap1)); SKX_TRY(c1.alloc(fan1)); SKX_TRY(c1.zero(st));
+    SKX_TRY(h2.alloc(n_part * cap2)); SKX_TRY(t2.alloc(n_part * cap2)); SKX_TRY(c2.alloc(n_part)); SKX_TRY(c2.zero(st));
+    RsArgs a1{hash.p, nullptr, flag.p, nullptr, 0, len, h1.p, t1.p, c1.p, cap1, d_over.p};
+    RsArgs a2{h1.p, t1.p, nullptr, c1.p, cap1, 0, h2.p, t2.p, c2.p, cap2, d_over.p};
+    const dim3 g1((unsigned)((len + RS_TILE - 1) / RS_TILE)), g2((unsigned)((cap1 + RS_TILE - 1) / RS_TILE), (unsigned)fan1);
+    SKX_TRY(acc_t.alloc(q.min_count == 2 ? n_win : n_win / 2 + 1024));                     // min_count >= 3: one position per group of >= 2... at most n_win / 2
+    DevBuf<unsigned long long> d_dbg;
+    if (getenv("SKX_DEBUG")) { SKX_TRY(d_dbg.alloc(8)); SKX_TRY(d_dbg.zero(st)); }
+    RgArgs ag{h2.p, t2.p, c2.p, cap2, (int)q.min_count, acc_t.p, d_n.p, d_over.p, d_dbg.p};
+    const size_t lds = (size_t)RG_CAP * 12 + ((size_t)RG_MB + 2) * 4 + (size_t)RG_CAP * 2 + 64;
+    if (!fine) {
+        hipLaunchKernelGGL((rs_scatter_kernel<48 * 256, 256, true>), g1, dim3(RS_NT), 0, st, a1);
+        hipLaunchKernelGGL((rs_scatter_kernel<48, 256, false>), g2, dim3(RS_NT), 0, st, a2);
+        (void)hipFuncSetAttribute((const void *)rs_groups_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(rs_groups_kernel<48>, dim3((unsigned)n_part), dim3(RG_NT), lds, st, ag);
+    } else {
+        hipLaunchKernelGGL((rs_scatter_kernel<12 * 256, 1024, true>), g1, dim3(RS_NT), 0, st, a1);
+        hipLaunchKernelGGL((rs_scatter_kernel<12, 256, false>), g2, dim3(RS_NT), 0, st, a2);
+        (void)hipFuncSetAttribute((const void *)rs_groups_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(rs_groups_kernel<12>, dim3((unsigned)n_part), dim3(RG_NT), lds, st, ag);
+    }
+    int over = 0;
+    SKX_HIP(hipMemcpyAsync(&n_acc, d_n.p, 8, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipMemcpyAsync(&over, d_over.p, 4, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipStreamSynchronize(st));
+    SKX_HIP(hipGetLastError());
+    if (d_dbg.p) { unsigned long long hd[8]; SKX_HIP(hipMemcpy(hd, d_dbg.p, 64, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[skx] rs_groups cycles per partition: load %.0f, count+scan+scatter %.0f, rank+write+heads %.0f, groups/FP (lane 0) %.0f, wait+scan %.0f, output %.0f (windows %llu, partitions %llu, passing %llu)\n",
+                hd[0] / (double)n_part, hd[1] / (double)n_part, hd[2] / (double)n_part, hd[3] / (double)n_part, hd[4] / (double)n_part, hd[5] / (double)n_part, n_win, (unsigned long long)n_part, n_acc); }
+    if (over) { if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] reads: a partition overflowed, sample left to the sort-based form\n"); return SKF_NOT_TAKEN; }
+    if (n_acc == 0) return SKX_OK;
+    SKX_TRY(out_lo.alloc(n_acc)); if (wide) SKX_TRY(out_hi.alloc(n_acc));
+    hipLaunchKernelGGL(words_gather_kernel, dim3(grid_of(n_acc)), dim3(256), 0, st, (const uint32_t *)acc_t.p, (uint64_t)n_acc, (const uint64_t *)wlo.p,
+                       wide ? (const uint64_t *)whi.p : (const uint64_t *)nullptr, out_lo.p, wide ? out_hi.p : (uint64_t *)nullptr);
+    SKX_HIP(hipStreamSynchronize(st));
+    SKX_HIP(hipGetLastError());
+    *n_out = n_acc;
+    return SKX_OK;
+}
+
+}  // namespace skx

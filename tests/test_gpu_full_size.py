@@ -158,3 +158,54 @@ def test_config2_hundred_assemblies_through_the_executable(E, thousand):
         return m[:, np.lexsort(m[::-1])]
     assert g.split(b"\n")[0::2][:n] == o.split(b"\n")[0::2][:n]
     assert np.array_equal(cols(g), cols(o))
+
+
+def test_config5_one_isolate_at_size(E, thousand):
+    """BASELINE.json configs[4] shape, one isolate at its real size: 2 x 150 bp reads at 50x of a 5 Mbp genome (833 334 pairs, 252 M
+    stream bytes), 0.5 % substitution errors, per-cycle Phred profile; k = 41 (128-bit keys), --min-count 5, --qual-filter strict
+    --min-qual 20.  The engine's own partition kernels (skx_reads2.hip) against the oracle's sequential KmerFilter, exactly."""
+    import synth
+    td, _ = thousand
+    glen, rl, cov = 5_000_000, 150, 50.0
+    anc = synth.ancestor(glen, seed=1)
+    rng = np.random.default_rng([1, 99, 0])
+    g = synth.sample_bases(anc, 0, 1000)
+    npairs = int(cov * glen / rl / 2)
+    comp = np.zeros(256, np.uint8)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    files = []
+    for mate in (0, 1):
+        start = rng.integers(0, glen - rl, size=npairs)
+        reads = g[start[:, None] + np.arange(rl)[None, :]]
+        rev = rng.random(npairs) < 0.5
+        reads[rev] = comp[reads[rev][:, ::-1]]
+        err = rng.random(reads.shape) < 0.005
+        reads[err] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=int(err.sum()))]
+        prof = np.clip(38 - (np.arange(rl) // 10), 2, 40)
+        q = np.clip(prof[None, :] + rng.integers(-6, 3, size=reads.shape), 2, 41).astype(np.uint8) + 33
+        q[err] = 33 + 8
+        rec = np.empty((npairs, 3 + rl + 3 + rl + 1), np.uint8)            # "@r\n" seq "\n+\n" qual "\n"
+        rec[:, 0:3] = np.frombuffer(b"@r\n", np.uint8)
+        rec[:, 3:3 + rl] = reads
+        rec[:, 3 + rl:6 + rl] = np.frombuffer(b"\n+\n", np.uint8)
+        rec[:, 6 + rl:6 + 2 * rl] = q
+        rec[:, -1] = 10
+        p = os.path.join(td, f"iso_{mate + 1}.fastq")
+        rec.tofile(p)
+        files.append(p)
+    qo = ora.qual(5, 20, ora.QUAL_STRICT)
+    og = ora.Dict.from_files(41, files[0], files[1], True, qo)
+    ok, ob = og.export()
+    ds = E.DictSet.from_files([(files[0], files[1])], 41, True, E.qual(5, 20, E.QUAL_STRICT), threads=1)
+    gk, gb = ds.export(0)
+    assert 4_900_000 < len(gk) < 5_100_000
+    assert np.array_equal(gk["lo"], ok["lo"]) and np.array_equal(gk["hi"], ok["hi"]) and np.array_equal(gb, ob)
+    # the sort-based first form (rocPRIM) agrees as well
+    os.environ["SKX_READS_SORT"] = "1"
+    try:
+        ds2 = E.DictSet.from_files([(files[0], files[1])], 41, True, E.qual(5, 20, E.QUAL_STRICT), threads=1)
+    finally:
+        os.environ.pop("SKX_READS_SORT")
+    k2, b2 = ds2.export(0)
+    assert np.array_equal(k2["lo"], gk["lo"]) and np.array_equal(k2["hi"], gk["hi"]) and np.array_equal(b2, gb)
