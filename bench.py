@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--cpu-genomes", type=int, default=160, help="size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the files -> .skf -> FASTA leg through the ska executable")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle comparison")
+    ap.add_argument("--no-distance", action="store_true", help="skip the all-vs-all distance stage")
     ap.add_argument("--check", action="store_true", help="(kept for compatibility: the check always runs unless --no-check)")
     ap.add_argument("--cli-threads", type=int, default=0, help="--threads given to the ska executable (0 = min(64, cores))")
     return ap.parse_args()
@@ -369,9 +370,29 @@ def main():
         dt = float(t.item())
 
     n_distinct = None
+    distance_stage = None
     if rank == 0:                      # sum of the per-sample dictionary sizes (untimed): the D of SURVEY.md 8d's per-stage bytes
         ds = E.DictSet.build_device(ptrs, lens, args.k, True, ctx=ctx)
         n_distinct = int(sum(ds.size(i) for i in range(G)))
+        if world == 1 and not args.no_distance:
+            # `ska distance` on the same array (outside `value`): the constant-site filter, bit planes, all pairs
+            arr_d = ds.merge(names)
+            ctx.sync()
+            ctx.timings(reset=True)
+            t_d0 = time.perf_counter()
+            dd, constant, rows_d = arr_d.distance_filtered(0.0, True)          # generic_modes.rs:136-189: constant rows skipped while the planes are built
+            ctx.sync()
+            t_d = time.perf_counter() - t_d0
+            pairs = G * (G - 1) // 2
+            k_ms = ctx.timings()["distance"]
+            distance_stage = {"samples": G, "rows_after_no_const": int(rows_d), "pairs": pairs, "wall_s": t_d, "kernels_ms": k_ms,
+                              "pairs_per_s": pairs / t_d, "naive_bytes": 2.0 * rows_d * pairs, "naive_GBps": 2.0 * rows_d * pairs / (k_ms * 1e-3) / 1e9,
+                              "tiled_bound_bytes": float(G) * rows_d, "tiled_bound_ms_at_peak": float(G) * rows_d / (HBM_PEAK_GBS * 1e9) * 1e3,
+                              "constant_rows": int(constant),
+                              "what": "in process, array resident: row verdicts + bit planes of the kept rows + 32x32-pair popcount tiles (merge_ska_array.rs:416-438,587-632); "
+                                      "naive = every pair reading both rows (the reference's loop), tiled bound = the matrix read once",
+                              "first_pair": [float(dd["distance"][0]), int(dd["match_count"][0]), int(dd["mismatch_count"][0])]}
+            arr_d.free()
         ds.free()
     res = None
     if rank == 0:
@@ -402,6 +423,8 @@ def main():
             "other_kernels": other_kernels(tm, steps, total_bases, n_distinct, shape[0], shape[1], G),
             "host_wall_ms_per_step": {k: v / steps for k, v in host_ms.items()},
         }
+        if distance_stage:
+            res["distance"] = distance_stage
         if sharded:
             res["exchange_per_step_rank0"] = {"key_table_allgather_ms": xch["key_table_allgather_s"] / steps * 1e3, "key_table_allgather_bytes": xch["key_table_allgather_bytes_per_rank"],
                                               "row_stats_ms": xch["row_stats_s"] / steps * 1e3, "row_stats_bytes": xch["row_stats_bytes_per_rank"],

@@ -170,6 +170,11 @@ int  skx_array_set_total_samples(skx_array *a, uint64_t total_samples);
 typedef struct { double distance, mismatch_prop; uint64_t match_count, mismatch_count; } skx_dist;
 /* MergeSkaArray::distance (merge_ska_array.rs:416-438,587-632): upper triangle, pairs (i<j) row-major */
 int  skx_array_distance(skx_array *a, double constant, int filt_ambig, skx_dist *out);
+/* generic_modes::distance (generic_modes.rs:136-189) in one call that leaves the array as it is: rows below ceil(n_samples *
+ * min_freq) (when min_freq * n_samples >= 1) and constant rows are skipped while the bit planes are built (*constant = rows the
+ * NoConst stage removes, added to every pair's matches), instead of being filtered out of the matrix first.  Same numbers as
+ * skx_array_filter x 2 + skx_array_distance. */
+int  skx_array_distance_filtered(skx_array *a, double min_freq, int filt_ambig, skx_dist *out, int64_t *constant, uint64_t *rows_used);
 /* The two halves of skx_array_distance, so that a multi-GPU host can exchange the bit planes between them (SURVEY.md 8e:
  * "tile the pair matrix over ranks"): every rank builds the planes of its own samples over the (globally filtered) rows, the
  * planes are all-gathered (plane-major: planes[p][sample][word], 4 planes with filt_ambig, 8 without), and each rank

@@ -1767,6 +1767,47 @@ static int planes_distance(skx_ctx *ctx, const uint64_t *planes, int S, uint64_t
     return SKX_OK;
 }
 
+// generic_modes::distance (generic_modes.rs:136-189) on an array in memory without touching it: the two filters decide per row, the
+// bit planes are built over the rows that stay, the pair sweep runs on those -- no compaction of the rows x samples matrix.
+extern "C" int skx_array_distance_filtered(skx_array *a, double min_freq, int filt_ambig, skx_dist *out, int64_t *constant, uint64_t *rows_used)
+{
+    return skx_guarded([&]() -> int {
+    if (!a || !out) { set_error("bad arguments"); return SKX_EINVAL; }
+    skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
+    SKX_HIP(hipSetDevice(ctx->device));
+    SKX_TRY(array_materialize(a));
+    const int S = (int)a->names.size(); const uint64_t U = a->n_rows;
+    const uint64_t S_total = a->total_samples ? a->total_samples : (uint64_t)S;
+    const uint64_t thr = min_freq * (double)S_total >= 1.0 ? (uint64_t)std::ceil((double)S_total * min_freq) : 0;       // generic_modes.rs:149-159
+    if (constant) *constant = 0;
+    if (rows_used) *rows_used = 0;
+    if (S < 2) return SKX_OK;
+    StageTimer t(ctx, &ctx->tm.distance);
+    uint64_t kept = 0; unsigned long long n_const = 0;
+    DevBuf<uint64_t> planes; uint64_t wpr = 1;
+    if (U) {
+        DevBuf<uint8_t> keep; DevBuf<uint64_t> pos, sc_offs, kb, gp; DevBuf<uint32_t> sc_sums; DevBuf<unsigned long long> d_c;
+        SKX_TRY(keep.alloc(U)); SKX_TRY(pos.alloc(U + 1)); SKX_TRY(sc_sums.alloc(scan_u8_blocks(U))); SKX_TRY(sc_offs.alloc(scan_u8_blocks(U) + 1));
+        SKX_TRY(kb.alloc((U + 63) / 64)); SKX_TRY(gp.alloc((U + 63) / 64)); SKX_TRY(d_c.alloc(1)); SKX_TRY(d_c.zero(st));
+        FilterArgs fa{a->vcount.p, a->present.p, a->unambig.p, a->mask.p, U, (uint32_t)S_total, thr, 0, SKX_FILTER_NO_CONST, 0, keep.p, 1};
+        launch_filter_flags(fa, st);
+        launch_scan_u8(keep.p, pos.p, U, sc_sums.p, sc_offs.p, st);
+        launch_count_u8(keep.p, U, 3, d_c.p, st);
+        SKX_HIP(hipMemcpyAsync(&kept, pos.p + U, 8, hipMemcpyDeviceToHost, st));
+        SKX_HIP(hipMemcpyAsync(&n_const, d_c.p, 8, hipMemcpyDeviceToHost, st));
+        SKX_HIP(hipStreamSynchronize(st));
+        wpr = std::max<uint64_t>((kept + 63) / 64, 1);
+        SKX_TRY(planes.alloc((filt_ambig ? 4 : 8) * (uint64_t)S * wpr)); SKX_TRY(planes.zero(st));
+        launch_keep_bits(keep.p, pos.p, U, kb.p, gp.p, st);
+        if (kept) launch_build_planes_keep(a->matrix.p, a->pitch, S, U, kb.p, gp.p, planes.p, wpr, filt_ambig, st);
+        SKX_HIP(hipStreamSynchronize(st));            // keep / pos / kb / gp go out of scope
+    } else { SKX_TRY(planes.alloc((filt_ambig ? 4 : 8) * (uint64_t)S)); SKX_TRY(planes.zero(st)); }
+    if (constant) *constant = (int64_t)n_const;
+    if (rows_used) *rows_used = kept;
+    return planes_distance(ctx, planes.p, S, wpr, filt_ambig, (double)n_const, 0, S, out);
+    });
+}
+
 extern "C" int skx_array_distance_planes(skx_array *a, int filt_ambig, const void **planes, uint64_t *words_per_row, int *n_planes)
 {
     return skx_guarded([&]() -> int {

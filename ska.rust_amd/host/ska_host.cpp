@@ -128,35 +128,24 @@ extern "C" int skh_align_fd(skx_array *a, int filter_type, int mask_ambig, int i
     });
 }
 
+static int distance_text(skx_array *a, const std::vector<skx_dist> &d, char **buf, uint64_t *len);
 extern "C" int skh_distance_tsv(skx_array *a, double min_freq, int filt_ambig, char **buf, uint64_t *len)
 {
     return skx_guarded([&]() -> int {
     skx_array_info_t info; skx_array_info(a, &info);
-    int32_t removed = 0; int r;
-    if (min_freq * (double)info.n_samples >= 1.0)                                             // generic_modes.rs:149-159
-        if ((r = skh_apply_filters(a, min_freq, 0, SKX_FILTER_NONE, 0, 0, &removed)) != SKX_OK) return r;
-    int32_t constant = 0;
-    if ((r = skh_apply_filters(a, 0.0, 0, SKX_FILTER_NO_CONST, 0, 0, &constant)) != SKX_OK) return r;   // :161-168
     const uint64_t S = info.n_samples;
     std::vector<skx_dist> d(S * (S - 1) / 2 + 1);
-    if ((r = skx_array_distance(a, (double)constant, filt_ambig, d.data())) != SKX_OK) return r;
-    std::string out = "Sample1\tSample2\tDistance\tMismatches (proportion)\tMatch count\tMismatch count\n";
-    size_t n = 0;
-    for (uint64_t i = 0; i < S; i++)
-        for (uint64_t j = i + 1; j < S; j++, n++)
-            put(out, "%s\t%s\t%.2f\t%.5f\t%llu\t%llu\n", skx_array_name(a, i), skx_array_name(a, j), d[n].distance, d[n].mismatch_prop,
-                (unsigned long long)d[n].match_count, (unsigned long long)d[n].mismatch_count);
-    return to_buf(out, buf, len);
+    int64_t constant = 0; uint64_t rows = 0; int r;
+    // the two filters of generic_modes.rs:149-168 are applied while the bit planes are built; the array itself stays as it is
+    { Phase pd("distance.pair_sweep"); if ((r = skx_array_distance_filtered(a, min_freq, filt_ambig, d.data(), &constant, &rows)) != SKX_OK) return r; }
+    return distance_text(a, d, buf, len);
     });
 }
 
-static int distance_table(skx_array *a, double constant, int filt_ambig, char **buf, uint64_t *len)
+static int distance_text(skx_array *a, const std::vector<skx_dist> &d, char **buf, uint64_t *len)
 {
     skx_array_info_t info; skx_array_info(a, &info);
     const uint64_t S = info.n_samples;
-    std::vector<skx_dist> d(S * (S - 1) / 2 + 1);
-    int r;
-    { Phase pd("distance.pair_sweep"); if ((r = skx_array_distance(a, constant, filt_ambig, d.data())) != SKX_OK) return r; }
     Phase pt("distance.table_text");
     std::string out = "Sample1\tSample2\tDistance\tMismatches (proportion)\tMatch count\tMismatch count\n";
     size_t n = 0;
@@ -165,6 +154,15 @@ static int distance_table(skx_array *a, double constant, int filt_ambig, char **
             put(out, "%s\t%s\t%.2f\t%.5f\t%llu\t%llu\n", skx_array_name(a, i), skx_array_name(a, j), d[n].distance, d[n].mismatch_prop,
                 (unsigned long long)d[n].match_count, (unsigned long long)d[n].mismatch_count);
     return to_buf(out, buf, len);
+}
+static int distance_table(skx_array *a, double constant, int filt_ambig, char **buf, uint64_t *len)
+{
+    skx_array_info_t info; skx_array_info(a, &info);
+    const uint64_t S = info.n_samples;
+    std::vector<skx_dist> d(S * (S - 1) / 2 + 1);
+    int r;
+    { Phase pd("distance.pair_sweep"); if ((r = skx_array_distance(a, constant, filt_ambig, d.data())) != SKX_OK) return r; }
+    return distance_text(a, d, buf, len);
 }
 
 extern "C" int skh_distance_skf_tsv(skx_ctx *ctx, const char *skf_file, double min_freq, int filt_ambig, char **buf, uint64_t *len)

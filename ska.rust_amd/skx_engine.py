@@ -57,7 +57,7 @@ skx_keyset_union skx_keyset_size skx_keyset_device skx_keyset_from_device skx_ke
 skx_array_assemble skx_merge skx_build_and_merge skx_array_free skx_array_save skx_array_load skx_array_from_host
 skx_array_info skx_array_name skx_array_version skx_array_export skx_array_sample_kmers skx_array_filter
 skx_array_write_fasta skx_array_fasta skx_array_device_matrix skx_array_device_stats skx_array_set_total_samples skx_array_distance skx_free skx_ctx_timings
-skx_array_merge skx_array_delete_samples skx_array_weed skx_keyset_from_fasta skx_array_ctx skx_set_last_error skx_array_map skx_cov_histogram skx_phases_json skx_phase_add skx_array_load_filtered skx_ctx_expect_output skx_array_distance_planes skx_planes_distance
+skx_array_merge skx_array_delete_samples skx_array_weed skx_keyset_from_fasta skx_array_ctx skx_set_last_error skx_array_map skx_cov_histogram skx_phases_json skx_phase_add skx_array_load_filtered skx_ctx_expect_output skx_array_distance_planes skx_planes_distance skx_array_distance_filtered
 skh_apply_filters skh_align skh_align_fd skh_distance_tsv skh_nk skh_save_skf skh_load_array skh_sample_name skh_main skh_merge skh_delete skh_weed skh_cov skh_cov_fit skh_align_inputs_fd skh_distance_skf_tsv""".split()
 
 _lib = None
@@ -142,6 +142,7 @@ def load_library():
     lib.skx_ctx_expect_output.argtypes = [vp, i]
     lib.skx_array_distance_planes.argtypes = [vp, i, pp, C.POINTER(u64), C.POINTER(i)]
     lib.skx_planes_distance.argtypes = [vp, vp, i, u64, i, d, i, i, vp]
+    lib.skx_array_distance_filtered.argtypes = [vp, d, i, vp, C.POINTER(C.c_int64), C.POINTER(u64)]
     lib.skx_array_load_filtered.argtypes = [vp, cp, C.POINTER(FilterSpec), pp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.skh_align_inputs_fd.argtypes = [vp, C.POINTER(cp), i, i, i, i, i, d, i, i]
     lib.skh_distance_skf_tsv.argtypes = [vp, cp, d, i, pp, C.POINTER(u64)]
@@ -578,6 +579,14 @@ class Array:
         out = np.zeros(s * (s - 1) // 2, DIST_DT)
         _check(_lib.skx_array_distance(self.h, constant, int(filt_ambig), _np_ptr(out)))
         return out
+
+    def distance_filtered(self, min_freq=0.0, filt_ambig=True):
+        """generic_modes::distance without filtering the array itself -> (pairs, constant sites, rows used)"""
+        s = self.nsamples
+        out = np.zeros(max(s * (s - 1) // 2, 1), DIST_DT)
+        cst, rows = C.c_int64(), C.c_uint64()
+        _check(_lib.skx_array_distance_filtered(self.h, float(min_freq), int(filt_ambig), _np_ptr(out), C.byref(cst), C.byref(rows)))
+        return out[: s * (s - 1) // 2], cst.value, rows.value
 
     def distance_planes(self, filt_ambig=True):
         """device pointer to this array's bit planes [n_planes][n_samples][words_per_row] -> (ptr, words_per_row, n_planes)"""
