@@ -455,6 +455,14 @@ __device__ static inline uint32_t home_slot(uint64_t w, int rem_bits, uint32_t n
     }
     return __umulhi(l32, nslots);
 }
+// FAST: the caller guarantees 32 <= rem_bits <= 59 (one v_alignbit, and no uniform branch for the compiler to unswitch the
+// unrolled probe loops on: that tripled the register count of union_kernel)
+template <bool FAST>
+__device__ static inline uint32_t home_slot_t(uint64_t w, int rem_bits, uint32_t nslots)
+{
+    if (FAST) return __umulhi(__builtin_amdgcn_alignbit((uint32_t)(w >> 32), (uint32_t)w, (uint32_t)(rem_bits - 28)), nslots);
+    return home_slot(w, rem_bits, nslots);
+}
 __device__ static inline bool table_insert(unsigned long long *tab, uint32_t total_slots, uint32_t home, uint64_t w)
 {
     const uint64_t key = w >> 4;
@@ -771,7 +779,13 @@ __device__ static inline void sub_slice(const DictView &d, int sample, uint64_t 
 }
 
 // K4: distinct keys of sub-bucket j over all samples -> sorted slab
-template <bool COUNT_ONLY>
+#ifndef SKX_UNION_U
+#define SKX_UNION_U 5
+#endif
+#ifndef SKX_UNION_PREFETCH
+#define SKX_UNION_PREFETCH 0
+#endif
+template <bool COUNT_ONLY, bool FAST>
 __global__ __launch_bounds__(1024, 8) void union_kernel(DictView d, int logN, uint64_t *stage, uint32_t stride, uint32_t *ncnt,
                                                     uint32_t nslots, int *overflow)
 {
@@ -793,23 +807,61 @@ __global__ __launch_bounds__(1024, 8) void union_kernel(DictView d, int logN, ui
         const uint64_t *my_reg = nullptr; uint32_t my_lo = 0, my_hi = 0;
         const int cnt = wend - s0 < 64 ? wend - s0 : 64;
         if (lane < cnt) sub_slice(d, s0 + lane, j, logN, my_reg, my_lo, my_hi);
-        // the two halves of the wave stream two samples' slices at once: twice the loads in flight per wave
-        const int half = lane >> 5, hl = lane & 31;
-        for (int t = 0; t < cnt; t += 2) {
-            const int src = t + half < cnt ? t + half : t;                 // odd count: the upper half idles on the last round
-            gwords_t reg = as_global(reinterpret_cast<const uint64_t *>(__shfl((unsigned long long)my_reg, src, 64)));
-            const uint32_t lo = __shfl(my_lo, src, 64), hi_s = __shfl(my_hi, src, 64);        // (shuffles outside any lane-dependent branch)
-            const uint32_t hi = t + half < cnt ? hi_s : lo;
-            const uint32_t other_lo = __shfl(lo, lane ^ 32, 64), other_hi = __shfl(hi, lane ^ 32, 64);
-            const uint32_t span = hi - lo > other_hi - other_lo ? hi - lo : other_hi - other_lo;     // wave-uniform trip count
-            for (uint32_t o = 0; o < span; o += 320) {
-                uint64_t wq[10];
+        // One slice at a time, UU words per lane (a slice of the 1 000 x 5 Mbp case is ~300 words: one batch).  >99 % of the
+        // words are already in the table with their base in the stored mask, so the home slots of a whole batch are probed
+        // with independent LDS reads (one latency per batch, not one per word) and only the rest takes the insert loop;
+        // the next slice's loads are issued before the current batch is looked at.
+        constexpr int UU = SKX_UNION_U;
+        auto fetch = [&](int t, uint64_t (&q)[UU], uint32_t &lo, uint32_t &hi, gwords_t &reg) {
+            reg = as_global(reinterpret_cast<const uint64_t *>(__shfl((unsigned long long)my_reg, t, 64)));
+            lo = __shfl(my_lo, t, 64); hi = __shfl(my_hi, t, 64);
 #pragma unroll
-                for (int u = 0; u < 10; u++) { const uint32_t i = lo + o + 32u * u + hl; wq[u] = i < hi ? reg[i] : 0ull; }
+            for (int u = 0; u < UU; u++) { const uint32_t i = lo + 64u * u + lane; q[u] = i < hi ? reg[i] : 0ull; }
+        };
+        auto absorb = [&](const uint64_t (&q)[UU], gwords_t reg, uint32_t first) {
+            uint32_t miss = 0;
 #pragma unroll
-                for (int u = 0; u < 10; u++)
-                    if (wq[u] && !table_insert(s_tab, total_slots, home_slot(wq[u], rem_bits, nslots), wq[u])) s_fail = 1;
+            for (int g = 0; g < UU; g += 3) {
+                unsigned long long s0[3], s1[3];
+#pragma unroll
+                for (int u = 0; u < 3; u++) {                            // home slot and its successor (one ds_read2_b64): a key displaced by
+                    if (g + u >= UU) continue;                           // one slot is still a hit
+                    const uint32_t hslot = home_slot_t<FAST>(q[g + u], rem_bits, nslots);
+                    s0[u] = s_tab[hslot]; s1[u] = s_tab[hslot + 1];
+                }
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    if (g + u >= UU) continue;
+                    const uint64_t w = q[g + u];
+                    const unsigned long long at = ((s0[u] ^ w) >> 4) == 0ull ? s0[u] : (s0[u] != 0ull && ((s1[u] ^ w) >> 4) == 0ull) ? s1[u] : 0ull;
+                    if (w && (w & 15ull & ~at) != 0ull) miss |= 1u << (g + u);      // not found, or found without this base in its mask
+                }
             }
+            while (miss) {                                               // first sightings, new bases, keys displaced further: the word is
+                const int u = __ffs(miss) - 1; miss &= miss - 1;         // read again (L2 / L1 hit) rather than selected from q[] by a
+                const uint64_t w = reg[first + 64u * u + lane];          // run-time index, which would put the batch into scratch memory
+                if (!table_insert(s_tab, total_slots, home_slot_t<FAST>(w, rem_bits, nslots), w)) s_fail = 1;
+            }
+        };
+        uint64_t nx[UU]; uint32_t nlo, nhi; gwords_t nreg;
+        fetch(0, nx, nlo, nhi, nreg);
+        for (int t = 0; t < cnt; t++) {
+            uint64_t cur[UU];
+#pragma unroll
+            for (int u = 0; u < UU; u++) cur[u] = nx[u];
+            const uint32_t lo = nlo, hi = nhi; gwords_t reg = nreg;
+#if SKX_UNION_PREFETCH
+            if (t + 1 < cnt) fetch(t + 1, nx, nlo, nhi, nreg);
+#endif
+            absorb(cur, reg, lo);
+            for (uint32_t o = lo + 64u * UU; o < hi; o += 64u * UU) {          // longer slices: the rest, batch by batch
+#pragma unroll
+                for (int u = 0; u < UU; u++) { const uint32_t i = o + 64u * u + lane; cur[u] = i < hi ? reg[i] : 0ull; }
+                absorb(cur, reg, o);
+            }
+#if !SKX_UNION_PREFETCH
+            if (t + 1 < cnt) fetch(t + 1, nx, nlo, nhi, nreg);
+#endif
         }
     }
     __syncthreads();
@@ -825,18 +877,28 @@ __global__ __launch_bounds__(1024, 8) void union_kernel(DictView d, int logN, ui
     uint32_t total = table_emit_sorted(s_tab, total_slots, s_tmp, [&](uint32_t idx, uint64_t w) { if (idx < stride) slab[idx] = (w & ~15ull) | 1ull; });
     if (threadIdx.x == 0) { ncnt[j] = total; if (total > stride) *overflow = 1; }
 }
+template <bool COUNT_ONLY>
+static void launch_union_t(const DictView &d, int logN, unsigned blocks, uint64_t *stage, uint32_t stride, uint32_t *ncnt, uint32_t table_slots,
+                           int *overflow, hipStream_t st)
+{
+    size_t lds = (size_t)(table_slots + TABLE_PAD) * 8;
+    const int rem = d.bits - logN;
+    if (rem >= 32 && rem <= 59) {
+        (void)hipFuncSetAttribute((const void *)union_kernel<COUNT_ONLY, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((union_kernel<COUNT_ONLY, true>), dim3(blocks), dim3(1024), lds, st, d, logN, stage, stride, ncnt, table_slots, overflow);
+    } else {
+        (void)hipFuncSetAttribute((const void *)union_kernel<COUNT_ONLY, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((union_kernel<COUNT_ONLY, false>), dim3(blocks), dim3(1024), lds, st, d, logN, stage, stride, ncnt, table_slots, overflow);
+    }
+}
 void launch_union(const DictView &d, int logN, uint64_t *stage, uint32_t stride, uint32_t *ncnt, uint32_t table_slots,
                   int *overflow, hipStream_t st)
 {
-    size_t lds = (size_t)(table_slots + TABLE_PAD) * 8;
-    (void)hipFuncSetAttribute((const void *)union_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(union_kernel<false>, dim3(1u << logN), dim3(1024), lds, st, d, logN, stage, stride, ncnt, table_slots, overflow);
+    launch_union_t<false>(d, logN, 1u << logN, stage, stride, ncnt, table_slots, overflow, st);
 }
 void launch_union_probe(const DictView &d, int logP, int probe, uint32_t *cnt, uint32_t table_slots, int *overflow, hipStream_t st)
 {
-    size_t lds = (size_t)(table_slots + TABLE_PAD) * 8;
-    (void)hipFuncSetAttribute((const void *)union_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(union_kernel<true>, dim3((unsigned)probe), dim3(1024), lds, st, d, logP, (uint64_t *)nullptr, 0u, cnt, table_slots, overflow);
+    launch_union_t<true>(d, logP, (unsigned)probe, nullptr, 0u, cnt, table_slots, overflow, st);
 }
 
 // IUPAC letter of a base set; bit i of the set == 2-bit code i (A0 C1 T2 G3), cf. bit_encoding.rs:337-368
@@ -924,26 +986,37 @@ __global__ __launch_bounds__(512, 8) void assemble_kernel(AssembleArgs a)
                 uint64_t wq[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++) { const uint32_t i = i0 + 64u * u + lane; wq[u] = i < hi ? reg[i] : 0ull; }
+                // look-ups of four words at a time: index cells, then first keys (independent LDS reads: two latencies per
+                // four words instead of eight or more); the statistics / cell writes need no return value
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const uint64_t w = wq[u];
-                    if (i0 + 64u * u + lane >= hi) continue;
-                    const uint64_t key = w >> 4;
-                    const uint32_t ib = word_field<false>(w, rem - logI + 4, nidx - 1);
-                    uint32_t l = s_idx[ib];
-                    const uint32_t le = s_idx[ib + 1];
-                    while (l < le && s_keys[l] < key) l++;
-                    if (l < le && s_keys[l] == key) {
-                        const uint32_t m4 = (uint32_t)(w & 15u);
-                        if (MODE == 0) row[shift + l] = mask2iupac(m4);
-                        if (MODE == 2) { const uint32_t o = s_map[l]; if (o != 0xFFFFu) row[shift + o] = (a.mask_ambig && (m4 & (m4 - 1))) ? (unsigned char)'N' : mask2iupac(m4); }
-                        if (MODE != 2) {
-                            const uint32_t single = (m4 & (m4 - 1)) == 0;
-                            atomicAdd(&s_cnt[l], 1u | (single << 16));
-                            atomicOr(&s_msk[l >> 1], (1u << m4) << (16u * (l & 1u)));
+                for (int h = 0; h < 8; h += 4) {
+                    uint32_t l[4], le[4]; uint64_t kk[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t ib = word_field<false>(wq[h + u], rem - logI + 4, nidx - 1);
+                        l[u] = s_idx[ib]; le[u] = s_idx[ib + 1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) kk[u] = s_keys[l[u]];                 // (l <= n < maxr: always inside the array)
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint64_t w = wq[h + u];
+                        if (i0 + 64u * (h + u) + lane >= hi) continue;
+                        const uint64_t key = w >> 4;
+                        uint32_t ll = l[u]; uint64_t k = kk[u];
+                        while (ll < le[u] && k < key) { ll++; k = s_keys[ll]; }
+                        if (ll < le[u] && k == key) {
+                            const uint32_t m4 = (uint32_t)(w & 15u);
+                            if (MODE == 0) row[shift + ll] = mask2iupac(m4);
+                            if (MODE == 2) { const uint32_t o = s_map[ll]; if (o != 0xFFFFu) row[shift + o] = (a.mask_ambig && (m4 & (m4 - 1))) ? (unsigned char)'N' : mask2iupac(m4); }
+                            if (MODE != 2) {
+                                const uint32_t single = (m4 & (m4 - 1)) == 0;
+                                atomicAdd(&s_cnt[ll], 1u | (single << 16));
+                                atomicOr(&s_msk[ll >> 1], (1u << m4) << (16u * (ll & 1u)));
+                            }
+                        } else {
+                            *a.missing = 1;
                         }
-                    } else {
-                        *a.missing = 1;
                     }
                 }
             }

@@ -1,12 +1,21 @@
 #!/bin/bash
-# tools/mkvariant.sh <name> <sed-expr>...: build ab/libskx_<name>.so from skx_device.hip patched with the sed expressions (A/B experiments)
+# tools/mkvariant.sh <name> [--rev <git rev>] [-D<macro>...] [<sed-expr>...]: build ab/libskx_<name>.so from skx_device.hip (the working file, or
+# the one of a revision) patched with the sed expressions / compiled with the macros, linked with the other objects of the current build (A/B experiments)
 set -e
 cd "$(dirname "$0")/../ska.rust_amd"
 name=$1; shift
-args=(); for e in "$@"; do args+=(-e "$e"); done
-if [ ${#args[@]} -gt 0 ]; then sed "${args[@]}" csrc/skx_device.hip > csrc/_v.hip; else cp csrc/skx_device.hip csrc/_v.hip; fi
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -c csrc/_v.hip -o build/_v.o
-rm csrc/_v.hip
+src=csrc/skx_device.hip; defs=(); args=()
+while [ $# -gt 0 ]; do
+  case "$1" in
+    --rev) git show "$2:ska.rust_amd/csrc/skx_device.hip" > csrc/_base.hip; src=csrc/_base.hip; shift 2;;
+    -D*) defs+=("$1"); shift;;
+    *) args+=(-e "$1"); shift;;
+  esac
+done
+if [ ${#args[@]} -gt 0 ]; then sed "${args[@]}" $src > csrc/_v.hip; else cp $src csrc/_v.hip; fi
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result "${defs[@]}" -c csrc/_v.hip -o build/_v.o
+rm -f csrc/_v.hip csrc/_base.hip
 mkdir -p ../ab
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../ab/libskx_$name.so build/_v.o build/skx_reads.o build/skx_setops.o build/skx_snappy.o build/skx_api.o build/skx_api_io.o build/fastx.o build/skf_codec.o build/ska_host.o -lz -lpthread
+objs=$(ls build/*.o | grep -v -e '/_v.o' -e '/skx_device.o' -e '/ska_main.o')
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../ab/libskx_$name.so build/_v.o $objs -lz -lpthread
 echo built ab/libskx_$name.so
