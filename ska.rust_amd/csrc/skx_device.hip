@@ -330,8 +330,15 @@ static void launch_extract(const ExtractArgs &a, hipStream_t st)
 // against 18.2 ms with 16 384-position tiles and one workgroup, 800 x 6 Mbp).
 int extract_tile_bases(int logB) { return logB <= 11 ? 12288 : 8192; }
 void launch_hist(const ExtractArgs &a, hipStream_t st) { launch_extract<false>(a, st); }
-void launch_scatter(const ExtractArgs &a, hipStream_t st) { launch_extract<true>(a, st); }
-
+#include "skx_extract_lines.inc"
+void launch_scatter(const ExtractArgs &a, hipStream_t st)
+{
+    // SKX_EXTRACT_LINES=1: the one-workgroup-per-sample form that writes whole lines (skx_extract_lines.inc).  Off by default:
+    // its writes run at the streaming rate, but keeping the open lines costs more VALU work than the staging pass it replaces
+    // (24.2 ms against 13.3 ms per 1 000 x 5 Mbp).
+    const char *force = getenv("SKX_EXTRACT_LINES");
+    if (force && atoi(force) != 0 && extract_lines_applicable(a)) launch_scatter_lines(a, st); else launch_extract<true>(a, st);
+}
 // ------------------------------------------------------------------------------------------------
 // block-wide helpers
 // ------------------------------------------------------------------------------------------------
@@ -910,6 +917,18 @@ __device__ static inline unsigned char mask2iupac(uint32_t m4)
     return (unsigned char)(((m4 & 8u) ? hi : lo) >> (8u * (m4 & 7u)));
 }
 
+#ifndef SKX_ASM_U
+#define SKX_ASM_U 6
+#endif
+#ifndef SKX_ASM_GRP
+#define SKX_ASM_GRP 3
+#endif
+#ifndef SKX_ASM_WPS
+#define SKX_ASM_WPS 6
+#endif
+#ifndef SKX_ASM_PREFETCH
+#define SKX_ASM_PREFETCH 0
+#endif
 // K5: rows = key slabs, columns = samples: fill the sample-major matrix + per-row statistics.
 // MODE 0: matrix + statistics (columns land at roff[j] - col_base: a window of sub-buckets can be assembled into a small
 //         buffer, which is how a lazily held array is streamed into a .skf without ever existing in full);
@@ -917,7 +936,7 @@ __device__ static inline unsigned char mask2iupac(uint32_t m4)
 // MODE 2: kept rows only -- keep[] / kpos[] (flags and their exclusive scan over all rows) select the rows, which land at
 //         column kpos[row]: the filtered array is written directly, the unfiltered one never is.
 template <int MODE>
-__global__ __launch_bounds__(512, 8) void assemble_kernel(AssembleArgs a)
+__global__ __launch_bounds__(512, SKX_ASM_WPS) void assemble_kernel(AssembleArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const uint64_t j = (uint64_t)blockIdx.x + a.j_base;
@@ -973,53 +992,75 @@ __global__ __launch_bounds__(512, 8) void assemble_kernel(AssembleArgs a)
             sub_slice(a.d, sbase + lane, j, a.logN, my_reg, my_lo, my_hi);
             my_off = (uint64_t)(my_reg - wbase);
         }
+        constexpr int AU = SKX_ASM_U, GRP = SKX_ASM_GRP;
+        auto fetch = [&](int t, uint64_t (&q)[AU], uint32_t &lo, uint32_t &hi, gwords_t &reg) {
+            reg = as_global(wbase + __shfl((unsigned long long)my_off, t, 64));
+            lo = __shfl(my_lo, t, 64); hi = __shfl(my_hi, t, 64);
+#pragma unroll
+            for (int u = 0; u < AU; u++) { const uint32_t i = lo + 64u * u + lane; q[u] = i < hi ? reg[i] : 0ull; }
+        };
+        // look-ups of GRP words at a time: index cells, then first keys (independent LDS reads: two latencies per group instead
+        // of two or more per word); the statistics / cell writes need no return value.  A word is never 0 (non-empty base set).
+        auto place = [&](const uint64_t (&q)[AU]) {
+#pragma unroll
+            for (int h = 0; h < AU; h += GRP) {
+                uint32_t l[GRP], le[GRP]; uint64_t kk[GRP];
+#pragma unroll
+                for (int u = 0; u < GRP; u++) {
+                    if (h + u >= AU) continue;
+                    const uint32_t ib = word_field<false>(q[h + u], rem - logI + 4, nidx - 1);
+                    l[u] = s_idx[ib]; le[u] = s_idx[ib + 1];
+                }
+#pragma unroll
+                for (int u = 0; u < GRP; u++) { if (h + u >= AU) continue; kk[u] = s_keys[l[u]]; }     // (l <= n <= maxr: inside the LDS block)
+#pragma unroll
+                for (int u = 0; u < GRP; u++) {
+                    if (h + u >= AU) continue;
+                    const uint64_t w = q[h + u];
+                    if (!w) continue;
+                    const uint64_t key = w >> 4;
+                    uint32_t ll = l[u]; uint64_t k = kk[u];
+                    while (ll < le[u] && k < key) { ll++; k = s_keys[ll]; }
+                    if (ll < le[u] && k == key) {
+                        const uint32_t m4 = (uint32_t)(w & 15u);
+                        if (MODE == 0) row[shift + ll] = mask2iupac(m4);
+                        if (MODE == 2) { const uint32_t o = s_map[ll]; if (o != 0xFFFFu) row[shift + o] = (a.mask_ambig && (m4 & (m4 - 1))) ? (unsigned char)'N' : mask2iupac(m4); }
+                        if (MODE != 2) {
+                            const uint32_t single = (m4 & (m4 - 1)) == 0;
+                            atomicAdd(&s_cnt[ll], 1u | (single << 16));
+                            atomicOr(&s_msk[ll >> 1], (1u << m4) << (16u * (ll & 1u)));
+                        }
+                    } else {
+                        *a.missing = 1;
+                    }
+                }
+            }
+        };
+        uint64_t nx[AU]; uint32_t nlo, nhi; gwords_t nreg;
+        fetch(0, nx, nlo, nhi, nreg);
         for (int t = 0; t < cnt; t++) {
             const int s = sbase + t;
-            gwords_t reg = as_global(wbase + __shfl((unsigned long long)my_off, t, 64));
-            const uint32_t lo = __shfl(my_lo, t, 64), hi = __shfl(my_hi, t, 64);
+            uint64_t cur[AU];
+#pragma unroll
+            for (int u = 0; u < AU; u++) cur[u] = nx[u];
+            const uint32_t lo = nlo, hi = nhi; gwords_t reg = nreg;
+#if SKX_ASM_PREFETCH
+            if (t + 1 < cnt) fetch(t + 1, nx, nlo, nhi, nreg);             // the next slice is on its way while this one is placed
+#endif
             if (MODE != 1) {
                 // fill with '-'
                 for (uint32_t i = lane * 4; i < nout + shift + 3; i += 256) *reinterpret_cast<uint32_t *>(row + i) = 0x2D2D2D2Du;
                 __builtin_amdgcn_wave_barrier();
             }
-            for (uint32_t i0 = lo; i0 < hi; i0 += 512) {
-                uint64_t wq[8];
+            place(cur);
+            for (uint32_t o = lo + 64u * AU; o < hi; o += 64u * AU) {          // longer slices: the rest, batch by batch
 #pragma unroll
-                for (int u = 0; u < 8; u++) { const uint32_t i = i0 + 64u * u + lane; wq[u] = i < hi ? reg[i] : 0ull; }
-                // look-ups of four words at a time: index cells, then first keys (independent LDS reads: two latencies per
-                // four words instead of eight or more); the statistics / cell writes need no return value
-#pragma unroll
-                for (int h = 0; h < 8; h += 4) {
-                    uint32_t l[4], le[4]; uint64_t kk[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const uint32_t ib = word_field<false>(wq[h + u], rem - logI + 4, nidx - 1);
-                        l[u] = s_idx[ib]; le[u] = s_idx[ib + 1];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) kk[u] = s_keys[l[u]];                 // (l <= n < maxr: always inside the array)
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const uint64_t w = wq[h + u];
-                        if (i0 + 64u * (h + u) + lane >= hi) continue;
-                        const uint64_t key = w >> 4;
-                        uint32_t ll = l[u]; uint64_t k = kk[u];
-                        while (ll < le[u] && k < key) { ll++; k = s_keys[ll]; }
-                        if (ll < le[u] && k == key) {
-                            const uint32_t m4 = (uint32_t)(w & 15u);
-                            if (MODE == 0) row[shift + ll] = mask2iupac(m4);
-                            if (MODE == 2) { const uint32_t o = s_map[ll]; if (o != 0xFFFFu) row[shift + o] = (a.mask_ambig && (m4 & (m4 - 1))) ? (unsigned char)'N' : mask2iupac(m4); }
-                            if (MODE != 2) {
-                                const uint32_t single = (m4 & (m4 - 1)) == 0;
-                                atomicAdd(&s_cnt[ll], 1u | (single << 16));
-                                atomicOr(&s_msk[ll >> 1], (1u << m4) << (16u * (ll & 1u)));
-                            }
-                        } else {
-                            *a.missing = 1;
-                        }
-                    }
-                }
+                for (int u = 0; u < AU; u++) { const uint32_t i = o + 64u * u + lane; cur[u] = i < hi ? reg[i] : 0ull; }
+                place(cur);
             }
+#if !SKX_ASM_PREFETCH
+            if (t + 1 < cnt) fetch(t + 1, nx, nlo, nhi, nreg);
+#endif
             if (MODE != 1) {
                 __builtin_amdgcn_wave_barrier();
                 // copy out: output column ocol + i  <-  row[shift + i]; 16-B body, byte head/tail

@@ -815,3 +815,18 @@ def test_dict_every_bucket_configuration(E, k, length):
     gk, gb = ds.export(0)
     assert len(gk) == len(ok)
     assert np.array_equal(gk["lo"], ok["lo"]) and np.array_equal(gk["hi"], ok["hi"]) and np.array_equal(gb, ob)
+
+
+@pytest.mark.parametrize("k,rc", [(31, True), (15, True), (21, False)])
+def test_line_writing_extraction_matches_oracle(E, k, rc, monkeypatch):
+    """SKX_EXTRACT_LINES=1: the one-workgroup-per-sample scatter that writes whole 128-byte lines (skx_extract_lines.inc) builds
+    the same dictionaries as the oracle: several tiles per sample, records of every length, one bucket far beyond a line."""
+    rng = np.random.default_rng(77 + k)
+    samples = []
+    for i in range(4):
+        recs = rand_records(rng, 5, 30_000) + [b"ACGT" * 3, b"", b"A" * (k - 1), b"C" * k]
+        if i == 2:
+            recs.append(b"A" * 3000 + b"ACGTN" * 50 + b"T" * 40)        # many words of one bucket in one tile: many flush rounds
+        samples.append(recs)
+    monkeypatch.setenv("SKX_EXTRACT_LINES", "1")
+    check_dicts(E, samples, k, rc)

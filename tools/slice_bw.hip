@@ -13,7 +13,7 @@
 typedef const uint64_t __attribute__((address_space(1))) *gw_t;
 
 template <int G, int U, bool PROBE>
-__global__ __launch_bounds__(1024) void slice_kernel(const uint64_t *words, int S, uint32_t W, uint32_t nsub, int layout, uint64_t *sink)
+__global__ __launch_bounds__(1024) void slice_kernel(const uint64_t *words, int S, uint32_t W, uint32_t nsub, int layout, uint64_t *sink, unsigned char *matrix, uint32_t nout)
 {
     __shared__ unsigned long long tab[4096];
     if (PROBE) { for (uint32_t i = threadIdx.x; i < 4096; i += blockDim.x) tab[i] = i * 0x9E3779B97F4A7C15ull; __syncthreads(); }
@@ -39,21 +39,33 @@ __global__ __launch_bounds__(1024) void slice_kernel(const uint64_t *words, int 
                 else acc ^= q[u];
             }
         }
+        if (G == 1 && matrix) {                                // assemble_kernel's copy-out: nout bytes of sample s at column j * nout
+            const uint64_t col = j * (uint64_t)nout;
+            unsigned char *dst = matrix + (uint64_t)s * ((uint64_t)nsub * nout + 64) + col;
+            const uint32_t head = (uint32_t)((16u - (col & 15u)) & 15u);
+            if ((uint32_t)lane < head) dst[lane] = (unsigned char)acc;
+            const uint32_t body = (nout - head) / 16u;
+            const uint32_t x = (uint32_t)acc;
+            for (uint32_t v = lane; v < body; v += 64) *reinterpret_cast<uint4 *>(dst + head + 16u * v) = make_uint4(x, x + v, x, x);
+            const uint32_t done = head + body * 16u;
+            if (done + lane < nout) dst[done + lane] = (unsigned char)acc;
+        }
     }
     if (acc == 0x1234567ull) sink[0] = acc;
 }
 
 template <int G, int U, bool PROBE>
-static void run(const uint64_t *words, int S, uint32_t W, int lognsub, int layout, int threads, uint64_t *sink)
+static void run(const uint64_t *words, int S, uint32_t W, int lognsub, int layout, int threads, uint64_t *sink, unsigned char *matrix = nullptr, uint32_t nout = 0)
 {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int rep = 0; rep < 3; rep++) {
         if (rep == 1) (void)hipEventRecord(e0);
-        hipLaunchKernelGGL((slice_kernel<G, U, PROBE>), dim3(1u << lognsub), dim3(threads), 0, 0, words, S, W, 1u << lognsub, layout, sink);
+        hipLaunchKernelGGL((slice_kernel<G, U, PROBE>), dim3(1u << lognsub), dim3(threads), 0, 0, words, S, W, 1u << lognsub, layout, sink, matrix, nout);
     }
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 2;
-    const double gb = (double)S * W * 8 * (double)(1u << lognsub) / 1e9;
+    const double gb = (double)S * (W * 8 + (matrix ? nout : 0)) * (double)(1u << lognsub) / 1e9;
+    if (matrix) printf("+ %u-byte pieces written: ", nout);
     printf("G=%d U=%2d probe=%d threads=%4d: %7.2f ms  %6.2f TB/s\n", G, U, (int)PROBE, threads, ms, gb / ms);
 }
 
@@ -76,5 +88,10 @@ int main(int argc, char **argv)
     run<16, 10, false>(words, S, W, lognsub, layout, threads, sink);
     run<2, 10, true>(words, S, W, lognsub, layout, threads, sink);
     run<8, 10, true>(words, S, W, lognsub, layout, threads, sink);
+    const uint32_t nout = argc > 6 ? (uint32_t)atoi(argv[6]) : 1380;
+    unsigned char *matrix;
+    if (hipMalloc((void **)&matrix, (uint64_t)S * (((uint64_t)nout << lognsub) + 64)) != hipSuccess) { fprintf(stderr, "alloc failed\n"); return 1; }
+    run<1, 5, false>(words, S, W, lognsub, layout, threads, sink, matrix, nout);
+    run<1, 5, true>(words, S, W, lognsub, layout, threads, sink, matrix, nout);
     return 0;
 }
