@@ -255,7 +255,7 @@ struct Mapped {
         if (populate && n >= (64u << 20)) {
             const int T = 8;
             std::vector<std::thread> th;
-            for (int t = 0; t < T; t++) th.emplace_back([this, t, T]() {
+            for (int t = 0; t < T; t++) th.emplace_back([this, t]() {
                 const size_t a = n / T * t, b = t + 1 == T ? n : n / T * (t + 1);
 #ifdef MADV_POPULATE_READ
                 if (madvise((void *)(p + (a & ~(size_t)4095)), b - (a & ~(size_t)4095), MADV_POPULATE_READ) == 0) return;

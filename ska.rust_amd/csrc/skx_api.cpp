@@ -413,14 +413,27 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
         }
         // LDS capacity (words) of the per-region counting sort: 12 B per word, <= 160 KiB
         uint32_t cap = std::max<uint32_t>(512, (uint32_t)std::min<uint64_t>(((uint64_t)lds_cap + 255) / 256 * 256, wide ? LDS_SORT_MAX_WIDE : LDS_SORT_MAX));
+        // windows per region are Poisson around len / B: all but ~5 in 10 000 regions stay below mean + 3.3 sigma, which may need a
+        // smaller launch shape than the regions' capacity does (launch_dedupe_mb)
+        const double mean_r = (double)(maxlen >> logB) + 1.0;
+        const uint32_t typical = wide ? 0u : (uint32_t)(mean_r + 3.3 * std::sqrt(mean_r) + 1.0);
+        DevBuf<uint32_t> d_big;
+        if (typical) SKX_TRY(d_big.alloc(nreg + 1));
         SKX_TRY(d_flag.zero(st));
         SKX_HIP(hipMemsetAsync(d->sidx.p, 0xFF, nreg * skx::SUBIDX * sizeof(uint16_t), st));     // 0xFFFF = sub-range without words
         { StageTimer t(ctx, &ctx->tm.dedupe);
           if (wide) launch_dedupe_wide((u128 *)d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, cap, key_bits_used - logB, d_flag.p, d->sidx.p, d->sb, st);
-          else launch_dedupe_mb(d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, cap, hp.bits - logB, d_flag.p, d->sidx.p, d->sb, st); }
+          else launch_dedupe_mb(d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, cap, hp.bits - logB, d_flag.p, d->sidx.p, d->sb, st, typical, d_big.p, 0); }
         int overflow = 0;
         SKX_HIP(hipMemcpyAsync(&overflow, d_flag.p, 4, hipMemcpyDeviceToHost, st));
         SKX_HIP(hipStreamSynchronize(st));
+        for (uint32_t from = DEDUPE_SPILL_GRID; !wide && (overflow & 4); from += DEDUPE_SPILL_GRID) {     // more listed regions than one grid of the second stage
+            int keep = overflow & ~4;
+            SKX_HIP(hipMemcpyAsync(d_flag.p, &keep, 4, hipMemcpyHostToDevice, st));
+            { StageTimer t(ctx, &ctx->tm.dedupe); launch_dedupe_mb(d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, cap, hp.bits - logB, d_flag.p, d->sidx.p, d->sb, st, typical, d_big.p, from); }
+            SKX_HIP(hipMemcpyAsync(&overflow, d_flag.p, 4, hipMemcpyDeviceToHost, st));
+            SKX_HIP(hipStreamSynchronize(st));
+        }
         if (!wide && overflow == 2) {
             // regions beyond the counting sort's capacity (repeat-rich buckets): table-based dedupe, only distinct keys must fit
             SKX_TRY(d_flag.zero(st));

@@ -99,8 +99,11 @@ constexpr int SUBIDX = 16;     // sub-ranges indexed per (sample, bucket) region
 void launch_dedupe(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_regions,
                    uint32_t table_slots, int rem_bits, int *overflow, uint32_t min_n, uint16_t *sidx, int sb, hipStream_t st);
 
+// typical / big_list / big_from: the two-shape launch (skx_device.hip); *overflow bit 4 = relaunch with big_from += DEDUPE_SPILL_GRID
+constexpr uint32_t DEDUPE_SPILL_GRID = 16384;
 void launch_dedupe_mb(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_regions,
-                      uint32_t cap, int rem_bits, int *overflow, uint16_t *sidx, int sb, hipStream_t st);
+                      uint32_t cap, int rem_bits, int *overflow, uint16_t *sidx, int sb, hipStream_t st,
+                      uint32_t typical = 0, uint32_t *big_list = nullptr, uint32_t big_from = 0);
 
 struct DictView {
     const uint64_t *words; const uint64_t *off; const uint32_t *ucnt;   // wide: words are u128 (2 x u64), off in elements

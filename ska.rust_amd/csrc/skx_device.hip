@@ -560,16 +560,27 @@ void launch_dedupe(uint64_t *words, const uint64_t *off, const uint32_t *raw, ui
 // chains: cost is O(n) LDS operations per region whatever the duplication level.
 template <int ITEMS, bool HI, int NT>
 __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt,
-                                                        uint32_t cap, int rem_bits, int *overflow, uint16_t *sidx, int sb)
+                                                        uint32_t cap, int rem_bits, int *overflow, uint16_t *sidx, int sb,
+                                                        const uint32_t *big, uint32_t big_from, int big_mode)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
     __shared__ uint32_t s_tmp[17];
-    const uint64_t region = blockIdx.x;
+    // big_mode 0: every region; 1: every region, those above this launch's capacity are on the list `big` ([0] = count) and
+    // left to a launch of mode 2; 2: the listed regions from entry big_from on, one per workgroup (bit 4 of *overflow: the list is
+    // longer than this grid, the host launches the rest)
+    uint64_t region = blockIdx.x;
+    if (big_mode == 2) {
+        const uint32_t cnt = big[0], idx = big_from + blockIdx.x;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && cnt > big_from + gridDim.x) atomicOr(overflow, 4);
+        if (idx >= cnt) return;
+        region = big[1 + idx];
+    }
     const uint32_t n = raw[region];
     if (n == 0) { if (threadIdx.x == 0) ucnt[region] = 0; return; }
+    if (big_mode == 1 && n > (uint32_t)NT * ITEMS) return;
     if (n > cap || n > (uint32_t)NT * ITEMS) { if (threadIdx.x == 0) atomicOr(overflow, 2); return; }      // left to dedupe_kernel
     uint64_t *s_elem = reinterpret_cast<uint64_t *>(s_mem);                 // [cap]
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_mem + (size_t)cap * 8) + 1;   // [-1] = 0 | [M] counts -> cursors (= bucket ends) -> leader counts
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_mem + (size_t)cap * 8 + 32) + 1;   // (four sentinel words first) [-1] = 0 | [M] counts -> cursors (= bucket ends) -> leader counts
     int logM = 31 - __clz(n);                                                // ~1..2 words per micro-bucket
     if (logM < 0) logM = 0;
     if (logM > rem_bits) logM = rem_bits;
@@ -583,6 +594,7 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
     for (int t = 0; t < ITEMS; t++) { const uint32_t i = threadIdx.x + (uint32_t)NT * t; e[t] = i < n ? reg[i] : 0ull; }
     for (uint32_t i = threadIdx.x; i < M; i += NT) s_cnt[i] = 0;
     if (threadIdx.x == 0) s_cnt[-1] = 0;                                     // end of the bucket before the first
+    if (threadIdx.x < 4) s_elem[n + threadIdx.x] = ~0ull;                    // what the ranking reads behind the last word
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) if (e[t]) atomicAdd(&s_cnt[word_field<HI>(e[t], mshift, M - 1)], 1u);
@@ -629,14 +641,15 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
         // Fast path: count the smaller keys and notice whether the key occurs again; only then (rare) order the equal
         // keys by position and fold their base masks.
         uint32_t less = 0, eqb = 0, mor = (uint32_t)w0 & 15u;
-        bool dup = false;
-        auto step = [&](uint32_t j, uint64_t w, bool valid) {
+        // Branch-free over the bucket's first NS slots: a slot past the bucket's end holds a word of a later bucket (larger, and
+        // never this key) or one of the four all-ones sentinels behind the region's last word, so it needs no validity test;
+        // `same` counts the slots holding this key -- the word itself is one of them when it lies in the first NS.
+        uint32_t same = 0;
+        auto step = [&](uint64_t w) {
             const uint64_t x = w ^ w0;
-            less += valid && w < w0lo;
-            dup |= valid && j != p && (((uint32_t)(x >> 32) | ((uint32_t)x >> 4)) == 0u);
+            less += w < w0lo ? 1u : 0u;
+            same += (((uint32_t)(x >> 32) | ((uint32_t)x >> 4)) == 0u) ? 1u : 0u;
         };
-        // the first slots are straight-line code (reads past the bucket stay inside the LDS carve and are masked), longer
-        // buckets finish in a loop
         constexpr uint32_t NS = 4;                                             // micro-buckets hold ~1.2 words on average
         uint64_t wq[NS];
 #pragma unroll
@@ -644,8 +657,13 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
 #pragma unroll
         for (uint32_t u = 0; u < NS; u++) asm volatile("" : "+v"(wq[u]));     // (keeps the compiler from sinking each read into its own branch)
 #pragma unroll
-        for (uint32_t u = 0; u < NS; u++) step(b + u, wq[u], b + u < eend);
-        for (uint32_t j = b + NS; j < eend; j++) step(j, s_elem[j], true);
+        for (uint32_t u = 0; u < NS; u++) step(wq[u]);
+        bool dup = same > (p - b < NS ? 1u : 0u);
+        for (uint32_t j = b + NS; j < eend; j++) {                           // longer buckets finish in a loop
+            const uint64_t w = s_elem[j], x = w ^ w0;
+            less += w < w0lo ? 1u : 0u;
+            dup |= j != p && (((uint32_t)(x >> 32) | ((uint32_t)x >> 4)) == 0u);
+        }
         if (dup)
             for (uint32_t j = b; j < eend; j++) {
                 const uint64_t w = s_elem[j];
@@ -708,31 +726,65 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
     if (threadIdx.x == 0) ucnt[region] = s_rows[ITEMS * NW];
 }
 template <int ITEMS, int NT>
-static void launch_dedupe_items(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_regions, uint32_t cap,
-                                int rem_bits, int *overflow, uint16_t *sidx, int sb, size_t lds, hipStream_t st)
+static void launch_dedupe_items(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_blocks, uint32_t cap,
+                                int rem_bits, int *overflow, uint16_t *sidx, int sb, size_t lds, hipStream_t st,
+                                const uint32_t *big, uint32_t big_from, int big_mode)
 {
     // every field the kernel extracts (micro-bucket, sub-range) starts at bit rem_bits + 4 - (<= log2 cap) or higher
     int lc = 0; while ((1u << lc) < cap) lc++;
     if (rem_bits + 4 - lc >= 32 && rem_bits + 4 - sb >= 32) {
         (void)hipFuncSetAttribute((const void *)dedupe_mb_kernel<ITEMS, true, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((dedupe_mb_kernel<ITEMS, true, NT>), dim3((unsigned)n_regions), dim3(NT), lds, st, words, off, raw, ucnt, cap, rem_bits, overflow, sidx, sb);
+        hipLaunchKernelGGL((dedupe_mb_kernel<ITEMS, true, NT>), dim3((unsigned)n_blocks), dim3(NT), lds, st, words, off, raw, ucnt, cap, rem_bits, overflow, sidx, sb, big, big_from, big_mode);
     } else {
         (void)hipFuncSetAttribute((const void *)dedupe_mb_kernel<ITEMS, false, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((dedupe_mb_kernel<ITEMS, false, NT>), dim3((unsigned)n_regions), dim3(NT), lds, st, words, off, raw, ucnt, cap, rem_bits, overflow, sidx, sb);
+        hipLaunchKernelGGL((dedupe_mb_kernel<ITEMS, false, NT>), dim3((unsigned)n_blocks), dim3(NT), lds, st, words, off, raw, ucnt, cap, rem_bits, overflow, sidx, sb, big, big_from, big_mode);
     }
 }
+// launch shapes of the counting sort: words per region = threads x words per thread.
+// 512 threads while three regions (<= 4 096 words, 49 KB) share a CU; beyond that the LDS footprint fixes two regions per
+// CU and 1 024 threads keep 32 waves on it (800 x 6 Mbp, 3 840-word regions: <6, 1024> 26.4 ms, <8, 512> 20.9 ms).
+static uint32_t dedupe_shape_words(uint32_t cap)
+{
+    return cap <= 512u * 4 ? 512u * 4 : cap <= 512u * 7 ? 512u * 7 : cap <= 512u * 8 ? 512u * 8 : cap <= 1024u * 5 ? 1024u * 5 : 1024u * 6;
+}
+static void launch_dedupe_shape(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_blocks, uint32_t cap,
+                                int rem_bits, int *overflow, uint16_t *sidx, int sb, hipStream_t st, const uint32_t *big, uint32_t big_from, int big_mode)
+{
+    size_t lds = (size_t)cap * 8 + 32 + (size_t)cap * 4 + 16;  // elements + four sentinels + two u32 arrays of cap/2 (+ sentinel)
+    if (cap <= 512u * 4) launch_dedupe_items<4, 512>(words, off, raw, ucnt, n_blocks, cap, rem_bits, overflow, sidx, sb, lds, st, big, big_from, big_mode);
+    else if (cap <= 512u * 7) launch_dedupe_items<7, 512>(words, off, raw, ucnt, n_blocks, cap, rem_bits, overflow, sidx, sb, lds, st, big, big_from, big_mode);
+    else if (cap <= 512u * 8) launch_dedupe_items<8, 512>(words, off, raw, ucnt, n_blocks, cap, rem_bits, overflow, sidx, sb, lds, st, big, big_from, big_mode);
+    else if (cap <= 1024u * 5) launch_dedupe_items<5, 1024>(words, off, raw, ucnt, n_blocks, cap, rem_bits, overflow, sidx, sb, lds, st, big, big_from, big_mode);
+    else launch_dedupe_items<6, 1024>(words, off, raw, ucnt, n_blocks, cap, rem_bits, overflow, sidx, sb, lds, st, big, big_from, big_mode);    // host keeps regions <= 6144 words
+}
+// regions with more than `above` words -> list[1..], count at list[0] (zeroed by the caller)
+__global__ void list_big_regions_kernel(const uint32_t *raw, uint64_t n, uint32_t above, uint32_t *list)
+{
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i < n && raw[i] > above) list[1 + atomicAdd(&list[0], 1u)] = (uint32_t)i;
+}
+// cap = the largest region the launch must hold (the regions' capacity); typical (0: unknown) = a size all but a few in ten
+// thousand regions stay below (mean + 3.3 sigma of the Poisson counts).  When typical needs a smaller launch shape than cap, the
+// regions are sorted in that shape -- a 4 900-word region fills 95 % of <5, 1024> but 80 % of <6, 1024>, and the kernel is bound
+// by its instruction count -- and the few above it, listed by a first small kernel, in a second launch of the full shape.
+// big_list: [n_regions + 1] words of scratch; big_from > 0 relaunches the second stage from that list entry (overflow bit 4).
 void launch_dedupe_mb(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_regions, uint32_t cap,
-                      int rem_bits, int *overflow, uint16_t *sidx, int sb, hipStream_t st)
+                      int rem_bits, int *overflow, uint16_t *sidx, int sb, hipStream_t st, uint32_t typical, uint32_t *big_list, uint32_t big_from)
 {
     if (!n_regions) return;
-    size_t lds = (size_t)cap * 8 + (size_t)cap * 4 + 16;  // elements + two u32 arrays of cap/2 (+ sentinel)
-    // 512 threads while three regions (<= 4 096 words, 49 KB) share a CU; beyond that the LDS footprint fixes two regions per
-    // CU and 1 024 threads keep 32 waves on it (800 x 6 Mbp, 3 840-word regions: <6, 1024> 26.4 ms, <8, 512> 20.9 ms).
-    if (cap <= 512u * 4) launch_dedupe_items<4, 512>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);
-    else if (cap <= 512u * 7) launch_dedupe_items<7, 512>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);
-    else if (cap <= 512u * 8) launch_dedupe_items<8, 512>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);
-    else if (cap <= 1024u * 5) launch_dedupe_items<5, 1024>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);
-    else launch_dedupe_items<6, 1024>(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, lds, st);    // host keeps regions <= 6144 words
+    if (getenv("SKX_DEDUPE_ONE_SHAPE")) typical = 0;
+    const uint32_t shape_all = dedupe_shape_words(cap), shape_typ = typical ? dedupe_shape_words(typical) : shape_all;
+    if (!big_list || shape_typ >= shape_all || n_regions > 0xFFFFFFFFull) {
+        launch_dedupe_shape(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, st, nullptr, 0u, 0);
+        return;
+    }
+    const unsigned spill_grid = DEDUPE_SPILL_GRID;
+    if (big_from == 0) {
+        (void)hipMemsetAsync(big_list, 0, 4, st);
+        hipLaunchKernelGGL(list_big_regions_kernel, dim3((unsigned)((n_regions + 255) / 256)), dim3(256), 0, st, raw, n_regions, shape_typ, big_list);
+        launch_dedupe_shape(words, off, raw, ucnt, n_regions, shape_typ, rem_bits, overflow, sidx, sb, st, big_list, 0u, 1);
+    }
+    launch_dedupe_shape(words, off, raw, ucnt, spill_grid, cap, rem_bits, overflow, sidx, sb, st, big_list, big_from, 2);
 }
 
 // pointers that reach a kernel inside an argument struct are generic (flat_load: slower, and it also ticks the LDS
