@@ -179,7 +179,7 @@ int  skx_array_distance_filtered(skx_array *a, double min_freq, int filt_ambig, 
  * "tile the pair matrix over ranks"): every rank builds the planes of its own samples over the (globally filtered) rows, the
  * planes are all-gathered (plane-major: planes[p][sample][word], 4 planes with filt_ambig, 8 without), and each rank
  * finishes a band of first samples [i_lo, i_hi) against every later sample -- `out` = those pairs, (i, j > i) row-major, in the
- * arithmetic of merge_ska_array.rs:596-631.  i_lo must be a multiple of 32.  The planes pointer stays valid while the array lives. */
+ * arithmetic of merge_ska_array.rs:596-631.  Any 0 <= i_lo < i_hi <= n_samples (pair tiles start at i_lo).  The planes pointer stays valid while the array lives. */
 int  skx_array_distance_planes(skx_array *a, int filt_ambig, const void **planes, uint64_t *words_per_row, int *n_planes);
 int  skx_planes_distance(skx_ctx *ctx, const void *planes, int n_samples, uint64_t words_per_row, int filt_ambig, double constant,
                          int i_lo, int i_hi, skx_dist *out);

@@ -1844,7 +1844,7 @@ extern "C" int skx_planes_distance(skx_ctx *ctx, const void *planes, int n_sampl
                                    int i_lo, int i_hi, skx_dist *out)
 {
     return skx_guarded([&]() -> int {
-    if (!ctx || !planes || !out || n_samples < 0 || i_lo < 0 || i_hi > n_samples || (i_lo % 32)) { set_error("bad arguments (i_lo must be a multiple of 32)"); return SKX_EINVAL; }
+    if (!ctx || !planes || !out || n_samples < 0 || i_lo < 0 || i_hi > n_samples) { set_error("bad arguments"); return SKX_EINVAL; }
     SKX_HIP(hipSetDevice(ctx->device));
     StageTimer t(ctx, &ctx->tm.distance);
     return planes_distance(ctx, (const uint64_t *)planes, n_samples, words_per_row, filt_ambig, constant, i_lo, i_hi, out);

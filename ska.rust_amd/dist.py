@@ -70,7 +70,7 @@ def reduce_row_stats(present: torch.Tensor, unambig: torch.Tensor, mask: torch.T
 
 
 # ---- all-vs-all distance over ranks ("tile the pair matrix over ranks") ---------------------------------------
-def pair_bands(n_samples, world, align=32):
+def pair_bands(n_samples, world, align=8):
     """Rows of the pair matrix dealt to ranks: contiguous bands [i_lo, i_hi), starts on multiples of `align`, about the same
     number of pairs (i, j > i) each (row i holds n - 1 - i of them)."""
     total = n_samples * (n_samples - 1) // 2

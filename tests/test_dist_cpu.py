@@ -199,10 +199,10 @@ def test_pair_bands_partition_the_pair_matrix():
         for w in (1, 2, 3, 8):
             b = skdist.pair_bands(n, w)
             assert len(b) == w and b[0][0] == 0 and b[-1][1] == n and all(x[1] == y[0] for x, y in zip(b, b[1:]))
-            assert all(lo % 32 == 0 for lo, hi in b if lo < hi)
+            assert all(lo % 8 == 0 for lo, hi in b if lo < hi)
             if n >= 1000 and w == 8:                                   # balanced by pairs, not by rows
                 pairs = [sum(n - 1 - i for i in range(lo, hi)) for lo, hi in b]
-                assert max(pairs) < 1.3 * (n * (n - 1) // 2) / w, (n, pairs)
+                assert max(pairs) < 1.1 * (n * (n - 1) // 2) / w, (n, pairs)
 
 
 def test_row_stat_reduction_edges():

@@ -66,7 +66,7 @@ def test_distance_by_bands_equals_whole(tmp_path):
     import ora
     import skx_engine as E
     E.load_library()
-    files, _ = _inputs(tmp_path, n=70, length=30_000, seed=4)          # 70 samples: three bands of 32 rows
+    files, _ = _inputs(tmp_path, n=70, length=30_000, seed=4)          # 70 samples: a 64 x 64 pair tile and a ragged one
     inputs = [(f"m{i}", f, None) for i, f in enumerate(files)]
     for filt in (True, False):
         arr = E.Array.build(inputs, k=31, threads=4)
@@ -74,8 +74,9 @@ def test_distance_by_bands_equals_whole(tmp_path):
         whole = arr.distance(constant, filt)
         p, wpr, _ = arr.distance_planes(filt)
         S = arr.nsamples
-        got = np.concatenate([E.planes_distance(p, S, wpr, filt, constant, lo, hi) for lo, hi in ((0, 32), (32, 64), (64, 70))])
-        assert np.array_equal(got, whole)
+        for bands in (((0, 32), (32, 64), (64, 70)), ((0, 5), (5, 37), (37, 69), (69, 70)), ((0, 1), (1, 70))):     # any band start: tiles begin at i_lo
+            got = np.concatenate([E.planes_distance(p, S, wpr, filt, constant, lo, hi) for lo, hi in bands])
+            assert np.array_equal(got, whole), bands
         oa = ora.Array.build(inputs, k=31, threads=2)
         oc = oa.filter(0, False, ora.FILTER_NO_CONST, False, False, False)
         od = oa.distance(oc, filt)
