@@ -427,12 +427,17 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
         int overflow = 0;
         SKX_HIP(hipMemcpyAsync(&overflow, d_flag.p, 4, hipMemcpyDeviceToHost, st));
         SKX_HIP(hipStreamSynchronize(st));
-        for (uint32_t from = DEDUPE_SPILL_GRID; !wide && (overflow & 4); from += DEDUPE_SPILL_GRID) {     // more listed regions than one grid of the second stage
+        for (uint32_t from = dedupe_spill_grid(); !wide && (overflow & 4); from += dedupe_spill_grid()) {     // more listed regions than one grid of the second stage
             int keep = overflow & ~4;
             SKX_HIP(hipMemcpyAsync(d_flag.p, &keep, 4, hipMemcpyHostToDevice, st));
             { StageTimer t(ctx, &ctx->tm.dedupe); launch_dedupe_mb(d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, cap, hp.bits - logB, d_flag.p, d->sidx.p, d->sb, st, typical, d_big.p, from); }
             SKX_HIP(hipMemcpyAsync(&overflow, d_flag.p, 4, hipMemcpyDeviceToHost, st));
             SKX_HIP(hipStreamSynchronize(st));
+        }
+        if (getenv("SKX_DEBUG") && typical) {
+            uint32_t listed = 0;
+            SKX_HIP(hipMemcpy(&listed, d_big.p, 4, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[skx] dedupe: typical region %u words, capacity %u; %u of %llu regions above the typical launch shape\n", typical, cap, listed, (unsigned long long)nreg);
         }
         if (!wide && overflow == 2) {
             // regions beyond the counting sort's capacity (repeat-rich buckets): table-based dedupe, only distinct keys must fit

@@ -99,8 +99,8 @@ constexpr int SUBIDX = 16;     // sub-ranges indexed per (sample, bucket) region
 void launch_dedupe(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_regions,
                    uint32_t table_slots, int rem_bits, int *overflow, uint32_t min_n, uint16_t *sidx, int sb, hipStream_t st);
 
-// typical / big_list / big_from: the two-shape launch (skx_device.hip); *overflow bit 4 = relaunch with big_from += DEDUPE_SPILL_GRID
-constexpr uint32_t DEDUPE_SPILL_GRID = 16384;
+// typical / big_list / big_from: the two-shape launch (skx_device.hip); *overflow bit 4 = relaunch with big_from += dedupe_spill_grid()
+uint32_t dedupe_spill_grid();      // workgroups of one second-stage launch (16 384; SKX_DEDUPE_SPILL_GRID overrides, for tests)
 void launch_dedupe_mb(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_regions,
                       uint32_t cap, int rem_bits, int *overflow, uint16_t *sidx, int sb, hipStream_t st,
                       uint32_t typical = 0, uint32_t *big_list = nullptr, uint32_t big_from = 0);

@@ -757,6 +757,12 @@ static void launch_dedupe_shape(uint64_t *words, const uint64_t *off, const uint
     else if (cap <= 1024u * 5) launch_dedupe_items<5, 1024>(words, off, raw, ucnt, n_blocks, cap, rem_bits, overflow, sidx, sb, lds, st, big, big_from, big_mode);
     else launch_dedupe_items<6, 1024>(words, off, raw, ucnt, n_blocks, cap, rem_bits, overflow, sidx, sb, lds, st, big, big_from, big_mode);    // host keeps regions <= 6144 words
 }
+uint32_t dedupe_spill_grid()
+{
+    const char *e = getenv("SKX_DEDUPE_SPILL_GRID");
+    const long v = e ? atol(e) : 0;
+    return v > 0 ? (uint32_t)v : 16384u;
+}
 // regions with more than `above` words -> list[1..], count at list[0] (zeroed by the caller)
 __global__ void list_big_regions_kernel(const uint32_t *raw, uint64_t n, uint32_t above, uint32_t *list)
 {
@@ -778,7 +784,7 @@ void launch_dedupe_mb(uint64_t *words, const uint64_t *off, const uint32_t *raw,
         launch_dedupe_shape(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, st, nullptr, 0u, 0);
         return;
     }
-    const unsigned spill_grid = DEDUPE_SPILL_GRID;
+    const unsigned spill_grid = dedupe_spill_grid();
     if (big_from == 0) {
         (void)hipMemsetAsync(big_list, 0, 4, st);
         hipLaunchKernelGGL(list_big_regions_kernel, dim3((unsigned)((n_regions + 255) / 256)), dim3(256), 0, st, raw, n_regions, shape_typ, big_list);

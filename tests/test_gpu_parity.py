@@ -830,3 +830,24 @@ def test_line_writing_extraction_matches_oracle(E, k, rc, monkeypatch):
         samples.append(recs)
     monkeypatch.setenv("SKX_EXTRACT_LINES", "1")
     check_dicts(E, samples, k, rc)
+
+
+def test_dedupe_two_shapes_and_listed_regions(E, monkeypatch):
+    """Regions are sorted in the launch shape the typical region needs; the few above it are listed and sorted by a second launch of
+    the full shape, grid after grid when the list is long.  A 200-base unit repeated 800 times puts ~800 extra words into ~200 of a
+    2.5 Mbp sample's 512 regions (mean 4 900 words: 5 x 1 024 for the typical region, 6 x 1 024 for the capacity)."""
+    rng = np.random.default_rng(5)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    unit = acgt[rng.integers(0, 4, size=200)].tobytes()
+    samples = []
+    for i in range(2):
+        body = acgt[rng.integers(0, 4, size=2_340_000)].tobytes()
+        samples.append([body[:1_000_000], unit * 800, body[1_000_000:], b"ACGT" * 5])
+    monkeypatch.setenv("SKX_DEDUPE_SPILL_GRID", "48")               # ~200 listed regions per sample: several second-stage launches
+    ds = check_dicts(E, samples, 31, True)
+    sizes = [ds.size(i) for i in range(2)]
+    ds.free()
+    monkeypatch.setenv("SKX_DEDUPE_ONE_SHAPE", "1")
+    ds1 = check_dicts(E, samples, 31, True)
+    assert [ds1.size(i) for i in range(2)] == sizes
+    ds1.free()
