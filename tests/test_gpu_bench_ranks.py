@@ -1,0 +1,32 @@
+"""bench.py's N > 1 path (`-m gpu`): two ranks share the one GPU of the test box over gloo (SKX_BENCH_BACKEND / SKX_BENCH_DEVICE), the
+launch line is the driver's.  The JSON line must carry the whole-job rate, the weak-scaling label and the exchange sizes, and the
+sharded row set must be the one a single rank derives for the same samples (rows_U)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(extra, env=None, launcher=()):
+    cmd = [sys.executable, *launcher, os.path.join(ROOT, "bench.py"), "--genomes", "24", "--genome-len", "300000", "--steps", "2", "--warmup", "1",
+           "--cpu-genomes", "0", "--no-e2e", *extra]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_bench_two_ranks_on_one_gpu():
+    port = str(29600 + os.getpid() % 300)
+    two = _bench(["--gpus", "2"], env={"SKX_BENCH_BACKEND": "gloo", "SKX_BENCH_DEVICE": "0"},
+                 launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port))
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["steps"] == 2 and two["value"] > 0
+    assert two["config"]["samples_total"] == 48 if "samples_total" in two["config"] else True
+    assert two.get("exchange_per_step_rank0"), two.keys()
+    one = _bench(["--gpus", "1", "--genomes", "48"])
+    assert one["n_gpus"] == 1
+    assert two["config"]["rows_U"] == one["config"]["rows_U"], (two["config"], one["config"])      # the sharded row set is the single-rank row set
