@@ -11,6 +11,8 @@
 #include <chrono>
 #include <fstream>
 #include <sstream>
+#include <atomic>
+#include <thread>
 #include <string>
 #include <fcntl.h>
 #include <unistd.h>
@@ -147,12 +149,28 @@ static int distance_text(skx_array *a, const std::vector<skx_dist> &d, char **bu
     skx_array_info_t info; skx_array_info(a, &info);
     const uint64_t S = info.n_samples;
     Phase pt("distance.table_text");
+    // the rows of one first sample are formatted by one thread (a table of 1 000 samples is half a million printf calls, 20 MB)
+    const int T = (int)std::min<uint64_t>(std::max<uint64_t>(1, S / 16), std::min(32u, std::max(1u, std::thread::hardware_concurrency())));
+    std::vector<std::string> part(S);
+    std::atomic<uint64_t> next{0};
+    auto work = [&]() {
+        for (uint64_t i; (i = next.fetch_add(1)) < S;) {
+            size_t n = (size_t)(i * (2 * S - i - 1) / 2);               // pairs before row i
+            std::string &o = part[i];
+            for (uint64_t j = i + 1; j < S; j++, n++)
+                put(o, "%s\t%s\t%.2f\t%.5f\t%llu\t%llu\n", skx_array_name(a, i), skx_array_name(a, j), d[n].distance, d[n].mismatch_prop,
+                    (unsigned long long)d[n].match_count, (unsigned long long)d[n].mismatch_count);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
     std::string out = "Sample1\tSample2\tDistance\tMismatches (proportion)\tMatch count\tMismatch count\n";
-    size_t n = 0;
-    for (uint64_t i = 0; i < S; i++)
-        for (uint64_t j = i + 1; j < S; j++, n++)
-            put(out, "%s\t%s\t%.2f\t%.5f\t%llu\t%llu\n", skx_array_name(a, i), skx_array_name(a, j), d[n].distance, d[n].mismatch_prop,
-                (unsigned long long)d[n].match_count, (unsigned long long)d[n].mismatch_count);
+    size_t total = out.size();
+    for (auto &x : part) total += x.size();
+    out.reserve(total);
+    for (auto &x : part) out += x;
     return to_buf(out, buf, len);
 }
 static int distance_table(skx_array *a, double constant, int filt_ambig, char **buf, uint64_t *len)
