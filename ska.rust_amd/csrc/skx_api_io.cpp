@@ -498,8 +498,12 @@ extern "C" int skx_array_load_filtered(skx_ctx *ctx, const char *path, const skx
     if (getenv("SKX_NO_STREAM_LOAD")) return load_then_filter(ctx, path, f, out, removed, constant);
     SKX_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    SkfFile sf;
+    struct Release { std::chrono::steady_clock::time_point t; bool on = false;
+                     ~Release() { if (on) phase_add("load.release_buffers_file", std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count()); } } rel;
+    std::unique_ptr<SkfFile> sfp(new SkfFile());
+    SkfFile &sf = *sfp;
     {
+        PhaseTimer t_open("load.open_header");
         const int r = sf.open(path);
         if (r == SKF_NOT_TAKEN) return load_then_filter(ctx, path, f, out, removed, constant);
         if (r != SKX_OK) return r;
@@ -646,6 +650,9 @@ extern "C" int skx_array_load_filtered(skx_ctx *ctx, const char *path, const skx
     a->n_rows = kept; a->pitch = cap;
     if (removed) *removed = (int64_t)(U - kept - n_silent - n_const);
     if (constant) *constant = (int64_t)n_const;
+    rel.t = std::chrono::steady_clock::now(); rel.on = true;                              // what follows is the destructors
+    // unmapping the 700 000 pages of the file takes 0.07-0.13 s: not on the caller's time (nothing else refers to the file any more)
+    std::thread([p = sfp.release()]() { delete p; }).detach();
     *out = a.release();
     return SKX_OK;
     });

@@ -205,14 +205,14 @@ extern "C" int skh_align_inputs_fd(skx_ctx *ctx, const char *const *inputs, int 
         skx_filter_spec fs{min_freq, filter_ambig_as_missing, filter_type, mask_ambig, ignore_const_gaps, 0};
         int64_t removed = 0;
         skx_ctx_expect_output(ctx, fd);                               // the file's pages are allocated while the rows are read
-        if ((r = skx_array_load_filtered(ctx, inputs[0], &fs, &a, &removed, nullptr)) != SKX_OK) return r;
+        { Phase pl("align.load_filtered"); if ((r = skx_array_load_filtered(ctx, inputs[0], &fs, &a, &removed, nullptr)) != SKX_OK) return r; }
         Phase pw("align.write_fasta");
         r = skx_array_write_fasta(a, fd);
     } else {
         if ((r = skh_load_array(ctx, inputs, n_inputs, threads, &a)) != SKX_OK) return r;
         r = skh_align_fd(a, filter_type, mask_ambig, ignore_const_gaps, min_freq, filter_ambig_as_missing, fd);
     }
-    skx_array_free(a);
+    { Phase pf("align.free_array"); skx_array_free(a); }
     return r;
     });
 }

@@ -19,7 +19,7 @@ def run(tag, args, env):
     t = time.perf_counter(); r = subprocess.run([SKA, *args], cwd=td, capture_output=True, env=e); dt = time.perf_counter() - t
     assert r.returncode == 0, r.stderr[-300:]
     p = json.load(open(ph))
-    print(f"{tag:9s} {env:22s} {dt:.3f} s  " + " ".join(f"{k.split('.')[-1]}={v:.3f}" for k, v in p.items() if v >= 0.02), flush=True)
+    print(f"{tag:9s} {env:22s} {dt:.3f} s  " + " ".join(f"{k.split('.')[-1]}={v:.3f}" for k, v in p.items() if v >= 0.004), flush=True)
 run("build", ["build", "-f", "list.txt", "-o", "all", "-k", "31", "--threads", "64"], "X=0")
 time.sleep(3)
 for rep in range(4):
