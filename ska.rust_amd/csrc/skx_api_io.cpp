@@ -651,8 +651,8 @@ extern "C" int skx_array_load_filtered(skx_ctx *ctx, const char *path, const skx
     if (removed) *removed = (int64_t)(U - kept - n_silent - n_const);
     if (constant) *constant = (int64_t)n_const;
     rel.t = std::chrono::steady_clock::now(); rel.on = true;                              // what follows is the destructors
-    // unmapping the 700 000 pages of the file takes 0.07-0.13 s: not on the caller's time (nothing else refers to the file any more)
-    std::thread([p = sfp.release()]() { delete p; }).detach();
+    // (unmapping the 700 000 pages of the file takes 0.07-0.13 s; handing it to a helper thread moved that time into the write that
+    // follows -- its page faults and pinned allocations wait for the same address-space lock -- so it stays here)
     *out = a.release();
     return SKX_OK;
     });
