@@ -103,6 +103,10 @@ int  skx_keyset_from_device(skx_ctx *ctx, const void *dptr, uint64_t n_keys, int
 int  skx_keyset_merge(skx_ctx *ctx, skx_keyset *const *sets, int n_sets, skx_keyset **out);
 void skx_keyset_free(skx_keyset *ks);
 int  skx_array_assemble(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows, const char *const *names, skx_array **out);
+/* The same array held as rows + dictionaries (no rows x samples matrix until an operation needs one: skx_array_device_stats gathers
+ * the row statistics alone, skx_array_filter then writes only the kept rows, skx_array_save streams windows).  TAKES OWNERSHIP of d and
+ * rows, also on failure: a multi-GPU rank's column slab over the global rows of 8 000 samples is 100+ GB it need not allocate. */
+int  skx_array_assemble_lazy(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows, const char *const *names, skx_array **out);
 int  skx_merge(skx_ctx *ctx, skx_dictset *d, const char *const *names, skx_array **out);
 
 /* build_and_merge (merge_ska_dict.rs:354-417) + MergeSkaArray::new: the `ska build` body.

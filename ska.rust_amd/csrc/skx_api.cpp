@@ -1023,6 +1023,20 @@ static int lazy_check_missing(skx_array *a, DevBuf<int> &d_flag)
     if (missing) { set_error("row keyset does not contain every split k-mer of the samples"); return SKX_EINVAL; }
     return SKX_OK;
 }
+extern "C" int skx_array_assemble_lazy(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows, const char *const *names, skx_array **out)
+{
+    return skx_guarded([&]() -> int {
+    if (!ctx || !d || !rows || !out) { skx_dictset_free(d); skx_keyset_free(rows); set_error("bad arguments"); return SKX_EINVAL; }
+    // the lazy form needs narrow keys and a row set slabbed at least as finely as the dictionaries' buckets; anything else is assembled at once
+    if (d->wide() || rows->k != d->k || rows->rc != d->rc || rows->logN < 0 || rows->logN < d->logB || d->n > 65535 || getenv("SKX_EAGER_ARRAY")) {
+        const int r = skx_array_assemble(ctx, d, rows, names, out);
+        skx_dictset_free(d); skx_keyset_free(rows);
+        return r;
+    }
+    SKX_HIP(hipSetDevice(ctx->device));
+    return array_make_lazy(ctx, d, rows, names, out);
+    });
+}
 int skx::array_lazy_stats(skx_array *a)
 {
     if (!a->lazy() || a->stats_ready) return SKX_OK;
@@ -1198,7 +1212,7 @@ extern "C" int skx_array_device_matrix(skx_array *a, const uint8_t **dptr, uint6
 
 extern "C" int skx_array_device_stats(skx_array *a, uint32_t **present, uint32_t **unambig, uint32_t **mask, uint32_t **variant_count)
 {
-    { const int r = skx_guarded([&]() -> int { return array_materialize(a); }); if (r != SKX_OK) return r; }
+    { const int r = skx_guarded([&]() -> int { return a->lazy() ? array_lazy_stats(a) : SKX_OK; }); if (r != SKX_OK) return r; }      // a lazily held array stays one: statistics only
     if (present) *present = a->present.p;
     if (unambig) *unambig = a->unambig.p;
     if (mask) *mask = a->mask.p;

@@ -12,6 +12,8 @@ handling of merge_ska_dict.rs:243-253,277-291).  Nothing on the data path is col
   * the per-row filter statistics (two counts in one all-reduce, 16-bit code sets all-gathered and OR-ed);
   * `distance`: one all-gather of the per-rank bit planes over the filtered rows; the pair matrix is tiled over ranks by bands
     of first samples (merge_ska_array.rs:416-438 order kept) and the finished pairs are gathered on rank 0.
+No rank ever holds its column slab of the global rows in full (8 000 samples: 100+ GB per rank): the array stays rows + dictionaries,
+the row statistics are gathered on their own, the filter then writes the kept rows only, `build` streams windows into its file.
 `align` needs no gather at all: the alignment is sample-major, every rank writes its own samples' records at their offsets of
 the one output file.  `build` leaves one .skf per rank (`<out>.part<r>of<N>.skf`: the global rows x that rank's samples; each is
 a valid MergeSkaArray, and `ska merge` -- this engine's or the reference's -- joins them); with --merge rank 0 joins them itself
@@ -122,8 +124,7 @@ def main():
     tabs = [t.to(dev).contiguous() for t in tables]
     sets = [E.KeySet.from_device(t.data_ptr(), t.numel() // wpk, args.k, not args.single_strand, ctx=ctx) for t in tabs]
     rows = E.KeySet.merge(sets, ctx=ctx)
-    arr = ds.assemble(rows, names[lo:hi])
-    ds.free()
+    arr = ds.assemble_lazy(rows, names[lo:hi])          # rows + dictionaries: the rank's column slab over the global rows is never allocated
     U = arr.nrows
     rep["rows"] = int(U)
 

@@ -54,7 +54,7 @@ class EngineError(RuntimeError):
 SYMBOLS = """skx_last_error skx_version skx_ctx_create skx_ctx_destroy skx_ctx_sync skx_ctx_stream skx_dictset_build
 skx_dictset_build_files skx_dictset_free skx_dictset_nsamples skx_dictset_key_bits skx_dictset_size skx_dictset_export
 skx_keyset_union skx_keyset_size skx_keyset_device skx_keyset_from_device skx_keyset_merge skx_keyset_free
-skx_array_assemble skx_merge skx_build_and_merge skx_array_free skx_array_save skx_array_load skx_array_from_host
+skx_array_assemble skx_array_assemble_lazy skx_merge skx_build_and_merge skx_array_free skx_array_save skx_array_load skx_array_from_host
 skx_array_info skx_array_name skx_array_version skx_array_export skx_array_sample_kmers skx_array_filter
 skx_array_write_fasta skx_array_fasta skx_array_device_matrix skx_array_device_stats skx_array_set_total_samples skx_array_distance skx_free skx_ctx_timings
 skx_array_merge skx_array_delete_samples skx_array_weed skx_keyset_from_fasta skx_array_ctx skx_set_last_error skx_array_map skx_cov_histogram skx_phases_json skx_phase_add skx_array_load_filtered skx_ctx_expect_output skx_array_distance_planes skx_planes_distance skx_array_distance_filtered
@@ -96,6 +96,7 @@ def load_library():
     lib.skx_keyset_merge.argtypes = [vp, pp, i, pp]
     lib.skx_keyset_free.argtypes = [vp]
     lib.skx_array_assemble.argtypes = [vp, vp, vp, C.POINTER(cp), pp]
+    lib.skx_array_assemble_lazy.argtypes = [vp, vp, vp, C.POINTER(cp), pp]
     lib.skx_merge.argtypes = [vp, vp, C.POINTER(cp), pp]
     lib.skx_build_and_merge.argtypes = [vp, C.POINTER(cp), C.POINTER(cp), C.POINTER(cp), i, i, i, C.POINTER(Qual), i, d, pp]
     lib.skx_array_free.argtypes = [vp]
@@ -350,6 +351,16 @@ class DictSet:
         nm = (C.c_char_p * n)(*[x.encode() for x in names])
         h = C.c_void_p()
         _check(_lib.skx_array_assemble(self.ctx.h, self.h, rows.h, nm, C.byref(h)))
+        return Array(h, self.ctx)
+
+    def assemble_lazy(self, rows, names):
+        """rows + these dictionaries as an array without a matrix; the dictset and the row set pass into the array (both handles end here)"""
+        n = len(names)
+        nm = (C.c_char_p * n)(*[x.encode() for x in names])
+        h = C.c_void_p()
+        dh, rh = self.h, rows.h
+        self.h = None; rows.h = None
+        _check(_lib.skx_array_assemble_lazy(self.ctx.h, dh, rh, nm, C.byref(h)))
         return Array(h, self.ctx)
 
     def free(self):

@@ -110,3 +110,39 @@ def test_lazy_array_other_operations_materialise(E, tmp_path):
     m = E.Array.merge([E.Array.build(inputs[:2], k=31), E.Array.build(inputs[2:], k=31)])
     for x, y in zip(_sorted(m), _sorted(oa)):
         assert np.array_equal(x, y)
+
+
+def test_assemble_lazy_equals_assemble(E, tmp_path):
+    """skx_array_assemble_lazy (the multi-GPU ranks' form: rows from elsewhere + the local dictionaries, no matrix) == skx_array_assemble:
+    statistics without a matrix, the filter writing kept rows only, the streamed .skf, the full export."""
+    inputs = _files(tmp_path, n=6, length=40_000, seed=41)
+    streams = [open(p, "rb").read() for _, p, _ in inputs]
+    recs = [b"\n".join(l for l in s.split(b"\n") if l and not l.startswith(b">")) + b"\n" for s in streams]
+    names = [nm for nm, _, _ in inputs]
+
+    def both():
+        ds = E.DictSet.build(recs, 31, True)
+        rows = ds.union_keys()
+        return ds, rows
+    ds, rows = both()
+    eager = ds.assemble(rows, names)
+    ds2, rows2 = both()
+    lazy = ds2.assemble_lazy(rows2, names)
+    assert ds2.h is None and rows2.h is None                        # both passed into the array
+    import torch  # noqa: F401  (device_stats hands out device pointers; compare through the exports instead)
+    for x, y in zip(_sorted(lazy), _sorted(eager)):                 # export materialises the lazy one
+        assert np.array_equal(x, y)
+    for ft, amb, mask, gaps in FILTERS[::7]:
+        ds3, rows3 = both()
+        lz = ds3.assemble_lazy(rows3, names)
+        lz.device_stats()                                           # statistics only: still no matrix
+        ds4, rows4 = both()
+        eg = ds4.assemble(rows4, names)
+        assert lz.filter(3, amb, ft, mask, gaps, True) == eg.filter(3, amb, ft, mask, gaps, True)
+        for x, y in zip(_sorted(lz), _sorted(eg)):
+            assert np.array_equal(x, y), (ft, amb, mask, gaps)
+    ds5, rows5 = both()
+    p = str(tmp_path / "lazy_assembled.skf")
+    ds5.assemble_lazy(rows5, names).save(p)
+    for x, y in zip(_sorted(ora.Array.load(p)), _sorted(eager)):
+        assert np.array_equal(x, y)
