@@ -146,3 +146,35 @@ def test_assemble_lazy_equals_assemble(E, tmp_path):
     ds5.assemble_lazy(rows5, names).save(p)
     for x, y in zip(_sorted(ora.Array.load(p)), _sorted(eager)):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("filt", [True, False])
+@pytest.mark.parametrize("min_freq", [0.0, 0.6])
+def test_distance_filtered_leaves_the_array_alone(E, tmp_path, filt, min_freq):
+    """skx_array_distance_filtered: generic_modes::distance's two filters decide per row, the bit planes are built over the rows that
+    stay -- same pairs as filter + filter + distance on the oracle, and the array afterwards is the array before."""
+    import math
+    inputs = _files(tmp_path, n=9, length=50_000, seed=51)
+    arr = E.Array.build(inputs, k=31, threads=2)
+    before = _sorted(arr)
+    got, constant, rows_used = arr.distance_filtered(min_freq, filt)
+    oa = ora.Array.build(inputs, k=31)
+    if min_freq * 9 >= 1.0:
+        oa.filter(math.ceil(9 * min_freq), False, ora.FILTER_NONE, False, False, False)
+    oc = oa.filter(0, False, ora.FILTER_NO_CONST, False, False, False)
+    od = oa.distance(oc, filt)
+    assert constant == oc and rows_used == oa.nrows
+    assert np.array_equal(got["match_count"], od["match_count"]) and np.array_equal(got["mismatch_count"], od["mismatch_count"])
+    assert np.allclose(got["distance"], od["distance"], rtol=0, atol=1e-6)
+    for x, y in zip(_sorted(arr), before):
+        assert np.array_equal(x, y)
+
+
+def test_phase_recorder_lists_what_ran(E, tmp_path):
+    inputs = _files(tmp_path, n=3, length=20_000, seed=61)
+    E.phases(reset=True)
+    a = E.Array.build(inputs, k=31, threads=2)
+    a.save(str(tmp_path / "p.skf"))
+    ph = E.phases()
+    assert {"build.read_upload", "build.dictionaries", "save.data_section"} <= set(ph) and all(v >= 0 for v in ph.values())
+    assert E.phases(reset=True) and not E.phases()
