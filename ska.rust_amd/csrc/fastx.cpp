@@ -8,14 +8,20 @@
 #include "skx_internal.h"
 #include <cmath>
 #include <cstring>
+#include <fcntl.h>
+#include <unistd.h>
 #include <zlib.h>
 
 namespace skx {
 
 static int slurp(const char *path, std::vector<uint8_t> &buf)
 {
-    gzFile g = gzopen(path, "rb");           // transparent for uncompressed files
-    if (!g) { set_error("Invalid path/file: %s", path); return SKX_EIO; }
+    // (read once: POSIX_FADV_NOREUSE keeps the kernel from promoting every page on first access -- one lock for all reader threads)
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) { set_error("Invalid path/file: %s", path); return SKX_EIO; }
+    (void)posix_fadvise(fd, 0, 0, POSIX_FADV_NOREUSE);
+    gzFile g = gzdopen(fd, "rb");            // transparent for uncompressed files; closes fd with gzclose
+    if (!g) { ::close(fd); set_error("Invalid path/file: %s", path); return SKX_EIO; }
     gzbuffer(g, 1 << 20);
     buf.clear();
     size_t n = 0;

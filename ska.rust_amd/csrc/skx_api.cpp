@@ -598,6 +598,9 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
                 const int fd = ::open(file1[i], O_RDONLY);
                 if (fd < 0) return SKF_NOT_TAKEN;                                    // the host reader reports it
                 struct Close { int fd; ~Close() { ::close(fd); } } cl{fd};
+                // the pages are read once: without this hint every first access promotes its page on the kernel's LRU lists, under one lock
+                // for all reader threads (1 000 fresh 5 MB files on tmpfs: 0.47 s instead of 0.23 s for the same read() calls)
+                (void)posix_fadvise(fd, 0, 0, POSIX_FADV_NOREUSE);
                 const uint64_t cap = slot_len[i] - 64;                               // the size stat reported
                 uint8_t *dst = raw_all.p + slot_off[i];
                 uint64_t off = 0;
