@@ -24,7 +24,7 @@ run("build", ["build", "-f", "list.txt", "-o", "all", "-k", "31", "--threads", "
 time.sleep(3)
 for rep in range(4):
     for env in envs:
-        if os.path.exists(os.path.join(td, "aln.fa")): os.unlink(os.path.join(td, "aln.fa")); time.sleep(1.0)      # (truncating 4.9 GB on open costs 0.4 s)
+        if os.path.exists(os.path.join(td, "aln.fa")): os.unlink(os.path.join(td, "aln.fa")); time.sleep(float(os.environ.get("AB_SLEEP", "1.0")))      # (truncating 4.9 GB on open costs 0.4 s)
         run("align", ["align", "all.skf", "-o", "aln.fa", "--threads", "64"], env)
 for rep in range(2):
     for env in envs:
