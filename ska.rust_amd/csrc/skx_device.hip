@@ -364,6 +364,33 @@ __device__ static inline uint32_t block_excl_scan(uint32_t v, uint32_t *s_tmp /*
     return r;
 }
 
+// the same scan without the walk of the waves' sums by thread 0 between two barriers: every thread adds up the sums of the waves
+// before its own (<= 16 broadcast LDS reads), the wave scan runs on DPP moves instead of LDS permutes.  (Used where registers allow:
+// in extract_kernel, at its 80-VGPR cap, the extra live values spilled.)
+__device__ static inline uint32_t block_excl_scan_dpp(uint32_t v, uint32_t *s_tmp /*[17]*/, uint32_t *total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    uint32_t inc = v;
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, true);      // row_shr:1
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, true);      // row_shr:2
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, true);      // row_shr:4
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, true);      // row_shr:8
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
+    if (lane == 63) s_tmp[wv] = inc;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t t = i < nw ? s_tmp[i] : 0u;
+        all += t;
+        before += i < wv ? t : 0u;
+    }
+    if (total) *total = all;
+    __syncthreads();
+    return before + inc - v;
+}
+
 // single-workgroup exclusive scan u32 -> u64 (n is at most a few million; launch-bound otherwise)
 __global__ __launch_bounds__(1024) void scan_u32_kernel(const uint32_t *in, uint64_t *out, uint64_t n, uint32_t *max_out)
 {
@@ -604,7 +631,7 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
     const uint32_t m0 = threadIdx.x * R < M ? threadIdx.x * R : M, m1 = m0 + R < M ? m0 + R : M;
     uint32_t sum = 0;
     for (uint32_t m = m0; m < m1; m++) sum += s_cnt[m];
-    uint32_t run = block_excl_scan(sum, s_tmp, nullptr);
+    uint32_t run = block_excl_scan_dpp(sum, s_tmp, nullptr);
     for (uint32_t m = m0; m < m1; m++) { uint32_t c = s_cnt[m]; s_cnt[m] = run; run += c; }      // start of m; the scatter below turns it into its end = start of m + 1
     __syncthreads();
     uint32_t pos[ITEMS];
