@@ -178,3 +178,19 @@ def test_phase_recorder_lists_what_ran(E, tmp_path):
     ph = E.phases()
     assert {"build.read_upload", "build.dictionaries", "save.data_section"} <= set(ph) and all(v >= 0 for v in ph.values())
     assert E.phases(reset=True) and not E.phases()
+
+
+@pytest.mark.parametrize("filt", [True, False])
+def test_distance_many_samples_several_pair_tiles(E, tmp_path, filt):
+    """131 samples: three tile rows / columns of the 64 x 64 (default) and five of the 32 x 32 (--allow-ambiguous) pair sweep, the last
+    ones ragged, ambiguity codes present -- every pair as the oracle counts it."""
+    inputs = _files(tmp_path, n=131, length=6_000, snps=40, seed=71)
+    arr = E.Array.build(inputs, k=21, threads=4)
+    got, constant, _ = arr.distance_filtered(0.0, filt)
+    oa = ora.Array.build(inputs, k=21)
+    oc = oa.filter(0, False, ora.FILTER_NO_CONST, False, False, False)
+    od = oa.distance(oc, filt)
+    assert constant == oc and len(got) == 131 * 130 // 2
+    assert np.array_equal(got["match_count"], od["match_count"]) and np.array_equal(got["mismatch_count"], od["mismatch_count"])
+    assert np.allclose(got["distance"], od["distance"], rtol=0, atol=1e-6)
+    assert np.allclose(got["mismatch_prop"], od["mismatch_prop"], rtol=0, atol=1e-9)
