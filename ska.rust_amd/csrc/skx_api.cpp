@@ -525,7 +525,10 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
     // a single uploader issues the copies on one stream and recycles the slots.  The ring is pinned by a helper thread while
     // this one sizes and allocates the device buffers.
     constexpr size_t SLOT = 8u << 20;
-    const int n_slots = std::max(4, std::min(2 * nt, 32));
+    bool any_pair = false;
+    for (int i = 0; file2 && i < n; i++) any_pair |= file2[i] != nullptr;
+    // (a thread streaming a FASTQ sample fills a sequence and a quality slot at a time: two per thread and a few in flight)
+    const int n_slots = any_pair ? 2 * nt + 8 : std::max(4, std::min(2 * nt, 32));
     struct Ring {
         uint8_t *base = nullptr; std::mutex mu; std::condition_variable cv_free, cv_work;
         std::vector<int> free_slots; struct Req { int slot; uint8_t *dst; size_t bytes; }; std::deque<Req> work; int readers_left = 0; bool failed = false;
@@ -540,7 +543,9 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
     struct JoinPin { std::thread &t; ~JoinPin() { if (t.joinable()) t.join(); } } join_pin{pin_thread};
     // one device buffer for all raw texts and one for all record streams (a slot per single-file sample, sized from stat):
     // two allocations whatever the number of samples
-    DevBuf<uint8_t> raw_all, out_all;
+    DevBuf<uint8_t> raw_all, out_all, hs_seq_all, hs_qual_all;
+    std::vector<uint64_t> hs_off(n, 0), hs_len(n, 0);
+    std::vector<uint8_t> hs_fq(n, 0);
     if (device_parse) {
         uint64_t tot = 0;
         for (int i = 0; i < n; i++) {
@@ -550,17 +555,39 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
             tot += slot_len[i];
         }
         if (tot) { SKX_HIP(hipSetDevice(ctx->device)); SKX_TRY(raw_all.alloc(tot)); SKX_TRY(out_all.alloc(tot)); }
+        // the samples the host reader will parse (two files, FASTQ): one buffer for all their record streams and one for the quality
+        // streams, a slot each bounded from the file sizes -- plain FASTQ holds at most half its bytes in either stream, plain FASTA
+        // all of them; gzip (size unknown) keeps an allocation of its own.  No device allocation per sample from the reader threads
+        // (64 of them for 32 isolates queued behind one another: most of 5 s).
+        uint64_t htot = 0; bool any_q = false;
+        for (int i = 0; i < n; i++) {
+            if (slot_len[i]) continue;
+            uint64_t bytes = 0; bool fq = false, ok = true;
+            for (const char *f : {file1[i], file2 ? file2[i] : nullptr}) {
+                if (!f) continue;
+                struct stat sb; unsigned char c0 = 0;
+                const int fd = ::open(f, O_RDONLY);
+                if (fd < 0 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || ::read(fd, &c0, 1) != 1 || (c0 != '@' && c0 != '>')) ok = false;
+                else { bytes += (uint64_t)sb.st_size; fq |= c0 == '@'; }
+                if (fd >= 0) ::close(fd);
+            }
+            if (!ok || !bytes) continue;
+            hs_off[i] = htot; hs_len[i] = ((fq ? bytes / 2 : bytes) + 64 + 255) & ~255ull; hs_fq[i] = fq ? 1 : 0;
+            htot += hs_len[i]; any_q |= fq;
+        }
+        if (htot) { SKX_HIP(hipSetDevice(ctx->device)); SKX_TRY(hs_seq_all.alloc(htot)); if (any_q) SKX_TRY(hs_qual_all.alloc(htot)); }
         pin_thread.join();
         phase_add("build.alloc_text_pin_ring", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_read0).count());
         if (pin_rc != 0) { ring.base = nullptr; }                                 // no pinned memory: every sample takes the host reader
         else for (int b = 0; b < n_slots; b++) ring.free_slots.push_back(b);
     }
-    const bool raw_ok = device_parse && ring.base && raw_all.p;
+    const bool ring_ok = device_parse && ring.base;                            // the pinned ring + uploader threads carry raw files and host-parsed streams alike
+    const bool raw_ok = ring_ok && raw_all.p;
     ring.readers_left = nt;
     // uploader: copies queued pieces on one stream, a batch at a time, and returns their slots
     std::vector<std::thread> uploaders;
     const int n_up = getenv("SKX_UPLOADERS") ? std::max(1, atoi(getenv("SKX_UPLOADERS"))) : 2;      // two streams keep both copy engines busy
-    if (raw_ok) for (int u = 0; u < n_up; u++) uploaders.emplace_back([&]() {
+    if (ring_ok) for (int u = 0; u < n_up; u++) uploaders.emplace_back([&]() {
         (void)hipSetDevice(ctx->device);
         hipStream_t up = nullptr;
         if (hipStreamCreateWithFlags(&up, hipStreamNonBlocking) != hipSuccess) up = nullptr;
@@ -631,26 +658,98 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
                 raw_len[i] = off; is_raw[i] = 1;
                 return SKX_OK;
             };
+            // a plain FASTQ sample: its files' lines go straight from a small read buffer into pinned slots -- one filling with sequence
+            // lines, one with quality lines -- which the uploaders copy to the sample's places in the two stream buffers
+            auto stream_fastq = [&](int i) -> int {
+                struct Out { int slot = -1; size_t used = 0; uint8_t *dst = nullptr; uint64_t off = 0; } o[2];
+                o[0].dst = hs_seq_all.p + hs_off[i]; o[1].dst = hs_qual_all.p + hs_off[i];
+                const uint64_t cap = hs_len[i] - 32;
+                auto flush = [&](Out &x) {
+                    if (x.slot < 0) return;
+                    { std::lock_guard<std::mutex> lk(ring.mu); ring.work.push_back({x.slot, x.dst + x.off, x.used}); }
+                    ring.cv_work.notify_one();
+                    x.off += x.used; x.slot = -1; x.used = 0;
+                };
+                auto give_back = [&]() {
+                    for (auto &x : o) if (x.slot >= 0) { { std::lock_guard<std::mutex> lk(ring.mu); ring.free_slots.push_back(x.slot); } ring.cv_free.notify_one(); x.slot = -1; }
+                };
+                const std::function<int(int, const uint8_t *, size_t)> emit = [&](int which, const uint8_t *p, size_t nb) -> int {
+                    Out &x = o[which];
+                    if (x.off + x.used + nb > cap) { set_error("Invalid FASTA/Q record"); return SKX_EIO; }      // (more sequence than half the file: not FASTQ)
+                    while (nb) {
+                        if (x.slot < 0) {
+                            std::unique_lock<std::mutex> lk(ring.mu);
+                            ring.cv_free.wait(lk, [&] { return !ring.free_slots.empty() || ring.failed; });
+                            if (ring.failed) { set_error("upload of the sequence files failed"); return SKX_ENODEV; }
+                            x.slot = ring.free_slots.back(); ring.free_slots.pop_back(); x.used = 0;
+                        }
+                        const size_t take = std::min(nb, SLOT - x.used);
+                        memcpy(ring.base + (size_t)x.slot * SLOT + x.used, p, take);
+                        x.used += take; p += take; nb -= take;
+                        if (x.used == SLOT) flush(x);
+                    }
+                    return SKX_OK;
+                };
+                for (const char *f : {file1[i], file2 ? file2[i] : nullptr}) {
+                    if (!f) continue;
+                    int r = stream_fastq_file(f, emit);
+                    if (r == SKF_NOT_TAKEN && f != file1[i]) { set_error("Invalid FASTA/Q record"); r = SKX_EIO; }      // file 2 is parsed in file 1's mode (ska_dict.rs:356-366)
+                    if (r != SKX_OK) { give_back(); return r; }              // (SKF_NOT_TAKEN: the first file, before anything was emitted)
+                }
+                flush(o[0]); flush(o[1]);
+                if (o[0].off != o[1].off) { set_error("Invalid FASTA/Q record"); return SKX_EIO; }
+                ss[i].seq = o[0].dst; ss[i].qual = o[1].dst; ss[i].len = o[0].off;
+                return SKX_OK;
+            };
+            HostStream h;                                                            // (its buffers live across this thread's samples: no fresh pages per sample)
             for (int i; (i = next.fetch_add(1)) < n;) {
                 if (raw_ok) {
                     const int r = raw_upload(i);
                     if (r == SKX_OK) continue;
                     if (r != SKF_NOT_TAKEN) { rcodes[i] = r; errs[i] = skx_last_error(); continue; }
                 }
-                HostStream h;
+                if (ring_ok && hs_len[i] && hs_fq[i] && hs_qual_all.p) {
+                    const int r = stream_fastq(i);
+                    if (r == SKX_OK) continue;
+                    if (r != SKF_NOT_TAKEN) { rcodes[i] = r; errs[i] = skx_last_error(); continue; }
+                }
                 rcodes[i] = read_sample_stream(file1[i], file2 ? file2[i] : nullptr, proportion_reads, h);
                 if (rcodes[i] != SKX_OK) { errs[i] = skx_last_error(); continue; }
-                if (!up_st) { (void)hipSetDevice(ctx->device); if (hipStreamCreateWithFlags(&up_st, hipStreamNonBlocking) != hipSuccess) up_st = nullptr; }
                 const size_t len = h.seq.size();
-                auto up = [&](DevBuf<uint8_t> &dst, const std::vector<uint8_t> &src) -> int {
-                    SKX_TRY(dst.alloc(len + 16));
-                    if (len) { SKX_HIP(hipMemcpyAsync(dst.p, src.data(), len, hipMemcpyHostToDevice, up_st)); SKX_HIP(hipStreamSynchronize(up_st)); }
+                // the parsed streams travel through the pinned ring like the raw files (a copy from pageable memory goes through the
+                // runtime's one staging path: 32 reader threads shared ~3 GB/s, 5.6 s for 32 isolates); the uploads are complete when the
+                // uploader threads have been joined, which is before anything reads them
+                auto up = [&](DevBuf<uint8_t> &own, uint8_t *slot_ptr, const std::vector<uint8_t> &src, uint8_t **where) -> int {
+                    struct { uint8_t *p; } dst{slot_ptr};
+                    if (!dst.p) { (void)hipSetDevice(ctx->device); SKX_TRY(own.alloc(len + 16)); dst.p = own.p; }      // no slot (gzip, a stream longer than its bound)
+                    *where = dst.p;
+                    if (!ring_ok) {
+                        (void)hipSetDevice(ctx->device);
+                        if (!up_st && hipStreamCreateWithFlags(&up_st, hipStreamNonBlocking) != hipSuccess) up_st = nullptr;
+                        if (len) { SKX_HIP(hipMemcpyAsync(dst.p, src.data(), len, hipMemcpyHostToDevice, up_st)); SKX_HIP(hipStreamSynchronize(up_st)); }
+                        return SKX_OK;
+                    }
+                    for (size_t off = 0; off < len; off += SLOT) {
+                        int slot;
+                        {
+                            std::unique_lock<std::mutex> lk(ring.mu);
+                            ring.cv_free.wait(lk, [&] { return !ring.free_slots.empty() || ring.failed; });
+                            if (ring.failed) { set_error("upload of the sequence files failed"); return SKX_ENODEV; }
+                            slot = ring.free_slots.back(); ring.free_slots.pop_back();
+                        }
+                        const size_t nb = std::min<size_t>(SLOT, len - off);
+                        memcpy(ring.base + (size_t)slot * SLOT, src.data() + off, nb);
+                        { std::lock_guard<std::mutex> lk(ring.mu); ring.work.push_back({slot, dst.p + off, nb}); }
+                        ring.cv_work.notify_one();
+                    }
                     return SKX_OK;
                 };
-                rcodes[i] = up(d_seq[i], h.seq);
-                if (rcodes[i] == SKX_OK && h.is_fastq) rcodes[i] = up(d_qual[i], h.qual);
+                const bool fits = hs_len[i] && len + 16 <= hs_len[i] && (!h.is_fastq || hs_qual_all.p);
+                uint8_t *at_seq = nullptr, *at_qual = nullptr;
+                rcodes[i] = up(d_seq[i], fits ? hs_seq_all.p + hs_off[i] : nullptr, h.seq, &at_seq);
+                if (rcodes[i] == SKX_OK && h.is_fastq) rcodes[i] = up(d_qual[i], fits ? hs_qual_all.p + hs_off[i] : nullptr, h.qual, &at_qual);
                 if (rcodes[i] != SKX_OK) { errs[i] = skx_last_error(); continue; }
-                ss[i].seq = d_seq[i].p; ss[i].qual = h.is_fastq ? d_qual[i].p : nullptr; ss[i].len = len;
+                ss[i].seq = at_seq; ss[i].qual = h.is_fastq ? at_qual : nullptr; ss[i].len = len;
             }
         });
     for (auto &th : pool) th.join();
@@ -1115,18 +1214,34 @@ extern "C" int skx_merge(skx_ctx *ctx, skx_dictset *d, const char *const *names,
 // array that survives is 1 byte per (row, sample).  A batch of samples whose dictionaries fit is built and merged into
 // an array, the batch arrays are then joined by the `ska merge` row-set path (skx_array_merge): the result has the same
 // rows and columns as one big batch (merge_ska_dict.rs:354-417 builds the same union through its tree of appends).
-static uint64_t sample_device_bytes(const char *f1, const char *f2, bool wide)
+// resident: what a sample holds on the device while its batch is built; transient: what building it needs for a moment (read sets are
+// counted one sample at a time).  An assembly's dictionary is a packed word per base, raw and deduplicated, with slack.  A read set
+// (first byte '@', or gzip: taken as reads) keeps its two record streams -- about the size of its files -- and a dictionary of at most
+// one word per min_count windows; the windows of ONE sample with their partition copies are the transient.  (Pricing a 50x isolate as
+// an assembly -- 22 GB instead of ~1.5 -- cut 12 isolates into three batches whose arrays were then joined on the host: 6 s instead of 2.5.)
+struct SampleNeed { uint64_t resident = 0, transient = 0; };
+static SampleNeed sample_device_bytes(const char *f1, const char *f2, bool wide, unsigned min_count)
 {
-    uint64_t bases = 0;
+    uint64_t bytes = 0; bool reads = false;
     for (const char *f : {f1, f2}) {
         if (!f) continue;
         struct stat sb;
         if (stat(f, &sb) != 0) continue;                       // the reader reports a missing file
-        const size_t L = strlen(f);
-        const bool gz = L > 3 && !strcmp(f + L - 3, ".gz");
-        bases += (uint64_t)sb.st_size * (gz ? 5u : 1u);        // upper estimate: FASTQ text holds about half as many bases
+        unsigned char c0 = 0;
+        const int fd = ::open(f, O_RDONLY);
+        if (fd >= 0) { if (::read(fd, &c0, 1) != 1) c0 = 0; ::close(fd); }
+        const bool gz = c0 == 0x1f;
+        reads |= gz || c0 == '@';
+        bytes += (uint64_t)sb.st_size * (gz ? 5u : 1u);        // upper estimate of the text
     }
-    return bases * (wide ? 44u : 24u) + (8u << 20);            // sequence + raw regions (with slack) + deduplicated words
+    SampleNeed n;
+    if (reads) {
+        const uint64_t bases = bytes / 2;                      // sequence and quality lines
+        n.resident = bytes + bases / std::max(1u, min_count) * (wide ? 20u : 12u) + (8u << 20);
+        n.transient = bases * (wide ? 56u : 28u);
+    } else
+        n.resident = bytes * (wide ? 44u : 24u) + (8u << 20);  // sequence + raw regions (with slack) + deduplicated words
+    return n;
 }
 static uint64_t cached_device_bytes()        // of the current device
 {
@@ -1187,13 +1302,14 @@ extern "C" int skx_build_and_merge(skx_ctx *ctx, const char *const *names, const
     struct Drop { std::vector<skx_array *> &v; ~Drop() { for (auto *a : v) skx_array_free(a); } } drop{parts};
     int r = SKX_OK, lo = 0;
     while (lo < n && r == SKX_OK) {
-        uint64_t need = 0;
+        uint64_t need = 0, transient = 0;
         int hi = lo;
         while (hi < n) {
-            const uint64_t s = sample_device_bytes(file1[hi], file2 ? file2[hi] : nullptr, k > 31);
-            if (hi > lo && need + s > budget) break;
-            need += s; hi++;
+            const SampleNeed s = sample_device_bytes(file1[hi], file2 ? file2[hi] : nullptr, k > 31, q ? q->min_count : 1);
+            if (hi > lo && need + s.resident + std::max(transient, s.transient) > budget) break;
+            need += s.resident; transient = std::max(transient, s.transient); hi++;
         }
+        need += transient;
         if (getenv("SKX_DEBUG") && (lo || hi < n)) fprintf(stderr, "[skx] build: samples %d..%d as one batch (estimate %.1f MB of %.1f MB)\n", lo, hi - 1, need / 1048576.0, budget / 1048576.0);
         r = build_range(ctx, names, file1, file2, lo, hi, k, rc, q, threads, proportion_reads, parts);
         lo = hi;
