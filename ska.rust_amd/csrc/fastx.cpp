@@ -107,7 +107,7 @@ static int parse_fastq(const std::vector<uint8_t> &b, size_t step, HostStream &o
     return SKX_OK;
 }
 
-// A plain FASTQ file as two streams of lines (sequence, quality; each followed by '\n'), handed to `emit` line by line: nothing of
+// A plain FASTQ file as two streams of lines (sequence, quality; the sink appends the '\n' that ends a record), handed to `emit` line by line: nothing of
 // the file's size is allocated (the reader threads of a batch of 50x isolates each took ~0.8 GB of fresh memory through the whole-file
 // parser, and 32 of them together ran at a sixth of the rate of 8).  Same checks as parse_fastq.  SKF_NOT_TAKEN: not a plain FASTQ file.
 int stream_fastq_file(const char *path, const std::function<int(int which, const uint8_t *p, size_t n)> &emit)
@@ -130,11 +130,11 @@ int stream_fastq_file(const char *path, const std::function<int(int which, const
             if (n == 0) return SKX_OK;                                      // blank line between records
             if (*s != '@') { set_error("Invalid FASTA/Q record"); return SKX_EIO; }
             in_record = true; break;
-        case 1: { seq_len = n; int r = emit(0, s, n); if (r != SKX_OK) return r; static const uint8_t nl = '\n'; r = emit(0, &nl, 1); if (r != SKX_OK) return r; break; }
+        case 1: { seq_len = n; const int r = emit(0, s, n); if (r != SKX_OK) return r; break; }
         case 2: if (n == 0 || *s != '+') { set_error("Invalid FASTA/Q record"); return SKX_EIO; } break;
         default: {
             if (n != seq_len) { set_error("Invalid FASTA/Q record"); return SKX_EIO; }
-            int r = emit(1, s, n); if (r != SKX_OK) return r; static const uint8_t nl = '\n'; r = emit(1, &nl, 1); if (r != SKX_OK) return r;
+            const int r = emit(1, s, n); if (r != SKX_OK) return r;
             in_record = false; break; }
         }
         line_no++;

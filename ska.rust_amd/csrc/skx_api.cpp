@@ -519,14 +519,14 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
     if (proportion_reads > 0.0) { step = (size_t)std::llround(1.0 / proportion_reads); if (step == 0) step = 1; }
     const bool device_parse = step == 1 && !getenv("SKX_HOST_PARSE");
     const auto t_read0 = std::chrono::steady_clock::now();
-    const int nt = std::max(1, std::min({threads, n, 32}));      // 5 GB of FASTA text: 0.43 / 0.24 / 0.24 / 0.32 s with 8 / 16 / 32 / 64 readers (tools/read_knobs.py)
+    bool any_pair = false;
+    for (int i = 0; file2 && i < n; i++) any_pair |= file2[i] != nullptr;
+    const int nt = std::max(1, std::min({threads, n, any_pair ? 64 : 32}));      // (paired read sets are parsed on the host: CPU work, more threads pay)      // 5 GB of FASTA text: 0.43 / 0.24 / 0.24 / 0.32 s with 8 / 16 / 32 / 64 readers (tools/read_knobs.py)
     // Raw path plumbing: reader threads make no HIP calls at all (creating a stream or a pinned buffer per thread serialises in
     // the runtime: 64 threads spent 0.28 s each waiting for theirs).  They read() file pieces into the slots of ONE pinned ring;
     // a single uploader issues the copies on one stream and recycles the slots.  The ring is pinned by a helper thread while
     // this one sizes and allocates the device buffers.
     constexpr size_t SLOT = 8u << 20;
-    bool any_pair = false;
-    for (int i = 0; file2 && i < n; i++) any_pair |= file2[i] != nullptr;
     // (a thread streaming a FASTQ sample fills a sequence and a quality slot at a time: two per thread and a few in flight)
     const int n_slots = any_pair ? 2 * nt + 8 : std::max(4, std::min(2 * nt, 32));
     struct Ring {
@@ -675,8 +675,18 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
                 };
                 const std::function<int(int, const uint8_t *, size_t)> emit = [&](int which, const uint8_t *p, size_t nb) -> int {
                     Out &x = o[which];
-                    if (x.off + x.used + nb > cap) { set_error("Invalid FASTA/Q record"); return SKX_EIO; }      // (more sequence than half the file: not FASTQ)
-                    while (nb) {
+                    if (x.off + x.used + nb + 1 > cap) { set_error("Invalid FASTA/Q record"); return SKX_EIO; }      // (more sequence than half the file: not FASTQ)
+                    if (x.slot >= 0 && x.used + nb + 1 <= SLOT) {                       // the common case: the line and its terminator fit the slot being filled
+                        uint8_t *d = ring.base + (size_t)x.slot * SLOT + x.used;
+                        memcpy(d, p, nb); d[nb] = '\n';
+                        x.used += nb + 1;
+                        if (x.used == SLOT) flush(x);
+                        return SKX_OK;
+                    }
+                    bool term = false;                                                  // the line, then its '\n', across slot ends
+                    static const uint8_t nl = '\n';
+                    for (;;) {
+                        if (nb == 0) { if (term) break; term = true; p = &nl; nb = 1; }
                         if (x.slot < 0) {
                             std::unique_lock<std::mutex> lk(ring.mu);
                             ring.cv_free.wait(lk, [&] { return !ring.free_slots.empty() || ring.failed; });

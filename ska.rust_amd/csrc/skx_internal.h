@@ -153,7 +153,8 @@ namespace skx {
 // host reader (fastx.cpp): one sample -> record stream; returns SKX_* and sets the error
 struct HostStream { std::vector<uint8_t> seq, qual; bool is_fastq = false; std::vector<std::string> ids; };   // ids: FASTA record ids (header up to white space)
 int read_sample_stream(const char *file1, const char *file2, double proportion_reads, HostStream &out);
-// a plain FASTQ file line by line: emit(0, sequence line) / emit(1, quality line), each followed by a '\n' of its own (SKF_NOT_TAKEN: not plain FASTQ)
+// a plain FASTQ file line by line: emit(0, sequence line) / emit(1, quality line), without terminators -- the sink adds the '\n' that ends a
+// record of the stream (SKF_NOT_TAKEN: not plain FASTQ)
 int stream_fastq_file(const char *path, const std::function<int(int which, const uint8_t *p, size_t n)> &emit);
 // FASTQ sample -> sorted unique packed words (skx_reads.hip)
 int reads_sample_dict(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t len, int k, int rc, const skx_qual &q,

@@ -37,6 +37,7 @@ with open(os.path.join(td, "list.txt"), "w") as lst:
             rec[:, 3 + rl:6 + rl] = np.frombuffer(b"\n+\n", np.uint8); rec[:, 6 + rl:6 + 2 * rl] = q; rec[:, -1] = 10
             p = os.path.join(td, f"iso{i}_{mate + 1}.fastq"); rec.tofile(p); names.append(p)
         lst.write(f"iso{i}\t{names[0]}\t{names[1]}\n")
+sys.stdout.flush()
 print(f"{n} isolates written in {time.perf_counter() - t0:.1f} s ({npairs} pairs each)", flush=True)
 SKA = os.path.join(ROOT, "ska.rust_amd", "ska")
 def run(tag, cmd, env=None):
@@ -48,6 +49,9 @@ def run(tag, cmd, env=None):
 opts = ["-k", "41", "--min-count", "5", "--min-qual", "20", "--qual-filter", "strict"]
 tb = run("ska build (one process)", [SKA, "build", "-f", "list.txt", "-o", "one", "--threads", os.environ.get("RSC_THREADS", "16"), *opts], {"SKX_PHASES": os.path.join(td, "ph.json"), "SKX_DEBUG": "1"} if os.environ.get("RSC_DEBUG") else {"SKX_PHASES": os.path.join(td, "ph.json")})
 print("  phases", open(os.path.join(td, "ph.json")).read())
+for up in os.environ.get("RSC_UPLOADERS", "").split():
+    run(f"ska build with SKX_UPLOADERS={up}", [SKA, "build", "-f", "list.txt", "-o", "two", "--threads", os.environ.get("RSC_THREADS", "16"), *opts], {"SKX_PHASES": os.path.join(td, "ph2.json"), "SKX_UPLOADERS": up})
+    print("  phases", open(os.path.join(td, "ph2.json")).read()[:330])
 run("ska distance one.skf", [SKA, "distance", "one.skf", "-o", "one.tsv"])
 print(f"  = {n / tb:.1f} isolates/s through the executable (files on tmpfs)")
 launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", "29642",
