@@ -1642,6 +1642,28 @@ extern "C" int skx_array_merge(skx_ctx *ctx, skx_array *const *in, int n, skx_ar
         if (U) SKX_HIP(hipMemcpyAsync(a->keys.p, rows.p, U * 8, hipMemcpyDeviceToDevice, st));
         SKX_HIP(hipStreamSynchronize(st));
         a->engine_order = true;
+    } else if (tot > 0 && std::all_of(in, in + n, [](const skx_array *x) { return x->engine_order && x->host_keys.empty() && (x->keys.p || !x->n_rows); })) {
+        // 128-bit keys of arrays this process built (batches of one `ska build`): each input's rows are a sorted list on the
+        // device, so the row set is the key-set union the build itself uses and the row indices are a device search
+        struct Sets { std::vector<skx_keyset *> v; ~Sets() { for (auto *k : v) skx_keyset_free(k); } } sets;
+        for (int i = 0; i < n; i++) {
+            if (!in[i]->n_rows) continue;
+            skx_keyset *ks = nullptr;
+            SKX_TRY(skx_keyset_from_device(ctx, in[i]->keys.p, in[i]->n_rows, a->k, a->rc, &ks));
+            sets.v.push_back(ks);
+        }
+        skx_keyset *rows = nullptr;
+        SKX_TRY(skx_keyset_merge(ctx, sets.v.data(), (int)sets.v.size(), &rows));
+        sets.v.push_back(rows);
+        if (rows->logN >= 0) SKX_TRY(keyset_flatten(rows));
+        U = rows->total;
+        for (int i = 0; i < n; i++) {
+            SKX_TRY(idx[i].alloc(in[i]->n_rows));
+            launch_lookup_rows_wide((const u128 *)in[i]->keys.p, in[i]->n_rows, (const u128 *)rows->flat.p, U, idx[i].p, st);
+        }
+        SKX_HIP(hipStreamSynchronize(st));
+        a->keys = std::move(rows->flat);
+        a->engine_order = true;
     } else {
         // 128-bit keys of loaded arrays live on the host: the row set is a host sort, the matrix work stays on the device
         std::vector<std::vector<skx_key>> hk(n);

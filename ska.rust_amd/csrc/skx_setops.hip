@@ -51,6 +51,22 @@ void launch_lookup_rows(const uint64_t *words, uint64_t n, const uint64_t *sorte
     hipLaunchKernelGGL(lookup_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, words, n, sorted, m, idx);
 }
 
+// the same for 128-bit keys (k > 31): both lists hold (H(key) << 4 | code bits) as u128, compared on the key bits
+__global__ __launch_bounds__(256) void lookup_rows_wide_kernel(const u128 *words, uint64_t n, const u128 *sorted, uint64_t m, uint32_t *idx)
+{
+    const uint64_t i = blockIdx.x * 256ull + threadIdx.x;
+    if (i >= n) return;
+    const u128 key = words[i] >> 4;
+    uint64_t lo = 0, hi = m;
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if ((sorted[mid] >> 4) < key) lo = mid + 1; else hi = mid; }
+    idx[i] = (lo < m && (sorted[lo] >> 4) == key) ? (uint32_t)lo : 0xFFFFFFFFu;
+}
+void launch_lookup_rows_wide(const u128 *words, uint64_t n, const u128 *sorted, uint64_t m, uint32_t *idx, hipStream_t st)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(lookup_rows_wide_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, words, n, sorted, m, idx);
+}
+
 // weed: keep[i] = 1 when the row survives ((!reverse && !found) || (reverse && found), merge_ska_array.rs:468), else 0
 __global__ __launch_bounds__(256) void member_flags_kernel(const uint32_t *idx, uint64_t n, int reverse, uint8_t *keep)
 {

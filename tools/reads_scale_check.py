@@ -49,6 +49,11 @@ def run(tag, cmd, env=None):
 opts = ["-k", "41", "--min-count", "5", "--min-qual", "20", "--qual-filter", "strict"]
 tb = run("ska build (one process)", [SKA, "build", "-f", "list.txt", "-o", "one", "--threads", os.environ.get("RSC_THREADS", "16"), *opts], {"SKX_PHASES": os.path.join(td, "ph.json"), "SKX_DEBUG": "1"} if os.environ.get("RSC_DEBUG") else {"SKX_PHASES": os.path.join(td, "ph.json")})
 print("  phases", open(os.path.join(td, "ph.json")).read())
+for mb in os.environ.get("RSC_BATCH_MB", "").split():
+    run(f"ska build with SKX_BUILD_BATCH_MB={mb}", [SKA, "build", "-f", "list.txt", "-o", "three", "--threads", os.environ.get("RSC_THREADS", "16"), *opts], {"SKX_PHASES": os.path.join(td, "ph3.json"), "SKX_BUILD_BATCH_MB": mb, "SKX_DEBUG": "1"})
+    print("  phases", open(os.path.join(td, "ph3.json")).read()[:600])
+    same = open(os.path.join(td, "one.skf"), "rb").read() == open(os.path.join(td, "three.skf"), "rb").read()
+    print("  batched .skf", "IDENTICAL to" if same else "DIFFERENT from", "the one-batch file")
 for up in os.environ.get("RSC_UPLOADERS", "").split():
     run(f"ska build with SKX_UPLOADERS={up}", [SKA, "build", "-f", "list.txt", "-o", "two", "--threads", os.environ.get("RSC_THREADS", "16"), *opts], {"SKX_PHASES": os.path.join(td, "ph2.json"), "SKX_UPLOADERS": up})
     print("  phases", open(os.path.join(td, "ph2.json")).read()[:330])
