@@ -1422,6 +1422,21 @@ int skx::array_host_keys(skx_array *a, std::vector<skx_key> &hk)
     return SKX_OK;
 }
 
+int skx::array_wide_words(skx_array *a, DevBuf<uint64_t> &tmp, const u128 **words)
+{
+    if (a->keys_absent) { set_error("this array was loaded without its split k-mers (skx_array_load_filtered)"); return SKX_EINVAL; }
+    const uint64_t K = a->n_kmers;
+    if (a->host_keys.empty()) { *words = (const u128 *)a->keys.p; return SKX_OK; }           // built here: already packed words
+    hipStream_t st = a->ctx->stream;
+    DevBuf<uint64_t> raw; SKX_TRY(raw.alloc(2 * K)); SKX_TRY(tmp.alloc(2 * K));
+    static_assert(sizeof(skx_key) == 16 && offsetof(skx_key, lo) == 0, "skx_key is a little-endian u128");
+    SKX_HIP(hipMemcpyAsync(raw.p, a->host_keys.data(), K * 16, hipMemcpyHostToDevice, st));
+    launch_hash_keys_wide((const u128 *)raw.p, (u128 *)tmp.p, K, a->wh, st);
+    SKX_HIP(hipStreamSynchronize(st));
+    *words = (const u128 *)tmp.p;
+    return SKX_OK;
+}
+
 extern "C" int skx_array_export(skx_array *a, skx_key *keys, uint8_t *variants, uint64_t *counts)
 {
     return skx_guarded([&]() -> int {
@@ -1642,45 +1657,24 @@ extern "C" int skx_array_merge(skx_ctx *ctx, skx_array *const *in, int n, skx_ar
         if (U) SKX_HIP(hipMemcpyAsync(a->keys.p, rows.p, U * 8, hipMemcpyDeviceToDevice, st));
         SKX_HIP(hipStreamSynchronize(st));
         a->engine_order = true;
-    } else if (tot > 0 && std::all_of(in, in + n, [](const skx_array *x) { return x->engine_order && x->host_keys.empty() && (x->keys.p || !x->n_rows); })) {
-        // 128-bit keys of arrays this process built (batches of one `ska build`): each input's rows are a sorted list on the
-        // device, so the row set is the key-set union the build itself uses and the row indices are a device search
-        struct Sets { std::vector<skx_keyset *> v; ~Sets() { for (auto *k : v) skx_keyset_free(k); } } sets;
+    } else {
+        // 128-bit keys: the same on 2-word packed words (arrays from files keep the reference's keys on the host; they are
+        // packed on the device for the occasion)
+        std::vector<DevBuf<uint64_t>> tmp(n); std::vector<const u128 *> w(n, nullptr);
+        DevBuf<uint64_t> all, rows; SKX_TRY(all.alloc(2 * tot));
+        uint64_t o = 0;
         for (int i = 0; i < n; i++) {
             if (!in[i]->n_rows) continue;
-            skx_keyset *ks = nullptr;
-            SKX_TRY(skx_keyset_from_device(ctx, in[i]->keys.p, in[i]->n_rows, a->k, a->rc, &ks));
-            sets.v.push_back(ks);
+            SKX_TRY(array_wide_words(in[i], tmp[i], &w[i]));
+            SKX_HIP(hipMemcpyAsync(all.p + 2 * o, w[i], in[i]->n_rows * 16, hipMemcpyDeviceToDevice, st));
+            o += in[i]->n_rows;
         }
-        skx_keyset *rows = nullptr;
-        SKX_TRY(skx_keyset_merge(ctx, sets.v.data(), (int)sets.v.size(), &rows));
-        sets.v.push_back(rows);
-        if (rows->logN >= 0) SKX_TRY(keyset_flatten(rows));
-        U = rows->total;
-        for (int i = 0; i < n; i++) {
-            SKX_TRY(idx[i].alloc(in[i]->n_rows));
-            launch_lookup_rows_wide((const u128 *)in[i]->keys.p, in[i]->n_rows, (const u128 *)rows->flat.p, U, idx[i].p, st);
-        }
+        SKX_TRY(sort_unique_wide((const u128 *)all.p, tot, rows, &U, st));
+        for (int i = 0; i < n; i++) { SKX_TRY(idx[i].alloc(in[i]->n_rows)); launch_lookup_rows_wide(w[i], in[i]->n_rows, (const u128 *)rows.p, U, idx[i].p, st); }
+        SKX_TRY(a->keys.alloc(2 * U));
+        if (U) SKX_HIP(hipMemcpyAsync(a->keys.p, rows.p, U * 16, hipMemcpyDeviceToDevice, st));
         SKX_HIP(hipStreamSynchronize(st));
-        a->keys = std::move(rows->flat);
         a->engine_order = true;
-    } else {
-        // 128-bit keys of loaded arrays live on the host: the row set is a host sort, the matrix work stays on the device
-        std::vector<std::vector<skx_key>> hk(n);
-        std::vector<skx_key> all; all.reserve(tot);
-        for (int i = 0; i < n; i++) { SKX_TRY(array_host_keys(in[i], hk[i])); all.insert(all.end(), hk[i].begin(), hk[i].end()); }
-        std::sort(all.begin(), all.end(), key_less);
-        all.erase(std::unique(all.begin(), all.end(), key_eq), all.end());
-        U = all.size();
-        for (int i = 0; i < n; i++) {
-            std::vector<uint32_t> h(hk[i].size());
-            for (size_t r = 0; r < hk[i].size(); r++) h[r] = (uint32_t)(std::lower_bound(all.begin(), all.end(), hk[i][r], key_less) - all.begin());
-            SKX_TRY(idx[i].alloc(h.size()));
-            if (!h.empty()) SKX_HIP(hipMemcpyAsync(idx[i].p, h.data(), h.size() * 4, hipMemcpyHostToDevice, st));
-            SKX_HIP(hipStreamSynchronize(st));
-        }
-        a->host_keys.swap(all);
-        a->engine_order = false;
     }
     if (U > 0xFFFFFFF0ull) { set_error("too many rows"); return SKX_EUNSUP; }
     a->n_rows = a->n_kmers = U; a->pitch = pitch_for(U);
@@ -1764,18 +1758,12 @@ extern "C" int skx_array_weed(skx_array *a, skx_keyset *weed, int reverse, uint6
         launch_member_flags(idx.p, U, reverse, keep.p, st);                                                                       // merge_ska_array.rs:468
         SKX_HIP(hipStreamSynchronize(st));
     } else {
-        std::vector<uint64_t> w(2 * weed->total);
-        if (weed->total) SKX_HIP(hipMemcpy(w.data(), weed->flat.p, weed->total * 16, hipMemcpyDeviceToHost));
-        std::vector<skx_key> wk(weed->total), hk;
-        for (uint64_t i = 0; i < weed->total; i++) {
-            const u128 key = hunmix_w((((u128)w[2 * i + 1] << 64) | w[2 * i]) >> 4, weed->wh);
-            wk[i].lo = (uint64_t)key; wk[i].hi = (uint64_t)(key >> 64);
-        }
-        std::sort(wk.begin(), wk.end(), key_less);
-        SKX_TRY(array_host_keys(a, hk));
-        std::vector<uint8_t> h(U);
-        for (uint64_t r = 0; r < U; r++) { const bool found = std::binary_search(wk.begin(), wk.end(), hk[r], key_less); h[r] = (uint8_t)(reverse ? found : !found); }
-        if (U) SKX_HIP(hipMemcpy(keep.p, h.data(), U, hipMemcpyHostToDevice));
+        DevBuf<uint64_t> tmp; const u128 *w = nullptr;
+        if (U) SKX_TRY(array_wide_words(a, tmp, &w));
+        DevBuf<uint32_t> idx; SKX_TRY(idx.alloc(U));
+        launch_lookup_rows_wide(w, U, (const u128 *)weed->flat.p, weed->total, idx.p, st);
+        launch_member_flags(idx.p, U, reverse, keep.p, st);
+        SKX_HIP(hipStreamSynchronize(st));
     }
     return array_keep_rows(a, keep, removed);
     });

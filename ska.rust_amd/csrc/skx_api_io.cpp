@@ -109,20 +109,12 @@ extern "C" int skx_array_map(skx_array *a, const char *reference, int ambig_mask
         launch_map_lookup(wlo.p, flag.p, d_seq.p, L, h, skeys, sperm, a->n_rows, row.p, is_rc.p, st);
         SKX_HIP(hipStreamSynchronize(st));
     } else {
-        std::vector<skx_key> ak; SKX_TRY(array_host_keys(a, ak));
-        std::vector<uint32_t> order(ak.size()); std::iota(order.begin(), order.end(), 0u);
-        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key_less(ak[x], ak[y]); });
-        std::vector<uint32_t> hrow(L, 0xFFFFFFFFu); std::vector<uint8_t> hrc(L, 0);
-        for (uint64_t p = 0; p < L; p++) {
-            if (!hflag[p]) continue;
-            const u128 key = hunmix_w((((u128)hhi[p] << 64) | hlo[p]) >> 4, a->wh);
-            const skx_key kk{(uint64_t)key, (uint64_t)(key >> 64)};
-            auto it = std::lower_bound(order.begin(), order.end(), kk, [&](uint32_t x, const skx_key &v) { return key_less(ak[x], v); });
-            if (it != order.end() && key_eq(ak[*it], kk)) hrow[p] = *it;
-            hrc[p] = ((uint32_t)hlo[p] & 15u) == (1u << ((((uint32_t)hs.seq[p - h] >> 1) & 3u) ^ 2u));
-        }
-        SKX_HIP(hipMemcpy(row.p, hrow.data(), L * 4, hipMemcpyHostToDevice));
-        SKX_HIP(hipMemcpy(is_rc.p, hrc.data(), L, hipMemcpyHostToDevice));
+        DevBuf<uint64_t> tmp, sorted; DevBuf<uint32_t> perm; const u128 *w = nullptr;
+        if (a->n_rows) SKX_TRY(array_wide_words(a, tmp, &w));
+        const u128 *skeys = w; const uint32_t *sperm = nullptr;
+        if (!a->engine_order) { SKX_TRY(sort_wide_perm(w, a->n_rows, sorted, perm, st)); skeys = (const u128 *)sorted.p; sperm = perm.p; }
+        launch_map_lookup_wide(wlo.p, whi.p, flag.p, d_seq.p, L, h, skeys, sperm, a->n_rows, row.p, is_rc.p, st);
+        SKX_HIP(hipStreamSynchronize(st));
     }
     DevBuf<uint32_t> mapped; uint64_t M = 0;
     SKX_TRY(select_mapped(row.p, L, mapped, &M, st));

@@ -226,6 +226,9 @@ void launch_fasta_parse(const uint8_t *const *raw, const uint64_t *rawlen, uint8
 // ---- row-set operations for `ska merge` / `ska weed` / `ska delete` (skx_setops.hip)
 void launch_lookup_rows(const uint64_t *words, uint64_t n, const uint64_t *sorted, uint64_t m, uint32_t *idx, hipStream_t st);
 void launch_lookup_rows_wide(const u128 *words, uint64_t n, const u128 *sorted, uint64_t m, uint32_t *idx, hipStream_t st);
+void launch_hash_keys_wide(const u128 *keys, u128 *words, uint64_t n, const WideHash &wh, hipStream_t st);
+void launch_map_lookup_wide(const uint64_t *wlo, const uint64_t *whi, const uint8_t *flag, const uint8_t *seq, uint64_t len, int h, const u128 *sorted,
+                            const uint32_t *perm, uint64_t U, uint32_t *row, uint8_t *is_rc, hipStream_t st);
 void launch_member_flags(const uint32_t *idx, uint64_t n, int reverse, uint8_t *keep, hipStream_t st);
 void launch_scatter_rows(const uint8_t *src, uint64_t src_pitch, int n_samples, uint8_t *dst, uint64_t dst_pitch, const uint32_t *idx,
                          uint64_t n, hipStream_t st);

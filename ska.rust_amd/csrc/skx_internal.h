@@ -173,6 +173,8 @@ int cov_histogram(skx_ctx *ctx, const uint8_t *d_seq, uint64_t len, int k, int r
 int ref_windows(skx_ctx *ctx, const uint8_t *d_seq, uint64_t len, int k, int rc, DevBuf<uint64_t> &wlo, DevBuf<uint64_t> &whi, DevBuf<uint8_t> &flag);
 int select_mapped(const uint32_t *row, uint64_t len, DevBuf<uint32_t> &mapped, uint64_t *m, hipStream_t st);
 int sort_words_perm(const uint64_t *words, uint64_t n, DevBuf<uint64_t> &sorted, DevBuf<uint32_t> &perm, hipStream_t st);
+int sort_unique_wide(const u128 *in, uint64_t n, DevBuf<uint64_t> &out, uint64_t *n_out, hipStream_t st);
+int sort_wide_perm(const u128 *words, uint64_t n, DevBuf<uint64_t> &sorted, DevBuf<uint32_t> &perm, hipStream_t st);
 // sorted duplicate-free copy of packed words (skx_setops.hip)
 int sort_unique_words(const uint64_t *in, uint64_t n, DevBuf<uint64_t> &out, uint64_t *n_out, hipStream_t st);
 // .skf codec (skf_codec.cpp)
@@ -223,6 +225,7 @@ int skf_read_stream(const char *path, SkfMeta &m, std::vector<skx_key> &keys, st
 namespace skx {
 int check_k(int k);                                                  // "Invalid k-mer length" (ska_dict.rs:342-344)
 bool mappable_output_fd(int fd, off_t *pos);                         // regular file, read-write, not O_APPEND: can be written through a mapping
+int array_wide_words(skx_array *a, DevBuf<uint64_t> &tmp, const u128 **words);   // k > 31: the rows' packed 128-bit words on the device (tmp backs them for loaded arrays)
 int array_host_keys(skx_array *a, std::vector<skx_key> &hk);         // the array's split k-mers as the reference stores them, in row order
 int array_materialize(skx_array *a);                                 // a lazily held array gets its matrix (no-op otherwise)
 int array_lazy_stats(skx_array *a);                                  // a lazily held array gets its per-row statistics

@@ -4,6 +4,7 @@
 // Rows are identified by their packed word (H(key) << 4 | 1), so "same split k-mer" is one 64-bit compare and every
 // set operation is a sort / search in the order of H.  The sort and the run-length unique are rocPRIM device
 // primitives (plain library calls); the look-ups and the column scatter are hand-written below.
+#include <algorithm>
 #include <cstring>
 #include "skx_internal.h"
 #include <rocprim/rocprim.hpp>
@@ -65,6 +66,85 @@ void launch_lookup_rows_wide(const u128 *words, uint64_t n, const u128 *sorted, 
 {
     if (!n) return;
     hipLaunchKernelGGL(lookup_rows_wide_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, words, n, sorted, m, idx);
+}
+
+// 128-bit row keys of arrays that came from files or from the caller (stored as the reference stores them) -> packed words
+__global__ __launch_bounds__(256) void hash_keys_wide_kernel(const u128 *keys, u128 *words, uint64_t n, WideHash wh)
+{
+    for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256ull) words[i] = (hmix_w(keys[i], wh) << 4) | (u128)1;
+}
+void launch_hash_keys_wide(const u128 *keys, u128 *words, uint64_t n, const WideHash &wh, hipStream_t st)
+{
+    if (!n) return;
+    const unsigned g = (unsigned)std::min<uint64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(hash_keys_wide_kernel, dim3(g), dim3(256), 0, st, keys, words, n, wh);
+}
+struct same_key_bits { __host__ __device__ bool operator()(const u128 &a, const u128 &b) const { return (a >> 4) == (b >> 4); } };
+// sort_unique_words for 128-bit words (out holds 2 x u64 per word)
+int sort_unique_wide(const u128 *in, uint64_t n, DevBuf<uint64_t> &out, uint64_t *n_out, hipStream_t st)
+{
+    *n_out = 0;
+    if (!n) return SKX_OK;
+    if (n > 0x7FFFFFFFull) return SKX_EUNSUP;
+    DevBuf<uint64_t> sorted; DevBuf<unsigned char> tmp; DevBuf<unsigned int> d_cnt;
+    SKX_TRY(sorted.alloc(2 * n)); SKX_TRY(out.alloc(2 * n)); SKX_TRY(d_cnt.alloc(1));
+    size_t bytes = 0;
+    RPS(rocprim::radix_sort_keys(nullptr, bytes, in, (u128 *)sorted.p, (unsigned int)n, 0, 128, st));
+    SKX_TRY(tmp.alloc(bytes ? bytes : 1));
+    RPS(rocprim::radix_sort_keys(tmp.p, bytes, in, (u128 *)sorted.p, (unsigned int)n, 0, 128, st));
+    size_t bytes2 = 0;
+    RPS(rocprim::unique(nullptr, bytes2, (const u128 *)sorted.p, (u128 *)out.p, d_cnt.p, (unsigned int)n, same_key_bits(), st));
+    DevBuf<unsigned char> tmp2; SKX_TRY(tmp2.alloc(bytes2 ? bytes2 : 1));
+    RPS(rocprim::unique(tmp2.p, bytes2, (const u128 *)sorted.p, (u128 *)out.p, d_cnt.p, (unsigned int)n, same_key_bits(), st));
+    unsigned int cnt = 0;
+    RPS(hipMemcpyAsync(&cnt, d_cnt.p, 4, hipMemcpyDeviceToHost, st));
+    RPS(hipStreamSynchronize(st));
+    *n_out = cnt;
+    return SKX_OK;
+}
+__global__ __launch_bounds__(256) void iota_rows_kernel(uint32_t *v, uint64_t n)
+{
+    const uint64_t i = blockIdx.x * 256ull + threadIdx.x;
+    if (i < n) v[i] = (uint32_t)i;
+}
+// sort_words_perm for 128-bit words: sorted copy + the row each sorted word came from
+int sort_wide_perm(const u128 *words, uint64_t n, DevBuf<uint64_t> &sorted, DevBuf<uint32_t> &perm, hipStream_t st)
+{
+    DevBuf<uint32_t> iota; DevBuf<unsigned char> tmp;
+    SKX_TRY(sorted.alloc(2 * n)); SKX_TRY(perm.alloc(n)); SKX_TRY(iota.alloc(n));
+    if (!n) return SKX_OK;
+    if (n > 0x7FFFFFFFull) return SKX_EUNSUP;
+    hipLaunchKernelGGL(iota_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, iota.p, n);
+    size_t bytes = 0;
+    RPS(rocprim::radix_sort_pairs(nullptr, bytes, words, (u128 *)sorted.p, iota.p, perm.p, (unsigned int)n, 0, 128, st));
+    SKX_TRY(tmp.alloc(bytes ? bytes : 1));
+    RPS(rocprim::radix_sort_pairs(tmp.p, bytes, words, (u128 *)sorted.p, iota.p, perm.p, (unsigned int)n, 0, 128, st));
+    RPS(hipStreamSynchronize(st));
+    return SKX_OK;
+}
+// map_lookup for 128-bit words: the window words arrive as two 64-bit halves
+__global__ __launch_bounds__(256) void map_lookup_wide_kernel(const uint64_t *wlo, const uint64_t *whi, const uint8_t *flag, const uint8_t *seq, uint64_t len,
+                                                             int h, const u128 *sorted, const uint32_t *perm, uint64_t U, uint32_t *row, uint8_t *is_rc)
+{
+    const uint64_t p = blockIdx.x * 256ull + threadIdx.x;
+    if (p >= len) return;
+    uint32_t r = 0xFFFFFFFFu; uint8_t rcf = 0;
+    if (flag[p]) {
+        const uint64_t w = wlo[p];
+        const u128 key = (((u128)whi[p] << 64) | w) >> 4;
+        uint64_t lo = 0, hi = U;
+        while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if ((sorted[mid] >> 4) < key) lo = mid + 1; else hi = mid; }
+        if (lo < U && (sorted[lo] >> 4) == key) r = perm ? perm[lo] : (uint32_t)lo;
+        const uint32_t mid_code = (seq[p - h] >> 1) & 3u;
+        rcf = ((uint32_t)w & 15u) == (1u << (mid_code ^ 2u));
+    }
+    row[p] = r; is_rc[p] = rcf;
+}
+void launch_map_lookup_wide(const uint64_t *wlo, const uint64_t *whi, const uint8_t *flag, const uint8_t *seq, uint64_t len, int h, const u128 *sorted,
+                            const uint32_t *perm, uint64_t U, uint32_t *row, uint8_t *is_rc, hipStream_t st)
+{
+    if (!len) return;
+    hipLaunchKernelGGL(map_lookup_wide_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, wlo, whi, flag, seq, len, h, sorted, perm, U, row, is_rc);
 }
 
 // weed: keep[i] = 1 when the row survives ((!reverse && !found) || (reverse && found), merge_ska_array.rs:468), else 0
