@@ -72,14 +72,15 @@ def private_snps(n_total):
     return 500 if n_total <= 1000 else 100
 
 
-def other_kernels(tm, steps, n_bases, n_distinct, rows, rows_kept, n_samples):
-    """HBM rate of the remaining stages against SURVEY.md 8d's algorithmic bytes (W + 1 = 9 B per dictionary entry,
-    P ~ N windows, D = sum of distinct split k-mers per sample, U rows, U' rows kept)."""
+def other_kernels(tm, steps, n_bases, n_distinct, rows, rows_kept, n_samples, key_bytes=8):
+    """HBM rate of the remaining stages against SURVEY.md 8d's algorithmic bytes (W + 1 = 9 B per dictionary entry -- 17 B for
+    k > 31 --, P ~ N windows, D = sum of distinct split k-mers per sample, U rows, U' rows kept)."""
     out = []
+    w1 = key_bytes + 1.0
     for name, ms, nbytes in (
-            ("per-sample dedup (dedupe_mb_kernel)", tm["dedupe"] / steps, 9.0 * (n_bases + n_distinct)),
-            ("merge (union_kernel + assemble_kernel)", (tm["key_union"] + tm["assemble"]) / steps, 9.0 * n_distinct + rows * (8.0 + n_samples)),
-            ("filter + compaction", (tm["filter"] + tm["compact"]) / steps, rows * (8.0 + n_samples) + rows_kept * float(n_samples))):
+            ("per-sample dedup (dedupe_mb_kernel)", tm["dedupe"] / steps, w1 * (n_bases + n_distinct)),
+            ("merge (union_kernel + assemble_kernel)", (tm["key_union"] + tm["assemble"]) / steps, w1 * n_distinct + rows * (float(key_bytes) + n_samples)),
+            ("filter + compaction", (tm["filter"] + tm["compact"]) / steps, rows * (float(key_bytes) + n_samples) + rows_kept * float(n_samples))):
         gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         out.append({"stage": name, "ms": ms, "algorithmic_bytes": nbytes, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
     return out
@@ -403,29 +404,31 @@ def main():
     if rank == 0:
         steps = max(args.steps, 1)
         scatter_ms = tm["scatter"] / steps
-        algo_bytes = 10.0 * total_bases
+        key_bytes = 8 if args.k <= 31 else 16                      # 1 B read + (W + 1) B written per base, W = 8 | 16
+        algo_bytes = (2.0 + key_bytes) * total_bases
         achieved = algo_bytes / (scatter_ms * 1e-3) / 1e9 if scatter_ms > 0 else 0.0
         traffic = None       # HBM bytes per launch from the PMC passes recorded in profiles/ (FETCH_SIZE x2 + WRITE_SIZE), scaled per base
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_extract.json")))
-            traffic = (pmc["read_bytes_per_base"] + pmc["write_bytes_per_base"]) * total_bases
+            if args.k <= 31:
+                traffic = (pmc["read_bytes_per_base"] + pmc["write_bytes_per_base"]) * total_bases
         except Exception:
             pass
         res = {
-            "metric": "genomes/sec ska build+align, 1 000x5 Mbp k=31; bit-exact vs CPU",
+            "metric": "genomes/sec ska build+align, 1 000x5 Mbp k=31; bit-exact vs CPU" if args.k == 31 else f"genomes/sec ska build+align, k={args.k}; bit-exact vs CPU",
             "value": n_total * steps / dt, "unit": "genomes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64", "data": "synthetic",
+            "dtype": "u64" if args.k <= 31 else "u128", "data": "synthetic",
             "config": {"workload": f"ska build + ska align, {G} synthetic {args.genome_len} bp assemblies per GPU, k={args.k}, "
                                    f"inputs resident in HBM (BASELINE.json configs[2])",
                        "samples_per_gpu": G, "private_snps": private_snps(n_total), "genome_len": args.genome_len, "k": args.k,
                        "rows_U": shape[0], "rows_kept": shape[1], "parallelism": f"samples sharded x{world}" + (" (key-table all-gather path)" if sharded else "")},
-            "roofline": {"bound": "hbm", "kernel": "extract_kernel<true> (split k-mer extraction + bucket scatter)",
+            "roofline": {"bound": "hbm", "kernel": ("extract_kernel<true>" if args.k <= 31 else "extract_wide_kernel<true>") + " (split k-mer extraction + bucket scatter)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": scatter_ms},
             "kernel_pipeline": {"genomes_per_s": n_total * steps / dt, "what": "= value: extraction -> dictionaries -> merge -> filter with the record streams resident in HBM"},
             "stage_ms_per_step": {k: v / steps for k, v in tm.items()},
-            "other_kernels": other_kernels(tm, steps, total_bases, n_distinct, shape[0], shape[1], G),
+            "other_kernels": other_kernels(tm, steps, total_bases, n_distinct, shape[0], shape[1], G, key_bytes),
             "host_wall_ms_per_step": {k: v / steps for k, v in host_ms.items()},
         }
         if distance_stage:
