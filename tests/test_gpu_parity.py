@@ -116,6 +116,27 @@ def test_merge_array(E, k, rc):
     assert list(ga.sample_kmers()) == [int(x) for x in (oa.export()[1] != ord("-")).sum(axis=0)]
 
 
+@pytest.mark.parametrize("k,rc", [(31, True), (41, True), (63, False)])
+def test_merge_array_many_samples(E, k, rc):
+    """More samples than a wave deals with at once (70 > 64), several sub-buckets per bucket and slices longer than one batch of
+    look-ups: the union / assemble kernels' sample loops, batched probes and insert paths, 64- and 128-bit, against the oracle."""
+    rng = np.random.default_rng(1000 + k)
+    anc = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=120_000)
+    samples = []
+    for i in range(70):
+        s = anc.copy()
+        pos = rng.integers(0, len(s), size=40)
+        s[pos] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=40)
+        recs = [bytes(s[:70_000]), bytes(s[70_000:])]
+        if i % 7 == 3:
+            recs.append(bytes(s[1000:1400]))                       # a repeat: ambiguity codes where the copies differ from nothing, counts unchanged
+        samples.append(recs)
+    ga, oa = build_both(E, samples, k, rc)
+    assert ga.names == oa.names and ga.nkmers == oa.nkmers
+    assert as_map(*ga.export()) == as_map(*oa.export())
+    assert list(ga.sample_kmers()) == [int(x) for x in (oa.export()[1] != ord("-")).sum(axis=0)]
+
+
 FILTERS = [(ft, amb, mask, gaps) for ft in range(4) for amb in (False, True) for mask in (False, True) for gaps in (False, True)]
 
 
