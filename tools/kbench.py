@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Kernel micro-benchmark: dictionary build (extract+scatter, dedupe) on random genomes generated on the GPU.
-usage: kbench.py [n_genomes] [genome_len] [reps]"""
+usage: kbench.py [n_genomes] [genome_len] [reps] [k]"""
 import os
 import sys
 
@@ -13,6 +13,7 @@ import skx_engine as E  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 glen = int(sys.argv[2]) if len(sys.argv) > 2 else 5_000_000
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+K = int(sys.argv[4]) if len(sys.argv) > 4 else 31
 E.load_library()
 ctx = E.Context(0)
 dev = torch.device("cuda", 0)
@@ -29,7 +30,7 @@ for r in range(reps + 1):
     if r == 1:
         ctx.timings(reset=True)
     try:
-        ds = E.DictSet.build_device(ptrs, lens, 31, True, ctx=ctx)
+        ds = E.DictSet.build_device(ptrs, lens, K, True, ctx=ctx)
         ds.free()
     except E.EngineError as e:
         print("engine error (expected in debug modes):", str(e)[:80])
