@@ -9,6 +9,7 @@
 #include <condition_variable>
 #include <deque>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <map>

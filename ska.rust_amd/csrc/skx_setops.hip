@@ -11,14 +11,14 @@
 
 namespace skx {
 
-#define RPS(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return SKX_ENODEV; } while (0)
+#define RPS(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s: %s", #x, hipGetErrorString(e_)); return SKX_ENODEV; } } while (0)
 
 // sorted, duplicate-free copy of `n` packed words (any order, duplicates allowed) -> out[0 .. *n_out)
 int sort_unique_words(const uint64_t *in, uint64_t n, DevBuf<uint64_t> &out, uint64_t *n_out, hipStream_t st)
 {
     *n_out = 0;
     if (!n) return SKX_OK;
-    if (n > 0x7FFFFFFFull) return SKX_EUNSUP;
+    if (n > 0x7FFFFFFFull) { set_error("more than 2^31 rows in one row-set operation"); return SKX_EUNSUP; }
     DevBuf<uint64_t> sorted; DevBuf<unsigned char> tmp; DevBuf<unsigned int> d_cnt;
     SKX_TRY(sorted.alloc(n)); SKX_TRY(out.alloc(n)); SKX_TRY(d_cnt.alloc(1));
     size_t bytes = 0;
@@ -85,7 +85,7 @@ int sort_unique_wide(const u128 *in, uint64_t n, DevBuf<uint64_t> &out, uint64_t
 {
     *n_out = 0;
     if (!n) return SKX_OK;
-    if (n > 0x7FFFFFFFull) return SKX_EUNSUP;
+    if (n > 0x7FFFFFFFull) { set_error("more than 2^31 rows in one row-set operation"); return SKX_EUNSUP; }
     DevBuf<uint64_t> sorted; DevBuf<unsigned char> tmp; DevBuf<unsigned int> d_cnt;
     SKX_TRY(sorted.alloc(2 * n)); SKX_TRY(out.alloc(2 * n)); SKX_TRY(d_cnt.alloc(1));
     size_t bytes = 0;
@@ -113,7 +113,7 @@ int sort_wide_perm(const u128 *words, uint64_t n, DevBuf<uint64_t> &sorted, DevB
     DevBuf<uint32_t> iota; DevBuf<unsigned char> tmp;
     SKX_TRY(sorted.alloc(2 * n)); SKX_TRY(perm.alloc(n)); SKX_TRY(iota.alloc(n));
     if (!n) return SKX_OK;
-    if (n > 0x7FFFFFFFull) return SKX_EUNSUP;
+    if (n > 0x7FFFFFFFull) { set_error("more than 2^31 rows in one row-set operation"); return SKX_EUNSUP; }
     hipLaunchKernelGGL(iota_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, iota.p, n);
     size_t bytes = 0;
     RPS(rocprim::radix_sort_pairs(nullptr, bytes, words, (u128 *)sorted.p, iota.p, perm.p, (unsigned int)n, 0, 128, st));
