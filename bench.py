@@ -272,6 +272,7 @@ def main():
         raise SystemExit("bench.py needs a gfx950 GPU: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = None
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -287,6 +288,7 @@ def main():
     import skx_engine as E
     E.load_library()
     ctx = E.Context(local_rank)
+    comm = skdist.make_comm(ctx, rank, world, transport="rccl" if backend == "nccl" else "local") if sharded else None
     pool = torch.empty(tot + 256, dtype=torch.uint8, device=dev)
     for i, s in enumerate(streams):
         pool[offs[i]:offs[i] + lens[i]] = torch.from_numpy(s).to(dev, non_blocking=False)
@@ -299,7 +301,7 @@ def main():
     torch.cuda.synchronize()
 
     host_ms = {"build": 0.0, "merge": 0.0, "align": 0.0, "free": 0.0}
-    xch = {"key_table_allgather_s": 0.0, "key_table_allgather_bytes_per_rank": 0, "row_stats_s": 0.0, "row_stats_bytes_per_rank": 0}     # sharded runs: the exchanges
+    xch = {"key_table_exchange_s": 0.0, "row_stats_s": 0.0, "row_stats_bytes_per_rank": 0}     # sharded runs: the exchanges
 
     def step():
         t_a = time.perf_counter()
@@ -310,27 +312,21 @@ def main():
         if not sharded:
             arr = ds.merge(names)
         else:
+            # the exchanges are the engine's (include/skx.h "Collectives": RCCL on the engine's stream)
             ks = ds.union_keys()
-            p, n, wpk = ks.device()                  # wpk 64-bit words per key (2 for k > 31)
             ctx.sync()
             t_x = time.perf_counter()
-            tables = skdist.allgather_tables(skdist.as_tensor(p, n * wpk, "<i8", dev))
-            torch.cuda.synchronize()
-            xch["key_table_allgather_s"] += time.perf_counter() - t_x
-            xch["key_table_allgather_bytes_per_rank"] = int(sum(t.numel() for t in tables) * 8)
-            sets = [E.KeySet.from_device(t.data_ptr(), t.numel() // wpk, args.k, True, ctx=ctx) for t in tables]
-            rows = E.KeySet.merge(sets, ctx=ctx)
+            rows = comm.keyset_allgather(ks)         # one all-gather of the per-rank key tables + their union: the global rows
+            ctx.sync()
+            xch["key_table_exchange_s"] += time.perf_counter() - t_x
+            ks.free()
             arr = ds.assemble(rows, names)
-            pp, pu, pm, pv = arr.device_stats()
-            U = arr.nrows
-            tp, tu, tm = (skdist.as_tensor(x, U, "<i4", dev) for x in (pp, pu, pm))
+            ctx.sync()
             t_x = time.perf_counter()
-            skdist.reduce_row_stats(tp, tu, tm, total_samples=n_total)
-            skdist.as_tensor(pv, U, "<i4", dev).copy_(tp)
-            torch.cuda.synchronize()
+            comm.reduce_stats(arr, n_total)          # counts in one all-reduce, code sets all-gathered and OR-ed
+            ctx.sync()
             xch["row_stats_s"] += time.perf_counter() - t_x
-            xch["row_stats_bytes_per_rank"] = int(U * (4 + 2 * world))
-            arr.set_total_samples(n_total)
+            xch["row_stats_bytes_per_rank"] = int(arr.nrows * (4 + 2 * world))
         ctx.sync()
         t_c = time.perf_counter()
         host_ms["merge"] += (t_c - t_b) * 1e3
@@ -350,7 +346,8 @@ def main():
     ctx.timings(reset=True)
     for kk in host_ms:
         host_ms[kk] = 0.0
-    xch["key_table_allgather_s"] = xch["row_stats_s"] = 0.0
+    xch["key_table_exchange_s"] = xch["row_stats_s"] = 0.0
+    E.phases(reset=True)
     if sharded:
         dist.barrier()
     torch.cuda.synchronize()
@@ -434,9 +431,14 @@ def main():
         if distance_stage:
             res["distance"] = distance_stage
         if sharded:
-            res["exchange_per_step_rank0"] = {"key_table_allgather_ms": xch["key_table_allgather_s"] / steps * 1e3, "key_table_allgather_bytes": xch["key_table_allgather_bytes_per_rank"],
+            ph = E.phases()
+            res["exchange_per_step_rank0"] = {"transport": "rccl" if backend == "nccl" else "local (host-staged: ranks sharing a device)",
+                                              "key_table_exchange_ms": xch["key_table_exchange_s"] / steps * 1e3,
+                                              "key_table_allgather_ms": ph.get("comm.key_table_allgather", 0.0) / steps * 1e3,
                                               "row_stats_ms": xch["row_stats_s"] / steps * 1e3, "row_stats_bytes": xch["row_stats_bytes_per_rank"],
-                                              "what": "one all-gather of the per-rank key tables + the reduction of the per-row filter statistics; nothing else crosses xGMI"}
+                                              "bytes_received_per_step": comm.bytes_received / (steps + args.warmup),
+                                              "what": "skx_keyset_allgather (one ncclAllGather of the per-rank key tables, then their union) + skx_array_reduce_stats "
+                                                      "(one ncclAllReduce + one ncclAllGather of the per-row filter statistics), issued by the engine; nothing else crosses xGMI"}
         res["roofline"]["traffic_source"] = "profiles/pmc_extract.json: FETCH_SIZE x 2 + WRITE_SIZE of a separate --pmc run of this kernel, scaled per base (not measured in this run)"
         if world == 1:
             # the legs below run outside the timed region; the bench's own device buffers go first (the ska executable gets the GPU)

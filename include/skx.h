@@ -189,6 +189,53 @@ int  skx_planes_distance(skx_ctx *ctx, const void *planes, int n_samples, uint64
                          int i_lo, int i_hi, skx_dist *out);
 void skx_free(void *p);
 
+/* ------------------------------------------------------------------------------------------
+ * Collectives: the exchanges of a job whose samples are sharded over the GPUs of a node, one process per
+ * GPU.  They stand where the reference's build_and_merge joins the dictionaries of its worker threads (merge_ska_dict.rs:354-417:
+ * samples dealt to threads in input order, per-thread dictionaries merged pairwise) -- here the "threads" are ranks, each rank keeps
+ * the columns of its own samples, and what is exchanged is the row set (one all-gather of the per-rank key tables), the per-row
+ * filter statistics, and for `ska distance` the bit planes.  Transport: RCCL over xGMI on the context's stream
+ * (skx_comm_create; librccl is opened at run time), or a host-staged exchange through a directory on tmpfs for ranks that share one
+ * device, which RCCL refuses (skx_comm_create_local; tests and single-GPU emulation of an N-rank job).  The host launches the
+ * processes and carries the 128-byte id from rank 0 to the others (a file, an environment variable, MPI, a torch store ...).
+ * Every call below is collective: all ranks of the communicator make it, in the same order.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct skx_comm skx_comm;
+#define SKX_COMM_ID_BYTES 128
+int  skx_comm_unique_id(uint8_t id[SKX_COMM_ID_BYTES]);                        /* ncclGetUniqueId; rank 0 only */
+int  skx_comm_create(skx_ctx *ctx, int rank, int world, const uint8_t id[SKX_COMM_ID_BYTES], skx_comm **out);   /* ncclCommInitRank on ctx's device */
+/* host-staged transport: `dir` is a fresh directory every rank can reach; ctx may be NULL when only host buffers are exchanged */
+int  skx_comm_create_local(skx_ctx *ctx, int rank, int world, const char *dir, skx_comm **out);
+void skx_comm_destroy(skx_comm *c);
+int  skx_comm_rank(const skx_comm *c);
+int  skx_comm_world(const skx_comm *c);
+uint64_t skx_comm_bytes_received(const skx_comm *c);                           /* payload this rank has received so far (reports) */
+int  skx_comm_barrier(skx_comm *c);
+/* the two primitives the exchanges are made of, for hosts with exchanges of their own: `bytes` from every rank, rank r's at
+ * recv + r * bytes (recv must not overlap send); in-place sum of n 32-bit counters.  on_device: the pointers are device memory
+ * (required by the RCCL transport). */
+int  skx_comm_allgather(skx_comm *c, const void *send, void *recv, uint64_t bytes, int on_device);
+int  skx_comm_allreduce_u32(skx_comm *c, uint32_t *buf, uint64_t n, int on_device);
+/* host blocks of different sizes (sizes[world], known to every rank) to rank 0: recv there = the blocks in rank order */
+int  skx_comm_gather_root(skx_comm *c, const void *send, const uint64_t *sizes, void *recv);
+/* partitioning, pure arithmetic: the contiguous shard [lo, hi) of `rank` (input order kept, so names stay in CLI order, cf. the
+ * offsets of merge_ska_dict.rs:243-253,277-291), and the bands of first samples of the pair matrix (lo_hi[2 r], lo_hi[2 r + 1];
+ * starts on multiples of `align`, about the same number of pairs each, merge_ska_array.rs:416-438 order kept) */
+int  skx_shard_range(uint64_t n_items, int rank, int world, uint64_t *lo, uint64_t *hi);
+int  skx_pair_bands(int n_samples, int world, int align, int *lo_hi);
+/* exchange 1: one all-gather of the per-rank key tables (padded to the longest) + their union: every rank gets the same global
+ * row set, which skx_array_assemble / skx_array_assemble_lazy then fills with the rank's own columns.  SKX_EINVAL with the
+ * reference's "K-mer lengths do not match" / "Strand use inconsistent" when ranks disagree. */
+int  skx_keyset_allgather(skx_comm *c, skx_keyset *local, skx_keyset **rows);
+/* exchange 2: the per-row statistics the filter reads, over all ranks (counts summed in one all-reduce, 16-bit code sets
+ * all-gathered and OR-ed); variant_count becomes the global count, the array's total_samples the job's sample count */
+int  skx_array_reduce_stats(skx_comm *c, skx_array *a, uint64_t total_samples);
+/* exchange 3: MergeSkaArray::distance (merge_ska_array.rs:416-438,587-632) for a sharded job: `a` = this rank's samples over the
+ * globally filtered rows; one all-gather of the bit planes, each rank finishes a band of the pair matrix, rank 0 receives all
+ * pairs: out[n_out], n_out >= S (S - 1) / 2 there (ignored elsewhere) */
+int  skx_array_distance_sharded(skx_comm *c, skx_array *a, int filt_ambig, double constant, skx_dist *out, uint64_t n_out);
+
+
 /* ---- .skf life-cycle: `ska merge`, `ska delete`, `ska weed` ---- */
 /* generic_modes::merge (generic_modes.rs:90-106) = MergeSkaArray::to_dict (merge_ska_array.rs:208-222) +
  * MergeSkaDict::extend (merge_ska_dict.rs:160-193) folded over the inputs + MergeSkaArray::new (:166-186): rows = union of

@@ -51,7 +51,35 @@ int skh_cov(skx_ctx *ctx, const char *fastq_fwd, const char *fastq_rev, int k, i
 int skh_cov_fit(const double *counts, uint64_t n, double *w0, double *c, uint64_t *cutoff);
 /* io_utils::read_input_fastas sample-name rule (io_utils.rs:31-46) */
 char *skh_sample_name(const char *path);
-/* the `ska` command line (build | align | map | distance | nk | merge | delete | weed | cov); returns the process exit code */
+/* ---- the same modes over the GPUs of one node, one process per GPU; each function is the body of ONE rank
+ * and is collective over `comm` (include/skx.h "Collectives").  The job's samples (all of them, in input order) are dealt to the
+ * ranks in contiguous shards; a rank builds the dictionaries of its shard (skx_dictset_build_files), the key tables are all-gathered
+ * (skx_keyset_allgather) and the rank holds its own columns over the global rows (skx_array_assemble_lazy).  This is what
+ * build_and_merge's thread tree becomes when the workers are GPUs (merge_ska_dict.rs:354-417). */
+typedef struct {
+    const char *const *names, *const *file1, *const *file2;   /* the whole job; file2[i] may be NULL (file2 itself too) */
+    int n_samples;
+    int k, rc;
+    skx_qual qual;
+    int threads;
+    double proportion_reads;                                   /* 0 == None */
+    const char *output;                                        /* build: prefix of the .skf; align / distance: the file (NULL = stdout, rank 0) */
+    int merge_parts;                                           /* build: rank 0 joins the per-rank parts into <output>.skf */
+    double min_freq;
+    int filter_type, mask_ambig, ignore_const_gaps, filter_ambig_as_missing;    /* align (generic_modes.rs:112-131) */
+    int filt_ambig;                                            /* distance: !--allow-ambiguous */
+} skh_job;
+/* `ska build`: one .skf per rank, <output>.part<r>of<N>.skf = the global rows x that rank's samples (each a valid MergeSkaArray;
+ * `ska merge` joins them), or with merge_parts the one file generic_modes::save_skf would write */
+int skh_build_sharded(skx_ctx *ctx, skx_comm *comm, const skh_job *job);
+/* `ska align`: row statistics reduced over ranks, the filter decided identically everywhere, every rank writes its own samples'
+ * records at their offsets of the one output file (write_fasta's order, merge_ska_array.rs:499-517) */
+int skh_align_sharded(skx_ctx *ctx, skx_comm *comm, const skh_job *job);
+/* `ska distance`: generic_modes::distance's two filters on the reduced statistics, then skx_array_distance_sharded; rank 0 writes the table */
+int skh_distance_sharded(skx_ctx *ctx, skx_comm *comm, const skh_job *job);
+/* the `ska` command line (build | align | map | distance | nk | merge | delete | weed | cov); returns the process exit code.
+ * `--gpus N` on build / align / distance starts one process per GPU (this executable again, SKX_RANK / SKX_WORLD / SKX_COMM_ID_FILE in
+ * their environment) and runs the sharded bodies above; a launcher of one's own sets the same variables. */
 int skh_main(int argc, char **argv);
 
 #ifdef __cplusplus

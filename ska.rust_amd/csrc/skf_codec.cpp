@@ -318,6 +318,7 @@ struct FrameReader {
         return true;
     }
     const char *err = nullptr;
+    bool too_many = false;                          // the asynchronous walk ran out of reserved directory entries (not a format error)
 
     bool walk()                                     // the file's chunk directory; publishes as it goes
     {
@@ -335,7 +336,9 @@ struct FrameReader {
                 c.ulen = c.compressed ? snappy_ulen(&raw[c.off], c.len, nullptr) : (uint32_t)c.len;
                 if (c.ulen == 0xFFFFFFFFu || c.ulen > CHUNK) { err = "skf: corrupt snappy block"; return false; }
                 c.uoff = tot; tot += c.ulen;
-                if (cap && chunks.size() == cap) { err = "skf: more chunks than reserved"; return false; }       // asynchronous walk: entries must not move
+                // asynchronous walk: entries must not move.  A valid file with smaller chunks than this writer's (another snappy framer,
+                // flushed writes) can have more of them than were reserved: the streaming load hands such a file to the general reader
+                if (cap && chunks.size() == cap) { err = "skf: more chunks than reserved"; too_many = true; return false; }
                 chunks.push_back(c);
                 if ((chunks.size() & 255u) == 0) n_pub.store(chunks.size(), std::memory_order_release);
             } else if (type < 0x80) { err = "skf: unsupported chunk type"; return false; }
@@ -614,7 +617,7 @@ int SkfFile::walk_result()
 {
     FrameReader &fr = impl->fr;
     while (fr.walking()) usleep(50);
-    if (fr.walk_state.load() == 2) { set_error("%s", fr.err ? fr.err : "skf: read failed"); return SKX_EFORMAT; }
+    if (fr.walk_state.load() == 2) { if (fr.too_many) return SKF_NOT_TAKEN; set_error("%s", fr.err ? fr.err : "skf: read failed"); return SKX_EFORMAT; }
     if (upos_data + 2 * m.n_rows * (uint64_t)m.names.size() > fr.total_ulen) { set_error("skf: truncated frame"); return SKX_EFORMAT; }
     return SKX_OK;
 }

@@ -146,7 +146,8 @@ skx::Preallocator::Preallocator(int fd_, off_t base_) : fd(fd_), base(base_)
             if (stop && done >= target) return;
             const uint64_t o = done, n = std::min(STEP, target - done);
             lk.unlock();
-            (void)posix_fallocate(fd, base + (off_t)o, (off_t)n);          // on failure the writer's page faults do the allocation
+            // a failure (ENOSPC, quota) is recorded: a writer that stores through a mapping of pages that do not exist dies of SIGBUS
+            if (posix_fallocate(fd, base + (off_t)o, (off_t)n) != 0) failed.store(true, std::memory_order_release);
             lk.lock();
             done = o + n;
             cv.notify_all();
@@ -550,8 +551,14 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
     if (device_parse) {
         uint64_t tot = 0;
         for (int i = 0; i < n; i++) {
-            struct stat sb;
-            if ((file2 && file2[i]) || stat(file1[i], &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 1) continue;
+            struct stat sb; unsigned char c0 = 0;
+            if (file2 && file2[i]) continue;
+            // only plain FASTA text is parsed on the device: a FASTQ or gzip sample reserves nothing here (raw_upload would refuse it and
+            // its two slots would stay allocated, uncounted by the batch planner)
+            const int fd = ::open(file1[i], O_RDONLY);
+            const bool fasta = fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size >= 1 && ::read(fd, &c0, 1) == 1 && c0 == '>';
+            if (fd >= 0) ::close(fd);
+            if (!fasta) continue;
             slot_off[i] = tot; slot_len[i] = ((uint64_t)sb.st_size + 64 + 255) & ~255ull;
             tot += slot_len[i];
         }
@@ -953,7 +960,7 @@ extern "C" int skx_keyset_union(skx_ctx *ctx, skx_dictset *d, skx_keyset **out)
     });
 }
 
-static int keyset_flatten(skx_keyset *ks)
+int skx::keyset_flatten(skx_keyset *ks)
 {
     if (ks->flat.p) return SKX_OK;
     SKX_TRY(ks->flat.alloc(ks->total * ks->wpk()));
@@ -996,37 +1003,49 @@ extern "C" int skx_keyset_from_device(skx_ctx *ctx, const void *dptr, uint64_t n
     });
 }
 
-// union of several keysets: each flat list is a "sample" of a synthetic one-bucket dict
+// union of several sorted key tables lying in one device buffer: table i = n[i] keys at words + off[i] * wpk (off in keys); each
+// table is a "sample" of a synthetic one-bucket dict
+int skx::keyset_union_tables(skx_ctx *ctx, const uint64_t *words, const std::vector<uint64_t> &h_off, const std::vector<uint32_t> &h_cnt, int k, int rc,
+                             skx_keyset **out)
+{
+    hipStream_t st = ctx->stream;
+    const int n_sets = (int)h_cnt.size();
+    StageTimer t(ctx, &ctx->tm.key_union);
+    uint64_t total = 0, maxn = 0;
+    for (int i = 0; i < n_sets; i++) { total += h_cnt[i]; maxn = std::max<uint64_t>(maxn, h_cnt[i]); }
+    DevBuf<uint64_t> off; DevBuf<uint32_t> ucnt;
+    SKX_TRY(off.alloc(n_sets + 1)); SKX_TRY(ucnt.alloc(n_sets));
+    SKX_HIP(hipMemcpyAsync(off.p, h_off.data(), (n_sets + 1) * 8, hipMemcpyHostToDevice, st));
+    SKX_HIP(hipMemcpyAsync(ucnt.p, h_cnt.data(), n_sets * 4, hipMemcpyHostToDevice, st));
+    DictView v{words, off.p, ucnt.p, n_sets, 0, 2 * (k - 1)};
+    int r = keyset_union_views(ctx, &v, 1, k, rc, make_hash_params(std::min(k, 31)), std::min(total, maxn * 2), out);
+    SKX_HIP(hipStreamSynchronize(st));
+    return r;
+}
+
 extern "C" int skx_keyset_merge(skx_ctx *ctx, skx_keyset *const *sets, int n_sets, skx_keyset **out)
 {
     return skx_guarded([&]() -> int {
     if (!ctx || !sets || n_sets <= 0 || !out) { set_error("bad arguments"); return SKX_EINVAL; }
     SKX_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    StageTimer t(ctx, &ctx->tm.key_union);
-    uint64_t total = 0, maxn = 0;
+    uint64_t total = 0;
     for (int i = 0; i < n_sets; i++) {
         if (sets[i]->k != sets[0]->k) { set_error("K-mer lengths do not match: %d %d", sets[i]->k, sets[0]->k); return SKX_EINVAL; }
         if (sets[i]->rc != sets[0]->rc) { set_error("Strand use inconsistent"); return SKX_EINVAL; }
         if (sets[i]->logN >= 0) SKX_TRY(keyset_flatten(sets[i]));
-        total += sets[i]->total; maxn = std::max(maxn, sets[i]->total);
+        total += sets[i]->total;
     }
-    DevBuf<uint64_t> words, off; DevBuf<uint32_t> ucnt;
+    DevBuf<uint64_t> words;
     const int wpk = sets[0]->wpk();
-    SKX_TRY(words.alloc(total * wpk)); SKX_TRY(off.alloc(n_sets + 1)); SKX_TRY(ucnt.alloc(n_sets));
+    SKX_TRY(words.alloc(total * wpk));
     std::vector<uint64_t> h_off(n_sets + 1, 0); std::vector<uint32_t> h_cnt(n_sets);
     for (int i = 0; i < n_sets; i++) {
         if (sets[i]->total > 0xFFFFFFFFull) { set_error("keyset too large"); return SKX_EUNSUP; }
         h_cnt[i] = (uint32_t)sets[i]->total; h_off[i + 1] = h_off[i] + sets[i]->total;
         SKX_HIP(hipMemcpyAsync(words.p + h_off[i] * wpk, sets[i]->flat.p, sets[i]->total * 8 * wpk, hipMemcpyDeviceToDevice, st));
     }
-    SKX_HIP(hipMemcpyAsync(off.p, h_off.data(), (n_sets + 1) * 8, hipMemcpyHostToDevice, st));
-    SKX_HIP(hipMemcpyAsync(ucnt.p, h_cnt.data(), n_sets * 4, hipMemcpyHostToDevice, st));
-    HashParams hp = sets[0]->hp;
-    DictView v{words.p, off.p, ucnt.p, n_sets, 0, 2 * (sets[0]->k - 1)};
-    int r = keyset_union_views(ctx, &v, 1, sets[0]->k, sets[0]->rc, hp, std::min(total, maxn * 2), out);
-    SKX_HIP(hipStreamSynchronize(st));
-    return r;
+    return keyset_union_tables(ctx, words.p, h_off, h_cnt, sets[0]->k, sets[0]->rc, out);
     });
 }
 
@@ -1830,20 +1849,21 @@ extern "C" int skx_array_write_fasta(skx_array *a, int fd)
     // it contend with it: 4.9 GB in 0.8 s this way, 1.0 s with the copies chasing the allocation, 1.0-1.4 s through
     // write()/pwrite() -- tools/fasta_knobs.py); the first batches come off the device meanwhile
     std::shared_ptr<Preallocator> pre;
+    std::atomic<bool> ok{true};                 // declared before the threads and slots that store to it
     std::atomic<bool> backed{false};
     struct Joiner { std::thread th; ~Joiner() { if (th.joinable()) th.join(); } } falloc;
     if (map) {
         if (a->prealloc && a->prealloc->fd == fd && a->prealloc->base == pos) pre = a->prealloc;      // started while the rows were being read
         else pre = std::make_shared<Preallocator>(fd, pos);
         a->prealloc.reset();
-        falloc.th = std::thread([&backed, pre, total]() { pre->finish(total); backed.store(true, std::memory_order_release); });
+        // no copier touches the mapping before its pages exist; when they cannot be had the call fails with SKX_EIO as the write() path does
+        falloc.th = std::thread([&backed, &ok, pre, total]() { pre->finish(total); if (pre->failed.load(std::memory_order_acquire)) ok = false; backed.store(true, std::memory_order_release); });
     }
     const size_t cap = std::max<size_t>(max_rec, map ? (32u << 20) : (64u << 20));
     auto knob = [](const char *name, int dflt) { const char *e = getenv(name); const int v = e ? atoi(e) : 0; return v > 0 ? v : dflt; };
     const int NB = map ? std::min(6, knob("SKX_FASTA_NB", 4)) : (regular && !append && pos >= 0 ? 6 : 2);
     const int KT = map ? knob("SKX_FASTA_KT", 4) : 1;                   // copier threads per batch (mapped output)
 
-    std::atomic<bool> ok{true};                 // declared before the slots: their destructors join writers that store to it
     struct Slot { char *p = nullptr; std::vector<std::thread> th; void join() { for (auto &t : th) if (t.joinable()) t.join(); th.clear(); }
                   ~Slot() { join(); if (p) (void)hipHostFree(p); } } slot[6];
     { PhaseTimer t_pin("fasta.pinned_buffers");
@@ -1871,8 +1891,9 @@ extern "C" int skx_array_write_fasta(skx_array *a, int fd)
             uint8_t *dst = map + map_skew + done;
             for (int t = 0; t < KT; t++) {
                 const size_t lo = used * (size_t)t / KT, hi = used * (size_t)(t + 1) / KT;
-                sl.th.emplace_back([dst, buf, lo, hi, &backed]() {
+                sl.th.emplace_back([dst, buf, lo, hi, &backed, &ok]() {
                     while (!backed.load(std::memory_order_acquire)) usleep(100);
+                    if (!ok.load()) return;
                     memcpy(dst + lo, buf + lo, hi - lo);
                 });
             }
@@ -1923,7 +1944,7 @@ static void finish_pairs(const unsigned long long *h, int S, int i_lo, int i_hi,
             out[n].match_count = (uint64_t)matches; out[n].mismatch_count = (uint64_t)mismatches;
         }
 }
-static int planes_distance(skx_ctx *ctx, const uint64_t *planes, int S, uint64_t wpr, int filt_ambig, double constant, int i_lo, int i_hi, skx_dist *out)
+int skx::planes_distance(skx_ctx *ctx, const uint64_t *planes, int S, uint64_t wpr, int filt_ambig, double constant, int i_lo, int i_hi, skx_dist *out)
 {
     hipStream_t st = ctx->stream;
     if (S < 2 || i_lo >= i_hi) return SKX_OK;

@@ -487,6 +487,9 @@ extern "C" int skx_array_load_filtered(skx_ctx *ctx, const char *path, const skx
 {
     return skx_guarded([&]() -> int {
     if (!ctx || !path || !f || !out) { set_error("bad arguments"); return SKX_EINVAL; }
+    // the output hint applies to exactly this call, whichever path it takes (a stale descriptor number may belong to another file by
+    // the time of a later call)
+    const int expect_fd = ctx->expect_fd; ctx->expect_fd = -1;
     if (getenv("SKX_NO_STREAM_LOAD")) return load_then_filter(ctx, path, f, out, removed, constant);
     SKX_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -511,7 +514,7 @@ extern "C" int skx_array_load_filtered(skx_ctx *ctx, const char *path, const skx
     const uint64_t upos = sf.upos_data, uend = upos + 2 * U * S, G = skf_group_chunks();
     const SkfChunk *ch = sf.chunks(); const uint8_t *file = sf.file();
     const size_t c0 = sf.chunk_of(upos);                     // first chunk of the data section (the walk is past it: the header was read there)
-    if (c0 >= sf.n_chunks()) { if (sf.walk_result() != SKX_OK) return SKX_EFORMAT; return load_then_filter(ctx, path, f, out, removed, constant); }
+    if (c0 >= sf.n_chunks()) { const int wr = sf.walk_result(); if (wr != SKX_OK && wr != SKF_NOT_TAKEN) return SKX_EFORMAT; return load_then_filter(ctx, path, f, out, removed, constant); }
 
     std::unique_ptr<skx_array> a(new skx_array());
     a->ctx = ctx; a->k = sf.m.k; a->rc = sf.m.rc; a->hp = make_hash_params(std::min(sf.m.k, 31)); a->wh = make_wide_hash(sf.m.k);
@@ -538,18 +541,20 @@ extern "C" int skx_array_load_filtered(skx_ctx *ctx, const char *path, const skx
     // the alignment's destination, when the caller announced it: its pages are allocated as the kept rows accumulate
     uint64_t name_bytes = 0;
     for (auto &nm : a->names) name_bytes += nm.size() + 3;
-    if (ctx->expect_fd >= 0 && !f->two_stage) {
+    if (expect_fd >= 0 && !f->two_stage) {
         off_t opos;
-        if (mappable_output_fd(ctx->expect_fd, &opos)) a->prealloc = std::make_shared<Preallocator>(ctx->expect_fd, opos);
+        if (mappable_output_fd(expect_fd, &opos)) a->prealloc = std::make_shared<Preallocator>(expect_fd, opos);
     }
-    ctx->expect_fd = -1;
     bool last_group = false;
     for (size_t g0 = c0; !last_group; ) {
         // the group's chunks as far as the walker has come (it stays ahead of the device: ~3 M chunks/s against ~2.5 M decoded)
-        (void)sf.wait_chunk(g0 + G - 1);
-        size_t g1 = std::min<size_t>(sf.n_chunks(), g0 + G);
+        // (at most gmax chunks: the buffers above are sized for gmax chunks of up to 64 KB each; a file framed in smaller chunks has more
+        // chunks than 64 KB pieces and simply takes more groups)
+        (void)sf.wait_chunk(g0 + gmax - 1);
+        size_t g1 = std::min<size_t>(sf.n_chunks(), g0 + gmax);
         if (g1 <= g0) {                                                                      // the walk ended before the data section did
             const int wr = sf.walk_result();
+            if (wr == SKF_NOT_TAKEN) { a->prealloc.reset(); a.reset(); return load_then_filter(ctx, path, f, out, removed, constant); }
             if (wr != SKX_OK) return wr;
             set_error("skf: truncated frame"); return SKX_EFORMAT;
         }
@@ -594,7 +599,11 @@ extern "C" int skx_array_load_filtered(skx_ctx *ctx, const char *path, const skx
         row_lo = row_done; cur ^= 1;
         g0 = g1;
     }
-    { const int wr = sf.walk_result(); if (wr != SKX_OK) return wr; }                        // framing errors anywhere in the file
+    {   // framing errors anywhere in the file
+        const int wr = sf.walk_result();
+        if (wr == SKF_NOT_TAKEN) { a->prealloc.reset(); a.reset(); return load_then_filter(ctx, path, f, out, removed, constant); }
+        if (wr != SKX_OK) return wr;
+    }
     int status = 0, bad = 0;
     SKX_HIP(hipMemcpyAsync(&status, d_status.p, 4, hipMemcpyDeviceToHost, st));
     SKX_HIP(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, st));

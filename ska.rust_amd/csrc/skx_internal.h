@@ -2,6 +2,7 @@
 #pragma once
 #include "../../include/skx.h"
 #include "skx_device.h"
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <condition_variable>
@@ -68,6 +69,7 @@ namespace skx {
 struct Preallocator {
     int fd; off_t base;
     std::mutex mu; std::condition_variable cv; uint64_t target = 0, done = 0; bool stop = false;
+    std::atomic<bool> failed{false};       // posix_fallocate refused (ENOSPC, quota): the range must not be written through a mapping
     std::thread th;
     Preallocator(int fd_, off_t base_);
     ~Preallocator();
@@ -223,6 +225,10 @@ int skf_read_stream(const char *path, SkfMeta &m, std::vector<skx_key> &keys, st
 
 // helpers shared by the ABI translation units (skx_api.cpp, skx_api_io.cpp)
 namespace skx {
+// pieces of the single-GPU path the collective layer (skx_comm.hip) composes
+int keyset_flatten(skx_keyset *ks);                                  // ks->flat = the rows as one compact list of packed words (engine order)
+int keyset_union_tables(skx_ctx *ctx, const uint64_t *words, const std::vector<uint64_t> &h_off, const std::vector<uint32_t> &h_cnt, int k, int rc, skx_keyset **out);
+int planes_distance(skx_ctx *ctx, const uint64_t *planes, int S, uint64_t wpr, int filt_ambig, double constant, int i_lo, int i_hi, skx_dist *out);
 int check_k(int k);                                                  // "Invalid k-mer length" (ska_dict.rs:342-344)
 bool mappable_output_fd(int fd, off_t *pos);                         // regular file, read-write, not O_APPEND: can be written through a mapping
 int array_wide_words(skx_array *a, DevBuf<uint64_t> &tmp, const u128 **words);   // k > 31: the rows' packed 128-bit words on the device (tmp backs them for loaded arrays)

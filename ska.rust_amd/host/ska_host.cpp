@@ -15,6 +15,10 @@
 #include <thread>
 #include <string>
 #include <fcntl.h>
+#include <signal.h>
+#include <spawn.h>
+#include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 #include <vector>
 
@@ -131,6 +135,7 @@ extern "C" int skh_align_fd(skx_array *a, int filter_type, int mask_ambig, int i
 }
 
 static int distance_text(skx_array *a, const std::vector<skx_dist> &d, char **buf, uint64_t *len);
+static int distance_text_names(const std::vector<const char *> &names, const skx_dist *d, char **buf, uint64_t *len);
 extern "C" int skh_distance_tsv(skx_array *a, double min_freq, int filt_ambig, char **buf, uint64_t *len)
 {
     return skx_guarded([&]() -> int {
@@ -147,7 +152,13 @@ extern "C" int skh_distance_tsv(skx_array *a, double min_freq, int filt_ambig, c
 static int distance_text(skx_array *a, const std::vector<skx_dist> &d, char **buf, uint64_t *len)
 {
     skx_array_info_t info; skx_array_info(a, &info);
-    const uint64_t S = info.n_samples;
+    std::vector<const char *> names(info.n_samples);
+    for (uint64_t i = 0; i < info.n_samples; i++) names[i] = skx_array_name(a, i);
+    return distance_text_names(names, d.data(), buf, len);
+}
+static int distance_text_names(const std::vector<const char *> &names, const skx_dist *d, char **buf, uint64_t *len)
+{
+    const uint64_t S = names.size();
     Phase pt("distance.table_text");
     // the rows of one first sample are formatted by one thread (a table of 1 000 samples is half a million printf calls, 20 MB)
     const int T = (int)std::min<uint64_t>(std::max<uint64_t>(1, S / 16), std::min(32u, std::max(1u, std::thread::hardware_concurrency())));
@@ -158,7 +169,7 @@ static int distance_text(skx_array *a, const std::vector<skx_dist> &d, char **bu
             size_t n = (size_t)(i * (2 * S - i - 1) / 2);               // pairs before row i
             std::string &o = part[i];
             for (uint64_t j = i + 1; j < S; j++, n++)
-                put(o, "%s\t%s\t%.2f\t%.5f\t%llu\t%llu\n", skx_array_name(a, i), skx_array_name(a, j), d[n].distance, d[n].mismatch_prop,
+                put(o, "%s\t%s\t%.2f\t%.5f\t%llu\t%llu\n", names[i], names[j], d[n].distance, d[n].mismatch_prop,
                     (unsigned long long)d[n].match_count, (unsigned long long)d[n].mismatch_count);
         }
     };
@@ -444,7 +455,138 @@ extern "C" int skh_cov(skx_ctx *ctx, const char *fastq_fwd, const char *fastq_re
     });
 }
 
+// ------------------------------------------------------------------------------------------ several GPUs, one process each
+namespace {
+// the common head of the three sharded modes: this rank's dictionaries -> key-table all-gather -> the rank's columns over the global rows
+int sharded_array(skx_ctx *ctx, skx_comm *comm, const skh_job *job, uint64_t *lo_out, uint64_t *hi_out, skx_array **out)
+{
+    if (!ctx || !comm || !job || job->n_samples <= 0) { skx_set_error("bad arguments"); return SKX_EINVAL; }
+    const int rank = skx_comm_rank(comm), world = skx_comm_world(comm);
+    uint64_t lo = 0, hi = 0;
+    int r = skx_shard_range((uint64_t)job->n_samples, rank, world, &lo, &hi);
+    if (r != SKX_OK) return r;
+    if (hi <= lo) { skx_set_error("rank %d: no samples (fewer samples than ranks)", rank); return SKX_EINVAL; }
+    skx_dictset *ds = nullptr; skx_keyset *ks = nullptr, *rows = nullptr;
+    {
+        Phase p("sharded.dictionaries");
+        std::vector<const char *> f2(hi - lo, nullptr);
+        if (job->file2) for (uint64_t i = lo; i < hi; i++) f2[i - lo] = job->file2[i];
+        r = skx_dictset_build_files(ctx, job->file1 + lo, f2.data(), (int)(hi - lo), job->k, job->rc, &job->qual, job->threads, job->proportion_reads, &ds);
+    }
+    // a rank that failed still takes part in the exchange of sizes (with an empty table would be wrong): stop everybody the same way
+    if (r != SKX_OK) return r;
+    { Phase p("sharded.local_union"); r = skx_keyset_union(ctx, ds, &ks); }
+    if (r == SKX_OK) { Phase p("sharded.key_table_exchange"); r = skx_keyset_allgather(comm, ks, &rows); }
+    if (ks) skx_keyset_free(ks);
+    if (r != SKX_OK) { skx_dictset_free(ds); return r; }
+    // rows + dictionaries: the rank's column slab over the global rows is never allocated (8 000 samples: 100+ GB per rank)
+    r = skx_array_assemble_lazy(ctx, ds, rows, job->names + lo, out);          // takes ds and rows, also on failure
+    *lo_out = lo; *hi_out = hi;
+    return r;
+}
+std::string part_name(const char *prefix, int rank, int world) { return std::string(prefix) + ".part" + std::to_string(rank) + "of" + std::to_string(world) + ".skf"; }
+}  // namespace
+
+extern "C" int skh_build_sharded(skx_ctx *ctx, skx_comm *comm, const skh_job *job)
+{
+    return skx_guarded([&]() -> int {
+    skx_array *arr = nullptr; uint64_t lo, hi;
+    int r = sharded_array(ctx, comm, job, &lo, &hi, &arr);
+    if (r != SKX_OK) return r;
+    if (!job->output) { skx_array_free(arr); skx_set_error("-o <output> is required"); return SKX_EINVAL; }
+    const int rank = skx_comm_rank(comm), world = skx_comm_world(comm);
+    r = skx_array_save(arr, part_name(job->output, rank, world).c_str());      // local counts: each part is a self-consistent MergeSkaArray
+    skx_array_free(arr);
+    const int rb = skx_comm_barrier(comm);
+    if (r != SKX_OK) return r;
+    if (rb != SKX_OK) return rb;
+    if (rank == 0) {
+        std::vector<std::string> parts; std::vector<const char *> cp;
+        for (int p = 0; p < world; p++) parts.push_back(part_name(job->output, p, world));
+        for (auto &x : parts) cp.push_back(x.c_str());
+        if (job->merge_parts) {
+            if (world == 1) {                                                    // one part is the array itself
+                std::string o(job->output); if (o.size() < 4 || o.compare(o.size() - 4, 4, ".skf") != 0) o += ".skf";
+                if (rename(parts[0].c_str(), o.c_str()) != 0) { skx_set_error("cannot rename %s", parts[0].c_str()); r = SKX_EIO; }
+            } else if ((r = skh_merge(ctx, cp.data(), world, job->output)) == SKX_OK)
+                for (auto &x : parts) unlink(x.c_str());
+        } else {
+            std::string msg = "wrote";
+            for (auto &x : parts) { msg += ' '; msg += x; }
+            fprintf(stderr, "%s\njoin them with: ska merge -o %s <parts>\n", msg.c_str(), job->output);
+        }
+    }
+    return r;
+    });
+}
+
+extern "C" int skh_align_sharded(skx_ctx *ctx, skx_comm *comm, const skh_job *job)
+{
+    return skx_guarded([&]() -> int {
+    skx_array *arr = nullptr; uint64_t lo, hi;
+    int r = sharded_array(ctx, comm, job, &lo, &hi, &arr);
+    if (r != SKX_OK) return r;
+    auto done = [&](int rc) { skx_array_free(arr); return rc; };
+    { Phase p("sharded.row_stats_exchange"); if ((r = skx_array_reduce_stats(comm, arr, (uint64_t)job->n_samples)) != SKX_OK) return done(r); }
+    int32_t removed = 0;
+    { Phase p("align.filter"); if ((r = skh_apply_filters(arr, job->min_freq, job->filter_ambig_as_missing, job->filter_type, job->mask_ambig, job->ignore_const_gaps, &removed)) != SKX_OK) return done(r); }
+    skx_array_info_t info; skx_array_info(arr, &info);
+    const uint64_t kept = info.n_rows;
+    // every rank writes its samples' records at their place in the one file: ">name\n" + kept bases + "\n" per sample
+    uint64_t offset = 0, total = 0;
+    for (int i = 0; i < job->n_samples; i++) { const uint64_t sz = strlen(job->names[i]) + kept + 3; if ((uint64_t)i < lo) offset += sz; total += sz; }
+    const int rank = skx_comm_rank(comm);
+    if (!job->output) { skx_set_error("with several GPUs the alignment goes to a file: give -o"); return done(SKX_EINVAL); }
+    if (rank == 0) {
+        int fd0 = open(job->output, O_RDWR | O_CREAT | O_TRUNC, 0644);
+        if (fd0 < 0 || ftruncate(fd0, (off_t)total) != 0) { if (fd0 >= 0) close(fd0); skx_set_error("cannot create output file"); r = SKX_EIO; }
+        else close(fd0);
+    }
+    const int rb = skx_comm_barrier(comm);                                       // the file exists at its full size
+    if (r != SKX_OK) return done(r);
+    if (rb != SKX_OK) return done(rb);
+    int fd = open(job->output, O_RDWR);
+    if (fd < 0) { skx_set_error("cannot open output file"); return done(SKX_EIO); }
+    if (lseek(fd, (off_t)offset, SEEK_SET) < 0) { close(fd); skx_set_error("cannot seek in output file"); return done(SKX_EIO); }
+    { Phase p("align.write_fasta"); r = skx_array_write_fasta(arr, fd); }
+    close(fd);
+    const int rb2 = skx_comm_barrier(comm);
+    return done(r != SKX_OK ? r : rb2);
+    });
+}
+
+extern "C" int skh_distance_sharded(skx_ctx *ctx, skx_comm *comm, const skh_job *job)
+{
+    return skx_guarded([&]() -> int {
+    skx_array *arr = nullptr; uint64_t lo, hi;
+    int r = sharded_array(ctx, comm, job, &lo, &hi, &arr);
+    if (r != SKX_OK) return r;
+    auto done = [&](int rc) { skx_array_free(arr); return rc; };
+    const uint64_t S = (uint64_t)job->n_samples;
+    { Phase p("sharded.row_stats_exchange"); if ((r = skx_array_reduce_stats(comm, arr, S)) != SKX_OK) return done(r); }
+    int32_t removed = 0, constant = 0;
+    if (job->min_freq * (double)S >= 1.0)                                          // generic_modes.rs:149-159
+        if ((r = skx_array_filter(arr, (uint64_t)std::ceil((double)S * job->min_freq), 0, SKX_FILTER_NONE, 0, 0, 0, &removed)) != SKX_OK) return done(r);
+    if ((r = skx_array_filter(arr, 0, 0, SKX_FILTER_NO_CONST, 0, 0, 0, &constant)) != SKX_OK) return done(r);      // :161-168
+    const int rank = skx_comm_rank(comm);
+    std::vector<skx_dist> d(rank == 0 ? S * (S - 1) / 2 + 1 : 1);
+    if ((r = skx_array_distance_sharded(comm, arr, job->filt_ambig, (double)constant, d.data(), d.size())) != SKX_OK) return done(r);
+    if (rank == 0) {
+        std::vector<const char *> names(job->names, job->names + S);
+        char *buf = nullptr; uint64_t len = 0;
+        if ((r = distance_text_names(names, d.data(), &buf, &len)) != SKX_OK) return done(r);
+        FILE *f = job->output ? fopen(job->output, "wb") : stdout;
+        if (!f) { skx_free(buf); skx_set_error("cannot create output file"); return done(SKX_EIO); }
+        fwrite(buf, 1, len, f);
+        if (f != stdout) fclose(f); else fflush(stdout);
+        skx_free(buf);
+    }
+    return done(SKX_OK);
+    });
+}
+
 // ------------------------------------------------------------------------------------------ CLI
+extern char **environ;
 namespace {
 struct Args {
     std::vector<std::string> pos;
@@ -453,7 +595,7 @@ struct Args {
     std::string get(const std::string &k, const std::string &d = "") const { for (auto &o : opt) if (o.first == k) return o.second; return d; }
 };
 const char *VALUE_OPTS[] = {"-o", "-k", "-f", "--threads", "--min-count", "--min-qual", "--qual-filter", "--proportion-reads",
-                            "--min-freq", "-m", "--filter", "-s", "--skf-file", "--format", nullptr};
+                            "--min-freq", "-m", "--filter", "-s", "--skf-file", "--format", "--gpus", nullptr};
 bool takes_value(const std::string &s) { for (int i = 0; VALUE_OPTS[i]; i++) if (s == VALUE_OPTS[i]) return true; return false; }
 int fail(const char *msg) { fprintf(stderr, "error: %s\n", msg); return 2; }
 int engine_fail() { fprintf(stderr, "error: %s\n", skx_last_error()); return 101; }   // Rust panics exit with 101
@@ -464,6 +606,159 @@ int parse_filter(const std::string &s)
     if (s == "no-ambig") return SKX_FILTER_NO_AMBIG;
     if (s == "no-ambig-or-const") return SKX_FILTER_NO_AMBIG_OR_CONST;
     return -1;
+}
+// `--gpus N`: this executable once per GPU, the ranks find each other through SKX_RANK / SKX_WORLD and a rendezvous directory
+// (rank 0 leaves the RCCL id there; SKX_COMM=local makes the ranks exchange through the directory itself, for ranks that share a device)
+int launch_ranks(int world, char **argv)
+{
+    char dir[64];
+    struct stat sb;
+    snprintf(dir, sizeof dir, "%s/skx_ranks_XXXXXX", stat("/dev/shm", &sb) == 0 ? "/dev/shm" : "/tmp");
+    if (!mkdtemp(dir)) return fail("cannot create the rendezvous directory");
+    const bool local = getenv("SKX_COMM") && !strcmp(getenv("SKX_COMM"), "local");
+    std::vector<pid_t> pids;
+    int rcode = 0;
+    for (int r = 0; r < world && !rcode; r++) {
+        std::vector<std::string> env;
+        for (char **e = environ; *e; e++) if (strncmp(*e, "SKX_RANK=", 9) && strncmp(*e, "SKX_WORLD=", 10) && strncmp(*e, "SKX_COMM_", 9)) env.push_back(*e);
+        env.push_back("SKX_RANK=" + std::to_string(r)); env.push_back("SKX_WORLD=" + std::to_string(world));
+        env.push_back(std::string(local ? "SKX_COMM_DIR=" : "SKX_COMM_ID_FILE=") + dir + (local ? "" : "/id"));
+        std::vector<char *> envp; for (auto &x : env) envp.push_back(&x[0]); envp.push_back(nullptr);
+        pid_t pid;
+        if (posix_spawn(&pid, "/proc/self/exe", nullptr, nullptr, argv, envp.data()) != 0) rcode = fail("cannot start a rank");
+        else pids.push_back(pid);
+    }
+    size_t left = pids.size();
+    while (left) {
+        int st = 0; const pid_t p = waitpid(-1, &st, 0);
+        if (p < 0) { if (errno == EINTR) continue; break; }
+        size_t i = 0; while (i < pids.size() && pids[i] != p) i++;
+        if (i == pids.size()) continue;
+        pids[i] = 0; left--;
+        const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + WTERMSIG(st);
+        if (code && !rcode) { rcode = code; for (pid_t q : pids) if (q) kill(q, SIGTERM); }      // the others wait in a collective for a rank that is gone
+    }
+    (void)!system((std::string("rm -rf '") + dir + "'").c_str());
+    return rcode;
+}
+// the communicator of this rank (RCCL unless SKX_COMM_DIR names a directory for the host-staged transport)
+int open_comm(skx_ctx *ctx, int rank, int world, skx_comm **out)
+{
+    if (const char *d = getenv("SKX_COMM_DIR")) return skx_comm_create_local(ctx, rank, world, d, out);
+    uint8_t id[SKX_COMM_ID_BYTES];
+    const char *idf = getenv("SKX_COMM_ID_FILE");
+    if (world > 1 && !idf) { skx_set_error("SKX_WORLD > 1 needs SKX_COMM_ID_FILE (where rank 0 leaves the RCCL id) or SKX_COMM_DIR"); return SKX_EINVAL; }
+    if (rank == 0) {
+        int r = skx_comm_unique_id(id);
+        if (r != SKX_OK) return r;
+        if (idf) {
+            const std::string tmp = std::string(idf) + ".tmp";
+            FILE *f = fopen(tmp.c_str(), "wb");
+            if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) { if (f) fclose(f); skx_set_error("cannot write %s", tmp.c_str()); return SKX_EIO; }
+            fclose(f);
+            if (rename(tmp.c_str(), idf) != 0) { skx_set_error("cannot publish %s", idf); return SKX_EIO; }
+        }
+    } else {
+        FILE *f = nullptr;
+        for (int i = 0; i < 6000 && !(f = fopen(idf, "rb")); i++) usleep(20000);               // two minutes
+        if (!f || fread(id, 1, sizeof id, f) != sizeof id) { if (f) fclose(f); skx_set_error("rank %d: no RCCL id at %s", rank, idf); return SKX_EIO; }
+        fclose(f);
+    }
+    return skx_comm_create(ctx, rank, world, id, out);
+}
+struct BuildOpts { int k = 31; skx_qual q{5, 20, SKX_QUAL_STRICT}; bool auto_count = false; double prop = 0.0; };
+int parse_build_opts(const Args &a, BuildOpts &o)                                      // cli.rs:27-108 (Build)
+{
+    o.k = atoi(a.get("-k", "31").c_str());
+    if (o.k < 5 || o.k > 63 || o.k % 2 == 0) return fail("K-mer must be an odd number between 5 and 63 (inclusive)");   // cli.rs:38-47
+    if (a.has("--min-count")) {
+        const std::string mc = a.get("--min-count");
+        if (mc == "auto") o.auto_count = true; else {
+        char *end; long v = strtol(mc.c_str(), &end, 10);
+        if (*end || v < 1 || v > 65535) return fail("Minimum kmer count must be >= 1");                           // cli.rs:94-108
+        o.q.min_count = (uint16_t)v; }
+    }
+    if (a.has("--min-qual")) o.q.min_qual = (uint8_t)atoi(a.get("--min-qual").c_str());
+    if (a.has("--qual-filter")) {
+        const std::string f = a.get("--qual-filter");
+        o.q.qual_filter = f == "no-filter" ? SKX_QUAL_NOFILTER : f == "middle" ? SKX_QUAL_MIDDLE : f == "strict" ? SKX_QUAL_STRICT : -1;
+        if (o.q.qual_filter < 0) return fail("invalid --qual-filter");
+    }
+    o.prop = a.has("--proportion-reads") ? atof(a.get("--proportion-reads").c_str()) : 0.0;
+    return 0;
+}
+struct Inputs { std::vector<std::string> names, f1, f2; std::vector<const char *> cn, c1, c2; };
+int read_inputs(const Args &a, Inputs &in)                                             // io_utils.rs:31-46,116-146
+{
+    if (a.has("-f")) {
+        std::ifstream f(a.get("-f"));
+        if (!f) return fail("Unable to open file_list");
+        std::string line;
+        while (std::getline(f, line)) {
+            std::istringstream ls(line); std::vector<std::string> fld; std::string t;
+            while (ls >> t) fld.push_back(t);
+            if (fld.size() < 2 || fld.size() > 3) return fail("Unable to parse line in file_list");
+            in.names.push_back(fld[0]); in.f1.push_back(fld[1]); in.f2.push_back(fld.size() == 3 ? fld[2] : "");
+        }
+    } else
+        for (auto &p : a.pos) { char *n = skh_sample_name(p.c_str()); in.names.push_back(n); free(n); in.f1.push_back(p); in.f2.push_back(""); }
+    for (size_t i = 0; i < in.names.size(); i++) { in.cn.push_back(in.names[i].c_str()); in.c1.push_back(in.f1[i].c_str()); in.c2.push_back(in.f2[i].empty() ? nullptr : in.f2[i].c_str()); }
+    return 0;
+}
+// --min-count auto (io_utils::kmer_min_cutoff, io_utils.rs:175-212): the FIRST file of the first two paired inputs
+int auto_min_count(skx_ctx *ctx, const Inputs &in, int k, bool rc, skx_qual &q, bool print)
+{
+    std::vector<std::string> fq;
+    for (size_t i = 0; i < in.names.size() && fq.size() < 2; i++) if (!in.f2[i].empty()) fq.push_back(in.f1[i]);
+    if (fq.size() >= 2) {
+        char *buf = nullptr; uint64_t len = 0, cutoff = 0;
+        if (skh_cov(ctx, fq[0].c_str(), fq[1].c_str(), k, rc, &buf, &len, &cutoff) != SKX_OK) return 101;
+        if (print) { fwrite(buf, 1, len, stdout); fflush(stdout); }                                               // cov.plot_hist()
+        skx_free(buf);
+        q.min_count = (uint16_t)cutoff;
+        if (print) fprintf(stderr, "Using inferred minimum kmer value of %llu\n", (unsigned long long)cutoff);
+    } else if (print) fprintf(stderr, "Not enough fastq files to fit mixture model, using default kmer count of 5\n");
+    return 0;
+}
+// build | align | distance as one rank of a job over several GPUs
+int main_sharded(skx_ctx *ctx, const std::string &cmd, const Args &a, int rank, int world, int threads)
+{
+    BuildOpts bo; Inputs in;
+    if (a.pos.empty() == !a.has("-f")) return fail("give either sequence files or -f <file_list>");
+    if (int e = parse_build_opts(a, bo)) return e;
+    if (int e = read_inputs(a, in)) return e;
+    for (auto &p : in.f1) if (p.size() > 4 && p.compare(p.size() - 4, 4, ".skf") == 0) return fail("with --gpus give the sequence files (or -f <file_list>), not a .skf");
+    if ((int)in.names.size() < world) return fail("fewer samples than GPUs");
+    const bool rc = !a.has("--single-strand");
+    if (bo.auto_count && auto_min_count(ctx, in, bo.k, rc, bo.q, rank == 0)) return engine_fail();    // every rank fits the same two files: same cutoff
+    skh_job job{};
+    job.names = in.cn.data(); job.file1 = in.c1.data(); job.file2 = in.c2.data(); job.n_samples = (int)in.cn.size();
+    job.k = bo.k; job.rc = rc; job.qual = bo.q; job.threads = threads; job.proportion_reads = bo.prop;
+    const std::string out = a.get("-o");
+    job.output = a.has("-o") ? out.c_str() : nullptr;
+    skx_comm *comm = nullptr;
+    if (open_comm(ctx, rank, world, &comm) != SKX_OK) return engine_fail();
+    int r;
+    if (cmd == "build") {
+        if (!a.has("-o")) return fail("-o <output> is required");
+        job.merge_parts = a.has("--merge");
+        r = skh_build_sharded(ctx, comm, &job);
+    } else if (cmd == "align") {
+        job.filter_type = parse_filter(a.get("--filter", "no-const"));
+        if (job.filter_type < 0) return fail("invalid --filter");
+        job.min_freq = atof(a.get("--min-freq", a.get("-m", "0.9")).c_str());
+        if (job.min_freq < 0 || job.min_freq > 1) return fail("Frequency must be between 0 and 1 (inclusive)");
+        job.mask_ambig = a.has("--ambig-mask"); job.ignore_const_gaps = a.has("--no-gap-only-sites"); job.filter_ambig_as_missing = a.has("--filter-ambig-as-missing");
+        r = skh_align_sharded(ctx, comm, &job);
+    } else {
+        job.min_freq = atof(a.get("--min-freq", a.get("-m", "0")).c_str());
+        job.filt_ambig = !a.has("--allow-ambiguous");
+        r = skh_distance_sharded(ctx, comm, &job);
+    }
+    const int rcode = r == SKX_OK ? 0 : engine_fail();
+    if (rank == 0 && getenv("SKX_DEBUG")) fprintf(stderr, "[skx] rank 0 received %llu bytes through the communicator\n", (unsigned long long)skx_comm_bytes_received(comm));
+    skx_comm_destroy(comm);
+    return rcode;
 }
 int emit(const std::string &out_path, const char *buf, uint64_t len)                 // io_utils::set_ostream
 {
@@ -477,7 +772,8 @@ int emit(const std::string &out_path, const char *buf, uint64_t len)            
 
 extern "C" int skh_main(int argc, char **argv)
 {
-    fprintf(stderr, "SKA: Split K-mer Analysis (the alignment-free aligner)\n");
+    const int env_world = getenv("SKX_WORLD") ? atoi(getenv("SKX_WORLD")) : 0, env_rank = getenv("SKX_RANK") ? atoi(getenv("SKX_RANK")) : 0;
+    if (env_rank == 0) fprintf(stderr, "SKA: Split K-mer Analysis (the alignment-free aligner)\n");
     if (argc < 2) return fail("usage: ska <build|align|map|distance|nk|merge|delete|weed|cov> ...");
     const std::string cmd = argv[1];
     Args a;
@@ -488,19 +784,23 @@ extern "C" int skh_main(int argc, char **argv)
             else a.opt.emplace_back(s, "");
         } else a.pos.push_back(s);
     }
+    // several GPUs (an extension; the reference has --threads only): `--gpus N` starts N ranks of this executable, a rank finds
+    // SKX_WORLD / SKX_RANK in its environment; align / distance then take sequence files or -f and the build options
+    const bool multi = a.has("--gpus") || env_world > 0;
     {   // clap rejects what a subcommand does not declare (cli.rs:109-330); -v / --verbose is global (cli.rs:103-104)
         static const struct { const char *cmd; const char *flags; } KNOWN[] = {
-            {"build", " -o -k -f --proportion-reads --single-strand --min-count --min-qual --qual-filter --threads "},
-            {"align", " -o -m --min-freq --filter-ambig-as-missing --filter --ambig-mask --no-gap-only-sites --threads "},
+            {"build", " -o -k -f --proportion-reads --single-strand --min-count --min-qual --qual-filter --threads --gpus --merge "},
+            {"align", " -o -m --min-freq --filter-ambig-as-missing --filter --ambig-mask --no-gap-only-sites --threads --gpus "},
             {"map", " -o -f --format --ambig-mask --repeat-mask --threads "},
-            {"distance", " -o -m --min-freq --allow-ambiguous --threads "},
+            {"distance", " -o -m --min-freq --allow-ambiguous --threads --gpus "},
             {"merge", " -o "}, {"delete", " -s --skf-file -o -f "},
             {"weed", " -o --reverse -m --min-freq --filter-ambig-as-missing --filter --ambig-mask --no-gap-only-sites "},
             {"nk", " --full-info "}, {"cov", " -k --single-strand "}};
         for (auto &kc : KNOWN)
             if (cmd == kc.cmd)
                 for (auto &o : a.opt)
-                    if (o.first != "-v" && o.first != "--verbose" && !strstr(kc.flags, (" " + o.first + " ").c_str())) {
+                    if (o.first != "-v" && o.first != "--verbose" && !strstr(kc.flags, (" " + o.first + " ").c_str()) &&
+                        !(multi && (cmd == "align" || cmd == "distance") && strstr(" -f -k --single-strand --min-count --min-qual --qual-filter --proportion-reads ", (" " + o.first + " ").c_str()))) {
                         fprintf(stderr, "error: unexpected argument '%s' found\n\nUsage: ska %s [OPTIONS]\n\nFor more information, try '--help'.\n", o.first.c_str(), cmd.c_str());
                         return 2;
                     }
@@ -510,58 +810,33 @@ extern "C" int skh_main(int argc, char **argv)
     const auto t_main = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_main).count(); };
     const bool dbg = getenv("SKX_DEBUG") != nullptr;
+    int world = 1, rank = 0;
+    if (multi) {
+        if (cmd != "build" && cmd != "align" && cmd != "distance") return fail("--gpus applies to build, align and distance");
+        const int gpus = a.has("--gpus") ? atoi(a.get("--gpus").c_str()) : env_world;
+        if (gpus < 1) return fail("--gpus must be one or higher");
+        if (env_world <= 0 && gpus > 1) return launch_ranks(gpus, argv);                   // the parent only starts and reaps the ranks
+        world = env_world > 0 ? env_world : 1; rank = env_rank;
+        if (rank < 0 || rank >= world) return fail("SKX_RANK outside SKX_WORLD");
+    }
     skx_ctx *ctx = nullptr;
-    if (skx_ctx_create(0, &ctx) != SKX_OK) return engine_fail();
+    const int device = getenv("SKX_DEVICE") ? atoi(getenv("SKX_DEVICE")) : getenv("SKX_LOCAL_RANK") ? atoi(getenv("SKX_LOCAL_RANK")) : rank;
+    if (skx_ctx_create(device, &ctx) != SKX_OK) return engine_fail();
     skx_phase_add("main.device_context", since());
     int rcode = 0;
     skx_array *arr = nullptr;
-    if (cmd == "build") {
+    if (multi) rcode = main_sharded(ctx, cmd, a, rank, world, threads);
+    else if (cmd == "build") {
         if (!a.has("-o")) return fail("-o <output> is required");
         if (a.pos.empty() == !a.has("-f")) return fail("give either sequence files or -f <file_list>");
-        const int k = atoi(a.get("-k", "31").c_str());
-        if (k < 5 || k > 63 || k % 2 == 0) return fail("K-mer must be an odd number between 5 and 63 (inclusive)");   // cli.rs:38-47
-        skx_qual q{5, 20, SKX_QUAL_STRICT};
-        bool auto_count = false;
-        if (a.has("--min-count")) {
-            const std::string mc = a.get("--min-count");
-            if (mc == "auto") auto_count = true; else {
-            char *end; long v = strtol(mc.c_str(), &end, 10);
-            if (*end || v < 1 || v > 65535) return fail("Minimum kmer count must be >= 1");                           // cli.rs:94-108
-            q.min_count = (uint16_t)v; }
-        }
-        if (a.has("--min-qual")) q.min_qual = (uint8_t)atoi(a.get("--min-qual").c_str());
-        if (a.has("--qual-filter")) {
-            const std::string f = a.get("--qual-filter");
-            q.qual_filter = f == "no-filter" ? SKX_QUAL_NOFILTER : f == "middle" ? SKX_QUAL_MIDDLE : f == "strict" ? SKX_QUAL_STRICT : -1;
-            if (q.qual_filter < 0) return fail("invalid --qual-filter");
-        }
-        double prop = a.has("--proportion-reads") ? atof(a.get("--proportion-reads").c_str()) : 0.0;
-        std::vector<std::string> names, f1, f2;
-        if (a.has("-f")) {                                                                                            // io_utils.rs:116-146
-            std::ifstream in(a.get("-f"));
-            if (!in) return fail("Unable to open file_list");
-            std::string line;
-            while (std::getline(in, line)) {
-                std::istringstream ls(line); std::vector<std::string> fld; std::string t;
-                while (ls >> t) fld.push_back(t);
-                if (fld.size() < 2 || fld.size() > 3) return fail("Unable to parse line in file_list");
-                names.push_back(fld[0]); f1.push_back(fld[1]); f2.push_back(fld.size() == 3 ? fld[2] : "");
-            }
-        } else
-            for (auto &p : a.pos) { char *n = skh_sample_name(p.c_str()); names.push_back(n); free(n); f1.push_back(p); f2.push_back(""); }
-        std::vector<const char *> cn, c1, c2;
-        for (size_t i = 0; i < names.size(); i++) { cn.push_back(names[i].c_str()); c1.push_back(f1[i].c_str()); c2.push_back(f2[i].empty() ? nullptr : f2[i].c_str()); }
-        if (auto_count) {                                                                                             // io_utils::kmer_min_cutoff, io_utils.rs:175-212
-            std::vector<std::string> fq;                              // get_2_fastq_path: the FIRST file of the first two paired inputs
-            for (size_t i = 0; i < names.size() && fq.size() < 2; i++) if (!f2[i].empty()) fq.push_back(f1[i]);
-            if (fq.size() >= 2) {
-                char *buf = nullptr; uint64_t len = 0, cutoff = 0;
-                if (skh_cov(ctx, fq[0].c_str(), fq[1].c_str(), k, !a.has("--single-strand"), &buf, &len, &cutoff) != SKX_OK) { skx_ctx_destroy(ctx); return engine_fail(); }
-                fwrite(buf, 1, len, stdout); fflush(stdout); skx_free(buf);                                               // cov.plot_hist()
-                q.min_count = (uint16_t)cutoff;
-                fprintf(stderr, "Using inferred minimum kmer value of %llu\n", (unsigned long long)cutoff);
-            } else fprintf(stderr, "Not enough fastq files to fit mixture model, using default kmer count of 5\n");
-        }
+        BuildOpts bo; Inputs in;
+        if (int e = parse_build_opts(a, bo)) return e;
+        if (int e = read_inputs(a, in)) return e;
+        const int k = bo.k; skx_qual &q = bo.q; const bool auto_count = bo.auto_count; const double prop = bo.prop;
+        std::vector<std::string> &names = in.names, &f1 = in.f1, &f2 = in.f2;
+        std::vector<const char *> &cn = in.cn, &c1 = in.c1, &c2 = in.c2;
+        (void)names; (void)f1; (void)f2;
+        if (auto_count && auto_min_count(ctx, in, k, !a.has("--single-strand"), q, true)) { skx_ctx_destroy(ctx); return engine_fail(); }
         if (skx_build_and_merge(ctx, cn.data(), c1.data(), c2.data(), (int)cn.size(), k, !a.has("--single-strand"), &q, threads, prop, &arr) != SKX_OK ||
             skh_save_skf(arr, a.get("-o").c_str()) != SKX_OK)
             rcode = engine_fail();
@@ -650,7 +925,7 @@ extern "C" int skh_main(int argc, char **argv)
     skx_ctx_destroy(ctx);
     skx_phase_add("main.release_device", since() - t_done);
     skx_phase_add("main.total", since());
-    if (const char *pp = getenv("SKX_PHASES")) {                  // phase table of this invocation as JSON (bench.py's end_to_end leg)
+    if (const char *pp = rank == 0 ? getenv("SKX_PHASES") : nullptr) {                  // phase table of this invocation as JSON (bench.py's end_to_end leg)
         char *js = nullptr; uint64_t jl = 0;
         if (skx_phases_json(&js, &jl, 0) == SKX_OK) { if (FILE *f = fopen(pp, "w")) { fwrite(js, 1, jl, f); fputc('\n', f); fclose(f); } skx_free(js); }
     }

@@ -19,11 +19,13 @@ the one output file.  `build` leaves one .skf per rank (`<out>.part<r>of<N>.skf`
 a valid MergeSkaArray, and `ska merge` -- this engine's or the reference's -- joins them); with --merge rank 0 joins them itself
 when the whole matrix fits one GPU.
 
-The engine is reached through the C ABI (skx_engine.py -> libskx.so); torch is here for torch.distributed ("nccl" is RCCL on ROCm)
-and device tensors only.  SKX_MULTI_BACKEND=gloo + SKX_MULTI_DEVICE=d let several ranks share one GPU (tests).
+The whole body of a rank -- dictionaries, the three exchanges (RCCL, issued by the engine on its own stream), filter, output -- is
+behind the C ABI (skh_build_sharded / skh_align_sharded / skh_distance_sharded over skx_comm_*; the `ska` executable reaches the
+same code with `--gpus N`).  torch.distributed is the launcher's rendezvous: it carries the 128-byte RCCL id from rank 0 to the
+others.  SKX_MULTI_BACKEND=gloo + SKX_MULTI_DEVICE=d let several ranks share one GPU (tests): the engine then exchanges through
+its host-staged transport, since RCCL refuses two ranks on one device.
 """
 import argparse
-import math
 import os
 import sys
 import time
@@ -78,7 +80,6 @@ def read_inputs(args, E):
 
 def main():
     args = parse()
-    import numpy as np
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,121 +89,44 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("ska_multi.py needs gfx950 GPUs: the engine has no CPU path")
     torch.cuda.set_device(device)
-    dev = torch.device("cuda", device)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
+    # torch.distributed is the rendezvous only (it carries the 128-byte RCCL id to the ranks); the exchanges are the engine's
     if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
     else:
         dist.init_process_group(backend, rank=rank, world_size=world)
     import dist as skdist
     import skx_engine as E
     E.load_library()
     ctx = E.Context(device)
-    xdev = dev if backend == "nccl" else torch.device("cpu")        # where the collectives' tensors live
+    comm = skdist.make_comm(ctx, rank, world, transport="rccl" if backend == "nccl" else "local")
 
     names, f1, f2 = read_inputs(args, E)
     n_total = len(names)
     lo, hi = skdist.shard_range(n_total, rank, world)
     if hi <= lo:
         raise SystemExit(f"rank {rank}: no samples (fewer samples than ranks)")
-    rep = {"world": world, "samples": n_total, "rank0_samples": hi - lo}
+    rep = {"world": world, "samples": n_total, "rank0_samples": hi - lo, "transport": "rccl" if backend == "nccl" else "local"}
     t0 = time.perf_counter()
     q = E.qual(min_count=args.min_count, min_qual=args.min_qual, qual_filter=QUALS[args.qual_filter])
-    ds = E.DictSet.from_files(list(zip(f1[lo:hi], f2[lo:hi])), args.k, not args.single_strand, q=q, threads=args.threads, ctx=ctx)
-    rep["build_dictionaries_s"] = time.perf_counter() - t0
-    # ---- exchange 1: key tables -> global rows
-    t1 = time.perf_counter()
-    ks = ds.union_keys()
-    p, n_keys, wpk = ks.device()
-    ctx.sync()
-    local = skdist.as_tensor(p, n_keys * wpk, "<i8", dev).to(xdev)
-    tables = skdist.allgather_tables(local)
-    torch.cuda.synchronize()
-    rep["key_table_allgather_bytes_per_rank"] = int(sum(t.numel() for t in tables) * 8)
-    rep["key_table_allgather_s"] = time.perf_counter() - t1
-    tabs = [t.to(dev).contiguous() for t in tables]
-    sets = [E.KeySet.from_device(t.data_ptr(), t.numel() // wpk, args.k, not args.single_strand, ctx=ctx) for t in tabs]
-    rows = E.KeySet.merge(sets, ctx=ctx)
-    arr = ds.assemble_lazy(rows, names[lo:hi])          # rows + dictionaries: the rank's column slab over the global rows is never allocated
-    U = arr.nrows
-    rep["rows"] = int(U)
-
+    common = dict(k=args.k, rc=not args.single_strand, q=q, threads=args.threads)
+    inputs = list(zip(f1, f2))
+    E.phases(reset=True)
     if args.command == "build":
-        part = f"{args.output}.part{rank}of{world}.skf"
-        arr.save(part)                                              # local counts: each part is a self-consistent MergeSkaArray
-        dist.barrier()
-        if rank == 0:
-            parts = [f"{args.output}.part{r}of{world}.skf" for r in range(world)]
-            if args.merge:
-                out = args.output if args.output.endswith(".skf") else args.output + ".skf"       # generic_modes.rs:272-276
-                E.Array.merge([E.Array.load(x, ctx=ctx) for x in parts], ctx=ctx).save(out)
-                for x in parts:
-                    os.unlink(x)
-                print(f"wrote {out}", file=sys.stderr)
-            else:
-                print("wrote " + " ".join(parts) + f"\njoin them with: ska merge -o {args.output} " + " ".join(parts), file=sys.stderr)
+        comm.build(names, inputs, args.output, merge_parts=args.merge, **common)
+    elif args.command == "align":
+        comm.align(names, inputs, args.output, min_freq=0.9 if args.min_freq is None else args.min_freq, filter_type=FILTERS[args.filter],
+                   mask_ambig=args.ambig_mask, ignore_const_gaps=args.no_gap_only_sites, filter_ambig_as_missing=args.filter_ambig_as_missing, **common)
     else:
-        # ---- exchange 2: per-row filter statistics over all ranks
-        t2 = time.perf_counter()
-        pp, pu, pm, pv = arr.device_stats()
-        tp, tu, tm = (skdist.as_tensor(x, U, "<i4", dev) for x in (pp, pu, pm))
-        cp, cu, cm = (t.to(xdev) for t in (tp, tu, tm))
-        skdist.reduce_row_stats(cp, cu, cm, total_samples=n_total)
-        tp.copy_(cp); tu.copy_(cu); tm.copy_(cm)
-        skdist.as_tensor(pv, U, "<i4", dev).copy_(tp)
-        torch.cuda.synchronize()
-        arr.set_total_samples(n_total)
-        rep["row_stats_bytes_per_rank"] = int(U * (4 + 2 * world))
-        rep["row_stats_s"] = time.perf_counter() - t2
-
-        if args.command == "align":
-            mf = 0.9 if args.min_freq is None else args.min_freq
-            arr.apply_filters(mf, args.filter_ambig_as_missing, FILTERS[args.filter], args.ambig_mask, args.no_gap_only_sites)
-            kept = arr.nrows
-            # every rank writes its samples' records at their place in the one file (merge_ska_array.rs:499-517 order)
-            sizes = [len(nm.encode()) + kept + 3 for nm in names]
-            offset = sum(sizes[:lo])
-            if rank == 0:
-                with open(args.output, "wb") as f:
-                    f.truncate(sum(sizes))
-            dist.barrier()
-            fd = os.open(args.output, os.O_RDWR)
-            try:
-                os.lseek(fd, offset, os.SEEK_SET)
-                arr.write_fasta(fd)
-            finally:
-                os.close(fd)
-            dist.barrier()
-            rep["alignment_columns"] = int(kept)
-        else:
-            mf = 0.0 if args.min_freq is None else args.min_freq
-            filt = not args.allow_ambiguous
-            if mf * n_total >= 1.0:                                     # generic_modes.rs:149-159
-                arr.filter(math.ceil(n_total * mf), False, E.FILTER_NONE, False, False, False)
-            constant = arr.filter(0, False, E.FILTER_NO_CONST, False, False, False)       # :161-168
-            t3 = time.perf_counter()
-            pl, wpr, n_planes = arr.distance_planes(filt)
-            local = skdist.as_tensor(pl, n_planes * (hi - lo) * wpr, "<i8", dev).view(n_planes, hi - lo, wpr).to(xdev)
-            keep = {}
-
-            def pair_fn(planes, i_lo, i_hi):
-                g = planes.to(dev).contiguous()
-                keep["planes"] = g
-                d = E.planes_distance(g.data_ptr(), g.shape[1], g.shape[2], filt, constant, i_lo, i_hi, ctx=ctx)
-                return np.stack([d["distance"], d["mismatch_prop"], d["match_count"].astype(np.float64), d["mismatch_count"].astype(np.float64)], axis=1)
-
-            table = skdist.distance_sharded(local, pair_fn)
-            rep["planes_allgather_bytes_per_rank"] = int(n_planes * n_total * wpr * 8)
-            rep["distance_s"] = time.perf_counter() - t3
-            if rank == 0:
-                with open(args.output, "wb") as f:
-                    f.write(skdist.distance_tsv(names, table))
+        comm.distance(names, inputs, args.output, min_freq=0.0 if args.min_freq is None else args.min_freq, filt_ambig=not args.allow_ambiguous, **common)
     rep["total_s"] = time.perf_counter() - t0
+    rep["bytes_received_rank0"] = comm.bytes_received
+    rep["phases_rank0"] = E.phases()
     if rank == 0 and args.report:
         import json
         json.dump(rep, open(args.report, "w"))
-    arr.free()
+    comm.free()
     dist.barrier()
     dist.destroy_process_group()
 

@@ -44,6 +44,15 @@ class Timings(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("hist", "scatter", "dedupe", "key_union", "assemble", "filter", "compact", "distance")]
 
 
+class Job(C.Structure):
+    """skh_job (include/skx_host.h): one build | align | distance job over the GPUs of a node"""
+    _fields_ = [("names", C.POINTER(C.c_char_p)), ("file1", C.POINTER(C.c_char_p)), ("file2", C.POINTER(C.c_char_p)), ("n_samples", C.c_int),
+                ("k", C.c_int), ("rc", C.c_int), ("qual", Qual), ("threads", C.c_int), ("proportion_reads", C.c_double),
+                ("output", C.c_char_p), ("merge_parts", C.c_int), ("min_freq", C.c_double),
+                ("filter_type", C.c_int), ("mask_ambig", C.c_int), ("ignore_const_gaps", C.c_int), ("filter_ambig_as_missing", C.c_int),
+                ("filt_ambig", C.c_int)]
+
+
 class EngineError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"[skx {code}] {msg}")
@@ -58,6 +67,9 @@ skx_array_assemble skx_array_assemble_lazy skx_merge skx_build_and_merge skx_arr
 skx_array_info skx_array_name skx_array_version skx_array_export skx_array_sample_kmers skx_array_filter
 skx_array_write_fasta skx_array_fasta skx_array_device_matrix skx_array_device_stats skx_array_set_total_samples skx_array_distance skx_free skx_ctx_timings
 skx_array_merge skx_array_delete_samples skx_array_weed skx_keyset_from_fasta skx_array_ctx skx_set_last_error skx_array_map skx_cov_histogram skx_phases_json skx_phase_add skx_array_load_filtered skx_ctx_expect_output skx_array_distance_planes skx_planes_distance skx_array_distance_filtered
+skx_comm_unique_id skx_comm_create skx_comm_create_local skx_comm_destroy skx_comm_rank skx_comm_world skx_comm_bytes_received skx_comm_barrier
+skx_comm_allgather skx_comm_allreduce_u32 skx_comm_gather_root skx_shard_range skx_pair_bands skx_keyset_allgather skx_array_reduce_stats skx_array_distance_sharded
+skh_build_sharded skh_align_sharded skh_distance_sharded
 skh_apply_filters skh_align skh_align_fd skh_distance_tsv skh_nk skh_save_skf skh_load_array skh_sample_name skh_main skh_merge skh_delete skh_weed skh_cov skh_cov_fit skh_align_inputs_fd skh_distance_skf_tsv""".split()
 
 _lib = None
@@ -150,6 +162,27 @@ def load_library():
     lib.skx_phases_json.argtypes = [pp, C.POINTER(u64), i]
     lib.skx_phase_add.argtypes = [cp, d]
     lib.skx_phase_add.restype = None
+    lib.skx_comm_unique_id.argtypes = [vp]
+    lib.skx_comm_create.argtypes = [vp, i, i, vp, pp]
+    lib.skx_comm_create_local.argtypes = [vp, i, i, cp, pp]
+    lib.skx_comm_destroy.argtypes = [vp]
+    lib.skx_comm_destroy.restype = None
+    lib.skx_comm_rank.argtypes = [vp]
+    lib.skx_comm_world.argtypes = [vp]
+    lib.skx_comm_bytes_received.argtypes = [vp]
+    lib.skx_comm_bytes_received.restype = u64
+    lib.skx_comm_barrier.argtypes = [vp]
+    lib.skx_comm_allgather.argtypes = [vp, vp, vp, u64, i]
+    lib.skx_comm_allreduce_u32.argtypes = [vp, vp, u64, i]
+    lib.skx_comm_gather_root.argtypes = [vp, vp, vp, vp]
+    lib.skx_shard_range.argtypes = [u64, i, i, C.POINTER(u64), C.POINTER(u64)]
+    lib.skx_pair_bands.argtypes = [i, i, i, vp]
+    lib.skx_keyset_allgather.argtypes = [vp, vp, pp]
+    lib.skx_array_reduce_stats.argtypes = [vp, vp, u64]
+    lib.skx_array_distance_sharded.argtypes = [vp, vp, i, d, vp, u64]
+    lib.skh_build_sharded.argtypes = [vp, vp, C.POINTER(Job)]
+    lib.skh_align_sharded.argtypes = [vp, vp, C.POINTER(Job)]
+    lib.skh_distance_sharded.argtypes = [vp, vp, C.POINTER(Job)]
     _lib = lib
     return lib
 
@@ -265,6 +298,141 @@ def default_context():
 def record_stream(records):
     """records: iterable of bytes -> the device record stream (each record + b'\\n')."""
     return b"".join(bytes(r) + b"\n" for r in records)
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the ABI: rank 0 makes it, the host carries the 128 bytes to the other ranks"""
+    load_library()
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    _check(_lib.skx_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous shard [lo, hi) of rank (skx_shard_range; input order kept, cf. merge_ska_dict.rs:243-253,277-291)"""
+    load_library()
+    lo, hi = C.c_uint64(), C.c_uint64()
+    _check(_lib.skx_shard_range(n_items, rank, world, C.byref(lo), C.byref(hi)))
+    return lo.value, hi.value
+
+
+def pair_bands(n_samples, world, align=8):
+    """Bands [i_lo, i_hi) of first samples of the pair matrix, one per rank (skx_pair_bands)"""
+    load_library()
+    out = np.zeros(2 * world, np.int32)
+    _check(_lib.skx_pair_bands(n_samples, world, align, _np_ptr(out)))
+    return [(int(out[2 * r]), int(out[2 * r + 1])) for r in range(world)]
+
+
+class Comm:
+    """The exchanges of a multi-GPU job behind the C ABI (include/skx.h "Collectives"): RCCL (Comm.rccl) or, for ranks that share
+    one device, host-staged through a directory (Comm.local).  Every method is collective."""
+
+    def __init__(self, handle, ctx):
+        self.h, self.ctx = handle, ctx
+
+    @classmethod
+    def rccl(cls, rank, world, unique_id, ctx=None):
+        ctx = ctx or default_context()
+        h = C.c_void_p()
+        idb = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        _check(_lib.skx_comm_create(ctx.h, rank, world, idb, C.byref(h)))
+        return cls(h, ctx)
+
+    @classmethod
+    def local(cls, rank, world, directory, ctx=None):
+        """ctx may be None: host buffers only (no GPU needed)"""
+        load_library()
+        h = C.c_void_p()
+        _check(_lib.skx_comm_create_local(ctx.h if ctx is not None else None, rank, world, directory.encode(), C.byref(h)))
+        return cls(h, ctx)
+
+    rank = property(lambda self: _lib.skx_comm_rank(self.h))
+    world = property(lambda self: _lib.skx_comm_world(self.h))
+    bytes_received = property(lambda self: int(_lib.skx_comm_bytes_received(self.h)))
+
+    def barrier(self):
+        _check(_lib.skx_comm_barrier(self.h))
+
+    def allgather_host(self, arr):
+        """numpy array (same shape on every rank) -> [world, ...]"""
+        a = np.ascontiguousarray(arr)
+        out = np.empty((self.world,) + a.shape, a.dtype)
+        _check(_lib.skx_comm_allgather(self.h, _np_ptr(a), _np_ptr(out), a.nbytes, 0))
+        return out
+
+    def allgather_device(self, send_ptr, recv_ptr, nbytes):
+        _check(_lib.skx_comm_allgather(self.h, send_ptr, recv_ptr, nbytes, 1))
+
+    def allreduce_u32_host(self, arr):
+        a = np.ascontiguousarray(arr, np.uint32).copy()
+        _check(_lib.skx_comm_allreduce_u32(self.h, _np_ptr(a), a.size, 0))
+        return a
+
+    def gather_root_host(self, arr, sizes):
+        """byte blocks of different sizes (sizes known everywhere) -> rank 0: one uint8 array there, None elsewhere"""
+        a = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+        sz = np.ascontiguousarray(sizes, np.uint64)
+        out = np.empty(int(sz.sum()) if self.rank == 0 else 0, np.uint8)
+        _check(_lib.skx_comm_gather_root(self.h, _np_ptr(a), _np_ptr(sz), _np_ptr(out)))
+        return out if self.rank == 0 else None
+
+    def allreduce_u32_device(self, ptr, n):
+        _check(_lib.skx_comm_allreduce_u32(self.h, ptr, n, 1))
+
+    def keyset_allgather(self, local):
+        """exchange 1: the global row set from every rank's key table (skx_keyset_allgather)"""
+        h = C.c_void_p()
+        _check(_lib.skx_keyset_allgather(self.h, local.h, C.byref(h)))
+        return KeySet(h, self.ctx)
+
+    def reduce_stats(self, array, total_samples):
+        """exchange 2: per-row filter statistics over all ranks (skx_array_reduce_stats)"""
+        _check(_lib.skx_array_reduce_stats(self.h, array.h, total_samples))
+
+    def distance_sharded(self, array, total_samples, filt_ambig=True, constant=0.0):
+        """exchange 3 + the pair sweep by bands (skx_array_distance_sharded): the whole table on rank 0, None elsewhere"""
+        n = total_samples * (total_samples - 1) // 2
+        out = np.zeros(n + 1 if self.rank == 0 else 1, DIST_DT)
+        _check(_lib.skx_array_distance_sharded(self.h, array.h, int(filt_ambig), float(constant), _np_ptr(out), out.size))
+        return out[:n] if self.rank == 0 else None
+
+    def _job(self, names, inputs, k, rc, q, threads, proportion_reads, output):
+        n = len(names)
+        keep = [(C.c_char_p * n)(*[x.encode() for x in names]), (C.c_char_p * n)(*[a.encode() for a, _ in inputs]),
+                (C.c_char_p * n)(*[(b.encode() if b else None) for _, b in inputs]), output.encode() if output else None]
+        j = Job()
+        j.names, j.file1, j.file2, j.n_samples = keep[0], keep[1], keep[2], n
+        j.k, j.rc, j.qual, j.threads, j.proportion_reads, j.output = k, int(rc), q or qual(), threads, proportion_reads, keep[3]
+        return j, keep
+
+    def build(self, names, inputs, output, k=31, rc=True, q=None, threads=1, proportion_reads=0.0, merge_parts=False):
+        """one rank of `ska build` over several GPUs (skh_build_sharded); inputs = [(file1, file2 | None)] of the WHOLE job"""
+        j, keep = self._job(names, inputs, k, rc, q, threads, proportion_reads, output)
+        j.merge_parts = int(merge_parts)
+        _check(_lib.skh_build_sharded(self.ctx.h, self.h, C.byref(j)))
+
+    def align(self, names, inputs, output, k=31, rc=True, q=None, threads=1, proportion_reads=0.0, min_freq=0.9, filter_type=FILTER_NO_CONST,
+              mask_ambig=False, ignore_const_gaps=False, filter_ambig_as_missing=False):
+        j, keep = self._job(names, inputs, k, rc, q, threads, proportion_reads, output)
+        j.min_freq, j.filter_type, j.mask_ambig, j.ignore_const_gaps, j.filter_ambig_as_missing = min_freq, filter_type, int(mask_ambig), int(ignore_const_gaps), int(filter_ambig_as_missing)
+        _check(_lib.skh_align_sharded(self.ctx.h, self.h, C.byref(j)))
+
+    def distance(self, names, inputs, output, k=31, rc=True, q=None, threads=1, proportion_reads=0.0, min_freq=0.0, filt_ambig=True):
+        j, keep = self._job(names, inputs, k, rc, q, threads, proportion_reads, output)
+        j.min_freq, j.filt_ambig = min_freq, int(filt_ambig)
+        _check(_lib.skh_distance_sharded(self.ctx.h, self.h, C.byref(j)))
+
+    def free(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.skx_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.free()
 
 
 class DictSet:

@@ -22,7 +22,7 @@ def _bench(extra, env=None, launcher=()):
 
 def test_bench_two_ranks_on_one_gpu():
     port = str(29600 + os.getpid() % 300)
-    two = _bench(["--gpus", "2"], env={"SKX_BENCH_BACKEND": "gloo", "SKX_BENCH_DEVICE": "0"},
+    two = _bench(["--gpus", "2"], env={"SKX_BENCH_BACKEND": "gloo", "SKX_BENCH_DEVICE": "0"},      # gloo rendezvous -> the engine's host-staged transport
                  launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port))
     assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["steps"] == 2 and two["value"] > 0
     assert two["config"]["samples_total"] == 48 if "samples_total" in two["config"] else True
@@ -30,3 +30,12 @@ def test_bench_two_ranks_on_one_gpu():
     one = _bench(["--gpus", "1", "--genomes", "48"])
     assert one["n_gpus"] == 1
     assert two["config"]["rows_U"] == one["config"]["rows_U"], (two["config"], one["config"])      # the sharded row set is the single-rank row set
+
+
+def test_bench_sharded_path_on_rccl_at_world_one():
+    """SKX_BENCH_FORCE_SHARDED=1 on the default backend: bench.py's N > 1 step (skx_keyset_allgather + skx_array_reduce_stats over an
+    RCCL communicator) runs on the one-GPU box before an 8-GPU node ever sees it, and derives the rows of the unsharded step"""
+    forced = _bench(["--gpus", "1"], env={"SKX_BENCH_FORCE_SHARDED": "1", "MASTER_PORT": str(29400 + os.getpid() % 90)})
+    plain = _bench(["--gpus", "1"])
+    assert forced["exchange_per_step_rank0"]["transport"] == "rccl"
+    assert forced["config"]["rows_U"] == plain["config"]["rows_U"] and forced["config"]["rows_kept"] == plain["config"]["rows_kept"]

@@ -62,6 +62,112 @@ def test_multi_align_distance_build_equal_single_process(tmp_path, world):
     assert r1.returncode == 0 and r1.stdout == r2.stdout
 
 
+def _ska_ranks(world, *args, cwd, env=None):
+    """the executable's own launcher: `ska <cmd> --gpus N ...` starts N ranks of itself; SKX_COMM=local + SKX_DEVICE=0 let them share the GPU"""
+    e = dict(os.environ, SKX_COMM="local", SKX_DEVICE="0", **(env or {}))
+    r = subprocess.run([SKA, args[0], "--gpus", str(world), *args[1:]], cwd=cwd, capture_output=True, env=e, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:].decode(errors="replace")
+    return r
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ska_gpus_flag_equals_single_process(tmp_path, world):
+    """`ska build|align|distance --gpus N` (ranks forked by the executable, exchanges through skx_comm_*) == the single process"""
+    files, lst = _inputs(tmp_path, n=10, length=90_000, seed=21)
+    wd = str(tmp_path)
+    assert subprocess.run([SKA, "build", "-f", lst, "-o", "one", "--threads", "4"], cwd=wd, capture_output=True, timeout=300).returncode == 0
+    assert subprocess.run([SKA, "align", "one.skf", "-o", "one.aln", "--filter", "no-filter", "-m", "0.5"], cwd=wd, capture_output=True, timeout=300).returncode == 0
+    assert subprocess.run([SKA, "distance", "one.skf", "-o", "one.dist"], cwd=wd, capture_output=True, timeout=300).returncode == 0
+    _ska_ranks(world, "align", "-f", lst, "-o", "multi.aln", "--filter", "no-filter", "-m", "0.5", "--threads", "2", cwd=wd)
+    assert open(os.path.join(wd, "multi.aln"), "rb").read() == open(os.path.join(wd, "one.aln"), "rb").read()
+    _ska_ranks(world, "distance", "-f", lst, "-o", "multi.dist", "--threads", "2", cwd=wd)
+    assert open(os.path.join(wd, "multi.dist"), "rb").read() == open(os.path.join(wd, "one.dist"), "rb").read()
+    r = _ska_ranks(world, "distance", *files, "--threads", "2", cwd=wd)                 # sequence files given directly, table on rank 0's stdout
+    names_from_files = open(os.path.join(wd, "one.dist"), "rb").read()
+    assert r.stdout.count(b"\n") == names_from_files.count(b"\n")
+    _ska_ranks(world, "build", "-f", lst, "-o", "parts", "--threads", "2", "--merge", cwd=wd)
+    r1 = subprocess.run([SKA, "nk", "parts.skf", "--full-info"], cwd=wd, capture_output=True, timeout=300)
+    r2 = subprocess.run([SKA, "nk", "one.skf", "--full-info"], cwd=wd, capture_output=True, timeout=300)
+    assert r1.returncode == 0 and r1.stdout == r2.stdout
+    _ska_ranks(world, "build", "-f", lst, "-o", "keep", "--threads", "2", cwd=wd)          # without --merge: one valid .skf per rank
+    parts = [f"keep.part{r}of{world}.skf" for r in range(world)]
+    assert all(os.path.exists(os.path.join(wd, p)) for p in parts)
+    assert subprocess.run([SKA, "merge", "-o", "joined", *parts], cwd=wd, capture_output=True, timeout=300).returncode == 0
+    r3 = subprocess.run([SKA, "nk", "joined.skf", "--full-info"], cwd=wd, capture_output=True, timeout=300)
+    assert r3.stdout == r2.stdout
+    # a rank that fails takes the job down with the engine's message instead of leaving its peers in a collective
+    bad = str(tmp_path / "bad.txt")
+    open(bad, "w").write(open(lst).read().replace(files[-1], files[-1] + ".missing"))
+    r = subprocess.run([SKA, "align", "--gpus", str(world), "-f", bad, "-o", "x.aln"], cwd=wd, capture_output=True, timeout=300,
+                       env=dict(os.environ, SKX_COMM="local", SKX_DEVICE="0", SKX_COMM_TIMEOUT_S="30"))
+    assert r.returncode != 0
+
+
+def test_rccl_branches_run_at_world_one(tmp_path):
+    """The RCCL transport (ncclCommInitRank, ncclAllGather, ncclAllReduce on the engine's stream) executes on a one-GPU box at world
+    size 1: through the executable (`--gpus 1`), through ska_multi.py on the nccl backend, and through the ABI directly."""
+    files, lst = _inputs(tmp_path, n=9, length=80_000, seed=31)
+    wd = str(tmp_path)
+    assert subprocess.run([SKA, "build", "-f", lst, "-o", "one", "--threads", "4"], cwd=wd, capture_output=True, timeout=300).returncode == 0
+    assert subprocess.run([SKA, "align", "one.skf", "-o", "one.aln"], cwd=wd, capture_output=True, timeout=300).returncode == 0
+    assert subprocess.run([SKA, "distance", "one.skf", "-o", "one.dist", "--allow-ambiguous"], cwd=wd, capture_output=True, timeout=300).returncode == 0
+    env = {k: v for k, v in os.environ.items() if not k.startswith("SKX_COMM")}
+    r = subprocess.run([SKA, "align", "--gpus", "1", "-f", lst, "-o", "g1.aln", "--threads", "2"], cwd=wd, capture_output=True, env=dict(env, SKX_DEBUG="1"), timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:].decode(errors="replace")
+    assert open(os.path.join(wd, "g1.aln"), "rb").read() == open(os.path.join(wd, "one.aln"), "rb").read()
+    r = subprocess.run([SKA, "distance", "--gpus", "1", "-f", lst, "-o", "g1.dist", "--allow-ambiguous"], cwd=wd, capture_output=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:].decode(errors="replace")
+    assert open(os.path.join(wd, "g1.dist"), "rb").read() == open(os.path.join(wd, "one.dist"), "rb").read()
+    # ska_multi.py, default backend (nccl == RCCL), one rank
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port",
+           str(29900 + os.getpid() % 90), MULTI, "distance", "-f", lst, "-o", "m1.dist", "--allow-ambiguous", "--threads", "2", "--report", "rep.json"]
+    r = subprocess.run(cmd, cwd=wd, capture_output=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:].decode(errors="replace")
+    assert open(os.path.join(wd, "m1.dist"), "rb").read() == open(os.path.join(wd, "one.dist"), "rb").read()
+    import json
+    assert json.load(open(os.path.join(wd, "rep.json")))["transport"] == "rccl"
+    # the ABI directly: an RCCL communicator of one rank, in a process of its own so that its exit (RCCL / HIP teardown) is checked too
+    r = subprocess.run([sys.executable, "-c", _ABI_RCCL_WORLD_ONE, lst], cwd=wd, capture_output=True, env=env, timeout=600)
+    assert r.returncode == 0 and b"rccl world-1 ok" in r.stdout, (r.returncode, r.stderr[-1500:].decode(errors="replace"))
+    assert b"double free" not in r.stderr and b"corruption" not in r.stderr, r.stderr[-1500:]
+
+
+_ABI_RCCL_WORLD_ONE = r"""
+import os, sys
+import numpy as np
+ROOT = %r
+sys.path[:0] = [os.path.join(ROOT, "ska.rust_amd"), os.path.join(ROOT, "tests")]
+import torch             # before the engine opens RCCL: a process holds one copy of librccl, and PyTorch brings its own
+import skx_engine as E
+E.load_library()
+names, files = zip(*[l.split()[:2] for l in open(sys.argv[1])])
+names, files = list(names), list(files)
+ctx = E.Context(0)
+comm = E.Comm.rccl(0, 1, E.comm_unique_id(), ctx=ctx)
+assert (comm.rank, comm.world) == (0, 1)
+ds = E.DictSet.from_files([(f, None) for f in files], 31, True, threads=4, ctx=ctx)
+ks = ds.union_keys()
+rows = comm.keyset_allgather(ks)
+assert len(rows) == len(ks)
+arr = ds.assemble(rows, names)
+want = E.Array.build([(n, f, None) for n, f in zip(names, files)], k=31, threads=4, ctx=ctx)
+comm.reduce_stats(arr, len(files))
+assert all(np.array_equal(x, y) for x, y in zip(arr.export(), want.export()))
+constant = arr.filter(0, False, E.FILTER_NO_CONST, False, False, False)
+want.filter(0, False, E.FILTER_NO_CONST, False, False, False)
+for filt in (True, False):
+    assert np.array_equal(comm.distance_sharded(arr, len(files), filt, constant), want.distance(constant, filt))
+t = torch.arange(1000, dtype=torch.int32, device="cuda:0")
+out = torch.empty_like(t)
+comm.allgather_device(t.data_ptr(), out.data_ptr(), t.numel() * 4)
+comm.allreduce_u32_device(t.data_ptr(), t.numel())
+ctx.sync()
+assert torch.equal(out, t) and int(t[999]) == 999
+comm.free()
+print("rccl world-1 ok")
+""" % ROOT
+
+
 def test_distance_by_bands_equals_whole(tmp_path):
     import ora
     import skx_engine as E
