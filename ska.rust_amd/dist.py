@@ -59,3 +59,17 @@ def distance_tsv(names, table):
             out.append("%s\t%s\t%.2f\t%.5f\t%d\t%d\n" % (names[i], names[j], t["distance"], t["mismatch_prop"], int(t["match_count"]), int(t["mismatch_count"])))
             n += 1
     return "".join(out).encode()
+
+
+class DevicePtr:
+    """Zero-copy view of engine-owned device memory as a torch tensor (via __cuda_array_interface__)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def as_tensor(ptr, n, typestr, device):
+    import torch
+    if n == 0:
+        return torch.empty(0, dtype={"<i8": torch.int64, "<i4": torch.int32, "|u1": torch.uint8}[typestr], device=device)
+    return torch.as_tensor(DevicePtr(ptr, n, typestr), device=device)

@@ -5,6 +5,9 @@ One random ancestor, samples related through a balanced binary tree: every clade
 sprinkled with a few N runs and lower-case stretches, and every 10th sample is reverse-complemented, so
 the inputs exercise contig ends, N restarts, case folding and the canonical (rc) path.
 
+`write_read_pair` simulates BASELINE config 5's read sets from the same genomes (2 x 150 bp at 50x, 0.5 % substitution errors, a
+per-cycle Phred profile).
+
 Output is the engine's *record stream* (contig bases + '\\n' per contig) as a numpy uint8 array; `to_fasta`
 writes the same sample as a 60-column FASTA file for the CPU baseline.
 """
@@ -87,3 +90,34 @@ def to_fasta(stream, path, width=60):
             parts.append(np.frombuffer(b"\n", dtype=np.uint8))
     with open(path, "wb") as f:
         f.write(np.concatenate(parts).tobytes() if parts else b"")
+
+
+def write_read_pair(anc, index, n_samples, prefix, read_len=150, coverage=50.0, error_rate=0.005, seed=1):
+    """BASELINE.json configs[4] / SURVEY.md 8d: paired reads of sample `index` (2 x read_len at `coverage` x, substitution errors at
+    `error_rate` with low qualities, Phred from a fixed per-cycle profile with jitter, half of the reads reverse-complemented) as
+    plain FASTQ files <prefix>_1.fastq / <prefix>_2.fastq.  Deterministic in (seed, index).  Returns the two paths."""
+    g = sample_bases(anc, index, n_samples, seed=seed)
+    glen = len(g)
+    npairs = int(coverage * glen / read_len / 2)
+    rng = np.random.default_rng([seed, 99, index])
+    paths = []
+    for mate in (0, 1):
+        start = rng.integers(0, glen - read_len, size=npairs)
+        reads = g[start[:, None] + np.arange(read_len)[None, :]]
+        rev = rng.random(npairs) < 0.5
+        reads[rev] = _COMP[reads[rev][:, ::-1]]
+        err = rng.random(reads.shape) < error_rate
+        reads[err] = _ACGT[rng.integers(0, 4, size=int(err.sum()))]
+        prof = np.clip(38 - (np.arange(read_len) // 10), 2, 40)
+        q = np.clip(prof[None, :] + rng.integers(-6, 3, size=reads.shape), 2, 41).astype(np.uint8) + 33
+        q[err] = 33 + 8
+        rec = np.empty((npairs, 3 + read_len + 3 + read_len + 1), np.uint8)        # "@r\n" seq "\n+\n" qual "\n"
+        rec[:, 0:3] = np.frombuffer(b"@r\n", np.uint8)
+        rec[:, 3:3 + read_len] = reads
+        rec[:, 3 + read_len:6 + read_len] = np.frombuffer(b"\n+\n", np.uint8)
+        rec[:, 6 + read_len:6 + 2 * read_len] = q
+        rec[:, -1] = 10
+        p = f"{prefix}_{mate + 1}.fastq"
+        rec.tofile(p)
+        paths.append(p)
+    return paths

@@ -209,3 +209,130 @@ def test_config5_one_isolate_at_size(E, thousand):
         os.environ.pop("SKX_READS_SORT")
     k2, b2 = ds2.export(0)
     assert np.array_equal(k2["lo"], gk["lo"]) and np.array_equal(k2["hi"], gk["hi"]) and np.array_equal(b2, gb)
+
+
+@pytest.fixture(scope="module")
+def isolates(tmp_path_factory):
+    """eight read sets of BASELINE config 5's shape at their real size (2 x 150 bp at 50x of a 5 Mbp genome each: 2 x 126 MB of FASTQ)"""
+    import shutil
+    import synth
+    from concurrent.futures import ProcessPoolExecutor
+    td = _shm(tmp_path_factory)
+    anc = synth.ancestor(5_000_000, seed=1)
+    n = 8
+    import multiprocessing
+    with ProcessPoolExecutor(max_workers=min(n, os.cpu_count() or 1), mp_context=multiprocessing.get_context("spawn")) as ex:   # not a fork of a process that holds the GPU
+        pairs = list(ex.map(synth.write_read_pair, [anc] * n, range(n), [n] * n, [os.path.join(td, f"iso{i}") for i in range(n)]))
+    lst = os.path.join(td, "list.txt")
+    with open(lst, "w") as f:
+        for i, (a, b) in enumerate(pairs):
+            f.write(f"iso{i}\t{a}\t{b}\n")
+    yield td, [f"iso{i}" for i in range(n)], pairs, lst
+    shutil.rmtree(td, ignore_errors=True)
+
+
+def test_config5_flow_eight_isolates_at_size(E, isolates):
+    """BASELINE.json configs[4] as a flow on one GPU: paired FASTQ isolates -> `ska build -k 41 --min-count 5 --min-qual 20 --qual-filter
+    strict` -> .skf -> `ska distance` (both modes, with and without --min-freq) and `ska align`, against the oracle's build_and_merge
+    (ska_dict.rs:118-180 + bloom_filter.rs:116-148 per isolate, merge_ska_dict.rs append/merge) and generic_modes::distance / align
+    on the same files: the .skf read by the oracle is the oracle's own array row for row, the tables are byte-identical, the alignment
+    has the oracle's columns.  The sharded form (`--gpus 2`, ranks sharing the GPU) writes the same bytes."""
+    td, names, pairs, lst = isolates
+    opts = ["-k", "41", "--min-count", "5", "--min-qual", "20", "--qual-filter", "strict"]
+    r = subprocess.run([SKA, "build", "-f", lst, "-o", "c5", "--threads", "16", *opts], cwd=td, capture_output=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-800:]
+    want = ora.Array.build([(n, a, b) for n, (a, b) in zip(names, pairs)], k=41, rc=True, q=ora.qual(5, 20, ora.QUAL_STRICT), threads=8)
+    got = ora.Array.load(os.path.join(td, "c5.skf"))                  # the engine's file through the oracle's reader
+    assert got.names == names
+    got.sort_rows(); want.sort_rows()
+    gk, gv, gc = got.export()
+    ok, ov, oc = want.export()
+    assert 5_000_000 < len(ok) < 6_500_000                             # 128-bit keys: the u128 path
+    assert np.array_equal(gk["lo"], ok["lo"]) and np.array_equal(gk["hi"], ok["hi"]) and np.array_equal(gv, ov) and np.array_equal(gc, oc)
+    want.save(os.path.join(td, "oracle.skf"))                          # the oracle's filters work in place: a fresh copy per table
+    for flags, mf, filt in (([], 0.0, True), (["--allow-ambiguous"], 0.0, False), (["--min-freq", "0.9"], 0.9, True)):
+        r = subprocess.run([SKA, "distance", "c5.skf", "-o", "c5.tsv", *flags], cwd=td, capture_output=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-800:]
+        tsv = open(os.path.join(td, "c5.tsv"), "rb").read()
+        assert tsv == ora.Array.load(os.path.join(td, "c5.skf")).distance_tsv(mf, filt), flags
+        if filt:                                                        # integer counts: independent of the row order
+            assert tsv == ora.Array.load(os.path.join(td, "oracle.skf")).distance_tsv(mf, filt), flags
+    # (the oracle array the tables come from is the file's: it was shown equal to the oracle's own build above, and rows in file order
+    # keep the reference's f64 accumulation order out of the comparison for --allow-ambiguous)
+    r = subprocess.run([SKA, "align", "c5.skf", "-o", "c5.aln"], cwd=td, capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-800:]
+    g = open(os.path.join(td, "c5.aln"), "rb").read()
+    assert g == ora.Array.load(os.path.join(td, "c5.skf")).align(min_freq=0.9)          # file order kept: byte-identical
+    o = ora.Array.load(os.path.join(td, "oracle.skf")).align(min_freq=0.9)
+
+    def cols(aln):
+        rws = aln.split(b"\n")[1::2]
+        m = np.frombuffer(b"".join(rws), dtype=np.uint8).reshape(len(rws), -1)
+        return m[:, np.lexsort(m[::-1])]
+    assert g.split(b"\n")[0::2] == o.split(b"\n")[0::2] and np.array_equal(cols(g), cols(o))
+    # two ranks sharing the GPU, exchanges through skx_comm_* (host-staged transport)
+    env = dict(os.environ, SKX_COMM="local", SKX_DEVICE="0")
+    r = subprocess.run([SKA, "distance", "--gpus", "2", "-f", lst, "-o", "c5_2.tsv", "--threads", "8", *opts], cwd=td, capture_output=True, env=env, timeout=1200)
+    assert r.returncode == 0, r.stderr[-800:]
+    r = subprocess.run([SKA, "distance", "c5.skf", "-o", "c5.tsv"], cwd=td, capture_output=True, timeout=600)
+    assert open(os.path.join(td, "c5_2.tsv"), "rb").read() == open(os.path.join(td, "c5.tsv"), "rb").read()
+
+
+def test_config4_one_ranks_share(E):
+    """BASELINE.json configs[3] (8 000 assemblies over 8 GPUs, 100 private SNPs each), one rank's share on one GPU: the eight ranks'
+    key tables are built one after the other (each from its own 1 000 samples), united as skx_keyset_allgather unites them, and rank
+    0 fills its column slab over the ~50 M global rows.  The row set is checked against an independent union (torch.unique), columns
+    against the oracle's dictionaries of their samples, the slab's statistics against the columns."""
+    import torch
+    import synth
+    import dist as skdist
+    world, G = 8, 1000
+    n_total = world * G
+    dev = torch.device("cuda", 0)
+    anc = synth.ancestor(5_000_000, seed=1)
+    tables, ds0, streams0 = [], None, {}
+    for r in range(world):
+        streams = [synth.sample_stream(anc, r * G + i, n_total, private_snps=100).tobytes() for i in range(G)]
+        if r == 0:
+            streams0 = {i: streams[i] for i in (0, 9, 500, 999)}
+        ds = E.DictSet.build(streams, 31, True)
+        del streams
+        ks = ds.union_keys()
+        p, n, _ = ks.device()
+        tables.append(skdist.as_tensor(p, n, "<i8", dev).clone())
+        ks.free()
+        if r == 0:
+            ds0 = ds
+        else:
+            ds.free()
+    sets = [E.KeySet.from_device(t.data_ptr(), t.numel(), 31, True) for t in tables]
+    rows = E.KeySet.merge(sets)
+    U = len(rows)
+    assert 40_000_000 < U < 60_000_000
+    p, n, _ = rows.device()
+    got_rows = skdist.as_tensor(p, n, "<i8", dev)
+    want_rows = torch.unique(torch.cat(tables))                         # signed order != engine order: compare as sorted sets
+    assert want_rows.numel() == U and torch.equal(torch.sort(got_rows).values, want_rows)
+    del want_rows, tables, sets
+    arr = ds0.assemble(rows, [f"g{i}" for i in range(G)])              # 50 GB: the eager slab of rank 0
+    arr.set_total_samples(n_total)
+    assert arr.nrows == U and arr.nsamples == G
+    keys, counts = arr.export_keys()                                    # sorted by key, with the slab's per-row counts
+    assert int(counts.sum()) == sum(ds0.size(i) for i in range(G))
+    # columns against the oracle's dictionaries (index 9 is reverse-complemented by the generator)
+    pm, pitch, nrows = arr.device_matrix()
+    mat = skdist.as_tensor(pm, G * pitch, "|u1", dev).view(G, pitch)[:, :U]
+    pp = skdist.as_tensor(arr.device_stats()[0], U, "<i4", dev)
+    for c0 in range(0, U, 1 << 21):                                     # 50 GB of cells: a slice of rows at a time
+        c1 = min(U, c0 + (1 << 21))
+        assert torch.equal((mat[:, c0:c1] != ord("-")).sum(dim=0, dtype=torch.int32), pp[c0:c1]), c0
+    for i, s in streams0.items():
+        d = ora.Dict.new(31, True)
+        for rec in s.split(b"\n")[:-1]:
+            d.add_record(rec)
+        ok, ob = d.export()
+        gk, gb = ds0.export(i)
+        assert np.array_equal(gk["lo"], ok["lo"]) and np.array_equal(gb, ob), i
+        assert int((mat[i] != ord("-")).sum()) == len(ok), i            # the column holds exactly the sample's split k-mers
+        assert np.isin(ok["lo"], keys["lo"], assume_unique=True).all(), i
+    arr.free(); ds0.free()

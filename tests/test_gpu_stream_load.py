@@ -148,3 +148,59 @@ def test_keyless_array_refuses_key_operations(E, tmp_path, monkeypatch):
         arr.save(str(tmp_path / "again.skf"))
     with pytest.raises(E.EngineError):
         arr.export()
+
+
+def _reframe_small_chunks(raw, rng, lo, hi):
+    """a snappy frame -> the same stream cut into chunks of lo..hi uncompressed bytes (what another framer, or a writer that flushes
+    often, produces): compressed and uncompressed chunks mixed, each with its own masked CRC-32C"""
+    from test_gpu_parity import _masked_crc32c, _snappy_decode, _snappy_encode_random
+    assert raw[:10] == b"\xff\x06\x00\x00sNaPpY"
+    data = bytearray()
+    i = 10
+    while i < len(raw):
+        typ, ln = raw[i], int.from_bytes(raw[i + 1:i + 4], "little")
+        body = raw[i + 4:i + 4 + ln]
+        i += 4 + ln
+        data += _snappy_decode(body[4:]) if typ == 0 else bytes(body[4:])
+    out = bytearray(raw[:10])
+    p = 0
+    while p < len(data):
+        n = int(rng.integers(lo, hi + 1))
+        piece = bytes(data[p:p + n])
+        p += n
+        if rng.random() < 0.5:
+            enc = _snappy_encode_random(piece, rng)
+            out += b"\x00" + (len(enc) + 4).to_bytes(3, "little") + _masked_crc32c(piece).to_bytes(4, "little") + enc
+        else:
+            out += b"\x01" + (len(piece) + 4).to_bytes(3, "little") + _masked_crc32c(piece).to_bytes(4, "little") + piece
+    return bytes(out)
+
+
+@pytest.mark.parametrize("lo,hi", [(200, 3000), (1, 40), (30000, 65536)])
+def test_files_framed_in_small_chunks(E, tmp_path, monkeypatch, lo, hi):
+    """A valid .skf whose snappy chunks are smaller than 64 KB has more chunks than its size suggests: the one-pass reader takes them
+    in more groups (its buffers are sized for 64 KB chunks) or hands the file to the general reader when its chunk directory runs
+    out; either way the array, the alignment and the distances are those of the original file and of the oracle."""
+    rng = np.random.default_rng(lo * 7 + hi)
+    S, U = 5, (8000 if hi <= 40 else 60000)            # tiny chunks: more of them than the asynchronous walk reserves
+    keys, var = _random_array(E, rng, U, S)
+    names = [f"s{i}" for i in range(S)]
+    path, small = str(tmp_path / "a.skf"), str(tmp_path / "small.skf")
+    E.Array.from_host(31, True, names, keys, var).save(path)
+    open(small, "wb").write(_reframe_small_chunks(open(path, "rb").read(), rng, lo, hi))
+    assert ora.Array.load(small).nrows == len(keys)                    # a valid file: the oracle's reader takes it
+    for group in ("8192", "3"):
+        monkeypatch.setenv("SKX_SKF_GROUP_CHUNKS", group)
+        for ft, mf in ((E.FILTER_NO_CONST, 0.9), (E.FILTER_NONE, 0.0), (E.FILTER_NO_AMBIG_OR_CONST, 0.5)):
+            a, rem_a, _ = E.Array.load_filtered(path, mf, False, ft, False, False)
+            b, rem_b, _ = E.Array.load_filtered(small, mf, False, ft, False, False)
+            assert rem_a == rem_b and a.fasta() == b.fasta(), (group, ft, mf)
+            oa = ora.Array.load(small)
+            assert rem_b == oa.apply_filters(mf, False, ft, False, False) and b.fasta() == oa.fasta()
+            a.free(); b.free()
+        whole = E.Array.load(small)                                     # the general loader
+        k1, v1, c1 = whole.export()
+        k0, v0, c0 = E.Array.load(path).export()
+        assert np.array_equal(k1, k0) and np.array_equal(v1, v0) and np.array_equal(c1, c0)
+        d1 = E.Array.load(small).distance_tsv(0.0, True)
+        assert d1 == ora.Array.load(small).distance_tsv(0.0, True)
