@@ -629,8 +629,8 @@ size_t SkfFile::chunk_of(uint64_t u)
     while (lo < hi) { const size_t mid = (lo + hi) / 2; if (fr.chunks[mid].uoff + fr.chunks[mid].ulen <= u) lo = mid + 1; else hi = mid; }
     return lo;
 }
-// Header, then the split k-mer list is stepped over without being decoded: it is U uints, 9 bytes each unless a key is below
-// 2^32 (then the bytes at +9U are not the "variants" field and the caller takes the general reader).
+// Header, then the split k-mer list is stepped over without being decoded: for k <= 31 it is U uints, 9 bytes each unless a key is below
+// 2^32 (then the bytes at +9U are not the "variants" field and the caller takes the general reader); for k > 31 its items are walked.
 int SkfFile::open(const char *path)
 {
     FrameReader &fr = impl->fr;
@@ -650,7 +650,28 @@ int SkfFile::open(const char *path)
     n_keys = rd.array();
     if (!rd.ok || n_keys > (1ull << 40)) return SKF_NOT_TAKEN;
     upos_keys = fr.upos();
-    if (!fr.seek(upos_keys + 9 * n_keys)) return SKF_NOT_TAKEN;
+    if (m.k <= 31) {
+        if (!fr.seek(upos_keys + 9 * n_keys)) return SKF_NOT_TAKEN;
+    } else {
+        // 128-bit keys (lib.rs:592-622): uints below 2^64, tag-2 bignums of up to 16 bytes above -- variable length, so the list is walked
+        // (header bytes only: ~2 ns per key) instead of jumped over
+        fr.fill_limit = 0;
+        uint64_t j = 0;
+        while (j < n_keys) {
+            const uint8_t *p = fr.data(); const size_t av = fr.avail(); size_t o = 0;
+            while (j < n_keys && o + 19 <= av) {
+                const uint8_t c = p[o];
+                if (c == 0xC2) { const uint8_t b = p[o + 1]; if (b < 0x40 || b > 0x50) return SKF_NOT_TAKEN; o += 2 + (size_t)(b - 0x40); }
+                else if (c < 0x18) o += 1;
+                else if (c <= 0x1B) o += 1 + ((size_t)1 << (c - 0x18));
+                else return SKF_NOT_TAKEN;
+                j++;
+            }
+            fr.consume(o);
+            if (j < n_keys && o == 0) { (void)rd.key(); if (!rd.ok) return SKF_NOT_TAKEN; j++; }      // near the end of what is buffered: the general decoder refills
+        }
+        fr.fill_limit = 1u << 20;
+    }
     rd.ok = true;
     if (rd.text() != "variants" || !rd.ok) return SKF_NOT_TAKEN;
     uint64_t n3 = 0;

@@ -1121,6 +1121,11 @@ extern "C" int skx_array_assemble(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows
 }
 
 // ---- lazily held arrays -------------------------------------------------------------------------------------------------
+// the assemble kernel of the array's key width
+static void launch_assemble_lazy(skx_array *a, const AssembleArgs &aa, hipStream_t st, int mode, uint32_t n_blocks = 0)
+{
+    if (a->lazy_rows->wide) launch_assemble_wide(aa, st, mode, n_blocks); else launch_assemble(aa, st, mode, n_blocks);
+}
 static AssembleArgs lazy_args(skx_array *a, int *d_flag)
 {
     AssembleArgs aa{};
@@ -1140,8 +1145,11 @@ static int array_make_lazy(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows, const
     for (int i = 0; i < d->n; i++) a->names.emplace_back(names && names[i] ? names[i] : "");
     const uint64_t U = rows->total;
     a->n_rows = a->n_kmers = U; a->pitch = 0; a->engine_order = true; a->stats_ready = false;
-    SKX_TRY(a->present.alloc(U)); SKX_TRY(a->unambig.alloc(U)); SKX_TRY(a->mask.alloc(U)); SKX_TRY(a->keys.alloc(U)); SKX_TRY(a->vcount.alloc(U));
-    if (U) launch_gather_keys(rows->stage.p, rows->stride, rows->ncnt.p, rows->roff.p, 1 << rows->logN, a->keys.p, 0, rows->hp, st);
+    SKX_TRY(a->present.alloc(U)); SKX_TRY(a->unambig.alloc(U)); SKX_TRY(a->mask.alloc(U)); SKX_TRY(a->keys.alloc(U * rows->wpk())); SKX_TRY(a->vcount.alloc(U));
+    if (U) {
+        if (rows->wide) launch_gather_keys_wide((const u128 *)rows->stage.p, rows->stride, rows->ncnt.p, rows->roff.p, 1 << rows->logN, (u128 *)a->keys.p, st);
+        else launch_gather_keys(rows->stage.p, rows->stride, rows->ncnt.p, rows->roff.p, 1 << rows->logN, a->keys.p, 0, rows->hp, st);
+    }
     SKX_HIP(hipStreamSynchronize(st));
     *out = a.release();
     return SKX_OK;
@@ -1159,8 +1167,8 @@ extern "C" int skx_array_assemble_lazy(skx_ctx *ctx, skx_dictset *d, skx_keyset 
 {
     return skx_guarded([&]() -> int {
     if (!ctx || !d || !rows || !out) { skx_dictset_free(d); skx_keyset_free(rows); set_error("bad arguments"); return SKX_EINVAL; }
-    // the lazy form needs narrow keys and a row set slabbed at least as finely as the dictionaries' buckets; anything else is assembled at once
-    if (d->wide() || rows->k != d->k || rows->rc != d->rc || rows->logN < 0 || rows->logN < d->logB || d->n > 65535 || getenv("SKX_EAGER_ARRAY")) {
+    // the lazy form needs a row set slabbed at least as finely as the dictionaries' buckets; anything else is assembled at once
+    if (rows->wide != d->wide() || rows->k != d->k || rows->rc != d->rc || rows->logN < 0 || rows->logN < d->logB || d->n > 65535 || getenv("SKX_EAGER_ARRAY")) {
         const int r = skx_array_assemble(ctx, d, rows, names, out);
         skx_dictset_free(d); skx_keyset_free(rows);
         return r;
@@ -1177,7 +1185,7 @@ int skx::array_lazy_stats(skx_array *a)
     DevBuf<int> d_flag; SKX_TRY(d_flag.alloc(1)); SKX_TRY(d_flag.zero(st));
     if (a->n_rows) {
         AssembleArgs aa = lazy_args(a, d_flag.p);
-        { StageTimer t(ctx, &ctx->tm.assemble); launch_assemble(aa, st, 1); }
+        { StageTimer t(ctx, &ctx->tm.assemble); launch_assemble_lazy(a, aa, st, 1); }
         SKX_HIP(hipMemcpyAsync(a->vcount.p, a->present.p, a->n_rows * 4, hipMemcpyDeviceToDevice, st));     // merge_ska_array.rs:172
     }
     SKX_TRY(lazy_check_missing(a, d_flag));
@@ -1196,7 +1204,7 @@ int skx::array_materialize(skx_array *a)
     if (U) {
         AssembleArgs aa = lazy_args(a, d_flag.p);
         aa.matrix = a->matrix.p; aa.pitch = a->pitch;
-        { StageTimer t(ctx, &ctx->tm.assemble); launch_assemble(aa, st, 0); }
+        { StageTimer t(ctx, &ctx->tm.assemble); launch_assemble_lazy(a, aa, st, 0); }
         if (!a->stats_ready) SKX_HIP(hipMemcpyAsync(a->vcount.p, a->present.p, U * 4, hipMemcpyDeviceToDevice, st));
     }
     SKX_TRY(lazy_check_missing(a, d_flag));
@@ -1222,7 +1230,7 @@ int skx::array_lazy_window(skx_array *a, uint64_t r0, uint64_t nr, DevBuf<uint8_
     DevBuf<int> d_flag; SKX_TRY(d_flag.alloc(1)); SKX_TRY(d_flag.zero(st));
     AssembleArgs aa = lazy_args(a, d_flag.p);
     aa.matrix = buf.p; aa.pitch = wp; aa.j_base = (uint32_t)j0; aa.col_base = c0;
-    { StageTimer t(ctx, &ctx->tm.assemble); launch_assemble(aa, st, 0, (uint32_t)(j1 - j0)); }
+    { StageTimer t(ctx, &ctx->tm.assemble); launch_assemble_lazy(a, aa, st, 0, (uint32_t)(j1 - j0)); }
     SKX_TRY(lazy_check_missing(a, d_flag));
     *win = buf.p + (r0 - c0); *wpitch = wp;
     return SKX_OK;
@@ -1297,7 +1305,7 @@ static int build_range(skx_ctx *ctx, const char *const *names, const char *const
     int r = skx_dictset_build_files(ctx, file1 + lo, file2 ? file2 + lo : nullptr, hi - lo, k, rc, q, threads, proportion_reads, &d);
     if (r == SKX_OK) {
         const auto t0 = std::chrono::steady_clock::now();
-        if (!d->wide() && !getenv("SKX_EAGER_ARRAY")) {
+        if (!getenv("SKX_EAGER_ARRAY")) {
             // rows now, cells on demand: the array keeps the dictionaries (see skx_array::lazy_dict)
             skx_keyset *ks = nullptr;
             r = skx_keyset_union(ctx, d, &ks);
@@ -1528,7 +1536,7 @@ static int array_compact(skx_array *a, DevBuf<uint8_t> &keep, DevBuf<uint64_t> &
             DevBuf<int> d_flag; SKX_TRY(d_flag.alloc(1)); SKX_TRY(d_flag.zero(st));
             AssembleArgs aa = lazy_args(a, d_flag.p);
             aa.matrix = nm.p; aa.pitch = np; aa.keep = keep.p; aa.kpos = pos.p; aa.mask_ambig = mask_ambig;
-            { StageTimer t2(ctx, &ctx->tm.assemble); launch_assemble(aa, st, 2); }
+            { StageTimer t2(ctx, &ctx->tm.assemble); launch_assemble_lazy(a, aa, st, 2); }
             SKX_TRY(lazy_check_missing(a, d_flag));
         } else
             launch_compact_matrix(a->matrix.p, a->pitch, nm.p, np, (int)S, U, keep.p, pos.p, mask_ambig, st);

@@ -504,7 +504,7 @@ extern "C" int skx_array_load_filtered(skx_ctx *ctx, const char *path, const skx
         if (r != SKX_OK) return r;
     }
     const uint64_t U = sf.m.n_rows, S = sf.m.names.size();
-    if (!U || !S || sf.m.k > 31) return load_then_filter(ctx, path, f, out, removed, constant);
+    if (!U || !S) return load_then_filter(ctx, path, f, out, removed, constant);
     SKX_TRY(check_k(sf.m.k));
     // the stored counts, parsed beside the device work
     std::vector<uint32_t> counts; int tail_rc = SKX_OK; std::string tail_err;

@@ -214,7 +214,7 @@ void launch_dedupe_wide(u128 *words, const uint64_t *off, const uint32_t *raw, u
 void launch_union_wide(const DictView &d, int logN, u128 *stage, uint32_t stride, uint32_t *ncnt, uint32_t table_slots, int *overflow,
                        hipStream_t st);
 void launch_union_probe_wide(const DictView &d, int logP, int probe, uint32_t *cnt, uint32_t table_slots, int *overflow, hipStream_t st);
-void launch_assemble_wide(const AssembleArgs &a, hipStream_t st);      // a.stage addresses u128 slabs
+void launch_assemble_wide(const AssembleArgs &a, hipStream_t st, int mode = 0, uint32_t n_blocks = 0);      // a.stage addresses u128 slabs; modes as launch_assemble
 void launch_gather_keys_wide(const u128 *stage, uint32_t stride, const uint32_t *ncnt, const uint64_t *roff, int n_sub, u128 *out,
                              hipStream_t st);
 

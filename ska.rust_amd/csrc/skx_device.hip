@@ -86,6 +86,15 @@ __device__ static inline uint32_t block_excl_scan(uint32_t v, uint32_t *s_tmp, u
 // SPLIT: the staging buffer holds half a tile at a time (the lower half of the bucket space, then the upper half), so a
 // 12 288-position tile needs 57 KB of LDS instead of 105 KB and two 768-thread workgroups share a CU (85-VGPR cap), with
 // the same (tile, bucket) chunks in the word buffer as single-pass staging would write.
+#ifndef SKX_EXT_TILECONTIG
+#define SKX_EXT_TILECONTIG 0      // 1 | 2: measurement only (tools/ab_extract.sh): the write pattern of a tile-local layout, without | with the cursor atomics
+#endif
+#ifndef SKX_EXT_W32
+#define SKX_EXT_W32 0
+#endif
+#ifndef SKX_EXT_BRANCHFREE
+#define SKX_EXT_BRANCHFREE 0
+#endif
 template <bool SCATTER, int TILE, bool HI, int PPT, bool SPLIT, int RMAX>
 __global__ __launch_bounds__(TILE / PPT, SPLIT ? 6 : 1) void extract_kernel(ExtractArgs a)
 {
@@ -210,10 +219,23 @@ __global__ __launch_bounds__(TILE / PPT, SPLIT ? 6 : 1) void extract_kernel(Extr
             uint32_t hl = gt ? rc_upper : upper, hr = gt ? rc_lower : lower;
             const uint32_t m4 = (1u << (gt ? rc_mid : mid)) | (eq ? (1u << rc_mid) : 0u);
             hmix_halves(hl, hr, a.hp);
+#if SKX_EXT_W32
+            // HI: the hashed upper arm starts in the word's upper half (hb + 4 >= 32): the word from 32-bit pieces, no 64-bit shifts
+            const uint64_t w = HI ? ((uint64_t)((hl << (hb + 4 - 32)) | (hb > 28 ? hr >> 28 : 0u)) << 32) | (uint32_t)((hr << 4) | m4)
+                                  : ((uint64_t)hl << (hb + 4)) | ((uint64_t)hr << 4) | m4;
+#else
             const uint64_t w = ((uint64_t)hl << (hb + 4)) | ((uint64_t)hr << 4) | m4;
+#endif
             wv[16 * half + j] = w;
             const bool valid = (vm >> j) & 1u;
+#if SKX_EXT_BRANCHFREE
+            // the bucket of every window, valid or not, then one select: a wave-uniform branch around the invalid ones costs more than
+            // the shift it saves (s_and_saveexec + two scalar branches per window in the ISA)
+            const uint32_t bk_any = top_from_hl ? hl >> top_shift : (uint32_t)((w >> 4) >> bshift);
+            const uint32_t bk = valid ? bk_any : (uint32_t)B;
+#else
             const uint32_t bk = valid ? (top_from_hl ? hl >> top_shift : (uint32_t)((w >> 4) >> bshift)) : (uint32_t)B;
+#endif
             const uint32_t r = atomicAdd(&s_hist[bk], 1u);
             rk[16 * half + j] = ((valid ? bk : 0xFFFFu) << 16) | (r & 0xFFFFu);
         }
@@ -232,7 +254,11 @@ __global__ __launch_bounds__(TILE / PPT, SPLIT ? 6 : 1) void extract_kernel(Extr
 #pragma unroll
     for (int r = 0; r < RMAX; r++) {
         gb[r] = 0;
+#if SKX_EXT_TILECONTIG == 1
+        if (b0 + r < b1) { const uint32_t n = s_hist[b0 + r]; lsum += n; }                   // (experiment: no cursor atomics)
+#else
         if (b0 + r < b1) { const uint32_t n = s_hist[b0 + r]; if (n) gb[r] = atomicAdd(&ghist[b0 + r], n); lsum += n; }
+#endif
     }
     uint32_t total;
     uint32_t lrun = block_excl_scan(lsum, s_tmp, &total);
@@ -275,6 +301,9 @@ __global__ __launch_bounds__(TILE / PPT, SPLIT ? 6 : 1) void extract_kernel(Extr
         const uint64_t w = s_stage[i];
         const uint32_t b = HI ? (uint32_t)(w >> 32) >> bsh_hi : (uint32_t)((w >> 4) >> bshift);
         uint32_t r = s_base[b] + i;
+#if SKX_EXT_TILECONTIG
+        r = (uint32_t)T0 + i + (s_base[b] & 0u);                              // (experiment: the tile's words in one contiguous piece)
+#endif
         r = r < span_last ? r : span_last;                                    // an overflowing chunk must not leave the sample's span
         out[r] = w;
     }
@@ -287,6 +316,9 @@ __global__ __launch_bounds__(TILE / PPT, SPLIT ? 6 : 1) void extract_kernel(Extr
             const uint64_t w = s_stage[i - HALF];
             const uint32_t b = HI ? (uint32_t)(w >> 32) >> bsh_hi : (uint32_t)((w >> 4) >> bshift);
             uint32_t r = s_base[b] + i;
+#if SKX_EXT_TILECONTIG
+            r = (uint32_t)T0 + i + (s_base[b] & 0u);
+#endif
             r = r < span_last ? r : span_last;
             out[r] = w;
         }

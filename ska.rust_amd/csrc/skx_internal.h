@@ -140,7 +140,7 @@ struct skx_array {
     skx::DevBuf<uint64_t> planes;    // bit planes of the distance sweep (skx_array_distance_planes)
     bool keys_absent = false;        // loaded through skx_array_load_filtered: the split k-mer list was stepped over
     std::shared_ptr<skx::Preallocator> prealloc;   // output pages being allocated for skx_array_write_fasta (skx_ctx_expect_output)
-    // Lazily held (the build path, 64-bit keys): rows, keys and names are known but the rows x samples matrix has not been
+    // Lazily held (the build path): rows, keys and names are known but the rows x samples matrix has not been
     // assembled; the dictionaries and the row keyset are kept instead.  `ska build` streams such an array into its .skf window
     // by window and `ska align *.fa` filters it before any cell is written, so neither ever holds the unfiltered matrix;
     // every other operation assembles it first (skx::array_materialize).

@@ -43,17 +43,18 @@ def _files(tmp_path, n=9, length=60_000, snps=120, seed=3):
 
 def _sorted(arr):
     k, v, c = arr.export()
-    o = np.argsort(k["lo"], kind="stable")
-    return k["lo"][o], v[o], c[o]
+    o = np.lexsort((k["lo"], k["hi"]))                          # 128-bit keys (k > 31) order by (hi, lo)
+    return k["lo"][o], k["hi"][o], v[o], c[o]
 
 
-def test_lazy_save_streams_the_same_file_rows(E, tmp_path, monkeypatch):
+@pytest.mark.parametrize("k", [31, 41])                        # 64- and 128-bit keys: the same lazily held form (lib.rs:592-622)
+def test_lazy_save_streams_the_same_file_rows(E, tmp_path, monkeypatch, k):
     inputs = _files(tmp_path)
-    oa = ora.Array.build(inputs, k=31)
+    oa = ora.Array.build(inputs, k=k)
     want = _sorted(oa)
     monkeypatch.setenv("SKX_SKF_DEVICE", "1")
     monkeypatch.setenv("SKX_SKF_GROUP_CHUNKS", "2")              # several windows
-    lazy = E.Array.build(inputs, k=31, threads=3)
+    lazy = E.Array.build(inputs, k=k, threads=3)
     assert list(lazy.sample_kmers()) == [int(x) for x in (oa.export()[1] != ord("-")).sum(axis=0)]      # answered from the dictionaries
     p = str(tmp_path / "lazy.skf")
     lazy.save(p)                                                 # still lazy: windows
@@ -62,7 +63,7 @@ def test_lazy_save_streams_the_same_file_rows(E, tmp_path, monkeypatch):
         assert np.array_equal(x, y)
     monkeypatch.setenv("SKX_SKF_DEVICE", "0")                    # host codec: rows fetched block by block
     p2 = str(tmp_path / "lazy_host.skf")
-    E.Array.build(inputs, k=31, threads=3).save(p2)
+    E.Array.build(inputs, k=k, threads=3).save(p2)
     for x, y in zip(_sorted(ora.Array.load(p2)), want):
         assert np.array_equal(x, y)
     # and the materialised array is the same array
@@ -70,27 +71,29 @@ def test_lazy_save_streams_the_same_file_rows(E, tmp_path, monkeypatch):
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("k", [15, 41])
 @pytest.mark.parametrize("min_freq", [0.0, 0.5, 0.9, 1.0])
-def test_lazy_filter_writes_only_kept_rows(E, tmp_path, monkeypatch, min_freq):
+def test_lazy_filter_writes_only_kept_rows(E, tmp_path, monkeypatch, min_freq, k):
     inputs = _files(tmp_path, n=7, length=30_000, seed=11)
-    for ft, amb, mask, gaps in FILTERS:
-        lazy = E.Array.build(inputs, k=15, threads=2)
+    for ft, amb, mask, gaps in (FILTERS if k == 15 else FILTERS[::3]):
+        lazy = E.Array.build(inputs, k=k, threads=2)
         g = lazy.align(filter_type=ft, mask_ambig=mask, ignore_const_gaps=gaps, min_freq=min_freq, filter_ambig_as_missing=amb)
         monkeypatch.setenv("SKX_EAGER_ARRAY", "1")
-        eager = E.Array.build(inputs, k=15, threads=2)
+        eager = E.Array.build(inputs, k=k, threads=2)
         monkeypatch.delenv("SKX_EAGER_ARRAY")
         e = eager.align(filter_type=ft, mask_ambig=mask, ignore_const_gaps=gaps, min_freq=min_freq, filter_ambig_as_missing=amb)
         assert g == e, (ft, amb, mask, gaps)                     # same engine order either way: byte-identical
-        oa = ora.Array.build(inputs, k=15)
+        oa = ora.Array.build(inputs, k=k)
         o = oa.align(filter_type=ft, mask_ambig=mask, ignore_const_gaps=gaps, min_freq=min_freq, filter_ambig_as_missing=amb)
         assert sorted(zip(*g.decode().splitlines()[1::2])) == sorted(zip(*o.decode().splitlines()[1::2])), (ft, amb, mask, gaps)
 
 
-def test_lazy_filter_then_export_and_counts(E, tmp_path):
+@pytest.mark.parametrize("k", [21, 41])
+def test_lazy_filter_then_export_and_counts(E, tmp_path, k):
     inputs = _files(tmp_path, n=6, length=25_000, seed=21)
     for ft, amb, mask, gaps in FILTERS[::5]:
-        lazy = E.Array.build(inputs, k=21, threads=2)
-        oa = ora.Array.build(inputs, k=21)
+        lazy = E.Array.build(inputs, k=k, threads=2)
+        oa = ora.Array.build(inputs, k=k)
         assert lazy.filter(3, amb, ft, mask, gaps, True) == oa.filter(3, amb, ft, mask, gaps, True)
         for x, y in zip(_sorted(lazy), _sorted(oa)):
             assert np.array_equal(x, y), (ft, amb, mask, gaps)
@@ -112,7 +115,8 @@ def test_lazy_array_other_operations_materialise(E, tmp_path):
         assert np.array_equal(x, y)
 
 
-def test_assemble_lazy_equals_assemble(E, tmp_path):
+@pytest.mark.parametrize("k", [31, 41])
+def test_assemble_lazy_equals_assemble(E, tmp_path, k):
     """skx_array_assemble_lazy (the multi-GPU ranks' form: rows from elsewhere + the local dictionaries, no matrix) == skx_array_assemble:
     statistics without a matrix, the filter writing kept rows only, the streamed .skf, the full export."""
     inputs = _files(tmp_path, n=6, length=40_000, seed=41)
@@ -121,7 +125,7 @@ def test_assemble_lazy_equals_assemble(E, tmp_path):
     names = [nm for nm, _, _ in inputs]
 
     def both():
-        ds = E.DictSet.build(recs, 31, True)
+        ds = E.DictSet.build(recs, k, True)
         rows = ds.union_keys()
         return ds, rows
     ds, rows = both()

@@ -204,3 +204,47 @@ def test_files_framed_in_small_chunks(E, tmp_path, monkeypatch, lo, hi):
         assert np.array_equal(k1, k0) and np.array_equal(v1, v0) and np.array_equal(c1, c0)
         d1 = E.Array.load(small).distance_tsv(0.0, True)
         assert d1 == ora.Array.load(small).distance_tsv(0.0, True)
+
+
+@pytest.mark.parametrize("S,U", [(4, 70000), (33, 9000)])
+def test_one_pass_load_with_128_bit_keys(E, tmp_path, monkeypatch, S, U):
+    """k = 41 (lib.rs:635-661: the u128 file): the split k-mer list holds items of every length -- small uints, 9-byte uints, tag-2
+    bignums of 9 to 11 bytes -- and is walked, not jumped over; the rows then stream through the same one-pass load + filter as 64-bit
+    files: == load-then-filter == the oracle, for `align`'s filters and `distance`'s two stages."""
+    rng = np.random.default_rng(4100 + S)
+    keys, var = _random_array(E, rng, U, S)
+    n = len(keys)
+    kind = rng.integers(0, 6, size=n)
+    keys["hi"] = np.where(kind >= 2, rng.integers(1, 1 << 16, size=n, dtype=np.uint64), 0)      # most beyond 64 bits
+    keys["lo"][kind == 0] = np.unique(rng.integers(0, 1 << 30, size=n * 2, dtype=np.uint64))[: int((kind == 0).sum())] | np.uint64(1 << 31)   # short uints
+    keys["lo"][:4] = [3, 200, 60000, 1 << 40]                          # 1-, 2-, 3- and 9-byte items
+    keys["hi"][:4] = 0
+    _, first = np.unique(keys, return_index=True)                      # distinct (hi, lo) pairs only
+    keys, var = keys[np.sort(first)], var[np.sort(first)]
+    names = [f"s{i}" for i in range(S)]
+    monkeypatch.setenv("SKX_SKF_DEVICE", "1")
+    monkeypatch.setenv("SKX_SKF_GROUP_CHUNKS", "2")
+    path = str(tmp_path / "wide.skf")
+    E.Array.from_host(41, True, names, keys, var).save(path)
+    assert ora.Array.load(path).nrows == len(keys)
+    E.phases(reset=True)
+    for ft, amb, mask, gaps, mf in [(1, False, False, False, 0.9), (0, False, False, False, 0.0), (3, True, True, False, 0.5), (2, False, True, True, 1.0)]:
+        fast, rem_f, _ = E.Array.load_filtered(path, mf, amb, ft, mask, gaps)
+        monkeypatch.setenv("SKX_NO_STREAM_LOAD", "1")
+        slow, rem_s, _ = E.Array.load_filtered(path, mf, amb, ft, mask, gaps)
+        monkeypatch.delenv("SKX_NO_STREAM_LOAD")
+        oa = ora.Array.load(path)
+        assert rem_f == rem_s == oa.apply_filters(mf, amb, ft, mask, gaps), (ft, amb, mask, gaps, mf)
+        assert fast.fasta() == slow.fasta() == oa.fasta(), (ft, amb, mask, gaps, mf)
+        fast.free(); slow.free()
+    assert "load.stream_decode_filter" in E.phases()                   # the one-pass reader took the file
+    for mf, filt in ((0.0, True), (0.6, False)):
+        a, _, constant = E.Array.load_filtered(path, mf, False, 1, False, False, two_stage=True)
+        d = a.distance(constant, filt)
+        oa = ora.Array.load(path)
+        if mf * S >= 1.0:
+            oa.filter(int(np.ceil(S * mf)), False, ora.FILTER_NONE, False, False, False)
+        oc = oa.filter(0, False, ora.FILTER_NO_CONST, False, False, False)
+        od = oa.distance(oc, filt)
+        assert constant == oc and np.array_equal(d["match_count"], od["match_count"]) and np.array_equal(d["mismatch_count"], od["mismatch_count"])
+        assert np.allclose(d["distance"], od["distance"], rtol=0, atol=1e-6)
