@@ -614,6 +614,9 @@ void launch_dedupe(uint64_t *words, const uint64_t *off, const uint32_t *raw, ui
     hipLaunchKernelGGL(dedupe_kernel, dim3((unsigned)n_regions), dim3(256), lds, st, words, off, raw, ucnt, table_slots, rem_bits, overflow, min_n, sidx, sb);
 }
 
+#ifndef SKX_DEDUPE_GROUPED
+#define SKX_DEDUPE_GROUPED 1
+#endif
 // K3 (fast path): counting sort of a region into micro-buckets of ~2-4 words by the next hash bits, then a tiny
 // per-thread insertion sort with duplicate folding (OR of base masks).  No CAS loops, no data-dependent probe
 // chains: cost is O(n) LDS operations per region whatever the duplication level.
@@ -642,6 +645,9 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_mem + (size_t)cap * 8 + 32) + 1;   // (four sentinel words first) [-1] = 0 | [M] counts -> cursors (= bucket ends) -> leader counts
     int logM = 31 - __clz(n);                                                // ~1..2 words per micro-bucket
     if (logM < 0) logM = 0;
+#if SKX_DEDUPE_GROUPED
+    if (logM < 10) logM = 10;                                                // grouped output: slices are cut at micro-bucket boundaries, so small
+#endif                                                                       // regions are split as finely as any later row split (<= 2^10 sub-buckets per bucket)
     if (logM > rem_bits) logM = rem_bits;
     while ((1u << logM) > cap) logM--;
     const uint32_t M = 1u << logM;
@@ -680,6 +686,75 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
     // keys at lower positions; equal keys also fold their base masks together.
     // The three dependent LDS reads per word (the word, its micro-bucket's bounds, the bucket's first slots) are issued
     // for all of the thread's words at once, stage by stage, so a thread waits for three round trips instead of 3 x ITEMS.
+#if SKX_DEDUPE_GROUPED
+    // A region leaves this kernel GROUPED by its micro-buckets (the next logM hash bits), duplicates folded, but not ordered inside a
+    // micro-bucket: a SkaDict is a hash map (ska_dict.rs:71-113), nothing downstream reads a region in key order -- the union table and
+    // the assemble look-up take words one by one, their slices are cut at sub-bucket boundaries, which are micro-bucket boundaries
+    // (logM >= min_logM >= the slicing depth), and skx_dictset_export sorts by key on the host.  That removes the rank of every word
+    // among its bucket's keys, the second pass through LDS and its two barriers: a fifth of the kernel's instructions.
+    uint32_t bb[ITEMS], ee[ITEMS];
+#pragma unroll
+    for (int t = 0; t < ITEMS; t++) { const uint32_t p = threadIdx.x + (uint32_t)NT * t; e[t] = s_elem[p < n ? p : n - 1]; }
+#pragma unroll
+    for (int t = 0; t < ITEMS; t++) asm volatile("" : "+v"(e[t]));
+#pragma unroll
+    for (int t = 0; t < ITEMS; t++) { const uint32_t m = word_field<HI>(e[t], mshift, M - 1); bb[t] = s_cnt[(int)m - 1]; ee[t] = s_cnt[m]; }
+#pragma unroll
+    for (int t = 0; t < ITEMS; t++) asm volatile("" : "+v"(bb[t]), "+v"(ee[t]));
+    uint32_t flags = 0, sflags = 0;
+    const int subshift = rem_bits - sb + 4;                 // sub-range of a word = its next sb hash bits
+    const uint32_t submask = (1u << sb) - 1;
+#pragma unroll
+    for (int t = 0; t < ITEMS; t++) {
+        const uint32_t p = threadIdx.x + (uint32_t)NT * t;
+        if (p >= n) { e[t] = 0; continue; }
+        const uint64_t w0 = e[t], w0lo = w0 & ~15ull;
+        const uint32_t b = bb[t], eend = ee[t];
+        // does the key occur again in its micro-bucket?  Branch-free over the bucket's first NS slots: a slot past the bucket's end holds
+        // a word of a later bucket or one of the four all-ones sentinels behind the region's last word -- never this key
+        constexpr uint32_t NS = 4;                                             // micro-buckets hold ~1.2 words on average
+        uint64_t wq[NS];
+#pragma unroll
+        for (uint32_t u = 0; u < NS; u++) wq[u] = s_elem[b + u];             // reads in flight whatever the bucket's size
+        const uint64_t pred = p ? s_elem[p - 1] : ~w0;                        // the word before this one, for the sub-range test below
+#pragma unroll
+        for (uint32_t u = 0; u < NS; u++) asm volatile("" : "+v"(wq[u]));     // (keeps the compiler from sinking each read into its own branch)
+        uint32_t same = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < NS; u++) same += (wq[u] & ~15ull) == w0lo ? 1u : 0u;
+        bool dup = same > (p - b < NS ? 1u : 0u);                            // the word itself is one of the slots when it lies in the first NS
+        for (uint32_t j = b + NS; j < eend; j++) dup |= j != p && (s_elem[j] & ~15ull) == w0lo;      // longer buckets finish in a loop
+        bool lead = true;
+        uint32_t mor = (uint32_t)w0 & 15u;
+        if (dup) {                                                           // rare: the first occurrence keeps the key, with every occurrence's bases
+            uint32_t eqb = 0;
+            for (uint32_t j = b; j < eend; j++) {
+                const uint64_t w = s_elem[j];
+                const bool iseq = (w & ~15ull) == w0lo;
+                eqb += iseq && j < p;
+                mor |= iseq ? (uint32_t)w & 15u : 0u;
+            }
+            lead = eqb == 0;
+        }
+        e[t] = w0lo | mor;
+        if (lead) flags |= 1u << t;
+        // first word of a new sub-range <=> a bit at or above subshift differs from the word before (all words of a region agree above
+        // rem_bits + 4; such a word is the first occurrence of its key: an equal key would lie in the same micro-bucket, before it)
+        const uint64_t x = pred ^ w0;
+        if (HI ? (uint32_t)(x >> 32) >= (1u << (subshift - 32)) : x >= (1ull << subshift)) sflags |= 1u << t;
+    }
+    __syncthreads();                                        // every bucket bound has been read: the cursor array becomes the (row, wave) table
+    constexpr int NW = NT / 64;
+    uint32_t *s_rows = s_cnt;                               // [ITEMS][NW] leaders per (row, wave)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t below[ITEMS];
+#pragma unroll
+    for (int t = 0; t < ITEMS; t++) {
+        const unsigned long long bal = __ballot((flags >> t) & 1u);
+        below[t] = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (lane == 0) s_rows[t * NW + wv] = __popcll(bal);
+    }
+#else
     uint32_t npos[ITEMS], bb[ITEMS], ee[ITEMS];
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) { const uint32_t p = threadIdx.x + (uint32_t)NT * t; e[t] = s_elem[p < n ? p : n - 1]; }
@@ -760,6 +835,7 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
         if (lead) flags |= 1u << t;
         if (lane == 0) s_rows[t * NW + wv] = __popcll(bal);
     }
+#endif
     __syncthreads();
     // counts per (row, wave) -> exclusive prefix in output order (one wave, entries i and i + 64), total at [ITEMS * 4]
     if (wv == 0) {
