@@ -893,7 +893,8 @@ static int keyset_finish(skx_keyset *ks)      // scan ncnt -> roff, total, max_r
 }
 
 // union over several dict views (one per source) into one keyset
-static int keyset_union_views(skx_ctx *ctx, const DictView *views, int nviews, int k, int rc, HashParams hp, uint64_t est_hint, skx_keyset **out)
+static int keyset_union_views(skx_ctx *ctx, const DictView *views, int nviews, int k, int rc, HashParams hp, uint64_t est_hint, skx_keyset **out,
+                              const skx_dictset *side_for = nullptr)
 {
     const bool wide = k > 31;
     const WideHash wh = make_wide_hash(k);
@@ -904,6 +905,7 @@ static int keyset_union_views(skx_ctx *ctx, const DictView *views, int nviews, i
     for (int v = 0; v < nviews; v++) min_logN = std::max(min_logN, views[v].logB);
     const uint32_t table = wide ? 4096 : 8192, stride = wide ? 2048 : 4096, target = wide ? 1200 : 2500;
     int logN = std::max(min_logN, std::min(kbits, ilog2_ceil((est_hint + target - 1) / target)));
+    DevBuf<uint16_t> side_buf;                     // kept across retries at a finer split
     for (;; logN++) {
         std::unique_ptr<skx_keyset> ks(new skx_keyset());
         ks->ctx = ctx; ks->k = k; ks->rc = rc; ks->logN = logN; ks->hp = hp; ks->wh = wh; ks->wide = wide; ks->stride = stride;
@@ -911,8 +913,16 @@ static int keyset_union_views(skx_ctx *ctx, const DictView *views, int nviews, i
         SKX_TRY(ks->stage.alloc(nsub * stride * ks->wpk())); SKX_TRY(ks->ncnt.alloc(nsub));
         SKX_TRY(d_flag.zero(st));
         if (nviews == 1) {
+            // side_for: the assemble over these dictionaries follows (skx_merge): the pass also notes where every word's key went, 2 bytes
+            // per word, and the matrix is then filled from the notes instead of a second read of the dictionaries
+            const bool with_side = side_for && !wide && union_side_ok(views[0], logN, stride) && !getenv("SKX_NO_MERGE_SIDE");
             if (wide) launch_union_wide(views[0], logN, (u128 *)ks->stage.p, stride, ks->ncnt.p, table, d_flag.p, st);
-            else launch_union(views[0], logN, ks->stage.p, stride, ks->ncnt.p, table, d_flag.p, st);
+            else if (with_side) {
+                if (!side_buf.p) SKX_TRY(side_buf.alloc(side_for->words.n));
+                SKX_TRY(ks->perm.alloc(nsub * stride));
+                launch_union_side(views[0], logN, ks->stage.p, stride, ks->ncnt.p, 7168u, d_flag.p, side_buf.p, ks->perm.p, st);
+                ks->side_of = side_for;
+            } else launch_union(views[0], logN, ks->stage.p, stride, ks->ncnt.p, table, d_flag.p, st);
         } else {
             set_error("multi-source union goes through keyset_merge"); return SKX_EINVAL;
         }
@@ -925,14 +935,20 @@ static int keyset_union_views(skx_ctx *ctx, const DictView *views, int nviews, i
             continue;
         }
         SKX_TRY(keyset_finish(ks.get()));
+        if (ks->side_of) ks->side = std::move(side_buf);
         *out = ks.release();
         return SKX_OK;
     }
 }
 
+static int keyset_union_dict(skx_ctx *ctx, skx_dictset *d, skx_keyset **out, bool with_side);
 extern "C" int skx_keyset_union(skx_ctx *ctx, skx_dictset *d, skx_keyset **out)
 {
-    return skx_guarded([&]() -> int {
+    return skx_guarded([&]() -> int { return keyset_union_dict(ctx, d, out, false); });
+}
+static int keyset_union_dict(skx_ctx *ctx, skx_dictset *d, skx_keyset **out, bool with_side)
+{
+    {
     if (!ctx || !d || !out) { set_error("bad arguments"); return SKX_EINVAL; }
     SKX_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -956,8 +972,8 @@ extern "C" int skx_keyset_union(skx_ctx *ctx, skx_dictset *d, skx_keyset **out)
         if (!ov) est = std::max<uint64_t>(maxs, (uint64_t)((double)cnt * (double)(1ull << logP) / probe * 1.1));
         else est = sum;
     }
-    return keyset_union_views(ctx, &v, 1, d->k, d->rc, d->hp, est, out);
-    });
+    return keyset_union_views(ctx, &v, 1, d->k, d->rc, d->hp, est, out, with_side ? d : nullptr);
+    }
 }
 
 int skx::keyset_flatten(skx_keyset *ks)
@@ -1105,7 +1121,12 @@ extern "C" int skx_array_assemble(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows
         aa.d = d->view(); aa.logN = rows->logN; aa.stage = rows->stage.p; aa.stride = rows->stride; aa.ncnt = rows->ncnt.p; aa.roff = rows->roff.p;
         aa.matrix = a->matrix.p; aa.pitch = a->pitch; aa.col_present = a->present.p; aa.col_unambig = a->unambig.p; aa.col_mask = a->mask.p;
         aa.max_rows = rows->max_rows; aa.missing = d_flag.p;
-        { StageTimer t(ctx, &ctx->tm.assemble); if (rows->wide) launch_assemble_wide(aa, st); else launch_assemble(aa, st); }
+        {
+            StageTimer t(ctx, &ctx->tm.assemble);
+            if (rows->wide) launch_assemble_wide(aa, st);
+            else if (rows->side.p && rows->side_of == d && !rebuilt) launch_assemble_side(aa, rows->side.p, rows->perm.p, st);      // the union over d left its notes
+            else launch_assemble(aa, st);
+        }
         if (rows->wide) launch_gather_keys_wide((const u128 *)rows->stage.p, rows->stride, rows->ncnt.p, rows->roff.p, 1 << rows->logN, (u128 *)a->keys.p, st);
         else launch_gather_keys(rows->stage.p, rows->stride, rows->ncnt.p, rows->roff.p, 1 << rows->logN, a->keys.p, 0, rows->hp, st);
         SKX_HIP(hipMemcpyAsync(a->vcount.p, a->present.p, U * 4, hipMemcpyDeviceToDevice, st));     // merge_ska_array.rs:172
@@ -1240,7 +1261,7 @@ extern "C" int skx_merge(skx_ctx *ctx, skx_dictset *d, const char *const *names,
 {
     return skx_guarded([&]() -> int {
     skx_keyset *ks = nullptr;
-    SKX_TRY(skx_keyset_union(ctx, d, &ks));
+    SKX_TRY(keyset_union_dict(ctx, d, &ks, true));
     int r = skx_array_assemble(ctx, d, ks, names, out);
     skx_keyset_free(ks);
     return r;

@@ -140,8 +140,14 @@ struct AssembleArgs {
     const uint8_t *keep = nullptr; const uint64_t *kpos = nullptr;    // mode 2: row flags (1 = kept) and their exclusive scan [U + 1]
     int mask_ambig = 0;        // mode 2: ambiguous cells are written as 'N' (MergeSkaArray::filter's ambig_mask)
 };
-// mode 0: matrix + statistics; 1: statistics only; 2: kept rows only (64-bit keys; the k > 31 kernel has mode 0 alone)
+// mode 0: matrix + statistics; 1: statistics only; 2: kept rows only
 void launch_assemble(const AssembleArgs &a, hipStream_t st, int mode = 0, uint32_t n_blocks = 0);
+// the union that also notes, per word of the dictionaries, where its key went (side: one u16 per element of d.words; perm: [2^logN][stride]
+// u16), and the assemble that fills the matrix from those notes instead of the words (64-bit keys, whole array, mode 0)
+bool union_side_ok(const DictView &d, int logN, uint32_t stride);
+void launch_union_side(const DictView &d, int logN, uint64_t *stage, uint32_t stride, uint32_t *ncnt, uint32_t table_slots, int *overflow,
+                       uint16_t *side, uint16_t *perm, hipStream_t st);
+void launch_assemble_side(const AssembleArgs &a, const uint16_t *side, const uint16_t *perm, hipStream_t st);
 
 // compact slabs into one array; unhash=1 converts engine-order words back to reference keys
 void launch_gather_keys(const uint64_t *stage, uint32_t stride, const uint32_t *ncnt, const uint64_t *roff, int n_sub,

@@ -543,6 +543,22 @@ __device__ static inline bool table_insert(unsigned long long *tab, uint32_t tot
     }
     return false;
 }
+// as table_insert, reporting where the key lives: 0 = table full, 1 = the key was there, 2 = this call put it there
+__device__ static inline int table_insert_slot(unsigned long long *tab, uint32_t total_slots, uint32_t home, uint64_t w, uint32_t &slot)
+{
+    const uint64_t key = w >> 4;
+    for (uint32_t i = home; i < total_slots; ++i) {
+        unsigned long long old = tab[i];
+        bool mine = false;
+        if (old == 0ull) { old = atomicCAS(&tab[i], 0ull, (unsigned long long)w); mine = old == 0ull; }
+        if (mine) { slot = i; return 2; }
+        if ((old >> 4) == key) {
+            if ((old | w) != old) atomicOr(&tab[i], (unsigned long long)(w & 15ull));
+            slot = i; return 1;
+        }
+    }
+    return 0;
+}
 // sorted emit of the table; f(idx, word) is called once per distinct key with its rank; returns the count
 template <typename F>
 __device__ static inline uint32_t table_emit_sorted(const unsigned long long *tab, uint32_t total_slots, uint32_t *s_tmp, F f)
@@ -561,6 +577,28 @@ __device__ static inline uint32_t table_emit_sorted(const unsigned long long *ta
         for (int64_t j = (int64_t)i - 1; j >= 0; j--) { unsigned long long o = tab[j]; if (!o) break; gl += o > w; }
         for (uint32_t j = i + 1; j < total_slots; j++) { unsigned long long o = tab[j]; if (!o) break; lr += o < w; }
         f(c - gl + lr, (uint64_t)w);
+        c++;
+    }
+    return total;
+}
+// the same, f(idx, word, slot)
+template <typename F>
+__device__ static inline uint32_t table_emit_sorted_slot(const unsigned long long *tab, uint32_t total_slots, uint32_t *s_tmp, F f)
+{
+    const uint32_t per = (total_slots + blockDim.x - 1) / blockDim.x;
+    const uint32_t lo = threadIdx.x * per;
+    const uint32_t hi = lo + per < total_slots ? lo + per : total_slots;
+    uint32_t cnt = 0;
+    for (uint32_t i = lo; i < hi; i++) cnt += tab[i] != 0ull;
+    uint32_t total;
+    uint32_t c = block_excl_scan(cnt, s_tmp, &total);
+    for (uint32_t i = lo; i < hi; i++) {
+        const unsigned long long w = tab[i];
+        if (!w) continue;
+        uint32_t gl = 0, lr = 0;
+        for (int64_t j = (int64_t)i - 1; j >= 0; j--) { unsigned long long o = tab[j]; if (!o) break; gl += o > w; }
+        for (uint32_t j = i + 1; j < total_slots; j++) { unsigned long long o = tab[j]; if (!o) break; lr += o < w; }
+        f(c - gl + lr, (uint64_t)w, i);
         c++;
     }
     return total;
@@ -614,9 +652,9 @@ void launch_dedupe(uint64_t *words, const uint64_t *off, const uint32_t *raw, ui
     hipLaunchKernelGGL(dedupe_kernel, dim3((unsigned)n_regions), dim3(256), lds, st, words, off, raw, ucnt, table_slots, rem_bits, overflow, min_n, sidx, sb);
 }
 
-#ifndef SKX_DEDUPE_GROUPED
-#define SKX_DEDUPE_GROUPED 1
-#endif
+// (Leaving a region grouped by micro-bucket but unordered inside -- all its consumers need, and 5 % cheaper here: 20.05 -> 19.05 ms -- was
+// measured and dropped: union and assemble then run at less than half their rate (8.4 -> 19.9 ms, 14.9 -> 28.4 ms), because with sorted
+// slices neighbouring lanes look up neighbouring table slots / rows in LDS; profiles/r03j_ab_grouped_full.log.)
 // K3 (fast path): counting sort of a region into micro-buckets of ~2-4 words by the next hash bits, then a tiny
 // per-thread insertion sort with duplicate folding (OR of base masks).  No CAS loops, no data-dependent probe
 // chains: cost is O(n) LDS operations per region whatever the duplication level.
@@ -645,9 +683,6 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_mem + (size_t)cap * 8 + 32) + 1;   // (four sentinel words first) [-1] = 0 | [M] counts -> cursors (= bucket ends) -> leader counts
     int logM = 31 - __clz(n);                                                // ~1..2 words per micro-bucket
     if (logM < 0) logM = 0;
-#if SKX_DEDUPE_GROUPED
-    if (logM < 10) logM = 10;                                                // grouped output: slices are cut at micro-bucket boundaries, so small
-#endif                                                                       // regions are split as finely as any later row split (<= 2^10 sub-buckets per bucket)
     if (logM > rem_bits) logM = rem_bits;
     while ((1u << logM) > cap) logM--;
     const uint32_t M = 1u << logM;
@@ -686,75 +721,6 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
     // keys at lower positions; equal keys also fold their base masks together.
     // The three dependent LDS reads per word (the word, its micro-bucket's bounds, the bucket's first slots) are issued
     // for all of the thread's words at once, stage by stage, so a thread waits for three round trips instead of 3 x ITEMS.
-#if SKX_DEDUPE_GROUPED
-    // A region leaves this kernel GROUPED by its micro-buckets (the next logM hash bits), duplicates folded, but not ordered inside a
-    // micro-bucket: a SkaDict is a hash map (ska_dict.rs:71-113), nothing downstream reads a region in key order -- the union table and
-    // the assemble look-up take words one by one, their slices are cut at sub-bucket boundaries, which are micro-bucket boundaries
-    // (logM >= min_logM >= the slicing depth), and skx_dictset_export sorts by key on the host.  That removes the rank of every word
-    // among its bucket's keys, the second pass through LDS and its two barriers: a fifth of the kernel's instructions.
-    uint32_t bb[ITEMS], ee[ITEMS];
-#pragma unroll
-    for (int t = 0; t < ITEMS; t++) { const uint32_t p = threadIdx.x + (uint32_t)NT * t; e[t] = s_elem[p < n ? p : n - 1]; }
-#pragma unroll
-    for (int t = 0; t < ITEMS; t++) asm volatile("" : "+v"(e[t]));
-#pragma unroll
-    for (int t = 0; t < ITEMS; t++) { const uint32_t m = word_field<HI>(e[t], mshift, M - 1); bb[t] = s_cnt[(int)m - 1]; ee[t] = s_cnt[m]; }
-#pragma unroll
-    for (int t = 0; t < ITEMS; t++) asm volatile("" : "+v"(bb[t]), "+v"(ee[t]));
-    uint32_t flags = 0, sflags = 0;
-    const int subshift = rem_bits - sb + 4;                 // sub-range of a word = its next sb hash bits
-    const uint32_t submask = (1u << sb) - 1;
-#pragma unroll
-    for (int t = 0; t < ITEMS; t++) {
-        const uint32_t p = threadIdx.x + (uint32_t)NT * t;
-        if (p >= n) { e[t] = 0; continue; }
-        const uint64_t w0 = e[t], w0lo = w0 & ~15ull;
-        const uint32_t b = bb[t], eend = ee[t];
-        // does the key occur again in its micro-bucket?  Branch-free over the bucket's first NS slots: a slot past the bucket's end holds
-        // a word of a later bucket or one of the four all-ones sentinels behind the region's last word -- never this key
-        constexpr uint32_t NS = 4;                                             // micro-buckets hold ~1.2 words on average
-        uint64_t wq[NS];
-#pragma unroll
-        for (uint32_t u = 0; u < NS; u++) wq[u] = s_elem[b + u];             // reads in flight whatever the bucket's size
-        const uint64_t pred = p ? s_elem[p - 1] : ~w0;                        // the word before this one, for the sub-range test below
-#pragma unroll
-        for (uint32_t u = 0; u < NS; u++) asm volatile("" : "+v"(wq[u]));     // (keeps the compiler from sinking each read into its own branch)
-        uint32_t same = 0;
-#pragma unroll
-        for (uint32_t u = 0; u < NS; u++) same += (wq[u] & ~15ull) == w0lo ? 1u : 0u;
-        bool dup = same > (p - b < NS ? 1u : 0u);                            // the word itself is one of the slots when it lies in the first NS
-        for (uint32_t j = b + NS; j < eend; j++) dup |= j != p && (s_elem[j] & ~15ull) == w0lo;      // longer buckets finish in a loop
-        bool lead = true;
-        uint32_t mor = (uint32_t)w0 & 15u;
-        if (dup) {                                                           // rare: the first occurrence keeps the key, with every occurrence's bases
-            uint32_t eqb = 0;
-            for (uint32_t j = b; j < eend; j++) {
-                const uint64_t w = s_elem[j];
-                const bool iseq = (w & ~15ull) == w0lo;
-                eqb += iseq && j < p;
-                mor |= iseq ? (uint32_t)w & 15u : 0u;
-            }
-            lead = eqb == 0;
-        }
-        e[t] = w0lo | mor;
-        if (lead) flags |= 1u << t;
-        // first word of a new sub-range <=> a bit at or above subshift differs from the word before (all words of a region agree above
-        // rem_bits + 4; such a word is the first occurrence of its key: an equal key would lie in the same micro-bucket, before it)
-        const uint64_t x = pred ^ w0;
-        if (HI ? (uint32_t)(x >> 32) >= (1u << (subshift - 32)) : x >= (1ull << subshift)) sflags |= 1u << t;
-    }
-    __syncthreads();                                        // every bucket bound has been read: the cursor array becomes the (row, wave) table
-    constexpr int NW = NT / 64;
-    uint32_t *s_rows = s_cnt;                               // [ITEMS][NW] leaders per (row, wave)
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t below[ITEMS];
-#pragma unroll
-    for (int t = 0; t < ITEMS; t++) {
-        const unsigned long long bal = __ballot((flags >> t) & 1u);
-        below[t] = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        if (lane == 0) s_rows[t * NW + wv] = __popcll(bal);
-    }
-#else
     uint32_t npos[ITEMS], bb[ITEMS], ee[ITEMS];
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) { const uint32_t p = threadIdx.x + (uint32_t)NT * t; e[t] = s_elem[p < n ? p : n - 1]; }
@@ -835,7 +801,6 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
         if (lead) flags |= 1u << t;
         if (lane == 0) s_rows[t * NW + wv] = __popcll(bal);
     }
-#endif
     __syncthreads();
     // counts per (row, wave) -> exclusive prefix in output order (one wave, entries i and i + 64), total at [ITEMS * 4]
     if (wv == 0) {
@@ -984,18 +949,28 @@ __device__ static inline void sub_slice(const DictView &d, int sample, uint64_t 
 #ifndef SKX_UNION_PREFETCH
 #define SKX_UNION_PREFETCH 0
 #endif
-template <bool COUNT_ONLY, bool FAST>
+// SIDE: the pass also leaves, for every word of every dictionary, WHERE its key went -- side[word index] = (first-seen rank of the key
+// in its sub-bucket << 4) | base set, 16 bits -- and per sub-bucket the map first-seen rank -> sorted row (perm).  assemble_side_kernel
+// then fills the matrix from those 2 bytes per word instead of reading the 8-byte words again and looking every key up a second time
+// (merge_ska_dict.rs:77-109 appends a sample in one pass over its dictionary: so does this pair of kernels, up to the 2-byte note).
+// A key gets its rank from the lane whose CAS put it into the table; a lane of another wave that meets the key before the rank is
+// written (0xFFFF) takes the slow path and waits for it there.
+template <bool COUNT_ONLY, bool FAST, bool SIDE>
 __global__ __launch_bounds__(1024, 8) void union_kernel(DictView d, int logN, uint64_t *stage, uint32_t stride, uint32_t *ncnt,
-                                                    uint32_t nslots, int *overflow)
+                                                    uint32_t nslots, int *overflow, uint16_t *side, uint16_t *perm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_tab[];
     __shared__ uint32_t s_tmp[17];
     __shared__ int s_fail;
+    __shared__ uint32_t s_nrows;
     const uint64_t j = blockIdx.x;
     const uint32_t total_slots = nslots + TABLE_PAD;
-    for (uint32_t i = threadIdx.x; i < total_slots; i += blockDim.x) s_tab[i] = 0ull;
-    if (threadIdx.x == 0) s_fail = 0;
+    uint16_t *s_rank = reinterpret_cast<uint16_t *>(s_tab + total_slots);      // SIDE: [total_slots] first-seen rank of the key in each slot
+    for (uint32_t i = threadIdx.x; i < total_slots; i += blockDim.x) { s_tab[i] = 0ull; if (SIDE) s_rank[i] = 0xFFFFu; }
+    if (threadIdx.x == 0) { s_fail = 0; s_nrows = 0; }
     __syncthreads();
+    typedef uint16_t __attribute__((address_space(1))) *gside_t;
+    gside_t gside = (gside_t)(uintptr_t)side;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int rem_bits = d.bits - logN;
     // every lane binary-searches the slice of one sample; the wave then streams the 64 slices one after another
@@ -1019,27 +994,56 @@ __global__ __launch_bounds__(1024, 8) void union_kernel(DictView d, int logN, ui
         };
         auto absorb = [&](const uint64_t (&q)[UU], gwords_t reg, uint32_t first) {
             uint32_t miss = 0;
+            const uint64_t sbase = SIDE ? (uint64_t)((const uint64_t *)reg - d.words) + first + lane : 0;      // this lane's first word in the side array
 #pragma unroll
             for (int g = 0; g < UU; g += 3) {
-                unsigned long long s0[3], s1[3];
+                unsigned long long s0[3], s1[3]; uint32_t hs[3];
 #pragma unroll
                 for (int u = 0; u < 3; u++) {                            // home slot and its successor (one ds_read2_b64): a key displaced by
                     if (g + u >= UU) continue;                           // one slot is still a hit
                     const uint32_t hslot = home_slot_t<FAST>(q[g + u], rem_bits, nslots);
-                    s0[u] = s_tab[hslot]; s1[u] = s_tab[hslot + 1];
+                    s0[u] = s_tab[hslot]; s1[u] = s_tab[hslot + 1]; hs[u] = hslot;
                 }
+                uint32_t rkq[3];
 #pragma unroll
                 for (int u = 0; u < 3; u++) {
                     if (g + u >= UU) continue;
                     const uint64_t w = q[g + u];
-                    const unsigned long long at = ((s0[u] ^ w) >> 4) == 0ull ? s0[u] : (s0[u] != 0ull && ((s1[u] ^ w) >> 4) == 0ull) ? s1[u] : 0ull;
+                    const bool at0 = ((s0[u] ^ w) >> 4) == 0ull;
+                    const unsigned long long at = at0 ? s0[u] : (s0[u] != 0ull && ((s1[u] ^ w) >> 4) == 0ull) ? s1[u] : 0ull;
                     if (w && (w & 15ull & ~at) != 0ull) miss |= 1u << (g + u);      // not found, or found without this base in its mask
+                    if (SIDE) rkq[u] = s_rank[hs[u] + (at0 ? 0u : 1u)];
+                }
+                if (SIDE) {
+#pragma unroll
+                    for (int u = 0; u < 3; u++) {
+                        if (g + u >= UU) continue;
+                        const uint64_t w = q[g + u];
+                        if (!w || ((miss >> (g + u)) & 1u)) continue;
+                        if (rkq[u] == 0xFFFFu) { miss |= 1u << (g + u); continue; }       // the key is there, its rank is still being written
+                        gside[sbase + 64u * (g + u)] = (uint16_t)((rkq[u] << 4) | ((uint32_t)w & 15u));
+                    }
                 }
             }
             while (miss) {                                               // first sightings, new bases, keys displaced further: the word is
                 const int u = __ffs(miss) - 1; miss &= miss - 1;         // read again (L2 / L1 hit) rather than selected from q[] by a
                 const uint64_t w = reg[first + 64u * u + lane];          // run-time index, which would put the batch into scratch memory
-                if (!table_insert(s_tab, total_slots, home_slot_t<FAST>(w, rem_bits, nslots), w)) s_fail = 1;
+                if (!SIDE) { if (!table_insert(s_tab, total_slots, home_slot_t<FAST>(w, rem_bits, nslots), w)) s_fail = 1; }
+                else {
+                    uint32_t sl = 0;
+                    const int res = table_insert_slot(s_tab, total_slots, home_slot_t<FAST>(w, rem_bits, nslots), w, sl);
+                    if (res == 0) { s_fail = 1; continue; }
+                    // two statements, in this order: the lanes that put a key there write its rank before any lane of the wave waits for
+                    // one (an if / else would let the compiler run the waiting side first, with the writers of the same wave masked off)
+                    uint32_t r = 0xFFFFu;
+                    if (res == 2) { r = atomicAdd(&s_nrows, 1u); reinterpret_cast<volatile uint16_t *>(s_rank)[sl] = (uint16_t)r; }
+                    __builtin_amdgcn_wave_barrier();
+                    if (res == 1) {                                       // (bounded: a rank that never arrives fails the launch instead of hanging it)
+                        for (int it = 0; it < (1 << 16) && r == 0xFFFFu; it++) r = reinterpret_cast<volatile uint16_t *>(s_rank)[sl];
+                        if (r == 0xFFFFu) s_fail = 1;
+                    }
+                    gside[sbase + 64u * u] = (uint16_t)((r << 4) | ((uint32_t)w & 15u));
+                }
             }
         };
         uint64_t nx[UU]; uint32_t nlo, nhi; gwords_t nreg;
@@ -1073,8 +1077,15 @@ __global__ __launch_bounds__(1024, 8) void union_kernel(DictView d, int logN, ui
         return;
     }
     uint64_t *slab = stage + j * (uint64_t)stride;
-    uint32_t total = table_emit_sorted(s_tab, total_slots, s_tmp, [&](uint32_t idx, uint64_t w) { if (idx < stride) slab[idx] = (w & ~15ull) | 1ull; });
-    if (threadIdx.x == 0) { ncnt[j] = total; if (total > stride) *overflow = 1; }
+    uint32_t total;
+    if (!SIDE) total = table_emit_sorted(s_tab, total_slots, s_tmp, [&](uint32_t idx, uint64_t w) { if (idx < stride) slab[idx] = (w & ~15ull) | 1ull; });
+    else {
+        uint16_t *pj = perm + j * (uint64_t)stride;                    // first-seen rank -> sorted row of the sub-bucket
+        total = table_emit_sorted_slot(s_tab, total_slots, s_tmp, [&](uint32_t idx, uint64_t w, uint32_t slot) {
+            if (idx < stride) { slab[idx] = (w & ~15ull) | 1ull; const uint32_t r = s_rank[slot]; if (r < stride) pj[r] = (uint16_t)idx; }
+        });
+    }
+    if (threadIdx.x == 0) { ncnt[j] = total; if (total > stride || (SIDE && total > 4095u)) *overflow = 1; }
 }
 template <bool COUNT_ONLY>
 static void launch_union_t(const DictView &d, int logN, unsigned blocks, uint64_t *stage, uint32_t stride, uint32_t *ncnt, uint32_t table_slots,
@@ -1083,12 +1094,22 @@ static void launch_union_t(const DictView &d, int logN, unsigned blocks, uint64_
     size_t lds = (size_t)(table_slots + TABLE_PAD) * 8;
     const int rem = d.bits - logN;
     if (rem >= 32 && rem <= 59) {
-        (void)hipFuncSetAttribute((const void *)union_kernel<COUNT_ONLY, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((union_kernel<COUNT_ONLY, true>), dim3(blocks), dim3(1024), lds, st, d, logN, stage, stride, ncnt, table_slots, overflow);
+        (void)hipFuncSetAttribute((const void *)union_kernel<COUNT_ONLY, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((union_kernel<COUNT_ONLY, true, false>), dim3(blocks), dim3(1024), lds, st, d, logN, stage, stride, ncnt, table_slots, overflow, (uint16_t *)nullptr, (uint16_t *)nullptr);
     } else {
-        (void)hipFuncSetAttribute((const void *)union_kernel<COUNT_ONLY, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((union_kernel<COUNT_ONLY, false>), dim3(blocks), dim3(1024), lds, st, d, logN, stage, stride, ncnt, table_slots, overflow);
+        (void)hipFuncSetAttribute((const void *)union_kernel<COUNT_ONLY, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((union_kernel<COUNT_ONLY, false, false>), dim3(blocks), dim3(1024), lds, st, d, logN, stage, stride, ncnt, table_slots, overflow, (uint16_t *)nullptr, (uint16_t *)nullptr);
     }
+}
+// the union that also notes where every word went (side: one u16 per word of d.words; perm: [2^logN][stride] u16); the caller checks
+// union_side_ok first
+bool union_side_ok(const DictView &d, int logN, uint32_t stride) { const int rem = d.bits - logN; return rem >= 32 && rem <= 59 && stride <= 4096u; }
+void launch_union_side(const DictView &d, int logN, uint64_t *stage, uint32_t stride, uint32_t *ncnt, uint32_t table_slots, int *overflow,
+                       uint16_t *side, uint16_t *perm, hipStream_t st)
+{
+    size_t lds = (size_t)(table_slots + TABLE_PAD) * 10;
+    (void)hipFuncSetAttribute((const void *)union_kernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((union_kernel<false, true, true>), dim3(1u << logN), dim3(1024), lds, st, d, logN, stage, stride, ncnt, table_slots, overflow, side, perm);
 }
 void launch_union(const DictView &d, int logN, uint64_t *stage, uint32_t stride, uint32_t *ncnt, uint32_t table_slots,
                   int *overflow, hipStream_t st)
@@ -1278,6 +1299,111 @@ __global__ __launch_bounds__(512, SKX_ASM_WPS) void assemble_kernel(AssembleArgs
         a.col_unambig[r0 + i] = s_cnt[i] >> 16;
         a.col_mask[r0 + i] = (s_msk[i >> 1] >> (16u * (i & 1u))) & 0xFFFFu;
     }
+}
+
+// K5': the matrix from the union's notes (union_kernel<.., SIDE>): per word 2 bytes -- (first-seen rank of its key in the sub-bucket << 4) |
+// base set -- instead of the 8-byte word, and no key look-up: perm[rank] is the row.  Same output as assemble_kernel<0>.
+__global__ __launch_bounds__(512, SKX_ASM_WPS) void assemble_side_kernel(AssembleArgs a, const uint16_t *side, const uint16_t *perm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    const uint64_t j = (uint64_t)blockIdx.x + a.j_base;
+    const uint32_t n = a.ncnt[j];
+    if (n == 0) return;
+    const uint32_t maxr = (a.max_rows + 15u) & ~15u;
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_raw);               // [maxr] present | unambiguous << 16
+    uint32_t *s_msk = s_cnt + maxr;                                       // [maxr/2] 16-bit code sets, two rows per word
+    uint16_t *s_perm = reinterpret_cast<uint16_t *>(s_msk + maxr / 2);    // [maxr] first-seen rank -> row
+    unsigned char *s_rows = reinterpret_cast<unsigned char *>(s_perm + maxr);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const uint16_t *pj = perm + j * (uint64_t)a.stride;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { s_cnt[i] = 0; if (!(i & 1u)) s_msk[i >> 1] = 0; s_perm[i] = pj[i]; }
+    __syncthreads();
+    const uint64_t r0 = a.roff[j];
+    const uint64_t ocol = r0 - a.col_base;
+    const uint32_t shift = (uint32_t)(ocol & 15u);
+    unsigned char *row = s_rows + (size_t)wv * (maxr + 32u);
+    typedef const uint16_t __attribute__((address_space(1))) *gside_t;
+    gside_t gs = (gside_t)(uintptr_t)side;
+    const uint64_t *wbase = a.d.words;
+    const int per = (a.d.n_samples + nw - 1) / nw;
+    const int wend = (wv + 1) * per < a.d.n_samples ? (wv + 1) * per : a.d.n_samples;
+    constexpr int AU = SKX_ASM_U;
+    for (int sbase = wv * per; sbase < wend; sbase += 64) {
+        uint64_t my_off = 0; uint32_t my_lo = 0, my_hi = 0;
+        const int cnt = wend - sbase < 64 ? wend - sbase : 64;
+        if (lane < cnt) {
+            const uint64_t *my_reg = nullptr;
+            sub_slice(a.d, sbase + lane, j, a.logN, my_reg, my_lo, my_hi);
+            my_off = (uint64_t)(my_reg - wbase);
+        }
+        auto fetch = [&](int t, uint32_t (&q)[AU], uint32_t &lo, uint32_t &hi) {
+            const uint64_t off = __shfl((unsigned long long)my_off, t, 64);
+            lo = __shfl(my_lo, t, 64); hi = __shfl(my_hi, t, 64);
+#pragma unroll
+            for (int u = 0; u < AU; u++) { const uint32_t i = lo + 64u * u + lane; q[u] = i < hi ? (uint32_t)gs[off + i] : 0xFFFFFFFFu; }
+        };
+        auto place = [&](const uint32_t (&q)[AU]) {
+            uint32_t rr[AU];
+#pragma unroll
+            for (int u = 0; u < AU; u++) rr[u] = q[u] != 0xFFFFFFFFu ? (uint32_t)s_perm[(q[u] >> 4) < n ? (q[u] >> 4) : 0u] : 0u;      // independent LDS reads
+#pragma unroll
+            for (int u = 0; u < AU; u++) {
+                if (q[u] == 0xFFFFFFFFu) continue;
+                if ((q[u] >> 4) >= n) { *a.missing = 1; continue; }
+                const uint32_t ll = rr[u], m4 = q[u] & 15u;
+                row[shift + ll] = mask2iupac(m4);
+                const uint32_t single = (m4 & (m4 - 1)) == 0;
+                atomicAdd(&s_cnt[ll], 1u | (single << 16));
+                atomicOr(&s_msk[ll >> 1], (1u << m4) << (16u * (ll & 1u)));
+            }
+        };
+        uint32_t nx[AU]; uint32_t nlo, nhi;
+        fetch(0, nx, nlo, nhi);
+        for (int t = 0; t < cnt; t++) {
+            const int s = sbase + t;
+            uint32_t cur[AU];
+#pragma unroll
+            for (int u = 0; u < AU; u++) cur[u] = nx[u];
+            const uint32_t lo = nlo, hi = nhi;
+            const uint64_t off = __shfl((unsigned long long)my_off, t, 64);
+            for (uint32_t i = lane * 4; i < n + shift + 3; i += 256) *reinterpret_cast<uint32_t *>(row + i) = 0x2D2D2D2Du;
+            __builtin_amdgcn_wave_barrier();
+            place(cur);
+            for (uint32_t o = lo + 64u * AU; o < hi; o += 64u * AU) {          // longer slices: the rest, batch by batch
+#pragma unroll
+                for (int u = 0; u < AU; u++) { const uint32_t i = o + 64u * u + lane; cur[u] = i < hi ? (uint32_t)gs[off + i] : 0xFFFFFFFFu; }
+                place(cur);
+            }
+            if (t + 1 < cnt) fetch(t + 1, nx, nlo, nhi);
+            __builtin_amdgcn_wave_barrier();
+            unsigned char *dst = a.matrix + (uint64_t)s * a.pitch + ocol;
+            const uint32_t head = (16u - shift) & 15u;
+            const uint32_t h = head < n ? head : n;
+            if ((uint32_t)lane < h) dst[lane] = row[shift + lane];
+            const uint32_t body = (n - h) / 16u;
+            for (uint32_t v = lane; v < body; v += 64) {
+                const uint4 x = *reinterpret_cast<const uint4 *>(row + shift + h + 16u * v);
+                *reinterpret_cast<uint4 *>(dst + h + 16u * v) = x;
+            }
+            const uint32_t done = h + body * 16u;
+            if (done + lane < n) dst[done + lane] = row[shift + done + lane];
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        a.col_present[r0 + i] = s_cnt[i] & 0xFFFFu;
+        a.col_unambig[r0 + i] = s_cnt[i] >> 16;
+        a.col_mask[r0 + i] = (s_msk[i >> 1] >> (16u * (i & 1u))) & 0xFFFFu;
+    }
+}
+void launch_assemble_side(const AssembleArgs &a, const uint16_t *side, const uint16_t *perm, hipStream_t st)
+{
+    const uint32_t maxr = (a.max_rows + 15u) & ~15u;
+    const int nw = 8;
+    size_t lds = (size_t)maxr * 4 + (size_t)maxr * 2 + (size_t)maxr * 2 + 64 + (size_t)nw * (maxr + 32u);
+    (void)hipFuncSetAttribute((const void *)assemble_side_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(assemble_side_kernel, dim3((1u << a.logN) - a.j_base), dim3(64 * nw), lds, st, a, side, perm);
 }
 template <int MODE>
 static void launch_assemble_t(const AssembleArgs &a, uint32_t n_blocks, hipStream_t st)

@@ -117,6 +117,10 @@ struct skx_keyset {
     skx::DevBuf<uint64_t> roff;      // [1<<logN + 1]
     skx::DevBuf<uint64_t> flat;      // lazily built compact copy (engine order words)
     std::vector<uint64_t> h_roff;    // host copy of roff (windows of a lazily held array)
+    // notes of the union pass for the assemble that follows it on the same dictionaries (skx_merge): where every word's key went
+    skx::DevBuf<uint16_t> side;      // [side_of->words.n] (first-seen rank in the sub-bucket << 4) | base set
+    skx::DevBuf<uint16_t> perm;      // [1 << logN][stride] first-seen rank -> row of the slab
+    const skx_dictset *side_of = nullptr;
 };
 
 struct skx_array {

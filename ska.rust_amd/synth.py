@@ -121,3 +121,8 @@ def write_read_pair(anc, index, n_samples, prefix, read_len=150, coverage=50.0, 
         rec.tofile(p)
         paths.append(p)
     return paths
+
+
+def write_read_pair_of(index, n_samples, prefix, genome_len=5_000_000, seed=1):
+    """write_read_pair with the ancestor made on the spot: the form worker processes call (nothing large is sent to them)"""
+    return write_read_pair(ancestor(genome_len, seed=seed), index, n_samples, prefix, seed=seed)

@@ -218,11 +218,10 @@ def isolates(tmp_path_factory):
     import synth
     from concurrent.futures import ProcessPoolExecutor
     td = _shm(tmp_path_factory)
-    anc = synth.ancestor(5_000_000, seed=1)
     n = 8
     import multiprocessing
     with ProcessPoolExecutor(max_workers=min(n, os.cpu_count() or 1), mp_context=multiprocessing.get_context("spawn")) as ex:   # not a fork of a process that holds the GPU
-        pairs = list(ex.map(synth.write_read_pair, [anc] * n, range(n), [n] * n, [os.path.join(td, f"iso{i}") for i in range(n)]))
+        pairs = list(ex.map(synth.write_read_pair_of, range(n), [n] * n, [os.path.join(td, f"iso{i}") for i in range(n)]))
     lst = os.path.join(td, "list.txt")
     with open(lst, "w") as f:
         for i, (a, b) in enumerate(pairs):
