@@ -404,11 +404,14 @@ def main():
         key_bytes = 8 if args.k <= 31 else 16                      # 1 B read + (W + 1) B written per base, W = 8 | 16
         algo_bytes = (2.0 + key_bytes) * total_bases
         achieved = algo_bytes / (scatter_ms * 1e-3) / 1e9 if scatter_ms > 0 else 0.0
-        traffic = None       # HBM bytes per launch from the PMC passes recorded in profiles/ (FETCH_SIZE x2 + WRITE_SIZE), scaled per base
+        traffic, traffic_src = None, None       # HBM bytes per launch from the newest PMC passes recorded under profiles/ (FETCH_SIZE x2 + WRITE_SIZE), scaled per base
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_extract.json")))
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_extract*.json")), key=lambda f: json.load(open(f)).get("date", ""))
+            pmc = json.load(open(cands[-1]))
             if args.k <= 31:
                 traffic = (pmc["read_bytes_per_base"] + pmc["write_bytes_per_base"]) * total_bases
+                traffic_src = f"{pmc.get('source', os.path.basename(cands[-1]))}, recorded {pmc.get('date', 'in round 2')}: a separate --pmc run of this kernel, scaled per base (not measured in this run)"
         except Exception:
             pass
         res = {
@@ -439,7 +442,7 @@ def main():
                                               "bytes_received_per_step": comm.bytes_received / (steps + args.warmup),
                                               "what": "skx_keyset_allgather (one ncclAllGather of the per-rank key tables, then their union) + skx_array_reduce_stats "
                                                       "(one ncclAllReduce + one ncclAllGather of the per-row filter statistics), issued by the engine; nothing else crosses xGMI"}
-        res["roofline"]["traffic_source"] = "profiles/pmc_extract.json: FETCH_SIZE x 2 + WRITE_SIZE of a separate --pmc run of this kernel, scaled per base (not measured in this run)"
+        res["roofline"]["traffic_source"] = traffic_src
         if world == 1:
             # the legs below run outside the timed region; the bench's own device buffers go first (the ska executable gets the GPU)
             if last is not None:

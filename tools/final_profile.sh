@@ -1,0 +1,53 @@
+#!/bin/bash
+# tools/final_profile.sh <tag>: evidence of the tree as it is, on the GPU box (gpurun -- 'bash tools/final_profile.sh r03_final'):
+#   gpurun_out/<tag>_kernel_stats.txt   rocprofv3 --kernel-trace --stats summary of the bench command (1 000 genomes, 5 steps)
+#   gpurun_out/<tag>_pmc_traffic.txt    FETCH_SIZE / WRITE_SIZE per kernel, one --pmc pass per counter (they do not fit one pass), same workload
+#   gpurun_out/<tag>_pmc_extract.json   the extraction kernel's HBM bytes per base from those passes (what bench.py quotes as roofline.traffic)
+tag=${1:-final}; g=${2:-1000}
+root=$(pwd); out=$root/gpurun_out; mkdir -p $out
+bench="python $root/bench.py --no-e2e --no-check --no-distance --cpu-genomes 0 --genomes $g"
+cd /tmp && export TMPDIR=/tmp
+rm -rf $out/${tag}_trace; (cd $root && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_trace -- $bench --steps 5 --warmup 2 > $out/${tag}_trace.log 2>&1)
+python - "$out/${tag}_trace" > $out/${tag}_kernel_stats.txt <<'PY'
+import csv, glob, sys, collections
+acc = collections.defaultdict(lambda: [0, 0.0, 1e30, 0.0])
+for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+        a = acc[r["Kernel_Name"]]; a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+tot = sum(a[1] for a in acc.values()) or 1
+print(f"{'kernel':<100} {'calls':>6} {'total_ms':>11} {'avg_ms':>10} {'min_ms':>10} {'max_ms':>10} {'pct':>6}")
+for k, a in sorted(acc.items(), key=lambda x: -x[1][1])[:40]:
+    print(f"{k[:100]:<100} {a[0]:>6} {a[1]:>11.3f} {a[1] / a[0]:>10.3f} {a[2]:>10.3f} {a[3]:>10.3f} {100 * a[1] / tot:>6.2f}")
+PY
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $out/${tag}_pmc_$c; (cd $root && timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/${tag}_pmc_$c -- $bench --steps 2 --warmup 1 > $out/${tag}_pmc_$c.log 2>&1)
+done
+python - "$out" "$tag" "$g" > $out/${tag}_pmc_traffic.txt <<'PY'
+import csv, glob, sys, collections, json, datetime
+out, tag, g = sys.argv[1], sys.argv[2], int(sys.argv[3])
+val = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(f"{out}/{tag}_pmc_{c}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != c: continue
+            k = r["Kernel_Name"].split("(")[0]
+            acc[k][0] += 1; acc[k][1] += float(r["Counter_Value"])
+    val[c] = {k: (n, v / n) for k, (n, v) in acc.items()}
+print(f"# rocprofv3 --pmc, one pass per counter, bench.py --genomes {g} (per-launch means; FETCH_SIZE / WRITE_SIZE in KB as rocprofv3 reports them;")
+print("# HBM bytes = FETCH_SIZE x 2 (gfx950 tallies 128-B read requests at 64 B: MI355X_MICROARCH.md) + WRITE_SIZE)")
+print(f"{'kernel':<90} {'launches':>8} {'FETCH x2 GB':>12} {'WRITE GB':>10} {'total GB':>10}")
+keys = sorted(set(val["FETCH_SIZE"]) | set(val["WRITE_SIZE"]), key=lambda k: -(val["FETCH_SIZE"].get(k, (0, 0))[1] * 2 + val["WRITE_SIZE"].get(k, (0, 0))[1]))
+ext = None
+for k in keys[:16]:
+    n, f = val["FETCH_SIZE"].get(k, (0, 0.0)); _, w = val["WRITE_SIZE"].get(k, (0, 0.0))
+    print(f"{k[:90]:<90} {n:>8} {f * 2 * 1024 / 1e9:>12.3f} {w * 1024 / 1e9:>10.3f} {(f * 2 + w) * 1024 / 1e9:>10.3f}")
+    if "extract_kernel<true" in k and ext is None: ext = (k, f * 2 * 1024, w * 1024)
+if ext:
+    bases = g * 5_000_060.0          # the generator's mean record-stream length
+    json.dump({"kernel": ext[0], "read_bytes_per_base": ext[1] / bases, "write_bytes_per_base": ext[2] / bases, "date": datetime.date.today().isoformat(),
+               "source": f"profiles/{tag}_pmc_traffic.txt (FETCH_SIZE x2 + WRITE_SIZE, {g} x 5 Mbp, k=31; separate --pmc passes on the bench command)"},
+              open(f"{out}/{tag}_pmc_extract.json", "w"), indent=1)
+PY
+cat $out/${tag}_kernel_stats.txt | head -14; cat $out/${tag}_pmc_traffic.txt | head -14
