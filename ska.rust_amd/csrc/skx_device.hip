@@ -58,6 +58,25 @@ __device__ static inline void pack16(const uint32_t w[4], uint32_t &code, uint32
         nl |= (((fn * 0x01020408u) >> 24) & 0xFu) << (4 * i);
     }
 }
+// the same without the newline mask (extract_kernel finds the few positions where it matters from the text itself)
+__device__ static inline void pack16_nonl(const uint32_t w[4], uint32_t &code, uint32_t &bad)
+{
+    code = 0; bad = 0;
+    uint32_t c0f = 0x0F0F0F0Fu, c7f = 0x7F7F7F7Fu;
+    asm volatile("" : "+v"(c0f), "+v"(c7f));                      // built here, for this call (as plain constants they are hoisted out of the tile loop into registers that stay live through it)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint32_t x = w[i];
+        uint32_t c = (x >> 1) & 0x03030303u;
+        code = (code << 8) | ((c * 0x40100401u) >> 24);
+        uint32_t t = (x & c0f) ^ 0x0E0E0E0Eu;                      // low nibble == 14  <=>  !valid_base ('\n' = 0x0A is valid_base by this test ...)
+        uint32_t nzt = (t + c7f) & 0x80808080u;
+        uint32_t u = x ^ 0x0A0A0A0Au;                              // ... so the record terminator is tested for on its own
+        uint32_t znl = ~(((u & c7f) + c7f) | u | c7f);
+        uint32_t fb = (((~nzt) & 0x80808080u) | znl) >> 7;
+        bad |= (((fb * 0x01020408u) >> 24) & 0xFu) << (4 * i);
+    }
+}
 __device__ static inline uint32_t qualbad16(const uint32_t w[4], int min_qual)
 {
     uint32_t m = 0;
@@ -78,22 +97,50 @@ __device__ static inline uint32_t qualbad16(const uint32_t w[4], int min_qual)
 // ------------------------------------------------------------------------------------------------
 // forward declaration (defined with the block-wide helpers below)
 __device__ static inline uint32_t block_excl_scan(uint32_t v, uint32_t *s_tmp, uint32_t *total);
+__device__ static inline uint32_t block_excl_scan_row(uint32_t v, uint32_t *s_tmp, uint32_t *total, int tid);
 
 // LDS carve (dynamic, 16-B aligned): [B+4] hist -> local starts (+ a dummy counter for invalid windows) | [B] chunk
-// bases | codes+masks, later aliased by the staging buffer.  16 window-end positions per thread.  The tile's words are
-// staged in bucket order (TILE words, or half of them at a time: SPLIT) so that the copy-out writes every (tile, bucket)
-// chunk with adjacent lanes (few, wide L2 write requests).  HI: the bucket bits of a packed word lie in its upper half.
-// SPLIT: the staging buffer holds half a tile at a time (the lower half of the bucket space, then the upper half), so a
-// 12 288-position tile needs 57 KB of LDS instead of 105 KB and two 768-thread workgroups share a CU (85-VGPR cap), with
-// the same (tile, bucket) chunks in the word buffer as single-pass staging would write.
-#ifndef SKX_EXT_TILECONTIG
-#define SKX_EXT_TILECONTIG 0      // 1 | 2: measurement only (tools/ab_extract.sh): the write pattern of a tile-local layout, without | with the cursor atomics
+// bases | scan scratch | codes+masks, later aliased by the staging buffer.  16 window-end positions per thread.  The tile's
+// words are staged in bucket order (TILE words, or half of them at a time: SPLIT) so that the copy-out writes every
+// (tile, bucket) chunk with adjacent lanes (few, wide L2 write requests).  HI: the bucket bits of a packed word lie in its
+// upper half.  SPLIT: the staging buffer holds half a tile at a time (the lower half of the bucket space, then the upper
+// half), so a 12 288-position tile needs 57 KB of LDS instead of 105 KB and two 768-thread workgroups share a CU (85-VGPR
+// cap), with the same (tile, bucket) chunks in the word buffer as single-pass staging would write.
+//
+// What bounds it (round 3): not its arithmetic.  A build with k as a compile-time constant issues 12 % fewer
+// VALU instructions (SQ_INSTS_VALU 1.24e9 -> 1.09e9 per 200 genomes) and takes the same time; cycle stamps between the barriers
+// (-DSKX_EXT_PROF, tools/kbench.py prints them) show a workgroup spending 24 % of its 37 800 cycles before its FIRST barrier --
+// every thread issues one 16-byte load and waits for it behind the chip's store traffic -- against 33 % in the window loop.
+// Walking several tiles per workgroup with the next tile's text requested early does not hide that wait: loads, atomics and
+// stores share one counter (vmcnt) on gfx9, so the wait for the text is a wait for the previous tile's stores, which take
+// longer than a tile to be acknowledged (16.0-16.8 ms against 13.2; profiles/r03s_ab_tpw.log).
+// Measurement only (-DSKX_PHASE_PROF=1: extract_kernel, =2: dedupe_mb_kernel): cycles of wave 0 between a kernel's barriers, summed over
+// the workgroups; tools/kbench.py prints the shares.  This is what showed where these kernels wait.
+#ifdef SKX_PHASE_PROF
+__device__ unsigned long long g_phase_prof[1024 * 16];
+#define PHASE_PROF_(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&g_phase_prof[(blockIdx.x & 1023) * 16 + (i)], t_ - tprof); tprof = t_; } } while (0)
+#define PHASE_PROF_START unsigned long long tprof = __builtin_readcyclecounter()
+extern "C" void skx_debug_phase_prof(unsigned long long *out, int reset)
+{
+    static unsigned long long h[1024 * 16];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_prof), sizeof(h));
+    for (int i = 0; i < 16; i++) { out[i] = 0; for (int j = 0; j < 1024; j++) out[i] += h[j * 16 + i]; }
+    if (reset) { for (auto &x : h) x = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_prof), h, sizeof(h)); }
+}
+#else
+#define PHASE_PROF_(i) do { } while (0)
+#define PHASE_PROF_START do { } while (0)
 #endif
-#ifndef SKX_EXT_W32
-#define SKX_EXT_W32 0
+#if defined(SKX_PHASE_PROF) && SKX_PHASE_PROF == 1
+#define EXT_PROF(i) do { if (SCATTER) PHASE_PROF_(i); } while (0)
+#else
+#define EXT_PROF(i) do { } while (0)
 #endif
-#ifndef SKX_EXT_BRANCHFREE
-#define SKX_EXT_BRANCHFREE 0
+#if defined(SKX_PHASE_PROF) && SKX_PHASE_PROF == 2
+#define DD_PROF(i) PHASE_PROF_(i)
+#else
+#define DD_PROF(i) do { } while (0)
 #endif
 template <bool SCATTER, int TILE, bool HI, int PPT, bool SPLIT, int RMAX>
 __global__ __launch_bounds__(TILE / PPT, SPLIT ? 6 : 1) void extract_kernel(ExtractArgs a)
@@ -109,10 +156,11 @@ __global__ __launch_bounds__(TILE / PPT, SPLIT ? 6 : 1) void extract_kernel(Extr
     unsigned char *s_rest = reinterpret_cast<unsigned char *>(s_tmp + 20);
     uint32_t *s_code = reinterpret_cast<uint32_t *>(s_rest);
     uint16_t *s_bad = reinterpret_cast<uint16_t *>(s_code + NCHUNK + 3);
-    uint16_t *s_nl = s_bad + NCHUNK + 3, *s_qbad = s_nl + NCHUNK + 3;
+    uint16_t *s_qbad = s_bad + NCHUNK + 3;
     uint64_t *s_stage = reinterpret_cast<uint64_t *>(s_rest);           // aliases the code arrays once they are dead
 
     const int tid = threadIdx.x;
+    PHASE_PROF_START;
     const uint64_t per_group = 8ull * (uint64_t)a.tiles_max;
     const uint64_t L = blockIdx.x;
     const int sample = (int)((L / per_group) * 8 + (L % per_group) % 8);
@@ -123,16 +171,26 @@ __global__ __launch_bounds__(TILE / PPT, SPLIT ? 6 : 1) void extract_kernel(Extr
     if (T0 >= len) return;
     // record streams live in HBM: explicit global address space (a pointer fetched from memory is generic -> flat_load)
     typedef const uint8_t __attribute__((address_space(1))) *gbytes_t;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef const u32x4 __attribute__((address_space(1))) *gvec_t;
     gbytes_t seq = (gbytes_t)(uintptr_t)a.seqs[sample];
     gbytes_t qual = a.quals ? (gbytes_t)(uintptr_t)a.quals[sample] : (gbytes_t)0;
+
+    const int k = a.k, h = (k - 1) / 2;
+    const HashParams hp = a.hp;
+    const int hb = hp.hb;
+    const int bshift = hp.bits - a.logB;                    // (word >> 4) >> bshift == bucket
+    const int bsh_hi = hp.bits + 4 - 32 - a.logB;           // HI: bucket = upper half >> bsh_hi
+    const uint32_t rcflag = a.rc ? ~0u : 0u;
+    const bool top_from_hl = a.logB <= hb;                  // bucket = top logB bits of H = top bits of the hashed upper arm
+    const int top_shift = top_from_hl ? hb - a.logB : 0;
+    const uint32_t am = (1u << (2 * h)) - 1;                // arm mask (h <= 15)
 
     for (int i = tid; i < B + 4; i += NT) s_hist[i] = 0;
     for (int c = tid; c < NCHUNK; c += NT) {
         const int64_t p = (int64_t)T0 - 64 + 16 * (int64_t)c;
         uint32_t w[4], q[4] = {0, 0, 0, 0};
         if (p >= 0 && (uint64_t)p + 16 <= len) {
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            typedef const u32x4 __attribute__((address_space(1))) *gvec_t;
             const u32x4 v = *(gvec_t)(seq + p);
             w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
             if (qual) { const u32x4 u = *(gvec_t)(qual + p); q[0] = u.x; q[1] = u.y; q[2] = u.z; q[3] = u.w; }
@@ -150,35 +208,49 @@ __global__ __launch_bounds__(TILE / PPT, SPLIT ? 6 : 1) void extract_kernel(Extr
                 w[i] = x; q[i] = y;
             }
         }
-        uint32_t code, bad, nl;
-        pack16(w, code, bad, nl);
+        uint32_t code, bad;
+        pack16_nonl(w, code, bad);
         uint32_t qb = 0;
         if (qual) {
+            uint32_t c2, b2, nl;
+            pack16(w, c2, b2, nl);
             qb = qualbad16(q, a.min_qual) & ~nl;
             if (a.qual_filter == 2) bad |= qb;          // QualFilter::Strict (split_kmer.rs:98-101,170-172)
         }
-        s_code[c] = code; s_bad[c] = (uint16_t)bad; s_nl[c] = (uint16_t)nl; s_qbad[c] = (uint16_t)qb;
+        s_code[c] = code; s_bad[c] = (uint16_t)bad; if (qual) s_qbad[c] = (uint16_t)qb;
     }
     __syncthreads();
+    EXT_PROF(0);
+    // The text of a tile this XCD will take up shortly (a sample's tiles stay on one XCD; PF_AHEAD tiles = ~4 us of its dispatch order) is
+    // pulled into this L2 now: one dword of each of its 128-byte lines, by the first TILE / 128 threads, kept in a register until the wait
+    // before the copy-out so that nothing waits for it.  The workgroup that processes that tile then finds its one load per thread --
+    // which it can do nothing but wait for -- in the L2 instead of behind the chip's store traffic: 13.2 -> 12.3 ms per 1 000 x 5 Mbp
+    // (profiles/r03v_ab_prefetch*.log; 8 tiles ahead is too late, 16 to 24 are alike, 64 fades).  Past the sample's end the head of
+    // the sample this XCD takes up next is fetched instead.
+    constexpr uint64_t PF_AHEAD = 20;
+    uint32_t pfw = 0;
+    if (SCATTER && tid < TILE / 128) {
+        uint64_t pos = T0 + PF_AHEAD * TILE + (uint64_t)tid * 128;
+        gbytes_t ps = seq;
+        uint64_t plen = len;
+        if (T0 + PF_AHEAD * TILE >= len && sample + 8 < a.n_samples) {
+            pos = (tile + PF_AHEAD - (len + TILE - 1) / TILE) * TILE + (uint64_t)tid * 128;
+            ps = (gbytes_t)(uintptr_t)a.seqs[sample + 8]; plen = a.lens[sample + 8];
+        }
+        if (pos < plen) pfw = *(const uint32_t __attribute__((address_space(1))) *)(ps + pos);
+    }
 
-    const int k = a.k, h = (k - 1) / 2;
+    uint64_t wv[PPT];
+    uint32_t rk[PPT];                                       // (bucket << 16) | rank within the tile's bucket; bucket B (the dummy counter) = no window
+    {
     const int c0 = tid * NCH + 4;
     // ---- rolling split k-mer over my PPT positions; arms are <= 30 bits, all 32-bit arithmetic ----
-    const uint32_t am = (1u << (2 * h)) - 1;                                  // arm mask (h <= 15)
     const uint64_t prev = ((uint64_t)s_code[c0 - 2] << 32) | s_code[c0 - 1];  // 32 bases before p0, first base most significant
     // window ending at p0-1: upper arm | middle | lower arm  (split_kmer.rs:104-116)
     uint32_t lower = (uint32_t)prev & am;
     uint32_t mid = (uint32_t)(prev >> (2 * h)) & 3u;
     uint32_t upper = (uint32_t)(prev >> (2 * h + 2)) & am;
     uint32_t rc_upper = revcomp_arm(lower, h), rc_lower = revcomp_arm(upper, h), rc_mid = mid ^ 2u;   // :149-153
-    const int hb = a.hp.hb;
-    const int bshift = a.hp.bits - a.logB;                  // (word >> 4) >> bshift == bucket
-    const uint32_t rcflag = a.rc ? ~0u : 0u;
-    const bool top_from_hl = a.logB <= hb;                  // bucket = top logB bits of H = top bits of the hashed upper arm
-    const int top_shift = top_from_hl ? hb - a.logB : 0;
-
-    uint64_t wv[PPT];
-    uint32_t rk[PPT];                                       // (bucket << 16) | rank within the tile's bucket; bucket 0xFFFF = no window
 #pragma unroll
     for (int half = 0; half < NCH; half++) {
         const int c = c0 + half;
@@ -195,9 +267,19 @@ __global__ __launch_bounds__(TILE / PPT, SPLIT ? 6 : 1) void extract_kernel(Extr
                 A &= A << span; span <<= 1;
             }
         }
-        const uint64_t NL = ((uint64_t)s_nl[c] << 32) | ((uint64_t)(s_nl[c + 1] & 1u) << 48);
-        const uint64_t exact = Wk & ~(G << k);
-        uint64_t V = Wk & ~(exact & (NL >> 1));
+        // the end rule needs "position i + 1 is the record terminator".  A terminator is a bad base, and a clean run of exactly k
+        // bases in front of a bad base is rare: only then is the text looked at again
+        uint64_t V = Wk;
+        const uint64_t cand = Wk & ~(G << k) & ((~G >> 1) | ((uint64_t)(s_bad[c + 1] & 1u) << 47)) & (0xFFFFull << 32);
+        if (cand) {
+            const int64_t pc = (int64_t)T0 - 64 + 16 * (int64_t)c;                  // the position of bit 32
+            uint32_t m = (uint32_t)(cand >> 32);
+            while (m) {
+                const int j = __builtin_ctz(m); m &= m - 1;
+                const uint64_t pos = (uint64_t)(pc + j + 1);
+                if (pos >= len || seq[pos] == (uint8_t)'\n') V &= ~(1ull << (32 + j));
+            }
+        }
         if (qual && a.qual_filter != 0)                                          // middle_base_qual, split_kmer.rs:328-339
             V &= ~((((uint64_t)s_qbad[c - 2] | ((uint64_t)s_qbad[c - 1] << 16) | ((uint64_t)s_qbad[c] << 32))) << h);
         const uint32_t vm = (uint32_t)(V >> 32) & 0xFFFFu;
@@ -218,29 +300,18 @@ __global__ __launch_bounds__(TILE / PPT, SPLIT ? 6 : 1) void extract_kernel(Extr
             const bool eq = kf == kr && rcflag;
             uint32_t hl = gt ? rc_upper : upper, hr = gt ? rc_lower : lower;
             const uint32_t m4 = (1u << (gt ? rc_mid : mid)) | (eq ? (1u << rc_mid) : 0u);
-            hmix_halves(hl, hr, a.hp);
-#if SKX_EXT_W32
-            // HI: the hashed upper arm starts in the word's upper half (hb + 4 >= 32): the word from 32-bit pieces, no 64-bit shifts
-            const uint64_t w = HI ? ((uint64_t)((hl << (hb + 4 - 32)) | (hb > 28 ? hr >> 28 : 0u)) << 32) | (uint32_t)((hr << 4) | m4)
-                                  : ((uint64_t)hl << (hb + 4)) | ((uint64_t)hr << 4) | m4;
-#else
+            hmix_halves(hl, hr, hp);
             const uint64_t w = ((uint64_t)hl << (hb + 4)) | ((uint64_t)hr << 4) | m4;
-#endif
             wv[16 * half + j] = w;
             const bool valid = (vm >> j) & 1u;
-#if SKX_EXT_BRANCHFREE
-            // the bucket of every window, valid or not, then one select: a wave-uniform branch around the invalid ones costs more than
-            // the shift it saves (s_and_saveexec + two scalar branches per window in the ISA)
-            const uint32_t bk_any = top_from_hl ? hl >> top_shift : (uint32_t)((w >> 4) >> bshift);
-            const uint32_t bk = valid ? bk_any : (uint32_t)B;
-#else
             const uint32_t bk = valid ? (top_from_hl ? hl >> top_shift : (uint32_t)((w >> 4) >> bshift)) : (uint32_t)B;
-#endif
             const uint32_t r = atomicAdd(&s_hist[bk], 1u);
-            rk[16 * half + j] = ((valid ? bk : 0xFFFFu) << 16) | (r & 0xFFFFu);
+            rk[16 * half + j] = (bk << 16) | r;             // r <= TILE < 65 536
         }
     }
+    }
     __syncthreads();                                        // also: the code arrays are dead from here on
+    EXT_PROF(1);
     uint32_t *ghist = a.hist + ((uint64_t)sample << a.logB);
     if (!SCATTER) {
         for (int i = tid; i < B; i += NT) { uint32_t n = s_hist[i]; if (n) atomicAdd(&ghist[i], n); }
@@ -254,27 +325,25 @@ __global__ __launch_bounds__(TILE / PPT, SPLIT ? 6 : 1) void extract_kernel(Extr
 #pragma unroll
     for (int r = 0; r < RMAX; r++) {
         gb[r] = 0;
-#if SKX_EXT_TILECONTIG == 1
-        if (b0 + r < b1) { const uint32_t n = s_hist[b0 + r]; lsum += n; }                   // (experiment: no cursor atomics)
-#else
         if (b0 + r < b1) { const uint32_t n = s_hist[b0 + r]; if (n) gb[r] = atomicAdd(&ghist[b0 + r], n); lsum += n; }
-#endif
     }
     uint32_t total;
-    uint32_t lrun = block_excl_scan(lsum, s_tmp, &total);
+    uint32_t lrun = block_excl_scan_row(lsum, s_tmp, &total, tid);
+    EXT_PROF(2);
     // s_hist: counts -> local starts (position of the bucket's first word in the staging buffer)
 #pragma unroll
     for (int r = 0; r < RMAX; r++)
         if (b0 + r < b1) { const uint32_t n = s_hist[b0 + r]; s_hist[b0 + r] = lrun; lrun += n; }
     if (tid == 0) s_hist[B] = total;                        // sentinel: start of the (non-existent) bucket B
     __syncthreads();
+    EXT_PROF(3);
     constexpr uint32_t HALF = SPLIT ? TILE / 2 : TILE;      // staged words per round
-    const int bsh_hi = a.hp.bits + 4 - 32 - a.logB;          // HI: bucket = upper half >> bsh_hi
-    uint32_t sidx_[SPLIT ? PPT : 1];                        // SPLIT: the staged index of my words (0xFFFFFFFF = no window), kept for round two
+    uint32_t sidx_[SPLIT ? PPT : 1];                        // SPLIT: the staged index of my words, kept for round two
 #pragma unroll
     for (int j = 0; j < PPT; j++) {
-        const uint32_t b = rk[j] >> 16;
-        const uint32_t idx = b < (uint32_t)B ? s_hist[b] + (rk[j] & 0xFFFFu) : 0xFFFFFFFFu;
+        // an invalid window gets an index at or behind the tile's word count (s_hist[B] = total; total + invalid windows = TILE): a slot
+        // the copy-out never reads
+        const uint32_t idx = s_hist[rk[j] >> 16] + (rk[j] & 0xFFFFu);
         if (SPLIT) sidx_[j] = idx;
         if (idx < HALF) s_stage[idx] = wv[j];
     }
@@ -284,52 +353,49 @@ __global__ __launch_bounds__(TILE / PPT, SPLIT ? 6 : 1) void extract_kernel(Extr
     const uint64_t *off = a.off + ((uint64_t)sample << a.logB);
     const bool fixed = a.capacity != 0xFFFFFFFFu;           // fixed-capacity regions: offsets are arithmetic
     const uint64_t span0 = fixed ? ((uint64_t)sample << a.logB) * a.capacity : off[0];
-    const uint32_t span_last = fixed ? (uint32_t)(((uint64_t)a.capacity << a.logB) - 1) : (uint32_t)(off[B] - off[0] - 1);
     bool dropped = false;
 #pragma unroll
     for (int r = 0; r < RMAX; r++)
         if (b0 + r < b1) {
             const uint32_t b = (uint32_t)(b0 + r), start = s_hist[b], n = s_hist[b + 1] - start;
-            if (n && gb[r] + n > a.capacity) dropped = true;                  // the region is full: the host falls back to exact offsets
-            s_base[b] = (fixed ? b * a.capacity : (uint32_t)(off[b] - off[0])) + gb[r] - start;
+            // a full region: the host falls back to exact offsets and builds every dictionary again, so the chunk only has to stay inside
+            // the word buffer -- it goes to the head of the sample's span (n <= this sample's windows <= the span)
+            const bool over = n && gb[r] + n > a.capacity;
+            if (over) dropped = true;
+            s_base[b] = over ? 0u - start : (fixed ? b * a.capacity : (uint32_t)(off[b] - off[0])) + gb[r] - start;
         }
+    asm volatile("" :: "v"(pfw));                           // (the prefetch's register is free from here: the wait for the cursors above covered it)
     __syncthreads();
+    EXT_PROF(4);
     typedef uint64_t __attribute__((address_space(1))) *gout_t;
     gout_t out = (gout_t)(uintptr_t)(a.words + span0);
     const uint32_t end0 = total < HALF ? total : HALF;
     for (uint32_t i = tid; i < end0; i += NT) {
         const uint64_t w = s_stage[i];
         const uint32_t b = HI ? (uint32_t)(w >> 32) >> bsh_hi : (uint32_t)((w >> 4) >> bshift);
-        uint32_t r = s_base[b] + i;
-#if SKX_EXT_TILECONTIG
-        r = (uint32_t)T0 + i + (s_base[b] & 0u);                              // (experiment: the tile's words in one contiguous piece)
-#endif
-        r = r < span_last ? r : span_last;                                    // an overflowing chunk must not leave the sample's span
-        out[r] = w;
+        out[s_base[b] + i] = w;
     }
+    EXT_PROF(5);
     if (SPLIT && total > HALF) {
         __syncthreads();
+        EXT_PROF(6);
 #pragma unroll
-        for (int j = 0; j < PPT; j++) if (sidx_[j] != 0xFFFFFFFFu && sidx_[j] >= HALF) s_stage[sidx_[j] - HALF] = wv[j];
+        for (int j = 0; j < PPT; j++) if (sidx_[j] - HALF < HALF) s_stage[sidx_[j] - HALF] = wv[j];
         __syncthreads();
+        EXT_PROF(7);
         for (uint32_t i = HALF + tid; i < total; i += NT) {
             const uint64_t w = s_stage[i - HALF];
             const uint32_t b = HI ? (uint32_t)(w >> 32) >> bsh_hi : (uint32_t)((w >> 4) >> bshift);
-            uint32_t r = s_base[b] + i;
-#if SKX_EXT_TILECONTIG
-            r = (uint32_t)T0 + i + (s_base[b] & 0u);
-#endif
-            r = r < span_last ? r : span_last;
-            out[r] = w;
+            out[s_base[b] + i] = w;
         }
     }
+    EXT_PROF(8);
     if (dropped) *a.overflow = 1;
 }
-
 template <int TILE, bool SPLIT>
 static inline size_t extract_lds(const ExtractArgs &a, bool scatter)
 {
-    size_t codes = (size_t)(TILE / 16 + 8) * 10 + 64;
+    size_t codes = (size_t)(TILE / 16 + 8) * 8 + 64;
     size_t stage = scatter ? (size_t)TILE * (SPLIT ? 4 : 8) : 0;
     return ((size_t)8 << a.logB) + 16 + 80 + (stage > codes ? stage : codes);
 }
@@ -396,12 +462,9 @@ __device__ static inline uint32_t block_excl_scan(uint32_t v, uint32_t *s_tmp /*
     return r;
 }
 
-// the same scan without the walk of the waves' sums by thread 0 between two barriers: every thread adds up the sums of the waves
-// before its own (<= 16 broadcast LDS reads), the wave scan runs on DPP moves instead of LDS permutes.  (Used where registers allow:
-// in extract_kernel, at its 80-VGPR cap, the extra live values spilled.)
-__device__ static inline uint32_t block_excl_scan_dpp(uint32_t v, uint32_t *s_tmp /*[17]*/, uint32_t *total)
+// inclusive scan over a wave on DPP moves (no LDS permutes)
+__device__ static inline uint32_t wave_incl_scan_dpp(uint32_t v)
 {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
     uint32_t inc = v;
     inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, true);      // row_shr:1
     inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, true);      // row_shr:2
@@ -409,17 +472,26 @@ __device__ static inline uint32_t block_excl_scan_dpp(uint32_t v, uint32_t *s_tm
     inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, true);      // row_shr:8
     inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
     inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
+    return inc;
+}
+// exclusive scan over the block without thread 0's walk of the waves' sums: those are scanned by sixteen lanes of every wave on DPP moves
+// and picked with v_readlane -- two registers, ONE barrier (the caller separates two uses of s_tmp by barriers of its own); tid = the thread
+// index as the caller holds it.  (A form that had every thread add up the sixteen sums from LDS kept sixteen registers busy and spilled
+// extract_kernel at its 80-VGPR cap.)
+__device__ static inline uint32_t block_excl_scan_row(uint32_t v, uint32_t *s_tmp /*[16]*/, uint32_t *total, int tid)
+{
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nw = (int)((blockDim.x + 63) >> 6);
+    const uint32_t inc = wave_incl_scan_dpp(v);
     if (lane == 63) s_tmp[wv] = inc;
     __syncthreads();
-    uint32_t before = 0, all = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const uint32_t t = i < nw ? s_tmp[i] : 0u;
-        all += t;
-        before += i < wv ? t : 0u;
-    }
-    if (total) *total = all;
-    __syncthreads();
+    uint32_t t = lane < nw ? s_tmp[lane & 15] : 0u;                                        // <= 16 waves: one row
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x111, 0xf, 0xf, true);
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x112, 0xf, 0xf, true);
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x114, 0xf, 0xf, true);
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x118, 0xf, 0xf, true);
+    const uint32_t before = wv ? (uint32_t)__builtin_amdgcn_readlane((int)t, wv - 1) : 0u;
+    if (total) *total = (uint32_t)__builtin_amdgcn_readlane((int)t, nw - 1);
     return before + inc - v;
 }
 
@@ -604,6 +676,11 @@ __device__ static inline uint32_t table_emit_sorted_slot(const unsigned long lon
     return total;
 }
 
+// pointers that reach a kernel inside an argument struct are generic (flat_load: slower, and it also ticks the LDS
+// counter); dictionary words only ever live in HBM, so read them through an explicit global-address-space pointer
+typedef const uint64_t __attribute__((address_space(1))) *gwords_t;
+__device__ static inline gwords_t as_global(const uint64_t *p) { return (gwords_t)(uintptr_t)p; }
+
 // K3: per (sample,bucket) region: dedupe (OR of base masks) + sort, in place
 // K3 (fallback for regions larger than the counting sort's LDS capacity, i.e. heavy repeat content: tandem repeats,
 // homopolymers): duplicates collapse on insertion, so only the number of DISTINCT keys has to fit.
@@ -668,6 +745,7 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
     // big_mode 0: every region; 1: every region, those above this launch's capacity are on the list `big` ([0] = count) and
     // left to a launch of mode 2; 2: the listed regions from entry big_from on, one per workgroup (bit 4 of *overflow: the list is
     // longer than this grid, the host launches the rest)
+    PHASE_PROF_START;
     uint64_t region = blockIdx.x;
     if (big_mode == 2) {
         const uint32_t cnt = big[0], idx = big_from + blockIdx.x;
@@ -688,7 +766,9 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
     const uint32_t M = 1u << logM;
     const int mshift = rem_bits - logM + 4;                                  // micro-bucket = word_field<HI>(w, mshift, M - 1)
     uint64_t *reg = words + off[region];
-    // the whole region goes into registers with all loads in flight at once (word 0 never occurs: base masks are non-zero)
+    // the whole region goes into registers with all loads in flight at once (word 0 never occurs: base masks are non-zero).
+    // (Requesting the words before the region's count is known -- fixed-capacity regions have arithmetic addresses -- was measured: 19.0 -> 19.7 ms,
+    // profiles/r03y_ab_dedupe_specload.log.)
     uint64_t e[ITEMS];
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) { const uint32_t i = threadIdx.x + (uint32_t)NT * t; e[t] = i < n ? reg[i] : 0ull; }
@@ -696,17 +776,20 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
     if (threadIdx.x == 0) s_cnt[-1] = 0;                                     // end of the bucket before the first
     if (threadIdx.x < 4) s_elem[n + threadIdx.x] = ~0ull;                    // what the ranking reads behind the last word
     __syncthreads();
+    DD_PROF(0);
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) if (e[t]) atomicAdd(&s_cnt[word_field<HI>(e[t], mshift, M - 1)], 1u);
     __syncthreads();
+    DD_PROF(1);
     // exclusive scan of the counts (each thread owns R consecutive micro-buckets)
     const uint32_t R = (M + NT - 1) / NT;
     const uint32_t m0 = threadIdx.x * R < M ? threadIdx.x * R : M, m1 = m0 + R < M ? m0 + R : M;
     uint32_t sum = 0;
     for (uint32_t m = m0; m < m1; m++) sum += s_cnt[m];
-    uint32_t run = block_excl_scan_dpp(sum, s_tmp, nullptr);
+    uint32_t run = block_excl_scan_row(sum, s_tmp, nullptr, (int)threadIdx.x);
     for (uint32_t m = m0; m < m1; m++) { uint32_t c = s_cnt[m]; s_cnt[m] = run; run += c; }      // start of m; the scatter below turns it into its end = start of m + 1
     __syncthreads();
+    DD_PROF(2);
     uint32_t pos[ITEMS];
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) {
@@ -714,6 +797,7 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
         if (e[t]) { pos[t] = atomicAdd(&s_cnt[word_field<HI>(e[t], mshift, M - 1)], 1u); s_elem[pos[t]] = e[t]; }
     }
     __syncthreads();
+    DD_PROF(3);
     // rank every word inside its micro-bucket (all words in parallel, 4 LDS reads in flight per step): sorted position =
     // start + #smaller keys + #equal keys at lower positions; equal keys also fold their base masks together
     // position-ordered from here on (p = tid + NT t): neighbouring lanes touch neighbouring LDS words, so the random-bank
@@ -774,9 +858,11 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
         e[t] = (w0 & ~15ull) | mor;
     }
     __syncthreads();
+    DD_PROF(4);
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) if (e[t]) s_elem[npos[t]] = e[t];
     __syncthreads();
+    DD_PROF(5);
     // keep the first word of every run of equal keys; compaction index from wave ballots + a tiny per-row table
     constexpr int NW = NT / 64;
     uint32_t *s_rows = s_cnt;                               // [ITEMS][NW] leaders per (row, wave); the cursors are dead now
@@ -802,17 +888,19 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
         if (lane == 0) s_rows[t * NW + wv] = __popcll(bal);
     }
     __syncthreads();
+    DD_PROF(6);
     // counts per (row, wave) -> exclusive prefix in output order (one wave, entries i and i + 64), total at [ITEMS * 4]
     if (wv == 0) {
         constexpr int NE = ITEMS * NW;
         const uint32_t a = lane < NE ? s_rows[lane] : 0u, b2 = lane + 64 < NE ? s_rows[lane + 64] : 0u;
-        const uint32_t ia = wave_incl_scan(a), ta = __shfl(ia, 63, 64);
-        const uint32_t ib = NE > 64 ? wave_incl_scan(b2) : 0u;
+        const uint32_t ia = wave_incl_scan_dpp(a), ta = (uint32_t)__builtin_amdgcn_readlane((int)ia, 63);
+        const uint32_t ib = NE > 64 ? wave_incl_scan_dpp(b2) : 0u;
         if (lane < NE) s_rows[lane] = ia - a;
         if (NE > 64 && lane + 64 < NE) s_rows[lane + 64] = ta + ib - b2;
         if (lane == 63) s_rows[NE] = ta + (NE > 64 ? ib : 0u);
     }
     __syncthreads();
+    DD_PROF(7);
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) {
         if (!((flags >> t) & 1u)) continue;
@@ -823,6 +911,7 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
         if ((sflags >> t) & 1u) sidx[region * SUBIDX + word_field<false>(e[t], subshift, submask)] = (uint16_t)o;
     }
     if (threadIdx.x == 0) ucnt[region] = s_rows[ITEMS * NW];
+    DD_PROF(8);
 }
 template <int ITEMS, int NT>
 static void launch_dedupe_items(uint64_t *words, const uint64_t *off, const uint32_t *raw, uint32_t *ucnt, uint64_t n_blocks, uint32_t cap,
@@ -892,10 +981,6 @@ void launch_dedupe_mb(uint64_t *words, const uint64_t *off, const uint32_t *raw,
     launch_dedupe_shape(words, off, raw, ucnt, spill_grid, cap, rem_bits, overflow, sidx, sb, st, big_list, big_from, 2);
 }
 
-// pointers that reach a kernel inside an argument struct are generic (flat_load: slower, and it also ticks the LDS
-// counter); dictionary words only ever live in HBM, so read them through an explicit global-address-space pointer
-typedef const uint64_t __attribute__((address_space(1))) *gwords_t;
-__device__ static inline gwords_t as_global(const uint64_t *p) { return (gwords_t)(uintptr_t)p; }
 
 // first index in [lo,hi) whose hashed key (word >> 4) is >= x
 __device__ static inline uint32_t lower_bound_words(const uint64_t *reg_, uint32_t lo, uint32_t hi, uint64_t x)

@@ -35,4 +35,13 @@ for r in range(reps + 1):
     except E.EngineError as e:
         print("engine error (expected in debug modes):", str(e)[:80])
 t = ctx.timings()
+try:                                     # builds with -DSKX_PHASE_PROF=1|2: cycles of wave 0 per phase of extract_kernel | dedupe_mb_kernel, summed over workgroups and launches
+    import ctypes
+    f = E._lib.skx_debug_phase_prof
+    buf = (ctypes.c_ulonglong * 16)()
+    f(buf, 1)
+    tot = sum(buf) or 1
+    print("phases (share of wave-0 cycles between barriers):", [round(x / tot, 3) for x in buf[:10]], "cycles in all:", tot)
+except AttributeError:
+    pass
 print({k: round(v / reps, 3) for k, v in t.items() if v})

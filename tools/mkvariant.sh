@@ -8,7 +8,7 @@ src=csrc/skx_device.hip; defs=(); args=()
 while [ $# -gt 0 ]; do
   case "$1" in
     --rev) git show "$2:ska.rust_amd/csrc/skx_device.hip" > csrc/_base.hip; src=csrc/_base.hip; shift 2;;
-    -D*) defs+=("$1"); shift;;
+    -D*|-W*) defs+=("$1"); shift;;
     *) args+=(-e "$1"); shift;;
   esac
 done
