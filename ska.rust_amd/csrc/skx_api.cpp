@@ -915,8 +915,13 @@ static int keyset_union_views(skx_ctx *ctx, const DictView *views, int nviews, i
         if (nviews == 1) {
             // side_for: the assemble over these dictionaries follows (skx_merge): the pass also notes where every word's key went, 2 bytes
             // per word, and the matrix is then filled from the notes instead of a second read of the dictionaries
-            const bool with_side = side_for && !wide && union_side_ok(views[0], logN, stride) && !getenv("SKX_NO_MERGE_SIDE");
-            if (wide) launch_union_wide(views[0], logN, (u128 *)ks->stage.p, stride, ks->ncnt.p, table, d_flag.p, st);
+            const bool with_side = side_for && (wide || union_side_ok(views[0], logN, stride)) && !getenv("SKX_NO_MERGE_SIDE");
+            if (wide && with_side) {
+                if (!side_buf.p) SKX_TRY(side_buf.alloc(side_for->words.n / 2 + 64));          // one note per 16-byte word
+                SKX_TRY(ks->perm.alloc(nsub * stride));
+                launch_union_side_wide(views[0], logN, (u128 *)ks->stage.p, stride, ks->ncnt.p, table, d_flag.p, side_buf.p, ks->perm.p, st);
+                ks->side_of = side_for;
+            } else if (wide) launch_union_wide(views[0], logN, (u128 *)ks->stage.p, stride, ks->ncnt.p, table, d_flag.p, st);
             else if (with_side) {
                 if (!side_buf.p) SKX_TRY(side_buf.alloc(side_for->words.n));
                 SKX_TRY(ks->perm.alloc(nsub * stride));
@@ -1123,8 +1128,8 @@ extern "C" int skx_array_assemble(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows
         aa.max_rows = rows->max_rows; aa.missing = d_flag.p;
         {
             StageTimer t(ctx, &ctx->tm.assemble);
-            if (rows->wide) launch_assemble_wide(aa, st);
-            else if (rows->side.p && rows->side_of == d && !rebuilt) launch_assemble_side(aa, rows->side.p, rows->perm.p, st);      // the union over d left its notes
+            if (rows->side.p && rows->side_of == d && !rebuilt) launch_assemble_side(aa, rows->side.p, rows->perm.p, st, rows->wide);      // the union over d left its notes
+            else if (rows->wide) launch_assemble_wide(aa, st);
             else launch_assemble(aa, st);
         }
         if (rows->wide) launch_gather_keys_wide((const u128 *)rows->stage.p, rows->stride, rows->ncnt.p, rows->roff.p, 1 << rows->logN, (u128 *)a->keys.p, st);

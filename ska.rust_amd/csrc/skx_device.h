@@ -147,7 +147,9 @@ void launch_assemble(const AssembleArgs &a, hipStream_t st, int mode = 0, uint32
 bool union_side_ok(const DictView &d, int logN, uint32_t stride);
 void launch_union_side(const DictView &d, int logN, uint64_t *stage, uint32_t stride, uint32_t *ncnt, uint32_t table_slots, int *overflow,
                        uint16_t *side, uint16_t *perm, hipStream_t st);
-void launch_assemble_side(const AssembleArgs &a, const uint16_t *side, const uint16_t *perm, hipStream_t st);
+void launch_assemble_side(const AssembleArgs &a, const uint16_t *side, const uint16_t *perm, hipStream_t st, bool wide = false);
+void launch_union_side_wide(const DictView &d, int logN, u128 *stage, uint32_t stride, uint32_t *ncnt, uint32_t table_slots, int *overflow,
+                            uint16_t *side, uint16_t *perm, hipStream_t st);
 
 // compact slabs into one array; unhash=1 converts engine-order words back to reference keys
 void launch_gather_keys(const uint64_t *stage, uint32_t stride, const uint32_t *ncnt, const uint64_t *roff, int n_sub,

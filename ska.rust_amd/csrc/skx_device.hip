@@ -1386,8 +1386,11 @@ __global__ __launch_bounds__(512, SKX_ASM_WPS) void assemble_kernel(AssembleArgs
     }
 }
 
+// (skx_device_wide.inc) slice [lo, hi) of a sample's region of 16-byte words that belongs to sub-bucket j; returns the region's first word index
+__device__ static inline uint64_t sub_slice_off_wide(const DictView &d, int sample, uint64_t j, int logN, uint32_t &lo, uint32_t &hi);
 // K5': the matrix from the union's notes (union_kernel<.., SIDE>): per word 2 bytes -- (first-seen rank of its key in the sub-bucket << 4) |
 // base set -- instead of the 8-byte word, and no key look-up: perm[rank] is the row.  Same output as assemble_kernel<0>.
+template <bool WIDE>                 // WIDE: the dictionaries hold 16-byte words (the notes are the same: 2 bytes per word, indexed by word)
 __global__ __launch_bounds__(512, SKX_ASM_WPS) void assemble_side_kernel(AssembleArgs a, const uint16_t *side, const uint16_t *perm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -1417,9 +1420,11 @@ __global__ __launch_bounds__(512, SKX_ASM_WPS) void assemble_side_kernel(Assembl
         uint64_t my_off = 0; uint32_t my_lo = 0, my_hi = 0;
         const int cnt = wend - sbase < 64 ? wend - sbase : 64;
         if (lane < cnt) {
-            const uint64_t *my_reg = nullptr;
-            sub_slice(a.d, sbase + lane, j, a.logN, my_reg, my_lo, my_hi);
-            my_off = (uint64_t)(my_reg - wbase);
+            if (!WIDE) {
+                const uint64_t *my_reg = nullptr;
+                sub_slice(a.d, sbase + lane, j, a.logN, my_reg, my_lo, my_hi);
+                my_off = (uint64_t)(my_reg - wbase);
+            } else my_off = sub_slice_off_wide(a.d, sbase + lane, j, a.logN, my_lo, my_hi);
         }
         auto fetch = [&](int t, uint32_t (&q)[AU], uint32_t &lo, uint32_t &hi) {
             const uint64_t off = __shfl((unsigned long long)my_off, t, 64);
@@ -1482,13 +1487,18 @@ __global__ __launch_bounds__(512, SKX_ASM_WPS) void assemble_side_kernel(Assembl
         a.col_mask[r0 + i] = (s_msk[i >> 1] >> (16u * (i & 1u))) & 0xFFFFu;
     }
 }
-void launch_assemble_side(const AssembleArgs &a, const uint16_t *side, const uint16_t *perm, hipStream_t st)
+void launch_assemble_side(const AssembleArgs &a, const uint16_t *side, const uint16_t *perm, hipStream_t st, bool wide)
 {
     const uint32_t maxr = (a.max_rows + 15u) & ~15u;
     const int nw = 8;
     size_t lds = (size_t)maxr * 4 + (size_t)maxr * 2 + (size_t)maxr * 2 + 64 + (size_t)nw * (maxr + 32u);
-    (void)hipFuncSetAttribute((const void *)assemble_side_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(assemble_side_kernel, dim3((1u << a.logN) - a.j_base), dim3(64 * nw), lds, st, a, side, perm);
+    if (wide) {
+        (void)hipFuncSetAttribute((const void *)assemble_side_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(assemble_side_kernel<true>, dim3((1u << a.logN) - a.j_base), dim3(64 * nw), lds, st, a, side, perm);
+        return;
+    }
+    (void)hipFuncSetAttribute((const void *)assemble_side_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(assemble_side_kernel<false>, dim3((1u << a.logN) - a.j_base), dim3(64 * nw), lds, st, a, side, perm);
 }
 template <int MODE>
 static void launch_assemble_t(const AssembleArgs &a, uint32_t n_blocks, hipStream_t st)
