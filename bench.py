@@ -443,6 +443,14 @@ def main():
                                               "what": "skx_keyset_allgather (one ncclAllGather of the per-rank key tables, then their union) + skx_array_reduce_stats "
                                                       "(one ncclAllReduce + one ncclAllGather of the per-row filter statistics), issued by the engine; nothing else crosses xGMI"}
         res["roofline"]["traffic_source"] = traffic_src
+        try:                                     # measurement builds (-DSKX_PHASE_PROF=n, tools/mkvariant.sh): cycle shares per phase of the instrumented kernel
+            import ctypes
+            buf = (ctypes.c_ulonglong * 16)()
+            E._lib.skx_debug_phase_prof(buf, 1)
+            tot = sum(buf) or 1
+            sys.stderr.write("phases (share of cycles): %s cycles in all: %d\n" % ([round(x / tot, 3) for x in buf[:10]], tot))
+        except AttributeError:
+            pass
         if world == 1:
             # the legs below run outside the timed region; the bench's own device buffers go first (the ska executable gets the GPU)
             if last is not None:

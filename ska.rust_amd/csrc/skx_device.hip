@@ -137,6 +137,13 @@ extern "C" void skx_debug_phase_prof(unsigned long long *out, int reset)
 #else
 #define EXT_PROF(i) do { } while (0)
 #endif
+#if defined(SKX_PHASE_PROF) && SKX_PHASE_PROF == 4      // union_kernel: per wave (lane 0), 0 slice look-up, 1 waiting for a slice's words, 2 looking them up, 3 emit
+#define UN_PROF(i) do { if ((threadIdx.x & 63) == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&g_phase_prof[(blockIdx.x & 1023) * 16 + (i)], t_ - tprof); tprof = t_; } } while (0)
+#define UN_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define UN_PROF(i) do { } while (0)
+#define UN_WAIT() do { } while (0)
+#endif
 #if defined(SKX_PHASE_PROF) && SKX_PHASE_PROF == 2
 #define DD_PROF(i) PHASE_PROF_(i)
 #else
@@ -1048,6 +1055,7 @@ __global__ __launch_bounds__(1024, 8) void union_kernel(DictView d, int logN, ui
     __shared__ uint32_t s_tmp[17];
     __shared__ int s_fail;
     __shared__ uint32_t s_nrows;
+    PHASE_PROF_START;
     const uint64_t j = blockIdx.x;
     const uint32_t total_slots = nslots + TABLE_PAD;
     uint16_t *s_rank = reinterpret_cast<uint16_t *>(s_tab + total_slots);      // SIDE: [total_slots] first-seen rank of the key in each slot
@@ -1132,6 +1140,7 @@ __global__ __launch_bounds__(1024, 8) void union_kernel(DictView d, int logN, ui
             }
         };
         uint64_t nx[UU]; uint32_t nlo, nhi; gwords_t nreg;
+        UN_WAIT(); UN_PROF(0);
         fetch(0, nx, nlo, nhi, nreg);
         for (int t = 0; t < cnt; t++) {
             uint64_t cur[UU];
@@ -1141,18 +1150,21 @@ __global__ __launch_bounds__(1024, 8) void union_kernel(DictView d, int logN, ui
 #if SKX_UNION_PREFETCH
             if (t + 1 < cnt) fetch(t + 1, nx, nlo, nhi, nreg);
 #endif
+            UN_WAIT(); UN_PROF(1);
             absorb(cur, reg, lo);
             for (uint32_t o = lo + 64u * UU; o < hi; o += 64u * UU) {          // longer slices: the rest, batch by batch
 #pragma unroll
                 for (int u = 0; u < UU; u++) { const uint32_t i = o + 64u * u + lane; cur[u] = i < hi ? reg[i] : 0ull; }
                 absorb(cur, reg, o);
             }
+            UN_PROF(2);
 #if !SKX_UNION_PREFETCH
             if (t + 1 < cnt) fetch(t + 1, nx, nlo, nhi, nreg);
 #endif
         }
     }
     __syncthreads();
+    UN_PROF(2);
     if (s_fail) { if (threadIdx.x == 0) *overflow = 1; return; }
     if (COUNT_ONLY) {
         uint32_t cnt = 0;
@@ -1171,6 +1183,7 @@ __global__ __launch_bounds__(1024, 8) void union_kernel(DictView d, int logN, ui
         });
     }
     if (threadIdx.x == 0) { ncnt[j] = total; if (total > stride || (SIDE && total > 4095u)) *overflow = 1; }
+    UN_PROF(3);
 }
 template <bool COUNT_ONLY>
 static void launch_union_t(const DictView &d, int logN, unsigned blocks, uint64_t *stage, uint32_t stride, uint32_t *ncnt, uint32_t table_slots,
