@@ -243,6 +243,61 @@ extern "C" void skx_dictset_free(skx_dictset *d) { delete d; }
 extern "C" int skx_dictset_nsamples(const skx_dictset *d) { return d->n; }
 extern "C" int skx_dictset_key_bits(const skx_dictset *d) { return d->key_bits; }
 
+// The passing windows' packed words of every sample (reads_sample_words) -> (sample, bucket) regions like an assembly's -> the same dedupe
+// kernel: sorted, folded, sub-indexed regions, so union / assemble treat reads and assemblies alike.  SKF_NOT_TAKEN: regions the LDS
+// sort cannot hold (the sort-based form takes the batch).
+static int reads_words_to_dictset(skx_ctx *ctx, std::vector<DevBuf<uint64_t>> &wl, std::vector<DevBuf<uint64_t>> &wh2, const std::vector<uint64_t> &cnt,
+                                  int k, int rc, skx_dictset **out)
+{
+    const int n = (int)wl.size();
+    hipStream_t st = ctx->stream;
+    const bool wide_r = k > 31;
+    const int wpk_r = wide_r ? 2 : 1, kbits = 2 * (k - 1);
+    uint64_t maxn = 0;
+    for (auto c : cnt) maxn = std::max(maxn, c);
+    const uint64_t per = wide_r ? 2500 : 3500, lds_max = wide_r ? LDS_SORT_MAX_WIDE : LDS_SORT_MAX;
+    int logB = std::min({ilog2_ceil((maxn + per - 1) / per), kbits, MAX_LOGB});
+    if (logB < 0) logB = 0;
+    std::unique_ptr<skx_dictset> d(new skx_dictset());
+    d->ctx = ctx; d->n = n; d->k = k; d->rc = rc; d->logB = logB; d->hp = make_hash_params(std::min(k, 31)); d->wh = make_wide_hash(k);
+    d->key_bits = wide_r ? 128 : 64;
+    const uint64_t nreg = (uint64_t)n << logB;
+    SKX_TRY(d->raw.alloc(nreg)); SKX_TRY(d->ucnt.alloc(nreg)); SKX_TRY(d->off.alloc(nreg + 1)); SKX_TRY(d->sidx.alloc(nreg * skx::SUBIDX));
+    d->sb = std::min(4, kbits - logB);
+    SKX_TRY(d->raw.zero(st));
+    for (int s = 0; s < n; s++) launch_words_regions(true, wl[s].p, wide_r ? wh2[s].p : nullptr, cnt[s], kbits, logB, (uint64_t)s << logB, d->raw.p, nullptr, nullptr, nullptr, st);
+    DevBuf<uint32_t> d_max, cursor; SKX_TRY(d_max.alloc(1)); SKX_TRY(cursor.alloc(nreg)); SKX_TRY(cursor.zero(st));
+    launch_scan_u32(d->raw.p, d->off.p, nreg, d_max.p, st);
+    uint64_t total = 0; uint32_t max_raw = 0;
+    SKX_HIP(hipMemcpyAsync(&total, d->off.p + nreg, 8, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipMemcpyAsync(&max_raw, d_max.p, 4, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipStreamSynchronize(st));
+    if (max_raw > lds_max) { if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] reads: region of %u words, batch left to the sort-based form\n", max_raw); return SKF_NOT_TAKEN; }   // e.g. min_count 2 on deep reads: every repeat occurrence is a word
+    SKX_TRY(d->words.alloc(std::max<uint64_t>(total, 1) * wpk_r));
+    for (int s = 0; s < n; s++) {
+        launch_words_regions(false, wl[s].p, wide_r ? wh2[s].p : nullptr, cnt[s], kbits, logB, (uint64_t)s << logB, nullptr, d->off.p, cursor.p, d->words.p, st);
+        wl[s].release(); wh2[s].release();
+    }
+    const uint32_t cap = std::max<uint32_t>(512, (uint32_t)std::min<uint64_t>(((uint64_t)max_raw + 255) / 256 * 256, lds_max));
+    DevBuf<int> d_flag2; SKX_TRY(d_flag2.alloc(1)); SKX_TRY(d_flag2.zero(st));
+    SKX_HIP(hipMemsetAsync(d->sidx.p, 0xFF, nreg * skx::SUBIDX * sizeof(uint16_t), st));
+    { StageTimer t(ctx, &ctx->tm.dedupe);
+      if (wide_r) launch_dedupe_wide((u128 *)d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, cap, kbits - logB, d_flag2.p, d->sidx.p, d->sb, st);
+      else launch_dedupe_mb(d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, cap, d->hp.bits - logB, d_flag2.p, d->sidx.p, d->sb, st); }
+    int overflow = 0;
+    std::vector<uint32_t> ucnt(nreg);
+    SKX_HIP(hipMemcpyAsync(&overflow, d_flag2.p, 4, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipMemcpyAsync(ucnt.data(), d->ucnt.p, nreg * 4, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipStreamSynchronize(st));
+    SKX_HIP(hipGetLastError());
+    if (overflow) { if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] reads: dedupe overflow, batch left to the sort-based form\n"); return SKF_NOT_TAKEN; }
+    d->sample_size.assign(n, 0);
+    for (int s = 0; s < n; s++) for (uint64_t b = 0; b < (1ull << logB); b++) d->sample_size[s] += ucnt[((uint64_t)s << logB) + b];
+    *out = d.release();
+    return SKX_OK;
+
+}
+
 static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *> &seqs, const std::vector<const uint8_t *> &quals,
                                 const std::vector<uint64_t> &lens, int k, int rc, const skx_qual *q, skx_dictset **out)
 {
@@ -299,46 +354,7 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
             if (r != SKX_OK) return r;                                                       // SKF_NOT_TAKEN included
             maxn = std::max(maxn, cnt[s]);
         }
-        const uint64_t per = wide_r ? 2500 : 3500, lds_max = wide_r ? LDS_SORT_MAX_WIDE : LDS_SORT_MAX;
-        int logB = std::min({ilog2_ceil((maxn + per - 1) / per), kbits, MAX_LOGB});
-        if (logB < 0) logB = 0;
-        std::unique_ptr<skx_dictset> d(new skx_dictset());
-        d->ctx = ctx; d->n = n; d->k = k; d->rc = rc; d->logB = logB; d->hp = make_hash_params(std::min(k, 31)); d->wh = make_wide_hash(k);
-        d->key_bits = wide_r ? 128 : 64;
-        const uint64_t nreg = (uint64_t)n << logB;
-        SKX_TRY(d->raw.alloc(nreg)); SKX_TRY(d->ucnt.alloc(nreg)); SKX_TRY(d->off.alloc(nreg + 1)); SKX_TRY(d->sidx.alloc(nreg * skx::SUBIDX));
-        d->sb = std::min(4, kbits - logB);
-        SKX_TRY(d->raw.zero(st));
-        for (int s = 0; s < n; s++) launch_words_regions(true, wl[s].p, wide_r ? wh2[s].p : nullptr, cnt[s], kbits, logB, (uint64_t)s << logB, d->raw.p, nullptr, nullptr, nullptr, st);
-        DevBuf<uint32_t> d_max, cursor; SKX_TRY(d_max.alloc(1)); SKX_TRY(cursor.alloc(nreg)); SKX_TRY(cursor.zero(st));
-        launch_scan_u32(d->raw.p, d->off.p, nreg, d_max.p, st);
-        uint64_t total = 0; uint32_t max_raw = 0;
-        SKX_HIP(hipMemcpyAsync(&total, d->off.p + nreg, 8, hipMemcpyDeviceToHost, st));
-        SKX_HIP(hipMemcpyAsync(&max_raw, d_max.p, 4, hipMemcpyDeviceToHost, st));
-        SKX_HIP(hipStreamSynchronize(st));
-        if (max_raw > lds_max) { if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] reads: region of %u words, batch left to the sort-based form\n", max_raw); return SKF_NOT_TAKEN; }   // e.g. min_count 2 on deep reads: every repeat occurrence is a word
-        SKX_TRY(d->words.alloc(std::max<uint64_t>(total, 1) * wpk_r));
-        for (int s = 0; s < n; s++) {
-            launch_words_regions(false, wl[s].p, wide_r ? wh2[s].p : nullptr, cnt[s], kbits, logB, (uint64_t)s << logB, nullptr, d->off.p, cursor.p, d->words.p, st);
-            wl[s].release(); wh2[s].release();
-        }
-        const uint32_t cap = std::max<uint32_t>(512, (uint32_t)std::min<uint64_t>(((uint64_t)max_raw + 255) / 256 * 256, lds_max));
-        DevBuf<int> d_flag2; SKX_TRY(d_flag2.alloc(1)); SKX_TRY(d_flag2.zero(st));
-        SKX_HIP(hipMemsetAsync(d->sidx.p, 0xFF, nreg * skx::SUBIDX * sizeof(uint16_t), st));
-        { StageTimer t(ctx, &ctx->tm.dedupe);
-          if (wide_r) launch_dedupe_wide((u128 *)d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, cap, kbits - logB, d_flag2.p, d->sidx.p, d->sb, st);
-          else launch_dedupe_mb(d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, cap, d->hp.bits - logB, d_flag2.p, d->sidx.p, d->sb, st); }
-        int overflow = 0;
-        std::vector<uint32_t> ucnt(nreg);
-        SKX_HIP(hipMemcpyAsync(&overflow, d_flag2.p, 4, hipMemcpyDeviceToHost, st));
-        SKX_HIP(hipMemcpyAsync(ucnt.data(), d->ucnt.p, nreg * 4, hipMemcpyDeviceToHost, st));
-        SKX_HIP(hipStreamSynchronize(st));
-        SKX_HIP(hipGetLastError());
-        if (overflow) { if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] reads: dedupe overflow, batch left to the sort-based form\n"); return SKF_NOT_TAKEN; }
-        d->sample_size.assign(n, 0);
-        for (int s = 0; s < n; s++) for (uint64_t b = 0; b < (1ull << logB); b++) d->sample_size[s] += ucnt[((uint64_t)s << logB) + b];
-        *out = d.release();
-        return SKX_OK;
+        return reads_words_to_dictset(ctx, wl, wh2, cnt, k, rc, out);
     };
     auto build_reads = [&]() -> int {
         if (!getenv("SKX_READS_SORT")) {
@@ -500,12 +516,220 @@ extern "C" int skx_dictset_build(skx_ctx *ctx, const skx_stream *samples, int n,
     });
 }
 
+
+// Read sets (every sample plain FASTQ, one or two files), pipelined.  The one-shot form below reads every sample, allocates stream buffers the
+// size of all files together (24 GB for 96 isolates of BASELINE config 5's shape: a 1-3 s allocation when the memory has just been released
+// by another process) and then filters one isolate after the other (11 ms each) on an idle PCIe link.  Here a small pool of stream slots
+// (two device buffers per slot, sized for the largest sample) is filled by the reader threads through the pinned ring, and this thread runs a
+// sample's window / count-filter kernels (reads_sample_words) as soon as its last piece has arrived, then hands the slot back: reading,
+// upload and kernels overlap, and the device holds a few samples' text instead of all of it.  Results are those of the one-shot form
+// (the per-sample kernels do not depend on the order samples arrive in).  SKF_NOT_TAKEN: not this kind of input, or a sample the
+// partition kernels leave to the sort-based form -- the caller takes the one-shot path from the start.
+static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const char *const *file2, int n, int k, int rc, const skx_qual *q, int threads,
+                                 skx_dictset **out)
+{
+    if (getenv("SKX_NO_READS_PIPELINE") || n < 2) return SKF_NOT_TAKEN;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<uint64_t> bound(n, 0);
+    uint64_t slot_bytes = 0;
+    for (int i = 0; i < n; i++) {
+        uint64_t bytes = 0;
+        for (const char *f : {file1[i], file2 ? file2[i] : nullptr}) {
+            if (!f) continue;
+            struct stat sb; unsigned char c0 = 0;
+            const int fd = ::open(f, O_RDONLY);
+            const bool ok = fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && ::read(fd, &c0, 1) == 1 && c0 == '@';
+            if (fd >= 0) ::close(fd);
+            if (!ok) return SKF_NOT_TAKEN;
+            bytes += (uint64_t)sb.st_size;
+        }
+        bound[i] = (bytes / 2 + 64 + 255) & ~255ull;                             // plain FASTQ holds at most half its bytes in either stream
+        slot_bytes = std::max(slot_bytes, bound[i]);
+    }
+    SKX_HIP(hipSetDevice(ctx->device));
+    const int nt = std::max(1, std::min({threads, n, 64}));
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    // a slot per reader thread and a few waiting for their kernels: more only costs allocation time (64 slots = 17 GB took 4.7 s right after
+    // another process had released the memory, 32 slots 0.26 s: profiles/r03zr_reads_pipeline_512.log)
+    int P = (int)std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(2, std::min<uint64_t>((uint64_t)nt + 8, (free_b / 8) / (2 * slot_bytes + 1))));
+    if (const char *e = getenv("SKX_READS_POOL")) P = std::max(1, std::min(n, atoi(e)));
+    DevBuf<uint8_t> seq_pool, qual_pool;
+    SKX_TRY(seq_pool.alloc((uint64_t)P * slot_bytes)); SKX_TRY(qual_pool.alloc((uint64_t)P * slot_bytes));
+    constexpr size_t SLOT = 8u << 20;
+    const int n_slots = 2 * nt + 8;
+    struct Sample { int slot = -1; int pending = 0; bool read_done = false, queued = false; uint64_t len = 0; };
+    struct Ring {
+        uint8_t *base = nullptr; std::mutex mu; std::condition_variable cv_free, cv_work, cv_stream, cv_ready;
+        std::vector<int> free_slots, free_stream; struct Req { int slot; uint8_t *dst; size_t bytes; int sample; }; std::deque<Req> work;
+        std::deque<int> ready; int readers_left = 0; bool failed = false, abort = false;
+        ~Ring() { if (base) (void)hipHostFree(base); }
+    } ring;
+    if (hipHostMalloc((void **)&ring.base, (size_t)n_slots * SLOT, hipHostMallocDefault) != hipSuccess) { ring.base = nullptr; return SKF_NOT_TAKEN; }
+    for (int b = 0; b < n_slots; b++) ring.free_slots.push_back(b);
+    for (int p = 0; p < P; p++) ring.free_stream.push_back(p);
+    ring.readers_left = nt;
+    phase_add("build.alloc_text_pin_ring", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    std::vector<Sample> smp(n);
+    std::vector<int> rcodes(n, SKX_OK);
+    std::vector<std::string> errs(n);
+    auto mark_ready_locked = [&](int i) { Sample &x = smp[i]; if (x.read_done && x.pending == 0 && !x.queued) { x.queued = true; ring.ready.push_back(i); } };
+    std::vector<std::thread> uploaders;
+    const int n_up = getenv("SKX_UPLOADERS") ? std::max(1, atoi(getenv("SKX_UPLOADERS"))) : 2;
+    for (int u = 0; u < n_up; u++) uploaders.emplace_back([&]() {
+        (void)hipSetDevice(ctx->device);
+        hipStream_t up = nullptr;
+        if (hipStreamCreateWithFlags(&up, hipStreamNonBlocking) != hipSuccess) up = nullptr;
+        std::vector<Ring::Req> batch;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(ring.mu);
+                ring.cv_work.wait(lk, [&] { return !ring.work.empty() || ring.readers_left == 0; });
+                if (ring.work.empty() && ring.readers_left == 0) break;
+                const size_t take = std::max<size_t>(1, ring.work.size() / 2);
+                batch.assign(ring.work.begin(), ring.work.begin() + (ptrdiff_t)take); ring.work.erase(ring.work.begin(), ring.work.begin() + (ptrdiff_t)take);
+            }
+            bool bad = false;
+            for (auto &r : batch) bad |= hipMemcpyAsync(r.dst, ring.base + (size_t)r.slot * SLOT, r.bytes, hipMemcpyHostToDevice, up) != hipSuccess;
+            bad |= hipStreamSynchronize(up) != hipSuccess;
+            {
+                std::lock_guard<std::mutex> lk(ring.mu);
+                if (bad) { ring.failed = true; ring.abort = true; }
+                for (auto &r : batch) { ring.free_slots.push_back(r.slot); smp[r.sample].pending--; mark_ready_locked(r.sample); }
+            }
+            ring.cv_free.notify_all(); ring.cv_ready.notify_all();
+            if (bad) { ring.cv_stream.notify_all(); }
+        }
+        if (up) (void)hipStreamDestroy(up);
+    });
+    std::vector<std::thread> pool;
+    std::atomic<int> next{0};
+    for (int t = 0; t < nt; t++)
+        pool.emplace_back([&]() {
+            struct Leave { Ring &r; ~Leave() { { std::lock_guard<std::mutex> lk(r.mu); r.readers_left--; } r.cv_work.notify_all(); r.cv_ready.notify_all(); } } leave{ring};
+            for (int i; (i = next.fetch_add(1)) < n;) {
+                int sslot = -1;
+                {
+                    std::unique_lock<std::mutex> lk(ring.mu);
+                    ring.cv_stream.wait(lk, [&] { return !ring.free_stream.empty() || ring.abort; });
+                    if (ring.abort) return;
+                    sslot = ring.free_stream.back(); ring.free_stream.pop_back();
+                    smp[i].slot = sslot;
+                }
+                struct Out { int slot = -1; size_t used = 0; uint8_t *dst = nullptr; uint64_t off = 0; } o[2];
+                o[0].dst = seq_pool.p + (uint64_t)sslot * slot_bytes; o[1].dst = qual_pool.p + (uint64_t)sslot * slot_bytes;
+                const uint64_t cap = bound[i] - 32;
+                auto flush = [&](Out &x) {
+                    if (x.slot < 0) return;
+                    { std::lock_guard<std::mutex> lk(ring.mu); ring.work.push_back({x.slot, x.dst + x.off, x.used, i}); smp[i].pending++; }
+                    ring.cv_work.notify_one();
+                    x.off += x.used; x.slot = -1; x.used = 0;
+                };
+                auto give_back = [&]() {
+                    for (auto &x : o) if (x.slot >= 0) { { std::lock_guard<std::mutex> lk(ring.mu); ring.free_slots.push_back(x.slot); } ring.cv_free.notify_one(); x.slot = -1; }
+                };
+                const std::function<int(int, const uint8_t *, size_t)> emit = [&](int which, const uint8_t *p, size_t nb) -> int {
+                    Out &x = o[which];
+                    if (x.off + x.used + nb + 1 > cap) { set_error("Invalid FASTA/Q record"); return SKX_EIO; }
+                    if (x.slot >= 0 && x.used + nb + 1 <= SLOT) {
+                        uint8_t *d = ring.base + (size_t)x.slot * SLOT + x.used;
+                        memcpy(d, p, nb); d[nb] = '\n';
+                        x.used += nb + 1;
+                        if (x.used == SLOT) flush(x);
+                        return SKX_OK;
+                    }
+                    bool term = false;
+                    static const uint8_t nl = '\n';
+                    for (;;) {
+                        if (nb == 0) { if (term) break; term = true; p = &nl; nb = 1; }
+                        if (x.slot < 0) {
+                            std::unique_lock<std::mutex> lk(ring.mu);
+                            ring.cv_free.wait(lk, [&] { return !ring.free_slots.empty() || ring.abort; });
+                            if (ring.abort) { set_error("upload of the sequence files failed"); return SKX_ENODEV; }
+                            x.slot = ring.free_slots.back(); ring.free_slots.pop_back(); x.used = 0;
+                        }
+                        const size_t take = std::min(nb, SLOT - x.used);
+                        memcpy(ring.base + (size_t)x.slot * SLOT + x.used, p, take);
+                        x.used += take; p += take; nb -= take;
+                        if (x.used == SLOT) flush(x);
+                    }
+                    return SKX_OK;
+                };
+                int r = SKX_OK;
+                for (const char *f : {file1[i], file2 ? file2[i] : nullptr}) {
+                    if (!f) continue;
+                    r = stream_fastq_file(f, emit);
+                    if (r == SKF_NOT_TAKEN) { set_error("Invalid FASTA/Q record"); r = SKX_EIO; }      // (the first byte was '@' a moment ago)
+                    if (r != SKX_OK) break;
+                }
+                if (r == SKX_OK) { flush(o[0]); flush(o[1]); if (o[0].off != o[1].off) { set_error("Invalid FASTA/Q record"); r = SKX_EIO; } }
+                if (r != SKX_OK) {
+                    give_back();
+                    rcodes[i] = r; errs[i] = skx_last_error();
+                    { std::lock_guard<std::mutex> lk(ring.mu); ring.abort = true; }
+                    ring.cv_stream.notify_all(); ring.cv_free.notify_all(); ring.cv_ready.notify_all();
+                    return;
+                }
+                { std::lock_guard<std::mutex> lk(ring.mu); smp[i].len = o[0].off; smp[i].read_done = true; mark_ready_locked(i); }
+                ring.cv_ready.notify_all();
+            }
+        });
+    // this thread: a sample's kernels as soon as its text is on the device
+    std::vector<DevBuf<uint64_t>> wl(n), wh2(n);
+    std::vector<uint64_t> cnt(n, 0);
+    int done = 0, krc = SKX_OK;
+    double t_kernels = 0.0;
+    while (done < n) {
+        int i = -1;
+        {
+            std::unique_lock<std::mutex> lk(ring.mu);
+            ring.cv_ready.wait(lk, [&] { return !ring.ready.empty() || ring.abort; });      // (every sample is queued by whoever sees its last piece arrive)
+            if (ring.abort) break;
+            i = ring.ready.front(); ring.ready.pop_front();
+        }
+        const auto tk = std::chrono::steady_clock::now();
+        skx_qual qs = q ? *q : skx_qual{5, 20, SKX_QUAL_STRICT};
+        const uint8_t *ds = seq_pool.p + (uint64_t)smp[i].slot * slot_bytes, *dq = qual_pool.p + (uint64_t)smp[i].slot * slot_bytes;
+        krc = reads_sample_words(ctx, ds, dq, smp[i].len, k, rc, qs, wl[i], wh2[i], &cnt[i]);      // (returns with the stream idle: the slot is free)
+        t_kernels += std::chrono::duration<double>(std::chrono::steady_clock::now() - tk).count();
+        { std::lock_guard<std::mutex> lk(ring.mu); ring.free_stream.push_back(smp[i].slot); if (krc != SKX_OK) ring.abort = true; }
+        ring.cv_stream.notify_all();
+        if (krc != SKX_OK) { ring.cv_free.notify_all(); break; }
+        done++;
+    }
+    { std::lock_guard<std::mutex> lk(ring.mu); if (done < n) ring.abort = true; }
+    ring.cv_stream.notify_all(); ring.cv_free.notify_all();
+    for (auto &th : pool) th.join();
+    for (auto &u : uploaders) u.join();
+    phase_add("build.read_upload", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    phase_add("build.reads_kernels_overlapped", t_kernels);
+    if (ring.failed) { set_error("upload of the sequence files failed"); return SKX_ENODEV; }
+    for (int i = 0; i < n; i++) if (rcodes[i] != SKX_OK) { set_error("%s", errs[i].c_str()); return rcodes[i]; }
+    if (krc != SKX_OK) return krc;                                              // SKF_NOT_TAKEN included: the one-shot form takes the batch
+    if (done < n) { set_error("internal: read-set pipeline stopped early"); return SKX_EUNSUP; }
+    seq_pool.release(); qual_pool.release();
+    const auto t1 = std::chrono::steady_clock::now();
+    skx_dictset *d = nullptr;
+    int r = reads_words_to_dictset(ctx, wl, wh2, cnt, k, rc, &d);
+    if (r == SKF_NOT_TAKEN) return r;                                           // (regions beyond the LDS sort: the sort-based form, from the files)
+    if (r != SKX_OK) return r;
+    phase_add("build.dictionaries", std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
+    for (int sidx2 = 0; sidx2 < n; sidx2++)
+        if (d->sample_size[sidx2] == 0) { set_error("%s has no valid sequence", file1[sidx2]); delete d; return SKX_EEMPTY; }
+    *out = d;
+    return SKX_OK;
+}
+
 extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, const char *const *file2, int n, int k, int rc,
                                        const skx_qual *q, int threads, double proportion_reads, skx_dictset **out)
 {
     return skx_guarded([&]() -> int {
     if (!ctx || !file1 || n <= 0 || !out) { set_error("bad arguments"); return SKX_EINVAL; }
     SKX_TRY(check_k(k));
+    if (!(proportion_reads > 0.0) && !getenv("SKX_HOST_PARSE") && !getenv("SKX_READS_SORT")) {
+        const int pr = build_reads_pipelined(ctx, file1, file2, n, k, rc, q, threads, out);
+        if (pr != SKF_NOT_TAKEN) return pr;
+    }
     // Reader threads.  A plain (uncompressed, single-file) FASTA sample is not parsed on the host at all: its bytes are read
     // into pinned memory and uploaded as they are, and the device strips headers and line breaks (skx_parse.hip) -- the host
     // side of an assembly is one read() and one asynchronous copy.  FASTQ, .gz and two-file samples are parsed by the host

@@ -42,6 +42,16 @@ for mb in os.environ.get("RSC_BATCH_MB", "").split():
 for up in os.environ.get("RSC_UPLOADERS", "").split():
     run(f"ska build with SKX_UPLOADERS={up}", [SKA, "build", "-f", "list.txt", "-o", "two", "--threads", os.environ.get("RSC_THREADS", "16"), *opts], {"SKX_PHASES": os.path.join(td, "ph2.json"), "SKX_UPLOADERS": up})
     print("  phases", open(os.path.join(td, "ph2.json")).read()[:330])
+if os.environ.get("RSC_ONE_SHOT"):                               # the same build without the reader / kernel pipeline: the .skf must be the same bytes
+    run("ska build, one-shot form (SKX_NO_READS_PIPELINE=1)", [SKA, "build", "-f", "list.txt", "-o", "oneshot", "--threads", os.environ.get("RSC_THREADS", "16"), *opts],
+        {"SKX_PHASES": os.path.join(td, "ph5.json"), "SKX_NO_READS_PIPELINE": "1"})
+    print("  phases", open(os.path.join(td, "ph5.json")).read()[:420])
+    same = open(os.path.join(td, "one.skf"), "rb").read() == open(os.path.join(td, "oneshot.skf"), "rb").read()
+    print("  one-shot .skf", "IDENTICAL to" if same else "DIFFERENT from", "the pipelined build's")
+    assert same
+for th in os.environ.get("RSC_THREADS_SWEEP", "").split():      # the same build with other reader-thread counts
+    run(f"ska build --threads {th}", [SKA, "build", "-f", "list.txt", "-o", "sweep", "--threads", th, *opts], {"SKX_PHASES": os.path.join(td, "ph4.json")})
+    print("  phases", open(os.path.join(td, "ph4.json")).read()[:420])
 run("ska distance one.skf", [SKA, "distance", "one.skf", "-o", "one.tsv"])
 print(f"  = {n / tb:.1f} isolates/s through the executable (files on tmpfs)")
 print(f"  one.skf {os.path.getsize(os.path.join(td, 'one.skf')) / 1e9:.2f} GB, one.tsv {os.path.getsize(os.path.join(td, 'one.tsv')) / 1e6:.1f} MB")
