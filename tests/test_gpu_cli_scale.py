@@ -311,3 +311,37 @@ def test_builds_are_deterministic(tmp_path, monkeypatch):
     rc, a1, err = ska("align", "a.skf", cwd=wd)
     rc2, a2, err2 = ska("align", "--threads", "2", *files, cwd=wd)
     assert rc == 0 and rc2 == 0 and a1 == a2
+
+
+def test_read_set_pipeline_equals_one_shot(tmp_path):
+    """`ska build` on read sets runs reader threads, uploads and the per-isolate kernels as a pipeline over a small pool of device slots
+    (skx_api.cpp build_reads_pipelined); SKX_NO_READS_PIPELINE=1 is the one-shot form it replaced.  Same .skf bytes either way and with a
+    pool of ONE slot (every sample reuses it), for paired and single-file samples, k = 31 and 41; a broken record fails both forms with the
+    reference's message (ska_dict.rs:131-153 via needletail)."""
+    import synth
+    wd = str(tmp_path)
+    anc = synth.ancestor(60_000, seed=3)
+    n = 6
+    pairs = [synth.write_read_pair(anc, i, n, os.path.join(wd, f"r{i}"), read_len=100, coverage=25.0, seed=3) for i in range(n)]
+    with open(os.path.join(wd, "list.txt"), "w") as f:
+        for i, (a, b) in enumerate(pairs):
+            f.write(f"r{i}\t{a}\t{b}\n" if i % 3 else f"r{i}\t{a}\n")                     # every third sample: one file only
+    for k in ("31", "41"):
+        outs = {}
+        for tag, env in (("pipe", {}), ("pool1", {"SKX_READS_POOL": "1"}), ("oneshot", {"SKX_NO_READS_PIPELINE": "1"})):
+            r = subprocess.run([SKA, "build", "-f", "list.txt", "-o", f"{tag}{k}", "-k", k, "--min-count", "3", "--threads", "4"], cwd=wd, capture_output=True,
+                               timeout=300, env=dict(os.environ, **env))
+            assert r.returncode == 0, r.stderr[-600:]
+            outs[tag] = open(os.path.join(wd, f"{tag}{k}.skf"), "rb").read()
+        assert outs["pipe"] == outs["oneshot"] and outs["pool1"] == outs["oneshot"]
+        want = ora.Array.build([(f"r{i}", a, b if i % 3 else None) for i, (a, b) in enumerate(pairs)], k=int(k), rc=True, q=ora.qual(3, 20, ora.QUAL_STRICT), threads=2)
+        got = ora.Array.load(os.path.join(wd, f"pipe{k}.skf"))
+        got.sort_rows(); want.sort_rows()
+        gk, gv, gc = got.export()
+        ok, ov, oc = want.export()
+        assert len(ok) > 10_000 and np.array_equal(gk, ok) and np.array_equal(gv, ov) and np.array_equal(gc, oc)
+    bad = open(pairs[2][0], "rb").read()
+    open(pairs[2][0], "wb").write(bad[:len(bad) // 2 - 7])                                # a record cut in the middle
+    for env in ({}, {"SKX_NO_READS_PIPELINE": "1"}):
+        r = subprocess.run([SKA, "build", "-f", "list.txt", "-o", "broken", "-k", "31", "--min-count", "3"], cwd=wd, capture_output=True, timeout=300, env=dict(os.environ, **env))
+        assert r.returncode != 0 and b"Invalid FASTA/Q record" in r.stderr, r.stderr[-400:]
