@@ -1173,7 +1173,8 @@ static int keyset_union_views(skx_ctx *ctx, const DictView *views, int nviews, i
 static int keyset_union_dict(skx_ctx *ctx, skx_dictset *d, skx_keyset **out, bool with_side);
 extern "C" int skx_keyset_union(skx_ctx *ctx, skx_dictset *d, skx_keyset **out)
 {
-    return skx_guarded([&]() -> int { return keyset_union_dict(ctx, d, out, false); });
+    // (with the notes: a sharded job hands this key set to skx_keyset_allgather, which carries them over to the global rows)
+    return skx_guarded([&]() -> int { return keyset_union_dict(ctx, d, out, !getenv("SKX_NO_SHARD_SIDE")); });
 }
 static int keyset_union_dict(skx_ctx *ctx, skx_dictset *d, skx_keyset **out, bool with_side)
 {
@@ -1352,7 +1353,14 @@ extern "C" int skx_array_assemble(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows
         aa.max_rows = rows->max_rows; aa.missing = d_flag.p;
         {
             StageTimer t(ctx, &ctx->tm.assemble);
-            if (rows->side.p && rows->side_of == d && !rebuilt) launch_assemble_side(aa, rows->side.p, rows->perm.p, st, rows->wide);      // the union over d left its notes
+            if (rows->g_perm.p && rows->side.p && rows->side_of == d && !rebuilt && !rows->wide) {
+                // a sharded job: the notes were taken against this rank's own rows and composed with the global rows (skx_keyset_allgather):
+                // workgroup j = own sub-bucket j, over the global rows of its hash range
+                AssembleArgs ag = aa;
+                ag.logN = rows->l_logN; ag.stride = rows->l_stride; ag.ncnt = rows->g_n.p; ag.roff = rows->g_base.p; ag.max_rows = rows->g_max;
+                launch_assemble_side(ag, rows->side.p, rows->g_perm.p, st, false);
+            }
+            else if (rows->side.p && !rows->g_perm.p && rows->side_of == d && !rebuilt) launch_assemble_side(aa, rows->side.p, rows->perm.p, st, rows->wide);      // the union over d left its notes
             else if (rows->wide) launch_assemble_wide(aa, st);
             else launch_assemble(aa, st);
         }

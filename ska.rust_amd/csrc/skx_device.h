@@ -148,6 +148,9 @@ bool union_side_ok(const DictView &d, int logN, uint32_t stride);
 void launch_union_side(const DictView &d, int logN, uint64_t *stage, uint32_t stride, uint32_t *ncnt, uint32_t table_slots, int *overflow,
                        uint16_t *side, uint16_t *perm, hipStream_t st);
 void launch_assemble_side(const AssembleArgs &a, const uint16_t *side, const uint16_t *perm, hipStream_t st, bool wide = false);
+void launch_compose_perm(const uint64_t *l_stage, uint32_t l_stride, const uint32_t *l_ncnt, const uint16_t *l_perm, int l_logN, const uint64_t *g_stage,
+                         uint32_t g_stride, const uint32_t *g_ncnt, const uint64_t *g_roff, int g_logN, int bits, uint16_t *g_perm, uint32_t *g_n,
+                         uint64_t *g_base, uint32_t *g_max, int *bad, hipStream_t st);
 void launch_union_side_wide(const DictView &d, int logN, u128 *stage, uint32_t stride, uint32_t *ncnt, uint32_t table_slots, int *overflow,
                             uint16_t *side, uint16_t *perm, hipStream_t st);
 

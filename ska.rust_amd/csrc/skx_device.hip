@@ -1417,7 +1417,7 @@ __global__ __launch_bounds__(512, SKX_ASM_WPS) void assemble_side_kernel(Assembl
     unsigned char *s_rows = reinterpret_cast<unsigned char *>(s_perm + maxr);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const uint16_t *pj = perm + j * (uint64_t)a.stride;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { s_cnt[i] = 0; if (!(i & 1u)) s_msk[i >> 1] = 0; s_perm[i] = pj[i]; }
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { s_cnt[i] = 0; if (!(i & 1u)) s_msk[i >> 1] = 0; s_perm[i] = i < a.stride ? pj[i] : (uint16_t)0; }      // (composed notes: n = the global rows of the range may exceed the ranks a perm row holds)
     __syncthreads();
     const uint64_t r0 = a.roff[j];
     const uint64_t ocol = r0 - a.col_base;
@@ -1545,6 +1545,47 @@ void launch_gather_keys(const uint64_t *stage, uint32_t stride, const uint32_t *
                         int unhash, HashParams hp, hipStream_t st)
 {
     hipLaunchKernelGGL(gather_keys_kernel, dim3((unsigned)n_sub), dim3(256), 0, st, stage, stride, ncnt, roff, out, unhash, hp);
+}
+// A rank's notes (union_kernel<.., SIDE> over its own dictionaries) against the rows of the whole job: workgroup j = own sub-bucket j (2^l_logN
+// of them), whose hash range is covered by 2^(g_logN - l_logN) consecutive global sub-buckets.  Every own row is looked up in the global slab it
+// falls into (binary search; the slabs hold the same packed words, base nibble 1); g_perm[j][rank] = that row's place among the range's global
+// rows, g_base[j] / g_n[j] = the range's first global row and row count.  *bad: a key missing from the global rows, or a range beyond 65 535 rows.
+__global__ __launch_bounds__(256) void compose_perm_kernel(const uint64_t *l_stage, uint32_t l_stride, const uint32_t *l_ncnt, const uint16_t *l_perm, int l_logN,
+                                                           const uint64_t *g_stage, uint32_t g_stride, const uint32_t *g_ncnt, const uint64_t *g_roff, int g_logN,
+                                                           int bits, uint16_t *g_perm, uint32_t *g_n, uint64_t *g_base, uint32_t *g_max, int *bad)
+{
+    extern __shared__ uint16_t s_rel[];                                   // [l_stride] own row -> place in the range
+    const uint64_t j = blockIdx.x;
+    const int d = g_logN - l_logN;
+    const uint64_t base = g_roff[j << d], end = g_roff[(j + 1) << d];
+    const uint32_t nl = l_ncnt[j];
+    if (threadIdx.x == 0) {
+        g_base[j] = base; g_n[j] = (uint32_t)(end - base);
+        if (end - base > 65535ull) *bad = 1;
+        atomicMax(g_max, (uint32_t)(end - base));
+    }
+    const uint64_t *ls = l_stage + j * (uint64_t)l_stride;
+    for (uint32_t r = threadIdx.x; r < nl; r += blockDim.x) {
+        const uint64_t key = ls[r] >> 4;
+        const uint64_t jg = key >> (bits - g_logN);
+        const uint64_t *gs = g_stage + jg * (uint64_t)g_stride;
+        uint32_t lo = 0, hi = g_ncnt[jg];
+        const uint32_t n = hi;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((gs[mid] >> 4) < key) lo = mid + 1; else hi = mid; }
+        if (lo >= n || (gs[lo] >> 4) != key) *bad = 1;
+        s_rel[r] = (uint16_t)(g_roff[jg] + lo - base);
+    }
+    __syncthreads();
+    const uint16_t *lp = l_perm + j * (uint64_t)l_stride;
+    uint16_t *gp = g_perm + j * (uint64_t)l_stride;
+    for (uint32_t r = threadIdx.x; r < nl; r += blockDim.x) { const uint32_t row = lp[r]; gp[r] = row < nl ? s_rel[row] : (uint16_t)0; }
+}
+void launch_compose_perm(const uint64_t *l_stage, uint32_t l_stride, const uint32_t *l_ncnt, const uint16_t *l_perm, int l_logN, const uint64_t *g_stage,
+                         uint32_t g_stride, const uint32_t *g_ncnt, const uint64_t *g_roff, int g_logN, int bits, uint16_t *g_perm, uint32_t *g_n,
+                         uint64_t *g_base, uint32_t *g_max, int *bad, hipStream_t st)
+{
+    hipLaunchKernelGGL(compose_perm_kernel, dim3(1u << l_logN), dim3(256), (size_t)l_stride * 2, st, l_stage, l_stride, l_ncnt, l_perm, l_logN, g_stage, g_stride,
+                       g_ncnt, g_roff, g_logN, bits, g_perm, g_n, g_base, g_max, bad);
 }
 // split k-mers as the .skf stores them: CBOR uints, 0x1b + 8 big-endian bytes each (a key below 2^32 has a shorter minimal form:
 // *short_key is set and the host encodes the list instead).  256 keys per workgroup through LDS, written as dwords.

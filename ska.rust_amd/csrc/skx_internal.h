@@ -121,6 +121,13 @@ struct skx_keyset {
     skx::DevBuf<uint16_t> side;      // [side_of->words.n] (first-seen rank in the sub-bucket << 4) | base set
     skx::DevBuf<uint16_t> perm;      // [1 << logN][stride] first-seen rank -> row of the slab
     const skx_dictset *side_of = nullptr;
+    // the same notes carried over to the rows of a sharded job (skx_keyset_allgather): they were taken against the rank's OWN rows; per own
+    // sub-bucket, g_perm maps a first-seen rank to its row among the GLOBAL rows of that sub-bucket's hash range, which start at row g_base
+    // and number g_n (skx_array_assemble then fills the rank's columns over the global rows without reading its dictionaries again)
+    skx::DevBuf<uint16_t> g_perm;    // [1 << l_logN][l_stride]
+    skx::DevBuf<uint32_t> g_n;       // [1 << l_logN]
+    skx::DevBuf<uint64_t> g_base;    // [1 << l_logN]
+    int l_logN = -1; uint32_t l_stride = 0, g_max = 0;
 };
 
 struct skx_array {
