@@ -244,7 +244,7 @@ __global__ __launch_bounds__(TILE / PPT, SPLIT ? 6 : 1) void extract_kernel(Extr
             pos = (tile + PF_AHEAD - (len + TILE - 1) / TILE) * TILE + (uint64_t)tid * 128;
             ps = (gbytes_t)(uintptr_t)a.seqs[sample + 8]; plen = a.lens[sample + 8];
         }
-        if (pos < plen) pfw = *(const uint32_t __attribute__((address_space(1))) *)(ps + pos);
+        if (pos + 4 <= plen) pfw = *(const uint32_t __attribute__((address_space(1))) *)(ps + pos);       // (never a byte beyond the stream)
     }
 
     uint64_t wv[PPT];
