@@ -79,7 +79,7 @@ def other_kernels(tm, steps, n_bases, n_distinct, rows, rows_kept, n_samples, ke
     w1 = key_bytes + 1.0
     for name, ms, nbytes in (
             ("per-sample dedup (dedupe_mb_kernel)", tm["dedupe"] / steps, w1 * (n_bases + n_distinct)),
-            ("merge (union_kernel + assemble_kernel)", (tm["key_union"] + tm["assemble"]) / steps, w1 * n_distinct + rows * (float(key_bytes) + n_samples)),
+            ("merge (union_kernel<SIDE> + assemble_side_kernel: the dictionaries read once)", (tm["key_union"] + tm["assemble"]) / steps, w1 * n_distinct + rows * (float(key_bytes) + n_samples)),
             ("filter + compaction", (tm["filter"] + tm["compact"]) / steps, rows * (float(key_bytes) + n_samples) + rows_kept * float(n_samples))):
         gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         out.append({"stage": name, "ms": ms, "algorithmic_bytes": nbytes, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
