@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/ab_extract.sh <variant>...: the bench step (1 000 genomes, kernels only) once per engine build ab/libskx_<variant>.so, twice round robin
-for rep in 1 2; do
+for rep in 1 2 3; do
   for v in "$@"; do
     cp ab/libskx_$v.so ska.rust_amd/libskx.so
     timeout 900 python bench.py --no-e2e --no-check --no-distance --cpu-genomes 0 --steps 5 --warmup 2 2>/dev/null | tail -1 | python -c "
