@@ -313,7 +313,7 @@ def main():
             arr = ds.merge(names)
         else:
             # the exchanges are the engine's (include/skx.h "Collectives": RCCL on the engine's stream)
-            ks = ds.union_keys()
+            ks = ds.union_keys(notes=True)           # the notes travel with the key set to the global rows: the assemble below reads no dictionary twice
             ctx.sync()
             t_x = time.perf_counter()
             rows = comm.keyset_allgather(ks)         # one all-gather of the per-rank key tables + their union: the global rows

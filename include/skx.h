@@ -96,6 +96,11 @@ int  skx_dictset_export(skx_dictset *d, int sample, skx_key *keys, uint8_t *base
  * skx_merge() is the single-GPU composition of the three.
  * ------------------------------------------------------------------------------------------ */
 int  skx_keyset_union(skx_ctx *ctx, skx_dictset *d, skx_keyset **out);
+/* The same pass, which also keeps its notes (2 bytes per dictionary word: which row of its sub-bucket the word's key became, which bases)
+ * for the skx_array_assemble over the same dictset that follows -- directly, or on the global rows skx_keyset_allgather returns for this
+ * key set (the notes travel with it): the matrix is then filled without a second read of the dictionaries, as skx_merge does on one GPU
+ * (merge_ska_dict.rs:77-109 appends a sample in one pass over its dictionary).  Costs the notes' memory until the key set / the rows are freed. */
+int  skx_keyset_union_notes(skx_ctx *ctx, skx_dictset *d, skx_keyset **out);
 int  skx_keyset_size(const skx_keyset *ks, uint64_t *n);
 /* device pointer to n packed 64-bit words per key (1 for k<=31, 2 above), engine order */
 int  skx_keyset_device(skx_keyset *ks, const void **dptr, uint64_t *n_keys, int *words_per_key);

@@ -1173,7 +1173,11 @@ static int keyset_union_views(skx_ctx *ctx, const DictView *views, int nviews, i
 static int keyset_union_dict(skx_ctx *ctx, skx_dictset *d, skx_keyset **out, bool with_side);
 extern "C" int skx_keyset_union(skx_ctx *ctx, skx_dictset *d, skx_keyset **out)
 {
-    // (with the notes: a sharded job hands this key set to skx_keyset_allgather, which carries them over to the global rows)
+    return skx_guarded([&]() -> int { return keyset_union_dict(ctx, d, out, false); });
+}
+extern "C" int skx_keyset_union_notes(skx_ctx *ctx, skx_dictset *d, skx_keyset **out)
+{
+    // (a sharded job hands this key set to skx_keyset_allgather, which carries the notes over to the global rows)
     return skx_guarded([&]() -> int { return keyset_union_dict(ctx, d, out, !getenv("SKX_NO_SHARD_SIDE")); });
 }
 static int keyset_union_dict(skx_ctx *ctx, skx_dictset *d, skx_keyset **out, bool with_side)
@@ -1398,6 +1402,9 @@ static int array_make_lazy(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows, const
 {
     std::unique_ptr<skx_array> a(new skx_array());
     a->lazy_dict = d; a->lazy_rows = rows;
+    // the union's notes serve the eager assemble only (skx_merge, skx_array_assemble): a lazily held array fills its windows from the
+    // dictionaries, so the 2 bytes per word are not kept for its lifetime
+    rows->side.release(); rows->perm.release(); rows->g_perm.release(); rows->g_n.release(); rows->g_base.release(); rows->side_of = nullptr;
     hipStream_t st = ctx->stream;
     a->ctx = ctx; a->k = d->k; a->rc = d->rc; a->k_bits = d->key_bits; a->hp = d->hp; a->wh = d->wh; a->version = skx_version();
     for (int i = 0; i < d->n; i++) a->names.emplace_back(names && names[i] ? names[i] : "");
@@ -1566,7 +1573,7 @@ static int build_range(skx_ctx *ctx, const char *const *names, const char *const
         if (!getenv("SKX_EAGER_ARRAY")) {
             // rows now, cells on demand: the array keeps the dictionaries (see skx_array::lazy_dict)
             skx_keyset *ks = nullptr;
-            r = skx_keyset_union(ctx, d, &ks);
+            r = skx_keyset_union(ctx, d, &ks);                                         // (without notes: a lazily held array does not use them)
             if (r == SKX_OK) r = array_make_lazy(ctx, d, ks, names + lo, &a); else skx_dictset_free(d);
             d = nullptr;
         } else

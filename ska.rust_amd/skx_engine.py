@@ -62,7 +62,7 @@ class EngineError(RuntimeError):
 # every symbol include/skx.h and include/skx_host.h declare
 SYMBOLS = """skx_last_error skx_version skx_ctx_create skx_ctx_destroy skx_ctx_sync skx_ctx_stream skx_dictset_build
 skx_dictset_build_files skx_dictset_free skx_dictset_nsamples skx_dictset_key_bits skx_dictset_size skx_dictset_export
-skx_keyset_union skx_keyset_size skx_keyset_device skx_keyset_from_device skx_keyset_merge skx_keyset_free
+skx_keyset_union skx_keyset_union_notes skx_keyset_size skx_keyset_device skx_keyset_from_device skx_keyset_merge skx_keyset_free
 skx_array_assemble skx_array_assemble_lazy skx_merge skx_build_and_merge skx_array_free skx_array_save skx_array_load skx_array_from_host
 skx_array_info skx_array_name skx_array_version skx_array_export skx_array_sample_kmers skx_array_filter
 skx_array_write_fasta skx_array_fasta skx_array_device_matrix skx_array_device_stats skx_array_set_total_samples skx_array_distance skx_free skx_ctx_timings
@@ -102,6 +102,7 @@ def load_library():
     lib.skx_dictset_size.argtypes = [vp, i, C.POINTER(u64)]
     lib.skx_dictset_export.argtypes = [vp, i, vp, vp, u64]
     lib.skx_keyset_union.argtypes = [vp, vp, pp]
+    lib.skx_keyset_union_notes.argtypes = [vp, vp, pp]
     lib.skx_keyset_size.argtypes = [vp, C.POINTER(u64)]
     lib.skx_keyset_device.argtypes = [vp, pp, C.POINTER(u64), C.POINTER(i)]
     lib.skx_keyset_from_device.argtypes = [vp, vp, u64, i, i, pp]
@@ -502,9 +503,10 @@ class DictSet:
         _check(_lib.skx_dictset_export(self.h, sample, _np_ptr(keys), _np_ptr(bases), n))
         return keys, bases
 
-    def union_keys(self):
+    def union_keys(self, notes=False):
+        """notes: keep the pass's notes for the eager assemble that follows (directly or after KeySet all-gather): skx_keyset_union_notes"""
         h = C.c_void_p()
-        _check(_lib.skx_keyset_union(self.ctx.h, self.h, C.byref(h)))
+        _check((_lib.skx_keyset_union_notes if notes else _lib.skx_keyset_union)(self.ctx.h, self.h, C.byref(h)))
         return KeySet(h, self.ctx)
 
     def merge(self, names):

@@ -146,7 +146,7 @@ ctx = E.Context(0)
 comm = E.Comm.rccl(0, 1, E.comm_unique_id(), ctx=ctx)
 assert (comm.rank, comm.world) == (0, 1)
 ds = E.DictSet.from_files([(f, None) for f in files], 31, True, threads=4, ctx=ctx)
-ks = ds.union_keys()
+ks = ds.union_keys(notes=True)
 rows = comm.keyset_allgather(ks)
 assert len(rows) == len(ks)
 arr = ds.assemble(rows, names)
