@@ -41,17 +41,27 @@ __device__ static inline uint64_t nt_pick(uint32_t c, uint64_t t0, uint64_t t1, 
 }
 __global__ __launch_bounds__(RW_NT) void reads_windows_kernel(ReadsArgs a)
 {
-    __shared__ uint8_t s_seq[RW_TILE + 80], s_q[RW_TILE + 80], s_flag[RW_TILE];
+    __shared__ __attribute__((aligned(16))) uint8_t s_seq[RW_TILE + 80], s_q[RW_TILE + 80], s_flag[RW_TILE];
     __shared__ uint64_t s_out[RW_PPT * RW_STRIDE];
     uint64_t o_hash[RW_PPT], o_lo[RW_PPT], o_hi[RW_PPT];
     const uint64_t p0 = (uint64_t)blockIdx.x * RW_TILE;
     const int k = a.k, h = (k - 1) / 2;
     // tile covers positions [p0 - 64, p0 + RW_TILE + 2)
-    for (int i = threadIdx.x; i < RW_TILE + 66; i += RW_NT) {
-        const int64_t pos = (int64_t)p0 - 64 + i;
-        const bool in = pos >= 0 && (uint64_t)pos < a.len;
-        s_seq[i] = in ? a.seq[pos] : (uint8_t)'\n';
-        s_q[i] = (in && a.qual) ? a.qual[pos] : (uint8_t)'~';
+    // 16 bytes per thread and array where the piece lies inside the stream (p0 - 64 is a multiple of 16 and the streams are 16-byte
+    // aligned), byte by byte at its two ends
+    for (int c = threadIdx.x; c < (RW_TILE + 80) / 16; c += RW_NT) {
+        const int64_t pos = (int64_t)p0 - 64 + 16 * c;
+        if (pos >= 0 && (uint64_t)pos + 16 <= a.len) {
+            *reinterpret_cast<uint4 *>(s_seq + 16 * c) = *reinterpret_cast<const uint4 *>(a.seq + pos);
+            if (a.qual) *reinterpret_cast<uint4 *>(s_q + 16 * c) = *reinterpret_cast<const uint4 *>(a.qual + pos);
+            else *reinterpret_cast<uint4 *>(s_q + 16 * c) = make_uint4(0x7E7E7E7Eu, 0x7E7E7E7Eu, 0x7E7E7E7Eu, 0x7E7E7E7Eu);
+        } else
+            for (int i = 16 * c; i < 16 * c + 16; i++) {
+                const int64_t q = (int64_t)p0 - 64 + i;
+                const bool in = q >= 0 && (uint64_t)q < a.len;
+                s_seq[i] = in ? a.seq[q] : (uint8_t)'\n';
+                s_q[i] = (in && a.qual) ? a.qual[q] : (uint8_t)'~';
+            }
     }
     __syncthreads();
     auto qbad = [&](int i) { return a.qual && (uint8_t)(s_q[i] - 33) <= (uint8_t)a.min_qual; };     // !((q-33) > min_qual)
