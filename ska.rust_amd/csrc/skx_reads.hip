@@ -34,7 +34,12 @@ struct ReadsArgs {
 // 2 048 results per array go through one LDS buffer, array after array, position-major (row stride 264: conflict-free both
 // ways), and leave as contiguous 16 KB pieces -- a per-thread store of its own 64 bytes per array would cost one L2
 // request per 8 bytes, and parking all three arrays at once would leave two workgroups per CU.
-constexpr int RW_PPT = 8, RW_NT = 256, RW_TILE = RW_PPT * RW_NT, RW_STRIDE = RW_NT + 8;
+#ifndef SKX_RW_NB
+#define SKX_RW_NB 2
+#endif
+// RW_NB batches of RW_PPT positions per thread, one after the other: the window state is built once per RW_NB * RW_PPT positions (building it
+// from its k bytes costs more than rolling it over eight positions)
+constexpr int RW_PPT = 8, RW_NB = SKX_RW_NB, RW_NT = 256, RW_TILE = RW_PPT * RW_NB * RW_NT, RW_STRIDE = RW_NT + 8;
 __device__ static inline uint64_t nt_pick(uint32_t c, uint64_t t0, uint64_t t1, uint64_t t2, uint64_t t3)
 {
     return (c & 2u) ? ((c & 1u) ? t3 : t2) : ((c & 1u) ? t1 : t0);
@@ -67,14 +72,15 @@ __global__ __launch_bounds__(RW_NT) void reads_windows_kernel(ReadsArgs a)
     auto qbad = [&](int i) { return a.qual && (uint8_t)(s_q[i] - 33) <= (uint8_t)a.min_qual; };     // !((q-33) > min_qual)
     auto bad = [&](int i) { const uint8_t b = s_seq[i]; return (b & 0xF) == 14 || b == '\n' || (a.qual_filter == 2 && qbad(i)); };
     auto code = [&](int i) -> uint32_t { return (s_seq[i] >> 1) & 3u; };
-    const uint64_t pstart = p0 + (uint64_t)threadIdx.x * RW_PPT;
-    const int e0 = 64 + (int)threadIdx.x * RW_PPT;        // tile index of my first window's last base
+    const uint64_t pstart = p0 + (uint64_t)threadIdx.x * (RW_PPT * RW_NB);
+    const int e0 = 64 + (int)threadIdx.x * (RW_PPT * RW_NB);        // tile index of my first window's last base
+    const uint64_t left = a.len - p0 < (uint64_t)RW_TILE ? a.len - p0 : (uint64_t)RW_TILE;
+    uint64_t upper = 0, lower = 0, rc_upper = 0, rc_lower = 0, fh = 0, rh = 0;
+    uint32_t mid = 0, rc_mid = 0, run = 0;
+    const uint64_t H0 = NT_H[0], H1 = NT_H[1], H2 = NT_H[2], H3 = NT_H[3], R0 = NT_RC[0], R1 = NT_RC[1], R2 = NT_RC[2], R3 = NT_RC[3];
+    const uint64_t am = (1ull << (2 * h)) - 1;        // arm mask (h <= 31)
     if (pstart < a.len) {
-        const uint64_t am = (1ull << (2 * h)) - 1;        // arm mask (h <= 31)
-        const uint64_t H0 = NT_H[0], H1 = NT_H[1], H2 = NT_H[2], H3 = NT_H[3], R0 = NT_RC[0], R1 = NT_RC[1], R2 = NT_RC[2], R3 = NT_RC[3];
         // the window ending one position before my first
-        uint64_t upper = 0, lower = 0, rc_upper = 0, rc_lower = 0, fh = 0, rh = 0;
-        uint32_t mid = 0;
         const int e = e0 - 1;
         for (int i = 0; i < k; i++) {
             const uint32_t c = code(e - (k - 1) + i);
@@ -86,12 +92,29 @@ __global__ __launch_bounds__(RW_NT) void reads_windows_kernel(ReadsArgs a)
             rc_upper = (rc_upper << 2) | (code(e - i) ^ 2u);                       // reverse complement of the lower arm
             rc_lower = (rc_lower << 2) | (code(e - (k - 1) + h - 1 - i) ^ 2u);     // ... of the upper arm
         }
-        uint32_t rc_mid = mid ^ 2u;
-        uint32_t run = 0;                                  // clean bases ending at e, counted up to k + 1
+        rc_mid = mid ^ 2u;
+        run = 0;                                           // clean bases ending at e, counted up to k + 1
         for (int t = e; t >= e - k && !bad(t); t--) run++;
+    }
+    auto put = [&](const uint64_t (&v)[RW_PPT], uint64_t *dst, int b, bool mine) {       // my eight values -> LDS -> the array, in 64-byte runs
+        if (mine) {
+#pragma unroll
+            for (int j = 0; j < RW_PPT; j++) s_out[j * RW_STRIDE + (int)threadIdx.x] = v[j];
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < (uint32_t)(RW_PPT * RW_NT); i += RW_NT) {
+            const uint32_t t = i / RW_PPT, j = i % RW_PPT, at = t * (RW_PPT * RW_NB) + (uint32_t)b * RW_PPT + j;
+            if (at < left) dst[p0 + at] = s_out[(int)j * RW_STRIDE + (int)t];
+        }
+        __syncthreads();
+    };
+#pragma unroll 1
+    for (int b = 0; b < RW_NB; b++) {
+    const bool mine = pstart + (uint64_t)b * RW_PPT < a.len;
+    if (mine) {
 #pragma unroll
         for (int j = 0; j < RW_PPT; j++) {
-            const int ej = e0 + j;
+            const int ej = e0 + b * RW_PPT + j;
             const uint32_t c = code(ej), cout = code(ej - k);
             // roll_fwd (split_kmer.rs:199-213)
             upper = ((upper << 2) | mid) & am;
@@ -122,23 +145,13 @@ __global__ __launch_bounds__(RW_NT) void reads_windows_kernel(ReadsArgs a)
             o_hash[j] = a.rc ? (fh < rh ? fh : rh) : fh;
             o_lo[j] = (uint64_t)w;
             o_hi[j] = (uint64_t)(w >> 64);
-            s_flag[threadIdx.x * RW_PPT + j] = valid && midq_ok;            // the `&&` of ska_dict.rs:155-157: the count filter is not touched otherwise
+            s_flag[threadIdx.x * (RW_PPT * RW_NB) + b * RW_PPT + j] = valid && midq_ok;            // the `&&` of ska_dict.rs:155-157: the count filter is not touched otherwise
         }
     }
-    const uint64_t left = a.len - p0 < (uint64_t)RW_TILE ? a.len - p0 : (uint64_t)RW_TILE;
-    const bool mine = pstart < a.len;
-    auto put = [&](const uint64_t (&v)[RW_PPT], uint64_t *dst) {       // my eight values -> LDS -> the array, contiguously
-        if (mine) {
-#pragma unroll
-            for (int j = 0; j < RW_PPT; j++) s_out[j * RW_STRIDE + (int)threadIdx.x] = v[j];
-        }
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < left; i += RW_NT) dst[p0 + i] = s_out[(int)(i % RW_PPT) * RW_STRIDE + (int)(i / RW_PPT)];
-        __syncthreads();
-    };
-    put(o_hash, a.hash);
-    put(o_lo, a.wlo);
-    if (a.whi) put(o_hi, a.whi);
+    put(o_hash, a.hash, b, mine);
+    put(o_lo, a.wlo, b, mine);
+    if (a.whi) put(o_hi, a.whi, b, mine);
+    }
     uint32_t nv = 0;
     for (uint32_t i = threadIdx.x; i < left; i += RW_NT) { a.flag[p0 + i] = s_flag[i]; nv += s_flag[i]; }
     if (a.n_valid) {
