@@ -111,7 +111,10 @@ __device__ static inline uint32_t micro_of(uint64_t m, uint32_t loc0, uint32_t &
     return loc_rel * (1u << FB) + (uint32_t)(frac >> (64 - FB));
 }
 template <int WPP>
-__global__ __launch_bounds__(RG_NT) void rs_groups_kernel(RgArgs a)
+#ifndef SKX_RG_STEP
+#define SKX_RG_STEP 4
+#endif
+__global__ __launch_bounds__(RG_NT, 8) void rs_groups_kernel(RgArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
     uint64_t *s_m = reinterpret_cast<uint64_t *>(s_mem);                  // [RG_CAP] mix(hash) sorted; then, at group heads, the hash's bloom fingerprint
@@ -182,13 +185,23 @@ __global__ __launch_bounds__(RG_NT) void rs_groups_kernel(RgArgs a)
         const uint64_t m = s_m[p]; const uint32_t tt = s_t[p];
         uint32_t lr; const uint32_t mb = micro_of<WPP>(m, loc0, lr);
         const uint32_t b = s_cnt[(int)mb - 1], e = s_cnt[mb];
+        // (m, position) compared as one 96-bit number (a subtract-with-borrow chain instead of two compares and their logic); the slots
+        // behind the bucket's end re-read its last record, whose verdict is taken off again once
+        typedef unsigned __int128 u128_t;
+        const u128_t mine = ((u128_t)m << 32) | tt;
         uint32_t less = 0;
-        for (uint32_t q = b; q < e; q += 8) {                                  // eight independent LDS reads in flight per step (a k-mer of a 50x isolate
-            uint64_t mq[8]; uint32_t tq[8];                                      // fills its micro-bucket with ~35 records)
+        constexpr uint32_t RS = SKX_RG_STEP;                                     // independent LDS reads in flight per step (a k-mer of a 50x isolate fills its
+        for (uint32_t q = b; q < e; q += RS) {                                  // micro-bucket with ~35 records)
+            uint64_t mq[RS]; uint32_t tq[RS];
 #pragma unroll
-            for (uint32_t u = 0; u < 8; u++) { const uint32_t qq = q + u < e ? q + u : e - 1; mq[u] = s_m[qq]; tq[u] = s_t[qq]; }
+            for (uint32_t u = 0; u < RS; u++) { const uint32_t qq = q + u < e ? q + u : e - 1; mq[u] = s_m[qq]; tq[u] = s_t[qq]; }
 #pragma unroll
-            for (uint32_t u = 0; u < 8; u++) less += (q + u < e) && (mq[u] < m || (mq[u] == m && tq[u] < tt));
+            for (uint32_t u = 0; u < RS; u++) less += ((((u128_t)mq[u] << 32) | tq[u]) < mine) ? 1u : 0u;
+        }
+        {
+            const uint32_t g = e - b, extra = ((g + RS - 1u) / RS) * RS - g;
+            const uint64_t ml = s_m[e - 1]; const uint32_t tl = s_t[e - 1];
+            if ((((u128_t)ml << 32) | tl) < mine) less -= extra;
         }
         npos[j] = b + less; e_m[j] = m; e_t[j] = tt; e_mb[j] = lr;
     }
