@@ -48,6 +48,13 @@ __global__ __launch_bounds__(RW_NT) void reads_windows_kernel(ReadsArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_seq[RW_TILE + 80], s_q[RW_TILE + 80], s_flag[RW_TILE];
     __shared__ uint64_t s_out[RW_PPT * RW_STRIDE];
+    // ntHash's per-base words as the roll needs them: [c] H, [4 + c] rotl(H, k) (the base that leaves), [8 + c] R, [12 + c] rotl(R, k - 1) (the base
+    // that enters the reverse strand): one LDS read each instead of a three-way select over two registers and a 64-bit rotate by a run-time count
+    __shared__ uint64_t s_nt[16];
+    if (threadIdx.x < 16) {
+        const int c4 = threadIdx.x & 3, kind = threadIdx.x >> 2;
+        s_nt[threadIdx.x] = kind == 0 ? NT_H[c4] : kind == 1 ? rotl64d(NT_H[c4], (unsigned)a.k) : kind == 2 ? NT_RC[c4] : rotl64d(NT_RC[c4], (unsigned)(a.k - 1));
+    }
     uint64_t o_hash[RW_PPT], o_lo[RW_PPT], o_hi[RW_PPT];
     const uint64_t p0 = (uint64_t)blockIdx.x * RW_TILE;
     const int k = a.k, h = (k - 1) / 2;
@@ -79,6 +86,12 @@ __global__ __launch_bounds__(RW_NT) void reads_windows_kernel(ReadsArgs a)
     uint32_t mid = 0, rc_mid = 0, run = 0;
     const uint64_t H0 = NT_H[0], H1 = NT_H[1], H2 = NT_H[2], H3 = NT_H[3], R0 = NT_RC[0], R1 = NT_RC[1], R2 = NT_RC[2], R3 = NT_RC[3];
     const uint64_t am = (1ull << (2 * h)) - 1;        // arm mask (h <= 31)
+    const bool userc = a.rc != 0;
+    // k > 31: the hashed upper arm L starts at bit sh = hb + 4 of the 128-bit word (36..66): its part of the low half = (L << wa1) & wm1, of
+    // the high half = (L >> wa2) << wa3 (wave-uniform counts, one formula on both sides of 64)
+    const int wsh = a.wh.hb + 4;
+    const int wa1 = wsh < 64 ? wsh : 0, wa2 = wsh < 64 ? 64 - wsh : 0, wa3 = wsh < 64 ? 0 : wsh - 64;
+    const uint64_t wm1 = wsh < 64 ? ~0ull : 0ull;
     if (pstart < a.len) {
         // the window ending one position before my first
         const int e = e0 - 1;
@@ -124,27 +137,26 @@ __global__ __launch_bounds__(RW_NT) void reads_windows_kernel(ReadsArgs a)
             rc_mid = mid ^ 2u;
             rc_upper = (rc_upper >> 2) | ((uint64_t)(c ^ 2u) << (2 * h - 2));
             // ntHash of the whole k-mer, both strands (nthash.rs:35-76)
-            fh = rotl64d(fh, 1) ^ rotl64d(nt_pick(cout, H0, H1, H2, H3), (unsigned)k) ^ nt_pick(c, H0, H1, H2, H3);
-            rh = rotl64d(rh ^ nt_pick(cout, R0, R1, R2, R3), 63) ^ rotl64d(nt_pick(c, R0, R1, R2, R3), (unsigned)(k - 1));
+            fh = ((fh << 1) | (fh >> 63)) ^ s_nt[4 + cout] ^ s_nt[c];
+            { const uint64_t x = rh ^ s_nt[8 + cout]; rh = ((x >> 1) | (x << 63)) ^ s_nt[12 + c]; }
             run = bad(ej) ? 0u : min(run + 1u, (uint32_t)k + 1u);
             // split_kmer.rs:89,121: a clean run of exactly k ending at the record's last base is never started
             bool valid = run >= (uint32_t)k;
             if (s_seq[ej + 1] == '\n') valid = valid && run > (uint32_t)k;
             // middle_base_qual (split_kmer.rs:328-339): Middle and Strict gate on the middle base
             const bool midq_ok = !(a.qual && a.qual_filter != 0 && qbad(ej - h));
-            uint32_t m4 = 1u << mid;
-            uint64_t hl = upper, hr = lower;
-            if (a.rc) {
-                const bool gt = upper != rc_upper ? upper > rc_upper : lower > rc_lower;
-                if (gt) { hl = rc_upper; hr = rc_lower; m4 = 1u << (mid ^ 2u); }
-                else if (upper == rc_upper && lower == rc_lower) m4 |= 1u << (mid ^ 2u);
-            }
-            u128 w;
-            if (k <= 31) { uint32_t L = (uint32_t)hl, R = (uint32_t)hr; hmix_halves(L, R, a.hp); w = ((u128)L << (a.hp.hb + 4)) | ((u128)R << 4) | m4; }
-            else { uint64_t L = hl, R = hr; hmix_halves_w(L, R, a.wh); w = ((u128)L << (a.wh.hb + 4)) | ((u128)R << 4) | m4; }
-            o_hash[j] = a.rc ? (fh < rh ? fh : rh) : fh;
-            o_lo[j] = (uint64_t)w;
-            o_hi[j] = (uint64_t)(w >> 64);
+            // canonical strand and base set without branches; the packed word on 64-bit halves (as extract_wide_kernel)
+            const bool ueq = upper == rc_upper;
+            const bool gt = userc & ((upper > rc_upper) | (ueq & (lower > rc_lower)));
+            const bool eq = userc & ueq & (lower == rc_lower);
+            const uint64_t hl = gt ? rc_upper : upper, hr = gt ? rc_lower : lower;
+            const uint32_t m4 = (1u << (gt ? rc_mid : mid)) | (eq ? (1u << rc_mid) : 0u);
+            uint64_t wlo, whi;
+            if (k <= 31) { uint32_t L = (uint32_t)hl, R = (uint32_t)hr; hmix_halves(L, R, a.hp); wlo = ((uint64_t)L << (a.hp.hb + 4)) | ((uint64_t)R << 4) | m4; whi = 0; }
+            else { uint64_t L = hl, R = hr; hmix_halves_w(L, R, a.wh); wlo = (R << 4) | m4 | ((L << wa1) & wm1); whi = (R >> 60) | ((L >> wa2) << wa3); }
+            o_hash[j] = userc ? (fh < rh ? fh : rh) : fh;
+            o_lo[j] = wlo;
+            o_hi[j] = whi;
             s_flag[threadIdx.x * (RW_PPT * RW_NB) + b * RW_PPT + j] = valid && midq_ok;            // the `&&` of ska_dict.rs:155-157: the count filter is not touched otherwise
         }
     }
