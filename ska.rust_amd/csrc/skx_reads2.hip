@@ -97,7 +97,7 @@ __global__ __launch_bounds__(RS_NT) void rs_scatter_kernel(RsArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------- one partition in LDS
-// WPP = bloom words per final partition: 48 (65 536 partitions; samples of up to ~200 M windows) or 12 (262 144 partitions).
+// WPP = bloom words per final partition: 48 (65 536 partitions; samples of up to ~160 M windows), 24 (131 072) or 12 (262 144 partitions).
 // 1 024 threads x 4 records, 69 KB of LDS: two workgroups per CU.
 constexpr int RG_NT = 1024, RG_ITEMS = 4, RG_CAP = RG_NT * RG_ITEMS, RG_MB = 48 * 64;       // micro-bucket = (bloom word, top bits of the fraction)
 struct RgArgs { const uint64_t *h; const uint32_t *t; const uint32_t *cnt; uint64_t cap; int min_count; uint32_t *out_t; unsigned long long *out_n; int *overflow; unsigned long long *dbg; };
@@ -105,7 +105,7 @@ struct RgArgs { const uint64_t *h; const uint32_t *t; const uint32_t *cnt; uint6
 template <int WPP>
 __device__ static inline uint32_t micro_of(uint64_t m, uint32_t loc0, uint32_t &loc_rel)
 {
-    constexpr int FB = WPP == 48 ? 6 : 8;                        // 48 x 64 = 12 x 256 = 3 072 micro-buckets
+    constexpr int FB = WPP == 48 ? 6 : WPP == 24 ? 7 : 8;        // 48 x 64 = 24 x 128 = 12 x 256 = 3 072 micro-buckets
     const uint64_t frac = m * BLOOM_WORDS;                       // low 64 bits of the 128-bit product whose high part is the bloom word
     loc_rel = loc_of(m) - loc0;
     return loc_rel * (1u << FB) + (uint32_t)(frac >> (64 - FB));
@@ -390,9 +390,17 @@ int reads_sample_words(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual
     if (n_win == 0) return SKX_OK;
     // partition sizes vary more than a Poisson count: the ~35 occurrences of a k-mer of a 50x isolate move together
     // (sigma ~ sqrt(35 x mean)); half the mean + 1 024 records of head-room covers that
-    const bool fine = (n_win / 65536) * 3 / 2 + 1024 > (uint64_t)RG_CAP;                  // > ~134 M windows: 262 144 partitions of 12 bloom words
-    const uint64_t n_part = fine ? 262144 : 65536, fan1 = n_part / 256;
-    const uint64_t cap1 = n_win / fan1 + n_win / (fan1 * 16) + 16384, cap2 = (n_win / n_part) * 3 / 2 + 1024;
+    // 65 536 partitions of 48 bloom words while a partition's records fit the group kernel with a quarter of the mean + 1 024 records of
+    // head-room (the mean + 5.7 sigma at 2 000 records; half the mean where that fits as well); beyond ~161 M windows 262 144 partitions of
+    // 12 bloom words, which the group kernel fills to an eighth only (6.6 ms against 2.7: k = 31 on a 50x isolate used to land there)
+    const uint64_t mean48 = n_win / 65536;
+    const bool coarse = mean48 + mean48 / 4 + 1024 <= (uint64_t)RG_CAP;
+    const bool mid = !coarse && (mean48 / 2) * 3 / 2 + 1024 <= (uint64_t)RG_CAP;         // 131 072 partitions of 24 bloom words (k = 17 on a 50x isolate: ~170 M windows)
+    const bool fine = !coarse && !mid;
+    const bool roomy = mean48 * 3 / 2 + 1024 <= (uint64_t)RG_CAP;
+    const uint64_t n_part = fine ? 262144 : mid ? 131072 : 65536, fan1 = n_part / 256;
+    const uint64_t cap1 = n_win / fan1 + n_win / (fan1 * 16) + 16384,
+                   cap2 = (!coarse || roomy) ? (n_win / n_part) * 3 / 2 + 1024 : mean48 + mean48 / 4 + 1024;
     if (cap2 > (uint64_t)RG_CAP) return SKF_NOT_TAKEN;                                     // beyond ~530 M windows
     DevBuf<uint64_t> h1, h2; DevBuf<uint32_t> t1, t2, c1, c2, acc_t;
     SKX_TRY(h1.alloc(fan1 * cap1)); SKX_TRY(t1.alloc(fan1 * cap1)); SKX_TRY(c1.alloc(fan1)); SKX_TRY(c1.zero(st));
@@ -405,7 +413,12 @@ int reads_sample_words(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual
     if (getenv("SKX_DEBUG")) { SKX_TRY(d_dbg.alloc(8)); SKX_TRY(d_dbg.zero(st)); }
     RgArgs ag{h2.p, t2.p, c2.p, cap2, (int)q.min_count, acc_t.p, d_n.p, d_over.p, d_dbg.p};
     const size_t lds = (size_t)RG_CAP * 12 + ((size_t)RG_MB + 2) * 4 + (size_t)RG_CAP * 2 + 64;
-    if (!fine) {
+    if (mid) {
+        hipLaunchKernelGGL((rs_scatter_kernel<24 * 256, 512, true>), g1, dim3(RS_NT), 0, st, a1);
+        hipLaunchKernelGGL((rs_scatter_kernel<24, 256, false>), g2, dim3(RS_NT), 0, st, a2);
+        (void)hipFuncSetAttribute((const void *)rs_groups_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(rs_groups_kernel<24>, dim3((unsigned)n_part), dim3(RG_NT), lds, st, ag);
+    } else if (!fine) {
         hipLaunchKernelGGL((rs_scatter_kernel<48 * 256, 256, true>), g1, dim3(RS_NT), 0, st, a1);
         hipLaunchKernelGGL((rs_scatter_kernel<48, 256, false>), g2, dim3(RS_NT), 0, st, a2);
         (void)hipFuncSetAttribute((const void *)rs_groups_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -209,6 +209,14 @@ def test_config5_one_isolate_at_size(E, thousand):
         os.environ.pop("SKX_READS_SORT")
     k2, b2 = ds2.export(0)
     assert np.array_equal(k2["lo"], gk["lo"]) and np.array_equal(k2["hi"], gk["hi"]) and np.array_equal(b2, gb)
+    # smaller k = more gated windows per read: k = 31 runs the 48-word partitions at their tighter head-room, k = 17 (the reference's
+    # default) the 24-word partitions -- both against the oracle's sequential filter as well
+    for k in (31, 17):
+        og = ora.Dict.from_files(k, files[0], files[1], True, qo)
+        ok, ob = og.export()
+        dsk = E.DictSet.from_files([(files[0], files[1])], k, True, E.qual(5, 20, E.QUAL_STRICT), threads=1)
+        gk, gb = dsk.export(0)
+        assert len(gk) > 4_000_000 and np.array_equal(gk["lo"], ok["lo"]) and np.array_equal(gk["hi"], ok["hi"]) and np.array_equal(gb, ob), k
 
 
 @pytest.fixture(scope="module")
