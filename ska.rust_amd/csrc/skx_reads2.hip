@@ -55,8 +55,10 @@ __global__ __launch_bounds__(RS_NT) void rs_scatter_kernel(RsArgs a)
 #pragma unroll
     for (int j = 0; j < RS_PER; j++) {
         const uint64_t i = i0 + threadIdx.x + (uint64_t)RS_NT * j;
+        // (the hash is requested beside the flag, not behind it: nearly every line of hashes holds gated windows anyway)
+        const uint64_t hv = i < n ? a.src_h[sbase + i] : 0ull;
         const bool valid = i < n && (!FROM_POS || a.flag[i]);
-        h[j] = valid ? a.src_h[sbase + i] : 0ull;
+        h[j] = valid ? hv : 0ull;
         t[j] = FROM_POS ? (uint32_t)i : (valid ? a.src_t[sbase + i] : 0u);
         rk[j] = 0xFFFFFFFFu;
         if (valid) { const uint32_t sub = (loc_of(mixh(h[j])) / (uint32_t)DIV) % (uint32_t)FAN; rk[j] = (sub << 16) | atomicAdd(&s_hist[sub], 1u); }
