@@ -2263,9 +2263,11 @@ extern "C" int skx_array_distance_filtered(skx_array *a, double min_freq, int fi
         SKX_HIP(hipMemcpyAsync(&n_const, d_c.p, 8, hipMemcpyDeviceToHost, st));
         SKX_HIP(hipStreamSynchronize(st));
         wpr = std::max<uint64_t>((kept + 63) / 64, 1);
-        SKX_TRY(planes.alloc((filt_ambig ? 4 : 8) * (uint64_t)S * wpr)); SKX_TRY(planes.zero(st));
+        SKX_TRY(planes.alloc((filt_ambig ? 4 : 8) * (uint64_t)S * wpr));
+        if (!kept) SKX_TRY(planes.zero(st));                                 // (otherwise every word is written by the plane kernel)
         launch_keep_bits(keep.p, pos.p, U, kb.p, gp.p, st);
-        if (kept) launch_build_planes_keep(a->matrix.p, a->pitch, S, U, kb.p, gp.p, planes.p, wpr, filt_ambig, st);
+        DevBuf<uint32_t> fg; SKX_TRY(fg.alloc(kept / 4096 + 2));
+        if (kept) launch_build_planes_keep(a->matrix.p, a->pitch, S, U, kb.p, gp.p, planes.p, wpr, filt_ambig, st, fg.p, kept);
         SKX_HIP(hipStreamSynchronize(st));            // keep / pos / kb / gp go out of scope
     } else { SKX_TRY(planes.alloc((filt_ambig ? 4 : 8) * (uint64_t)S)); SKX_TRY(planes.zero(st)); }
     if (constant) *constant = (int64_t)n_const;
