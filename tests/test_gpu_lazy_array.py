@@ -198,3 +198,34 @@ def test_distance_many_samples_several_pair_tiles(E, tmp_path, filt):
     assert np.array_equal(got["match_count"], od["match_count"]) and np.array_equal(got["mismatch_count"], od["mismatch_count"])
     assert np.allclose(got["distance"], od["distance"], rtol=0, atol=1e-6)
     assert np.allclose(got["mismatch_prop"], od["mismatch_prop"], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("filt", [True, False])
+def test_bit_planes_are_the_cells(E, tmp_path, filt):
+    """The bit planes the pair sweep reads (skx_array_distance_planes: 4 planes when ambiguous cells are filtered, 8 with
+    --allow-ambiguous), bit for bit against the cells of the array: row r of sample s is bit r % 64 of word r / 64; the padding of the
+    last word is zero.  Ambiguity codes and missing cells are present; 11 samples = one full group of eight per workgroup and a ragged one."""
+    import torch
+    import dist as skdist
+    inputs = _files(tmp_path, n=11, length=50_000, snps=150, seed=29)
+    arr = E.Array.build(inputs, k=31, threads=4)
+    _, v, _ = arr.export()                                      # [rows][samples], the array's own row order
+    U, S = v.shape
+    assert U > 3 * 4096 and len(set(np.unique(v).tolist()) - set(b"-ACGT")) > 0
+    p, wpr, n_planes = arr.distance_planes(filt)
+    assert wpr == (U + 63) // 64 and n_planes == (4 if filt else 8)
+    got = skdist.as_tensor(p, n_planes * S * wpr, "<i8", torch.device("cuda", 0)).cpu().numpy().view(np.uint64).reshape(n_planes, S, wpr)
+    code = np.full(256, 15, np.uint8)                           # set codes of the IUPAC letters: A 1, C 2, T 4, G 8 and their unions
+    for ch, c in zip(b"-ACMTWYHGRSVKDBN", range(16)):
+        code[ch] = c
+    c = code[v.T]                                               # [samples][rows]
+    size = np.array([bin(x).count("1") for x in range(16)], np.uint8)[c]
+    if filt:
+        bits = [c != 0, size == 1, (size == 1) & ((c & 10) != 0), (size == 1) & ((c & 12) != 0)]
+    else:
+        bits = [c != 0, (c & 1) != 0, (c & 2) != 0, (c & 4) != 0, (c & 8) != 0, size == 1, size == 2, size == 3]
+    for pl, b in enumerate(bits):
+        padded = np.zeros((S, wpr * 64), np.uint8)
+        padded[:, :U] = b
+        want = np.packbits(padded.reshape(S, wpr, 64), axis=2, bitorder="little").view(np.uint64).reshape(S, wpr)
+        assert np.array_equal(got[pl], want), pl
