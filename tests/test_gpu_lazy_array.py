@@ -205,16 +205,20 @@ def test_bit_planes_are_the_cells(E, tmp_path, filt):
     """The bit planes the pair sweep reads (skx_array_distance_planes: 4 planes when ambiguous cells are filtered, 8 with
     --allow-ambiguous), bit for bit against the cells of the array: row r of sample s is bit r % 64 of word r / 64; the padding of the
     last word is zero.  Ambiguity codes and missing cells are present; 11 samples = one full group of eight per workgroup and a ragged one."""
-    import torch
-    import dist as skdist
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so.7")                       # the runtime the engine itself is linked against (already mapped)
     inputs = _files(tmp_path, n=11, length=50_000, snps=150, seed=29)
     arr = E.Array.build(inputs, k=31, threads=4)
-    _, v, _ = arr.export()                                      # [rows][samples], the array's own row order
-    U, S = v.shape
+    mp, pitch, U = arr.device_matrix()                          # the cells as the plane kernel reads them: [samples][pitch], row r of sample s at s * pitch + r
+    S = arr.nsamples
+    cells = np.zeros((S, pitch), np.uint8)
+    assert hip.hipMemcpy(ctypes.c_void_p(cells.ctypes.data), ctypes.c_void_p(int(mp)), ctypes.c_size_t(cells.nbytes), 2) == 0     # hipMemcpyDeviceToHost
+    v = cells[:, :U].T
     assert U > 3 * 4096 and len(set(np.unique(v).tolist()) - set(b"-ACGT")) > 0
     p, wpr, n_planes = arr.distance_planes(filt)
     assert wpr == (U + 63) // 64 and n_planes == (4 if filt else 8)
-    got = skdist.as_tensor(p, n_planes * S * wpr, "<i8", torch.device("cuda", 0)).cpu().numpy().view(np.uint64).reshape(n_planes, S, wpr)
+    got = np.zeros((n_planes, S, wpr), np.uint64)
+    assert hip.hipMemcpy(ctypes.c_void_p(got.ctypes.data), ctypes.c_void_p(int(p)), ctypes.c_size_t(got.nbytes), 2) == 0      # hipMemcpyDeviceToHost
     code = np.full(256, 15, np.uint8)                           # set codes of the IUPAC letters: A 1, C 2, T 4, G 8 and their unions
     for ch, c in zip(b"-ACMTWYHGRSVKDBN", range(16)):
         code[ch] = c
