@@ -580,7 +580,7 @@ void launch_scan_u8(const uint8_t *flags, uint64_t *pos, uint64_t n, uint32_t *s
 constexpr uint32_t TABLE_PAD = 128;
 
 // bits [sh, sh + popcount(mask)) of a packed word.  HI: the caller guarantees sh >= 32 (field in the upper half): two
-// 32-bit operations instead of a quarter-rate 64-bit shift.  (A run-time test of the uniform sh inside the unrolled
+// 32-bit operations instead of a 64-bit shift and an AND (on gfx950 the 64-bit shift itself issues at the full rate: tools/valu_rate.hip).  (A run-time test of the uniform sh inside the unrolled
 // loops makes the compiler unswitch them and triples the register count.)
 template <bool HI>
 __device__ static inline uint32_t word_field(uint64_t w, int sh, uint32_t mask)
@@ -828,7 +828,7 @@ __global__ __launch_bounds__(NT) void dedupe_mb_kernel(uint64_t *words, const ui
         if (p >= n) { e[t] = 0; continue; }
         const uint64_t w0 = e[t], w0lo = w0 & ~15ull;
         const uint32_t b = bb[t], eend = ee[t];
-        // key_j < key  <=>  w_j < (w0 & ~15);  key_j == key  <=>  (w_j ^ w0) < 16: no 64-bit shifts (quarter rate) in the loop.
+        // key_j < key  <=>  w_j < (w0 & ~15);  key_j == key  <=>  (w_j ^ w0) < 16: no 64-bit shifts in the loop.
         // Fast path: count the smaller keys and notice whether the key occurs again; only then (rare) order the equal
         // keys by position and fold their base masks.
         uint32_t less = 0, eqb = 0, mor = (uint32_t)w0 & 15u;
