@@ -2217,6 +2217,50 @@ static void finish_pairs(const unsigned long long *h, int S, int i_lo, int i_hi,
             out[n].match_count = (uint64_t)matches; out[n].mismatch_count = (uint64_t)mismatches;
         }
 }
+// bit planes of the rows flagged 1 in keep: scan, keep words, planes (every word written).  rows = how many
+static int planes_of_kept_rows(skx_array *a, const uint8_t *keep, int filt, DevBuf<uint64_t> &planes, uint64_t &wpr, uint64_t &rows)
+{
+    skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
+    const int S = (int)a->names.size(); const uint64_t U = a->n_rows;
+    DevBuf<uint64_t> pos, sc_offs, kb, gp; DevBuf<uint32_t> sc_sums, fg;
+    SKX_TRY(pos.alloc(U + 1)); SKX_TRY(sc_sums.alloc(scan_u8_blocks(U))); SKX_TRY(sc_offs.alloc(scan_u8_blocks(U) + 1));
+    SKX_TRY(kb.alloc((U + 63) / 64)); SKX_TRY(gp.alloc((U + 63) / 64));
+    launch_scan_u8(keep, pos.p, U, sc_sums.p, sc_offs.p, st);
+    SKX_HIP(hipMemcpyAsync(&rows, pos.p + U, 8, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipStreamSynchronize(st));
+    wpr = std::max<uint64_t>((rows + 63) / 64, 1);
+    SKX_TRY(planes.alloc((filt ? 4 : 8) * (uint64_t)S * wpr));
+    if (!rows) { SKX_TRY(planes.zero(st)); return SKX_OK; }
+    launch_keep_bits(keep, pos.p, U, kb.p, gp.p, st);
+    SKX_TRY(fg.alloc(rows / 4096 + 2));
+    launch_build_planes_keep(a->matrix.p, a->pitch, S, U, kb.p, gp.p, planes.p, wpr, filt, st, fg.p, rows);
+    SKX_HIP(hipStreamSynchronize(st));            // pos / kb / gp / fg go out of scope
+    return SKX_OK;
+}
+// --allow-ambiguous over the rows flagged in keep (nullptr: all): the twelve pair classes differ from the three of the default sweep only on rows
+// that hold an ambiguous cell (the row statistics say which), so the rows without one go through the 4-plane sweep, their counts filed as classes
+// 0-2, and only the others through the 8-plane, twelve-class one (merge_ska_array.rs:587-632 sums per row: any split of the rows gives the sums)
+static int distance_ambiguous_split(skx_array *a, const uint8_t *keep, double constant, skx_dist *out)
+{
+    skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
+    const int S = (int)a->names.size(); const uint64_t U = a->n_rows;
+    DevBuf<uint8_t> clean, dirty;
+    SKX_TRY(clean.alloc(U)); SKX_TRY(dirty.alloc(U));
+    launch_split_keep(keep, a->mask.p, U, clean.p, dirty.p, st);
+    DevBuf<uint64_t> pc, pd; uint64_t wc = 1, wd = 1, nc = 0, nd = 0;
+    SKX_TRY(planes_of_kept_rows(a, clean.p, 1, pc, wc, nc));
+    SKX_TRY(planes_of_kept_rows(a, dirty.p, 0, pd, wd, nd));
+    DevBuf<unsigned long long> cnt;
+    SKX_TRY(cnt.alloc((uint64_t)S * S * DIST_NCOUNT)); SKX_TRY(cnt.zero(st));
+    if (nc) launch_pair_counts(pc.p, S, wc, 2, cnt.p, st, 0, S);
+    if (nd) launch_pair_counts(pd.p, S, wd, 0, cnt.p, st, 0, S);
+    std::vector<unsigned long long> h((uint64_t)S * S * DIST_NCOUNT);
+    SKX_HIP(hipMemcpyAsync(h.data(), cnt.p, h.size() * 8, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipStreamSynchronize(st));
+    SKX_HIP(hipGetLastError());
+    finish_pairs(h.data(), S, 0, S, constant, 0, out);
+    return SKX_OK;
+}
 int skx::planes_distance(skx_ctx *ctx, const uint64_t *planes, int S, uint64_t wpr, int filt_ambig, double constant, int i_lo, int i_hi, skx_dist *out)
 {
     hipStream_t st = ctx->stream;
@@ -2262,6 +2306,11 @@ extern "C" int skx_array_distance_filtered(skx_array *a, double min_freq, int fi
         SKX_HIP(hipMemcpyAsync(&kept, pos.p + U, 8, hipMemcpyDeviceToHost, st));
         SKX_HIP(hipMemcpyAsync(&n_const, d_c.p, 8, hipMemcpyDeviceToHost, st));
         SKX_HIP(hipStreamSynchronize(st));
+        if (!filt_ambig && kept && !getenv("SKX_DISTANCE_DENSE")) {
+            if (constant) *constant = (int64_t)n_const;
+            if (rows_used) *rows_used = kept;
+            return distance_ambiguous_split(a, keep.p, (double)n_const, out);
+        }
         wpr = std::max<uint64_t>((kept + 63) / 64, 1);
         SKX_TRY(planes.alloc((filt_ambig ? 4 : 8) * (uint64_t)S * wpr));
         if (!kept) SKX_TRY(planes.zero(st));                                 // (otherwise every word is written by the plane kernel)
@@ -2315,6 +2364,7 @@ extern "C" int skx_array_distance(skx_array *a, double constant, int filt_ambig,
     const int S = (int)a->names.size(); const uint64_t U = a->n_rows;
     if (S < 2) return SKX_OK;
     StageTimer t(ctx, &ctx->tm.distance);
+    if (!filt_ambig && U && !getenv("SKX_DISTANCE_DENSE")) return distance_ambiguous_split(a, nullptr, constant, out);
     const uint64_t wpr = (U + 63) / 64;
     DevBuf<uint64_t> planes;
     SKX_TRY(planes.alloc((filt_ambig ? 4 : 8) * (uint64_t)S * std::max<uint64_t>(wpr, 1)));
