@@ -233,3 +233,21 @@ def test_bit_planes_are_the_cells(E, tmp_path, filt):
         padded[:, :U] = b
         want = np.packbits(padded.reshape(S, wpr, 64), axis=2, bitorder="little").view(np.uint64).reshape(S, wpr)
         assert np.array_equal(got[pl], want), pl
+
+
+def test_allow_ambiguous_does_not_trust_stale_row_statistics(E, tmp_path, monkeypatch):
+    """--allow-ambiguous sends the rows whose statistics show no ambiguous cell through the three-count sweep.  With statistics that missed
+    the ambiguity codes (forced here: every kept row passed off as clean) the planes give it away -- present != unambiguous somewhere --
+    and every row takes the twelve-class sweep: same table as the oracle's either way."""
+    inputs = _files(tmp_path, n=13, length=20_000, snps=60, seed=5)
+    oa = ora.Array.build(inputs, k=21)
+    oc = oa.filter(0, False, ora.FILTER_NO_CONST, False, False, False)
+    od = oa.distance(oc, False)
+    for stale in (False, True):
+        if stale:
+            monkeypatch.setenv("SKX_TEST_STALE_ROW_MASK", "1")
+        arr = E.Array.build(inputs, k=21, threads=4)
+        got, constant, _ = arr.distance_filtered(0.0, False)
+        assert constant == oc
+        assert np.array_equal(got["match_count"], od["match_count"]) and np.array_equal(got["mismatch_count"], od["mismatch_count"])
+        assert np.allclose(got["distance"], od["distance"], rtol=0, atol=1e-6)
