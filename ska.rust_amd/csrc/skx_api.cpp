@@ -2218,7 +2218,7 @@ static void finish_pairs(const unsigned long long *h, int S, int i_lo, int i_hi,
         }
 }
 // bit planes of the rows flagged 1 in keep: scan, keep words, planes (every word written).  rows = how many
-static int planes_of_kept_rows(skx_array *a, const uint8_t *keep, int filt, DevBuf<uint64_t> &planes, uint64_t &wpr, uint64_t &rows)
+int skx::planes_of_kept_rows(skx_array *a, const uint8_t *keep, int filt, DevBuf<uint64_t> &planes, uint64_t &wpr, uint64_t &rows)
 {
     skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
     const int S = (int)a->names.size(); const uint64_t U = a->n_rows;
@@ -2261,15 +2261,23 @@ static int distance_ambiguous_split(skx_array *a, const uint8_t *keep, double co
         if (differ) { launch_split_keep(keep, a->mask.p, U, clean.p, dirty.p, st, 1); nc = 0; pc.release(); }
     }
     SKX_TRY(planes_of_kept_rows(a, dirty.p, 0, pd, wd, nd));
+    return planes_distance_split(ctx, pc.p, wc, nc, pd.p, wd, nd, S, constant, 0, S, out);
+}
+int skx::planes_distance_split(skx_ctx *ctx, const uint64_t *planes_clean, uint64_t wpr_clean, uint64_t rows_clean, const uint64_t *planes_dirty, uint64_t wpr_dirty,
+                               uint64_t rows_dirty, int S, double constant, int i_lo, int i_hi, skx_dist *out)
+{
+    hipStream_t st = ctx->stream;
+    if (S < 2 || i_lo >= i_hi) return SKX_OK;
+    const uint64_t rows = (uint64_t)(i_hi - i_lo);
     DevBuf<unsigned long long> cnt;
-    SKX_TRY(cnt.alloc((uint64_t)S * S * DIST_NCOUNT)); SKX_TRY(cnt.zero(st));
-    if (nc) launch_pair_counts(pc.p, S, wc, 2, cnt.p, st, 0, S);
-    if (nd) launch_pair_counts(pd.p, S, wd, 0, cnt.p, st, 0, S);
-    std::vector<unsigned long long> h((uint64_t)S * S * DIST_NCOUNT);
+    SKX_TRY(cnt.alloc(rows * S * DIST_NCOUNT)); SKX_TRY(cnt.zero(st));
+    if (rows_clean && planes_clean) launch_pair_counts(planes_clean, S, wpr_clean, 2, cnt.p, st, i_lo, i_hi);
+    if (rows_dirty && planes_dirty) launch_pair_counts(planes_dirty, S, wpr_dirty, 0, cnt.p, st, i_lo, i_hi);
+    std::vector<unsigned long long> h(rows * S * DIST_NCOUNT);
     SKX_HIP(hipMemcpyAsync(h.data(), cnt.p, h.size() * 8, hipMemcpyDeviceToHost, st));
     SKX_HIP(hipStreamSynchronize(st));
     SKX_HIP(hipGetLastError());
-    finish_pairs(h.data(), S, 0, S, constant, 0, out);
+    finish_pairs(h.data(), S, i_lo, i_hi, constant, 0, out);
     return SKX_OK;
 }
 int skx::planes_distance(skx_ctx *ctx, const uint64_t *planes, int S, uint64_t wpr, int filt_ambig, double constant, int i_lo, int i_hi, skx_dist *out)

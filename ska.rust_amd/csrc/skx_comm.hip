@@ -536,34 +536,76 @@ extern "C" int skx_array_distance_sharded(skx_comm *c, skx_array *a, int filt_am
     if (!a || a->ctx != c->ctx) { set_error("bad arguments"); return SKX_EINVAL; }
     skx_ctx *ctx = c->ctx; hipStream_t st = ctx->stream;
     SKX_HIP(hipSetDevice(ctx->device));
+    // --allow-ambiguous: the rows without an ambiguous cell in ANY rank's samples (the ranks agree on them through one all-reduce of a byte
+    // per row) travel as 4 planes and go through the three-count sweep, only the others as 8 planes through the twelve-class one
+    const bool split = !filt_ambig && !getenv("SKX_DISTANCE_DENSE");
     const void *lp = nullptr; uint64_t wpr = 0; int np = 0;
-    SKX_TRY(skx_array_distance_planes(a, filt_ambig, &lp, &wpr, &np));
+    DevBuf<uint64_t> lp_clean, lp_dirty; uint64_t wpr_c = 1, wpr_d = 1, rows_c = 0, rows_d = 0;
+    if (!split) SKX_TRY(skx_array_distance_planes(a, filt_ambig, &lp, &wpr, &np));
+    else {
+        SKX_TRY(array_materialize(a));
+        const uint64_t U = a->n_rows, U4 = (U + 3) / 4 * 4;
+        DevBuf<uint8_t> clean, dirty;
+        SKX_TRY(clean.alloc(U4 + 4)); SKX_TRY(dirty.alloc(U4 + 4)); SKX_TRY(dirty.zero(st));
+        launch_split_keep(nullptr, a->mask.p, U, clean.p, dirty.p, st);
+        if (c->world > 1 && U) SKX_TRY(comm_allreduce_u32(c, reinterpret_cast<uint32_t *>(dirty.p), U4 / 4, true));       // a byte per row, summed: < 256 ranks
+        launch_split_keep_from_dirty(dirty.p, U, clean.p, st);                     // dirty: != 0 -> 1; clean = !dirty
+        SKX_TRY(planes_of_kept_rows(a, clean.p, 1, lp_clean, wpr_c, rows_c));
+        // what the split rests on, checked as the single process checks it (present == unambiguous on the rows passed off as clean), by all ranks
+        // together: statistics that missed a code on any of them send every row through the twelve-class sweep on all of them
+        uint64_t differ = 0;
+        if (rows_c) {
+            DevBuf<int> d_flag; SKX_TRY(d_flag.alloc(1)); SKX_TRY(d_flag.zero(st));
+            launch_differ_u32((const uint32_t *)lp_clean.p, (const uint32_t *)(lp_clean.p + (uint64_t)a->names.size() * wpr_c), (uint64_t)a->names.size() * wpr_c * 2, d_flag.p, st);
+            int df = 0;
+            SKX_HIP(hipMemcpyAsync(&df, d_flag.p, 4, hipMemcpyDeviceToHost, st));
+            SKX_HIP(hipStreamSynchronize(st));
+            differ = df ? 1 : 0;
+        }
+        std::vector<uint64_t> differs((size_t)c->world);
+        SKX_TRY(comm_allgather_host(c, &differ, differs.data(), sizeof differ));
+        for (uint64_t d : differs) differ |= d;
+        if (differ || getenv("SKX_TEST_STALE_ROW_MASK")) {
+            launch_split_keep(nullptr, a->mask.p, U, clean.p, dirty.p, st, 1);
+            lp_clean.release(); rows_c = 0; wpr_c = 1;
+        }
+        SKX_TRY(planes_of_kept_rows(a, dirty.p, 0, lp_dirty, wpr_d, rows_d));
+        SKX_HIP(hipStreamSynchronize(st));
+    }
     const uint64_t s_loc = a->names.size();
-    const uint64_t mine[2] = {s_loc, wpr};
-    std::vector<uint64_t> all(2 * (size_t)c->world);
+    const uint64_t mine[3] = {s_loc, split ? wpr_c : wpr, split ? wpr_d : 0};
+    std::vector<uint64_t> all(3 * (size_t)c->world);
     SKX_TRY(comm_allgather_host(c, mine, all.data(), sizeof mine));
     uint64_t S = 0, mx = 1;
     for (int r = 0; r < c->world; r++) {
-        if (all[2 * r + 1] != wpr) { set_error("ranks disagree on the filtered rows (%llu vs %llu words per sample)", (unsigned long long)all[2 * r + 1], (unsigned long long)wpr); return SKX_EINVAL; }
-        S += all[2 * r]; mx = std::max(mx, all[2 * r]);
+        if (all[3 * r + 1] != mine[1] || all[3 * r + 2] != mine[2]) { set_error("ranks disagree on the filtered rows (%llu vs %llu words per sample)", (unsigned long long)all[3 * r + 1], (unsigned long long)mine[1]); return SKX_EINVAL; }
+        S += all[3 * r]; mx = std::max(mx, all[3 * r]);
     }
     if (S > 0x7FFFFFFF) { set_error("too many samples"); return SKX_EUNSUP; }
     // planes[p][sample][word] over all samples, samples in rank order
-    DevBuf<uint64_t> planes; SKX_TRY(planes.alloc((uint64_t)np * S * wpr));
-    if (c->world == 1) SKX_HIP(hipMemcpyAsync(planes.p, lp, (uint64_t)np * S * wpr * 8, hipMemcpyDeviceToDevice, st));
-    else {
+    auto gather = [&](const void *lpl, int npl, uint64_t w, DevBuf<uint64_t> &planes) -> int {
+        SKX_TRY(planes.alloc((uint64_t)npl * S * w));
+        if (c->world == 1) { SKX_HIP(hipMemcpyAsync(planes.p, lpl, (uint64_t)npl * S * w * 8, hipMemcpyDeviceToDevice, st)); return SKX_OK; }
         PhaseTimer pt("comm.planes_allgather");
-        const uint64_t slot = (uint64_t)np * mx * wpr;               // ranks may hold different numbers of samples: padded to the largest
+        const uint64_t slot = (uint64_t)npl * mx * w;                // ranks may hold different numbers of samples: padded to the largest
         DevBuf<uint64_t> padded, gathered; SKX_TRY(padded.alloc(slot)); SKX_TRY(gathered.alloc(slot * (uint64_t)c->world)); SKX_TRY(padded.zero(st));
-        SKX_HIP(hipMemcpy2DAsync(padded.p, mx * wpr * 8, lp, s_loc * wpr * 8, s_loc * wpr * 8, np, hipMemcpyDeviceToDevice, st));
+        SKX_HIP(hipMemcpy2DAsync(padded.p, mx * w * 8, lpl, s_loc * w * 8, s_loc * w * 8, npl, hipMemcpyDeviceToDevice, st));
         SKX_TRY(comm_allgather(c, padded.p, gathered.p, slot * 8, true));
         uint64_t s0 = 0;
         for (int r = 0; r < c->world; r++) {
-            const uint64_t sr = all[2 * r];
-            if (sr) SKX_HIP(hipMemcpy2DAsync(planes.p + s0 * wpr, S * wpr * 8, gathered.p + (uint64_t)r * slot, mx * wpr * 8, sr * wpr * 8, np, hipMemcpyDeviceToDevice, st));
+            const uint64_t sr = all[3 * r];
+            if (sr) SKX_HIP(hipMemcpy2DAsync(planes.p + s0 * w, S * w * 8, gathered.p + (uint64_t)r * slot, mx * w * 8, sr * w * 8, npl, hipMemcpyDeviceToDevice, st));
             s0 += sr;
         }
         SKX_HIP(hipStreamSynchronize(st));
+        return SKX_OK;
+    };
+    DevBuf<uint64_t> planes, planes_c, planes_d;
+    if (!split) SKX_TRY(gather(lp, np, wpr, planes));
+    else {
+        if (rows_c && lp_clean.p) SKX_TRY(gather(lp_clean.p, 4, wpr_c, planes_c));
+        if (rows_d) SKX_TRY(gather(lp_dirty.p, 8, wpr_d, planes_d));
+        lp_clean.release(); lp_dirty.release();
     }
     std::vector<int> bands(2 * (size_t)c->world);
     SKX_TRY(skx_pair_bands((int)S, c->world, 8, bands.data()));
@@ -577,7 +619,8 @@ extern "C" int skx_array_distance_sharded(skx_comm *c, skx_array *a, int filt_am
     skx_dist *mine_out = c->rank == 0 ? out : (band.resize(sizes[c->rank] / sizeof(skx_dist) + 1), band.data());
     {
         PhaseTimer pt("distance.pair_sweep");
-        if (hi > lo) SKX_TRY(planes_distance(ctx, planes.p, (int)S, wpr, filt_ambig, constant, lo, hi, mine_out));
+        if (hi > lo && !split) SKX_TRY(planes_distance(ctx, planes.p, (int)S, wpr, filt_ambig, constant, lo, hi, mine_out));
+        if (hi > lo && split) SKX_TRY(planes_distance_split(ctx, planes_c.p, wpr_c, rows_c, planes_d.p, wpr_d, rows_d, (int)S, constant, lo, hi, mine_out));
     }
     PhaseTimer pt("comm.pairs_to_rank0");
     return comm_gather_root_host(c, mine_out, sizes, out);

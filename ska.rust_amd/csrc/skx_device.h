@@ -210,6 +210,7 @@ void launch_build_planes(const uint8_t *matrix, uint64_t pitch, int n_samples, u
 // the same over the rows with keep == 1 only (pos = exclusive scan of the flags): keep_bits / gpos hold one word per 64 rows; planes zeroed by the caller
 void launch_keep_bits(const uint8_t *keep, const uint64_t *pos, uint64_t n, uint64_t *keep_bits, uint64_t *gpos, hipStream_t st);
 void launch_split_keep(const uint8_t *keep, const uint32_t *col_mask, uint64_t n, uint8_t *clean, uint8_t *dirty, hipStream_t st, int mode = 0);
+void launch_split_keep_from_dirty(uint8_t *dirty, uint64_t n, uint8_t *clean, hipStream_t st);
 void launch_build_planes_keep(const uint8_t *matrix, uint64_t pitch, int n_samples, uint64_t n_cols, const uint64_t *keep_bits, const uint64_t *gpos,
                               uint64_t *planes, uint64_t wpr, int filt, hipStream_t st, uint32_t *first_group, uint64_t kept);
 // (first_group: [kept / 4096 + 2] words of scratch; kept = rows that stay: every word [0, wpr) of every plane and sample is written)

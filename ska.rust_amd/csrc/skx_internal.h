@@ -240,6 +240,12 @@ namespace skx {
 int keyset_flatten(skx_keyset *ks);                                  // ks->flat = the rows as one compact list of packed words (engine order)
 int keyset_union_tables(skx_ctx *ctx, const uint64_t *words, const std::vector<uint64_t> &h_off, const std::vector<uint32_t> &h_cnt, int k, int rc, skx_keyset **out);
 int planes_distance(skx_ctx *ctx, const uint64_t *planes, int S, uint64_t wpr, int filt_ambig, double constant, int i_lo, int i_hi, skx_dist *out);
+// --allow-ambiguous with the rows split by whether one of their cells is ambiguous: planes_clean = 4 planes (FILT) of the rows without such a cell
+// (counts filed as classes 0-2), planes_dirty = 8 planes of the others; either may be absent (nullptr / 0 rows)
+int planes_distance_split(skx_ctx *ctx, const uint64_t *planes_clean, uint64_t wpr_clean, uint64_t rows_clean, const uint64_t *planes_dirty, uint64_t wpr_dirty,
+                          uint64_t rows_dirty, int S, double constant, int i_lo, int i_hi, skx_dist *out);
+// bit planes of the rows flagged 1 in keep (4 planes with filt, else 8): every word written; rows = how many
+int planes_of_kept_rows(skx_array *a, const uint8_t *keep, int filt, DevBuf<uint64_t> &planes, uint64_t &wpr, uint64_t &rows);
 int check_k(int k);                                                  // "Invalid k-mer length" (ska_dict.rs:342-344)
 bool mappable_output_fd(int fd, off_t *pos);                         // regular file, read-write, not O_APPEND: can be written through a mapping
 int array_wide_words(skx_array *a, DevBuf<uint64_t> &tmp, const u128 **words);   // k > 31: the rows' packed 128-bit words on the device (tmp backs them for loaded arrays)
