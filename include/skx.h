@@ -177,7 +177,9 @@ int  skx_array_device_stats(skx_array *a, uint32_t **present, uint32_t **unambig
 int  skx_array_set_total_samples(skx_array *a, uint64_t total_samples);
 
 typedef struct { double distance, mismatch_prop; uint64_t match_count, mismatch_count; } skx_dist;
-/* MergeSkaArray::distance (merge_ska_array.rs:416-438,587-632): upper triangle, pairs (i<j) row-major */
+/* MergeSkaArray::distance (merge_ska_array.rs:416-438,587-632): upper triangle, pairs (i<j) row-major.  filt_ambig = 0 (--allow-ambiguous):
+ * rows in which no cell is ambiguous -- the array's row statistics say which -- are counted by the 4-plane sweep, the others by the
+ * twelve-class one; the sums are the reference's per-row sums either way */
 int  skx_array_distance(skx_array *a, double constant, int filt_ambig, skx_dist *out);
 /* generic_modes::distance (generic_modes.rs:136-189) in one call that leaves the array as it is: rows below ceil(n_samples *
  * min_freq) (when min_freq * n_samples >= 1) and constant rows are skipped while the bit planes are built (*constant = rows the
@@ -236,8 +238,9 @@ int  skx_keyset_allgather(skx_comm *c, skx_keyset *local, skx_keyset **rows);
  * all-gathered and OR-ed); variant_count becomes the global count, the array's total_samples the job's sample count */
 int  skx_array_reduce_stats(skx_comm *c, skx_array *a, uint64_t total_samples);
 /* exchange 3: MergeSkaArray::distance (merge_ska_array.rs:416-438,587-632) for a sharded job: `a` = this rank's samples over the
- * globally filtered rows; one all-gather of the bit planes, each rank finishes a band of the pair matrix, rank 0 receives all
- * pairs: out[n_out], n_out >= S (S - 1) / 2 there (ignored elsewhere) */
+ * globally filtered rows; one all-gather of the bit planes (--allow-ambiguous: one all-reduce of a byte per row first, so that the ranks
+ * agree on the rows without an ambiguous cell, which travel as 4 planes; the others as 8), each rank finishes a band of the pair
+ * matrix, rank 0 receives all pairs: out[n_out], n_out >= S (S - 1) / 2 there (ignored elsewhere) */
 int  skx_array_distance_sharded(skx_comm *c, skx_array *a, int filt_ambig, double constant, skx_dist *out, uint64_t n_out);
 
 
