@@ -371,7 +371,8 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
     const int key_bits_used = 2 * (k - 1);
     // windows per bucket (upper bound): the 64-bit dedupe sorts up to 6 144 words per region in LDS and the regions get 20 % + 256
     // words of head-room, so 4 900 is the largest mean that fits -- and the largest buckets give the scatter its widest chunks
-    const uint64_t per_region = wide ? 4096 : 4900;
+    uint64_t per_region = wide ? 4096 : 4900;
+    if (const char *e = getenv("SKX_WORDS_PER_REGION")) { const long v = atol(e); if (v >= 64 && v <= 4900) per_region = (uint64_t)v; }      // (measurement: more, smaller regions)
     if (any_qual || maxlen > (per_region << MAX_LOGB)) return build_reads();
     int logB = std::min({ilog2_ceil((maxlen + per_region - 1) / per_region), key_bits_used, MAX_LOGB});
     if (logB < 0) logB = 0;
