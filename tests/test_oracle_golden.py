@@ -75,3 +75,32 @@ def test_nthash_roll_equals_recompute():
             for i in (0, 1, 50, len(h) - 2):
                 _, _, _, h1 = ora.extract_record(seq[i:i + k + 1], k, rc=rc, qual_bytes=b"I" * (k + 1), is_reads=True)
                 assert h[i] == h1[0]
+
+
+def test_distance_modes_on_rows_without_ambiguous_cells(tmp_path):
+    """What the engine's --allow-ambiguous row split rests on, stated on the oracle alone (merge_ska_array.rs:587-632 sums per row, so rows
+    can be counted in any grouping): on rows without an ambiguous cell the three counts of the default sweep -- exactly one cell missing,
+    both present (= both unambiguous there), both present and equal -- are all the twelve-class form needs.  In the reference's own
+    outputs: same distance and mismatch count in both modes, and the allow-ambiguous "matches" (cells that share a base) are the default
+    mode's "matches" (cells compared) minus the differing ones."""
+    import numpy as np
+    rng = np.random.default_rng(11)
+    anc = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=6000)]
+    inputs = []
+    for i in range(7):
+        s = anc.copy()
+        pos = rng.integers(0, len(s), size=40)
+        s[pos] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=40)]
+        if i % 3 == 2:
+            s = s[:4000]                                        # missing k-mers
+        p = tmp_path / f"c{i}.fa"
+        p.write_bytes(b">c\n" + s.tobytes() + b"\n")
+        inputs.append((f"c{i}", str(p), None))
+    a = ora.Array.build(inputs, k=21)
+    _, v, _ = a.export()
+    assert set(np.unique(v).tolist()) <= set(b"-ACGT") and (v == ord("-")).any()      # no ambiguity codes in this set
+    c = a.filter(0, False, ora.FILTER_NO_CONST, False, False, False)
+    f, g = a.distance(c, True), a.distance(c, False)
+    assert np.array_equal(f["mismatch_count"], g["mismatch_count"])
+    assert np.allclose(f["distance"], g["distance"], rtol=0, atol=1e-9) and (f["distance"] > 0).any()
+    assert np.array_equal(g["match_count"], f["match_count"] - np.rint(f["distance"]).astype(np.uint64))
