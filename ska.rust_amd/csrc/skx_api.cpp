@@ -298,6 +298,76 @@ static int reads_words_to_dictset(skx_ctx *ctx, std::vector<DevBuf<uint64_t>> &w
 
 }
 
+// the regions of a dictset sorted and folded in place (a sample's SkaDict per bucket: dedupe_mb_kernel / dedupe_wide_kernel, the table
+// form for repeat-rich regions); *overflow != 0: a region does not fit, the caller builds again with more buckets
+static int dedupe_regions(skx_ctx *ctx, skx_dictset *d, uint32_t lds_cap, uint64_t maxlen, int *overflow_out, std::vector<uint32_t> &ucnt)
+{
+    hipStream_t st = ctx->stream;
+    const bool wide = d->wide();
+    const int logB = d->logB;
+    const uint64_t nreg = (uint64_t)d->n << logB;
+    const HashParams hp = d->hp;
+    const int key_bits_used = 2 * (d->k - 1);
+    DevBuf<int> d_flag; SKX_TRY(d_flag.alloc(1));
+    {
+    // LDS capacity (words) of the per-region counting sort: 12 B per word, <= 160 KiB
+    uint32_t cap = std::max<uint32_t>(512, (uint32_t)std::min<uint64_t>(((uint64_t)lds_cap + 255) / 256 * 256, wide ? LDS_SORT_MAX_WIDE : LDS_SORT_MAX));
+    // windows per region are Poisson around len / B: all but ~5 in 10 000 regions stay below mean + 3.3 sigma, which may need a
+    // smaller launch shape than the regions' capacity does (launch_dedupe_mb)
+    const double mean_r = (double)(maxlen >> logB) + 1.0;
+    const uint32_t typical = wide ? 0u : (uint32_t)(mean_r + 3.3 * std::sqrt(mean_r) + 1.0);
+    DevBuf<uint32_t> d_big;
+    if (typical) SKX_TRY(d_big.alloc(nreg + 1));
+    SKX_TRY(d_flag.zero(st));
+    SKX_HIP(hipMemsetAsync(d->sidx.p, 0xFF, nreg * skx::SUBIDX * sizeof(uint16_t), st));     // 0xFFFF = sub-range without words
+    { StageTimer t(ctx, &ctx->tm.dedupe);
+      if (wide) launch_dedupe_wide((u128 *)d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, cap, key_bits_used - logB, d_flag.p, d->sidx.p, d->sb, st);
+      else launch_dedupe_mb(d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, cap, hp.bits - logB, d_flag.p, d->sidx.p, d->sb, st, typical, d_big.p, 0); }
+    int overflow = 0;
+    SKX_HIP(hipMemcpyAsync(&overflow, d_flag.p, 4, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipStreamSynchronize(st));
+    for (uint32_t from = dedupe_spill_grid(); !wide && (overflow & 4); from += dedupe_spill_grid()) {     // more listed regions than one grid of the second stage
+        int keep = overflow & ~4;
+        SKX_HIP(hipMemcpyAsync(d_flag.p, &keep, 4, hipMemcpyHostToDevice, st));
+        { StageTimer t(ctx, &ctx->tm.dedupe); launch_dedupe_mb(d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, cap, hp.bits - logB, d_flag.p, d->sidx.p, d->sb, st, typical, d_big.p, from); }
+        SKX_HIP(hipMemcpyAsync(&overflow, d_flag.p, 4, hipMemcpyDeviceToHost, st));
+        SKX_HIP(hipStreamSynchronize(st));
+    }
+    if (getenv("SKX_DEBUG") && typical) {
+        uint32_t listed = 0;
+        SKX_HIP(hipMemcpy(&listed, d_big.p, 4, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[skx] dedupe: typical region %u words, capacity %u; %u of %llu regions above the typical launch shape\n", typical, cap, listed, (unsigned long long)nreg);
+    }
+    if (!wide && overflow == 2) {
+        // regions beyond the counting sort's capacity (repeat-rich buckets): table-based dedupe, only distinct keys must fit
+        SKX_TRY(d_flag.zero(st));
+        { StageTimer t(ctx, &ctx->tm.dedupe); launch_dedupe(d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, LDS_TABLE_MAX, hp.bits - logB, d_flag.p, cap, d->sidx.p, d->sb, st); }
+        SKX_HIP(hipMemcpyAsync(&overflow, d_flag.p, 4, hipMemcpyDeviceToHost, st));
+    }
+    ucnt.resize(nreg);
+    SKX_HIP(hipMemcpyAsync(ucnt.data(), d->ucnt.p, nreg * 4, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipStreamSynchronize(st));
+    SKX_HIP(hipGetLastError());
+    *overflow_out = overflow;
+    return SKX_OK;
+    }
+}
+
+int skx::dictset_sort(skx_dictset *d)
+{
+    if (d->sorted) return SKX_OK;
+    skx_ctx *ctx = d->ctx;
+    SKX_HIP(hipSetDevice(ctx->device));
+    int overflow = 0;
+    std::vector<uint32_t> ucnt;
+    SKX_TRY(dedupe_regions(ctx, d, d->region_cap, d->maxlen, &overflow, ucnt));
+    if (overflow) { set_error("internal: a fixed-capacity region did not fit the counting sort (%d)", overflow); return SKX_EUNSUP; }
+    d->sample_size.assign(d->n, 0);
+    for (int s = 0; s < d->n; s++) for (uint64_t b = 0; b < (1ull << d->logB); b++) d->sample_size[s] += ucnt[((uint64_t)s << d->logB) + b];
+    d->sorted = true;
+    return SKX_OK;
+}
+
 static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *> &seqs, const std::vector<const uint8_t *> &quals,
                                 const std::vector<uint64_t> &lens, int k, int rc, const skx_qual *q, skx_dictset **out)
 {
@@ -430,44 +500,25 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
               if (wide) launch_scatter_wide(a, st); else launch_scatter(a, st); }
             lds_cap = max_raw;
         }
-        // LDS capacity (words) of the per-region counting sort: 12 B per word, <= 160 KiB
-        uint32_t cap = std::max<uint32_t>(512, (uint32_t)std::min<uint64_t>(((uint64_t)lds_cap + 255) / 256 * 256, wide ? LDS_SORT_MAX_WIDE : LDS_SORT_MAX));
-        // windows per region are Poisson around len / B: all but ~5 in 10 000 regions stay below mean + 3.3 sigma, which may need a
-        // smaller launch shape than the regions' capacity does (launch_dedupe_mb)
-        const double mean_r = (double)(maxlen >> logB) + 1.0;
-        const uint32_t typical = wide ? 0u : (uint32_t)(mean_r + 3.3 * std::sqrt(mean_r) + 1.0);
-        DevBuf<uint32_t> d_big;
-        if (typical) SKX_TRY(d_big.alloc(nreg + 1));
-        SKX_TRY(d_flag.zero(st));
-        SKX_HIP(hipMemsetAsync(d->sidx.p, 0xFF, nreg * skx::SUBIDX * sizeof(uint16_t), st));     // 0xFFFF = sub-range without words
-        { StageTimer t(ctx, &ctx->tm.dedupe);
-          if (wide) launch_dedupe_wide((u128 *)d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, cap, key_bits_used - logB, d_flag.p, d->sidx.p, d->sb, st);
-          else launch_dedupe_mb(d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, cap, hp.bits - logB, d_flag.p, d->sidx.p, d->sb, st, typical, d_big.p, 0); }
-        int overflow = 0;
-        SKX_HIP(hipMemcpyAsync(&overflow, d_flag.p, 4, hipMemcpyDeviceToHost, st));
-        SKX_HIP(hipStreamSynchronize(st));
-        for (uint32_t from = dedupe_spill_grid(); !wide && (overflow & 4); from += dedupe_spill_grid()) {     // more listed regions than one grid of the second stage
-            int keep = overflow & ~4;
-            SKX_HIP(hipMemcpyAsync(d_flag.p, &keep, 4, hipMemcpyHostToDevice, st));
-            { StageTimer t(ctx, &ctx->tm.dedupe); launch_dedupe_mb(d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, cap, hp.bits - logB, d_flag.p, d->sidx.p, d->sb, st, typical, d_big.p, from); }
-            SKX_HIP(hipMemcpyAsync(&overflow, d_flag.p, 4, hipMemcpyDeviceToHost, st));
+        // Assemblies with 64-bit keys whose regions kept their fixed capacity stay as the extraction kernel left them: MergeSkaDict::append
+        // (skx_append.hip) reads them unsorted, and the sorted, folded form (a sample's SkaDict) is made when something asks for it
+        // (skx::dictset_sort: skx_dictset_size / _export, the key-set union of a sharded job).  A fixed-capacity region always fits
+        // the counting sort (region_cap <= LDS_SORT_MAX), so that later sort cannot come back for a finer split.
+        d->maxlen = maxlen; d->region_cap = lds_cap;
+        if (!wide && !exact && !any_qual && lds_cap <= LDS_SORT_MAX && !getenv("SKX_SORTED_DICTS")) {
+            DevBuf<unsigned long long> d_tot; SKX_TRY(d_tot.alloc(n));
+            launch_region_totals(d->raw.p, n, logB, d_tot.p, st);
+            d->raw_total.resize(n);
+            SKX_HIP(hipMemcpyAsync(d->raw_total.data(), d_tot.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
             SKX_HIP(hipStreamSynchronize(st));
+            SKX_HIP(hipGetLastError());
+            d->sorted = false;
+            *out = d.release();
+            return SKX_OK;
         }
-        if (getenv("SKX_DEBUG") && typical) {
-            uint32_t listed = 0;
-            SKX_HIP(hipMemcpy(&listed, d_big.p, 4, hipMemcpyDeviceToHost));
-            fprintf(stderr, "[skx] dedupe: typical region %u words, capacity %u; %u of %llu regions above the typical launch shape\n", typical, cap, listed, (unsigned long long)nreg);
-        }
-        if (!wide && overflow == 2) {
-            // regions beyond the counting sort's capacity (repeat-rich buckets): table-based dedupe, only distinct keys must fit
-            SKX_TRY(d_flag.zero(st));
-            { StageTimer t(ctx, &ctx->tm.dedupe); launch_dedupe(d->words.p, d->off.p, d->raw.p, d->ucnt.p, nreg, LDS_TABLE_MAX, hp.bits - logB, d_flag.p, cap, d->sidx.p, d->sb, st); }
-            SKX_HIP(hipMemcpyAsync(&overflow, d_flag.p, 4, hipMemcpyDeviceToHost, st));
-        }
-        std::vector<uint32_t> ucnt(nreg);
-        SKX_HIP(hipMemcpyAsync(ucnt.data(), d->ucnt.p, nreg * 4, hipMemcpyDeviceToHost, st));
-        SKX_HIP(hipStreamSynchronize(st));
-        SKX_HIP(hipGetLastError());
+        int overflow = 0;
+        std::vector<uint32_t> ucnt;
+        SKX_TRY(dedupe_regions(ctx, d.get(), lds_cap, maxlen, &overflow, ucnt));
         if (overflow) {
             if (logB >= std::min(key_bits_used, MAX_LOGB)) return build_reads();       // repeat content beyond every region size
             logB++;
@@ -511,7 +562,7 @@ extern "C" int skx_dictset_build(skx_ctx *ctx, const skx_stream *samples, int n,
     skx_dictset *d = nullptr;
     SKX_TRY(dictset_build_device(ctx, seqs, quals, lens, k, rc, q, &d));
     for (int s = 0; s < n; s++)
-        if (d->sample_size[s] == 0) { set_error("sample %d has no valid sequence", s); delete d; return SKX_EEMPTY; }
+        if ((d->sorted ? d->sample_size[s] : d->raw_total[s]) == 0) { set_error("sample %d has no valid sequence", s); delete d; return SKX_EEMPTY; }
     *out = d;
     return SKX_OK;
     });
@@ -716,7 +767,7 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     if (r != SKX_OK) return r;
     phase_add("build.dictionaries", std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
     for (int sidx2 = 0; sidx2 < n; sidx2++)
-        if (d->sample_size[sidx2] == 0) { set_error("%s has no valid sequence", file1[sidx2]); delete d; return SKX_EEMPTY; }
+        if ((d->sorted ? d->sample_size[sidx2] : d->raw_total[sidx2]) == 0) { set_error("%s has no valid sequence", file1[sidx2]); delete d; return SKX_EEMPTY; }
     *out = d;
     return SKX_OK;
 }
@@ -1053,6 +1104,7 @@ extern "C" int skx_dictset_size(skx_dictset *d, int sample, uint64_t *n)
 {
     return skx_guarded([&]() -> int {
     if (!d || sample < 0 || sample >= d->n) { set_error("bad sample index"); return SKX_EINVAL; }
+    SKX_TRY(dictset_sort(d));
     *n = d->sample_size[sample];
     return SKX_OK;
     });
@@ -1064,6 +1116,7 @@ extern "C" int skx_dictset_export(skx_dictset *d, int sample, skx_key *keys, uin
     if (!d || sample < 0 || sample >= d->n) { set_error("bad sample index"); return SKX_EINVAL; }
     skx_ctx *ctx = d->ctx; hipStream_t st = ctx->stream;
     SKX_HIP(hipSetDevice(ctx->device));
+    SKX_TRY(dictset_sort(d));
     const uint64_t B = 1ull << d->logB, sz = d->sample_size[sample];
     if (cap < sz) { set_error("buffer too small"); return SKX_EINVAL; }
     std::vector<uint64_t> off(B + 1); std::vector<uint32_t> uc(B);
@@ -1187,6 +1240,7 @@ static int keyset_union_dict(skx_ctx *ctx, skx_dictset *d, skx_keyset **out, boo
     if (!ctx || !d || !out) { set_error("bad arguments"); return SKX_EINVAL; }
     SKX_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    SKX_TRY(dictset_sort(d));                        // the union kernels read sorted slices
     StageTimer t(ctx, &ctx->tm.key_union);
     DictView v = d->view();
     // estimate |U| from a thin slice of the hash space (probe sub-buckets of a 2^logP split)
@@ -1323,6 +1377,7 @@ extern "C" int skx_array_assemble(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows
     if (d->n > 65535) { set_error("more than 65535 samples per device array"); return SKX_EUNSUP; }
     SKX_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    SKX_TRY(dictset_sort(d));
     std::unique_ptr<skx_keyset> rebuilt;
     if (rows->logN < 0 || rows->logN < d->logB) {      // flat / too coarse: re-slab at a compatible granularity
         skx_keyset *one[1] = {rows}; skx_keyset *tmp = nullptr;
@@ -1383,6 +1438,15 @@ extern "C" int skx_array_assemble(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows
     });
 }
 
+// the pieces of an array merged by the append pass (skx_append.hip), as the kernel that turns them into rows x samples cells takes them
+static PiecesRowsArgs pieces_args(skx_array *a)
+{
+    PiecesRowsArgs pa{};
+    const skx_pieces *pc = a->pieces; const skx_keyset *rows = a->lazy_rows;
+    pa.pieces = pc->data.p; pa.plen = pc->plen.p; pa.perm = pc->perm.p; pa.nrank = pc->nrank.p; pa.cap = pc->cap; pa.n_samples = (int)a->names.size();
+    pa.ncnt = rows->ncnt.p; pa.roff = rows->roff.p;
+    return pa;
+}
 // ---- lazily held arrays -------------------------------------------------------------------------------------------------
 // the assemble kernel of the array's key width
 static void launch_assemble_lazy(skx_array *a, const AssembleArgs &aa, hipStream_t st, int mode, uint32_t n_blocks = 0)
@@ -1440,6 +1504,7 @@ extern "C" int skx_array_assemble_lazy(skx_ctx *ctx, skx_dictset *d, skx_keyset 
         return r;
     }
     SKX_HIP(hipSetDevice(ctx->device));
+    { const int rs = dictset_sort(d); if (rs != SKX_OK) { skx_dictset_free(d); skx_keyset_free(rows); return rs; } }
     return array_make_lazy(ctx, d, rows, names, out);
     });
 }
@@ -1467,6 +1532,17 @@ int skx::array_materialize(skx_array *a)
     a->pitch = pitch_for(U);
     SKX_TRY(a->matrix.alloc((uint64_t)S * a->pitch));
     DevBuf<int> d_flag; SKX_TRY(d_flag.alloc(1)); SKX_TRY(d_flag.zero(st));
+    if (a->pieces) {
+        if (U) {
+            PiecesRowsArgs pa = pieces_args(a);
+            pa.out = a->matrix.p; pa.pitch = a->pitch;
+            { StageTimer t(ctx, &ctx->tm.assemble); launch_pieces_rows(pa, 1u << a->pieces->logQ, st); }
+        }
+        SKX_HIP(hipStreamSynchronize(st));
+        SKX_HIP(hipGetLastError());
+        a->drop_lazy();
+        return SKX_OK;
+    }
     if (U) {
         AssembleArgs aa = lazy_args(a, d_flag.p);
         aa.matrix = a->matrix.p; aa.pitch = a->pitch;
@@ -1493,6 +1569,14 @@ int skx::array_lazy_window(skx_array *a, uint64_t r0, uint64_t nr, DevBuf<uint8_
     const uint64_t wp = pitch_for(span);
     const size_t S = a->names.size();
     if (buf.n < S * wp) SKX_TRY(buf.alloc(S * wp));
+    if (a->pieces) {
+        PiecesRowsArgs pa = pieces_args(a);
+        pa.out = buf.p; pa.pitch = wp; pa.j_base = (uint32_t)j0; pa.col_base = c0;
+        { StageTimer t(ctx, &ctx->tm.assemble); launch_pieces_rows(pa, (uint32_t)(j1 - j0), st); }
+        SKX_HIP(hipGetLastError());
+        *win = buf.p + (r0 - c0); *wpitch = wp;
+        return SKX_OK;
+    }
     DevBuf<int> d_flag; SKX_TRY(d_flag.alloc(1)); SKX_TRY(d_flag.zero(st));
     AssembleArgs aa = lazy_args(a, d_flag.p);
     aa.matrix = buf.p; aa.pitch = wp; aa.j_base = (uint32_t)j0; aa.col_base = c0;
@@ -1502,9 +1586,110 @@ int skx::array_lazy_window(skx_array *a, uint64_t r0, uint64_t nr, DevBuf<uint8_
     return SKX_OK;
 }
 
+// ---- MergeSkaDict::append from the raw regions (skx_append.hip) ----------------------------------------------------------------------
+// rows, row statistics and the cells (as pieces) of all samples in one pass over the words the extraction kernel scattered; no sample is
+// sorted.  SKF_NOT_TAKEN: not this kind of dictset (sorted already, 128-bit keys, regions beyond the kernel's load rounds, a row-block split
+// that would read every region too often), or blocks that kept overflowing -- the caller sorts the dictionaries and takes the union /
+// assemble kernels.
+static int merge_append(skx_ctx *ctx, skx_dictset *d, const char *const *names, skx_array **out)
+{
+    if (d->sorted || d->wide() || d->n > 65535 || d->n < 1 || getenv("SKX_NO_APPEND")) return SKF_NOT_TAKEN;
+    SKX_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int S = d->n, bits = d->hp.bits, logB = d->logB;
+    const uint32_t region_cap = d->region_cap;
+    uint64_t raw_sum = 0, raw_max = 0;
+    for (auto v : d->raw_total) { raw_sum += v; raw_max = std::max(raw_max, v); }
+    const int min_logQ = std::max(logB, bits - 50);
+    if (min_logQ > bits || region_cap > 8192u) return SKF_NOT_TAKEN;
+    const double target = 5400.0;                    // mean rows per block: 6 144 ranks hold it with eight sigma to spare
+    auto ranks_for = [&](double mean) -> uint32_t {
+        const double c = mean * 1.03 + 8.0 * std::sqrt(mean + 1.0) + 96.0;
+        return (uint32_t)std::min<double>(APPEND_MAX_CAP, std::ceil(c / 32.0) * 32.0);
+    };
+    auto slots_for = [&](uint32_t cap) -> uint32_t { return std::min<uint32_t>(8192u, std::max<uint32_t>(256u, (cap + cap / 3 + 63u) / 64u * 64u)); };
+    DevBuf<int> d_flag; SKX_TRY(d_flag.alloc(1));
+    DevBuf<unsigned long long> d_probe; SKX_TRY(d_probe.alloc(2));
+    AppendArgs aa{};
+    aa.words = d->words.p; aa.off = d->off.p; aa.raw = d->raw.p; aa.n_samples = S; aa.logB = logB; aa.bits = bits; aa.overflow = d_flag.p; aa.probe = d_probe.p;
+    StageTimer t(ctx, &ctx->tm.key_union);
+    // |U| from a thin slice of the hash space: the first row blocks of a 2^logP split, rows counted only
+    double u_est = (double)raw_max;
+    int logQ = std::min(bits, std::max(min_logQ, ilog2_ceil((uint64_t)((double)raw_max / target) + 1)));
+    if (S > 1) {
+        int logP = std::min(bits, std::max(min_logQ, ilog2_ceil((uint64_t)((double)raw_max * 3.0 / target) + 1)));
+        for (int attempt = 0;; attempt++) {
+            const unsigned blocks = (unsigned)std::min<uint64_t>(64, 1ull << logP);
+            aa.logQ = logP; aa.nslots = 8192u; aa.cap = APPEND_MAX_CAP;
+            if (!append_ok(bits, logB, logP, region_cap, aa.nslots, aa.cap)) return SKF_NOT_TAKEN;
+            SKX_TRY(d_flag.zero(st)); SKX_TRY(d_probe.zero(st));
+            launch_append_probe(aa, region_cap, blocks, st);
+            unsigned long long pr[2] = {0, 0}; int ov = 0;
+            SKX_HIP(hipMemcpyAsync(pr, d_probe.p, 16, hipMemcpyDeviceToHost, st));
+            SKX_HIP(hipMemcpyAsync(&ov, d_flag.p, 4, hipMemcpyDeviceToHost, st));
+            SKX_HIP(hipStreamSynchronize(st));
+            SKX_HIP(hipGetLastError());
+            if (!ov) { u_est = std::max((double)raw_max * 0.5, (double)pr[0] / blocks * (double)(1ull << logP)); break; }
+            if (attempt >= 4 || logP + 2 > bits) return SKF_NOT_TAKEN;
+            logP += 2;
+        }
+        logQ = std::min(bits, std::max(min_logQ, ilog2_ceil((uint64_t)(u_est / target) + 1)));
+    }
+    for (int attempt = 0;; attempt++, logQ++) {
+        if (logQ > bits || attempt > 3) return SKF_NOT_TAKEN;
+        const uint64_t nsub = 1ull << logQ;
+        const double mean = u_est / (double)nsub;
+        const uint32_t cap = ranks_for(mean), nslots = slots_for(cap);
+        const uint64_t amp = 1ull << (logQ - logB);
+        if (amp > 8 && (double)raw_sum * (double)amp > 4e8) return SKF_NOT_TAKEN;          // every region would be read too often
+        if (!append_ok(bits, logB, logQ, region_cap, nslots, cap)) return SKF_NOT_TAKEN;
+        std::unique_ptr<skx_keyset> ks(new skx_keyset());
+        ks->ctx = ctx; ks->k = d->k; ks->rc = d->rc; ks->logN = logQ; ks->hp = d->hp; ks->wh = d->wh; ks->wide = false; ks->stride = cap;
+        std::unique_ptr<skx_pieces> pc(new skx_pieces());
+        pc->cap = cap; pc->logQ = logQ;
+        DevBuf<uint16_t> sp, su, sm; DevBuf<unsigned long long> d_cells;
+        SKX_TRY(ks->stage.alloc(nsub * cap)); SKX_TRY(ks->ncnt.alloc(nsub));
+        SKX_TRY(pc->data.alloc(nsub * (uint64_t)S * (cap / 2))); SKX_TRY(pc->plen.alloc(nsub * (uint64_t)S + 2)); SKX_TRY(pc->perm.alloc(nsub * cap)); SKX_TRY(pc->nrank.alloc(nsub));
+        SKX_TRY(sp.alloc(nsub * cap)); SKX_TRY(su.alloc(nsub * cap)); SKX_TRY(sm.alloc(nsub * cap)); SKX_TRY(d_cells.alloc(S));
+        SKX_TRY(d_flag.zero(st)); SKX_TRY(d_cells.zero(st));
+        aa.logQ = logQ; aa.nslots = nslots; aa.cap = cap;
+        aa.pieces = pc->data.p; aa.plen = pc->plen.p; aa.perm = pc->perm.p; aa.nrank = pc->nrank.p;
+        aa.stage = ks->stage.p; aa.stride = cap; aa.ncnt = ks->ncnt.p; aa.st_present = sp.p; aa.st_unambig = su.p; aa.st_mask = sm.p; aa.sample_cells = d_cells.p;
+        launch_append(aa, region_cap, st);
+        int ov = 0;
+        SKX_HIP(hipMemcpyAsync(&ov, d_flag.p, 4, hipMemcpyDeviceToHost, st));
+        SKX_HIP(hipStreamSynchronize(st));
+        SKX_HIP(hipGetLastError());
+        if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] append: logQ=%d (x%llu per region) cap=%u slots=%u rows~%.0f -> %s\n", logQ, (unsigned long long)amp, cap, nslots, u_est, ov ? "overflow" : "ok");
+        if (ov) continue;
+        SKX_TRY(keyset_finish(ks.get()));
+        const uint64_t U = ks->total;
+        std::unique_ptr<skx_array> a(new skx_array());
+        a->ctx = ctx; a->k = d->k; a->rc = d->rc; a->k_bits = d->key_bits; a->hp = d->hp; a->wh = d->wh; a->version = skx_version();
+        for (int i = 0; i < S; i++) a->names.emplace_back(names && names[i] ? names[i] : "");
+        a->n_rows = a->n_kmers = U; a->pitch = 0; a->engine_order = true; a->stats_ready = true;
+        SKX_TRY(a->present.alloc(U)); SKX_TRY(a->unambig.alloc(U)); SKX_TRY(a->mask.alloc(U)); SKX_TRY(a->keys.alloc(U)); SKX_TRY(a->vcount.alloc(U));
+        if (U) {
+            launch_gather_keys(ks->stage.p, ks->stride, ks->ncnt.p, ks->roff.p, 1 << logQ, a->keys.p, 0, ks->hp, st);
+            launch_append_stats(sp.p, su.p, sm.p, cap, ks->ncnt.p, ks->roff.p, 1 << logQ, a->present.p, a->unambig.p, a->mask.p, a->vcount.p, st);
+        }
+        std::vector<unsigned long long> cells(S);
+        SKX_HIP(hipMemcpyAsync(cells.data(), d_cells.p, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+        SKX_HIP(hipStreamSynchronize(st));
+        SKX_HIP(hipGetLastError());
+        pc->sample_cells.assign(cells.begin(), cells.end());
+        ks->stage.release();                           // the keys live in the array now; the row blocks keep ncnt / roff
+        a->pieces = pc.release(); a->lazy_rows = ks.release();
+        *out = a.release();
+        return SKX_OK;
+    }
+}
+
 extern "C" int skx_merge(skx_ctx *ctx, skx_dictset *d, const char *const *names, skx_array **out)
 {
     return skx_guarded([&]() -> int {
+    if (!ctx || !d || !out) { set_error("bad arguments"); return SKX_EINVAL; }
+    { const int ra = merge_append(ctx, d, names, out); if (ra != SKF_NOT_TAKEN) return ra; }
     skx_keyset *ks = nullptr;
     SKX_TRY(keyset_union_dict(ctx, d, &ks, true));
     int r = skx_array_assemble(ctx, d, ks, names, out);
@@ -1571,7 +1756,9 @@ static int build_range(skx_ctx *ctx, const char *const *names, const char *const
     int r = skx_dictset_build_files(ctx, file1 + lo, file2 ? file2 + lo : nullptr, hi - lo, k, rc, q, threads, proportion_reads, &d);
     if (r == SKX_OK) {
         const auto t0 = std::chrono::steady_clock::now();
-        if (!getenv("SKX_EAGER_ARRAY")) {
+        int ra = merge_append(ctx, d, names + lo, &a);           // assemblies: straight from the extraction kernel's regions; the array holds the pieces
+        if (ra != SKF_NOT_TAKEN) r = ra;
+        else if (!getenv("SKX_EAGER_ARRAY")) {
             // rows now, cells on demand: the array keeps the dictionaries (see skx_array::lazy_dict)
             skx_keyset *ks = nullptr;
             r = skx_keyset_union(ctx, d, &ks);                                         // (without notes: a lazily held array does not use them)
@@ -1769,6 +1956,7 @@ extern "C" int skx_array_sample_kmers(skx_array *a, int64_t *out)
     skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
     SKX_HIP(hipSetDevice(ctx->device));
     const size_t S = a->names.size();
+    if (a->pieces) { for (size_t i = 0; i < S; i++) out[i] = (int64_t)a->pieces->sample_cells[i]; return SKX_OK; }       // first sightings counted by the append pass
     if (a->lazy()) { for (size_t i = 0; i < S; i++) out[i] = (int64_t)a->lazy_dict->sample_size[i]; return SKX_OK; }      // a sample's cells = its dictionary
     DevBuf<unsigned long long> d; SKX_TRY(d.alloc(S)); SKX_TRY(d.zero(st));
     launch_row_nonmissing(a->matrix.p, a->pitch, (int)S, a->n_rows, d.p, st);
@@ -1797,7 +1985,12 @@ static int array_compact(skx_array *a, DevBuf<uint8_t> &keep, DevBuf<uint64_t> &
         const uint64_t np = pitch_for(kept);
         DevBuf<uint8_t> nm; DevBuf<uint32_t> p2, u2, m2, v2;
         SKX_TRY(nm.alloc((uint64_t)S * np)); SKX_TRY(p2.alloc(kept)); SKX_TRY(u2.alloc(kept)); SKX_TRY(m2.alloc(kept)); SKX_TRY(v2.alloc(kept));
-        if (a->lazy()) {
+        if (a->pieces) {
+            // the kept rows straight from the pieces: the unfiltered rows x samples matrix is never written
+            PiecesRowsArgs pa = pieces_args(a);
+            pa.out = nm.p; pa.pitch = np; pa.keep = keep.p; pa.kpos = pos.p; pa.mask_ambig = mask_ambig;
+            launch_pieces_rows(pa, 1u << a->pieces->logQ, st);
+        } else if (a->lazy()) {
             // the kept rows are assembled straight from the dictionaries: the unfiltered matrix is never written
             DevBuf<int> d_flag; SKX_TRY(d_flag.alloc(1)); SKX_TRY(d_flag.zero(st));
             AssembleArgs aa = lazy_args(a, d_flag.p);

@@ -154,6 +154,39 @@ void launch_compose_perm(const uint64_t *l_stage, uint32_t l_stride, const uint3
 void launch_union_side_wide(const DictView &d, int logN, u128 *stage, uint32_t stride, uint32_t *ncnt, uint32_t table_slots, int *overflow,
                             uint16_t *side, uint16_t *perm, hipStream_t st);
 
+// ---- MergeSkaDict::append straight from the extraction kernel's regions (skx_append.hip): no per-sample sorted dictionaries ----
+// A *row block* j holds the rows whose top logQ hash bits are j (logQ >= logB); its workgroup appends the samples in order and leaves, per
+// sample, a *piece*: the sample's cells of the block as 4-bit base sets indexed by first-seen rank, plen[j * S + s] of them, at
+// pieces + (j * S + s) * (cap / 2).  perm[j * cap + rank] = row of the block (key order) or 0xFFFF; nrank[j] = ranks handed out.
+constexpr uint32_t APPEND_MAX_CAP = 6144;
+struct AppendArgs {
+    const uint64_t *words; const uint64_t *off; const uint32_t *raw;      // regions as extract_kernel left them (off in words, raw = fill)
+    int n_samples, logB, bits, logQ;
+    uint32_t nslots, cap;                                                // table slots; ranks a block may hand out (multiple of 32)
+    uint8_t *pieces; uint16_t *plen; uint16_t *perm; uint32_t *nrank;
+    uint64_t *stage; uint32_t stride; uint32_t *ncnt;                    // row keys of block j: sorted slab at stage + j * stride
+    uint16_t *st_present, *st_unambig, *st_mask;                         // row statistics, laid out like the slabs
+    unsigned long long *sample_cells;                                    // [S] distinct split k-mers per sample (SkaDict::ksize), added up over the blocks
+    unsigned long long *probe;                                           // count-only launches: [0] += rows, [1] = max rows of a block
+    int *overflow;                                                       // |= 1 table / ranks / slab full, |= 2 queue full
+};
+bool append_ok(int bits, int logB, int logQ, uint32_t region_cap, uint32_t nslots, uint32_t cap);
+void launch_append(const AppendArgs &a, uint32_t region_cap, hipStream_t st);
+void launch_append_probe(const AppendArgs &a, uint32_t region_cap, unsigned blocks, hipStream_t st);     // the first `blocks` row blocks, rows counted only
+void launch_append_stats(const uint16_t *sp, const uint16_t *su, const uint16_t *sm, uint32_t stride, const uint32_t *ncnt, const uint64_t *roff, int n_blocks,
+                         uint32_t *present, uint32_t *unambig, uint32_t *mask, uint32_t *vcount, hipStream_t st);
+void launch_region_totals(const uint32_t *raw, int n_samples, int logB, unsigned long long *out, hipStream_t st);
+struct PiecesRowsArgs {
+    const uint8_t *pieces; const uint16_t *plen; const uint16_t *perm; const uint32_t *nrank; uint32_t cap; int n_samples;
+    const uint32_t *ncnt; const uint64_t *roff;                          // rows per block and their exclusive scan
+    uint8_t *out; uint64_t pitch;                                        // cell (s, c) at out + s * pitch + c
+    uint32_t j_base = 0; uint64_t col_base = 0;                          // all rows: block j's rows land at columns roff[j] - col_base
+    const uint8_t *keep = nullptr; const uint64_t *kpos = nullptr;        // kept rows only: row r (keep[r] == 1) lands at column kpos[r]
+    int mask_ambig = 0;                                                  // ambiguous cells are written as 'N'
+    int samples_per_wg = 0;                                              // (set by the launcher)
+};
+void launch_pieces_rows(const PiecesRowsArgs &a, uint32_t n_blocks, hipStream_t st);      // blocks [j_base, j_base + n_blocks)
+
 // compact slabs into one array; unhash=1 converts engine-order words back to reference keys
 void launch_gather_keys(const uint64_t *stage, uint32_t stride, const uint32_t *ncnt, const uint64_t *roff, int n_sub,
                         uint64_t *out, int unhash, HashParams hp, hipStream_t st);

@@ -99,7 +99,12 @@ struct skx_dictset {
     skx::DevBuf<uint32_t> ucnt;      // [n<<logB] distinct split k-mers per region
     skx::DevBuf<uint16_t> sidx;      // [n<<logB][16] sub-index of every region (narrow keys, device-built dictionaries)
     int sb = 0;
-    std::vector<uint64_t> sample_size;   // SkaDict::ksize per sample
+    std::vector<uint64_t> sample_size;   // SkaDict::ksize per sample (sorted dictionaries)
+    // Assemblies are kept as the extraction kernel scattered them (regions unsorted, repeats not folded) until something needs a sample's
+    // SkaDict as such: MergeSkaDict::append reads the raw regions (skx_append.hip), skx::dictset_sort makes the sorted form in place.
+    bool sorted = true;
+    uint32_t region_cap = 0; uint64_t maxlen = 0;        // what the later sort needs: words per region, the longest record stream
+    std::vector<uint64_t> raw_total;     // windows per sample (raw form): 0 = the sample has no valid sequence
     skx::DictView view() const { return skx::DictView{words.p, off.p, ucnt.p, n, logB, wide() ? wh.bits : hp.bits, sidx.p, sb}; }
 };
 
@@ -130,6 +135,17 @@ struct skx_keyset {
     int l_logN = -1; uint32_t l_stride = 0, g_max = 0;
 };
 
+// An array as MergeSkaDict::append leaves it (skx_append.hip): per row block and sample a piece of 4-bit base sets indexed by first-seen
+// rank; the rows x samples cells in the order of H are produced from the pieces on demand (all rows, a window, or the rows a filter keeps).
+struct skx_pieces {
+    skx::DevBuf<uint8_t> data;       // [1 << logQ][S][cap / 2]
+    skx::DevBuf<uint16_t> plen;      // [1 << logQ][S] ranks a piece holds
+    skx::DevBuf<uint16_t> perm;      // [1 << logQ][cap] first-seen rank -> row of the block (0xFFFF: none)
+    skx::DevBuf<uint32_t> nrank;     // [1 << logQ] ranks handed out
+    uint32_t cap = 0; int logQ = 0;
+    std::vector<uint64_t> sample_cells;   // SkaDict::ksize per sample
+};
+
 struct skx_array {
     skx_ctx *ctx = nullptr;
     int k = 0, rc = 0, k_bits = 64;
@@ -155,10 +171,11 @@ struct skx_array {
     // assembled; the dictionaries and the row keyset are kept instead.  `ska build` streams such an array into its .skf window
     // by window and `ska align *.fa` filters it before any cell is written, so neither ever holds the unfiltered matrix;
     // every other operation assembles it first (skx::array_materialize).
-    skx_dictset *lazy_dict = nullptr; skx_keyset *lazy_rows = nullptr;
+    // Or (arrays merged by the append pass): the pieces and the row blocks (lazy_rows: ncnt / roff), statistics ready.
+    skx_dictset *lazy_dict = nullptr; skx_keyset *lazy_rows = nullptr; skx_pieces *pieces = nullptr;
     bool stats_ready = true;         // present / unambig / mask / vcount filled (lazy arrays get them from a statistics-only pass)
-    bool lazy() const { return lazy_dict != nullptr; }
-    void drop_lazy() { delete lazy_dict; delete lazy_rows; lazy_dict = nullptr; lazy_rows = nullptr; }
+    bool lazy() const { return lazy_dict != nullptr || pieces != nullptr; }
+    void drop_lazy() { delete lazy_dict; delete lazy_rows; delete pieces; lazy_dict = nullptr; lazy_rows = nullptr; pieces = nullptr; }
     ~skx_array() { drop_lazy(); }
 };
 
@@ -237,6 +254,7 @@ int skf_read_stream(const char *path, SkfMeta &m, std::vector<skx_key> &keys, st
 // helpers shared by the ABI translation units (skx_api.cpp, skx_api_io.cpp)
 namespace skx {
 // pieces of the single-GPU path the collective layer (skx_comm.hip) composes
+int dictset_sort(skx_dictset *d);                                    // raw regions -> sorted, folded regions + sub-index (no-op when they are)
 int keyset_flatten(skx_keyset *ks);                                  // ks->flat = the rows as one compact list of packed words (engine order)
 int keyset_union_tables(skx_ctx *ctx, const uint64_t *words, const std::vector<uint64_t> &h_off, const std::vector<uint32_t> &h_cnt, int k, int rc, skx_keyset **out);
 int planes_distance(skx_ctx *ctx, const uint64_t *planes, int S, uint64_t wpr, int filt_ambig, double constant, int i_lo, int i_hi, skx_dist *out);
