@@ -1602,12 +1602,11 @@ static int merge_append(skx_ctx *ctx, skx_dictset *d, const char *const *names, 
     for (auto v : d->raw_total) { raw_sum += v; raw_max = std::max(raw_max, v); }
     const int min_logQ = std::max(logB, bits - 50);
     if (min_logQ > bits || region_cap > 8192u) return SKF_NOT_TAKEN;
-    const double target = 5400.0;                    // mean rows per block: 6 144 ranks hold it with eight sigma to spare
     auto ranks_for = [&](double mean) -> uint32_t {
-        const double c = mean * 1.03 + 8.0 * std::sqrt(mean + 1.0) + 96.0;
-        return (uint32_t)std::min<double>(APPEND_MAX_CAP, std::ceil(c / 32.0) * 32.0);
+        const double c = mean + 6.0 * std::sqrt(mean + 1.0) + 32.0;
+        return (uint32_t)std::min<double>(APPEND_MAX_CAP, std::ceil(c / 128.0) * 128.0);
     };
-    auto slots_for = [&](uint32_t cap) -> uint32_t { return std::min<uint32_t>(8192u, std::max<uint32_t>(256u, (cap + cap / 3 + 63u) / 64u * 64u)); };
+    auto slots_for = [&](uint32_t cap) -> uint32_t { return std::min<uint32_t>(APPEND_MAX_SLOTS, std::max<uint32_t>(256u, (cap + cap / 3 + 63u) / 64u * 64u)); };
     DevBuf<int> d_flag; SKX_TRY(d_flag.alloc(1));
     DevBuf<unsigned long long> d_probe; SKX_TRY(d_probe.alloc(2));
     AppendArgs aa{};
@@ -1615,12 +1614,13 @@ static int merge_append(skx_ctx *ctx, skx_dictset *d, const char *const *names, 
     StageTimer t(ctx, &ctx->tm.key_union);
     // |U| from a thin slice of the hash space: the first row blocks of a 2^logP split, rows counted only
     double u_est = (double)raw_max;
-    int logQ = std::min(bits, std::max(min_logQ, ilog2_ceil((uint64_t)((double)raw_max / target) + 1)));
+    const double target = 5400.0;                    // mean rows of a probe block (the final split: the coarsest whose blocks fit their ranks)
+    int logQ = min_logQ;
     if (S > 1) {
         int logP = std::min(bits, std::max(min_logQ, ilog2_ceil((uint64_t)((double)raw_max * 3.0 / target) + 1)));
         for (int attempt = 0;; attempt++) {
             const unsigned blocks = (unsigned)std::min<uint64_t>(64, 1ull << logP);
-            aa.logQ = logP; aa.nslots = 8192u; aa.cap = APPEND_MAX_CAP;
+            aa.logQ = logP; aa.nslots = APPEND_MAX_SLOTS; aa.cap = APPEND_MAX_CAP;
             if (!append_ok(bits, logB, logP, region_cap, aa.nslots, aa.cap)) return SKF_NOT_TAKEN;
             SKX_TRY(d_flag.zero(st)); SKX_TRY(d_probe.zero(st));
             launch_append_probe(aa, region_cap, blocks, st);
@@ -1633,8 +1633,9 @@ static int merge_append(skx_ctx *ctx, skx_dictset *d, const char *const *names, 
             if (attempt >= 4 || logP + 2 > bits) return SKF_NOT_TAKEN;
             logP += 2;
         }
-        logQ = std::min(bits, std::max(min_logQ, ilog2_ceil((uint64_t)(u_est / target) + 1)));
     }
+    // the coarsest split whose blocks hold their rows with six sigma to spare (a finer one reads every region more often)
+    for (logQ = min_logQ; logQ < bits && u_est / (double)(1ull << logQ) + 6.0 * std::sqrt(u_est / (double)(1ull << logQ) + 1.0) + 32.0 > (double)APPEND_MAX_CAP; logQ++) { }
     for (int attempt = 0;; attempt++, logQ++) {
         if (logQ > bits || attempt > 3) return SKF_NOT_TAKEN;
         const uint64_t nsub = 1ull << logQ;

@@ -4,42 +4,43 @@
 // split k-mer up, insert a row of '-' if it is new, write the sample's column), and a sample's own dictionary folds repeated split
 // k-mers by OR-ing their middle bases into an IUPAC code (ska_dict.rs:76-113).  Rounds 1-3 sorted and folded every sample's regions
 // first (dedupe_mb_kernel: 80 GB of traffic, a third of the step) so that the union could read them in order.  This file does what the
-// reference does: one workgroup owns a *row block* -- the split k-mers whose top logQ hash bits are j -- and appends the samples one after
-// the other, in sample order, reading each sample's raw region (words as extract_kernel scattered them: unsorted, with repeats):
+// reference does: one workgroup owns a *row block* -- the split k-mers whose top logQ hash bits are j -- and its sixteen waves append
+// samples independently of one another (wave w takes samples w, w + 16, ...: no barrier until the last sample is in), each reading its
+// sample's raw region (words as extract_kernel scattered them: unsorted, with repeats):
 //
 //   * the block's rows live in an order-preserving LDS hash table (slot = monotone function of H, linear probing without wrap); an entry is
-//     (low hash bits << 14) | (first-seen rank + 1): the rank a row got when it was first inserted is its column in everything the pass writes
-//     while the final row order (the order of H) is not known yet;
+//     {top 32 of the low hash bits ; (the rest << 14) | first-seen rank + 1}: the rank a row got when it was first inserted is its column in
+//     everything the pass writes while the final row order (the order of H) is not known yet;
 //   * a region holds the words of A = 2^(logQ - logB) row blocks.  The A workgroups of a region run on the same XCD at the same time
-//     (blockIdx -> XCD is b % 8), each reads the whole region and keeps its share: the first reader takes a line from HBM, the others find it in
-//     that XCD's L2.  Kept words are compacted through an LDS queue so that the look-ups run with full waves;
-//   * a sample's cells of the block are OR-ed into a row buffer of 4-bit base sets indexed by rank (LDS atomics; the returned old value tells a first
-//     sighting -- counted in the row's present / unambiguous statistics and the sample's k-mer count -- from a repeat, which is where ska_dict.rs folds);
+//     (blockIdx -> XCD is b % 8), each reads the whole region and keeps its share: the first reader takes a line from HBM, the others find it
+//     in that XCD's L2 (or the memory-side cache).  A wave reads 512 words at a time (the next 512 are on their way meanwhile), keeps its
+//     block's, and compacts them into a queue of its own so that the look-ups run with full waves: 64 words at a time against the home slot
+//     and its successor; the few words that sit further from home go to a second queue and through the insert loop 64 at a time as well
+//     (looked up in place, they would make every batch wait for its unluckiest lane);
+//   * a sample's cells of the block are OR-ed into the wave's row buffer of 4-bit base sets indexed by rank (LDS atomics; the returned old value
+//     tells a first sighting -- counted in the row's statistics and the sample's k-mer count -- from a repeat, which is where ska_dict.rs folds);
 //   * the row buffer leaves as the sample's *piece* of the block: plen ranks, two per byte, at a fixed place (pieces[(j * S + s) * cap / 2]).
-//     Ranks beyond plen were first seen by later samples: the cell is '-'.  The rows x samples matrix in the order of H is produced from
-//     the pieces by pieces_rows_kernel (all rows, a window of row blocks, or only the rows a filter keeps) -- 1 byte per cell there, 4 bits
-//     and no cell for unseen rows here;
+//     Ranks beyond plen were handed out later: the cell is '-'.  The rows x samples matrix in the order of H is produced from the pieces
+//     by pieces_rows_kernel (all rows, a window of row blocks, or only the rows a filter keeps) -- 1 byte per cell there, 4 bits and no cell
+//     for unseen rows here;
+//   * per row the pass keeps a present count and the union of the bases seen (two LDS atomics per first sighting); rows where a cell is
+//     ambiguous (a palindrome's W / S, or a sample that folded two bases) are marked and get their statistics from the finished pieces;
 //   * when the last sample is in, the table is emitted in key order: the block's row keys, perm (rank -> row of the block) and the row statistics.
-//
-// Three activities overlap in one pass of the sample loop, each on its own buffers, with ONE barrier per sample: filter sample s into queue
-// s & 1, look up / insert the queue of sample s - 1 into row buffer (s - 1) % 3, write out the piece of sample s - 3.
 #include "skx_device.h"
 #include <cstdlib>
 
 namespace skx {
 
-typedef const uint64_t __attribute__((address_space(1))) *gq_t;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const u32x4 __attribute__((address_space(1))) *g4_t;
-typedef const uint32_t __attribute__((address_space(1))) *g1_t;
 
-// Measurement only (-DSKX_AP_PROF): cycles of every wave's lane 0 between the phases of append_kernel's sample loop, summed over waves, workgroups and
-// launches: 0 waiting for the sample's words, 1 filter into the queue, 2 look-ups / inserts, 3 piece written, 4 at the barrier, 5 the tail (emit)
+// Measurement only (-DSKX_AP_PROF): cycles of every wave's lane 0 in the phases of append_kernel, summed over waves, workgroups and launches:
+// 0 waiting for a chunk's words, 1 filter into the queue, 2 look-ups of full batches, 3 the insert loop's batches, 4 end of a sample (drain + piece), 5 the tail (emit)
 #ifdef SKX_AP_PROF
 __device__ unsigned long long g_ap_prof[16];
-#define AP_PROF_START unsigned long long tprof = __builtin_readcyclecounter()
-#define AP_PROF(i) do { if ((threadIdx.x & 63) == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&g_ap_prof[(i)], t_ - tprof); tprof = t_; } } while (0)
-#define AP_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define AP_PROF_START unsigned long long tprof = __builtin_readcyclecounter(), tacc[6] = {0, 0, 0, 0, 0, 0}
+#define AP_PROF(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[(i)] += t_ - tprof; tprof = t_; } while (0)
+#define AP_PROF_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 6; i_++) atomicAdd(&g_ap_prof[i_], tacc[i_]); } while (0)
 extern "C" void skx_debug_phase_prof(unsigned long long *out, int reset)
 {
     unsigned long long h[16];
@@ -51,12 +52,13 @@ extern "C" void skx_debug_phase_prof(unsigned long long *out, int reset)
 #else
 #define AP_PROF_START do { } while (0)
 #define AP_PROF(i) do { } while (0)
-#define AP_WAIT() do { } while (0)
+#define AP_PROF_FLUSH() do { } while (0)
 #endif
 
-constexpr int AP_THREADS = 1024;
-constexpr uint32_t AP_PAD = 128;            // slots behind the table's last home slot (probing does not wrap)
-constexpr uint32_t AP_QCAP = 2048;          // kept words of one sample and block the queue holds
+constexpr int AP_THREADS = 1024, AP_WAVES = 16;
+constexpr uint32_t AP_PAD = 64;             // slots behind the table's last home slot (probing does not wrap)
+constexpr uint32_t AP_Q = 160;              // entries of a wave's queue of kept words: 63 left over + the ~32 +- 5 of one load (more: a batch goes first); the insert loop's queue holds 128
+constexpr int AP_CH = 4;                    // 16-byte loads per lane and chunk: a wave reads 512 words at a time
 constexpr int AP_RANK_BITS = 14;
 constexpr uint32_t AP_RANK_MASK = (1u << AP_RANK_BITS) - 1;
 
@@ -82,40 +84,38 @@ __device__ static inline uint32_t ap_block_excl(uint32_t v, uint32_t *s_tmp /*[1
     __syncthreads();
     return r;
 }
-
-// top 32 of the word's rem local hash bits (word bits [4, rem + 4)), left-aligned
-template <bool HI>
-__device__ static inline uint32_t ap_l32(uint32_t lo, uint32_t hi, int rem)
+__device__ static inline uint32_t ap_mbcnt(unsigned long long b)
 {
-    if (HI) return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(rem - 28));      // 32 <= rem
-    return rem == 0 ? 0u : (uint32_t)(((lo >> 4) | (hi << 28)) << (32 - rem));   // rem < 32: the bits above fall off the left end
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
 }
 
-// ctl words: 0..3 queue fill, 4..6 rank snapshots, 7 ranks handed out, 8 failure, 9..12 first sightings per sample, 13..29 scan scratch, 30 a row is dirty
-constexpr int CTL_QN = 0, CTL_SNAP = 4, CTL_NROWS = 7, CTL_FAIL = 8, CTL_CELLS = 9, CTL_TMP = 13, CTL_DIRTY = 30, CTL_WORDS = 32;
+// ctl words: 0 ranks handed out, 1 failure, 2 a row is dirty, 8..24 scan scratch
+constexpr int CTL_NROWS = 0, CTL_FAIL = 1, CTL_DIRTY = 2, CTL_TMP = 8, CTL_WORDS = 32;
 
 static inline size_t append_lds_bytes(uint32_t nslots, uint32_t cap, bool count_only)
 {
-    size_t b = (size_t)(nslots + AP_PAD) * 8 + (size_t)AP_QCAP * 2 * 8 + CTL_WORDS * 4;
-    if (!count_only) b += (size_t)cap * 4 + (size_t)cap * 2 + (size_t)(cap / 8) * 4 * 3 + (size_t)(cap / 32) * 4 + 128 * 4;
+    size_t b = (size_t)(nslots + AP_PAD) * 8 + (size_t)AP_WAVES * (AP_Q + 128u) * 8 + CTL_WORDS * 4;
+    if (!count_only) b += (size_t)(cap / 2) * 4 + (size_t)(cap / 8) * 4 + (size_t)(cap / 32) * 4 + (size_t)AP_WAVES * (cap / 8) * 4;
     return b;
 }
 
-template <int ROUNDS, bool COUNT_ONLY, bool HI>
+// HI: at least 32 hash bits below the block bits (rem >= 32): the table is addressed by their top 32 and the part bits of a word lie in its
+// upper half -- 32-bit operations throughout.  !HI (short k-mers, small inputs): the same steps on left-aligned fields.
+template <bool COUNT_ONLY, bool HI>
 __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const uint32_t total_slots = a.nslots + AP_PAD;
     const uint32_t cap = a.cap, rbw = cap / 8;                       // ranks per block; dwords of one row buffer
     unsigned long long *s_tab = reinterpret_cast<unsigned long long *>(s_raw);
-    unsigned long long *s_q = s_tab + total_slots;                   // [2][AP_QCAP]
-    uint32_t *s_ctl = reinterpret_cast<uint32_t *>(s_q + 2 * AP_QCAP);
-    uint32_t *s_cnt = s_ctl + CTL_WORDS;                             // [cap] present | unambiguous << 16
-    uint32_t *s_msk = s_cnt + cap;                                   // [cap / 2] 16-bit code sets, two ranks per word
-    uint32_t *s_rb = s_msk + cap / 2;                                // [3][rbw] 4-bit base sets by rank
-    uint32_t *s_dirty = s_rb + 3 * rbw;                              // [cap / 32] ranks whose code set must be taken from the finished cells
-    uint32_t *s_park = s_dirty + cap / 32;                           // [128] piece length | first sightings << 16 of the last samples
+    unsigned long long *s_q = s_tab + total_slots;                   // [AP_WAVES][AP_Q kept words + 128 words for the insert loop]
+    uint32_t *s_ctl = reinterpret_cast<uint32_t *>(s_q + (size_t)AP_WAVES * (AP_Q + 128u));
+    uint32_t *s_cnt = s_ctl + CTL_WORDS;                             // [cap / 2] present counts, two ranks per word
+    uint32_t *s_uni = s_cnt + cap / 2;                               // [cap / 8] union of the bases seen, eight ranks per word
+    uint32_t *s_dirty = s_uni + cap / 8;                             // [cap / 32] ranks whose statistics are taken from the finished cells
+    uint32_t *s_rb = s_dirty + cap / 32;                             // [AP_WAVES][rbw] 4-bit base sets by rank, one buffer per wave
     const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int S = a.n_samples;
     const int shA = a.logQ - a.logB;
     const uint32_t A = 1u << shA;
@@ -124,194 +124,217 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
     else { region = blockIdx.x >> shA; part = blockIdx.x & (A - 1u); }
     const uint64_t j = ((uint64_t)region << shA) + part;             // the block's place in the order of H
     const int rem = a.bits - a.logQ;                                 // hash bits below the block bits
-    const int psh = rem + 4;                                         // the part bits of a word start here (>= 32 when HI)
+    const int psh = rem + 4;                                         // the part bits of a word start here (>= 36 when HI)
+    const int lowb = HI ? rem - 32 : 0;                              // hash bits below the 32 that address the table
 
     for (uint32_t i = tid; i < total_slots; i += AP_THREADS) s_tab[i] = 0ull;
     if (!COUNT_ONLY) {
-        for (uint32_t i = tid; i < cap; i += AP_THREADS) s_cnt[i] = 0u;
-        for (uint32_t i = tid; i < cap / 2; i += AP_THREADS) s_msk[i] = 0u;
-        for (uint32_t i = tid; i < 3 * rbw; i += AP_THREADS) s_rb[i] = 0u;
+        for (uint32_t i = tid; i < cap / 2; i += AP_THREADS) s_cnt[i] = 0u;
+        for (uint32_t i = tid; i < cap / 8; i += AP_THREADS) s_uni[i] = 0u;
         for (uint32_t i = tid; i < cap / 32; i += AP_THREADS) s_dirty[i] = 0u;
+        for (uint32_t i = tid; i < AP_WAVES * rbw; i += AP_THREADS) s_rb[i] = 0u;
     }
     if (tid < CTL_WORDS) s_ctl[tid] = 0u;
     __syncthreads();
 
-    // region offsets and fills are read through the constant address space: scalar loads, no vector-memory counter involved
+    // region offsets and fills are read through the constant address space: scalar loads
     typedef const uint64_t __attribute__((address_space(4))) *cq_t;
     typedef const uint32_t __attribute__((address_space(4))) *c1_t;
     cq_t c_off = (cq_t)(uintptr_t)a.off;
     c1_t c_raw = (c1_t)(uintptr_t)a.raw;
     const uint64_t rstride = 1ull << a.logB;                         // regions per sample
-    // Three samples' words are on their way at any time, each set in registers of its own (the loop below is unrolled three times so that no
-    // set is ever copied: a copy would wait for the loads).  A load is issued by every lane, whatever the region's fill -- lanes past the
-    // fill re-read its last pair -- so that the compiler can count the loads behind the one it waits for (a conditional load makes that
-    // wait a wait for everything, the stores of the pieces included).
-    u32x4 bufA[ROUNDS], bufB[ROUNDS], bufC[ROUNDS];
-    uint32_t cntA = 0, cntB = 0, cntC = 0;
-    // The loads are written as inline assembly and waited for by hand (ap_wait below): the compiler's own count at the head of the unrolled
-    // loop comes out as "everything" (vmcnt(0): the loads just issued and the piece stores included), which would put the memory latency
-    // back into every step.  Nothing else in the loop is a vector-memory load, so the hand count is exact up to the stores in between.
-    auto issue = [&](u32x4 (&buf)[ROUNDS], uint64_t off, uint32_t cnt) {
+    unsigned long long *q = s_q + (size_t)wv * (AP_Q + 128u), *sq = q + AP_Q;      // kept words ; words for the insert loop
+    uint32_t *rb = s_rb + (size_t)wv * rbw;
+    uint8_t *piece0 = a.pieces + j * (uint64_t)S * (cap / 2);
+    uint32_t nq = 0, nsq = 0, firsts = 0;                            // wave-uniform: queue fills, first sightings of the current sample
+    AP_PROF_START;
+
+    // a word's key as the table holds it: hi = the top 32 of its low hash bits (= what the home slot is computed from), lo = the rest << 14
+    auto key_hi = [&](uint32_t wlo, uint32_t whi) -> uint32_t {
+        if (HI) return __builtin_amdgcn_alignbit(whi, wlo, (uint32_t)(rem - 28));
+        return rem == 0 ? 0u : (uint32_t)(((wlo >> 4) | (whi << 28)) << (32 - rem));
+    };
+    auto key_lo = [&](uint32_t wlo) -> uint32_t { return HI ? __builtin_amdgcn_ubfe(wlo, 4u, (uint32_t)lowb) << AP_RANK_BITS : 0u; };
+    // the cell of (current sample, rank1 - 1) takes base set m4; first sightings are counted
+    auto record = [&](uint32_t rank1, uint32_t m4) -> bool {
+        const uint32_t rank = rank1 - 1u, sh = (rank & 7u) * 4u, di = rank >> 3, val = m4 << sh;
+        const uint32_t old = atomicOr(&rb[di], val);
+        const uint32_t on = __builtin_amdgcn_ubfe(old, sh, 4u);
+        if (on == 0u) {
+            atomicOr(&s_uni[di], val);
+            atomicAdd(&s_cnt[rank >> 1], 1u << (16u * (rank & 1u)));
+            if (m4 & (m4 - 1u)) { atomicOr(&s_dirty[rank >> 5], 1u << (rank & 31u)); s_ctl[CTL_DIRTY] = 1u; }      // a palindrome's two bases: an ambiguous cell
+            return true;
+        }
+        if ((on | m4) != on) {                                         // the sample has this split k-mer again with another middle base (ska_dict.rs:92-101)
+            atomicOr(&s_dirty[rank >> 5], 1u << (rank & 31u)); s_ctl[CTL_DIRTY] = 1u;
+        }
+        return false;
+    };
+    // up to 64 queued words against their home slot and its successor; what is not there goes to the insert queue
+    auto slow_batch = [&]() {
+        const uint32_t take = nsq < 64u ? nsq : 64u;
+        nsq -= take;
+        bool first = false;
+        if ((uint32_t)lane < take) {
+            const unsigned long long w = sq[nsq + lane];
+            const uint32_t wlo = (uint32_t)w, whi = (uint32_t)(w >> 32);
+            const uint32_t kh = key_hi(wlo, whi), kl = key_lo(wlo);
+            const unsigned long long keyE = ((unsigned long long)kh << 32) | kl;
+            // A row gets its rank from the lane whose CAS put its key into the table -- AFTER the CAS (sixteen waves meet the same new key in
+            // sixteen related samples: a rank taken before the CAS would be wasted fifteen times).  The key goes in with the rank field all ones;
+            // who finds it so waits for the rank (bounded).  Two statements, in this order: the lanes that won write their ranks before any lane
+            // of the same wave waits for one.
+            uint32_t rank1 = 0;
+            for (uint32_t t = __umulhi(kh, a.nslots); t < total_slots; t++) {
+                unsigned long long e = s_tab[t];
+                bool won = false;
+                if (e == 0ull) { e = atomicCAS(&s_tab[t], 0ull, keyE | AP_RANK_MASK); won = e == 0ull; }
+                if (won) {
+                    const uint32_t mine = atomicAdd(&s_ctl[CTL_NROWS], 1u) + 1u;
+                    if (mine > (COUNT_ONLY ? AP_RANK_MASK - 1u : cap)) s_ctl[CTL_FAIL] = 1u;
+                    reinterpret_cast<volatile uint32_t *>(&s_tab[t])[0] = kl | (mine < AP_RANK_MASK ? mine : AP_RANK_MASK - 1u);
+                    rank1 = mine;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (!won && (e ^ keyE) <= AP_RANK_MASK) {
+                    uint32_t r = (uint32_t)e & AP_RANK_MASK;
+                    for (int it = 0; it < (1 << 16) && r == AP_RANK_MASK; it++) r = reinterpret_cast<volatile uint32_t *>(&s_tab[t])[0] & AP_RANK_MASK;
+                    if (r == AP_RANK_MASK) { s_ctl[CTL_FAIL] = 1u; r = 0; }
+                    rank1 = r;
+                    break;
+                }
+                if (won) break;
+            }
+            if (rank1 > cap && !COUNT_ONLY) rank1 = 0;
+            if (rank1 == 0) s_ctl[CTL_FAIL] = 1u;
+            else if (!COUNT_ONLY) first = record(rank1, wlo & 15u);
+        }
+        if (!COUNT_ONLY) firsts += (uint32_t)__popcll(__ballot(first));
+    };
+    auto batch = [&]() {
+        const uint32_t take = nq < 64u ? nq : 64u;
+        nq -= take;
+        bool miss = false, first = false;
+        unsigned long long w = 0;
+        if ((uint32_t)lane < take) {
+            w = q[nq + lane];
+            const uint32_t wlo = (uint32_t)w, whi = (uint32_t)(w >> 32);
+            const uint32_t kh = key_hi(wlo, whi), kl = key_lo(wlo);
+            const uint32_t hs = __umulhi(kh, a.nslots);
+            const unsigned long long e0 = s_tab[hs], e1 = s_tab[hs + 1];
+            const uint32_t e0l = (uint32_t)e0, e1l = (uint32_t)e1;
+            // (both slots are read at once and compared without short cuts: one LDS round trip per batch)
+            const bool m0 = ((uint32_t)(e0 >> 32) == kh) & ((e0l ^ kl) <= AP_RANK_MASK);
+            const bool m1 = (e0l != 0u) & ((uint32_t)(e1 >> 32) == kh) & ((e1l ^ kl) <= AP_RANK_MASK);
+            const uint32_t rank1 = (m0 ? e0l : m1 ? e1l : 0u) & AP_RANK_MASK;
+            if (rank1 == 0 || rank1 == AP_RANK_MASK) miss = true;          // not there, further from home -- or there, its rank still being written
+            else if (!COUNT_ONLY) first = record(rank1, wlo & 15u);
+        }
+        if (!COUNT_ONLY) firsts += (uint32_t)__popcll(__ballot(first));
+        const unsigned long long mb = __ballot(miss);
+        if (mb) {
+            if (miss) sq[nsq + ap_mbcnt(mb)] = w;
+            nsq += (uint32_t)__popcll(mb);
+        }
+    };
+
+    // the wave's stream of chunks: (sample, chunk) for its samples in turn.  The next chunk is on its way (nxt) while one is looked at (cur: copied
+    // out of nxt once it has arrived -- sixteen moves per 512 words, and one instance of the code below instead of two).  The loads are inline
+    // assembly and waited for by hand: nothing else in the loop is a vector-memory load.
+    u32x4 nxt[AP_CH], cur[AP_CH];
+    auto issue = [&](uint64_t off, uint32_t cnt, uint32_t c) {
         const uint64_t base = (uint64_t)(uintptr_t)(a.words + off);
         const uint32_t last = cnt ? (cnt - 1u) >> 1 : 0u;
 #pragma unroll
-        for (int r = 0; r < ROUNDS; r++) {
-            const uint32_t w = (uint32_t)tid + (uint32_t)AP_THREADS * r;      // pair index
-            const uint32_t vo = (w < last ? w : last) * 16u;
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(buf[r]) : "v"(vo), "s"(base) : "memory");
+        for (int r = 0; r < AP_CH; r++) {
+            const uint32_t p = c * (64u * AP_CH) + 64u * r + (uint32_t)lane;      // pair index
+            const uint32_t vo = (p < last ? p : last) * 16u;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(nxt[r]) : "v"(vo), "s"(base) : "memory");
         }
     };
-    // the words of the set whose loads are followed by those of the two other sets: 2 * ROUNDS younger loads may stay in flight
-    auto ap_wait = [&](u32x4 (&buf)[ROUNDS]) {
-        if (ROUNDS == 1) asm volatile("s_waitcnt vmcnt(2)" : "+v"(buf[0]));
-        if (ROUNDS == 2) asm volatile("s_waitcnt vmcnt(4)" : "+v"(buf[0]), "+v"(buf[ROUNDS > 1 ? 1 : 0]));
-        if (ROUNDS == 3) asm volatile("s_waitcnt vmcnt(6)" : "+v"(buf[0]), "+v"(buf[ROUNDS > 1 ? 1 : 0]), "+v"(buf[ROUNDS > 2 ? 2 : 0]));
-        if (ROUNDS == 4) asm volatile("s_waitcnt vmcnt(8)" : "+v"(buf[0]), "+v"(buf[ROUNDS > 1 ? 1 : 0]), "+v"(buf[ROUNDS > 2 ? 2 : 0]), "+v"(buf[ROUNDS > 3 ? 3 : 0]));
-    };
-    auto region_of = [&](int smp, uint64_t &off, uint32_t &cnt) {
-        const uint64_t rr = (uint64_t)smp * rstride + region;
-        off = c_off[rr]; cnt = c_raw[rr];
-    };
-    uint64_t off_n = 0; uint32_t cnt_n = 0;                           // of the sample whose words are requested next
-    region_of(0, off_n, cnt_n); issue(bufA, off_n, cnt_n); cntA = cnt_n;
-    region_of(S > 1 ? 1 : S - 1, off_n, cnt_n); issue(bufB, off_n, cnt_n); cntB = cnt_n;
-    region_of(S > 2 ? 2 : S - 1, off_n, cnt_n); issue(bufC, off_n, cnt_n); cntC = cnt_n;
-    region_of(S > 3 ? 3 : S - 1, off_n, cnt_n);
-    uint8_t *piece0 = a.pieces + j * (uint64_t)S * (cap / 2);
-    AP_PROF_START;
-    // one sample step; M3 = s % 3 (static: the step is instantiated three times)
-    auto step = [&](const int s, u32x4 (&buf)[ROUNDS], uint32_t &cnt_c, const int M3) {
-        ap_wait(buf);
-        AP_PROF(0);
-        if (tid == 0) {
-            s_ctl[CTL_QN + ((s + 1) & 3)] = 0u;
-            if (s >= 2) s_ctl[CTL_SNAP + (M3 == 2 ? 0 : M3 + 1)] = s_ctl[CTL_NROWS];      // (s - 2) % 3 == (s + 1) % 3: the ranks handed out once sample s - 2 is in
-        }
-        // ---- F(s): this block's share of sample s goes into queue s & 1
-        if (s < S) {
-            unsigned long long *q = s_q + (size_t)(s & 1) * AP_QCAP;
-            uint32_t kf = 0, before[2 * ROUNDS], tot = 0;
+    auto region_of = [&](int smp, uint64_t &off, uint32_t &cnt) { const uint64_t rr = (uint64_t)smp * rstride + region; off = c_off[rr]; cnt = c_raw[rr]; };
+    if (wv < S) {
+        int s = wv;                                                   // the sample of the chunk in hand
+        uint64_t off_c, off_n = 0; uint32_t cnt_c, cnt_n = 0, c = 0;
+        region_of(s, off_c, cnt_c);
+        issue(off_c, cnt_c, 0u);
+        for (;;) {
+            // (the wait and the moves are volatile assembly, in this order: a plain copy may be placed in front of the wait by the compiler,
+            // which knows nothing of loads still on their way into these registers)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int r = 0; r < ROUNDS; r++) {
-                const uint32_t w = 2u * ((uint32_t)tid + (uint32_t)AP_THREADS * r);
-                const uint32_t h0 = HI ? buf[r].y >> (psh - 32) : (uint32_t)((((uint64_t)buf[r].y << 32) | buf[r].x) >> psh);
-                const uint32_t h1 = HI ? buf[r].w >> (psh - 32) : (uint32_t)((((uint64_t)buf[r].w << 32) | buf[r].z) >> psh);
-                const bool k0 = w < cnt_c && (h0 & (A - 1u)) == part, k1 = w + 1u < cnt_c && (h1 & (A - 1u)) == part;
-                const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1);
-                before[2 * r] = tot + __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u));
-                tot += (uint32_t)__popcll(b0);
-                before[2 * r + 1] = tot + __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
-                tot += (uint32_t)__popcll(b1);
-                kf |= (uint32_t)k0 << (2 * r) | (uint32_t)k1 << (2 * r + 1);
+            for (int r = 0; r < AP_CH; r++) {
+                uint32_t x, y, z, w;
+                asm volatile("v_mov_b32 %0, %1" : "=v"(x) : "v"(nxt[r].x));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(y) : "v"(nxt[r].y));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(z) : "v"(nxt[r].z));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(w) : "v"(nxt[r].w));
+                cur[r].x = x; cur[r].y = y; cur[r].z = z; cur[r].w = w;
             }
-            uint32_t base = 0;
-            if (lane == 0 && tot) base = atomicAdd(&s_ctl[CTL_QN + (s & 3)], tot);
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (base + tot > AP_QCAP) { if (lane == 0) s_ctl[CTL_FAIL] = 2u; }
-            else {
+            AP_PROF(0);
+            const uint32_t nch = (cnt_c + 64u * AP_CH * 2u - 1u) / (64u * AP_CH * 2u);
+            const bool last_chunk = c + 1u >= nch;                    // (an empty region has its one, empty, chunk)
+            // the chunk after this one: the sample's next, or the first of the wave's next sample
+            // (ONE place where loads are issued: two would be given registers of their own and be joined by copies at the loop's end -- of
+            // registers whose loads are still on their way)
+            const bool more = !last_chunk || s + AP_WAVES < S;
+            if (last_chunk && more) region_of(s + AP_WAVES, off_n, cnt_n);
+            if (more) issue(last_chunk ? off_n : off_c, last_chunk ? cnt_n : cnt_c, last_chunk ? 0u : c + 1u);
+            // keep this block's words -- the two words of a 16-byte load at a time: about 32 of 128 stay --, look full batches up as they come
+            // together (straight-line code: a loop over the loads with the batch code in one place spent three quarters of the kernel's time on
+            // its own control flow).  The queue holds the 63 words a batch may leave plus 96 of a load; a load that keeps more (a sample that
+            // is one repeat) fails the launch and the host takes the sorted path.
+            const uint32_t w0 = 2u * (c * (64u * AP_CH) + (uint32_t)lane);
 #pragma unroll
-                for (int r = 0; r < ROUNDS; r++) {
-                    if ((kf >> (2 * r)) & 1u) q[base + before[2 * r]] = ((unsigned long long)buf[r].y << 32) | buf[r].x;
-                    if ((kf >> (2 * r + 1)) & 1u) q[base + before[2 * r + 1]] = ((unsigned long long)buf[r].w << 32) | buf[r].z;
+            for (int r = 0; r < AP_CH; r++) {
+                const uint32_t alo = cur[r].x, ahi = cur[r].y, blo = cur[r].z, bhi = cur[r].w;
+                const uint32_t widx = w0 + 128u * r;
+                const uint32_t pa = HI ? ahi >> (psh - 32) : (uint32_t)((((uint64_t)ahi << 32) | alo) >> psh);
+                const uint32_t pb = HI ? bhi >> (psh - 32) : (uint32_t)((((uint64_t)bhi << 32) | blo) >> psh);
+                const bool ka = widx < cnt_c && (pa & (A - 1u)) == part, kbb = widx + 1u < cnt_c && (pb & (A - 1u)) == part;
+                const unsigned long long ba = __ballot(ka), bb = __ballot(kbb);
+                const uint32_t na = (uint32_t)__popcll(ba), nb = (uint32_t)__popcll(bb);
+                if (nq + na + nb > AP_Q) { if (lane == 0) s_ctl[CTL_FAIL] = 2u; }
+                else {
+                    if (ka) q[nq + ap_mbcnt(ba)] = ((unsigned long long)ahi << 32) | alo;
+                    if (kbb) q[nq + na + ap_mbcnt(bb)] = ((unsigned long long)bhi << 32) | blo;
+                    nq += na + nb;
                 }
+                AP_PROF(1);
+                while (nq >= 64u) { batch(); AP_PROF(2); if (nsq >= 64u) { slow_batch(); AP_PROF(3); } }
             }
-        }
-        AP_PROF(1);
-        // ---- W(s - 3): the piece of sample s - 3 leaves (its rank count was snapshot a step ago); stores before the loads below, which are the
-        // ones the next steps wait for
-        if (!COUNT_ONLY && s >= 3 && s - 3 < S) {
-            const int sw = s - 3;
-            uint32_t n = s_ctl[CTL_SNAP + M3];                       // (s - 3) % 3 == s % 3
-            if (n > cap) n = cap;
-            uint32_t *rb = s_rb + (size_t)M3 * rbw;
-            if ((uint32_t)tid * 32u < n) {
-                uint4 *src = reinterpret_cast<uint4 *>(rb) + tid;
-                const uint4 v = *src;
-                *reinterpret_cast<uint4 *>(piece0 + (uint64_t)sw * (cap / 2) + (uint32_t)tid * 16u) = v;
-                *src = make_uint4(0u, 0u, 0u, 0u);
+            if (last_chunk) {
+                while (nq) { batch(); AP_PROF(2); if (nsq >= 64u) { slow_batch(); AP_PROF(3); } }
+                while (nsq) { slow_batch(); AP_PROF(3); }
             }
-            // the piece's length and the sample's first sightings are parked and leave 64 samples at a time (wave 3: it stores no piece)
-            if (tid == 0) {
-                s_park[sw & 127] = n | (s_ctl[CTL_CELLS + (sw & 3)] << 16);
-                s_ctl[CTL_CELLS + (sw & 3)] = 0u;
-            }
-        }
-        if (!COUNT_ONLY && s >= 4 && (tid >> 6) == 3 && (((s - 4) & 63) == 63 || s - 4 == S - 1)) {      // samples up to s - 4 are parked (the step before this one)
-            const int last = s - 4, first = last & ~63, sm = first + lane;
-            if (sm <= last) {
-                const uint32_t v = s_park[(first & 127) + lane];
-                a.plen[j * (uint64_t)S + sm] = (uint16_t)(v & 0xFFFFu);
-                if (v >> 16) atomicAdd(&a.sample_cells[sm], (unsigned long long)(v >> 16));
-            }
-        }
-        AP_PROF(3);
-        // the words of sample s + 3 are requested into the registers F(s) has just read
-        // (always, past the last sample too -- it is read again: a conditional load would not be counted, see above)
-        issue(buf, off_n, cnt_n); cnt_c = cnt_n;
-        region_of(s + 4 < S ? s + 4 : S - 1, off_n, cnt_n);
-        // ---- I(s - 1): the queue of sample s - 1 against the table; its cells into row buffer (s - 1) % 3
-        if (s >= 1 && s - 1 < S) {
-            const unsigned long long *q = s_q + (size_t)((s - 1) & 1) * AP_QCAP;
-            uint32_t qn = s_ctl[CTL_QN + ((s - 1) & 3)];
-            if (qn > AP_QCAP) qn = AP_QCAP;
-            uint32_t *rb = s_rb + (size_t)(M3 == 0 ? 2 : M3 - 1) * rbw;
-            uint32_t firsts = 0;
-            for (uint32_t i = tid; i < qn; i += AP_THREADS) {
-                const unsigned long long w = q[i];
-                const uint32_t hs = __umulhi(ap_l32<HI>((uint32_t)w, (uint32_t)(w >> 32), rem), a.nslots);
-                const unsigned long long e0 = s_tab[hs], e1 = s_tab[hs + 1];
-                const unsigned long long keyE = ((w << (60 - rem)) >> (50 - rem)) & ~(unsigned long long)AP_RANK_MASK;      // (low hash bits) << 14
-                uint32_t rank1 = 0;
-                if ((e0 ^ keyE) <= AP_RANK_MASK) rank1 = (uint32_t)e0 & AP_RANK_MASK;
-                else if (e0 != 0ull && (e1 ^ keyE) <= AP_RANK_MASK) rank1 = (uint32_t)e1 & AP_RANK_MASK;
-                if (rank1 == 0) {                                      // first sighting, or a key displaced further: the insert loop
-                    uint32_t mine = 0;
-                    for (uint32_t t = hs; t < total_slots; t++) {
-                        unsigned long long e = s_tab[t];
-                        if (e == 0ull) {
-                            if (!mine) { mine = atomicAdd(&s_ctl[CTL_NROWS], 1u) + 1u; if (mine > (COUNT_ONLY ? AP_RANK_MASK : cap)) { s_ctl[CTL_FAIL] = 1u; break; } }
-                            e = atomicCAS(&s_tab[t], 0ull, keyE | mine);
-                            if (e == 0ull) { rank1 = mine; break; }
-                        }
-                        if ((e ^ keyE) <= AP_RANK_MASK && (e & AP_RANK_MASK)) { rank1 = (uint32_t)e & AP_RANK_MASK; break; }
+            AP_PROF(1);
+            if (last_chunk) {
+                if (!COUNT_ONLY) {
+                    uint32_t n = *reinterpret_cast<volatile uint32_t *>(&s_ctl[CTL_NROWS]);
+                    n = __builtin_amdgcn_readfirstlane(n);
+                    if (n > cap) n = cap;
+                    uint8_t *dst = piece0 + (uint64_t)s * (cap / 2);
+                    for (uint32_t v = lane; v * 32u < n; v += 64u) {
+                        uint4 *src = reinterpret_cast<uint4 *>(rb) + v;
+                        const uint4 x = *src;
+                        *reinterpret_cast<uint4 *>(dst + v * 16u) = x;
+                        *src = make_uint4(0u, 0u, 0u, 0u);
                     }
-                    if (rank1 == 0) { s_ctl[CTL_FAIL] = 1u; continue; }
+                    if (lane == 0) {
+                        a.plen[j * (uint64_t)S + s] = (uint16_t)n;
+                        if (firsts) atomicAdd(&a.sample_cells[s], (unsigned long long)firsts);
+                    }
+                    firsts = 0;
                 }
-                if (COUNT_ONLY) continue;
-                const uint32_t rank = rank1 - 1u, m4 = (uint32_t)w & 15u, sh = (rank & 7u) * 4u;
-                const uint32_t old = atomicOr(&rb[rank >> 3], m4 << sh);
-                const uint32_t on = (old >> sh) & 15u, nn = on | m4;
-                if (on == 0u) {
-                    const uint32_t single = (m4 & (m4 - 1u)) == 0u;
-                    atomicAdd(&s_cnt[rank], 1u | (single << 16));
-                    atomicOr(&s_msk[rank >> 1], (1u << m4) << (16u * (rank & 1u)));
-                    firsts++;
-                } else if (nn != on) {                                 // the sample has this split k-mer again with another middle base (ska_dict.rs:92-101)
-                    if ((on & (on - 1u)) == 0u) atomicSub(&s_cnt[rank], 1u << 16);
-                    atomicOr(&s_dirty[rank >> 5], 1u << (rank & 31u)); s_ctl[CTL_DIRTY] = 1u;
-                }
-            }
-            if (!COUNT_ONLY) {
-                const unsigned long long anyf = __ballot(firsts != 0u);
-                if (anyf) {
-                    uint32_t wt; (void)ap_wave_excl(firsts, &wt);
-                    if (lane == 0) atomicAdd(&s_ctl[CTL_CELLS + ((s - 1) & 3)], wt);
-                }
-            }
+                AP_PROF(4);
+                if (!more) break;
+                s += AP_WAVES; c = 0; off_c = off_n; cnt_c = cnt_n;
+            } else c++;
         }
-        AP_PROF(2);
-        __syncthreads();
-        AP_PROF(4);
-    };
-    for (int s = 0; s < S + 4; s += 3) {
-        step(s, bufA, cntA, 0);
-        step(s + 1, bufB, cntB, 1);
-        step(s + 2, bufC, cntC, 2);
     }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bufA[0]), "+v"(bufB[0]), "+v"(bufC[0]));      // (the loads past the last sample: nothing may still be on its way into these registers)
-    if (ROUNDS > 1) asm volatile("" : "+v"(bufA[ROUNDS > 1 ? 1 : 0]), "+v"(bufB[ROUNDS > 1 ? 1 : 0]), "+v"(bufC[ROUNDS > 1 ? 1 : 0]));
-    if (ROUNDS > 2) asm volatile("" : "+v"(bufA[ROUNDS > 2 ? 2 : 0]), "+v"(bufB[ROUNDS > 2 ? 2 : 0]), "+v"(bufC[ROUNDS > 2 ? 2 : 0]));
-    if (ROUNDS > 3) asm volatile("" : "+v"(bufA[ROUNDS > 3 ? 3 : 0]), "+v"(bufB[ROUNDS > 3 ? 3 : 0]), "+v"(bufC[ROUNDS > 3 ? 3 : 0]));
+    AP_PROF_FLUSH();
+    __syncthreads();
     const uint32_t nr = s_ctl[CTL_NROWS];                             // ranks handed out (a few may belong to no row: a lost insertion race)
     if (s_ctl[CTL_FAIL]) { if (tid == 0) atomicOr(a.overflow, (int)s_ctl[CTL_FAIL]); return; }
     uint32_t *s_tmp = s_ctl + CTL_TMP;
@@ -322,18 +345,27 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
         if (tid == 0) { atomicAdd(&a.probe[0], (unsigned long long)tot); atomicMax(&a.probe[1], (unsigned long long)tot); }
         return;
     }
-    // code sets of the rows where a sample folded two middle bases: from the finished cells (the intermediate codes never were a cell)
+    // statistics by rank: present count, unambiguous count, code set.  Clean rows hold single bases only: every present cell is unambiguous and
+    // the code set follows from the union of the bases; dirty rows are counted from the finished cells of all samples.
+    uint32_t *s_un = s_rb;                                            // [cap] unambiguous | code set << 16, over the row buffers (done as well)
+    __syncthreads();
+    for (uint32_t r = tid; r < cap; r += AP_THREADS) {
+        const uint32_t p = (s_cnt[r >> 1] >> (16u * (r & 1u))) & 0xFFFFu;
+        const uint32_t u = (s_uni[r >> 3] >> ((r & 7u) * 4u)) & 15u;
+        const uint32_t m16 = ((u & 1u) << 1) | ((u & 2u) << 1) | ((u & 4u) << 2) | ((u & 8u) << 5);
+        s_un[r] = p | (m16 << 16);
+    }
+    __syncthreads();
     if (s_ctl[CTL_DIRTY]) {
         __threadfence();
         __syncthreads();
-        const int wv = tid >> 6;
         uint32_t seen = 0;
         for (uint32_t i = 0; i < cap / 32; i++) {
             uint32_t bits = s_dirty[i];
             while (bits) {
                 const uint32_t r = i * 32u + (uint32_t)__ffs(bits) - 1u; bits &= bits - 1u;
                 if ((int)(seen++ & 15u) != wv) continue;              // dirty rows are dealt to the sixteen waves in turn
-                uint32_t m = 0;
+                uint32_t m = 0, pc = 0, uc = 0;
                 for (int s = lane; s < S; s += 64) {
                     const uint64_t pi = j * (uint64_t)S + s;
                     const uint32_t pw2 = __hip_atomic_load(reinterpret_cast<const uint32_t *>(a.plen) + (pi >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -342,15 +374,11 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
                     const uint32_t *pw = reinterpret_cast<const uint32_t *>(piece0 + (uint64_t)s * (cap / 2)) + (r >> 3);
                     const uint32_t x = __hip_atomic_load(pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const uint32_t nib = (x >> ((r & 7u) * 4u)) & 15u;
-                    if (nib) m |= 1u << nib;
+                    if (nib) { m |= 1u << nib; pc++; uc += (nib & (nib - 1u)) == 0u; }
                 }
 #pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) m |= __shfl_xor(m, d, 64);
-                if (lane == 0) {                                       // (the word's other half is rank r ^ 1's, possibly another wave's: atomics)
-                    const uint32_t shm = 16u * (r & 1u);
-                    atomicAnd(&s_msk[r >> 1], ~(0xFFFFu << shm));
-                    atomicOr(&s_msk[r >> 1], m << shm);
-                }
+                for (int d = 32; d >= 1; d >>= 1) { m |= __shfl_xor(m, d, 64); pc += __shfl_xor(pc, d, 64); uc += __shfl_xor(uc, d, 64); }
+                if (lane == 0) { s_un[r] = uc | (m << 16); const uint32_t sh16 = 16u * (r & 1u); atomicAnd(&s_cnt[r >> 1], ~(0xFFFFu << sh16)); atomicOr(&s_cnt[r >> 1], pc << sh16); }
             }
         }
         __syncthreads();
@@ -376,52 +404,48 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
         const uint32_t idx = pos - gl + lr, rank = ((uint32_t)e & AP_RANK_MASK) - 1u;
         pos++;
         if (idx < a.stride && rank < cap) {
-            slab[idx] = ((((uint64_t)j << rem) | (uint64_t)(e >> AP_RANK_BITS)) << 4) | 1ull;
+            // the low hash bits back from {top 32 ; rest << 14 | rank}
+            uint64_t hl;
+            if (HI) hl = ((uint64_t)(uint32_t)(e >> 32) << lowb) | (uint64_t)((uint32_t)e >> AP_RANK_BITS);
+            else hl = rem == 0 ? 0ull : (uint64_t)((uint32_t)(e >> 32) >> (32 - rem));
+            slab[idx] = ((((uint64_t)j << rem) | hl) << 4) | 1ull;
             s_perm[rank] = (uint16_t)idx;
-            const uint32_t cw = s_cnt[rank];
-            o_p[idx] = (uint16_t)(cw & 0xFFFFu); o_u[idx] = (uint16_t)(cw >> 16);
-            o_m[idx] = (uint16_t)((s_msk[rank >> 1] >> (16u * (rank & 1u))) & 0xFFFFu);
+            const uint32_t un = s_un[rank];
+            o_p[idx] = (uint16_t)((s_cnt[rank >> 1] >> (16u * (rank & 1u))) & 0xFFFFu);
+            o_u[idx] = (uint16_t)(un & 0xFFFFu);
+            o_m[idx] = (uint16_t)(un >> 16);
         }
     }
     __syncthreads();
     uint16_t *pj = a.perm + j * (uint64_t)cap;
     for (uint32_t i = tid; i < cap; i += AP_THREADS) pj[i] = s_perm[i];
     if (tid == 0) { a.ncnt[j] = total; a.nrank[j] = nr < cap ? nr : cap; if (total > a.stride) atomicOr(a.overflow, 1); }
-    AP_PROF(5);
 }
 
-template <int ROUNDS, bool COUNT_ONLY>
+template <bool COUNT_ONLY>
 static void launch_append_t(const AppendArgs &a, unsigned blocks, hipStream_t st)
 {
     const size_t lds = append_lds_bytes(a.nslots, a.cap, COUNT_ONLY);
     const bool hi = a.bits - a.logQ >= 32;
     if (hi) {
-        (void)hipFuncSetAttribute((const void *)append_kernel<ROUNDS, COUNT_ONLY, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((append_kernel<ROUNDS, COUNT_ONLY, true>), dim3(blocks), dim3(AP_THREADS), lds, st, a);
+        (void)hipFuncSetAttribute((const void *)append_kernel<COUNT_ONLY, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((append_kernel<COUNT_ONLY, true>), dim3(blocks), dim3(AP_THREADS), lds, st, a);
     } else {
-        (void)hipFuncSetAttribute((const void *)append_kernel<ROUNDS, COUNT_ONLY, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((append_kernel<ROUNDS, COUNT_ONLY, false>), dim3(blocks), dim3(AP_THREADS), lds, st, a);
+        (void)hipFuncSetAttribute((const void *)append_kernel<COUNT_ONLY, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((append_kernel<COUNT_ONLY, false>), dim3(blocks), dim3(AP_THREADS), lds, st, a);
     }
 }
-template <bool COUNT_ONLY>
-static void launch_append_r(const AppendArgs &a, uint32_t region_cap, unsigned blocks, hipStream_t st)
-{
-    const uint32_t rounds = (region_cap + 2 * AP_THREADS - 1) / (2 * AP_THREADS);
-    if (rounds <= 1) launch_append_t<1, COUNT_ONLY>(a, blocks, st);
-    else if (rounds == 2) launch_append_t<2, COUNT_ONLY>(a, blocks, st);
-    else if (rounds == 3) launch_append_t<3, COUNT_ONLY>(a, blocks, st);
-    else launch_append_t<4, COUNT_ONLY>(a, blocks, st);
-}
-// what the pass takes: hash bits below the block bits that leave room for a rank in a table entry, regions of at most four load rounds,
-// a table and row buffers that fit the LDS
+// what the pass takes: hash bits below the block bits that leave room for a rank in a table entry; a table, sixteen row buffers and the
+// queues that fit the LDS
 bool append_ok(int bits, int logB, int logQ, uint32_t region_cap, uint32_t nslots, uint32_t cap)
 {
     const int rem = bits - logQ;
-    return logQ >= logB && rem >= 0 && rem <= 50 && region_cap <= 8u * AP_THREADS && cap % 32u == 0 && cap >= 32u && cap <= APPEND_MAX_CAP &&
-           nslots >= cap && append_lds_bytes(nslots, cap, false) <= 160u * 1024u;
+    (void)region_cap;
+    return logQ >= logB && rem >= 0 && rem <= 50 && cap % 128u == 0 && cap >= 128u && cap <= APPEND_MAX_CAP && nslots >= cap &&
+           append_lds_bytes(nslots, cap, false) <= 160u * 1024u - 256u;
 }
-void launch_append(const AppendArgs &a, uint32_t region_cap, hipStream_t st) { launch_append_r<false>(a, region_cap, 1u << a.logQ, st); }
-void launch_append_probe(const AppendArgs &a, uint32_t region_cap, unsigned blocks, hipStream_t st) { launch_append_r<true>(a, region_cap, blocks, st); }
+void launch_append(const AppendArgs &a, uint32_t region_cap, hipStream_t st) { (void)region_cap; launch_append_t<false>(a, 1u << a.logQ, st); }
+void launch_append_probe(const AppendArgs &a, uint32_t region_cap, unsigned blocks, hipStream_t st) { (void)region_cap; launch_append_t<true>(a, blocks, st); }
 
 // the statistics of the row blocks (16-bit, one slab per block) as the array holds them: one 32-bit value per row, rows in the order of H
 __global__ __launch_bounds__(256) void append_stats_kernel(const uint16_t *sp, const uint16_t *su, const uint16_t *sm, uint32_t stride, const uint32_t *ncnt,

@@ -158,7 +158,7 @@ void launch_union_side_wide(const DictView &d, int logN, u128 *stage, uint32_t s
 // A *row block* j holds the rows whose top logQ hash bits are j (logQ >= logB); its workgroup appends the samples in order and leaves, per
 // sample, a *piece*: the sample's cells of the block as 4-bit base sets indexed by first-seen rank, plen[j * S + s] of them, at
 // pieces + (j * S + s) * (cap / 2).  perm[j * cap + rank] = row of the block (key order) or 0xFFFF; nrank[j] = ranks handed out.
-constexpr uint32_t APPEND_MAX_CAP = 6144;
+constexpr uint32_t APPEND_MAX_CAP = 6016, APPEND_MAX_SLOTS = 7600;    // what sixteen row buffers, the queues and the table leave of 160 KB
 struct AppendArgs {
     const uint64_t *words; const uint64_t *off; const uint32_t *raw;      // regions as extract_kernel left them (off in words, raw = fill)
     int n_samples, logB, bits, logQ;
