@@ -126,6 +126,7 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
     const int rem = a.bits - a.logQ;                                 // hash bits below the block bits
     const int psh = rem + 4;                                         // the part bits of a word start here (>= 36 when HI)
     const int lowb = HI ? rem - 32 : 0;                              // hash bits below the 32 that address the table
+    const uint32_t fmask = HI ? (A - 1u) << (psh - 32) : 0u, pshift = HI ? part << (psh - 32) : 0u;      // the part bits in a word's upper half
 
     for (uint32_t i = tid; i < total_slots; i += AP_THREADS) s_tab[i] = 0ull;
     if (!COUNT_ONLY) {
@@ -286,20 +287,65 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
             // its own control flow).  The queue holds the 63 words a batch may leave plus 96 of a load; a load that keeps more (a sample that
             // is one repeat) fails the launch and the host takes the sorted path.
             const uint32_t w0 = 2u * (c * (64u * AP_CH) + (uint32_t)lane);
+            const uint32_t qbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned long long *)q;      // the queue's LDS byte address
 #pragma unroll
             for (int r = 0; r < AP_CH; r++) {
                 const uint32_t alo = cur[r].x, ahi = cur[r].y, blo = cur[r].z, bhi = cur[r].w;
                 const uint32_t widx = w0 + 128u * r;
-                const uint32_t pa = HI ? ahi >> (psh - 32) : (uint32_t)((((uint64_t)ahi << 32) | alo) >> psh);
-                const uint32_t pb = HI ? bhi >> (psh - 32) : (uint32_t)((((uint64_t)bhi << 32) | blo) >> psh);
-                const bool ka = widx < cnt_c && (pa & (A - 1u)) == part, kbb = widx + 1u < cnt_c && (pb & (A - 1u)) == part;
-                const unsigned long long ba = __ballot(ka), bb = __ballot(kbb);
-                const uint32_t na = (uint32_t)__popcll(ba), nb = (uint32_t)__popcll(bb);
-                if (nq + na + nb > AP_Q) { if (lane == 0) s_ctl[CTL_FAIL] = 2u; }
-                else {
-                    if (ka) q[nq + ap_mbcnt(ba)] = ((unsigned long long)ahi << 32) | alo;
-                    if (kbb) q[nq + na + ap_mbcnt(bb)] = ((unsigned long long)bhi << 32) | blo;
-                    nq += na + nb;
+                if (HI) {
+                    // which of the two words are this block's (part bits in the upper half, the region's fill), as lane masks; then the kept
+                    // words side by side into the queue.  Written out: the compiler's version of the same spends three times the instructions
+                    // on turning conditions into lane masks and back (twelve vector instructions here per 128 words).
+                    unsigned long long ma, mb; uint32_t na, nb, ta, tb;
+                    asm volatile("v_and_b32 %4, %6, %8\n\t"
+                                 "v_cmp_eq_u32_e32 vcc, %7, %4\n\t"
+                                 "s_mov_b64 %0, vcc\n\t"
+                                 "v_cmp_gt_u32_e32 vcc, %10, %11\n\t"
+                                 "s_and_b64 %0, %0, vcc\n\t"
+                                 "v_and_b32 %5, %6, %9\n\t"
+                                 "v_cmp_eq_u32_e32 vcc, %7, %5\n\t"
+                                 "s_mov_b64 %1, vcc\n\t"
+                                 "v_cmp_gt_u32_e32 vcc, %10, %12\n\t"
+                                 "s_and_b64 %1, %1, vcc\n\t"
+                                 "s_bcnt1_i32_b64 %2, %0\n\t"
+                                 "s_bcnt1_i32_b64 %3, %1"
+                                 : "=&s"(ma), "=&s"(mb), "=&s"(na), "=&s"(nb), "=&v"(ta), "=&v"(tb)
+                                 : "s"(fmask), "s"(pshift), "v"(ahi), "v"(bhi), "s"(cnt_c), "v"(widx), "v"(widx + 1u)
+                                 : "vcc", "scc");
+                    if (nq + na + nb > AP_Q) { if (lane == 0) s_ctl[CTL_FAIL] = 2u; }
+                    else {
+                        const uint32_t qa = qbase + nq * 8u, qb = qa + na * 8u;
+                        unsigned long long sv;
+                        asm volatile("s_mov_b64 vcc, %3\n\t"
+                                     "v_mbcnt_lo_u32_b32 %0, vcc_lo, 0\n\t"
+                                     "v_mbcnt_hi_u32_b32 %0, vcc_hi, %0\n\t"
+                                     "v_lshl_add_u32 %0, %0, 3, %5\n\t"
+                                     "s_mov_b64 vcc, %4\n\t"
+                                     "v_mbcnt_lo_u32_b32 %1, vcc_lo, 0\n\t"
+                                     "v_mbcnt_hi_u32_b32 %1, vcc_hi, %1\n\t"
+                                     "v_lshl_add_u32 %1, %1, 3, %6\n\t"
+                                     "s_and_saveexec_b64 %2, %3\n\t"
+                                     "ds_write2_b32 %0, %7, %8 offset1:1\n\t"
+                                     "s_mov_b64 exec, %2\n\t"
+                                     "s_and_saveexec_b64 %2, %4\n\t"
+                                     "ds_write2_b32 %1, %9, %10 offset1:1\n\t"
+                                     "s_mov_b64 exec, %2"
+                                     : "=&v"(ta), "=&v"(tb), "=&s"(sv)
+                                     : "s"(ma), "s"(mb), "s"(qa), "s"(qb), "v"(alo), "v"(ahi), "v"(blo), "v"(bhi)
+                                     : "vcc", "scc", "memory");
+                        nq += na + nb;
+                    }
+                } else {
+                    const uint32_t pa = (uint32_t)((((uint64_t)ahi << 32) | alo) >> psh), pb = (uint32_t)((((uint64_t)bhi << 32) | blo) >> psh);
+                    const bool ka = widx < cnt_c && (pa & (A - 1u)) == part, kbb = widx + 1u < cnt_c && (pb & (A - 1u)) == part;
+                    const unsigned long long ba = __ballot(ka), bb = __ballot(kbb);
+                    const uint32_t na = (uint32_t)__popcll(ba), nb = (uint32_t)__popcll(bb);
+                    if (nq + na + nb > AP_Q) { if (lane == 0) s_ctl[CTL_FAIL] = 2u; }
+                    else {
+                        if (ka) q[nq + ap_mbcnt(ba)] = ((unsigned long long)ahi << 32) | alo;
+                        if (kbb) q[nq + na + ap_mbcnt(bb)] = ((unsigned long long)bhi << 32) | blo;
+                        nq += na + nb;
+                    }
                 }
                 AP_PROF(1);
                 while (nq >= 64u) { batch(); AP_PROF(2); if (nsq >= 64u) { slow_batch(); AP_PROF(3); } }
