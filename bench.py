@@ -448,7 +448,7 @@ def main():
             buf = (ctypes.c_ulonglong * 16)()
             E._lib.skx_debug_phase_prof(buf, 1)
             tot = sum(buf) or 1
-            sys.stderr.write("phases (share of cycles): %s cycles in all: %d\n" % ([round(x / tot, 3) for x in buf[:10]], tot))
+            sys.stderr.write("phases (share of cycles): %s cycles in all: %d raw: %s\n" % ([round(x / tot, 3) for x in buf[:10]], tot, list(buf)))
         except AttributeError:
             pass
         if world == 1:

@@ -1620,7 +1620,7 @@ static int merge_append(skx_ctx *ctx, skx_dictset *d, const char *const *names, 
         int logP = std::min(bits, std::max(min_logQ, ilog2_ceil((uint64_t)((double)raw_max * 3.0 / target) + 1)));
         for (int attempt = 0;; attempt++) {
             const unsigned blocks = (unsigned)std::min<uint64_t>(64, 1ull << logP);
-            aa.logQ = logP; aa.nslots = APPEND_MAX_SLOTS; aa.cap = APPEND_MAX_CAP;
+            aa.logQ = logP; aa.nslots = APPEND_MAX_SLOTS; aa.cap = APPEND_MAX_CAP; aa.rounds = 1; aa.bar = nullptr;
             if (!append_ok(bits, logB, logP, region_cap, aa.nslots, aa.cap)) return SKF_NOT_TAKEN;
             SKX_TRY(d_flag.zero(st)); SKX_TRY(d_probe.zero(st));
             launch_append_probe(aa, region_cap, blocks, st);
@@ -1648,14 +1648,26 @@ static int merge_append(skx_ctx *ctx, skx_dictset *d, const char *const *names, 
         ks->ctx = ctx; ks->k = d->k; ks->rc = d->rc; ks->logN = logQ; ks->hp = d->hp; ks->wh = d->wh; ks->wide = false; ks->stride = cap;
         std::unique_ptr<skx_pieces> pc(new skx_pieces());
         pc->cap = cap; pc->logQ = logQ;
-        DevBuf<uint16_t> sp, su, sm; DevBuf<unsigned long long> d_cells;
+        DevBuf<uint16_t> sp, su, sm;
         SKX_TRY(ks->stage.alloc(nsub * cap)); SKX_TRY(ks->ncnt.alloc(nsub));
         SKX_TRY(pc->data.alloc(nsub * (uint64_t)S * (cap / 2))); SKX_TRY(pc->plen.alloc(nsub * (uint64_t)S + 2)); SKX_TRY(pc->perm.alloc(nsub * cap)); SKX_TRY(pc->nrank.alloc(nsub));
-        SKX_TRY(sp.alloc(nsub * cap)); SKX_TRY(su.alloc(nsub * cap)); SKX_TRY(sm.alloc(nsub * cap)); SKX_TRY(d_cells.alloc(S));
-        SKX_TRY(d_flag.zero(st)); SKX_TRY(d_cells.zero(st));
+        SKX_TRY(sp.alloc(nsub * cap)); SKX_TRY(su.alloc(nsub * cap)); SKX_TRY(sm.alloc(nsub * cap));
+        SKX_TRY(d_flag.zero(st));
         aa.logQ = logQ; aa.nslots = nslots; aa.cap = cap;
+        // persistent launch: one workgroup per CU, whole groups of a region's readers (8 XCDs x A) -- when the blocks divide that way
+        aa.rounds = 1; aa.bar = nullptr;
+        DevBuf<int> d_bar;
+        {
+            int cus = 0; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+            uint64_t g = nsub;
+            while (g > (uint64_t)std::max(cus, 1) && g % 2 == 0) g /= 2;
+            if (g <= (uint64_t)std::max(cus, 1) && nsub % g == 0 && g % (8 * amp) == 0 && logB >= 3) {
+                aa.rounds = (uint32_t)(nsub / g);
+                SKX_TRY(d_bar.alloc(1ull << logB)); SKX_TRY(d_bar.zero(st)); aa.bar = d_bar.p;
+            }
+        }
         aa.pieces = pc->data.p; aa.plen = pc->plen.p; aa.perm = pc->perm.p; aa.nrank = pc->nrank.p;
-        aa.stage = ks->stage.p; aa.stride = cap; aa.ncnt = ks->ncnt.p; aa.st_present = sp.p; aa.st_unambig = su.p; aa.st_mask = sm.p; aa.sample_cells = d_cells.p;
+        aa.stage = ks->stage.p; aa.stride = cap; aa.ncnt = ks->ncnt.p;
         launch_append(aa, region_cap, st);
         int ov = 0;
         SKX_HIP(hipMemcpyAsync(&ov, d_flag.p, 4, hipMemcpyDeviceToHost, st));
@@ -1672,13 +1684,12 @@ static int merge_append(skx_ctx *ctx, skx_dictset *d, const char *const *names, 
         SKX_TRY(a->present.alloc(U)); SKX_TRY(a->unambig.alloc(U)); SKX_TRY(a->mask.alloc(U)); SKX_TRY(a->keys.alloc(U)); SKX_TRY(a->vcount.alloc(U));
         if (U) {
             launch_gather_keys(ks->stage.p, ks->stride, ks->ncnt.p, ks->roff.p, 1 << logQ, a->keys.p, 0, ks->hp, st);
-            launch_append_stats(sp.p, su.p, sm.p, cap, ks->ncnt.p, ks->roff.p, 1 << logQ, a->present.p, a->unambig.p, a->mask.p, a->vcount.p, st);
+            // the rows' statistics: counted from the pieces by first-seen rank, then carried to the rows
+            launch_pieces_stats(pc->data.p, pc->plen.p, pc->nrank.p, cap, S, 1 << logQ, sp.p, su.p, sm.p, st);
+            launch_append_stats(sp.p, su.p, sm.p, cap, pc->perm.p, pc->nrank.p, ks->ncnt.p, ks->roff.p, 1 << logQ, a->present.p, a->unambig.p, a->mask.p, a->vcount.p, st);
         }
-        std::vector<unsigned long long> cells(S);
-        SKX_HIP(hipMemcpyAsync(cells.data(), d_cells.p, (size_t)S * 8, hipMemcpyDeviceToHost, st));
         SKX_HIP(hipStreamSynchronize(st));
         SKX_HIP(hipGetLastError());
-        pc->sample_cells.assign(cells.begin(), cells.end());
         ks->stage.release();                           // the keys live in the array now; the row blocks keep ncnt / roff
         a->pieces = pc.release(); a->lazy_rows = ks.release();
         *out = a.release();
@@ -1957,7 +1968,19 @@ extern "C" int skx_array_sample_kmers(skx_array *a, int64_t *out)
     skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
     SKX_HIP(hipSetDevice(ctx->device));
     const size_t S = a->names.size();
-    if (a->pieces) { for (size_t i = 0; i < S; i++) out[i] = (int64_t)a->pieces->sample_cells[i]; return SKX_OK; }       // first sightings counted by the append pass
+    if (a->pieces) {                                                  // the cells of the sample's pieces that are not empty (counted when first asked for)
+        skx_pieces *pc = a->pieces;
+        if (pc->sample_cells.size() != S) {
+            DevBuf<unsigned long long> d; SKX_TRY(d.alloc(S)); SKX_TRY(d.zero(st));
+            launch_pieces_cells(pc->data.p, pc->plen.p, pc->cap, (int)S, 1 << pc->logQ, d.p, st);
+            std::vector<unsigned long long> h(S);
+            SKX_HIP(hipMemcpyAsync(h.data(), d.p, S * 8, hipMemcpyDeviceToHost, st));
+            SKX_HIP(hipStreamSynchronize(st));
+            pc->sample_cells.assign(h.begin(), h.end());
+        }
+        for (size_t i = 0; i < S; i++) out[i] = (int64_t)pc->sample_cells[i];
+        return SKX_OK;
+    }
     if (a->lazy()) { for (size_t i = 0; i < S; i++) out[i] = (int64_t)a->lazy_dict->sample_size[i]; return SKX_OK; }      // a sample's cells = its dictionary
     DevBuf<unsigned long long> d; SKX_TRY(d.alloc(S)); SKX_TRY(d.zero(st));
     launch_row_nonmissing(a->matrix.p, a->pitch, (int)S, a->n_rows, d.p, st);

@@ -38,9 +38,9 @@ typedef const u32x4 __attribute__((address_space(1))) *g4_t;
 // 0 waiting for a chunk's words, 1 filter into the queue, 2 look-ups of full batches, 3 the insert loop's batches, 4 end of a sample (drain + piece), 5 the tail (emit)
 #ifdef SKX_AP_PROF
 __device__ unsigned long long g_ap_prof[16];
-#define AP_PROF_START unsigned long long tprof = __builtin_readcyclecounter(), tacc[6] = {0, 0, 0, 0, 0, 0}
+#define AP_PROF_START unsigned long long tprof = __builtin_readcyclecounter(), tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define AP_PROF(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[(i)] += t_ - tprof; tprof = t_; } while (0)
-#define AP_PROF_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 6; i_++) atomicAdd(&g_ap_prof[i_], tacc[i_]); } while (0)
+#define AP_PROF_FLUSH() do { for (int i_ = 0; i_ < 12; i_++) if (tacc[i_] && (i_ >= 6 || (threadIdx.x & 63) == 0)) atomicAdd(&g_ap_prof[i_], tacc[i_]); } while (0)
 extern "C" void skx_debug_phase_prof(unsigned long long *out, int reset)
 {
     unsigned long long h[16];
@@ -54,11 +54,16 @@ extern "C" void skx_debug_phase_prof(unsigned long long *out, int reset)
 #define AP_PROF(i) do { } while (0)
 #define AP_PROF_FLUSH() do { } while (0)
 #endif
+#ifdef SKX_AP_PROF
+#define AP_COUNT(i, v) do { tacc[(i)] += (v); } while (0)
+#else
+#define AP_COUNT(i, v) do { } while (0)
+#endif
 
 constexpr int AP_THREADS = 1024, AP_WAVES = 16;
 constexpr uint32_t AP_PAD = 64;             // slots behind the table's last home slot (probing does not wrap)
-constexpr uint32_t AP_Q = 160;              // entries of a wave's queue of kept words: 63 left over + the ~32 +- 5 of one load (more: a batch goes first); the insert loop's queue holds 128
-constexpr int AP_CH = 4;                    // 16-byte loads per lane and chunk: a wave reads 512 words at a time
+constexpr uint32_t AP_Q = 192, AP_SQ = 128; // a wave's queue of kept words: 127 left over + the ~32 +- 5 of one load; its insert queue (emptied first when a batch's misses would not fit)
+constexpr int AP_CH = 8;                    // 16-byte loads per lane and chunk: a wave reads 1 024 words at a time
 constexpr int AP_RANK_BITS = 14;
 constexpr uint32_t AP_RANK_MASK = (1u << AP_RANK_BITS) - 1;
 
@@ -94,8 +99,8 @@ constexpr int CTL_NROWS = 0, CTL_FAIL = 1, CTL_DIRTY = 2, CTL_TMP = 8, CTL_WORDS
 
 static inline size_t append_lds_bytes(uint32_t nslots, uint32_t cap, bool count_only)
 {
-    size_t b = (size_t)(nslots + AP_PAD) * 8 + (size_t)AP_WAVES * (AP_Q + 128u) * 8 + CTL_WORDS * 4;
-    if (!count_only) b += (size_t)(cap / 2) * 4 + (size_t)(cap / 8) * 4 + (size_t)(cap / 32) * 4 + (size_t)AP_WAVES * (cap / 8) * 4;
+    size_t b = (size_t)(nslots + AP_PAD) * 8 + (size_t)(nslots + AP_PAD) + (size_t)AP_WAVES * (AP_Q + AP_SQ) * 8 + CTL_WORDS * 4;      // (AP_PAD is a multiple of 16)
+    if (!count_only) b += (size_t)AP_WAVES * (cap / 8) * 4;
     return b;
 }
 
@@ -108,34 +113,48 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
     const uint32_t total_slots = a.nslots + AP_PAD;
     const uint32_t cap = a.cap, rbw = cap / 8;                       // ranks per block; dwords of one row buffer
     unsigned long long *s_tab = reinterpret_cast<unsigned long long *>(s_raw);
-    unsigned long long *s_q = s_tab + total_slots;                   // [AP_WAVES][AP_Q kept words + 128 words for the insert loop]
-    uint32_t *s_ctl = reinterpret_cast<uint32_t *>(s_q + (size_t)AP_WAVES * (AP_Q + 128u));
-    uint32_t *s_cnt = s_ctl + CTL_WORDS;                             // [cap / 2] present counts, two ranks per word
-    uint32_t *s_uni = s_cnt + cap / 2;                               // [cap / 8] union of the bases seen, eight ranks per word
-    uint32_t *s_dirty = s_uni + cap / 8;                             // [cap / 32] ranks whose statistics are taken from the finished cells
-    uint32_t *s_rb = s_dirty + cap / 32;                             // [AP_WAVES][rbw] 4-bit base sets by rank, one buffer per wave
+    unsigned char *s_fp = reinterpret_cast<unsigned char *>(s_tab + total_slots);      // [total_slots] a byte of every slot's key (0: empty), what a look-up reads first
+    unsigned long long *s_q = reinterpret_cast<unsigned long long *>(s_fp + total_slots);      // [AP_WAVES][AP_Q kept words + AP_SQ words for the insert loop]
+    uint32_t *s_ctl = reinterpret_cast<uint32_t *>(s_q + (size_t)AP_WAVES * (AP_Q + AP_SQ));
+    uint32_t *s_rb = s_ctl + CTL_WORDS;                              // [AP_WAVES][rbw] 4-bit base sets by rank, one buffer per wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int S = a.n_samples;
     const int shA = a.logQ - a.logB;
     const uint32_t A = 1u << shA;
-    uint32_t region, part;
-    if (a.logB >= 3) { const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3; region = ((slot >> shA) << 3) + xcd; part = slot & (A - 1u); }
-    else { region = blockIdx.x >> shA; part = blockIdx.x & (A - 1u); }
-    const uint64_t j = ((uint64_t)region << shA) + part;             // the block's place in the order of H
+    // The launch is persistent: as many workgroups as the chip holds at once (one per CU), each taking a row block per round.  The A blocks of
+    // a region are taken by A workgroups of the same XCD (blockIdx -> XCD is b % 8) in the same round, and these start a round together (a
+    // counter per region in global memory): all of them read the region's words, sample after sample, and only the first reader of a line
+    // fetches it from HBM if the others come by while it is still in that XCD's L2.  (Launched as one workgroup per block, the four
+    // readers of a region started whenever a CU came free: 103 GB fetched for 40 GB of words, and the kernel ran at the speed of that traffic.)
+    const uint32_t G = gridDim.x;
+    const bool xmap = a.logB >= 3 && G % (8u * A) == 0u;
     const int rem = a.bits - a.logQ;                                 // hash bits below the block bits
     const int psh = rem + 4;                                         // the part bits of a word start here (>= 36 when HI)
     const int lowb = HI ? rem - 32 : 0;                              // hash bits below the 32 that address the table
-    const uint32_t fmask = HI ? (A - 1u) << (psh - 32) : 0u, pshift = HI ? part << (psh - 32) : 0u;      // the part bits in a word's upper half
+    const uint32_t fmask = HI ? (A - 1u) << (psh - 32) : 0u;         // the part bits in a word's upper half
+    uint32_t region = 0, part = 0, pshift = 0;
+    uint64_t j = 0;
+    uint8_t *piece0 = nullptr;
+    unsigned long long *q = s_q + (size_t)wv * (AP_Q + AP_SQ), *sq = q + AP_Q;      // kept words ; words for the insert loop
+    uint32_t *rb = s_rb + (size_t)wv * rbw;
+    for (uint32_t rnd = 0; rnd < a.rounds; rnd++) {
+    if (xmap) {
+        const uint32_t xcd = blockIdx.x & 7u, ls = blockIdx.x >> 3, gpr = (G >> 3) >> shA;      // groups of A workgroups per XCD
+        region = ((rnd * gpr + (ls >> shA)) << 3) + xcd; part = ls & (A - 1u);
+    } else { const uint32_t blk = rnd * G + blockIdx.x; region = blk >> shA; part = blk & (A - 1u); }
+    j = ((uint64_t)region << shA) + part;                            // the block's place in the order of H
+    pshift = HI ? part << (psh - 32) : 0u;
+    piece0 = a.pieces + j * (uint64_t)S * (cap / 2);
 
     for (uint32_t i = tid; i < total_slots; i += AP_THREADS) s_tab[i] = 0ull;
-    if (!COUNT_ONLY) {
-        for (uint32_t i = tid; i < cap / 2; i += AP_THREADS) s_cnt[i] = 0u;
-        for (uint32_t i = tid; i < cap / 8; i += AP_THREADS) s_uni[i] = 0u;
-        for (uint32_t i = tid; i < cap / 32; i += AP_THREADS) s_dirty[i] = 0u;
-        for (uint32_t i = tid; i < AP_WAVES * rbw; i += AP_THREADS) s_rb[i] = 0u;
-    }
+    for (uint32_t i = tid; i < total_slots / 4u; i += AP_THREADS) reinterpret_cast<uint32_t *>(s_fp)[i] = 0u;
+    if (!COUNT_ONLY) for (uint32_t i = tid; i < AP_WAVES * rbw; i += AP_THREADS) s_rb[i] = 0u;
     if (tid < CTL_WORDS) s_ctl[tid] = 0u;
+    if (xmap && A > 1u && a.bar && tid == 0) {                       // the region's readers start together (bounded: late ones are not waited for for ever)
+        atomicAdd(&a.bar[region], 1);
+        for (int it = 0; it < (1 << 18) && __hip_atomic_load(&a.bar[region], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)A; it++) __builtin_amdgcn_s_sleep(8);
+    }
     __syncthreads();
 
     // region offsets and fills are read through the constant address space: scalar loads
@@ -144,10 +163,7 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
     cq_t c_off = (cq_t)(uintptr_t)a.off;
     c1_t c_raw = (c1_t)(uintptr_t)a.raw;
     const uint64_t rstride = 1ull << a.logB;                         // regions per sample
-    unsigned long long *q = s_q + (size_t)wv * (AP_Q + 128u), *sq = q + AP_Q;      // kept words ; words for the insert loop
-    uint32_t *rb = s_rb + (size_t)wv * rbw;
-    uint8_t *piece0 = a.pieces + j * (uint64_t)S * (cap / 2);
-    uint32_t nq = 0, nsq = 0, firsts = 0;                            // wave-uniform: queue fills, first sightings of the current sample
+    uint32_t nq = 0, nsq = 0;                                        // wave-uniform: the fills of the two queues
     AP_PROF_START;
 
     // a word's key as the table holds it: hi = the top 32 of its low hash bits (= what the home slot is computed from), lo = the rest << 14
@@ -156,27 +172,18 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
         return rem == 0 ? 0u : (uint32_t)(((wlo >> 4) | (whi << 28)) << (32 - rem));
     };
     auto key_lo = [&](uint32_t wlo) -> uint32_t { return HI ? __builtin_amdgcn_ubfe(wlo, 4u, (uint32_t)lowb) << AP_RANK_BITS : 0u; };
-    // the cell of (current sample, rank1 - 1) takes base set m4; first sightings are counted
-    auto record = [&](uint32_t rank1, uint32_t m4) -> bool {
-        const uint32_t rank = rank1 - 1u, sh = (rank & 7u) * 4u, di = rank >> 3, val = m4 << sh;
-        const uint32_t old = atomicOr(&rb[di], val);
-        const uint32_t on = __builtin_amdgcn_ubfe(old, sh, 4u);
-        if (on == 0u) {
-            atomicOr(&s_uni[di], val);
-            atomicAdd(&s_cnt[rank >> 1], 1u << (16u * (rank & 1u)));
-            if (m4 & (m4 - 1u)) { atomicOr(&s_dirty[rank >> 5], 1u << (rank & 31u)); s_ctl[CTL_DIRTY] = 1u; }      // a palindrome's two bases: an ambiguous cell
-            return true;
-        }
-        if ((on | m4) != on) {                                         // the sample has this split k-mer again with another middle base (ska_dict.rs:92-101)
-            atomicOr(&s_dirty[rank >> 5], 1u << (rank & 31u)); s_ctl[CTL_DIRTY] = 1u;
-        }
-        return false;
+    auto key_fp = [&](uint32_t kh, uint32_t kl) -> uint32_t { const uint32_t v = ((kh ^ (kl >> AP_RANK_BITS)) * 0x9E3779B1u) >> 24; return v ? v : 255u; };      // 1..255
+    // the cell of (current sample, rank1 - 1) takes base set m4: one LDS atomic without a return value -- what the cells add up to per row (present,
+    // unambiguous, code set) is counted from the finished pieces by pieces_stats_kernel, 4 bits per cell and no atomics, instead of here
+    auto record = [&](uint32_t rank1, uint32_t m4) {
+        const uint32_t rank = rank1 - 1u;
+        atomicOr(&rb[rank >> 3], m4 << ((rank & 7u) * 4u));
     };
-    // up to 64 queued words against their home slot and its successor; what is not there goes to the insert queue
+    // up to 64 words of the insert queue: the full probe sequence, new keys inserted
     auto slow_batch = [&]() {
         const uint32_t take = nsq < 64u ? nsq : 64u;
         nsq -= take;
-        bool first = false;
+        if (lane == 0) { AP_COUNT(8, 1); AP_COUNT(9, take); }
         if ((uint32_t)lane < take) {
             const unsigned long long w = sq[nsq + lane];
             const uint32_t wlo = (uint32_t)w, whi = (uint32_t)(w >> 32);
@@ -186,57 +193,106 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
             // sixteen related samples: a rank taken before the CAS would be wasted fifteen times).  The key goes in with the rank field all ones;
             // who finds it so waits for the rank (bounded).  Two statements, in this order: the lanes that won write their ranks before any lane
             // of the same wave waits for one.
+            // four slots per step of the probe sequence (at 5 500 rows in 8 192 slots a few keys in a hundred sit eight slots and more from home,
+            // the unluckiest of 64 some thirty: one slot per step made this loop two thirds of the kernel's time)
             uint32_t rank1 = 0;
-            for (uint32_t t = __umulhi(kh, a.nslots); t < total_slots; t++) {
-                unsigned long long e = s_tab[t];
+            for (uint32_t t = __umulhi(kh, a.nslots); t + 3u < total_slots;) {
+                AP_COUNT(10, 1); if (ap_mbcnt(__ballot(true)) == 0u) AP_COUNT(11, 1);
+                const unsigned long long e0 = s_tab[t], e1 = s_tab[t + 1], e2 = s_tab[t + 2], e3 = s_tab[t + 3];
+                const bool m0 = (e0 ^ keyE) <= AP_RANK_MASK, m1 = (e1 ^ keyE) <= AP_RANK_MASK, m2 = (e2 ^ keyE) <= AP_RANK_MASK, m3 = (e3 ^ keyE) <= AP_RANK_MASK;
                 bool won = false;
-                if (e == 0ull) { e = atomicCAS(&s_tab[t], 0ull, keyE | AP_RANK_MASK); won = e == 0ull; }
+                uint32_t at = 0;
+                if (!(m0 | m1 | m2 | m3)) {
+                    // not in these four: into the first empty one, if there is one (a lost race for it: the same four again)
+                    at = e0 == 0ull ? 0u : e1 == 0ull ? 1u : e2 == 0ull ? 2u : e3 == 0ull ? 3u : 4u;
+                    if (at < 4u) won = atomicCAS(&s_tab[t + at], 0ull, keyE | AP_RANK_MASK) == 0ull;
+                }
                 if (won) {
                     const uint32_t mine = atomicAdd(&s_ctl[CTL_NROWS], 1u) + 1u;
                     if (mine > (COUNT_ONLY ? AP_RANK_MASK - 1u : cap)) s_ctl[CTL_FAIL] = 1u;
-                    reinterpret_cast<volatile uint32_t *>(&s_tab[t])[0] = kl | (mine < AP_RANK_MASK ? mine : AP_RANK_MASK - 1u);
+                    reinterpret_cast<volatile uint32_t *>(&s_tab[t + at])[0] = kl | (mine < AP_RANK_MASK ? mine : AP_RANK_MASK - 1u);
+                    s_fp[t + at] = (unsigned char)key_fp(kh, kl);
                     rank1 = mine;
                 }
                 __builtin_amdgcn_wave_barrier();
-                if (!won && (e ^ keyE) <= AP_RANK_MASK) {
-                    uint32_t r = (uint32_t)e & AP_RANK_MASK;
-                    for (int it = 0; it < (1 << 16) && r == AP_RANK_MASK; it++) r = reinterpret_cast<volatile uint32_t *>(&s_tab[t])[0] & AP_RANK_MASK;
+                if (m0 | m1 | m2 | m3) {
+                    const uint32_t mt = t + (m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u);
+                    uint32_t r = (uint32_t)(m0 ? e0 : m1 ? e1 : m2 ? e2 : e3) & AP_RANK_MASK;
+                    for (int it = 0; it < (1 << 16) && r == AP_RANK_MASK; it++) r = reinterpret_cast<volatile uint32_t *>(&s_tab[mt])[0] & AP_RANK_MASK;
                     if (r == AP_RANK_MASK) { s_ctl[CTL_FAIL] = 1u; r = 0; }
                     rank1 = r;
                     break;
                 }
                 if (won) break;
+                if (at == 4u) t += 4u;
             }
             if (rank1 > cap && !COUNT_ONLY) rank1 = 0;
             if (rank1 == 0) s_ctl[CTL_FAIL] = 1u;
-            else if (!COUNT_ONLY) first = record(rank1, wlo & 15u);
+            else if (!COUNT_ONLY) record(rank1, wlo & 15u);
         }
-        if (!COUNT_ONLY) firsts += (uint32_t)__popcll(__ballot(first));
     };
+    // up to 128 queued words, two per lane, against their home slots and the slots behind them: the two look-ups are independent, so every
+    // LDS round trip of the chain queue -> table -> row buffer serves two words (the kernel waits for these round trips, it does not compute:
+    // VALU 47 % busy with one word per lane).  What is not found there goes to the insert queue.
     auto batch = [&]() {
-        const uint32_t take = nq < 64u ? nq : 64u;
+        const uint32_t take = nq < 128u ? nq : 128u;
         nq -= take;
-        bool miss = false, first = false;
-        unsigned long long w = 0;
-        if ((uint32_t)lane < take) {
-            w = q[nq + lane];
-            const uint32_t wlo = (uint32_t)w, whi = (uint32_t)(w >> 32);
-            const uint32_t kh = key_hi(wlo, whi), kl = key_lo(wlo);
-            const uint32_t hs = __umulhi(kh, a.nslots);
-            const unsigned long long e0 = s_tab[hs], e1 = s_tab[hs + 1];
-            const uint32_t e0l = (uint32_t)e0, e1l = (uint32_t)e1;
-            // (both slots are read at once and compared without short cuts: one LDS round trip per batch)
-            const bool m0 = ((uint32_t)(e0 >> 32) == kh) & ((e0l ^ kl) <= AP_RANK_MASK);
-            const bool m1 = (e0l != 0u) & ((uint32_t)(e1 >> 32) == kh) & ((e1l ^ kl) <= AP_RANK_MASK);
-            const uint32_t rank1 = (m0 ? e0l : m1 ? e1l : 0u) & AP_RANK_MASK;
-            if (rank1 == 0 || rank1 == AP_RANK_MASK) miss = true;          // not there, further from home -- or there, its rank still being written
-            else if (!COUNT_ONLY) first = record(rank1, wlo & 15u);
+        if (lane == 0) { AP_COUNT(6, 1); AP_COUNT(7, take); }
+        const bool va = (uint32_t)lane < take, vb = (uint32_t)lane + 64u < take;
+        unsigned long long wa = 0, wb = 0;
+        if (va) wa = q[nq + lane];
+        if (vb) wb = q[nq + 64u + lane];
+        const uint32_t alo = (uint32_t)wa, ahi = (uint32_t)(wa >> 32), blo = (uint32_t)wb, bhi = (uint32_t)(wb >> 32);
+        const uint32_t kha = key_hi(alo, ahi), kla = key_lo(alo), khb = key_hi(blo, bhi), klb = key_lo(blo);
+        const uint32_t hsa = __umulhi(kha, a.nslots), hsb = __umulhi(khb, a.nslots);      // (an idle lane probes the slot of key 0: harmless)
+        // Two small reads instead of a scan of the slots: the bytes of the eight slots around home (one byte of every key, 0 = empty) say where
+        // the key may be, then that one entry is read and compared in full.  The look-ups are bound by what they read from LDS at random
+        // places (reading the entries of 2 x 8 slots per word: 33 ms; 2 x 4: 29 ms); a key lies up to seven slots behind its home for all but
+        // two words in a hundred (5 500 rows in 8 192 slots), and those -- with the one in 128 whose byte matches a wrong key first -- take the
+        // insert loop.
+        auto where = [&](uint32_t hs, uint32_t fp) -> uint32_t {          // the first slot from home on whose byte is fp (0xFFFFFFFF: none among those read)
+            const uint32_t base = hs & ~3u;
+            const uint32_t *f = reinterpret_cast<const uint32_t *>(s_fp + base);
+            const uint32_t x0 = f[0] ^ (fp * 0x01010101u), x1 = f[1] ^ (fp * 0x01010101u);
+            uint32_t z0 = ~(((x0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x0 | 0x7F7F7F7Fu), z1 = ~(((x1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x1 | 0x7F7F7F7Fu);
+            z0 &= 0xFFFFFFFFu << (8u * (hs & 3u));                       // (not in front of home)
+            const unsigned long long z = ((unsigned long long)z1 << 32) | z0;
+            return z ? base + (((uint32_t)__ffsll((long long)z) - 1u) >> 3) : 0xFFFFFFFFu;
+        };
+        const uint32_t sa = where(hsa, key_fp(kha, kla)), sb = where(hsb, key_fp(khb, klb));
+        const unsigned long long ea = s_tab[sa != 0xFFFFFFFFu ? sa : hsa], eb = s_tab[sb != 0xFFFFFFFFu ? sb : hsb];
+        auto hit = [&](unsigned long long e, uint32_t kh, uint32_t kl) -> uint32_t {
+            return (((uint32_t)(e >> 32) == kh) & (((uint32_t)e ^ kl) <= AP_RANK_MASK)) ? (uint32_t)e & AP_RANK_MASK : 0u;
+        };
+        const uint32_t ra = sa != 0xFFFFFFFFu ? hit(ea, kha, kla) : 0u, rbk = sb != 0xFFFFFFFFu ? hit(eb, khb, klb) : 0u;
+#if defined(AP_X_FAKE4)
+        const uint32_t ra_ = (ra & 0u) | (hsa % cap + 1u), rb_ = (rbk & 0u) | (hsb % cap + 1u);
+        const bool hita = va, hitb = vb;
+#define ra ra_
+#define rbk rb_
+#elif defined(AP_X_NOPROBE)
+        const uint32_t ra_ = hsa % cap + 1u, rb_ = hsb % cap + 1u;
+        const bool hita = va, hitb = vb;
+#define ra ra_
+#define rbk rb_
+#else
+        const bool hita = va & (ra != 0u) & (ra != AP_RANK_MASK), hitb = vb & (rbk != 0u) & (rbk != AP_RANK_MASK);
+#endif
+#if !defined(AP_X_NORECORD)
+        if (!COUNT_ONLY) {
+            if (hita) record(ra, alo & 15u);
+            if (hitb) record(rbk, blo & 15u);
         }
-        if (!COUNT_ONLY) firsts += (uint32_t)__popcll(__ballot(first));
-        const unsigned long long mb = __ballot(miss);
-        if (mb) {
-            if (miss) sq[nsq + ap_mbcnt(mb)] = w;
-            nsq += (uint32_t)__popcll(mb);
+#endif
+#undef ra
+#undef rbk
+        const unsigned long long xa = __ballot(va & !hita), xb = __ballot(vb & !hitb);
+        if (xa | xb) {
+            const uint32_t na = (uint32_t)__popcll(xa);
+            while (nsq + na + (uint32_t)__popcll(xb) > AP_SQ) slow_batch();
+            if (va & !hita) sq[nsq + ap_mbcnt(xa)] = wa;
+            if (vb & !hitb) sq[nsq + na + ap_mbcnt(xb)] = wb;
+            nsq += na + (uint32_t)__popcll(xb);
         }
     };
 
@@ -292,7 +348,11 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
             for (int r = 0; r < AP_CH; r++) {
                 const uint32_t alo = cur[r].x, ahi = cur[r].y, blo = cur[r].z, bhi = cur[r].w;
                 const uint32_t widx = w0 + 128u * r;
+#if defined(AP_X_NOFILTER)
+                if (false) {
+#else
                 if (HI) {
+#endif
                     // which of the two words are this block's (part bits in the upper half, the region's fill), as lane masks; then the kept
                     // words side by side into the queue.  Written out: the compiler's version of the same spends three times the instructions
                     // on turning conditions into lane masks and back (twelve vector instructions here per 128 words).
@@ -335,7 +395,11 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
                                      : "vcc", "scc", "memory");
                         nq += na + nb;
                     }
+#if defined(AP_X_NOFILTER)
+                } else if (alo == 0x12345u && bhi == 0x54321u) {
+#else
                 } else {
+#endif
                     const uint32_t pa = (uint32_t)((((uint64_t)ahi << 32) | alo) >> psh), pb = (uint32_t)((((uint64_t)bhi << 32) | blo) >> psh);
                     const bool ka = widx < cnt_c && (pa & (A - 1u)) == part, kbb = widx + 1u < cnt_c && (pb & (A - 1u)) == part;
                     const unsigned long long ba = __ballot(ka), bb = __ballot(kbb);
@@ -348,10 +412,20 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
                     }
                 }
                 AP_PROF(1);
-                while (nq >= 64u) { batch(); AP_PROF(2); if (nsq >= 64u) { slow_batch(); AP_PROF(3); } }
+#if defined(AP_X_NOBATCH)
+                if (nq >= 128u) nq -= 128u;
+#else
+                while (nq >= 128u) { batch(); AP_PROF(2);
+#if defined(AP_X_NOSLOW)
+                    if (nsq >= 64u) nsq -= 64u;
+#else
+                    while (nsq >= 64u) { slow_batch(); AP_PROF(3); }
+#endif
+                }
+#endif
             }
             if (last_chunk) {
-                while (nq) { batch(); AP_PROF(2); if (nsq >= 64u) { slow_batch(); AP_PROF(3); } }
+                while (nq) { batch(); AP_PROF(2); while (nsq >= 64u) { slow_batch(); AP_PROF(3); } }
                 while (nsq) { slow_batch(); AP_PROF(3); }
             }
             AP_PROF(1);
@@ -367,11 +441,7 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
                         *reinterpret_cast<uint4 *>(dst + v * 16u) = x;
                         *src = make_uint4(0u, 0u, 0u, 0u);
                     }
-                    if (lane == 0) {
-                        a.plen[j * (uint64_t)S + s] = (uint16_t)n;
-                        if (firsts) atomicAdd(&a.sample_cells[s], (unsigned long long)firsts);
-                    }
-                    firsts = 0;
+                    if (lane == 0) a.plen[j * (uint64_t)S + s] = (uint16_t)n;
                 }
                 AP_PROF(4);
                 if (!more) break;
@@ -382,54 +452,16 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
     AP_PROF_FLUSH();
     __syncthreads();
     const uint32_t nr = s_ctl[CTL_NROWS];                             // ranks handed out (a few may belong to no row: a lost insertion race)
-    if (s_ctl[CTL_FAIL]) { if (tid == 0) atomicOr(a.overflow, (int)s_ctl[CTL_FAIL]); return; }
+    if (s_ctl[CTL_FAIL]) { if (tid == 0) atomicOr(a.overflow, (int)s_ctl[CTL_FAIL]); __syncthreads(); continue; }
     uint32_t *s_tmp = s_ctl + CTL_TMP;
     if (COUNT_ONLY) {
         uint32_t c = 0;
         for (uint32_t i = tid; i < total_slots; i += AP_THREADS) c += s_tab[i] != 0ull;
         uint32_t tot; (void)ap_block_excl(c, s_tmp, &tot);
         if (tid == 0) { atomicAdd(&a.probe[0], (unsigned long long)tot); atomicMax(&a.probe[1], (unsigned long long)tot); }
-        return;
+        continue;
     }
-    // statistics by rank: present count, unambiguous count, code set.  Clean rows hold single bases only: every present cell is unambiguous and
-    // the code set follows from the union of the bases; dirty rows are counted from the finished cells of all samples.
-    uint32_t *s_un = s_rb;                                            // [cap] unambiguous | code set << 16, over the row buffers (done as well)
-    __syncthreads();
-    for (uint32_t r = tid; r < cap; r += AP_THREADS) {
-        const uint32_t p = (s_cnt[r >> 1] >> (16u * (r & 1u))) & 0xFFFFu;
-        const uint32_t u = (s_uni[r >> 3] >> ((r & 7u) * 4u)) & 15u;
-        const uint32_t m16 = ((u & 1u) << 1) | ((u & 2u) << 1) | ((u & 4u) << 2) | ((u & 8u) << 5);
-        s_un[r] = p | (m16 << 16);
-    }
-    __syncthreads();
-    if (s_ctl[CTL_DIRTY]) {
-        __threadfence();
-        __syncthreads();
-        uint32_t seen = 0;
-        for (uint32_t i = 0; i < cap / 32; i++) {
-            uint32_t bits = s_dirty[i];
-            while (bits) {
-                const uint32_t r = i * 32u + (uint32_t)__ffs(bits) - 1u; bits &= bits - 1u;
-                if ((int)(seen++ & 15u) != wv) continue;              // dirty rows are dealt to the sixteen waves in turn
-                uint32_t m = 0, pc = 0, uc = 0;
-                for (int s = lane; s < S; s += 64) {
-                    const uint64_t pi = j * (uint64_t)S + s;
-                    const uint32_t pw2 = __hip_atomic_load(reinterpret_cast<const uint32_t *>(a.plen) + (pi >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const uint32_t pl = (pw2 >> (16u * (uint32_t)(pi & 1u))) & 0xFFFFu;
-                    if (pl <= r) continue;
-                    const uint32_t *pw = reinterpret_cast<const uint32_t *>(piece0 + (uint64_t)s * (cap / 2)) + (r >> 3);
-                    const uint32_t x = __hip_atomic_load(pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const uint32_t nib = (x >> ((r & 7u) * 4u)) & 15u;
-                    if (nib) { m |= 1u << nib; pc++; uc += (nib & (nib - 1u)) == 0u; }
-                }
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) { m |= __shfl_xor(m, d, 64); pc += __shfl_xor(pc, d, 64); uc += __shfl_xor(uc, d, 64); }
-                if (lane == 0) { s_un[r] = uc | (m << 16); const uint32_t sh16 = 16u * (r & 1u); atomicAnd(&s_cnt[r >> 1], ~(0xFFFFu << sh16)); atomicOr(&s_cnt[r >> 1], pc << sh16); }
-            }
-        }
-        __syncthreads();
-    }
-    // emit in key order: row keys, rank -> row, statistics
+    // emit in key order: row keys, rank -> row
     uint16_t *s_perm = reinterpret_cast<uint16_t *>(s_q);            // [cap] (the queues are done)
     for (uint32_t i = tid; i < cap; i += AP_THREADS) s_perm[i] = 0xFFFFu;
     __syncthreads();
@@ -440,7 +472,6 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
     uint32_t total;
     uint32_t pos = ap_block_excl(c, s_tmp, &total);
     uint64_t *slab = a.stage + j * (uint64_t)a.stride;
-    uint16_t *o_p = a.st_present + j * (uint64_t)a.stride, *o_u = a.st_unambig + j * (uint64_t)a.stride, *o_m = a.st_mask + j * (uint64_t)a.stride;
     for (uint32_t i = lo; i < hi; i++) {
         const unsigned long long e = s_tab[i];
         if (!e) continue;
@@ -456,16 +487,14 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
             else hl = rem == 0 ? 0ull : (uint64_t)((uint32_t)(e >> 32) >> (32 - rem));
             slab[idx] = ((((uint64_t)j << rem) | hl) << 4) | 1ull;
             s_perm[rank] = (uint16_t)idx;
-            const uint32_t un = s_un[rank];
-            o_p[idx] = (uint16_t)((s_cnt[rank >> 1] >> (16u * (rank & 1u))) & 0xFFFFu);
-            o_u[idx] = (uint16_t)(un & 0xFFFFu);
-            o_m[idx] = (uint16_t)(un >> 16);
         }
     }
     __syncthreads();
     uint16_t *pj = a.perm + j * (uint64_t)cap;
     for (uint32_t i = tid; i < cap; i += AP_THREADS) pj[i] = s_perm[i];
     if (tid == 0) { a.ncnt[j] = total; a.nrank[j] = nr < cap ? nr : cap; if (total > a.stride) atomicOr(a.overflow, 1); }
+    __syncthreads();
+    }   // rounds
 }
 
 template <bool COUNT_ONLY>
@@ -490,25 +519,148 @@ bool append_ok(int bits, int logB, int logQ, uint32_t region_cap, uint32_t nslot
     return logQ >= logB && rem >= 0 && rem <= 50 && cap % 128u == 0 && cap >= 128u && cap <= APPEND_MAX_CAP && nslots >= cap &&
            append_lds_bytes(nslots, cap, false) <= 160u * 1024u - 256u;
 }
-void launch_append(const AppendArgs &a, uint32_t region_cap, hipStream_t st) { (void)region_cap; launch_append_t<false>(a, 1u << a.logQ, st); }
+void launch_append(const AppendArgs &a, uint32_t region_cap, hipStream_t st) { (void)region_cap; launch_append_t<false>(a, (1u << a.logQ) / a.rounds, st); }
 void launch_append_probe(const AppendArgs &a, uint32_t region_cap, unsigned blocks, hipStream_t st) { (void)region_cap; launch_append_t<true>(a, blocks, st); }
 
-// the statistics of the row blocks (16-bit, one slab per block) as the array holds them: one 32-bit value per row, rows in the order of H
-__global__ __launch_bounds__(256) void append_stats_kernel(const uint16_t *sp, const uint16_t *su, const uint16_t *sm, uint32_t stride, const uint32_t *ncnt,
-                                                           const uint64_t *roff, uint32_t *present, uint32_t *unambig, uint32_t *mask, uint32_t *vcount)
+// ------------------------------------------------------------------------------------------------
+// Row statistics from the finished pieces: per first-seen rank of a row block the number of samples with a cell (present), with an
+// unambiguous one, and the set of IUPAC codes that occur (merge_ska_array.rs:139-186 counts the same from the rows).  A thread owns one
+// dword column of the block's pieces -- eight ranks, 4 bits each -- and walks the samples: nibble-parallel counters (a byte per rank, folded
+// into 16 bits every 255 samples), no atomics, the pieces read once, coalesced.  Cells are single bases almost everywhere: the code set of such
+// a row follows from the OR of its cells; rows with an ambiguous cell (a palindrome's W / S, a sample that folded two bases) are listed and
+// their code sets taken cell by cell.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pieces_stats_kernel(const uint8_t *pieces, const uint16_t *plen, const uint32_t *nrank, uint32_t cap, int S,
+                                                           uint16_t *o_present, uint16_t *o_unambig, uint16_t *o_mask)
 {
+    __shared__ uint32_t s_list[2048 + 1];
+    __shared__ uint32_t s_nlist;
     const uint64_t j = blockIdx.x;
-    const uint32_t n = ncnt[j];
-    const uint64_t r0 = roff[j], b = j * (uint64_t)stride;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint32_t p = sp[b + i];
-        present[r0 + i] = p; unambig[r0 + i] = su[b + i]; mask[r0 + i] = sm[b + i]; vcount[r0 + i] = p;      // (variant_count: merge_ska_array.rs:172)
+    const uint32_t nr = nrank[j];
+    const uint32_t d = blockIdx.y * 256u + threadIdx.x;              // dword column: ranks 8 d .. 8 d + 7
+    if (blockIdx.y * 256u * 8u >= nr) return;
+    if (threadIdx.x == 0) s_nlist = 0;
+    __syncthreads();
+    typedef const uint16_t __attribute__((address_space(4))) *c16_t;
+    c16_t pl = (c16_t)(uintptr_t)(plen + j * (uint64_t)S);
+    const uint32_t *col = reinterpret_cast<const uint32_t *>(pieces + j * (uint64_t)S * (cap / 2)) + d;
+    const uint32_t step = cap / 8;                                    // dwords from one sample's piece to the next
+    const bool mine = d * 8u < nr;
+    uint32_t pE = 0, pO = 0, aE = 0, aO = 0, uni = 0;                 // byte counters: present / ambiguous cells of the even and odd ranks; OR of the cells
+    uint32_t PE0 = 0, PE1 = 0, PO0 = 0, PO1 = 0, AE0 = 0, AE1 = 0, AO0 = 0, AO1 = 0;      // the same, 16 bits per rank
+    auto fold = [&]() {
+        PE0 += pE & 0x00FF00FFu; PE1 += (pE >> 8) & 0x00FF00FFu; PO0 += pO & 0x00FF00FFu; PO1 += (pO >> 8) & 0x00FF00FFu;
+        AE0 += aE & 0x00FF00FFu; AE1 += (aE >> 8) & 0x00FF00FFu; AO0 += aO & 0x00FF00FFu; AO1 += (aO >> 8) & 0x00FF00FFu;
+        pE = pO = aE = aO = 0;
+    };
+    auto take = [&](uint32_t x) {
+        uint32_t t = x | (x >> 1); t |= t >> 2;
+        const uint32_t nz = t & 0x11111111u;                          // one bit per nibble that is not 0
+        const uint32_t y = x & (x - nz);                              // every nibble without its lowest bit
+        uint32_t u = y | (y >> 1); u |= u >> 2;
+        const uint32_t am = u & 0x11111111u;                          // one bit per nibble with two bases or more
+        pE += nz & 0x01010101u; pO += (nz >> 4) & 0x01010101u;
+        aE += am & 0x01010101u; aO += (am >> 4) & 0x01010101u;
+        uni |= x;
+    };
+    int s = 0;
+    for (int s0 = 0; s0 < S; s0 += 252) {                             // 252 samples, four at a time, then the byte counters are folded
+        const int s1 = s0 + 252 < S ? s0 + 252 : S;
+        for (s = s0; s + 4 <= s1; s += 4) {
+            const uint32_t l0 = pl[s], l1 = pl[s + 1], l2 = pl[s + 2], l3 = pl[s + 3];
+            uint32_t x0 = 0, x1 = 0, x2 = 0, x3 = 0;
+            if (mine) {
+                if (d * 8u < l0) x0 = col[(uint64_t)s * step];
+                if (d * 8u < l1) x1 = col[(uint64_t)(s + 1) * step];
+                if (d * 8u < l2) x2 = col[(uint64_t)(s + 2) * step];
+                if (d * 8u < l3) x3 = col[(uint64_t)(s + 3) * step];
+            }
+            take(x0); take(x1); take(x2); take(x3);
+        }
+        for (; s < s1; s++) { uint32_t x = 0; if (mine && d * 8u < pl[s]) x = col[(uint64_t)s * step]; take(x); }
+        fold();
+    }
+    uint32_t pres[8], amb[8];
+    pres[0] = PE0 & 0xFFFFu; pres[4] = PE0 >> 16; pres[2] = PE1 & 0xFFFFu; pres[6] = PE1 >> 16;
+    pres[1] = PO0 & 0xFFFFu; pres[5] = PO0 >> 16; pres[3] = PO1 & 0xFFFFu; pres[7] = PO1 >> 16;
+    amb[0] = AE0 & 0xFFFFu; amb[4] = AE0 >> 16; amb[2] = AE1 & 0xFFFFu; amb[6] = AE1 >> 16;
+    amb[1] = AO0 & 0xFFFFu; amb[5] = AO0 >> 16; amb[3] = AO1 & 0xFFFFu; amb[7] = AO1 >> 16;
+    if (mine) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t r = d * 8u + i;
+            if (r >= nr) break;
+            const uint32_t u = (uni >> (4 * i)) & 15u;
+            o_present[j * (uint64_t)cap + r] = (uint16_t)pres[i];
+            o_unambig[j * (uint64_t)cap + r] = (uint16_t)(pres[i] - amb[i]);
+            o_mask[j * (uint64_t)cap + r] = (uint16_t)(((u & 1u) << 1) | ((u & 2u) << 1) | ((u & 4u) << 2) | ((u & 8u) << 5));
+            if (amb[i]) { const uint32_t at = atomicAdd(&s_nlist, 1u); if (at < 2048u) s_list[at] = r; }
+        }
+    }
+    __syncthreads();
+    const uint32_t nl = s_nlist < 2048u ? s_nlist : 2048u;           // (256 x 8 ranks at most)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (uint32_t i = wv; i < nl; i += 4) {
+        const uint32_t r = s_list[i];
+        uint32_t m = 0;
+        for (int t = lane; t < S; t += 64) {
+            if ((uint32_t)pl[t] <= r) continue;
+            const uint32_t x = *(reinterpret_cast<const uint32_t *>(pieces + (j * (uint64_t)S + t) * (cap / 2)) + (r >> 3));
+            const uint32_t nib = (x >> ((r & 7u) * 4u)) & 15u;
+            if (nib) m |= 1u << nib;
+        }
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) m |= __shfl_xor(m, dd, 64);
+        if (lane == 0) o_mask[j * (uint64_t)cap + r] = (uint16_t)m;
     }
 }
-void launch_append_stats(const uint16_t *sp, const uint16_t *su, const uint16_t *sm, uint32_t stride, const uint32_t *ncnt, const uint64_t *roff, int n_blocks,
-                         uint32_t *present, uint32_t *unambig, uint32_t *mask, uint32_t *vcount, hipStream_t st)
+void launch_pieces_stats(const uint8_t *pieces, const uint16_t *plen, const uint32_t *nrank, uint32_t cap, int n_samples, int n_blocks,
+                         uint16_t *o_present, uint16_t *o_unambig, uint16_t *o_mask, hipStream_t st)
 {
-    if (n_blocks > 0) hipLaunchKernelGGL(append_stats_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, sp, su, sm, stride, ncnt, roff, present, unambig, mask, vcount);
+    if (n_blocks <= 0) return;
+    const unsigned gy = (cap / 8 + 255u) / 256u;
+    hipLaunchKernelGGL(pieces_stats_kernel, dim3((unsigned)n_blocks, gy), dim3(256), 0, st, pieces, plen, nrank, cap, n_samples, o_present, o_unambig, o_mask);
+}
+// the statistics by rank as the array holds them: one 32-bit value per row, rows in the order of H (perm: rank -> row of the block)
+__global__ __launch_bounds__(256) void append_stats_kernel(const uint16_t *sp, const uint16_t *su, const uint16_t *sm, uint32_t cap, const uint16_t *perm,
+                                                           const uint32_t *nrank, const uint32_t *ncnt, const uint64_t *roff, uint32_t *present, uint32_t *unambig,
+                                                           uint32_t *mask, uint32_t *vcount)
+{
+    const uint64_t j = blockIdx.x;
+    const uint32_t n = ncnt[j], nr = nrank[j];
+    const uint64_t r0 = roff[j], b = j * (uint64_t)cap;
+    for (uint32_t r = threadIdx.x; r < nr; r += blockDim.x) {
+        const uint32_t p = perm[b + r];
+        if (p >= n) continue;                                         // (0xFFFF: a rank without a row)
+        const uint32_t pv = sp[b + r];
+        present[r0 + p] = pv; unambig[r0 + p] = su[b + r]; mask[r0 + p] = sm[b + r]; vcount[r0 + p] = pv;      // (variant_count: merge_ska_array.rs:172)
+    }
+}
+void launch_append_stats(const uint16_t *sp, const uint16_t *su, const uint16_t *sm, uint32_t cap, const uint16_t *perm, const uint32_t *nrank, const uint32_t *ncnt,
+                         const uint64_t *roff, int n_blocks, uint32_t *present, uint32_t *unambig, uint32_t *mask, uint32_t *vcount, hipStream_t st)
+{
+    if (n_blocks > 0) hipLaunchKernelGGL(append_stats_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, sp, su, sm, cap, perm, nrank, ncnt, roff, present, unambig, mask, vcount);
+}
+// split k-mers per sample (SkaDict::ksize): the cells of its pieces that are not empty; a wave per piece
+__global__ __launch_bounds__(256) void pieces_cells_kernel(const uint8_t *pieces, const uint16_t *plen, uint32_t cap, int S, unsigned long long *out)
+{
+    const uint64_t j = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    for (int s = blockIdx.y * 4 + (threadIdx.x >> 6); s < S; s += gridDim.y * 4) {
+        const uint32_t pl = plen[j * (uint64_t)S + s];
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(pieces + (j * (uint64_t)S + s) * (cap / 2));
+        uint32_t c = 0;
+        for (uint32_t i = lane; i < (pl + 7u) / 8u; i += 64) { const uint32_t x = src[i]; uint32_t t = x | (x >> 1); t |= t >> 2; c += (uint32_t)__popc(t & 0x11111111u); }
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) c += __shfl_xor(c, dd, 64);
+        if (lane == 0 && c) atomicAdd(&out[s], (unsigned long long)c);
+    }
+}
+void launch_pieces_cells(const uint8_t *pieces, const uint16_t *plen, uint32_t cap, int n_samples, int n_blocks, unsigned long long *out, hipStream_t st)
+{
+    if (n_blocks <= 0 || n_samples <= 0) return;
+    unsigned gy = (unsigned)((n_samples + 3) / 4); if (gy > 16) gy = 16;
+    hipLaunchKernelGGL(pieces_cells_kernel, dim3((unsigned)n_blocks, gy), dim3(256), 0, st, pieces, plen, cap, n_samples, out);
 }
 // windows per sample (the sum of its regions' fills): a sample without any has no valid sequence
 __global__ __launch_bounds__(256) void region_totals_kernel(const uint32_t *raw, int logB, unsigned long long *out)

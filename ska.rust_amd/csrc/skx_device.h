@@ -158,23 +158,27 @@ void launch_union_side_wide(const DictView &d, int logN, u128 *stage, uint32_t s
 // A *row block* j holds the rows whose top logQ hash bits are j (logQ >= logB); its workgroup appends the samples in order and leaves, per
 // sample, a *piece*: the sample's cells of the block as 4-bit base sets indexed by first-seen rank, plen[j * S + s] of them, at
 // pieces + (j * S + s) * (cap / 2).  perm[j * cap + rank] = row of the block (key order) or 0xFFFF; nrank[j] = ranks handed out.
-constexpr uint32_t APPEND_MAX_CAP = 6016, APPEND_MAX_SLOTS = 7600;    // what sixteen row buffers, the queues and the table leave of 160 KB
+constexpr uint32_t APPEND_MAX_CAP = 6016, APPEND_MAX_SLOTS = 8192;    // what sixteen row buffers, the queues and the table leave of 160 KB
 struct AppendArgs {
     const uint64_t *words; const uint64_t *off; const uint32_t *raw;      // regions as extract_kernel left them (off in words, raw = fill)
     int n_samples, logB, bits, logQ;
     uint32_t nslots, cap;                                                // table slots; ranks a block may hand out (multiple of 32)
     uint8_t *pieces; uint16_t *plen; uint16_t *perm; uint32_t *nrank;
     uint64_t *stage; uint32_t stride; uint32_t *ncnt;                    // row keys of block j: sorted slab at stage + j * stride
-    uint16_t *st_present, *st_unambig, *st_mask;                         // row statistics, laid out like the slabs
-    unsigned long long *sample_cells;                                    // [S] distinct split k-mers per sample (SkaDict::ksize), added up over the blocks
     unsigned long long *probe;                                           // count-only launches: [0] += rows, [1] = max rows of a block
     int *overflow;                                                       // |= 1 table / ranks / slab full, |= 2 queue full
+    uint32_t rounds = 1;                                                 // row blocks per workgroup: the launch has (1 << logQ) / rounds workgroups (launch_append)
+    int *bar = nullptr;                                                  // [1 << logB] zeroed: where the readers of a region meet before a round
 };
 bool append_ok(int bits, int logB, int logQ, uint32_t region_cap, uint32_t nslots, uint32_t cap);
 void launch_append(const AppendArgs &a, uint32_t region_cap, hipStream_t st);
 void launch_append_probe(const AppendArgs &a, uint32_t region_cap, unsigned blocks, hipStream_t st);     // the first `blocks` row blocks, rows counted only
-void launch_append_stats(const uint16_t *sp, const uint16_t *su, const uint16_t *sm, uint32_t stride, const uint32_t *ncnt, const uint64_t *roff, int n_blocks,
-                         uint32_t *present, uint32_t *unambig, uint32_t *mask, uint32_t *vcount, hipStream_t st);
+// row statistics from the pieces, by first-seen rank ([j * cap + rank], 16 bits each), and the same as the array holds them (rows in the order of H)
+void launch_pieces_stats(const uint8_t *pieces, const uint16_t *plen, const uint32_t *nrank, uint32_t cap, int n_samples, int n_blocks,
+                         uint16_t *o_present, uint16_t *o_unambig, uint16_t *o_mask, hipStream_t st);
+void launch_append_stats(const uint16_t *sp, const uint16_t *su, const uint16_t *sm, uint32_t cap, const uint16_t *perm, const uint32_t *nrank, const uint32_t *ncnt,
+                         const uint64_t *roff, int n_blocks, uint32_t *present, uint32_t *unambig, uint32_t *mask, uint32_t *vcount, hipStream_t st);
+void launch_pieces_cells(const uint8_t *pieces, const uint16_t *plen, uint32_t cap, int n_samples, int n_blocks, unsigned long long *out, hipStream_t st);
 void launch_region_totals(const uint32_t *raw, int n_samples, int logB, unsigned long long *out, hipStream_t st);
 struct PiecesRowsArgs {
     const uint8_t *pieces; const uint16_t *plen; const uint16_t *perm; const uint32_t *nrank; uint32_t cap; int n_samples;
