@@ -1648,10 +1648,8 @@ static int merge_append(skx_ctx *ctx, skx_dictset *d, const char *const *names, 
         ks->ctx = ctx; ks->k = d->k; ks->rc = d->rc; ks->logN = logQ; ks->hp = d->hp; ks->wh = d->wh; ks->wide = false; ks->stride = cap;
         std::unique_ptr<skx_pieces> pc(new skx_pieces());
         pc->cap = cap; pc->logQ = logQ;
-        DevBuf<uint16_t> sp, su, sm;
         SKX_TRY(ks->stage.alloc(nsub * cap)); SKX_TRY(ks->ncnt.alloc(nsub));
         SKX_TRY(pc->data.alloc(nsub * (uint64_t)S * (cap / 2))); SKX_TRY(pc->plen.alloc(nsub * (uint64_t)S + 2)); SKX_TRY(pc->perm.alloc(nsub * cap)); SKX_TRY(pc->nrank.alloc(nsub));
-        SKX_TRY(sp.alloc(nsub * cap)); SKX_TRY(su.alloc(nsub * cap)); SKX_TRY(sm.alloc(nsub * cap));
         SKX_TRY(d_flag.zero(st));
         aa.logQ = logQ; aa.nslots = nslots; aa.cap = cap;
         // persistent launch: one workgroup per CU, whole groups of a region's readers (8 XCDs x A) -- when the blocks divide that way
@@ -1684,9 +1682,8 @@ static int merge_append(skx_ctx *ctx, skx_dictset *d, const char *const *names, 
         SKX_TRY(a->present.alloc(U)); SKX_TRY(a->unambig.alloc(U)); SKX_TRY(a->mask.alloc(U)); SKX_TRY(a->keys.alloc(U)); SKX_TRY(a->vcount.alloc(U));
         if (U) {
             launch_gather_keys(ks->stage.p, ks->stride, ks->ncnt.p, ks->roff.p, 1 << logQ, a->keys.p, 0, ks->hp, st);
-            // the rows' statistics: counted from the pieces by first-seen rank, then carried to the rows
-            launch_pieces_stats(pc->data.p, pc->plen.p, pc->nrank.p, cap, S, 1 << logQ, sp.p, su.p, sm.p, st);
-            launch_append_stats(sp.p, su.p, sm.p, cap, pc->perm.p, pc->nrank.p, ks->ncnt.p, ks->roff.p, 1 << logQ, a->present.p, a->unambig.p, a->mask.p, a->vcount.p, st);
+            // the rows' statistics, counted from the pieces
+            launch_pieces_stats(pc->data.p, pc->plen.p, pc->perm.p, pc->nrank.p, ks->ncnt.p, ks->roff.p, cap, S, 1 << logQ, a->present.p, a->unambig.p, a->mask.p, a->vcount.p, st);
         }
         SKX_HIP(hipStreamSynchronize(st));
         SKX_HIP(hipGetLastError());

@@ -94,8 +94,8 @@ __device__ static inline uint32_t ap_mbcnt(unsigned long long b)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
 }
 
-// ctl words: 0 ranks handed out, 1 failure, 2 a row is dirty, 8..24 scan scratch
-constexpr int CTL_NROWS = 0, CTL_FAIL = 1, CTL_DIRTY = 2, CTL_TMP = 8, CTL_WORDS = 32;
+// ctl words: 0 ranks handed out, 1 failure, 8..24 scan scratch
+constexpr int CTL_NROWS = 0, CTL_FAIL = 1, CTL_TMP = 8, CTL_WORDS = 32;
 
 static inline size_t append_lds_bytes(uint32_t nslots, uint32_t cap, bool count_only)
 {
@@ -528,21 +528,23 @@ void launch_append_probe(const AppendArgs &a, uint32_t region_cap, unsigned bloc
 // dword column of the block's pieces -- eight ranks, 4 bits each -- and walks the samples: nibble-parallel counters (a byte per rank, folded
 // into 16 bits every 255 samples), no atomics, the pieces read once, coalesced.  Cells are single bases almost everywhere: the code set of such
 // a row follows from the OR of its cells; rows with an ambiguous cell (a palindrome's W / S, a sample that folded two bases) are listed and
-// their code sets taken cell by cell.
+// their code sets taken cell by cell.  The results go straight to the rows (perm: rank -> row of the block).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pieces_stats_kernel(const uint8_t *pieces, const uint16_t *plen, const uint32_t *nrank, uint32_t cap, int S,
-                                                           uint16_t *o_present, uint16_t *o_unambig, uint16_t *o_mask)
+__global__ __launch_bounds__(256) void pieces_stats_kernel(const uint8_t *pieces, const uint16_t *plen, const uint16_t *perm, const uint32_t *nrank, const uint32_t *ncnt,
+                                                           const uint64_t *roff, uint32_t cap, int S, uint32_t *o_present, uint32_t *o_unambig, uint32_t *o_mask,
+                                                           uint32_t *o_vcount)
 {
     __shared__ uint32_t s_list[2048 + 1];
     __shared__ uint32_t s_nlist;
     const uint64_t j = blockIdx.x;
-    const uint32_t nr = nrank[j];
+    const uint32_t nr = nrank[j], nrows = ncnt[j];
+    const uint64_t r0 = roff[j];
     const uint32_t d = blockIdx.y * 256u + threadIdx.x;              // dword column: ranks 8 d .. 8 d + 7
     if (blockIdx.y * 256u * 8u >= nr) return;
     if (threadIdx.x == 0) s_nlist = 0;
     __syncthreads();
-    typedef const uint16_t __attribute__((address_space(4))) *c16_t;
-    c16_t pl = (c16_t)(uintptr_t)(plen + j * (uint64_t)S);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint16_t *pl = plen + j * (uint64_t)S;
     const uint32_t *col = reinterpret_cast<const uint32_t *>(pieces + j * (uint64_t)S * (cap / 2)) + d;
     const uint32_t step = cap / 8;                                    // dwords from one sample's piece to the next
     const bool mine = d * 8u < nr;
@@ -563,43 +565,49 @@ __global__ __launch_bounds__(256) void pieces_stats_kernel(const uint8_t *pieces
         aE += am & 0x01010101u; aO += (am >> 4) & 0x01010101u;
         uni |= x;
     };
-    int s = 0;
-    for (int s0 = 0; s0 < S; s0 += 252) {                             // 252 samples, four at a time, then the byte counters are folded
-        const int s1 = s0 + 252 < S ? s0 + 252 : S;
-        for (s = s0; s + 4 <= s1; s += 4) {
-            const uint32_t l0 = pl[s], l1 = pl[s + 1], l2 = pl[s + 2], l3 = pl[s + 3];
-            uint32_t x0 = 0, x1 = 0, x2 = 0, x3 = 0;
-            if (mine) {
-                if (d * 8u < l0) x0 = col[(uint64_t)s * step];
-                if (d * 8u < l1) x1 = col[(uint64_t)(s + 1) * step];
-                if (d * 8u < l2) x2 = col[(uint64_t)(s + 2) * step];
-                if (d * 8u < l3) x3 = col[(uint64_t)(s + 3) * step];
+    // 64 samples at a time: their piece lengths arrive as one vector load (a lane each) and are handed round with v_readlane; eight loads in
+    // flight per lane; the byte counters are folded every 192 samples
+    for (int s0 = 0, since = 0; s0 < S; s0 += 64) {
+        const uint32_t plv = s0 + lane < S ? (uint32_t)pl[s0 + lane] : 0u;
+        const int n = S - s0 < 64 ? S - s0 : 64;
+#pragma unroll 1
+        for (int i0 = 0; i0 < n; i0 += 8) {
+            uint32_t x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)plv, (i0 + u) & 63);      // (past n: length 0)
+                x[u] = 0;
+                if (mine && i0 + u < n && d * 8u < l) x[u] = col[(uint64_t)(s0 + i0 + u) * step];
             }
-            take(x0); take(x1); take(x2); take(x3);
+#pragma unroll
+            for (int u = 0; u < 8; u++) take(x[u]);
         }
-        for (; s < s1; s++) { uint32_t x = 0; if (mine && d * 8u < pl[s]) x = col[(uint64_t)s * step]; take(x); }
-        fold();
+        since += 64;
+        if (since >= 192) { fold(); since = 0; }
     }
+    fold();
     uint32_t pres[8], amb[8];
     pres[0] = PE0 & 0xFFFFu; pres[4] = PE0 >> 16; pres[2] = PE1 & 0xFFFFu; pres[6] = PE1 >> 16;
     pres[1] = PO0 & 0xFFFFu; pres[5] = PO0 >> 16; pres[3] = PO1 & 0xFFFFu; pres[7] = PO1 >> 16;
     amb[0] = AE0 & 0xFFFFu; amb[4] = AE0 >> 16; amb[2] = AE1 & 0xFFFFu; amb[6] = AE1 >> 16;
     amb[1] = AO0 & 0xFFFFu; amb[5] = AO0 >> 16; amb[3] = AO1 & 0xFFFFu; amb[7] = AO1 >> 16;
+    const uint16_t *pj = perm + j * (uint64_t)cap;
     if (mine) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const uint32_t r = d * 8u + i;
             if (r >= nr) break;
+            const uint32_t p = pj[r];                                 // the rank's row of the block (0xFFFF: none)
+            if (p >= nrows) continue;
             const uint32_t u = (uni >> (4 * i)) & 15u;
-            o_present[j * (uint64_t)cap + r] = (uint16_t)pres[i];
-            o_unambig[j * (uint64_t)cap + r] = (uint16_t)(pres[i] - amb[i]);
-            o_mask[j * (uint64_t)cap + r] = (uint16_t)(((u & 1u) << 1) | ((u & 2u) << 1) | ((u & 4u) << 2) | ((u & 8u) << 5));
+            o_present[r0 + p] = pres[i]; o_vcount[r0 + p] = pres[i];      // (variant_count: merge_ska_array.rs:172)
+            o_unambig[r0 + p] = pres[i] - amb[i];
+            o_mask[r0 + p] = ((u & 1u) << 1) | ((u & 2u) << 1) | ((u & 4u) << 2) | ((u & 8u) << 5);
             if (amb[i]) { const uint32_t at = atomicAdd(&s_nlist, 1u); if (at < 2048u) s_list[at] = r; }
         }
     }
     __syncthreads();
     const uint32_t nl = s_nlist < 2048u ? s_nlist : 2048u;           // (256 x 8 ranks at most)
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (uint32_t i = wv; i < nl; i += 4) {
         const uint32_t r = s_list[i];
         uint32_t m = 0;
@@ -611,35 +619,15 @@ __global__ __launch_bounds__(256) void pieces_stats_kernel(const uint8_t *pieces
         }
 #pragma unroll
         for (int dd = 32; dd >= 1; dd >>= 1) m |= __shfl_xor(m, dd, 64);
-        if (lane == 0) o_mask[j * (uint64_t)cap + r] = (uint16_t)m;
+        if (lane == 0) o_mask[r0 + pj[r]] = m;
     }
 }
-void launch_pieces_stats(const uint8_t *pieces, const uint16_t *plen, const uint32_t *nrank, uint32_t cap, int n_samples, int n_blocks,
-                         uint16_t *o_present, uint16_t *o_unambig, uint16_t *o_mask, hipStream_t st)
+void launch_pieces_stats(const uint8_t *pieces, const uint16_t *plen, const uint16_t *perm, const uint32_t *nrank, const uint32_t *ncnt, const uint64_t *roff, uint32_t cap,
+                         int n_samples, int n_blocks, uint32_t *present, uint32_t *unambig, uint32_t *mask, uint32_t *vcount, hipStream_t st)
 {
     if (n_blocks <= 0) return;
     const unsigned gy = (cap / 8 + 255u) / 256u;
-    hipLaunchKernelGGL(pieces_stats_kernel, dim3((unsigned)n_blocks, gy), dim3(256), 0, st, pieces, plen, nrank, cap, n_samples, o_present, o_unambig, o_mask);
-}
-// the statistics by rank as the array holds them: one 32-bit value per row, rows in the order of H (perm: rank -> row of the block)
-__global__ __launch_bounds__(256) void append_stats_kernel(const uint16_t *sp, const uint16_t *su, const uint16_t *sm, uint32_t cap, const uint16_t *perm,
-                                                           const uint32_t *nrank, const uint32_t *ncnt, const uint64_t *roff, uint32_t *present, uint32_t *unambig,
-                                                           uint32_t *mask, uint32_t *vcount)
-{
-    const uint64_t j = blockIdx.x;
-    const uint32_t n = ncnt[j], nr = nrank[j];
-    const uint64_t r0 = roff[j], b = j * (uint64_t)cap;
-    for (uint32_t r = threadIdx.x; r < nr; r += blockDim.x) {
-        const uint32_t p = perm[b + r];
-        if (p >= n) continue;                                         // (0xFFFF: a rank without a row)
-        const uint32_t pv = sp[b + r];
-        present[r0 + p] = pv; unambig[r0 + p] = su[b + r]; mask[r0 + p] = sm[b + r]; vcount[r0 + p] = pv;      // (variant_count: merge_ska_array.rs:172)
-    }
-}
-void launch_append_stats(const uint16_t *sp, const uint16_t *su, const uint16_t *sm, uint32_t cap, const uint16_t *perm, const uint32_t *nrank, const uint32_t *ncnt,
-                         const uint64_t *roff, int n_blocks, uint32_t *present, uint32_t *unambig, uint32_t *mask, uint32_t *vcount, hipStream_t st)
-{
-    if (n_blocks > 0) hipLaunchKernelGGL(append_stats_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, sp, su, sm, cap, perm, nrank, ncnt, roff, present, unambig, mask, vcount);
+    hipLaunchKernelGGL(pieces_stats_kernel, dim3((unsigned)n_blocks, gy), dim3(256), 0, st, pieces, plen, perm, nrank, ncnt, roff, cap, n_samples, present, unambig, mask, vcount);
 }
 // split k-mers per sample (SkaDict::ksize): the cells of its pieces that are not empty; a wave per piece
 __global__ __launch_bounds__(256) void pieces_cells_kernel(const uint8_t *pieces, const uint16_t *plen, uint32_t cap, int S, unsigned long long *out)
@@ -686,20 +674,25 @@ void launch_region_totals(const uint32_t *raw, int n_samples, int logB, unsigned
 // row of the block]) -- then every wave takes samples in turn: the sample's piece into LDS, one dword of four cells per lane from there
 // (IUPAC letter of the 4-bit base set; '-' where the rank lies beyond the piece), stored at its own alignment so that a wave writes whole lines.
 // ------------------------------------------------------------------------------------------------
-__device__ static inline uint32_t ap_iupac(uint32_t m4)
-{
-    const uint64_t lo = 0x485957544D43412Dull;      // "-ACMTWYH"
-    const uint64_t hi = 0x4E42444B56535247ull;      // "GRSVKDBN"
-    return (uint32_t)(((m4 & 8u) ? hi : lo) >> (8u * (m4 & 7u))) & 0xFFu;
-}
 constexpr int PR_WAVES = 8;
+// 4 base sets (a byte each) -> their IUPAC letters: two byte permutes over "-ACMTWYH" / "GRSVKDBN" and a select on bit 3
+__device__ static inline uint32_t ap_iupac4(uint32_t m)
+{
+    const uint32_t idx = m & 0x07070707u;
+    const uint32_t lo = __builtin_amdgcn_perm(0x48595754u, 0x4D43412Du, idx);      // bytes 0-3 from "-ACM", 4-7 from "TWYH"
+    const uint32_t hi = __builtin_amdgcn_perm(0x4E42444Bu, 0x56535247u, idx);      // "GRSV", "KDBN"
+    const uint32_t sel = ((m >> 3) & 0x01010101u) * 0xFFu;
+    return (hi & sel) | (lo & ~sel);
+}
 template <bool KEPT>
 __global__ __launch_bounds__(64 * PR_WAVES) void pieces_rows_kernel(PiecesRowsArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const uint32_t cap = a.cap;
-    uint16_t *s_src = reinterpret_cast<uint16_t *>(s_raw);                    // [cap + 8] output column -> rank (0xFFFF: none)
-    uint32_t *s_piece = reinterpret_cast<uint32_t *>(s_raw + (((size_t)cap + 8) * 2 + 15) / 16 * 16);      // [PR_WAVES][cap / 8]
+    // [cap + 16] which rank an output byte takes its cell from, laid out like the aligned dwords the block's cells are stored in (so that a
+    // lane reads the four ranks of its dword at once); `cap` = none: that "rank" lies in a word of the piece buffer that is always 0
+    uint16_t *s_src = reinterpret_cast<uint16_t *>(s_raw);
+    uint32_t *s_piece = reinterpret_cast<uint32_t *>(s_raw + (((size_t)cap + 16) * 2 + 15) / 16 * 16);      // [PR_WAVES][cap / 8 + 4]
     const uint64_t j = (uint64_t)blockIdx.x + a.j_base;
     const uint32_t n = a.ncnt[j];
     if (n == 0) return;
@@ -708,43 +701,44 @@ __global__ __launch_bounds__(64 * PR_WAVES) void pieces_rows_kernel(PiecesRowsAr
     const uint32_t nout = KEPT ? (uint32_t)(a.kpos[r0 + n] - k0) : n;
     if (nout == 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (uint32_t i = tid; i < cap + 8; i += blockDim.x) s_src[i] = 0xFFFFu;
+    const uint64_t ocol = KEPT ? k0 : r0 - a.col_base;                        // first output column of the block
+    const uint32_t shift = (uint32_t)(ocol & 3u);
+    const uint32_t ndw = (nout + shift + 3u) / 4u;                            // aligned dwords that hold the block's cells
+    for (uint32_t i = tid; i < cap + 16u; i += blockDim.x) s_src[i] = (uint16_t)cap;
     __syncthreads();
     const uint16_t *pj = a.perm + j * (uint64_t)cap;
     const uint32_t nr = a.nrank[j];
     for (uint32_t r = tid; r < nr; r += blockDim.x) {
         const uint32_t p = pj[r];
         if (p == 0xFFFFu || p >= n) continue;
-        if (!KEPT) s_src[p] = (uint16_t)r;
-        else if (a.keep[r0 + p] == 1) s_src[(uint32_t)(a.kpos[r0 + p] - k0)] = (uint16_t)r;
+        if (!KEPT) s_src[shift + p] = (uint16_t)r;
+        else if (a.keep[r0 + p] == 1) s_src[shift + (uint32_t)(a.kpos[r0 + p] - k0)] = (uint16_t)r;
     }
     __syncthreads();
-    const uint64_t ocol = KEPT ? k0 : r0 - a.col_base;                        // first output column of the block
-    const uint32_t shift = (uint32_t)(ocol & 3u);
-    const uint32_t ndw = (nout + shift + 3u) / 4u;                            // aligned dwords that hold the block's cells
     const int S = a.n_samples;
     const int s_lo = blockIdx.y * a.samples_per_wg, s_hi = s_lo + a.samples_per_wg < S ? s_lo + a.samples_per_wg : S;
-    uint32_t *pc = s_piece + (size_t)wv * (cap / 8);
+    uint32_t *pc = s_piece + (size_t)wv * (cap / 8 + 4);
     const unsigned char *pcb = reinterpret_cast<const unsigned char *>(pc);
+    const uint32_t nrw = (nr + 7u) / 8u;                                      // piece words that ranks of this block can name
+    if (lane < 4) pc[cap / 8 + lane] = 0u;                                    // (rank `cap`: no cell)
     for (int s = s_lo + wv; s < s_hi; s += PR_WAVES) {
         const uint32_t pl = a.plen[j * (uint64_t)S + s];
+        const uint32_t plw = (pl + 7u) / 8u;
         const uint32_t *src = reinterpret_cast<const uint32_t *>(a.pieces + (j * (uint64_t)S + s) * (cap / 2));
-        for (uint32_t i = lane; i < (pl + 7u) / 8u; i += 64) pc[i] = src[i];
+        for (uint32_t i = lane; i < nrw; i += 64) pc[i] = i < plw ? src[i] : 0u;      // ranks handed out after this sample: no cell
         __builtin_amdgcn_wave_barrier();
         unsigned char *dst = a.out + (uint64_t)s * a.pitch + (ocol - shift);
         for (uint32_t v = lane; v < ndw; v += 64) {
-            uint32_t word = 0;
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int c = (int)(4u * v + b) - (int)shift;                  // column of the block
-                uint32_t ch = 0;
-                if (c >= 0 && (uint32_t)c < nout) {
-                    const uint32_t r = s_src[c];
-                    uint32_t m4 = 0;
-                    if (r < pl) m4 = ((uint32_t)pcb[r >> 1] >> ((r & 1u) * 4u)) & 15u;
-                    ch = (a.mask_ambig && (m4 & (m4 - 1u))) ? (uint32_t)'N' : ap_iupac(m4);
-                }
-                word |= ch << (8 * b);
+            const uint2 rr = *reinterpret_cast<const uint2 *>(s_src + 4u * v);      // four ranks
+            const uint32_t ra = rr.x & 0xFFFFu, rb = rr.x >> 16, rc = rr.y & 0xFFFFu, rd = rr.y >> 16;
+            const uint32_t na = ((uint32_t)pcb[ra >> 1] >> ((ra & 1u) * 4u)) & 15u, nb = ((uint32_t)pcb[rb >> 1] >> ((rb & 1u) * 4u)) & 15u;
+            const uint32_t nc = ((uint32_t)pcb[rc >> 1] >> ((rc & 1u) * 4u)) & 15u, nd = ((uint32_t)pcb[rd >> 1] >> ((rd & 1u) * 4u)) & 15u;
+            uint32_t m = na | (nb << 8) | (nc << 16) | (nd << 24);
+            uint32_t word = ap_iupac4(m);
+            if (a.mask_ambig) {                                                 // cells of two bases and more are written as 'N'
+                const uint32_t y = m & (m - ((m | (m >> 1) | (m >> 2) | (m >> 3)) & 0x01010101u));      // every byte without its lowest bit
+                const uint32_t amb = ((y | (y >> 1) | (y >> 2) | (y >> 3)) & 0x01010101u) * 0xFFu;
+                word = (word & ~amb) | (0x4E4E4E4Eu & amb);
             }
             const bool head = v == 0 && shift != 0, tail = v == ndw - 1 && ((nout + shift) & 3u) != 0;
             if (!head && !tail) *reinterpret_cast<uint32_t *>(dst + 4u * v) = word;
@@ -765,7 +759,7 @@ void launch_pieces_rows(const PiecesRowsArgs &a, uint32_t n_blocks, hipStream_t 
     while (spw > PR_WAVES * 4 && (uint64_t)n_blocks * ((a.n_samples + spw - 1) / spw) < 8192) spw = (spw + 1) / 2;
     b.samples_per_wg = spw;
     const unsigned gy = (unsigned)((a.n_samples + spw - 1) / spw);
-    const size_t lds = (((size_t)a.cap + 8) * 2 + 15) / 16 * 16 + (size_t)PR_WAVES * (a.cap / 8) * 4;
+    const size_t lds = (((size_t)a.cap + 16) * 2 + 15) / 16 * 16 + (size_t)PR_WAVES * (a.cap / 8 + 4) * 4;
     if (a.keep) {
         (void)hipFuncSetAttribute((const void *)pieces_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(pieces_rows_kernel<true>, dim3(n_blocks, gy), dim3(64 * PR_WAVES), lds, st, b);

@@ -173,11 +173,9 @@ struct AppendArgs {
 bool append_ok(int bits, int logB, int logQ, uint32_t region_cap, uint32_t nslots, uint32_t cap);
 void launch_append(const AppendArgs &a, uint32_t region_cap, hipStream_t st);
 void launch_append_probe(const AppendArgs &a, uint32_t region_cap, unsigned blocks, hipStream_t st);     // the first `blocks` row blocks, rows counted only
-// row statistics from the pieces, by first-seen rank ([j * cap + rank], 16 bits each), and the same as the array holds them (rows in the order of H)
-void launch_pieces_stats(const uint8_t *pieces, const uint16_t *plen, const uint32_t *nrank, uint32_t cap, int n_samples, int n_blocks,
-                         uint16_t *o_present, uint16_t *o_unambig, uint16_t *o_mask, hipStream_t st);
-void launch_append_stats(const uint16_t *sp, const uint16_t *su, const uint16_t *sm, uint32_t cap, const uint16_t *perm, const uint32_t *nrank, const uint32_t *ncnt,
-                         const uint64_t *roff, int n_blocks, uint32_t *present, uint32_t *unambig, uint32_t *mask, uint32_t *vcount, hipStream_t st);
+// row statistics from the pieces (present, unambiguous, code set, variant_count), written to the rows in the order of H
+void launch_pieces_stats(const uint8_t *pieces, const uint16_t *plen, const uint16_t *perm, const uint32_t *nrank, const uint32_t *ncnt, const uint64_t *roff, uint32_t cap,
+                         int n_samples, int n_blocks, uint32_t *present, uint32_t *unambig, uint32_t *mask, uint32_t *vcount, hipStream_t st);
 void launch_pieces_cells(const uint8_t *pieces, const uint16_t *plen, uint32_t cap, int n_samples, int n_blocks, unsigned long long *out, hipStream_t st);
 void launch_region_totals(const uint32_t *raw, int n_samples, int logB, unsigned long long *out, hipStream_t st);
 struct PiecesRowsArgs {
