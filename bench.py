@@ -74,13 +74,21 @@ def private_snps(n_total):
 
 def other_kernels(tm, steps, n_bases, n_distinct, rows, rows_kept, n_samples, key_bytes=8):
     """HBM rate of the remaining stages against SURVEY.md 8d's algorithmic bytes (W + 1 = 9 B per dictionary entry -- 17 B for
-    k > 31 --, P ~ N windows, D = sum of distinct split k-mers per sample, U rows, U' rows kept)."""
+    k > 31 --, P ~ N windows, D = sum of distinct split k-mers per sample, U rows, U' rows kept).  For 64-bit keys the per-sample
+    dictionaries are no stage of their own any more: MergeSkaDict::append (append_kernel) reads the regions as the extraction kernel
+    scattered them, so SURVEY's "per-sample dedup" and "merge" rows are one stage here and are priced together."""
     out = []
     w1 = key_bytes + 1.0
-    for name, ms, nbytes in (
-            ("per-sample dedup (dedupe_mb_kernel)", tm["dedupe"] / steps, w1 * (n_bases + n_distinct)),
-            ("merge (union_kernel<SIDE> + assemble_side_kernel: the dictionaries read once)", (tm["key_union"] + tm["assemble"]) / steps, w1 * n_distinct + rows * (float(key_bytes) + n_samples)),
-            ("filter + compaction", (tm["filter"] + tm["compact"]) / steps, rows * (float(key_bytes) + n_samples) + rows_kept * float(n_samples))):
+    dict_ms, merge_ms = tm["dedupe"] / steps, (tm["key_union"] + tm["assemble"]) / steps
+    dict_b, merge_b = w1 * (n_bases + n_distinct), w1 * n_distinct + rows * (float(key_bytes) + n_samples)
+    if dict_ms > 0:
+        stages = [("per-sample dedup (dedupe kernel)", dict_ms, dict_b), ("merge (union + assemble kernels)", merge_ms, merge_b)]
+    else:
+        stages = [("dictionaries + merge as one pass (append probe + append_kernel + pieces_stats_kernel: regions read unsorted, cells kept as 4-bit pieces)",
+                   merge_ms, dict_b + merge_b)]
+    stages.append(("filter + compaction (row verdicts + pieces_rows_kernel: kept rows only)" if dict_ms == 0 else "filter + compaction",
+                   (tm["filter"] + tm["compact"]) / steps, rows * (float(key_bytes) + n_samples) + rows_kept * float(n_samples)))
+    for name, ms, nbytes in stages:
         gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         out.append({"stage": name, "ms": ms, "algorithmic_bytes": nbytes, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
     return out
@@ -228,10 +236,25 @@ def end_to_end(args, files, td):
     return res
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks (torch.distributed.run, one per GPU, 127.0.0.1) and hand on
+    their exit code -- a plain call must never run one rank and print n_gpus: 1."""
+    port = int(os.environ.get("MASTER_PORT", "29533"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus and os.environ.get("SKX_BENCH_FORCE_SHARDED") != "1":
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): refusing to report a line for the wrong number of GPUs")
     local_rank = int(os.environ.get("SKX_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))   # override: ranks sharing one GPU in tests
     if not os.path.exists("/dev/kfd"):
         raise SystemExit("bench.py needs a gfx950 GPU: the engine has no CPU path")
@@ -369,6 +392,21 @@ def main():
 
     n_distinct = None
     distance_stage = None
+    unfiltered = None
+    if rank == 0 and world == 1:       # the unfiltered rows x samples matrix (what a .skf holds), produced from the merge's pieces: outside `value`
+        ds = E.DictSet.build_device(ptrs, lens, args.k, True, ctx=ctx)
+        arr_u = ds.merge(names)
+        ctx.sync()
+        ctx.timings(reset=True)
+        t_u0 = time.perf_counter()
+        arr_u.device_matrix()
+        ctx.sync()
+        unfiltered = {"rows": int(arr_u.nrows), "samples": G, "matrix_bytes": float(arr_u.nrows) * G, "wall_ms": (time.perf_counter() - t_u0) * 1e3,
+                      "kernel_ms": ctx.timings()["assemble"],
+                      "what": "MergeSkaArray's full matrix (1 byte per cell, rows in the order of H) written from the 4-bit pieces the merge leaves "
+                              "(pieces_rows_kernel<all rows>); `ska build` streams it window by window into the .skf, `ska align` never writes it"}
+        arr_u.free()
+        ds.free()
     if rank == 0:                      # sum of the per-sample dictionary sizes (untimed): the D of SURVEY.md 8d's per-stage bytes
         ds = E.DictSet.build_device(ptrs, lens, args.k, True, ctx=ctx)
         n_distinct = int(sum(ds.size(i) for i in range(G)))
@@ -433,6 +471,8 @@ def main():
         }
         if distance_stage:
             res["distance"] = distance_stage
+        if unfiltered:
+            res["unfiltered_form"] = unfiltered
         if sharded:
             ph = E.phases()
             res["exchange_per_step_rank0"] = {"transport": "rccl" if backend == "nccl" else "local (host-staged: ranks sharing a device)",

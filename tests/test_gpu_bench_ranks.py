@@ -39,3 +39,24 @@ def test_bench_sharded_path_on_rccl_at_world_one():
     plain = _bench(["--gpus", "1"])
     assert forced["exchange_per_step_rank0"]["transport"] == "rccl"
     assert forced["config"]["rows_U"] == plain["config"]["rows_U"] and forced["config"]["rows_kept"] == plain["config"]["rows_kept"]
+
+
+def test_bench_gpus_without_a_launcher_starts_its_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE around it must start two ranks itself (never one rank printing n_gpus: 1)"""
+    env = {"SKX_BENCH_BACKEND": "gloo", "SKX_BENCH_DEVICE": "0", "MASTER_PORT": str(29650 + os.getpid() % 200)}
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--genomes", "16", "--genome-len", "200000", "--steps", "1", "--warmup", "1",
+           "--cpu-genomes", "0", "--no-e2e"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(base, **env))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([x for x in r.stdout.strip().splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """a launcher that started one rank for --gpus 2 gets a non-zero exit, not a line"""
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--genomes", "8", "--genome-len", "100000", "--steps", "1", "--warmup", "0",
+           "--cpu-genomes", "0", "--no-e2e"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300, env=dict(base, WORLD_SIZE="1", RANK="0"))
+    assert r.returncode != 0 and "refusing" in r.stderr
