@@ -534,6 +534,7 @@ extern "C" int skx_array_distance_sharded(skx_comm *c, skx_array *a, int filt_am
     return skx_guarded([&]() -> int {
     SKX_TRY(check_dev(c));
     if (!a || a->ctx != c->ctx) { set_error("bad arguments"); return SKX_EINVAL; }
+    if (c->world > 255) { set_error("more than 255 ranks: the per-row agreement of the sharded distance sums one byte per row over the ranks"); return SKX_EUNSUP; }
     skx_ctx *ctx = c->ctx; hipStream_t st = ctx->stream;
     SKX_HIP(hipSetDevice(ctx->device));
     // --allow-ambiguous: the rows without an ambiguous cell in ANY rank's samples (the ranks agree on them through one all-reduce of a byte

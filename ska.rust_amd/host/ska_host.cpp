@@ -473,8 +473,18 @@ int sharded_array(skx_ctx *ctx, skx_comm *comm, const skh_job *job, uint64_t *lo
         if (job->file2) for (uint64_t i = lo; i < hi; i++) f2[i - lo] = job->file2[i];
         r = skx_dictset_build_files(ctx, job->file1 + lo, f2.data(), (int)(hi - lo), job->k, job->rc, &job->qual, job->threads, job->proportion_reads, &ds);
     }
-    // a rank that failed still takes part in the exchange of sizes (with an empty table would be wrong): stop everybody the same way
-    if (r != SKX_OK) return r;
+    // a rank whose build failed must not leave the others waiting in the key-table exchange: the ranks agree on a status first, and
+    // everybody returns the failure (the failing rank reports its own message, the others name the rank)
+    {
+        std::vector<uint32_t> st(world, 0u);
+        st[rank] = r == SKX_OK ? 0u : 1u;
+        const std::string mine = r == SKX_OK ? "" : skx_last_error();
+        const int ra = skx_comm_allreduce_u32(comm, st.data(), (uint64_t)world, 0);
+        if (ra != SKX_OK) { if (ds) skx_dictset_free(ds); return ra; }
+        if (r != SKX_OK) { skx_set_last_error(mine.c_str()); return r; }
+        for (int q = 0; q < world; q++)
+            if (st[q]) { skx_dictset_free(ds); skx_set_last_error(("rank " + std::to_string(q) + " could not build its samples").c_str()); return SKX_EINVAL; }
+    }
     { Phase p("sharded.local_union"); r = skx_keyset_union(ctx, ds, &ks); }
     if (r == SKX_OK) { Phase p("sharded.key_table_exchange"); r = skx_keyset_allgather(comm, ks, &rows); }
     if (ks) skx_keyset_free(ks);
@@ -625,8 +635,10 @@ int launch_ranks(int world, char **argv)
         env.push_back(std::string(local ? "SKX_COMM_DIR=" : "SKX_COMM_ID_FILE=") + dir + (local ? "" : "/id"));
         std::vector<char *> envp; for (auto &x : env) envp.push_back(&x[0]); envp.push_back(nullptr);
         pid_t pid;
-        if (posix_spawn(&pid, "/proc/self/exe", nullptr, nullptr, argv, envp.data()) != 0) rcode = fail("cannot start a rank");
-        else pids.push_back(pid);
+        if (posix_spawn(&pid, "/proc/self/exe", nullptr, nullptr, argv, envp.data()) != 0) {
+            rcode = fail("cannot start a rank");
+            for (pid_t q : pids) kill(q, SIGTERM);                                          // (they would wait for the missing peer)
+        } else pids.push_back(pid);
     }
     size_t left = pids.size();
     while (left) {
@@ -647,6 +659,11 @@ int open_comm(skx_ctx *ctx, int rank, int world, skx_comm **out)
     if (const char *d = getenv("SKX_COMM_DIR")) return skx_comm_create_local(ctx, rank, world, d, out);
     uint8_t id[SKX_COMM_ID_BYTES];
     const char *idf = getenv("SKX_COMM_ID_FILE");
+    if (world == 1 && !idf) {                                                           // a single rank exchanges with nobody: no RCCL needed
+        char dir[] = "/tmp/skx_one_rank_XXXXXX";
+        if (!mkdtemp(dir)) { skx_set_last_error("cannot create a directory for the single rank's communicator"); return SKX_EIO; }
+        return skx_comm_create_local(ctx, 0, 1, dir, out);
+    }
     if (world > 1 && !idf) { skx_set_error("SKX_WORLD > 1 needs SKX_COMM_ID_FILE (where rank 0 leaves the RCCL id) or SKX_COMM_DIR"); return SKX_EINVAL; }
     if (rank == 0) {
         int r = skx_comm_unique_id(id);
@@ -721,6 +738,82 @@ int auto_min_count(skx_ctx *ctx, const Inputs &in, int k, bool rc, skx_qual &q, 
     return 0;
 }
 // build | align | distance as one rank of a job over several GPUs
+// `ska selftest --gpus N`: what a sharded job needs of the node, in a few seconds and with the engine's own message when something is missing --
+// the hand-off of the RCCL id, one all-gather of key tables of unequal sizes (skx_keyset_allgather), one all-reduce, one gather of unequal
+// pieces to rank 0, each compared with the same exchange over the host-staged transport in the same group of ranks.  60 s, then it gives up.
+static const char *g_selftest_stage = "start";
+static void selftest_alarm(int) { char b[160]; const int n = snprintf(b, sizeof b, "error: selftest: no progress for 60 s in: %s\n", g_selftest_stage); if (n > 0) (void)!write(2, b, (size_t)n); _exit(3); }
+int selftest(skx_ctx *ctx, int rank, int world)
+{
+    signal(SIGALRM, selftest_alarm);
+    alarm(60);
+    auto stage = [&](const char *s) { g_selftest_stage = s; if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] selftest rank %d: %s\n", rank, s); };
+    stage("communicator (RCCL id hand-off)");
+    skx_comm *comm = nullptr, *local = nullptr;
+    if (open_comm(ctx, rank, world, &comm) != SKX_OK) return engine_fail();
+    // the same ranks over the host-staged transport, in a directory next to the id file
+    std::string ldir;
+    if (const char *idf = getenv("SKX_COMM_ID_FILE")) { ldir = idf; ldir = ldir.substr(0, ldir.find_last_of('/')) + "/selftest_local"; if (rank == 0) mkdir(ldir.c_str(), 0700); }
+    stage("barrier");
+    if (skx_comm_barrier(comm) != SKX_OK) return engine_fail();
+    if (!ldir.empty() && world > 1) { stage("host-staged communicator"); if (skx_comm_create_local(ctx, rank, world, ldir.c_str(), &local) != SKX_OK) return engine_fail(); }
+    int bad = 0;
+    // all-reduce
+    stage("all-reduce");
+    std::vector<uint32_t> v(4096), v2;
+    for (size_t i = 0; i < v.size(); i++) v[i] = (uint32_t)(rank + 1) * (uint32_t)(i % 7 + 1);
+    v2 = v;
+    if (skx_comm_allreduce_u32(comm, v.data(), v.size(), 0) != SKX_OK) return engine_fail();
+    for (size_t i = 0; i < v.size(); i++) if (v[i] != (uint32_t)(world * (world + 1) / 2) * (uint32_t)(i % 7 + 1)) bad |= 1;
+    if (local) { if (skx_comm_allreduce_u32(local, v2.data(), v2.size(), 0) != SKX_OK) return engine_fail(); if (v2 != v) bad |= 2; }
+    // gather of unequal pieces to rank 0
+    stage("gather to rank 0");
+    std::vector<uint64_t> sizes(world); uint64_t total = 0;
+    for (int q = 0; q < world; q++) { sizes[q] = 1000 + 333 * (uint64_t)q; total += sizes[q]; }
+    std::vector<uint8_t> piece(sizes[rank]), all(rank == 0 ? total : 1), all2(rank == 0 ? total : 1);
+    for (size_t i = 0; i < piece.size(); i++) piece[i] = (uint8_t)(i * 31 + rank);
+    if (skx_comm_gather_root(comm, piece.data(), sizes.data(), all.data()) != SKX_OK) return engine_fail();
+    if (rank == 0) { uint64_t o = 0; for (int q = 0; q < world; q++) { for (uint64_t i = 0; i < sizes[q]; i++) if (all[o + i] != (uint8_t)(i * 31 + q)) bad |= 4; o += sizes[q]; } }
+    if (local) { if (skx_comm_gather_root(local, piece.data(), sizes.data(), all2.data()) != SKX_OK) return engine_fail(); if (rank == 0 && all2 != all) bad |= 8; }
+    // key tables of unequal sizes: every rank's own sequence plus one all share
+    stage("key tables (all-gather of unequal tables + union)");
+    {
+        char tmpl[] = "/tmp/skx_selftest_XXXXXX";
+        const int fd = mkstemp(tmpl);
+        if (fd < 0) return fail("selftest: cannot write a temporary file");
+        std::string fa = ">shared\n";
+        uint64_t x = 88172645463325252ull;
+        auto base = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return "ACGT"[x & 3]; };
+        for (int i = 0; i < 20000; i++) fa += base();
+        fa += "\n>own\n";
+        x = 0x9E3779B97F4A7C15ull * (uint64_t)(rank + 1);
+        for (int i = 0; i < 5000 * (rank + 1); i++) fa += base();
+        fa += "\n";
+        (void)!write(fd, fa.data(), fa.size()); close(fd);
+        skx_keyset *ks = nullptr, *rows = nullptr, *ks2 = nullptr, *rows2 = nullptr;
+        int r = skx_keyset_from_fasta(ctx, tmpl, 31, 1, &ks);
+        if (r == SKX_OK && local) r = skx_keyset_from_fasta(ctx, tmpl, 31, 1, &ks2);
+        unlink(tmpl);
+        if (r != SKX_OK) return engine_fail();
+        if (skx_keyset_allgather(comm, ks, &rows) != SKX_OK) return engine_fail();
+        uint64_t n1 = 0, n2 = 0, mine_n = 0;
+        skx_keyset_size(rows, &n1); skx_keyset_size(ks, &mine_n);
+        if (n1 < mine_n || (world > 1 && n1 == mine_n)) bad |= 16;
+        if (local) { if (skx_keyset_allgather(local, ks2, &rows2) != SKX_OK) return engine_fail(); skx_keyset_size(rows2, &n2); if (n2 != n1) bad |= 32; }
+        std::vector<uint32_t> agree(1, (uint32_t)(n1 & 0xFFFFFFu));
+        if (skx_comm_allreduce_u32(comm, agree.data(), 1, 0) != SKX_OK) return engine_fail();
+        if (agree[0] != (uint32_t)(n1 & 0xFFFFFFu) * (uint32_t)world) bad |= 64;              // every rank derived the same number of rows
+        if (rank == 0) fprintf(stderr, "selftest: %d rank(s): id hand-off, all-reduce, gather to rank 0, all-gather of unequal key tables (%llu rows)%s: %s\n", world,
+                               (unsigned long long)n1, local ? ", each also over the host-staged transport" : "", bad ? "MISMATCH" : "ok");
+        skx_keyset_free(ks); skx_keyset_free(rows); if (ks2) skx_keyset_free(ks2); if (rows2) skx_keyset_free(rows2);
+    }
+    stage("closing");
+    if (local) skx_comm_destroy(local);
+    skx_comm_destroy(comm);
+    alarm(0);
+    if (bad) { fprintf(stderr, "error: selftest: rank %d: results differ (mask %d)\n", rank, bad); return 4; }
+    return 0;
+}
 int main_sharded(skx_ctx *ctx, const std::string &cmd, const Args &a, int rank, int world, int threads)
 {
     BuildOpts bo; Inputs in;
@@ -786,7 +879,8 @@ extern "C" int skh_main(int argc, char **argv)
     }
     // several GPUs (an extension; the reference has --threads only): `--gpus N` starts N ranks of this executable, a rank finds
     // SKX_WORLD / SKX_RANK in its environment; align / distance then take sequence files or -f and the build options
-    const bool multi = a.has("--gpus") || env_world > 0;
+    const bool shards = cmd == "build" || cmd == "align" || cmd == "distance" || cmd == "selftest";
+    const bool multi = a.has("--gpus") || (env_world > 0 && shards);                       // (a stray SKX_WORLD does not reach merge / nk / map / weed / cov)
     {   // clap rejects what a subcommand does not declare (cli.rs:109-330); -v / --verbose is global (cli.rs:103-104)
         static const struct { const char *cmd; const char *flags; } KNOWN[] = {
             {"build", " -o -k -f --proportion-reads --single-strand --min-count --min-qual --qual-filter --threads --gpus --merge "},
@@ -795,7 +889,7 @@ extern "C" int skh_main(int argc, char **argv)
             {"distance", " -o -m --min-freq --allow-ambiguous --threads --gpus "},
             {"merge", " -o "}, {"delete", " -s --skf-file -o -f "},
             {"weed", " -o --reverse -m --min-freq --filter-ambig-as-missing --filter --ambig-mask --no-gap-only-sites "},
-            {"nk", " --full-info "}, {"cov", " -k --single-strand "}};
+            {"nk", " --full-info "}, {"cov", " -k --single-strand "}, {"selftest", " --gpus "}};
         for (auto &kc : KNOWN)
             if (cmd == kc.cmd)
                 for (auto &o : a.opt)
@@ -812,7 +906,7 @@ extern "C" int skh_main(int argc, char **argv)
     const bool dbg = getenv("SKX_DEBUG") != nullptr;
     int world = 1, rank = 0;
     if (multi) {
-        if (cmd != "build" && cmd != "align" && cmd != "distance") return fail("--gpus applies to build, align and distance");
+        if (!shards) return fail("--gpus applies to build, align, distance and selftest");
         const int gpus = a.has("--gpus") ? atoi(a.get("--gpus").c_str()) : env_world;
         if (gpus < 1) return fail("--gpus must be one or higher");
         if (env_world <= 0 && gpus > 1) return launch_ranks(gpus, argv);                   // the parent only starts and reaps the ranks
@@ -825,7 +919,9 @@ extern "C" int skh_main(int argc, char **argv)
     skx_phase_add("main.device_context", since());
     int rcode = 0;
     skx_array *arr = nullptr;
-    if (multi) rcode = main_sharded(ctx, cmd, a, rank, world, threads);
+    if (multi && cmd == "selftest") rcode = selftest(ctx, rank, world);
+    else if (cmd == "selftest") rcode = selftest(ctx, 0, 1);
+    else if (multi) rcode = main_sharded(ctx, cmd, a, rank, world, threads);
     else if (cmd == "build") {
         if (!a.has("-o")) return fail("-o <output> is required");
         if (a.pos.empty() == !a.has("-f")) return fail("give either sequence files or -f <file_list>");

@@ -188,3 +188,17 @@ def test_distance_by_bands_equals_whole(tmp_path):
         od = oa.distance(oc, filt)
         assert oc == constant and np.array_equal(od["match_count"], whole["match_count"]) and np.array_equal(od["mismatch_count"], whole["mismatch_count"])
         assert np.allclose(od["distance"], whole["distance"], rtol=0, atol=1e-6)
+
+
+def test_selftest_two_ranks_and_one(tmp_path):
+    """`ska selftest --gpus N`: the pre-flight of a sharded job (id hand-off or directory, all-reduce, gather, all-gather of unequal key tables)"""
+    ska = os.path.join(ROOT, "ska.rust_amd", "ska")
+    env = dict(os.environ, SKX_COMM="local", SKX_DEVICE="0")
+    r = subprocess.run([ska, "selftest", "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0 and "2 rank(s)" in r.stderr and ": ok" in r.stderr, r.stderr[-1500:]
+    r = subprocess.run([ska, "selftest"], capture_output=True, text=True, timeout=120, env=dict(os.environ, SKX_DEVICE="0"))
+    assert r.returncode == 0 and "1 rank(s)" in r.stderr, r.stderr[-1500:]
+    # a stray SKX_WORLD does not turn `ska nk` into a sharded job
+    r = subprocess.run([ska, "nk", os.path.join(ROOT, "tests", "golden", "input", "merge.skf")], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, SKX_WORLD="2", SKX_RANK="0", SKX_DEVICE="0"))
+    assert r.returncode == 0, r.stderr[-1500:]
