@@ -55,7 +55,7 @@ constexpr size_t CHUNK = 65536;                 // uncompressed bytes per snappy
 // bytes of CBOR in flight per direction: 128 MB (thread teams are forked per super-block); SKX_SKF_BLOCK_MB trades memory for forks
 static size_t super_bytes()
 {
-    static const size_t v = [] { const char *e = getenv("SKX_SKF_BLOCK_MB"); long mb = e ? atol(e) : 128; if (mb < 1) mb = 1; if (mb > 4096) mb = 4096; return (size_t)mb * 16 * CHUNK; }();
+    static const size_t v = [] { long mb = knob("skf_block_mb", 128); if (mb < 1) mb = 1; if (mb > 4096) mb = 4096; return (size_t)mb * 16 * CHUNK; }();
     return v;
 }
 #define SUPER (super_bytes())
@@ -64,15 +64,15 @@ static size_t super_bytes()
 // default: from 1 MB up (below that the host codec is as fast as the launches)
 bool device_section(uint64_t bytes)
 {
-    const char *e = getenv("SKX_SKF_DEVICE");
-    if (e && *e == '0') return false;
-    if (e && *e == '1') return bytes >= CHUNK;
+    const long e = knob("skf_device", -1);
+    if (e == 0) return false;
+    if (e == 1) return bytes >= CHUNK;
     return bytes >= (1u << 20);
 }
 int n_workers(int threads)
 {
     if (threads <= 0) { threads = (int)std::thread::hardware_concurrency(); if (threads <= 0) threads = 4; }
-    static const int cap = [] { const char *e = getenv("SKX_SKF_THREADS"); const int v = e ? atoi(e) : 64; return v > 0 ? v : 64; }();
+    static const int cap = [] { const int v = (int)knob("skf_threads", 64); return v > 0 ? v : 64; }();
     return std::min(threads, cap);
 }
 template <typename F>

@@ -32,6 +32,18 @@ void skx::set_error(const char *fmt, ...)
 {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
 }
+long skx::knob(const char *name, long absent)
+{
+    const char *e = getenv("SKX_KNOBS");
+    if (!e) return absent;
+    const size_t n = strlen(name);
+    for (const char *p = e; *p;) {
+        const char *q = strchr(p, ','); if (!q) q = p + strlen(p);
+        if ((size_t)(q - p) >= n && !strncmp(p, name, n) && (p[n] == '=' || p + n == q)) return p[n] == '=' ? atol(p + n + 1) : 1;
+        p = *q ? q + 1 : q;
+    }
+    return absent;
+}
 int skx::hip_fail(hipError_t e, const char *what)
 {
     set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
@@ -177,7 +189,7 @@ extern "C" int skx_ctx_expect_output(skx_ctx *ctx, int fd)
 {
     if (!ctx) return SKX_EINVAL;
     off_t pos;
-    ctx->expect_fd = (fd >= 0 && mappable_output_fd(fd, &pos) && !getenv("SKX_NO_MMAP_OUTPUT")) ? fd : -1;
+    ctx->expect_fd = (fd >= 0 && mappable_output_fd(fd, &pos)) ? fd : -1;
     return SKX_OK;
 }
 
@@ -427,7 +439,7 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
         return reads_words_to_dictset(ctx, wl, wh2, cnt, k, rc, out);
     };
     auto build_reads = [&]() -> int {
-        if (!getenv("SKX_READS_SORT")) {
+        if (!knob("reads_sort")) {
             const int r = build_bucketed_reads();
             if (r != SKF_NOT_TAKEN) return r;
         }
@@ -442,7 +454,6 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
     // windows per bucket (upper bound): the 64-bit dedupe sorts up to 6 144 words per region in LDS and the regions get 20 % + 256
     // words of head-room, so 4 900 is the largest mean that fits -- and the largest buckets give the scatter its widest chunks
     uint64_t per_region = wide ? 4096 : 4900;
-    if (const char *e = getenv("SKX_WORDS_PER_REGION")) { const long v = atol(e); if (v >= 64 && v <= 4900) per_region = (uint64_t)v; }      // (measurement: more, smaller regions)
     if (any_qual || maxlen > (per_region << MAX_LOGB)) return build_reads();
     int logB = std::min({ilog2_ceil((maxlen + per_region - 1) / per_region), key_bits_used, MAX_LOGB});
     if (logB < 0) logB = 0;
@@ -505,7 +516,7 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
         // (skx::dictset_sort: skx_dictset_size / _export, the key-set union of a sharded job).  A fixed-capacity region always fits
         // the counting sort (region_cap <= LDS_SORT_MAX), so that later sort cannot come back for a finer split.
         d->maxlen = maxlen; d->region_cap = lds_cap;
-        if (!wide && !exact && !any_qual && lds_cap <= LDS_SORT_MAX && !getenv("SKX_SORTED_DICTS")) {
+        if (!wide && !exact && !any_qual && lds_cap <= LDS_SORT_MAX && !knob("sorted_dicts")) {
             DevBuf<unsigned long long> d_tot; SKX_TRY(d_tot.alloc(n));
             launch_region_totals(d->raw.p, n, logB, d_tot.p, st);
             d->raw_total.resize(n);
@@ -580,7 +591,7 @@ extern "C" int skx_dictset_build(skx_ctx *ctx, const skx_stream *samples, int n,
 static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const char *const *file2, int n, int k, int rc, const skx_qual *q, int threads,
                                  skx_dictset **out)
 {
-    if (getenv("SKX_NO_READS_PIPELINE") || n < 2) return SKF_NOT_TAKEN;
+    if (knob("no_reads_pipeline") || n < 2) return SKF_NOT_TAKEN;
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<uint64_t> bound(n, 0);
     uint64_t slot_bytes = 0;
@@ -605,7 +616,6 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     // a slot per reader thread and a few waiting for their kernels: more only costs allocation time (64 slots = 17 GB took 4.7 s right after
     // another process had released the memory, 32 slots 0.26 s: profiles/r03zr_reads_pipeline_512.log)
     int P = (int)std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(2, std::min<uint64_t>((uint64_t)nt + 8, (free_b / 8) / (2 * slot_bytes + 1))));
-    if (const char *e = getenv("SKX_READS_POOL")) P = std::max(1, std::min(n, atoi(e)));
     DevBuf<uint8_t> seq_pool, qual_pool;
     SKX_TRY(seq_pool.alloc((uint64_t)P * slot_bytes)); SKX_TRY(qual_pool.alloc((uint64_t)P * slot_bytes));
     constexpr size_t SLOT = 8u << 20;
@@ -627,7 +637,7 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     std::vector<std::string> errs(n);
     auto mark_ready_locked = [&](int i) { Sample &x = smp[i]; if (x.read_done && x.pending == 0 && !x.queued) { x.queued = true; ring.ready.push_back(i); } };
     std::vector<std::thread> uploaders;
-    const int n_up = getenv("SKX_UPLOADERS") ? std::max(1, atoi(getenv("SKX_UPLOADERS"))) : 2;
+    const int n_up = 2;
     for (int u = 0; u < n_up; u++) uploaders.emplace_back([&]() {
         (void)hipSetDevice(ctx->device);
         hipStream_t up = nullptr;
@@ -697,7 +707,7 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
                         if (x.slot < 0) {
                             std::unique_lock<std::mutex> lk(ring.mu);
                             ring.cv_free.wait(lk, [&] { return !ring.free_slots.empty() || ring.abort; });
-                            if (ring.abort) { set_error("upload of the sequence files failed"); return SKX_ENODEV; }
+                            if (ring.abort) return SKF_ABORTED;               // somebody else stopped the pipeline: not this reader's failure
                             x.slot = ring.free_slots.back(); ring.free_slots.pop_back(); x.used = 0;
                         }
                         const size_t take = std::min(nb, SLOT - x.used);
@@ -717,7 +727,7 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
                 if (r == SKX_OK) { flush(o[0]); flush(o[1]); if (o[0].off != o[1].off) { set_error("Invalid FASTA/Q record"); r = SKX_EIO; } }
                 if (r != SKX_OK) {
                     give_back();
-                    rcodes[i] = r; errs[i] = skx_last_error();
+                    if (r != SKF_ABORTED) { rcodes[i] = r; errs[i] = skx_last_error(); }      // (only the failure that started it is reported)
                     { std::lock_guard<std::mutex> lk(ring.mu); ring.abort = true; }
                     ring.cv_stream.notify_all(); ring.cv_free.notify_all(); ring.cv_ready.notify_all();
                     return;
@@ -756,8 +766,10 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     phase_add("build.read_upload", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     phase_add("build.reads_kernels_overlapped", t_kernels);
     if (ring.failed) { set_error("upload of the sequence files failed"); return SKX_ENODEV; }
+    // the kernels' verdict first (SKF_NOT_TAKEN included: the one-shot form takes the batch -- the readers it interrupted recorded nothing),
+    // then the reader whose own failure stopped the pipeline
+    if (krc != SKX_OK) return krc;
     for (int i = 0; i < n; i++) if (rcodes[i] != SKX_OK) { set_error("%s", errs[i].c_str()); return rcodes[i]; }
-    if (krc != SKX_OK) return krc;                                              // SKF_NOT_TAKEN included: the one-shot form takes the batch
     if (done < n) { set_error("internal: read-set pipeline stopped early"); return SKX_EUNSUP; }
     seq_pool.release(); qual_pool.release();
     const auto t1 = std::chrono::steady_clock::now();
@@ -778,7 +790,7 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
     return skx_guarded([&]() -> int {
     if (!ctx || !file1 || n <= 0 || !out) { set_error("bad arguments"); return SKX_EINVAL; }
     SKX_TRY(check_k(k));
-    if (!(proportion_reads > 0.0) && !getenv("SKX_HOST_PARSE") && !getenv("SKX_READS_SORT")) {
+    if (!(proportion_reads > 0.0) && !knob("host_parse") && !knob("reads_sort")) {
         const int pr = build_reads_pipelined(ctx, file1, file2, n, k, rc, q, threads, out);
         if (pr != SKF_NOT_TAKEN) return pr;
     }
@@ -795,7 +807,7 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
     std::vector<skx_stream> ss(n);
     size_t step = 1;
     if (proportion_reads > 0.0) { step = (size_t)std::llround(1.0 / proportion_reads); if (step == 0) step = 1; }
-    const bool device_parse = step == 1 && !getenv("SKX_HOST_PARSE");
+    const bool device_parse = step == 1 && !knob("host_parse");
     const auto t_read0 = std::chrono::steady_clock::now();
     bool any_pair = false;
     for (int i = 0; file2 && i < n; i++) any_pair |= file2[i] != nullptr;
@@ -870,7 +882,7 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
     ring.readers_left = nt;
     // uploader: copies queued pieces on one stream, a batch at a time, and returns their slots
     std::vector<std::thread> uploaders;
-    const int n_up = getenv("SKX_UPLOADERS") ? std::max(1, atoi(getenv("SKX_UPLOADERS"))) : 2;      // two streams keep both copy engines busy
+    const int n_up = 2;                                                         // two streams keep both copy engines busy
     if (ring_ok) for (int u = 0; u < n_up; u++) uploaders.emplace_back([&]() {
         (void)hipSetDevice(ctx->device);
         hipStream_t up = nullptr;
@@ -1193,7 +1205,7 @@ static int keyset_union_views(skx_ctx *ctx, const DictView *views, int nviews, i
         if (nviews == 1) {
             // side_for: the assemble over these dictionaries follows (skx_merge): the pass also notes where every word's key went, 2 bytes
             // per word, and the matrix is then filled from the notes instead of a second read of the dictionaries
-            const bool with_side = side_for && (wide || union_side_ok(views[0], logN, stride)) && !getenv("SKX_NO_MERGE_SIDE");
+            const bool with_side = side_for && (wide || union_side_ok(views[0], logN, stride));
             if (wide && with_side) {
                 if (!side_buf.p) SKX_TRY(side_buf.alloc(side_for->words.n / 2 + 64));          // one note per 16-byte word
                 SKX_TRY(ks->perm.alloc(nsub * stride));
@@ -1232,7 +1244,7 @@ extern "C" int skx_keyset_union(skx_ctx *ctx, skx_dictset *d, skx_keyset **out)
 extern "C" int skx_keyset_union_notes(skx_ctx *ctx, skx_dictset *d, skx_keyset **out)
 {
     // (a sharded job hands this key set to skx_keyset_allgather, which carries the notes over to the global rows)
-    return skx_guarded([&]() -> int { return keyset_union_dict(ctx, d, out, !getenv("SKX_NO_SHARD_SIDE")); });
+    return skx_guarded([&]() -> int { return keyset_union_dict(ctx, d, out, true); });
 }
 static int keyset_union_dict(skx_ctx *ctx, skx_dictset *d, skx_keyset **out, bool with_side)
 {
@@ -1498,7 +1510,7 @@ extern "C" int skx_array_assemble_lazy(skx_ctx *ctx, skx_dictset *d, skx_keyset 
     return skx_guarded([&]() -> int {
     if (!ctx || !d || !rows || !out) { skx_dictset_free(d); skx_keyset_free(rows); set_error("bad arguments"); return SKX_EINVAL; }
     // the lazy form needs a row set slabbed at least as finely as the dictionaries' buckets; anything else is assembled at once
-    if (rows->wide != d->wide() || rows->k != d->k || rows->rc != d->rc || rows->logN < 0 || rows->logN < d->logB || d->n > 65535 || getenv("SKX_EAGER_ARRAY")) {
+    if (rows->wide != d->wide() || rows->k != d->k || rows->rc != d->rc || rows->logN < 0 || rows->logN < d->logB || d->n > 65535 || knob("eager_array")) {
         const int r = skx_array_assemble(ctx, d, rows, names, out);
         skx_dictset_free(d); skx_keyset_free(rows);
         return r;
@@ -1593,7 +1605,7 @@ int skx::array_lazy_window(skx_array *a, uint64_t r0, uint64_t nr, DevBuf<uint8_
 // assemble kernels.
 static int merge_append(skx_ctx *ctx, skx_dictset *d, const char *const *names, skx_array **out)
 {
-    if (d->sorted || d->wide() || d->n > 65535 || d->n < 1 || getenv("SKX_NO_APPEND")) return SKF_NOT_TAKEN;
+    if (d->sorted || d->wide() || d->n > 65535 || d->n < 1) return SKF_NOT_TAKEN;
     SKX_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const int S = d->n, bits = d->hp.bits, logB = d->logB;
@@ -1767,7 +1779,7 @@ static int build_range(skx_ctx *ctx, const char *const *names, const char *const
         const auto t0 = std::chrono::steady_clock::now();
         int ra = merge_append(ctx, d, names + lo, &a);           // assemblies: straight from the extraction kernel's regions; the array holds the pieces
         if (ra != SKF_NOT_TAKEN) r = ra;
-        else if (!getenv("SKX_EAGER_ARRAY")) {
+        else if (!knob("eager_array")) {
             // rows now, cells on demand: the array keeps the dictionaries (see skx_array::lazy_dict)
             skx_keyset *ks = nullptr;
             r = skx_keyset_union(ctx, d, &ks);                                         // (without notes: a lazily held array does not use them)
@@ -2321,7 +2333,7 @@ extern "C" int skx_array_write_fasta(skx_array *a, int fd)
     off_t pos = regular ? lseek(fd, 0, SEEK_CUR) : 0;
     // ---- mapped output
     uint8_t *map = nullptr; size_t map_len = 0, map_skew = 0;
-    if (regular && !append && pos >= 0 && fl >= 0 && (fl & O_ACCMODE) == O_RDWR && total && !getenv("SKX_NO_MMAP_OUTPUT")) {
+    if (regular && !append && pos >= 0 && fl >= 0 && (fl & O_ACCMODE) == O_RDWR && total) {
         const long pg = sysconf(_SC_PAGESIZE);
         map_skew = (size_t)(pos % pg);
         // the file is only ever grown: several writers (one per GPU) may each hold a window of the same file
@@ -2461,7 +2473,7 @@ static int distance_ambiguous_split(skx_array *a, const uint8_t *keep, double co
     const int S = (int)a->names.size(); const uint64_t U = a->n_rows;
     DevBuf<uint8_t> clean, dirty;
     SKX_TRY(clean.alloc(U)); SKX_TRY(dirty.alloc(U));
-    launch_split_keep(keep, a->mask.p, U, clean.p, dirty.p, st, getenv("SKX_TEST_STALE_ROW_MASK") ? 2 : 0);
+    launch_split_keep(keep, a->mask.p, U, clean.p, dirty.p, st, knob("stale_row_mask") ? 2 : 0);
     DevBuf<uint64_t> pc, pd; uint64_t wc = 1, wd = 1, nc = 0, nd = 0;
     SKX_TRY(planes_of_kept_rows(a, clean.p, 1, pc, wc, nc));
     if (nc) {
@@ -2540,7 +2552,7 @@ extern "C" int skx_array_distance_filtered(skx_array *a, double min_freq, int fi
         SKX_HIP(hipMemcpyAsync(&kept, pos.p + U, 8, hipMemcpyDeviceToHost, st));
         SKX_HIP(hipMemcpyAsync(&n_const, d_c.p, 8, hipMemcpyDeviceToHost, st));
         SKX_HIP(hipStreamSynchronize(st));
-        if (!filt_ambig && kept && !getenv("SKX_DISTANCE_DENSE")) {
+        if (!filt_ambig && kept) {
             if (constant) *constant = (int64_t)n_const;
             if (rows_used) *rows_used = kept;
             return distance_ambiguous_split(a, keep.p, (double)n_const, out);
@@ -2598,7 +2610,7 @@ extern "C" int skx_array_distance(skx_array *a, double constant, int filt_ambig,
     const int S = (int)a->names.size(); const uint64_t U = a->n_rows;
     if (S < 2) return SKX_OK;
     StageTimer t(ctx, &ctx->tm.distance);
-    if (!filt_ambig && U && !getenv("SKX_DISTANCE_DENSE")) return distance_ambiguous_split(a, nullptr, constant, out);
+    if (!filt_ambig && U) return distance_ambiguous_split(a, nullptr, constant, out);
     const uint64_t wpr = (U + 63) / 64;
     DevBuf<uint64_t> planes;
     SKX_TRY(planes.alloc((filt_ambig ? 4 : 8) * (uint64_t)S * std::max<uint64_t>(wpr, 1)));

@@ -224,7 +224,7 @@ extern "C" int skx_array_map(skx_array *a, const char *reference, int ambig_mask
 // 64 KB chunks per launch of the device codec (512 MB of CBOR; SKX_SKF_GROUP_CHUNKS overrides, tests use small groups)
 static uint64_t skf_group_chunks()
 {
-    const char *e = getenv("SKX_SKF_GROUP_CHUNKS");
+    const long e_ = knob("skf_group_chunks"); char ebuf_[24]; snprintf(ebuf_, sizeof ebuf_, "%ld", e_); const char *e = e_ ? ebuf_ : nullptr;
     const long v = e ? atol(e) : 8192;
     return (uint64_t)std::max<long>(1, std::min<long>(v, 1 << 20));
 }
@@ -245,7 +245,7 @@ extern "C" int skx_array_save(skx_array *a, const char *path)
     SkfFastSections fast;
     struct PinnedBuf { uint8_t *p = nullptr; ~PinnedBuf() { if (p) (void)hipHostFree(p); } } pin_keys, pin_counts;
     const auto t_k0 = std::chrono::steady_clock::now();
-    if (a->k <= 31 && a->keys.p && U && !a->keys_absent && a->n_kmers == U && !getenv("SKX_SKF_HOST_KEYS")) {
+    if (a->k <= 31 && a->keys.p && U && !a->keys_absent && a->n_kmers == U) {
         DevBuf<uint8_t> d_kc; DevBuf<int> d_short;
         SKX_TRY(d_kc.alloc(9 * U + 64)); SKX_TRY(d_short.alloc(1)); SKX_TRY(d_short.zero(st));
         launch_keys_cbor(a->keys.p, U, a->hp, d_kc.p, d_short.p, st);
@@ -490,7 +490,7 @@ extern "C" int skx_array_load_filtered(skx_ctx *ctx, const char *path, const skx
     // the output hint applies to exactly this call, whichever path it takes (a stale descriptor number may belong to another file by
     // the time of a later call)
     const int expect_fd = ctx->expect_fd; ctx->expect_fd = -1;
-    if (getenv("SKX_NO_STREAM_LOAD")) return load_then_filter(ctx, path, f, out, removed, constant);
+    if (knob("no_stream_load")) return load_then_filter(ctx, path, f, out, removed, constant);
     SKX_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     struct Release { std::chrono::steady_clock::time_point t; bool on = false;

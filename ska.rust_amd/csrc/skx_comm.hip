@@ -429,7 +429,7 @@ extern "C" int skx_keyset_allgather(skx_comm *c, skx_keyset *local, skx_keyset *
     SKX_TRY(keyset_union_tables(ctx, gathered.p, h_off, h_cnt, local->k, local->rc, rows));
     // the notes of the rank's own union pass (skx_keyset_union took them) move to the global rows: own row -> global row per own sub-bucket
     skx_keyset *g = *rows;
-    if (local->side.p && local->side_of && local->perm.p && !local->wide && g->logN >= local->logN && local->logN >= 0 && !getenv("SKX_NO_SHARD_SIDE")) {
+    if (local->side.p && local->side_of && local->perm.p && !local->wide && g->logN >= local->logN && local->logN >= 0) {
         const uint64_t nsub = 1ull << local->logN;
         DevBuf<int> d_bad; DevBuf<uint32_t> d_max;
         SKX_TRY(d_bad.alloc(1)); SKX_TRY(d_bad.zero(st)); SKX_TRY(d_max.alloc(1)); SKX_TRY(d_max.zero(st));
@@ -539,7 +539,7 @@ extern "C" int skx_array_distance_sharded(skx_comm *c, skx_array *a, int filt_am
     SKX_HIP(hipSetDevice(ctx->device));
     // --allow-ambiguous: the rows without an ambiguous cell in ANY rank's samples (the ranks agree on them through one all-reduce of a byte
     // per row) travel as 4 planes and go through the three-count sweep, only the others as 8 planes through the twelve-class one
-    const bool split = !filt_ambig && !getenv("SKX_DISTANCE_DENSE");
+    const bool split = !filt_ambig;
     const void *lp = nullptr; uint64_t wpr = 0; int np = 0;
     DevBuf<uint64_t> lp_clean, lp_dirty; uint64_t wpr_c = 1, wpr_d = 1, rows_c = 0, rows_d = 0;
     if (!split) SKX_TRY(skx_array_distance_planes(a, filt_ambig, &lp, &wpr, &np));
@@ -566,7 +566,7 @@ extern "C" int skx_array_distance_sharded(skx_comm *c, skx_array *a, int filt_am
         std::vector<uint64_t> differs((size_t)c->world);
         SKX_TRY(comm_allgather_host(c, &differ, differs.data(), sizeof differ));
         for (uint64_t d : differs) differ |= d;
-        if (differ || getenv("SKX_TEST_STALE_ROW_MASK")) {
+        if (differ || knob("stale_row_mask")) {
             launch_split_keep(nullptr, a->mask.p, U, clean.p, dirty.p, st, 1);
             lp_clean.release(); rows_c = 0; wpr_c = 1;
         }

@@ -14,6 +14,8 @@
 
 namespace skx {
 
+// test / measurement knobs: SKX_KNOBS="name=value,name,..." (ONE environment variable; a bare name is 1); absent = the product path
+long knob(const char *name, long absent = 0);
 int extract_tile_bases(int logB);         // window end positions per workgroup of the extraction kernels (16 per thread)
 constexpr int MAX_LOGB = 13;              // buckets per sample <= 8192 (LDS histogram)
 constexpr uint64_t EMPTY64 = ~0ull;

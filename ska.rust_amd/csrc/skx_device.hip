@@ -435,14 +435,9 @@ static void launch_extract(const ExtractArgs &a, hipStream_t st)
 // against 18.2 ms with 16 384-position tiles and one workgroup, 800 x 6 Mbp).
 int extract_tile_bases(int logB) { return logB <= 11 ? 12288 : 8192; }
 void launch_hist(const ExtractArgs &a, hipStream_t st) { launch_extract<false>(a, st); }
-#include "skx_extract_lines.inc"
 void launch_scatter(const ExtractArgs &a, hipStream_t st)
 {
-    // SKX_EXTRACT_LINES=1: the one-workgroup-per-sample form that writes whole lines (skx_extract_lines.inc).  Off by default:
-    // its writes run at the streaming rate, but keeping the open lines costs more VALU work than the staging pass it replaces
-    // (24.2 ms against 13.3 ms per 1 000 x 5 Mbp).
-    const char *force = getenv("SKX_EXTRACT_LINES");
-    if (force && atoi(force) != 0 && extract_lines_applicable(a)) launch_scatter_lines(a, st); else launch_extract<true>(a, st);
+    launch_extract<true>(a, st);
 }
 // ------------------------------------------------------------------------------------------------
 // block-wide helpers
@@ -954,8 +949,7 @@ static void launch_dedupe_shape(uint64_t *words, const uint64_t *off, const uint
 }
 uint32_t dedupe_spill_grid()
 {
-    const char *e = getenv("SKX_DEDUPE_SPILL_GRID");
-    const long v = e ? atol(e) : 0;
+    const long v = knob("dedupe_spill_grid");
     return v > 0 ? (uint32_t)v : 16384u;
 }
 // regions with more than `above` words -> list[1..], count at list[0] (zeroed by the caller)
@@ -973,7 +967,6 @@ void launch_dedupe_mb(uint64_t *words, const uint64_t *off, const uint32_t *raw,
                       int rem_bits, int *overflow, uint16_t *sidx, int sb, hipStream_t st, uint32_t typical, uint32_t *big_list, uint32_t big_from)
 {
     if (!n_regions) return;
-    if (getenv("SKX_DEDUPE_ONE_SHAPE")) typical = 0;
     const uint32_t shape_all = dedupe_shape_words(cap), shape_typ = typical ? dedupe_shape_words(typical) : shape_all;
     if (!big_list || shape_typ >= shape_all || n_regions > 0xFFFFFFFFull) {
         launch_dedupe_shape(words, off, raw, ucnt, n_regions, cap, rem_bits, overflow, sidx, sb, st, nullptr, 0u, 0);

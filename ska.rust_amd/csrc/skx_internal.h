@@ -19,6 +19,7 @@
 namespace skx {
 
 void set_error(const char *fmt, ...);
+
 int hip_fail(hipError_t e, const char *what);       // sets the error, returns SKX_ENODEV / SKX_ENOMEM
 
 #define SKX_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return skx::hip_fail(e_, #call); } while (0)
@@ -225,6 +226,7 @@ typedef std::function<int(uint64_t row0, uint64_t nrows, const uint8_t *src)> Ro
 // [uoff0, uoff0 + n_chunks * 64 KB) to f.
 struct SkfChunk { size_t off, len; uint32_t ulen, crc; bool compressed; uint64_t uoff; };
 constexpr int SKF_NOT_TAKEN = -1000;
+constexpr int SKF_ABORTED = -1001;      // a reader of the read-set pipeline that was stopped by somebody else's failure
 typedef std::function<int(const uint8_t *file, const SkfChunk *chunks, size_t n_chunks, uint64_t upos, uint64_t n_rows, uint64_t n_samples)> DevDecode;
 typedef std::function<int(FILE *f, uint64_t upos, uint64_t uoff0, uint64_t n_chunks)> DevEncode;
 // layout-only view of a .skf for the streaming load (`ska align x.skf`, `ska distance x.skf`): header parsed, the split k-mer

@@ -294,7 +294,7 @@ def test_builds_are_deterministic(tmp_path, monkeypatch):
         synth.to_fasta(synth.sample_stream(anc, i, 10, private_snps=40, shared_snps=10, seed=3), p)
         files.append(p)
     outs = {}
-    for tag, env in (("a", {}), ("b", {}), ("batched", {"SKX_BUILD_BATCH_MB": "8"}), ("eager", {"SKX_EAGER_ARRAY": "1"}), ("host_parse", {"SKX_HOST_PARSE": "1"})):
+    for tag, env in (("a", {}), ("b", {}), ("batched", {"SKX_BUILD_BATCH_MB": "8"}), ("eager", {"SKX_KNOBS": "eager_array=1"}), ("host_parse", {"SKX_KNOBS": "host_parse=1"}), ("sorted", {"SKX_KNOBS": "sorted_dicts=1"})):
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
         rc, out, err = ska("build", "-o", tag, "-k", "31", "--threads", "3", *files, cwd=wd)
@@ -315,7 +315,7 @@ def test_builds_are_deterministic(tmp_path, monkeypatch):
 
 def test_read_set_pipeline_equals_one_shot(tmp_path):
     """`ska build` on read sets runs reader threads, uploads and the per-isolate kernels as a pipeline over a small pool of device slots
-    (skx_api.cpp build_reads_pipelined); SKX_NO_READS_PIPELINE=1 is the one-shot form it replaced.  Same .skf bytes either way and with a
+    (skx_api.cpp build_reads_pipelined); SKX_KNOBS=no_reads_pipeline is the one-shot form it replaced.  Same .skf bytes either way and with a
     pool of ONE slot (every sample reuses it), for paired and single-file samples, k = 31 and 41; a broken record fails both forms with the
     reference's message (ska_dict.rs:131-153 via needletail)."""
     import synth
@@ -328,12 +328,12 @@ def test_read_set_pipeline_equals_one_shot(tmp_path):
             f.write(f"r{i}\t{a}\t{b}\n" if i % 3 else f"r{i}\t{a}\n")                     # every third sample: one file only
     for k in ("31", "41"):
         outs = {}
-        for tag, env in (("pipe", {}), ("pool1", {"SKX_READS_POOL": "1"}), ("oneshot", {"SKX_NO_READS_PIPELINE": "1"})):
+        for tag, env in (("pipe", {}), ("oneshot", {"SKX_KNOBS": "no_reads_pipeline=1"})):
             r = subprocess.run([SKA, "build", "-f", "list.txt", "-o", f"{tag}{k}", "-k", k, "--min-count", "3", "--threads", "4"], cwd=wd, capture_output=True,
                                timeout=300, env=dict(os.environ, **env))
             assert r.returncode == 0, r.stderr[-600:]
             outs[tag] = open(os.path.join(wd, f"{tag}{k}.skf"), "rb").read()
-        assert outs["pipe"] == outs["oneshot"] and outs["pool1"] == outs["oneshot"]
+        assert outs["pipe"] == outs["oneshot"]
         want = ora.Array.build([(f"r{i}", a, b if i % 3 else None) for i, (a, b) in enumerate(pairs)], k=int(k), rc=True, q=ora.qual(3, 20, ora.QUAL_STRICT), threads=2)
         got = ora.Array.load(os.path.join(wd, f"pipe{k}.skf"))
         got.sort_rows(); want.sort_rows()
@@ -342,6 +342,6 @@ def test_read_set_pipeline_equals_one_shot(tmp_path):
         assert len(ok) > 10_000 and np.array_equal(gk, ok) and np.array_equal(gv, ov) and np.array_equal(gc, oc)
     bad = open(pairs[2][0], "rb").read()
     open(pairs[2][0], "wb").write(bad[:len(bad) // 2 - 7])                                # a record cut in the middle
-    for env in ({}, {"SKX_NO_READS_PIPELINE": "1"}):
+    for env in ({}, {"SKX_KNOBS": "no_reads_pipeline=1"}):
         r = subprocess.run([SKA, "build", "-f", "list.txt", "-o", "broken", "-k", "31", "--min-count", "3"], cwd=wd, capture_output=True, timeout=300, env=dict(os.environ, **env))
         assert r.returncode != 0 and b"Invalid FASTA/Q record" in r.stderr, r.stderr[-400:]

@@ -202,11 +202,11 @@ def test_config5_one_isolate_at_size(E, thousand):
     assert 4_900_000 < len(gk) < 5_100_000
     assert np.array_equal(gk["lo"], ok["lo"]) and np.array_equal(gk["hi"], ok["hi"]) and np.array_equal(gb, ob)
     # the sort-based first form (rocPRIM) agrees as well
-    os.environ["SKX_READS_SORT"] = "1"
+    os.environ["SKX_KNOBS"] = "reads_sort=1"
     try:
         ds2 = E.DictSet.from_files([(files[0], files[1])], 41, True, E.qual(5, 20, E.QUAL_STRICT), threads=1)
     finally:
-        os.environ.pop("SKX_READS_SORT")
+        os.environ.pop("SKX_KNOBS", None)
     k2, b2 = ds2.export(0)
     assert np.array_equal(k2["lo"], gk["lo"]) and np.array_equal(k2["hi"], gk["hi"]) and np.array_equal(b2, gb)
     # smaller k = more gated windows per read: k = 31 runs the 48-word partitions at their tighter head-room, k = 17 (the reference's

@@ -1,10 +1,11 @@
 """Lazily held arrays (`-m gpu`): skx_build_and_merge returns rows + dictionaries, not a matrix.  `ska build` streams such an
 array into its .skf window by window, `ska align *.fa` filters it before any cell is written; every other operation assembles
-the matrix first.  All of them must give what the eagerly assembled array (SKX_EAGER_ARRAY=1) and the oracle give."""
+the matrix first.  All of them must give what the eagerly assembled array (SKX_KNOBS=eager_array) and the oracle give."""
 import os
 
 import numpy as np
 import pytest
+from conftest import set_knob, del_knob
 
 import ora
 
@@ -52,8 +53,8 @@ def test_lazy_save_streams_the_same_file_rows(E, tmp_path, monkeypatch, k):
     inputs = _files(tmp_path)
     oa = ora.Array.build(inputs, k=k)
     want = _sorted(oa)
-    monkeypatch.setenv("SKX_SKF_DEVICE", "1")
-    monkeypatch.setenv("SKX_SKF_GROUP_CHUNKS", "2")              # several windows
+    set_knob(monkeypatch, "skf_device", "1")
+    set_knob(monkeypatch, "skf_group_chunks", "2")              # several windows
     lazy = E.Array.build(inputs, k=k, threads=3)
     assert list(lazy.sample_kmers()) == [int(x) for x in (oa.export()[1] != ord("-")).sum(axis=0)]      # answered from the dictionaries
     p = str(tmp_path / "lazy.skf")
@@ -61,7 +62,7 @@ def test_lazy_save_streams_the_same_file_rows(E, tmp_path, monkeypatch, k):
     back = ora.Array.load(p)
     for x, y in zip(_sorted(back), want):
         assert np.array_equal(x, y)
-    monkeypatch.setenv("SKX_SKF_DEVICE", "0")                    # host codec: rows fetched block by block
+    set_knob(monkeypatch, "skf_device", "0")                    # host codec: rows fetched block by block
     p2 = str(tmp_path / "lazy_host.skf")
     E.Array.build(inputs, k=k, threads=3).save(p2)
     for x, y in zip(_sorted(ora.Array.load(p2)), want):
@@ -78,9 +79,9 @@ def test_lazy_filter_writes_only_kept_rows(E, tmp_path, monkeypatch, min_freq, k
     for ft, amb, mask, gaps in (FILTERS if k == 15 else FILTERS[::3]):
         lazy = E.Array.build(inputs, k=k, threads=2)
         g = lazy.align(filter_type=ft, mask_ambig=mask, ignore_const_gaps=gaps, min_freq=min_freq, filter_ambig_as_missing=amb)
-        monkeypatch.setenv("SKX_EAGER_ARRAY", "1")
+        set_knob(monkeypatch, "eager_array", "1")
         eager = E.Array.build(inputs, k=k, threads=2)
-        monkeypatch.delenv("SKX_EAGER_ARRAY")
+        del_knob(monkeypatch, "eager_array")
         e = eager.align(filter_type=ft, mask_ambig=mask, ignore_const_gaps=gaps, min_freq=min_freq, filter_ambig_as_missing=amb)
         assert g == e, (ft, amb, mask, gaps)                     # same engine order either way: byte-identical
         oa = ora.Array.build(inputs, k=k)
@@ -245,7 +246,7 @@ def test_allow_ambiguous_does_not_trust_stale_row_statistics(E, tmp_path, monkey
     od = oa.distance(oc, False)
     for stale in (False, True):
         if stale:
-            monkeypatch.setenv("SKX_TEST_STALE_ROW_MASK", "1")
+            set_knob(monkeypatch, "stale_row_mask", "1")
         arr = E.Array.build(inputs, k=21, threads=4)
         got, constant, _ = arr.distance_filtered(0.0, False)
         assert constant == oc

@@ -4,6 +4,7 @@ import os
 
 import numpy as np
 import pytest
+from conftest import set_knob, del_knob
 
 import golden_cases as G
 import ora
@@ -439,8 +440,8 @@ def test_skf_lifecycle_errors(E, tmp_path):
             m.delete_samples(["a"])
 
 
-SKF_MODES = {"host": {"SKX_SKF_DEVICE": "0"}, "device": {"SKX_SKF_DEVICE": "1"},
-             "device_small_groups": {"SKX_SKF_DEVICE": "1", "SKX_SKF_GROUP_CHUNKS": "3"}}
+SKF_MODES = {"host": {"skf_device": "0"}, "device": {"skf_device": "1"},
+             "device_small_groups": {"skf_device": "1", "skf_group_chunks": "3"}}
 
 
 @pytest.mark.parametrize("mode", list(SKF_MODES))
@@ -449,9 +450,9 @@ def test_skf_stream_codec_integrity(E, tmp_path, mode, monkeypatch):
     and a flipped byte / a truncated file is an error (masked CRC-32C per chunk), never a silently different array.
     Once with the `variants` section on the host thread team, once on the device (snappy + CRC-32C + CBOR cells in
     skx_snappy.hip), once on the device in groups of 3 chunks (rows straddle groups)."""
-    os.environ["SKX_SKF_BLOCK_MB"] = "4"       # read once, at the codec's first use: many super-blocks in this test
+    set_knob(monkeypatch, "skf_block_mb", "4")       # read once, at the codec's first use: many super-blocks in this test
     for kk, vv in SKF_MODES[mode].items():
-        monkeypatch.setenv(kk, vv)
+        set_knob(monkeypatch, kk, vv)
     rng = np.random.default_rng(11)
     _, samples = _related_samples(rng, 40, length=60_000, snps=300)
     names = [f"s{i}" for i in range(40)]
@@ -460,9 +461,9 @@ def test_skf_stream_codec_integrity(E, tmp_path, mode, monkeypatch):
     ga.save(p)
     ref = as_map(*ga.export())
     assert as_map(*E.Array.load(p).export()) == ref
-    monkeypatch.setenv("SKX_SKF_DEVICE", "1" if mode == "host" else "0")                   # written one way, read the other
+    set_knob(monkeypatch, "skf_device", "1" if mode == "host" else "0")                   # written one way, read the other
     assert as_map(*E.Array.load(p).export()) == ref
-    monkeypatch.setenv("SKX_SKF_DEVICE", SKF_MODES[mode]["SKX_SKF_DEVICE"])
+    set_knob(monkeypatch, "skf_device", SKF_MODES[mode]["skf_device"])
     oa = ora.Array.load(p)
     assert oa.names == names and as_map(*oa.export()) == ref
     p2 = str(tmp_path / "big_oracle.skf")
@@ -636,13 +637,13 @@ def test_skf_device_codec_alignments(E, tmp_path, n_samples, pad, monkeypatch):
     rows = _sorted_export(ga)
     files = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("SKX_SKF_DEVICE", mode)
-        monkeypatch.setenv("SKX_SKF_GROUP_CHUNKS", "2")
+        set_knob(monkeypatch, "skf_device", mode)
+        set_knob(monkeypatch, "skf_group_chunks", "2")
         files[mode] = str(tmp_path / f"w{mode}.skf")
         ga.save(files[mode])
     for written in ("0", "1"):
         for read in ("0", "1"):
-            monkeypatch.setenv("SKX_SKF_DEVICE", read)
+            set_knob(monkeypatch, "skf_device", read)
             back = E.Array.load(files[written])
             assert back.names == names
             for x, y in zip(_sorted_export(back), rows):
@@ -806,15 +807,15 @@ def test_skf_device_decoder_takes_any_valid_element_stream(E, tmp_path, monkeypa
     names = [f"s{i}" for i in range(5)]
     ga = E.DictSet.build([E.record_stream(s) for s in samples], 31, True).merge(names)
     rows = _sorted_export(ga)
-    monkeypatch.setenv("SKX_SKF_DEVICE", "0")
+    set_knob(monkeypatch, "skf_device", "0")
     p = str(tmp_path / "host.skf")
     ga.save(p)
     re = _reencode_skf(open(p, "rb").read(), rng)
     p2 = str(tmp_path / "random_elements.skf")
     open(p2, "wb").write(re)
     for mode, group in (("1", "2"), ("1", "8192"), ("0", "8192")):
-        monkeypatch.setenv("SKX_SKF_DEVICE", mode)
-        monkeypatch.setenv("SKX_SKF_GROUP_CHUNKS", group)
+        set_knob(monkeypatch, "skf_device", mode)
+        set_knob(monkeypatch, "skf_group_chunks", group)
         back = E.Array.load(p2)
         assert back.names == names
         for x, y in zip(_sorted_export(back), rows):
@@ -838,21 +839,6 @@ def test_dict_every_bucket_configuration(E, k, length):
     assert np.array_equal(gk["lo"], ok["lo"]) and np.array_equal(gk["hi"], ok["hi"]) and np.array_equal(gb, ob)
 
 
-@pytest.mark.parametrize("k,rc", [(31, True), (15, True), (21, False)])
-def test_line_writing_extraction_matches_oracle(E, k, rc, monkeypatch):
-    """SKX_EXTRACT_LINES=1: the one-workgroup-per-sample scatter that writes whole 128-byte lines (skx_extract_lines.inc) builds
-    the same dictionaries as the oracle: several tiles per sample, records of every length, one bucket far beyond a line."""
-    rng = np.random.default_rng(77 + k)
-    samples = []
-    for i in range(4):
-        recs = rand_records(rng, 5, 30_000) + [b"ACGT" * 3, b"", b"A" * (k - 1), b"C" * k]
-        if i == 2:
-            recs.append(b"A" * 3000 + b"ACGTN" * 50 + b"T" * 40)        # many words of one bucket in one tile: many flush rounds
-        samples.append(recs)
-    monkeypatch.setenv("SKX_EXTRACT_LINES", "1")
-    check_dicts(E, samples, k, rc)
-
-
 def test_dedupe_two_shapes_and_listed_regions(E, monkeypatch):
     """Regions are sorted in the launch shape the typical region needs; the few above it are listed and sorted by a second launch of
     the full shape, grid after grid when the list is long.  A 200-base unit repeated 800 times puts ~800 extra words into ~200 of a
@@ -864,11 +850,11 @@ def test_dedupe_two_shapes_and_listed_regions(E, monkeypatch):
     for i in range(2):
         body = acgt[rng.integers(0, 4, size=2_340_000)].tobytes()
         samples.append([body[:1_000_000], unit * 800, body[1_000_000:], b"ACGT" * 5])
-    monkeypatch.setenv("SKX_DEDUPE_SPILL_GRID", "48")               # ~200 listed regions per sample: several second-stage launches
+    set_knob(monkeypatch, "dedupe_spill_grid", "48")               # ~200 listed regions per sample: several second-stage launches
     ds = check_dicts(E, samples, 31, True)
     sizes = [ds.size(i) for i in range(2)]
     ds.free()
-    monkeypatch.setenv("SKX_DEDUPE_ONE_SHAPE", "1")
-    ds1 = check_dicts(E, samples, 31, True)
+    del_knob(monkeypatch, "dedupe_spill_grid")
+    ds1 = check_dicts(E, samples, 31, True)                          # one grid of the second stage
     assert [ds1.size(i) for i in range(2)] == sizes
     ds1.free()

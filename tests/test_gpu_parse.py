@@ -20,14 +20,14 @@ def E():
 
 def _dicts(E, files, k, host_parse, threads=4):
     if host_parse:
-        os.environ["SKX_HOST_PARSE"] = "1"
+        os.environ["SKX_KNOBS"] = "host_parse=1"
     else:
-        os.environ.pop("SKX_HOST_PARSE", None)
+        os.environ.pop("SKX_KNOBS", None)
     try:
         ds = E.DictSet.from_files([(f, None) for f in files], k, True, threads=threads)
         return [ds.export(i) for i in range(len(files))]
     finally:
-        os.environ.pop("SKX_HOST_PARSE", None)
+        os.environ.pop("SKX_KNOBS", None)
 
 
 def _same(a, b):

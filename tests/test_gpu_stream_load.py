@@ -6,6 +6,7 @@ import os
 
 import numpy as np
 import pytest
+from conftest import set_knob, del_knob
 
 import ora
 
@@ -53,8 +54,8 @@ def test_one_pass_load_equals_load_then_filter(E, tmp_path, monkeypatch, S, U):
     rng = np.random.default_rng(1000 + S)
     keys, var = _random_array(E, rng, U, S)
     names = [f"s{i}" for i in range(S)]
-    monkeypatch.setenv("SKX_SKF_DEVICE", "1")
-    monkeypatch.setenv("SKX_SKF_GROUP_CHUNKS", "2")
+    set_knob(monkeypatch, "skf_device", "1")
+    set_knob(monkeypatch, "skf_group_chunks", "2")
     path = str(tmp_path / "a.skf")
     E.Array.from_host(31, True, names, keys, var).save(path)
     oa_full = ora.Array.load(path)
@@ -62,9 +63,9 @@ def test_one_pass_load_equals_load_then_filter(E, tmp_path, monkeypatch, S, U):
               for mf in (0.0, 0.5, 0.9, 1.0)]
     for ft, amb, mask, gaps, mf in combos[:: (1 if S <= 7 else 5)]:
         fast, rem_f, _ = E.Array.load_filtered(path, mf, amb, ft, mask, gaps)
-        monkeypatch.setenv("SKX_NO_STREAM_LOAD", "1")
+        set_knob(monkeypatch, "no_stream_load", "1")
         slow, rem_s, _ = E.Array.load_filtered(path, mf, amb, ft, mask, gaps)
-        monkeypatch.delenv("SKX_NO_STREAM_LOAD")
+        del_knob(monkeypatch, "no_stream_load")
         assert (fast.nrows, rem_f) == (slow.nrows, rem_s), (ft, amb, mask, gaps, mf)
         fa, sa = fast.fasta(), slow.fasta()
         assert fa == sa, (ft, amb, mask, gaps, mf)
@@ -82,8 +83,8 @@ def test_one_pass_distance_equals_oracle(E, tmp_path, monkeypatch, S, filt_ambig
     rng = np.random.default_rng(2000 + S)
     keys, var = _random_array(E, rng, 40000 // S + 500, S)
     names = [f"d{i}" for i in range(S)]
-    monkeypatch.setenv("SKX_SKF_DEVICE", "1")
-    monkeypatch.setenv("SKX_SKF_GROUP_CHUNKS", "2")
+    set_knob(monkeypatch, "skf_device", "1")
+    set_knob(monkeypatch, "skf_group_chunks", "2")
     path = str(tmp_path / "d.skf")
     E.Array.from_host(31, True, names, keys, var).save(path)
     lib = E.load_library()
@@ -99,8 +100,8 @@ def test_one_pass_distance_equals_oracle(E, tmp_path, monkeypatch, S, filt_ambig
 
 def test_files_the_one_pass_reader_hands_over(E, tmp_path, monkeypatch):
     rng = np.random.default_rng(3)
-    monkeypatch.setenv("SKX_SKF_DEVICE", "1")
-    monkeypatch.setenv("SKX_SKF_GROUP_CHUNKS", "2")
+    set_knob(monkeypatch, "skf_device", "1")
+    set_knob(monkeypatch, "skf_group_chunks", "2")
     # (1) keys below 2^32 are shorter CBOR items: the key list is not 9 bytes per key
     keys, var = _random_array(E, rng, 30000, 5, small_keys=True)
     names = [f"s{i}" for i in range(5)]
@@ -141,7 +142,7 @@ def test_keyless_array_refuses_key_operations(E, tmp_path, monkeypatch):
     rng = np.random.default_rng(4)
     keys, var = _random_array(E, rng, 20000, 4)
     path = str(tmp_path / "k.skf")
-    monkeypatch.setenv("SKX_SKF_DEVICE", "1")
+    set_knob(monkeypatch, "skf_device", "1")
     E.Array.from_host(31, True, ["a", "b", "c", "d"], keys, var).save(path)
     arr, _, _ = E.Array.load_filtered(path, 0.0, False, 0, False, False)      # nothing removed: rows == split k-mers, but no keys
     with pytest.raises(E.EngineError):
@@ -190,7 +191,7 @@ def test_files_framed_in_small_chunks(E, tmp_path, monkeypatch, lo, hi):
     open(small, "wb").write(_reframe_small_chunks(open(path, "rb").read(), rng, lo, hi))
     assert ora.Array.load(small).nrows == len(keys)                    # a valid file: the oracle's reader takes it
     for group in ("8192", "3"):
-        monkeypatch.setenv("SKX_SKF_GROUP_CHUNKS", group)
+        set_knob(monkeypatch, "skf_group_chunks", group)
         for ft, mf in ((E.FILTER_NO_CONST, 0.9), (E.FILTER_NONE, 0.0), (E.FILTER_NO_AMBIG_OR_CONST, 0.5)):
             a, rem_a, _ = E.Array.load_filtered(path, mf, False, ft, False, False)
             b, rem_b, _ = E.Array.load_filtered(small, mf, False, ft, False, False)
@@ -222,17 +223,17 @@ def test_one_pass_load_with_128_bit_keys(E, tmp_path, monkeypatch, S, U):
     _, first = np.unique(keys, return_index=True)                      # distinct (hi, lo) pairs only
     keys, var = keys[np.sort(first)], var[np.sort(first)]
     names = [f"s{i}" for i in range(S)]
-    monkeypatch.setenv("SKX_SKF_DEVICE", "1")
-    monkeypatch.setenv("SKX_SKF_GROUP_CHUNKS", "2")
+    set_knob(monkeypatch, "skf_device", "1")
+    set_knob(monkeypatch, "skf_group_chunks", "2")
     path = str(tmp_path / "wide.skf")
     E.Array.from_host(41, True, names, keys, var).save(path)
     assert ora.Array.load(path).nrows == len(keys)
     E.phases(reset=True)
     for ft, amb, mask, gaps, mf in [(1, False, False, False, 0.9), (0, False, False, False, 0.0), (3, True, True, False, 0.5), (2, False, True, True, 1.0)]:
         fast, rem_f, _ = E.Array.load_filtered(path, mf, amb, ft, mask, gaps)
-        monkeypatch.setenv("SKX_NO_STREAM_LOAD", "1")
+        set_knob(monkeypatch, "no_stream_load", "1")
         slow, rem_s, _ = E.Array.load_filtered(path, mf, amb, ft, mask, gaps)
-        monkeypatch.delenv("SKX_NO_STREAM_LOAD")
+        del_knob(monkeypatch, "no_stream_load")
         oa = ora.Array.load(path)
         assert rem_f == rem_s == oa.apply_filters(mf, amb, ft, mask, gaps), (ft, amb, mask, gaps, mf)
         assert fast.fasta() == slow.fasta() == oa.fasta(), (ft, amb, mask, gaps, mf)
