@@ -2360,9 +2360,8 @@ extern "C" int skx_array_write_fasta(skx_array *a, int fd)
         falloc.th = std::thread([&backed, &ok, pre, total]() { pre->finish(total); if (pre->failed.load(std::memory_order_acquire)) ok = false; backed.store(true, std::memory_order_release); });
     }
     const size_t cap = std::max<size_t>(max_rec, map ? (32u << 20) : (64u << 20));
-    auto knob = [](const char *name, int dflt) { const char *e = getenv(name); const int v = e ? atoi(e) : 0; return v > 0 ? v : dflt; };
-    const int NB = map ? std::min(6, knob("SKX_FASTA_NB", 4)) : (regular && !append && pos >= 0 ? 6 : 2);
-    const int KT = map ? knob("SKX_FASTA_KT", 4) : 1;                   // copier threads per batch (mapped output)
+    const int NB = map ? 4 : (regular && !append && pos >= 0 ? 6 : 2);
+    const int KT = map ? 4 : 1;                   // copier threads per batch (mapped output)
 
     struct Slot { char *p = nullptr; std::vector<std::thread> th; void join() { for (auto &t : th) if (t.joinable()) t.join(); th.clear(); }
                   ~Slot() { join(); if (p) (void)hipHostFree(p); } } slot[6];

@@ -2,7 +2,7 @@
 """tools/reads_scale_check.py [isolates] [world]: BASELINE config 5's shape through the product -- paired FASTQ isolates (2 x 150 bp at 50x of a
 5 Mbp genome, 0.5 % errors, per-cycle Phred profile), k = 41, --min-count 5, strict q20: `ska build` + `ska distance` in one process, and
 `ska distance --gpus <world>` with the ranks sharing the GPU (world 0: skipped); the two distance tables must be byte-identical.  (Parity
-against the oracle at this shape: tests/test_gpu_full_size.py::test_config5_flow_eight_isolates_at_size.)"""
+against the oracle at this shape: tests/test_gpu_zz_full_size.py::test_config5_flow_eight_isolates_at_size.)"""
 import hashlib, os, shutil, subprocess, sys, tempfile, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
