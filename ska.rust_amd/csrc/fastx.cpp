@@ -14,8 +14,108 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#include <dlfcn.h>
 
 namespace skx {
+
+// bzip2 / xz / zstd inputs (needletail's `compression` feature, Cargo.toml:32, takes them besides gzip): inflated through the system's
+// libbz2 / liblzma / libzstd, opened at run time and bound by their published C interfaces (the image has the libraries, not their headers).
+// A file of one of these kinds whose library is missing is refused with the reference's message instead of being parsed as text.
+namespace {
+struct BzStream { char *next_in; unsigned avail_in, total_in_lo32, total_in_hi32; char *next_out; unsigned avail_out, total_out_lo32, total_out_hi32;
+                  void *state; void *(*bzalloc)(void *, int, int); void (*bzfree)(void *, void *); void *opaque; };
+struct LzmaStream { const uint8_t *next_in; size_t avail_in; uint64_t total_in; uint8_t *next_out; size_t avail_out; uint64_t total_out;
+                    const void *allocator; void *internal; void *rp1, *rp2, *rp3, *rp4; uint64_t ri1, ri2; size_t ri3, ri4; int re1, re2; };
+struct ZstdIn { const void *src; size_t size, pos; };
+struct ZstdOut { void *dst; size_t size, pos; };
+void *open_lib(const char *const *names) { for (; *names; names++) if (void *h = dlopen(*names, RTLD_NOW | RTLD_LOCAL)) return h; return nullptr; }
+void grow(std::vector<uint8_t> &out, size_t used) { if (out.size() - used < (1u << 20)) out.resize(out.size() * 2 + (8u << 20)); }
+// 0 = done, 1 = the library (or a symbol) is missing, 2 = the data is bad
+int inflate_bz2(const std::vector<uint8_t> &in, std::vector<uint8_t> &out)
+{
+    static const char *const L[] = {"libbz2.so.1.0", "libbz2.so.1", "libbz2.so", nullptr};
+    static void *h = open_lib(L);
+    if (!h) return 1;
+    auto init = (int (*)(BzStream *, int, int))dlsym(h, "BZ2_bzDecompressInit");
+    auto run = (int (*)(BzStream *))dlsym(h, "BZ2_bzDecompress");
+    auto end = (int (*)(BzStream *))dlsym(h, "BZ2_bzDecompressEnd");
+    if (!init || !run || !end) return 1;
+    size_t ipos = 0, used = 0;
+    out.clear();
+    while (ipos < in.size()) {                                     // concatenated streams, as bzip2 itself reads them
+        BzStream z{};
+        if (init(&z, 0, 0) != 0) return 2;
+        for (;;) {
+            grow(out, used);
+            z.next_in = (char *)in.data() + ipos; z.avail_in = (unsigned)std::min<size_t>(in.size() - ipos, 1u << 30);
+            z.next_out = (char *)out.data() + used; z.avail_out = (unsigned)std::min<size_t>(out.size() - used, 1u << 30);
+            const unsigned ai = z.avail_in, ao = z.avail_out;
+            const int r = run(&z);
+            ipos += ai - z.avail_in; used += ao - z.avail_out;
+            if (r == 4) break;                                     // BZ_STREAM_END
+            if (r != 0 || (ai == z.avail_in && ao == z.avail_out)) { end(&z); return 2; }
+        }
+        end(&z);
+    }
+    out.resize(used);
+    return 0;
+}
+int inflate_xz(const std::vector<uint8_t> &in, std::vector<uint8_t> &out)
+{
+    static const char *const L[] = {"liblzma.so.5", "liblzma.so", nullptr};
+    static void *h = open_lib(L);
+    if (!h) return 1;
+    auto dec = (int (*)(LzmaStream *, uint64_t, uint32_t))dlsym(h, "lzma_stream_decoder");
+    auto code = (int (*)(LzmaStream *, int))dlsym(h, "lzma_code");
+    auto end = (void (*)(LzmaStream *))dlsym(h, "lzma_end");
+    if (!dec || !code || !end) return 1;
+    LzmaStream z{};
+    if (dec(&z, ~0ull, 0x08u /* LZMA_CONCATENATED */) != 0) return 2;
+    size_t used = 0;
+    out.clear();
+    z.next_in = in.data(); z.avail_in = in.size();
+    for (;;) {
+        grow(out, used);
+        z.next_out = out.data() + used; z.avail_out = out.size() - used;
+        const size_t ao = z.avail_out;
+        const int r = code(&z, z.avail_in ? 0 /* LZMA_RUN */ : 3 /* LZMA_FINISH */);
+        used += ao - z.avail_out;
+        if (r == 1) break;                                         // LZMA_STREAM_END
+        if (r != 0) { end(&z); return 2; }
+    }
+    end(&z);
+    out.resize(used);
+    return 0;
+}
+int inflate_zstd(const std::vector<uint8_t> &in, std::vector<uint8_t> &out)
+{
+    static const char *const L[] = {"libzstd.so.1", "libzstd.so", nullptr};
+    static void *h = open_lib(L);
+    if (!h) return 1;
+    auto mk = (void *(*)())dlsym(h, "ZSTD_createDStream");
+    auto fr = (size_t (*)(void *))dlsym(h, "ZSTD_freeDStream");
+    auto run = (size_t (*)(void *, ZstdOut *, ZstdIn *))dlsym(h, "ZSTD_decompressStream");
+    auto bad = (unsigned (*)(size_t))dlsym(h, "ZSTD_isError");
+    if (!mk || !fr || !run || !bad) return 1;
+    void *d = mk();
+    if (!d) return 2;
+    ZstdIn zi{in.data(), in.size(), 0};
+    size_t used = 0, last = 1;
+    out.clear();
+    while (zi.pos < zi.size || last != 0) {
+        grow(out, used);
+        ZstdOut zo{out.data() + used, out.size() - used, 0};
+        const size_t before = zi.pos;
+        last = run(d, &zo, &zi);
+        if (bad(last)) { fr(d); return 2; }
+        used += zo.pos;
+        if (zi.pos == zi.size && zo.pos == 0 && before == zi.pos) { if (last != 0) { fr(d); return 2; } break; }      // input ended inside a frame
+    }
+    fr(d);
+    out.resize(used);
+    return 0;
+}
+}  // namespace
 
 static int slurp(const char *path, std::vector<uint8_t> &buf)
 {
@@ -34,6 +134,14 @@ static int slurp(const char *path, std::vector<uint8_t> &buf)
         ::close(fd);
         buf.resize(got);
         if (got == 0) { set_error("Invalid path/file: %s", path); return SKX_EIO; }
+        // bzip2 ("BZh"), xz (FD 37 7A 58 5A 00), zstd (28 B5 2F FD)
+        const int kind = got >= 3 && !memcmp(buf.data(), "BZh", 3) ? 1 : got >= 6 && !memcmp(buf.data(), "\xFD" "7zXZ\0", 6) ? 2 : got >= 4 && !memcmp(buf.data(), "\x28\xB5\x2F\xFD", 4) ? 3 : 0;
+        if (kind) {
+            std::vector<uint8_t> plain;
+            const int r = kind == 1 ? inflate_bz2(buf, plain) : kind == 2 ? inflate_xz(buf, plain) : inflate_zstd(buf, plain);
+            if (r != 0 || plain.empty()) { set_error("Invalid path/file: %s", path); return SKX_EIO; }      // (library missing or data bad: never parsed as text)
+            buf.swap(plain);
+        }
         return SKX_OK;
     }
     gzFile g = gzdopen(fd, "rb");            // transparent for uncompressed input that is not a regular file; closes fd with gzclose

@@ -106,3 +106,47 @@ def test_device_parse_errors_match_host_reader(E, tmp_path):
                 _dicts(E, [str(f)], 31, host_parse=host, threads=1)
             errs.append((ei.value.code, str(ei.value)))
         assert errs[0] == errs[1], errs
+
+
+def test_bzip2_xz_zstd_inputs_equal_plain(E, tmp_path):
+    """needletail (Cargo.toml:32, `compression`) reads bzip2 / xz / zstd besides gzip: the same dictionaries from every form of the same
+    FASTA and FASTQ; a damaged file is "Invalid path/file", never parsed as text"""
+    import bz2
+    import ctypes
+    import gzip
+    import lzma
+    rng = np.random.default_rng(3)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    recs = [acgt[rng.integers(0, 4, size=n)].tobytes() for n in (5000, 31, 700, 12000)]
+    fa = b"".join(b">r%d\n" % i + b"\n".join(r[j:j + 60] for j in range(0, len(r), 60)) + b"\n" for i, r in enumerate(recs))
+    fq = b"".join(b"@q%d\n" % i + r[:150] + b"\n+\n" + b"I" * len(r[:150]) + b"\n" for i, r in enumerate(recs * 30))
+
+    def zstd(data):
+        lib = ctypes.CDLL("libzstd.so.1")
+        lib.ZSTD_compressBound.restype = ctypes.c_size_t; lib.ZSTD_compressBound.argtypes = [ctypes.c_size_t]
+        lib.ZSTD_compress.restype = ctypes.c_size_t
+        lib.ZSTD_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
+        out = ctypes.create_string_buffer(lib.ZSTD_compressBound(len(data)))
+        n = lib.ZSTD_compress(out, len(out), data, len(data), 3)
+        return out.raw[:n]
+
+    forms = {"plain": lambda d: d, "gz": gzip.compress, "bz2": lambda d: bz2.compress(d[:len(d) // 2]) + bz2.compress(d[len(d) // 2:]),      # two streams
+             "xz": lzma.compress, "zst": zstd}
+    for kind, data, q in (("fa", fa, None), ("fq", fq, E.qual(1, 0, E.QUAL_NOFILTER))):
+        want = None
+        for tag, f in forms.items():
+            p = str(tmp_path / f"x_{kind}.{tag}")
+            open(p, "wb").write(f(data))
+            ds = E.DictSet.from_files([(p, None)], 31, True, q=q)
+            got = ds.export(0)
+            ds.free()
+            if want is None:
+                want = got
+            else:
+                assert np.array_equal(got[0]["lo"], want[0]["lo"]) and np.array_equal(got[1], want[1]), (kind, tag)
+    bad = bz2.compress(fa)
+    p = str(tmp_path / "broken.bz2")
+    open(p, "wb").write(bad[:len(bad) // 2])
+    with pytest.raises(E.EngineError) as ei:
+        E.DictSet.from_files([(p, None)], 31, True)
+    assert "Invalid path/file" in str(ei.value)
