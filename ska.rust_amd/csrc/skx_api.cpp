@@ -1237,6 +1237,8 @@ static int keyset_union_views(skx_ctx *ctx, const DictView *views, int nviews, i
 }
 
 static int keyset_union_dict(skx_ctx *ctx, skx_dictset *d, skx_keyset **out, bool with_side);
+static int append_pass(skx_ctx *ctx, skx_dictset *d, std::unique_ptr<skx_keyset> &ks_out, std::unique_ptr<skx_pieces> &pc_out);
+static int array_over_pieces(skx_ctx *ctx, const skx_dictset *d, skx_keyset *ks, skx_pieces *pc_, skx_keyset *g, const char *const *names, skx_array **out);
 extern "C" int skx_keyset_union(skx_ctx *ctx, skx_dictset *d, skx_keyset **out)
 {
     return skx_guarded([&]() -> int { return keyset_union_dict(ctx, d, out, false); });
@@ -1252,6 +1254,14 @@ static int keyset_union_dict(skx_ctx *ctx, skx_dictset *d, skx_keyset **out, boo
     if (!ctx || !d || !out) { set_error("bad arguments"); return SKX_EINVAL; }
     SKX_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    if (with_side && !d->sorted) {
+        // assemblies as the extraction kernel left them: the append pass finds the rank's rows AND leaves the samples' cells as pieces, which
+        // travel with the key set (to the global rows of a sharded job: skx_keyset_allgather) like the notes of the union pass
+        std::unique_ptr<skx_keyset> ks; std::unique_ptr<skx_pieces> pc;
+        const int r = append_pass(ctx, d, ks, pc);
+        if (r == SKX_OK) { ks->pieces = pc.release(); ks->pieces_of = d; *out = ks.release(); return SKX_OK; }
+        if (r != SKF_NOT_TAKEN) return r;
+    }
     SKX_TRY(dictset_sort(d));                        // the union kernels read sorted slices
     StageTimer t(ctx, &ctx->tm.key_union);
     DictView v = d->view();
@@ -1389,6 +1399,16 @@ extern "C" int skx_array_assemble(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows
     if (d->n > 65535) { set_error("more than 65535 samples per device array"); return SKX_EUNSUP; }
     SKX_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    if (rows->pieces && rows->pieces_of == d && rows->logN >= 0) {
+        // the rows came from an append pass over these samples (skx_keyset_union_notes), directly or through the key-table exchange of a sharded
+        // job: the cells are there already, as pieces
+        const bool global = rows->g_perm.p != nullptr;
+        if (global || rows->logN == rows->pieces->logQ) {
+            skx_pieces *pc = rows->pieces; rows->pieces = nullptr; rows->pieces_of = nullptr;
+            StageTimer t(ctx, &ctx->tm.assemble);
+            return array_over_pieces(ctx, d, rows, pc, global ? rows : nullptr, names, out);
+        }
+    }
     SKX_TRY(dictset_sort(d));
     std::unique_ptr<skx_keyset> rebuilt;
     if (rows->logN < 0 || rows->logN < d->logB) {      // flat / too coarse: re-slab at a compatible granularity
@@ -1509,6 +1529,11 @@ extern "C" int skx_array_assemble_lazy(skx_ctx *ctx, skx_dictset *d, skx_keyset 
 {
     return skx_guarded([&]() -> int {
     if (!ctx || !d || !rows || !out) { skx_dictset_free(d); skx_keyset_free(rows); set_error("bad arguments"); return SKX_EINVAL; }
+    if (rows->pieces && rows->pieces_of == d) {                        // (an append pass's rows: the array over its pieces is the lazy form)
+        const int r = skx_array_assemble(ctx, d, rows, names, out);
+        skx_dictset_free(d); skx_keyset_free(rows);
+        return r;
+    }
     // the lazy form needs a row set slabbed at least as finely as the dictionaries' buckets; anything else is assembled at once
     if (rows->wide != d->wide() || rows->k != d->k || rows->rc != d->rc || rows->logN < 0 || rows->logN < d->logB || d->n > 65535 || knob("eager_array")) {
         const int r = skx_array_assemble(ctx, d, rows, names, out);
@@ -1603,7 +1628,8 @@ int skx::array_lazy_window(skx_array *a, uint64_t r0, uint64_t nr, DevBuf<uint8_
 // sorted.  SKF_NOT_TAKEN: not this kind of dictset (sorted already, 128-bit keys, regions beyond the kernel's load rounds, a row-block split
 // that would read every region too often), or blocks that kept overflowing -- the caller sorts the dictionaries and takes the union /
 // assemble kernels.
-static int merge_append(skx_ctx *ctx, skx_dictset *d, const char *const *names, skx_array **out)
+// the pass itself: the row blocks' keys (ks: stage / ncnt / roff, stride = cap) and the samples' pieces
+static int append_pass(skx_ctx *ctx, skx_dictset *d, std::unique_ptr<skx_keyset> &ks_out, std::unique_ptr<skx_pieces> &pc_out)
 {
     if (d->sorted || d->wide() || d->n > 65535 || d->n < 1) return SKF_NOT_TAKEN;
     SKX_HIP(hipSetDevice(ctx->device));
@@ -1686,24 +1712,60 @@ static int merge_append(skx_ctx *ctx, skx_dictset *d, const char *const *names, 
         if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] append: logQ=%d (x%llu per region) cap=%u slots=%u rows~%.0f -> %s\n", logQ, (unsigned long long)amp, cap, nslots, u_est, ov ? "overflow" : "ok");
         if (ov) continue;
         SKX_TRY(keyset_finish(ks.get()));
-        const uint64_t U = ks->total;
-        std::unique_ptr<skx_array> a(new skx_array());
-        a->ctx = ctx; a->k = d->k; a->rc = d->rc; a->k_bits = d->key_bits; a->hp = d->hp; a->wh = d->wh; a->version = skx_version();
-        for (int i = 0; i < S; i++) a->names.emplace_back(names && names[i] ? names[i] : "");
-        a->n_rows = a->n_kmers = U; a->pitch = 0; a->engine_order = true; a->stats_ready = true;
-        SKX_TRY(a->present.alloc(U)); SKX_TRY(a->unambig.alloc(U)); SKX_TRY(a->mask.alloc(U)); SKX_TRY(a->keys.alloc(U)); SKX_TRY(a->vcount.alloc(U));
-        if (U) {
-            launch_gather_keys(ks->stage.p, ks->stride, ks->ncnt.p, ks->roff.p, 1 << logQ, a->keys.p, 0, ks->hp, st);
-            // the rows' statistics, counted from the pieces
-            launch_pieces_stats(pc->data.p, pc->plen.p, pc->perm.p, pc->nrank.p, ks->ncnt.p, ks->roff.p, cap, S, 1 << logQ, a->present.p, a->unambig.p, a->mask.p, a->vcount.p, st);
-        }
-        SKX_HIP(hipStreamSynchronize(st));
-        SKX_HIP(hipGetLastError());
-        ks->stage.release();                           // the keys live in the array now; the row blocks keep ncnt / roff
-        a->pieces = pc.release(); a->lazy_rows = ks.release();
-        *out = a.release();
+        ks_out = std::move(ks); pc_out = std::move(pc);
         return SKX_OK;
     }
+}
+// An array over the pieces of an append pass.  own rows: the pass's own row blocks (ks: ncnt / roff / stage, the pieces' perm); global rows
+// (a sharded job, `g` = the rows skx_keyset_allgather returned): the rank's columns over all ranks' rows -- block j covers rows
+// [g_base[j], g_base[j] + g_n[j]) and g_perm maps its first-seen ranks to places in that range; rows the rank does not hold have no cell.
+static int array_over_pieces(skx_ctx *ctx, const skx_dictset *d, skx_keyset *ks, skx_pieces *pc_, skx_keyset *g, const char *const *names, skx_array **out)
+{
+    std::unique_ptr<skx_pieces> pc(pc_);
+    hipStream_t st = ctx->stream;
+    const int S = d->n, logQ = pc->logQ;
+    const uint64_t nsub = 1ull << logQ;
+    std::unique_ptr<skx_keyset> blk(new skx_keyset());                 // what the array keeps of the row blocks: ncnt / roff
+    blk->ctx = ctx; blk->k = d->k; blk->rc = d->rc; blk->logN = logQ; blk->hp = d->hp; blk->wh = d->wh; blk->wide = false; blk->stride = pc->cap;
+    uint64_t U;
+    if (g) {
+        U = g->total;
+        pc->perm = std::move(g->g_perm);
+        blk->ncnt = std::move(g->g_n);
+        SKX_TRY(blk->roff.alloc(nsub + 1));
+        SKX_HIP(hipMemcpyAsync(blk->roff.p, g->g_base.p, nsub * 8, hipMemcpyDeviceToDevice, st));
+        SKX_HIP(hipMemcpyAsync(blk->roff.p + nsub, &U, 8, hipMemcpyHostToDevice, st));
+        SKX_HIP(hipStreamSynchronize(st));                             // (&U)
+        g->g_base.release();
+        blk->total = U; blk->max_rows = g->g_max;
+    } else {
+        U = ks->total;
+        blk->ncnt = std::move(ks->ncnt); blk->roff = std::move(ks->roff); blk->total = U; blk->max_rows = ks->max_rows;
+    }
+    std::unique_ptr<skx_array> a(new skx_array());
+    a->ctx = ctx; a->k = d->k; a->rc = d->rc; a->k_bits = d->key_bits; a->hp = d->hp; a->wh = d->wh; a->version = skx_version();
+    for (int i = 0; i < S; i++) a->names.emplace_back(names && names[i] ? names[i] : "");
+    a->n_rows = a->n_kmers = U; a->pitch = 0; a->engine_order = true; a->stats_ready = true;
+    SKX_TRY(a->present.alloc(U)); SKX_TRY(a->unambig.alloc(U)); SKX_TRY(a->mask.alloc(U)); SKX_TRY(a->keys.alloc(U)); SKX_TRY(a->vcount.alloc(U));
+    if (U) {
+        skx_keyset *src = g ? g : ks;                                  // the rows' keys
+        launch_gather_keys(src->stage.p, src->stride, g ? g->ncnt.p : blk->ncnt.p, g ? g->roff.p : blk->roff.p, 1 << src->logN, a->keys.p, 0, src->hp, st);
+        if (g) { SKX_TRY(a->present.zero(st)); SKX_TRY(a->unambig.zero(st)); SKX_TRY(a->mask.zero(st)); SKX_TRY(a->vcount.zero(st)); }
+        // the rows' statistics, counted from the pieces
+        launch_pieces_stats(pc->data.p, pc->plen.p, pc->perm.p, pc->nrank.p, blk->ncnt.p, blk->roff.p, pc->cap, S, 1 << logQ, a->present.p, a->unambig.p, a->mask.p, a->vcount.p, st);
+    }
+    SKX_HIP(hipStreamSynchronize(st));
+    SKX_HIP(hipGetLastError());
+    a->pieces = pc.release(); a->lazy_rows = blk.release();
+    *out = a.release();
+    return SKX_OK;
+}
+static int merge_append(skx_ctx *ctx, skx_dictset *d, const char *const *names, skx_array **out)
+{
+    std::unique_ptr<skx_keyset> ks; std::unique_ptr<skx_pieces> pc;
+    const int r = append_pass(ctx, d, ks, pc);
+    if (r != SKX_OK) return r;
+    return array_over_pieces(ctx, d, ks.get(), pc.release(), nullptr, names, out);
 }
 
 extern "C" int skx_merge(skx_ctx *ctx, skx_dictset *d, const char *const *names, skx_array **out)

@@ -429,19 +429,23 @@ extern "C" int skx_keyset_allgather(skx_comm *c, skx_keyset *local, skx_keyset *
     SKX_TRY(keyset_union_tables(ctx, gathered.p, h_off, h_cnt, local->k, local->rc, rows));
     // the notes of the rank's own union pass (skx_keyset_union took them) move to the global rows: own row -> global row per own sub-bucket
     skx_keyset *g = *rows;
-    if (local->side.p && local->side_of && local->perm.p && !local->wide && g->logN >= local->logN && local->logN >= 0) {
+    const uint16_t *l_perm = local->pieces ? local->pieces->perm.p : local->perm.p;      // notes of the union pass, or pieces of the append pass
+    if (((local->side.p && local->side_of) || local->pieces) && l_perm && !local->wide && g->logN >= local->logN && local->logN >= 0) {
         const uint64_t nsub = 1ull << local->logN;
         DevBuf<int> d_bad; DevBuf<uint32_t> d_max;
         SKX_TRY(d_bad.alloc(1)); SKX_TRY(d_bad.zero(st)); SKX_TRY(d_max.alloc(1)); SKX_TRY(d_max.zero(st));
         SKX_TRY(g->g_perm.alloc(nsub * local->stride)); SKX_TRY(g->g_n.alloc(nsub)); SKX_TRY(g->g_base.alloc(nsub));
-        launch_compose_perm(local->stage.p, local->stride, local->ncnt.p, local->perm.p, local->logN, g->stage.p, g->stride, g->ncnt.p, g->roff.p, g->logN,
+        launch_compose_perm(local->stage.p, local->stride, local->ncnt.p, l_perm, local->logN, g->stage.p, g->stride, g->ncnt.p, g->roff.p, g->logN,
                             2 * (local->k - 1), g->g_perm.p, g->g_n.p, g->g_base.p, d_max.p, d_bad.p, st);
         int bad = 0; uint32_t gmax = 0;
         SKX_HIP(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, st));
         SKX_HIP(hipMemcpyAsync(&gmax, d_max.p, 4, hipMemcpyDeviceToHost, st));
         SKX_HIP(hipStreamSynchronize(st));
         SKX_HIP(hipGetLastError());
-        if (!bad && gmax > 0) {
+        if (!bad && gmax > 0 && local->pieces) {
+            g->pieces = local->pieces; g->pieces_of = local->pieces_of; local->pieces = nullptr; local->pieces_of = nullptr;
+            g->l_logN = local->logN; g->l_stride = local->stride; g->g_max = gmax;
+        } else if (!bad && gmax > 0) {
             g->side = std::move(local->side); g->side_of = local->side_of; local->side_of = nullptr;
             g->l_logN = local->logN; g->l_stride = local->stride; g->g_max = gmax;
         } else { g->g_perm.release(); g->g_n.release(); g->g_base.release(); }      // (the two-read assemble takes it)

@@ -109,6 +109,17 @@ struct skx_dictset {
     skx::DictView view() const { return skx::DictView{words.p, off.p, ucnt.p, n, logB, wide() ? wh.bits : hp.bits, sidx.p, sb}; }
 };
 
+// An array as MergeSkaDict::append leaves it (skx_append.hip): per row block and sample a piece of 4-bit base sets indexed by first-seen
+// rank; the rows x samples cells in the order of H are produced from the pieces on demand (all rows, a window, or the rows a filter keeps).
+struct skx_pieces {
+    skx::DevBuf<uint8_t> data;       // [1 << logQ][S][cap / 2]
+    skx::DevBuf<uint16_t> plen;      // [1 << logQ][S] ranks a piece holds
+    skx::DevBuf<uint16_t> perm;      // [1 << logQ][cap] first-seen rank -> row of the block (0xFFFF: none)
+    skx::DevBuf<uint32_t> nrank;     // [1 << logQ] ranks handed out
+    uint32_t cap = 0; int logQ = 0;
+    std::vector<uint64_t> sample_cells;   // SkaDict::ksize per sample
+};
+
 struct skx_keyset {
     skx_ctx *ctx = nullptr;
     int k = 0, rc = 0, logN = 0;
@@ -134,17 +145,11 @@ struct skx_keyset {
     skx::DevBuf<uint32_t> g_n;       // [1 << l_logN]
     skx::DevBuf<uint64_t> g_base;    // [1 << l_logN]
     int l_logN = -1; uint32_t l_stride = 0, g_max = 0;
-};
-
-// An array as MergeSkaDict::append leaves it (skx_append.hip): per row block and sample a piece of 4-bit base sets indexed by first-seen
-// rank; the rows x samples cells in the order of H are produced from the pieces on demand (all rows, a window, or the rows a filter keeps).
-struct skx_pieces {
-    skx::DevBuf<uint8_t> data;       // [1 << logQ][S][cap / 2]
-    skx::DevBuf<uint16_t> plen;      // [1 << logQ][S] ranks a piece holds
-    skx::DevBuf<uint16_t> perm;      // [1 << logQ][cap] first-seen rank -> row of the block (0xFFFF: none)
-    skx::DevBuf<uint32_t> nrank;     // [1 << logQ] ranks handed out
-    uint32_t cap = 0; int logQ = 0;
-    std::vector<uint64_t> sample_cells;   // SkaDict::ksize per sample
+    // or the pieces of an append pass over `pieces_of` (skx_keyset_union_notes on assemblies kept as extracted): they travel like the notes
+    skx_pieces *pieces = nullptr; const skx_dictset *pieces_of = nullptr;
+    skx_keyset() = default;
+    skx_keyset(const skx_keyset &) = delete; skx_keyset &operator=(const skx_keyset &) = delete;
+    ~skx_keyset() { delete pieces; }
 };
 
 struct skx_array {

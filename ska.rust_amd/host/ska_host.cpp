@@ -485,7 +485,7 @@ int sharded_array(skx_ctx *ctx, skx_comm *comm, const skh_job *job, uint64_t *lo
         for (int q = 0; q < world; q++)
             if (st[q]) { skx_dictset_free(ds); skx_set_last_error(("rank " + std::to_string(q) + " could not build its samples").c_str()); return SKX_EINVAL; }
     }
-    { Phase p("sharded.local_union"); r = skx_keyset_union(ctx, ds, &ks); }
+    { Phase p("sharded.local_union"); r = skx_keyset_union_notes(ctx, ds, &ks); }      // (assemblies: the append pass -- its pieces travel with the key set)
     if (r == SKX_OK) { Phase p("sharded.key_table_exchange"); r = skx_keyset_allgather(comm, ks, &rows); }
     if (ks) skx_keyset_free(ks);
     if (r != SKX_OK) { skx_dictset_free(ds); return r; }
