@@ -1405,7 +1405,6 @@ extern "C" int skx_array_assemble(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows
         const bool global = rows->g_perm.p != nullptr;
         if (global || rows->logN == rows->pieces->logQ) {
             skx_pieces *pc = rows->pieces; rows->pieces = nullptr; rows->pieces_of = nullptr;
-            StageTimer t(ctx, &ctx->tm.assemble);
             return array_over_pieces(ctx, d, rows, pc, global ? rows : nullptr, names, out);
         }
     }
@@ -1752,6 +1751,7 @@ static int array_over_pieces(skx_ctx *ctx, const skx_dictset *d, skx_keyset *ks,
         launch_gather_keys(src->stage.p, src->stride, g ? g->ncnt.p : blk->ncnt.p, g ? g->roff.p : blk->roff.p, 1 << src->logN, a->keys.p, 0, src->hp, st);
         if (g) { SKX_TRY(a->present.zero(st)); SKX_TRY(a->unambig.zero(st)); SKX_TRY(a->mask.zero(st)); SKX_TRY(a->vcount.zero(st)); }
         // the rows' statistics, counted from the pieces
+        StageTimer t(ctx, &ctx->tm.assemble);
         launch_pieces_stats(pc->data.p, pc->plen.p, pc->perm.p, pc->nrank.p, blk->ncnt.p, blk->roff.p, pc->cap, S, 1 << logQ, a->present.p, a->unambig.p, a->mask.p, a->vcount.p, st);
     }
     SKX_HIP(hipStreamSynchronize(st));
