@@ -138,6 +138,32 @@ def test_merge_array_many_samples(E, k, rc):
     assert list(ga.sample_kmers()) == [int(x) for x in (oa.export()[1] != ord("-")).sum(axis=0)]
 
 
+@pytest.mark.parametrize("k", [31, 21])
+def test_append_pass_gives_way_to_the_sorted_path_on_repeats(E, k, capfd, monkeypatch):
+    """A sample that is one repeat puts nearly every word of a load into one row block: the append pass's queue cannot take it, the launch
+    fails, and the merge must come out of the sorted path unharmed (same array as the oracle; ambiguity codes where copies differ).  A batch
+    of ordinary samples beside it goes through the append pass (SKX_DEBUG tells which)."""
+    rng = np.random.default_rng(40 + k)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    anc = acgt[rng.integers(0, 4, size=60_000)]
+    ordinary = []
+    for i in range(20):
+        s = anc.copy()
+        pos = rng.integers(0, len(s), size=30)
+        s[pos] = acgt[rng.integers(0, 4, size=30)]
+        ordinary.append([bytes(s[:30_000]), bytes(s[30_000:])])
+    monkeypatch.setenv("SKX_DEBUG", "1")
+    ga, oa = build_both(E, ordinary, k, True)
+    assert as_map(*ga.export()) == as_map(*oa.export())
+    assert "append: logQ=" in capfd.readouterr().err and True
+    unit = acgt[rng.integers(0, 4, size=70)].tobytes()
+    odd = ordinary[:6] + [[b"A" * 120_000, unit * 1500], [b"AC" * 50_000 + bytes(anc[:5000])]]
+    ga, oa = build_both(E, odd, k, True)
+    assert ga.names == oa.names and ga.nkmers == oa.nkmers
+    assert as_map(*ga.export()) == as_map(*oa.export())
+    assert list(ga.sample_kmers()) == [int(x) for x in (oa.export()[1] != ord("-")).sum(axis=0)]
+
+
 FILTERS = [(ft, amb, mask, gaps) for ft in range(4) for amb in (False, True) for mask in (False, True) for gaps in (False, True)]
 
 
