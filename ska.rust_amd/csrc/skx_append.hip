@@ -704,50 +704,60 @@ __global__ __launch_bounds__(64 * PR_WAVES) void pieces_rows_kernel(PiecesRowsAr
     const uint64_t ocol = KEPT ? k0 : r0 - a.col_base;                        // first output column of the block
     const uint32_t shift = (uint32_t)(ocol & 3u);
     const uint32_t ndw = (nout + shift + 3u) / 4u;                            // aligned dwords that hold the block's cells
-    for (uint32_t i = tid; i < cap + 16u; i += blockDim.x) s_src[i] = (uint16_t)cap;
-    __syncthreads();
     const uint16_t *pj = a.perm + j * (uint64_t)cap;
     const uint32_t nr = a.nrank[j];
-    for (uint32_t r = tid; r < nr; r += blockDim.x) {
-        const uint32_t p = pj[r];
-        if (p == 0xFFFFu || p >= n) continue;
-        if (!KEPT) s_src[shift + p] = (uint16_t)r;
-        else if (a.keep[r0 + p] == 1) s_src[shift + (uint32_t)(a.kpos[r0 + p] - k0)] = (uint16_t)r;
-    }
-    __syncthreads();
     const int S = a.n_samples;
     const int s_lo = blockIdx.y * a.samples_per_wg, s_hi = s_lo + a.samples_per_wg < S ? s_lo + a.samples_per_wg : S;
     uint32_t *pc = s_piece + (size_t)wv * (cap / 8 + 4);
     const unsigned char *pcb = reinterpret_cast<const unsigned char *>(pc);
     const uint32_t nrw = (nr + 7u) / 8u;                                      // piece words that ranks of this block can name
     if (lane < 4) pc[cap / 8 + lane] = 0u;                                    // (rank `cap`: no cell)
-    for (int s = s_lo + wv; s < s_hi; s += PR_WAVES) {
-        const uint32_t pl = a.plen[j * (uint64_t)S + s];
-        const uint32_t plw = (pl + 7u) / 8u;
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.pieces + (j * (uint64_t)S + s) * (cap / 2));
-        for (uint32_t i = lane; i < nrw; i += 64) pc[i] = i < plw ? src[i] : 0u;      // ranks handed out after this sample: no cell
-        __builtin_amdgcn_wave_barrier();
-        unsigned char *dst = a.out + (uint64_t)s * a.pitch + (ocol - shift);
-        for (uint32_t v = lane; v < ndw; v += 64) {
-            const uint2 rr = *reinterpret_cast<const uint2 *>(s_src + 4u * v);      // four ranks
-            const uint32_t ra = rr.x & 0xFFFFu, rb = rr.x >> 16, rc = rr.y & 0xFFFFu, rd = rr.y >> 16;
-            const uint32_t na = ((uint32_t)pcb[ra >> 1] >> ((ra & 1u) * 4u)) & 15u, nb = ((uint32_t)pcb[rb >> 1] >> ((rb & 1u) * 4u)) & 15u;
-            const uint32_t nc = ((uint32_t)pcb[rc >> 1] >> ((rc & 1u) * 4u)) & 15u, nd = ((uint32_t)pcb[rd >> 1] >> ((rd & 1u) * 4u)) & 15u;
-            uint32_t m = na | (nb << 8) | (nc << 16) | (nd << 24);
-            uint32_t word = ap_iupac4(m);
-            if (a.mask_ambig) {                                                 // cells of two bases and more are written as 'N'
-                const uint32_t y = m & (m - ((m | (m >> 1) | (m >> 2) | (m >> 3)) & 0x01010101u));      // every byte without its lowest bit
-                const uint32_t amb = ((y | (y >> 1) | (y >> 2) | (y >> 3)) & 0x01010101u) * 0xFFu;
-                word = (word & ~amb) | (0x4E4E4E4Eu & amb);
-            }
-            const bool head = v == 0 && shift != 0, tail = v == ndw - 1 && ((nout + shift) & 3u) != 0;
-            if (!head && !tail) *reinterpret_cast<uint32_t *>(dst + 4u * v) = word;
-            else {
-#pragma unroll
-                for (int b = 0; b < 4; b++) { const int c = (int)(4u * v + b) - (int)shift; if (c >= 0 && (uint32_t)c < nout) dst[4u * v + b] = (unsigned char)(word >> (8 * b)); }
-            }
+    // The block's output columns are taken `cap` at a time (one pass when they are the block's own rows; the rows of a sharded job's hash
+    // range -- all ranks' rows, most of them without a cell here -- may be several times as many).  sc = shift + column: the index into the
+    // aligned dwords.
+    for (uint32_t t0 = 0; t0 < nout + shift; t0 += cap) {
+        for (uint32_t i = tid; i < cap + 16u; i += blockDim.x) s_src[i] = (uint16_t)cap;
+        __syncthreads();
+        for (uint32_t r = tid; r < nr; r += blockDim.x) {
+            const uint32_t p = pj[r];
+            if (p == 0xFFFFu || p >= n) continue;
+            uint32_t sc;
+            if (!KEPT) sc = shift + p;
+            else if (a.keep[r0 + p] == 1) sc = shift + (uint32_t)(a.kpos[r0 + p] - k0);
+            else continue;
+            if (sc >= t0 && sc < t0 + cap) s_src[sc - t0] = (uint16_t)r;
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+        const uint32_t v_lo = t0 / 4u, v_hi = (t0 + cap) / 4u < ndw ? (t0 + cap) / 4u : ndw;      // this pass's dwords
+        for (int s = s_lo + wv; s < s_hi; s += PR_WAVES) {
+            const uint32_t pl = a.plen[j * (uint64_t)S + s];
+            const uint32_t plw = (pl + 7u) / 8u;
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(a.pieces + (j * (uint64_t)S + s) * (cap / 2));
+            for (uint32_t i = lane; i < nrw; i += 64) pc[i] = i < plw ? src[i] : 0u;      // ranks handed out after this sample: no cell
+            __builtin_amdgcn_wave_barrier();
+            unsigned char *dst = a.out + (uint64_t)s * a.pitch + (ocol - shift);
+            for (uint32_t v = v_lo + lane; v < v_hi; v += 64) {
+                const uint2 rr = *reinterpret_cast<const uint2 *>(s_src + 4u * (v - v_lo));      // four ranks
+                const uint32_t ra = rr.x & 0xFFFFu, rb = rr.x >> 16, rc = rr.y & 0xFFFFu, rd = rr.y >> 16;
+                const uint32_t na = ((uint32_t)pcb[ra >> 1] >> ((ra & 1u) * 4u)) & 15u, nb = ((uint32_t)pcb[rb >> 1] >> ((rb & 1u) * 4u)) & 15u;
+                const uint32_t nc = ((uint32_t)pcb[rc >> 1] >> ((rc & 1u) * 4u)) & 15u, nd = ((uint32_t)pcb[rd >> 1] >> ((rd & 1u) * 4u)) & 15u;
+                uint32_t m = na | (nb << 8) | (nc << 16) | (nd << 24);
+                uint32_t word = ap_iupac4(m);
+                if (a.mask_ambig) {                                                 // cells of two bases and more are written as 'N'
+                    const uint32_t y = m & (m - ((m | (m >> 1) | (m >> 2) | (m >> 3)) & 0x01010101u));      // every byte without its lowest bit
+                    const uint32_t amb = ((y | (y >> 1) | (y >> 2) | (y >> 3)) & 0x01010101u) * 0xFFu;
+                    word = (word & ~amb) | (0x4E4E4E4Eu & amb);
+                }
+                const bool head = v == 0 && shift != 0, tail = v == ndw - 1 && ((nout + shift) & 3u) != 0;
+                if (!head && !tail) *reinterpret_cast<uint32_t *>(dst + 4u * v) = word;
+                else {
+#pragma unroll
+                    for (int b = 0; b < 4; b++) { const int c = (int)(4u * v + b) - (int)shift; if (c >= 0 && (uint32_t)c < nout) dst[4u * v + b] = (unsigned char)(word >> (8 * b)); }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
     }
 }
 void launch_pieces_rows(const PiecesRowsArgs &a, uint32_t n_blocks, hipStream_t st)

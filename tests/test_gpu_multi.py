@@ -202,3 +202,28 @@ def test_selftest_two_ranks_and_one(tmp_path):
     r = subprocess.run([ska, "nk", os.path.join(ROOT, "tests", "golden", "input", "merge.skf")], capture_output=True, text=True, timeout=120,
                        env=dict(os.environ, SKX_WORLD="2", SKX_RANK="0", SKX_DEVICE="0"))
     assert r.returncode == 0, r.stderr[-1500:]
+
+
+def test_ranks_with_unrelated_samples_equal_single_process(tmp_path):
+    """Three ranks whose samples share nothing: the rows of a rank's hash range are three times its own (its pieces are laid over all ranks'
+    rows in several passes of the rows kernel), most cells of its columns are '-'.  align and distance == the single process, byte for byte."""
+    import synth
+    files = []
+    for i in range(6):
+        anc = synth.ancestor(150_000, seed=100 + i // 2)               # pairs of related samples; the pairs are unrelated
+        p = str(tmp_path / f"u{i}.fa")
+        synth.to_fasta(synth.sample_stream(anc, i % 2, 2, private_snps=40, shared_snps=5, seed=100 + i // 2), p)
+        files.append(p)
+    lst = str(tmp_path / "list.txt")
+    with open(lst, "w") as f:
+        for i, p in enumerate(files):
+            f.write(f"u{i}\t{p}\n")
+    wd = str(tmp_path)
+    for cmd, out, extra in (("align", "aln", ["--min-freq", "0.3", "--filter", "no-filter"]), ("distance", "dist", ["--min-freq", "0"])):
+        r = subprocess.run([SKA, cmd, "-f", lst, "-o", f"one.{out}", "-k", "31", *extra], cwd=wd, capture_output=True, timeout=300)
+        if r.returncode != 0:                                            # (align / distance of sequence files in one process go through build first)
+            assert subprocess.run([SKA, "build", "-f", lst, "-o", "one", "-k", "31"], cwd=wd, capture_output=True, timeout=300).returncode == 0
+            r = subprocess.run([SKA, cmd, "one.skf", "-o", f"one.{out}", *extra], cwd=wd, capture_output=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-800:]
+        _ska_ranks(3, cmd, "-f", lst, "-o", f"multi.{out}", "-k", "31", *extra, cwd=wd)
+        assert open(os.path.join(wd, f"multi.{out}"), "rb").read() == open(os.path.join(wd, f"one.{out}"), "rb").read(), cmd
