@@ -1686,7 +1686,8 @@ static int append_pass(skx_ctx *ctx, skx_dictset *d, std::unique_ptr<skx_keyset>
         std::unique_ptr<skx_pieces> pc(new skx_pieces());
         pc->cap = cap; pc->logQ = logQ;
         SKX_TRY(ks->stage.alloc(nsub * cap)); SKX_TRY(ks->ncnt.alloc(nsub));
-        SKX_TRY(pc->data.alloc(nsub * (uint64_t)S * (cap / 2))); SKX_TRY(pc->plen.alloc(nsub * (uint64_t)S + 2)); SKX_TRY(pc->perm.alloc(nsub * cap)); SKX_TRY(pc->nrank.alloc(nsub));
+        if (pc->data.alloc(nsub * (uint64_t)S * (cap / 2)) != SKX_OK) return SKF_NOT_TAKEN;      // (no room for the pieces: the sorted path holds rows + dictionaries instead)
+        SKX_TRY(pc->plen.alloc(nsub * (uint64_t)S + 2)); SKX_TRY(pc->perm.alloc(nsub * cap)); SKX_TRY(pc->nrank.alloc(nsub));
         SKX_TRY(d_flag.zero(st));
         aa.logQ = logQ; aa.nslots = nslots; aa.cap = cap;
         // persistent launch: one workgroup per CU, whole groups of a region's readers (8 XCDs x A) -- when the blocks divide that way
