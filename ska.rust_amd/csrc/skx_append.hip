@@ -11,21 +11,24 @@
 //   * the block's rows live in an order-preserving LDS hash table (slot = monotone function of H, linear probing without wrap); an entry is
 //     {top 32 of the low hash bits ; (the rest << 14) | first-seen rank + 1}: the rank a row got when it was first inserted is its column in
 //     everything the pass writes while the final row order (the order of H) is not known yet;
-//   * a region holds the words of A = 2^(logQ - logB) row blocks.  The A workgroups of a region run on the same XCD at the same time
-//     (blockIdx -> XCD is b % 8), each reads the whole region and keeps its share: the first reader takes a line from HBM, the others find it
-//     in that XCD's L2 (or the memory-side cache).  A wave reads 512 words at a time (the next 512 are on their way meanwhile), keeps its
-//     block's, and compacts them into a queue of its own so that the look-ups run with full waves: 64 words at a time against the home slot
-//     and its successor; the few words that sit further from home go to a second queue and through the insert loop 64 at a time as well
-//     (looked up in place, they would make every batch wait for its unluckiest lane);
-//   * a sample's cells of the block are OR-ed into the wave's row buffer of 4-bit base sets indexed by rank (LDS atomics; the returned old value
-//     tells a first sighting -- counted in the row's statistics and the sample's k-mer count -- from a repeat, which is where ska_dict.rs folds);
+//   * a region holds the words of A = 2^(logQ - logB) row blocks.  The launch is persistent (one workgroup per CU, a row block per round); the A
+//     blocks of a region are taken by A workgroups of the same XCD (blockIdx -> XCD is b % 8) in the same round, which start it together: each
+//     reads the whole region and keeps its share, and a line is fetched from HBM once if its readers come by while it is in that XCD's L2.  A
+//     wave reads 1 024 words at a time (the next chunk on its way meanwhile), keeps its block's, and compacts them into a queue of its own so
+//     that the look-ups run with full waves, 128 words at a time (two per lane): a byte per slot tells where around home the key may be, then
+//     that one entry is read and compared in full; the ~1 % that are not found this way go to a second queue and through the insert loop 64
+//     at a time, four slots per step (looked up in place, they would make every batch wait for its unluckiest lane);
+//   * a sample's cells of the block are OR-ed into the wave's row buffer of 4-bit base sets indexed by rank (one LDS atomic without a return
+//     value per word: a repeated split k-mer folds here, which is where ska_dict.rs:92-101 folds);
 //   * the row buffer leaves as the sample's *piece* of the block: plen ranks, two per byte, at a fixed place (pieces[(j * S + s) * cap / 2]).
 //     Ranks beyond plen were handed out later: the cell is '-'.  The rows x samples matrix in the order of H is produced from the pieces
 //     by pieces_rows_kernel (all rows, a window of row blocks, or only the rows a filter keeps) -- 1 byte per cell there, 4 bits and no cell
 //     for unseen rows here;
-//   * per row the pass keeps a present count and the union of the bases seen (two LDS atomics per first sighting); rows where a cell is
-//     ambiguous (a palindrome's W / S, or a sample that folded two bases) are marked and get their statistics from the finished pieces;
-//   * when the last sample is in, the table is emitted in key order: the block's row keys, perm (rank -> row of the block) and the row statistics.
+//   * what the cells add up to per row (present, unambiguous, code set: merge_ska_array.rs:139-186) is counted from the finished pieces by
+//     pieces_stats_kernel, nibble-parallel and without atomics; a sample's k-mer count, when asked for, by pieces_cells_kernel;
+//   * when the last sample of a round is in, the table is emitted in key order: the block's row keys and perm (rank -> row of the block).
+// Measurement builds: -DSKX_AP_PROF (cycle stamps and counters per phase), -DAP_X_NOBATCH / _NOFILTER / _NORECORD / _NOPROBE / _FAKE4 (the kernel with
+// one part left out: what showed that loads + filter + queues are 6.8 of its 24 ms; results are wrong by construction) -- tools/mkvariant.sh.
 #include "skx_device.h"
 #include <cstdlib>
 
