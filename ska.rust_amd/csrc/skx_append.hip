@@ -175,7 +175,10 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
         return rem == 0 ? 0u : (uint32_t)(((wlo >> 4) | (whi << 28)) << (32 - rem));
     };
     auto key_lo = [&](uint32_t wlo) -> uint32_t { return HI ? __builtin_amdgcn_ubfe(wlo, 4u, (uint32_t)lowb) << AP_RANK_BITS : 0u; };
-    auto key_fp = [&](uint32_t kh, uint32_t kl) -> uint32_t { const uint32_t v = ((kh ^ (kl >> AP_RANK_BITS)) * 0x9E3779B1u) >> 24; return v ? v : 255u; };      // 1..255
+    auto key_fp = [&](uint32_t kh, uint32_t kl) -> uint32_t {          // a byte of the key, 1..255 (0 = an empty slot)
+        const uint32_t v = HI ? kh & 0xFFu : ((kh ^ (kl >> AP_RANK_BITS)) * 0x9E3779B1u) >> 24;      // (the home slot comes from kh's top bits: its low byte is independent of it)
+        return v ? v : 255u;
+    };
     // the cell of (current sample, rank1 - 1) takes base set m4: one LDS atomic without a return value -- what the cells add up to per row (present,
     // unambiguous, code set) is counted from the finished pieces by pieces_stats_kernel, 4 bits per cell and no atomics, instead of here
     auto record = [&](uint32_t rank1, uint32_t m4) {
@@ -304,14 +307,20 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
     // assembly and waited for by hand: nothing else in the loop is a vector-memory load.
     u32x4 nxt[AP_CH], cur[AP_CH];
     auto issue = [&](uint64_t off, uint32_t cnt, uint32_t c) {
-        const uint64_t base = (uint64_t)(uintptr_t)(a.words + off);
-        const uint32_t last = cnt ? (cnt - 1u) >> 1 : 0u;
-#pragma unroll
-        for (int r = 0; r < AP_CH; r++) {
-            const uint32_t p = c * (64u * AP_CH) + 64u * r + (uint32_t)lane;      // pair index
-            const uint32_t vo = (p < last ? p : last) * 16u;
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(nxt[r]) : "v"(vo), "s"(base) : "memory");
-        }
+        // (no clamping of addresses: a chunk may reach past its region's fill -- the words there fail the fill test -- and past its capacity
+        // into the next region; the buffer ends in 8 KB of slack)
+        (void)cnt;
+        static_assert(AP_CH == 8, "the loads are written out for eight per chunk");
+        const uint64_t base = (uint64_t)(uintptr_t)(a.words + off) + (uint64_t)c * (64u * AP_CH * 16u), base2 = base + 4096u;
+        const uint32_t vo = (uint32_t)lane * 16u;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(nxt[0]) : "v"(vo), "s"(base) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(nxt[1]) : "v"(vo), "s"(base) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(nxt[2]) : "v"(vo), "s"(base) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(nxt[3]) : "v"(vo), "s"(base) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(nxt[4]) : "v"(vo), "s"(base2) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(nxt[5]) : "v"(vo), "s"(base2) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(nxt[6]) : "v"(vo), "s"(base2) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(nxt[7]) : "v"(vo), "s"(base2) : "memory");
     };
     auto region_of = [&](int smp, uint64_t &off, uint32_t &cnt) { const uint64_t rr = (uint64_t)smp * rstride + region; off = c_off[rr]; cnt = c_raw[rr]; };
     if (wv < S) {
