@@ -19,6 +19,8 @@ def run(tag, args):
     t = time.perf_counter(); r = subprocess.run([SKA, *args], cwd=td, capture_output=True, env=dict(os.environ, SKX_PHASES=ph)); dt = time.perf_counter() - t
     assert r.returncode == 0, r.stderr[-300:]
     p = json.load(open(ph))
+    if os.environ.get("SKX_DEBUG"):
+        print("".join("    " + l + "\n" for l in r.stderr.decode(errors="replace").splitlines() if l.startswith("[skx]")), end="")
     print(f"{tag} {dt:.3f} s  " + " ".join(f"{k.split('.')[-1]}={v:.3f}" for k, v in p.items() if v >= 0.02), flush=True)
 for rep in range(3):
     run("build ", ["build", "-f", "list.txt", "-o", "all", "-k", "31", "--threads", thr])
