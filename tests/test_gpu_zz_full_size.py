@@ -45,11 +45,10 @@ def thousand(tmp_path_factory):
     td = _shm(tmp_path_factory)
     anc = synth.ancestor(5_000_000, seed=1)
     n = 1000
-    files = []
-    for i in range(n):
-        p = os.path.join(td, f"g{i}.fa")
-        synth.to_fasta(synth.sample_stream(anc, i, n), p)
-        files.append(p)
+    files = [os.path.join(td, f"g{i}.fa") for i in range(n)]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=8) as pool:                 # numpy's copies and the file writes release the interpreter lock
+        list(pool.map(lambda i: synth.to_fasta(synth.sample_stream(anc, i, n), files[i]), range(n)))
     yield td, files
     shutil.rmtree(td, ignore_errors=True)
 
@@ -160,43 +159,18 @@ def test_config2_hundred_assemblies_through_the_executable(E, thousand):
     assert np.array_equal(cols(g), cols(o))
 
 
-def test_config5_one_isolate_at_size(E, thousand):
+def test_config5_one_isolate_at_size(E, isolates):
     """BASELINE.json configs[4] shape, one isolate at its real size: 2 x 150 bp reads at 50x of a 5 Mbp genome (833 334 pairs, 252 M
-    stream bytes), 0.5 % substitution errors, per-cycle Phred profile; k = 41 (128-bit keys), --min-count 5, --qual-filter strict
-    --min-qual 20.  The engine's own partition kernels (skx_reads2.hip) against the oracle's sequential KmerFilter, exactly."""
-    import synth
-    td, _ = thousand
-    glen, rl, cov = 5_000_000, 150, 50.0
-    anc = synth.ancestor(glen, seed=1)
-    rng = np.random.default_rng([1, 99, 0])
-    g = synth.sample_bases(anc, 0, 1000)
-    npairs = int(cov * glen / rl / 2)
-    comp = np.zeros(256, np.uint8)
-    for a, b in zip(b"ACGT", b"TGCA"):
-        comp[a] = b
-    files = []
-    for mate in (0, 1):
-        start = rng.integers(0, glen - rl, size=npairs)
-        reads = g[start[:, None] + np.arange(rl)[None, :]]
-        rev = rng.random(npairs) < 0.5
-        reads[rev] = comp[reads[rev][:, ::-1]]
-        err = rng.random(reads.shape) < 0.005
-        reads[err] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=int(err.sum()))]
-        prof = np.clip(38 - (np.arange(rl) // 10), 2, 40)
-        q = np.clip(prof[None, :] + rng.integers(-6, 3, size=reads.shape), 2, 41).astype(np.uint8) + 33
-        q[err] = 33 + 8
-        rec = np.empty((npairs, 3 + rl + 3 + rl + 1), np.uint8)            # "@r\n" seq "\n+\n" qual "\n"
-        rec[:, 0:3] = np.frombuffer(b"@r\n", np.uint8)
-        rec[:, 3:3 + rl] = reads
-        rec[:, 3 + rl:6 + rl] = np.frombuffer(b"\n+\n", np.uint8)
-        rec[:, 6 + rl:6 + 2 * rl] = q
-        rec[:, -1] = 10
-        p = os.path.join(td, f"iso_{mate + 1}.fastq")
-        rec.tofile(p)
-        files.append(p)
+    stream bytes), 0.5 % substitution errors, per-cycle Phred profile (synth.write_read_pair: isolate 0 of the module's read sets);
+    k = 41 (128-bit keys), --min-count 5, --qual-filter strict --min-qual 20.  The engine's own partition kernels (skx_reads2.hip)
+    against the oracle's sequential KmerFilter, exactly.  (The oracle's three dictionaries are computed on threads of their own: 20 s
+    each on one core.)"""
+    from concurrent.futures import ThreadPoolExecutor
+    files = list(isolates[2][0])
     qo = ora.qual(5, 20, ora.QUAL_STRICT)
-    og = ora.Dict.from_files(41, files[0], files[1], True, qo)
-    ok, ob = og.export()
+    pool = ThreadPoolExecutor(max_workers=3)
+    want = {k: pool.submit(lambda k=k: ora.Dict.from_files(k, files[0], files[1], True, qo).export()) for k in (41, 31, 17)}
+    ok, ob = want[41].result()
     ds = E.DictSet.from_files([(files[0], files[1])], 41, True, E.qual(5, 20, E.QUAL_STRICT), threads=1)
     gk, gb = ds.export(0)
     assert 4_900_000 < len(gk) < 5_100_000
@@ -212,8 +186,7 @@ def test_config5_one_isolate_at_size(E, thousand):
     # smaller k = more gated windows per read: k = 31 runs the 48-word partitions at their tighter head-room, k = 17 (the reference's
     # default) the 24-word partitions -- both against the oracle's sequential filter as well
     for k in (31, 17):
-        og = ora.Dict.from_files(k, files[0], files[1], True, qo)
-        ok, ob = og.export()
+        ok, ob = want[k].result()
         dsk = E.DictSet.from_files([(files[0], files[1])], k, True, E.qual(5, 20, E.QUAL_STRICT), threads=1)
         gk, gb = dsk.export(0)
         assert len(gk) > 4_000_000 and np.array_equal(gk["lo"], ok["lo"]) and np.array_equal(gk["hi"], ok["hi"]) and np.array_equal(gb, ob), k
@@ -248,7 +221,13 @@ def test_config5_flow_eight_isolates_at_size(E, isolates):
     opts = ["-k", "41", "--min-count", "5", "--min-qual", "20", "--qual-filter", "strict"]
     r = subprocess.run([SKA, "build", "-f", lst, "-o", "c5", "--threads", "16", *opts], cwd=td, capture_output=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-800:]
-    want = ora.Array.build([(n, a, b) for n, (a, b) in zip(names, pairs)], k=41, rc=True, q=ora.qual(5, 20, ora.QUAL_STRICT), threads=8)
+    # (the oracle's dictionaries on one thread each, then its append / merge and MergeSkaArray::new: build_and_merge itself takes one thread
+    # for eight samples -- merge_ska_dict.rs:384 -- and 20 s per isolate)
+    from concurrent.futures import ThreadPoolExecutor
+    qo = ora.qual(5, 20, ora.QUAL_STRICT)
+    with ThreadPoolExecutor(max_workers=len(pairs)) as pool:
+        dicts = list(pool.map(lambda ab: ora.Dict.from_files(41, ab[0], ab[1], True, qo), pairs))
+    want = ora.Array.from_dicts(dicts, names)
     got = ora.Array.load(os.path.join(td, "c5.skf"))                  # the engine's file through the oracle's reader
     assert got.names == names
     got.sort_rows(); want.sort_rows()
