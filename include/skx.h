@@ -138,11 +138,6 @@ int  skx_array_load(skx_ctx *ctx, const char *path, int want_bits, skx_array **o
  * skx_array_load + skx_array_filter inside the call. */
 typedef struct { double min_freq; int32_t filter_ambig_as_missing, filter_type, mask_ambig, ignore_const_gaps, two_stage; } skx_filter_spec;
 int  skx_array_load_filtered(skx_ctx *ctx, const char *path, const skx_filter_spec *f, skx_array **out, int64_t *removed, int64_t *constant);
-/* Optional hint before skx_array_load_filtered(path): open the file now and start reading what needs no device -- its header, its chunk
- * directory (io_utils.rs:97-109's decoder, framing only) and the stored counts behind the variants -- on the engine's own threads.  Takes
- * no context, returns at once, always SKX_OK (whatever is wrong with the file is reported by the load): a caller announces the file and
- * creates its context meanwhile (`ska align x.skf`: the 0.2 s of skx_ctx_create no longer precede the read). */
-int  skx_file_prefetch(const char *path);
 /* construct from host data (row-major [n_rows, n_samples] as in the .skf) */
 int  skx_array_from_host(skx_ctx *ctx, int k, int rc, const char *const *names, int n_samples,
                          const skx_key *keys, const uint8_t *variants, const uint64_t *variant_count /* NULL: recount */,

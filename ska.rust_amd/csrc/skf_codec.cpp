@@ -285,8 +285,7 @@ struct FrameReader {
     std::atomic<size_t> n_pub{0};
     std::atomic<int> walk_state{0};
     std::thread walker;
-    std::vector<std::thread> populators;           // map the file's pages ahead of the walk (open_async)
-    ~FrameReader() { for (auto &t : populators) if (t.joinable()) t.join(); if (walker.joinable()) walker.join(); }
+    ~FrameReader() { if (walker.joinable()) walker.join(); }
     size_t published() const { return n_pub.load(std::memory_order_acquire); }
     bool walking() const { return walk_state.load(std::memory_order_acquire) == 1; }
     bool wait_for(size_t idx)                       // chunk idx published?  (false: the walk ended before it)
@@ -363,19 +362,6 @@ struct FrameReader {
         threads = nthreads;
         if (!raw.open(path, false)) { err = "open"; return false; }
         chunks.reserve(raw.size() / 512 + 4096);         // virtual until used; a chunk of 64 KB rarely compresses below 3 KB
-        // the walk touches every page of the file (a chunk of this data is about one page long: 700 000 faults, one after another, are most
-        // of its 0.23 s): a few threads map the pages in bulk ahead of it, each its part of the file from the front
-#ifdef MADV_POPULATE_READ
-        if (raw.size() >= (64u << 20)) {
-            const size_t T = 4, step = 16u << 20;
-            for (size_t t = 0; t < T; t++) populators.emplace_back([this, t, T, step]() {
-                const size_t n = raw.size();
-                const size_t a = (n / T * t) & ~(size_t)4095, b = t + 1 == T ? n : (n / T * (t + 1)) & ~(size_t)4095;
-                for (size_t o = a; o < b; o += step)
-                    if (madvise((void *)(raw.data() + o), std::min(step, b - o), MADV_POPULATE_READ) != 0) return;
-            });
-        }
-#endif
         walk_state.store(1, std::memory_order_release);
         walker = std::thread([this]() { const bool ok = walk(); walk_state.store(ok ? 0 : 2, std::memory_order_release); });
         return true;

@@ -7,9 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
-#include <map>
 #include <memory>
-#include <mutex>
 #include <numeric>
 #include <thread>
 #include <unistd.h>
@@ -485,43 +483,6 @@ static int load_then_filter(skx_ctx *ctx, const char *path, const skx_filter_spe
     return SKX_OK;
 }
 
-// A file announced before it is loaded (skx_file_prefetch): opened, its chunk directory being walked and its stored counts being parsed on
-// their threads -- none of which needs the device, so a caller announces the file first and creates its context meanwhile.
-namespace {
-struct Prefetched {
-    std::unique_ptr<SkfFile> sf; int open_rc = SKX_OK;
-    std::vector<uint32_t> counts; int tail_rc = SKX_OK; std::string tail_err; std::thread tail;
-    ~Prefetched() { if (tail.joinable()) tail.join(); }
-};
-std::mutex g_prefetch_mu;
-std::map<std::string, std::unique_ptr<Prefetched>> g_prefetched;
-std::unique_ptr<Prefetched> take_prefetched(const char *path)
-{
-    std::lock_guard<std::mutex> lk(g_prefetch_mu);
-    auto it = g_prefetched.find(path);
-    if (it == g_prefetched.end()) return nullptr;
-    std::unique_ptr<Prefetched> e = std::move(it->second);
-    g_prefetched.erase(it);
-    return e;
-}
-}
-extern "C" int skx_file_prefetch(const char *path)
-{
-    return skx_guarded([&]() -> int {
-    if (!path) { set_error("bad arguments"); return SKX_EINVAL; }
-    std::unique_ptr<Prefetched> e(new Prefetched());
-    e->sf.reset(new SkfFile());
-    e->open_rc = e->sf->open(path);
-    if (e->open_rc == SKX_OK && e->sf->m.n_rows && !e->sf->m.names.empty()) {
-        Prefetched *q = e.get(); SkfFile *fp = e->sf.get();                    // (the file object changes hands when the entry is taken; the entry itself stays where it is)
-        e->tail = std::thread([q, fp]() { q->tail_rc = fp->read_tail(q->counts); if (q->tail_rc != SKX_OK) q->tail_err = skx_last_error(); });
-    }
-    std::unique_ptr<Prefetched> old;
-    { std::lock_guard<std::mutex> lk(g_prefetch_mu); auto &slot = g_prefetched[path]; old = std::move(slot); slot = std::move(e); }
-    return SKX_OK;                                   // a hint: whatever is wrong with the file is reported by the call that loads it
-    });
-}
-
 extern "C" int skx_array_load_filtered(skx_ctx *ctx, const char *path, const skx_filter_spec *f, skx_array **out, int64_t *removed, int64_t *constant)
 {
     return skx_guarded([&]() -> int {
@@ -534,11 +495,9 @@ extern "C" int skx_array_load_filtered(skx_ctx *ctx, const char *path, const skx
     hipStream_t st = ctx->stream;
     struct Release { std::chrono::steady_clock::time_point t; bool on = false;
                      ~Release() { if (on) phase_add("load.release_buffers_file", std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count()); } } rel;
-    std::unique_ptr<Prefetched> pf = take_prefetched(path);
-    if (pf && (pf->open_rc != SKX_OK || !pf->tail.joinable())) pf.reset();              // not in the shape this path takes: opened again below, reported there
-    std::unique_ptr<SkfFile> sfp(pf ? pf->sf.release() : new SkfFile());
+    std::unique_ptr<SkfFile> sfp(new SkfFile());
     SkfFile &sf = *sfp;
-    if (!pf) {
+    {
         PhaseTimer t_open("load.open_header");
         const int r = sf.open(path);
         if (r == SKF_NOT_TAKEN) return load_then_filter(ctx, path, f, out, removed, constant);
@@ -548,9 +507,8 @@ extern "C" int skx_array_load_filtered(skx_ctx *ctx, const char *path, const skx
     if (!U || !S) return load_then_filter(ctx, path, f, out, removed, constant);
     SKX_TRY(check_k(sf.m.k));
     // the stored counts, parsed beside the device work
-    std::vector<uint32_t> counts_own; int tail_rc_own = SKX_OK; std::string tail_err_own;
-    std::vector<uint32_t> &counts = pf ? pf->counts : counts_own; int &tail_rc = pf ? pf->tail_rc : tail_rc_own; std::string &tail_err = pf ? pf->tail_err : tail_err_own;
-    std::thread tail = pf ? std::move(pf->tail) : std::thread([&]() { tail_rc = sf.read_tail(counts); if (tail_rc != SKX_OK) tail_err = skx_last_error(); });
+    std::vector<uint32_t> counts; int tail_rc = SKX_OK; std::string tail_err;
+    std::thread tail([&]() { tail_rc = sf.read_tail(counts); if (tail_rc != SKX_OK) tail_err = skx_last_error(); });
     struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join_tail{tail};
 
     const uint64_t upos = sf.upos_data, uend = upos + 2 * U * S, G = skf_group_chunks();
@@ -587,48 +545,25 @@ extern "C" int skx_array_load_filtered(skx_ctx *ctx, const char *path, const skx
         off_t opos;
         if (mappable_output_fd(expect_fd, &opos)) a->prealloc = std::make_shared<Preallocator>(expect_fd, opos);
     }
-    // a group = the next gmax chunks as far as the walker has come (it stays ahead of the device: ~3 M chunks/s against ~2.5 M decoded;
-    // at most gmax chunks: the buffers above are sized for gmax chunks of up to 64 KB each; a file framed in smaller chunks has more
-    // chunks than 64 KB pieces and simply takes more groups).  1 = the walk ended before the data section did.
-    struct Group { size_t g0 = 0, g1 = 0, f_lo = 0, f_hi = 0; bool last = false; };
-    auto plan = [&](size_t g0, Group &gr) -> int {
+    bool last_group = false;
+    for (size_t g0 = c0; !last_group; ) {
+        // the group's chunks as far as the walker has come (it stays ahead of the device: ~3 M chunks/s against ~2.5 M decoded)
+        // (at most gmax chunks: the buffers above are sized for gmax chunks of up to 64 KB each; a file framed in smaller chunks has more
+        // chunks than 64 KB pieces and simply takes more groups)
         (void)sf.wait_chunk(g0 + gmax - 1);
         size_t g1 = std::min<size_t>(sf.n_chunks(), g0 + gmax);
-        if (g1 <= g0) return 1;
-        bool last = false;
-        for (size_t c = g0; c < g1; c++) if (ch[c].uoff + ch[c].ulen >= uend) { g1 = c + 1; last = true; break; }
-        gr.g0 = g0; gr.g1 = g1; gr.last = last; gr.f_lo = ch[g0].off; gr.f_hi = ch[g1 - 1].off + ch[g1 - 1].len;
-        return 0;
-    };
-    auto walk_ended_early = [&]() -> int {
-        const int wr = sf.walk_result();
-        if (wr == SKF_NOT_TAKEN) { a->prealloc.reset(); a.reset(); return load_then_filter(ctx, path, f, out, removed, constant); }
-        if (wr != SKX_OK) return wr;
-        set_error("skf: truncated frame"); return SKX_EFORMAT;
-    };
-    // The file's bytes reach the device through two pinned buffers, filled a group ahead by a few threads: handed to the runtime as
-    // pageable memory (the mapped file) a group is staged by one thread of the runtime's at ~8 GB/s, and the whole load runs at that rate
-    struct Pin { uint8_t *p = nullptr; size_t cap = 0; ~Pin() { if (p) (void)hipHostFree(p); }
-                 bool need(size_t n) { if (n <= cap) return true; if (p) (void)hipHostFree(p); p = nullptr; cap = 0; const size_t c = n + n / 4 + 4096;
-                                       if (hipHostMalloc((void **)&p, c, hipHostMallocDefault) != hipSuccess) { p = nullptr; (void)hipGetLastError(); return false; } cap = c; return true; } } pin[2];
-    struct Team { std::vector<std::thread> th;
-                  void start(uint8_t *dst, const uint8_t *src, size_t n) { const size_t T = n >= (4u << 20) ? 4 : 1;
-                      for (size_t t = 0; t < T; t++) th.emplace_back([=]() { const size_t lo = n * t / T, hi = n * (t + 1) / T; memcpy(dst + lo, src + lo, hi - lo); }); }
-                  void join() { for (auto &t : th) t.join(); th.clear(); }
-                  ~Team() { join(); } } team;
-    const bool staged = !knob("no_pinned_load");
-    Group gr, gr_next;
-    if (plan(c0, gr)) return walk_ended_early();
-    int cp = 0;
-    bool in_pin = staged && pin[cp].need(gr.f_hi - gr.f_lo);
-    if (in_pin) { team.start(pin[cp].p, file + gr.f_lo, gr.f_hi - gr.f_lo); team.join(); }
-    for (;;) {
-        const size_t g0 = gr.g0, g1 = gr.g1, f_lo = gr.f_lo, f_hi = gr.f_hi;
-        const bool last_group = gr.last;
+        if (g1 <= g0) {                                                                      // the walk ended before the data section did
+            const int wr = sf.walk_result();
+            if (wr == SKF_NOT_TAKEN) { a->prealloc.reset(); a.reset(); return load_then_filter(ctx, path, f, out, removed, constant); }
+            if (wr != SKX_OK) return wr;
+            set_error("skf: truncated frame"); return SKX_EFORMAT;
+        }
+        for (size_t c = g0; c < g1; c++) if (ch[c].uoff + ch[c].ulen >= uend) { g1 = c + 1; last_group = true; break; }
+        const size_t f_lo = ch[g0].off, f_hi = ch[g1 - 1].off + ch[g1 - 1].len;
         if (f_hi - f_lo + 512 > src_cap) { src_cap = f_hi - f_lo + 512; SKX_TRY(d_src.alloc(src_cap)); }
         tab.resize(g1 - g0);
         for (size_t c = g0; c < g1; c++) tab[c - g0] = SnapChunk{ch[c].off - f_lo, ch[c].uoff, (uint32_t)ch[c].len, ch[c].ulen, ch[c].crc, ch[c].compressed ? 1u : 0u};
-        SKX_HIP(hipMemcpyAsync(d_src.p, in_pin ? pin[cp].p : file + f_lo, f_hi - f_lo, hipMemcpyHostToDevice, st));
+        SKX_HIP(hipMemcpyAsync(d_src.p, file + f_lo, f_hi - f_lo, hipMemcpyHostToDevice, st));
         SKX_HIP(hipMemcpyAsync(d_chunks.p, tab.data(), tab.size() * sizeof(SnapChunk), hipMemcpyHostToDevice, st));
         const uint64_t base_cell = (row_lo * S) & ~7ull;
         SKX_TRY(launch_skf_decode_cells(ctx->device, d_src.p, d_chunks.p, (uint32_t)(g1 - g0), upos, uend, d_scratch.p, d_cells[cur].p, base_cell, d_status.p, st));
@@ -651,15 +586,7 @@ extern "C" int skx_array_load_filtered(skx_ctx *ctx, const char *path, const skx
             const uint64_t nb = (row_done * S) & ~7ull, left = have_hi - row_done * S;
             if (left) SKX_HIP(hipMemcpyAsync(d_cells[cur ^ 1].p + (row_done * S - nb), d_cells[cur].p + (row_done * S - base_cell), left, hipMemcpyDeviceToDevice, st));
         }
-        // the next group's bytes into the other pinned buffer while the device works on this one
-        int next_rc = 0; bool next_pin = false;
-        if (!last_group) {
-            next_rc = plan(g1, gr_next);
-            if (!next_rc && staged && (next_pin = pin[cp ^ 1].need(gr_next.f_hi - gr_next.f_lo))) team.start(pin[cp ^ 1].p, file + gr_next.f_lo, gr_next.f_hi - gr_next.f_lo);
-        }
         SKX_HIP(hipStreamSynchronize(st));                                                   // gk; tab / d_src are reused
-        team.join();
-        if (next_rc) return walk_ended_early();
         if (kept + gk > cap - 256) {                                                        // more rows survive than guessed: a wider matrix
             const uint64_t ncap = pitch_for(std::max((kept + gk) * 2, cap * 2));
             DevBuf<uint8_t> nm; SKX_TRY(nm.alloc(S * ncap));
@@ -670,8 +597,7 @@ extern "C" int skx_array_load_filtered(skx_ctx *ctx, const char *path, const skx
         if (gk) launch_compact_rm(in, S, nr, keep.p + row_lo, pos.p, a->matrix.p, cap, kept, f->two_stage ? 0 : f->mask_ambig, st);
         kept += gk;
         row_lo = row_done; cur ^= 1;
-        if (last_group) break;
-        gr = gr_next; cp ^= 1; in_pin = next_pin;
+        g0 = g1;
     }
     {   // framing errors anywhere in the file
         const int wr = sf.walk_result();

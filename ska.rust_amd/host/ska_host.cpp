@@ -913,8 +913,6 @@ extern "C" int skh_main(int argc, char **argv)
         world = env_world > 0 ? env_world : 1; rank = env_rank;
         if (rank < 0 || rank >= world) return fail("SKX_RANK outside SKX_WORLD");
     }
-    // one .skf to align or to take distances of: the file is opened and walked while the device context comes up
-    if (!multi && (cmd == "align" || cmd == "distance") && a.pos.size() == 1 && !a.has("-f")) (void)skx_file_prefetch(a.pos[0].c_str());
     skx_ctx *ctx = nullptr;
     const int device = getenv("SKX_DEVICE") ? atoi(getenv("SKX_DEVICE")) : getenv("SKX_LOCAL_RANK") ? atoi(getenv("SKX_LOCAL_RANK")) : rank;
     if (skx_ctx_create(device, &ctx) != SKX_OK) return engine_fail();
