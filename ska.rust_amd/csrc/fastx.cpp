@@ -284,6 +284,74 @@ int stream_fastq_file(const char *path, const std::function<int(int which, const
     return SKX_OK;
 }
 
+// ---- read sets as bit planes (the reader threads of a batch of read sets: 5 bits per position cross PCIe instead of two bytes) ----
+// A sequence line as three planes, one 32-bit word per 32 bases, bits beyond the line zero: lo / hi = bits 1 / 2 of the byte (the code
+// encode_base gives: A 0, C 1, T 2, G 3 -- bit_encoding.rs:42-51), bad = the bytes valid_base rejects (low nibble 14: N, n;
+// bit_encoding.rs:52-54).  A quality line as one plane: the bases the quality filters reject, !(q - 33 > min_qual) in u8 arithmetic
+// (split_kmer.rs:98-101).  AVX2 where the processor has it (32 bytes a step), byte by byte otherwise.
+#include <immintrin.h>
+__attribute__((target("avx2"))) static void pack_bases_avx2(const uint8_t *s, size_t n, uint32_t *lo, uint32_t *hi, uint32_t *bad)
+{
+    const __m256i nib = _mm256_set1_epi8(0x0F), v14 = _mm256_set1_epi8(14);
+    size_t w = 0;
+    for (size_t i = 0; i < n; i += 32, w++) {
+        const size_t m = n - i;
+        __m256i b;
+        if (m >= 32) b = _mm256_loadu_si256((const __m256i *)(s + i));
+        else { alignas(32) uint8_t tmp[32] = {0}; memcpy(tmp, s + i, m); b = _mm256_load_si256((const __m256i *)tmp); }
+        const uint32_t in = m >= 32 ? 0xFFFFFFFFu : (1u << m) - 1u;
+        const uint32_t bm = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_and_si256(b, nib), v14)) & in;
+        lo[w] = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(b, 6)) & in & ~bm;          // bit 1 of every byte at its top
+        hi[w] = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(b, 5)) & in & ~bm;          // bit 2
+        bad[w] = bm;
+    }
+}
+__attribute__((target("avx2"))) static void pack_qual_avx2(const uint8_t *q, size_t n, int min_qual, uint32_t *qb)
+{
+    const __m256i v33 = _mm256_set1_epi8(33), vm = _mm256_set1_epi8((char)(uint8_t)min_qual);
+    size_t w = 0;
+    for (size_t i = 0; i < n; i += 32, w++) {
+        const size_t m = n - i;
+        __m256i b;
+        if (m >= 32) b = _mm256_loadu_si256((const __m256i *)(q + i));
+        else { alignas(32) uint8_t tmp[32] = {0}; memcpy(tmp, q + i, m); b = _mm256_load_si256((const __m256i *)tmp); }
+        const uint32_t in = m >= 32 ? 0xFFFFFFFFu : (1u << m) - 1u;
+        const __m256i t = _mm256_sub_epi8(b, v33);
+        qb[w] = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_max_epu8(t, vm), vm)) & in;      // t <= min_qual, unsigned
+    }
+}
+static void pack_bases_plain(const uint8_t *s, size_t n, uint32_t *lo, uint32_t *hi, uint32_t *bad)
+{
+    for (size_t w = 0; w * 32 < n; w++) {
+        uint32_t l = 0, h = 0, b = 0;
+        const size_t m = std::min<size_t>(32, n - w * 32);
+        for (size_t j = 0; j < m; j++) {
+            const uint8_t c = s[w * 32 + j];
+            const uint32_t isbad = (c & 0xF) == 14;
+            b |= isbad << j; l |= (((uint32_t)c >> 1) & 1u & ~isbad) << j; h |= (((uint32_t)c >> 2) & 1u & ~isbad) << j;
+        }
+        lo[w] = l; hi[w] = h; bad[w] = b;
+    }
+}
+static void pack_qual_plain(const uint8_t *q, size_t n, int min_qual, uint32_t *qb)
+{
+    for (size_t w = 0; w * 32 < n; w++) {
+        uint32_t v = 0;
+        const size_t m = std::min<size_t>(32, n - w * 32);
+        for (size_t j = 0; j < m; j++) v |= (uint32_t)((uint8_t)(q[w * 32 + j] - 33) <= (uint8_t)min_qual) << j;
+        qb[w] = v;
+    }
+}
+static bool have_avx2() { static const bool v = __builtin_cpu_supports("avx2") && !knob("no_avx2"); return v; }
+void pack_bases_planes(const uint8_t *s, size_t n, uint32_t *lo, uint32_t *hi, uint32_t *bad)
+{
+    if (have_avx2()) pack_bases_avx2(s, n, lo, hi, bad); else pack_bases_plain(s, n, lo, hi, bad);
+}
+void pack_qual_plane(const uint8_t *q, size_t n, int min_qual, uint32_t *qb)
+{
+    if (have_avx2()) pack_qual_avx2(q, n, min_qual, qb); else pack_qual_plain(q, n, min_qual, qb);
+}
+
 int read_sample_stream(const char *file1, const char *file2, double proportion_reads, HostStream &out)
 {
     size_t step = 1;

@@ -615,10 +615,16 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     (void)hipMemGetInfo(&free_b, &total_b);
     // a slot per reader thread and a few waiting for their kernels: more only costs allocation time (64 slots = 17 GB took 4.7 s right after
     // another process had released the memory, 32 slots 0.26 s: profiles/r03zr_reads_pipeline_512.log)
-    int P = (int)std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(2, std::min<uint64_t>((uint64_t)nt + 8, (free_b / 8) / (2 * slot_bytes + 1))));
-    DevBuf<uint8_t> seq_pool, qual_pool;
-    SKX_TRY(seq_pool.alloc((uint64_t)P * slot_bytes)); SKX_TRY(qual_pool.alloc((uint64_t)P * slot_bytes));
-    constexpr size_t SLOT = 8u << 20;
+    // A sample crosses PCIe as bit planes -- groups of 64 positions, five words each: two code bits, the bases valid_base rejects, the line
+    // ends, the quality verdicts (fastx.cpp pack_*_planes) -- packed by its reader thread: 5 bits per position instead of two bytes; one
+    // launch per sample takes them apart into the record streams the kernels below read (the copy was what bounded a batch: 504 MB per
+    // 50x isolate at ~32 GB/s = 63 isolates/s)
+    const uint64_t pslot_bytes = ((slot_bytes / 64 + 2) * READ_GROUP_BYTES + 255) & ~255ull;
+    int P = (int)std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(2, std::min<uint64_t>((uint64_t)nt + 8, (free_b / 8) / (pslot_bytes + 1))));
+    DevBuf<uint8_t> packed_pool, seq_pool, qual_pool;                           // (the two streams: of the sample whose kernels run)
+    SKX_TRY(packed_pool.alloc((uint64_t)P * pslot_bytes)); SKX_TRY(seq_pool.alloc(slot_bytes + 64)); SKX_TRY(qual_pool.alloc(slot_bytes + 64));
+    constexpr size_t SLOT = ((8u << 20) / READ_GROUP_BYTES) * READ_GROUP_BYTES;          // whole groups
+    const int min_qual_host = q ? (int)q->min_qual : 20;
     const int n_slots = 2 * nt + 8;
     struct Sample { int slot = -1; int pending = 0; bool read_done = false, queued = false; uint64_t len = 0; };
     struct Ring {
@@ -664,56 +670,78 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
         }
         if (up) (void)hipStreamDestroy(up);
     });
+    std::atomic<long long> us_wait_stream{0}, us_wait_ring{0}, us_files{0};      // summed over the reader threads
+    auto us_since = [](std::chrono::steady_clock::time_point t) { return (long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count(); };
     std::vector<std::thread> pool;
     std::atomic<int> next{0};
     for (int t = 0; t < nt; t++)
         pool.emplace_back([&]() {
             struct Leave { Ring &r; ~Leave() { { std::lock_guard<std::mutex> lk(r.mu); r.readers_left--; } r.cv_work.notify_all(); r.cv_ready.notify_all(); } } leave{ring};
+            std::vector<uint32_t> planes;                                     // a record's four planes (sequence line, then its quality line)
             for (int i; (i = next.fetch_add(1)) < n;) {
                 int sslot = -1;
                 {
+                    const auto tw = std::chrono::steady_clock::now();
                     std::unique_lock<std::mutex> lk(ring.mu);
                     ring.cv_stream.wait(lk, [&] { return !ring.free_stream.empty() || ring.abort; });
+                    us_wait_stream += us_since(tw);
                     if (ring.abort) return;
                     sslot = ring.free_stream.back(); ring.free_stream.pop_back();
                     smp[i].slot = sslot;
                 }
-                struct Out { int slot = -1; size_t used = 0; uint8_t *dst = nullptr; uint64_t off = 0; } o[2];
-                o[0].dst = seq_pool.p + (uint64_t)sslot * slot_bytes; o[1].dst = qual_pool.p + (uint64_t)sslot * slot_bytes;
-                const uint64_t cap = bound[i] - 32;
-                auto flush = [&](Out &x) {
+                const auto t_files = std::chrono::steady_clock::now();
+                struct Out { int slot = -1; size_t used = 0; uint8_t *dst = nullptr; uint64_t off = 0; } x;
+                x.dst = packed_pool.p + (uint64_t)sslot * pslot_bytes;
+                const uint64_t cap = bound[i] - 32;                             // positions
+                auto flush = [&]() {
                     if (x.slot < 0) return;
                     { std::lock_guard<std::mutex> lk(ring.mu); ring.work.push_back({x.slot, x.dst + x.off, x.used, i}); smp[i].pending++; }
                     ring.cv_work.notify_one();
                     x.off += x.used; x.slot = -1; x.used = 0;
                 };
                 auto give_back = [&]() {
-                    for (auto &x : o) if (x.slot >= 0) { { std::lock_guard<std::mutex> lk(ring.mu); ring.free_slots.push_back(x.slot); } ring.cv_free.notify_one(); x.slot = -1; }
+                    if (x.slot >= 0) { { std::lock_guard<std::mutex> lk(ring.mu); ring.free_slots.push_back(x.slot); } ring.cv_free.notify_one(); x.slot = -1; }
                 };
+                uint64_t cur[5] = {0, 0, 0, 0, 0}, pos = 0;                     // the group being filled; positions so far
+                auto push_group = [&]() -> int {
+                    if (x.slot < 0) {
+                        const auto tw = std::chrono::steady_clock::now();
+                        std::unique_lock<std::mutex> lk(ring.mu);
+                        ring.cv_free.wait(lk, [&] { return !ring.free_slots.empty() || ring.abort; });
+                        us_wait_ring += us_since(tw);
+                        if (ring.abort) return SKF_ABORTED;                   // somebody else stopped the pipeline: not this reader's failure
+                        x.slot = ring.free_slots.back(); ring.free_slots.pop_back(); x.used = 0;
+                    }
+                    memcpy(ring.base + (size_t)x.slot * SLOT + x.used, cur, READ_GROUP_BYTES);
+                    x.used += READ_GROUP_BYTES;
+                    if (x.used == SLOT) flush();
+                    return SKX_OK;
+                };
+                // a record: its sequence line's planes wait for the quality line (the two lines may lie in different pieces of the file)
+                std::vector<uint32_t> &pl = planes;
+                size_t line_n = 0;
                 const std::function<int(int, const uint8_t *, size_t)> emit = [&](int which, const uint8_t *p, size_t nb) -> int {
-                    Out &x = o[which];
-                    if (x.off + x.used + nb + 1 > cap) { set_error("Invalid FASTA/Q record"); return SKX_EIO; }
-                    if (x.slot >= 0 && x.used + nb + 1 <= SLOT) {
-                        uint8_t *d = ring.base + (size_t)x.slot * SLOT + x.used;
-                        memcpy(d, p, nb); d[nb] = '\n';
-                        x.used += nb + 1;
-                        if (x.used == SLOT) flush(x);
+                    const size_t words = (nb + 1 + 31) / 32;                    // the line and its end
+                    if (which == 0) {
+                        if (pos + nb + 1 > cap) { set_error("Invalid FASTA/Q record"); return SKX_EIO; }
+                        if (pl.size() < 4 * words) pl.resize(4 * words + 64);
+                        line_n = nb;
+                        for (int pln = 0; pln < 4; pln++) pl[pln * words + words - 1] = 0;
+                        pack_bases_planes(p, nb, &pl[0], &pl[words], &pl[2 * words]);
                         return SKX_OK;
                     }
-                    bool term = false;
-                    static const uint8_t nl = '\n';
-                    for (;;) {
-                        if (nb == 0) { if (term) break; term = true; p = &nl; nb = 1; }
-                        if (x.slot < 0) {
-                            std::unique_lock<std::mutex> lk(ring.mu);
-                            ring.cv_free.wait(lk, [&] { return !ring.free_slots.empty() || ring.abort; });
-                            if (ring.abort) return SKF_ABORTED;               // somebody else stopped the pipeline: not this reader's failure
-                            x.slot = ring.free_slots.back(); ring.free_slots.pop_back(); x.used = 0;
+                    if (nb != line_n) { set_error("Invalid FASTA/Q record"); return SKX_EIO; }
+                    pack_qual_plane(p, nb, min_qual_host, &pl[3 * words]);
+                    const uint32_t *lo = &pl[0], *hi = &pl[words], *bd = &pl[2 * words], *qb = &pl[3 * words];
+                    for (size_t w = 0; w < words; w++) {
+                        const unsigned take = (unsigned)std::min<size_t>(32, nb + 1 - 32 * w), off = (unsigned)(pos & 63);
+                        const uint64_t v[5] = {lo[w], hi[w], bd[w], nb / 32 == w ? 1ull << (nb & 31) : 0ull, qb[w]};
+                        for (int pln = 0; pln < 5; pln++) cur[pln] |= v[pln] << off;
+                        pos += take;
+                        if (off + take >= 64) {
+                            const int pr = push_group(); if (pr != SKX_OK) return pr;
+                            for (int pln = 0; pln < 5; pln++) cur[pln] = off + take > 64 ? v[pln] >> (64 - off) : 0ull;
                         }
-                        const size_t take = std::min(nb, SLOT - x.used);
-                        memcpy(ring.base + (size_t)x.slot * SLOT + x.used, p, take);
-                        x.used += take; p += take; nb -= take;
-                        if (x.used == SLOT) flush(x);
                     }
                     return SKX_OK;
                 };
@@ -724,7 +752,8 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
                     if (r == SKF_NOT_TAKEN) { set_error("Invalid FASTA/Q record"); r = SKX_EIO; }      // (the first byte was '@' a moment ago)
                     if (r != SKX_OK) break;
                 }
-                if (r == SKX_OK) { flush(o[0]); flush(o[1]); if (o[0].off != o[1].off) { set_error("Invalid FASTA/Q record"); r = SKX_EIO; } }
+                if (r == SKX_OK && (pos & 63)) r = push_group();                 // the last, partly filled group
+                if (r == SKX_OK) flush();
                 if (r != SKX_OK) {
                     give_back();
                     if (r != SKF_ABORTED) { rcodes[i] = r; errs[i] = skx_last_error(); }      // (only the failure that started it is reported)
@@ -732,7 +761,8 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
                     ring.cv_stream.notify_all(); ring.cv_free.notify_all(); ring.cv_ready.notify_all();
                     return;
                 }
-                { std::lock_guard<std::mutex> lk(ring.mu); smp[i].len = o[0].off; smp[i].read_done = true; mark_ready_locked(i); }
+                us_files += us_since(t_files);
+                { std::lock_guard<std::mutex> lk(ring.mu); smp[i].len = pos; smp[i].read_done = true; mark_ready_locked(i); }
                 ring.cv_ready.notify_all();
             }
         });
@@ -751,8 +781,8 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
         }
         const auto tk = std::chrono::steady_clock::now();
         skx_qual qs = q ? *q : skx_qual{5, 20, SKX_QUAL_STRICT};
-        const uint8_t *ds = seq_pool.p + (uint64_t)smp[i].slot * slot_bytes, *dq = qual_pool.p + (uint64_t)smp[i].slot * slot_bytes;
-        krc = reads_sample_words(ctx, ds, dq, smp[i].len, k, rc, qs, wl[i], wh2[i], &cnt[i]);      // (returns with the stream idle: the slot is free)
+        launch_expand_planes((const uint64_t *)(packed_pool.p + (uint64_t)smp[i].slot * pslot_bytes), smp[i].len, seq_pool.p, qual_pool.p, ctx->stream);
+        krc = reads_sample_words(ctx, seq_pool.p, qual_pool.p, smp[i].len, k, rc, qs, wl[i], wh2[i], &cnt[i]);      // (returns with the stream idle: the slot and the two streams are free)
         t_kernels += std::chrono::duration<double>(std::chrono::steady_clock::now() - tk).count();
         { std::lock_guard<std::mutex> lk(ring.mu); ring.free_stream.push_back(smp[i].slot); if (krc != SKX_OK) ring.abort = true; }
         ring.cv_stream.notify_all();
@@ -765,13 +795,16 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     for (auto &u : uploaders) u.join();
     phase_add("build.read_upload", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     phase_add("build.reads_kernels_overlapped", t_kernels);
+    phase_add("build.readers_files_thread_s", us_files.load() * 1e-6);               // parse + pack, waits for pinned slots included
+    phase_add("build.readers_wait_pinned_thread_s", us_wait_ring.load() * 1e-6);
+    phase_add("build.readers_wait_device_slot_thread_s", us_wait_stream.load() * 1e-6);
     if (ring.failed) { set_error("upload of the sequence files failed"); return SKX_ENODEV; }
     // the kernels' verdict first (SKF_NOT_TAKEN included: the one-shot form takes the batch -- the readers it interrupted recorded nothing),
     // then the reader whose own failure stopped the pipeline
     if (krc != SKX_OK) return krc;
     for (int i = 0; i < n; i++) if (rcodes[i] != SKX_OK) { set_error("%s", errs[i].c_str()); return rcodes[i]; }
     if (done < n) { set_error("internal: read-set pipeline stopped early"); return SKX_EUNSUP; }
-    seq_pool.release(); qual_pool.release();
+    packed_pool.release(); seq_pool.release(); qual_pool.release();
     const auto t1 = std::chrono::steady_clock::now();
     skx_dictset *d = nullptr;
     int r = reads_words_to_dictset(ctx, wl, wh2, cnt, k, rc, &d);

@@ -271,6 +271,8 @@ void launch_gather_keys_wide(const u128 *stage, uint32_t stride, const uint32_t 
 
 // ---- FASTA text -> record stream (skx_parse.hip): tiles of 16 KB; scratch per tile: 8 B summary, 8 B offset, 1 B kind
 uint64_t fasta_parse_tiles(uint64_t len);
+// packed read sets (groups of 64 positions x 5 planes) -> sequence / quality record streams; the streams need 16 bytes of slack past len
+void launch_expand_planes(const uint64_t *groups, uint64_t len, uint8_t *seq, uint8_t *qual, hipStream_t st);
 void launch_fasta_parse(const uint8_t *const *raw, const uint64_t *rawlen, uint8_t *const *out, uint64_t *outlen, const uint32_t *tile_file,
                         const uint64_t *tile_base, uint64_t n_tiles, void *summary, uint64_t *tile_off, uint8_t *tile_kind, int n, hipStream_t st);
 

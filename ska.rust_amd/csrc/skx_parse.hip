@@ -189,6 +189,43 @@ __global__ __launch_bounds__(PT_NT) void fasta_tile_emit(ParseArgs a)
 
 uint64_t fasta_parse_tiles(uint64_t len) { return (len + PT_TILE - 1) / PT_TILE; }
 
+// ---- read sets packed by the reader threads (fastx.cpp pack_*_planes): groups of 64 positions, five words each -> the record streams
+// the read-set kernels take: sequence bytes A C T G (any byte of that code), N (a byte valid_base rejects), '\n'; quality bytes ' ' (passes
+// every min_qual below 255: (32 - 33) & 255 = 255), '!' (fails every one), '\n'.  One thread = 16 positions = one 16-byte store per stream.
+__global__ __launch_bounds__(256) void expand_planes_kernel(const uint64_t *groups, uint64_t len, uint8_t *seq, uint8_t *qual)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t p0 = t * 16;
+    if (p0 >= len) return;
+    const uint64_t *g = groups + (t >> 2) * 5;
+    const int sh = (int)(t & 3) * 16;
+    const uint32_t lo = (uint32_t)(g[0] >> sh) & 0xFFFFu, hi = (uint32_t)(g[1] >> sh) & 0xFFFFu, bad = (uint32_t)(g[2] >> sh) & 0xFFFFu,
+                   nl = (uint32_t)(g[3] >> sh) & 0xFFFFu, qb = (uint32_t)(g[4] >> sh) & 0xFFFFu;
+    uint32_t sw[4], qw[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint32_t x = 0, y = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int j = 4 * i + b;
+            const uint32_t code = ((lo >> j) & 1u) | (((hi >> j) & 1u) << 1);
+            const bool past = p0 + (uint64_t)j >= len, isnl = ((nl >> j) & 1u) || past;
+            const uint32_t c = isnl ? 10u : ((bad >> j) & 1u) ? 78u : (0x47544341u >> (8 * code)) & 0xFFu;      // "ACTG"
+            const uint32_t q = isnl ? 10u : ((qb >> j) & 1u) ? 33u : 32u;
+            x |= c << (8 * b); y |= q << (8 * b);
+        }
+        sw[i] = x; qw[i] = y;
+    }
+    *reinterpret_cast<uint4 *>(seq + p0) = make_uint4(sw[0], sw[1], sw[2], sw[3]);
+    *reinterpret_cast<uint4 *>(qual + p0) = make_uint4(qw[0], qw[1], qw[2], qw[3]);
+}
+void launch_expand_planes(const uint64_t *groups, uint64_t len, uint8_t *seq, uint8_t *qual, hipStream_t st)
+{
+    if (!len) return;
+    const uint64_t threads = (len + 15) / 16;
+    hipLaunchKernelGGL(expand_planes_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, groups, len, seq, qual);
+}
+
 void launch_fasta_parse(const uint8_t *const *raw, const uint64_t *rawlen, uint8_t *const *out, uint64_t *outlen, const uint32_t *tile_file,
                         const uint64_t *tile_base, uint64_t n_tiles, void *summary /* 8 B per tile */, uint64_t *tile_off, uint8_t *tile_kind, int n,
                         hipStream_t st)

@@ -44,6 +44,9 @@ __device__ static inline uint64_t nt_pick(uint32_t c, uint64_t t0, uint64_t t1, 
 {
     return (c & 2u) ? ((c & 1u) ? t3 : t2) : ((c & 1u) ? t1 : t0);
 }
+// WORDS = false: ntHash and the gates only (the count filter passes ~2 % of a deep read set's windows: their packed words are put together
+// afterwards from the text, words_rebuild_kernel) -- 9 instead of 25 bytes written per window, no canonical compare, no key hash
+template <bool WORDS>
 __global__ __launch_bounds__(RW_NT) void reads_windows_kernel(ReadsArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_seq[RW_TILE + 80], s_q[RW_TILE + 80], s_flag[RW_TILE];
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(RW_NT) void reads_windows_kernel(ReadsArgs a)
         const int c4 = threadIdx.x & 3, kind = threadIdx.x >> 2;
         s_nt[threadIdx.x] = kind == 0 ? NT_H[c4] : kind == 1 ? rotl64d(NT_H[c4], (unsigned)a.k) : kind == 2 ? NT_RC[c4] : rotl64d(NT_RC[c4], (unsigned)(a.k - 1));
     }
-    uint64_t o_hash[RW_PPT], o_lo[RW_PPT], o_hi[RW_PPT];
+    uint64_t o_hash[RW_PPT], o_lo[WORDS ? RW_PPT : 1], o_hi[WORDS ? RW_PPT : 1];
     const uint64_t p0 = (uint64_t)blockIdx.x * RW_TILE;
     const int k = a.k, h = (k - 1) / 2;
     // tile covers positions [p0 - 64, p0 + RW_TILE + 2)
@@ -145,6 +148,9 @@ __global__ __launch_bounds__(RW_NT) void reads_windows_kernel(ReadsArgs a)
             if (s_seq[ej + 1] == '\n') valid = valid && run > (uint32_t)k;
             // middle_base_qual (split_kmer.rs:328-339): Middle and Strict gate on the middle base
             const bool midq_ok = !(a.qual && a.qual_filter != 0 && qbad(ej - h));
+            o_hash[j] = userc ? (fh < rh ? fh : rh) : fh;
+            s_flag[threadIdx.x * (RW_PPT * RW_NB) + b * RW_PPT + j] = valid && midq_ok;            // the `&&` of ska_dict.rs:155-157: the count filter is not touched otherwise
+            if (!WORDS) continue;
             // canonical strand and base set without branches; the packed word on 64-bit halves (as extract_wide_kernel)
             const bool ueq = upper == rc_upper;
             const bool gt = userc & ((upper > rc_upper) | (ueq & (lower > rc_lower)));
@@ -154,15 +160,15 @@ __global__ __launch_bounds__(RW_NT) void reads_windows_kernel(ReadsArgs a)
             uint64_t wlo, whi;
             if (k <= 31) { uint32_t L = (uint32_t)hl, R = (uint32_t)hr; hmix_halves(L, R, a.hp); wlo = ((uint64_t)L << (a.hp.hb + 4)) | ((uint64_t)R << 4) | m4; whi = 0; }
             else { uint64_t L = hl, R = hr; hmix_halves_w(L, R, a.wh); wlo = (R << 4) | m4 | ((L << wa1) & wm1); whi = (R >> 60) | ((L >> wa2) << wa3); }
-            o_hash[j] = userc ? (fh < rh ? fh : rh) : fh;
-            o_lo[j] = wlo;
-            o_hi[j] = whi;
-            s_flag[threadIdx.x * (RW_PPT * RW_NB) + b * RW_PPT + j] = valid && midq_ok;            // the `&&` of ska_dict.rs:155-157: the count filter is not touched otherwise
+            o_lo[WORDS ? j : 0] = wlo;
+            o_hi[WORDS ? j : 0] = whi;
         }
     }
     put(o_hash, a.hash, b, mine);
-    put(o_lo, a.wlo, b, mine);
-    if (a.whi) put(o_hi, a.whi, b, mine);
+    if constexpr (WORDS) {
+        put(o_lo, a.wlo, b, mine);
+        if (a.whi) put(o_hi, a.whi, b, mine);
+    }
     }
     uint32_t nv = 0;
     for (uint32_t i = threadIdx.x; i < left; i += RW_NT) { a.flag[p0 + i] = s_flag[i]; nv += s_flag[i]; }
@@ -283,16 +289,64 @@ int select_flagged(Temp &tmp, In in, const uint8_t *flags, Out *out, uint64_t n,
 }
 }  // namespace
 
-// the window pass alone: per window-end position its ntHash, packed word and whether it passes the quality gates
+// The packed words of the windows at the given end positions (all of them clean runs of k bases: they passed the gates), put together from
+// the text as reads_windows_kernel<true> rolls them: arms, canonical strand, base set (split_kmer.rs:141-217), then the key hash.
+__global__ __launch_bounds__(256) void words_rebuild_kernel(const uint32_t *pos, uint64_t n, const uint8_t *seq, int k, int rc, HashParams hp, WideHash wh,
+                                                             uint64_t *out_lo, uint64_t *out_hi)
+{
+    const int h = (k - 1) / 2;
+    const uint64_t am = (1ull << (2 * h)) - 1;
+    const int wsh = wh.hb + 4;
+    const int wa1 = wsh < 64 ? wsh : 0, wa2 = wsh < 64 ? 64 - wsh : 0, wa3 = wsh < 64 ? 0 : wsh - 64;
+    const uint64_t wm1 = wsh < 64 ? ~0ull : 0ull;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint8_t *w = seq + ((uint64_t)pos[i] - (uint64_t)(k - 1));
+        uint64_t upper = 0, lower = 0, rc_upper = 0, rc_lower = 0;
+        // (all of the window's bytes asked for before the first is used: a loop over h waits for every pair in turn, 1.2 ms per 5 M windows)
+        uint8_t bu[31], bl[31];
+#pragma unroll
+        for (int j = 0; j < 31; j++) { const int jj = j < h ? j : h - 1; bu[j] = w[jj]; bl[j] = w[h + 1 + jj]; }      // (every load issued whatever h is: a load under a condition is waited for on the spot)
+        const uint32_t mid = (w[h] >> 1) & 3u, rc_mid = mid ^ 2u;
+#pragma unroll
+        for (int j = 0; j < 31; j++) {
+            if (j < h) {
+                const uint64_t cu = (bu[j] >> 1) & 3u, cl = (bl[j] >> 1) & 3u;
+                upper = (upper << 2) | cu; lower = (lower << 2) | cl;
+                rc_lower |= (cu ^ 2u) << (2 * j);                  // the reverse complement's lower arm: the upper arm backwards, complemented
+                rc_upper |= (cl ^ 2u) << (2 * j);
+            }
+        }
+        const bool userc = rc != 0;
+        const bool ueq = upper == rc_upper;
+        const bool gt = userc & ((upper > rc_upper) | (ueq & (lower > rc_lower)));
+        const bool eq = userc & ueq & (lower == rc_lower);
+        const uint64_t hl = gt ? rc_upper : upper, hr = gt ? rc_lower : lower;
+        const uint32_t m4 = (1u << (gt ? rc_mid : mid)) | (eq ? (1u << rc_mid) : 0u);
+        if (k <= 31) { uint32_t L = (uint32_t)hl, R = (uint32_t)hr; hmix_halves(L, R, hp); out_lo[i] = ((uint64_t)L << (hp.hb + 4)) | ((uint64_t)R << 4) | m4; }
+        else { uint64_t L = hl, R = hr; hmix_halves_w(L, R, wh); out_lo[i] = (R << 4) | m4 | ((L << wa1) & wm1); out_hi[i] = (R >> 60) | ((L >> wa2) << wa3); }
+        (void)am;
+    }
+}
+void launch_words_rebuild(const uint32_t *pos, uint64_t n, const uint8_t *seq, int k, int rc, uint64_t *out_lo, uint64_t *out_hi, hipStream_t st)
+{
+    if (!n) return;
+    const uint64_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(words_rebuild_kernel, dim3((unsigned)(g > 65536 ? 65536 : g)), dim3(256), 0, st, pos, n, seq, k, rc, make_hash_params(k < 31 ? k : 31), make_wide_hash(k),
+                       out_lo, out_hi);
+}
+
+// the window pass alone: per window-end position its ntHash, whether it passes the quality gates and -- want_words -- its packed word
 int reads_windows(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t len, int k, int rc, const skx_qual &q, DevBuf<uint64_t> &hash,
-                  DevBuf<uint64_t> &wlo, DevBuf<uint64_t> &whi, DevBuf<uint8_t> &flag, unsigned long long *d_n_valid)
+                  DevBuf<uint64_t> &wlo, DevBuf<uint64_t> &whi, DevBuf<uint8_t> &flag, unsigned long long *d_n_valid, bool want_words)
 {
     const bool wide = k > 31;
-    SKX_TRY(hash.alloc(len)); SKX_TRY(wlo.alloc(len)); SKX_TRY(flag.alloc(len));
-    if (wide) SKX_TRY(whi.alloc(len));
+    SKX_TRY(hash.alloc(len)); SKX_TRY(flag.alloc(len));
+    if (want_words) { SKX_TRY(wlo.alloc(len)); if (wide) SKX_TRY(whi.alloc(len)); }
     ReadsArgs ra{d_seq, d_qual, len, k, rc, q.min_qual, q.qual_filter, make_hash_params(k < 31 ? k : 31), make_wide_hash(k),
-                 hash.p, wlo.p, wide ? whi.p : nullptr, flag.p, d_n_valid};
-    hipLaunchKernelGGL(reads_windows_kernel, dim3((unsigned)((len + RW_TILE - 1) / RW_TILE)), dim3(RW_NT), 0, ctx->stream, ra);
+                 hash.p, want_words ? wlo.p : nullptr, want_words && wide ? whi.p : nullptr, flag.p, d_n_valid};
+    const dim3 g((unsigned)((len + RW_TILE - 1) / RW_TILE));
+    if (want_words) hipLaunchKernelGGL(reads_windows_kernel<true>, g, dim3(RW_NT), 0, ctx->stream, ra);
+    else hipLaunchKernelGGL(reads_windows_kernel<false>, g, dim3(RW_NT), 0, ctx->stream, ra);
     return SKX_OK;
 }
 
@@ -312,7 +366,7 @@ int reads_sample_dict(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual,
     if (wide) SKX_TRY(whi.alloc(len));
     ReadsArgs ra{d_seq, d_qual, len, k, rc, q.min_qual, q.qual_filter, make_hash_params(k < 31 ? k : 31), make_wide_hash(k),
                  hash.p, wlo.p, wide ? whi.p : nullptr, flag.p};
-    hipLaunchKernelGGL(reads_windows_kernel, dim3((unsigned)((len + RW_TILE - 1) / RW_TILE)), dim3(RW_NT), 0, st, ra);
+    hipLaunchKernelGGL(reads_windows_kernel<true>, dim3((unsigned)((len + RW_TILE - 1) / RW_TILE)), dim3(RW_NT), 0, st, ra);
 
     // candidate windows in stream order
     DevBuf<uint32_t> idx; SKX_TRY(idx.alloc(len));
@@ -407,7 +461,7 @@ int ref_windows(skx_ctx *ctx, const uint8_t *d_seq, uint64_t len, int k, int rc,
     SKX_TRY(hash.alloc(len)); SKX_TRY(wlo.alloc(len)); SKX_TRY(flag.alloc(len));
     if (wide) SKX_TRY(whi.alloc(len));
     ReadsArgs ra{d_seq, nullptr, len, k, rc, 0, 0, make_hash_params(k < 31 ? k : 31), make_wide_hash(k), hash.p, wlo.p, wide ? whi.p : nullptr, flag.p};
-    hipLaunchKernelGGL(reads_windows_kernel, dim3((unsigned)((len + RW_TILE - 1) / RW_TILE)), dim3(RW_NT), 0, ctx->stream, ra);
+    hipLaunchKernelGGL(reads_windows_kernel<true>, dim3((unsigned)((len + RW_TILE - 1) / RW_TILE)), dim3(RW_NT), 0, ctx->stream, ra);
     return SKX_OK;
 }
 

@@ -372,7 +372,8 @@ int reads_sample_words(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual
     DevBuf<uint64_t> wlo, whi, hash; DevBuf<uint8_t> flag;
     DevBuf<unsigned long long> d_n; DevBuf<int> d_over;            // d_n[0]: positions / words that leave; d_n[1 .. 257): gated windows (spread counters)
     SKX_TRY(d_n.alloc(257)); SKX_TRY(d_n.zero(st)); SKX_TRY(d_over.alloc(1)); SKX_TRY(d_over.zero(st));
-    SKX_TRY(reads_windows(ctx, d_seq, d_qual, len, k, rc, q, hash, wlo, whi, flag, d_n.p + 1));
+    const bool all_words = q.min_count <= 1;                       // every gated window enters: the window pass writes the words itself
+    SKX_TRY(reads_windows(ctx, d_seq, d_qual, len, k, rc, q, hash, wlo, whi, flag, d_n.p + 1, all_words));
     unsigned long long n_acc = 0;
     if (q.min_count <= 1) {                                        // KmerFilter: 0 | 1 => every gated window enters
         SKX_TRY(out_lo.alloc(len)); if (wide) SKX_TRY(out_hi.alloc(len));
@@ -442,8 +443,7 @@ int reads_sample_words(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual
     if (over) { if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] reads: a partition overflowed, sample left to the sort-based form\n"); return SKF_NOT_TAKEN; }
     if (n_acc == 0) return SKX_OK;
     SKX_TRY(out_lo.alloc(n_acc)); if (wide) SKX_TRY(out_hi.alloc(n_acc));
-    hipLaunchKernelGGL(words_gather_kernel, dim3(grid_of(n_acc)), dim3(256), 0, st, (const uint32_t *)acc_t.p, (uint64_t)n_acc, (const uint64_t *)wlo.p,
-                       wide ? (const uint64_t *)whi.p : (const uint64_t *)nullptr, out_lo.p, wide ? out_hi.p : (uint64_t *)nullptr);
+    launch_words_rebuild(acc_t.p, n_acc, d_seq, k, rc, out_lo.p, wide ? out_hi.p : nullptr, st);
     SKX_HIP(hipStreamSynchronize(st));
     SKX_HIP(hipGetLastError());
     *n_out = n_acc;

@@ -345,3 +345,62 @@ def test_read_set_pipeline_equals_one_shot(tmp_path):
     for env in ({}, {"SKX_KNOBS": "no_reads_pipeline=1"}):
         r = subprocess.run([SKA, "build", "-f", "list.txt", "-o", "broken", "-k", "31", "--min-count", "3"], cwd=wd, capture_output=True, timeout=300, env=dict(os.environ, **env))
         assert r.returncode != 0 and b"Invalid FASTA/Q record" in r.stderr, r.stderr[-400:]
+
+
+def test_read_set_pipeline_odd_bytes_and_line_lengths(tmp_path):
+    """The pipeline's reader threads pack a read set into bit planes (fastx.cpp pack_*_planes: two code bits, the bytes valid_base rejects,
+    line ends, quality verdicts) and one launch per sample takes them apart on the device: lines of every length around the 32- and
+    64-position word edges (0, 1, 31 ... 129, 150), IUPAC codes and other bytes that encode_base folds onto a base (bit_encoding.rs:42-54),
+    N / n / '.' / '>' (low nibble 14: rejected), lower case, qualities on both sides of the threshold, one file with CRLF line ends.
+    Same .skf as the one-shot form (byte streams, no packing) and the oracle's array, k = 31 and 41, strict and middle-base filters."""
+    wd = str(tmp_path)
+    rng = np.random.default_rng(77)
+    glen = 40_000
+    g = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=glen)]
+    lens = np.array([0, 1, 30, 31, 32, 33, 62, 63, 64, 65, 95, 96, 97, 127, 128, 129, 150])
+    odd = np.frombuffer(b"NnRYKMSWryk.>-*Xx", np.uint8)
+    comp = np.zeros(256, np.uint8)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    files = []
+    for i in range(4):
+        gi = g.copy()
+        gi[rng.integers(0, glen, size=60)] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=60)]
+        pair = []
+        for mate in (0, 1):
+            out = []
+            for _ in range(9000):
+                L = int(lens[rng.integers(0, len(lens))])
+                st = int(rng.integers(0, glen - 150))
+                r = gi[st:st + L].copy()
+                if rng.random() < 0.5:
+                    r = comp[r[::-1]]
+                m = rng.random(L) < 0.01
+                r[m] = odd[rng.integers(0, len(odd), size=int(m.sum()))]
+                low = rng.random(L) < 0.05
+                r[low] |= 0x20
+                q = (33 + rng.integers(0, 42, size=L)).astype(np.uint8)
+                q[rng.random(L) < 0.97] = 33 + 35
+                eol = b"\r\n" if (i == 1 and mate == 1) else b"\n"
+                out.append(b"@r" + eol + r.tobytes() + eol + b"+" + eol + q.tobytes() + eol)
+            p = os.path.join(wd, f"o{i}_{mate + 1}.fastq")
+            open(p, "wb").write(b"".join(out))
+            pair.append(p)
+        files.append(pair)
+    with open(os.path.join(wd, "list.txt"), "w") as f:
+        for i, (a, b) in enumerate(files):
+            f.write(f"o{i}\t{a}\t{b}\n")
+    for k, qf, oq in (("31", "strict", ora.QUAL_STRICT), ("41", "middle", ora.QUAL_MIDDLE)):
+        outs = {}
+        for tag, env in (("pipe", {}), ("plain", {"SKX_KNOBS": "no_avx2=1"}), ("oneshot", {"SKX_KNOBS": "no_reads_pipeline=1"})):
+            r = subprocess.run([SKA, "build", "-f", "list.txt", "-o", f"{tag}{k}", "-k", k, "--min-count", "2", "--min-qual", "20", "--qual-filter", qf, "--threads", "3"],
+                               cwd=wd, capture_output=True, timeout=300, env=dict(os.environ, **env))
+            assert r.returncode == 0, r.stderr[-600:]
+            outs[tag] = open(os.path.join(wd, f"{tag}{k}.skf"), "rb").read()
+        assert outs["pipe"] == outs["oneshot"] and outs["plain"] == outs["oneshot"], k
+        want = ora.Array.build([(f"o{i}", a, b) for i, (a, b) in enumerate(files)], k=int(k), rc=True, q=ora.qual(2, 20, oq), threads=2)
+        got = ora.Array.load(os.path.join(wd, f"pipe{k}.skf"))
+        got.sort_rows(); want.sort_rows()
+        gk, gv, gc = got.export()
+        ok, ov, oc = want.export()
+        assert len(ok) > 5_000 and np.array_equal(gk, ok) and np.array_equal(gv, ov) and np.array_equal(gc, oc), k
