@@ -445,7 +445,7 @@ def main():
         traffic, traffic_src = None, None       # HBM bytes per launch from the newest PMC passes recorded under profiles/ (FETCH_SIZE x2 + WRITE_SIZE), scaled per base
         try:
             import glob
-            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_extract*.json")), key=lambda f: json.load(open(f)).get("date", ""))
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_extract*.json")), key=lambda f: (json.load(open(f)).get("date", ""), os.path.basename(f)))
             pmc = json.load(open(cands[-1]))
             if args.k <= 31:
                 traffic = (pmc["read_bytes_per_base"] + pmc["write_bytes_per_base"]) * total_bases
