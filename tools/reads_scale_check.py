@@ -34,6 +34,26 @@ def run(tag, cmd, env=None):
 opts = ["-k", "41", "--min-count", "5", "--min-qual", "20", "--qual-filter", "strict"]
 tb = run("ska build (one process)", [SKA, "build", "-f", "list.txt", "-o", "one", "--threads", os.environ.get("RSC_THREADS", "16"), *opts], {"SKX_PHASES": os.path.join(td, "ph.json"), "SKX_DEBUG": "1"} if os.environ.get("RSC_DEBUG") else {"SKX_PHASES": os.path.join(td, "ph.json")})
 print("  phases", open(os.path.join(td, "ph.json")).read())
+if os.environ.get("RSC_SPOT"):                                  # isolates of this very run against the oracle's dictionaries of their files (CPU, one thread each)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ora
+    from concurrent.futures import ThreadPoolExecutor
+    m = min(int(os.environ["RSC_SPOT"]), n)
+    idx = sorted({(n - 1) * j // max(1, m - 1) for j in range(m)})
+    t = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=len(idx)) as pool:
+        dicts = list(pool.map(lambda i: ora.Dict.from_files(41, pairs[i][0], pairs[i][1], True, ora.qual(5, 20, ora.QUAL_STRICT)).export(), idx))
+    arr = ora.Array.load(os.path.join(td, "one.skf"))
+    keys, var, _ = arr.export()
+    order = np.lexsort((keys["lo"], keys["hi"]))
+    for i, (ok, ob) in zip(idx, dicts):
+        col = var[order, i]
+        have = col != ord("-")
+        same = int(have.sum()) == len(ok) and np.array_equal(keys["lo"][order][have], ok["lo"]) and np.array_equal(keys["hi"][order][have], ok["hi"]) and np.array_equal(col[have], ob)
+        print(f"  isolate {i}: {len(ok)} split k-mers in the oracle's dictionary; column {i} of one.skf {'IDENTICAL' if same else 'DIFFERENT'}", flush=True)
+        assert same
+    print(f"  ({len(idx)} isolates of the {n} spot-checked against the oracle in {time.perf_counter() - t:.1f} s)", flush=True)
+    del arr, keys, var, dicts
 for mb in os.environ.get("RSC_BATCH_MB", "").split():
     run(f"ska build with SKX_BUILD_BATCH_MB={mb}", [SKA, "build", "-f", "list.txt", "-o", "three", "--threads", os.environ.get("RSC_THREADS", "16"), *opts], {"SKX_PHASES": os.path.join(td, "ph3.json"), "SKX_BUILD_BATCH_MB": mb, "SKX_DEBUG": "1"})
     print("  phases", open(os.path.join(td, "ph3.json")).read()[:600])
