@@ -224,6 +224,15 @@ int stream_fastq_file(const char *path, const std::function<int(int which, const
     if (fd < 0) { set_error("Invalid path/file: %s", path); return SKX_EIO; }
     struct Close { int fd; ~Close() { ::close(fd); } } cl{fd};
     (void)posix_fadvise(fd, 0, 0, POSIX_FADV_NOREUSE);
+    // a gzip file is inflated piece by piece as it is read (zlib's gzread on a descriptor of its own: members one after the other, as gzip reads them)
+    unsigned char mg[2] = {0, 0};
+    gzFile gz = nullptr;
+    if (pread(fd, mg, 2, 0) == 2 && mg[0] == 0x1f && mg[1] == 0x8b) {
+        const int fd2 = dup(fd);
+        if (fd2 < 0 || !(gz = gzdopen(fd2, "rb"))) { if (fd2 >= 0) ::close(fd2); set_error("Invalid path/file: %s", path); return SKX_EIO; }
+        gzbuffer(gz, 1u << 20);
+    }
+    struct GzClose { gzFile &g; ~GzClose() { if (g) gzclose(g); } } gzc{gz};
     static thread_local std::vector<uint8_t> chunk;
     constexpr size_t CH = 4u << 20;
     if (chunk.size() < CH + 1) chunk.resize(CH + 1);
@@ -249,8 +258,8 @@ int stream_fastq_file(const char *path, const std::function<int(int which, const
         return SKX_OK;
     };
     for (;;) {
-        ssize_t r = ::read(fd, chunk.data() + have, CH - have);
-        if (r < 0 && errno == EINTR) continue;
+        ssize_t r = gz ? (ssize_t)gzread(gz, chunk.data() + have, (unsigned)(CH - have)) : ::read(fd, chunk.data() + have, CH - have);
+        if (r < 0 && !gz && errno == EINTR) continue;
         if (r < 0) { set_error("Invalid path/file: %s", path); return SKX_EIO; }
         if (first) {
             if (r == 0) { set_error("Invalid path/file: %s", path); return SKX_EIO; }

@@ -595,16 +595,28 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<uint64_t> bound(n, 0);
     uint64_t slot_bytes = 0;
+    bool any_gz = false;
+    constexpr int SKF_OVER_BOUND = -1002;                                       // a gzip file longer than its trailer says: not an error of the input
     for (int i = 0; i < n; i++) {
         uint64_t bytes = 0;
         for (const char *f : {file1[i], file2 ? file2[i] : nullptr}) {
             if (!f) continue;
-            struct stat sb; unsigned char c0 = 0;
+            struct stat sb; unsigned char c0[2] = {0, 0}, tail[4] = {0, 0, 0, 0};
             const int fd = ::open(f, O_RDONLY);
-            const bool ok = fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && ::read(fd, &c0, 1) == 1 && c0 == '@';
+            bool ok = fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && ::read(fd, c0, 2) == 2;
+            uint64_t plain = ok ? (uint64_t)sb.st_size : 0;
+            if (ok && c0[0] == 0x1f && c0[1] == 0x8b) {
+                // gzip: the reader thread inflates as it goes; the stream's size from the trailer (ISIZE, the last member's length mod 2^32).  A
+                // file whose trailer cannot be its whole text -- several members, 4 GB and more -- is left to the one-shot form, and so is a
+                // batch in which a file turns out longer than its trailer says (SKF_OVER_BOUND below)
+                ok = sb.st_size > 18 && pread(fd, tail, 4, sb.st_size - 4) == 4;
+                plain = (uint64_t)tail[0] | ((uint64_t)tail[1] << 8) | ((uint64_t)tail[2] << 16) | ((uint64_t)tail[3] << 24);
+                ok = ok && plain >= (uint64_t)sb.st_size;
+                any_gz = true;
+            } else ok = ok && c0[0] == '@';
             if (fd >= 0) ::close(fd);
             if (!ok) return SKF_NOT_TAKEN;
-            bytes += (uint64_t)sb.st_size;
+            bytes += plain;
         }
         bound[i] = (bytes / 2 + 64 + 255) & ~255ull;                             // plain FASTQ holds at most half its bytes in either stream
         slot_bytes = std::max(slot_bytes, bound[i]);
@@ -723,7 +735,7 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
                 const std::function<int(int, const uint8_t *, size_t)> emit = [&](int which, const uint8_t *p, size_t nb) -> int {
                     const size_t words = (nb + 1 + 31) / 32;                    // the line and its end
                     if (which == 0) {
-                        if (pos + nb + 1 > cap) { set_error("Invalid FASTA/Q record"); return SKX_EIO; }
+                        if (pos + nb + 1 > cap) { if (any_gz) return SKF_OVER_BOUND; set_error("Invalid FASTA/Q record"); return SKX_EIO; }
                         if (pl.size() < 4 * words) pl.resize(4 * words + 64);
                         line_n = nb;
                         for (int pln = 0; pln < 4; pln++) pl[pln * words + words - 1] = 0;
@@ -749,7 +761,8 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
                 for (const char *f : {file1[i], file2 ? file2[i] : nullptr}) {
                     if (!f) continue;
                     r = stream_fastq_file(f, emit);
-                    if (r == SKF_NOT_TAKEN) { set_error("Invalid FASTA/Q record"); r = SKX_EIO; }      // (the first byte was '@' a moment ago)
+                    if (r == SKF_NOT_TAKEN && !any_gz) { set_error("Invalid FASTA/Q record"); r = SKX_EIO; }      // (the first byte was '@' a moment ago)
+                    if (r == SKF_NOT_TAKEN) r = SKF_OVER_BOUND;                                      // (a gzip file that is not FASTQ: the one-shot form takes the batch)
                     if (r != SKX_OK) break;
                 }
                 if (r == SKX_OK && (pos & 63)) r = push_group();                 // the last, partly filled group
@@ -802,6 +815,7 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     // the kernels' verdict first (SKF_NOT_TAKEN included: the one-shot form takes the batch -- the readers it interrupted recorded nothing),
     // then the reader whose own failure stopped the pipeline
     if (krc != SKX_OK) return krc;
+    for (int i = 0; i < n; i++) if (rcodes[i] == SKF_OVER_BOUND) return SKF_NOT_TAKEN;
     for (int i = 0; i < n; i++) if (rcodes[i] != SKX_OK) { set_error("%s", errs[i].c_str()); return rcodes[i]; }
     if (done < n) { set_error("internal: read-set pipeline stopped early"); return SKX_EUNSUP; }
     packed_pool.release(); seq_pool.release(); qual_pool.release();

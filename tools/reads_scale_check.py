@@ -17,8 +17,26 @@ t0 = time.perf_counter()
 # the isolates are simulated by worker processes (synth.write_read_pair: ~10 s of numpy each; this process never opens the GPU, so forks are fine)
 from concurrent.futures import ProcessPoolExecutor
 workers = int(os.environ.get("RSC_WORKERS", str(min(n, 64, os.cpu_count() or 1))))
+def _write(i, n_, prefix):
+    pr = synth.write_read_pair_of(i, n_, prefix)
+    if os.environ.get("RSC_GZ"):                                  # the read sets as .fastq.gz (zlib level 1)
+        import zlib
+        out = []
+        for f in pr:
+            c = zlib.compressobj(1, zlib.DEFLATED, 31)
+            with open(f, "rb") as src, open(f + ".gz", "wb") as dst:
+                while True:
+                    b = src.read(8 << 20)
+                    if not b:
+                        break
+                    dst.write(c.compress(b))
+                dst.write(c.flush())
+            os.unlink(f)
+            out.append(f + ".gz")
+        pr = out
+    return pr
 with ProcessPoolExecutor(max_workers=workers) as ex:
-    pairs = list(ex.map(synth.write_read_pair_of, range(n), [n] * n, [os.path.join(td, f"iso{i}") for i in range(n)], chunksize=1))
+    pairs = list(ex.map(_write, range(n), [n] * n, [os.path.join(td, f"iso{i}") for i in range(n)], chunksize=1))
 with open(os.path.join(td, "list.txt"), "w") as lst:
     for i, (f1, f2) in enumerate(pairs):
         lst.write(f"iso{i}\t{f1}\t{f2}\n")
