@@ -132,7 +132,13 @@ def cpu_baseline(args, files, n_total, td):
     par = tm["read_parse"] + tm["dict"] + tm["append"]           # summed over threads
     build_serial = max(0.0, build_s - par / threads)
     per_genome_scaled = (par / n) / threads_full + (build_serial + save_s + load_s + align_s) / n
-    res = {"value": n / total, "unit": "genomes/s", "cores": threads, "threads": threads, "host_cores": cores, "kind": "port",
+    quota = None                                       # CPUs the job may use at a time (cgroup v2 cpu.max), where the box says
+    try:
+        q_, p_ = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q_ == "max" else float(q_) / float(p_)
+    except Exception:
+        pass
+    res = {"value": n / total, "unit": "genomes/s", "cores": threads, "threads": threads, "host_cores": cores, "cpu_quota": quota, "kind": "port",
            "sample": f"{n} of the {n_total} synthetic {args.genome_len} bp assemblies as FASTA files on tmpfs: ska build ({threads} threads = "
                      f"the reference's rule for {n} samples) -> .skf -> load -> filter + write_fasta",
            "phases_s": {"build": build_s, "skf_save": save_s, "skf_load": load_s, "filter_write_fasta": align_s},
