@@ -141,6 +141,27 @@ void skx::dev_trim()
     g_cache.free_blocks.clear(); g_cache.cached_bytes = 0;
 }
 
+// CPUs this process may keep busy: the hardware's count or, where a control group caps the job (cgroup v2 cpu.max, v1 cfs quota), the cap --
+// thread teams larger than that only take turns, and a team that overruns the quota has the whole process (the thread that feeds the GPU
+// included) stopped for the rest of the scheduler's period
+int skx::cpu_budget()
+{
+    static const int v = [] {
+        int hc = (int)std::thread::hardware_concurrency(); if (hc < 1) hc = 1;
+        double q = 0, per = 0; char w[64] = {0};
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) { if (fscanf(f, "%63s %lf", w, &per) == 2 && strcmp(w, "max") != 0) q = atof(w); fclose(f); }
+        if (q <= 0) {
+            long long qq = -1, pp = 0;
+            if (FILE *f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(f, "%lld", &qq) != 1) qq = -1; fclose(f); }
+            if (FILE *f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f, "%lld", &pp) != 1) pp = 0; fclose(f); }
+            if (qq > 0 && pp > 0) { q = (double)qq; per = (double)pp; }
+        }
+        if (q > 0 && per > 0) hc = std::min(hc, std::max(1, (int)std::ceil(q / per)));
+        return hc;
+    }();
+    return v;
+}
+
 int skx::check_k(int k)
 {
     if (k < 5 || k > 63 || (k & 1) == 0) { set_error("Invalid k-mer length"); return SKX_EINVAL; }   // ska_dict.rs:342-344
@@ -622,7 +643,7 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
         slot_bytes = std::max(slot_bytes, bound[i]);
     }
     SKX_HIP(hipSetDevice(ctx->device));
-    const int nt = std::max(1, std::min({threads, n, 64}));
+    const int nt = std::max(1, std::min({threads, n, 64, cpu_budget()}));      // (parsing + packing: a reader keeps a CPU busy)
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     // a slot per reader thread and a few waiting for their kernels: more only costs allocation time (64 slots = 17 GB took 4.7 s right after
@@ -858,7 +879,7 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
     const auto t_read0 = std::chrono::steady_clock::now();
     bool any_pair = false;
     for (int i = 0; file2 && i < n; i++) any_pair |= file2[i] != nullptr;
-    const int nt = std::max(1, std::min({threads, n, any_pair ? 64 : 32}));      // (paired read sets are parsed on the host: CPU work, more threads pay)      // 5 GB of FASTA text: 0.43 / 0.24 / 0.24 / 0.32 s with 8 / 16 / 32 / 64 readers (tools/read_knobs.py)
+    const int nt = std::max(1, std::min({threads, n, any_pair ? 64 : 32, std::max(8, 2 * cpu_budget())}));      // (paired read sets are parsed on the host: CPU work, more threads pay)      // 5 GB of FASTA text: 0.43 / 0.24 / 0.24 / 0.32 s with 8 / 16 / 32 / 64 readers (tools/read_knobs.py)
     // Raw path plumbing: reader threads make no HIP calls at all (creating a stream or a pinned buffer per thread serialises in
     // the runtime: 64 threads spent 0.28 s each waiting for theirs).  They read() file pieces into the slots of ONE pinned ring;
     // a single uploader issues the copies on one stream and recycles the slots.  The ring is pinned by a helper thread while

@@ -277,6 +277,7 @@ int planes_distance_split(skx_ctx *ctx, const uint64_t *planes_clean, uint64_t w
                           uint64_t rows_dirty, int S, double constant, int i_lo, int i_hi, skx_dist *out);
 // bit planes of the rows flagged 1 in keep (4 planes with filt, else 8): every word written; rows = how many
 int planes_of_kept_rows(skx_array *a, const uint8_t *keep, int filt, DevBuf<uint64_t> &planes, uint64_t &wpr, uint64_t &rows);
+int cpu_budget();                                                    // CPUs the process may keep busy (hardware threads, or the control group's quota)
 int check_k(int k);                                                  // "Invalid k-mer length" (ska_dict.rs:342-344)
 bool mappable_output_fd(int fd, off_t *pos);                         // regular file, read-write, not O_APPEND: can be written through a mapping
 int array_wide_words(skx_array *a, DevBuf<uint64_t> &tmp, const u128 **words);   // k > 31: the rows' packed 128-bit words on the device (tmp backs them for loaded arrays)
