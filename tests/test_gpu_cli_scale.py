@@ -424,3 +424,35 @@ def test_read_set_pipeline_odd_bytes_and_line_lengths(tmp_path):
         gk, gv, gc = got.export()
         ok, ov, oc = want.export()
         assert len(ok) > 5_000 and np.array_equal(gk, ok) and np.array_equal(gv, ov) and np.array_equal(gc, oc), k
+
+
+def test_read_set_pipeline_gives_way_to_the_sort_based_form(tmp_path):
+    """A sample whose reads are one read six thousand times over puts every one of its k-mers into a partition of the count filter that
+    cannot hold it: reads_sample_words leaves the sample to the sort-based form (SKF_NOT_TAKEN) while other readers are still in their
+    files.  The pipeline must stop, report nothing of its own, and the one-shot form must take the batch: same .skf as
+    SKX_KNOBS=no_reads_pipeline, which is the oracle's array (the kernels' verdict before any reader's)."""
+    import synth
+    wd = str(tmp_path)
+    anc = synth.ancestor(60_000, seed=5)
+    n = 6
+    pairs = [synth.write_read_pair(anc, i, n, os.path.join(wd, f"r{i}"), read_len=100, coverage=25.0, seed=5) for i in range(n)]
+    one = open(pairs[2][0], "rb").read().split(b"\n")[:4]
+    open(pairs[2][0], "wb").write((b"\n".join(one) + b"\n") * 6000)
+    open(pairs[2][1], "wb").write((b"\n".join(one) + b"\n") * 10)
+    with open(os.path.join(wd, "list.txt"), "w") as f:
+        for i, (a, b) in enumerate(pairs):
+            f.write(f"r{i}\t{a}\t{b}\n")
+    outs = {}
+    for tag, env in (("pipe", {}), ("oneshot", {"SKX_KNOBS": "no_reads_pipeline=1"})):
+        r = subprocess.run([SKA, "build", "-f", "list.txt", "-o", tag, "-k", "31", "--min-count", "3", "--threads", "4"], cwd=wd, capture_output=True, timeout=300,
+                           env=dict(os.environ, SKX_DEBUG="1", **env))
+        assert r.returncode == 0, r.stderr[-600:]
+        outs[tag] = (open(os.path.join(wd, tag + ".skf"), "rb").read(), r.stderr)
+    assert b"left to the sort-based form" in outs["pipe"][1]                    # the case this test is about did arise
+    assert outs["pipe"][0] == outs["oneshot"][0]
+    want = ora.Array.build([(f"r{i}", a, b) for i, (a, b) in enumerate(pairs)], k=31, rc=True, q=ora.qual(3, 20, ora.QUAL_STRICT), threads=2)
+    got = ora.Array.load(os.path.join(wd, "pipe.skf"))
+    got.sort_rows(); want.sort_rows()
+    gk, gv, gc = got.export()
+    ok, ov, oc = want.export()
+    assert len(ok) > 10_000 and np.array_equal(gk, ok) and np.array_equal(gv, ov) and np.array_equal(gc, oc)
