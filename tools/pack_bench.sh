@@ -1,7 +1,8 @@
 #!/bin/bash
 # tools/pack_bench.sh [isolates]: the reader threads' work alone (tools/pack_bench.cpp) on freshly simulated read sets, one thread per file
 n=${1:-16}; root=$(pwd); td=$(mktemp -d /dev/shm/pb.XXXX)
-g++ -O2 -pthread -o $td/pack_bench tools/pack_bench.cpp -L ska.rust_amd -lskx -Wl,-rpath,$root/ska.rust_amd || exit 1
+bin=$(mktemp /tmp/pack_bench.XXXX)    # (/dev/shm is mounted noexec on the GPU boxes)
+g++ -O2 -pthread -o $bin tools/pack_bench.cpp -L ska.rust_amd -lskx -Wl,-rpath,$root/ska.rust_amd || exit 1
 python - "$n" "$td" <<'PY'
 import sys, os
 sys.path.insert(0, "ska.rust_amd")
@@ -11,5 +12,5 @@ n, td = int(sys.argv[1]), sys.argv[2]
 with ProcessPoolExecutor(max_workers=min(n, 64)) as ex:
     list(ex.map(synth.write_read_pair_of, range(n), [n] * n, [os.path.join(td, f"iso{i}") for i in range(n)]))
 PY
-for rep in 1 2; do for m in 0 1 2; do $td/pack_bench $m $td/*.fastq; done; done
-rm -rf $td
+for rep in 1 2; do for m in 0 1 2; do $bin $m $td/*.fastq; done; done
+rm -rf $td $bin
