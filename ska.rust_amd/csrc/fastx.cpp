@@ -11,6 +11,7 @@
 #include <cstring>
 #include <cerrno>
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -218,6 +219,7 @@ static int parse_fastq(const std::vector<uint8_t> &b, size_t step, HostStream &o
 // A plain FASTQ file as two streams of lines (sequence, quality; the sink appends the '\n' that ends a record), handed to `emit` line by line: nothing of
 // the file's size is allocated (the reader threads of a batch of 50x isolates each took ~0.8 GB of fresh memory through the whole-file
 // parser, and 32 of them together ran at a sixth of the rate of 8).  Same checks as parse_fastq.  SKF_NOT_TAKEN: not a plain FASTQ file.
+static size_t newline_offsets(const uint8_t *p, size_t n, uint32_t *out, size_t cap, size_t *used);      // (below, beside the other vector code)
 int stream_fastq_file(const char *path, const std::function<int(int which, const uint8_t *p, size_t n)> &emit)
 {
     const int fd = ::open(path, O_RDONLY);
@@ -257,6 +259,41 @@ int stream_fastq_file(const char *path, const std::function<int(int which, const
         line_no++;
         return SKX_OK;
     };
+    // the complete lines of [p, end): line ends found in bulk (newline_offsets), a whole record at a time where its four lines are in hand and
+    // plain (no blank line before it, no carriage returns, the lengths agree) -- two calls of the sink instead of four trips through the
+    // line-by-line rules above; *rest = where the unfinished last line starts.  (Walking a mapping of the file instead of read()ing it was
+    // tried: 1.4 x faster on one thread, 2.5 x slower on sixteen -- page faults and unmapping share the process's address-space lock.)
+    static thread_local std::vector<uint32_t> ends;
+    constexpr size_t PIECE = 1u << 20, CAP = 1u << 15;
+    if (ends.size() < CAP) ends.resize(CAP);
+    auto walk = [&](const uint8_t *p, const uint8_t *end, const uint8_t **rest) -> int {
+        const uint8_t *line = p;
+        while (p < end) {
+            size_t used = 0;
+            const size_t c = newline_offsets(p, std::min<size_t>(PIECE, (size_t)(end - p)), ends.data(), CAP, &used);
+            for (size_t j = 0; j < c;) {
+                if ((line_no & 3u) == 0 && j + 4 <= c) {
+                    const uint8_t *e0 = p + ends[j], *e1 = p + ends[j + 1], *e2 = p + ends[j + 2], *e3 = p + ends[j + 3];
+                    const uint8_t *sq = e0 + 1, *pl = e1 + 1, *ql = e2 + 1;
+                    if (line < e0 && *line == '@' && pl < e2 && *pl == '+' && e0[-1] != '\r' && e2[-1] != '\r' && (sq == e1 || e1[-1] != '\r') &&
+                        (ql == e3 || e3[-1] != '\r') && e1 - sq == e3 - ql) {
+                        int rc = emit(0, sq, (size_t)(e1 - sq));
+                        if (rc == SKX_OK) rc = emit(1, ql, (size_t)(e3 - ql));
+                        if (rc != SKX_OK) return rc;
+                        line = e3 + 1; line_no += 4; j += 4;
+                        continue;
+                    }
+                }
+                const uint8_t *nl = p + ends[j];
+                const int rc = take_line(line, nl);
+                if (rc != SKX_OK) return rc;
+                line = nl + 1; j++;
+            }
+            p += used;
+        }
+        *rest = line;
+        return SKX_OK;
+    };
     for (;;) {
         ssize_t r = gz ? (ssize_t)gzread(gz, chunk.data() + have, (unsigned)(CH - have)) : ::read(fd, chunk.data() + have, CH - have);
         if (r < 0 && !gz && errno == EINTR) continue;
@@ -268,15 +305,17 @@ int stream_fastq_file(const char *path, const std::function<int(int which, const
         }
         const size_t n = have + (size_t)r;
         const uint8_t *p = chunk.data(), *end = p + n;
-        while (p < end) {
+        if (!spill.empty()) {                                              // the end of a line that began in an earlier chunk
             const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
-            if (!nl) break;
-            int rc;
-            if (!spill.empty()) { spill.insert(spill.end(), p, nl); rc = take_line(spill.data(), spill.data() + spill.size()); spill.clear(); }
-            else rc = take_line(p, nl);
-            if (rc != SKX_OK) return rc;
-            p = nl + 1;
+            if (nl) {
+                spill.insert(spill.end(), p, nl);
+                const int rc = take_line(spill.data(), spill.data() + spill.size());
+                spill.clear();
+                if (rc != SKX_OK) return rc;
+                p = nl + 1;
+            }
         }
+        if (spill.empty()) { const int rc = walk(p, end, &p); if (rc != SKX_OK) return rc; }
         have = (size_t)(end - p);
         if (r == 0) {                                                       // end of file: a last line without terminator
             if (have || !spill.empty()) {
@@ -294,71 +333,160 @@ int stream_fastq_file(const char *path, const std::function<int(int which, const
 }
 
 // ---- read sets as bit planes (the reader threads of a batch of read sets: 5 bits per position cross PCIe instead of two bytes) ----
-// A sequence line as three planes, one 32-bit word per 32 bases, bits beyond the line zero: lo / hi = bits 1 / 2 of the byte (the code
+// A sequence line as three planes, one 64-bit word per 64 bases, bits beyond the line zero: lo / hi = bits 1 / 2 of the byte (the code
 // encode_base gives: A 0, C 1, T 2, G 3 -- bit_encoding.rs:42-51), bad = the bytes valid_base rejects (low nibble 14: N, n;
 // bit_encoding.rs:52-54).  A quality line as one plane: the bases the quality filters reject, !(q - 33 > min_qual) in u8 arithmetic
-// (split_kmer.rs:98-101).  AVX2 where the processor has it (32 bytes a step), byte by byte otherwise.
+// (split_kmer.rs:98-101).  AVX-512 (64 bytes a step, the compare masks are the plane words) or AVX2 (32) where the processor has them,
+// byte by byte otherwise.
 #include <immintrin.h>
-__attribute__((target("avx2"))) static void pack_bases_avx2(const uint8_t *s, size_t n, uint32_t *lo, uint32_t *hi, uint32_t *bad)
+__attribute__((target("avx512f,avx512bw"))) static void pack_bases_avx512(const uint8_t *s, size_t n, uint64_t *lo, uint64_t *hi, uint64_t *bad)
 {
-    const __m256i nib = _mm256_set1_epi8(0x0F), v14 = _mm256_set1_epi8(14);
+    const __m512i nib = _mm512_set1_epi8(0x0F), v14 = _mm512_set1_epi8(14);
     size_t w = 0;
-    for (size_t i = 0; i < n; i += 32, w++) {
+    for (size_t i = 0; i < n; i += 64, w++) {
         const size_t m = n - i;
-        __m256i b;
-        if (m >= 32) b = _mm256_loadu_si256((const __m256i *)(s + i));
-        else { alignas(32) uint8_t tmp[32] = {0}; memcpy(tmp, s + i, m); b = _mm256_load_si256((const __m256i *)tmp); }
-        const uint32_t in = m >= 32 ? 0xFFFFFFFFu : (1u << m) - 1u;
-        const uint32_t bm = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_and_si256(b, nib), v14)) & in;
-        lo[w] = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(b, 6)) & in & ~bm;          // bit 1 of every byte at its top
-        hi[w] = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(b, 5)) & in & ~bm;          // bit 2
+        const __mmask64 in = m >= 64 ? ~0ull : (1ull << m) - 1ull;
+        const __m512i b = _mm512_maskz_loadu_epi8(in, s + i);                    // (masked: nothing is read beyond the line)
+        const uint64_t bm = _mm512_mask_cmpeq_epi8_mask(in, _mm512_and_si512(b, nib), v14);
+        lo[w] = (uint64_t)_mm512_movepi8_mask(_mm512_slli_epi16(b, 6)) & in & ~bm;          // bit 1 of every byte at its top
+        hi[w] = (uint64_t)_mm512_movepi8_mask(_mm512_slli_epi16(b, 5)) & in & ~bm;          // bit 2
         bad[w] = bm;
     }
 }
-__attribute__((target("avx2"))) static void pack_qual_avx2(const uint8_t *q, size_t n, int min_qual, uint32_t *qb)
+__attribute__((target("avx512f,avx512bw"))) static void pack_qual_avx512(const uint8_t *q, size_t n, int min_qual, uint64_t *qb)
 {
-    const __m256i v33 = _mm256_set1_epi8(33), vm = _mm256_set1_epi8((char)(uint8_t)min_qual);
+    const __m512i v33 = _mm512_set1_epi8(33), vm = _mm512_set1_epi8((char)(uint8_t)min_qual);
     size_t w = 0;
-    for (size_t i = 0; i < n; i += 32, w++) {
+    for (size_t i = 0; i < n; i += 64, w++) {
         const size_t m = n - i;
-        __m256i b;
-        if (m >= 32) b = _mm256_loadu_si256((const __m256i *)(q + i));
-        else { alignas(32) uint8_t tmp[32] = {0}; memcpy(tmp, q + i, m); b = _mm256_load_si256((const __m256i *)tmp); }
-        const uint32_t in = m >= 32 ? 0xFFFFFFFFu : (1u << m) - 1u;
-        const __m256i t = _mm256_sub_epi8(b, v33);
-        qb[w] = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_max_epu8(t, vm), vm)) & in;      // t <= min_qual, unsigned
+        const __mmask64 in = m >= 64 ? ~0ull : (1ull << m) - 1ull;
+        const __m512i b = _mm512_maskz_loadu_epi8(in, q + i);
+        qb[w] = _mm512_mask_cmple_epu8_mask(in, _mm512_sub_epi8(b, v33), vm);             // q - 33 <= min_qual, unsigned
     }
 }
-static void pack_bases_plain(const uint8_t *s, size_t n, uint32_t *lo, uint32_t *hi, uint32_t *bad)
+__attribute__((target("avx2"))) static inline void planes32_avx2(const uint8_t *s, size_t m, uint32_t &lo, uint32_t &hi, uint32_t &bad)
 {
-    for (size_t w = 0; w * 32 < n; w++) {
-        uint32_t l = 0, h = 0, b = 0;
-        const size_t m = std::min<size_t>(32, n - w * 32);
+    const __m256i nib = _mm256_set1_epi8(0x0F), v14 = _mm256_set1_epi8(14);
+    __m256i b;
+    if (m >= 32) b = _mm256_loadu_si256((const __m256i *)s);
+    else { alignas(32) uint8_t tmp[32] = {0}; memcpy(tmp, s, m); b = _mm256_load_si256((const __m256i *)tmp); }
+    const uint32_t in = m >= 32 ? 0xFFFFFFFFu : (1u << m) - 1u;
+    bad = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_and_si256(b, nib), v14)) & in;
+    lo = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(b, 6)) & in & ~bad;
+    hi = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(b, 5)) & in & ~bad;
+}
+__attribute__((target("avx2"))) static void pack_bases_avx2(const uint8_t *s, size_t n, uint64_t *lo, uint64_t *hi, uint64_t *bad)
+{
+    size_t w = 0;
+    for (size_t i = 0; i < n; i += 64, w++) {
+        uint32_t l0, h0, b0, l1 = 0, h1 = 0, b1 = 0;
+        planes32_avx2(s + i, n - i, l0, h0, b0);
+        if (n - i > 32) planes32_avx2(s + i + 32, n - i - 32, l1, h1, b1);
+        lo[w] = ((uint64_t)l1 << 32) | l0; hi[w] = ((uint64_t)h1 << 32) | h0; bad[w] = ((uint64_t)b1 << 32) | b0;
+    }
+}
+__attribute__((target("avx2"))) static inline uint32_t qual32_avx2(const uint8_t *q, size_t m, int min_qual)
+{
+    const __m256i v33 = _mm256_set1_epi8(33), vm = _mm256_set1_epi8((char)(uint8_t)min_qual);
+    __m256i b;
+    if (m >= 32) b = _mm256_loadu_si256((const __m256i *)q);
+    else { alignas(32) uint8_t tmp[32] = {0}; memcpy(tmp, q, m); b = _mm256_load_si256((const __m256i *)tmp); }
+    const uint32_t in = m >= 32 ? 0xFFFFFFFFu : (1u << m) - 1u;
+    const __m256i t = _mm256_sub_epi8(b, v33);
+    return (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_max_epu8(t, vm), vm)) & in;      // t <= min_qual, unsigned
+}
+__attribute__((target("avx2"))) static void pack_qual_avx2(const uint8_t *q, size_t n, int min_qual, uint64_t *qb)
+{
+    size_t w = 0;
+    for (size_t i = 0; i < n; i += 64, w++) {
+        const uint32_t a = qual32_avx2(q + i, n - i, min_qual), b = n - i > 32 ? qual32_avx2(q + i + 32, n - i - 32, min_qual) : 0u;
+        qb[w] = ((uint64_t)b << 32) | a;
+    }
+}
+static void pack_bases_plain(const uint8_t *s, size_t n, uint64_t *lo, uint64_t *hi, uint64_t *bad)
+{
+    for (size_t w = 0; w * 64 < n; w++) {
+        uint64_t l = 0, h = 0, b = 0;
+        const size_t m = std::min<size_t>(64, n - w * 64);
         for (size_t j = 0; j < m; j++) {
-            const uint8_t c = s[w * 32 + j];
-            const uint32_t isbad = (c & 0xF) == 14;
-            b |= isbad << j; l |= (((uint32_t)c >> 1) & 1u & ~isbad) << j; h |= (((uint32_t)c >> 2) & 1u & ~isbad) << j;
+            const uint8_t c = s[w * 64 + j];
+            const uint64_t isbad = (c & 0xF) == 14;
+            b |= isbad << j; l |= (((uint64_t)c >> 1) & 1u & ~isbad) << j; h |= (((uint64_t)c >> 2) & 1u & ~isbad) << j;
         }
         lo[w] = l; hi[w] = h; bad[w] = b;
     }
 }
-static void pack_qual_plain(const uint8_t *q, size_t n, int min_qual, uint32_t *qb)
+static void pack_qual_plain(const uint8_t *q, size_t n, int min_qual, uint64_t *qb)
 {
-    for (size_t w = 0; w * 32 < n; w++) {
-        uint32_t v = 0;
-        const size_t m = std::min<size_t>(32, n - w * 32);
-        for (size_t j = 0; j < m; j++) v |= (uint32_t)((uint8_t)(q[w * 32 + j] - 33) <= (uint8_t)min_qual) << j;
+    for (size_t w = 0; w * 64 < n; w++) {
+        uint64_t v = 0;
+        const size_t m = std::min<size_t>(64, n - w * 64);
+        for (size_t j = 0; j < m; j++) v |= (uint64_t)((uint8_t)(q[w * 64 + j] - 33) <= (uint8_t)min_qual) << j;
         qb[w] = v;
     }
 }
-static bool have_avx2() { static const bool v = __builtin_cpu_supports("avx2") && !knob("no_avx2"); return v; }
-void pack_bases_planes(const uint8_t *s, size_t n, uint32_t *lo, uint32_t *hi, uint32_t *bad)
+// 2 = AVX-512 (F + BW), 1 = AVX2, 0 = neither; SKX_KNOBS=simd=<n> caps it (tests run all three)
+static int simd_level()
 {
-    if (have_avx2()) pack_bases_avx2(s, n, lo, hi, bad); else pack_bases_plain(s, n, lo, hi, bad);
+    static const int v = [] {
+        int lv = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") ? 2 : __builtin_cpu_supports("avx2") ? 1 : 0;
+        if (knob("simd_cap")) lv = std::min<int>(lv, (int)knob("simd_cap") - 1);
+        return lv;
+    }();
+    return v;
 }
-void pack_qual_plane(const uint8_t *q, size_t n, int min_qual, uint32_t *qb)
+// the line ends of a piece of text, in bulk: offsets of '\n' in [p, p + n), at most `cap` of them (cap >= 64); *used = the bytes looked at (n unless the
+// list filled up first).  64 / 32 bytes a step where the processor has AVX-512 / AVX2 (a memchr per 76-byte line was a third of a reader thread's time)
+__attribute__((target("avx512f,avx512bw"))) static size_t newlines_avx512(const uint8_t *p, size_t n, uint32_t *out, size_t cap, size_t *used)
 {
-    if (have_avx2()) pack_qual_avx2(q, n, min_qual, qb); else pack_qual_plain(q, n, min_qual, qb);
+    const __m512i nl = _mm512_set1_epi8('\n');
+    size_t c = 0, i = 0;
+    for (; i < n && c + 64 <= cap; i += 64) {
+        const size_t m = n - i;
+        const __mmask64 in = m >= 64 ? ~0ull : (1ull << m) - 1ull;
+        uint64_t k = _mm512_mask_cmpeq_epi8_mask(in, _mm512_maskz_loadu_epi8(in, p + i), nl);
+        while (k) { out[c++] = (uint32_t)(i + (size_t)__builtin_ctzll(k)); k &= k - 1; }
+    }
+    *used = i < n ? i : n;
+    return c;
+}
+__attribute__((target("avx2"))) static size_t newlines_avx2(const uint8_t *p, size_t n, uint32_t *out, size_t cap, size_t *used)
+{
+    const __m256i nl = _mm256_set1_epi8('\n');
+    size_t c = 0, i = 0;
+    for (; i + 32 <= n && c + 32 <= cap; i += 32) {
+        uint32_t k = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)(p + i)), nl));
+        while (k) { out[c++] = (uint32_t)(i + (size_t)__builtin_ctz(k)); k &= k - 1; }
+    }
+    for (; i < n && c < cap && n - i < 32; i++) if (p[i] == '\n') out[c++] = (uint32_t)i;      // the tail, byte by byte
+    *used = i;
+    return c;
+}
+static size_t newlines_plain(const uint8_t *p, size_t n, uint32_t *out, size_t cap, size_t *used)
+{
+    size_t c = 0, i = 0;
+    while (i < n && c < cap) {
+        const uint8_t *q = (const uint8_t *)memchr(p + i, '\n', n - i);
+        if (!q) { i = n; break; }
+        out[c++] = (uint32_t)(q - p); i = (size_t)(q - p) + 1;
+    }
+    *used = i;
+    return c;
+}
+static size_t newline_offsets(const uint8_t *p, size_t n, uint32_t *out, size_t cap, size_t *used)
+{
+    const int lv = simd_level();
+    return lv == 2 ? newlines_avx512(p, n, out, cap, used) : lv == 1 ? newlines_avx2(p, n, out, cap, used) : newlines_plain(p, n, out, cap, used);
+}
+void pack_bases_planes(const uint8_t *s, size_t n, uint64_t *lo, uint64_t *hi, uint64_t *bad)
+{
+    const int lv = simd_level();
+    if (lv == 2) pack_bases_avx512(s, n, lo, hi, bad); else if (lv == 1) pack_bases_avx2(s, n, lo, hi, bad); else pack_bases_plain(s, n, lo, hi, bad);
+}
+void pack_qual_plane(const uint8_t *q, size_t n, int min_qual, uint64_t *qb)
+{
+    const int lv = simd_level();
+    if (lv == 2) pack_qual_avx512(q, n, min_qual, qb); else if (lv == 1) pack_qual_avx2(q, n, min_qual, qb); else pack_qual_plain(q, n, min_qual, qb);
 }
 
 int read_sample_stream(const char *file1, const char *file2, double proportion_reads, HostStream &out)

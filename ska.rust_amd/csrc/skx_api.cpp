@@ -710,7 +710,7 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     for (int t = 0; t < nt; t++)
         pool.emplace_back([&]() {
             struct Leave { Ring &r; ~Leave() { { std::lock_guard<std::mutex> lk(r.mu); r.readers_left--; } r.cv_work.notify_all(); r.cv_ready.notify_all(); } } leave{ring};
-            std::vector<uint32_t> planes;                                     // a record's four planes (sequence line, then its quality line)
+            std::vector<uint64_t> planes;                                     // a record's four planes (sequence line, then its quality line)
             for (int i; (i = next.fetch_add(1)) < n;) {
                 int sslot = -1;
                 {
@@ -751,10 +751,10 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
                     return SKX_OK;
                 };
                 // a record: its sequence line's planes wait for the quality line (the two lines may lie in different pieces of the file)
-                std::vector<uint32_t> &pl = planes;
+                std::vector<uint64_t> &pl = planes;
                 size_t line_n = 0;
                 const std::function<int(int, const uint8_t *, size_t)> emit = [&](int which, const uint8_t *p, size_t nb) -> int {
-                    const size_t words = (nb + 1 + 31) / 32;                    // the line and its end
+                    const size_t words = (nb + 1 + 63) / 64;                    // the line and its end
                     if (which == 0) {
                         if (pos + nb + 1 > cap) { if (any_gz) return SKF_OVER_BOUND; set_error("Invalid FASTA/Q record"); return SKX_EIO; }
                         if (pl.size() < 4 * words) pl.resize(4 * words + 64);
@@ -765,15 +765,15 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
                     }
                     if (nb != line_n) { set_error("Invalid FASTA/Q record"); return SKX_EIO; }
                     pack_qual_plane(p, nb, min_qual_host, &pl[3 * words]);
-                    const uint32_t *lo = &pl[0], *hi = &pl[words], *bd = &pl[2 * words], *qb = &pl[3 * words];
+                    const uint64_t *lo = &pl[0], *hi = &pl[words], *bd = &pl[2 * words], *qb = &pl[3 * words];
                     for (size_t w = 0; w < words; w++) {
-                        const unsigned take = (unsigned)std::min<size_t>(32, nb + 1 - 32 * w), off = (unsigned)(pos & 63);
-                        const uint64_t v[5] = {lo[w], hi[w], bd[w], nb / 32 == w ? 1ull << (nb & 31) : 0ull, qb[w]};
+                        const unsigned take = (unsigned)std::min<size_t>(64, nb + 1 - 64 * w), off = (unsigned)(pos & 63);
+                        const uint64_t v[5] = {lo[w], hi[w], bd[w], nb / 64 == w ? 1ull << (nb & 63) : 0ull, qb[w]};
                         for (int pln = 0; pln < 5; pln++) cur[pln] |= v[pln] << off;
                         pos += take;
                         if (off + take >= 64) {
                             const int pr = push_group(); if (pr != SKX_OK) return pr;
-                            for (int pln = 0; pln < 5; pln++) cur[pln] = off + take > 64 ? v[pln] >> (64 - off) : 0ull;
+                            for (int pln = 0; pln < 5; pln++) cur[pln] = off ? v[pln] >> (64 - off) : 0ull;      // (what did not fit; bits beyond `take` are zero)
                         }
                     }
                     return SKX_OK;

@@ -192,10 +192,10 @@ int read_sample_stream(const char *file1, const char *file2, double proportion_r
 // a plain FASTQ file line by line: emit(0, sequence line) / emit(1, quality line), without terminators -- the sink adds the '\n' that ends a
 // record of the stream (SKF_NOT_TAKEN: not plain FASTQ)
 int stream_fastq_file(const char *path, const std::function<int(int which, const uint8_t *p, size_t n)> &emit);
-// a sequence / quality line of a read as bit planes, 32 positions per word, bits beyond the line zero (fastx.cpp; READ_GROUP_BYTES: five
+// a sequence / quality line of a read as bit planes, 64 positions per word, bits beyond the line zero (fastx.cpp; READ_GROUP_BYTES: five
 // 64-position words -- lo, hi, bad, newline, quality verdict -- make one group of the packed stream, launch_expand_planes takes it apart)
-void pack_bases_planes(const uint8_t *s, size_t n, uint32_t *lo, uint32_t *hi, uint32_t *bad);
-void pack_qual_plane(const uint8_t *q, size_t n, int min_qual, uint32_t *qb);
+void pack_bases_planes(const uint8_t *s, size_t n, uint64_t *lo, uint64_t *hi, uint64_t *bad);
+void pack_qual_plane(const uint8_t *q, size_t n, int min_qual, uint64_t *qb);
 constexpr size_t READ_GROUP_BYTES = 40;
 // FASTQ sample -> sorted unique packed words (skx_reads.hip)
 int reads_sample_dict(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t len, int k, int rc, const skx_qual &q,

@@ -412,12 +412,12 @@ def test_read_set_pipeline_odd_bytes_and_line_lengths(tmp_path):
             f.write(f"o{i}\t{a}\t{b}\n")
     for k, qf, oq in (("31", "strict", ora.QUAL_STRICT), ("41", "middle", ora.QUAL_MIDDLE)):
         outs = {}
-        for tag, env in (("pipe", {}), ("plain", {"SKX_KNOBS": "no_avx2=1"}), ("oneshot", {"SKX_KNOBS": "no_reads_pipeline=1"})):
+        for tag, env in (("pipe", {}), ("avx2", {"SKX_KNOBS": "simd_cap=2"}), ("plain", {"SKX_KNOBS": "simd_cap=1"}), ("oneshot", {"SKX_KNOBS": "no_reads_pipeline=1"})):
             r = subprocess.run([SKA, "build", "-f", "list.txt", "-o", f"{tag}{k}", "-k", k, "--min-count", "2", "--min-qual", "20", "--qual-filter", qf, "--threads", "3"],
                                cwd=wd, capture_output=True, timeout=300, env=dict(os.environ, **env))
             assert r.returncode == 0, r.stderr[-600:]
             outs[tag] = open(os.path.join(wd, f"{tag}{k}.skf"), "rb").read()
-        assert outs["pipe"] == outs["oneshot"] and outs["plain"] == outs["oneshot"], k
+        assert outs["pipe"] == outs["oneshot"] and outs["avx2"] == outs["oneshot"] and outs["plain"] == outs["oneshot"], k
         want = ora.Array.build([(f"o{i}", a, b) for i, (a, b) in enumerate(files)], k=int(k), rc=True, q=ora.qual(2, 20, oq), threads=2)
         got = ora.Array.load(os.path.join(wd, f"pipe{k}.skf"))
         got.sort_rows(); want.sort_rows()
