@@ -649,13 +649,13 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     // a slot per reader thread and a few waiting for their kernels: more only costs allocation time (64 slots = 17 GB took 4.7 s right after
     // another process had released the memory, 32 slots 0.26 s: profiles/r03zr_reads_pipeline_512.log)
     // A sample crosses PCIe as bit planes -- groups of 64 positions, five words each: two code bits, the bases valid_base rejects, the line
-    // ends, the quality verdicts (fastx.cpp pack_*_planes) -- packed by its reader thread: 5 bits per position instead of two bytes; one
-    // launch per sample takes them apart into the record streams the kernels below read (the copy was what bounded a batch: 504 MB per
+    // ends, the quality verdicts (fastx.cpp pack_*_planes) -- packed by its reader thread: 5 bits per position instead of two bytes; the
+    // window pass and the rebuild of the passing windows' words read them as they are (the copy was what bounded a batch: 504 MB per
     // 50x isolate at ~32 GB/s = 63 isolates/s)
     const uint64_t pslot_bytes = ((slot_bytes / 64 + 2) * READ_GROUP_BYTES + 255) & ~255ull;
     int P = (int)std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(2, std::min<uint64_t>((uint64_t)nt + 8, (free_b / 8) / (pslot_bytes + 1))));
-    DevBuf<uint8_t> packed_pool, seq_pool, qual_pool;                           // (the two streams: of the sample whose kernels run)
-    SKX_TRY(packed_pool.alloc((uint64_t)P * pslot_bytes)); SKX_TRY(seq_pool.alloc(slot_bytes + 64)); SKX_TRY(qual_pool.alloc(slot_bytes + 64));
+    DevBuf<uint8_t> packed_pool;
+    SKX_TRY(packed_pool.alloc((uint64_t)P * pslot_bytes));
     constexpr size_t SLOT = ((8u << 20) / READ_GROUP_BYTES) * READ_GROUP_BYTES;          // whole groups
     const int min_qual_host = q ? (int)q->min_qual : 20;
     const int n_slots = 2 * nt + 8;
@@ -815,8 +815,8 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
         }
         const auto tk = std::chrono::steady_clock::now();
         skx_qual qs = q ? *q : skx_qual{5, 20, SKX_QUAL_STRICT};
-        launch_expand_planes((const uint64_t *)(packed_pool.p + (uint64_t)smp[i].slot * pslot_bytes), smp[i].len, seq_pool.p, qual_pool.p, ctx->stream);
-        krc = reads_sample_words(ctx, seq_pool.p, qual_pool.p, smp[i].len, k, rc, qs, wl[i], wh2[i], &cnt[i]);      // (returns with the stream idle: the slot and the two streams are free)
+        // (the kernels read the packed planes themselves: the two record streams never exist in memory)
+        krc = reads_sample_words(ctx, nullptr, nullptr, smp[i].len, k, rc, qs, wl[i], wh2[i], &cnt[i], (const uint64_t *)(packed_pool.p + (uint64_t)smp[i].slot * pslot_bytes));      // (returns with the stream idle: the slot is free)
         t_kernels += std::chrono::duration<double>(std::chrono::steady_clock::now() - tk).count();
         { std::lock_guard<std::mutex> lk(ring.mu); ring.free_stream.push_back(smp[i].slot); if (krc != SKX_OK) ring.abort = true; }
         ring.cv_stream.notify_all();
@@ -839,7 +839,7 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     for (int i = 0; i < n; i++) if (rcodes[i] == SKF_OVER_BOUND) return SKF_NOT_TAKEN;
     for (int i = 0; i < n; i++) if (rcodes[i] != SKX_OK) { set_error("%s", errs[i].c_str()); return rcodes[i]; }
     if (done < n) { set_error("internal: read-set pipeline stopped early"); return SKX_EUNSUP; }
-    packed_pool.release(); seq_pool.release(); qual_pool.release();
+    packed_pool.release();
     const auto t1 = std::chrono::steady_clock::now();
     skx_dictset *d = nullptr;
     int r = reads_words_to_dictset(ctx, wl, wh2, cnt, k, rc, &d);

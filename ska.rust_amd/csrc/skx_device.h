@@ -271,7 +271,35 @@ void launch_gather_keys_wide(const u128 *stage, uint32_t stride, const uint32_t 
 
 // ---- FASTA text -> record stream (skx_parse.hip): tiles of 16 KB; scratch per tile: 8 B summary, 8 B offset, 1 B kind
 uint64_t fasta_parse_tiles(uint64_t len);
-// packed read sets (groups of 64 positions x 5 planes) -> sequence / quality record streams; the streams need 16 bytes of slack past len
+// Packed read sets (fastx.cpp pack_*_planes: groups of 64 positions, five words each -- two code bits, the bytes valid_base rejects, line ends,
+// quality verdicts).  planes_bytes16: sixteen positions from position 16 t as the bytes the read-set kernels look at: sequence A C T G (any
+// byte of that code), N (rejected), '\n'; quality ' ' (passes every min_qual below 255: (32 - 33) & 255 = 255), '!' (fails every one), '\n';
+// positions from `len` on are line ends.
+#ifdef __HIPCC__
+__device__ static inline void planes_bytes16(const uint64_t *groups, uint64_t t, uint64_t len, uint32_t sw[4], uint32_t qw[4])
+{
+    const uint64_t p0 = t * 16;
+    const uint64_t *g = groups + (t >> 2) * 5;
+    const int sh = (int)(t & 3) * 16;
+    const uint32_t lo = (uint32_t)(g[0] >> sh) & 0xFFFFu, hi = (uint32_t)(g[1] >> sh) & 0xFFFFu, bad = (uint32_t)(g[2] >> sh) & 0xFFFFu,
+                   nl = (uint32_t)(g[3] >> sh) & 0xFFFFu, qb = (uint32_t)(g[4] >> sh) & 0xFFFFu;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint32_t x = 0, y = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int j = 4 * i + b;
+            const uint32_t code = ((lo >> j) & 1u) | (((hi >> j) & 1u) << 1);
+            const bool isnl = ((nl >> j) & 1u) || p0 + (uint64_t)j >= len;
+            const uint32_t c = isnl ? 10u : ((bad >> j) & 1u) ? 78u : (0x47544341u >> (8 * code)) & 0xFFu;      // "ACTG"
+            const uint32_t q = isnl ? 10u : ((qb >> j) & 1u) ? 33u : 32u;
+            x |= c << (8 * b); y |= q << (8 * b);
+        }
+        sw[i] = x; qw[i] = y;
+    }
+}
+#endif
+// the same as two record streams in device memory (16 bytes of slack past len): the forms that read streams (sort-based read sets, tests)
 void launch_expand_planes(const uint64_t *groups, uint64_t len, uint8_t *seq, uint8_t *qual, hipStream_t st);
 void launch_fasta_parse(const uint8_t *const *raw, const uint64_t *rawlen, uint8_t *const *out, uint64_t *outlen, const uint32_t *tile_file,
                         const uint64_t *tile_base, uint64_t n_tiles, void *summary, uint64_t *tile_off, uint8_t *tile_kind, int n, hipStream_t st);

@@ -195,29 +195,11 @@ uint64_t fasta_parse_tiles(uint64_t len) { return (len + PT_TILE - 1) / PT_TILE;
 __global__ __launch_bounds__(256) void expand_planes_kernel(const uint64_t *groups, uint64_t len, uint8_t *seq, uint8_t *qual)
 {
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint64_t p0 = t * 16;
-    if (p0 >= len) return;
-    const uint64_t *g = groups + (t >> 2) * 5;
-    const int sh = (int)(t & 3) * 16;
-    const uint32_t lo = (uint32_t)(g[0] >> sh) & 0xFFFFu, hi = (uint32_t)(g[1] >> sh) & 0xFFFFu, bad = (uint32_t)(g[2] >> sh) & 0xFFFFu,
-                   nl = (uint32_t)(g[3] >> sh) & 0xFFFFu, qb = (uint32_t)(g[4] >> sh) & 0xFFFFu;
+    if (t * 16 >= len) return;
     uint32_t sw[4], qw[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        uint32_t x = 0, y = 0;
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const int j = 4 * i + b;
-            const uint32_t code = ((lo >> j) & 1u) | (((hi >> j) & 1u) << 1);
-            const bool past = p0 + (uint64_t)j >= len, isnl = ((nl >> j) & 1u) || past;
-            const uint32_t c = isnl ? 10u : ((bad >> j) & 1u) ? 78u : (0x47544341u >> (8 * code)) & 0xFFu;      // "ACTG"
-            const uint32_t q = isnl ? 10u : ((qb >> j) & 1u) ? 33u : 32u;
-            x |= c << (8 * b); y |= q << (8 * b);
-        }
-        sw[i] = x; qw[i] = y;
-    }
-    *reinterpret_cast<uint4 *>(seq + p0) = make_uint4(sw[0], sw[1], sw[2], sw[3]);
-    *reinterpret_cast<uint4 *>(qual + p0) = make_uint4(qw[0], qw[1], qw[2], qw[3]);
+    planes_bytes16(groups, t, len, sw, qw);
+    *reinterpret_cast<uint4 *>(seq + t * 16) = make_uint4(sw[0], sw[1], sw[2], sw[3]);
+    *reinterpret_cast<uint4 *>(qual + t * 16) = make_uint4(qw[0], qw[1], qw[2], qw[3]);
 }
 void launch_expand_planes(const uint64_t *groups, uint64_t len, uint8_t *seq, uint8_t *qual, hipStream_t st)
 {

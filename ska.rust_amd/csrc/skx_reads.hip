@@ -27,6 +27,7 @@ struct ReadsArgs {
     HashParams hp; WideHash wh;
     uint64_t *hash; uint64_t *wlo; uint64_t *whi; uint8_t *flag;
     unsigned long long *n_valid;      // optional: [256] counters, slot blockIdx % 256 += windows that pass the gates (one hot counter costs 2 ms)
+    const uint64_t *planes;           // optional: the sample as packed bit planes (skx_device.h planes_bytes16) instead of seq / qual
 };
 
 // Eight consecutive window-end positions per thread: the state of the window before the first one is built from its k
@@ -66,7 +67,12 @@ __global__ __launch_bounds__(RW_NT) void reads_windows_kernel(ReadsArgs a)
     // aligned), byte by byte at its two ends
     for (int c = threadIdx.x; c < (RW_TILE + 80) / 16; c += RW_NT) {
         const int64_t pos = (int64_t)p0 - 64 + 16 * c;
-        if (pos >= 0 && (uint64_t)pos + 16 <= a.len) {
+        if (a.planes) {                                            // the tile's bytes straight from the packed planes (no record streams in memory)
+            uint32_t sw[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au}, qw[4] = {0x7E7E7E7Eu, 0x7E7E7E7Eu, 0x7E7E7E7Eu, 0x7E7E7E7Eu};
+            if (pos >= 0 && (uint64_t)pos < a.len) planes_bytes16(a.planes, (uint64_t)pos / 16, a.len, sw, qw);
+            *reinterpret_cast<uint4 *>(s_seq + 16 * c) = make_uint4(sw[0], sw[1], sw[2], sw[3]);
+            *reinterpret_cast<uint4 *>(s_q + 16 * c) = make_uint4(qw[0], qw[1], qw[2], qw[3]);
+        } else if (pos >= 0 && (uint64_t)pos + 16 <= a.len) {
             *reinterpret_cast<uint4 *>(s_seq + 16 * c) = *reinterpret_cast<const uint4 *>(a.seq + pos);
             if (a.qual) *reinterpret_cast<uint4 *>(s_q + 16 * c) = *reinterpret_cast<const uint4 *>(a.qual + pos);
             else *reinterpret_cast<uint4 *>(s_q + 16 * c) = make_uint4(0x7E7E7E7Eu, 0x7E7E7E7Eu, 0x7E7E7E7Eu, 0x7E7E7E7Eu);
@@ -79,7 +85,8 @@ __global__ __launch_bounds__(RW_NT) void reads_windows_kernel(ReadsArgs a)
             }
     }
     __syncthreads();
-    auto qbad = [&](int i) { return a.qual && (uint8_t)(s_q[i] - 33) <= (uint8_t)a.min_qual; };     // !((q-33) > min_qual)
+    const bool has_q = a.qual != nullptr || a.planes != nullptr;
+    auto qbad = [&](int i) { return has_q && (uint8_t)(s_q[i] - 33) <= (uint8_t)a.min_qual; };     // !((q-33) > min_qual)
     auto bad = [&](int i) { const uint8_t b = s_seq[i]; return (b & 0xF) == 14 || b == '\n' || (a.qual_filter == 2 && qbad(i)); };
     auto code = [&](int i) -> uint32_t { return (s_seq[i] >> 1) & 3u; };
     const uint64_t pstart = p0 + (uint64_t)threadIdx.x * (RW_PPT * RW_NB);
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(RW_NT) void reads_windows_kernel(ReadsArgs a)
             bool valid = run >= (uint32_t)k;
             if (s_seq[ej + 1] == '\n') valid = valid && run > (uint32_t)k;
             // middle_base_qual (split_kmer.rs:328-339): Middle and Strict gate on the middle base
-            const bool midq_ok = !(a.qual && a.qual_filter != 0 && qbad(ej - h));
+            const bool midq_ok = !(has_q && a.qual_filter != 0 && qbad(ej - h));
             o_hash[j] = userc ? (fh < rh ? fh : rh) : fh;
             s_flag[threadIdx.x * (RW_PPT * RW_NB) + b * RW_PPT + j] = valid && midq_ok;            // the `&&` of ska_dict.rs:155-157: the count filter is not touched otherwise
             if (!WORDS) continue;
@@ -327,6 +334,49 @@ __global__ __launch_bounds__(256) void words_rebuild_kernel(const uint32_t *pos,
         (void)am;
     }
 }
+// the same from the packed planes: a window's code bits are two 64-bit pieces of the lo / hi planes (the window may straddle two groups)
+__global__ __launch_bounds__(256) void words_rebuild_planes_kernel(const uint32_t *pos, uint64_t n, const uint64_t *planes, int k, int rc, HashParams hp, WideHash wh,
+                                                                    uint64_t *out_lo, uint64_t *out_hi)
+{
+    const int h = (k - 1) / 2;
+    const int wsh = wh.hb + 4;
+    const int wa1 = wsh < 64 ? wsh : 0, wa2 = wsh < 64 ? 64 - wsh : 0, wa3 = wsh < 64 ? 0 : wsh - 64;
+    const uint64_t wm1 = wsh < 64 ? ~0ull : 0ull;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t last = pos[i], first = last - (uint64_t)(k - 1);
+        const uint64_t g0 = first >> 6, g1 = last >> 6;
+        const int s = (int)(first & 63);
+        const uint64_t l0 = planes[g0 * 5], h0 = planes[g0 * 5 + 1], l1 = g1 != g0 ? planes[g1 * 5] : 0ull, h1 = g1 != g0 ? planes[g1 * 5 + 1] : 0ull;
+        const uint64_t wl = s ? (l0 >> s) | (l1 << (64 - s)) : l0, wh_ = s ? (h0 >> s) | (h1 << (64 - s)) : h0;      // bit j = position first + j
+        auto code = [&](int j) -> uint64_t { return ((wl >> j) & 1ull) | (((wh_ >> j) & 1ull) << 1); };
+        uint64_t upper = 0, lower = 0, rc_upper = 0, rc_lower = 0;
+#pragma unroll
+        for (int j = 0; j < 31; j++) {
+            if (j < h) {
+                const uint64_t cu = code(j), cl = code(h + 1 + j);
+                upper = (upper << 2) | cu; lower = (lower << 2) | cl;
+                rc_lower |= (cu ^ 2u) << (2 * j);
+                rc_upper |= (cl ^ 2u) << (2 * j);
+            }
+        }
+        const uint32_t mid = (uint32_t)code(h), rc_mid = mid ^ 2u;
+        const bool userc = rc != 0;
+        const bool ueq = upper == rc_upper;
+        const bool gt = userc & ((upper > rc_upper) | (ueq & (lower > rc_lower)));
+        const bool eq = userc & ueq & (lower == rc_lower);
+        const uint64_t hl = gt ? rc_upper : upper, hr = gt ? rc_lower : lower;
+        const uint32_t m4 = (1u << (gt ? rc_mid : mid)) | (eq ? (1u << rc_mid) : 0u);
+        if (k <= 31) { uint32_t L = (uint32_t)hl, R = (uint32_t)hr; hmix_halves(L, R, hp); out_lo[i] = ((uint64_t)L << (hp.hb + 4)) | ((uint64_t)R << 4) | m4; }
+        else { uint64_t L = hl, R = hr; hmix_halves_w(L, R, wh); out_lo[i] = (R << 4) | m4 | ((L << wa1) & wm1); out_hi[i] = (R >> 60) | ((L >> wa2) << wa3); }
+    }
+}
+void launch_words_rebuild_planes(const uint32_t *pos, uint64_t n, const uint64_t *planes, int k, int rc, uint64_t *out_lo, uint64_t *out_hi, hipStream_t st)
+{
+    if (!n) return;
+    const uint64_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(words_rebuild_planes_kernel, dim3((unsigned)(g > 65536 ? 65536 : g)), dim3(256), 0, st, pos, n, planes, k, rc, make_hash_params(k < 31 ? k : 31),
+                       make_wide_hash(k), out_lo, out_hi);
+}
 void launch_words_rebuild(const uint32_t *pos, uint64_t n, const uint8_t *seq, int k, int rc, uint64_t *out_lo, uint64_t *out_hi, hipStream_t st)
 {
     if (!n) return;
@@ -337,13 +387,13 @@ void launch_words_rebuild(const uint32_t *pos, uint64_t n, const uint8_t *seq, i
 
 // the window pass alone: per window-end position its ntHash, whether it passes the quality gates and -- want_words -- its packed word
 int reads_windows(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t len, int k, int rc, const skx_qual &q, DevBuf<uint64_t> &hash,
-                  DevBuf<uint64_t> &wlo, DevBuf<uint64_t> &whi, DevBuf<uint8_t> &flag, unsigned long long *d_n_valid, bool want_words)
+                  DevBuf<uint64_t> &wlo, DevBuf<uint64_t> &whi, DevBuf<uint8_t> &flag, unsigned long long *d_n_valid, bool want_words, const uint64_t *planes)
 {
     const bool wide = k > 31;
     SKX_TRY(hash.alloc(len)); SKX_TRY(flag.alloc(len));
     if (want_words) { SKX_TRY(wlo.alloc(len)); if (wide) SKX_TRY(whi.alloc(len)); }
     ReadsArgs ra{d_seq, d_qual, len, k, rc, q.min_qual, q.qual_filter, make_hash_params(k < 31 ? k : 31), make_wide_hash(k),
-                 hash.p, want_words ? wlo.p : nullptr, want_words && wide ? whi.p : nullptr, flag.p, d_n_valid};
+                 hash.p, want_words ? wlo.p : nullptr, want_words && wide ? whi.p : nullptr, flag.p, d_n_valid, planes};
     const dim3 g((unsigned)((len + RW_TILE - 1) / RW_TILE));
     if (want_words) hipLaunchKernelGGL(reads_windows_kernel<true>, g, dim3(RW_NT), 0, ctx->stream, ra);
     else hipLaunchKernelGGL(reads_windows_kernel<false>, g, dim3(RW_NT), 0, ctx->stream, ra);

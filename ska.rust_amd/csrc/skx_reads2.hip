@@ -362,7 +362,7 @@ void launch_words_regions(bool count, const uint64_t *in_lo, const uint64_t *in_
 // One FASTQ / oversize sample -> the packed words of the windows that enter its dictionary (unsorted, duplicates included).
 // SKF_NOT_TAKEN: the sample is left to the first form (partition overflow: a hash far more frequent than a partition holds).
 int reads_sample_words(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t len, int k, int rc, const skx_qual &q,
-                       DevBuf<uint64_t> &out_lo, DevBuf<uint64_t> &out_hi, uint64_t *n_out)
+                       DevBuf<uint64_t> &out_lo, DevBuf<uint64_t> &out_hi, uint64_t *n_out, const uint64_t *planes)
 {
     hipStream_t st = ctx->stream;
     const bool wide = k > 31;
@@ -373,7 +373,7 @@ int reads_sample_words(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual
     DevBuf<unsigned long long> d_n; DevBuf<int> d_over;            // d_n[0]: positions / words that leave; d_n[1 .. 257): gated windows (spread counters)
     SKX_TRY(d_n.alloc(257)); SKX_TRY(d_n.zero(st)); SKX_TRY(d_over.alloc(1)); SKX_TRY(d_over.zero(st));
     const bool all_words = q.min_count <= 1;                       // every gated window enters: the window pass writes the words itself
-    SKX_TRY(reads_windows(ctx, d_seq, d_qual, len, k, rc, q, hash, wlo, whi, flag, d_n.p + 1, all_words));
+    SKX_TRY(reads_windows(ctx, d_seq, d_qual, len, k, rc, q, hash, wlo, whi, flag, d_n.p + 1, all_words, planes));      // (planes: the sample packed, d_seq / d_qual unused)
     unsigned long long n_acc = 0;
     if (q.min_count <= 1) {                                        // KmerFilter: 0 | 1 => every gated window enters
         SKX_TRY(out_lo.alloc(len)); if (wide) SKX_TRY(out_hi.alloc(len));
@@ -443,7 +443,8 @@ int reads_sample_words(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual
     if (over) { if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] reads: a partition overflowed, sample left to the sort-based form\n"); return SKF_NOT_TAKEN; }
     if (n_acc == 0) return SKX_OK;
     SKX_TRY(out_lo.alloc(n_acc)); if (wide) SKX_TRY(out_hi.alloc(n_acc));
-    launch_words_rebuild(acc_t.p, n_acc, d_seq, k, rc, out_lo.p, wide ? out_hi.p : nullptr, st);
+    if (planes) launch_words_rebuild_planes(acc_t.p, n_acc, planes, k, rc, out_lo.p, wide ? out_hi.p : nullptr, st);
+    else launch_words_rebuild(acc_t.p, n_acc, d_seq, k, rc, out_lo.p, wide ? out_hi.p : nullptr, st);
     SKX_HIP(hipStreamSynchronize(st));
     SKX_HIP(hipGetLastError());
     *n_out = n_acc;

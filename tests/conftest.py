@@ -30,3 +30,16 @@ def set_knob(monkeypatch, name, value):
 def del_knob(monkeypatch, name):
     import os
     monkeypatch.setenv("SKX_KNOBS", _knob_string(os.environ.get("SKX_KNOBS"), name))
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU runs: torch's copy of the HIP runtime must be the first one loaded in the process (the copy loaded second finds no GPU), whichever
+    test files were selected and in whichever order -- so it is initialised here, before any test loads the engine."""
+    if "not gpu" in (config.getoption("markexpr") or "") or not any(it.get_closest_marker("gpu") for it in items):
+        return
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
