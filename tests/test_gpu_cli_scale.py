@@ -372,7 +372,8 @@ def test_read_set_pipeline_odd_bytes_and_line_lengths(tmp_path):
     line ends, quality verdicts) and one launch per sample takes them apart on the device: lines of every length around the 32- and
     64-position word edges (0, 1, 31 ... 129, 150), IUPAC codes and other bytes that encode_base folds onto a base (bit_encoding.rs:42-54),
     N / n / '.' / '>' (low nibble 14: rejected), lower case, qualities on both sides of the threshold, one file with CRLF line ends.
-    Same .skf as the one-shot form (byte streams, no packing) and the oracle's array, k = 31 and 41, strict and middle-base filters."""
+    Same .skf as the one-shot form (byte streams, no packing) and the oracle's array: k = 31 strict, k = 41 middle base, and k = 21 without
+    filters at --min-count 1 (every gated window enters: the window pass writes the words itself)."""
     wd = str(tmp_path)
     rng = np.random.default_rng(77)
     glen = 40_000
@@ -410,15 +411,15 @@ def test_read_set_pipeline_odd_bytes_and_line_lengths(tmp_path):
     with open(os.path.join(wd, "list.txt"), "w") as f:
         for i, (a, b) in enumerate(files):
             f.write(f"o{i}\t{a}\t{b}\n")
-    for k, qf, oq in (("31", "strict", ora.QUAL_STRICT), ("41", "middle", ora.QUAL_MIDDLE)):
+    for k, qf, oq, mc in (("31", "strict", ora.QUAL_STRICT, 2), ("41", "middle", ora.QUAL_MIDDLE, 2), ("21", "no-filter", ora.QUAL_NOFILTER, 1)):
         outs = {}
         for tag, env in (("pipe", {}), ("avx2", {"SKX_KNOBS": "simd_cap=2"}), ("plain", {"SKX_KNOBS": "simd_cap=1"}), ("oneshot", {"SKX_KNOBS": "no_reads_pipeline=1"})):
-            r = subprocess.run([SKA, "build", "-f", "list.txt", "-o", f"{tag}{k}", "-k", k, "--min-count", "2", "--min-qual", "20", "--qual-filter", qf, "--threads", "3"],
+            r = subprocess.run([SKA, "build", "-f", "list.txt", "-o", f"{tag}{k}", "-k", k, "--min-count", str(mc), "--min-qual", "20", "--qual-filter", qf, "--threads", "3"],
                                cwd=wd, capture_output=True, timeout=300, env=dict(os.environ, **env))
             assert r.returncode == 0, r.stderr[-600:]
             outs[tag] = open(os.path.join(wd, f"{tag}{k}.skf"), "rb").read()
         assert outs["pipe"] == outs["oneshot"] and outs["avx2"] == outs["oneshot"] and outs["plain"] == outs["oneshot"], k
-        want = ora.Array.build([(f"o{i}", a, b) for i, (a, b) in enumerate(files)], k=int(k), rc=True, q=ora.qual(2, 20, oq), threads=2)
+        want = ora.Array.build([(f"o{i}", a, b) for i, (a, b) in enumerate(files)], k=int(k), rc=True, q=ora.qual(mc, 20, oq), threads=2)
         got = ora.Array.load(os.path.join(wd, f"pipe{k}.skf"))
         got.sort_rows(); want.sort_rows()
         gk, gv, gc = got.export()
