@@ -157,6 +157,10 @@ static int slurp(const char *path, std::vector<uint8_t> &buf)
         if (r == 0) break;
         n += (size_t)r;
     }
+    {   // a gzip stream that stops before its end (a truncated file) is an error, not a short input
+        int zerr = Z_OK; (void)gzerror(g, &zerr);
+        if (zerr != Z_OK && zerr != Z_STREAM_END) { gzclose(g); set_error("Invalid path/file: %s", path); return SKX_EIO; }
+    }
     gzclose(g);
     buf.resize(n);
     if (n == 0) { set_error("Invalid path/file: %s", path); return SKX_EIO; }
@@ -317,6 +321,10 @@ int stream_fastq_file(const char *path, const std::function<int(int which, const
         }
         if (spill.empty()) { const int rc = walk(p, end, &p); if (rc != SKX_OK) return rc; }
         have = (size_t)(end - p);
+        if (r == 0 && gz) {                                                 // a gzip stream that stops before its end (a truncated file) is an error
+            int zerr = Z_OK; (void)gzerror(gz, &zerr);
+            if (zerr != Z_OK && zerr != Z_STREAM_END) { set_error("Invalid path/file: %s", path); return SKX_EIO; }
+        }
         if (r == 0) {                                                       // end of file: a last line without terminator
             if (have || !spill.empty()) {
                 spill.insert(spill.end(), p, end);
