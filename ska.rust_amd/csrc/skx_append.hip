@@ -63,6 +63,11 @@ extern "C" void skx_debug_phase_prof(unsigned long long *out, int reset)
 #define AP_COUNT(i, v) do { } while (0)
 #endif
 
+// Wave priorities (s_setprio): a wave that is taking words off its loads -- filter, queue, the next loads' issue -- goes before one that is
+// inside a look-up batch, and that before one in the insert loop.  With equal priorities the sixteen waves drift into the same phase and the
+// CU alternates between everybody waiting for global loads and everybody waiting for LDS; the order keeps the loads in flight (23.7 -> 21.5
+// ms per 1 000 x 5 Mbp; the reverse order -- look-ups first -- 22.9; profiles/r04zx_ab_append_priorities.log).
+constexpr int AP_PRIO_STREAM = 3, AP_PRIO_LOOKUP = 1, AP_PRIO_INSERT = 0;
 constexpr int AP_THREADS = 1024, AP_WAVES = 16;
 constexpr uint32_t AP_PAD = 64;             // slots behind the table's last home slot (probing does not wrap)
 constexpr uint32_t AP_Q = 192, AP_SQ = 128; // a wave's queue of kept words: 127 left over + the ~32 +- 5 of one load; its insert queue (emptied first when a batch's misses would not fit)
@@ -168,6 +173,7 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
     const uint64_t rstride = 1ull << a.logB;                         // regions per sample
     uint32_t nq = 0, nsq = 0;                                        // wave-uniform: the fills of the two queues
     AP_PROF_START;
+    __builtin_amdgcn_s_setprio(AP_PRIO_STREAM);
 
     // a word's key as the table holds it: hi = the top 32 of its low hash bits (= what the home slot is computed from), lo = the rest << 14
     auto key_hi = [&](uint32_t wlo, uint32_t whi) -> uint32_t {
@@ -187,6 +193,7 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
     };
     // up to 64 words of the insert queue: the full probe sequence, new keys inserted
     auto slow_batch = [&]() {
+        __builtin_amdgcn_s_setprio(AP_PRIO_INSERT);
         const uint32_t take = nsq < 64u ? nsq : 64u;
         nsq -= take;
         if (lane == 0) { AP_COUNT(8, 1); AP_COUNT(9, take); }
@@ -236,11 +243,13 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
             if (rank1 == 0) s_ctl[CTL_FAIL] = 1u;
             else if (!COUNT_ONLY) record(rank1, wlo & 15u);
         }
+        __builtin_amdgcn_s_setprio(AP_PRIO_STREAM);
     };
     // up to 128 queued words, two per lane, against their home slots and the slots behind them: the two look-ups are independent, so every
     // LDS round trip of the chain queue -> table -> row buffer serves two words (the kernel waits for these round trips, it does not compute:
     // VALU 47 % busy with one word per lane).  What is not found there goes to the insert queue.
     auto batch = [&]() {
+        __builtin_amdgcn_s_setprio(AP_PRIO_LOOKUP);
         const uint32_t take = nq < 128u ? nq : 128u;
         nq -= take;
         if (lane == 0) { AP_COUNT(6, 1); AP_COUNT(7, take); }
@@ -300,6 +309,7 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
             if (vb & !hitb) sq[nsq + na + ap_mbcnt(xb)] = wb;
             nsq += na + (uint32_t)__popcll(xb);
         }
+        __builtin_amdgcn_s_setprio(AP_PRIO_STREAM);
     };
 
     // the wave's stream of chunks: (sample, chunk) for its samples in turn.  The next chunk is on its way (nxt) while one is looked at (cur: copied
