@@ -64,9 +64,11 @@ extern "C" void skx_debug_phase_prof(unsigned long long *out, int reset)
 #endif
 
 // Wave priorities (s_setprio): a wave that is taking words off its loads -- filter, queue, the next loads' issue -- goes before one that is
-// inside a look-up batch, and that before one in the insert loop.  With equal priorities the sixteen waves drift into the same phase and the
-// CU alternates between everybody waiting for global loads and everybody waiting for LDS; the order keeps the loads in flight (23.7 -> 21.5
-// ms per 1 000 x 5 Mbp; the reverse order -- look-ups first -- 22.9; profiles/r04zx_ab_append_priorities.log).
+// inside a look-up batch, and that before one in the insert loop: 23.7 -> 21.5 ms per 1 000 x 5 Mbp (the reverse order -- look-ups first --
+// 22.9; any order beats none: profiles/r04zx_ab_append_priorities.log).  Measured, not derived; the likely reason: the sixteen waves of a
+// workgroup run independently, a look-up batch is a chain of LDS round trips with little to issue in between, and the arbiter's round robin
+// gives such a wave its turn as often as a wave with a hundred instructions ready -- with the order, the short dense phase gets through and
+// its wave reaches its own LDS chain sooner, so more chains overlap.
 constexpr int AP_PRIO_STREAM = 3, AP_PRIO_LOOKUP = 1, AP_PRIO_INSERT = 0;
 constexpr int AP_THREADS = 1024, AP_WAVES = 16;
 constexpr uint32_t AP_PAD = 64;             // slots behind the table's last home slot (probing does not wrap)
