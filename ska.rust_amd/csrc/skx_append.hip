@@ -558,80 +558,90 @@ __global__ __launch_bounds__(256) void pieces_stats_kernel(const uint8_t *pieces
                                                            const uint64_t *roff, uint32_t cap, int S, uint32_t *o_present, uint32_t *o_unambig, uint32_t *o_mask,
                                                            uint32_t *o_vcount)
 {
-    __shared__ uint32_t s_list[2048 + 1];
+    constexpr int W = 4;                                              // dwords per thread: one 16-byte load per sample (append_kernel writes the pieces 16 bytes -- 32 ranks -- at a time,
+                                                                      // so such a piece of a sample's piece is either written whole or not at all)
+    __shared__ uint32_t s_list[256 * 8 * W + 1];
     __shared__ uint32_t s_nlist;
     const uint64_t j = blockIdx.x;
     const uint32_t nr = nrank[j], nrows = ncnt[j];
     const uint64_t r0 = roff[j];
-    const uint32_t d = blockIdx.y * 256u + threadIdx.x;              // dword column: ranks 8 d .. 8 d + 7
-    if (blockIdx.y * 256u * 8u >= nr) return;
+    const uint32_t d = blockIdx.y * 256u + threadIdx.x;              // 16-byte column: ranks 32 d .. 32 d + 31
+    if (blockIdx.y * 256u * 8u * W >= nr) return;
     if (threadIdx.x == 0) s_nlist = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint16_t *pl = plen + j * (uint64_t)S;
-    const uint32_t *col = reinterpret_cast<const uint32_t *>(pieces + j * (uint64_t)S * (cap / 2)) + d;
-    const uint32_t step = cap / 8;                                    // dwords from one sample's piece to the next
-    const bool mine = d * 8u < nr;
-    uint32_t pE = 0, pO = 0, aE = 0, aO = 0, uni = 0;                 // byte counters: present / ambiguous cells of the even and odd ranks; OR of the cells
-    uint32_t PE0 = 0, PE1 = 0, PO0 = 0, PO1 = 0, AE0 = 0, AE1 = 0, AO0 = 0, AO1 = 0;      // the same, 16 bits per rank
+    const uint4 *col = reinterpret_cast<const uint4 *>(pieces + j * (uint64_t)S * (cap / 2)) + d;
+    const uint32_t step = cap / 32;                                   // 16-byte pieces from one sample's piece to the next
+    const bool mine = d * 32u < nr;
+    uint32_t pE[W], pO[W], aE[W], aO[W], uni[W];                      // byte counters: present / ambiguous cells of the even and odd ranks; OR of the cells
+    uint32_t PE0[W], PE1[W], PO0[W], PO1[W], AE0[W], AE1[W], AO0[W], AO1[W];      // the same, 16 bits per rank
+#pragma unroll
+    for (int w = 0; w < W; w++) { pE[w] = pO[w] = aE[w] = aO[w] = uni[w] = 0; PE0[w] = PE1[w] = PO0[w] = PO1[w] = AE0[w] = AE1[w] = AO0[w] = AO1[w] = 0; }
     auto fold = [&]() {
-        PE0 += pE & 0x00FF00FFu; PE1 += (pE >> 8) & 0x00FF00FFu; PO0 += pO & 0x00FF00FFu; PO1 += (pO >> 8) & 0x00FF00FFu;
-        AE0 += aE & 0x00FF00FFu; AE1 += (aE >> 8) & 0x00FF00FFu; AO0 += aO & 0x00FF00FFu; AO1 += (aO >> 8) & 0x00FF00FFu;
-        pE = pO = aE = aO = 0;
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            PE0[w] += pE[w] & 0x00FF00FFu; PE1[w] += (pE[w] >> 8) & 0x00FF00FFu; PO0[w] += pO[w] & 0x00FF00FFu; PO1[w] += (pO[w] >> 8) & 0x00FF00FFu;
+            AE0[w] += aE[w] & 0x00FF00FFu; AE1[w] += (aE[w] >> 8) & 0x00FF00FFu; AO0[w] += aO[w] & 0x00FF00FFu; AO1[w] += (aO[w] >> 8) & 0x00FF00FFu;
+            pE[w] = pO[w] = aE[w] = aO[w] = 0;
+        }
     };
-    auto take = [&](uint32_t x) {
+    auto take = [&](int w, uint32_t x) {
         uint32_t t = x | (x >> 1); t |= t >> 2;
         const uint32_t nz = t & 0x11111111u;                          // one bit per nibble that is not 0
         const uint32_t y = x & (x - nz);                              // every nibble without its lowest bit
         uint32_t u = y | (y >> 1); u |= u >> 2;
         const uint32_t am = u & 0x11111111u;                          // one bit per nibble with two bases or more
-        pE += nz & 0x01010101u; pO += (nz >> 4) & 0x01010101u;
-        aE += am & 0x01010101u; aO += (am >> 4) & 0x01010101u;
-        uni |= x;
+        pE[w] += nz & 0x01010101u; pO[w] += (nz >> 4) & 0x01010101u;
+        aE[w] += am & 0x01010101u; aO[w] += (am >> 4) & 0x01010101u;
+        uni[w] |= x;
     };
-    // 64 samples at a time: their piece lengths arrive as one vector load (a lane each) and are handed round with v_readlane; eight loads in
-    // flight per lane; the byte counters are folded every 192 samples
+    // 64 samples at a time: their piece lengths arrive as one vector load (a lane each) and are handed round with v_readlane; four 16-byte loads in
+    // flight per lane (a dword per lane and load made 27 M small requests of this pass: 2.7 ms); the byte counters are folded every 192 samples
     for (int s0 = 0, since = 0; s0 < S; s0 += 64) {
         const uint32_t plv = s0 + lane < S ? (uint32_t)pl[s0 + lane] : 0u;
         const int n = S - s0 < 64 ? S - s0 : 64;
 #pragma unroll 1
-        for (int i0 = 0; i0 < n; i0 += 8) {
-            uint32_t x[8];
+        for (int i0 = 0; i0 < n; i0 += 4) {
+            uint4 x[4];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < 4; u++) {
                 const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)plv, (i0 + u) & 63);      // (past n: length 0)
-                x[u] = 0;
-                if (mine && i0 + u < n && d * 8u < l) x[u] = col[(uint64_t)(s0 + i0 + u) * step];
+                x[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (mine && i0 + u < n && d * 32u < l) x[u] = col[(uint64_t)(s0 + i0 + u) * step];
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) take(x[u]);
+            for (int u = 0; u < 4; u++) { take(0, x[u].x); take(1, x[u].y); take(2, x[u].z); take(3, x[u].w); }
         }
         since += 64;
         if (since >= 192) { fold(); since = 0; }
     }
     fold();
-    uint32_t pres[8], amb[8];
-    pres[0] = PE0 & 0xFFFFu; pres[4] = PE0 >> 16; pres[2] = PE1 & 0xFFFFu; pres[6] = PE1 >> 16;
-    pres[1] = PO0 & 0xFFFFu; pres[5] = PO0 >> 16; pres[3] = PO1 & 0xFFFFu; pres[7] = PO1 >> 16;
-    amb[0] = AE0 & 0xFFFFu; amb[4] = AE0 >> 16; amb[2] = AE1 & 0xFFFFu; amb[6] = AE1 >> 16;
-    amb[1] = AO0 & 0xFFFFu; amb[5] = AO0 >> 16; amb[3] = AO1 & 0xFFFFu; amb[7] = AO1 >> 16;
     const uint16_t *pj = perm + j * (uint64_t)cap;
     if (mine) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const uint32_t r = d * 8u + i;
-            if (r >= nr) break;
-            const uint32_t p = pj[r];                                 // the rank's row of the block (0xFFFF: none)
-            if (p >= nrows) continue;
-            const uint32_t u = (uni >> (4 * i)) & 15u;
-            o_present[r0 + p] = pres[i]; o_vcount[r0 + p] = pres[i];      // (variant_count: merge_ska_array.rs:172)
-            o_unambig[r0 + p] = pres[i] - amb[i];
-            o_mask[r0 + p] = ((u & 1u) << 1) | ((u & 2u) << 1) | ((u & 4u) << 2) | ((u & 8u) << 5);
-            if (amb[i]) { const uint32_t at = atomicAdd(&s_nlist, 1u); if (at < 2048u) s_list[at] = r; }
+        for (int w = 0; w < W; w++) {
+            uint32_t pres[8], amb[8];
+            pres[0] = PE0[w] & 0xFFFFu; pres[4] = PE0[w] >> 16; pres[2] = PE1[w] & 0xFFFFu; pres[6] = PE1[w] >> 16;
+            pres[1] = PO0[w] & 0xFFFFu; pres[5] = PO0[w] >> 16; pres[3] = PO1[w] & 0xFFFFu; pres[7] = PO1[w] >> 16;
+            amb[0] = AE0[w] & 0xFFFFu; amb[4] = AE0[w] >> 16; amb[2] = AE1[w] & 0xFFFFu; amb[6] = AE1[w] >> 16;
+            amb[1] = AO0[w] & 0xFFFFu; amb[5] = AO0[w] >> 16; amb[3] = AO1[w] & 0xFFFFu; amb[7] = AO1[w] >> 16;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t r = d * 32u + (uint32_t)w * 8u + i;
+                if (r >= nr) break;
+                const uint32_t p = pj[r];                             // the rank's row of the block (0xFFFF: none)
+                if (p >= nrows) continue;
+                const uint32_t u = (uni[w] >> (4 * i)) & 15u;
+                o_present[r0 + p] = pres[i]; o_vcount[r0 + p] = pres[i];      // (variant_count: merge_ska_array.rs:172)
+                o_unambig[r0 + p] = pres[i] - amb[i];
+                o_mask[r0 + p] = ((u & 1u) << 1) | ((u & 2u) << 1) | ((u & 4u) << 2) | ((u & 8u) << 5);
+                if (amb[i]) { const uint32_t at = atomicAdd(&s_nlist, 1u); if (at < 256u * 8u * W) s_list[at] = r; }
+            }
         }
     }
     __syncthreads();
-    const uint32_t nl = s_nlist < 2048u ? s_nlist : 2048u;           // (256 x 8 ranks at most)
+    const uint32_t nl = s_nlist < 256u * 8u * W ? s_nlist : 256u * 8u * W;          // (256 x 32 ranks at most)
     for (uint32_t i = wv; i < nl; i += 4) {
         const uint32_t r = s_list[i];
         uint32_t m = 0;
@@ -650,7 +660,7 @@ void launch_pieces_stats(const uint8_t *pieces, const uint16_t *plen, const uint
                          int n_samples, int n_blocks, uint32_t *present, uint32_t *unambig, uint32_t *mask, uint32_t *vcount, hipStream_t st)
 {
     if (n_blocks <= 0) return;
-    const unsigned gy = (cap / 8 + 255u) / 256u;
+    const unsigned gy = (cap / 32 + 255u) / 256u;
     hipLaunchKernelGGL(pieces_stats_kernel, dim3((unsigned)n_blocks, gy), dim3(256), 0, st, pieces, plen, perm, nrank, ncnt, roff, cap, n_samples, present, unambig, mask, vcount);
 }
 // split k-mers per sample (SkaDict::ksize): the cells of its pieces that are not empty; a wave per piece
@@ -757,7 +767,18 @@ __global__ __launch_bounds__(64 * PR_WAVES) void pieces_rows_kernel(PiecesRowsAr
             const uint32_t pl = a.plen[j * (uint64_t)S + s];
             const uint32_t plw = (pl + 7u) / 8u;
             const uint32_t *src = reinterpret_cast<const uint32_t *>(a.pieces + (j * (uint64_t)S + s) * (cap / 2));
-            for (uint32_t i = lane; i < nrw; i += 64) pc[i] = i < plw ? src[i] : 0u;      // ranks handed out after this sample: no cell
+            {   // sixteen bytes per lane and step (the pieces and the wave's buffer are 16-byte aligned: cap is a multiple of 128); a dword per
+                // lane made this copy a quarter of the kernel's time (3.95 -> 3.10 ms for the kept rows of 1 000 x 5 Mbp)
+                const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
+                uint4 *pc4 = reinterpret_cast<uint4 *>(pc);
+                for (uint32_t i = lane; i < (nrw + 3u) / 4u; i += 64) {
+                    uint4 x = 4u * i < plw ? src4[i] : make_uint4(0u, 0u, 0u, 0u);      // ranks handed out after this sample: no cell
+                    if (4u * i + 1u >= plw) x.y = 0u;
+                    if (4u * i + 2u >= plw) x.z = 0u;
+                    if (4u * i + 3u >= plw) x.w = 0u;
+                    pc4[i] = x;
+                }
+            }
             __builtin_amdgcn_wave_barrier();
             unsigned char *dst = a.out + (uint64_t)s * a.pitch + (ocol - shift);
             for (uint32_t v = v_lo + lane; v < v_hi; v += 64) {
