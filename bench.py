@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--no-distance", action="store_true", help="skip the all-vs-all distance stage")
     ap.add_argument("--check", action="store_true", help="(kept for compatibility: the check always runs unless --no-check)")
     ap.add_argument("--cli-threads", type=int, default=0, help="--threads given to the ska executable (0 = min(64, cores))")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic in this run")
+    ap.add_argument("--pmc-genomes", type=int, default=0, help="samples of the workload the --pmc passes extract (0 = all of --genomes)")
+    ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)      # the process rocprofv3 runs: extraction of that many samples, nothing else
     return ap.parse_args()
 
 
@@ -261,8 +264,83 @@ def launch_ranks(args):
     return subprocess.call(cmd)
 
 
+def pmc_child(args):
+    """What the --pmc passes profile: the first --pmc-child samples of the same workload (same ancestor, same SNP pattern) extracted
+    twice, nothing else on the device -- the counters of the extraction kernel's launches are what measure_traffic reads."""
+    import synth
+    import torch
+    import skx_engine as E
+    n = args.pmc_child
+    anc = synth.ancestor(args.genome_len, seed=1)
+    streams = [synth.sample_stream(anc, i, args.genomes, private_snps=private_snps(args.genomes)) for i in range(n)]
+    offs, tot = [], 0
+    for s in streams:
+        offs.append(tot)
+        tot += (len(s) + 255) // 256 * 256
+    E.load_library()
+    ctx = E.Context(0)
+    dev = torch.device("cuda", 0)
+    pool = torch.empty(tot + 256, dtype=torch.uint8, device=dev)
+    for o, s in zip(offs, streams):
+        pool[o:o + len(s)] = torch.from_numpy(s).to(dev)
+    torch.cuda.synchronize()
+    ptrs, lens = [pool.data_ptr() + o for o in offs], [len(s) for s in streams]
+    for _ in range(2):
+        ds = E.DictSet.build_device(ptrs, lens, args.k, True, ctx=ctx)
+        ctx.sync()
+        ds.free()
+
+
+def measure_traffic(args, lens, kernel_tag):
+    """roofline.traffic measured in this run: two rocprofv3 passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass, and --pmc goes with
+    --kernel-trace only) over a child process that extracts the first n samples of this workload; HBM bytes of the extraction kernel's
+    launches = FETCH_SIZE x 2 (gfx950 tallies 128-B read requests at 64 B: MI355X_MICROARCH.md) + WRITE_SIZE, both in KB, per base of
+    what the child extracted.  Returns (bytes per base, description) or (None, why not)."""
+    import csv
+    import glob
+    import subprocess
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    if "ROCP_TOOL_LIBRARIES" in os.environ or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process is itself running under a profiler"
+    n = min(args.pmc_genomes or args.genomes, args.genomes)
+    bases = float(sum(lens[:n]))
+    out = tempfile.mkdtemp(prefix="skx_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(v, None)
+    per = {}
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(out, c), "--", sys.executable,
+                   os.path.abspath(__file__), "--pmc-child", str(n), "--genomes", str(args.genomes), "--genome-len", str(args.genome_len), "-k", str(args.k)]
+            try:
+                p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+            except subprocess.TimeoutExpired:
+                return None, f"the {c} pass did not finish in 240 s"
+            if p.returncode != 0:
+                return None, f"the {c} pass failed (rc {p.returncode}): " + p.stdout.decode(errors="replace")[-200:].replace("\n", " | ")
+            vals = []
+            for f in glob.glob(os.path.join(out, c, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r.get("Counter_Name") == c and kernel_tag in r.get("Kernel_Name", ""):
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None, f"no {c} rows for {kernel_tag} in the pass's output"
+            per[c] = (sum(vals) / len(vals) * 1024.0, len(vals))
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    rd, wr = per["FETCH_SIZE"][0] * 2.0, per["WRITE_SIZE"][0]
+    return (rd + wr) / bases, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (one pass each, --kernel-trace only) over a child process extracting "
+                               f"{n} samples of this workload, mean of {per['FETCH_SIZE'][1]} launches of {kernel_tag}: FETCH_SIZE x2 = {rd / bases:.3f} B + WRITE_SIZE = "
+                               f"{wr / bases:.3f} B per base, scaled to this step's bases")
+
+
 def main():
     args = parse()
+    if args.pmc_child > 0:
+        return pmc_child(args)
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -513,6 +591,13 @@ def main():
                 last.free()
             del pool
             torch.cuda.empty_cache()
+            if not args.no_pmc:
+                per_base, why = measure_traffic(args, lens, "extract_kernel<true" if args.k <= 31 else "extract_wide_kernel<true")
+                if per_base is not None:
+                    res["roofline"]["traffic"] = per_base * total_bases
+                    res["roofline"]["traffic_source"] = why
+                else:
+                    res["roofline"]["traffic_source"] = (res["roofline"]["traffic_source"] or "none recorded") + f" [the --pmc passes of this run gave nothing: {why}]"
             try:
                 if e2e is not None:
                     res["end_to_end"] = e2e

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _bench(extra, env=None, launcher=()):
     cmd = [sys.executable, *launcher, os.path.join(ROOT, "bench.py"), "--genomes", "24", "--genome-len", "300000", "--steps", "2", "--warmup", "1",
-           "--cpu-genomes", "0", "--no-e2e", *extra]
+           "--cpu-genomes", "0", "--no-e2e", *([] if "--pmc-genomes" in extra else ["--no-pmc"]), *extra]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stderr[-2000:]
     return json.loads(r.stdout.strip().splitlines()[-1])
@@ -60,3 +60,12 @@ def test_bench_refuses_a_world_that_is_not_gpus():
            "--cpu-genomes", "0", "--no-e2e"]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300, env=dict(base, WORLD_SIZE="1", RANK="0"))
     assert r.returncode != 0 and "refusing" in r.stderr
+
+
+def test_bench_measures_the_extraction_kernels_traffic_in_the_run():
+    """roofline.traffic comes from rocprofv3 --pmc passes of this very run (FETCH_SIZE x 2 + WRITE_SIZE of the extraction kernel's launches over a
+    child process), not from a file under profiles/: at least the W + 1 bytes a base leaves in the regions, and no more than a few times that"""
+    line = _bench(["--gpus", "1", "--pmc-genomes", "12", "--no-check", "--no-distance"])
+    rl = line["roofline"]
+    assert rl["traffic_source"].startswith("measured in this run"), rl["traffic_source"]
+    assert 0.3 * rl["algorithmic_bytes_per_launch"] < rl["traffic"] < 6.0 * rl["algorithmic_bytes_per_launch"], rl

@@ -5,7 +5,7 @@
 #   gpurun_out/<tag>_pmc_extract.json   the extraction kernel's HBM bytes per base from those passes (what bench.py quotes as roofline.traffic)
 tag=${1:-final}; g=${2:-1000}
 root=$(pwd); out=$root/gpurun_out; mkdir -p $out
-bench="python $root/bench.py --no-e2e --no-check --no-distance --cpu-genomes 0 --genomes $g"
+bench="python $root/bench.py --no-e2e --no-check --no-distance --cpu-genomes 0 --no-pmc --genomes $g"
 cd /tmp && export TMPDIR=/tmp
 rm -rf $out/${tag}_trace; (cd $root && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_trace -- $bench --steps 5 --warmup 2 > $out/${tag}_trace.log 2>&1)
 python - "$out/${tag}_trace" > $out/${tag}_kernel_stats.txt <<'PY'

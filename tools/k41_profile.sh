@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/k41_profile.sh <tag>: the bench step at k = 41 (500 genomes: the 128-bit kernels) + the rocprofv3 kernel summary of the same command
 tag=${1:-k41}; root=$(pwd); out=$root/gpurun_out; mkdir -p $out
-B="python $root/bench.py --no-e2e --no-check --no-distance --cpu-genomes 0 --genomes 500 -k 41 --steps 5 --warmup 2"
+B="python $root/bench.py --no-e2e --no-check --no-distance --cpu-genomes 0 --no-pmc --genomes 500 -k 41 --steps 5 --warmup 2"
 $B 2>/dev/null | tail -1 > $out/${tag}_bench_k41.json
 python -c "
 import json; d=json.load(open('$out/${tag}_bench_k41.json')); print(round(d['ms_per_step'],2), {k: round(v,2) for k,v in d['stage_ms_per_step'].items() if v}, 'frac', round(d['roofline']['frac'],4))"
