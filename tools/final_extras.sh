@@ -21,5 +21,5 @@ PY
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/fx_reads; timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/fx_reads -- python $root/tools/reads_bench.py 4 50 41 > /tmp/fx_reads.log 2>&1
 summ /tmp/fx_reads "rocprofv3 --kernel-trace of: python tools/reads_bench.py 4 50 41 (2 x 150 bp, 50 x, 252 Mbases per isolate, k = 41, --min-count 5, strict q20); $(tail -1 /tmp/fx_reads.log | cut -c1-110)" > $out/${tag}_reads_kernel_stats.txt
-rm -rf /tmp/fx_dist; timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/fx_dist -- python $root/bench.py --genomes 1000 --steps 1 --warmup 1 --cpu-genomes 0 --no-e2e --no-check > /tmp/fx_dist.log 2>&1
+rm -rf /tmp/fx_dist; timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/fx_dist -- python $root/bench.py --genomes 1000 --steps 1 --warmup 1 --cpu-genomes 0 --no-pmc --no-e2e --no-check > /tmp/fx_dist.log 2>&1
 summ /tmp/fx_dist "rocprofv3 --kernel-trace of: python bench.py --genomes 1000 --steps 1 --warmup 1 --no-e2e --no-check (the step + ska distance on the resident array: 499 500 pairs x 22.5 M rows)" > $out/${tag}_distance_kernel_stats.txt
