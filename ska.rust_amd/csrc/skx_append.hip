@@ -185,7 +185,11 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
     auto key_lo = [&](uint32_t wlo) -> uint32_t { return HI ? __builtin_amdgcn_ubfe(wlo, 4u, (uint32_t)lowb) << AP_RANK_BITS : 0u; };
     auto key_fp = [&](uint32_t kh, uint32_t kl) -> uint32_t {          // a byte of the key, 1..255 (0 = an empty slot)
         const uint32_t v = HI ? kh & 0xFFu : ((kh ^ (kl >> AP_RANK_BITS)) * 0x9E3779B1u) >> 24;      // (the home slot comes from kh's top bits: its low byte is independent of it)
+#if defined(AP_V_FPODD)
+        return v | 1u;
+#else
         return v ? v : 255u;
+#endif
     };
     // the cell of (current sample, rank1 - 1) takes base set m4: one LDS atomic without a return value -- what the cells add up to per row (present,
     // unambiguous, code set) is counted from the finished pieces by pieces_stats_kernel, 4 bits per cell and no atomics, instead of here
@@ -267,16 +271,59 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
         // places (reading the entries of 2 x 8 slots per word: 33 ms; 2 x 4: 29 ms); a key lies up to seven slots behind its home for all but
         // two words in a hundred (5 500 rows in 8 192 slots), and those -- with the one in 128 whose byte matches a wrong key first -- take the
         // insert loop.
+#if defined(AP_V_LEAN)
+        // The same in as few vector operations as it takes: (x - 0x01..01) & ~x & 0x80..80 flags every zero byte of x and, above a zero byte
+        // only, a byte that is 1 -- the lowest flag is always a true match, and a false one behind a match in front of home just sends the
+        // word to the insert loop; v_ffbl gives all ones for "no flag", which survives the OR with 32 and the minimum; no match among the
+        // bytes read: the slot behind them is read instead (in the table's slack at worst), and that entry is either the key -- a hit all
+        // the same -- or not.  Returns the slot's byte offset in the table.
+        auto where8 = [&](uint32_t hs, uint32_t fp) -> uint32_t {
+            const uint32_t *f = reinterpret_cast<const uint32_t *>(s_fp + (hs & ~3u));
+            const uint32_t fp4 = __builtin_amdgcn_perm(fp, fp, 0u);
+            const uint32_t x0 = f[0] ^ fp4, x1 = f[1] ^ fp4;
+            const uint32_t hs8 = hs << 3;
+            const uint32_t z0 = (x0 - 0x01010101u) & ~x0 & (0x80808080u << (hs8 & 31u)), z1 = (x1 - 0x01010101u) & ~x1 & 0x80808080u;
+            uint32_t p0, p1;
+            asm("v_ffbl_b32 %0, %1" : "=v"(p0) : "v"(z0));                  // (all ones for 0: the compiler's own count-trailing-zeros guards that case with two more instructions)
+            asm("v_ffbl_b32 %0, %1" : "=v"(p1) : "v"(z1));
+            p1 |= 32u;
+            const uint32_t p = (p0 < p1 ? p0 : p1) & ~7u;                   // bit 8 i + 7 -> the entry's byte offset 8 i
+            return (hs8 & ~31u) + (p < 64u ? p : 64u);
+        };
+#endif
         auto where = [&](uint32_t hs, uint32_t fp) -> uint32_t {          // the first slot from home on whose byte is fp (0xFFFFFFFF: none among those read)
             const uint32_t base = hs & ~3u;
             const uint32_t *f = reinterpret_cast<const uint32_t *>(s_fp + base);
-            const uint32_t x0 = f[0] ^ (fp * 0x01010101u), x1 = f[1] ^ (fp * 0x01010101u);
+#if defined(AP_V_FPODD)
+            const uint32_t fp4 = __builtin_amdgcn_perm(fp, fp, 0u);
+#else
+            const uint32_t fp4 = fp * 0x01010101u;
+#endif
+            const uint32_t x0 = f[0] ^ fp4, x1 = f[1] ^ fp4;
             uint32_t z0 = ~(((x0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x0 | 0x7F7F7F7Fu), z1 = ~(((x1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x1 | 0x7F7F7F7Fu);
             z0 &= 0xFFFFFFFFu << (8u * (hs & 3u));                       // (not in front of home)
             const unsigned long long z = ((unsigned long long)z1 << 32) | z0;
+#if defined(AP_V_LEAN)
+            return z ? base + (((uint32_t)__ffsll((long long)z) - 1u) >> 3) : hs;      // none: home, whose entry is not the key (home's byte was among those read)
+#else
             return z ? base + (((uint32_t)__ffsll((long long)z) - 1u) >> 3) : 0xFFFFFFFFu;
+#endif
         };
         const uint32_t sa = where(hsa, key_fp(kha, kla)), sb = where(hsb, key_fp(khb, klb));
+#if defined(AP_V_LEAN)
+        // (entry ^ key)'s low half is the rank field (rank + 1) when the low key bits agree and something above it when they do not: less one,
+        // a single unsigned compare tells a rank from "not the key", from an empty slot (0) and from a rank still to come (all ones)
+        (void)sa; (void)sb;
+        const uint32_t oa = where8(hsa, key_fp(kha, kla)), ob = where8(hsb, key_fp(khb, klb));
+        const unsigned long long ea = *reinterpret_cast<const unsigned long long *>(reinterpret_cast<const unsigned char *>(s_tab) + oa),
+                                 eb = *reinterpret_cast<const unsigned long long *>(reinterpret_cast<const unsigned char *>(s_tab) + ob);
+        const uint32_t ra0 = ((uint32_t)ea ^ kla) - 1u, rb0 = ((uint32_t)eb ^ klb) - 1u;
+        const bool hita = va & ((uint32_t)(ea >> 32) == kha) & (ra0 < AP_RANK_MASK - 1u), hitb = vb & ((uint32_t)(eb >> 32) == khb) & (rb0 < AP_RANK_MASK - 1u);
+        if (!COUNT_ONLY) {
+            if (hita) atomicOr(&rb[ra0 >> 3], (alo & 15u) << ((ra0 & 7u) * 4u));
+            if (hitb) atomicOr(&rb[rb0 >> 3], (blo & 15u) << ((rb0 & 7u) * 4u));
+        }
+#else
         const unsigned long long ea = s_tab[sa != 0xFFFFFFFFu ? sa : hsa], eb = s_tab[sb != 0xFFFFFFFFu ? sb : hsb];
         auto hit = [&](unsigned long long e, uint32_t kh, uint32_t kl) -> uint32_t {
             return (((uint32_t)(e >> 32) == kh) & (((uint32_t)e ^ kl) <= AP_RANK_MASK)) ? (uint32_t)e & AP_RANK_MASK : 0u;
@@ -303,7 +350,8 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
 #endif
 #undef ra
 #undef rbk
-        const unsigned long long xa = __ballot(va & !hita), xb = __ballot(vb & !hitb);
+#endif
+        const unsigned long long xa = __builtin_amdgcn_ballot_w64(va & !hita), xb = __builtin_amdgcn_ballot_w64(vb & !hitb);
         if (xa | xb) {
             const uint32_t na = (uint32_t)__popcll(xa);
             while (nsq + na + (uint32_t)__popcll(xb) > AP_SQ) slow_batch();
@@ -334,6 +382,22 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(nxt[6]) : "v"(vo), "s"(base2) : "memory");
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(nxt[7]) : "v"(vo), "s"(base2) : "memory");
     };
+#if defined(AP_V_NOCOPY)
+    // one 16-byte load per lane of a chunk, into the registers the same load of the chunk before was consumed from a moment ago
+    auto issue_one = [&](int r, uint64_t b1, uint64_t b2) {
+        const uint32_t vo = (uint32_t)lane * 16u;
+        switch (r) {
+        case 0: asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(nxt[0]) : "v"(vo), "s"(b1) : "memory"); break;
+        case 1: asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(nxt[1]) : "v"(vo), "s"(b1) : "memory"); break;
+        case 2: asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(nxt[2]) : "v"(vo), "s"(b1) : "memory"); break;
+        case 3: asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(nxt[3]) : "v"(vo), "s"(b1) : "memory"); break;
+        case 4: asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(nxt[4]) : "v"(vo), "s"(b2) : "memory"); break;
+        case 5: asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(nxt[5]) : "v"(vo), "s"(b2) : "memory"); break;
+        case 6: asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(nxt[6]) : "v"(vo), "s"(b2) : "memory"); break;
+        default: asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(nxt[7]) : "v"(vo), "s"(b2) : "memory"); break;
+        }
+    };
+#endif
     auto region_of = [&](int smp, uint64_t &off, uint32_t &cnt) { const uint64_t rr = (uint64_t)smp * rstride + region; off = c_off[rr]; cnt = c_raw[rr]; };
     if (wv < S) {
         int s = wv;                                                   // the sample of the chunk in hand
@@ -343,6 +407,7 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
         for (;;) {
             // (the wait and the moves are volatile assembly, in this order: a plain copy may be placed in front of the wait by the compiler,
             // which knows nothing of loads still on their way into these registers)
+#if !defined(AP_V_NOCOPY)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int r = 0; r < AP_CH; r++) {
@@ -353,6 +418,7 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
                 asm volatile("v_mov_b32 %0, %1" : "=v"(w) : "v"(nxt[r].w));
                 cur[r].x = x; cur[r].y = y; cur[r].z = z; cur[r].w = w;
             }
+#endif
             AP_PROF(0);
             const uint32_t nch = (cnt_c + 64u * AP_CH * 2u - 1u) / (64u * AP_CH * 2u);
             const bool last_chunk = c + 1u >= nch;                    // (an empty region has its one, empty, chunk)
@@ -361,16 +427,42 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
             // registers whose loads are still on their way)
             const bool more = !last_chunk || s + AP_WAVES < S;
             if (last_chunk && more) region_of(s + AP_WAVES, off_n, cnt_n);
+#if defined(AP_V_NOCOPY)
+            // No copies: load r of the next chunk is issued into nxt[r] as soon as load r of this chunk has been taken from it, so the loads
+            // younger than the one about to be consumed are always seven (7 - r of this chunk, r of the next; they return in order; a
+            // sample's piece stores in between only make the wait longer) -- s_waitcnt vmcnt(7) in front of every load's words.  After the
+            // wave's last chunk the same chunk is asked for again (never looked at: no branch around the loads) and waited for at the end.
+            const uint64_t nb1 = (uint64_t)(uintptr_t)(a.words + (more && last_chunk ? off_n : off_c)) + (uint64_t)(more ? (last_chunk ? 0u : c + 1u) : c) * (64u * AP_CH * 16u);
+            const uint64_t nb2 = nb1 + 4096u;
+#else
             if (more) issue(last_chunk ? off_n : off_c, last_chunk ? cnt_n : cnt_c, last_chunk ? 0u : c + 1u);
+#endif
             // keep this block's words -- the two words of a 16-byte load at a time: about 32 of 128 stay --, look full batches up as they come
             // together (straight-line code: a loop over the loads with the batch code in one place spent three quarters of the kernel's time on
             // its own control flow).  The queue holds the 63 words a batch may leave plus 96 of a load; a load that keeps more (a sample that
             // is one repeat) fails the launch and the host takes the sorted path.
             const uint32_t w0 = 2u * (c * (64u * AP_CH) + (uint32_t)lane);
+#if defined(AP_V_FILLSKIP)
+            const uint32_t w0l = 2u * (uint32_t)lane;
+            const int fill_left = (int)(cnt_c - c * (64u * AP_CH * 2u));           // words of the region's fill from this chunk's start on (>= 0: c < nch)
+            const bool full_chunk = __builtin_amdgcn_readfirstlane((uint32_t)((c + 1u) * (64u * AP_CH * 2u) <= cnt_c)) != 0u;      // every word of the chunk lies inside the region's fill: no fill test
+#endif
             const uint32_t qbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned long long *)q;      // the queue's LDS byte address
 #pragma unroll
             for (int r = 0; r < AP_CH; r++) {
+#if defined(AP_V_NOCOPY)
+                asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+                uint32_t alo, ahi, blo, bhi;
+                if (HI) { alo = nxt[r].x; ahi = nxt[r].y; blo = nxt[r].z; bhi = nxt[r].w; }      // (read by volatile assembly only, below the wait)
+                else {
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(alo) : "v"(nxt[r].x));
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(ahi) : "v"(nxt[r].y));
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(blo) : "v"(nxt[r].z));
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(bhi) : "v"(nxt[r].w));
+                }
+#else
                 const uint32_t alo = cur[r].x, ahi = cur[r].y, blo = cur[r].z, bhi = cur[r].w;
+#endif
                 const uint32_t widx = w0 + 128u * r;
 #if defined(AP_X_NOFILTER)
                 if (false) {
@@ -381,6 +473,27 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
                     // words side by side into the queue.  Written out: the compiler's version of the same spends three times the instructions
                     // on turning conditions into lane masks and back (twelve vector instructions here per 128 words).
                     unsigned long long ma, mb; uint32_t na, nb, ta, tb;
+#if defined(AP_V_FILLSKIP)
+                    // (the fill test only where a chunk reaches past the region's fill -- a sample's last chunk: one scalar compare otherwise;
+                    // word index against fill as w0 against the fill less the load's offset, so no vector add per load either)
+                    const int cA = fill_left - 128 * r, cB = cA - 1;                  // (signed: a load past the fill compares as less than any lane's 2 * lane)
+                    asm volatile("v_and_b32 %4, %6, %8\n\t"
+                                 "v_cmp_eq_u32_e64 %0, %7, %4\n\t"
+                                 "v_and_b32 %5, %6, %9\n\t"
+                                 "v_cmp_eq_u32_e64 %1, %7, %5\n\t"
+                                 "s_cmp_lg_u32 %13, 0\n\t"
+                                 "s_cbranch_scc1 .Lapf%=\n\t"
+                                 "v_cmp_gt_i32_e32 vcc, %10, %12\n\t"
+                                 "s_and_b64 %0, %0, vcc\n\t"
+                                 "v_cmp_gt_i32_e32 vcc, %11, %12\n\t"
+                                 "s_and_b64 %1, %1, vcc\n"
+                                 ".Lapf%=:\n\t"
+                                 "s_bcnt1_i32_b64 %2, %0\n\t"
+                                 "s_bcnt1_i32_b64 %3, %1"
+                                 : "=&s"(ma), "=&s"(mb), "=&s"(na), "=&s"(nb), "=&v"(ta), "=&v"(tb)
+                                 : "s"(fmask), "s"(pshift), "v"(ahi), "v"(bhi), "s"(cA), "s"(cB), "v"(w0l), "s"((uint32_t)full_chunk)
+                                 : "vcc", "scc");
+#else
                     asm volatile("v_and_b32 %4, %6, %8\n\t"
                                  "v_cmp_eq_u32_e32 vcc, %7, %4\n\t"
                                  "s_mov_b64 %0, vcc\n\t"
@@ -396,6 +509,7 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
                                  : "=&s"(ma), "=&s"(mb), "=&s"(na), "=&s"(nb), "=&v"(ta), "=&v"(tb)
                                  : "s"(fmask), "s"(pshift), "v"(ahi), "v"(bhi), "s"(cnt_c), "v"(widx), "v"(widx + 1u)
                                  : "vcc", "scc");
+#endif
                     if (nq + na + nb > AP_Q) { if (lane == 0) s_ctl[CTL_FAIL] = 2u; }
                     else {
                         const uint32_t qa = qbase + nq * 8u, qb = qa + na * 8u;
@@ -435,6 +549,9 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
                         nq += na + nb;
                     }
                 }
+#if defined(AP_V_NOCOPY)
+                issue_one(r, nb1, nb2);
+#endif
                 AP_PROF(1);
 #if defined(AP_X_NOBATCH)
                 if (nq >= 128u) nq -= 128u;
@@ -472,6 +589,9 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
                 s += AP_WAVES; c = 0; off_c = off_n; cnt_c = cnt_n;
             } else c++;
         }
+#if defined(AP_V_NOCOPY)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the chunk asked for after the last one)
+#endif
     }
     AP_PROF_FLUSH();
     __syncthreads();

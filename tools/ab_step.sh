@@ -5,7 +5,7 @@ g=${1:-1000}; shift
 for rep in 1 2; do
   for v in "$@"; do
     cp ab/libskx_$v.so ska.rust_amd/libskx.so
-    timeout 600 python bench.py -k ${K:-31} --genomes $g --steps 5 --warmup 2 --cpu-genomes 0 --no-e2e --no-check --no-distance 2>/dev/null | tail -1 | python -c "
+    timeout 600 python bench.py -k ${K:-31} --genomes $g --steps 5 --warmup 2 --cpu-genomes 0 --no-pmc --no-e2e --no-check --no-distance 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('$v', round(d['ms_per_step'],2), {k: round(x,2) for k,x in d['stage_ms_per_step'].items() if x}, d['config']['rows_U'], d['config']['rows_kept'])"
