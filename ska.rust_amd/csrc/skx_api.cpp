@@ -1711,7 +1711,11 @@ static int append_pass(skx_ctx *ctx, skx_dictset *d, std::unique_ptr<skx_keyset>
         const double c = mean + 6.0 * std::sqrt(mean + 1.0) + 32.0;
         return (uint32_t)std::min<double>(APPEND_MAX_CAP, std::ceil(c / 128.0) * 128.0);
     };
-    auto slots_for = [&](uint32_t cap) -> uint32_t { return std::min<uint32_t>(APPEND_MAX_SLOTS, std::max<uint32_t>(256u, (cap + cap / 3 + 63u) / 64u * 64u)); };
+    auto slots_for = [&](uint32_t cap) -> uint32_t {                  // a power of two (the home slot is a shift), a third more than the ranks at least
+        uint32_t n = 256u;
+        while (n < cap + cap / 3 && n < APPEND_MAX_SLOTS) n <<= 1;
+        return n;
+    };
     DevBuf<int> d_flag; SKX_TRY(d_flag.alloc(1));
     DevBuf<unsigned long long> d_probe; SKX_TRY(d_probe.alloc(2));
     AppendArgs aa{};

@@ -104,6 +104,10 @@ __device__ static inline uint32_t ap_mbcnt(unsigned long long b)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
 }
 
+// a volatile view of an LDS location AS an LDS location: through a generic pointer the compiler issues flat instructions and waits for the
+// wave's vector-memory counter -- that is, for the chunk of words on its way -- before and after each
+typedef volatile uint32_t __attribute__((address_space(3))) *lds_vol_t;
+__device__ static inline lds_vol_t lds_vol(void *p) { return (lds_vol_t)(__attribute__((address_space(3))) void *)p; }
 // ctl words: 0 ranks handed out, 1 failure, 8..24 scan scratch
 constexpr int CTL_NROWS = 0, CTL_FAIL = 1, CTL_TMP = 8, CTL_WORDS = 32;
 
@@ -122,9 +126,9 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const uint32_t total_slots = a.nslots + AP_PAD;
     const uint32_t cap = a.cap, rbw = cap / 8;                       // ranks per block; dwords of one row buffer
-    unsigned long long *s_tab = reinterpret_cast<unsigned long long *>(s_raw);
-    unsigned char *s_fp = reinterpret_cast<unsigned char *>(s_tab + total_slots);      // [total_slots] a byte of every slot's key (0: empty), what a look-up reads first
-    unsigned long long *s_q = reinterpret_cast<unsigned long long *>(s_fp + total_slots);      // [AP_WAVES][AP_Q kept words + AP_SQ words for the insert loop]
+    unsigned char *s_fp = s_raw;                                     // [total_slots] a byte of every slot's key (0: empty), what a look-up reads first -- at LDS address 0: a slot's byte is at the slot's number
+    unsigned long long *s_tab = reinterpret_cast<unsigned long long *>(s_raw + total_slots);      // [total_slots] (total_slots is a multiple of 16)
+    unsigned long long *s_q = s_tab + total_slots;                   // [AP_WAVES][AP_Q kept words + AP_SQ words for the insert loop]
     uint32_t *s_ctl = reinterpret_cast<uint32_t *>(s_q + (size_t)AP_WAVES * (AP_Q + AP_SQ));
     uint32_t *s_rb = s_ctl + CTL_WORDS;                              // [AP_WAVES][rbw] 4-bit base sets by rank, one buffer per wave
     const int tid = threadIdx.x, lane = tid & 63;
@@ -161,6 +165,7 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
     for (uint32_t i = tid; i < total_slots / 4u; i += AP_THREADS) reinterpret_cast<uint32_t *>(s_fp)[i] = 0u;
     if (!COUNT_ONLY) for (uint32_t i = tid; i < AP_WAVES * rbw; i += AP_THREADS) s_rb[i] = 0u;
     if (tid < CTL_WORDS) s_ctl[tid] = 0u;
+    if (tid == 0 && (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)s_fp != 0u) atomicOr(a.overflow, 4);      // (a look-up takes a slot's number for the address of its byte)
     if (xmap && A > 1u && a.bar && tid == 0) {                       // the region's readers start together (bounded: late ones are not waited for for ever)
         atomicAdd(&a.bar[region], 1);
         for (int it = 0; it < (1 << 18) && __hip_atomic_load(&a.bar[region], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)A; it++) __builtin_amdgcn_s_sleep(8);
@@ -182,14 +187,14 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
         if (HI) return __builtin_amdgcn_alignbit(whi, wlo, (uint32_t)(rem - 28));
         return rem == 0 ? 0u : (uint32_t)(((wlo >> 4) | (whi << 28)) << (32 - rem));
     };
+    // home slot: monotone in the key.  The table's size is a power of two (append_ok): a shift -- the multiply-high it stands for runs at a
+    // quarter of the rate, and the look-ups are bound by their vector instructions
+    const uint32_t hshift = (uint32_t)__builtin_clz(a.nslots) + 1u;
+    auto home = [&](uint32_t kh) -> uint32_t { return kh >> hshift; };
     auto key_lo = [&](uint32_t wlo) -> uint32_t { return HI ? __builtin_amdgcn_ubfe(wlo, 4u, (uint32_t)lowb) << AP_RANK_BITS : 0u; };
     auto key_fp = [&](uint32_t kh, uint32_t kl) -> uint32_t {          // a byte of the key, 1..255 (0 = an empty slot)
         const uint32_t v = HI ? kh & 0xFFu : ((kh ^ (kl >> AP_RANK_BITS)) * 0x9E3779B1u) >> 24;      // (the home slot comes from kh's top bits: its low byte is independent of it)
-#if defined(AP_V_FPODD)
         return v | 1u;
-#else
-        return v ? v : 255u;
-#endif
     };
     // the cell of (current sample, rank1 - 1) takes base set m4: one LDS atomic without a return value -- what the cells add up to per row (present,
     // unambiguous, code set) is counted from the finished pieces by pieces_stats_kernel, 4 bits per cell and no atomics, instead of here
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
             // four slots per step of the probe sequence (at 5 500 rows in 8 192 slots a few keys in a hundred sit eight slots and more from home,
             // the unluckiest of 64 some thirty: one slot per step made this loop two thirds of the kernel's time)
             uint32_t rank1 = 0;
-            for (uint32_t t = __umulhi(kh, a.nslots); t + 3u < total_slots;) {
+            for (uint32_t t = home(kh); t + 3u < total_slots;) {
                 AP_COUNT(10, 1); if (ap_mbcnt(__ballot(true)) == 0u) AP_COUNT(11, 1);
                 const unsigned long long e0 = s_tab[t], e1 = s_tab[t + 1], e2 = s_tab[t + 2], e3 = s_tab[t + 3];
                 const bool m0 = (e0 ^ keyE) <= AP_RANK_MASK, m1 = (e1 ^ keyE) <= AP_RANK_MASK, m2 = (e2 ^ keyE) <= AP_RANK_MASK, m3 = (e3 ^ keyE) <= AP_RANK_MASK;
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
                 if (won) {
                     const uint32_t mine = atomicAdd(&s_ctl[CTL_NROWS], 1u) + 1u;
                     if (mine > (COUNT_ONLY ? AP_RANK_MASK - 1u : cap)) s_ctl[CTL_FAIL] = 1u;
-                    reinterpret_cast<volatile uint32_t *>(&s_tab[t + at])[0] = kl | (mine < AP_RANK_MASK ? mine : AP_RANK_MASK - 1u);
+                    lds_vol(&s_tab[t + at])[0] = kl | (mine < AP_RANK_MASK ? mine : AP_RANK_MASK - 1u);
                     s_fp[t + at] = (unsigned char)key_fp(kh, kl);
                     rank1 = mine;
                 }
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
                 if (m0 | m1 | m2 | m3) {
                     const uint32_t mt = t + (m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u);
                     uint32_t r = (uint32_t)(m0 ? e0 : m1 ? e1 : m2 ? e2 : e3) & AP_RANK_MASK;
-                    for (int it = 0; it < (1 << 16) && r == AP_RANK_MASK; it++) r = reinterpret_cast<volatile uint32_t *>(&s_tab[mt])[0] & AP_RANK_MASK;
+                    for (int it = 0; it < (1 << 16) && r == AP_RANK_MASK; it++) r = lds_vol(&s_tab[mt])[0] & AP_RANK_MASK;
                     if (r == AP_RANK_MASK) { s_ctl[CTL_FAIL] = 1u; r = 0; }
                     rank1 = r;
                     break;
@@ -265,20 +270,19 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
         if (vb) wb = q[nq + 64u + lane];
         const uint32_t alo = (uint32_t)wa, ahi = (uint32_t)(wa >> 32), blo = (uint32_t)wb, bhi = (uint32_t)(wb >> 32);
         const uint32_t kha = key_hi(alo, ahi), kla = key_lo(alo), khb = key_hi(blo, bhi), klb = key_lo(blo);
-        const uint32_t hsa = __umulhi(kha, a.nslots), hsb = __umulhi(khb, a.nslots);      // (an idle lane probes the slot of key 0: harmless)
-        // Two small reads instead of a scan of the slots: the bytes of the eight slots around home (one byte of every key, 0 = empty) say where
-        // the key may be, then that one entry is read and compared in full.  The look-ups are bound by what they read from LDS at random
-        // places (reading the entries of 2 x 8 slots per word: 33 ms; 2 x 4: 29 ms); a key lies up to seven slots behind its home for all but
-        // two words in a hundred (5 500 rows in 8 192 slots), and those -- with the one in 128 whose byte matches a wrong key first -- take the
-        // insert loop.
-#if defined(AP_V_LEAN)
-        // The same in as few vector operations as it takes: (x - 0x01..01) & ~x & 0x80..80 flags every zero byte of x and, above a zero byte
-        // only, a byte that is 1 -- the lowest flag is always a true match, and a false one behind a match in front of home just sends the
-        // word to the insert loop; v_ffbl gives all ones for "no flag", which survives the OR with 32 and the minimum; no match among the
-        // bytes read: the slot behind them is read instead (in the table's slack at worst), and that entry is either the key -- a hit all
-        // the same -- or not.  Returns the slot's byte offset in the table.
+        const uint32_t hsa = home(kha), hsb = home(khb);      // (an idle lane probes the slot of key 0: harmless)
+        // Two small reads instead of a scan of the slots: the bytes of the eight slots around home (one byte of every key, odd; 0 = empty) say
+        // where the key may be, then that one entry is read and compared in full.  (Reading the entries of 2 x 8 slots per word: 33 ms; 2 x 4:
+        // 29 ms.)  A key lies up to seven slots behind its home for all but two words in a hundred, and those -- with the one in 64 whose byte
+        // matches a wrong key first -- take the insert loop.  In as few vector operations as it takes (the kernel answers to every one of
+        // them: profiles/r04zzh_ab_append_lean.log): (x - 0x01..01) & ~x & 0x80..80 flags every zero byte of x and, above a zero byte only, a
+        // byte that is 1 -- the lowest flag is always a true match, and a false one behind a match in front of home just sends the word to the
+        // insert loop; v_ffbl gives all ones for "no flag", which survives the OR with 32 and the minimum; no match among the bytes read: the
+        // slot behind them is read instead (in the table's slack at worst), and that entry is either the key -- a hit all the same -- or
+        // not.  Returns the entry's byte offset in the table.
         auto where8 = [&](uint32_t hs, uint32_t fp) -> uint32_t {
-            const uint32_t *f = reinterpret_cast<const uint32_t *>(s_fp + (hs & ~3u));
+            typedef const uint32_t __attribute__((address_space(3))) *lds_c32_t;
+            const lds_c32_t f = (lds_c32_t)(hs & ~3u);                         // (s_fp is LDS address 0 -- checked at the kernel's start: the slot's number is the address)
             const uint32_t fp4 = __builtin_amdgcn_perm(fp, fp, 0u);
             const uint32_t x0 = f[0] ^ fp4, x1 = f[1] ^ fp4;
             const uint32_t hs8 = hs << 3;
@@ -290,68 +294,18 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
             const uint32_t p = (p0 < p1 ? p0 : p1) & ~7u;                   // bit 8 i + 7 -> the entry's byte offset 8 i
             return (hs8 & ~31u) + (p < 64u ? p : 64u);
         };
-#endif
-        auto where = [&](uint32_t hs, uint32_t fp) -> uint32_t {          // the first slot from home on whose byte is fp (0xFFFFFFFF: none among those read)
-            const uint32_t base = hs & ~3u;
-            const uint32_t *f = reinterpret_cast<const uint32_t *>(s_fp + base);
-#if defined(AP_V_FPODD)
-            const uint32_t fp4 = __builtin_amdgcn_perm(fp, fp, 0u);
-#else
-            const uint32_t fp4 = fp * 0x01010101u;
-#endif
-            const uint32_t x0 = f[0] ^ fp4, x1 = f[1] ^ fp4;
-            uint32_t z0 = ~(((x0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x0 | 0x7F7F7F7Fu), z1 = ~(((x1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x1 | 0x7F7F7F7Fu);
-            z0 &= 0xFFFFFFFFu << (8u * (hs & 3u));                       // (not in front of home)
-            const unsigned long long z = ((unsigned long long)z1 << 32) | z0;
-#if defined(AP_V_LEAN)
-            return z ? base + (((uint32_t)__ffsll((long long)z) - 1u) >> 3) : hs;      // none: home, whose entry is not the key (home's byte was among those read)
-#else
-            return z ? base + (((uint32_t)__ffsll((long long)z) - 1u) >> 3) : 0xFFFFFFFFu;
-#endif
-        };
-        const uint32_t sa = where(hsa, key_fp(kha, kla)), sb = where(hsb, key_fp(khb, klb));
-#if defined(AP_V_LEAN)
         // (entry ^ key)'s low half is the rank field (rank + 1) when the low key bits agree and something above it when they do not: less one,
         // a single unsigned compare tells a rank from "not the key", from an empty slot (0) and from a rank still to come (all ones)
-        (void)sa; (void)sb;
         const uint32_t oa = where8(hsa, key_fp(kha, kla)), ob = where8(hsb, key_fp(khb, klb));
         const unsigned long long ea = *reinterpret_cast<const unsigned long long *>(reinterpret_cast<const unsigned char *>(s_tab) + oa),
                                  eb = *reinterpret_cast<const unsigned long long *>(reinterpret_cast<const unsigned char *>(s_tab) + ob);
         const uint32_t ra0 = ((uint32_t)ea ^ kla) - 1u, rb0 = ((uint32_t)eb ^ klb) - 1u;
         const bool hita = va & ((uint32_t)(ea >> 32) == kha) & (ra0 < AP_RANK_MASK - 1u), hitb = vb & ((uint32_t)(eb >> 32) == khb) & (rb0 < AP_RANK_MASK - 1u);
+        const unsigned long long xa = __builtin_amdgcn_ballot_w64(va & !hita), xb = __builtin_amdgcn_ballot_w64(vb & !hitb);      // (taken before the branches below: after them the compiler carries the conditions through registers)
         if (!COUNT_ONLY) {
-            if (hita) atomicOr(&rb[ra0 >> 3], (alo & 15u) << ((ra0 & 7u) * 4u));
-            if (hitb) atomicOr(&rb[rb0 >> 3], (blo & 15u) << ((rb0 & 7u) * 4u));
+            if (hita) atomicOr(rb + __builtin_amdgcn_ubfe(ra0, 3u, 11u), (alo & 15u) << ((ra0 << 2) & 31u));
+            if (hitb) atomicOr(rb + __builtin_amdgcn_ubfe(rb0, 3u, 11u), (blo & 15u) << ((rb0 << 2) & 31u));
         }
-#else
-        const unsigned long long ea = s_tab[sa != 0xFFFFFFFFu ? sa : hsa], eb = s_tab[sb != 0xFFFFFFFFu ? sb : hsb];
-        auto hit = [&](unsigned long long e, uint32_t kh, uint32_t kl) -> uint32_t {
-            return (((uint32_t)(e >> 32) == kh) & (((uint32_t)e ^ kl) <= AP_RANK_MASK)) ? (uint32_t)e & AP_RANK_MASK : 0u;
-        };
-        const uint32_t ra = sa != 0xFFFFFFFFu ? hit(ea, kha, kla) : 0u, rbk = sb != 0xFFFFFFFFu ? hit(eb, khb, klb) : 0u;
-#if defined(AP_X_FAKE4)
-        const uint32_t ra_ = (ra & 0u) | (hsa % cap + 1u), rb_ = (rbk & 0u) | (hsb % cap + 1u);
-        const bool hita = va, hitb = vb;
-#define ra ra_
-#define rbk rb_
-#elif defined(AP_X_NOPROBE)
-        const uint32_t ra_ = hsa % cap + 1u, rb_ = hsb % cap + 1u;
-        const bool hita = va, hitb = vb;
-#define ra ra_
-#define rbk rb_
-#else
-        const bool hita = va & (ra != 0u) & (ra != AP_RANK_MASK), hitb = vb & (rbk != 0u) & (rbk != AP_RANK_MASK);
-#endif
-#if !defined(AP_X_NORECORD)
-        if (!COUNT_ONLY) {
-            if (hita) record(ra, alo & 15u);
-            if (hitb) record(rbk, blo & 15u);
-        }
-#endif
-#undef ra
-#undef rbk
-#endif
-        const unsigned long long xa = __builtin_amdgcn_ballot_w64(va & !hita), xb = __builtin_amdgcn_ballot_w64(vb & !hitb);
         if (xa | xb) {
             const uint32_t na = (uint32_t)__popcll(xa);
             while (nsq + na + (uint32_t)__popcll(xb) > AP_SQ) slow_batch();
@@ -362,10 +316,11 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
         __builtin_amdgcn_s_setprio(AP_PRIO_STREAM);
     };
 
-    // the wave's stream of chunks: (sample, chunk) for its samples in turn.  The next chunk is on its way (nxt) while one is looked at (cur: copied
-    // out of nxt once it has arrived -- sixteen moves per 512 words, and one instance of the code below instead of two).  The loads are inline
-    // assembly and waited for by hand: nothing else in the loop is a vector-memory load.
-    u32x4 nxt[AP_CH], cur[AP_CH];
+    // the wave's stream of chunks: (sample, chunk) for its samples in turn, eight 16-byte loads per lane and chunk.  The loads are inline
+    // assembly and waited for by hand (nothing else in the loop is a vector-memory load); the words are consumed from the registers they
+    // arrive in, by volatile assembly placed behind the wait, and each register quad is asked for again -- the same load of the next chunk --
+    // as soon as it has been consumed: no copies (32 moves per chunk before), no second set of registers.
+    u32x4 nxt[AP_CH];
     auto issue = [&](uint64_t off, uint32_t cnt, uint32_t c) {
         // (no clamping of addresses: a chunk may reach past its region's fill -- the words there fail the fill test -- and past its capacity
         // into the next region; the buffer ends in 8 KB of slack)
@@ -382,7 +337,6 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(nxt[6]) : "v"(vo), "s"(base2) : "memory");
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(nxt[7]) : "v"(vo), "s"(base2) : "memory");
     };
-#if defined(AP_V_NOCOPY)
     // one 16-byte load per lane of a chunk, into the registers the same load of the chunk before was consumed from a moment ago
     auto issue_one = [&](int r, uint64_t b1, uint64_t b2) {
         const uint32_t vo = (uint32_t)lane * 16u;
@@ -397,7 +351,6 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
         default: asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(nxt[7]) : "v"(vo), "s"(b2) : "memory"); break;
         }
     };
-#endif
     auto region_of = [&](int smp, uint64_t &off, uint32_t &cnt) { const uint64_t rr = (uint64_t)smp * rstride + region; off = c_off[rr]; cnt = c_raw[rr]; };
     if (wv < S) {
         int s = wv;                                                   // the sample of the chunk in hand
@@ -407,18 +360,6 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
         for (;;) {
             // (the wait and the moves are volatile assembly, in this order: a plain copy may be placed in front of the wait by the compiler,
             // which knows nothing of loads still on their way into these registers)
-#if !defined(AP_V_NOCOPY)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int r = 0; r < AP_CH; r++) {
-                uint32_t x, y, z, w;
-                asm volatile("v_mov_b32 %0, %1" : "=v"(x) : "v"(nxt[r].x));
-                asm volatile("v_mov_b32 %0, %1" : "=v"(y) : "v"(nxt[r].y));
-                asm volatile("v_mov_b32 %0, %1" : "=v"(z) : "v"(nxt[r].z));
-                asm volatile("v_mov_b32 %0, %1" : "=v"(w) : "v"(nxt[r].w));
-                cur[r].x = x; cur[r].y = y; cur[r].z = z; cur[r].w = w;
-            }
-#endif
             AP_PROF(0);
             const uint32_t nch = (cnt_c + 64u * AP_CH * 2u - 1u) / (64u * AP_CH * 2u);
             const bool last_chunk = c + 1u >= nch;                    // (an empty region has its one, empty, chunk)
@@ -427,30 +368,23 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
             // registers whose loads are still on their way)
             const bool more = !last_chunk || s + AP_WAVES < S;
             if (last_chunk && more) region_of(s + AP_WAVES, off_n, cnt_n);
-#if defined(AP_V_NOCOPY)
             // No copies: load r of the next chunk is issued into nxt[r] as soon as load r of this chunk has been taken from it, so the loads
             // younger than the one about to be consumed are always seven (7 - r of this chunk, r of the next; they return in order; a
             // sample's piece stores in between only make the wait longer) -- s_waitcnt vmcnt(7) in front of every load's words.  After the
             // wave's last chunk the same chunk is asked for again (never looked at: no branch around the loads) and waited for at the end.
             const uint64_t nb1 = (uint64_t)(uintptr_t)(a.words + (more && last_chunk ? off_n : off_c)) + (uint64_t)(more ? (last_chunk ? 0u : c + 1u) : c) * (64u * AP_CH * 16u);
             const uint64_t nb2 = nb1 + 4096u;
-#else
-            if (more) issue(last_chunk ? off_n : off_c, last_chunk ? cnt_n : cnt_c, last_chunk ? 0u : c + 1u);
-#endif
             // keep this block's words -- the two words of a 16-byte load at a time: about 32 of 128 stay --, look full batches up as they come
             // together (straight-line code: a loop over the loads with the batch code in one place spent three quarters of the kernel's time on
             // its own control flow).  The queue holds the 63 words a batch may leave plus 96 of a load; a load that keeps more (a sample that
             // is one repeat) fails the launch and the host takes the sorted path.
             const uint32_t w0 = 2u * (c * (64u * AP_CH) + (uint32_t)lane);
-#if defined(AP_V_FILLSKIP)
             const uint32_t w0l = 2u * (uint32_t)lane;
             const int fill_left = (int)(cnt_c - c * (64u * AP_CH * 2u));           // words of the region's fill from this chunk's start on (>= 0: c < nch)
             const bool full_chunk = __builtin_amdgcn_readfirstlane((uint32_t)((c + 1u) * (64u * AP_CH * 2u) <= cnt_c)) != 0u;      // every word of the chunk lies inside the region's fill: no fill test
-#endif
             const uint32_t qbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned long long *)q;      // the queue's LDS byte address
 #pragma unroll
             for (int r = 0; r < AP_CH; r++) {
-#if defined(AP_V_NOCOPY)
                 asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
                 uint32_t alo, ahi, blo, bhi;
                 if (HI) { alo = nxt[r].x; ahi = nxt[r].y; blo = nxt[r].z; bhi = nxt[r].w; }      // (read by volatile assembly only, below the wait)
@@ -460,9 +394,6 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
                     asm volatile("v_mov_b32 %0, %1" : "=v"(blo) : "v"(nxt[r].z));
                     asm volatile("v_mov_b32 %0, %1" : "=v"(bhi) : "v"(nxt[r].w));
                 }
-#else
-                const uint32_t alo = cur[r].x, ahi = cur[r].y, blo = cur[r].z, bhi = cur[r].w;
-#endif
                 const uint32_t widx = w0 + 128u * r;
 #if defined(AP_X_NOFILTER)
                 if (false) {
@@ -471,9 +402,8 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
 #endif
                     // which of the two words are this block's (part bits in the upper half, the region's fill), as lane masks; then the kept
                     // words side by side into the queue.  Written out: the compiler's version of the same spends three times the instructions
-                    // on turning conditions into lane masks and back (twelve vector instructions here per 128 words).
+                    // on turning conditions into lane masks and back (ten vector instructions here per 128 words, eight where the fill test is skipped).
                     unsigned long long ma, mb; uint32_t na, nb, ta, tb;
-#if defined(AP_V_FILLSKIP)
                     // (the fill test only where a chunk reaches past the region's fill -- a sample's last chunk: one scalar compare otherwise;
                     // word index against fill as w0 against the fill less the load's offset, so no vector add per load either)
                     const int cA = fill_left - 128 * r, cB = cA - 1;                  // (signed: a load past the fill compares as less than any lane's 2 * lane)
@@ -493,23 +423,6 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
                                  : "=&s"(ma), "=&s"(mb), "=&s"(na), "=&s"(nb), "=&v"(ta), "=&v"(tb)
                                  : "s"(fmask), "s"(pshift), "v"(ahi), "v"(bhi), "s"(cA), "s"(cB), "v"(w0l), "s"((uint32_t)full_chunk)
                                  : "vcc", "scc");
-#else
-                    asm volatile("v_and_b32 %4, %6, %8\n\t"
-                                 "v_cmp_eq_u32_e32 vcc, %7, %4\n\t"
-                                 "s_mov_b64 %0, vcc\n\t"
-                                 "v_cmp_gt_u32_e32 vcc, %10, %11\n\t"
-                                 "s_and_b64 %0, %0, vcc\n\t"
-                                 "v_and_b32 %5, %6, %9\n\t"
-                                 "v_cmp_eq_u32_e32 vcc, %7, %5\n\t"
-                                 "s_mov_b64 %1, vcc\n\t"
-                                 "v_cmp_gt_u32_e32 vcc, %10, %12\n\t"
-                                 "s_and_b64 %1, %1, vcc\n\t"
-                                 "s_bcnt1_i32_b64 %2, %0\n\t"
-                                 "s_bcnt1_i32_b64 %3, %1"
-                                 : "=&s"(ma), "=&s"(mb), "=&s"(na), "=&s"(nb), "=&v"(ta), "=&v"(tb)
-                                 : "s"(fmask), "s"(pshift), "v"(ahi), "v"(bhi), "s"(cnt_c), "v"(widx), "v"(widx + 1u)
-                                 : "vcc", "scc");
-#endif
                     if (nq + na + nb > AP_Q) { if (lane == 0) s_ctl[CTL_FAIL] = 2u; }
                     else {
                         const uint32_t qa = qbase + nq * 8u, qb = qa + na * 8u;
@@ -549,9 +462,7 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
                         nq += na + nb;
                     }
                 }
-#if defined(AP_V_NOCOPY)
                 issue_one(r, nb1, nb2);
-#endif
                 AP_PROF(1);
 #if defined(AP_X_NOBATCH)
                 if (nq >= 128u) nq -= 128u;
@@ -572,7 +483,7 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
             AP_PROF(1);
             if (last_chunk) {
                 if (!COUNT_ONLY) {
-                    uint32_t n = *reinterpret_cast<volatile uint32_t *>(&s_ctl[CTL_NROWS]);
+                    uint32_t n = *lds_vol(&s_ctl[CTL_NROWS]);
                     n = __builtin_amdgcn_readfirstlane(n);
                     if (n > cap) n = cap;
                     uint8_t *dst = piece0 + (uint64_t)s * (cap / 2);
@@ -589,9 +500,7 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
                 s += AP_WAVES; c = 0; off_c = off_n; cnt_c = cnt_n;
             } else c++;
         }
-#if defined(AP_V_NOCOPY)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the chunk asked for after the last one)
-#endif
     }
     AP_PROF_FLUSH();
     __syncthreads();
@@ -660,7 +569,7 @@ bool append_ok(int bits, int logB, int logQ, uint32_t region_cap, uint32_t nslot
 {
     const int rem = bits - logQ;
     (void)region_cap;
-    return logQ >= logB && rem >= 0 && rem <= 50 && cap % 128u == 0 && cap >= 128u && cap <= APPEND_MAX_CAP && nslots >= cap &&
+    return logQ >= logB && rem >= 0 && rem <= 50 && cap % 128u == 0 && cap >= 128u && cap <= APPEND_MAX_CAP && nslots >= cap && (nslots & (nslots - 1u)) == 0u &&
            append_lds_bytes(nslots, cap, false) <= 160u * 1024u - 256u;
 }
 void launch_append(const AppendArgs &a, uint32_t region_cap, hipStream_t st) { (void)region_cap; launch_append_t<false>(a, (1u << a.logQ) / a.rounds, st); }
