@@ -510,7 +510,7 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
             const uint64_t mean = (maxlen >> logB) + 1;
             const uint32_t region_cap = (uint32_t)std::min<uint64_t>(((mean + mean / 5 + 256) + 63) / 64 * 64, 0x7FFFFFFFull);
             launch_fill_offsets(d->off.p, nreg, region_cap, st);
-            SKX_TRY(d->words.alloc(nreg * (uint64_t)region_cap * wpk + 1024));      // (+ slack: the append pass reads whole 4 KB chunks)
+            SKX_TRY(d->words.alloc(nreg * (uint64_t)region_cap * wpk + 2048));      // (+ slack: the append pass reads whole chunks of up to 12 KB)
             { StageTimer t(ctx, &ctx->tm.scatter); a.hist = d->raw.p; a.off = d->off.p; a.words = d->words.p; a.capacity = region_cap;
               if (wide) launch_scatter_wide(a, st); else launch_scatter(a, st); }
             int over = 0;

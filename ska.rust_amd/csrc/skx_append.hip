@@ -73,7 +73,10 @@ constexpr int AP_PRIO_STREAM = 3, AP_PRIO_LOOKUP = 1, AP_PRIO_INSERT = 0;
 constexpr int AP_THREADS = 1024, AP_WAVES = 16;
 constexpr uint32_t AP_PAD = 64;             // slots behind the table's last home slot (probing does not wrap)
 constexpr uint32_t AP_Q = 192, AP_SQ = 128; // a wave's queue of kept words: 127 left over + the ~32 +- 5 of one load; its insert queue (emptied first when a batch's misses would not fit)
-constexpr int AP_CH = 8;                    // 16-byte loads per lane and chunk: a wave reads 1 024 words at a time
+#ifndef AP_CH_N
+#define AP_CH_N 8
+#endif
+constexpr int AP_CH = AP_CH_N;              // 16-byte loads per lane and chunk: a wave reads 128 x AP_CH words at a time
 constexpr int AP_RANK_BITS = 14;
 constexpr uint32_t AP_RANK_MASK = (1u << AP_RANK_BITS) - 1;
 
@@ -321,34 +324,17 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
     // arrive in, by volatile assembly placed behind the wait, and each register quad is asked for again -- the same load of the next chunk --
     // as soon as it has been consumed: no copies (32 moves per chunk before), no second set of registers.
     u32x4 nxt[AP_CH];
-    auto issue = [&](uint64_t off, uint32_t cnt, uint32_t c) {
-        // (no clamping of addresses: a chunk may reach past its region's fill -- the words there fail the fill test -- and past its capacity
-        // into the next region; the buffer ends in 8 KB of slack)
-        (void)cnt;
-        static_assert(AP_CH == 8, "the loads are written out for eight per chunk");
-        const uint64_t base = (uint64_t)(uintptr_t)(a.words + off) + (uint64_t)c * (64u * AP_CH * 16u), base2 = base + 4096u;
+    // one 16-byte load per lane of a chunk (load r of the chunk at b), into the registers the same load of the chunk before was consumed from
+    // a moment ago.  (No clamping of addresses: a chunk may reach past its region's fill -- the words there fail the fill test -- and past its
+    // capacity into the next region; the buffer ends in slack.)
+    auto issue_one = [&](int r, uint64_t b) {
         const uint32_t vo = (uint32_t)lane * 16u;
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(nxt[0]) : "v"(vo), "s"(base) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(nxt[1]) : "v"(vo), "s"(base) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(nxt[2]) : "v"(vo), "s"(base) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(nxt[3]) : "v"(vo), "s"(base) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(nxt[4]) : "v"(vo), "s"(base2) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(nxt[5]) : "v"(vo), "s"(base2) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(nxt[6]) : "v"(vo), "s"(base2) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(nxt[7]) : "v"(vo), "s"(base2) : "memory");
-    };
-    // one 16-byte load per lane of a chunk, into the registers the same load of the chunk before was consumed from a moment ago
-    auto issue_one = [&](int r, uint64_t b1, uint64_t b2) {
-        const uint32_t vo = (uint32_t)lane * 16u;
-        switch (r) {
-        case 0: asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(nxt[0]) : "v"(vo), "s"(b1) : "memory"); break;
-        case 1: asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(nxt[1]) : "v"(vo), "s"(b1) : "memory"); break;
-        case 2: asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(nxt[2]) : "v"(vo), "s"(b1) : "memory"); break;
-        case 3: asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(nxt[3]) : "v"(vo), "s"(b1) : "memory"); break;
-        case 4: asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(nxt[4]) : "v"(vo), "s"(b2) : "memory"); break;
-        case 5: asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(nxt[5]) : "v"(vo), "s"(b2) : "memory"); break;
-        case 6: asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(nxt[6]) : "v"(vo), "s"(b2) : "memory"); break;
-        default: asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(nxt[7]) : "v"(vo), "s"(b2) : "memory"); break;
+        const uint64_t bq = b + (uint64_t)(r >> 2) * 4096u;
+        switch (r & 3) {
+        case 0: asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(nxt[r]) : "v"(vo), "s"(bq) : "memory"); break;
+        case 1: asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(nxt[r]) : "v"(vo), "s"(bq) : "memory"); break;
+        case 2: asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(nxt[r]) : "v"(vo), "s"(bq) : "memory"); break;
+        default: asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(nxt[r]) : "v"(vo), "s"(bq) : "memory"); break;
         }
     };
     auto region_of = [&](int smp, uint64_t &off, uint32_t &cnt) { const uint64_t rr = (uint64_t)smp * rstride + region; off = c_off[rr]; cnt = c_raw[rr]; };
@@ -356,11 +342,15 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
         int s = wv;                                                   // the sample of the chunk in hand
         uint64_t off_c, off_n = 0; uint32_t cnt_c, cnt_n = 0, c = 0;
         region_of(s, off_c, cnt_c);
-        issue(off_c, cnt_c, 0u);
+        {
+            const uint64_t b0 = (uint64_t)(uintptr_t)(a.words + off_c);
+#pragma unroll
+            for (int r = 0; r < AP_CH; r++) issue_one(r, b0);
+        }
         for (;;) {
             // (the wait and the moves are volatile assembly, in this order: a plain copy may be placed in front of the wait by the compiler,
             // which knows nothing of loads still on their way into these registers)
-            AP_PROF(0);
+            AP_PROF(1);
             const uint32_t nch = (cnt_c + 64u * AP_CH * 2u - 1u) / (64u * AP_CH * 2u);
             const bool last_chunk = c + 1u >= nch;                    // (an empty region has its one, empty, chunk)
             // the chunk after this one: the sample's next, or the first of the wave's next sample
@@ -373,7 +363,6 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
             // sample's piece stores in between only make the wait longer) -- s_waitcnt vmcnt(7) in front of every load's words.  After the
             // wave's last chunk the same chunk is asked for again (never looked at: no branch around the loads) and waited for at the end.
             const uint64_t nb1 = (uint64_t)(uintptr_t)(a.words + (more && last_chunk ? off_n : off_c)) + (uint64_t)(more ? (last_chunk ? 0u : c + 1u) : c) * (64u * AP_CH * 16u);
-            const uint64_t nb2 = nb1 + 4096u;
             // keep this block's words -- the two words of a 16-byte load at a time: about 32 of 128 stay --, look full batches up as they come
             // together (straight-line code: a loop over the loads with the batch code in one place spent three quarters of the kernel's time on
             // its own control flow).  The queue holds the 63 words a batch may leave plus 96 of a load; a load that keeps more (a sample that
@@ -385,7 +374,8 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
             const uint32_t qbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned long long *)q;      // the queue's LDS byte address
 #pragma unroll
             for (int r = 0; r < AP_CH; r++) {
-                asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(AP_CH - 1) : "memory");
+                AP_PROF(0);
                 uint32_t alo, ahi, blo, bhi;
                 if (HI) { alo = nxt[r].x; ahi = nxt[r].y; blo = nxt[r].z; bhi = nxt[r].w; }      // (read by volatile assembly only, below the wait)
                 else {
@@ -462,7 +452,7 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
                         nq += na + nb;
                     }
                 }
-                issue_one(r, nb1, nb2);
+                issue_one(r, nb1);
                 AP_PROF(1);
 #if defined(AP_X_NOBATCH)
                 if (nq >= 128u) nq -= 128u;
