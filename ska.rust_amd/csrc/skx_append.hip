@@ -69,7 +69,13 @@ extern "C" void skx_debug_phase_prof(unsigned long long *out, int reset)
 // workgroup run independently, a look-up batch is a chain of LDS round trips with little to issue in between, and the arbiter's round robin
 // gives such a wave its turn as often as a wave with a hundred instructions ready -- with the order, the short dense phase gets through and
 // its wave reaches its own LDS chain sooner, so more chains overlap.
-constexpr int AP_PRIO_STREAM = 3, AP_PRIO_LOOKUP = 1, AP_PRIO_INSERT = 0;
+#ifndef AP_PRIO_L
+#define AP_PRIO_L 1
+#endif
+#ifndef AP_PRIO_I
+#define AP_PRIO_I 0
+#endif
+constexpr int AP_PRIO_STREAM = 3, AP_PRIO_LOOKUP = AP_PRIO_L, AP_PRIO_INSERT = AP_PRIO_I;
 constexpr int AP_THREADS = 1024, AP_WAVES = 16;
 constexpr uint32_t AP_PAD = 64;             // slots behind the table's last home slot (probing does not wrap)
 constexpr uint32_t AP_Q = 192, AP_SQ = 128; // a wave's queue of kept words: 127 left over + the ~32 +- 5 of one load; its insert queue (emptied first when a batch's misses would not fit)
