@@ -374,7 +374,7 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
             // its own control flow).  The queue holds the 63 words a batch may leave plus 96 of a load; a load that keeps more (a sample that
             // is one repeat) fails the launch and the host takes the sorted path.
             const uint32_t w0 = 2u * (c * (64u * AP_CH) + (uint32_t)lane);
-            const uint32_t w0l = 2u * (uint32_t)lane;
+            const uint32_t w0l = 2u * (uint32_t)lane, w1l = w0l + 1u;
             const int fill_left = (int)(cnt_c - c * (64u * AP_CH * 2u));           // words of the region's fill from this chunk's start on (>= 0: c < nch)
             const bool full_chunk = __builtin_amdgcn_readfirstlane((uint32_t)((c + 1u) * (64u * AP_CH * 2u) <= cnt_c)) != 0u;      // every word of the chunk lies inside the region's fill: no fill test
             const uint32_t qbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned long long *)q;      // the queue's LDS byte address
@@ -402,44 +402,49 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
                     unsigned long long ma, mb; uint32_t na, nb, ta, tb;
                     // (the fill test only where a chunk reaches past the region's fill -- a sample's last chunk: one scalar compare otherwise;
                     // word index against fill as w0 against the fill less the load's offset, so no vector add per load either)
-                    const int cA = fill_left - 128 * r, cB = cA - 1;                  // (signed: a load past the fill compares as less than any lane's 2 * lane)
+                    const int cA = fill_left - 128 * r;                              // (signed: a load past the fill compares as less than any lane's 2 * lane)
                     asm volatile("v_and_b32 %4, %6, %8\n\t"
                                  "v_cmp_eq_u32_e64 %0, %7, %4\n\t"
                                  "v_and_b32 %5, %6, %9\n\t"
                                  "v_cmp_eq_u32_e64 %1, %7, %5\n\t"
                                  "s_cmp_lg_u32 %13, 0\n\t"
                                  "s_cbranch_scc1 .Lapf%=\n\t"
-                                 "v_cmp_gt_i32_e32 vcc, %10, %12\n\t"
+                                 "v_cmp_gt_i32_e32 vcc, %10, %11\n\t"
                                  "s_and_b64 %0, %0, vcc\n\t"
-                                 "v_cmp_gt_i32_e32 vcc, %11, %12\n\t"
+                                 "v_cmp_gt_i32_e32 vcc, %10, %12\n\t"
                                  "s_and_b64 %1, %1, vcc\n"
                                  ".Lapf%=:\n\t"
                                  "s_bcnt1_i32_b64 %2, %0\n\t"
                                  "s_bcnt1_i32_b64 %3, %1"
                                  : "=&s"(ma), "=&s"(mb), "=&s"(na), "=&s"(nb), "=&v"(ta), "=&v"(tb)
-                                 : "s"(fmask), "s"(pshift), "v"(ahi), "v"(bhi), "s"(cA), "s"(cB), "v"(w0l), "s"((uint32_t)full_chunk)
+                                 : "s"(fmask), "s"(pshift), "v"(ahi), "v"(bhi), "s"(cA), "v"(w0l), "v"(w1l), "s"((uint32_t)full_chunk)
                                  : "vcc", "scc");
-                    if (nq + na + nb > AP_Q) { if (lane == 0) s_ctl[CTL_FAIL] = 2u; }
-                    else {
-                        const uint32_t qa = qbase + nq * 8u, qb = qa + na * 8u;
-                        unsigned long long sv;
-                        asm volatile("s_mov_b64 vcc, %3\n\t"
-                                     "v_mbcnt_lo_u32_b32 %0, vcc_lo, 0\n\t"
-                                     "v_mbcnt_hi_u32_b32 %0, vcc_hi, %0\n\t"
-                                     "v_lshl_add_u32 %0, %0, 3, %5\n\t"
-                                     "s_mov_b64 vcc, %4\n\t"
-                                     "v_mbcnt_lo_u32_b32 %1, vcc_lo, 0\n\t"
-                                     "v_mbcnt_hi_u32_b32 %1, vcc_hi, %1\n\t"
-                                     "v_lshl_add_u32 %1, %1, 3, %6\n\t"
-                                     "s_and_saveexec_b64 %2, %3\n\t"
-                                     "ds_write2_b32 %0, %7, %8 offset1:1\n\t"
+                    if (__builtin_expect(nq + na + nb > AP_Q, 0)) {                  // (a sample that is one repeat: the launch fails, nothing is queued, the host takes the sorted path)
+                        if (lane == 0) s_ctl[CTL_FAIL] = 2u;
+                        ma = 0ull; mb = 0ull; na = 0u; nb = 0u;
+                    }
+                    {
+                        // the kept words side by side into the queue: scalar address arithmetic in two shift-adds, the lane masks read by v_mbcnt as
+                        // they are (the kernel's scalar unit is its busiest: profiles/r04zzo_pmc_append_lean.log)
+                        unsigned long long sv; uint32_t qa, qb;
+                        asm volatile("s_lshl3_add_u32 %3, %5, %6\n\t"
+                                     "s_lshl3_add_u32 %4, %7, %3\n\t"
+                                     "v_mbcnt_lo_u32_b32 %0, %8, 0\n\t"
+                                     "v_mbcnt_hi_u32_b32 %0, %9, %0\n\t"
+                                     "v_lshl_add_u32 %0, %0, 3, %3\n\t"
+                                     "v_mbcnt_lo_u32_b32 %1, %10, 0\n\t"
+                                     "v_mbcnt_hi_u32_b32 %1, %11, %1\n\t"
+                                     "v_lshl_add_u32 %1, %1, 3, %4\n\t"
+                                     "s_and_saveexec_b64 %2, %12\n\t"
+                                     "ds_write2_b32 %0, %14, %15 offset1:1\n\t"
                                      "s_mov_b64 exec, %2\n\t"
-                                     "s_and_saveexec_b64 %2, %4\n\t"
-                                     "ds_write2_b32 %1, %9, %10 offset1:1\n\t"
+                                     "s_and_saveexec_b64 %2, %13\n\t"
+                                     "ds_write2_b32 %1, %16, %17 offset1:1\n\t"
                                      "s_mov_b64 exec, %2"
-                                     : "=&v"(ta), "=&v"(tb), "=&s"(sv)
-                                     : "s"(ma), "s"(mb), "s"(qa), "s"(qb), "v"(alo), "v"(ahi), "v"(blo), "v"(bhi)
-                                     : "vcc", "scc", "memory");
+                                     : "=&v"(ta), "=&v"(tb), "=&s"(sv), "=&s"(qa), "=&s"(qb)
+                                     : "s"(nq), "s"(qbase), "s"(na), "s"((uint32_t)ma), "s"((uint32_t)(ma >> 32)), "s"((uint32_t)mb), "s"((uint32_t)(mb >> 32)),
+                                       "s"(ma), "s"(mb), "v"(alo), "v"(ahi), "v"(blo), "v"(bhi)
+                                     : "scc", "memory");
                         nq += na + nb;
                     }
 #if defined(AP_X_NOFILTER)
