@@ -63,7 +63,7 @@ def parse():
     ap.add_argument("--no-distance", action="store_true", help="skip the all-vs-all distance stage")
     ap.add_argument("--check", action="store_true", help="(kept for compatibility: the check always runs unless --no-check)")
     ap.add_argument("--cli-threads", type=int, default=0, help="--threads given to the ska executable (0 = min(64, cores))")
-    ap.add_argument("--settle-s", type=float, default=8.0, help="idle seconds before each independent end-to-end measurement (the chain build -> align has none in between)")
+    ap.add_argument("--settle-s", type=float, default=12.0, help="idle seconds before each independent end-to-end measurement (the chain build -> align has none in between)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic in this run")
     ap.add_argument("--pmc-genomes", type=int, default=0, help="samples of the workload the --pmc passes extract (0 = all of --genomes)")
     ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)      # the process rocprofv3 runs: extraction of that many samples, nothing else
@@ -229,20 +229,26 @@ def files_equal(a, b, block=64 << 20):
                 return True
 
 
-def warm_device(gb=56):
-    """The first large device allocation on a box that has just come up costs about a second whatever follows it (tools/vram_probe.sh,
-    profiles/r04zzm_vram_probe.log: hipMalloc of 56 GB 0.97 s as the box's first GPU process, 0.000 s two seconds after a process that
-    released as much, 2.4-3.8 s right behind one): like the warm-up steps of the timed loop, that is paid before the end-to-end chain, by a
-    process that allocates and releases the chain's footprint through the HIP runtime (no torch: the executable does not use it either).
-    The idle seconds that follow cover the driver's wipe of what it released."""
+def warm_device(gb=240, chunk_gb=16):
+    """Device memory costs a process time twice over, and neither is the executable's: a box that has just come up clears VRAM the first time
+    it is handed out (tools/vram_probe.sh, profiles/r04zzm_vram_probe.log: hipMalloc of 56 GB 0.97 s as the box's first GPU process, and
+    `ska build` 0.98 s in build.dictionaries behind a warm-up that had only taken 56 GB -- the allocator need not hand out the same
+    pages), and memory a process released a moment ago is wiped before it is handed out again (2.4-3.8 s right behind one, 0.000 s two
+    seconds later).  Like the warm-up steps of the timed loop, the first is paid before the end-to-end chain: a process takes most of the
+    device's memory through the HIP runtime (no torch: the executable does not use it either), chunk by chunk until the device has no
+    more, and releases it; the idle seconds that follow cover the wipe."""
     code = ("import ctypes\n"
             "h = ctypes.CDLL('libamdhip64.so')\n"
-            "p = ctypes.c_void_p()\n"
             "assert h.hipSetDevice(0) == 0\n"
-            f"assert h.hipMalloc(ctypes.byref(p), ctypes.c_size_t({gb} << 30)) == 0\n"
-            "h.hipMemset(p, 0, ctypes.c_size_t(1)); h.hipDeviceSynchronize(); h.hipFree(p)\n")
+            "ps = []\n"
+            f"for i in range({gb} // {chunk_gb}):\n"
+            "    p = ctypes.c_void_p()\n"
+            f"    if h.hipMalloc(ctypes.byref(p), ctypes.c_size_t({chunk_gb} << 30)) != 0: break\n"
+            "    h.hipMemset(p, 0, ctypes.c_size_t(1)); ps.append(p)\n"
+            "h.hipDeviceSynchronize()\n"
+            "for p in ps: h.hipFree(p)\n")
     try:
-        subprocess.run([sys.executable, "-c", code], timeout=120, env=dict(os.environ, LD_LIBRARY_PATH=os.environ.get("LD_LIBRARY_PATH", "") + ":/opt/rocm/lib"))
+        subprocess.run([sys.executable, "-c", code], timeout=180, env=dict(os.environ, LD_LIBRARY_PATH=os.environ.get("LD_LIBRARY_PATH", "") + ":/opt/rocm/lib"))
     except Exception as e:            # a warm-up that fails changes a number, not a result
         sys.stderr.write(f"bench.py: device warm-up skipped: {e}\n")
 
@@ -273,7 +279,7 @@ def end_to_end(args, files, td):
         same = files_equal(os.path.join(td, "aln.fa"), os.path.join(td, "aln2.fa"))
     res = {"genomes_per_s": n / (tb + ta), "unit": "genomes/s", "samples": n, "cli_threads": threads,
            "what": "wall clock around the ska executable (process start to exit), FASTA files / .skf / alignment on tmpfs; build -> align back to back, "
-                   f"one 56 GB device allocation made and released by a warm-up process, then {args.settle_s:g} s of idle, before the chain; the same idle before the single-invocation form",
+                   f"most of the device's memory taken and released by a warm-up process, then {args.settle_s:g} s of idle, before the chain; the same idle before the single-invocation form",
            "ska_build_s": tb, "ska_align_skf_s": ta, "skf_bytes": skf_bytes, "alignment_bytes": aln_bytes,
            "phases_ska_build": pb, "phases_ska_align_skf": pa}
     if ts is not None:
