@@ -285,6 +285,10 @@ void skx_phase_add(const char *name, double seconds);
 /* per-stage device timings of the last call on this ctx (ms; HIP events on the ctx stream) */
 typedef struct { double hist, scatter, dedupe, key_union, assemble, filter, compact, distance; } skx_timings;
 int  skx_ctx_timings(skx_ctx *ctx, skx_timings *t, int reset);
+/* which kernels the last merge on this context went through: "append64" / "append128" (MergeSkaDict::append in one pass over the
+ * unsorted regions, merge_ska_dict.rs:77-109, for u64 / u128 keys) or "sorted: <why the pass was not taken>" (per-sample sort +
+ * union + assemble); "" before the first merge.  The reference has no counterpart: its append is one code path. */
+const char *skx_ctx_merge_path(skx_ctx *ctx);
 
 #ifdef __cplusplus
 }

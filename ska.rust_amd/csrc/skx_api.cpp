@@ -244,6 +244,7 @@ extern "C" void skx_ctx_destroy(skx_ctx *c)
 }
 extern "C" int skx_ctx_sync(skx_ctx *c) { SKX_HIP(hipSetDevice(c->device)); SKX_HIP(hipStreamSynchronize(c->stream)); return SKX_OK; }
 extern "C" void *skx_ctx_stream(skx_ctx *c) { return (void *)c->stream; }
+extern "C" const char *skx_ctx_merge_path(skx_ctx *c) { return c ? c->merge_path.c_str() : ""; }
 extern "C" int skx_ctx_timings(skx_ctx *c, skx_timings *t, int reset)
 {
     return skx_guarded([&]() -> int {
@@ -532,12 +533,12 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
               if (wide) launch_scatter_wide(a, st); else launch_scatter(a, st); }
             lds_cap = max_raw;
         }
-        // Assemblies with 64-bit keys whose regions kept their fixed capacity stay as the extraction kernel left them: MergeSkaDict::append
+        // Assemblies whose regions kept their fixed capacity stay as the extraction kernel left them (both key widths): MergeSkaDict::append
         // (skx_append.hip) reads them unsorted, and the sorted, folded form (a sample's SkaDict) is made when something asks for it
         // (skx::dictset_sort: skx_dictset_size / _export, the key-set union of a sharded job).  A fixed-capacity region always fits
         // the counting sort (region_cap <= LDS_SORT_MAX), so that later sort cannot come back for a finer split.
         d->maxlen = maxlen; d->region_cap = lds_cap;
-        if (!wide && !exact && !any_qual && lds_cap <= LDS_SORT_MAX && !knob("sorted_dicts")) {
+        if (!exact && !any_qual && lds_cap <= (wide ? LDS_SORT_MAX_WIDE : LDS_SORT_MAX) && !knob("sorted_dicts") && !(wide && knob("sorted_wide"))) {
             DevBuf<unsigned long long> d_tot; SKX_TRY(d_tot.alloc(n));
             launch_region_totals(d->raw.p, n, logB, d_tot.p, st);
             d->raw_total.resize(n);
@@ -1322,14 +1323,17 @@ static int keyset_union_dict(skx_ctx *ctx, skx_dictset *d, skx_keyset **out, boo
     if (!ctx || !d || !out) { set_error("bad arguments"); return SKX_EINVAL; }
     SKX_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    if (with_side && !d->sorted) {
+    if (with_side && !d->sorted && !d->wide()) {
         // assemblies as the extraction kernel left them: the append pass finds the rank's rows AND leaves the samples' cells as pieces, which
         // travel with the key set (to the global rows of a sharded job: skx_keyset_allgather) like the notes of the union pass
+        // (128-bit keys: the exchange composes 64-bit rows only -- skx_comm.hip -- so a sharded job's ranks sort their dictionaries)
         std::unique_ptr<skx_keyset> ks; std::unique_ptr<skx_pieces> pc;
         const int r = append_pass(ctx, d, ks, pc);
         if (r == SKX_OK) { ks->pieces = pc.release(); ks->pieces_of = d; *out = ks.release(); return SKX_OK; }
         if (r != SKF_NOT_TAKEN) return r;
     }
+    if (!d->sorted && d->wide() && with_side) ctx->merge_path = "sorted: the key-table exchange of a sharded job composes 64-bit rows only";
+    else if (!d->sorted && !with_side) ctx->merge_path = "sorted: a row set without cells was asked for (skx_keyset_union)";
     SKX_TRY(dictset_sort(d));                        // the union kernels read sorted slices
     StageTimer t(ctx, &ctx->tm.key_union);
     DictView v = d->view();
@@ -1692,30 +1696,39 @@ int skx::array_lazy_window(skx_array *a, uint64_t r0, uint64_t nr, DevBuf<uint8_
 
 // ---- MergeSkaDict::append from the raw regions (skx_append.hip) ----------------------------------------------------------------------
 // rows, row statistics and the cells (as pieces) of all samples in one pass over the words the extraction kernel scattered; no sample is
-// sorted.  SKF_NOT_TAKEN: not this kind of dictset (sorted already, 128-bit keys, regions beyond the kernel's load rounds, a row-block split
-// that would read every region too often), or blocks that kept overflowing -- the caller sorts the dictionaries and takes the union /
-// assemble kernels.
+// sorted.  Both key widths (append_kernel; append_wide_kernel for k > 31).  SKF_NOT_TAKEN: not this kind of dictset (sorted already, regions
+// beyond the kernel's load rounds, a row-block split that would read every region too often), or blocks that kept overflowing -- the caller
+// sorts the dictionaries and takes the union / assemble kernels.  ctx->last_merge_path says which way a merge went (skx_debug_last_merge_path).
 // the pass itself: the row blocks' keys (ks: stage / ncnt / roff, stride = cap) and the samples' pieces
 static int append_pass(skx_ctx *ctx, skx_dictset *d, std::unique_ptr<skx_keyset> &ks_out, std::unique_ptr<skx_pieces> &pc_out)
 {
-    if (d->sorted || d->wide() || d->n > 65535 || d->n < 1) return SKF_NOT_TAKEN;
+    auto not_taken = [&](const char *why) -> int {
+        ctx->merge_path = std::string("sorted: ") + why;
+        if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] merge: %s\n", ctx->merge_path.c_str());
+        return SKF_NOT_TAKEN;
+    };
+    if (d->sorted) return not_taken("the dictionaries are sorted (read sets, oversize or repeat-rich samples, SKX_KNOBS=sorted_dicts)");
+    if (d->n > 65535 || d->n < 1) return not_taken("more than 65535 samples");
     SKX_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    const int S = d->n, bits = d->hp.bits, logB = d->logB;
+    const bool wide = d->wide();                                       // 16-byte words, 16-byte table entries: skx_append_wide.inc
+    const int S = d->n, bits = wide ? d->wh.bits : d->hp.bits, logB = d->logB, wpk = wide ? 2 : 1;
     const uint32_t region_cap = d->region_cap;
+    const uint32_t max_cap = wide ? APPEND_WIDE_MAX_CAP : APPEND_MAX_CAP, max_slots = wide ? APPEND_WIDE_MAX_SLOTS : APPEND_MAX_SLOTS;
     uint64_t raw_sum = 0, raw_max = 0;
     for (auto v : d->raw_total) { raw_sum += v; raw_max = std::max(raw_max, v); }
-    const int min_logQ = std::max(logB, bits - 50);
-    if (min_logQ > bits || region_cap > 8192u) return SKF_NOT_TAKEN;
+    const int min_logQ = std::max(logB, bits - (wide ? 113 : 50));
+    if (min_logQ > bits || region_cap > 8192u) return not_taken("regions of more than 8192 words");
     auto ranks_for = [&](double mean) -> uint32_t {
         const double c = mean + 6.0 * std::sqrt(mean + 1.0) + 32.0;
-        return (uint32_t)std::min<double>(APPEND_MAX_CAP, std::ceil(c / 128.0) * 128.0);
+        return (uint32_t)std::min<double>(max_cap, std::ceil(c / 128.0) * 128.0);
     };
     auto slots_for = [&](uint32_t cap) -> uint32_t {                  // a power of two (the home slot is a shift), a third more than the ranks at least
         uint32_t n = 256u;
-        while (n < cap + cap / 3 && n < APPEND_MAX_SLOTS) n <<= 1;
+        while (n < cap + cap / 3 && n < max_slots) n <<= 1;
         return n;
     };
+    auto pass_ok = [&](int lq, uint32_t nslots, uint32_t cap) { return wide ? append_wide_ok(bits, logB, lq, nslots, cap) : append_ok(bits, logB, lq, region_cap, nslots, cap); };
     DevBuf<int> d_flag; SKX_TRY(d_flag.alloc(1));
     DevBuf<unsigned long long> d_probe; SKX_TRY(d_probe.alloc(2));
     AppendArgs aa{};
@@ -1723,42 +1736,43 @@ static int append_pass(skx_ctx *ctx, skx_dictset *d, std::unique_ptr<skx_keyset>
     StageTimer t(ctx, &ctx->tm.key_union);
     // |U| from a thin slice of the hash space: the first row blocks of a 2^logP split, rows counted only
     double u_est = (double)raw_max;
-    const double target = 5400.0;                    // mean rows of a probe block (the final split: the coarsest whose blocks fit their ranks)
+    const double target = wide ? 2600.0 : 5400.0;    // mean rows of a probe block (the final split: the coarsest whose blocks fit their ranks)
     int logQ = min_logQ;
     if (S > 1) {
         int logP = std::min(bits, std::max(min_logQ, ilog2_ceil((uint64_t)((double)raw_max * 3.0 / target) + 1)));
         for (int attempt = 0;; attempt++) {
             const unsigned blocks = (unsigned)std::min<uint64_t>(64, 1ull << logP);
-            aa.logQ = logP; aa.nslots = APPEND_MAX_SLOTS; aa.cap = APPEND_MAX_CAP; aa.rounds = 1; aa.bar = nullptr;
-            if (!append_ok(bits, logB, logP, region_cap, aa.nslots, aa.cap)) return SKF_NOT_TAKEN;
+            aa.logQ = logP; aa.nslots = max_slots; aa.cap = max_cap; aa.rounds = 1; aa.bar = nullptr;
+            if (!pass_ok(logP, aa.nslots, aa.cap)) return not_taken("no probe split with room for a rank in a table entry (very short or very long hash)");
             SKX_TRY(d_flag.zero(st)); SKX_TRY(d_probe.zero(st));
-            launch_append_probe(aa, region_cap, blocks, st);
+            if (wide) launch_append_wide_probe(aa, blocks, st); else launch_append_probe(aa, region_cap, blocks, st);
             unsigned long long pr[2] = {0, 0}; int ov = 0;
             SKX_HIP(hipMemcpyAsync(pr, d_probe.p, 16, hipMemcpyDeviceToHost, st));
             SKX_HIP(hipMemcpyAsync(&ov, d_flag.p, 4, hipMemcpyDeviceToHost, st));
             SKX_HIP(hipStreamSynchronize(st));
             SKX_HIP(hipGetLastError());
             if (!ov) { u_est = std::max((double)raw_max * 0.5, (double)pr[0] / blocks * (double)(1ull << logP)); break; }
-            if (attempt >= 4 || logP + 2 > bits) return SKF_NOT_TAKEN;
+            if (ov & 4) return not_taken("the table's bytes are not at LDS address 0");
+            if (attempt >= 4 || logP + 2 > bits) return not_taken("the probe blocks kept overflowing");
             logP += 2;
         }
     }
     // the coarsest split whose blocks hold their rows with six sigma to spare (a finer one reads every region more often)
-    for (logQ = min_logQ; logQ < bits && u_est / (double)(1ull << logQ) + 6.0 * std::sqrt(u_est / (double)(1ull << logQ) + 1.0) + 32.0 > (double)APPEND_MAX_CAP; logQ++) { }
+    for (logQ = min_logQ; logQ < bits && u_est / (double)(1ull << logQ) + 6.0 * std::sqrt(u_est / (double)(1ull << logQ) + 1.0) + 32.0 > (double)max_cap; logQ++) { }
     for (int attempt = 0;; attempt++, logQ++) {
-        if (logQ > bits || attempt > 3) return SKF_NOT_TAKEN;
+        if (logQ > bits || attempt > 3) return not_taken("row blocks kept overflowing (a sample that is one repeat, or far more rows than the probe saw)");
         const uint64_t nsub = 1ull << logQ;
         const double mean = u_est / (double)nsub;
         const uint32_t cap = ranks_for(mean), nslots = slots_for(cap);
         const uint64_t amp = 1ull << (logQ - logB);
-        if (amp > 8 && (double)raw_sum * (double)amp > 4e8) return SKF_NOT_TAKEN;          // every region would be read too often
-        if (!append_ok(bits, logB, logQ, region_cap, nslots, cap)) return SKF_NOT_TAKEN;
+        if (amp > 8 && (double)raw_sum * (double)amp > 4e8) return not_taken("more than 8 row blocks per region: every region would be read too often");
+        if (!pass_ok(logQ, nslots, cap)) return not_taken("no row-block split that fits the LDS");
         std::unique_ptr<skx_keyset> ks(new skx_keyset());
-        ks->ctx = ctx; ks->k = d->k; ks->rc = d->rc; ks->logN = logQ; ks->hp = d->hp; ks->wh = d->wh; ks->wide = false; ks->stride = cap;
+        ks->ctx = ctx; ks->k = d->k; ks->rc = d->rc; ks->logN = logQ; ks->hp = d->hp; ks->wh = d->wh; ks->wide = wide; ks->stride = cap;
         std::unique_ptr<skx_pieces> pc(new skx_pieces());
         pc->cap = cap; pc->logQ = logQ;
-        SKX_TRY(ks->stage.alloc(nsub * cap)); SKX_TRY(ks->ncnt.alloc(nsub));
-        if (pc->data.alloc(nsub * (uint64_t)S * (cap / 2)) != SKX_OK) return SKF_NOT_TAKEN;      // (no room for the pieces: the sorted path holds rows + dictionaries instead)
+        SKX_TRY(ks->stage.alloc(nsub * cap * wpk)); SKX_TRY(ks->ncnt.alloc(nsub));
+        if (pc->data.alloc(nsub * (uint64_t)S * (cap / 2)) != SKX_OK) return not_taken("no room for the pieces");      // (the sorted path holds rows + dictionaries instead)
         SKX_TRY(pc->plen.alloc(nsub * (uint64_t)S + 2)); SKX_TRY(pc->perm.alloc(nsub * cap)); SKX_TRY(pc->nrank.alloc(nsub));
         SKX_TRY(d_flag.zero(st));
         aa.logQ = logQ; aa.nslots = nslots; aa.cap = cap;
@@ -1776,14 +1790,16 @@ static int append_pass(skx_ctx *ctx, skx_dictset *d, std::unique_ptr<skx_keyset>
         }
         aa.pieces = pc->data.p; aa.plen = pc->plen.p; aa.perm = pc->perm.p; aa.nrank = pc->nrank.p;
         aa.stage = ks->stage.p; aa.stride = cap; aa.ncnt = ks->ncnt.p;
-        launch_append(aa, region_cap, st);
+        if (wide) launch_append_wide(aa, st); else launch_append(aa, region_cap, st);
         int ov = 0;
         SKX_HIP(hipMemcpyAsync(&ov, d_flag.p, 4, hipMemcpyDeviceToHost, st));
         SKX_HIP(hipStreamSynchronize(st));
         SKX_HIP(hipGetLastError());
-        if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] append: logQ=%d (x%llu per region) cap=%u slots=%u rows~%.0f -> %s\n", logQ, (unsigned long long)amp, cap, nslots, u_est, ov ? "overflow" : "ok");
+        if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] append%s: logQ=%d (x%llu per region) cap=%u slots=%u rows~%.0f -> %s\n", wide ? " (128-bit keys)" : "", logQ, (unsigned long long)amp, cap, nslots, u_est, ov ? "overflow" : "ok");
+        if (ov & 4) return not_taken("the table's bytes are not at LDS address 0");
         if (ov) continue;
         SKX_TRY(keyset_finish(ks.get()));
+        ctx->merge_path = wide ? "append128" : "append64";
         ks_out = std::move(ks); pc_out = std::move(pc);
         return SKX_OK;
     }
@@ -1798,7 +1814,7 @@ static int array_over_pieces(skx_ctx *ctx, const skx_dictset *d, skx_keyset *ks,
     const int S = d->n, logQ = pc->logQ;
     const uint64_t nsub = 1ull << logQ;
     std::unique_ptr<skx_keyset> blk(new skx_keyset());                 // what the array keeps of the row blocks: ncnt / roff
-    blk->ctx = ctx; blk->k = d->k; blk->rc = d->rc; blk->logN = logQ; blk->hp = d->hp; blk->wh = d->wh; blk->wide = false; blk->stride = pc->cap;
+    blk->ctx = ctx; blk->k = d->k; blk->rc = d->rc; blk->logN = logQ; blk->hp = d->hp; blk->wh = d->wh; blk->wide = d->wide(); blk->stride = pc->cap;
     uint64_t U;
     if (g) {
         U = g->total;
@@ -1818,10 +1834,11 @@ static int array_over_pieces(skx_ctx *ctx, const skx_dictset *d, skx_keyset *ks,
     a->ctx = ctx; a->k = d->k; a->rc = d->rc; a->k_bits = d->key_bits; a->hp = d->hp; a->wh = d->wh; a->version = skx_version();
     for (int i = 0; i < S; i++) a->names.emplace_back(names && names[i] ? names[i] : "");
     a->n_rows = a->n_kmers = U; a->pitch = 0; a->engine_order = true; a->stats_ready = true;
-    SKX_TRY(a->present.alloc(U)); SKX_TRY(a->unambig.alloc(U)); SKX_TRY(a->mask.alloc(U)); SKX_TRY(a->keys.alloc(U)); SKX_TRY(a->vcount.alloc(U));
+    SKX_TRY(a->present.alloc(U)); SKX_TRY(a->unambig.alloc(U)); SKX_TRY(a->mask.alloc(U)); SKX_TRY(a->keys.alloc(U * (d->wide() ? 2 : 1))); SKX_TRY(a->vcount.alloc(U));
     if (U) {
         skx_keyset *src = g ? g : ks;                                  // the rows' keys
-        launch_gather_keys(src->stage.p, src->stride, g ? g->ncnt.p : blk->ncnt.p, g ? g->roff.p : blk->roff.p, 1 << src->logN, a->keys.p, 0, src->hp, st);
+        if (src->wide) launch_gather_keys_wide((const u128 *)src->stage.p, src->stride, g ? g->ncnt.p : blk->ncnt.p, g ? g->roff.p : blk->roff.p, 1 << src->logN, (u128 *)a->keys.p, st);
+        else launch_gather_keys(src->stage.p, src->stride, g ? g->ncnt.p : blk->ncnt.p, g ? g->roff.p : blk->roff.p, 1 << src->logN, a->keys.p, 0, src->hp, st);
         if (g) { SKX_TRY(a->present.zero(st)); SKX_TRY(a->unambig.zero(st)); SKX_TRY(a->mask.zero(st)); SKX_TRY(a->vcount.zero(st)); }
         // the rows' statistics, counted from the pieces
         StageTimer t(ctx, &ctx->tm.assemble);

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
         // not.  Returns the entry's byte offset in the table.
         auto where8 = [&](uint32_t hs, uint32_t fp) -> uint32_t {
             typedef const uint32_t __attribute__((address_space(3))) *lds_c32_t;
-            const lds_c32_t f = (lds_c32_t)(hs & ~3u);                         // (s_fp is LDS address 0 -- checked at the kernel's start: the slot's number is the address)
+            const lds_c32_t f = (lds_c32_t)(uintptr_t)(hs & ~3u);                         // (s_fp is LDS address 0 -- checked at the kernel's start: the slot's number is the address)
             const uint32_t fp4 = __builtin_amdgcn_perm(fp, fp, 0u);
             const uint32_t x0 = f[0] ^ fp4, x1 = f[1] ^ fp4;
             const uint32_t hs8 = hs << 3;
@@ -855,3 +855,5 @@ void launch_pieces_rows(const PiecesRowsArgs &a, uint32_t n_blocks, hipStream_t 
 }
 
 }  // namespace skx
+
+#include "skx_append_wide.inc"

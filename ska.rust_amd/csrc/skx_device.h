@@ -175,6 +175,11 @@ struct AppendArgs {
 bool append_ok(int bits, int logB, int logQ, uint32_t region_cap, uint32_t nslots, uint32_t cap);
 void launch_append(const AppendArgs &a, uint32_t region_cap, hipStream_t st);
 void launch_append_probe(const AppendArgs &a, uint32_t region_cap, unsigned blocks, hipStream_t st);     // the first `blocks` row blocks, rows counted only
+// the same pass over 16-byte words (k > 31; skx_append_wide.inc): words / stage address u128 elements, off counts them; 16-byte table entries
+constexpr uint32_t APPEND_WIDE_MAX_CAP = 3072, APPEND_WIDE_MAX_SLOTS = 4096;
+bool append_wide_ok(int bits, int logB, int logQ, uint32_t nslots, uint32_t cap);
+void launch_append_wide(const AppendArgs &a, hipStream_t st);
+void launch_append_wide_probe(const AppendArgs &a, unsigned blocks, hipStream_t st);
 // row statistics from the pieces (present, unambiguous, code set, variant_count), written to the rows in the order of H
 void launch_pieces_stats(const uint8_t *pieces, const uint16_t *plen, const uint16_t *perm, const uint32_t *nrank, const uint32_t *ncnt, const uint64_t *roff, uint32_t cap,
                          int n_samples, int n_blocks, uint32_t *present, uint32_t *unambig, uint32_t *mask, uint32_t *vcount, hipStream_t st);

@@ -86,6 +86,7 @@ struct skx_ctx {
     hipEvent_t ev[2] = {nullptr, nullptr};
     skx_timings tm{};
     bool timing = true;
+    std::string merge_path;          // which kernels the last merge on this context went through, and why (skx_ctx_merge_path)
 };
 
 struct skx_dictset {
