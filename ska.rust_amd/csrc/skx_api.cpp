@@ -475,7 +475,9 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
     const int key_bits_used = 2 * (k - 1);
     // windows per bucket (upper bound): the 64-bit dedupe sorts up to 6 144 words per region in LDS and the regions get 20 % + 256
     // words of head-room, so 4 900 is the largest mean that fits -- and the largest buckets give the scatter its widest chunks
-    uint64_t per_region = wide ? 4096 : 4900;
+    // (128-bit keys: 3 200, so that a region's fixed capacity -- 20 % + 256 above the mean -- stays within the 4 096 words of the wide counting sort
+    // and the samples can stay as extracted for the append pass whatever their length)
+    uint64_t per_region = wide ? 3200 : 4900;
     if (any_qual || maxlen > (per_region << MAX_LOGB)) return build_reads();
     int logB = std::min({ilog2_ceil((maxlen + per_region - 1) / per_region), key_bits_used, MAX_LOGB});
     if (logB < 0) logB = 0;
