@@ -107,6 +107,8 @@ def _load():
     lib.ora_timers_get.argtypes = [C.POINTER(Timers), i]
     lib.ora_sample_name.restype = vp
     lib.ora_sample_name.argtypes = [cp]
+    lib.ora_snappy_frame_decode.restype = vp
+    lib.ora_snappy_frame_decode.argtypes = [cp, sz, C.POINTER(sz)]
     return lib
 
 
@@ -115,6 +117,16 @@ lib = _load()
 
 class OracleError(RuntimeError):
     pass
+
+
+def skf_cbor(path):
+    """the CBOR document inside a .skf: its snappy frame taken off (chunk CRCs checked) -- what ciborium reads (merge_ska_array.rs:199-203)"""
+    raw = open(path, "rb").read()
+    n = C.c_size_t()
+    p = lib.ora_snappy_frame_decode(raw, len(raw), C.byref(n))
+    if not p:
+        raise OracleError(lib.ora_last_error().decode())
+    return _take(p, n.value)
 
 
 def _err():

@@ -63,7 +63,8 @@ def test_wide_append_many_samples_repeats_and_palindromes(E, k):
     rng = np.random.default_rng(7 + k)
     samples = related(rng, 30_000, 37, 15, cut=3)
     unit = ACGT[rng.integers(0, 4, size=k + 9)].tobytes()
-    samples += [[b"A" * 20_000, unit * 400], [b"AT" * 8000 + samples[0][0][:3000]], [b"ACGT" * 3000]]
+    # (small enough for the regions' fixed capacity: a repeat that overflows a region sends the build to exact offsets and sorted dictionaries)
+    samples += [[b"A" * 700, unit * 8], [b"AT" * 300 + samples[0][0][:3000]], [b"ACGT" * 150]]
     var = bytearray(unit * 50)
     for p in range(k // 2, len(var), len(unit)):
         var[p] = b"ACGT"[(p // len(unit)) % 4]                          # the same flanks around different middle bases: folded into ambiguity codes
@@ -79,6 +80,15 @@ def test_wide_append_many_samples_repeats_and_palindromes(E, k):
         assert sorted(zip(*g.decode().splitlines()[1::2])) == sorted(zip(*o.decode().splitlines()[1::2])), (min_freq, ft, amb)
     ga, oa = build_both(E, samples[:12], k, True)
     assert ga.distance_tsv(min_freq=0.5) == oa.distance_tsv(min_freq=0.5)
+
+
+@pytest.mark.parametrize("k", [33, 63])
+def test_wide_repeat_that_overflows_a_region_takes_the_sorted_path(E, k):
+    rng = np.random.default_rng(70 + k)
+    samples = related(rng, 30_000, 6, 15) + [[b"A" * 20_000, b"AC" * 9000]]
+    ga, oa = build_both(E, samples, k, True)
+    assert E.default_context().merge_path().startswith("sorted: the dictionaries are sorted")
+    check_equal(E, ga, oa)
 
 
 @pytest.mark.parametrize("k", [41])
@@ -101,3 +111,38 @@ def test_merge_path_is_reported_for_64_bit_keys(E):
     ga, oa = build_both(E, samples, 31, True)
     assert E.default_context().merge_path() == "append64"
     check_equal(E, ga, oa)
+
+
+# ---- the .skf writer, byte for byte (merge_ska_array.rs:108-126,191-204: ciborium over the struct, snap's frame around it) ----
+import golden_cases as G
+
+
+@pytest.mark.parametrize("fixture", ["merge.skf", "merge_k9.skf", "merge_k41.skf", "multidist.skf"])
+def test_engine_rewrites_a_rust_written_skf_byte_for_byte(E, fixture, tmp_path):
+    """A file the Rust binary wrote, loaded through skx_array_load and saved again: rows stay in file order and ska_version is the file's, so
+    the CBOR document must come out identical -- field order, definite lengths, minimal-length integers, tag-2 bignums for 128-bit keys,
+    two bytes per cell.  (The snappy frame around it is free: any valid frame loads; the engine compresses, the fixture's writer did too.)"""
+    a = E.Array.load(G.fin(fixture))
+    p = str(tmp_path / fixture)
+    a.save(p)
+    assert ora.skf_cbor(p) == ora.skf_cbor(G.fin(fixture))
+    # and the streaming writer of `ska build` (skh_save_skf: device-encoded data section)
+    b = E.Array.load(G.fin(fixture))
+    b.save_skf(str(tmp_path / ("s_" + fixture[:-4])))
+    assert ora.skf_cbor(str(tmp_path / ("s_" + fixture))) == ora.skf_cbor(G.fin(fixture))
+
+
+@pytest.mark.parametrize("k", [31, 41, 63])
+def test_engine_built_skf_equals_the_oracle_writer_on_the_same_rows(E, k, tmp_path):
+    """An array built here, written by the engine; the oracle reads it (rows in file order) and writes it with its own writer -- the one
+    test_oracle_golden.py pins against the Rust-written fixtures byte for byte: the two CBOR documents must be identical."""
+    rng = np.random.default_rng(k)
+    samples = related(rng, 40_000, 11, 25)
+    names = [f"s{i}" for i in range(len(samples))]
+    ga = E.DictSet.build([E.record_stream(r) for r in samples], k, True).merge(names)
+    p, q = str(tmp_path / "e.skf"), str(tmp_path / "o.skf")
+    ga.save(p)
+    o = ora.Array.load(p)
+    o.save(q)
+    assert ora.skf_cbor(p) == ora.skf_cbor(q)
+    assert o.version == ga.version if hasattr(ga, "version") else True

@@ -41,6 +41,19 @@ def test_skf_roundtrip(tmp_path):
         assert _as_map(a) == _as_map(b) and a.names == b.names and a.version == b.version
 
 
+@pytest.mark.parametrize("fixture", ["merge.skf", "merge_k9.skf", "merge_k41.skf", "multidist.skf"])
+def test_skf_writer_reproduces_the_rust_written_bytes(fixture, tmp_path):
+    """merge_ska_array.rs:108-126,191-197: load -> save of a file the Rust binary wrote gives back its CBOR document byte for byte (field
+    order, definite lengths, minimal-length integers, tag-2 bignums for keys above 64 bits, 2 bytes per cell above 23).  The snappy framing
+    around it is free (any valid frame loads), so the comparison is of the un-framed streams."""
+    a = ora.Array.load(G.fin(fixture))
+    p = str(tmp_path / fixture)
+    a.save(p)
+    want, got = ora.skf_cbor(G.fin(fixture)), ora.skf_cbor(p)
+    assert len(want) == {"merge.skf": 894, "merge_k9.skf": 655, "merge_k41.skf": 843, "multidist.skf": 1577}[fixture]
+    assert got == want
+
+
 def test_load_u64_then_u128():
     # lib.rs:635-661: a k=41 file must fail as u64 and load as u128
     with pytest.raises(ora.OracleError):
