@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--check", action="store_true", help="(kept for compatibility: the check always runs unless --no-check)")
     ap.add_argument("--cli-threads", type=int, default=0, help="--threads given to the ska executable (0 = min(64, cores))")
     ap.add_argument("--settle-s", type=float, default=12.0, help="idle seconds before each independent end-to-end measurement (the chain build -> align has none in between)")
+    ap.add_argument("--no-selftest", action="store_true", help="--gpus N > 1: skip the `ska selftest --gpus N` pre-flight (id hand-off, all-reduce, gather, all-gather of unequal key tables over RCCL)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic in this run")
     ap.add_argument("--pmc-genomes", type=int, default=0, help="samples of the workload the --pmc passes extract (0 = all of --genomes)")
     ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)      # the process rocprofv3 runs: extraction of that many samples, nothing else
@@ -76,36 +77,83 @@ def private_snps(n_total):
     return 500 if n_total <= 1000 else 100
 
 
-def other_kernels(tm, steps, n_bases, n_distinct, rows, rows_kept, n_samples, key_bytes=8):
-    """HBM rate of the remaining stages against SURVEY.md 8d's algorithmic bytes (W + 1 = 9 B per dictionary entry -- 17 B for
-    k > 31 --, P ~ N windows, D = sum of distinct split k-mers per sample, U rows, U' rows kept).  For 64-bit keys the per-sample
-    dictionaries are no stage of their own any more: MergeSkaDict::append (append_kernel) reads the regions as the extraction kernel
-    scattered them, so SURVEY's "per-sample dedup" and "merge" rows are one stage here and are priced together."""
+def classify_kernel(name):
+    """which stage of the step a kernel of the rocprofv3 trace belongs to"""
+    if "extract_kernel<true" in name or "extract_wide_kernel<true" in name:
+        return "extract"
+    if "dedupe" in name:
+        return "dedup"
+    for t in ("append_kernel", "append_wide_kernel", "pieces_stats_kernel", "union_kernel", "union_wide_kernel", "assemble", "gather_keys", "region_totals", "compose_perm"):
+        if t in name:
+            return "merge"
+    for t in ("filter_flags", "scan_u8", "pieces_rows_kernel", "compact", "count_u8", "mask_ambig"):
+        if t in name:
+            return "filter"
+    return "other"
+
+
+def other_kernels(tm, steps, n_bases, n_distinct, rows, rows_kept, n_samples, key_bytes=8, piece_bytes=None, traffic=None):
+    """The stages behind the extraction kernel.  `achieved` / `frac` are HBM rates on BYTES MOVED: the FETCH_SIZE x 2 + WRITE_SIZE of the
+    stage's kernels measured in this run (`traffic`), or -- without the --pmc passes -- the bytes the stage's kernels must move by
+    design (`needed_bytes`), and `achieved_basis` says which.  SURVEY.md 8d prices the REFERENCE's data flow (W + 1 = 9 | 17 B per
+    dictionary entry, a byte per cell read and written); the fused kernels here do not move those bytes, so that figure is given as
+    `reference_flow_bytes` with `speedup_vs_reference_flow` = the time that flow would take at the HBM peak / this stage's time -- a
+    ratio of times that may pass 1, never a bandwidth."""
     out = []
     w1 = key_bytes + 1.0
     dict_ms, merge_ms = tm["dedupe"] / steps, (tm["key_union"] + tm["assemble"]) / steps
-    dict_b, merge_b = w1 * (n_bases + n_distinct), w1 * n_distinct + rows * (float(key_bytes) + n_samples)
-    if dict_ms > 0:
-        stages = [("per-sample dedup (dedupe kernel)", dict_ms, dict_b), ("merge (union + assemble kernels)", merge_ms, merge_b)]
-    else:
-        stages = [("dictionaries + merge as one pass (append probe + append_kernel + pieces_stats_kernel: regions read unsorted, cells kept as 4-bit pieces)",
-                   merge_ms, dict_b + merge_b)]
-    stages.append(("filter + compaction (row verdicts + pieces_rows_kernel: kept rows only)" if dict_ms == 0 else "filter + compaction",
-                   (tm["filter"] + tm["compact"]) / steps, rows * (float(key_bytes) + n_samples) + rows_kept * float(n_samples)))
-    for name, ms, nbytes in stages:
-        gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        o = {"stage": name, "ms": ms, "algorithmic_bytes": nbytes, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
-        if dict_ms == 0:
-            # These are SURVEY 8d's bytes -- the reference's data flow (a byte per cell read and written) -- over this engine's time: a rate of the
-            # pipeline against the reference's flow, not of a kernel against HBM (the cells are 4 bits here and the unfiltered matrix is never
-            # read by the filter: such a "fraction" may pass 1).  frac_of_hbm_on_own_bytes prices the stage by what its kernels must move.
-            own = (rows * n_samples / 2.0 + rows_kept * float(n_samples) + 16.0 * rows) if name.startswith("filter") else (float(key_bytes) * n_bases + rows * n_samples / 2.0 + 12.0 * rows)
-            o["basis"] = "SURVEY 8d bytes of the reference's data flow / this stage's time"
-            o["own_bytes"] = own
-            o["frac_of_hbm_on_own_bytes"] = own / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0
-            o["frac_vs_reference_flow"] = o.pop("frac")
-        out.append(o)
+    ref_dict, ref_merge = w1 * (n_bases + n_distinct), w1 * n_distinct + rows * (float(key_bytes) + n_samples)
+    ref_filter = rows * (float(key_bytes) + n_samples) + rows_kept * float(n_samples)
+    pieces = float(piece_bytes) if piece_bytes else rows * n_samples / 2.0 * 0.6
+    if dict_ms > 0:     # sorted path: per-sample dictionaries sorted and folded, then union + assemble
+        stages = [("dedup", "per-sample dedup (dedupe kernel)", dict_ms, ref_dict, float(key_bytes) * (n_bases + n_distinct)),
+                  ("merge", "merge (union + assemble kernels)", merge_ms, ref_merge, float(key_bytes) * n_distinct * 2 + rows * (float(key_bytes) + n_samples)),
+                  ("filter", "filter + compaction", (tm["filter"] + tm["compact"]) / steps, ref_filter, ref_filter)]
+    else:               # append pass: dictionaries + merge in one kernel over the unsorted regions, cells kept as 4-bit pieces
+        stages = [("merge", "dictionaries + merge as one pass (append probe + append kernel + pieces_stats_kernel: regions read unsorted, cells kept as 4-bit pieces)",
+                   merge_ms, ref_dict + ref_merge, float(key_bytes) * n_bases + 2.0 * pieces + rows * (key_bytes + 2.0 + 16.0)),
+                  ("filter", "filter + compaction (row verdicts + pieces_rows_kernel: kept rows only)", (tm["filter"] + tm["compact"]) / steps, ref_filter,
+                   pieces + rows_kept * float(n_samples) + 16.0 * rows + 9.0 * rows)]
+    for key, name, ms, ref_b, need_b in stages:
+        moved = None
+        if traffic:
+            moved = sum(v["fetch_bytes"] + v["write_bytes"] for kname, v in traffic.items() if classify_kernel(kname) == key) or None
+        basis_b = moved if moved else need_b
+        gbs = basis_b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out.append({"stage": name, "ms": ms, "needed_bytes": need_b, "traffic": moved,
+                    "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                    "achieved_basis": "bytes moved (FETCH_SIZE x 2 + WRITE_SIZE of the stage's kernels, measured in this run)" if moved else "needed_bytes (what the stage's kernels must move by design; no --pmc passes in this run)",
+                    "frac_of_hbm_on_needed_bytes": need_b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0,
+                    "reference_flow_bytes": ref_b,
+                    "speedup_vs_reference_flow": (ref_b / (HBM_PEAK_GBS * 1e9)) / (ms * 1e-3) if ms > 0 else 0.0})
     return out
+
+
+def fill_dominant(res, tm, steps, n_bases, shape, n_samples, key_bytes, pieces_info, traffic, n_pmc):
+    """roofline.dominant: the append kernel (MergeSkaDict::append for all samples, csrc/skx_append.hip -- since round 4 the largest kernel of the
+    k <= 31 step).  needed_bytes = what it must move by design: every packed word of the regions once (W B per window) + the pieces, the row
+    keys and perm it writes; traffic = FETCH_SIZE x 2 + WRITE_SIZE of its launches measured in this run.  Both fractions of the 8 TB/s peak."""
+    ms = tm["append"] / steps
+    if ms <= 0:
+        res["roofline"]["dominant"] = None          # the sorted path ran (see merge_path): no append kernel in this step
+        return
+    words = float(key_bytes) * n_bases               # P ~ N windows (SURVEY.md 8d), W bytes each
+    written = float(pieces_info[0]) + shape[0] * (key_bytes + 2.0) if pieces_info[0] else None
+    d = {"kernel": ("append_kernel<false, true>" if key_bytes == 8 else "append_wide_kernel<false, ..>") + " (rows, first-seen ranks and every sample's cells in one pass over the unsorted regions)",
+         "bound": "hbm", "launch_ms": ms, "largest_kernel_of_step": bool(ms > tm["scatter"] / steps),
+         "needed_bytes": None if written is None else words + written, "needed_read_bytes": words, "needed_write_bytes": written,
+         "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
+    if written is not None:
+        d["achieved_on_needed_bytes"] = (words + written) / (ms * 1e-3) / 1e9
+        d["frac_on_needed_bytes"] = d["achieved_on_needed_bytes"] / HBM_PEAK_GBS
+    if traffic:
+        ap = [v for k, v in traffic.items() if ("append_kernel<false" in k or "append_wide_kernel<false" in k)]
+        if ap:
+            fetch, wr = sum(v["fetch_bytes"] for v in ap), sum(v["write_bytes"] for v in ap)
+            d.update({"traffic": fetch + wr, "fetch_bytes": fetch, "write_bytes": wr, "refetch_factor": fetch / words,
+                      "achieved_on_traffic": (fetch + wr) / (ms * 1e-3) / 1e9, "frac_on_traffic": (fetch + wr) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "traffic_source": f"measured in this run: the same --pmc passes as roofline.traffic ({n_pmc} samples" + (")" if n_pmc == n_samples else f", scaled per base: the re-fetch of a region by its readers depends on the set's size)")})
+    res["roofline"]["dominant"] = d
 
 
 def reference_threads(n_samples, cores):
@@ -203,8 +251,8 @@ def check_against_oracle(args, E, ctx, files, oarr, oaln, n_total, anc, synth):
     return out
 
 
-def run_cli(ska, argv, cwd, phases_path):
-    env = dict(os.environ, SKX_PHASES=phases_path)
+def run_cli(ska, argv, cwd, phases_path, extra_env=None):
+    env = dict(os.environ, SKX_PHASES=phases_path, **(extra_env or {}))
     t0 = time.perf_counter()
     r = subprocess.run([ska, *argv], cwd=cwd, capture_output=True, env=env)
     dt = time.perf_counter() - t0
@@ -229,22 +277,24 @@ def files_equal(a, b, block=64 << 20):
                 return True
 
 
-def warm_device(gb=240, chunk_gb=16):
+def warm_device(device=0, frac=0.9, chunk_gb=16):
     """Device memory costs a process time twice over, and neither is the executable's: a box that has just come up clears VRAM the first time
     it is handed out (tools/vram_probe.sh, profiles/r04zzm_vram_probe.log: hipMalloc of 56 GB 0.97 s as the box's first GPU process, and
     `ska build` 0.98 s in build.dictionaries behind a warm-up that had only taken 56 GB -- the allocator need not hand out the same
     pages), and memory a process released a moment ago is wiped before it is handed out again (2.4-3.8 s right behind one, 0.000 s two
-    seconds later).  Like the warm-up steps of the timed loop, the first is paid before the end-to-end chain: a process takes most of the
-    device's memory through the HIP runtime (no torch: the executable does not use it either), chunk by chunk until the device has no
-    more, and releases it; the idle seconds that follow cover the wipe."""
+    seconds later).  The CONDITIONED end-to-end chain is measured behind this: a process takes `frac` of what hipMemGetInfo calls free on
+    the bench's device through the HIP runtime (no torch: the executable does not use it either), chunk by chunk, and releases it; the idle
+    seconds that follow cover the wipe.  The cold chain (end_to_end.first_process) runs before it, as a user's first job on a fresh node."""
     code = ("import ctypes\n"
             "h = ctypes.CDLL('libamdhip64.so')\n"
-            "assert h.hipSetDevice(0) == 0\n"
-            "ps = []\n"
-            f"for i in range({gb} // {chunk_gb}):\n"
+            f"assert h.hipSetDevice({int(device)}) == 0\n"
+            "fr, tot = ctypes.c_size_t(), ctypes.c_size_t()\n"
+            "assert h.hipMemGetInfo(ctypes.byref(fr), ctypes.byref(tot)) == 0\n"
+            f"want, ps = int(fr.value * {frac}), []\n"
+            f"while want >= ({chunk_gb} << 30):\n"
             "    p = ctypes.c_void_p()\n"
             f"    if h.hipMalloc(ctypes.byref(p), ctypes.c_size_t({chunk_gb} << 30)) != 0: break\n"
-            "    h.hipMemset(p, 0, ctypes.c_size_t(1)); ps.append(p)\n"
+            f"    h.hipMemset(p, 0, ctypes.c_size_t(1)); ps.append(p); want -= ({chunk_gb} << 30)\n"
             "h.hipDeviceSynchronize()\n"
             "for p in ps: h.hipFree(p)\n")
     try:
@@ -253,39 +303,68 @@ def warm_device(gb=240, chunk_gb=16):
         sys.stderr.write(f"bench.py: device warm-up skipped: {e}\n")
 
 
-def end_to_end(args, files, td):
-    """files -> `ska build` -> .skf -> `ska align` and the single `ska align *.fa`, through the executable, on tmpfs"""
+def end_to_end(args, files, td, device=0):
+    """files -> `ska build` -> .skf -> `ska align` and the single `ska align *.fa`, through the executable, on tmpfs -- twice: as the first GPU
+    processes this bench starts (on a fresh node: the box's first, device memory cleared as it is first handed out), then conditioned"""
     ska = os.path.join(ROOT, "ska.rust_amd", "ska")
     n = len(files)
     threads = args.cli_threads or min(64, os.cpu_count() or 1)
     with open(os.path.join(td, "list.txt"), "w") as f:
         for i, p in enumerate(files):
             f.write(f"g{i}\t{p}\n")
-    # Each independent measurement starts on a box that has been idle for a few seconds: VRAM another process has just released is wiped by
-    # the driver before it is handed out again, and an allocation of tens of GB made right after waits for it (DESIGN.md section 8: `ska build`
-    # pays ~1 s in build.dictionaries when a GPU job -- the test suite, say -- ended a moment earlier; fast again after a few seconds).  The
-    # chain `ska build` -> `ska align x.skf` is one measurement and runs back to back, as a user's script would.
-    warm_device()
+    env_dev = {"HIP_VISIBLE_DEVICES": str(device)} if device else {}
+    build_argv = ["build", "-f", "list.txt", "-o", "all", "-k", str(args.k), "--threads", str(threads)]
+    align_argv = ["align", "all.skf", "-o", "aln.fa", "--threads", str(threads)]
+    # 1. the cold chain: no GPU process of this bench has run yet (bench.py opens the device only after this leg)
+    tb0, pb0 = run_cli(ska, build_argv, td, os.path.join(td, "ph_build0.json"), env_dev)
+    ta0, pa0 = run_cli(ska, align_argv, td, os.path.join(td, "ph_align0.json"), env_dev)
+    os.replace(os.path.join(td, "aln.fa"), os.path.join(td, "aln0.fa"))
+    # 2. the conditioned chain.  Each independent measurement starts on a box that has been idle for a few seconds: VRAM another process has
+    # just released is wiped by the driver before it is handed out again, and an allocation of tens of GB made right after waits for it
+    # (DESIGN.md section 8).  The chain `ska build` -> `ska align x.skf` is one measurement and runs back to back, as a user's script would.
+    warm_device(device)
     time.sleep(max(args.settle_s, 0.0))
-    tb, pb = run_cli(ska, ["build", "-f", "list.txt", "-o", "all", "-k", str(args.k), "--threads", str(threads)], td, os.path.join(td, "ph_build.json"))
+    tb, pb = run_cli(ska, build_argv, td, os.path.join(td, "ph_build.json"), env_dev)
     skf_bytes = os.path.getsize(os.path.join(td, "all.skf"))
-    ta, pa = run_cli(ska, ["align", "all.skf", "-o", "aln.fa", "--threads", str(threads)], td, os.path.join(td, "ph_align.json"))
+    ta, pa = run_cli(ska, align_argv, td, os.path.join(td, "ph_align.json"), env_dev)
     aln_bytes = os.path.getsize(os.path.join(td, "aln.fa"))
+    same_cold = files_equal(os.path.join(td, "aln.fa"), os.path.join(td, "aln0.fa"))
+    os.unlink(os.path.join(td, "aln0.fa"))
     # the single-invocation form builds with the CLI defaults (k = 31): only comparable when the bench runs at k = 31
     ts, ps, same = None, None, None
     if args.k == 31:
         time.sleep(max(args.settle_s, 0.0))
-        ts, ps = run_cli(ska, ["align", "--threads", str(threads), "-o", "aln2.fa", *files], td, os.path.join(td, "ph_single.json"))
+        ts, ps = run_cli(ska, ["align", "--threads", str(threads), "-o", "aln2.fa", *files], td, os.path.join(td, "ph_single.json"), env_dev)
         same = files_equal(os.path.join(td, "aln.fa"), os.path.join(td, "aln2.fa"))
     res = {"genomes_per_s": n / (tb + ta), "unit": "genomes/s", "samples": n, "cli_threads": threads,
-           "what": "wall clock around the ska executable (process start to exit), FASTA files / .skf / alignment on tmpfs; build -> align back to back, "
-                   f"most of the device's memory taken and released by a warm-up process, then {args.settle_s:g} s of idle, before the chain; the same idle before the single-invocation form",
+           "what": "wall clock around the ska executable (process start to exit), FASTA files / .skf / alignment on tmpfs; build -> align back to back.  "
+                   f"genomes_per_s is the CONDITIONED chain (a warm-up process took and released 90 % of the device's free memory, then {args.settle_s:g} s of idle; "
+                   "the same idle before the single-invocation form); first_process is the same chain run BEFORE any other GPU process of this bench -- "
+                   "on a fresh node the box's first: what a user's first job gets",
            "ska_build_s": tb, "ska_align_skf_s": ta, "skf_bytes": skf_bytes, "alignment_bytes": aln_bytes,
+           "first_process": {"genomes_per_s": n / (tb0 + ta0), "ska_build_s_first_process": tb0, "ska_align_skf_s_first_process": ta0,
+                             "alignment_identical_to_conditioned_run": same_cold, "phases_ska_build": pb0, "phases_ska_align_skf": pa0},
            "phases_ska_build": pb, "phases_ska_align_skf": pa}
     if ts is not None:
         res.update({"ska_align_fasta_single_s": ts, "genomes_per_s_single_invocation": n / ts, "phases_ska_align_fasta_single": ps,
                     "single_invocation_alignment_identical": same})
     return res
+
+
+def preflight(args, world):
+    """The first contact of a sharded job with a node should not be the timed run: rank 0 runs `ska selftest --gpus N` (one process per GPU,
+    each exchange of the sharded job once over RCCL and once over the host-staged transport; 60 s limit with the stage it stopped in) before
+    any rank of the bench opens its device, and the bench stops with that message when it fails."""
+    ska = os.path.join(ROOT, "ska.rust_amd", "ska")
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([ska, "selftest", "--gpus", str(world)], capture_output=True, timeout=180)
+    except subprocess.TimeoutExpired:
+        raise SystemExit(f"bench.py: `ska selftest --gpus {world}` did not finish in 180 s")
+    msg = r.stderr.decode(errors="replace").strip().splitlines()
+    if r.returncode != 0:
+        raise SystemExit(f"bench.py: `ska selftest --gpus {world}` failed (rc {r.returncode}): " + " | ".join(msg[-4:]))
+    return {"seconds": time.perf_counter() - t0, "report": msg[-1] if msg else ""}
 
 
 def launch_ranks(args):
@@ -297,9 +376,13 @@ def launch_ranks(args):
     return subprocess.call(cmd)
 
 
+PMC_CHILD_STEPS = 2
+
+
 def pmc_child(args):
-    """What the --pmc passes profile: the first --pmc-child samples of the same workload (same ancestor, same SNP pattern) extracted
-    twice, nothing else on the device -- the counters of the extraction kernel's launches are what measure_traffic reads."""
+    """What the --pmc passes profile: the whole step (extraction, merge, filter + kept rows) on the first --pmc-child samples of the same
+    workload (same ancestor, same SNP pattern), PMC_CHILD_STEPS times, nothing else on the device -- measure_traffic reads the counters of
+    every kernel launched."""
     import synth
     import torch
     import skx_engine as E
@@ -311,32 +394,36 @@ def pmc_child(args):
         offs.append(tot)
         tot += (len(s) + 255) // 256 * 256
     E.load_library()
-    ctx = E.Context(0)
-    dev = torch.device("cuda", 0)
+    ctx = E.Context(int(os.environ.get("SKX_BENCH_DEVICE", "0")))
+    dev = torch.device("cuda", int(os.environ.get("SKX_BENCH_DEVICE", "0")))
     pool = torch.empty(tot + 256, dtype=torch.uint8, device=dev)
     for o, s in zip(offs, streams):
         pool[o:o + len(s)] = torch.from_numpy(s).to(dev)
     torch.cuda.synchronize()
     ptrs, lens = [pool.data_ptr() + o for o in offs], [len(s) for s in streams]
-    for _ in range(2):
+    names = [f"g{i}" for i in range(n)]
+    for _ in range(PMC_CHILD_STEPS):
         ds = E.DictSet.build_device(ptrs, lens, args.k, True, ctx=ctx)
+        arr = ds.merge(names)
+        arr.apply_filters(0.9, False, E.FILTER_NO_CONST, False, False)
         ctx.sync()
+        arr.free()
         ds.free()
 
 
-def measure_traffic(args, lens, kernel_tag):
-    """roofline.traffic measured in this run: two rocprofv3 passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass, and --pmc goes with
-    --kernel-trace only) over a child process that extracts the first n samples of this workload; HBM bytes of the extraction kernel's
-    launches = FETCH_SIZE x 2 (gfx950 tallies 128-B read requests at 64 B: MI355X_MICROARCH.md) + WRITE_SIZE, both in KB, per base of
-    what the child extracted.  Returns (bytes per base, description) or (None, why not)."""
+def measure_traffic(args, lens):
+    """HBM traffic measured in this run: two rocprofv3 passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass, and --pmc goes with
+    --kernel-trace only) over a child process that runs the step on the first n samples of this workload.  Per kernel name and step: HBM
+    bytes read = FETCH_SIZE x 2 (gfx950 tallies 128-B read requests at 64 B: MI355X_MICROARCH.md) and written = WRITE_SIZE, both counted in KB.
+    Returns ({kernel name: {fetch_bytes, write_bytes, launches_per_step}}, n, bases the child processed per step) or (None, why not, 0)."""
     import csv
     import glob
     import subprocess
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
-        return None, "rocprofv3 not found"
+        return None, "rocprofv3 not found", 0
     if "ROCP_TOOL_LIBRARIES" in os.environ or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
-        return None, "this process is itself running under a profiler"
+        return None, "this process is itself running under a profiler", 0
     n = min(args.pmc_genomes or args.genomes, args.genomes)
     bases = float(sum(lens[:n]))
     out = tempfile.mkdtemp(prefix="skx_pmc_", dir="/tmp")
@@ -349,25 +436,28 @@ def measure_traffic(args, lens, kernel_tag):
             cmd = [exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(out, c), "--", sys.executable,
                    os.path.abspath(__file__), "--pmc-child", str(n), "--genomes", str(args.genomes), "--genome-len", str(args.genome_len), "-k", str(args.k)]
             try:
-                p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+                p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420)
             except subprocess.TimeoutExpired:
-                return None, f"the {c} pass did not finish in 240 s"
+                return None, f"the {c} pass did not finish in 420 s", 0
             if p.returncode != 0:
-                return None, f"the {c} pass failed (rc {p.returncode}): " + p.stdout.decode(errors="replace")[-200:].replace("\n", " | ")
-            vals = []
+                return None, f"the {c} pass failed (rc {p.returncode}): " + p.stdout.decode(errors="replace")[-200:].replace("\n", " | "), 0
+            rows = 0
             for f in glob.glob(os.path.join(out, c, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if r.get("Counter_Name") == c and kernel_tag in r.get("Kernel_Name", ""):
-                        vals.append(float(r["Counter_Value"]))
-            if not vals:
-                return None, f"no {c} rows for {kernel_tag} in the pass's output"
-            per[c] = (sum(vals) / len(vals) * 1024.0, len(vals))
+                    if r.get("Counter_Name") != c:
+                        continue
+                    e = per.setdefault(r.get("Kernel_Name", "?"), {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "n": 0})
+                    e[c] += float(r["Counter_Value"]) * 1024.0
+                    if c == "FETCH_SIZE":
+                        e["n"] += 1
+                    rows += 1
+            if not rows:
+                return None, f"no {c} rows in the pass's output", 0
     finally:
         shutil.rmtree(out, ignore_errors=True)
-    rd, wr = per["FETCH_SIZE"][0] * 2.0, per["WRITE_SIZE"][0]
-    return (rd + wr) / bases, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (one pass each, --kernel-trace only) over a child process extracting "
-                               f"{n} samples of this workload, mean of {per['FETCH_SIZE'][1]} launches of {kernel_tag}: FETCH_SIZE x2 = {rd / bases:.3f} B + WRITE_SIZE = "
-                               f"{wr / bases:.3f} B per base, scaled to this step's bases")
+    res = {k: {"fetch_bytes": v["FETCH_SIZE"] * 2.0 / PMC_CHILD_STEPS, "write_bytes": v["WRITE_SIZE"] / PMC_CHILD_STEPS, "launches_per_step": v["n"] / PMC_CHILD_STEPS}
+           for k, v in per.items()}
+    return res, n, bases
 
 
 def main():
@@ -386,6 +476,9 @@ def main():
     if not os.path.exists("/dev/kfd"):
         raise SystemExit("bench.py needs a gfx950 GPU: the engine has no CPU path")
     sharded = world > 1 or os.environ.get("SKX_BENCH_FORCE_SHARDED") == "1"     # the override runs the exchange path at world size 1
+    selftest = None
+    if world > 1 and rank == 0 and not args.no_selftest and os.environ.get("SKX_BENCH_BACKEND", "nccl") == "nccl":
+        selftest = preflight(args, world)      # (the other ranks wait in init_process_group below)
     import synth
 
     G = args.genomes
@@ -414,7 +507,7 @@ def main():
     # for them)
     e2e = None
     if want_files and not args.no_e2e:
-        e2e = end_to_end(args, files, td)
+        e2e = end_to_end(args, files, td, local_rank)
     global torch, dist
     import torch
     import torch.distributed as dist
@@ -439,6 +532,20 @@ def main():
     E.load_library()
     ctx = E.Context(local_rank)
     comm = skdist.make_comm(ctx, rank, world, transport="rccl" if backend == "nccl" else "local") if sharded else None
+    rank_report = None
+    if sharded:
+        # what the communicator says it runs on, per rank: ncclCommCount, the device RCCL bound, the context's device, the device's bus id
+        nr, rdev, cdev = comm.transport()
+        mine = {"rank": rank, "rccl_ranks": nr, "rccl_device": rdev, "ctx_device": cdev, "pci_bus_id": getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None),
+                "hip_device": torch.cuda.current_device()}
+        allr = [None] * world
+        if world > 1:
+            dist.all_gather_object(allr, mine)
+        else:
+            allr = [mine]
+        rank_report = {"rccl_ranks": nr, "devices": allr}
+        if backend == "nccl" and nr != world:
+            raise SystemExit(f"bench.py: rank {rank}: the RCCL communicator has {nr} rank(s), the job {world}")
     pool = torch.empty(tot + 256, dtype=torch.uint8, device=dev)
     for i, s in enumerate(streams):
         pool[offs[i]:offs[i] + lens[i]] = torch.from_numpy(s).to(dev, non_blocking=False)
@@ -520,10 +627,13 @@ def main():
     n_distinct = None
     distance_stage = None
     unfiltered = None
+    pieces_info, merge_path = (0, 0, 0), ctx.merge_path()
     if rank == 0 and world == 1:       # the unfiltered rows x samples matrix (what a .skf holds), produced from the merge's pieces: outside `value`
         ds = E.DictSet.build_device(ptrs, lens, args.k, True, ctx=ctx)
         arr_u = ds.merge(names)
         ctx.sync()
+        pieces_info = arr_u.pieces_info()          # (bytes of pieces, row blocks, ranks per block) while the array is still held as the append pass left it
+        merge_path = ctx.merge_path()
         ctx.timings(reset=True)
         t_u0 = time.perf_counter()
         arr_u.device_matrix()
@@ -590,10 +700,11 @@ def main():
                        "rows_U": shape[0], "rows_kept": shape[1], "parallelism": f"samples sharded x{world}" + (" (key-table all-gather path)" if sharded else "")},
             "roofline": {"bound": "hbm", "kernel": ("extract_kernel<true>" if args.k <= 31 else "extract_wide_kernel<true>") + " (split k-mer extraction + bucket scatter)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": scatter_ms},
+                         "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": scatter_ms,
+                         "largest_kernel_of_step": "extraction" if scatter_ms >= tm["append"] / steps else "append (see dominant)"},
             "kernel_pipeline": {"genomes_per_s": n_total * steps / dt, "what": "= value: extraction -> dictionaries -> merge -> filter with the record streams resident in HBM"},
             "stage_ms_per_step": {k: v / steps for k, v in tm.items()},
-            "other_kernels": other_kernels(tm, steps, total_bases, n_distinct, shape[0], shape[1], G, key_bytes),
+            "merge_path": merge_path,
             "host_wall_ms_per_step": {k: v / steps for k, v in host_ms.items()},
         }
         if distance_stage:
@@ -601,6 +712,9 @@ def main():
         if unfiltered:
             res["unfiltered_form"] = unfiltered
         if sharded:
+            res["selftest"] = selftest
+            res["rccl_ranks"] = rank_report["rccl_ranks"]
+            res["rank_devices"] = rank_report["devices"]
             ph = E.phases()
             res["exchange_per_step_rank0"] = {"transport": "rccl" if backend == "nccl" else "local (host-staged: ranks sharing a device)",
                                               "key_table_exchange_ms": xch["key_table_exchange_s"] / steps * 1e3,
@@ -610,6 +724,8 @@ def main():
                                               "what": "skx_keyset_allgather (one ncclAllGather of the per-rank key tables, then their union) + skx_array_reduce_stats "
                                                       "(one ncclAllReduce + one ncclAllGather of the per-row filter statistics), issued by the engine; nothing else crosses xGMI"}
         res["roofline"]["traffic_source"] = traffic_src
+        if world > 1:
+            res["other_kernels"] = other_kernels(tm, steps, total_bases, n_distinct, shape[0], shape[1], G, key_bytes)
         try:                                     # measurement builds (-DSKX_PHASE_PROF=n, tools/mkvariant.sh): cycle shares per phase of the instrumented kernel
             import ctypes
             buf = (ctypes.c_ulonglong * 16)()
@@ -624,13 +740,27 @@ def main():
                 last.free()
             del pool
             torch.cuda.empty_cache()
+            kernel_traffic = None
             if not args.no_pmc:
-                per_base, why = measure_traffic(args, lens, "extract_kernel<true" if args.k <= 31 else "extract_wide_kernel<true")
-                if per_base is not None:
-                    res["roofline"]["traffic"] = per_base * total_bases
-                    res["roofline"]["traffic_source"] = why
+                kt, n_pmc, bases_pmc = measure_traffic(args, lens)
+                if kt is not None:
+                    scale = total_bases / bases_pmc            # (1 when the child ran the whole workload: the default)
+                    kernel_traffic = {k: {"fetch_bytes": v["fetch_bytes"] * scale, "write_bytes": v["write_bytes"] * scale, "launches_per_step": v["launches_per_step"]} for k, v in kt.items()}
+                    ex = [v for k, v in kernel_traffic.items() if classify_kernel(k) == "extract"]
+                    if ex:
+                        res["roofline"]["traffic"] = sum(v["fetch_bytes"] + v["write_bytes"] for v in ex)
+                        res["roofline"]["traffic_source"] = (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (one pass each, --kernel-trace only) over a child process running the step on "
+                                                             f"{n_pmc} samples of this workload {PMC_CHILD_STEPS} times; per launch of the extraction kernel: FETCH_SIZE x2 = "
+                                                             f"{sum(v['fetch_bytes'] for v in ex) / total_bases:.3f} B + WRITE_SIZE = {sum(v['write_bytes'] for v in ex) / total_bases:.3f} B per base"
+                                                             + ("" if n_pmc == G else ", scaled per base to this step"))
+                    else:
+                        kernel_traffic = None
+                        res["roofline"]["traffic_source"] = (res["roofline"]["traffic_source"] or "none recorded") + " [the --pmc passes of this run held no row of the extraction kernel]"
                 else:
-                    res["roofline"]["traffic_source"] = (res["roofline"]["traffic_source"] or "none recorded") + f" [the --pmc passes of this run gave nothing: {why}]"
+                    res["roofline"]["traffic_source"] = (res["roofline"]["traffic_source"] or "none recorded") + f" [the --pmc passes of this run gave nothing: {n_pmc}]"
+            res["traffic_by_kernel"] = None if kernel_traffic is None else {k: v for k, v in sorted(kernel_traffic.items(), key=lambda kv: -(kv[1]["fetch_bytes"] + kv[1]["write_bytes"]))[:12]}
+            fill_dominant(res, tm, steps, total_bases, shape, G, key_bytes, pieces_info, kernel_traffic, n_pmc if kernel_traffic else 0)
+            res["other_kernels"] = other_kernels(tm, steps, total_bases, n_distinct, shape[0], shape[1], G, key_bytes, pieces_info[0], kernel_traffic)
             try:
                 if e2e is not None:
                     res["end_to_end"] = e2e

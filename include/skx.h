@@ -156,6 +156,10 @@ const char *skx_array_version(const skx_array *a);
 int  skx_array_export(skx_array *a, skx_key *keys, uint8_t *variants, uint64_t *counts);
 /* n_sample_kmers (merge_ska_array.rs:554-559) */
 int  skx_array_sample_kmers(skx_array *a, int64_t *out);
+/* an array still held as the append pass left it (pieces of 4-bit base sets by first-seen rank: csrc/skx_append.hip): bytes of pieces written,
+ * row blocks, ranks per block; *piece_bytes = 0 when the array holds a matrix instead.  No counterpart in the reference (its merged dictionary
+ * holds a Vec<u8> per row, merge_ska_dict.rs:41-58); bench.py prices the append kernel's needed traffic with it. */
+int  skx_array_pieces_info(skx_array *a, uint64_t *piece_bytes, uint64_t *row_blocks, uint32_t *ranks_per_block);
 /* MergeSkaArray::filter (merge_ska_array.rs:289-402); *removed = its i32 return value */
 int  skx_array_filter(skx_array *a, uint64_t min_count, int filter_ambig_as_missing, int filter_type,
                       int mask_ambig, int ignore_const_gaps, int update_kmers, int32_t *removed);
@@ -217,6 +221,10 @@ void skx_comm_destroy(skx_comm *c);
 int  skx_comm_rank(const skx_comm *c);
 int  skx_comm_world(const skx_comm *c);
 uint64_t skx_comm_bytes_received(const skx_comm *c);                           /* payload this rank has received so far (reports) */
+/* what the communicator runs on: *rccl_ranks = ncclCommCount of the RCCL communicator (0: the host-staged transport), *rccl_device = the
+ * device RCCL bound it to (ncclCommCuDevice; -1: none), *ctx_device = the engine context's device.  A report for a job's first contact with
+ * a node (bench.py prints them per rank); stands where merge_ska_dict.rs:354-417 logs its thread count. */
+int  skx_comm_transport(const skx_comm *c, int *rccl_ranks, int *rccl_device, int *ctx_device);
 int  skx_comm_barrier(skx_comm *c);
 /* the two primitives the exchanges are made of, for hosts with exchanges of their own: `bytes` from every rank, rank r's at
  * recv + r * bytes (recv must not overlap send); in-place sum of n 32-bit counters.  on_device: the pointers are device memory
@@ -282,8 +290,10 @@ void skx_set_last_error(const char *msg);
 int  skx_phases_json(char **buf, uint64_t *len, int reset);
 void skx_phase_add(const char *name, double seconds);
 
-/* per-stage device timings of the last call on this ctx (ms; HIP events on the ctx stream) */
-typedef struct { double hist, scatter, dedupe, key_union, assemble, filter, compact, distance; } skx_timings;
+/* per-stage device timings of the last call on this ctx (ms; HIP events on the ctx stream).  The last four are single kernels of the
+ * append pass, measured inside their stages (probe + append inside key_union, pieces_stats inside assemble, the kept rows' pieces_rows
+ * inside compact): what bench.py's `roofline.dominant` is computed from. */
+typedef struct { double hist, scatter, dedupe, key_union, assemble, filter, compact, distance, append_probe, append, pieces_stats, pieces_rows; } skx_timings;
 int  skx_ctx_timings(skx_ctx *ctx, skx_timings *t, int reset);
 /* which kernels the last merge on this context went through: "append64" / "append128" (MergeSkaDict::append in one pass over the
  * unsorted regions, merge_ska_dict.rs:77-109, for u64 / u128 keys) or "sorted: <why the pass was not taken>" (per-sample sort +

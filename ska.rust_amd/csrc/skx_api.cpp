@@ -227,7 +227,8 @@ extern "C" int skx_ctx_create(int device, skx_ctx **out)
     skx_ctx *c = new skx_ctx();
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&c->ev[0]) != hipSuccess || hipEventCreate(&c->ev[1]) != hipSuccess) {
+        hipEventCreate(&c->ev[0]) != hipSuccess || hipEventCreate(&c->ev[1]) != hipSuccess || hipEventCreate(&c->ev[2]) != hipSuccess ||
+        hipEventCreate(&c->ev[3]) != hipSuccess) {
         delete c; set_error("cannot create HIP stream/events"); return SKX_ENODEV;
     }
     *out = c;
@@ -264,6 +265,17 @@ struct StageTimer {        // HIP-event bracket around one stage on the ctx stre
         (void)hipEventRecord(c->ev[1], c->stream);
         (void)hipEventSynchronize(c->ev[1]);
         float ms = 0; if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) *slot += ms;
+    }
+};
+struct KernelTimer {       // the same around one kernel inside a stage (its own pair of events)
+    skx_ctx *c; double *slot;
+    KernelTimer(skx_ctx *c_, double *s) : c(c_), slot(s) { if (c->timing) (void)hipEventRecord(c->ev[2], c->stream); }
+    ~KernelTimer()
+    {
+        if (!c->timing) return;
+        (void)hipEventRecord(c->ev[3], c->stream);
+        (void)hipEventSynchronize(c->ev[3]);
+        float ms = 0; if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) *slot += ms;
     }
 };
 int ilog2_ceil(uint64_t x) { int l = 0; while ((1ull << l) < x) l++; return l; }
@@ -1747,7 +1759,7 @@ static int append_pass(skx_ctx *ctx, skx_dictset *d, std::unique_ptr<skx_keyset>
             aa.logQ = logP; aa.nslots = max_slots; aa.cap = max_cap; aa.rounds = 1; aa.bar = nullptr;
             if (!pass_ok(logP, aa.nslots, aa.cap)) return not_taken("no probe split with room for a rank in a table entry (very short or very long hash)");
             SKX_TRY(d_flag.zero(st)); SKX_TRY(d_probe.zero(st));
-            if (wide) launch_append_wide_probe(aa, blocks, st); else launch_append_probe(aa, region_cap, blocks, st);
+            { KernelTimer kt(ctx, &ctx->tm.append_probe); if (wide) launch_append_wide_probe(aa, blocks, st); else launch_append_probe(aa, region_cap, blocks, st); }
             unsigned long long pr[2] = {0, 0}; int ov = 0;
             SKX_HIP(hipMemcpyAsync(pr, d_probe.p, 16, hipMemcpyDeviceToHost, st));
             SKX_HIP(hipMemcpyAsync(&ov, d_flag.p, 4, hipMemcpyDeviceToHost, st));
@@ -1792,7 +1804,7 @@ static int append_pass(skx_ctx *ctx, skx_dictset *d, std::unique_ptr<skx_keyset>
         }
         aa.pieces = pc->data.p; aa.plen = pc->plen.p; aa.perm = pc->perm.p; aa.nrank = pc->nrank.p;
         aa.stage = ks->stage.p; aa.stride = cap; aa.ncnt = ks->ncnt.p;
-        if (wide) launch_append_wide(aa, st); else launch_append(aa, region_cap, st);
+        { KernelTimer kt(ctx, &ctx->tm.append); if (wide) launch_append_wide(aa, st); else launch_append(aa, region_cap, st); }
         int ov = 0;
         SKX_HIP(hipMemcpyAsync(&ov, d_flag.p, 4, hipMemcpyDeviceToHost, st));
         SKX_HIP(hipStreamSynchronize(st));
@@ -1844,6 +1856,7 @@ static int array_over_pieces(skx_ctx *ctx, const skx_dictset *d, skx_keyset *ks,
         if (g) { SKX_TRY(a->present.zero(st)); SKX_TRY(a->unambig.zero(st)); SKX_TRY(a->mask.zero(st)); SKX_TRY(a->vcount.zero(st)); }
         // the rows' statistics, counted from the pieces
         StageTimer t(ctx, &ctx->tm.assemble);
+        KernelTimer kt(ctx, &ctx->tm.pieces_stats);
         launch_pieces_stats(pc->data.p, pc->plen.p, pc->perm.p, pc->nrank.p, blk->ncnt.p, blk->roff.p, pc->cap, S, 1 << logQ, a->present.p, a->unambig.p, a->mask.p, a->vcount.p, st);
     }
     SKX_HIP(hipStreamSynchronize(st));
@@ -2155,6 +2168,30 @@ extern "C" int skx_array_sample_kmers(skx_array *a, int64_t *out)
     });
 }
 
+extern "C" int skx_array_pieces_info(skx_array *a, uint64_t *piece_bytes, uint64_t *row_blocks, uint32_t *ranks_per_block)
+{
+    return skx_guarded([&]() -> int {
+    if (!a) { set_error("bad arguments"); return SKX_EINVAL; }
+    if (piece_bytes) *piece_bytes = 0;
+    if (row_blocks) *row_blocks = 0;
+    if (ranks_per_block) *ranks_per_block = 0;
+    const skx_pieces *pc = a->pieces;
+    if (!pc) return SKX_OK;
+    skx_ctx *ctx = a->ctx; hipStream_t st = ctx->stream;
+    SKX_HIP(hipSetDevice(ctx->device));
+    const uint64_t n = ((uint64_t)1 << pc->logQ) * a->names.size();
+    std::vector<uint16_t> h(n);
+    SKX_HIP(hipMemcpyAsync(h.data(), pc->plen.p, n * 2, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipStreamSynchronize(st));
+    uint64_t b = 0;
+    for (uint16_t v : h) b += ((uint64_t)v + 31) / 32 * 16;           // append_kernel stores a piece 16 bytes (32 ranks) at a time
+    if (piece_bytes) *piece_bytes = b;
+    if (row_blocks) *row_blocks = (uint64_t)1 << pc->logQ;
+    if (ranks_per_block) *ranks_per_block = pc->cap;
+    return SKX_OK;
+    });
+}
+
 // shared tail of filter / weed / delete_samples: rows with keep == 1 survive (pos = exclusive scan of keep)
 static int array_compact(skx_array *a, DevBuf<uint8_t> &keep, DevBuf<uint64_t> &pos, uint64_t kept, int mask_ambig, bool vcount_from_unambig,
                          bool keys_follow)
@@ -2176,6 +2213,7 @@ static int array_compact(skx_array *a, DevBuf<uint8_t> &keep, DevBuf<uint64_t> &
             // the kept rows straight from the pieces: the unfiltered rows x samples matrix is never written
             PiecesRowsArgs pa = pieces_args(a);
             pa.out = nm.p; pa.pitch = np; pa.keep = keep.p; pa.kpos = pos.p; pa.mask_ambig = mask_ambig;
+            KernelTimer kt(ctx, &ctx->tm.pieces_rows);
             launch_pieces_rows(pa, 1u << a->pieces->logQ, st);
         } else if (a->lazy()) {
             // the kept rows are assembled straight from the dictionaries: the unfiltered matrix is never written

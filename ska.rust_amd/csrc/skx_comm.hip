@@ -40,6 +40,8 @@ struct Rccl {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;             // (optional: skx_comm_transport, reports)
+    decltype(&ncclCommCuDevice) CommCuDevice = nullptr;
 };
 Rccl *rccl()
 {
@@ -61,7 +63,7 @@ Rccl *rccl()
         if (!r.lib) return;
 #define SKX_SYM(f) r.f = (decltype(r.f))dlsym(r.lib, "nccl" #f)
         SKX_SYM(GetUniqueId); SKX_SYM(CommInitRank); SKX_SYM(CommDestroy); SKX_SYM(AllGather); SKX_SYM(AllReduce); SKX_SYM(Send); SKX_SYM(Recv);
-        SKX_SYM(GroupStart); SKX_SYM(GroupEnd); SKX_SYM(GetErrorString);
+        SKX_SYM(GroupStart); SKX_SYM(GroupEnd); SKX_SYM(GetErrorString); SKX_SYM(CommCount); SKX_SYM(CommCuDevice);
 #undef SKX_SYM
         if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.AllReduce || !r.Send || !r.Recv || !r.GroupStart || !r.GroupEnd) r.lib = nullptr;
     });
@@ -315,6 +317,20 @@ extern "C" void skx_comm_destroy(skx_comm *c)
 extern "C" int skx_comm_rank(const skx_comm *c) { return c ? c->rank : 0; }
 extern "C" int skx_comm_world(const skx_comm *c) { return c ? c->world : 1; }
 extern "C" uint64_t skx_comm_bytes_received(const skx_comm *c) { return c ? c->bytes_moved : 0; }
+extern "C" int skx_comm_transport(const skx_comm *c, int *rccl_ranks, int *rccl_device, int *ctx_device)
+{
+    return skx_guarded([&]() -> int {
+    SKX_TRY(check(c));
+    if (rccl_ranks) *rccl_ranks = 0;
+    if (rccl_device) *rccl_device = -1;
+    if (ctx_device) *ctx_device = c->ctx ? c->ctx->device : -1;
+    if (c->local()) return SKX_OK;
+    Rccl *r = rccl();
+    if (r && r->CommCount && rccl_ranks) SKX_NCCL(r->CommCount(c->nccl, rccl_ranks));
+    if (r && r->CommCuDevice && rccl_device) SKX_NCCL(r->CommCuDevice(c->nccl, rccl_device));
+    return SKX_OK;
+    });
+}
 extern "C" int skx_comm_barrier(skx_comm *c)
 {
     return skx_guarded([&]() -> int { SKX_TRY(check(c)); if (c->ctx) SKX_HIP(hipSetDevice(c->ctx->device)); return comm_barrier(c); });

@@ -83,7 +83,7 @@ struct skx_ctx {
     int expect_fd = -1;              // skx_ctx_expect_output: where the next alignment goes (pages allocated while its rows are read)
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};      // [0..1] a stage, [2..3] one kernel inside it
     skx_timings tm{};
     bool timing = true;
     std::string merge_path;          // which kernels the last merge on this context went through, and why (skx_ctx_merge_path)

@@ -41,7 +41,8 @@ class ArrayInfo(C.Structure):
 
 
 class Timings(C.Structure):
-    _fields_ = [(n, C.c_double) for n in ("hist", "scatter", "dedupe", "key_union", "assemble", "filter", "compact", "distance")]
+    _fields_ = [(n, C.c_double) for n in ("hist", "scatter", "dedupe", "key_union", "assemble", "filter", "compact", "distance",
+                                                 "append_probe", "append", "pieces_stats", "pieces_rows")]
 
 
 class Job(C.Structure):
@@ -64,10 +65,10 @@ SYMBOLS = """skx_last_error skx_version skx_ctx_create skx_ctx_destroy skx_ctx_s
 skx_dictset_build_files skx_dictset_free skx_dictset_nsamples skx_dictset_key_bits skx_dictset_size skx_dictset_export
 skx_keyset_union skx_keyset_union_notes skx_keyset_size skx_keyset_device skx_keyset_from_device skx_keyset_merge skx_keyset_free
 skx_array_assemble skx_array_assemble_lazy skx_merge skx_build_and_merge skx_array_free skx_array_save skx_array_load skx_array_from_host
-skx_array_info skx_array_name skx_array_version skx_array_export skx_array_sample_kmers skx_array_filter
+skx_array_info skx_array_name skx_array_version skx_array_export skx_array_sample_kmers skx_array_pieces_info skx_array_filter
 skx_array_write_fasta skx_array_fasta skx_array_device_matrix skx_array_device_stats skx_array_set_total_samples skx_array_distance skx_free skx_ctx_timings skx_ctx_merge_path
 skx_array_merge skx_array_delete_samples skx_array_weed skx_keyset_from_fasta skx_array_ctx skx_set_last_error skx_array_map skx_cov_histogram skx_phases_json skx_phase_add skx_array_load_filtered skx_ctx_expect_output skx_array_distance_planes skx_planes_distance skx_array_distance_filtered
-skx_comm_unique_id skx_comm_create skx_comm_create_local skx_comm_destroy skx_comm_rank skx_comm_world skx_comm_bytes_received skx_comm_barrier
+skx_comm_unique_id skx_comm_create skx_comm_create_local skx_comm_destroy skx_comm_rank skx_comm_world skx_comm_bytes_received skx_comm_transport skx_comm_barrier
 skx_comm_allgather skx_comm_allreduce_u32 skx_comm_gather_root skx_shard_range skx_pair_bands skx_keyset_allgather skx_array_reduce_stats skx_array_distance_sharded
 skh_build_sharded skh_align_sharded skh_distance_sharded
 skh_apply_filters skh_align skh_align_fd skh_distance_tsv skh_nk skh_save_skf skh_load_array skh_sample_name skh_main skh_merge skh_delete skh_weed skh_cov skh_cov_fit skh_align_inputs_fd skh_distance_skf_tsv""".split()
@@ -125,6 +126,7 @@ def load_library():
     lib.skx_array_version.restype = cp
     lib.skx_array_export.argtypes = [vp, vp, vp, vp]
     lib.skx_array_sample_kmers.argtypes = [vp, vp]
+    lib.skx_array_pieces_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_uint32)]
     lib.skx_array_filter.argtypes = [vp, u64, i, i, i, i, i, C.POINTER(C.c_int32)]
     lib.skx_array_write_fasta.argtypes = [vp, i]
     lib.skx_array_fasta.argtypes = [vp, pp, C.POINTER(u64)]
@@ -174,6 +176,7 @@ def load_library():
     lib.skx_comm_world.argtypes = [vp]
     lib.skx_comm_bytes_received.argtypes = [vp]
     lib.skx_comm_bytes_received.restype = u64
+    lib.skx_comm_transport.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     lib.skx_comm_barrier.argtypes = [vp]
     lib.skx_comm_allgather.argtypes = [vp, vp, vp, u64, i]
     lib.skx_comm_allreduce_u32.argtypes = [vp, vp, u64, i]
@@ -360,6 +363,12 @@ class Comm:
     rank = property(lambda self: _lib.skx_comm_rank(self.h))
     world = property(lambda self: _lib.skx_comm_world(self.h))
     bytes_received = property(lambda self: int(_lib.skx_comm_bytes_received(self.h)))
+
+    def transport(self):
+        """(ranks of the RCCL communicator -- 0 for the host-staged transport --, the device RCCL bound it to, the context's device)"""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        _check(_lib.skx_comm_transport(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def barrier(self):
         _check(_lib.skx_comm_barrier(self.h))
@@ -719,6 +728,12 @@ class Array:
         out = np.zeros(self.nsamples, np.int64)
         _check(_lib.skx_array_sample_kmers(self.h, _np_ptr(out)))
         return out
+
+    def pieces_info(self):
+        """(bytes of pieces, row blocks, ranks per block) of an array still held as the append pass left it; (0, 0, 0) otherwise"""
+        b, j, c = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        _check(_lib.skx_array_pieces_info(self.h, C.byref(b), C.byref(j), C.byref(c)))
+        return b.value, j.value, c.value
 
     def filter(self, min_count, filter_ambig_as_missing=False, filter_type=FILTER_NO_CONST, mask_ambig=False,
                ignore_const_gaps=False, update_kmers=True):

@@ -227,3 +227,60 @@ def test_ranks_with_unrelated_samples_equal_single_process(tmp_path):
         assert r.returncode == 0, r.stderr[-800:]
         _ska_ranks(3, cmd, "-f", lst, "-o", f"multi.{out}", "-k", "31", *extra, cwd=wd)
         assert open(os.path.join(wd, f"multi.{out}"), "rb").read() == open(os.path.join(wd, f"one.{out}"), "rb").read(), cmd
+
+
+def _n_devices():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.skipif(_n_devices() < 2, reason="needs two GPUs: the RCCL transport at world 2 (skipped on the one-GPU test box, runs wherever two devices exist)")
+def test_rccl_world_two_equals_single_process(tmp_path):
+    """First contact with a second device should not be a scaling run: `ska selftest --gpus 2`, then skx_keyset_allgather (ncclAllGather of
+    padded key tables from two devices), skx_array_reduce_stats (ncclAllReduce + ncclAllGather) and skx_array_distance_sharded (plane
+    all-gather, grouped ncclSend / ncclRecv to rank 0) through `ska align | distance | build --gpus 2` over RCCL -- byte-identical to the
+    single process.  Stands where merge_ska_dict.rs:354-417 joins its worker threads."""
+    files, lst = _inputs(tmp_path, n=13, length=150_000, seed=41)
+    wd = str(tmp_path)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("SKX_COMM") and k != "SKX_DEVICE"}
+    r = subprocess.run([SKA, "selftest", "--gpus", "2"], cwd=wd, capture_output=True, env=env, timeout=300)
+    assert r.returncode == 0 and b": ok" in r.stderr, r.stderr[-1500:].decode(errors="replace")
+    assert subprocess.run([SKA, "build", "-f", lst, "-o", "one", "--threads", "4"], cwd=wd, capture_output=True, timeout=300).returncode == 0
+    assert subprocess.run([SKA, "align", "one.skf", "-o", "one.aln"], cwd=wd, capture_output=True, timeout=300).returncode == 0
+    for flags, tag in (([], "d0"), (["--allow-ambiguous"], "d2")):
+        assert subprocess.run([SKA, "distance", "one.skf", "-o", f"one.{tag}", *flags], cwd=wd, capture_output=True, timeout=300).returncode == 0
+    r = subprocess.run([SKA, "align", "--gpus", "2", "-f", lst, "-o", "two.aln", "--threads", "2"], cwd=wd, capture_output=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:].decode(errors="replace")
+    assert open(os.path.join(wd, "two.aln"), "rb").read() == open(os.path.join(wd, "one.aln"), "rb").read()
+    for flags, tag in (([], "d0"), (["--allow-ambiguous"], "d2")):
+        r = subprocess.run([SKA, "distance", "--gpus", "2", "-f", lst, "-o", f"two.{tag}", *flags], cwd=wd, capture_output=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:].decode(errors="replace")
+        assert open(os.path.join(wd, f"two.{tag}"), "rb").read() == open(os.path.join(wd, f"one.{tag}"), "rb").read(), tag
+    r = subprocess.run([SKA, "build", "--gpus", "2", "-f", lst, "-o", "parts", "--threads", "2", "--merge"], cwd=wd, capture_output=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:].decode(errors="replace")
+    r1 = subprocess.run([SKA, "nk", "parts.skf", "--full-info"], cwd=wd, capture_output=True, timeout=300)
+    r2 = subprocess.run([SKA, "nk", "one.skf", "--full-info"], cwd=wd, capture_output=True, timeout=300)
+    assert r1.returncode == 0 and r1.stdout == r2.stdout
+
+
+@pytest.mark.skipif(_n_devices() < 2, reason="needs two GPUs")
+def test_bench_two_gpus_over_rccl_reports_its_ranks(tmp_path):
+    """bench.py --gpus 2 as the driver launches it: the selftest pre-flight ran, the line reports the RCCL communicator's own rank count and a
+    device per rank, and the sharded row set is the single-rank one"""
+    import json
+    bench = os.path.join(ROOT, "bench.py")
+    common = ["--genomes", "24", "--genome-len", "300000", "--steps", "2", "--warmup", "1", "--cpu-genomes", "0", "--no-e2e", "--no-pmc"]
+    env = {k: v for k, v in os.environ.items() if not k.startswith("SKX_") and k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(29700 + os.getpid() % 200), bench, "--gpus", "2", *common]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    two = json.loads([x for x in r.stdout.strip().splitlines() if x.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and two["rccl_ranks"] == 2 and two["selftest"] and ": ok" in two["selftest"]["report"]
+    assert sorted(d["hip_device"] for d in two["rank_devices"]) == [0, 1]
+    r = subprocess.run([sys.executable, bench, "--gpus", "1", *common[:1], "48", *common[2:]], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    one = json.loads([x for x in r.stdout.strip().splitlines() if x.startswith("{")][-1])
+    assert two["config"]["rows_U"] == one["config"]["rows_U"]
