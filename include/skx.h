@@ -215,7 +215,8 @@ typedef struct skx_comm skx_comm;
 #define SKX_COMM_ID_BYTES 128
 int  skx_comm_unique_id(uint8_t id[SKX_COMM_ID_BYTES]);                        /* ncclGetUniqueId; rank 0 only */
 int  skx_comm_create(skx_ctx *ctx, int rank, int world, const uint8_t id[SKX_COMM_ID_BYTES], skx_comm **out);   /* ncclCommInitRank on ctx's device */
-/* host-staged transport: `dir` is a fresh directory every rank can reach; ctx may be NULL when only host buffers are exchanged */
+/* host-staged transport: `dir` is a fresh directory every rank can reach (NULL at world 1: the library makes its own and removes it with the
+ * communicator); ctx may be NULL when only host buffers are exchanged */
 int  skx_comm_create_local(skx_ctx *ctx, int rank, int world, const char *dir, skx_comm **out);
 void skx_comm_destroy(skx_comm *c);
 int  skx_comm_rank(const skx_comm *c);

@@ -433,7 +433,7 @@ static void pack_qual_plain(const uint8_t *q, size_t n, int min_qual, uint64_t *
         qb[w] = v;
     }
 }
-// 2 = AVX-512 (F + BW), 1 = AVX2, 0 = neither; SKX_KNOBS=simd=<n> caps it (tests run all three)
+// 2 = AVX-512 (F + BW), 1 = AVX2, 0 = neither; SKX_KNOBS=simd_cap=<n> caps it at level n - 1 (tests run all three)
 static int simd_level()
 {
     static const int v = [] {

@@ -245,6 +245,7 @@ extern "C" void skx_ctx_destroy(skx_ctx *c)
 }
 extern "C" int skx_ctx_sync(skx_ctx *c) { SKX_HIP(hipSetDevice(c->device)); SKX_HIP(hipStreamSynchronize(c->stream)); return SKX_OK; }
 extern "C" void *skx_ctx_stream(skx_ctx *c) { return (void *)c->stream; }
+uint64_t skx::next_object_id() { static std::atomic<uint64_t> n{0}; return ++n; }
 extern "C" const char *skx_ctx_merge_path(skx_ctx *c) { return c ? c->merge_path.c_str() : ""; }
 extern "C" int skx_ctx_timings(skx_ctx *c, skx_timings *t, int reset)
 {
@@ -1343,7 +1344,7 @@ static int keyset_union_dict(skx_ctx *ctx, skx_dictset *d, skx_keyset **out, boo
         // (128-bit keys: the exchange composes 64-bit rows only -- skx_comm.hip -- so a sharded job's ranks sort their dictionaries)
         std::unique_ptr<skx_keyset> ks; std::unique_ptr<skx_pieces> pc;
         const int r = append_pass(ctx, d, ks, pc);
-        if (r == SKX_OK) { ks->pieces = pc.release(); ks->pieces_of = d; *out = ks.release(); return SKX_OK; }
+        if (r == SKX_OK) { ks->pieces = pc.release(); ks->pieces_of = d; ks->pieces_of_id = d->id; *out = ks.release(); return SKX_OK; }
         if (r != SKF_NOT_TAKEN) return r;
     }
     if (!d->sorted && d->wide() && with_side) ctx->merge_path = "sorted: the key-table exchange of a sharded job composes 64-bit rows only";
@@ -1485,7 +1486,7 @@ extern "C" int skx_array_assemble(skx_ctx *ctx, skx_dictset *d, skx_keyset *rows
     if (d->n > 65535) { set_error("more than 65535 samples per device array"); return SKX_EUNSUP; }
     SKX_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    if (rows->pieces && rows->pieces_of == d && rows->logN >= 0) {
+    if (rows->holds_pieces_of(d) && rows->logN >= 0) {
         // the rows came from an append pass over these samples (skx_keyset_union_notes), directly or through the key-table exchange of a sharded
         // job: the cells are there already, as pieces
         const bool global = rows->g_perm.p != nullptr;
@@ -1614,7 +1615,7 @@ extern "C" int skx_array_assemble_lazy(skx_ctx *ctx, skx_dictset *d, skx_keyset 
 {
     return skx_guarded([&]() -> int {
     if (!ctx || !d || !rows || !out) { skx_dictset_free(d); skx_keyset_free(rows); set_error("bad arguments"); return SKX_EINVAL; }
-    if (rows->pieces && rows->pieces_of == d) {                        // (an append pass's rows: the array over its pieces is the lazy form)
+    if (rows->holds_pieces_of(d)) {                                    // (an append pass's rows: the array over its pieces is the lazy form)
         const int r = skx_array_assemble(ctx, d, rows, names, out);
         skx_dictset_free(d); skx_keyset_free(rows);
         return r;
@@ -1841,8 +1842,12 @@ static int array_over_pieces(skx_ctx *ctx, const skx_dictset *d, skx_keyset *ks,
         g->g_base.release();
         blk->total = U; blk->max_rows = g->g_max;
     } else {
+        // (copied, not taken: the caller's key set stays whole -- skx_keyset_allgather, keyset_flatten or a second assemble may follow)
         U = ks->total;
-        blk->ncnt = std::move(ks->ncnt); blk->roff = std::move(ks->roff); blk->total = U; blk->max_rows = ks->max_rows;
+        SKX_TRY(blk->ncnt.alloc(nsub)); SKX_TRY(blk->roff.alloc(nsub + 1));
+        SKX_HIP(hipMemcpyAsync(blk->ncnt.p, ks->ncnt.p, nsub * 4, hipMemcpyDeviceToDevice, st));
+        SKX_HIP(hipMemcpyAsync(blk->roff.p, ks->roff.p, (nsub + 1) * 8, hipMemcpyDeviceToDevice, st));
+        blk->total = U; blk->max_rows = ks->max_rows;
     }
     std::unique_ptr<skx_array> a(new skx_array());
     a->ctx = ctx; a->k = d->k; a->rc = d->rc; a->k_bits = d->key_bits; a->hp = d->hp; a->wh = d->wh; a->version = skx_version();

@@ -86,6 +86,7 @@ struct skx_comm {
     int rank = 0, world = 1;
     ncclComm_t nccl = nullptr;       // RCCL transport
     std::string dir;                 // host-staged transport
+    bool own_dir = false;            // a single rank's private directory (created here, removed with the communicator)
     LocalCtrl *ctrl = nullptr;
     uint64_t seq = 0;
     double timeout_s = 600.0;
@@ -289,9 +290,15 @@ extern "C" int skx_comm_create(skx_ctx *ctx, int rank, int world, const uint8_t 
 extern "C" int skx_comm_create_local(skx_ctx *ctx, int rank, int world, const char *dir, skx_comm **out)
 {
     return skx_guarded([&]() -> int {
-    if (!dir || !out || world < 1 || rank < 0 || rank >= world) { set_error("bad arguments"); return SKX_EINVAL; }
+    if ((!dir && world != 1) || !out || world < 1 || rank < 0 || rank >= world) { set_error("bad arguments"); return SKX_EINVAL; }
     std::unique_ptr<skx_comm> c(new skx_comm());
-    c->ctx = ctx; c->rank = rank; c->world = world; c->dir = dir;
+    c->ctx = ctx; c->rank = rank; c->world = world;
+    if (dir) c->dir = dir;
+    else {                                                         // a single rank exchanges with nobody: a directory of its own, gone with the communicator
+        char tmpl[] = "/tmp/skx_one_rank_XXXXXX";
+        if (!mkdtemp(tmpl)) { set_error("cannot create a directory for the single rank's communicator: %s", strerror(errno)); return SKX_EIO; }
+        c->dir = tmpl; c->own_dir = true;
+    }
     if (const char *t = getenv("SKX_COMM_TIMEOUT_S")) c->timeout_s = atof(t) > 0 ? atof(t) : c->timeout_s;
     const std::string path = c->dir + "/ctrl";
     int fd = open(path.c_str(), O_RDWR | O_CREAT, 0600);          // every rank creates-or-opens; a fresh page of zeros is the initial state
@@ -312,6 +319,7 @@ extern "C" void skx_comm_destroy(skx_comm *c)
     if (!c) return;
     if (c->nccl) { if (c->ctx) { (void)hipSetDevice(c->ctx->device); (void)hipStreamSynchronize(c->ctx->stream); } (void)rccl()->CommDestroy(c->nccl); }
     if (c->ctrl) munmap(c->ctrl, 4096);
+    if (c->own_dir) { unlink((c->dir + "/ctrl").c_str()); rmdir(c->dir.c_str()); }
     delete c;
 }
 extern "C" int skx_comm_rank(const skx_comm *c) { return c ? c->rank : 0; }
@@ -459,7 +467,7 @@ extern "C" int skx_keyset_allgather(skx_comm *c, skx_keyset *local, skx_keyset *
         SKX_HIP(hipStreamSynchronize(st));
         SKX_HIP(hipGetLastError());
         if (!bad && gmax > 0 && local->pieces) {
-            g->pieces = local->pieces; g->pieces_of = local->pieces_of; local->pieces = nullptr; local->pieces_of = nullptr;
+            g->pieces = local->pieces; g->pieces_of = local->pieces_of; g->pieces_of_id = local->pieces_of_id; local->pieces = nullptr; local->pieces_of = nullptr;
             g->l_logN = local->logN; g->l_stride = local->stride; g->g_max = gmax;
         } else if (!bad && gmax > 0) {
             g->side = std::move(local->side); g->side_of = local->side_of; local->side_of = nullptr;

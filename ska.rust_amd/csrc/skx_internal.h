@@ -89,7 +89,9 @@ struct skx_ctx {
     std::string merge_path;          // which kernels the last merge on this context went through, and why (skx_ctx_merge_path)
 };
 
+namespace skx { uint64_t next_object_id(); }
 struct skx_dictset {
+    const uint64_t id = skx::next_object_id();   // what a key set's pieces / notes are matched to their dictset by (an address can be reused)
     skx_ctx *ctx = nullptr;
     int n = 0, k = 0, rc = 0, logB = 0, key_bits = 64;
     skx::HashParams hp{};
@@ -147,7 +149,8 @@ struct skx_keyset {
     skx::DevBuf<uint64_t> g_base;    // [1 << l_logN]
     int l_logN = -1; uint32_t l_stride = 0, g_max = 0;
     // or the pieces of an append pass over `pieces_of` (skx_keyset_union_notes on assemblies kept as extracted): they travel like the notes
-    skx_pieces *pieces = nullptr; const skx_dictset *pieces_of = nullptr;
+    skx_pieces *pieces = nullptr; const skx_dictset *pieces_of = nullptr; uint64_t pieces_of_id = 0;
+    bool holds_pieces_of(const skx_dictset *d) const { return pieces && pieces_of == d && d && pieces_of_id == d->id; }
     skx_keyset() = default;
     skx_keyset(const skx_keyset &) = delete; skx_keyset &operator=(const skx_keyset &) = delete;
     ~skx_keyset() { delete pieces; }

@@ -463,11 +463,12 @@ int sharded_array(skx_ctx *ctx, skx_comm *comm, const skh_job *job, uint64_t *lo
     if (!ctx || !comm || !job || job->n_samples <= 0) { skx_set_error("bad arguments"); return SKX_EINVAL; }
     const int rank = skx_comm_rank(comm), world = skx_comm_world(comm);
     uint64_t lo = 0, hi = 0;
+    // (a rank that cannot start -- no share of the samples -- goes through the status agreement below like one whose build failed: its
+    // peers must not be left waiting in the all-reduce)
     int r = skx_shard_range((uint64_t)job->n_samples, rank, world, &lo, &hi);
-    if (r != SKX_OK) return r;
-    if (hi <= lo) { skx_set_error("rank %d: no samples (fewer samples than ranks)", rank); return SKX_EINVAL; }
+    if (r == SKX_OK && hi <= lo) { skx_set_error("rank %d: no samples (fewer samples than ranks)", rank); r = SKX_EINVAL; }
     skx_dictset *ds = nullptr; skx_keyset *ks = nullptr, *rows = nullptr;
-    {
+    if (r == SKX_OK) {
         Phase p("sharded.dictionaries");
         std::vector<const char *> f2(hi - lo, nullptr);
         if (job->file2) for (uint64_t i = lo; i < hi; i++) f2[i - lo] = job->file2[i];
@@ -659,11 +660,7 @@ int open_comm(skx_ctx *ctx, int rank, int world, skx_comm **out)
     if (const char *d = getenv("SKX_COMM_DIR")) return skx_comm_create_local(ctx, rank, world, d, out);
     uint8_t id[SKX_COMM_ID_BYTES];
     const char *idf = getenv("SKX_COMM_ID_FILE");
-    if (world == 1 && !idf) {                                                           // a single rank exchanges with nobody: no RCCL needed
-        char dir[] = "/tmp/skx_one_rank_XXXXXX";
-        if (!mkdtemp(dir)) { skx_set_last_error("cannot create a directory for the single rank's communicator"); return SKX_EIO; }
-        return skx_comm_create_local(ctx, 0, 1, dir, out);
-    }
+    if (world == 1 && !idf) return skx_comm_create_local(ctx, 0, 1, nullptr, out);      // a single rank exchanges with nobody: no RCCL needed (the library's own directory, removed with the communicator)
     if (world > 1 && !idf) { skx_set_error("SKX_WORLD > 1 needs SKX_COMM_ID_FILE (where rank 0 leaves the RCCL id) or SKX_COMM_DIR"); return SKX_EINVAL; }
     if (rank == 0) {
         int r = skx_comm_unique_id(id);

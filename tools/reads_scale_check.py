@@ -77,12 +77,9 @@ for mb in os.environ.get("RSC_BATCH_MB", "").split():
     print("  phases", open(os.path.join(td, "ph3.json")).read()[:600])
     same = open(os.path.join(td, "one.skf"), "rb").read() == open(os.path.join(td, "three.skf"), "rb").read()
     print("  batched .skf", "IDENTICAL to" if same else "DIFFERENT from", "the one-batch file")
-for up in os.environ.get("RSC_UPLOADERS", "").split():
-    run(f"ska build with SKX_UPLOADERS={up}", [SKA, "build", "-f", "list.txt", "-o", "two", "--threads", os.environ.get("RSC_THREADS", "16"), *opts], {"SKX_PHASES": os.path.join(td, "ph2.json"), "SKX_UPLOADERS": up})
-    print("  phases", open(os.path.join(td, "ph2.json")).read()[:330])
 if os.environ.get("RSC_ONE_SHOT"):                               # the same build without the reader / kernel pipeline: the .skf must be the same bytes
-    run("ska build, one-shot form (SKX_NO_READS_PIPELINE=1)", [SKA, "build", "-f", "list.txt", "-o", "oneshot", "--threads", os.environ.get("RSC_THREADS", "16"), *opts],
-        {"SKX_PHASES": os.path.join(td, "ph5.json"), "SKX_NO_READS_PIPELINE": "1"})
+    run("ska build, one-shot form (SKX_KNOBS=no_reads_pipeline)", [SKA, "build", "-f", "list.txt", "-o", "oneshot", "--threads", os.environ.get("RSC_THREADS", "16"), *opts],
+        {"SKX_PHASES": os.path.join(td, "ph5.json"), "SKX_KNOBS": "no_reads_pipeline"})
     print("  phases", open(os.path.join(td, "ph5.json")).read()[:420])
     same = open(os.path.join(td, "one.skf"), "rb").read() == open(os.path.join(td, "oneshot.skf"), "rb").read()
     print("  one-shot .skf", "IDENTICAL to" if same else "DIFFERENT from", "the pipelined build's")
