@@ -645,11 +645,14 @@ def main():
         arr_u.free()
         ds.free()
     if rank == 0:                      # sum of the per-sample dictionary sizes (untimed): the D of SURVEY.md 8d's per-stage bytes
+        # (counted from the merged array's cells -- a sample's split k-mers are its cells: no dictionary is sorted for it)
         ds = E.DictSet.build_device(ptrs, lens, args.k, True, ctx=ctx)
-        n_distinct = int(sum(ds.size(i) for i in range(G)))
-        if world == 1 and not args.no_distance:
+        arr_d = ds.merge(names)
+        n_distinct = int(arr_d.sample_kmers().sum())
+        if world != 1 or args.no_distance:
+            arr_d.free()
+        else:
             # `ska distance` on the same array (outside `value`): the constant-site filter, bit planes, all pairs
-            arr_d = ds.merge(names)
             ctx.sync()
             ctx.timings(reset=True)
             t_d0 = time.perf_counter()

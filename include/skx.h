@@ -79,6 +79,12 @@ int skx_dictset_build(skx_ctx *ctx, const skx_stream *samples, int n_samples, in
 int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, const char *const *file2, int n_samples,
                             int k, int rc, const skx_qual *qual, int threads, double proportion_reads,
                             skx_dictset **out);
+/* One sample's files as the record stream skx_dictset_build takes: what needletail's parse_fastx_file hands SkaDict::new record by
+ * record (ska_dict.rs:131-153, 356-366) -- each record's bases (and qualities) followed by '\n'.  Host only, no device: plain, gzip
+ * (the library's own inflater; members' CRC-32 and length checked: a damaged or truncated file is SKX_EIO), bzip2 / xz / zstd; FASTA or
+ * FASTQ.  streaming != 0: through the line-by-line FASTQ reader of the read-set pipeline (SKX_EUNSUP: not FASTQ).  seq / qual:
+ * malloc'd (skx_free); *qual = NULL for FASTA. */
+int skx_read_records(const char *file1, const char *file2, double proportion_reads, int streaming, uint8_t **seq, uint8_t **qual, uint64_t *len);
 void skx_dictset_free(skx_dictset *d);
 int  skx_dictset_nsamples(const skx_dictset *d);
 int  skx_dictset_key_bits(const skx_dictset *d);      /* 64 | 128 (lib.rs:592) */

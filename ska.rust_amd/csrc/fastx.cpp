@@ -15,6 +15,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#include <memory>
 #include <dlfcn.h>
 
 namespace skx {
@@ -125,7 +126,7 @@ static int slurp(const char *path, std::vector<uint8_t> &buf)
     if (fd < 0) { set_error("Invalid path/file: %s", path); return SKX_EIO; }
     (void)posix_fadvise(fd, 0, 0, POSIX_FADV_NOREUSE);
     // a plain (not gzip) regular file is read straight into a buffer of its size -- no inflate layer, no doubling of the buffer
-    struct stat sb;
+    struct stat sb{};
     unsigned char magic[2] = {0, 0};
     if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && pread(fd, magic, 2, 0) == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b)) {
         const size_t n = (size_t)sb.st_size;
@@ -145,6 +146,26 @@ static int slurp(const char *path, std::vector<uint8_t> &buf)
         }
         return SKX_OK;
     }
+    // a gzip file: through the reader threads' own inflater (gz_inflate.cpp)
+    if (S_ISREG(sb.st_mode) && magic[0] == 0x1f && magic[1] == 0x8b && !knob("zlib_reader")) {
+        GzReader zr;
+        zr.open(fd);
+        buf.clear();
+        size_t n = 0;
+        for (;;) {
+            const uint8_t *p; size_t got;
+            if (zr.next(&p, &got, 0) != 0) { ::close(fd); set_error("Invalid path/file: %s", path); return SKX_EIO; }      // damaged or truncated: an error, not a short input
+            if (got == 0) break;
+            if (buf.size() - n < got) buf.resize(std::max(buf.size() * 2, n + got + (4u << 20)));
+            memcpy(buf.data() + n, p, got);
+            n += got;
+        }
+        ::close(fd);
+        buf.resize(n);
+        if (n == 0) { set_error("Invalid path/file: %s", path); return SKX_EIO; }
+        return SKX_OK;
+    }
+    // what is not a regular file (a pipe cannot be looked at first), and SKX_KNOBS=zlib_reader (A/B measurements, differential tests): zlib's gzread
     gzFile g = gzdopen(fd, "rb");            // transparent for uncompressed input that is not a regular file; closes fd with gzclose
     if (!g) { ::close(fd); set_error("Invalid path/file: %s", path); return SKX_EIO; }
     gzbuffer(g, 1 << 20);
@@ -230,13 +251,18 @@ int stream_fastq_file(const char *path, const std::function<int(int which, const
     if (fd < 0) { set_error("Invalid path/file: %s", path); return SKX_EIO; }
     struct Close { int fd; ~Close() { ::close(fd); } } cl{fd};
     (void)posix_fadvise(fd, 0, 0, POSIX_FADV_NOREUSE);
-    // a gzip file is inflated piece by piece as it is read (zlib's gzread on a descriptor of its own: members one after the other, as gzip reads them)
+    // a gzip file is inflated piece by piece as it is read, by the reader thread's own inflater (gz_inflate.cpp: members one after the other, as
+    // gzip reads them; the text is walked where the inflater put it); SKX_KNOBS=zlib_reader: through zlib's gzread on a descriptor of its own
     unsigned char mg[2] = {0, 0};
     gzFile gz = nullptr;
+    std::unique_ptr<GzReader> zr;
     if (pread(fd, mg, 2, 0) == 2 && mg[0] == 0x1f && mg[1] == 0x8b) {
-        const int fd2 = dup(fd);
-        if (fd2 < 0 || !(gz = gzdopen(fd2, "rb"))) { if (fd2 >= 0) ::close(fd2); set_error("Invalid path/file: %s", path); return SKX_EIO; }
-        gzbuffer(gz, 1u << 20);
+        if (!knob("zlib_reader")) { zr.reset(new GzReader); zr->open(fd); }
+        else {
+            const int fd2 = dup(fd);
+            if (fd2 < 0 || !(gz = gzdopen(fd2, "rb"))) { if (fd2 >= 0) ::close(fd2); set_error("Invalid path/file: %s", path); return SKX_EIO; }
+            gzbuffer(gz, 1u << 20);
+        }
     }
     struct GzClose { gzFile &g; ~GzClose() { if (g) gzclose(g); } } gzc{gz};
     static thread_local std::vector<uint8_t> chunk;
@@ -299,16 +325,22 @@ int stream_fastq_file(const char *path, const std::function<int(int which, const
         return SKX_OK;
     };
     for (;;) {
-        ssize_t r = gz ? (ssize_t)gzread(gz, chunk.data() + have, (unsigned)(CH - have)) : ::read(fd, chunk.data() + have, CH - have);
+        ssize_t r;
+        const uint8_t *base = chunk.data();                                  // where the unconsumed bytes (`have` of them) start
+        if (zr) {
+            const uint8_t *np; size_t got;
+            if (zr->next(&np, &got, have) != 0) { set_error("Invalid path/file: %s", path); return SKX_EIO; }      // damaged or truncated: an error, not a short input
+            base = np - have; r = (ssize_t)got;
+        } else r = gz ? (ssize_t)gzread(gz, chunk.data() + have, (unsigned)(CH - have)) : ::read(fd, chunk.data() + have, CH - have);
         if (r < 0 && !gz && errno == EINTR) continue;
         if (r < 0) { set_error("Invalid path/file: %s", path); return SKX_EIO; }
         if (first) {
             if (r == 0) { set_error("Invalid path/file: %s", path); return SKX_EIO; }
-            if (chunk[0] != '@') return SKF_NOT_TAKEN;
+            if (base[0] != '@') return SKF_NOT_TAKEN;
             first = false;
         }
         const size_t n = have + (size_t)r;
-        const uint8_t *p = chunk.data(), *end = p + n;
+        const uint8_t *p = base, *end = p + n;
         if (!spill.empty()) {                                              // the end of a line that began in an earlier chunk
             const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
             if (nl) {
@@ -333,7 +365,8 @@ int stream_fastq_file(const char *path, const std::function<int(int which, const
             }
             break;
         }
-        if (have == CH) { spill.insert(spill.end(), p, end); have = 0; }    // no line end in a whole chunk
+        if (zr) { if (have > GzReader::KEEP_MAX) { spill.insert(spill.end(), p, end); have = 0; } }      // (the inflater keeps the unfinished line in front of its next text)
+        else if (have == CH) { spill.insert(spill.end(), p, end); have = 0; }    // no line end in a whole chunk
         else if (have) memmove(chunk.data(), p, have);
     }
     if (in_record || (line_no & 3u) != 0) { set_error("Invalid FASTA/Q record"); return SKX_EIO; }

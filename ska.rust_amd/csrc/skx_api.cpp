@@ -1196,6 +1196,37 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
     });
 }
 
+extern "C" int skx_read_records(const char *file1, const char *file2, double proportion_reads, int streaming, uint8_t **seq, uint8_t **qual, uint64_t *len)
+{
+    return skx_guarded([&]() -> int {
+    if (!file1 || !seq || !qual || !len) { set_error("bad arguments"); return SKX_EINVAL; }
+    *seq = nullptr; *qual = nullptr; *len = 0;
+    HostStream h;
+    if (streaming) {
+        const std::function<int(int, const uint8_t *, size_t)> emit = [&](int which, const uint8_t *p, size_t nb) -> int {
+            std::vector<uint8_t> &v = which ? h.qual : h.seq;
+            v.insert(v.end(), p, p + nb); v.push_back('\n');
+            return SKX_OK;
+        };
+        for (const char *f : {file1, file2}) {
+            if (!f) continue;
+            const int r = stream_fastq_file(f, emit);
+            if (r == SKF_NOT_TAKEN) { set_error("not a FASTQ file: %s", f); return SKX_EUNSUP; }
+            if (r != SKX_OK) return r;
+        }
+        h.is_fastq = true;
+    } else SKX_TRY(read_sample_stream(file1, file2, proportion_reads, h));
+    if (h.is_fastq && h.qual.size() != h.seq.size()) { set_error("Invalid FASTA/Q record"); return SKX_EIO; }
+    const size_t n = h.seq.size();
+    uint8_t *s = (uint8_t *)malloc(n + 1), *q = h.is_fastq ? (uint8_t *)malloc(n + 1) : nullptr;
+    if (!s || (h.is_fastq && !q)) { free(s); free(q); set_error("out of memory"); return SKX_ENOMEM; }
+    memcpy(s, h.seq.data(), n);
+    if (q) memcpy(q, h.qual.data(), n);
+    *seq = s; *qual = q; *len = n;
+    return SKX_OK;
+    });
+}
+
 extern "C" int skx_dictset_size(skx_dictset *d, int sample, uint64_t *n)
 {
     return skx_guarded([&]() -> int {

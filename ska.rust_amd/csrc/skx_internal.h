@@ -196,6 +196,18 @@ int read_sample_stream(const char *file1, const char *file2, double proportion_r
 // a plain FASTQ file line by line: emit(0, sequence line) / emit(1, quality line), without terminators -- the sink adds the '\n' that ends a
 // record of the stream (SKF_NOT_TAKEN: not plain FASTQ)
 int stream_fastq_file(const char *path, const std::function<int(int which, const uint8_t *p, size_t n)> &emit);
+// gzip members inflated piece by piece into a window of the reader's own (gz_inflate.cpp: the reader threads' inflater).  next(): more text,
+// in place -- the `keep` bytes in front of the last call's end stay in front of it (the caller's unfinished line); *n == 0 at the end of the
+// last member; -1: not gzip, damaged, truncated (CRC-32 and length of every member are checked) or a read error
+struct GzReader {
+    struct Impl; Impl *impl;
+    GzReader(); ~GzReader();
+    GzReader(const GzReader &) = delete; GzReader &operator=(const GzReader &) = delete;
+    void open(int fd);                                        // (the descriptor stays the caller's)
+    int next(const uint8_t **p, size_t *n, size_t keep);
+    static constexpr size_t KEEP_MAX = 128u << 10;            // callers put longer unfinished lines aside themselves
+};
+uint32_t gz_crc32(uint32_t crc, const uint8_t *p, size_t n);  // zlib's crc32() convention
 // a sequence / quality line of a read as bit planes, 64 positions per word, bits beyond the line zero (fastx.cpp; READ_GROUP_BYTES: five
 // 64-position words -- lo, hi, bad, newline, quality verdict -- make one group of the packed stream, launch_expand_planes takes it apart)
 void pack_bases_planes(const uint8_t *s, size_t n, uint64_t *lo, uint64_t *hi, uint64_t *bad);

@@ -62,7 +62,7 @@ class EngineError(RuntimeError):
 
 # every symbol include/skx.h and include/skx_host.h declare
 SYMBOLS = """skx_last_error skx_version skx_ctx_create skx_ctx_destroy skx_ctx_sync skx_ctx_stream skx_dictset_build
-skx_dictset_build_files skx_dictset_free skx_dictset_nsamples skx_dictset_key_bits skx_dictset_size skx_dictset_export
+skx_dictset_build_files skx_read_records skx_dictset_free skx_dictset_nsamples skx_dictset_key_bits skx_dictset_size skx_dictset_export
 skx_keyset_union skx_keyset_union_notes skx_keyset_size skx_keyset_device skx_keyset_from_device skx_keyset_merge skx_keyset_free
 skx_array_assemble skx_array_assemble_lazy skx_merge skx_build_and_merge skx_array_free skx_array_save skx_array_load skx_array_from_host
 skx_array_info skx_array_name skx_array_version skx_array_export skx_array_sample_kmers skx_array_pieces_info skx_array_filter
@@ -155,6 +155,7 @@ def load_library():
     lib.skh_merge.argtypes = [vp, C.POINTER(cp), i, cp]
     lib.skh_delete.argtypes = [vp, C.POINTER(cp), i, cp]
     lib.skh_weed.argtypes = [vp, cp, i, d, i, i, i, i, cp]
+    lib.skx_read_records.argtypes = [cp, cp, d, i, pp, pp, C.POINTER(u64)]
     lib.skh_sample_name.argtypes = [cp]
     lib.skh_sample_name.restype = vp
     lib.skx_ctx_expect_output.argtypes = [vp, i]
@@ -253,6 +254,19 @@ def planes_distance(planes_ptr, n_samples, words_per_row, filt_ambig, constant, 
         return out
     _check(_lib.skx_planes_distance(ctx.h, planes_ptr, n_samples, words_per_row, int(filt_ambig), float(constant), i_lo, i_hi, _np_ptr(out)))
     return out
+
+
+def read_records(file1, file2=None, proportion_reads=0.0, streaming=False):
+    """One sample's files as the record stream the device takes (host only): (seq bytes, qual bytes or None)."""
+    lib = load_library()
+    ps, pq, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+    _check(lib.skx_read_records(file1.encode(), file2.encode() if file2 else None, float(proportion_reads), int(bool(streaming)), C.byref(ps), C.byref(pq), C.byref(n)))
+    seq = C.string_at(ps, n.value)
+    q = C.string_at(pq, n.value) if pq.value else None
+    lib.skx_free(ps)
+    if pq.value:
+        lib.skx_free(pq)
+    return seq, q
 
 
 def sample_name(path):

@@ -1,0 +1,196 @@
+"""The reader threads' own inflater (csrc/gz_inflate.cpp) against Python's zlib, on the CPU: every kind of DEFLATE block, gzip header
+fields, several members, trailing bytes, and the damaged / truncated files that must be errors (needletail through flate2 refuses
+them: ska_dict.rs:131-153) -- through skx_read_records, both the one-shot reader and the line-by-line FASTQ reader of the read-set
+pipeline."""
+import gzip
+import os
+import random
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import skx_engine as E
+
+
+def _fastq(n_reads, read_len, seed, qual_mode="profile", crlf=False, n_rate=0.001):
+    rng = np.random.default_rng(seed)
+    genome = rng.integers(0, 4, 200_000, dtype=np.uint8)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    prof = bytes(33 + max(2, 40 - (i * i) // 600) for i in range(read_len))
+    out = []
+    eol = b"\r\n" if crlf else b"\n"
+    for r in range(n_reads):
+        p = int(rng.integers(0, len(genome) - read_len))
+        s = lut[genome[p:p + read_len]].copy()
+        if n_rate:
+            s[rng.random(read_len) < n_rate] = ord("N")
+        if qual_mode == "profile":
+            q = prof
+        else:
+            q = bytes(rng.integers(33, 74, read_len, dtype=np.uint8))
+        out.append(b"@read_%d/1" % r + eol + s.tobytes() + eol + b"+" + eol + q + eol)
+    return b"".join(out)
+
+
+def _expect_fastq(text):
+    lines = text.replace(b"\r\n", b"\n").split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()
+    seq = b"".join(l + b"\n" for l in lines[1::4])
+    qual = b"".join(l + b"\n" for l in lines[3::4])
+    return seq, qual
+
+
+def _gz_member(data, level=6, fname=None, comment=None, extra=None, hcrc=False, strategy=zlib.Z_DEFAULT_STRATEGY, wbits=15):
+    flg = (8 if fname else 0) | (16 if comment else 0) | (4 if extra else 0) | (2 if hcrc else 0)
+    h = b"\x1f\x8b\x08" + bytes([flg]) + struct.pack("<IBB", 0, 0, 255)
+    if extra:
+        h += struct.pack("<H", len(extra)) + extra
+    if fname:
+        h += fname + b"\0"
+    if comment:
+        h += comment + b"\0"
+    if hcrc:
+        h += struct.pack("<H", zlib.crc32(h) & 0xFFFF)
+    c = zlib.compressobj(level, zlib.DEFLATED, -wbits, 9, strategy)
+    body = c.compress(data) + c.flush()
+    return h + body + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data) & 0xFFFFFFFF)
+
+
+def _both(path, expect_seq, expect_qual):
+    for streaming in (False, True):
+        s, q = E.read_records(path, streaming=streaming)
+        assert s == expect_seq, (streaming, len(s), len(expect_seq))
+        assert q == expect_qual, streaming
+
+
+@pytest.mark.parametrize("level,strategy", [(1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY),
+                                            (0, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE)])
+def test_gz_reader_block_kinds(tmp_path, level, strategy):
+    # stored blocks (level 0), fixed codes, dynamic codes, literals only, distance-1 runs
+    text = _fastq(6000, 151, seed=level * 10 + strategy)
+    p = tmp_path / "a.fastq.gz"
+    p.write_bytes(_gz_member(text, level=level, strategy=strategy))
+    _both(str(p), *_expect_fastq(text))
+
+
+def test_gz_reader_random_qualities_and_crlf(tmp_path):
+    text = _fastq(5000, 100, seed=3, qual_mode="random", crlf=True)
+    p = tmp_path / "a.fastq.gz"
+    p.write_bytes(gzip.compress(text, 6))
+    _both(str(p), *_expect_fastq(text))
+
+
+def test_gz_reader_header_fields_members_and_trailing_bytes(tmp_path):
+    a, b, c = _fastq(3000, 151, 1), _fastq(10, 50, 2), _fastq(4000, 75, 3, qual_mode="random")
+    blob = (_gz_member(a, fname=b"reads_1.fastq", comment=b"made by a test", extra=b"BC\x02\x00\x00\x10", hcrc=True)
+            + _gz_member(b, level=1) + _gz_member(b"") + _gz_member(c, level=9, wbits=9) + b"\0" * 37)       # bgzip-like fields, an empty member, a small window, padding
+    p = tmp_path / "a.fastq.gz"
+    p.write_bytes(blob)
+    _both(str(p), *_expect_fastq(a + b + c))
+
+
+def test_gz_reader_text_larger_than_every_buffer(tmp_path):
+    # > the inflater's 1 MB window and 1 MB input buffer, several times; a last line without a line end
+    text = _fastq(60_000, 151, 9, qual_mode="random")[:-1]
+    assert len(text) > 16 << 20
+    p = tmp_path / "big.fastq.gz"
+    p.write_bytes(gzip.compress(text, 1))
+    _both(str(p), *_expect_fastq(text))
+    # and through the one-shot reader as FASTA (one long record: no line end for megabytes)
+    fa = b">contig\n" + text.replace(b"\n", b"") + b"\n"
+    p2 = tmp_path / "long.fa.gz"
+    p2.write_bytes(gzip.compress(fa, 6))
+    s, q = E.read_records(str(p2))
+    assert q is None and s == text.replace(b"\n", b"") + b"\n"
+
+
+def test_gz_reader_a_line_longer_than_the_kept_window(tmp_path):
+    # FASTQ whose lines are longer than what the inflater keeps for the caller (the caller puts them aside)
+    rng = np.random.default_rng(5)
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 700_000)].tobytes()
+    qual = bytes(rng.integers(33, 74, 700_000, dtype=np.uint8))
+    text = b"@long\n" + seq + b"\n+\n" + qual + b"\n" + _fastq(100, 151, 1)
+    p = tmp_path / "l.fastq.gz"
+    p.write_bytes(gzip.compress(text, 6))
+    _both(str(p), *_expect_fastq(text))
+
+
+def test_gz_reader_agrees_with_zlib_reader_on_fixtures(tmp_path):
+    # the reference's own gzip fixtures, and the knob that brings zlib's gzread back: same records
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    found = []
+    for dp, _, files in os.walk(root):
+        found += [os.path.join(dp, f) for f in files if f.endswith(".gz")]
+    assert found
+    for f in sorted(found):
+        raw = gzip.decompress(open(f, "rb").read())
+        s, q = E.read_records(f)
+        if raw[:1] == b"@":
+            assert (s, q) == _expect_fastq(raw), f
+            assert E.read_records(f, streaming=True) == (s, q), f
+
+
+def test_gz_reader_refuses_damaged_files(tmp_path):
+    text = _fastq(20_000, 151, 11, qual_mode="random")
+    good = gzip.compress(text, 6)
+    p = tmp_path / "x.fastq.gz"
+    rnd = random.Random(1)
+
+    def refused(blob):
+        p.write_bytes(blob)
+        for streaming in (False, True):
+            with pytest.raises(E.EngineError) as ei:
+                E.read_records(str(p), streaming=streaming)
+            assert ei.value.code == E.EIO, (streaming, ei.value)
+
+    refused(good[:len(good) // 2])                      # truncated in the middle of a block
+    refused(good[:-8])                                  # trailer missing
+    refused(good[:-3])                                  # trailer cut
+    refused(good[:-8] + struct.pack("<II", (zlib.crc32(text) ^ 1) & 0xFFFFFFFF, len(text)))      # wrong CRC
+    refused(good[:-4] + struct.pack("<I", len(text) + 1))                                        # wrong length
+    refused(good[:10] + b"\x07" + good[11:])            # block type 3
+    refused(b"\x1f\x8b\x08\xe0" + good[4:])             # reserved header flags
+    refused(b"\x1f\x8b\x07" + good[3:])                 # not DEFLATE
+    bad_dist = b"\x1f\x8b\x08\x00" + b"\0" * 6 + zlib.compressobj(6, zlib.DEFLATED, -15).compress(b"") + bytes([0x73, 0x04, 0x91, 0x00]) + b"\0" * 8
+    refused(bad_dist)
+    flips = 0
+    for _ in range(200):                                # a flipped bit anywhere: an error or, if the text survives (header time stamp), the same text
+        i = rnd.randrange(len(good))
+        blob = bytearray(good)
+        blob[i] ^= 1 << rnd.randrange(8)
+        p.write_bytes(bytes(blob))
+        try:
+            s, q = E.read_records(str(p), streaming=True)
+        except E.EngineError as e:
+            assert e.code == E.EIO
+            flips += 1
+            continue
+        assert (s, q) == _expect_fastq(text), i
+    assert flips > 150
+
+
+def test_gz_reader_member_checksums_at_every_length(tmp_path):
+    # one member per length 0..600 (and a few around the folded CRC's block sizes): each member's CRC-32 is checked over exactly that
+    # many bytes, short ones by the table form, long ones by the carry-less-multiplication form, at whatever alignment the window gives
+    rng = np.random.default_rng(2)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    members, expect = [], []
+    for i, n in enumerate(list(range(0, 600)) + [1023, 1024, 1025, 4096 + 15, 65_536 + 1, 300_001]):
+        body = lut[rng.integers(0, 4, n)].tobytes()
+        rec = b">r%d\n" % i + body + b"\n"
+        members.append(_gz_member(rec, level=(0, 1, 6)[i % 3]))
+        expect.append(body + b"\n")
+    p = tmp_path / "m.fa.gz"
+    p.write_bytes(b"".join(members))
+    s, q = E.read_records(str(p))
+    assert q is None and s == b"".join(expect)
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r); import skx_engine as E; s, q = E.read_records(%r); "
+            "import hashlib; print(hashlib.sha1(s).hexdigest())" % (os.path.dirname(E.__file__), str(p)))
+    import hashlib
+    for knobs in ("no_clmul", "zlib_reader"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SKX_KNOBS=knobs), capture_output=True, text=True, check=True).stdout.strip()
+        assert out == hashlib.sha1(b"".join(expect)).hexdigest(), knobs
