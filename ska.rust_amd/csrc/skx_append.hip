@@ -31,6 +31,7 @@
 // one part left out: what showed that loads + filter + queues are 6.8 of its 24 ms; results are wrong by construction) -- tools/mkvariant.sh.
 #include "skx_device.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace skx {
 
@@ -78,7 +79,8 @@ extern "C" void skx_debug_phase_prof(unsigned long long *out, int reset)
 constexpr int AP_PRIO_STREAM = 3, AP_PRIO_LOOKUP = AP_PRIO_L, AP_PRIO_INSERT = AP_PRIO_I;
 constexpr int AP_THREADS = 1024, AP_WAVES = 16;
 constexpr uint32_t AP_PAD = 64;             // slots behind the table's last home slot (probing does not wrap)
-constexpr uint32_t AP_Q = 192, AP_SQ = 128; // a wave's queue of kept words: 127 left over + the ~32 +- 5 of one load; its insert queue (emptied first when a batch's misses would not fit)
+constexpr uint32_t AP_Q = 256, AP_SQ = 64;  // a wave's queue of kept words: the 127 a batch may leave + the 128 of one load -- it cannot overflow, whatever the sample (no test, no
+                                            // way out: round 5); its insert queue (one batch of the insert loop: emptied first when a look-up batch's misses would not fit)
 #ifndef AP_CH_N
 #define AP_CH_N 8
 #endif
@@ -187,7 +189,10 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
     cq_t c_off = (cq_t)(uintptr_t)a.off;
     c1_t c_raw = (c1_t)(uintptr_t)a.raw;
     const uint64_t rstride = 1ull << a.logB;                         // regions per sample
-    uint32_t nq = 0, nsq = 0;                                        // wave-uniform: the fills of the two queues
+    // wave-uniform: the fills of the two queues -- the queue of kept words as the LDS byte address of its end (what the filter step adds to: the
+    // step's two write addresses and the new end are two scalar shift-adds)
+    const uint32_t qbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned long long *)q, qfull = qbase + 128u * 8u;
+    uint32_t qw = qbase, nsq = 0;
     AP_PROF_START;
     __builtin_amdgcn_s_setprio(AP_PRIO_STREAM);
 
@@ -268,12 +273,16 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
     // up to 128 queued words, two per lane, against their home slots and the slots behind them: the two look-ups are independent, so every
     // LDS round trip of the chain queue -> table -> row buffer serves two words (the kernel waits for these round trips, it does not compute:
     // VALU 47 % busy with one word per lane).  What is not found there goes to the insert queue.
-    auto batch = [&]() {
+    // (full_tag: a batch of 128 -- every batch but a sample's last: no lane is idle, nothing is masked)
+    auto batch = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
         __builtin_amdgcn_s_setprio(AP_PRIO_LOOKUP);
-        const uint32_t take = nq < 128u ? nq : 128u;
+        uint32_t nq = (qw - qbase) >> 3;
+        const uint32_t take = FULL ? 128u : nq < 128u ? nq : 128u;
         nq -= take;
+        qw -= take * 8u;
         if (lane == 0) { AP_COUNT(6, 1); AP_COUNT(7, take); }
-        const bool va = (uint32_t)lane < take, vb = (uint32_t)lane + 64u < take;
+        const bool va = FULL || (uint32_t)lane < take, vb = FULL || (uint32_t)lane + 64u < take;
         unsigned long long wa = 0, wb = 0;
         if (va) wa = q[nq + lane];
         if (vb) wb = q[nq + 64u + lane];
@@ -316,11 +325,14 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
             if (hitb) atomicOr(rb + __builtin_amdgcn_ubfe(rb0, 3u, 11u), (blo & 15u) << ((rb0 << 2) & 31u));
         }
         if (xa | xb) {
-            const uint32_t na = (uint32_t)__popcll(xa);
-            while (nsq + na + (uint32_t)__popcll(xb) > AP_SQ) slow_batch();
+            // (the misses of the lanes' first words, then of their second words: either lot fits the emptied insert queue)
+            const uint32_t na = (uint32_t)__popcll(xa), nb = (uint32_t)__popcll(xb);
+            if (nsq + na > AP_SQ) slow_batch();
             if (va & !hita) sq[nsq + ap_mbcnt(xa)] = wa;
-            if (vb & !hitb) sq[nsq + na + ap_mbcnt(xb)] = wb;
-            nsq += na + (uint32_t)__popcll(xb);
+            nsq += na;
+            if (nsq + nb > AP_SQ) slow_batch();
+            if (vb & !hitb) sq[nsq + ap_mbcnt(xb)] = wb;
+            nsq += nb;
         }
         __builtin_amdgcn_s_setprio(AP_PRIO_STREAM);
     };
@@ -377,7 +389,6 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
             const uint32_t w0l = 2u * (uint32_t)lane, w1l = w0l + 1u;
             const int fill_left = (int)(cnt_c - c * (64u * AP_CH * 2u));           // words of the region's fill from this chunk's start on (>= 0: c < nch)
             const bool full_chunk = __builtin_amdgcn_readfirstlane((uint32_t)((c + 1u) * (64u * AP_CH * 2u) <= cnt_c)) != 0u;      // every word of the chunk lies inside the region's fill: no fill test
-            const uint32_t qbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned long long *)q;      // the queue's LDS byte address
 #pragma unroll
             for (int r = 0; r < AP_CH; r++) {
                 asm volatile("s_waitcnt vmcnt(%0)" :: "n"(AP_CH - 1) : "memory");
@@ -399,54 +410,50 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
                     // which of the two words are this block's (part bits in the upper half, the region's fill), as lane masks; then the kept
                     // words side by side into the queue.  Written out: the compiler's version of the same spends three times the instructions
                     // on turning conditions into lane masks and back (ten vector instructions here per 128 words, eight where the fill test is skipped).
-                    unsigned long long ma, mb; uint32_t na, nb, ta, tb;
                     // (the fill test only where a chunk reaches past the region's fill -- a sample's last chunk: one scalar compare otherwise;
-                    // word index against fill as w0 against the fill less the load's offset, so no vector add per load either)
-                    const int cA = fill_left - 128 * r;                              // (signed: a load past the fill compares as less than any lane's 2 * lane)
-                    asm volatile("v_and_b32 %4, %6, %8\n\t"
-                                 "v_cmp_eq_u32_e64 %0, %7, %4\n\t"
-                                 "v_and_b32 %5, %6, %9\n\t"
-                                 "v_cmp_eq_u32_e64 %1, %7, %5\n\t"
-                                 "s_cmp_lg_u32 %13, 0\n\t"
-                                 "s_cbranch_scc1 .Lapf%=\n\t"
-                                 "v_cmp_gt_i32_e32 vcc, %10, %11\n\t"
-                                 "s_and_b64 %0, %0, vcc\n\t"
-                                 "v_cmp_gt_i32_e32 vcc, %10, %12\n\t"
-                                 "s_and_b64 %1, %1, vcc\n"
-                                 ".Lapf%=:\n\t"
-                                 "s_bcnt1_i32_b64 %2, %0\n\t"
-                                 "s_bcnt1_i32_b64 %3, %1"
-                                 : "=&s"(ma), "=&s"(mb), "=&s"(na), "=&s"(nb), "=&v"(ta), "=&v"(tb)
-                                 : "s"(fmask), "s"(pshift), "v"(ahi), "v"(bhi), "s"(cA), "v"(w0l), "v"(w1l), "s"((uint32_t)full_chunk)
-                                 : "vcc", "scc");
-                    if (__builtin_expect(nq + na + nb > AP_Q, 0)) {                  // (a sample that is one repeat: the launch fails, nothing is queued, the host takes the sorted path)
-                        if (lane == 0) s_ctl[CTL_FAIL] = 2u;
-                        ma = 0ull; mb = 0ull; na = 0u; nb = 0u;
+                    // word index against fill as w0 against the fill less the load's offset, so no vector add per load either.)  The queue
+                    // holds whatever a load keeps on top of what a batch left (127 + 128 <= AP_Q): no test.  All 64 lanes are active here:
+                    // the execution mask is set, not saved -- 14 scalar instructions a step where round 4's kernel had 21 (the CU's one
+                    // scalar unit is the busiest part of this kernel: profiles/r04zzo_pmc_append_lean.log)
+                    unsigned long long ma, mb; uint32_t na, nb, ta, tb, qb, cA;      // (cA: signed -- a load past the fill compares as less than any lane's 2 * lane)
+                    // (the load's offset in the fill test is a literal of the instruction: one assembly text per load of the chunk)
+#define AP_FILTER_STEP(OFF) asm volatile("v_and_b32 %4, %9, %11\n\t" \
+                                 "v_cmp_eq_u32_e64 %0, %10, %4\n\t" \
+                                 "v_and_b32 %5, %9, %12\n\t" \
+                                 "v_cmp_eq_u32_e64 %1, %10, %5\n\t" \
+                                 "s_cmp_lg_u32 %16, 0\n\t" \
+                                 "s_cbranch_scc1 .Lapf%=\n\t" \
+                                 "s_sub_i32 %7, %13, " #OFF "\n\t" \
+                                 "v_cmp_gt_i32_e32 vcc, %7, %14\n\t" \
+                                 "s_and_b64 %0, %0, vcc\n\t" \
+                                 "v_cmp_gt_i32_e32 vcc, %7, %15\n\t" \
+                                 "s_and_b64 %1, %1, vcc\n" \
+                                 ".Lapf%=:\n\t" \
+                                 "s_bcnt1_i32_b64 %2, %0\n\t" \
+                                 "s_bcnt1_i32_b64 %3, %1\n\t" \
+                                 "s_lshl3_add_u32 %6, %2, %8\n\t" \
+                                 "s_mov_b64 exec, %0\n\t" \
+                                 "v_mbcnt_lo_u32_b32 %4, exec_lo, 0\n\t" \
+                                 "v_mbcnt_hi_u32_b32 %4, exec_hi, %4\n\t" \
+                                 "v_lshl_add_u32 %4, %4, 3, %8\n\t" \
+                                 "ds_write2_b32 %4, %17, %11 offset1:1\n\t" \
+                                 "s_mov_b64 exec, %1\n\t" \
+                                 "v_mbcnt_lo_u32_b32 %5, exec_lo, 0\n\t" \
+                                 "v_mbcnt_hi_u32_b32 %5, exec_hi, %5\n\t" \
+                                 "v_lshl_add_u32 %5, %5, 3, %6\n\t" \
+                                 "ds_write2_b32 %5, %18, %12 offset1:1\n\t" \
+                                 "s_mov_b64 exec, -1\n\t" \
+                                 "s_lshl3_add_u32 %8, %3, %6" \
+                                 : "=&s"(ma), "=&s"(mb), "=&s"(na), "=&s"(nb), "=&v"(ta), "=&v"(tb), "=&s"(qb), "=&s"(cA), "+s"(qw) \
+                                 : "s"(fmask), "s"(pshift), "v"(ahi), "v"(bhi), "s"(fill_left), "v"(w0l), "v"(w1l), "s"((uint32_t)full_chunk), "v"(alo), "v"(blo) \
+                                 : "vcc", "scc", "memory")
+                    static_assert(AP_CH <= 12, "one assembly text per load of a chunk");
+                    switch (r) {
+                    case 0: AP_FILTER_STEP(0); break; case 1: AP_FILTER_STEP(128); break; case 2: AP_FILTER_STEP(256); break; case 3: AP_FILTER_STEP(384); break;
+                    case 4: AP_FILTER_STEP(512); break; case 5: AP_FILTER_STEP(640); break; case 6: AP_FILTER_STEP(768); break; case 7: AP_FILTER_STEP(896); break;
+                    case 8: AP_FILTER_STEP(1024); break; case 9: AP_FILTER_STEP(1152); break; case 10: AP_FILTER_STEP(1280); break; default: AP_FILTER_STEP(1408); break;
                     }
-                    {
-                        // the kept words side by side into the queue: scalar address arithmetic in two shift-adds, the lane masks read by v_mbcnt as
-                        // they are (the kernel's scalar unit is its busiest: profiles/r04zzo_pmc_append_lean.log)
-                        unsigned long long sv; uint32_t qa, qb;
-                        asm volatile("s_lshl3_add_u32 %3, %5, %6\n\t"
-                                     "s_lshl3_add_u32 %4, %7, %3\n\t"
-                                     "v_mbcnt_lo_u32_b32 %0, %8, 0\n\t"
-                                     "v_mbcnt_hi_u32_b32 %0, %9, %0\n\t"
-                                     "v_lshl_add_u32 %0, %0, 3, %3\n\t"
-                                     "v_mbcnt_lo_u32_b32 %1, %10, 0\n\t"
-                                     "v_mbcnt_hi_u32_b32 %1, %11, %1\n\t"
-                                     "v_lshl_add_u32 %1, %1, 3, %4\n\t"
-                                     "s_and_saveexec_b64 %2, %12\n\t"
-                                     "ds_write2_b32 %0, %14, %15 offset1:1\n\t"
-                                     "s_mov_b64 exec, %2\n\t"
-                                     "s_and_saveexec_b64 %2, %13\n\t"
-                                     "ds_write2_b32 %1, %16, %17 offset1:1\n\t"
-                                     "s_mov_b64 exec, %2"
-                                     : "=&v"(ta), "=&v"(tb), "=&s"(sv), "=&s"(qa), "=&s"(qb)
-                                     : "s"(nq), "s"(qbase), "s"(na), "s"((uint32_t)ma), "s"((uint32_t)(ma >> 32)), "s"((uint32_t)mb), "s"((uint32_t)(mb >> 32)),
-                                       "s"(ma), "s"(mb), "v"(alo), "v"(ahi), "v"(blo), "v"(bhi)
-                                     : "scc", "memory");
-                        nq += na + nb;
-                    }
+#undef AP_FILTER_STEP
 #if defined(AP_X_NOFILTER)
                 } else if (alo == 0x12345u && bhi == 0x54321u) {
 #else
@@ -456,19 +463,17 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
                     const bool ka = widx < cnt_c && (pa & (A - 1u)) == part, kbb = widx + 1u < cnt_c && (pb & (A - 1u)) == part;
                     const unsigned long long ba = __ballot(ka), bb = __ballot(kbb);
                     const uint32_t na = (uint32_t)__popcll(ba), nb = (uint32_t)__popcll(bb);
-                    if (nq + na + nb > AP_Q) { if (lane == 0) s_ctl[CTL_FAIL] = 2u; }
-                    else {
-                        if (ka) q[nq + ap_mbcnt(ba)] = ((unsigned long long)ahi << 32) | alo;
-                        if (kbb) q[nq + na + ap_mbcnt(bb)] = ((unsigned long long)bhi << 32) | blo;
-                        nq += na + nb;
-                    }
+                    const uint32_t nq = (qw - qbase) >> 3;
+                    if (ka) q[nq + ap_mbcnt(ba)] = ((unsigned long long)ahi << 32) | alo;      // (127 + 128 <= AP_Q: it fits)
+                    if (kbb) q[nq + na + ap_mbcnt(bb)] = ((unsigned long long)bhi << 32) | blo;
+                    qw += (na + nb) * 8u;
                 }
                 issue_one(r, nb1);
                 AP_PROF(1);
 #if defined(AP_X_NOBATCH)
-                if (nq >= 128u) nq -= 128u;
+                if (qw >= qfull) qw -= 128u * 8u;
 #else
-                while (nq >= 128u) { batch(); AP_PROF(2);
+                while (qw >= qfull) { batch(std::true_type{}); AP_PROF(2);
 #if defined(AP_X_NOSLOW)
                     if (nsq >= 64u) nsq -= 64u;
 #else
@@ -478,7 +483,7 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
 #endif
             }
             if (last_chunk) {
-                while (nq) { batch(); AP_PROF(2); while (nsq >= 64u) { slow_batch(); AP_PROF(3); } }
+                while (qw != qbase) { batch(std::false_type{}); AP_PROF(2); while (nsq >= 64u) { slow_batch(); AP_PROF(3); } }
                 while (nsq) { slow_batch(); AP_PROF(3); }
             }
             AP_PROF(1);
