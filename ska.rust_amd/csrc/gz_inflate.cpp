@@ -346,81 +346,131 @@ int GzReader::Impl::block_head()
     return 0;
 }
 
-// the symbols of a Huffman block until its end, `out_limit`, or the end of the input in hand.  1: block finished, 0: come again, -1: bad data
-int GzReader::Impl::huff(size_t out_limit)
+// the symbols of a Huffman block until its end, `out_limit`, or the end of the input in hand.  1: block finished, 0: come again, -1: bad data.
+// What a read set's text decodes to is matches, not literals: in a 32 KB window of four letters nearly every stretch of 8 to 14 bases has been
+// seen before (a level-6 stream of reads: 14 bytes per match, one literal in fifty symbols), so the loop is built around the match -- the
+// next symbol's table entry is looked up BEFORE the copy of this match (the look-up's latency hides behind the copy), a match that
+// follows a refill directly decodes length and distance from the same 56 bits, the copy is two unconditional 16-byte moves (a loop only
+// beyond 32 bytes: its exit would be the one branch of the iteration that cannot be predicted), and the body is compiled twice, once for
+// processors with BMI2 (field extraction and shifts by a register count in one instruction each).
+namespace {
+template <typename Z>
+__attribute__((always_inline)) inline int huff_body(Z &z, size_t out_limit)
 {
-    uint8_t *const w = win.data();
-    const uint8_t *const ib = in.data();
-    size_t ip = in_pos, op = out_pos;
-    uint64_t bb = bitbuf; int bc = bitcnt;
+    uint8_t *const w = z.win.data();
+    const uint8_t *const ib = z.in.data();
+    const uint64_t *const lit = z.lit; const uint32_t *const dist = z.dist;
+    size_t ip = z.in_pos, op = z.out_pos;
+    uint64_t bb = z.bitbuf; int bc = z.bitcnt;
     bb &= bc >= 64 ? ~0ull : (((uint64_t)1 << bc) - 1u);
     // with the end of the file in hand the loop may run into the zeros behind it: every symbol is then checked against the input's end
-    const bool tail = in_eof && in_pos + 64 > in_end;
-    const size_t in_stop = tail ? in_end + 8 : (in_end >= 32 ? in_end - 32 : 0);
-    const size_t hist0 = member_start;
+    const bool tail = z.in_eof && z.in_pos + 64 > z.in_end;
+    const size_t in_end = z.in_end;
+    const size_t in_stop = tail ? in_end + 8 : (in_end >= 40 ? in_end - 40 : 0);
+    const size_t hist0 = z.member_start;
+    constexpr uint64_t LM = (1u << LIT_BITS) - 1u;
     int rc = 0;
 #define GZ_REFILL() do { bb |= load64(ib + ip) << bc; const int add_ = (63 - bc) >> 3; ip += (size_t)add_; bc += add_ * 8; } while (0)
 #define GZ_TAKE(n_) do { bb >>= (n_); bc -= (int)(n_); } while (0)
+#define GZ_LOW(n_) (bb & (((uint64_t)1 << (n_)) - 1u))
 #define GZ_PUT(e_) do { const uint64_t v_ = (e_) >> 16; memcpy(w + op, &v_, 8); op += ((e_) >> 8) & 15u; GZ_TAKE((e_) & 0xFFu); } while (0)
-    while (op < out_limit && ip <= in_stop) {
-        GZ_REFILL();
-        uint64_t e = lit[bb & ((1u << LIT_BITS) - 1u)];
-        // up to three entries of literals on one refill (33 of its 56 bits)
+#define GZ_TAILCHECK() if (tail && ip - (size_t)(bc >> 3) > in_end) { rc = -1; break; }
+    if (!(op < out_limit && ip <= in_stop)) return 0;
+    GZ_REFILL();
+    uint64_t e = lit[bb & LM];
+    for (;;) {
+        // here: at least 56 bits in hand, none of them taken since the refill, e = the entry of the next symbol
+        bool fresh = true;
         if ((e & 0xF000u) == 0) {
+            // up to three entries of literals on one refill (33 of its 56 bits)
             GZ_PUT(e);
-            e = lit[bb & ((1u << LIT_BITS) - 1u)];
+            e = lit[bb & LM];
             if ((e & 0xF000u) == 0) {
                 GZ_PUT(e);
-                e = lit[bb & ((1u << LIT_BITS) - 1u)];
+                e = lit[bb & LM];
                 if ((e & 0xF000u) == 0) {
                     GZ_PUT(e);
-                    if (tail && ip - (size_t)(bc >> 3) > in_end) { rc = -1; break; }
+                    GZ_TAILCHECK();
+                    if (!(op < out_limit && ip <= in_stop)) break;
+                    GZ_REFILL();
+                    e = lit[bb & LM];
                     continue;
                 }
             }
+            fresh = false;
         }
         uint32_t k = (uint32_t)kind_of(e);
-        if (k == K_SUB) {
+        if (__builtin_expect(k == K_SUB, 0)) {
             GZ_TAKE(LIT_BITS);
-            e = lit[((e >> 16) & 0xFFFFu) + (bb & (((uint64_t)1 << ((e >> 32) & 0xFFu)) - 1u))];
+            e = lit[((e >> 16) & 0xFFFFu) + GZ_LOW((e >> 32) & 0xFFu)];
             k = (uint32_t)kind_of(e);
-            if (k == K_LIT) { w[op++] = (uint8_t)(e >> 16); GZ_TAKE(e & 0xFFu); if (tail && ip - (size_t)(bc >> 3) > in_end) { rc = -1; break; } continue; }
+            fresh = false;
+            if (k == K_LIT) {
+                w[op++] = (uint8_t)(e >> 16); GZ_TAKE(e & 0xFFu);
+                GZ_TAILCHECK();
+                if (!(op < out_limit && ip <= in_stop)) break;
+                GZ_REFILL();
+                e = lit[bb & LM];
+                continue;
+            }
         }
-        if (k == K_EOB) { GZ_TAKE(e & 0xFFu); rc = 1; break; }
-        if (k != K_LEN) { rc = -1; break; }
+        if (__builtin_expect(k != K_LEN, 0)) { if (k == K_EOB) { GZ_TAKE(e & 0xFFu); rc = 1; } else rc = -1; break; }
         GZ_TAKE(e & 0xFFu);
         const uint32_t xl = (uint32_t)((e >> 32) & 0xFFu);
-        const size_t len = (size_t)((e >> 16) & 0xFFFFu) + (size_t)(bb & (((uint64_t)1 << xl) - 1u));
+        const size_t len = (size_t)((e >> 16) & 0xFFFFu) + (size_t)GZ_LOW(xl);
         GZ_TAKE(xl);
-        GZ_REFILL();
+        if (!fresh) GZ_REFILL();                         // (a length straight after the refill took 20 bits at most: the 28 of a distance are there)
         uint32_t d = dist[bb & ((1u << DIST_BITS) - 1u)];
-        if (((d >> 12) & 15u) == K_SUB) { GZ_TAKE(DIST_BITS); d = dist[(d >> 16) + (uint32_t)(bb & ((1u << ((d >> 8) & 15u)) - 1u))]; }
-        if (((d >> 12) & 15u) != K_DIST) { rc = -1; break; }
+        if (__builtin_expect(((d >> 12) & 15u) == K_SUB, 0)) { GZ_TAKE(DIST_BITS); d = dist[(d >> 16) + (uint32_t)GZ_LOW((d >> 8) & 15u)]; }
+        if (__builtin_expect(((d >> 12) & 15u) != K_DIST, 0)) { rc = -1; break; }
         GZ_TAKE(d & 0xFFu);
         const uint32_t xd = (d >> 8) & 15u;
-        const size_t back = (size_t)(d >> 16) + (size_t)(bb & (((uint64_t)1 << xd) - 1u));
+        const size_t back = (size_t)(d >> 16) + (size_t)GZ_LOW(xd);
         GZ_TAKE(xd);
-        if (back > op - hist0) { rc = -1; break; }
-        if (tail && ip - (size_t)(bc >> 3) > in_end) { rc = -1; break; }
-        uint8_t *o = w + op; const uint8_t *s = o - back; uint8_t *const oe = o + len;
-        if (back >= 16) {
-            do { __m128i v = _mm_loadu_si128((const __m128i *)s); _mm_storeu_si128((__m128i *)o, v); o += 16; s += 16; } while (o < oe);
-        } else if (back >= 8) {
-            do { uint64_t v; memcpy(&v, s, 8); memcpy(o, &v, 8); o += 8; s += 8; } while (o < oe);
-        } else if (back == 1) {
-            const uint64_t v = 0x0101010101010101ull * s[0];
-            do { memcpy(o, &v, 8); o += 8; } while (o < oe);
-        } else {
-            do { *o++ = *s++; } while (o < oe);
-        }
+        if (__builtin_expect(back > op - hist0, 0)) { rc = -1; break; }
+        GZ_TAILCHECK();
+        // the next symbol's entry, before this match is copied
+        GZ_REFILL();
+        e = lit[bb & LM];
+        uint8_t *o = w + op; const uint8_t *s = o - back;
         op += len;
+        if (__builtin_expect(back >= 16, 1)) {
+            _mm_storeu_si128((__m128i *)o, _mm_loadu_si128((const __m128i *)s));
+            _mm_storeu_si128((__m128i *)(o + 16), _mm_loadu_si128((const __m128i *)(s + 16)));
+            if (__builtin_expect(len > 32, 0)) {
+                uint8_t *const oe = o + len;
+                o += 32; s += 32;
+                do { _mm_storeu_si128((__m128i *)o, _mm_loadu_si128((const __m128i *)s)); o += 16; s += 16; } while (o < oe);
+            }
+        } else {
+            uint8_t *const oe = o + len;
+            if (back >= 8) {
+                do { uint64_t v; memcpy(&v, s, 8); memcpy(o, &v, 8); o += 8; s += 8; } while (o < oe);
+            } else if (back == 1) {
+                const uint64_t v = 0x0101010101010101ull * s[0];
+                do { memcpy(o, &v, 8); o += 8; } while (o < oe);
+            } else {
+                do { *o++ = *s++; } while (o < oe);
+            }
+        }
+        if (!(op < out_limit && ip <= in_stop)) break;
     }
 #undef GZ_REFILL
 #undef GZ_TAKE
+#undef GZ_LOW
 #undef GZ_PUT
-    in_pos = ip; out_pos = op; bitbuf = bb; bitcnt = bc;
-    if (rc == 1 && overrun()) return -1;
+#undef GZ_TAILCHECK
+    z.in_pos = ip; z.out_pos = op; z.bitbuf = bb; z.bitcnt = bc;
+    if (rc == 1 && z.overrun()) return -1;
     return rc;
+}
+template <typename Z> __attribute__((target("bmi2"))) int huff_bmi2(Z &z, size_t out_limit) { return huff_body(z, out_limit); }
+template <typename Z> int huff_plain(Z &z, size_t out_limit) { return huff_body(z, out_limit); }
+}  // namespace
+int GzReader::Impl::huff(size_t out_limit)
+{
+    static const bool bmi2 = __builtin_cpu_supports("bmi2") && !knob("no_bmi2");
+    return bmi2 ? huff_bmi2(*this, out_limit) : huff_plain(*this, out_limit);
 }
 
 int GzReader::Impl::trailer()
