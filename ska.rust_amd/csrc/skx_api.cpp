@@ -459,8 +459,6 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
     // -- sorted, folded, sub-indexed regions, so union / assemble treat reads and assemblies alike.  A sample the partition
     // kernels do not take (or regions the LDS sort cannot hold) sends the batch to the sort-based form above.
     auto build_bucketed_reads = [&]() -> int {
-        const bool wide_r = k > 31;
-        const int wpk_r = wide_r ? 2 : 1, kbits = 2 * (k - 1);
         std::vector<DevBuf<uint64_t>> wl(n), wh2(n);
         std::vector<uint64_t> cnt(n, 0);
         uint64_t maxn = 0;

@@ -234,6 +234,20 @@ int select_mapped(const uint32_t *row, uint64_t len, DevBuf<uint32_t> &mapped, u
 int sort_words_perm(const uint64_t *words, uint64_t n, DevBuf<uint64_t> &sorted, DevBuf<uint32_t> &perm, hipStream_t st);
 int sort_unique_wide(const u128 *in, uint64_t n, DevBuf<uint64_t> &out, uint64_t *n_out, hipStream_t st);
 int sort_wide_perm(const u128 *words, uint64_t n, DevBuf<uint64_t> &sorted, DevBuf<uint32_t> &perm, hipStream_t st);
+// the engine's own device primitives (skx_prims.hip): stable radix sorts (`bits` significant key bits, 8 a pass; the input is left as it is),
+// inclusive scans, order-keeping selections, unique on sorted keys, exclusive OR-scan within runs of equal keys.  Each returns with the stream idle.
+int prim_sort_keys_u64(const uint64_t *in, uint64_t *out, uint64_t n, int bits, hipStream_t st);
+int prim_sort_pairs_u64(const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout, uint64_t n, int bits, hipStream_t st);
+int prim_sort_keys_u128(const u128 *in, u128 *out, uint64_t n, int bits, hipStream_t st);
+int prim_sort_pairs_u128(const u128 *kin, u128 *kout, const uint32_t *vin, uint32_t *vout, uint64_t n, int bits, hipStream_t st);
+int prim_scan_add_u32(const uint32_t *in, uint32_t *out, uint64_t n, hipStream_t st);
+int prim_scan_max_u32(const uint32_t *in, uint32_t *out, uint64_t n, hipStream_t st);
+int prim_select_index_u8(const uint8_t *flags, uint32_t *out, uint64_t n, uint64_t *count, hipStream_t st);       // the positions of the flagged items
+int prim_select_index_u32(const uint32_t *flags, uint32_t *out, uint64_t n, uint64_t *count, hipStream_t st);
+int prim_select_u32(const uint32_t *in, const uint8_t *flags, uint32_t *out, uint64_t n, uint64_t *count, hipStream_t st);
+int prim_unique_u64(const uint64_t *sorted, uint64_t *out, uint64_t n, uint64_t *count, hipStream_t st);
+int prim_unique_keys_u128(const u128 *sorted, u128 *out, uint64_t n, uint64_t *count, hipStream_t st);             // equal = equal above the 4 base-set bits
+int prim_seg_exscan_or_u64(const uint32_t *keys, const uint64_t *vals, uint64_t *out, uint64_t n, hipStream_t st);
 // sorted duplicate-free copy of packed words (skx_setops.hip)
 int sort_unique_words(const uint64_t *in, uint64_t n, DevBuf<uint64_t> &out, uint64_t *n_out, hipStream_t st);
 // .skf codec (skf_codec.cpp)

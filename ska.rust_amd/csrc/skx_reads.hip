@@ -9,11 +9,10 @@
 //   min_count == 2 : every occurrence passes except t_1, which passes iff FP(h)
 //   min_count >= 3 : exactly the (min_count - FP(h))-th occurrence passes
 // so the device evaluates it with a stable sort by hash, a sort of the distinct hashes by (bloom word, first
-// occurrence) and a segmented prefix-OR.  Sorts/scans are rocPRIM device primitives (plain library calls on the
-// reads-only side path); everything specific to the path is hand-written below.
+// occurrence) and a segmented prefix-OR.  Sorts, scans and selections are the engine's own primitives (skx_prims.hip; rocPRIM calls
+// until round 5); everything specific to the path is below.
 #include <cstring>
 #include "skx_internal.h"
-#include <rocprim/rocprim.hpp>
 
 namespace skx {
 
@@ -255,44 +254,12 @@ struct BitOr64 { __host__ __device__ uint64_t operator()(uint64_t a, uint64_t b)
 
 namespace {
 inline unsigned grid_for(uint64_t n) { uint64_t g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 65535 ? 65535 : g)); }
-struct Temp {             // rocPRIM scratch, grown on demand
-    DevBuf<uint8_t> buf;
-    int need(size_t bytes) { if (bytes > buf.n) return buf.alloc(bytes + bytes / 4 + 256); return SKX_OK; }
-};
+struct Temp { };          // (the primitives of skx_prims.hip hold their own scratch)
 #define RP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail(e_, #call); } while (0)
 
-template <typename K, typename V>
-int sort_pairs(Temp &tmp, const K *kin, K *kout, const V *vin, V *vout, uint64_t n, hipStream_t st)
+inline int sort_pairs(Temp &, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout, uint64_t n, hipStream_t st)
 {
-    size_t bytes = 0;
-    RP(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0, sizeof(K) * 8, st));
-    SKX_TRY(tmp.need(bytes));
-    RP(rocprim::radix_sort_pairs(tmp.buf.p, bytes, kin, kout, vin, vout, n, 0, sizeof(K) * 8, st));
-    return SKX_OK;
-}
-template <typename T, typename Op>
-int incl_scan(Temp &tmp, const T *in, T *out, uint64_t n, Op op, hipStream_t st)
-{
-    size_t bytes = 0;
-    RP(rocprim::inclusive_scan(nullptr, bytes, in, out, n, op, st));
-    SKX_TRY(tmp.need(bytes));
-    RP(rocprim::inclusive_scan(tmp.buf.p, bytes, in, out, n, op, st));
-    return SKX_OK;
-}
-// indices (or values) of the flagged items; returns the count
-template <typename In, typename Out>
-int select_flagged(Temp &tmp, In in, const uint8_t *flags, Out *out, uint64_t n, uint64_t *count, hipStream_t st)
-{
-    DevBuf<size_t> d_cnt; SKX_TRY(d_cnt.alloc(1));
-    size_t bytes = 0;
-    RP(rocprim::select(nullptr, bytes, in, flags, out, d_cnt.p, n, st));
-    SKX_TRY(tmp.need(bytes));
-    RP(rocprim::select(tmp.buf.p, bytes, in, flags, out, d_cnt.p, n, st));
-    size_t c = 0;
-    RP(hipMemcpyAsync(&c, d_cnt.p, sizeof c, hipMemcpyDeviceToHost, st));
-    RP(hipStreamSynchronize(st));
-    *count = c;
-    return SKX_OK;
+    return prim_sort_pairs_u64(kin, kout, vin, vout, n, 64, st);                  // stable: equal keys keep their order
 }
 }  // namespace
 
@@ -421,7 +388,7 @@ int reads_sample_dict(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual,
     // candidate windows in stream order
     DevBuf<uint32_t> idx; SKX_TRY(idx.alloc(len));
     uint64_t m = 0;
-    SKX_TRY(select_flagged(tmp, rocprim::counting_iterator<uint32_t>(0), flag.p, idx.p, len, &m, st));
+    SKX_TRY(prim_select_index_u8(flag.p, idx.p, len, &m, st));
     if (m == 0) return SKX_OK;
 
     DevBuf<uint32_t> acc_t;            // stream positions of the windows that enter the dictionary
@@ -436,8 +403,8 @@ int reads_sample_dict(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual,
         DevBuf<uint32_t> head, startpos, gsum, start;
         SKX_TRY(head.alloc(m)); SKX_TRY(startpos.alloc(m)); SKX_TRY(gsum.alloc(m)); SKX_TRY(start.alloc(m));
         hipLaunchKernelGGL(heads_kernel, dim3(grid_for(m)), dim3(256), 0, st, hs.p, head.p, startpos.p, m);
-        SKX_TRY(incl_scan(tmp, head.p, gsum.p, m, rocprim::plus<uint32_t>(), st));
-        SKX_TRY(incl_scan(tmp, startpos.p, start.p, m, rocprim::maximum<uint32_t>(), st));
+        SKX_TRY(prim_scan_add_u32(head.p, gsum.p, m, st));
+        SKX_TRY(prim_scan_max_u32(startpos.p, start.p, m, st));
         uint32_t nd = 0;
         RP(hipMemcpyAsync(&nd, gsum.p + (m - 1), 4, hipMemcpyDeviceToHost, st));
         RP(hipStreamSynchronize(st));
@@ -447,19 +414,12 @@ int reads_sample_dict(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual,
         hipLaunchKernelGGL(distinct_kernel, dim3(grid_for(m)), dim3(256), 0, st, hs.p, ts.p, head.p, gsum.p, ckey.p, gidx.p, dhash.p, m);
         SKX_TRY(sort_pairs(tmp, ckey.p, cks.p, gidx.p, gs.p, nd, st));
         hipLaunchKernelGGL(fp_prepare_kernel, dim3(grid_for(nd)), dim3(256), 0, st, cks.p, gs.p, dhash.p, lockey.p, fpv.p, (uint64_t)nd);
-        {
-            size_t bytes = 0;
-            RP(rocprim::exclusive_scan_by_key(nullptr, bytes, lockey.p, fpv.p, prev.p, (uint64_t)0, nd, BitOr64(),
-                                              rocprim::equal_to<uint32_t>(), st));
-            SKX_TRY(tmp.need(bytes));
-            RP(rocprim::exclusive_scan_by_key(tmp.buf.p, bytes, lockey.p, fpv.p, prev.p, (uint64_t)0, nd, BitOr64(),
-                                              rocprim::equal_to<uint32_t>(), st));
-        }
+        SKX_TRY(prim_seg_exscan_or_u64(lockey.p, fpv.p, prev.p, nd, st));          // per bloom word: the OR of the fingerprints that came before
         hipLaunchKernelGGL(fp_decide_kernel, dim3(grid_for(nd)), dim3(256), 0, st, gs.p, fpv.p, prev.p, FP.p, (uint64_t)nd);
         DevBuf<uint8_t> acc; SKX_TRY(acc.alloc(m));
         hipLaunchKernelGGL(accept_kernel, dim3(grid_for(m)), dim3(256), 0, st, gsum.p, start.p, FP.p, acc.p, (int)q.min_count, m);
         SKX_TRY(acc_t.alloc(m));
-        SKX_TRY(select_flagged(tmp, ts.p, acc.p, acc_t.p, m, &m2, st));
+        SKX_TRY(prim_select_u32(ts.p, acc.p, acc_t.p, m, &m2, st));
         if (m2 == 0) return SKX_OK;
     }
 
@@ -468,10 +428,7 @@ int reads_sample_dict(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual,
     SKX_TRY(alo.alloc(m2)); SKX_TRY(slo.alloc(m2));
     hipLaunchKernelGGL(gather_u64_kernel, dim3(grid_for(m2)), dim3(256), 0, st, wlo.p, acc_t.p, alo.p, m2);
     if (!wide) {
-        size_t bytes = 0;
-        RP(rocprim::radix_sort_keys(nullptr, bytes, alo.p, slo.p, m2, 0, 64, st));
-        SKX_TRY(tmp.need(bytes));
-        RP(rocprim::radix_sort_keys(tmp.buf.p, bytes, alo.p, slo.p, m2, 0, 64, st));
+        SKX_TRY(prim_sort_keys_u64(alo.p, slo.p, m2, 64, st));
     } else {
         // 128-bit order = stable sort by the low word, then stable sort by the high word
         SKX_TRY(ahi.alloc(m2)); SKX_TRY(shi.alloc(m2));
@@ -487,7 +444,7 @@ int reads_sample_dict(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual,
     DevBuf<uint32_t> whead, whsum;
     SKX_TRY(whead.alloc(m2)); SKX_TRY(whsum.alloc(m2));
     hipLaunchKernelGGL(word_heads_kernel, dim3(grid_for(m2)), dim3(256), 0, st, slo.p, wide ? shi.p : nullptr, whead.p, m2);
-    SKX_TRY(incl_scan(tmp, whead.p, whsum.p, m2, rocprim::plus<uint32_t>(), st));
+    SKX_TRY(prim_scan_add_u32(whead.p, whsum.p, m2, st));
     uint32_t nu = 0;
     RP(hipMemcpyAsync(&nu, whsum.p + (m2 - 1), 4, hipMemcpyDeviceToHost, st));
     RP(hipStreamSynchronize(st));
@@ -524,6 +481,11 @@ __global__ void and_not15_kernel(uint64_t *v, uint64_t n)
 {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) v[i] &= ~15ull;
 }
+__global__ void run_lengths_kernel(const uint32_t *starts, uint64_t nr, uint64_t n, uint32_t *len)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < nr; i += (uint64_t)gridDim.x * blockDim.x)
+        len[i] = (uint32_t)((i + 1 < nr ? (uint64_t)starts[i + 1] : n) - starts[i]);
+}
 __global__ void count_hist_kernel(const uint32_t *counts, uint64_t n, uint32_t *hist)
 {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
@@ -540,17 +502,14 @@ int cov_histogram(skx_ctx *ctx, const uint8_t *d_seq, uint64_t len, int k, int r
     SKX_TRY(ref_windows(ctx, d_seq, len, k, rc, wlo, whi, flag));
     DevBuf<uint32_t> idx; SKX_TRY(idx.alloc(len));
     uint64_t m = 0;
-    SKX_TRY(select_flagged(tmp, rocprim::counting_iterator<uint32_t>(0), flag.p, idx.p, len, &m, st));
+    SKX_TRY(prim_select_index_u8(flag.p, idx.p, len, &m, st));
     if (m == 0) return SKX_OK;
     DevBuf<uint64_t> lo, slo, hi, shi;
     SKX_TRY(lo.alloc(m)); SKX_TRY(slo.alloc(m));
     hipLaunchKernelGGL(gather_u64_kernel, dim3(grid_for(m)), dim3(256), 0, st, wlo.p, idx.p, lo.p, m);
     hipLaunchKernelGGL(and_not15_kernel, dim3(grid_for(m)), dim3(256), 0, st, lo.p, m);       // the middle base does not count (kmer only)
     if (!wide) {
-        size_t bytes = 0;
-        RP(rocprim::radix_sort_keys(nullptr, bytes, lo.p, slo.p, m, 0, 64, st));
-        SKX_TRY(tmp.need(bytes));
-        RP(rocprim::radix_sort_keys(tmp.buf.p, bytes, lo.p, slo.p, m, 0, 64, st));
+        SKX_TRY(prim_sort_keys_u64(lo.p, slo.p, m, 64, st));
     } else {
         // order by (hi, lo): stable LSD passes
         DevBuf<uint32_t> iota, p1, p2; DevBuf<uint64_t> h1;
@@ -562,17 +521,13 @@ int cov_histogram(skx_ctx *ctx, const uint8_t *d_seq, uint64_t len, int k, int r
         SKX_TRY(sort_pairs(tmp, h1.p, shi.p, p1.p, p2.p, m, st));
         hipLaunchKernelGGL(gather_u64_kernel, dim3(grid_for(m)), dim3(256), 0, st, lo.p, p2.p, slo.p, m);
     }
-    DevBuf<uint32_t> head, gid, runs, rcnt; DevBuf<size_t> nruns;
-    SKX_TRY(head.alloc(m)); SKX_TRY(gid.alloc(m)); SKX_TRY(runs.alloc(m)); SKX_TRY(rcnt.alloc(m)); SKX_TRY(nruns.alloc(1));
+    // run lengths = occurrence counts: where the runs of equal split k-mers start, then the distances between the starts
+    DevBuf<uint32_t> head, starts, rcnt;
+    SKX_TRY(head.alloc(m)); SKX_TRY(starts.alloc(m)); SKX_TRY(rcnt.alloc(m));
     hipLaunchKernelGGL(word_heads_kernel, dim3(grid_for(m)), dim3(256), 0, st, slo.p, wide ? shi.p : nullptr, head.p, m);
-    SKX_TRY(incl_scan(tmp, head.p, gid.p, m, rocprim::plus<uint32_t>(), st));
-    size_t bytes = 0;
-    RP(rocprim::run_length_encode(nullptr, bytes, gid.p, (unsigned int)m, runs.p, rcnt.p, nruns.p, st));
-    SKX_TRY(tmp.need(bytes));
-    RP(rocprim::run_length_encode(tmp.buf.p, bytes, gid.p, (unsigned int)m, runs.p, rcnt.p, nruns.p, st));
-    size_t nr = 0;
-    RP(hipMemcpyAsync(&nr, nruns.p, sizeof nr, hipMemcpyDeviceToHost, st));
-    RP(hipStreamSynchronize(st));
+    uint64_t nr = 0;
+    SKX_TRY(prim_select_index_u32(head.p, starts.p, m, &nr, st));
+    hipLaunchKernelGGL(run_lengths_kernel, dim3(grid_for(nr)), dim3(256), 0, st, starts.p, nr, m, rcnt.p);
     hipLaunchKernelGGL(count_hist_kernel, dim3(grid_for(nr)), dim3(256), 0, st, rcnt.p, (uint64_t)nr, d_hist);
     RP(hipStreamSynchronize(st));
     return SKX_OK;
@@ -613,7 +568,8 @@ int select_mapped(const uint32_t *row, uint64_t len, DevBuf<uint32_t> &mapped, u
     Temp tmp; DevBuf<uint8_t> found;
     SKX_TRY(found.alloc(len)); SKX_TRY(mapped.alloc(len));
     hipLaunchKernelGGL(row_found_kernel, dim3(grid_for(len)), dim3(256), 0, st, row, found.p, len);
-    return select_flagged(tmp, rocprim::counting_iterator<uint32_t>(0), found.p, mapped.p, len, m, st);
+    (void)tmp;
+    return prim_select_index_u8(found.p, mapped.p, len, m, st);
 }
 // sorted copy of unsorted array keys with the permutation back to rows (arrays loaded from a file keep the file's order)
 int sort_words_perm(const uint64_t *words, uint64_t n, DevBuf<uint64_t> &sorted, DevBuf<uint32_t> &perm, hipStream_t st)

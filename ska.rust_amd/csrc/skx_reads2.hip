@@ -347,7 +347,6 @@ __global__ __launch_bounds__(WR_NT) void words_regions_kernel(const uint64_t *in
     }
 }
 
-static inline unsigned grid_of(uint64_t n, unsigned per = 256) { uint64_t g = (n + per - 1) / per; return (unsigned)(g < 1 ? 1 : (g > 262144 ? 262144 : g)); }
 
 void launch_words_regions(bool count, const uint64_t *in_lo, const uint64_t *in_hi, uint64_t n, int bits, int logB, uint64_t region0, uint32_t *raw,
                           const uint64_t *off, uint32_t *cursor, uint64_t *words, hipStream_t st)

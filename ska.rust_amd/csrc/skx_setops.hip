@@ -2,16 +2,14 @@
 //   `ska merge`  : to_dict + MergeSkaDict::extend + MergeSkaArray::new   (generic_modes.rs:90-106, merge_ska_dict.rs:160-193)
 //   `ska weed`   : MergeSkaArray::weed                                   (merge_ska_array.rs:452-487)
 // Rows are identified by their packed word (H(key) << 4 | 1), so "same split k-mer" is one 64-bit compare and every
-// set operation is a sort / search in the order of H.  The sort and the run-length unique are rocPRIM device
-// primitives (plain library calls); the look-ups and the column scatter are hand-written below.
+// set operation is a sort / search in the order of H.  The sort and the unique are the engine's own primitives
+// (skx_prims.hip: stable LSD radix sort, compaction; rocPRIM calls until round 5); the look-ups and the column scatter are below.
 #include <algorithm>
 #include <cstring>
 #include "skx_internal.h"
-#include <rocprim/rocprim.hpp>
 
 namespace skx {
 
-#define RPS(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s: %s", #x, hipGetErrorString(e_)); return SKX_ENODEV; } } while (0)
 
 // sorted, duplicate-free copy of `n` packed words (any order, duplicates allowed) -> out[0 .. *n_out)
 int sort_unique_words(const uint64_t *in, uint64_t n, DevBuf<uint64_t> &out, uint64_t *n_out, hipStream_t st)
@@ -19,21 +17,10 @@ int sort_unique_words(const uint64_t *in, uint64_t n, DevBuf<uint64_t> &out, uin
     *n_out = 0;
     if (!n) return SKX_OK;
     if (n > 0x7FFFFFFFull) { set_error("more than 2^31 rows in one row-set operation"); return SKX_EUNSUP; }
-    DevBuf<uint64_t> sorted; DevBuf<unsigned char> tmp; DevBuf<unsigned int> d_cnt;
-    SKX_TRY(sorted.alloc(n)); SKX_TRY(out.alloc(n)); SKX_TRY(d_cnt.alloc(1));
-    size_t bytes = 0;
-    RPS(rocprim::radix_sort_keys(nullptr, bytes, in, sorted.p, (unsigned int)n, 0, 64, st));
-    SKX_TRY(tmp.alloc(bytes ? bytes : 1));
-    RPS(rocprim::radix_sort_keys(tmp.p, bytes, in, sorted.p, (unsigned int)n, 0, 64, st));
-    size_t bytes2 = 0;
-    RPS(rocprim::unique(nullptr, bytes2, sorted.p, out.p, d_cnt.p, (unsigned int)n, rocprim::equal_to<uint64_t>(), st));
-    DevBuf<unsigned char> tmp2; SKX_TRY(tmp2.alloc(bytes2 ? bytes2 : 1));
-    RPS(rocprim::unique(tmp2.p, bytes2, sorted.p, out.p, d_cnt.p, (unsigned int)n, rocprim::equal_to<uint64_t>(), st));
-    unsigned int cnt = 0;
-    RPS(hipMemcpyAsync(&cnt, d_cnt.p, 4, hipMemcpyDeviceToHost, st));
-    RPS(hipStreamSynchronize(st));
-    *n_out = cnt;
-    return SKX_OK;
+    DevBuf<uint64_t> sorted;
+    SKX_TRY(sorted.alloc(n)); SKX_TRY(out.alloc(n));
+    SKX_TRY(prim_sort_keys_u64(in, sorted.p, n, 64, st));
+    return prim_unique_u64(sorted.p, out.p, n, n_out, st);
 }
 
 // position of every word in a sorted, duplicate-free word list (compare on word >> 4); 0xFFFFFFFF when absent
@@ -79,28 +66,16 @@ void launch_hash_keys_wide(const u128 *keys, u128 *words, uint64_t n, const Wide
     const unsigned g = (unsigned)std::min<uint64_t>((n + 255) / 256, 4096);
     hipLaunchKernelGGL(hash_keys_wide_kernel, dim3(g), dim3(256), 0, st, keys, words, n, wh);
 }
-struct same_key_bits { __host__ __device__ bool operator()(const u128 &a, const u128 &b) const { return (a >> 4) == (b >> 4); } };
 // sort_unique_words for 128-bit words (out holds 2 x u64 per word)
 int sort_unique_wide(const u128 *in, uint64_t n, DevBuf<uint64_t> &out, uint64_t *n_out, hipStream_t st)
 {
     *n_out = 0;
     if (!n) return SKX_OK;
     if (n > 0x7FFFFFFFull) { set_error("more than 2^31 rows in one row-set operation"); return SKX_EUNSUP; }
-    DevBuf<uint64_t> sorted; DevBuf<unsigned char> tmp; DevBuf<unsigned int> d_cnt;
-    SKX_TRY(sorted.alloc(2 * n)); SKX_TRY(out.alloc(2 * n)); SKX_TRY(d_cnt.alloc(1));
-    size_t bytes = 0;
-    RPS(rocprim::radix_sort_keys(nullptr, bytes, in, (u128 *)sorted.p, (unsigned int)n, 0, 128, st));
-    SKX_TRY(tmp.alloc(bytes ? bytes : 1));
-    RPS(rocprim::radix_sort_keys(tmp.p, bytes, in, (u128 *)sorted.p, (unsigned int)n, 0, 128, st));
-    size_t bytes2 = 0;
-    RPS(rocprim::unique(nullptr, bytes2, (const u128 *)sorted.p, (u128 *)out.p, d_cnt.p, (unsigned int)n, same_key_bits(), st));
-    DevBuf<unsigned char> tmp2; SKX_TRY(tmp2.alloc(bytes2 ? bytes2 : 1));
-    RPS(rocprim::unique(tmp2.p, bytes2, (const u128 *)sorted.p, (u128 *)out.p, d_cnt.p, (unsigned int)n, same_key_bits(), st));
-    unsigned int cnt = 0;
-    RPS(hipMemcpyAsync(&cnt, d_cnt.p, 4, hipMemcpyDeviceToHost, st));
-    RPS(hipStreamSynchronize(st));
-    *n_out = cnt;
-    return SKX_OK;
+    DevBuf<uint64_t> sorted;
+    SKX_TRY(sorted.alloc(2 * n)); SKX_TRY(out.alloc(2 * n));
+    SKX_TRY(prim_sort_keys_u128(in, (u128 *)sorted.p, n, 128, st));
+    return prim_unique_keys_u128((const u128 *)sorted.p, (u128 *)out.p, n, n_out, st);      // one word per key: equal above the base-set bits
 }
 __global__ __launch_bounds__(256) void iota_rows_kernel(uint32_t *v, uint64_t n)
 {
@@ -110,17 +85,12 @@ __global__ __launch_bounds__(256) void iota_rows_kernel(uint32_t *v, uint64_t n)
 // sort_words_perm for 128-bit words: sorted copy + the row each sorted word came from
 int sort_wide_perm(const u128 *words, uint64_t n, DevBuf<uint64_t> &sorted, DevBuf<uint32_t> &perm, hipStream_t st)
 {
-    DevBuf<uint32_t> iota; DevBuf<unsigned char> tmp;
+    DevBuf<uint32_t> iota;
     SKX_TRY(sorted.alloc(2 * n)); SKX_TRY(perm.alloc(n)); SKX_TRY(iota.alloc(n));
     if (!n) return SKX_OK;
     if (n > 0x7FFFFFFFull) { set_error("more than 2^31 rows in one row-set operation"); return SKX_EUNSUP; }
     hipLaunchKernelGGL(iota_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, iota.p, n);
-    size_t bytes = 0;
-    RPS(rocprim::radix_sort_pairs(nullptr, bytes, words, (u128 *)sorted.p, iota.p, perm.p, (unsigned int)n, 0, 128, st));
-    SKX_TRY(tmp.alloc(bytes ? bytes : 1));
-    RPS(rocprim::radix_sort_pairs(tmp.p, bytes, words, (u128 *)sorted.p, iota.p, perm.p, (unsigned int)n, 0, 128, st));
-    RPS(hipStreamSynchronize(st));
-    return SKX_OK;
+    return prim_sort_pairs_u128(words, (u128 *)sorted.p, iota.p, perm.p, n, 128, st);
 }
 // map_lookup for 128-bit words: the window words arrive as two 64-bit halves
 __global__ __launch_bounds__(256) void map_lookup_wide_kernel(const uint64_t *wlo, const uint64_t *whi, const uint8_t *flag, const uint8_t *seq, uint64_t len,
