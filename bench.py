@@ -357,13 +357,23 @@ def preflight(args, world):
     any rank of the bench opens its device, and the bench stops with that message when it fails."""
     ska = os.path.join(ROOT, "ska.rust_amd", "ska")
     t0 = time.perf_counter()
+    # A failed pre-flight is reported -- on stderr at once, and in the line's `selftest` -- and the timed run goes ahead: the self-test
+    # covers more than the bench uses (the host-staged transport, the gather to rank 0), and a bench that can run should leave its line.
+    # What the bench itself needs and does not get fails it loudly further down (SKX_BENCH_STRICT_SELFTEST=1: stop here instead).
+    def failed(why):
+        sys.stderr.write(f"bench.py: `ska selftest --gpus {world}` {why}\n")
+        if os.environ.get("SKX_BENCH_STRICT_SELFTEST") == "1":
+            raise SystemExit(f"bench.py: `ska selftest --gpus {world}` {why}")
+        return {"seconds": time.perf_counter() - t0, "failed": why}
     try:
         r = subprocess.run([ska, "selftest", "--gpus", str(world)], capture_output=True, timeout=180)
     except subprocess.TimeoutExpired:
-        raise SystemExit(f"bench.py: `ska selftest --gpus {world}` did not finish in 180 s")
+        return failed("did not finish in 180 s")
+    except OSError as e:
+        return failed(f"could not be started: {e}")
     msg = r.stderr.decode(errors="replace").strip().splitlines()
     if r.returncode != 0:
-        raise SystemExit(f"bench.py: `ska selftest --gpus {world}` failed (rc {r.returncode}): " + " | ".join(msg[-4:]))
+        return failed(f"failed (rc {r.returncode}): " + " | ".join(msg[-4:]))
     return {"seconds": time.perf_counter() - t0, "report": msg[-1] if msg else ""}
 
 
