@@ -1829,7 +1829,7 @@ static int append_pass(skx_ctx *ctx, skx_dictset *d, std::unique_ptr<skx_keyset>
             while (g > (uint64_t)std::max(cus, 1) && g % 2 == 0) g /= 2;
             if (g <= (uint64_t)std::max(cus, 1) && nsub % g == 0 && g % (8 * amp) == 0 && logB >= 3) {
                 aa.rounds = (uint32_t)(nsub / g);
-                SKX_TRY(d_bar.alloc(1ull << logB)); SKX_TRY(d_bar.zero(st)); aa.bar = d_bar.p;
+                SKX_TRY(d_bar.alloc(2ull << logB)); SKX_TRY(d_bar.zero(st)); aa.bar = d_bar.p;      // (second half: the readers' meetings inside a round)
             }
         }
         aa.pieces = pc->data.p; aa.plen = pc->plen.p; aa.perm = pc->perm.p; aa.nrank = pc->nrank.p;

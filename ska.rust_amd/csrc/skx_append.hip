@@ -84,6 +84,9 @@ constexpr uint32_t AP_Q = 256, AP_SQ = 64;  // a wave's queue of kept words: the
 #ifndef AP_CH_N
 #define AP_CH_N 8
 #endif
+#ifndef AP_RESYNC
+#define AP_RESYNC 16
+#endif
 constexpr int AP_CH = AP_CH_N;              // 16-byte loads per lane and chunk: a wave reads 128 x AP_CH words at a time
 constexpr int AP_RANK_BITS = 14;
 constexpr uint32_t AP_RANK_MASK = (1u << AP_RANK_BITS) - 1;
@@ -504,6 +507,24 @@ __global__ __launch_bounds__(AP_THREADS) void append_kernel(AppendArgs a)
                 AP_PROF(4);
                 if (!more) break;
                 s += AP_WAVES; c = 0; off_c = off_n; cnt_c = cnt_n;
+                // The readers of a region meet again every AP_RESYNC samples of a wave: the workgroup's waves at a barrier, then the region's A
+                // workgroups through a counter (bounded).  Readers that drift apart fetch a region's lines up to A times: without the meetings
+                // FETCH_SIZE x 2 is 54.5 GB for the 40 GB of words of 1 000 x 5 Mbp, with one every 16 samples 43.8 GB -- for 0.15 ms of the pass's
+                // 15.7 (profiles/r05n, r05o; every 4: 42.3 GB and + 0.9 ms; per-wave meetings without the barrier cost more: the waiting waves
+                // take issue slots, r05p).  0 = none.
+                if (AP_RESYNC > 0) {
+                    const int it = (s - wv) / AP_WAVES;                       // the wave's sample number (the same count in every wave up to S / 16)
+                    if (xmap && A > 1u && a.bar && it % (AP_RESYNC > 0 ? AP_RESYNC : 1) == 0 && it <= (S - AP_WAVES) / AP_WAVES) {
+                        __syncthreads();
+                        if (tid == 0) {
+                            int *ctr = a.bar + (1 << a.logB) + region;
+                            const int want = (int)A * (it / (AP_RESYNC > 0 ? AP_RESYNC : 1));
+                            atomicAdd(ctr, 1);
+                            for (int spin = 0; spin < (1 << 16) && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want; spin++) __builtin_amdgcn_s_sleep(4);
+                        }
+                        __syncthreads();
+                    }
+                }
             } else c++;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the chunk asked for after the last one)
