@@ -322,6 +322,9 @@ def end_to_end(args, files, td, device=0):
     # 2. the conditioned chain.  Each independent measurement starts on a box that has been idle for a few seconds: VRAM another process has
     # just released is wiped by the driver before it is handed out again, and an allocation of tens of GB made right after waits for it
     # (DESIGN.md section 8).  The chain `ska build` -> `ska align x.skf` is one measurement and runs back to back, as a user's script would.
+    # (the cold chain's .skf goes first: overwriting it would charge `ska build` for giving back the 2.8 GB of the old file -- 0.3 s of tmpfs
+    # page frees inside its fopen -- which is no part of a build that writes a new file)
+    os.unlink(os.path.join(td, "all.skf"))
     warm_device(device)
     time.sleep(max(args.settle_s, 0.0))
     tb, pb = run_cli(ska, build_argv, td, os.path.join(td, "ph_build.json"), env_dev)
