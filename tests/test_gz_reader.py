@@ -194,3 +194,47 @@ def test_gz_reader_member_checksums_at_every_length(tmp_path):
     for knobs in ("no_clmul", "zlib_reader"):
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SKX_KNOBS=knobs), capture_output=True, text=True, check=True).stdout.strip()
         assert out == hashlib.sha1(b"".join(expect)).hexdigest(), knobs
+
+
+def test_gz_reader_random_streams(tmp_path):
+    """Seeded streams of every zlib strategy (default, filtered, Huffman only, RLE, fixed codes), level 0-9, window 2^9-2^15, memLevel 1-9, over
+    five kinds of bytes (uniform, four letters, long runs, short periods, re-used stretches), cut into up to three members: the records that
+    come out are the bytes that went in."""
+    rnd = random.Random(7)
+    allowed = np.array([b for b in range(32, 127) if b != ord(">")], dtype=np.uint8)
+    p = str(tmp_path / "f.fa.gz")
+
+    def payload(kind, n):
+        rng = np.random.default_rng(rnd.randrange(1 << 30))
+        if kind == 0:
+            return allowed[rng.integers(0, len(allowed), n)].tobytes()
+        if kind == 1:
+            return allowed[rng.integers(0, 4, n)].tobytes()
+        if kind == 2:
+            out = bytearray()
+            while len(out) < n:
+                out += bytes([int(allowed[rng.integers(0, len(allowed))])]) * int(rng.integers(1, 600))
+            return bytes(out[:n])
+        if kind == 3:
+            unit = allowed[rng.integers(0, len(allowed), int(rng.integers(1, 40)))].tobytes()
+            return (unit * (n // len(unit) + 1))[:n]
+        base = allowed[rng.integers(0, 8, 5000)].tobytes()
+        out = bytearray()
+        while len(out) < n:
+            o = int(rng.integers(0, 4900))
+            out += base[o:o + int(rng.integers(3, 300))]
+        return bytes(out[:n])
+
+    for it in range(80):
+        kind = rnd.randrange(5)
+        n = rnd.choice([0, 1, 5, 100, 70_000, 300_000, 1_100_000]) + rnd.randrange(50)
+        body = payload(kind, n)
+        text = b">r\n" + body + b"\n"
+        cuts = sorted(rnd.sample(range(1, len(text)), min(len(text) - 1, rnd.randrange(0, 3))))
+        parts = [text[a:b] for a, b in zip([0] + cuts, cuts + [len(text)])]
+        blob = b"".join(_gz_member(pt, level=rnd.randrange(0, 10), wbits=rnd.randrange(9, 16),
+                                   strategy=rnd.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED])) for pt in parts)
+        with open(p, "wb") as f:
+            f.write(blob)
+        s, q = E.read_records(p)
+        assert q is None and s == body + b"\n", (it, kind, n)
