@@ -102,6 +102,7 @@ __global__ __launch_bounds__(RS_NT) void rs_scatter_kernel(RsArgs a)
 // WPP = bloom words per final partition: 48 (65 536 partitions; samples of up to ~160 M windows), 24 (131 072) or 12 (262 144 partitions).
 // 1 024 threads x 4 records, 69 KB of LDS: two workgroups per CU.
 constexpr int RG_NT = 1024, RG_ITEMS = 4, RG_CAP = RG_NT * RG_ITEMS, RG_MB = 48 * 64;       // micro-bucket = (bloom word, top bits of the fraction)
+constexpr int RG_PAD = 8;                                                                     // records behind the last one that the rank step may read
 struct RgArgs { const uint64_t *h; const uint32_t *t; const uint32_t *cnt; uint64_t cap; int min_count; uint32_t *out_t; unsigned long long *out_n; int *overflow; unsigned long long *dbg; };
 #define RG_MARK(i) do { if (a.dbg && threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&a.dbg[i], now_ - t_mark); t_mark = now_; } } while (0)
 template <int WPP>
@@ -112,6 +113,16 @@ __device__ static inline uint32_t micro_of(uint64_t m, uint32_t loc0, uint32_t &
     loc_rel = loc_of(m) - loc0;
     return loc_rel * (1u << FB) + (uint32_t)(frac >> (64 - FB));
 }
+// less += (mq, tq) < (m, tt) as 96-bit numbers: a subtract-with-borrow chain whose last borrow is added (4 vector instructions; the
+// compiler's form of the same comparison -- two 64-bit compares, an equality and their selects -- came to 16)
+__device__ static inline void add_if_below(uint32_t &less, uint64_t mq, uint32_t tq, uint64_t m, uint32_t tt)
+{
+    uint32_t scratch;
+    asm("v_sub_co_u32 %1, vcc, %2, %5\n\tv_subb_co_u32 %1, vcc, %3, %6, vcc\n\tv_subb_co_u32 %1, vcc, %4, %7, vcc\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc"
+        : "+v"(less), "=&v"(scratch)
+        : "v"(tq), "v"((uint32_t)mq), "v"((uint32_t)(mq >> 32)), "v"(tt), "v"((uint32_t)m), "v"((uint32_t)(m >> 32))
+        : "vcc");
+}
 template <int WPP>
 #ifndef SKX_RG_STEP
 #define SKX_RG_STEP 4
@@ -120,8 +131,8 @@ __global__ __launch_bounds__(RG_NT, 8) void rs_groups_kernel(RgArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
     uint64_t *s_m = reinterpret_cast<uint64_t *>(s_mem);                  // [RG_CAP] mix(hash) sorted; then, at group heads, the hash's bloom fingerprint
-    uint32_t *s_t = reinterpret_cast<uint32_t *>(s_m + RG_CAP);            // [RG_CAP] stream position
-    uint32_t *s_cnt = s_t + RG_CAP + 1;                                    // [-1] = 0 | [RG_MB] counts -> cursors (= micro-bucket ends)
+    uint32_t *s_t = reinterpret_cast<uint32_t *>(s_m + RG_CAP + RG_PAD);   // [RG_CAP] stream position
+    uint32_t *s_cnt = s_t + RG_CAP + RG_PAD + 1;                                    // [-1] = 0 | [RG_MB] counts -> cursors (= micro-bucket ends)
     uint8_t *s_loc = reinterpret_cast<uint8_t *>(s_cnt + RG_MB + 1);       // [RG_CAP] bloom word inside the partition (0..47)
     __shared__ uint32_t s_tmp[17];
     __shared__ unsigned long long s_gb;
@@ -175,6 +186,7 @@ __global__ __launch_bounds__(RG_NT, 8) void rs_groups_kernel(RgArgs a)
 #pragma unroll
     for (int j = 0; j < RG_ITEMS; j++)
         if (e_mb[j] != 0xFFFFFFFFu) { const uint32_t o = atomicAdd(&s_cnt[e_mb[j]], 1u); s_m[o] = e_m[j]; s_t[o] = e_t[j]; }
+    if (threadIdx.x < (uint32_t)RG_PAD) { s_m[n + threadIdx.x] = ~0ull; s_t[n + threadIdx.x] = ~0u; }      // (2^64 - 1, 2^32 - 1): below no record
     __syncthreads();
     RG_MARK(1);
     // rank inside the micro-bucket by (m, position): positions are unique, so there are no ties
@@ -187,23 +199,17 @@ __global__ __launch_bounds__(RG_NT, 8) void rs_groups_kernel(RgArgs a)
         const uint64_t m = s_m[p]; const uint32_t tt = s_t[p];
         uint32_t lr; const uint32_t mb = micro_of<WPP>(m, loc0, lr);
         const uint32_t b = s_cnt[(int)mb - 1], e = s_cnt[mb];
-        // (m, position) compared as one 96-bit number (a subtract-with-borrow chain instead of two compares and their logic); the slots
-        // behind the bucket's end re-read its last record, whose verdict is taken off again once
-        typedef unsigned __int128 u128_t;
-        const u128_t mine = ((u128_t)m << 32) | tt;
+        // A step reads past the bucket's end without a clamp: what lies there are the records of the following micro-buckets, whose m is
+        // larger (the micro-bucket index is monotone in m), and behind the last record the pad, which is below nothing
         uint32_t less = 0;
         constexpr uint32_t RS = SKX_RG_STEP;                                     // independent LDS reads in flight per step (a k-mer of a 50x isolate fills its
-        for (uint32_t q = b; q < e; q += RS) {                                  // micro-bucket with ~35 records)
+        static_assert(RS <= (uint32_t)RG_PAD, "the pad covers one step");        // micro-bucket with ~35 records)
+        for (uint32_t q = b; q < e; q += RS) {
             uint64_t mq[RS]; uint32_t tq[RS];
 #pragma unroll
-            for (uint32_t u = 0; u < RS; u++) { const uint32_t qq = q + u < e ? q + u : e - 1; mq[u] = s_m[qq]; tq[u] = s_t[qq]; }
+            for (uint32_t u = 0; u < RS; u++) { mq[u] = s_m[q + u]; tq[u] = s_t[q + u]; }
 #pragma unroll
-            for (uint32_t u = 0; u < RS; u++) less += ((((u128_t)mq[u] << 32) | tq[u]) < mine) ? 1u : 0u;
-        }
-        {
-            const uint32_t g = e - b, extra = ((g + RS - 1u) / RS) * RS - g;
-            const uint64_t ml = s_m[e - 1]; const uint32_t tl = s_t[e - 1];
-            if ((((u128_t)ml << 32) | tl) < mine) less -= extra;
+            for (uint32_t u = 0; u < RS; u++) add_if_below(less, mq[u], tq[u], m, tt);
         }
         npos[j] = b + less; e_m[j] = m; e_t[j] = tt; e_mb[j] = lr;
     }
@@ -414,7 +420,7 @@ int reads_sample_words(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual
     DevBuf<unsigned long long> d_dbg;
     if (getenv("SKX_DEBUG")) { SKX_TRY(d_dbg.alloc(8)); SKX_TRY(d_dbg.zero(st)); }
     RgArgs ag{h2.p, t2.p, c2.p, cap2, (int)q.min_count, acc_t.p, d_n.p, d_over.p, d_dbg.p};
-    const size_t lds = (size_t)RG_CAP * 12 + ((size_t)RG_MB + 2) * 4 + (size_t)RG_CAP * 2 + 64;
+    const size_t lds = (size_t)(RG_CAP + RG_PAD) * 12 + ((size_t)RG_MB + 2) * 4 + (size_t)RG_CAP * 2 + 64;
     if (mid) {
         hipLaunchKernelGGL((rs_scatter_kernel<24 * 256, 512, true>), g1, dim3(RS_NT), 0, st, a1);
         hipLaunchKernelGGL((rs_scatter_kernel<24, 256, false>), g2, dim3(RS_NT), 0, st, a2);
