@@ -29,71 +29,139 @@ struct ReadsArgs {
     const uint64_t *planes;           // optional: the sample as packed bit planes (skx_device.h planes_bytes16) instead of seq / qual
 };
 
-// Eight consecutive window-end positions per thread: the state of the window before the first one is built from its k
-// bytes, the rest roll (arms, reverse-complement arms, both ntHash strands, the length of the clean run).  The workgroup's
-// 2 048 results per array go through one LDS buffer, array after array, position-major (row stride 264: conflict-free both
-// ways), and leave as contiguous 16 KB pieces -- a per-thread store of its own 64 bytes per array would cost one L2
-// request per 8 bytes, and parking all three arrays at once would leave two workgroups per CU.
+// Sixteen consecutive window-end positions per thread (two batches of eight).
+//   * the tile's text never lies in LDS as bytes: whoever loads 16 positions (16 + 16 bytes, or a slice of the packed planes) boils them down
+//     to 32 code bits and three 16-bit masks -- rejected base, line end, quality below the threshold -- and stores those 10 bytes.  Everything a
+//     thread needs afterwards is a few words of these arrays at uniform offsets from its own index: the 64 positions before its first (window
+//     state, clean run), its sixteen, the bases that leave its windows (k back), the middle bases' verdicts (h back).  (The byte form cost four
+//     dependent LDS round trips per position: base, leaving base, their table words, quality -- half the kernel's time was waiting for them.)
+//   * the state of the window before the first position is built from its k codes with a table of pre-rotated ntHash words; the rest roll, one
+//     16-byte table entry per position: [leaving base][entering base] -> what the two strands' hashes are XORed with.
+//   * the workgroup's 2 048 hashes per batch go through one LDS buffer position-major (row stride 264: conflict-free both ways) and leave as
+//     contiguous 16 KB pieces -- a per-thread store of its own 64 bytes would cost one L2 request per 8 bytes; the flags leave as one
+//     16-byte store per thread.
 #ifndef SKX_RW_NB
 #define SKX_RW_NB 2
 #endif
-// RW_NB batches of RW_PPT positions per thread, one after the other: the window state is built once per RW_NB * RW_PPT positions (building it
-// from its k bytes costs more than rolling it over eight positions)
 constexpr int RW_PPT = 8, RW_NB = SKX_RW_NB, RW_NT = 256, RW_TILE = RW_PPT * RW_NB * RW_NT, RW_STRIDE = RW_NT + 8;
-__device__ static inline uint64_t nt_pick(uint32_t c, uint64_t t0, uint64_t t1, uint64_t t2, uint64_t t3)
+constexpr int RW_CH = (RW_TILE + 80) / 16;                  // chunks of 16 positions of a tile: [p0 - 64, p0 + RW_TILE + 16)
+static_assert(RW_PPT * RW_NB == 16 && RW_CH >= RW_NT + 5, "a thread's positions are one chunk; it reads chunks tid .. tid + 5");
+__device__ static inline uint32_t zero_bytes(uint32_t x)    // 0x80 in every byte of x that is zero (exact: no borrow between bytes)
 {
-    return (c & 2u) ? ((c & 1u) ? t3 : t2) : ((c & 1u) ? t1 : t0);
+    const uint32_t t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return ~(t | x | 0x7F7F7F7Fu);
+}
+__device__ static inline uint32_t flags4(uint32_t f)        // bits 7, 15, 23, 31 -> bits 0..3
+{
+    return (((f >> 7) * 0x00204081u) >> 21) & 0xFu;
+}
+__device__ static inline uint32_t codes4(uint32_t d)        // bytes b0..b3 -> their codes ((b >> 1) & 3) at bits 0-1 .. 6-7
+{
+    uint32_t c = (d >> 1) & 0x03030303u;
+    c |= c >> 6;
+    return (c | (c >> 12)) & 0xFFu;
+}
+__device__ static inline uint32_t spread16(uint32_t x)      // bit j -> bit 2 j
+{
+    x = (x | (x << 8)) & 0x00FF00FFu; x = (x | (x << 4)) & 0x0F0F0F0Fu; x = (x | (x << 2)) & 0x33333333u;
+    return (x | (x << 1)) & 0x55555555u;
+}
+// 16 sequence bytes + 16 quality bytes -> codes, N mask ((b & 15) == 14: split_kmer.rs:66-71's rejects as the engine's text holds them), line
+// ends, quality verdicts ((q - 33) as a byte <= min_qual, i.e. NOT (q - 33 > min_qual): split_kmer.rs:328-339)
+__device__ static inline void pack_bytes16(const uint32_t sw[4], const uint32_t qw[4], bool has_q, uint32_t mq4, uint32_t &code, uint32_t &nb, uint32_t &nl, uint32_t &qb)
+{
+    constexpr uint32_t H = 0x80808080u;
+    code = 0; nb = 0; nl = 0; qb = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t w = sw[i], q = qw[i];
+        code |= codes4(w) << (8 * i);
+        nb |= flags4(zero_bytes((w & 0x0F0F0F0Fu) ^ 0x0E0E0E0Eu)) << (4 * i);
+        nl |= flags4(zero_bytes(w ^ 0x0A0A0A0Au)) << (4 * i);
+        if (has_q) {
+            const uint32_t r = (q | H) - 0x21212121u;                          // per byte, no borrow: low 7 bits of q - 33; bit 7 = (low 7 of q >= 33)
+            const uint32_t y = (r & ~H) | (~(q ^ r) & H);                       // q - 33 as a byte
+            const uint32_t t = (mq4 | H) - (y & ~H);                            // bit 7 = (low 7 of min_qual >= low 7 of y)
+            qb |= flags4(((~y & mq4) | (~(y ^ mq4) & t)) & H) << (4 * i);       // y <= min_qual
+        }
+    }
 }
 // WORDS = false: ntHash and the gates only (the count filter passes ~2 % of a deep read set's windows: their packed words are put together
 // afterwards from the text, words_rebuild_kernel) -- 9 instead of 25 bytes written per window, no canonical compare, no key hash
 template <bool WORDS>
 __global__ __launch_bounds__(RW_NT) void reads_windows_kernel(ReadsArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_seq[RW_TILE + 80], s_q[RW_TILE + 80], s_flag[RW_TILE];
-    __shared__ uint64_t s_out[RW_PPT * RW_STRIDE];
-    // ntHash's per-base words as the roll needs them: [c] H, [4 + c] rotl(H, k) (the base that leaves), [8 + c] R, [12 + c] rotl(R, k - 1) (the base
-    // that enters the reverse strand): one LDS read each instead of a three-way select over two registers and a 64-bit rotate by a run-time count
-    __shared__ uint64_t s_nt[16];
-    if (threadIdx.x < 16) {
-        const int c4 = threadIdx.x & 3, kind = threadIdx.x >> 2;
-        s_nt[threadIdx.x] = kind == 0 ? NT_H[c4] : kind == 1 ? rotl64d(NT_H[c4], (unsigned)a.k) : kind == 2 ? NT_RC[c4] : rotl64d(NT_RC[c4], (unsigned)(a.k - 1));
+    __shared__ uint32_t s_code[RW_CH + 3];
+    __shared__ uint16_t s_bad[RW_CH + 3], s_nl[RW_CH + 3], s_qb[RW_CH + 3];
+    __shared__ __attribute__((aligned(16))) uint64_t s_out[RW_PPT * RW_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint64_t s_T[32];            // [2 (4 leaving + entering)] = rotl(H[leaving], k) ^ H[entering], [.. + 1] = rotr(R[leaving], 1) ^ rotl(R[entering], k - 1)
+    const uint32_t tid = threadIdx.x;
+    const int k = a.k, h = (k - 1) / 2;
+    if (tid < 16) {
+        const int cout = (int)tid >> 2, c = (int)tid & 3;
+        s_T[2 * tid] = rotl64d(NT_H[cout], (unsigned)k) ^ NT_H[c];
+        s_T[2 * tid + 1] = rotl64d(NT_RC[cout], 63u) ^ rotl64d(NT_RC[c], (unsigned)(k - 1));
+    }
+    // Before the first put() the output buffer holds ntHash's words as the FIRST window needs them: [4 i + c] = rotl(H[c], k - 1 - i) and
+    // [256 + 4 i + c] = rotl(R[c], i) for the window's i-th base
+    uint64_t *s_rot = s_out;
+    static_assert(RW_PPT * RW_STRIDE >= 512, "the start-up table fits the output buffer");
+    for (int i = (int)tid; i < 4 * k; i += RW_NT) {
+        s_rot[i] = rotl64d(NT_H[i & 3], (unsigned)(k - 1 - (i >> 2)));
+        s_rot[256 + i] = rotl64d(NT_RC[i & 3], (unsigned)(i >> 2));
     }
     uint64_t o_hash[RW_PPT], o_lo[WORDS ? RW_PPT : 1], o_hi[WORDS ? RW_PPT : 1];
     const uint64_t p0 = (uint64_t)blockIdx.x * RW_TILE;
-    const int k = a.k, h = (k - 1) / 2;
-    // tile covers positions [p0 - 64, p0 + RW_TILE + 2)
-    // 16 bytes per thread and array where the piece lies inside the stream (p0 - 64 is a multiple of 16 and the streams are 16-byte
-    // aligned), byte by byte at its two ends
-    for (int c = threadIdx.x; c < (RW_TILE + 80) / 16; c += RW_NT) {
+    const bool has_q = a.qual != nullptr || a.planes != nullptr;
+    const bool strict = a.qual_filter == 2, midq = a.qual_filter != 0;
+    const uint32_t mq = (uint32_t)(uint8_t)a.min_qual, mq4 = mq * 0x01010101u;
+    // the tile: chunk c = positions [p0 - 64 + 16 c, + 16)  (p0 - 64 is a multiple of 16 and the streams are 16-byte aligned)
+    for (int c = (int)tid; c < RW_CH; c += RW_NT) {
         const int64_t pos = (int64_t)p0 - 64 + 16 * c;
-        if (a.planes) {                                            // the tile's bytes straight from the packed planes (no record streams in memory)
-            uint32_t sw[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au}, qw[4] = {0x7E7E7E7Eu, 0x7E7E7E7Eu, 0x7E7E7E7Eu, 0x7E7E7E7Eu};
-            if (pos >= 0 && (uint64_t)pos < a.len) planes_bytes16(a.planes, (uint64_t)pos / 16, a.len, sw, qw);
-            *reinterpret_cast<uint4 *>(s_seq + 16 * c) = make_uint4(sw[0], sw[1], sw[2], sw[3]);
-            *reinterpret_cast<uint4 *>(s_q + 16 * c) = make_uint4(qw[0], qw[1], qw[2], qw[3]);
-        } else if (pos >= 0 && (uint64_t)pos + 16 <= a.len) {
-            *reinterpret_cast<uint4 *>(s_seq + 16 * c) = *reinterpret_cast<const uint4 *>(a.seq + pos);
-            if (a.qual) *reinterpret_cast<uint4 *>(s_q + 16 * c) = *reinterpret_cast<const uint4 *>(a.qual + pos);
-            else *reinterpret_cast<uint4 *>(s_q + 16 * c) = make_uint4(0x7E7E7E7Eu, 0x7E7E7E7Eu, 0x7E7E7E7Eu, 0x7E7E7E7Eu);
-        } else
-            for (int i = 16 * c; i < 16 * c + 16; i++) {
-                const int64_t q = (int64_t)p0 - 64 + i;
-                const bool in = q >= 0 && (uint64_t)q < a.len;
-                s_seq[i] = in ? a.seq[q] : (uint8_t)'\n';
-                s_q[i] = (in && a.qual) ? a.qual[q] : (uint8_t)'~';
+        uint32_t code, nb, nl, qb;
+        if (a.planes) {                                            // the packed planes hold these masks already (fastx.cpp pack_*_planes; the bytes planes_bytes16 stands for)
+            if (pos >= 0 && (uint64_t)pos < a.len) {
+                const uint64_t t = (uint64_t)pos / 16;
+                const uint64_t *g = a.planes + (t >> 2) * 5;
+                const int sh = (int)(t & 3) * 16;
+                const uint32_t lo = (uint32_t)(g[0] >> sh) & 0xFFFFu, hi = (uint32_t)(g[1] >> sh) & 0xFFFFu, bd = (uint32_t)(g[2] >> sh) & 0xFFFFu,
+                               qv = (uint32_t)(g[4] >> sh) & 0xFFFFu;
+                const uint64_t room = a.len - (uint64_t)pos;
+                nl = ((uint32_t)(g[3] >> sh) & 0xFFFFu) | (room < 16 ? (0xFFFFu << room) & 0xFFFFu : 0u);      // positions from `len` on are line ends
+                nb = bd & ~nl;
+                qb = ~nl & (qv | (mq == 255u ? 0xFFFFu : 0u));     // the verdict of the bytes ' ' / '!' that stand for a passing / failing quality
+                code = spread16(nl | bd | lo) | (spread16(~nl & (bd | hi)) << 1);       // '\n' -> code 1, 'N' -> 3, as the bytes give
+            } else { code = 0x55555555u; nb = 0; nl = 0xFFFFu; qb = 0; }
+        } else {
+            uint32_t sw[4], qw[4];
+            if (pos >= 0 && (uint64_t)pos + 16 <= a.len) {
+                const uint4 sv = *reinterpret_cast<const uint4 *>(a.seq + pos);
+                sw[0] = sv.x; sw[1] = sv.y; sw[2] = sv.z; sw[3] = sv.w;
+                if (a.qual) { const uint4 qv = *reinterpret_cast<const uint4 *>(a.qual + pos); qw[0] = qv.x; qw[1] = qv.y; qw[2] = qv.z; qw[3] = qv.w; }
+                else { qw[0] = qw[1] = qw[2] = qw[3] = 0x7E7E7E7Eu; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    uint32_t x = 0, y = 0;
+                    for (int bb = 0; bb < 4; bb++) {
+                        const int64_t q = pos + 4 * i + bb;
+                        const bool in = q >= 0 && (uint64_t)q < a.len;
+                        x |= (uint32_t)(in ? a.seq[q] : (uint8_t)'\n') << (8 * bb);
+                        y |= (uint32_t)((in && a.qual) ? a.qual[q] : (uint8_t)'~') << (8 * bb);
+                    }
+                    sw[i] = x; qw[i] = y;
+                }
             }
+            pack_bytes16(sw, qw, has_q, mq4, code, nb, nl, qb);
+        }
+        s_code[c] = code; s_nl[c] = (uint16_t)nl; s_qb[c] = (uint16_t)(midq ? qb : 0u);
+        s_bad[c] = (uint16_t)(nb | nl | (strict ? qb : 0u));
     }
     __syncthreads();
-    const bool has_q = a.qual != nullptr || a.planes != nullptr;
-    auto qbad = [&](int i) { return has_q && (uint8_t)(s_q[i] - 33) <= (uint8_t)a.min_qual; };     // !((q-33) > min_qual)
-    auto bad = [&](int i) { const uint8_t b = s_seq[i]; return (b & 0xF) == 14 || b == '\n' || (a.qual_filter == 2 && qbad(i)); };
-    auto code = [&](int i) -> uint32_t { return (s_seq[i] >> 1) & 3u; };
-    const uint64_t pstart = p0 + (uint64_t)threadIdx.x * (RW_PPT * RW_NB);
-    const int e0 = 64 + (int)threadIdx.x * (RW_PPT * RW_NB);        // tile index of my first window's last base
+    const uint64_t pstart = p0 + (uint64_t)tid * (RW_PPT * RW_NB);
     const uint64_t left = a.len - p0 < (uint64_t)RW_TILE ? a.len - p0 : (uint64_t)RW_TILE;
     uint64_t upper = 0, lower = 0, rc_upper = 0, rc_lower = 0, fh = 0, rh = 0;
     uint32_t mid = 0, rc_mid = 0, run = 0;
-    const uint64_t H0 = NT_H[0], H1 = NT_H[1], H2 = NT_H[2], H3 = NT_H[3], R0 = NT_RC[0], R1 = NT_RC[1], R2 = NT_RC[2], R3 = NT_RC[3];
     const uint64_t am = (1ull << (2 * h)) - 1;        // arm mask (h <= 31)
     const bool userc = a.rc != 0;
     // k > 31: the hashed upper arm L starts at bit sh = hb + 4 of the 128-bit word (36..66): its part of the low half = (L << wa1) & wm1, of
@@ -101,61 +169,85 @@ __global__ __launch_bounds__(RW_NT) void reads_windows_kernel(ReadsArgs a)
     const int wsh = a.wh.hb + 4;
     const int wa1 = wsh < 64 ? wsh : 0, wa2 = wsh < 64 ? 64 - wsh : 0, wa3 = wsh < 64 ? 0 : wsh - 64;
     const uint64_t wm1 = wsh < 64 ? ~0ull : 0ull;
-    if (pstart < a.len) {
-        // the window ending one position before my first
-        const int e = e0 - 1;
-        for (int i = 0; i < k; i++) {
-            const uint32_t c = code(e - (k - 1) + i);
-            if (i < h) upper = (upper << 2) | c; else if (i == h) mid = c; else lower = (lower << 2) | c;
-            fh ^= rotl64d(nt_pick(c, H0, H1, H2, H3), (unsigned)(k - 1 - i));
-            rh ^= rotl64d(nt_pick(c, R0, R1, R2, R3), (unsigned)i);
-        }
-        for (int i = 0; i < h; i++) {
-            rc_upper = (rc_upper << 2) | (code(e - i) ^ 2u);                       // reverse complement of the lower arm
-            rc_lower = (rc_lower << 2) | (code(e - (k - 1) + h - 1 - i) ^ 2u);     // ... of the upper arm
-        }
-        rc_mid = mid ^ 2u;
-        run = 0;                                           // clean bases ending at e, counted up to k + 1
-        for (int t = e; t >= e - k && !bad(t); t--) run++;
+    // with r = position - (p0 - 64 + 16 tid): r = 0..63 is the history, 64..79 my positions.  Words at uniform offsets:
+    uint32_t cw = s_code[tid + 4];                                             // my codes
+    uint32_t coutw, badw = s_bad[tid + 4], nlw, qbw;
+    {
+        const int ro = 64 - k, wi = ro >> 4;                                   // the base that leaves the window ending at r is r - k
+        coutw = __funnelshift_r(s_code[tid + wi], s_code[tid + wi + 1], 2 * (ro & 15));
+        nlw = ((uint32_t)s_nl[tid + 4] >> 1) | (((uint32_t)s_nl[tid + 5] & 1u) << 15);      // is r + 1 a line end
+        const int rq = 64 - h, wq = rq >> 4;                                   // the middle base of the window ending at r is r - h
+        qbw = ((((uint32_t)s_qb[tid + wq]) | ((uint32_t)s_qb[tid + wq + 1] << 16)) >> (rq & 15)) & 0xFFFFu;
     }
+    if (pstart < a.len) {
+        // the window ending one position before my first (r = 63): its i-th base is r = 64 - k + i
+        const uint64_t cl = (uint64_t)s_code[tid] | ((uint64_t)s_code[tid + 1] << 32), ch = (uint64_t)s_code[tid + 2] | ((uint64_t)s_code[tid + 3] << 32);
+        const int sb = 2 * (64 - k);                                           // 2 .. 126
+        const uint64_t wl = sb < 64 ? (cl >> sb) | (ch << (64 - sb)) : ch >> (sb - 64), wh = sb < 64 ? ch >> sb : 0ull;      // base i at bits 2 i, 2 i + 1
+        auto wbase = [&](int i) -> uint32_t { return (uint32_t)((i < 32 ? wl >> (2 * i) : wh >> (2 * (i - 32))) & 3ull); };
+        uint64_t w = wl;
+        for (int i = 0; i < k; i++) {
+            if (i == 32) w = wh;
+            const uint32_t c = (uint32_t)w & 3u; w >>= 2;
+            if (WORDS) { if (i < h) upper = (upper << 2) | c; else if (i == h) mid = c; else lower = (lower << 2) | c; }
+            fh ^= s_rot[4 * i + (int)c];
+            rh ^= s_rot[256 + 4 * i + (int)c];
+        }
+        if (WORDS) {
+            for (int i = 0; i < h; i++) {
+                rc_upper = (rc_upper << 2) | (wbase(k - 1 - i) ^ 2u);           // reverse complement of the lower arm
+                rc_lower = (rc_lower << 2) | (wbase(h - 1 - i) ^ 2u);           // ... of the upper arm
+            }
+            rc_mid = mid ^ 2u;
+        }
+        // clean bases ending at r = 63, counted up to k + 1
+        const uint64_t hb = (uint64_t)s_bad[tid] | ((uint64_t)s_bad[tid + 1] << 16) | ((uint64_t)s_bad[tid + 2] << 32) | ((uint64_t)s_bad[tid + 3] << 48);
+        run = hb ? (uint32_t)__clzll((long long)hb) : 64u;
+        run = min(run, (uint32_t)k + 1u);
+    }
+    __syncthreads();                                       // (the start-up table is done with: put() writes there)
     auto put = [&](const uint64_t (&v)[RW_PPT], uint64_t *dst, int b, bool mine) {       // my eight values -> LDS -> the array, in 64-byte runs
         if (mine) {
 #pragma unroll
-            for (int j = 0; j < RW_PPT; j++) s_out[j * RW_STRIDE + (int)threadIdx.x] = v[j];
+            for (int j = 0; j < RW_PPT; j++) s_out[j * RW_STRIDE + (int)tid] = v[j];
         }
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < (uint32_t)(RW_PPT * RW_NT); i += RW_NT) {
+        for (uint32_t i = tid; i < (uint32_t)(RW_PPT * RW_NT); i += RW_NT) {
             const uint32_t t = i / RW_PPT, j = i % RW_PPT, at = t * (RW_PPT * RW_NB) + (uint32_t)b * RW_PPT + j;
             if (at < left) dst[p0 + at] = s_out[(int)j * RW_STRIDE + (int)t];
         }
         __syncthreads();
     };
+    uint32_t flags = 0;                                    // bit j: my j-th window passes the gates
 #pragma unroll 1
     for (int b = 0; b < RW_NB; b++) {
     const bool mine = pstart + (uint64_t)b * RW_PPT < a.len;
     if (mine) {
+        uint32_t fb = 0;
 #pragma unroll
         for (int j = 0; j < RW_PPT; j++) {
-            const int ej = e0 + b * RW_PPT + j;
-            const uint32_t c = code(ej), cout = code(ej - k);
+            const uint32_t c = (cw >> (2 * j)) & 3u, cout = (coutw >> (2 * j)) & 3u;
+            const uint4 tw = *reinterpret_cast<const uint4 *>(&s_T[2 * (4 * cout + c)]);
             // roll_fwd (split_kmer.rs:199-213)
-            upper = ((upper << 2) | mid) & am;
-            mid = (uint32_t)(lower >> (2 * h - 2));
-            lower = ((lower << 2) | c) & am;
-            rc_lower = (rc_lower >> 2) | ((uint64_t)rc_mid << (2 * h - 2));
-            rc_mid = mid ^ 2u;
-            rc_upper = (rc_upper >> 2) | ((uint64_t)(c ^ 2u) << (2 * h - 2));
+            if (WORDS) {
+                upper = ((upper << 2) | mid) & am;
+                mid = (uint32_t)(lower >> (2 * h - 2));
+                lower = ((lower << 2) | c) & am;
+                rc_lower = (rc_lower >> 2) | ((uint64_t)rc_mid << (2 * h - 2));
+                rc_mid = mid ^ 2u;
+                rc_upper = (rc_upper >> 2) | ((uint64_t)(c ^ 2u) << (2 * h - 2));
+            }
             // ntHash of the whole k-mer, both strands (nthash.rs:35-76)
-            fh = ((fh << 1) | (fh >> 63)) ^ s_nt[4 + cout] ^ s_nt[c];
-            { const uint64_t x = rh ^ s_nt[8 + cout]; rh = ((x >> 1) | (x << 63)) ^ s_nt[12 + c]; }
-            run = bad(ej) ? 0u : min(run + 1u, (uint32_t)k + 1u);
+            fh = ((fh << 1) | (fh >> 63)) ^ ((uint64_t)tw.x | ((uint64_t)tw.y << 32));
+            rh = ((rh >> 1) | (rh << 63)) ^ ((uint64_t)tw.z | ((uint64_t)tw.w << 32));
+            run = ((badw >> j) & 1u) ? 0u : min(run + 1u, (uint32_t)k + 1u);
             // split_kmer.rs:89,121: a clean run of exactly k ending at the record's last base is never started
             bool valid = run >= (uint32_t)k;
-            if (s_seq[ej + 1] == '\n') valid = valid && run > (uint32_t)k;
+            if ((nlw >> j) & 1u) valid = valid && run > (uint32_t)k;
             // middle_base_qual (split_kmer.rs:328-339): Middle and Strict gate on the middle base
-            const bool midq_ok = !(has_q && a.qual_filter != 0 && qbad(ej - h));
+            const bool midq_ok = !((qbw >> j) & 1u);
             o_hash[j] = userc ? (fh < rh ? fh : rh) : fh;
-            s_flag[threadIdx.x * (RW_PPT * RW_NB) + b * RW_PPT + j] = valid && midq_ok;            // the `&&` of ska_dict.rs:155-157: the count filter is not touched otherwise
+            fb |= (valid && midq_ok ? 1u : 0u) << j;                                 // the `&&` of ska_dict.rs:155-157: the count filter is not touched otherwise
             if (!WORDS) continue;
             // canonical strand and base set without branches; the packed word on 64-bit halves (as extract_wide_kernel)
             const bool ueq = upper == rc_upper;
@@ -169,6 +261,8 @@ __global__ __launch_bounds__(RW_NT) void reads_windows_kernel(ReadsArgs a)
             o_lo[WORDS ? j : 0] = wlo;
             o_hi[WORDS ? j : 0] = whi;
         }
+        flags |= fb << (RW_PPT * b);
+        cw >>= 2 * RW_PPT; coutw >>= 2 * RW_PPT; badw >>= RW_PPT; nlw >>= RW_PPT; qbw >>= RW_PPT;
     }
     put(o_hash, a.hash, b, mine);
     if constexpr (WORDS) {
@@ -176,11 +270,22 @@ __global__ __launch_bounds__(RW_NT) void reads_windows_kernel(ReadsArgs a)
         if (a.whi) put(o_hi, a.whi, b, mine);
     }
     }
+    // my sixteen flags: one byte each, 16 bytes at a multiple of 16
+    const uint32_t at0 = tid * (RW_PPT * RW_NB);
     uint32_t nv = 0;
-    for (uint32_t i = threadIdx.x; i < left; i += RW_NT) { a.flag[p0 + i] = s_flag[i]; nv += s_flag[i]; }
+    if (at0 < left) {
+        const uint32_t room = (uint32_t)left - at0;
+        if (room < 16u) flags &= (1u << room) - 1u;
+        nv = (uint32_t)__popc(flags);
+        uint32_t fw[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) fw[i] = (((flags >> (4 * i)) & 0xFu) * 0x00204081u) & 0x01010101u;
+        if (room >= 16u) *reinterpret_cast<uint4 *>(a.flag + p0 + at0) = make_uint4(fw[0], fw[1], fw[2], fw[3]);
+        else for (uint32_t i = 0; i < room; i++) a.flag[p0 + at0 + i] = (uint8_t)((flags >> i) & 1u);
+    }
     if (a.n_valid) {
         for (int d = 32; d; d >>= 1) nv += __shfl_down(nv, d, 64);
-        if ((threadIdx.x & 63) == 0 && nv) atomicAdd(a.n_valid + (blockIdx.x & 255u), (unsigned long long)nv);
+        if ((tid & 63u) == 0 && nv) atomicAdd(a.n_valid + (blockIdx.x & 255u), (unsigned long long)nv);
     }
 }
 
@@ -265,7 +370,21 @@ inline int sort_pairs(Temp &, const uint64_t *kin, uint64_t *kout, const uint32_
 
 // The packed words of the windows at the given end positions (all of them clean runs of k bases: they passed the gates), put together from
 // the text as reads_windows_kernel<true> rolls them: arms, canonical strand, base set (split_kmer.rs:141-217), then the key hash.
-__global__ __launch_bounds__(256) void words_rebuild_kernel(const uint32_t *pos, uint64_t n, const uint8_t *seq, int k, int rc, HashParams hp, WideHash wh,
+// The window's bytes arrive as dwords from the 4-byte boundary below its first base (up to 17 of them; byte loads -- 63 a window -- took 0.48 ms
+// per 5 M windows), every dword's four 2-bit codes are squeezed into a byte, and the bytes form P: base j of the window at bits 2j, 2j + 1.
+// Then: reverse complement's lower arm = P's first h pairs complemented, the upper arm = the same pairs in reverse order; likewise the other arm.
+__device__ static inline uint64_t pairs_reversed(uint64_t x)             // the 32 two-bit fields of x in reverse order
+{
+    const uint64_t r = __brevll(x);
+    return ((r >> 1) & 0x5555555555555555ull) | ((r & 0x5555555555555555ull) << 1);
+}
+__device__ static inline uint32_t codes_of_dword(uint32_t d)             // ASCII bases b0..b3 -> their codes ((b >> 1) & 3) at bits 0-1 .. 6-7
+{
+    uint32_t c = (d >> 1) & 0x03030303u;
+    c |= c >> 6;
+    return (c | (c >> 12)) & 0xFFu;
+}
+__global__ __launch_bounds__(256) void words_rebuild_kernel(const uint32_t *pos, uint64_t n, const uint8_t *seq, uint64_t len, int k, int rc, HashParams hp, WideHash wh,
                                                              uint64_t *out_lo, uint64_t *out_hi)
 {
     const int h = (k - 1) / 2;
@@ -273,23 +392,37 @@ __global__ __launch_bounds__(256) void words_rebuild_kernel(const uint32_t *pos,
     const int wsh = wh.hb + 4;
     const int wa1 = wsh < 64 ? wsh : 0, wa2 = wsh < 64 ? 64 - wsh : 0, wa3 = wsh < 64 ? 0 : wsh - 64;
     const uint64_t wm1 = wsh < 64 ? ~0ull : 0ull;
+    const bool more = k + 3 > 48;                                        // dwords 12..16 are needed
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint8_t *w = seq + ((uint64_t)pos[i] - (uint64_t)(k - 1));
-        uint64_t upper = 0, lower = 0, rc_upper = 0, rc_lower = 0;
-        // (all of the window's bytes asked for before the first is used: a loop over h waits for every pair in turn, 1.2 ms per 5 M windows)
-        uint8_t bu[31], bl[31];
+        const uint64_t first = (uint64_t)pos[i] - (uint64_t)(k - 1);
+        const uint64_t a0 = first - ((uint64_t)(uintptr_t)(seq + first) & 3ull);                     // (may be "-1..-3" for a stream that starts off a boundary: then the byte path)
+        uint64_t P0 = 0, P1 = 0, P2 = 0;                                 // the codes from a0 on: 4 bases a byte, 136 bits
+        if (a0 + 68 <= len && a0 <= first) {
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(seq + a0);
+            uint32_t d[17];
 #pragma unroll
-        for (int j = 0; j < 31; j++) { const int jj = j < h ? j : h - 1; bu[j] = w[jj]; bl[j] = w[h + 1 + jj]; }      // (every load issued whatever h is: a load under a condition is waited for on the spot)
-        const uint32_t mid = (w[h] >> 1) & 3u, rc_mid = mid ^ 2u;
+            for (int j = 0; j < 12; j++) d[j] = w[j];
 #pragma unroll
-        for (int j = 0; j < 31; j++) {
-            if (j < h) {
-                const uint64_t cu = (bu[j] >> 1) & 3u, cl = (bl[j] >> 1) & 3u;
-                upper = (upper << 2) | cu; lower = (lower << 2) | cl;
-                rc_lower |= (cu ^ 2u) << (2 * j);                  // the reverse complement's lower arm: the upper arm backwards, complemented
-                rc_upper |= (cl ^ 2u) << (2 * j);
+            for (int j = 12; j < 17; j++) d[j] = more ? w[j] : 0u;
+#pragma unroll
+            for (int j = 0; j < 8; j++) P0 |= (uint64_t)codes_of_dword(d[j]) << (8 * j);
+#pragma unroll
+            for (int j = 8; j < 16; j++) P1 |= (uint64_t)codes_of_dword(d[j]) << (8 * (j - 8));
+            P2 = codes_of_dword(d[16]);
+        } else {                                                          // the stream's last bytes: one by one
+            for (uint64_t q = first; q < first + (uint64_t)k; q++) {
+                const uint64_t c = (seq[q] >> 1) & 3u; const unsigned at = 2u * (unsigned)(q - first + (first - a0));
+                if (at < 64) P0 |= c << at; else if (at < 128) P1 |= c << (at - 64); else P2 |= c << (at - 128);
             }
         }
+        const unsigned s0 = 2u * (unsigned)(first - a0);                 // 0, 2, 4 or 6: the window starts there
+        if (s0) { P0 = (P0 >> s0) | (P1 << (64 - s0)); P1 = (P1 >> s0) | (P2 << (64 - s0)); }
+        const unsigned sq = 2u * (unsigned)(h + 1);                      // the lower arm starts at bit 2 (h + 1) <= 64
+        const uint64_t up = P0 & am, lo = (sq < 64 ? (P0 >> sq) | (P1 << (64 - sq)) : P1) & am;
+        const uint32_t mid = (uint32_t)(2 * h < 64 ? (P0 >> (2 * h)) | (P1 << (64 - 2 * h)) : P1) & 3u, rc_mid = mid ^ 2u;
+        const uint64_t comp = 0xAAAAAAAAAAAAAAAAull & am;
+        const uint64_t upper = pairs_reversed(up) >> (64 - 2 * h), lower = pairs_reversed(lo) >> (64 - 2 * h);
+        const uint64_t rc_lower = up ^ comp, rc_upper = lo ^ comp;
         const bool userc = rc != 0;
         const bool ueq = upper == rc_upper;
         const bool gt = userc & ((upper > rc_upper) | (ueq & (lower > rc_lower)));
@@ -298,7 +431,6 @@ __global__ __launch_bounds__(256) void words_rebuild_kernel(const uint32_t *pos,
         const uint32_t m4 = (1u << (gt ? rc_mid : mid)) | (eq ? (1u << rc_mid) : 0u);
         if (k <= 31) { uint32_t L = (uint32_t)hl, R = (uint32_t)hr; hmix_halves(L, R, hp); out_lo[i] = ((uint64_t)L << (hp.hb + 4)) | ((uint64_t)R << 4) | m4; }
         else { uint64_t L = hl, R = hr; hmix_halves_w(L, R, wh); out_lo[i] = (R << 4) | m4 | ((L << wa1) & wm1); out_hi[i] = (R >> 60) | ((L >> wa2) << wa3); }
-        (void)am;
     }
 }
 // the same from the packed planes: a window's code bits are two 64-bit pieces of the lo / hi planes (the window may straddle two groups)
@@ -344,11 +476,11 @@ void launch_words_rebuild_planes(const uint32_t *pos, uint64_t n, const uint64_t
     hipLaunchKernelGGL(words_rebuild_planes_kernel, dim3((unsigned)(g > 65536 ? 65536 : g)), dim3(256), 0, st, pos, n, planes, k, rc, make_hash_params(k < 31 ? k : 31),
                        make_wide_hash(k), out_lo, out_hi);
 }
-void launch_words_rebuild(const uint32_t *pos, uint64_t n, const uint8_t *seq, int k, int rc, uint64_t *out_lo, uint64_t *out_hi, hipStream_t st)
+void launch_words_rebuild(const uint32_t *pos, uint64_t n, const uint8_t *seq, uint64_t len, int k, int rc, uint64_t *out_lo, uint64_t *out_hi, hipStream_t st)
 {
     if (!n) return;
     const uint64_t g = (n + 255) / 256;
-    hipLaunchKernelGGL(words_rebuild_kernel, dim3((unsigned)(g > 65536 ? 65536 : g)), dim3(256), 0, st, pos, n, seq, k, rc, make_hash_params(k < 31 ? k : 31), make_wide_hash(k),
+    hipLaunchKernelGGL(words_rebuild_kernel, dim3((unsigned)(g > 65536 ? 65536 : g)), dim3(256), 0, st, pos, n, seq, len, k, rc, make_hash_params(k < 31 ? k : 31), make_wide_hash(k),
                        out_lo, out_hi);
 }
 

@@ -35,18 +35,28 @@ constexpr int RS_TILE = 4096, RS_NT = 512, RS_PER = RS_TILE / RS_NT;
 struct RsArgs {
     const uint64_t *src_h; const uint32_t *src_t; const uint8_t *flag;      // FROM_POS: hash[p], flag[p], t = p; else records of source partitions
     const uint32_t *src_cnt; uint64_t src_cap, n_pos;
-    uint64_t *dst_h; uint32_t *dst_t; uint32_t *dst_cnt; uint64_t dst_cap;   // destination partition (src * FAN + sub) holds dst_cap records
+    uint64_t *dst_h; uint32_t *dst_t; uint32_t *dst_cnt; uint64_t dst_cap;   // destination partition holds dst_cap records
     int *overflow;
+    uint32_t src_mod, src_tiles;                                             // !FROM_POS: source s is slice s / src_mod of coarse partition s % src_mod; tiles a source
 };
+// Who writes a destination decides what its lines cost: workgroups go round the 8 XCDs by their linear index, each XCD has its own L2, and a
+// run of ~11-16 records ends inside a line that the next run -- from whichever tile reserves next -- goes on with.  So the first pass keeps
+// RS_SLICES areas per coarse partition, one per XCD (slice = blockIdx.x % 8: every line of a slice is put together in ONE L2: 1.35 -> 1.05 ms),
+// and the second pass numbers its workgroups so that XCD x takes the sources x, x + 8, ... one after the other, all tiles of a source in a row
+// (sources numbered slice-major, so x is also the coarse partition modulo 8): the 256 final partitions of a coarse one are written from one
+// XCD, a few sources at a time, and their lines are complete before they leave its L2.
+constexpr uint32_t RS_SLICES = 8;
 template <int DIV, int FAN, bool FROM_POS>
 __global__ __launch_bounds__(RS_NT) void rs_scatter_kernel(RsArgs a)
 {
     __shared__ uint32_t s_hist[FAN], s_lbase[FAN + 1], s_gbase[FAN];
     __shared__ uint64_t s_h[RS_TILE];
     __shared__ uint32_t s_t[RS_TILE];
-    const uint32_t src = FROM_POS ? 0u : blockIdx.y;
+    const uint32_t xr = blockIdx.x / RS_SLICES;                                         // (second pass) my number on my XCD
+    const uint32_t src = FROM_POS ? 0u : (xr / a.src_tiles) * RS_SLICES + blockIdx.x % RS_SLICES;
+    const uint32_t dpre = FROM_POS ? blockIdx.x % RS_SLICES : src % a.src_mod;          // destination = dpre * FAN + sub
     const uint64_t n = FROM_POS ? a.n_pos : (uint64_t)a.src_cnt[src];
-    const uint64_t i0 = (uint64_t)blockIdx.x * RS_TILE;
+    const uint64_t i0 = (uint64_t)(FROM_POS ? blockIdx.x : xr % a.src_tiles) * RS_TILE;
     if (i0 >= n) return;
     const uint64_t sbase = FROM_POS ? 0 : (uint64_t)src * a.src_cap;
     for (int i = threadIdx.x; i < FAN; i += RS_NT) s_hist[i] = 0;
@@ -68,7 +78,7 @@ __global__ __launch_bounds__(RS_NT) void rs_scatter_kernel(RsArgs a)
     for (int b = threadIdx.x; b < FAN; b += RS_NT) {
         const uint32_t nb = s_hist[b];
         uint32_t g = 0;
-        if (nb) { g = atomicAdd(&a.dst_cnt[(uint64_t)src * FAN + b], nb); if ((uint64_t)g + nb > a.dst_cap) *a.overflow = 1; }
+        if (nb) { g = atomicAdd(&a.dst_cnt[(uint64_t)dpre * FAN + b], nb); if ((uint64_t)g + nb > a.dst_cap) *a.overflow = 1; }
         s_gbase[b] = g;
     }
     if (threadIdx.x < 64) {
@@ -94,13 +104,13 @@ __global__ __launch_bounds__(RS_NT) void rs_scatter_kernel(RsArgs a)
         const uint64_t hh = s_h[i];
         const uint32_t sub = (loc_of(mixh(hh)) / (uint32_t)DIV) % (uint32_t)FAN;
         const uint64_t r = (uint64_t)s_gbase[sub] + (i - s_lbase[sub]);
-        if (r < a.dst_cap) { const uint64_t o = ((uint64_t)src * FAN + sub) * a.dst_cap + r; a.dst_h[o] = hh; a.dst_t[o] = s_t[i]; }
+        if (r < a.dst_cap) { const uint64_t o = ((uint64_t)dpre * FAN + sub) * a.dst_cap + r; a.dst_h[o] = hh; a.dst_t[o] = s_t[i]; }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------- one partition in LDS
 // WPP = bloom words per final partition: 48 (65 536 partitions; samples of up to ~160 M windows), 24 (131 072) or 12 (262 144 partitions).
-// 1 024 threads x 4 records, 69 KB of LDS: two workgroups per CU.
+// 1 024 threads x 4 records, 78 KB of LDS: two workgroups per CU.
 constexpr int RG_NT = 1024, RG_ITEMS = 4, RG_CAP = RG_NT * RG_ITEMS, RG_MB = 48 * 64;       // micro-bucket = (bloom word, top bits of the fraction)
 constexpr int RG_PAD = 8;                                                                     // records behind the last one that the rank step may read
 struct RgArgs { const uint64_t *h; const uint32_t *t; const uint32_t *cnt; uint64_t cap; int min_count; uint32_t *out_t; unsigned long long *out_n; int *overflow; unsigned long long *dbg; };
@@ -130,29 +140,38 @@ template <int WPP>
 __global__ __launch_bounds__(RG_NT, 8) void rs_groups_kernel(RgArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
-    uint64_t *s_m = reinterpret_cast<uint64_t *>(s_mem);                  // [RG_CAP] mix(hash) sorted; then, at group heads, the hash's bloom fingerprint
-    uint32_t *s_t = reinterpret_cast<uint32_t *>(s_m + RG_CAP + RG_PAD);   // [RG_CAP] stream position
-    uint32_t *s_cnt = s_t + RG_CAP + RG_PAD + 1;                                    // [-1] = 0 | [RG_MB] counts -> cursors (= micro-bucket ends)
-    uint8_t *s_loc = reinterpret_cast<uint8_t *>(s_cnt + RG_MB + 1);       // [RG_CAP] bloom word inside the partition (0..47)
+    uint64_t *s_m = reinterpret_cast<uint64_t *>(s_mem);                  // [RG_CAP + pad] mix(hash) sorted; then, at group heads, the hash's bloom fingerprint
+    uint32_t *s_t = reinterpret_cast<uint32_t *>(s_m + RG_CAP + RG_PAD);   // [RG_CAP + pad] stream position
+    uint32_t *s_cnt = s_t + RG_CAP + RG_PAD + 1;                           // [-1] = 0 | [RG_MB] counts -> cursors (= micro-bucket ends; bit 31: holds more than one hash)
+    uint16_t *s_mb = reinterpret_cast<uint16_t *>(s_cnt + RG_MB + 1);      // [RG_CAP] micro-bucket of the record at a sorted position
+    uint8_t *s_loc = reinterpret_cast<uint8_t *>(s_mb + RG_CAP);           // [RG_CAP] bloom word inside the partition (0..47) | [RG_CAP] the same of the group heads, dense
+    __shared__ uint32_t s_hc[64];
     __shared__ uint32_t s_tmp[17];
     __shared__ unsigned long long s_gb;
+    const uint32_t tid = threadIdx.x;
+    const int lane = (int)(tid & 63u), wv = (int)(tid >> 6);
     const uint64_t region = blockIdx.x;
     const uint32_t n = a.cnt[region];
     if (n == 0) return;
-    if (n > (uint32_t)RG_CAP || n > a.cap) { if (threadIdx.x == 0) *a.overflow = 1; return; }
+    if (n > (uint32_t)RG_CAP || n > a.cap) { if (tid == 0) *a.overflow = 1; return; }
     const uint64_t base = region * a.cap;
     const uint32_t loc0 = (uint32_t)region * (uint32_t)WPP;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned long long t_mark = __builtin_readcyclecounter();
     uint64_t e_m[RG_ITEMS]; uint32_t e_t[RG_ITEMS], e_mb[RG_ITEMS];
 #pragma unroll
     for (int j = 0; j < RG_ITEMS; j++) {
-        const uint32_t p = threadIdx.x + (uint32_t)RG_NT * j;
-        e_m[j] = 0; e_t[j] = 0; e_mb[j] = 0xFFFFFFFFu;
-        if (p < n) { e_m[j] = mixh(a.h[base + p]); e_t[j] = a.t[base + p]; uint32_t lr; e_mb[j] = micro_of<WPP>(e_m[j], loc0, lr); }
+        const uint32_t p = tid + (uint32_t)RG_NT * j;
+        const uint32_t pc = p < n ? p : 0u;                     // (every load asked for before the first is used: a load under its condition is waited for on the spot)
+        e_m[j] = a.h[base + pc]; e_t[j] = a.t[base + pc];
     }
-    for (uint32_t i = threadIdx.x; i < (uint32_t)RG_MB; i += RG_NT) s_cnt[i] = 0;
-    if (threadIdx.x == 0) s_cnt[-1] = 0;
+#pragma unroll
+    for (int j = 0; j < RG_ITEMS; j++) {
+        const uint32_t p = tid + (uint32_t)RG_NT * j;
+        e_mb[j] = 0xFFFFFFFFu;
+        if (p < n) { e_m[j] = mixh(e_m[j]); uint32_t lr; e_mb[j] = micro_of<WPP>(e_m[j], loc0, lr); }
+    }
+    for (uint32_t i = tid; i < (uint32_t)RG_MB; i += RG_NT) s_cnt[i] = 0;
+    if (tid == 0) s_cnt[-1] = 0;
     __syncthreads();
     RG_MARK(0);
 #pragma unroll
@@ -173,7 +192,7 @@ __global__ __launch_bounds__(RG_NT, 8) void rs_groups_kernel(RgArgs a)
     };
     {   // exclusive scan of the counts: 3 consecutive micro-buckets per thread
         constexpr uint32_t R = RG_MB / RG_NT;
-        const uint32_t m0 = threadIdx.x * R;
+        const uint32_t m0 = tid * R;
         uint32_t sum = 0;
 #pragma unroll
         for (uint32_t u = 0; u < R; u++) sum += s_cnt[m0 + u];
@@ -185,66 +204,107 @@ __global__ __launch_bounds__(RG_NT, 8) void rs_groups_kernel(RgArgs a)
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < RG_ITEMS; j++)
-        if (e_mb[j] != 0xFFFFFFFFu) { const uint32_t o = atomicAdd(&s_cnt[e_mb[j]], 1u); s_m[o] = e_m[j]; s_t[o] = e_t[j]; }
-    if (threadIdx.x < (uint32_t)RG_PAD) { s_m[n + threadIdx.x] = ~0ull; s_t[n + threadIdx.x] = ~0u; }      // (2^64 - 1, 2^32 - 1): below no record
+        if (e_mb[j] != 0xFFFFFFFFu) { const uint32_t o = atomicAdd(&s_cnt[e_mb[j]], 1u); s_m[o] = e_m[j]; s_t[o] = e_t[j]; s_mb[o] = (uint16_t)e_mb[j]; }
+    if (tid < (uint32_t)RG_PAD) { s_m[n + tid] = ~0ull; s_t[n + tid] = ~0u; }      // (2^64 - 1, 2^32 - 1): below no record
+    __syncthreads();
+    // a micro-bucket nearly always holds the occurrences of ONE hash (3 072 micro-buckets for the ~100 hashes of a deep isolate's partition): the
+    // ones that hold more are marked, and only those rank by (m, position) -- the others by position alone
+    constexpr int FB = WPP == 48 ? 6 : WPP == 24 ? 7 : 8;
+#pragma unroll
+    for (int j = 0; j < RG_ITEMS; j++) {
+        const uint32_t p = tid + (uint32_t)RG_NT * j;
+        e_mb[j] = 0xFFFFFFFFu;
+        if (p >= n) continue;
+        e_m[j] = s_m[p]; e_t[j] = s_t[p]; e_mb[j] = s_mb[p];
+        if (s_m[s_cnt[(int)e_mb[j] - 1] & 0x7FFFFFFFu] != e_m[j]) atomicOr(&s_cnt[e_mb[j]], 0x80000000u);       // (the cursors below are final: only bit 31 changes)
+    }
     __syncthreads();
     RG_MARK(1);
-    // rank inside the micro-bucket by (m, position): positions are unique, so there are no ties
+    // rank inside the micro-bucket: positions are unique, so there are no ties
     uint32_t npos[RG_ITEMS];
 #pragma unroll
     for (int j = 0; j < RG_ITEMS; j++) {
-        const uint32_t p = threadIdx.x + (uint32_t)RG_NT * j;
         npos[j] = 0xFFFFFFFFu;
-        if (p >= n) continue;
-        const uint64_t m = s_m[p]; const uint32_t tt = s_t[p];
-        uint32_t lr; const uint32_t mb = micro_of<WPP>(m, loc0, lr);
-        const uint32_t b = s_cnt[(int)mb - 1], e = s_cnt[mb];
-        // A step reads past the bucket's end without a clamp: what lies there are the records of the following micro-buckets, whose m is
-        // larger (the micro-bucket index is monotone in m), and behind the last record the pad, which is below nothing
-        uint32_t less = 0;
-        constexpr uint32_t RS = SKX_RG_STEP;                                     // independent LDS reads in flight per step (a k-mer of a 50x isolate fills its
-        static_assert(RS <= (uint32_t)RG_PAD, "the pad covers one step");        // micro-bucket with ~35 records)
-        for (uint32_t q = b; q < e; q += RS) {
+        if (e_mb[j] == 0xFFFFFFFFu) continue;
+        const uint64_t m = e_m[j]; const uint32_t tt = e_t[j], mb = e_mb[j];
+        const uint32_t cb = s_cnt[(int)mb - 1], ce = s_cnt[mb];
+        const uint32_t b = cb & 0x7FFFFFFFu, e = ce & 0x7FFFFFFFu;
+        uint32_t less = 0, q = b;
+        constexpr uint32_t RS = SKX_RG_STEP;                                     // independent LDS reads in flight per step
+        static_assert(RS <= (uint32_t)RG_PAD, "the pad covers one step");
+        if (!(ce >> 31)) {                                                       // one hash: whole steps by position alone (2 instructions a record, a third of the LDS bytes)
+            for (; q + RS <= e; q += RS) {
+                uint32_t tq[RS];
+#pragma unroll
+                for (uint32_t u = 0; u < RS; u++) tq[u] = s_t[q + u];
+#pragma unroll
+                for (uint32_t u = 0; u < RS; u++) less += tq[u] < tt ? 1u : 0u;
+            }
+        }
+        // (m, position) as one 96-bit number.  A step reads past the bucket's end without a clamp: what lies there are the records of the
+        // following micro-buckets, whose m is larger (the micro-bucket index is monotone in m), and behind the last record the pad
+        for (; q < e; q += RS) {
             uint64_t mq[RS]; uint32_t tq[RS];
 #pragma unroll
             for (uint32_t u = 0; u < RS; u++) { mq[u] = s_m[q + u]; tq[u] = s_t[q + u]; }
 #pragma unroll
             for (uint32_t u = 0; u < RS; u++) add_if_below(less, mq[u], tq[u], m, tt);
         }
-        npos[j] = b + less; e_m[j] = m; e_t[j] = tt; e_mb[j] = lr;
+        npos[j] = b + less;
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < RG_ITEMS; j++) if (npos[j] != 0xFFFFFFFFu) { s_m[npos[j]] = e_m[j]; s_t[npos[j]] = e_t[j]; }
+    for (int j = 0; j < RG_ITEMS; j++) if (npos[j] != 0xFFFFFFFFu) { s_m[npos[j]] = e_m[j]; s_t[npos[j]] = e_t[j]; s_loc[npos[j]] = (uint8_t)(e_mb[j] >> FB); }
     __syncthreads();
-    // group heads (first = earliest occurrence of a hash): marked in s_loc, their s_m entry becomes the hash's bloom fingerprint,
-    // and their positions go into a compact list, so that everything below runs one lane per GROUP with short, similar loops
-    // (scanning the records themselves cost ~100 cycles of LDS latency per step in a few divergent lanes: 75 k of 110 k cycles)
-    bool is_head[RG_ITEMS]; uint64_t fpv[RG_ITEMS];
-#pragma unroll
-    for (int j = 0; j < RG_ITEMS; j++) {
-        const uint32_t p = threadIdx.x + (uint32_t)RG_NT * j;
-        is_head[j] = false; fpv[j] = 0;
-        if (p >= n) continue;
-        const uint64_t m = s_m[p];
-        is_head[j] = p == 0 || s_m[p - 1] != m;
-        fpv[j] = bloom_fp5(unmixh(m));
-        uint32_t lr; (void)micro_of<WPP>(m, loc0, lr);
-        s_loc[p] = (uint8_t)lr;
-    }
-    __syncthreads();
+    // group heads (first = earliest occurrence of a hash): their positions go into a compact list, in order, and their s_m entry becomes the
+    // hash's bloom fingerprint, so that everything below runs one lane per GROUP with short, similar loops (scanning the records themselves
+    // cost ~100 cycles of LDS latency per step in a few divergent lanes: 75 k of 110 k cycles)
     uint16_t *s_hidx = reinterpret_cast<uint16_t *>(s_cnt - 1);             // [heads + 1] positions of the group heads, in order (the cursors are dead)
-    uint32_t n_heads = 0;
+    bool is_head[RG_ITEMS]; uint64_t bal[RG_ITEMS];
 #pragma unroll
     for (int j = 0; j < RG_ITEMS; j++) {
-        const uint32_t p = threadIdx.x + (uint32_t)RG_NT * j;
-        uint32_t tot;
-        const uint32_t ex = block_excl_scan(is_head[j] ? 1u : 0u, tot);
-        if (is_head[j]) { s_m[p] = fpv[j]; s_hidx[n_heads + ex] = (uint16_t)p; }
-        n_heads += tot;
+        const uint32_t p = tid + (uint32_t)RG_NT * j;
+        is_head[j] = p < n && (p == 0 || s_m[p - 1] != s_m[p]);
+        bal[j] = __ballot(is_head[j]);
+        if (lane == 0) s_hc[j * (RG_NT / 64) + wv] = (uint32_t)__popcll(bal[j]);
     }
-    if (threadIdx.x == 0) s_hidx[n_heads] = (uint16_t)n;
+    static_assert(RG_ITEMS * (RG_NT / 64) == 64, "one wave scans the head counts");
+    __syncthreads();                                                        // (also: every s_cnt cursor has been read)
+    if (wv == 0) {
+        const uint32_t v = s_hc[lane];
+        uint32_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(inc, d, 64); if (lane >= d) inc += y; }
+        s_hc[lane] = inc - v;
+        if (lane == 63) s_tmp[16] = inc;
+    }
     __syncthreads();
+    const uint32_t n_heads = s_tmp[16];
+#pragma unroll
+    for (int j = 0; j < RG_ITEMS; j++)
+        if (is_head[j]) s_hidx[s_hc[j * (RG_NT / 64) + wv] + (uint32_t)__popcll(bal[j] & ((1ull << lane) - 1ull))] = (uint16_t)(tid + (uint32_t)RG_NT * j);
+    if (tid == 0) s_hidx[n_heads] = (uint16_t)n;
+    __syncthreads();
+    // what the groups need of their heads, dense and in group order (fingerprint over the dead s_m, position over the dead cursors' tail + s_mb +
+    // s_loc, bloom word behind them): the neighbour loops below read consecutive entries instead of following s_hidx into three arrays
+    uint64_t *s_hfp = s_m; uint32_t *s_ht = (s_cnt - 1) + (RG_CAP + 2) / 2; uint8_t *s_hloc = s_loc + RG_CAP;
+    static_assert(((RG_MB + 2) * 4 + RG_CAP * 3) / 4 - (RG_CAP + 2) / 2 >= RG_CAP, "the positions of RG_CAP heads fit behind the head list");
+    {
+        uint64_t r_fp[RG_ITEMS]; uint32_t r_t[RG_ITEMS]; uint8_t r_loc[RG_ITEMS];
+#pragma unroll
+        for (int j = 0; j < RG_ITEMS; j++) {
+            const uint32_t kh = tid + (uint32_t)RG_NT * j;
+            r_fp[j] = 0; r_t[j] = 0; r_loc[j] = 0;
+            if (kh < n_heads) { const uint32_t p = s_hidx[kh]; r_fp[j] = bloom_fp5(unmixh(s_m[p])); r_t[j] = s_t[p]; r_loc[j] = s_loc[p]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RG_ITEMS; j++) {
+            const uint32_t kh = tid + (uint32_t)RG_NT * j;
+            if (kh < n_heads) { s_hfp[kh] = r_fp[j]; s_ht[kh] = r_t[j]; s_hloc[kh] = r_loc[j]; }
+        }
+        __syncthreads();
+    }
     RG_MARK(2);
     // per group: size, FP where it can change the verdict (bloom fingerprints of the hashes of the same bloom word first seen
     // earlier), and what the group emits
@@ -252,17 +312,17 @@ __global__ __launch_bounds__(RG_NT, 8) void rs_groups_kernel(RgArgs a)
     uint32_t g_p[RG_ITEMS], g_occ[RG_ITEMS], g_emit[RG_ITEMS], g_fp = 0, mine = 0;
 #pragma unroll
     for (int j = 0; j < RG_ITEMS; j++) {
-        const uint32_t kh = threadIdx.x + (uint32_t)RG_NT * j;
+        const uint32_t kh = tid + (uint32_t)RG_NT * j;
         g_p[j] = 0; g_occ[j] = 0; g_emit[j] = 0;
         if (kh >= n_heads) continue;
         const uint32_t p = s_hidx[kh], occ = (uint32_t)s_hidx[kh + 1] - p;
         uint32_t fpos = 0;
         if (mc == 2 || occ + 1 >= mc) {               // a smaller group passes nothing whatever its FP (occurrence number <= occ < min_count - 1)
-            const uint8_t lc = s_loc[p]; const uint32_t tp = s_t[p];
+            const uint8_t lc = s_hloc[kh]; const uint32_t tp = s_ht[kh];
             uint64_t seen = 0;
-            for (int kk = (int)kh - 1; kk >= 0; kk--) { const uint32_t q = s_hidx[kk]; if (s_loc[q] != lc) break; if (s_t[q] < tp) seen |= s_m[q]; }
-            for (uint32_t kk = kh + 1; kk < n_heads; kk++) { const uint32_t q = s_hidx[kk]; if (s_loc[q] != lc) break; if (s_t[q] < tp) seen |= s_m[q]; }
-            fpos = (s_m[p] & ~seen) == 0;
+            for (int kk = (int)kh - 1; kk >= 0 && s_hloc[kk] == lc; kk--) if (s_ht[kk] < tp) seen |= s_hfp[kk];
+            for (uint32_t kk = kh + 1; kk < n_heads && s_hloc[kk] == lc; kk++) if (s_ht[kk] < tp) seen |= s_hfp[kk];
+            fpos = (s_hfp[kh] & ~seen) == 0;
         }
         g_p[j] = p; g_occ[j] = occ; g_fp |= fpos << j;
         g_emit[j] = mc == 2 ? occ - 1 + fpos : (occ >= mc - fpos ? 1u : 0u);
@@ -271,7 +331,7 @@ __global__ __launch_bounds__(RG_NT, 8) void rs_groups_kernel(RgArgs a)
     RG_MARK(3);
     uint32_t total;
     const uint32_t ex = block_excl_scan(mine, total);
-    if (threadIdx.x == 0) s_gb = total ? atomicAdd(a.out_n, (unsigned long long)total) : 0ull;
+    if (tid == 0) s_gb = total ? atomicAdd(a.out_n, (unsigned long long)total) : 0ull;
     __syncthreads();
     RG_MARK(4);
     unsigned long long o = s_gb + ex;
@@ -407,20 +467,21 @@ int reads_sample_words(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual
     const bool fine = !coarse && !mid;
     const bool roomy = mean48 * 3 / 2 + 1024 <= (uint64_t)RG_CAP;
     const uint64_t n_part = fine ? 262144 : mid ? 131072 : 65536, fan1 = n_part / 256;
-    const uint64_t cap1 = n_win / fan1 + n_win / (fan1 * 16) + 16384,
+    const uint64_t nsrc = fan1 * RS_SLICES;                                                  // areas of the first pass: (slice, coarse partition)
+    const uint64_t cap1 = n_win / nsrc + n_win / (nsrc * 16) + 4096,
                    cap2 = (!coarse || roomy) ? (n_win / n_part) * 3 / 2 + 1024 : mean48 + mean48 / 4 + 1024;
     if (cap2 > (uint64_t)RG_CAP) return SKF_NOT_TAKEN;                                     // beyond ~530 M windows
     DevBuf<uint64_t> h1, h2; DevBuf<uint32_t> t1, t2, c1, c2, acc_t;
-    SKX_TRY(h1.alloc(fan1 * cap1)); SKX_TRY(t1.alloc(fan1 * cap1)); SKX_TRY(c1.alloc(fan1)); SKX_TRY(c1.zero(st));
+    SKX_TRY(h1.alloc(nsrc * cap1)); SKX_TRY(t1.alloc(nsrc * cap1)); SKX_TRY(c1.alloc(nsrc)); SKX_TRY(c1.zero(st));
     SKX_TRY(h2.alloc(n_part * cap2)); SKX_TRY(t2.alloc(n_part * cap2)); SKX_TRY(c2.alloc(n_part)); SKX_TRY(c2.zero(st));
-    RsArgs a1{hash.p, nullptr, flag.p, nullptr, 0, len, h1.p, t1.p, c1.p, cap1, d_over.p};
-    RsArgs a2{h1.p, t1.p, nullptr, c1.p, cap1, 0, h2.p, t2.p, c2.p, cap2, d_over.p};
-    const dim3 g1((unsigned)((len + RS_TILE - 1) / RS_TILE)), g2((unsigned)((cap1 + RS_TILE - 1) / RS_TILE), (unsigned)fan1);
+    RsArgs a1{hash.p, nullptr, flag.p, nullptr, 0, len, h1.p, t1.p, c1.p, cap1, d_over.p, 0u, 1u};
+    RsArgs a2{h1.p, t1.p, nullptr, c1.p, cap1, 0, h2.p, t2.p, c2.p, cap2, d_over.p, (uint32_t)fan1, (uint32_t)((cap1 + RS_TILE - 1) / RS_TILE)};
+    const dim3 g1((unsigned)((len + RS_TILE - 1) / RS_TILE)), g2((unsigned)(nsrc * ((cap1 + RS_TILE - 1) / RS_TILE)));
     SKX_TRY(acc_t.alloc(q.min_count == 2 ? n_win : n_win / 2 + 1024));                     // min_count >= 3: one position per group of >= 2... at most n_win / 2
     DevBuf<unsigned long long> d_dbg;
     if (getenv("SKX_DEBUG")) { SKX_TRY(d_dbg.alloc(8)); SKX_TRY(d_dbg.zero(st)); }
     RgArgs ag{h2.p, t2.p, c2.p, cap2, (int)q.min_count, acc_t.p, d_n.p, d_over.p, d_dbg.p};
-    const size_t lds = (size_t)(RG_CAP + RG_PAD) * 12 + ((size_t)RG_MB + 2) * 4 + (size_t)RG_CAP * 2 + 64;
+    const size_t lds = (size_t)(RG_CAP + RG_PAD) * 12 + ((size_t)RG_MB + 2) * 4 + (size_t)RG_CAP * 4 + 64;
     if (mid) {
         hipLaunchKernelGGL((rs_scatter_kernel<24 * 256, 512, true>), g1, dim3(RS_NT), 0, st, a1);
         hipLaunchKernelGGL((rs_scatter_kernel<24, 256, false>), g2, dim3(RS_NT), 0, st, a2);
@@ -449,7 +510,7 @@ int reads_sample_words(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual
     if (n_acc == 0) return SKX_OK;
     SKX_TRY(out_lo.alloc(n_acc)); if (wide) SKX_TRY(out_hi.alloc(n_acc));
     if (planes) launch_words_rebuild_planes(acc_t.p, n_acc, planes, k, rc, out_lo.p, wide ? out_hi.p : nullptr, st);
-    else launch_words_rebuild(acc_t.p, n_acc, d_seq, k, rc, out_lo.p, wide ? out_hi.p : nullptr, st);
+    else launch_words_rebuild(acc_t.p, n_acc, d_seq, len, k, rc, out_lo.p, wide ? out_hi.p : nullptr, st);
     SKX_HIP(hipStreamSynchronize(st));
     SKX_HIP(hipGetLastError());
     *n_out = n_acc;
