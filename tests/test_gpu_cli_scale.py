@@ -419,7 +419,9 @@ def test_read_set_pipeline_odd_bytes_and_line_lengths(tmp_path):
     with open(os.path.join(wd, "list.txt"), "w") as f:
         for i, (a, b) in enumerate(files):
             f.write(f"o{i}\t{a}\t{b}\n")
-    for k, qf, oq, mc in (("31", "strict", ora.QUAL_STRICT, 2), ("41", "middle", ora.QUAL_MIDDLE, 2), ("21", "no-filter", ora.QUAL_NOFILTER, 1)):
+    # (k = 9 and 15: the base that leaves a window lies inside the thread's own sixteen positions; k = 63: the whole 64-position history)
+    for k, qf, oq, mc in (("31", "strict", ora.QUAL_STRICT, 2), ("41", "middle", ora.QUAL_MIDDLE, 2), ("21", "no-filter", ora.QUAL_NOFILTER, 1),
+                          ("9", "strict", ora.QUAL_STRICT, 2), ("15", "middle", ora.QUAL_MIDDLE, 3), ("63", "strict", ora.QUAL_STRICT, 2)):
         outs = {}
         for tag, env in (("pipe", {}), ("avx2", {"SKX_KNOBS": "simd_cap=2"}), ("plain", {"SKX_KNOBS": "simd_cap=1"}), ("oneshot", {"SKX_KNOBS": "no_reads_pipeline=1"})):
             r = subprocess.run([SKA, "build", "-f", "list.txt", "-o", f"{tag}{k}", "-k", k, "--min-count", str(mc), "--min-qual", "20", "--qual-filter", qf, "--threads", "3"],
@@ -432,7 +434,7 @@ def test_read_set_pipeline_odd_bytes_and_line_lengths(tmp_path):
         got.sort_rows(); want.sort_rows()
         gk, gv, gc = got.export()
         ok, ov, oc = want.export()
-        assert len(ok) > 5_000 and np.array_equal(gk, ok) and np.array_equal(gv, ov) and np.array_equal(gc, oc), k
+        assert len(ok) > (5_000 if int(k) > 9 else 500) and np.array_equal(gk, ok) and np.array_equal(gv, ov) and np.array_equal(gc, oc), k
 
 
 def test_read_set_pipeline_gives_way_to_the_sort_based_form(tmp_path):

@@ -296,6 +296,46 @@ def test_fastq_kmer_filter(E, fastq_pair, k, min_count, qf, min_qual):
     assert np.array_equal(gk["lo"], ok["lo"]) and np.array_equal(gk["hi"], ok["hi"]) and np.array_equal(gb, ob)
 
 
+@pytest.fixture(scope="module")
+def ragged_fastq(tmp_path_factory):
+    """Reads of every awkward length -- shorter than k, exactly k, k + 1, odd, long -- with N runs, lower-case bases and the whole quality range;
+    total length no multiple of 16, deep enough (a 3 kbp genome) that every count threshold is met by some k-mers and missed by others."""
+    rng = np.random.default_rng(7)
+    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=3_000)
+    reads, quals = [], []
+    for i in range(6_000):
+        L = int(rng.choice([3, 6, 7, 8, 14, 15, 16, 17, 18, 31, 32, 33, 41, 42, 63, 64, 65, 97, 151]))
+        s = int(rng.integers(0, len(genome) - L))
+        r = genome[s:s + L].copy()
+        err = rng.random(L) < 0.01
+        r[err] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(err.sum()))
+        if rng.random() < 0.05:
+            a = int(rng.integers(0, L)); r[a:a + int(rng.integers(1, 4))] = ord("N")
+        if rng.random() < 0.05:
+            r = np.frombuffer(r.tobytes().lower(), dtype=np.uint8).copy()
+        q = rng.integers(100, 127, size=L).astype(np.uint8)          # mostly high, one in ten anywhere in '!' .. '~'
+        lowq = rng.random(L) < 0.1
+        q[lowq] = rng.integers(33, 127, size=int(lowq.sum())).astype(np.uint8)
+        reads.append(r.tobytes()); quals.append(q.tobytes())
+    d = tmp_path_factory.mktemp("rfq")
+    p = str(d / "ragged.fastq")
+    _write_fastq(p, reads, quals)
+    return p
+
+
+@pytest.mark.parametrize("k,rc,min_count,qf,min_qual", [(7, True, 2, 2, 20), (15, True, 3, 1, 40), (17, False, 2, 2, 0), (31, True, 3, 2, 60),
+                                                        (33, False, 4, 0, 20), (63, True, 2, 2, 20), (63, False, 3, 1, 80)])
+def test_fastq_kmer_filter_ragged_reads(E, ragged_fastq, k, rc, min_count, qf, min_qual):
+    """The window pass at its edges: k below 16 (the base that leaves a window lies in the thread's own sixteen positions), k = 63 (the whole 64-position
+    history), single strand, reads shorter than k, every quality threshold from 0 to the top of the range; one file (ska_dict.rs:118-180)."""
+    og = ora.Dict.from_files(k, ragged_fastq, None, rc, ora.qual(min_count, min_qual, qf))
+    ds = E.DictSet.from_files([(ragged_fastq, None)], k, rc, E.qual(min_count, min_qual, qf))
+    ok, ob = og.export()
+    gk, gb = ds.export(0)
+    assert len(ok) > 50
+    assert len(gk) == len(ok) and np.array_equal(gk["lo"], ok["lo"]) and np.array_equal(gk["hi"], ok["hi"]) and np.array_equal(gb, ob)
+
+
 # ---- failure behaviour (the reference panics; the C ABI returns codes with the same message text) ----
 def test_error_codes(E, tmp_path):
     with pytest.raises(E.EngineError) as ei:                                   # ska_dict.rs:342-344
