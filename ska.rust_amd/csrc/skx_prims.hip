@@ -202,10 +202,7 @@ __global__ __launch_bounds__(PR_NT) void rs_scatter_kernel(const K *kin, K *kout
 {
     __shared__ uint32_t s_run[PR_NT / 64][256];
     const int wv = threadIdx.x >> 6;
-    // Workgroups go round the 8 XCDs by their index: XCD x takes the x-th eighth of the tiles, in order -- a digit's run of one block (~16 keys) ends
-    // inside a line that the NEXT block's run goes on with, and both then pass through the same L2 (the grid is a multiple of 8 blocks)
-    const uint64_t blk = (uint64_t)(blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u;
-    const uint64_t tile = blk * (PR_NT / 64) + wv;
+    const uint64_t tile = (uint64_t)blockIdx.x * (PR_NT / 64) + wv;
     if (tile >= ntiles) return;
     for (int d = lane_id(); d < 256; d += 64) s_run[wv][d] = offs[(uint64_t)d * ntiles + tile];
     __builtin_amdgcn_wave_barrier();
@@ -251,7 +248,7 @@ int radix_sort(const K *kin, K *kout, const uint32_t *vin, uint32_t *vout, uint6
         K *dst = to_out ? kout : ktmp.p; uint32_t *vdst = to_out ? vout : vtmp.p;
         hipLaunchKernelGGL(rs_hist_kernel<K>, dim3((unsigned)nblocks), dim3(PR_NT), 0, st, src, n, 8 * p, ntiles, counts.p);
         SKX_TRY((scan_u32<OpAdd, true>(counts.p, counts.p, 256 * ntiles, st)));
-        hipLaunchKernelGGL((rs_scatter_kernel<K, HASV>), dim3((unsigned)((nblocks + 7) / 8 * 8)), dim3(PR_NT), 0, st, src, dst, vsrc, vdst, n, 8 * p, ntiles, counts.p);
+        hipLaunchKernelGGL((rs_scatter_kernel<K, HASV>), dim3((unsigned)nblocks), dim3(PR_NT), 0, st, src, dst, vsrc, vdst, n, 8 * p, ntiles, counts.p);
         src = dst; vsrc = vdst;
     }
     PRH(hipStreamSynchronize(st));
