@@ -219,7 +219,9 @@ int reads_sample_dict(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual,
 // the same through the engine's own partition kernels (skx_reads2.hip): the packed words of the windows that enter the dictionary,
 // unsorted and with duplicates; SKF_NOT_TAKEN leaves the sample to reads_sample_dict
 int reads_windows(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t len, int k, int rc, const skx_qual &q, DevBuf<uint64_t> &hash,
-                  DevBuf<uint64_t> &wlo, DevBuf<uint64_t> &whi, DevBuf<uint8_t> &flag, unsigned long long *d_n_valid = nullptr, bool want_words = true, const uint64_t *planes = nullptr);
+                  DevBuf<uint64_t> &wlo, DevBuf<uint64_t> &whi, DevBuf<uint8_t> &flag, unsigned long long *d_n_valid, bool want_words, const uint64_t *planes,
+                  DevBuf<uint16_t> &rec_t, DevBuf<uint32_t> &tile_cnt);
+int reads_tile();                      // positions a workgroup of the window pass takes (= the first partition pass's tile)
 void launch_words_rebuild(const uint32_t *pos, uint64_t n, const uint8_t *seq, uint64_t len, int k, int rc, uint64_t *out_lo, uint64_t *out_hi, hipStream_t st);
 void launch_words_rebuild_planes(const uint32_t *pos, uint64_t n, const uint64_t *planes, int k, int rc, uint64_t *out_lo, uint64_t *out_hi, hipStream_t st);
 int reads_sample_words(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t len, int k, int rc, const skx_qual &q,

@@ -27,6 +27,7 @@ struct ReadsArgs {
     uint64_t *hash; uint64_t *wlo; uint64_t *whi; uint8_t *flag;
     unsigned long long *n_valid;      // optional: [256] counters, slot blockIdx % 256 += windows that pass the gates (one hot counter costs 2 ms)
     const uint64_t *planes;           // optional: the sample as packed bit planes (skx_device.h planes_bytes16) instead of seq / qual
+    uint16_t *rec_t; uint32_t *tile_cnt;      // WORDS = false: the tile's gated windows leave compacted -- hash[tile * RW_TILE + r], rec_t[..] = position inside the tile, tile_cnt[tile] of them
 };
 
 // Sixteen consecutive window-end positions per thread (two batches of eight).
@@ -94,6 +95,8 @@ __global__ __launch_bounds__(RW_NT) void reads_windows_kernel(ReadsArgs a)
     __shared__ uint32_t s_code[RW_CH + 3];
     __shared__ uint16_t s_bad[RW_CH + 3], s_nl[RW_CH + 3], s_qb[RW_CH + 3];
     __shared__ __attribute__((aligned(16))) uint64_t s_out[RW_PPT * RW_STRIDE];
+    __shared__ uint16_t s_off[WORDS ? 1 : RW_PPT * RW_NT];               // (compact form) the position inside the tile of a batch's gated windows
+    __shared__ uint32_t s_ws[RW_NT / 64 + 1];
     __shared__ __attribute__((aligned(16))) uint64_t s_T[32];            // [2 (4 leaving + entering)] = rotl(H[leaving], k) ^ H[entering], [.. + 1] = rotr(R[leaving], 1) ^ rotl(R[entering], k - 1)
     const uint32_t tid = threadIdx.x;
     const int k = a.k, h = (k - 1) / 2;
@@ -218,7 +221,9 @@ __global__ __launch_bounds__(RW_NT) void reads_windows_kernel(ReadsArgs a)
         }
         __syncthreads();
     };
+    (void)put;
     uint32_t flags = 0;                                    // bit j: my j-th window passes the gates
+    uint32_t n_out = 0;                                    // (compact form) records of this tile written so far
 #pragma unroll 1
     for (int b = 0; b < RW_NB; b++) {
     const bool mine = pstart + (uint64_t)b * RW_PPT < a.len;
@@ -264,11 +269,38 @@ __global__ __launch_bounds__(RW_NT) void reads_windows_kernel(ReadsArgs a)
         flags |= fb << (RW_PPT * b);
         cw >>= 2 * RW_PPT; coutw >>= 2 * RW_PPT; badw >>= RW_PPT; nlw >>= RW_PPT; qbw >>= RW_PPT;
     }
-    put(o_hash, a.hash, b, mine);
     if constexpr (WORDS) {
+        put(o_hash, a.hash, b, mine);
         put(o_lo, a.wlo, b, mine);
         if (a.whi) put(o_hi, a.whi, b, mine);
+    } else {
+        // only the gated windows leave (47 % of a deep isolate's positions), as (hash, position in the tile) in the order of the threads: the partition
+        // pass reads these instead of a hash and a flag per position
+        const uint32_t at_b = tid * (RW_PPT * RW_NB) + (uint32_t)b * RW_PPT;
+        uint32_t fb = mine ? (flags >> (RW_PPT * b)) & ((1u << RW_PPT) - 1u) : 0u;
+        if (at_b + RW_PPT > (uint32_t)left) fb &= at_b < (uint32_t)left ? (1u << ((uint32_t)left - at_b)) - 1u : 0u;
+        const uint32_t c = (uint32_t)__popc(fb);
+        uint32_t inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(inc, d, 64); if ((int)(tid & 63u) >= d) inc += y; }
+        if ((tid & 63u) == 63u) s_ws[tid >> 6] = inc;
+        __syncthreads();
+        uint32_t ex = inc - c, total = 0;
+#pragma unroll
+        for (int w = 0; w < RW_NT / 64; w++) { const uint32_t v = s_ws[w]; if (w < (int)(tid >> 6)) ex += v; total += v; }
+#pragma unroll
+        for (int j = 0; j < RW_PPT; j++)
+            if ((fb >> j) & 1u) { s_out[ex] = o_hash[j]; s_off[ex] = (uint16_t)(at_b + j); ex++; }
+        __syncthreads();
+        const uint64_t tb = p0 + n_out;                                     // (a tile's slots are its RW_TILE positions)
+        for (uint32_t i = tid; i < total; i += RW_NT) { a.hash[tb + i] = s_out[i]; a.rec_t[tb + i] = s_off[i]; }
+        n_out += total;
+        __syncthreads();
     }
+    }
+    if constexpr (!WORDS) {
+        if (tid == 0) { a.tile_cnt[blockIdx.x] = n_out; if (a.n_valid && n_out) atomicAdd(a.n_valid + (blockIdx.x & 255u), (unsigned long long)n_out); }
+        return;
     }
     // my sixteen flags: one byte each, 16 bytes at a multiple of 16
     const uint32_t at0 = tid * (RW_PPT * RW_NB);
@@ -486,18 +518,22 @@ void launch_words_rebuild(const uint32_t *pos, uint64_t n, const uint8_t *seq, u
 
 // the window pass alone: per window-end position its ntHash, whether it passes the quality gates and -- want_words -- its packed word
 int reads_windows(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t len, int k, int rc, const skx_qual &q, DevBuf<uint64_t> &hash,
-                  DevBuf<uint64_t> &wlo, DevBuf<uint64_t> &whi, DevBuf<uint8_t> &flag, unsigned long long *d_n_valid, bool want_words, const uint64_t *planes)
+                  DevBuf<uint64_t> &wlo, DevBuf<uint64_t> &whi, DevBuf<uint8_t> &flag, unsigned long long *d_n_valid, bool want_words, const uint64_t *planes,
+                  DevBuf<uint16_t> &rec_t, DevBuf<uint32_t> &tile_cnt)
 {
     const bool wide = k > 31;
-    SKX_TRY(hash.alloc(len)); SKX_TRY(flag.alloc(len));
-    if (want_words) { SKX_TRY(wlo.alloc(len)); if (wide) SKX_TRY(whi.alloc(len)); }
+    const uint64_t tiles = (len + RW_TILE - 1) / RW_TILE;
+    SKX_TRY(hash.alloc(tiles * RW_TILE));
+    if (want_words) { SKX_TRY(flag.alloc(len)); SKX_TRY(wlo.alloc(len)); if (wide) SKX_TRY(whi.alloc(len)); }
+    else { SKX_TRY(rec_t.alloc(tiles * RW_TILE)); SKX_TRY(tile_cnt.alloc(tiles)); }          // the gated windows only, compacted per tile
     ReadsArgs ra{d_seq, d_qual, len, k, rc, q.min_qual, q.qual_filter, make_hash_params(k < 31 ? k : 31), make_wide_hash(k),
-                 hash.p, want_words ? wlo.p : nullptr, want_words && wide ? whi.p : nullptr, flag.p, d_n_valid, planes};
-    const dim3 g((unsigned)((len + RW_TILE - 1) / RW_TILE));
+                 hash.p, want_words ? wlo.p : nullptr, want_words && wide ? whi.p : nullptr, flag.p, d_n_valid, planes, rec_t.p, tile_cnt.p};
+    const dim3 g((unsigned)tiles);
     if (want_words) hipLaunchKernelGGL(reads_windows_kernel<true>, g, dim3(RW_NT), 0, ctx->stream, ra);
     else hipLaunchKernelGGL(reads_windows_kernel<false>, g, dim3(RW_NT), 0, ctx->stream, ra);
     return SKX_OK;
 }
+int reads_tile() { return RW_TILE; }
 
 // One FASTQ sample -> its SkaDict as a sorted (engine order) list of unique packed words.
 int reads_sample_dict(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t len, int k, int rc, const skx_qual &q,

@@ -31,9 +31,12 @@ __device__ static inline uint64_t bloom_fp5(uint64_t h)                  // bloo
 }
 
 // ---------------------------------------------------------------------------------------------------------- partition
-constexpr int RS_TILE = 4096, RS_NT = 512, RS_PER = RS_TILE / RS_NT;
+#ifndef SKX_RS_NT
+#define SKX_RS_NT 512
+#endif
+constexpr int RS_TILE = 4096, RS_NT = SKX_RS_NT, RS_PER = RS_TILE / RS_NT;
 struct RsArgs {
-    const uint64_t *src_h; const uint32_t *src_t; const uint8_t *flag;      // FROM_POS: hash[p], flag[p], t = p; else records of source partitions
+    const uint64_t *src_h; const uint32_t *src_t; const uint16_t *src_t16;  // FROM_POS: the window pass's tiles (hash, position inside the tile; src_cnt a tile); else records of source partitions
     const uint32_t *src_cnt; uint64_t src_cap, n_pos;
     uint64_t *dst_h; uint32_t *dst_t; uint32_t *dst_cnt; uint64_t dst_cap;   // destination partition holds dst_cap records
     int *overflow;
@@ -55,21 +58,20 @@ __global__ __launch_bounds__(RS_NT) void rs_scatter_kernel(RsArgs a)
     const uint32_t xr = blockIdx.x / RS_SLICES;                                         // (second pass) my number on my XCD
     const uint32_t src = FROM_POS ? 0u : (xr / a.src_tiles) * RS_SLICES + blockIdx.x % RS_SLICES;
     const uint32_t dpre = FROM_POS ? blockIdx.x % RS_SLICES : src % a.src_mod;          // destination = dpre * FAN + sub
-    const uint64_t n = FROM_POS ? a.n_pos : (uint64_t)a.src_cnt[src];
-    const uint64_t i0 = (uint64_t)(FROM_POS ? blockIdx.x : xr % a.src_tiles) * RS_TILE;
+    // first pass: workgroup = one tile of the window pass (RS_TILE positions, its gated windows compacted at the tile's first slots)
+    const uint64_t n = FROM_POS ? (uint64_t)a.src_cnt[blockIdx.x] : (uint64_t)a.src_cnt[src];
+    const uint64_t i0 = FROM_POS ? 0ull : (uint64_t)(xr % a.src_tiles) * RS_TILE;
     if (i0 >= n) return;
-    const uint64_t sbase = FROM_POS ? 0 : (uint64_t)src * a.src_cap;
+    const uint64_t sbase = FROM_POS ? (uint64_t)blockIdx.x * RS_TILE : (uint64_t)src * a.src_cap;
     for (int i = threadIdx.x; i < FAN; i += RS_NT) s_hist[i] = 0;
     __syncthreads();
     uint64_t h[RS_PER]; uint32_t t[RS_PER], rk[RS_PER];
 #pragma unroll
     for (int j = 0; j < RS_PER; j++) {
         const uint64_t i = i0 + threadIdx.x + (uint64_t)RS_NT * j;
-        // (the hash is requested beside the flag, not behind it: nearly every line of hashes holds gated windows anyway)
-        const uint64_t hv = i < n ? a.src_h[sbase + i] : 0ull;
-        const bool valid = i < n && (!FROM_POS || a.flag[i]);
-        h[j] = valid ? hv : 0ull;
-        t[j] = FROM_POS ? (uint32_t)i : (valid ? a.src_t[sbase + i] : 0u);
+        const bool valid = i < n;
+        h[j] = valid ? a.src_h[sbase + i] : 0ull;
+        t[j] = !valid ? 0u : FROM_POS ? (uint32_t)sbase + (uint32_t)a.src_t16[sbase + i] : a.src_t[sbase + i];
         rk[j] = 0xFFFFFFFFu;
         if (valid) { const uint32_t sub = (loc_of(mixh(h[j])) / (uint32_t)DIV) % (uint32_t)FAN; rk[j] = (sub << 16) | atomicAdd(&s_hist[sub], 1u); }
     }
@@ -434,11 +436,11 @@ int reads_sample_words(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual
     *n_out = 0;
     if (len == 0) return SKX_OK;
     if (len > 0xFFFFFFF0ull) { set_error("FASTQ sample longer than 4 G bases"); return SKX_EUNSUP; }
-    DevBuf<uint64_t> wlo, whi, hash; DevBuf<uint8_t> flag;
+    DevBuf<uint64_t> wlo, whi, hash; DevBuf<uint8_t> flag; DevBuf<uint16_t> rec_t; DevBuf<uint32_t> tile_cnt;
     DevBuf<unsigned long long> d_n; DevBuf<int> d_over;            // d_n[0]: positions / words that leave; d_n[1 .. 257): gated windows (spread counters)
     SKX_TRY(d_n.alloc(257)); SKX_TRY(d_n.zero(st)); SKX_TRY(d_over.alloc(1)); SKX_TRY(d_over.zero(st));
     const bool all_words = q.min_count <= 1;                       // every gated window enters: the window pass writes the words itself
-    SKX_TRY(reads_windows(ctx, d_seq, d_qual, len, k, rc, q, hash, wlo, whi, flag, d_n.p + 1, all_words, planes));      // (planes: the sample packed, d_seq / d_qual unused)
+    SKX_TRY(reads_windows(ctx, d_seq, d_qual, len, k, rc, q, hash, wlo, whi, flag, d_n.p + 1, all_words, planes, rec_t, tile_cnt));      // (planes: the sample packed, d_seq / d_qual unused)
     unsigned long long n_acc = 0;
     if (q.min_count <= 1) {                                        // KmerFilter: 0 | 1 => every gated window enters
         SKX_TRY(out_lo.alloc(len)); if (wide) SKX_TRY(out_hi.alloc(len));
@@ -474,8 +476,9 @@ int reads_sample_words(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual
     DevBuf<uint64_t> h1, h2; DevBuf<uint32_t> t1, t2, c1, c2, acc_t;
     SKX_TRY(h1.alloc(nsrc * cap1)); SKX_TRY(t1.alloc(nsrc * cap1)); SKX_TRY(c1.alloc(nsrc)); SKX_TRY(c1.zero(st));
     SKX_TRY(h2.alloc(n_part * cap2)); SKX_TRY(t2.alloc(n_part * cap2)); SKX_TRY(c2.alloc(n_part)); SKX_TRY(c2.zero(st));
-    RsArgs a1{hash.p, nullptr, flag.p, nullptr, 0, len, h1.p, t1.p, c1.p, cap1, d_over.p, 0u, 1u};
+    RsArgs a1{hash.p, nullptr, rec_t.p, tile_cnt.p, 0, len, h1.p, t1.p, c1.p, cap1, d_over.p, 0u, 1u};
     RsArgs a2{h1.p, t1.p, nullptr, c1.p, cap1, 0, h2.p, t2.p, c2.p, cap2, d_over.p, (uint32_t)fan1, (uint32_t)((cap1 + RS_TILE - 1) / RS_TILE)};
+    if (reads_tile() != RS_TILE) { set_error("the window pass and the partition pass disagree on the tile"); return SKX_EUNSUP; }
     const dim3 g1((unsigned)((len + RS_TILE - 1) / RS_TILE)), g2((unsigned)(nsrc * ((cap1 + RS_TILE - 1) / RS_TILE)));
     SKX_TRY(acc_t.alloc(q.min_count == 2 ? n_win : n_win / 2 + 1024));                     // min_count >= 3: one position per group of >= 2... at most n_win / 2
     DevBuf<unsigned long long> d_dbg;
