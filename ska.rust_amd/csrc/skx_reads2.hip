@@ -31,10 +31,8 @@ __device__ static inline uint64_t bloom_fp5(uint64_t h)                  // bloo
 }
 
 // ---------------------------------------------------------------------------------------------------------- partition
-#ifndef SKX_RS_NT
-#define SKX_RS_NT 512
-#endif
-constexpr int RS_TILE = 4096, RS_NT = SKX_RS_NT, RS_PER = RS_TILE / RS_NT;
+constexpr int RS_TILE = 4096, RS_NT = 512, RS_PER = RS_TILE / RS_NT;          // (256 threads: + 30 %, 1 024: the same)
+constexpr uint32_t RS_GROUP = 2;                                               // tiles of the window pass a workgroup of the first pass takes
 struct RsArgs {
     const uint64_t *src_h; const uint32_t *src_t; const uint16_t *src_t16;  // FROM_POS: the window pass's tiles (hash, position inside the tile; src_cnt a tile); else records of source partitions
     const uint32_t *src_cnt; uint64_t src_cap, n_pos;
@@ -58,11 +56,21 @@ __global__ __launch_bounds__(RS_NT) void rs_scatter_kernel(RsArgs a)
     const uint32_t xr = blockIdx.x / RS_SLICES;                                         // (second pass) my number on my XCD
     const uint32_t src = FROM_POS ? 0u : (xr / a.src_tiles) * RS_SLICES + blockIdx.x % RS_SLICES;
     const uint32_t dpre = FROM_POS ? blockIdx.x % RS_SLICES : src % a.src_mod;          // destination = dpre * FAN + sub
-    // first pass: workgroup = one tile of the window pass (RS_TILE positions, its gated windows compacted at the tile's first slots)
-    const uint64_t n = FROM_POS ? (uint64_t)a.src_cnt[blockIdx.x] : (uint64_t)a.src_cnt[src];
+    // first pass: a workgroup takes RS_GROUP tiles of the window pass (RS_TILE positions each, their gated windows compacted at the tile's first
+    // slots) -- together where they fit its RS_TILE record slots (a deep isolate gates 47 % of its positions: a destination's run is then ~22 records
+    // instead of ~11), one after the other where they do not
+    const uint32_t ntl = FROM_POS ? (uint32_t)((a.n_pos + RS_TILE - 1) / RS_TILE) : 0u, tl0 = blockIdx.x * RS_GROUP;
+    const uint32_t c0 = FROM_POS ? a.src_cnt[tl0] : 0u, c1 = FROM_POS && tl0 + 1u < ntl ? a.src_cnt[tl0 + 1u] : 0u;
+    const bool together = c0 + c1 <= (uint32_t)RS_TILE;
+    const uint32_t rounds = FROM_POS ? (together ? 1u : 2u) : 1u;
+    for (uint32_t rd = 0; rd < rounds; rd++) {
+    const uint32_t nA = !FROM_POS ? 0u : (together || rd == 0) ? c0 : c1, nB = FROM_POS && together ? c1 : 0u;      // records of the round's first / second tile
+    const uint64_t baseA = (uint64_t)(tl0 + (together ? 0u : rd)) * RS_TILE, baseB = (uint64_t)(tl0 + 1u) * RS_TILE;
+    const uint64_t n = FROM_POS ? (uint64_t)(nA + nB) : (uint64_t)a.src_cnt[src];
     const uint64_t i0 = FROM_POS ? 0ull : (uint64_t)(xr % a.src_tiles) * RS_TILE;
-    if (i0 >= n) return;
-    const uint64_t sbase = FROM_POS ? (uint64_t)blockIdx.x * RS_TILE : (uint64_t)src * a.src_cap;
+    if (i0 >= n) { if (FROM_POS) continue; return; }
+    const uint64_t sbase = (uint64_t)src * a.src_cap;
+    if (rd) __syncthreads();                                                // (the round before is done with the tables)
     for (int i = threadIdx.x; i < FAN; i += RS_NT) s_hist[i] = 0;
     __syncthreads();
     uint64_t h[RS_PER]; uint32_t t[RS_PER], rk[RS_PER];
@@ -70,8 +78,9 @@ __global__ __launch_bounds__(RS_NT) void rs_scatter_kernel(RsArgs a)
     for (int j = 0; j < RS_PER; j++) {
         const uint64_t i = i0 + threadIdx.x + (uint64_t)RS_NT * j;
         const bool valid = i < n;
-        h[j] = valid ? a.src_h[sbase + i] : 0ull;
-        t[j] = !valid ? 0u : FROM_POS ? (uint32_t)sbase + (uint32_t)a.src_t16[sbase + i] : a.src_t[sbase + i];
+        const uint64_t at = !FROM_POS ? sbase + i : i < nA ? baseA + i : baseB + (i - nA);
+        h[j] = valid ? a.src_h[at] : 0ull;
+        t[j] = !valid ? 0u : FROM_POS ? (uint32_t)(at & ~(uint64_t)(RS_TILE - 1)) + (uint32_t)a.src_t16[at] : a.src_t[at];
         rk[j] = 0xFFFFFFFFu;
         if (valid) { const uint32_t sub = (loc_of(mixh(h[j])) / (uint32_t)DIV) % (uint32_t)FAN; rk[j] = (sub << 16) | atomicAdd(&s_hist[sub], 1u); }
     }
@@ -107,6 +116,7 @@ __global__ __launch_bounds__(RS_NT) void rs_scatter_kernel(RsArgs a)
         const uint32_t sub = (loc_of(mixh(hh)) / (uint32_t)DIV) % (uint32_t)FAN;
         const uint64_t r = (uint64_t)s_gbase[sub] + (i - s_lbase[sub]);
         if (r < a.dst_cap) { const uint64_t o = ((uint64_t)dpre * FAN + sub) * a.dst_cap + r; a.dst_h[o] = hh; a.dst_t[o] = s_t[i]; }
+    }
     }
 }
 
@@ -479,7 +489,7 @@ int reads_sample_words(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual
     RsArgs a1{hash.p, nullptr, rec_t.p, tile_cnt.p, 0, len, h1.p, t1.p, c1.p, cap1, d_over.p, 0u, 1u};
     RsArgs a2{h1.p, t1.p, nullptr, c1.p, cap1, 0, h2.p, t2.p, c2.p, cap2, d_over.p, (uint32_t)fan1, (uint32_t)((cap1 + RS_TILE - 1) / RS_TILE)};
     if (reads_tile() != RS_TILE) { set_error("the window pass and the partition pass disagree on the tile"); return SKX_EUNSUP; }
-    const dim3 g1((unsigned)((len + RS_TILE - 1) / RS_TILE)), g2((unsigned)(nsrc * ((cap1 + RS_TILE - 1) / RS_TILE)));
+    const dim3 g1((unsigned)(((len + RS_TILE - 1) / RS_TILE + RS_GROUP - 1) / RS_GROUP)), g2((unsigned)(nsrc * ((cap1 + RS_TILE - 1) / RS_TILE)));
     SKX_TRY(acc_t.alloc(q.min_count == 2 ? n_win : n_win / 2 + 1024));                     // min_count >= 3: one position per group of >= 2... at most n_win / 2
     DevBuf<unsigned long long> d_dbg;
     if (getenv("SKX_DEBUG")) { SKX_TRY(d_dbg.alloc(8)); SKX_TRY(d_dbg.zero(st)); }
