@@ -630,11 +630,20 @@ __global__ __launch_bounds__(256) void pieces_stats_kernel(const uint8_t *pieces
     const uint4 *col = reinterpret_cast<const uint4 *>(pieces + j * (uint64_t)S * (cap / 2)) + d;
     const uint32_t step = cap / 32;                                   // 16-byte pieces from one sample's piece to the next
     const bool mine = d * 32u < nr;
+    uint32_t pN[W], aN[W];                                            // nibble counters (a rank each): present / ambiguous cells, folded into the byte counters every 12 samples
     uint32_t pE[W], pO[W], aE[W], aO[W], uni[W];                      // byte counters: present / ambiguous cells of the even and odd ranks; OR of the cells
     uint32_t PE0[W], PE1[W], PO0[W], PO1[W], AE0[W], AE1[W], AO0[W], AO1[W];      // the same, 16 bits per rank
 #pragma unroll
-    for (int w = 0; w < W; w++) { pE[w] = pO[w] = aE[w] = aO[w] = uni[w] = 0; PE0[w] = PE1[w] = PO0[w] = PO1[w] = AE0[w] = AE1[w] = AO0[w] = AO1[w] = 0; }
+    for (int w = 0; w < W; w++) { pN[w] = aN[w] = 0; pE[w] = pO[w] = aE[w] = aO[w] = uni[w] = 0; PE0[w] = PE1[w] = PO0[w] = PO1[w] = AE0[w] = AE1[w] = AO0[w] = AO1[w] = 0; }
+    auto nibfold = [&]() {
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            pE[w] += pN[w] & 0x0F0F0F0Fu; pO[w] += (pN[w] >> 4) & 0x0F0F0F0Fu; aE[w] += aN[w] & 0x0F0F0F0Fu; aO[w] += (aN[w] >> 4) & 0x0F0F0F0Fu;
+            pN[w] = aN[w] = 0;
+        }
+    };
     auto fold = [&]() {
+        nibfold();
 #pragma unroll
         for (int w = 0; w < W; w++) {
             PE0[w] += pE[w] & 0x00FF00FFu; PE1[w] += (pE[w] >> 8) & 0x00FF00FFu; PO0[w] += pO[w] & 0x00FF00FFu; PO1[w] += (pO[w] >> 8) & 0x00FF00FFu;
@@ -648,17 +657,18 @@ __global__ __launch_bounds__(256) void pieces_stats_kernel(const uint8_t *pieces
         const uint32_t y = x & (x - nz);                              // every nibble without its lowest bit
         uint32_t u = y | (y >> 1); u |= u >> 2;
         const uint32_t am = u & 0x11111111u;                          // one bit per nibble with two bases or more
-        pE[w] += nz & 0x01010101u; pO[w] += (nz >> 4) & 0x01010101u;
-        aE[w] += am & 0x01010101u; aO[w] += (am >> 4) & 0x01010101u;
+        pN[w] += nz; aN[w] += am;                                     // (a nibble holds 12 samples' worth before it is folded)
         uni[w] |= x;
     };
     // 64 samples at a time: their piece lengths arrive as one vector load (a lane each) and are handed round with v_readlane; four 16-byte loads in
     // flight per lane (a dword per lane and load made 27 M small requests of this pass: 2.7 ms); the byte counters are folded every 192 samples
-    for (int s0 = 0, since = 0; s0 < S; s0 += 64) {
+    for (int s0 = 0, since = 0, nib = 0; s0 < S; s0 += 64) {
         const uint32_t plv = s0 + lane < S ? (uint32_t)pl[s0 + lane] : 0u;
         const int n = S - s0 < 64 ? S - s0 : 64;
 #pragma unroll 1
         for (int i0 = 0; i0 < n; i0 += 4) {
+            if (nib == 12) { nibfold(); nib = 0; }
+            nib += 4;
             uint4 x[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -670,7 +680,7 @@ __global__ __launch_bounds__(256) void pieces_stats_kernel(const uint8_t *pieces
             for (int u = 0; u < 4; u++) { take(0, x[u].x); take(1, x[u].y); take(2, x[u].z); take(3, x[u].w); }
         }
         since += 64;
-        if (since >= 192) { fold(); since = 0; }
+        if (since >= 192) { fold(); since = 0; nib = 0; }
     }
     fold();
     const uint16_t *pj = perm + j * (uint64_t)cap;
