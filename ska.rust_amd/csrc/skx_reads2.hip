@@ -1,20 +1,22 @@
 // skx_reads2.hip -- KmerFilter (bloom_filter.rs:35-148) for a whole FASTQ sample with the engine's own kernels: the windows of
-// the sample are partitioned by bloom word and every partition is evaluated in LDS.  (skx_reads.hip holds the first form, a
-// chain of rocPRIM sorts / scans / selections; it remains as the fallback for samples this form does not take.)
+// the sample are partitioned by bloom word and every partition is evaluated in LDS.  (skx_reads.hip holds the window pass and the
+// first form, a chain of sorts / scans / selections on skx_prims.hip; that form remains for the samples this one does not take.)
 //
 // What the reference computes per k-mer hash h, with occurrences t_1 < t_2 < ... in stream order:
 //   FP(h)  <=>  fp(h) is a subset of OR{ fp(g) : loc(g) == loc(h), first(g) < first(h) }          (the blocked bloom's false positive)
 //   min_count == 2 : every occurrence passes except t_1, which passes iff FP(h)
 //   min_count >= 3 : exactly the (min_count - FP(h))-th occurrence passes
 // loc(h) = (mix(h) * 3 145 728) >> 64 with mix a bijection (bloom_filter.rs:50-58,72-74), so ordering the windows by m = mix(h)
-// groups equal hashes AND equal bloom words: one partition by loc serves both.  3 145 728 = 32 768 x 96, so a final partition is
-// exactly 96 consecutive bloom words (~5 500 windows of a 50x isolate) -- no bloom word straddles two partitions.
-//   rs_scatter_kernel<24576,128> : windows (hash, position) -> 128 coarse partitions   (tiles of 4 096, chunks of ~23 records)
-//   rs_scatter_kernel<96,256>    : each coarse partition -> 256 final ones
-//   rs_groups_kernel             : a final partition in LDS: counting sort by m into micro-buckets, rank by (m, position),
-//                                  hash groups, bloom-word groups, FP, verdict per occurrence -> positions that pass
-//   words_* kernels              : passing positions -> packed words -> (sample, bucket) regions of a dictset, which the
-//                                  assemblies' dedupe_mb_kernel sorts / folds (so reads get sub-indexed regions too)
+// groups equal hashes AND equal bloom words: one partition by loc serves both.  3 145 728 = 65 536 x 48, so a final partition is
+// exactly 48 consecutive bloom words (~1 800 windows of a 50x isolate; 24 or 12 words for larger samples) -- no bloom word straddles two.
+//   reads_windows_kernel<false>   : (skx_reads.hip) per tile of 4 096 positions the gated windows as (ntHash, position in the tile), compacted
+//   rs_scatter_kernel<12288,256,1>: two such tiles a workgroup -> 256 coarse partitions x 8 slices (one per XCD)
+//   rs_scatter_kernel<48,256,0>   : each (slice, coarse partition) -> the coarse partition's 256 final ones, its sources on one XCD in sequence
+//   rs_groups_kernel              : a final partition in LDS: counting sort by m into micro-buckets, rank by position (by (m, position) in
+//                                   the few micro-buckets that hold two hashes), hash groups, bloom-word groups, FP, verdict per occurrence
+//                                   -> positions that pass
+//   words_* kernels               : passing positions -> packed words -> (sample, bucket) regions of a dictset, which the
+//                                   assemblies' dedupe_mb_kernel sorts / folds (so reads get sub-indexed regions too)
 #include "skx_internal.h"
 #include <algorithm>
 
