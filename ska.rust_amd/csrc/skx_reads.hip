@@ -108,10 +108,21 @@ __global__ __launch_bounds__(RW_NT) void reads_windows_kernel(ReadsArgs a)
     // Before the first put() the output buffer holds ntHash's words as the FIRST window needs them: [4 i + c] = rotl(H[c], k - 1 - i) and
     // [256 + 4 i + c] = rotl(R[c], i) for the window's i-th base
     uint64_t *s_rot = s_out;
-    static_assert(RW_PPT * RW_STRIDE >= 512, "the start-up table fits the output buffer");
-    for (int i = (int)tid; i < 4 * k; i += RW_NT) {
-        s_rot[i] = rotl64d(NT_H[i & 3], (unsigned)(k - 1 - (i >> 2)));
-        s_rot[256 + i] = rotl64d(NT_RC[i & 3], (unsigned)(i >> 2));
+    static_assert(RW_PPT * RW_STRIDE >= 1024, "the start-up tables fit the output buffer");
+    if constexpr (WORDS) {
+        for (int i = (int)tid; i < 4 * k; i += RW_NT) {
+            s_rot[i] = rotl64d(NT_H[i & 3], (unsigned)(k - 1 - (i >> 2)));
+            s_rot[256 + i] = rotl64d(NT_RC[i & 3], (unsigned)(i >> 2));
+        }
+    } else {
+        // hashes only: two bases a look-up -- [16 ip + c0 + 4 c1] = what bases 2 ip (c0) and 2 ip + 1 (c1) add to the forward hash, [512 + ..] to the
+        // reverse strand's; an odd k's last base stands alone (every c1 gives the same)
+        for (int i = (int)tid; i < 16 * ((k + 1) / 2); i += RW_NT) {
+            const int ip = i >> 4, c0 = i & 3, c1 = (i >> 2) & 3, b0 = 2 * ip, b1 = 2 * ip + 1;
+            uint64_t f = rotl64d(NT_H[c0], (unsigned)(k - 1 - b0)), r = rotl64d(NT_RC[c0], (unsigned)b0);
+            if (b1 < k) { f ^= rotl64d(NT_H[c1], (unsigned)(k - 1 - b1)); r ^= rotl64d(NT_RC[c1], (unsigned)b1); }
+            s_rot[i] = f; s_rot[512 + i] = r;
+        }
     }
     uint64_t o_hash[RW_PPT], o_lo[WORDS ? RW_PPT : 1], o_hi[WORDS ? RW_PPT : 1];
     const uint64_t p0 = (uint64_t)blockIdx.x * RW_TILE;
@@ -189,12 +200,21 @@ __global__ __launch_bounds__(RW_NT) void reads_windows_kernel(ReadsArgs a)
         const uint64_t wl = sb < 64 ? (cl >> sb) | (ch << (64 - sb)) : ch >> (sb - 64), wh = sb < 64 ? ch >> sb : 0ull;      // base i at bits 2 i, 2 i + 1
         auto wbase = [&](int i) -> uint32_t { return (uint32_t)((i < 32 ? wl >> (2 * i) : wh >> (2 * (i - 32))) & 3ull); };
         uint64_t w = wl;
-        for (int i = 0; i < k; i++) {
-            if (i == 32) w = wh;
-            const uint32_t c = (uint32_t)w & 3u; w >>= 2;
-            if (WORDS) { if (i < h) upper = (upper << 2) | c; else if (i == h) mid = c; else lower = (lower << 2) | c; }
-            fh ^= s_rot[4 * i + (int)c];
-            rh ^= s_rot[256 + 4 * i + (int)c];
+        if constexpr (WORDS) {
+            for (int i = 0; i < k; i++) {
+                if (i == 32) w = wh;
+                const uint32_t c = (uint32_t)w & 3u; w >>= 2;
+                if (i < h) upper = (upper << 2) | c; else if (i == h) mid = c; else lower = (lower << 2) | c;
+                fh ^= s_rot[4 * i + (int)c];
+                rh ^= s_rot[256 + 4 * i + (int)c];
+            }
+        } else {
+            for (int ip = 0; ip < (k + 1) / 2; ip++) {                          // (the bits above the window's last base are 0)
+                if (ip == 16) w = wh;
+                const int at = 16 * ip + (int)((uint32_t)w & 15u); w >>= 4;
+                fh ^= s_rot[at];
+                rh ^= s_rot[512 + at];
+            }
         }
         if (WORDS) {
             for (int i = 0; i < h; i++) {

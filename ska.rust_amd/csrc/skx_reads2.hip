@@ -246,7 +246,7 @@ __global__ __launch_bounds__(RG_NT, 8) void rs_groups_kernel(RgArgs a)
         uint32_t less = 0, q = b;
         constexpr uint32_t RS = SKX_RG_STEP;                                     // independent LDS reads in flight per step
         static_assert(RS <= (uint32_t)RG_PAD, "the pad covers one step");
-        if (!(ce >> 31)) {                                                       // one hash: whole steps by position alone (2 instructions a record, a third of the LDS bytes)
+        if (!(ce >> 31)) {                                                       // one hash: by position alone (2 instructions a record, a third of the LDS bytes)
             for (; q + RS <= e; q += RS) {
                 uint32_t tq[RS];
 #pragma unroll
@@ -254,15 +254,23 @@ __global__ __launch_bounds__(RG_NT, 8) void rs_groups_kernel(RgArgs a)
 #pragma unroll
                 for (uint32_t u = 0; u < RS; u++) less += tq[u] < tt ? 1u : 0u;
             }
-        }
-        // (m, position) as one 96-bit number.  A step reads past the bucket's end without a clamp: what lies there are the records of the
-        // following micro-buckets, whose m is larger (the micro-bucket index is monotone in m), and behind the last record the pad
-        for (; q < e; q += RS) {
-            uint64_t mq[RS]; uint32_t tq[RS];
+            if (q < e) {                                                         // the last one to three: what lies behind the end is read and not counted
+                uint32_t tq[RS];
 #pragma unroll
-            for (uint32_t u = 0; u < RS; u++) { mq[u] = s_m[q + u]; tq[u] = s_t[q + u]; }
+                for (uint32_t u = 0; u < RS; u++) tq[u] = s_t[q + u];
 #pragma unroll
-            for (uint32_t u = 0; u < RS; u++) add_if_below(less, mq[u], tq[u], m, tt);
+                for (uint32_t u = 0; u < RS; u++) less += (q + u < e && tq[u] < tt) ? 1u : 0u;
+            }
+        } else {
+            // (m, position) as one 96-bit number.  A step reads past the bucket's end without a clamp: what lies there are the records of the
+            // following micro-buckets, whose m is larger (the micro-bucket index is monotone in m), and behind the last record the pad
+            for (; q < e; q += RS) {
+                uint64_t mq[RS]; uint32_t tq[RS];
+#pragma unroll
+                for (uint32_t u = 0; u < RS; u++) { mq[u] = s_m[q + u]; tq[u] = s_t[q + u]; }
+#pragma unroll
+                for (uint32_t u = 0; u < RS; u++) add_if_below(less, mq[u], tq[u], m, tt);
+            }
         }
         npos[j] = b + less;
     }
