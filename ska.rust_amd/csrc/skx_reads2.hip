@@ -484,8 +484,10 @@ int reads_sample_words(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual
     // head-room (the mean + 5.7 sigma at 2 000 records; half the mean where that fits as well); beyond ~161 M windows 262 144 partitions of
     // 12 bloom words, which the group kernel fills to an eighth only (6.6 ms against 2.7: k = 31 on a 50x isolate used to land there)
     const uint64_t mean48 = n_win / 65536;
-    const bool coarse = mean48 + mean48 / 4 + 1024 <= (uint64_t)RG_CAP;
-    const bool mid = !coarse && (mean48 / 2) * 3 / 2 + 1024 <= (uint64_t)RG_CAP;         // 131 072 partitions of 24 bloom words (k = 17 on a 50x isolate: ~170 M windows)
+    // (SKX_KNOBS=reads_layout=2 | 3: the 24- / 12-word layouts whatever the size -- the tests run small samples through every instantiation)
+    const long forced = knob("reads_layout");
+    const bool coarse = forced ? forced == 1 : mean48 + mean48 / 4 + 1024 <= (uint64_t)RG_CAP;
+    const bool mid = forced ? forced == 2 : !coarse && (mean48 / 2) * 3 / 2 + 1024 <= (uint64_t)RG_CAP;         // 131 072 partitions of 24 bloom words (k = 17 on a 50x isolate: ~170 M windows)
     const bool fine = !coarse && !mid;
     const bool roomy = mean48 * 3 / 2 + 1024 <= (uint64_t)RG_CAP;
     const uint64_t n_part = fine ? 262144 : mid ? 131072 : 65536, fan1 = n_part / 256;

@@ -336,6 +336,20 @@ def test_fastq_kmer_filter_ragged_reads(E, ragged_fastq, k, rc, min_count, qf, m
     assert len(gk) == len(ok) and np.array_equal(gk["lo"], ok["lo"]) and np.array_equal(gk["hi"], ok["hi"]) and np.array_equal(gb, ob)
 
 
+@pytest.mark.parametrize("layout", [2, 3])
+def test_fastq_kmer_filter_in_every_partition_layout(E, fastq_pair, layout, monkeypatch):
+    """The count filter's partition passes have three instantiations -- 65 536 partitions of 48 bloom words, 131 072 of 24 (k = 17 on a deep isolate),
+    262 144 of 12 (beyond ~270 M windows) -- chosen by the sample's size; SKX_KNOBS=reads_layout forces the other two on this small sample."""
+    f1, f2 = fastq_pair
+    k, min_count = 31, 3
+    og = ora.Dict.from_files(k, f1, f2, True, ora.qual(min_count, 20, 2))
+    ok, ob = og.export()
+    monkeypatch.setenv("SKX_KNOBS", f"reads_layout={layout}")
+    ds = E.DictSet.from_files([(f1, f2)], k, True, E.qual(min_count, 20, 2))
+    gk, gb = ds.export(0)
+    assert len(gk) == len(ok) and np.array_equal(gk["lo"], ok["lo"]) and np.array_equal(gk["hi"], ok["hi"]) and np.array_equal(gb, ob)
+
+
 # ---- failure behaviour (the reference panics; the C ABI returns codes with the same message text) ----
 def test_error_codes(E, tmp_path):
     with pytest.raises(E.EngineError) as ei:                                   # ska_dict.rs:342-344
