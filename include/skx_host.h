@@ -81,6 +81,9 @@ int skh_distance_sharded(skx_ctx *ctx, skx_comm *comm, const skh_job *job);
  * `--gpus N` on build / align / distance starts one process per GPU (this executable again, SKX_RANK / SKX_WORLD / SKX_COMM_ID_FILE in
  * their environment) and runs the sharded bodies above; a launcher of one's own sets the same variables. */
 int skh_main(int argc, char **argv);
+/* `ska --help | -h | help [cmd] | <cmd> --help | --version | -V` (cli.rs:154 `#[command(author, version, about)]`, propagate_version; per-flag
+ * help cli.rs:168-459): 1 = answered on stdout (exit code 0), 0 = not a help / version request, 2 = `ska help <unknown>`.  skh_main calls it first. */
+int skh_help(int argc, char **argv);
 
 #ifdef __cplusplus
 }

@@ -256,8 +256,11 @@ int GzReader::Impl::header()
     // RFC 1952: ID1 ID2 CM FLG MTIME(4) XFL OS [XLEN + extra] [name 0] [comment 0] [CRC16]
     int r = need_bytes(10);
     if (r < 0) return -1;
-    if (r > 0 || in[in_pos] != 0x1f || in[in_pos + 1] != 0x8b) {
+    const size_t left = in_end - in_pos;
+    const bool magic = left >= 2 ? (in[in_pos] == 0x1f && in[in_pos + 1] == 0x8b) : (left == 1 && in[in_pos] == 0x1f);
+    if (r > 0 || !magic) {
         if (!any_member) return -1;
+        if (r > 0 && magic) return -1;                        // a further member's header cut short: truncated, as gzip reports it
         st = DONE; return 0;                                  // what follows the last member is not a member: ignored
     }
     if (in[in_pos + 2] != 8 || (in[in_pos + 3] & 0xE0)) return -1;
@@ -317,7 +320,9 @@ int GzReader::Impl::block_head()
     if (hlit > 286 || hdist > 30) return -1;
     static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     uint8_t cl[19] = {0};
-    for (int i = 0; i < hclen; i++) { if (bitcnt < 3) refill(); cl[order[i]] = (uint8_t)bits(3); }
+    // (every refill below is followed by an end-of-input check before the next one: the zeros behind in_end are IN_PAD bytes, a refill
+    // moves in_pos by eight at most, so a file that ends inside this header is refused before a load could leave the buffer)
+    for (int i = 0; i < hclen; i++) { if (bitcnt < 3) { refill(); if (overrun()) return -1; } cl[order[i]] = (uint8_t)bits(3); }
     uint32_t pre[128 + 19 * 1];
     const auto pre_entry = [](int s) -> uint64_t { return ((uint64_t)s << 16) | ((uint64_t)K_LIT << 12); };
     if (!build_table(cl, 19, 7, pre, sizeof(pre) / sizeof(pre[0]), pre_entry, false)) return -1;
@@ -325,6 +330,7 @@ int GzReader::Impl::block_head()
     int n = 0;
     while (n < hlit + hdist) {
         refill();
+        if (overrun()) return -1;
         const uint32_t e = pre[bitbuf & 127u];
         if (kind_of(e) != K_LIT) return -1;
         bits((int)(e & 0xFFu));
@@ -497,6 +503,9 @@ void GzReader::open(int fd)
     z.in.assign(Impl::IN_CAP + Impl::IN_PAD, 0);
     z.win.assign(Impl::WIN + Impl::WIN_SLACK + 320, 0);
     z.in_pos = z.in_end = 0; z.in_eof = false; z.out_pos = 0; z.st = Impl::HEADER; z.any_member = false;
+    // a reader reopened after an error in mid-stream starts clean (bits held from the old input would shift fill_input's base)
+    z.bitbuf = 0; z.bitcnt = 0; z.last_block = false; z.stored_left = 0;
+    z.crc = 0; z.member_start = 0; z.crc_from = 0; z.member_len = 0;
 }
 // More text.  The `keep` bytes in front of the last call's end stay in front of the new text (*p - keep is where they start): the caller's
 // unfinished line.  *n == 0: the end of the last member.  -1: not gzip, damaged, truncated, or a read error.

@@ -2723,8 +2723,8 @@ int skx::planes_distance_split(skx_ctx *ctx, const uint64_t *planes_clean, uint6
     const uint64_t rows = (uint64_t)(i_hi - i_lo);
     DevBuf<unsigned long long> cnt;
     SKX_TRY(cnt.alloc(rows * S * DIST_NCOUNT)); SKX_TRY(cnt.zero(st));
-    if (rows_clean && planes_clean) launch_pair_counts(planes_clean, S, wpr_clean, 2, cnt.p, st, i_lo, i_hi);
-    if (rows_dirty && planes_dirty) launch_pair_counts(planes_dirty, S, wpr_dirty, 0, cnt.p, st, i_lo, i_hi);
+    if (rows_clean && planes_clean) SKX_HIP((hipError_t)launch_pair_counts(planes_clean, S, wpr_clean, 2, cnt.p, st, i_lo, i_hi));
+    if (rows_dirty && planes_dirty) SKX_HIP((hipError_t)launch_pair_counts(planes_dirty, S, wpr_dirty, 0, cnt.p, st, i_lo, i_hi));
     std::vector<unsigned long long> h(rows * S * DIST_NCOUNT);
     SKX_HIP(hipMemcpyAsync(h.data(), cnt.p, h.size() * 8, hipMemcpyDeviceToHost, st));
     SKX_HIP(hipStreamSynchronize(st));
@@ -2739,7 +2739,7 @@ int skx::planes_distance(skx_ctx *ctx, const uint64_t *planes, int S, uint64_t w
     const uint64_t rows = (uint64_t)(i_hi - i_lo);
     DevBuf<unsigned long long> cnt;
     SKX_TRY(cnt.alloc(rows * S * DIST_NCOUNT)); SKX_TRY(cnt.zero(st));
-    launch_pair_counts(planes, S, wpr, filt_ambig, cnt.p, st, i_lo, i_hi);
+    SKX_HIP((hipError_t)launch_pair_counts(planes, S, wpr, filt_ambig, cnt.p, st, i_lo, i_hi));
     std::vector<unsigned long long> h(rows * S * DIST_NCOUNT);
     SKX_HIP(hipMemcpyAsync(h.data(), cnt.p, h.size() * 8, hipMemcpyDeviceToHost, st));
     SKX_HIP(hipStreamSynchronize(st));

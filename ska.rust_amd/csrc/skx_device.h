@@ -258,8 +258,8 @@ void launch_build_planes_keep(const uint8_t *matrix, uint64_t pitch, int n_sampl
 // (first_group: [kept / 4096 + 2] words of scratch; kept = rows that stay: every word [0, wpr) of every plane and sample is written)
 // out[pair][c]: integer pair-class counts, see skx_device.hip
 constexpr int DIST_NCOUNT = 16;
-void launch_pair_counts(const uint64_t *planes, int n_samples, uint64_t words_per_row, int filt_ambig,
-                        unsigned long long *out, hipStream_t st, int i_lo = 0, int i_hi = 0);       // rows [i_lo, i_hi) of the pair matrix (0, 0: all)
+int launch_pair_counts(const uint64_t *planes, int n_samples, uint64_t words_per_row, int filt_ambig,
+                       unsigned long long *out, hipStream_t st, int i_lo = 0, int i_hi = 0);        // rows [i_lo, i_hi) of the pair matrix (0, 0: all); 0 or a hipError_t
 
 // ---- wide (k > 31) launchers: same roles as their 64-bit counterparts; word pointers address u128 elements ----
 void launch_hist_wide(const ExtractArgs &a, hipStream_t st);

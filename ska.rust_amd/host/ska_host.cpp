@@ -863,8 +863,13 @@ int emit(const std::string &out_path, const char *buf, uint64_t len)            
 extern "C" int skh_main(int argc, char **argv)
 {
     const int env_world = getenv("SKX_WORLD") ? atoi(getenv("SKX_WORLD")) : 0, env_rank = getenv("SKX_RANK") ? atoi(getenv("SKX_RANK")) : 0;
+    // clap answers --help / --version (and refuses what it cannot parse) before lib.rs::main prints its banner (lib.rs:558-565)
+    if (const int h = skh_help(argc, argv)) return h == 1 ? 0 : h;
+    if (argc < 2) {                                                                        // clap: help on stderr, exit code 2
+        fprintf(stderr, "Split k-mer analysis\n\nUsage: ska [OPTIONS] <COMMAND>\n\nFor more information, try '--help'.\n");
+        return 2;
+    }
     if (env_rank == 0) fprintf(stderr, "SKA: Split K-mer Analysis (the alignment-free aligner)\n");
-    if (argc < 2) return fail("usage: ska <build|align|map|distance|nk|merge|delete|weed|cov> ...");
     const std::string cmd = argv[1];
     Args a;
     for (int i = 2; i < argc; i++) {

@@ -238,3 +238,43 @@ def test_gz_reader_random_streams(tmp_path):
             f.write(blob)
         s, q = E.read_records(p)
         assert q is None and s == body + b"\n", (it, kind, n)
+
+
+def test_gz_reader_file_that_ends_inside_a_header(tmp_path):
+    """A file cut inside a dynamic block's code-length header, or inside the gzip header of a further member, is truncated -- an error,
+    never a short input; only bytes that do not begin like a member are ignored behind the last one (round 5's advisor findings: the
+    code-length loops check the input's end at every refill, and `1f 8b ...` cut short is not trailing garbage)."""
+    text = _fastq(4000, 151, 21, qual_mode="random")
+    good = gzip.compress(text, 6)
+    p = tmp_path / "t.fastq.gz"
+
+    def refused(blob):
+        p.write_bytes(blob)
+        for streaming in (False, True):
+            with pytest.raises(E.EngineError) as ei:
+                E.read_records(str(p), streaming=streaming)
+            assert ei.value.code == E.EIO
+
+    for cut in range(11, 140):                          # the first block's header: HLIT / HDIST / HCLEN, the code-length code, the lengths
+        refused(good[:cut])
+    # the same with the cut just under the input buffer's size, where the loads behind the end would leave the buffer: a stored member
+    # of about 1 MB first, so that the header lies at the buffer's end
+    pad_text = _fastq(3500, 151, 22, qual_mode="random")
+    pad = _gz_member(pad_text, level=0)
+    for want in ((1 << 20) - 3, (1 << 20) - 40, (1 << 20) + 64 - 20):
+        fill = want - len(pad) - 12
+        if fill < 0:
+            continue
+        blob = pad + good[:12 + fill] if fill < 100 else None
+        if blob is None:                                # stretch the stored member instead
+            extra = _fastq((fill // 310) + 1, 151, 23, qual_mode="random")
+            pad2 = _gz_member(extra[:max(0, want - len(pad) - 60 - 18)], level=0)
+            blob = pad + pad2
+            blob = blob + good[:max(12, want - len(blob))]
+        refused(blob)
+    for k in range(1, 10):                              # a second member's header cut after k bytes
+        refused(good + good[:k])
+    p.write_bytes(good + b"\x00\x01\x02\x03\x04")       # not a member: ignored, as gzip ignores it
+    _both(str(p), *_expect_fastq(text))
+    p.write_bytes(good + b"\x1e")
+    _both(str(p), *_expect_fastq(text))
