@@ -72,10 +72,7 @@ extern "C" int skx_array_map(skx_array *a, const char *reference, int ambig_mask
     DevBuf<uint64_t> wlo, whi; DevBuf<uint8_t> flag;
     SKX_TRY(ref_windows(ctx, d_seq.p, L, k, a->rc, wlo, whi, flag));
     std::vector<uint8_t> hflag(L);
-    std::vector<uint64_t> hlo(L), hhi;
     SKX_HIP(hipMemcpyAsync(hflag.data(), flag.p, L, hipMemcpyDeviceToHost, st));
-    SKX_HIP(hipMemcpyAsync(hlo.data(), wlo.p, L * 8, hipMemcpyDeviceToHost, st));
-    if (k > 31) { hhi.resize(L); SKX_HIP(hipMemcpyAsync(hhi.data(), whi.p, L * 8, hipMemcpyDeviceToHost, st)); }
     SKX_HIP(hipStreamSynchronize(st));
     uint64_t n_windows = 0; for (uint64_t p = 0; p < L; p++) n_windows += hflag[p] != 0;
     if (n_windows == 0) { set_error("%s has no valid sequence", reference); return SKX_EEMPTY; }                                  // ska_ref.rs:255-257
@@ -83,11 +80,11 @@ extern "C" int skx_array_map(skx_array *a, const char *reference, int ambig_mask
     // repeat coordinates (ska_ref.rs:259-293): every window whose split k-mer occurs more than once in the reference
     std::vector<uint64_t> repeat;
     if (repeat_mask) {
-        std::vector<std::pair<skx_key, uint64_t>> ks; ks.reserve(n_windows);
-        for (uint64_t p = 0; p < L; p++) if (hflag[p]) ks.push_back({skx_key{hlo[p] >> 4, k > 31 ? hhi[p] : 0}, p});
+        // which windows: on the device (sorted with the engine's radix sort, neighbours compared); the coordinates below are bookkeeping
+        DevBuf<uint8_t> d_rep;
+        SKX_TRY(ref_repeat_flags(ctx, wlo.p, k > 31 ? whi.p : nullptr, flag.p, L, d_rep));
         std::vector<uint8_t> rep(L, 0);
-        std::sort(ks.begin(), ks.end(), [](const std::pair<skx_key, uint64_t> &x, const std::pair<skx_key, uint64_t> &y) { return key_less(x.first, y.first); });
-        for (size_t i = 0; i < ks.size();) { size_t j = i; while (j < ks.size() && key_eq(ks[j].first, ks[i].first)) j++; if (j - i > 1) for (size_t q = i; q < j; q++) rep[ks[q].second] = 1; i = j; }
+        SKX_HIP(hipMemcpy(rep.data(), d_rep.p, L, hipMemcpyDeviceToHost));
         uint64_t last_chrom = 0, last_end = 0, chrom_offset = 0;
         for (uint64_t p = 0; p < L; p++) {
             if (!hflag[p]) continue;

@@ -721,6 +721,51 @@ int cov_histogram(skx_ctx *ctx, const uint8_t *d_seq, uint64_t len, int k, int r
     return SKX_OK;
 }
 
+// `ska map --repeat-mask` (ska_ref.rs:259-293): rep[p] = 1 for every window whose split k-mer (the middle base does not count) occurs
+// more than once in the reference.  The windows' words sorted together with their stream positions (the engine's own radix sort), a window
+// is a repeat when a neighbour in that order holds the same k-mer.
+__global__ void mark_repeats_kernel(const uint64_t *slo, const uint64_t *shi, const uint32_t *spos, const uint32_t *via, uint64_t n, uint8_t *rep)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t lo = slo[i], hi = shi ? shi[i] : 0;
+        const bool prev = i > 0 && slo[i - 1] == lo && (!shi || shi[i - 1] == hi), next = i + 1 < n && slo[i + 1] == lo && (!shi || shi[i + 1] == hi);
+        if (prev || next) rep[via ? via[spos[i]] : spos[i]] = 1;
+    }
+}
+int ref_repeat_flags(skx_ctx *ctx, const uint64_t *wlo, const uint64_t *whi, const uint8_t *flag, uint64_t len, DevBuf<uint8_t> &rep)
+{
+    hipStream_t st = ctx->stream;
+    const bool wide = whi != nullptr;
+    SKX_TRY(rep.alloc(len + 1)); SKX_TRY(rep.zero(st));
+    if (len == 0) return SKX_OK;
+    Temp tmp;
+    DevBuf<uint32_t> idx; SKX_TRY(idx.alloc(len));
+    uint64_t m = 0;
+    SKX_TRY(prim_select_index_u8(flag, idx.p, len, &m, st));
+    if (m < 2) return SKX_OK;
+    DevBuf<uint64_t> lo, slo, hi, shi; DevBuf<uint32_t> sidx;
+    SKX_TRY(lo.alloc(m)); SKX_TRY(slo.alloc(m));
+    hipLaunchKernelGGL(gather_u64_kernel, dim3(grid_for(m)), dim3(256), 0, st, wlo, idx.p, lo.p, m);
+    hipLaunchKernelGGL(and_not15_kernel, dim3(grid_for(m)), dim3(256), 0, st, lo.p, m);
+    if (!wide) {
+        SKX_TRY(sidx.alloc(m));
+        SKX_TRY(sort_pairs(tmp, lo.p, slo.p, idx.p, sidx.p, m, st));
+        hipLaunchKernelGGL(mark_repeats_kernel, dim3(grid_for(m)), dim3(256), 0, st, slo.p, (const uint64_t *)nullptr, sidx.p, (const uint32_t *)nullptr, m, rep.p);
+    } else {
+        DevBuf<uint32_t> iota, p1, p2; DevBuf<uint64_t> h1;
+        SKX_TRY(hi.alloc(m)); SKX_TRY(shi.alloc(m)); SKX_TRY(iota.alloc(m)); SKX_TRY(p1.alloc(m)); SKX_TRY(p2.alloc(m)); SKX_TRY(h1.alloc(m));
+        hipLaunchKernelGGL(gather_u64_kernel, dim3(grid_for(m)), dim3(256), 0, st, whi, idx.p, hi.p, m);
+        hipLaunchKernelGGL(iota_u32_kernel, dim3(grid_for(m)), dim3(256), 0, st, iota.p, m);
+        SKX_TRY(sort_pairs(tmp, lo.p, slo.p, iota.p, p1.p, m, st));
+        hipLaunchKernelGGL(gather_u64_kernel, dim3(grid_for(m)), dim3(256), 0, st, hi.p, p1.p, h1.p, m);
+        SKX_TRY(sort_pairs(tmp, h1.p, shi.p, p1.p, p2.p, m, st));
+        hipLaunchKernelGGL(gather_u64_kernel, dim3(grid_for(m)), dim3(256), 0, st, lo.p, p2.p, slo.p, m);
+        hipLaunchKernelGGL(mark_repeats_kernel, dim3(grid_for(m)), dim3(256), 0, st, slo.p, shi.p, p2.p, idx.p, m, rep.p);
+    }
+    RP(hipStreamSynchronize(st));
+    return SKX_OK;
+}
+
 // row of the array holding each reference window's split k-mer (0xFFFFFFFF: none / no window), and whether the reference
 // strand is the reverse complement of the canonical form (RefKmer::rc): then the canonical middle base is the complement of
 // the forward one, i.e. the word's base mask is exactly 1 << (mid ^ 2)

@@ -173,6 +173,17 @@ def case_count_check_long(E, tmp_path):             # fastq_input.rs:111-192
     assert var_hash(ss.align()) == h3
 
 
+def case_map_fastq(E, tmp_path):                    # fastq_input.rs:196-276: the one reference test that joins the reads path to `ska map`
+    r = roundtrip(E, E.Array.build(rfile("test", True), k=9, q=E.qual(min_count=1, min_qual=2)), tmp_path, "reads")
+    f = roundtrip(E, E.Array.build(fasta_inputs(E, [fin("test_1.fa"), fin("test_2.fa")]), k=9), tmp_path, "assemblies")
+    aln = r.map(fin("test_ref.fa"))
+    assert aln == f.map(fin("test_ref.fa")) and aln.startswith(b">test_1\n")
+    r = E.Array.load(os.path.join(str(tmp_path), "reads.skf"))                      # (a second `ska map` invocation: the file again)
+    f = E.Array.load(os.path.join(str(tmp_path), "assemblies.skf"))
+    vcf = r.map(fin("test_ref.fa"), fmt="vcf")
+    assert vcf == f.map(fin("test_ref.fa"), fmt="vcf") and vcf.startswith(b"##fileformat=VCF")
+
+
 def case_error_fastq(E, tmp_path):                  # fastq_input.rs:276-470
     allh = var_hash(E.Array.build(rfile("test", True), k=9, q=E.qual(min_count=3, min_qual=2)).align())
     assert allh
