@@ -605,26 +605,35 @@ void launch_append_probe(const AppendArgs &a, uint32_t region_cap, unsigned bloc
 // ------------------------------------------------------------------------------------------------
 // Row statistics from the finished pieces: per first-seen rank of a row block the number of samples with a cell (present), with an
 // unambiguous one, and the set of IUPAC codes that occur (merge_ska_array.rs:139-186 counts the same from the rows).  A thread owns one
-// dword column of the block's pieces -- eight ranks, 4 bits each -- and walks the samples: nibble-parallel counters (a byte per rank, folded
+// 16-byte column of the block's pieces -- 32 ranks, 4 bits each -- and walks the samples: nibble-parallel counters (a byte per rank, folded
 // into 16 bits every 255 samples), no atomics, the pieces read once, coalesced.  Cells are single bases almost everywhere: the code set of such
-// a row follows from the OR of its cells; rows with an ambiguous cell (a palindrome's W / S, a sample that folded two bases) are listed and
-// their code sets taken cell by cell.  The results go straight to the rows (perm: rank -> row of the block).
+// a row follows from the OR of its cells; rows with an ambiguous cell (a palindrome's W / S, a sample that folded two bases) are found
+// afterwards (unambiguous < present) and their code sets taken cell by cell.
+// The results belong to ROWS (perm: rank -> row of the block) and rows are what the output arrays are indexed by: a block's three results are
+// staged in LDS by row (16 bits each: <= 65 535 samples, code sets are 16 bits) and leave as whole lines -- four arrays x 4 bytes x rows is all
+// this kernel writes (round 5 stored them from the ranks' threads, 4 bytes at a time through perm: 3.5 GB of write traffic for 0.36 GB of
+// results, profiles/r05_final_pmc_traffic.txt).  A block with more rows than the stage holds (global rows of a sharded job over unrelated
+// samples) or split over several workgroups (never at the append pass's capacities) stores per rank as before.
 // ------------------------------------------------------------------------------------------------
+constexpr uint32_t PS_STAGE = 6144;                                   // rows staged: >= APPEND_MAX_CAP (a pass's own rows: nrows <= nrank <= cap)
+static_assert(PS_STAGE >= APPEND_MAX_CAP, "the stage holds a row block of the append pass");
 __global__ __launch_bounds__(256) void pieces_stats_kernel(const uint8_t *pieces, const uint16_t *plen, const uint16_t *perm, const uint32_t *nrank, const uint32_t *ncnt,
                                                            const uint64_t *roff, uint32_t cap, int S, uint32_t *o_present, uint32_t *o_unambig, uint32_t *o_mask,
-                                                           uint32_t *o_vcount)
+                                                           uint32_t *o_vcount, int force_direct)
 {
     constexpr int W = 4;                                              // dwords per thread: one 16-byte load per sample (append_kernel writes the pieces 16 bytes -- 32 ranks -- at a time,
                                                                       // so such a piece of a sample's piece is either written whole or not at all)
-    __shared__ uint32_t s_list[256 * 8 * W + 1];
-    __shared__ uint32_t s_nlist;
+    __shared__ uint16_t s_pr[PS_STAGE], s_un[PS_STAGE], s_mk[PS_STAGE];
     const uint64_t j = blockIdx.x;
     const uint32_t nr = nrank[j], nrows = ncnt[j];
     const uint64_t r0 = roff[j];
     const uint32_t d = blockIdx.y * 256u + threadIdx.x;              // 16-byte column: ranks 32 d .. 32 d + 31
-    if (blockIdx.y * 256u * 8u * W >= nr) return;
-    if (threadIdx.x == 0) s_nlist = 0;
-    __syncthreads();
+    if (blockIdx.y * 256u * 8u * W >= nr && !(blockIdx.y == 0 && nrows)) return;
+    const bool staged = gridDim.y == 1 && nrows <= PS_STAGE && !force_direct;
+    if (staged) {
+        for (uint32_t p = threadIdx.x; p < nrows; p += 256) { s_pr[p] = 0; s_un[p] = 0; s_mk[p] = 0; }      // (a row without a rank here: no cell in these samples)
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint16_t *pl = plen + j * (uint64_t)S;
     const uint4 *col = reinterpret_cast<const uint4 *>(pieces + j * (uint64_t)S * (cap / 2)) + d;
@@ -692,34 +701,64 @@ __global__ __launch_bounds__(256) void pieces_stats_kernel(const uint8_t *pieces
             pres[1] = PO0[w] & 0xFFFFu; pres[5] = PO0[w] >> 16; pres[3] = PO1[w] & 0xFFFFu; pres[7] = PO1[w] >> 16;
             amb[0] = AE0[w] & 0xFFFFu; amb[4] = AE0[w] >> 16; amb[2] = AE1[w] & 0xFFFFu; amb[6] = AE1[w] >> 16;
             amb[1] = AO0[w] & 0xFFFFu; amb[5] = AO0[w] >> 16; amb[3] = AO1[w] & 0xFFFFu; amb[7] = AO1[w] >> 16;
+            // the eight ranks' rows: one 16-byte load (perm is 2 bytes a rank, the column starts at a multiple of 32 ranks)
+            const uint4 pv = *reinterpret_cast<const uint4 *>(pj + d * 32u + (uint32_t)w * 8u);
+            const uint32_t pw[4] = {pv.x, pv.y, pv.z, pv.w};
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const uint32_t r = d * 32u + (uint32_t)w * 8u + i;
                 if (r >= nr) break;
-                const uint32_t p = pj[r];                             // the rank's row of the block (0xFFFF: none)
+                const uint32_t p = (pw[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;      // the rank's row of the block (0xFFFF: none)
                 if (p >= nrows) continue;
                 const uint32_t u = (uni[w] >> (4 * i)) & 15u;
-                o_present[r0 + p] = pres[i]; o_vcount[r0 + p] = pres[i];      // (variant_count: merge_ska_array.rs:172)
-                o_unambig[r0 + p] = pres[i] - amb[i];
-                o_mask[r0 + p] = ((u & 1u) << 1) | ((u & 2u) << 1) | ((u & 4u) << 2) | ((u & 8u) << 5);
-                if (amb[i]) { const uint32_t at = atomicAdd(&s_nlist, 1u); if (at < 256u * 8u * W) s_list[at] = r; }
+                const uint32_t mk = ((u & 1u) << 1) | ((u & 2u) << 1) | ((u & 4u) << 2) | ((u & 8u) << 5);
+                if (staged) { s_pr[p] = (uint16_t)pres[i]; s_un[p] = (uint16_t)(pres[i] - amb[i]); s_mk[p] = (uint16_t)mk; }
+                else {
+                    o_vcount[r0 + p] = pres[i];                                  // (variant_count: merge_ska_array.rs:172)
+                    __hip_atomic_store(&o_present[r0 + p], pres[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&o_unambig[r0 + p], pres[i] - amb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    o_mask[r0 + p] = mk;
+                }
             }
         }
     }
+    if (!staged) __threadfence();                                      // (the walk below reads what the ranks' threads stored)
     __syncthreads();
-    const uint32_t nl = s_nlist < 256u * 8u * W ? s_nlist : 256u * 8u * W;          // (256 x 32 ranks at most)
-    for (uint32_t i = wv; i < nl; i += 4) {
-        const uint32_t r = s_list[i];
-        uint32_t m = 0;
-        for (int t = lane; t < S; t += 64) {
-            if ((uint32_t)pl[t] <= r) continue;
-            const uint32_t x = *(reinterpret_cast<const uint32_t *>(pieces + (j * (uint64_t)S + t) * (cap / 2)) + (r >> 3));
-            const uint32_t nib = (x >> ((r & 7u) * 4u)) & 15u;
-            if (nib) m |= 1u << nib;
+    // rows with an ambiguous cell: their code sets cell by cell, a wave per row, found by a walk over the workgroup's ranks (64 at a time)
+    const uint32_t rk0 = blockIdx.y * 256u * 8u * W, rk1 = rk0 + 256u * 8u * W < nr ? rk0 + 256u * 8u * W : nr;
+    for (uint32_t rb = rk0 + (uint32_t)wv * 64u; rb < rk1; rb += 256u) {
+        const uint32_t rr = rb + (uint32_t)lane;
+        uint32_t pp = 0xFFFFu; bool hit = false;
+        if (rr < rk1) {
+            pp = pj[rr];
+            if (pp < nrows) {
+                if (staged) hit = s_un[pp] != s_pr[pp];
+                else hit = __hip_atomic_load(&o_unambig[r0 + pp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != __hip_atomic_load(&o_present[r0 + pp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
+        unsigned long long todo = __ballot(hit);
+        while (todo) {
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t r = rb + (uint32_t)src, prow = (uint32_t)__shfl((int)pp, src, 64);
+            uint32_t m = 0;
+            for (int t = lane; t < S; t += 64) {
+                if ((uint32_t)pl[t] <= r) continue;
+                const uint32_t x = *(reinterpret_cast<const uint32_t *>(pieces + (j * (uint64_t)S + t) * (cap / 2)) + (r >> 3));
+                const uint32_t nib = (x >> ((r & 7u) * 4u)) & 15u;
+                if (nib) m |= 1u << nib;
+            }
 #pragma unroll
-        for (int dd = 32; dd >= 1; dd >>= 1) m |= __shfl_xor(m, dd, 64);
-        if (lane == 0) o_mask[r0 + pj[r]] = m;
+            for (int dd = 32; dd >= 1; dd >>= 1) m |= __shfl_xor(m, dd, 64);
+            if (lane == 0) { if (staged) s_mk[prow] = (uint16_t)m; else o_mask[r0 + prow] = m; }
+        }
+    }
+    if (!staged) return;
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < nrows; p += 256) {
+        const uint32_t pr = s_pr[p];
+        o_present[r0 + p] = pr; o_vcount[r0 + p] = pr;                // (variant_count: merge_ska_array.rs:172)
+        o_unambig[r0 + p] = s_un[p]; o_mask[r0 + p] = s_mk[p];
     }
 }
 void launch_pieces_stats(const uint8_t *pieces, const uint16_t *plen, const uint16_t *perm, const uint32_t *nrank, const uint32_t *ncnt, const uint64_t *roff, uint32_t cap,
@@ -727,7 +766,8 @@ void launch_pieces_stats(const uint8_t *pieces, const uint16_t *plen, const uint
 {
     if (n_blocks <= 0) return;
     const unsigned gy = (cap / 32 + 255u) / 256u;
-    hipLaunchKernelGGL(pieces_stats_kernel, dim3((unsigned)n_blocks, gy), dim3(256), 0, st, pieces, plen, perm, nrank, ncnt, roff, cap, n_samples, present, unambig, mask, vcount);
+    static const int direct = knob("stats_direct") ? 1 : 0;           // (tests: the per-rank stores of blocks the stage does not hold)
+    hipLaunchKernelGGL(pieces_stats_kernel, dim3((unsigned)n_blocks, gy), dim3(256), 0, st, pieces, plen, perm, nrank, ncnt, roff, cap, n_samples, present, unambig, mask, vcount, direct);
 }
 // split k-mers per sample (SkaDict::ksize): the cells of its pieces that are not empty; a wave per piece
 __global__ __launch_bounds__(256) void pieces_cells_kernel(const uint8_t *pieces, const uint16_t *plen, uint32_t cap, int S, unsigned long long *out)

@@ -322,3 +322,79 @@ def test_config4_one_ranks_share(E):
         assert int((mat[i] != ord("-")).sum()) == len(ok), i            # the column holds exactly the sample's split k-mers
         assert np.isin(ok["lo"], keys["lo"], assume_unique=True).all(), i
     arr.free(); ds0.free()
+
+
+def test_config5_batched_build_merge_distance_chain():
+    """tools/reads_1000.py in small: BASELINE.json configs[4]'s chain as a user with more isolates than one build holds runs it -- paired
+    FASTQ isolates (2 x 150 bp at 50x of a 500 kbp genome; the last batch as .fastq.gz) in 4 batches of 8 through `ska build -k 41
+    --min-count 5 --min-qual 20 --qual-filter strict`, the batch files joined by `ska merge` (merge_ska_dict.rs:160-193 through
+    generic_modes.rs / lib.rs:728-741), then `ska distance` over all 496 pairs.  Two isolates of every batch are checked against the
+    oracle: the isolate's column of its batch .skf is the oracle's dictionary of its two files (ska_dict.rs:118-180,
+    bloom_filter.rs:116-148), and the rows of the final table for every pair of those eight isolates are the rows of the oracle's table
+    over an array of its own dictionaries (generic_modes.rs:136-189: a pair's counts do not depend on the other samples)."""
+    import multiprocessing
+    import shutil
+    import tempfile
+    import zlib
+    from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
+    import synth
+    td = tempfile.mkdtemp(prefix="skx_c5chain_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        N, NB, G = 32, 4, 500_000
+        opts = ["-k", "41", "--min-count", "5", "--min-qual", "20", "--qual-filter", "strict"]
+        qo = ora.qual(5, 20, ora.QUAL_STRICT)
+        spot_dicts, spot_batch = {}, {}
+        with ProcessPoolExecutor(max_workers=min(8, os.cpu_count() or 1), mp_context=multiprocessing.get_context("spawn")) as ex, ThreadPoolExecutor(max_workers=2) as opool:
+            for b in range(NB):
+                lo, hi = N * b // NB, N * (b + 1) // NB
+                pairs = list(ex.map(synth.write_read_pair_of, range(lo, hi), [N] * (hi - lo), [os.path.join(td, f"iso{i}") for i in range(lo, hi)], [G] * (hi - lo)))
+                if b == NB - 1:                                     # what read sets come as
+                    gz = []
+                    for pr in pairs:
+                        out = []
+                        for f in pr:
+                            c = zlib.compressobj(1, zlib.DEFLATED, 31)
+                            with open(f, "rb") as src, open(f + ".gz", "wb") as dst:
+                                dst.write(c.compress(src.read()) + c.flush())
+                            os.unlink(f)
+                            out.append(f + ".gz")
+                        gz.append(tuple(out))
+                    pairs = gz
+                with open(os.path.join(td, f"list{b}.txt"), "w") as lst:
+                    for i, (f1, f2) in zip(range(lo, hi), pairs):
+                        lst.write(f"iso{i}\t{f1}\t{f2}\n")
+                r = subprocess.run([SKA, "build", "-f", f"list{b}.txt", "-o", f"batch{b}", "--threads", "8", *opts], cwd=td, capture_output=True, timeout=900)
+                assert r.returncode == 0, r.stderr[-800:]
+                spots = (lo, hi - 1)
+                ds = list(opool.map(lambda i: ora.Dict.from_files(41, pairs[i - lo][0], pairs[i - lo][1], True, qo), spots))
+                for i, d in zip(spots, ds):
+                    spot_dicts[i] = d
+                    spot_batch[i] = (b, lo)
+                for pr in pairs:
+                    for f in pr:
+                        os.unlink(f)
+        for i, (b, lo) in sorted(spot_batch.items()):
+            keys, var, _ = ora.Array.load(os.path.join(td, f"batch{b}.skf")).export()
+            order = np.lexsort((keys["lo"], keys["hi"]))
+            ok, ob = spot_dicts[i].export()
+            col = var[order, i - lo]
+            have = col != ord("-")
+            assert 400_000 < len(ok) < 700_000
+            assert int(have.sum()) == len(ok) and np.array_equal(keys["lo"][order][have], ok["lo"]) and np.array_equal(keys["hi"][order][have], ok["hi"]), i
+            assert np.array_equal(col[have], ob), i
+        r = subprocess.run([SKA, "merge", *[f"batch{b}.skf" for b in range(NB)], "-o", "all"], cwd=td, capture_output=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-800:]
+        merged = ora.Array.load(os.path.join(td, "all.skf"))
+        assert merged.names == [f"iso{i}" for i in range(N)]
+        r = subprocess.run([SKA, "distance", "all.skf", "-o", "all.tsv"], cwd=td, capture_output=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-800:]
+        tsv = open(os.path.join(td, "all.tsv"), "rb").read()
+        assert tsv == merged.distance_tsv(0.0, True)                # the oracle's table over the merged file: all 496 rows
+        order = sorted(spot_dicts)
+        oarr = ora.Array.from_dicts([spot_dicts[i] for i in order], [f"iso{i}" for i in order])
+        want = {tuple(l.split("\t")[:2]): l for l in oarr.distance_tsv(0.0, True).decode().splitlines()[1:]}
+        got = {tuple(l.split("\t")[:2]): l for l in tsv.decode().splitlines()[1:]}
+        assert len(got) == N * (N - 1) // 2 and len(want) == 28
+        assert all(got.get(k) == v for k, v in want.items()), [k for k, v in want.items() if got.get(k) != v][:3]
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
