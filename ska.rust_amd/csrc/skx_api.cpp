@@ -615,6 +615,47 @@ extern "C" int skx_dictset_build(skx_ctx *ctx, const skx_stream *samples, int n,
 }
 
 
+// A read set's records -> the five bit planes (groups of 64 positions x 5 words: two code bits, the bytes valid_base rejects, line ends,
+// quality verdicts), fed line by line from stream_fastq_file; `push` takes a finished group.  Used by the reader threads that pack on the
+// host and by the consumer when the device's framing calls a sample irregular (then it is this code that accepts or refuses the file).
+namespace {
+struct PlanePacker {
+    std::vector<uint64_t> pl;                                           // a record's four planes (sequence line, then its quality line)
+    size_t line_n = 0;
+    uint64_t cur[5] = {0, 0, 0, 0, 0}, pos = 0, cap = 0;                // the group being filled; positions so far; the most that may come
+    int min_qual = 20; bool gz = false;
+    std::function<int(const uint64_t *)> push;
+    static constexpr int OVER_BOUND = -1002;                            // a gzip file longer than its trailer says: not an error of the input
+    int emit(int which, const uint8_t *p, size_t nb)
+    {
+        const size_t words = (nb + 1 + 63) / 64;                        // the line and its end
+        if (which == 0) {
+            if (pos + nb + 1 > cap) { if (gz) return OVER_BOUND; skx::set_error("Invalid FASTA/Q record"); return SKX_EIO; }
+            if (pl.size() < 4 * words) pl.resize(4 * words + 64);
+            line_n = nb;
+            for (int pln = 0; pln < 4; pln++) pl[pln * words + words - 1] = 0;
+            skx::pack_bases_planes(p, nb, &pl[0], &pl[words], &pl[2 * words]);
+            return SKX_OK;
+        }
+        if (nb != line_n) { skx::set_error("Invalid FASTA/Q record"); return SKX_EIO; }
+        skx::pack_qual_plane(p, nb, min_qual, &pl[3 * words]);
+        const uint64_t *lo = &pl[0], *hi = &pl[words], *bd = &pl[2 * words], *qb = &pl[3 * words];
+        for (size_t w = 0; w < words; w++) {
+            const unsigned take = (unsigned)std::min<size_t>(64, nb + 1 - 64 * w), off = (unsigned)(pos & 63);
+            const uint64_t v[5] = {lo[w], hi[w], bd[w], nb / 64 == w ? 1ull << (nb & 63) : 0ull, qb[w]};
+            for (int pln = 0; pln < 5; pln++) cur[pln] |= v[pln] << off;
+            pos += take;
+            if (off + take >= 64) {
+                const int pr = push(cur); if (pr != SKX_OK) return pr;
+                for (int pln = 0; pln < 5; pln++) cur[pln] = off ? v[pln] >> (64 - off) : 0ull;      // (what did not fit; bits beyond `take` are zero)
+            }
+        }
+        return SKX_OK;
+    }
+    int finish() { return (pos & 63) ? push(cur) : SKX_OK; }           // the last, partly filled group
+};
+}  // namespace
+
 // Read sets (every sample plain FASTQ, one or two files), pipelined.  The one-shot form below reads every sample, allocates stream buffers the
 // size of all files together (24 GB for 96 isolates of BASELINE config 5's shape: a 1-3 s allocation when the memory has just been released
 // by another process) and then filters one isolate after the other (11 ms each) on an idle PCIe link.  Here a small pool of stream slots
@@ -628,10 +669,10 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
 {
     if (knob("no_reads_pipeline") || n < 2) return SKF_NOT_TAKEN;
     const auto t0 = std::chrono::steady_clock::now();
-    std::vector<uint64_t> bound(n, 0);
-    uint64_t slot_bytes = 0;
+    std::vector<uint64_t> bound(n, 0), text_bytes(n, 0);
+    uint64_t slot_bytes = 0, raw_cap = 0;
     bool any_gz = false;
-    constexpr int SKF_OVER_BOUND = -1002;                                       // a gzip file longer than its trailer says: not an error of the input
+    constexpr int SKF_OVER_BOUND = PlanePacker::OVER_BOUND;
     for (int i = 0; i < n; i++) {
         uint64_t bytes = 0;
         for (const char *f : {file1[i], file2 ? file2[i] : nullptr}) {
@@ -654,7 +695,9 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
             bytes += plain;
         }
         bound[i] = (bytes / 2 + 64 + 255) & ~255ull;                             // plain FASTQ holds at most half its bytes in either stream
+        text_bytes[i] = bytes;
         slot_bytes = std::max(slot_bytes, bound[i]);
+        raw_cap = std::max(raw_cap, bytes);
     }
     SKX_HIP(hipSetDevice(ctx->device));
     const int nt = std::max(1, std::min({threads, n, 64, cpu_budget()}));      // (parsing + packing: a reader keeps a CPU busy)
@@ -662,22 +705,33 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     (void)hipMemGetInfo(&free_b, &total_b);
     // a slot per reader thread and a few waiting for their kernels: more only costs allocation time (64 slots = 17 GB took 4.7 s right after
     // another process had released the memory, 32 slots 0.26 s: profiles/r03zr_reads_pipeline_512.log)
-    // A sample crosses PCIe as bit planes -- groups of 64 positions, five words each: two code bits, the bases valid_base rejects, the line
-    // ends, the quality verdicts (fastx.cpp pack_*_planes) -- packed by its reader thread: 5 bits per position instead of two bytes; the
-    // window pass and the rebuild of the passing windows' words read them as they are (the copy was what bounded a batch: 504 MB per
-    // 50x isolate at ~32 GB/s = 63 isolates/s)
+    // A sample crosses PCIe in one of two forms, chosen by its reader thread when it starts on it (round 6):
+    //   * PACKED -- bit planes, groups of 64 positions, five words each: two code bits, the bases valid_base rejects, the line ends, the quality
+    //     verdicts (fastx.cpp pack_*_planes) -- framed and packed by the reader thread: 5 bits per position instead of two bytes, 157 MB per 50x
+    //     isolate, 0.1-0.3 s of a CPU;
+    //   * RAW -- the file's bytes as read() delivers them (0.55 GB per 50x isolate), the reader thread does nothing else; the device frames the
+    //     records and makes the same planes (skx_fastq.hip).
+    // Raw text alone is bound by the link (~32 GB/s with the readers running = 60 isolates/s), packing alone by the CPUs (16 of them: 40-80
+    // isolates/s); a reader takes RAW while the pinned ring has room -- the link is keeping up -- and PACKED when it is filling up, so
+    // both are busy.  SKX_KNOBS=reads_raw=1: never raw; =2: always.  The window pass and the rebuild of the passing windows' words read the planes
+    // as they are, whoever made them.
+    const long raw_knob = knob("reads_raw");
+    const bool raw_possible = raw_knob != 1 && raw_cap + 2 < 0xFFFFFF00ull;
     const uint64_t pslot_bytes = ((slot_bytes / 64 + 2) * READ_GROUP_BYTES + 255) & ~255ull;
-    int P = (int)std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(2, std::min<uint64_t>((uint64_t)nt + 8, (free_b / 8) / (pslot_bytes + 1))));
+    const uint64_t rslot_bytes = raw_possible ? ((raw_cap + 2 + 64 + 255) & ~255ull) : 0;
+    const uint64_t dslot_bytes = pslot_bytes + rslot_bytes;                    // a device slot: the planes, then the text
+    int P = (int)std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(2, std::min<uint64_t>((uint64_t)nt + 8, (free_b / 8) / (dslot_bytes + 1))));
     DevBuf<uint8_t> packed_pool;
-    SKX_TRY(packed_pool.alloc((uint64_t)P * pslot_bytes));
+    SKX_TRY(packed_pool.alloc((uint64_t)P * dslot_bytes));
     constexpr size_t SLOT = ((8u << 20) / READ_GROUP_BYTES) * READ_GROUP_BYTES;          // whole groups
+    constexpr size_t RAW_CHUNK = (SLOT - 1) / 256 * 256;                                 // raw text leaves in pieces that keep their destinations aligned
     const int min_qual_host = q ? (int)q->min_qual : 20;
     const int n_slots = 2 * nt + 8;
-    struct Sample { int slot = -1; int pending = 0; bool read_done = false, queued = false; uint64_t len = 0; };
+    struct Sample { int slot = -1; int pending = 0; bool read_done = false, queued = false, raw = false; uint64_t len = 0, junction = 0; };
     struct Ring {
         uint8_t *base = nullptr; std::mutex mu; std::condition_variable cv_free, cv_work, cv_stream, cv_ready;
         std::vector<int> free_slots, free_stream; struct Req { int slot; uint8_t *dst; size_t bytes; int sample; }; std::deque<Req> work;
-        std::deque<int> ready; int readers_left = 0; bool failed = false, abort = false;
+        std::deque<int> ready; int readers_left = 0; bool failed = false, abort = false, prefer_packed = false;
         ~Ring() { if (base) (void)hipHostFree(base); }
     } ring;
     if (hipHostMalloc((void **)&ring.base, (size_t)n_slots * SLOT, hipHostMallocDefault) != hipSuccess) { ring.base = nullptr; return SKF_NOT_TAKEN; }
@@ -717,16 +771,17 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
         }
         if (up) (void)hipStreamDestroy(up);
     });
-    std::atomic<long long> us_wait_stream{0}, us_wait_ring{0}, us_files{0};      // summed over the reader threads
+    std::atomic<long long> us_wait_stream{0}, us_wait_ring{0}, us_files{0}, n_raw{0}, bytes_up{0};      // summed over the reader threads
     auto us_since = [](std::chrono::steady_clock::time_point t) { return (long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count(); };
     std::vector<std::thread> pool;
     std::atomic<int> next{0};
     for (int t = 0; t < nt; t++)
         pool.emplace_back([&]() {
             struct Leave { Ring &r; ~Leave() { { std::lock_guard<std::mutex> lk(r.mu); r.readers_left--; } r.cv_work.notify_all(); r.cv_ready.notify_all(); } } leave{ring};
-            std::vector<uint64_t> planes;                                     // a record's four planes (sequence line, then its quality line)
+            PlanePacker pk;
+            pk.min_qual = min_qual_host; pk.gz = any_gz;
             for (int i; (i = next.fetch_add(1)) < n;) {
-                int sslot = -1;
+                int sslot = -1; bool raw = false;
                 {
                     const auto tw = std::chrono::steady_clock::now();
                     std::unique_lock<std::mutex> lk(ring.mu);
@@ -735,72 +790,119 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
                     if (ring.abort) return;
                     sslot = ring.free_stream.back(); ring.free_stream.pop_back();
                     smp[i].slot = sslot;
+                    // the link keeps up (most of the pinned ring is free): this sample goes as it is; otherwise it is packed here
+                    raw = raw_possible && !ring.prefer_packed && (raw_knob == 2 || (int)ring.free_slots.size() * 2 >= n_slots);
+                    smp[i].raw = raw;
                 }
                 const auto t_files = std::chrono::steady_clock::now();
                 struct Out { int slot = -1; size_t used = 0; uint8_t *dst = nullptr; uint64_t off = 0; } x;
-                x.dst = packed_pool.p + (uint64_t)sslot * pslot_bytes;
-                const uint64_t cap = bound[i] - 32;                             // positions
+                x.dst = packed_pool.p + (uint64_t)sslot * dslot_bytes + (raw ? pslot_bytes : 0);
                 auto flush = [&]() {
                     if (x.slot < 0) return;
                     { std::lock_guard<std::mutex> lk(ring.mu); ring.work.push_back({x.slot, x.dst + x.off, x.used, i}); smp[i].pending++; }
                     ring.cv_work.notify_one();
+                    bytes_up += (long long)x.used;
                     x.off += x.used; x.slot = -1; x.used = 0;
                 };
                 auto give_back = [&]() {
                     if (x.slot >= 0) { { std::lock_guard<std::mutex> lk(ring.mu); ring.free_slots.push_back(x.slot); } ring.cv_free.notify_one(); x.slot = -1; }
                 };
-                uint64_t cur[5] = {0, 0, 0, 0, 0}, pos = 0;                     // the group being filled; positions so far
-                auto push_group = [&]() -> int {
-                    if (x.slot < 0) {
-                        const auto tw = std::chrono::steady_clock::now();
-                        std::unique_lock<std::mutex> lk(ring.mu);
-                        ring.cv_free.wait(lk, [&] { return !ring.free_slots.empty() || ring.abort; });
-                        us_wait_ring += us_since(tw);
-                        if (ring.abort) return SKF_ABORTED;                   // somebody else stopped the pipeline: not this reader's failure
-                        x.slot = ring.free_slots.back(); ring.free_slots.pop_back(); x.used = 0;
-                    }
-                    memcpy(ring.base + (size_t)x.slot * SLOT + x.used, cur, READ_GROUP_BYTES);
-                    x.used += READ_GROUP_BYTES;
-                    if (x.used == SLOT) flush();
-                    return SKX_OK;
-                };
-                // a record: its sequence line's planes wait for the quality line (the two lines may lie in different pieces of the file)
-                std::vector<uint64_t> &pl = planes;
-                size_t line_n = 0;
-                const std::function<int(int, const uint8_t *, size_t)> emit = [&](int which, const uint8_t *p, size_t nb) -> int {
-                    const size_t words = (nb + 1 + 63) / 64;                    // the line and its end
-                    if (which == 0) {
-                        if (pos + nb + 1 > cap) { if (any_gz) return SKF_OVER_BOUND; set_error("Invalid FASTA/Q record"); return SKX_EIO; }
-                        if (pl.size() < 4 * words) pl.resize(4 * words + 64);
-                        line_n = nb;
-                        for (int pln = 0; pln < 4; pln++) pl[pln * words + words - 1] = 0;
-                        pack_bases_planes(p, nb, &pl[0], &pl[words], &pl[2 * words]);
-                        return SKX_OK;
-                    }
-                    if (nb != line_n) { set_error("Invalid FASTA/Q record"); return SKX_EIO; }
-                    pack_qual_plane(p, nb, min_qual_host, &pl[3 * words]);
-                    const uint64_t *lo = &pl[0], *hi = &pl[words], *bd = &pl[2 * words], *qb = &pl[3 * words];
-                    for (size_t w = 0; w < words; w++) {
-                        const unsigned take = (unsigned)std::min<size_t>(64, nb + 1 - 64 * w), off = (unsigned)(pos & 63);
-                        const uint64_t v[5] = {lo[w], hi[w], bd[w], nb / 64 == w ? 1ull << (nb & 63) : 0ull, qb[w]};
-                        for (int pln = 0; pln < 5; pln++) cur[pln] |= v[pln] << off;
-                        pos += take;
-                        if (off + take >= 64) {
-                            const int pr = push_group(); if (pr != SKX_OK) return pr;
-                            for (int pln = 0; pln < 5; pln++) cur[pln] = off ? v[pln] >> (64 - off) : 0ull;      // (what did not fit; bits beyond `take` are zero)
-                        }
-                    }
+                auto take_slot = [&]() -> int {
+                    if (x.slot >= 0) return SKX_OK;
+                    const auto tw = std::chrono::steady_clock::now();
+                    std::unique_lock<std::mutex> lk(ring.mu);
+                    ring.cv_free.wait(lk, [&] { return !ring.free_slots.empty() || ring.abort; });
+                    us_wait_ring += us_since(tw);
+                    if (ring.abort) return SKF_ABORTED;                   // somebody else stopped the pipeline: not this reader's failure
+                    x.slot = ring.free_slots.back(); ring.free_slots.pop_back(); x.used = 0;
                     return SKX_OK;
                 };
                 int r = SKX_OK;
-                for (const char *f : {file1[i], file2 ? file2[i] : nullptr}) {
-                    if (!f) continue;
-                    r = stream_fastq_file(f, emit);
-                    if (r == SKF_NOT_TAKEN && !any_gz) { set_error("Invalid FASTA/Q record"); r = SKX_EIO; }      // (the first byte was '@' a moment ago)
-                    if (r == SKF_NOT_TAKEN) r = SKF_OVER_BOUND;                                      // (a gzip file that is not FASTQ: the one-shot form takes the batch)
-                    if (r != SKX_OK) break;
+                uint64_t sample_len = 0, junction = 0;
+                if (raw) {
+                    // the files' bytes into the pinned ring, nothing else: plain files by read() straight into a slot, gzip files inflated by this
+                    // thread's inflater and copied there.  A '\n' is put behind a file that lacks its last one (the device frames lines by their ends)
+                    n_raw++;
+                    uint64_t total = 0; const uint64_t cap = text_bytes[i] + 2;
+                    int fno = 0;
+                    for (const char *f : {file1[i], file2 ? file2[i] : nullptr}) {
+                        if (!f) continue;
+                        if (fno++ == 1) junction = total;
+                        const int fd = ::open(f, O_RDONLY);
+                        if (fd < 0) { set_error("Invalid path/file: %s", f); r = SKX_EIO; break; }
+                        struct Close { int fd; ~Close() { ::close(fd); } } cl{fd};
+                        (void)posix_fadvise(fd, 0, 0, POSIX_FADV_NOREUSE);
+                        unsigned char mg[2] = {0, 0};
+                        const bool gz = pread(fd, mg, 2, 0) == 2 && mg[0] == 0x1f && mg[1] == 0x8b;
+                        std::unique_ptr<GzReader> zr;
+                        if (gz) { zr.reset(new GzReader); zr->open(fd); }
+                        uint8_t last = '\n'; bool first = true; uint64_t got_file = 0;
+                        for (;;) {
+                            if ((r = take_slot()) != SKX_OK) break;
+                            uint8_t *dstp = ring.base + (size_t)x.slot * SLOT + x.used;
+                            const size_t room = RAW_CHUNK - x.used;               // (> 0: a full piece has left; a byte beyond it stays free for the '\n' a file may lack)
+                            size_t got = 0;
+                            if (zr) {
+                                const uint8_t *np; size_t ng;
+                                // (the inflater hands out what it has, up to its window: copied piecewise into the slot)
+                                if (zr->next(&np, &ng, 0) != 0) { set_error("Invalid path/file: %s", f); r = SKX_EIO; break; }
+                                if (ng == 0) break;
+                                size_t done = 0;
+                                while (done < ng && r == SKX_OK) {
+                                    if ((r = take_slot()) != SKX_OK) break;
+                                    dstp = ring.base + (size_t)x.slot * SLOT + x.used;
+                                    const size_t c = std::min(ng - done, RAW_CHUNK - x.used);
+                                    if (total + c > cap) { r = SKF_OVER_BOUND; break; }
+                                    memcpy(dstp, np + done, c);
+                                    if (first) { first = false; if (np[0] != '@') { r = SKF_OVER_BOUND; break; } }      // (a gzip file that is not FASTQ: the one-shot form takes the batch)
+                                    x.used += c; done += c; total += c; got_file += c; last = np[done - 1];
+                                    if (x.used >= RAW_CHUNK) flush();
+                                }
+                                if (r != SKX_OK) break;
+                                continue;
+                            }
+                            const ssize_t rd = ::read(fd, dstp, std::min<uint64_t>(room, cap - total));
+                            if (rd < 0 && errno == EINTR) continue;
+                            if (rd < 0) { set_error("Invalid path/file: %s", f); r = SKX_EIO; break; }
+                            got = (size_t)rd;
+                            if (got == 0) {
+                                // (the file grew since it was measured: what the bound was made from no longer holds)
+                                if (total >= cap) { char c1; if (::read(fd, &c1, 1) > 0) { set_error("Invalid FASTA/Q record"); r = SKX_EIO; } }
+                                break;
+                            }
+                            if (first) { first = false; if (dstp[0] != '@') { set_error("Invalid FASTA/Q record"); r = SKX_EIO; break; } }
+                            x.used += got; total += got; got_file += got; last = dstp[got - 1];
+                            if (x.used >= RAW_CHUNK) flush();
+                        }
+                        if (r != SKX_OK) break;
+                        if (got_file == 0) { set_error("Invalid path/file: %s", f); r = SKX_EIO; break; }
+                        if (last != '\n') {
+                            if ((r = take_slot()) != SKX_OK) break;
+                            ring.base[(size_t)x.slot * SLOT + x.used] = '\n'; x.used++; total++;
+                            if (x.used >= RAW_CHUNK) flush();
+                        }
+                    }
+                    sample_len = total;
+                } else {
+                    pk.pos = 0; pk.cap = bound[i] - 32; for (auto &c : pk.cur) c = 0;
+                    pk.push = [&](const uint64_t *grp) -> int {
+                        const int tr = take_slot(); if (tr != SKX_OK) return tr;
+                        memcpy(ring.base + (size_t)x.slot * SLOT + x.used, grp, READ_GROUP_BYTES);
+                        x.used += READ_GROUP_BYTES;
+                        if (x.used == SLOT) flush();
+                        return SKX_OK;
+                    };
+                    const std::function<int(int, const uint8_t *, size_t)> emit = [&](int which, const uint8_t *p, size_t nb) -> int { return pk.emit(which, p, nb); };
+                    for (const char *f : {file1[i], file2 ? file2[i] : nullptr}) {
+                        if (!f) continue;
+                        r = stream_fastq_file(f, emit);
+                        if (r == SKF_NOT_TAKEN && !any_gz) { set_error("Invalid FASTA/Q record"); r = SKX_EIO; }      // (the first byte was '@' a moment ago)
+                        if (r == SKF_NOT_TAKEN) r = SKF_OVER_BOUND;                                      // (a gzip file that is not FASTQ: the one-shot form takes the batch)
+                        if (r != SKX_OK) break;
+                    }
+                    if (r == SKX_OK) r = pk.finish();
+                    sample_len = pk.pos;
                 }
-                if (r == SKX_OK && (pos & 63)) r = push_group();                 // the last, partly filled group
                 if (r == SKX_OK) flush();
                 if (r != SKX_OK) {
                     give_back();
@@ -810,15 +912,16 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
                     return;
                 }
                 us_files += us_since(t_files);
-                { std::lock_guard<std::mutex> lk(ring.mu); smp[i].len = pos; smp[i].read_done = true; mark_ready_locked(i); }
+                { std::lock_guard<std::mutex> lk(ring.mu); smp[i].len = sample_len; smp[i].junction = junction; smp[i].read_done = true; mark_ready_locked(i); }
                 ring.cv_ready.notify_all();
             }
         });
     // this thread: a sample's kernels as soon as its text is on the device
     std::vector<DevBuf<uint64_t>> wl(n), wh2(n);
     std::vector<uint64_t> cnt(n, 0);
-    int done = 0, krc = SKX_OK;
-    double t_kernels = 0.0;
+    int done = 0, krc = SKX_OK, n_irregular = 0;
+    double t_kernels = 0.0, t_frame = 0.0;
+    FastqScratch fsc;
     while (done < n) {
         int i = -1;
         {
@@ -829,8 +932,38 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
         }
         const auto tk = std::chrono::steady_clock::now();
         skx_qual qs = q ? *q : skx_qual{5, 20, SKX_QUAL_STRICT};
+        uint8_t *slot_p = packed_pool.p + (uint64_t)smp[i].slot * dslot_bytes;
+        uint64_t positions = smp[i].len;
+        if (smp[i].raw) {
+            // the device frames the records and makes the planes; a text it calls irregular goes through the host reader here and now (which
+            // accepts what is merely unusual -- blank lines between records -- and words the error for what is wrong), and the readers pack the
+            // samples that follow: files of one run tend to share their quirks
+            int irregular = 0;
+            krc = fastq_frame_planes(ctx, slot_p + pslot_bytes, smp[i].len, smp[i].junction, min_qual_host, (uint64_t *)slot_p, fsc, &positions, &irregular);
+            if (krc == SKX_OK && irregular) {
+                n_irregular++;
+                { std::lock_guard<std::mutex> lk(ring.mu); ring.prefer_packed = true; }
+                std::vector<uint64_t> host_planes;
+                PlanePacker pk; pk.min_qual = min_qual_host; pk.gz = any_gz; pk.cap = bound[i] - 32;
+                pk.push = [&](const uint64_t *grp) -> int { host_planes.insert(host_planes.end(), grp, grp + 5); return SKX_OK; };
+                const std::function<int(int, const uint8_t *, size_t)> emit = [&](int which, const uint8_t *p, size_t nb) -> int { return pk.emit(which, p, nb); };
+                for (const char *f : {file1[i], file2 ? file2[i] : nullptr}) {
+                    if (!f) continue;
+                    krc = stream_fastq_file(f, emit);
+                    if (krc == SKF_NOT_TAKEN && !any_gz) { set_error("Invalid FASTA/Q record"); krc = SKX_EIO; }
+                    if (krc == SKF_NOT_TAKEN || krc == SKF_OVER_BOUND) krc = SKF_NOT_TAKEN;          // (the one-shot form takes the batch)
+                    if (krc != SKX_OK) break;
+                }
+                if (krc == SKX_OK) krc = pk.finish();
+                if (krc == SKX_OK && !host_planes.empty() &&
+                    hipMemcpyAsync(slot_p, host_planes.data(), host_planes.size() * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) krc = SKX_ENODEV;
+                if (krc == SKX_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) krc = SKX_ENODEV;      // (host_planes goes)
+                positions = pk.pos;
+            }
+            t_frame += std::chrono::duration<double>(std::chrono::steady_clock::now() - tk).count();
+        }
         // (the kernels read the packed planes themselves: the two record streams never exist in memory)
-        krc = reads_sample_words(ctx, nullptr, nullptr, smp[i].len, k, rc, qs, wl[i], wh2[i], &cnt[i], (const uint64_t *)(packed_pool.p + (uint64_t)smp[i].slot * pslot_bytes));      // (returns with the stream idle: the slot is free)
+        if (krc == SKX_OK) krc = reads_sample_words(ctx, nullptr, nullptr, positions, k, rc, qs, wl[i], wh2[i], &cnt[i], (const uint64_t *)slot_p);      // (returns with the stream idle: the slot is free)
         t_kernels += std::chrono::duration<double>(std::chrono::steady_clock::now() - tk).count();
         { std::lock_guard<std::mutex> lk(ring.mu); ring.free_stream.push_back(smp[i].slot); if (krc != SKX_OK) ring.abort = true; }
         ring.cv_stream.notify_all();
@@ -843,9 +976,13 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     for (auto &u : uploaders) u.join();
     phase_add("build.read_upload", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     phase_add("build.reads_kernels_overlapped", t_kernels);
+    phase_add("build.reads_device_framing_overlapped", t_frame);
     phase_add("build.readers_files_thread_s", us_files.load() * 1e-6);               // parse + pack, waits for pinned slots included
     phase_add("build.readers_wait_pinned_thread_s", us_wait_ring.load() * 1e-6);
     phase_add("build.readers_wait_device_slot_thread_s", us_wait_stream.load() * 1e-6);
+    phase_add("build.reads_samples_sent_raw", (double)n_raw.load());
+    phase_add("build.reads_samples_irregular", (double)n_irregular);
+    phase_add("build.reads_uploaded_GB", (double)bytes_up.load() * 1e-9);
     if (ring.failed) { set_error("upload of the sequence files failed"); return SKX_ENODEV; }
     // the kernels' verdict first (SKF_NOT_TAKEN included: the one-shot form takes the batch -- the readers it interrupted recorded nothing),
     // then the reader whose own failure stopped the pipeline
@@ -864,6 +1001,32 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
         if ((d->sorted ? d->sample_size[sidx2] : d->raw_total[sidx2]) == 0) { set_error("%s has no valid sequence", file1[sidx2]); delete d; return SKX_EEMPTY; }
     *out = d;
     return SKX_OK;
+}
+
+// Test hook (not part of the drop-in boundary): FASTQ text through the device framing (skx_fastq.hip), the planes expanded to the two record
+// streams the read-set kernels would see -- sequence A C T G N '\n', quality ' ' (passes) / '!' (fails) / '\n'.  seq / qual: room for len / 2 + 64.
+extern "C" int skx_debug_fastq_frame(skx_ctx *ctx, const uint8_t *text, uint64_t len, uint64_t junction, int min_qual, uint8_t *seq, uint8_t *qual,
+                                     uint64_t *positions, int *irregular)
+{
+    return skx_guarded([&]() -> int {
+    if (!ctx || !text || !seq || !qual || !positions || !irregular) { set_error("bad arguments"); return SKX_EINVAL; }
+    SKX_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevBuf<uint8_t> d_text, d_seq, d_qual; DevBuf<uint64_t> planes;
+    SKX_TRY(d_text.alloc(len + 64)); SKX_TRY(planes.alloc((len / 2 / 64 + 4) * 5));
+    SKX_HIP(hipMemsetAsync(d_text.p, 0xAA, len + 64, st));                // (what lies behind the text is not zero in the pipeline either)
+    SKX_HIP(hipMemcpyAsync(d_text.p, text, len, hipMemcpyHostToDevice, st));
+    FastqScratch sc;
+    SKX_TRY(fastq_frame_planes(ctx, d_text.p, len, junction, min_qual, planes.p, sc, positions, irregular));
+    if (*irregular || *positions == 0) { SKX_HIP(hipStreamSynchronize(st)); return SKX_OK; }
+    SKX_TRY(d_seq.alloc(*positions + 64)); SKX_TRY(d_qual.alloc(*positions + 64));
+    launch_expand_planes(planes.p, *positions, d_seq.p, d_qual.p, st);
+    SKX_HIP(hipMemcpyAsync(seq, d_seq.p, *positions, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipMemcpyAsync(qual, d_qual.p, *positions, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipStreamSynchronize(st));
+    SKX_HIP(hipGetLastError());
+    return SKX_OK;
+    });
 }
 
 extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, const char *const *file2, int n, int k, int rc,

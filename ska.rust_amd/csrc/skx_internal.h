@@ -195,6 +195,9 @@ struct HostStream { std::vector<uint8_t> seq, qual; bool is_fastq = false; std::
 int read_sample_stream(const char *file1, const char *file2, double proportion_reads, HostStream &out);
 // a plain FASTQ file line by line: emit(0, sequence line) / emit(1, quality line), without terminators -- the sink adds the '\n' that ends a
 // record of the stream (SKF_NOT_TAKEN: not plain FASTQ)
+// FASTQ text -> the read-set kernels' bit planes on the device (skx_fastq.hip); scratch that lives across a batch's samples
+struct FastqScratch { DevBuf<uint32_t> tile, info, line_end, rec_seq, rec_qual, rec_len, rec_end; };
+int fastq_frame_planes(skx_ctx *ctx, const uint8_t *raw, uint64_t len, uint64_t junction, int min_qual, uint64_t *planes, FastqScratch &sc, uint64_t *positions, int *irregular);
 int stream_fastq_file(const char *path, const std::function<int(int which, const uint8_t *p, size_t n)> &emit);
 // gzip members inflated piece by piece into a window of the reader's own (gz_inflate.cpp: the reader threads' inflater).  next(): more text,
 // in place -- the `keep` bytes in front of the last call's end stay in front of it (the caller's unfinished line); *n == 0 at the end of the

@@ -328,12 +328,14 @@ def test_read_set_pipeline_equals_one_shot(tmp_path):
             f.write(f"r{i}\t{a}\t{b}\n" if i % 3 else f"r{i}\t{a}\n")                     # every third sample: one file only
     for k in ("31", "41"):
         outs = {}
-        for tag, env in (("pipe", {}), ("oneshot", {"SKX_KNOBS": "no_reads_pipeline=1"})):
+        # (round 6: a sample crosses PCIe as its reader thread chooses -- the file's bytes, framed and packed on the device (reads_raw=2: always),
+        #  or planes packed by the reader (reads_raw=1: always); left alone the choice follows the pinned ring's fill)
+        for tag, env in (("pipe", {}), ("raw", {"SKX_KNOBS": "reads_raw=2"}), ("packed", {"SKX_KNOBS": "reads_raw=1"}), ("oneshot", {"SKX_KNOBS": "no_reads_pipeline=1"})):
             r = subprocess.run([SKA, "build", "-f", "list.txt", "-o", f"{tag}{k}", "-k", k, "--min-count", "3", "--threads", "4"], cwd=wd, capture_output=True,
                                timeout=300, env=dict(os.environ, **env))
             assert r.returncode == 0, r.stderr[-600:]
             outs[tag] = open(os.path.join(wd, f"{tag}{k}.skf"), "rb").read()
-        assert outs["pipe"] == outs["oneshot"]
+        assert outs["pipe"] == outs["oneshot"] and outs["raw"] == outs["oneshot"] and outs["packed"] == outs["oneshot"]
         want = ora.Array.build([(f"r{i}", a, b if i % 3 else None) for i, (a, b) in enumerate(pairs)], k=int(k), rc=True, q=ora.qual(3, 20, ora.QUAL_STRICT), threads=2)
         got = ora.Array.load(os.path.join(wd, f"pipe{k}.skf"))
         got.sort_rows(); want.sort_rows()
@@ -357,20 +359,22 @@ def test_read_set_pipeline_equals_one_shot(tmp_path):
                         open(dst, "wb").write(gzip.compress(raw, 1))
                     names.append(dst)
                 f.write(f"r{i}\t" + "\t".join(names) + "\n")
-        r = subprocess.run([SKA, "build", "-f", f"list_{tag}.txt", "-o", f"{tag}31", "-k", "31", "--min-count", "3", "--threads", "4"], cwd=wd, capture_output=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-600:]
-        assert open(os.path.join(wd, f"{tag}31.skf"), "rb").read() == open(os.path.join(wd, "pipe31.skf"), "rb").read(), tag
+        for knobs in ("", "reads_raw=2", "reads_raw=1"):
+            r = subprocess.run([SKA, "build", "-f", f"list_{tag}.txt", "-o", f"{tag}31", "-k", "31", "--min-count", "3", "--threads", "4"], cwd=wd, capture_output=True, timeout=300,
+                               env=dict(os.environ, SKX_KNOBS=knobs))
+            assert r.returncode == 0, r.stderr[-600:]
+            assert open(os.path.join(wd, f"{tag}31.skf"), "rb").read() == open(os.path.join(wd, "pipe31.skf"), "rb").read(), (tag, knobs)
     # a gzip file that stops before its end is refused by both forms (never taken for a shorter input)
     z = open(pairs[4][0] + ".gz.gz", "rb").read()
     open(os.path.join(wd, "cut.fastq.gz"), "wb").write(z[:len(z) * 6 // 10])
     with open(os.path.join(wd, "list_cut.txt"), "w") as f:
         f.write(f"r0\t{pairs[0][0]}.gz.gz\nr4\t{os.path.join(wd, 'cut.fastq.gz')}\nr5\t{pairs[5][0]}.gz.gz\n")
-    for env in ({}, {"SKX_KNOBS": "no_reads_pipeline=1"}):
+    for env in ({}, {"SKX_KNOBS": "reads_raw=2"}, {"SKX_KNOBS": "reads_raw=1"}, {"SKX_KNOBS": "no_reads_pipeline=1"}):
         r = subprocess.run([SKA, "build", "-f", "list_cut.txt", "-o", "cut", "-k", "31", "--min-count", "3", "--threads", "3"], cwd=wd, capture_output=True, timeout=300, env=dict(os.environ, **env))
         assert r.returncode != 0 and b"Invalid" in r.stderr, r.stderr[-400:]
     bad = open(pairs[2][0], "rb").read()
     open(pairs[2][0], "wb").write(bad[:len(bad) // 2 - 7])                                # a record cut in the middle
-    for env in ({}, {"SKX_KNOBS": "no_reads_pipeline=1"}):
+    for env in ({}, {"SKX_KNOBS": "reads_raw=2"}, {"SKX_KNOBS": "reads_raw=1"}, {"SKX_KNOBS": "no_reads_pipeline=1"}):
         r = subprocess.run([SKA, "build", "-f", "list.txt", "-o", "broken", "-k", "31", "--min-count", "3"], cwd=wd, capture_output=True, timeout=300, env=dict(os.environ, **env))
         assert r.returncode != 0 and b"Invalid FASTA/Q record" in r.stderr, r.stderr[-400:]
 
@@ -423,12 +427,13 @@ def test_read_set_pipeline_odd_bytes_and_line_lengths(tmp_path):
     for k, qf, oq, mc in (("31", "strict", ora.QUAL_STRICT, 2), ("41", "middle", ora.QUAL_MIDDLE, 2), ("21", "no-filter", ora.QUAL_NOFILTER, 1),
                           ("9", "strict", ora.QUAL_STRICT, 2), ("15", "middle", ora.QUAL_MIDDLE, 3), ("63", "strict", ora.QUAL_STRICT, 2)):
         outs = {}
-        for tag, env in (("pipe", {}), ("avx2", {"SKX_KNOBS": "simd_cap=2"}), ("plain", {"SKX_KNOBS": "simd_cap=1"}), ("oneshot", {"SKX_KNOBS": "no_reads_pipeline=1"})):
+        for tag, env in (("pipe", {"SKX_KNOBS": "reads_raw=2"}), ("avx2", {"SKX_KNOBS": "simd_cap=2,reads_raw=1"}), ("plain", {"SKX_KNOBS": "simd_cap=1,reads_raw=1"}),
+                         ("avx512", {"SKX_KNOBS": "reads_raw=1"}), ("oneshot", {"SKX_KNOBS": "no_reads_pipeline=1"})):
             r = subprocess.run([SKA, "build", "-f", "list.txt", "-o", f"{tag}{k}", "-k", k, "--min-count", str(mc), "--min-qual", "20", "--qual-filter", qf, "--threads", "3"],
                                cwd=wd, capture_output=True, timeout=300, env=dict(os.environ, **env))
             assert r.returncode == 0, r.stderr[-600:]
             outs[tag] = open(os.path.join(wd, f"{tag}{k}.skf"), "rb").read()
-        assert outs["pipe"] == outs["oneshot"] and outs["avx2"] == outs["oneshot"] and outs["plain"] == outs["oneshot"], k
+        assert outs["pipe"] == outs["oneshot"] and outs["avx2"] == outs["oneshot"] and outs["plain"] == outs["oneshot"] and outs["avx512"] == outs["oneshot"], k
         want = ora.Array.build([(f"o{i}", a, b) for i, (a, b) in enumerate(files)], k=int(k), rc=True, q=ora.qual(mc, 20, oq), threads=2)
         got = ora.Array.load(os.path.join(wd, f"pipe{k}.skf"))
         got.sort_rows(); want.sort_rows()
@@ -454,13 +459,14 @@ def test_read_set_pipeline_gives_way_to_the_sort_based_form(tmp_path):
         for i, (a, b) in enumerate(pairs):
             f.write(f"r{i}\t{a}\t{b}\n")
     outs = {}
-    for tag, env in (("pipe", {}), ("oneshot", {"SKX_KNOBS": "no_reads_pipeline=1"})):
+    for tag, env in (("pipe", {}), ("packed", {"SKX_KNOBS": "reads_raw=1"}), ("oneshot", {"SKX_KNOBS": "no_reads_pipeline=1"})):
         r = subprocess.run([SKA, "build", "-f", "list.txt", "-o", tag, "-k", "31", "--min-count", "3", "--threads", "4"], cwd=wd, capture_output=True, timeout=300,
                            env=dict(os.environ, SKX_DEBUG="1", **env))
         assert r.returncode == 0, r.stderr[-600:]
         outs[tag] = (open(os.path.join(wd, tag + ".skf"), "rb").read(), r.stderr)
     assert b"left to the sort-based form" in outs["pipe"][1]                    # the case this test is about did arise
-    assert outs["pipe"][0] == outs["oneshot"][0]
+    assert b"left to the sort-based form" in outs["packed"][1]
+    assert outs["pipe"][0] == outs["oneshot"][0] and outs["packed"][0] == outs["oneshot"][0]
     want = ora.Array.build([(f"r{i}", a, b) for i, (a, b) in enumerate(pairs)], k=31, rc=True, q=ora.qual(3, 20, ora.QUAL_STRICT), threads=2)
     got = ora.Array.load(os.path.join(wd, "pipe.skf"))
     got.sort_rows(); want.sort_rows()
