@@ -347,6 +347,7 @@ static int reads_words_to_dictset(skx_ctx *ctx, std::vector<DevBuf<uint64_t>> &w
 
 // the regions of a dictset sorted and folded in place (a sample's SkaDict per bucket: dedupe_mb_kernel / dedupe_wide_kernel, the table
 // form for repeat-rich regions); *overflow != 0: a region does not fit, the caller builds again with more buckets
+static int dictset_sort_flat(skx_ctx *ctx, skx_dictset *d);
 static int dedupe_regions(skx_ctx *ctx, skx_dictset *d, uint32_t lds_cap, uint64_t maxlen, int *overflow_out, std::vector<uint32_t> &ucnt)
 {
     hipStream_t st = ctx->stream;
@@ -400,11 +401,59 @@ static int dedupe_regions(skx_ctx *ctx, skx_dictset *d, uint32_t lds_cap, uint64
     }
 }
 
+// Samples whose regions are beyond the per-region LDS sort (assemblies above ~5 Mbp keep 2^10 regions that grow with them, so that the
+// extraction kernel's (tile, bucket) chunks stay whole lines: round 6): every sample's words as ONE sorted, folded list -- the form the
+// sort-based read-set path leaves (logB = 0), which every consumer of sorted dictionaries takes.  Radix sort + fold (skx_prims, skx_reads.hip).
+static int dictset_sort_flat(skx_ctx *ctx, skx_dictset *d)
+{
+    hipStream_t st = ctx->stream;
+    const bool wide = d->wide();
+    const int wpk = wide ? 2 : 1, n = d->n;
+    const uint64_t B = 1ull << d->logB, nreg = (uint64_t)n << d->logB;
+    std::vector<uint32_t> raw(nreg);
+    SKX_HIP(hipMemcpyAsync(raw.data(), d->raw.p, nreg * 4, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipStreamSynchronize(st));
+    std::vector<DevBuf<uint64_t>> lists(n);
+    std::vector<uint64_t> sizes(n, 0), offs(n + 1, 0), dst(B);
+    DevBuf<uint64_t> d_dst, lo, hi;
+    SKX_TRY(d_dst.alloc(B));
+    for (int s = 0; s < n; s++) {
+        uint64_t m = 0;
+        for (uint64_t b = 0; b < B; b++) { dst[b] = m; m += raw[(uint64_t)s * B + b]; }
+        if (m == 0) continue;
+        if (lo.n < m) { SKX_TRY(lo.alloc(m + m / 8)); if (wide) SKX_TRY(hi.alloc(m + m / 8)); }
+        SKX_HIP(hipMemcpyAsync(d_dst.p, dst.data(), B * 8, hipMemcpyHostToDevice, st));
+        launch_gather_regions(d->words.p, d->off.p, d->raw.p, d_dst.p, (uint64_t)s * B, B, wpk, lo.p, wide ? hi.p : nullptr, st);
+        SKX_TRY(sort_fold_words(ctx, lo.p, wide ? hi.p : nullptr, m, lists[s], &sizes[s]));      // (returns with the stream idle: dst may be refilled)
+        if (sizes[s] > 0xFFFFFFFFull) { set_error("sample too large"); return SKX_EUNSUP; }
+    }
+    for (int s = 0; s < n; s++) offs[s + 1] = offs[s] + sizes[s];
+    lo.release(); hi.release();
+    DevBuf<uint64_t> words, off; DevBuf<uint32_t> rawn, ucnt;
+    SKX_TRY(words.alloc(offs[n] * wpk)); SKX_TRY(off.alloc(n + 1)); SKX_TRY(rawn.alloc(n)); SKX_TRY(ucnt.alloc(n));
+    std::vector<uint32_t> uc(n);
+    for (int s = 0; s < n; s++) {
+        uc[s] = (uint32_t)sizes[s];
+        if (sizes[s]) SKX_HIP(hipMemcpyAsync(words.p + offs[s] * wpk, lists[s].p, sizes[s] * 8 * wpk, hipMemcpyDeviceToDevice, st));
+    }
+    SKX_HIP(hipMemcpyAsync(off.p, offs.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
+    SKX_HIP(hipMemcpyAsync(ucnt.p, uc.data(), n * 4, hipMemcpyHostToDevice, st));
+    SKX_HIP(hipMemcpyAsync(rawn.p, uc.data(), n * 4, hipMemcpyHostToDevice, st));
+    SKX_HIP(hipStreamSynchronize(st));
+    SKX_HIP(hipGetLastError());
+    d->words = std::move(words); d->off = std::move(off); d->raw = std::move(rawn); d->ucnt = std::move(ucnt);
+    d->sidx.release(); d->sb = 0; d->logB = 0;
+    d->sample_size = sizes;
+    d->sorted = true;
+    return SKX_OK;
+}
+
 int skx::dictset_sort(skx_dictset *d)
 {
     if (d->sorted) return SKX_OK;
     skx_ctx *ctx = d->ctx;
     SKX_HIP(hipSetDevice(ctx->device));
+    if (d->region_cap > (d->wide() ? LDS_SORT_MAX_WIDE : LDS_SORT_MAX)) return dictset_sort_flat(ctx, d);
     int overflow = 0;
     std::vector<uint32_t> ucnt;
     SKX_TRY(dedupe_regions(ctx, d, d->region_cap, d->maxlen, &overflow, ucnt));
@@ -489,8 +538,17 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
     // (128-bit keys: 3 200, so that a region's fixed capacity -- 20 % + 256 above the mean -- stays within the 4 096 words of the wide counting sort
     // and the samples can stay as extracted for the append pass whatever their length)
     uint64_t per_region = wide ? 3200 : 4900;
-    if (any_qual || maxlen > (per_region << MAX_LOGB)) return build_reads();
-    int logB = std::min({ilog2_ceil((maxlen + per_region - 1) / per_region), key_bits_used, MAX_LOGB});
+    if (any_qual) return build_reads();
+    // Longer samples (round 6): the bucket count stops growing at the 5 Mbp shape (2^10 regions; 2^11 for 128-bit keys) and the regions grow
+    // instead -- the extraction kernel's (tile, bucket) chunks stay whole lines (with regions capped at 4 900 words a 20 Mbp sample took 13 ps per
+    // base against 2.5, a 40 Mbp one 43, and beyond that the assembly kernels were left altogether), the append pass reads regions of any
+    // size unsorted (2^(logQ - logB) row blocks per region: up to 32 readers a region), and who asks for sorted dictionaries of such samples
+    // gets the flat sorted form (dictset_sort_flat).  Beyond 32 row blocks per region the buckets grow again (to 2^13: ~1.3 Gbp).
+    const int need = std::max(0, ilog2_ceil((maxlen + per_region - 1) / per_region));
+    const int base_logB = wide ? 11 : 10;
+    const bool grow_regions = !knob("small_regions");
+    if ((grow_regions ? need - 5 : need) > MAX_LOGB) return build_reads();
+    int logB = std::min({grow_regions && need > base_logB ? std::max(base_logB, need - 5) : need, key_bits_used, MAX_LOGB});
     if (logB < 0) logB = 0;
 
     DevBuf<const uint8_t *> d_seqs, d_quals;
@@ -551,7 +609,8 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
         // (skx::dictset_sort: skx_dictset_size / _export, the key-set union of a sharded job).  A fixed-capacity region always fits
         // the counting sort (region_cap <= LDS_SORT_MAX), so that later sort cannot come back for a finer split.
         d->maxlen = maxlen; d->region_cap = lds_cap;
-        if (!exact && !any_qual && lds_cap <= (wide ? LDS_SORT_MAX_WIDE : LDS_SORT_MAX) && !knob("sorted_dicts") && !(wide && knob("sorted_wide"))) {
+        const bool big_regions = lds_cap > (wide ? LDS_SORT_MAX_WIDE : LDS_SORT_MAX);
+        if (!exact && !any_qual && (big_regions || (!knob("sorted_dicts") && !(wide && knob("sorted_wide"))))) {
             DevBuf<unsigned long long> d_tot; SKX_TRY(d_tot.alloc(n));
             launch_region_totals(d->raw.p, n, logB, d_tot.p, st);
             d->raw_total.resize(n);
@@ -559,6 +618,16 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
             SKX_HIP(hipStreamSynchronize(st));
             SKX_HIP(hipGetLastError());
             d->sorted = false;
+            // (regions beyond the per-region sort stay as extracted whatever the knobs say -- that is what keeps the extraction's chunks whole --
+            // and the knobs that ask for sorted dictionaries get them from the flat sort)
+            if (big_regions && (knob("sorted_dicts") || (wide && knob("sorted_wide")))) SKX_TRY(dictset_sort(d.get()));
+            *out = d.release();
+            return SKX_OK;
+        }
+        if (big_regions) {
+            // an exact layout (a region overflowed its fixed capacity: repeat content) of regions the LDS sort cannot hold: the flat sort
+            d->sorted = false;
+            SKX_TRY(dictset_sort(d.get()));
             *out = d.release();
             return SKX_OK;
         }
@@ -719,10 +788,16 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     const bool raw_possible = raw_knob != 1 && raw_cap + 2 < 0xFFFFFF00ull;
     const uint64_t pslot_bytes = ((slot_bytes / 64 + 2) * READ_GROUP_BYTES + 255) & ~255ull;
     const uint64_t rslot_bytes = raw_possible ? ((raw_cap + 2 + 64 + 255) & ~255ull) : 0;
-    const uint64_t dslot_bytes = pslot_bytes + rslot_bytes;                    // a device slot: the planes, then the text
-    int P = (int)std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(2, std::min<uint64_t>((uint64_t)nt + 8, (free_b / 8) / (dslot_bytes + 1))));
-    DevBuf<uint8_t> packed_pool;
-    SKX_TRY(packed_pool.alloc((uint64_t)P * dslot_bytes));
+    // Two pools of device slots: packed samples (157 MB each at 50x of 5 Mbp; a reader each and a few waiting for their kernels) and raw ones
+    // (0.55 GB each: a few -- the link carries about one at a time -- plus ONE buffer for the planes the device makes of them, since the
+    // kernels take a sample at a time).  Kept small on purpose: a pool of 24 slots that hold either form is 17 GB, and allocating that right
+    // after another process has released its memory took 1.4-1.9 s of a 3 s build (profiles/r06b_reads_modes.log).
+    int P = (int)std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(2, std::min<uint64_t>((uint64_t)nt + 8, (free_b / 8) / (pslot_bytes + 1))));
+    int R = raw_possible ? (int)std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(2, std::min<uint64_t>(raw_knob == 2 ? (uint64_t)nt / 2 + 2 : 6, (free_b / 16) / (rslot_bytes + 1)))) : 0;
+    if (raw_knob == 2) P = 1;
+    DevBuf<uint8_t> packed_pool, raw_pool, raw_planes;
+    SKX_TRY(packed_pool.alloc((uint64_t)P * pslot_bytes));
+    if (R) { SKX_TRY(raw_pool.alloc((uint64_t)R * rslot_bytes)); SKX_TRY(raw_planes.alloc(pslot_bytes)); }
     constexpr size_t SLOT = ((8u << 20) / READ_GROUP_BYTES) * READ_GROUP_BYTES;          // whole groups
     constexpr size_t RAW_CHUNK = (SLOT - 1) / 256 * 256;                                 // raw text leaves in pieces that keep their destinations aligned
     const int min_qual_host = q ? (int)q->min_qual : 20;
@@ -730,13 +805,14 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     struct Sample { int slot = -1; int pending = 0; bool read_done = false, queued = false, raw = false; uint64_t len = 0, junction = 0; };
     struct Ring {
         uint8_t *base = nullptr; std::mutex mu; std::condition_variable cv_free, cv_work, cv_stream, cv_ready;
-        std::vector<int> free_slots, free_stream; struct Req { int slot; uint8_t *dst; size_t bytes; int sample; }; std::deque<Req> work;
+        std::vector<int> free_slots, free_stream, free_raw; struct Req { int slot; uint8_t *dst; size_t bytes; int sample; }; std::deque<Req> work;
         std::deque<int> ready; int readers_left = 0; bool failed = false, abort = false, prefer_packed = false;
         ~Ring() { if (base) (void)hipHostFree(base); }
     } ring;
     if (hipHostMalloc((void **)&ring.base, (size_t)n_slots * SLOT, hipHostMallocDefault) != hipSuccess) { ring.base = nullptr; return SKF_NOT_TAKEN; }
     for (int b = 0; b < n_slots; b++) ring.free_slots.push_back(b);
     for (int p = 0; p < P; p++) ring.free_stream.push_back(p);
+    for (int p = 0; p < R; p++) ring.free_raw.push_back(p);
     ring.readers_left = nt;
     phase_add("build.alloc_text_pin_ring", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     std::vector<Sample> smp(n);
@@ -785,18 +861,20 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
                 {
                     const auto tw = std::chrono::steady_clock::now();
                     std::unique_lock<std::mutex> lk(ring.mu);
-                    ring.cv_stream.wait(lk, [&] { return !ring.free_stream.empty() || ring.abort; });
+                    // the link keeps up (most of the pinned ring is free) and a raw slot is to be had: this sample goes as it is; otherwise it is
+                    // packed here.  (reads_raw=2: raw whatever the ring says -- then a raw slot is waited for.)
+                    auto want_raw = [&] { return R > 0 && !ring.prefer_packed && (raw_knob == 2 || (!ring.free_raw.empty() && (int)ring.free_slots.size() * 2 >= n_slots)); };
+                    ring.cv_stream.wait(lk, [&] { return ring.abort || (want_raw() ? !ring.free_raw.empty() : !ring.free_stream.empty()); });
                     us_wait_stream += us_since(tw);
                     if (ring.abort) return;
-                    sslot = ring.free_stream.back(); ring.free_stream.pop_back();
-                    smp[i].slot = sslot;
-                    // the link keeps up (most of the pinned ring is free): this sample goes as it is; otherwise it is packed here
-                    raw = raw_possible && !ring.prefer_packed && (raw_knob == 2 || (int)ring.free_slots.size() * 2 >= n_slots);
-                    smp[i].raw = raw;
+                    raw = want_raw();
+                    std::vector<int> &fl = raw ? ring.free_raw : ring.free_stream;
+                    sslot = fl.back(); fl.pop_back();
+                    smp[i].slot = sslot; smp[i].raw = raw;
                 }
                 const auto t_files = std::chrono::steady_clock::now();
                 struct Out { int slot = -1; size_t used = 0; uint8_t *dst = nullptr; uint64_t off = 0; } x;
-                x.dst = packed_pool.p + (uint64_t)sslot * dslot_bytes + (raw ? pslot_bytes : 0);
+                x.dst = raw ? raw_pool.p + (uint64_t)sslot * rslot_bytes : packed_pool.p + (uint64_t)sslot * pslot_bytes;
                 auto flush = [&]() {
                     if (x.slot < 0) return;
                     { std::lock_guard<std::mutex> lk(ring.mu); ring.work.push_back({x.slot, x.dst + x.off, x.used, i}); smp[i].pending++; }
@@ -932,14 +1010,14 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
         }
         const auto tk = std::chrono::steady_clock::now();
         skx_qual qs = q ? *q : skx_qual{5, 20, SKX_QUAL_STRICT};
-        uint8_t *slot_p = packed_pool.p + (uint64_t)smp[i].slot * dslot_bytes;
+        uint8_t *slot_p = smp[i].raw ? raw_planes.p : packed_pool.p + (uint64_t)smp[i].slot * pslot_bytes;      // where the sample's planes are
         uint64_t positions = smp[i].len;
         if (smp[i].raw) {
             // the device frames the records and makes the planes; a text it calls irregular goes through the host reader here and now (which
             // accepts what is merely unusual -- blank lines between records -- and words the error for what is wrong), and the readers pack the
             // samples that follow: files of one run tend to share their quirks
             int irregular = 0;
-            krc = fastq_frame_planes(ctx, slot_p + pslot_bytes, smp[i].len, smp[i].junction, min_qual_host, (uint64_t *)slot_p, fsc, &positions, &irregular);
+            krc = fastq_frame_planes(ctx, raw_pool.p + (uint64_t)smp[i].slot * rslot_bytes, smp[i].len, smp[i].junction, min_qual_host, (uint64_t *)slot_p, fsc, &positions, &irregular);
             if (krc == SKX_OK && irregular) {
                 n_irregular++;
                 { std::lock_guard<std::mutex> lk(ring.mu); ring.prefer_packed = true; }
@@ -965,7 +1043,7 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
         // (the kernels read the packed planes themselves: the two record streams never exist in memory)
         if (krc == SKX_OK) krc = reads_sample_words(ctx, nullptr, nullptr, positions, k, rc, qs, wl[i], wh2[i], &cnt[i], (const uint64_t *)slot_p);      // (returns with the stream idle: the slot is free)
         t_kernels += std::chrono::duration<double>(std::chrono::steady_clock::now() - tk).count();
-        { std::lock_guard<std::mutex> lk(ring.mu); ring.free_stream.push_back(smp[i].slot); if (krc != SKX_OK) ring.abort = true; }
+        { std::lock_guard<std::mutex> lk(ring.mu); (smp[i].raw ? ring.free_raw : ring.free_stream).push_back(smp[i].slot); if (krc != SKX_OK) ring.abort = true; }
         ring.cv_stream.notify_all();
         if (krc != SKX_OK) { ring.cv_free.notify_all(); break; }
         done++;
@@ -990,7 +1068,7 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     for (int i = 0; i < n; i++) if (rcodes[i] == SKF_OVER_BOUND) return SKF_NOT_TAKEN;
     for (int i = 0; i < n; i++) if (rcodes[i] != SKX_OK) { set_error("%s", errs[i].c_str()); return rcodes[i]; }
     if (done < n) { set_error("internal: read-set pipeline stopped early"); return SKX_EUNSUP; }
-    packed_pool.release();
+    packed_pool.release(); raw_pool.release(); raw_planes.release();
     const auto t1 = std::chrono::steady_clock::now();
     skx_dictset *d = nullptr;
     int r = reads_words_to_dictset(ctx, wl, wh2, cnt, k, rc, &d);
@@ -1925,7 +2003,9 @@ static int append_pass(skx_ctx *ctx, skx_dictset *d, std::unique_ptr<skx_keyset>
     uint64_t raw_sum = 0, raw_max = 0;
     for (auto v : d->raw_total) { raw_sum += v; raw_max = std::max(raw_max, v); }
     const int min_logQ = std::max(logB, bits - (wide ? 113 : 50));
-    if (min_logQ > bits || region_cap > 8192u) return not_taken("regions of more than 8192 words");
+    if (min_logQ > bits) return not_taken("no row-block split with room for a rank in a table entry");
+    // (regions of any size: a wave streams a region in chunks of 1 024 words -- the samples above ~5 Mbp of round 6 keep their bucket count and
+    // grow their regions)
     auto ranks_for = [&](double mean) -> uint32_t {
         const double c = mean + 6.0 * std::sqrt(mean + 1.0) + 32.0;
         return (uint32_t)std::min<double>(max_cap, std::ceil(c / 128.0) * 128.0);
@@ -1972,7 +2052,10 @@ static int append_pass(skx_ctx *ctx, skx_dictset *d, std::unique_ptr<skx_keyset>
         const double mean = u_est / (double)nsub;
         const uint32_t cap = ranks_for(mean), nslots = slots_for(cap);
         const uint64_t amp = 1ull << (logQ - logB);
-        if (amp > 8 && (double)raw_sum * (double)amp > 4e8) return not_taken("more than 8 row blocks per region: every region would be read too often");
+        // every region is read by `amp` workgroups that keep a share each: 8 at most where the regions are the 5 Mbp shape's (beyond that the
+        // samples are unrelated and the sorted path reads less), 32 where the regions have grown with the samples (one XCD's workgroups: 256 / 8)
+        const uint64_t amp_max = region_cap > (wide ? LDS_SORT_MAX_WIDE : LDS_SORT_MAX) ? 32 : 8;
+        if (amp > amp_max && (double)raw_sum * (double)amp > 4e8) return not_taken("too many row blocks per region: every region would be read too often");
         if (!pass_ok(logQ, nslots, cap)) return not_taken("no row-block split that fits the LDS");
         std::unique_ptr<skx_keyset> ks(new skx_keyset());
         ks->ctx = ctx; ks->k = d->k; ks->rc = d->rc; ks->logN = logQ; ks->hp = d->hp; ks->wh = d->wh; ks->wide = wide; ks->stride = cap;

@@ -76,6 +76,7 @@ struct ExtractArgs {
     const uint64_t *lens;         // [n]
     int n_samples;
     int tiles_max;                // ceil(max len / TILE_BASES)
+    int parts = 0, tiles_part = 0; // fewer than 8 samples: a sample's tiles in `parts` contiguous ranges of tiles_part, a range per XCD (set by the launcher)
     int k, rc;
     int min_qual, qual_filter;    // FASTQ only
     int logB;

@@ -170,8 +170,16 @@ __global__ __launch_bounds__(TILE / PPT, SPLIT ? 6 : 1) void extract_kernel(Extr
     PHASE_PROF_START;
     const uint64_t per_group = 8ull * (uint64_t)a.tiles_max;
     const uint64_t L = blockIdx.x;
-    const int sample = (int)((L / per_group) * 8 + (L % per_group) % 8);
-    const uint64_t tile = (L % per_group) / 8;
+    // workgroup L runs on XCD L % 8: a sample's tiles stay on one XCD, one after the other (its regions' lines are put together in ONE L2).  With
+    // fewer than eight samples that would leave XCDs idle (one 100 Mbp sample: an eighth of the chip): then a sample's tiles are dealt to
+    // `parts` XCDs in contiguous ranges
+    int sample; uint64_t tile;
+    if (a.parts > 1) {
+        const int v = (int)(L & 7u);
+        if (v >= a.n_samples * a.parts) return;
+        sample = v / a.parts; tile = (uint64_t)(v % a.parts) * (uint64_t)a.tiles_part + (L >> 3);
+        if (tile >= (uint64_t)a.tiles_max || (L >> 3) >= (uint64_t)a.tiles_part) return;
+    } else { sample = (int)((L / per_group) * 8 + (L % per_group) % 8); tile = (L % per_group) / 8; }
     if (sample >= a.n_samples) return;
     const uint64_t len = a.lens[sample];
     const uint64_t T0 = tile * TILE;
@@ -406,10 +414,18 @@ static inline size_t extract_lds(const ExtractArgs &a, bool scatter)
     size_t stage = scatter ? (size_t)TILE * (SPLIT ? 4 : 8) : 0;
     return ((size_t)8 << a.logB) + 16 + 80 + (stage > codes ? stage : codes);
 }
-template <bool SCATTER, int TILE, bool HI, int PPT, bool SPLIT, int RMAX>
-static void launch_extract_t(const ExtractArgs &a, hipStream_t st)
+// fewer than eight samples with enough tiles each: 8 / n ranges of tiles per sample
+static inline void extract_parts(ExtractArgs &a)
 {
-    const uint64_t g = (((uint64_t)a.n_samples + 7) / 8) * 8ull * (uint64_t)a.tiles_max;
+    a.parts = 0; a.tiles_part = 0;
+    if (a.n_samples >= 1 && a.n_samples < 8 && a.tiles_max >= 64) { a.parts = 8 / a.n_samples; a.tiles_part = (a.tiles_max + a.parts - 1) / a.parts; if (a.parts < 2) a.parts = 0; }
+}
+template <bool SCATTER, int TILE, bool HI, int PPT, bool SPLIT, int RMAX>
+static void launch_extract_t(const ExtractArgs &a_, hipStream_t st)
+{
+    ExtractArgs a = a_;
+    extract_parts(a);
+    const uint64_t g = a.parts > 1 ? 8ull * (uint64_t)a.tiles_part : (((uint64_t)a.n_samples + 7) / 8) * 8ull * (uint64_t)a.tiles_max;
     if (!g) return;
     const size_t lds = extract_lds<TILE, SPLIT>(a, SCATTER);
     (void)hipFuncSetAttribute((const void *)extract_kernel<SCATTER, TILE, HI, PPT, SPLIT, RMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

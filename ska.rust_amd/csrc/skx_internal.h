@@ -235,6 +235,9 @@ void launch_words_regions(bool count, const uint64_t *in_lo, const uint64_t *in_
 int cov_histogram(skx_ctx *ctx, const uint8_t *d_seq, uint64_t len, int k, int rc, uint32_t *d_hist);
 // `ska map` helpers (skx_reads.hip)
 int ref_windows(skx_ctx *ctx, const uint8_t *d_seq, uint64_t len, int k, int rc, DevBuf<uint64_t> &wlo, DevBuf<uint64_t> &whi, DevBuf<uint8_t> &flag);
+int sort_fold_words(skx_ctx *ctx, const uint64_t *alo, const uint64_t *ahi, uint64_t m, DevBuf<uint64_t> &out_words, uint64_t *n_out);   // ahi: nullptr for 64-bit keys
+void launch_gather_regions(const uint64_t *words, const uint64_t *off, const uint32_t *raw, const uint64_t *dst_off, uint64_t r0, uint64_t n_regions, int wpk,
+                           uint64_t *lo, uint64_t *hi, hipStream_t st);
 int ref_repeat_flags(skx_ctx *ctx, const uint64_t *wlo, const uint64_t *whi, const uint8_t *flag, uint64_t len, DevBuf<uint8_t> &rep);   // whi: nullptr for k <= 31
 int select_mapped(const uint32_t *row, uint64_t len, DevBuf<uint32_t> &mapped, uint64_t *m, hipStream_t st);
 int sort_words_perm(const uint64_t *words, uint64_t n, DevBuf<uint64_t> &sorted, DevBuf<uint32_t> &perm, hipStream_t st);

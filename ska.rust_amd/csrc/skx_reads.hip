@@ -561,7 +561,6 @@ int reads_sample_dict(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual,
 {
     hipStream_t st = ctx->stream;
     const bool wide = k > 31;
-    const int wpk = wide ? 2 : 1;
     *n_out = 0;
     if (len == 0) return SKX_OK;
     if (len > 0xFFFFFFF0ull) { set_error("FASTQ sample longer than 4 G bases"); return SKX_EUNSUP; }
@@ -612,22 +611,43 @@ int reads_sample_dict(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual,
     }
 
     // accepted windows -> sorted unique packed words
-    DevBuf<uint64_t> alo, ahi, slo, shi;
-    SKX_TRY(alo.alloc(m2)); SKX_TRY(slo.alloc(m2));
+    DevBuf<uint64_t> alo, ahi;
+    SKX_TRY(alo.alloc(m2));
     hipLaunchKernelGGL(gather_u64_kernel, dim3(grid_for(m2)), dim3(256), 0, st, wlo.p, acc_t.p, alo.p, m2);
+    if (wide) {
+        SKX_TRY(ahi.alloc(m2));
+        hipLaunchKernelGGL(gather_u64_kernel, dim3(grid_for(m2)), dim3(256), 0, st, whi.p, acc_t.p, ahi.p, m2);
+    }
+    return sort_fold_words(ctx, alo.p, wide ? ahi.p : nullptr, m2, out_words, n_out);
+}
+
+// m packed words (low halves, and high halves when the keys are 128 bits wide) -> sorted by key, equal keys folded into one word whose base
+// set is the OR of theirs (ska_dict.rs:92-101): a sample's SkaDict as one sorted list.  The tail of the sort-based read-set form, and what
+// skx::dictset_sort makes of an assembly whose regions are beyond the per-region LDS sort (samples above ~5 Mbp keep 1 024 regions that grow
+// with them: round 6).  out_words: wpk words per key.
+int sort_fold_words(skx_ctx *ctx, const uint64_t *alo, const uint64_t *ahi, uint64_t m2, DevBuf<uint64_t> &out_words, uint64_t *n_out)
+{
+    hipStream_t st = ctx->stream;
+    const bool wide = ahi != nullptr;
+    const int wpk = wide ? 2 : 1;
+    *n_out = 0;
+    if (m2 == 0) return SKX_OK;
+    if (m2 > 0xFFFFFFF0ull) { set_error("sample longer than 4 G windows"); return SKX_EUNSUP; }
+    Temp tmp;
+    DevBuf<uint64_t> slo, shi;
+    SKX_TRY(slo.alloc(m2));
     if (!wide) {
-        SKX_TRY(prim_sort_keys_u64(alo.p, slo.p, m2, 64, st));
+        SKX_TRY(prim_sort_keys_u64(alo, slo.p, m2, 64, st));
     } else {
         // 128-bit order = stable sort by the low word, then stable sort by the high word
-        SKX_TRY(ahi.alloc(m2)); SKX_TRY(shi.alloc(m2));
-        hipLaunchKernelGGL(gather_u64_kernel, dim3(grid_for(m2)), dim3(256), 0, st, whi.p, acc_t.p, ahi.p, m2);
+        SKX_TRY(shi.alloc(m2));
         DevBuf<uint32_t> i0, i1, i2; DevBuf<uint64_t> t1, t2;
         SKX_TRY(i0.alloc(m2)); SKX_TRY(i1.alloc(m2)); SKX_TRY(i2.alloc(m2)); SKX_TRY(t1.alloc(m2)); SKX_TRY(t2.alloc(m2));
         hipLaunchKernelGGL(iota_u32_kernel, dim3(grid_for(m2)), dim3(256), 0, st, i0.p, m2);
-        SKX_TRY(sort_pairs(tmp, alo.p, t1.p, i0.p, i1.p, m2, st));                         // by low word
-        hipLaunchKernelGGL(gather_u64_kernel, dim3(grid_for(m2)), dim3(256), 0, st, ahi.p, i1.p, t2.p, m2);
+        SKX_TRY(sort_pairs(tmp, alo, t1.p, i0.p, i1.p, m2, st));                         // by low word
+        hipLaunchKernelGGL(gather_u64_kernel, dim3(grid_for(m2)), dim3(256), 0, st, ahi, i1.p, t2.p, m2);
         SKX_TRY(sort_pairs(tmp, t2.p, shi.p, i1.p, i2.p, m2, st));                          // then by high word (stable)
-        hipLaunchKernelGGL(gather_u64_kernel, dim3(grid_for(m2)), dim3(256), 0, st, alo.p, i2.p, slo.p, m2);
+        hipLaunchKernelGGL(gather_u64_kernel, dim3(grid_for(m2)), dim3(256), 0, st, alo, i2.p, slo.p, m2);
     }
     DevBuf<uint32_t> whead, whsum;
     SKX_TRY(whead.alloc(m2)); SKX_TRY(whsum.alloc(m2));
@@ -642,6 +662,25 @@ int reads_sample_dict(skx_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual,
     RP(hipGetLastError());
     *n_out = nu;
     return SKX_OK;
+}
+
+// the words of one sample's regions (as the extraction kernel left them: region r holds raw[r] words from off[r]) as one list: dst_off[r] =
+// where region r's words go; 128-bit words are split into their halves
+__global__ __launch_bounds__(256) void gather_regions_kernel(const uint64_t *words, const uint64_t *off, const uint32_t *raw, const uint64_t *dst_off, uint64_t r0, int wpk,
+                                                             uint64_t *lo, uint64_t *hi)
+{
+    const uint64_t r = r0 + blockIdx.x;
+    const uint64_t src = off[r], dst = dst_off[blockIdx.x];
+    const uint32_t n = raw[r];
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        if (wpk == 1) lo[dst + i] = words[src + i];
+        else { lo[dst + i] = words[(src + i) * 2]; hi[dst + i] = words[(src + i) * 2 + 1]; }
+    }
+}
+void launch_gather_regions(const uint64_t *words, const uint64_t *off, const uint32_t *raw, const uint64_t *dst_off, uint64_t r0, uint64_t n_regions, int wpk,
+                           uint64_t *lo, uint64_t *hi, hipStream_t st)
+{
+    if (n_regions) hipLaunchKernelGGL(gather_regions_kernel, dim3((unsigned)n_regions), dim3(256), 0, st, words, off, raw, dst_off, r0, wpk, lo, hi);
 }
 
 // ------------------------------------------------------------------------------------------------

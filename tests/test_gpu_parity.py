@@ -681,30 +681,49 @@ def _sorted_export(arr):
     return keys["hi"][order], keys["lo"][order], np.asarray(var)[order], np.asarray(counts)[order]
 
 
-@pytest.mark.parametrize("k,length", [(31, 41_000_000), (41, 34_000_000)])
-def test_oversize_assembly_takes_the_sorted_path(E, k, length):
-    """An assembly with more windows than 2^13 bucket regions hold (40.1 Mbp at k <= 31, 33.5 Mbp above) is built by the
-    sort-based path the read sets use, filters off; its dictionary, and an array merged with an ordinary sample, must equal
-    the oracle's."""
-    rng = np.random.default_rng(k)
+@pytest.mark.parametrize("k,length,contigs", [(31, 41_000_000, 2), (41, 34_000_000, 2), (31, 100_000_000, 1), (31, 12_000_000, 3)])
+def test_large_assembly_stays_on_the_assembly_kernels(E, k, length, contigs, monkeypatch):
+    """The reference's add_file_kmers has no size limit (ska_dict.rs:118-180).  Until round 6 a sample's regions were capped at what the
+    per-region LDS sort holds, so the bucket count grew with the genome (17x the time per base at 40 Mbp) and beyond 2^13 regions -- 40.1 Mbp at
+    k <= 31, 33.5 Mbp above -- the sample left the assembly kernels for the read sets' sort-based form.  Now the regions grow instead: such a sample
+    is extracted by the same kernel into 2^10 (2^11) regions, merged by the append pass (skx_ctx_merge_path says so), and its sorted dictionary --
+    what skx_dictset_export asks for -- comes from the flat sort.  The merged array with an ordinary sample and both dictionaries equal the
+    oracle's; SKX_KNOBS=sorted_dicts sends the same samples through the sorted path: the same array."""
+    rng = np.random.default_rng(k + contigs)
     g = rng.integers(0, 4, size=length, dtype=np.uint8)
     big = np.frombuffer(b"ACGT", dtype=np.uint8)[g]
+    del g
     small = big[: 1_000_000].copy()
     small[rng.integers(0, len(small), size=300)] = ord("A")
-    samples = [[big[: length // 2].tobytes(), big[length // 2:].tobytes()], [small.tobytes()]]
-    ds = E.DictSet.build([E.record_stream(r) for r in samples], k, True)
+    cuts = [length * i // contigs for i in range(contigs + 1)]
+    samples = [[big[a:b].tobytes() for a, b in zip(cuts[:-1], cuts[1:])], [small.tobytes()]]
+    streams = [E.record_stream(r) for r in samples]
     ods = [oracle_dict(r, k, True) for r in samples]
-    for i in range(2):
+    oa = ora.Array.from_dicts(ods, ["big", "small"])
+    want = _sorted_export(oa)
+    ds = E.DictSet.build(streams, k, True)
+    ga = ds.merge(["big", "small"])                                   # the dictionaries as extracted: the append pass
+    assert E.default_context().merge_path() == ("append128" if k > 31 else "append64")
+    assert ga.nkmers == oa.nkmers
+    for x, y in zip(_sorted_export(ga), want):
+        assert np.array_equal(x, y)
+    del ga
+    for i in range(2):                                                # a sample's SkaDict as such: the flat sort
         ok, ob = ods[i].export()
         gk, gb = ds.export(i)
         assert len(gk) == len(ok)
         assert np.array_equal(gk["lo"], ok["lo"]) and np.array_equal(gk["hi"], ok["hi"]) and np.array_equal(gb, ob)
-    if k > 31:
-        return                 # the merged-array half once is enough for the suite's running time
-    ga = ds.merge(["big", "small"])
-    oa = ora.Array.from_dicts(ods, ["big", "small"])
-    assert ga.nkmers == oa.nkmers
-    for x, y in zip(_sorted_export(ga), _sorted_export(oa)):
+    if length > 50_000_000:
+        return                 # (the sorted path's half once at each key width is enough for the suite's running time)
+    ga = ds.merge(["big", "small"])                                   # the same dictset, sorted by now: union + assemble
+    assert E.default_context().merge_path().startswith("sorted: the dictionaries are sorted")
+    for x, y in zip(_sorted_export(ga), want):
+        assert np.array_equal(x, y)
+    ds.free()
+    set_knob(monkeypatch, "sorted_dicts", "1")
+    gs = E.DictSet.build(streams, k, True).merge(["big", "small"])
+    assert E.default_context().merge_path().startswith("sorted:")
+    for x, y in zip(_sorted_export(gs), want):
         assert np.array_equal(x, y)
 
 
