@@ -615,15 +615,17 @@ void launch_append_probe(const AppendArgs &a, uint32_t region_cap, unsigned bloc
 // results, profiles/r05_final_pmc_traffic.txt).  A block with more rows than the stage holds (global rows of a sharded job over unrelated
 // samples) or split over several workgroups (never at the append pass's capacities) stores per rank as before.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t PS_STAGE = 6144;                                   // rows staged: >= APPEND_MAX_CAP (a pass's own rows: nrows <= nrank <= cap)
-static_assert(PS_STAGE >= APPEND_MAX_CAP, "the stage holds a row block of the append pass");
+// (the stage is as large as the launch's piece capacity -- a pass's own rows: nrows <= nrank <= cap -- so that 3 072-rank blocks of 128-bit keys
+// keep their occupancy: a fixed 36 KB cost the k = 41 form more than the stores had, profiles/r05v_ab_stats_staged.log)
 __global__ __launch_bounds__(256) void pieces_stats_kernel(const uint8_t *pieces, const uint16_t *plen, const uint16_t *perm, const uint32_t *nrank, const uint32_t *ncnt,
                                                            const uint64_t *roff, uint32_t cap, int S, uint32_t *o_present, uint32_t *o_unambig, uint32_t *o_mask,
-                                                           uint32_t *o_vcount, int force_direct)
+                                                           uint32_t *o_vcount, int force_direct, uint32_t stage)
 {
     constexpr int W = 4;                                              // dwords per thread: one 16-byte load per sample (append_kernel writes the pieces 16 bytes -- 32 ranks -- at a time,
                                                                       // so such a piece of a sample's piece is either written whole or not at all)
-    __shared__ uint16_t s_pr[PS_STAGE], s_un[PS_STAGE], s_mk[PS_STAGE];
+    extern __shared__ __attribute__((aligned(16))) uint16_t s_stage[];  // [3][stage]: present, unambiguous, code set -- by row
+    const uint32_t PS_STAGE = stage;
+    uint16_t *const s_pr = s_stage, *const s_un = s_stage + stage, *const s_mk = s_stage + 2 * (size_t)stage;
     const uint64_t j = blockIdx.x;
     const uint32_t nr = nrank[j], nrows = ncnt[j];
     const uint64_t r0 = roff[j];
@@ -767,7 +769,9 @@ void launch_pieces_stats(const uint8_t *pieces, const uint16_t *plen, const uint
     if (n_blocks <= 0) return;
     const unsigned gy = (cap / 32 + 255u) / 256u;
     static const int direct = knob("stats_direct") ? 1 : 0;           // (tests: the per-rank stores of blocks the stage does not hold)
-    hipLaunchKernelGGL(pieces_stats_kernel, dim3((unsigned)n_blocks, gy), dim3(256), 0, st, pieces, plen, perm, nrank, ncnt, roff, cap, n_samples, present, unambig, mask, vcount, direct);
+    const uint32_t stage = (cap + 63u) / 64u * 64u;                    // <= 6 016 (12 032 with gy > 1, where nothing is staged): <= 36 KB
+    hipLaunchKernelGGL(pieces_stats_kernel, dim3((unsigned)n_blocks, gy), dim3(256), (size_t)stage * 6, st, pieces, plen, perm, nrank, ncnt, roff, cap, n_samples, present, unambig, mask, vcount,
+                       direct, stage);
 }
 // split k-mers per sample (SkaDict::ksize): the cells of its pieces that are not empty; a wave per piece
 __global__ __launch_bounds__(256) void pieces_cells_kernel(const uint8_t *pieces, const uint16_t *plen, uint32_t cap, int S, unsigned long long *out)

@@ -804,6 +804,51 @@ int selftest(skx_ctx *ctx, int rank, int world)
                                (unsigned long long)n1, local ? ", each also over the host-staged transport" : "", bad ? "MISMATCH" : "ok");
         skx_keyset_free(ks); skx_keyset_free(rows); if (ks2) skx_keyset_free(ks2); if (rows2) skx_keyset_free(rows2);
     }
+    // BASELINE config 4's exchange at its size: every rank's key table holds ~8 M keys (a 5 Mbp genome all ranks share + 3 to 3.7 Mbp of its
+    // own, as 1 000 related assemblies with private SNPs leave it), unequal from rank to rank; the union of eight such tables is ~32 M rows.  The
+    // number of rows is known in advance -- shared + the sum of the private parts -- and every rank must arrive at it.  (SKX_SELFTEST_SMALL: skipped.)
+    if (!getenv("SKX_SELFTEST_SMALL")) {
+        alarm(180);
+        stage("config-4 shape: key tables of ~8 M keys per rank (all-gather + union)");
+        auto write_fa = [&](std::string &path, uint64_t shared_bases, uint64_t own_bases) -> bool {
+            char tmpl[] = "/tmp/skx_selftest_big_XXXXXX";
+            const int fd = mkstemp(tmpl);
+            if (fd < 0) return false;
+            std::string fa; fa.reserve(shared_bases + own_bases + 64);
+            uint64_t x = 0x2545F4914F6CDD1Dull;
+            auto base = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return "ACGT"[(x >> 11) & 3]; };
+            if (shared_bases) { fa += ">shared\n"; for (uint64_t i = 0; i < shared_bases; i++) fa += base(); fa += "\n"; }
+            if (own_bases) { fa += ">own\n"; x = 0xD1B54A32D192ED03ull * (uint64_t)(rank + 7); for (uint64_t i = 0; i < own_bases; i++) fa += base(); fa += "\n"; }
+            const bool ok = write(fd, fa.data(), fa.size()) == (ssize_t)fa.size();
+            close(fd);
+            path = tmpl;
+            return ok;
+        };
+        const uint64_t shared_bases = 5000000, own_bases = 3000000 + 100000 * (uint64_t)rank;
+        std::string p_all, p_shared;
+        if (!write_fa(p_all, shared_bases, own_bases) || !write_fa(p_shared, shared_bases, 0)) return fail("selftest: cannot write a temporary file");
+        skx_keyset *ks = nullptr, *kshared = nullptr, *rows = nullptr;
+        int r = skx_keyset_from_fasta(ctx, p_all.c_str(), 31, 1, &ks);
+        if (r == SKX_OK) r = skx_keyset_from_fasta(ctx, p_shared.c_str(), 31, 1, &kshared);
+        unlink(p_all.c_str()); unlink(p_shared.c_str());
+        if (r != SKX_OK) return engine_fail();
+        uint64_t mine_n = 0, shared_n = 0, n1 = 0;
+        skx_keyset_size(ks, &mine_n); skx_keyset_size(kshared, &shared_n);
+        stage("config-4 shape: the all-gather");
+        if (skx_keyset_allgather(comm, ks, &rows) != SKX_OK) return engine_fail();
+        skx_keyset_size(rows, &n1);
+        stage("config-4 shape: agreement on the row count");
+        // (sums in 16-bit halves: the all-reduce adds 32-bit words)
+        const uint64_t own_n = mine_n - shared_n;
+        std::vector<uint32_t> parts = {(uint32_t)(own_n & 0xFFFF), (uint32_t)((own_n >> 16) & 0xFFFF), (uint32_t)(own_n >> 32), (uint32_t)(n1 & 0xFFFF), (uint32_t)((n1 >> 16) & 0xFFFF), (uint32_t)(n1 >> 32)};
+        if (skx_comm_allreduce_u32(comm, parts.data(), parts.size(), 0) != SKX_OK) return engine_fail();
+        const uint64_t own_sum = (uint64_t)parts[0] + ((uint64_t)parts[1] << 16) + ((uint64_t)parts[2] << 32), n_sum = (uint64_t)parts[3] + ((uint64_t)parts[4] << 16) + ((uint64_t)parts[5] << 32);
+        if (mine_n <= shared_n || n1 != shared_n + own_sum) bad |= 128;                      // the union is what the tables add up to
+        if (n_sum != n1 * (uint64_t)world) bad |= 256;                                       // and every rank holds the same one
+        if (rank == 0) fprintf(stderr, "selftest: config-4 shape: %llu keys on rank 0 (%llu shared), union of %d tables %llu rows (expected %llu): %s\n", (unsigned long long)mine_n,
+                               (unsigned long long)shared_n, world, (unsigned long long)n1, (unsigned long long)(shared_n + own_sum), (bad & 384) ? "MISMATCH" : "ok");
+        skx_keyset_free(ks); skx_keyset_free(kshared); skx_keyset_free(rows);
+    }
     stage("closing");
     if (local) skx_comm_destroy(local);
     skx_comm_destroy(comm);

@@ -196,8 +196,11 @@ def test_selftest_two_ranks_and_one(tmp_path):
     env = dict(os.environ, SKX_COMM="local", SKX_DEVICE="0")
     r = subprocess.run([ska, "selftest", "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0 and "2 rank(s)" in r.stderr and ": ok" in r.stderr, r.stderr[-1500:]
+    # BASELINE config 4's exchange at its size (round 6): ~8 M keys per rank, unequal, the union's row count known in advance
+    shape = [l for l in r.stderr.splitlines() if "config-4 shape" in l]
+    assert shape and shape[-1].endswith(": ok") and "union of 2 tables" in shape[-1], r.stderr[-1500:]
     r = subprocess.run([ska, "selftest"], capture_output=True, text=True, timeout=120, env=dict(os.environ, SKX_DEVICE="0"))
-    assert r.returncode == 0 and "1 rank(s)" in r.stderr, r.stderr[-1500:]
+    assert r.returncode == 0 and "1 rank(s)" in r.stderr and "config-4 shape" in r.stderr, r.stderr[-1500:]
     # a stray SKX_WORLD does not turn `ska nk` into a sharded job
     r = subprocess.run([ska, "nk", os.path.join(ROOT, "tests", "golden", "input", "merge.skf")], capture_output=True, text=True, timeout=120,
                        env=dict(os.environ, SKX_WORLD="2", SKX_RANK="0", SKX_DEVICE="0"))
