@@ -86,7 +86,7 @@ for b in range(NB):
     dt = run(f"batch {b}: ska build ({hi - lo} isolates)", [SKA, "build", "-f", f"list{b}.txt", "-o", f"batch{b}", "--threads", THREADS, *opts], ph)
     wall["build"] += dt
     p = json.load(open(ph))
-    print("  phases", {k: round(v, 3) for k, v in p.items() if v >= 0.05}, f"= {(hi - lo) / dt:.1f} isolates/s", flush=True)
+    print("  phases", {k: round(v, 3) for k, v in p.items() if v >= 0.03}, f"= {(hi - lo) / dt:.1f} isolates/s", flush=True)
     # the oracle's dictionaries of this batch's spot isolates run beside the next batch's simulation; every other file goes now
     idx = sorted({lo + (hi - lo - 1) * j // max(1, SPOTS - 1) for j in range(SPOTS)}) if SPOTS > 0 else []
     for i, (f1, f2) in zip(range(lo, hi), pairs):
@@ -149,6 +149,24 @@ if len(spot_dicts) >= 2:
         print("   ", got.get(k))
     print(f"  {len(want)} pairs of the spot isolates: rows of all.tsv {'IDENTICAL to' if not bad else 'DIFFERENT from'} the oracle's table ({time.perf_counter() - t0:.1f} s)", flush=True)
     assert not bad, bad[:3]
+if os.environ.get("RSC_PROFILE"):                  # where `ska merge` / `ska distance` spend their device time on these very files (rocprofv3 kernel trace)
+    import glob
+    for tag, cmd in (("ska distance all.skf", [SKA, "distance", "all.skf", "-o", "prof.tsv"]), ("ska merge", [SKA, "merge", *[f"batch{b}.skf" for b in range(NB)], "-o", "prof_all"])):
+        pd = os.path.join(td, "prof")
+        shutil.rmtree(pd, ignore_errors=True)
+        env = dict(os.environ, TMPDIR="/tmp", SKX_KEEP_TEARDOWN="1", SKX_PHASES=os.path.join(td, "php.json"))
+        r = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "-d", pd, "--", *cmd], cwd=td, capture_output=True, env=env)
+        print(f"== {tag} under rocprofv3 (rc {r.returncode})", flush=True)
+        try:
+            print("  phases", {k: round(v, 3) for k, v in json.load(open(os.path.join(td, "php.json"))).items() if v >= 0.03}, flush=True)
+        except Exception:
+            pass
+        dbs = glob.glob(os.path.join(pd, "**", "*.db"), recursive=True)
+        if dbs:
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocprof_stats.py"), dbs[0]], capture_output=True, text=True).stdout
+            print("\n".join(l[:150] for l in out.splitlines()[:14]), flush=True)
+        else:
+            print(r.stderr.decode()[-800:], flush=True)
 total = time.perf_counter() - t_all
 print(f"wall clock: simulate {wall['simulate']:.1f} s, ska build {wall['build']:.2f} s ({N / wall['build']:.1f} isolates/s), ska merge {t_merge:.2f} s, "
       f"ska distance {t_dist:.2f} s; everything incl. the oracle {total:.1f} s", flush=True)

@@ -41,7 +41,7 @@ def build(tag, lst, knobs):
     dt = time.perf_counter() - t
     assert r.returncode == 0, (tag, r.stderr[-1500:])
     p = json.load(open(ph))
-    keep = {k.replace("build.", ""): round(v, 3) for k, v in p.items() if k.startswith("build.") and v >= 0.01}
+    keep = {k.replace("build.", ""): round(v, 3) for k, v in p.items() if v >= 0.02}
     h = hashlib.sha1(open(os.path.join(td, tag + ".skf"), "rb").read()).hexdigest()[:12]
     os.unlink(os.path.join(td, tag + ".skf"))
     return dt, keep, h
