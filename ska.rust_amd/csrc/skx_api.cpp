@@ -793,11 +793,16 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     // kernels take a sample at a time).  Kept small on purpose: a pool of 24 slots that hold either form is 17 GB, and allocating that right
     // after another process has released its memory took 1.4-1.9 s of a 3 s build (profiles/r06b_reads_modes.log).
     int P = (int)std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(2, std::min<uint64_t>((uint64_t)nt + 8, (free_b / 8) / (pslot_bytes + 1))));
-    int R = raw_possible ? (int)std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(2, std::min<uint64_t>(raw_knob == 2 ? (uint64_t)nt / 2 + 2 : 6, (free_b / 16) / (rslot_bytes + 1)))) : 0;
+    // raw slots: up to one per reader and two waiting for their kernels (a reader holds its slot for as long as it reads -- 0.1 s of a file read
+    // before, 0.25 s of one read for the first time, when sixteen read()s contend for the page cache's LRU lock -- so six slots carried 24 raw
+    // samples a second at most and the link idled at 12 GB/s: profiles/r06d_reads_1000.log).  They are allocated one by one by a helper thread
+    // while the pipeline already runs on the packed pool: 11 GB taken at once right after another process released its memory cost 1.4-1.9 s.
+    const int R = raw_possible ? (int)std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(2, std::min<uint64_t>((uint64_t)nt + 2, (free_b / 8) / (rslot_bytes + 1)))) : 0;
     if (raw_knob == 2) P = 1;
-    DevBuf<uint8_t> packed_pool, raw_pool, raw_planes;
+    DevBuf<uint8_t> packed_pool, raw_planes;
+    std::vector<DevBuf<uint8_t>> raw_slots((size_t)R);
     SKX_TRY(packed_pool.alloc((uint64_t)P * pslot_bytes));
-    if (R) { SKX_TRY(raw_pool.alloc((uint64_t)R * rslot_bytes)); SKX_TRY(raw_planes.alloc(pslot_bytes)); }
+    if (R) { SKX_TRY(raw_planes.alloc(pslot_bytes)); SKX_TRY(raw_slots[0].alloc(rslot_bytes)); }
     constexpr size_t SLOT = ((8u << 20) / READ_GROUP_BYTES) * READ_GROUP_BYTES;          // whole groups
     constexpr size_t RAW_CHUNK = (SLOT - 1) / 256 * 256;                                 // raw text leaves in pieces that keep their destinations aligned
     const int min_qual_host = q ? (int)q->min_qual : 20;
@@ -806,14 +811,24 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     struct Ring {
         uint8_t *base = nullptr; std::mutex mu; std::condition_variable cv_free, cv_work, cv_stream, cv_ready;
         std::vector<int> free_slots, free_stream, free_raw; struct Req { int slot; uint8_t *dst; size_t bytes; int sample; }; std::deque<Req> work;
-        std::deque<int> ready; int readers_left = 0; bool failed = false, abort = false, prefer_packed = false;
+        std::deque<int> ready; int readers_left = 0, up_pending = 0; bool failed = false, abort = false, prefer_packed = false;
         ~Ring() { if (base) (void)hipHostFree(base); }
     } ring;
     if (hipHostMalloc((void **)&ring.base, (size_t)n_slots * SLOT, hipHostMallocDefault) != hipSuccess) { ring.base = nullptr; return SKF_NOT_TAKEN; }
     for (int b = 0; b < n_slots; b++) ring.free_slots.push_back(b);
     for (int p = 0; p < P; p++) ring.free_stream.push_back(p);
-    for (int p = 0; p < R; p++) ring.free_raw.push_back(p);
+    if (R) ring.free_raw.push_back(0);
     ring.readers_left = nt;
+    std::thread raw_alloc([&]() {
+        (void)hipSetDevice(ctx->device);
+        for (int p = 1; p < R; p++) {
+            { std::lock_guard<std::mutex> lk(ring.mu); if (ring.abort || ring.readers_left == 0) break; }
+            if (raw_slots[(size_t)p].alloc(rslot_bytes) != SKX_OK) break;               // (no room: the pipeline goes on with what there is)
+            { std::lock_guard<std::mutex> lk(ring.mu); ring.free_raw.push_back(p); }
+            ring.cv_stream.notify_all();
+        }
+    });
+    struct JoinAlloc { std::thread &t; ~JoinAlloc() { if (t.joinable()) t.join(); } } join_alloc{raw_alloc};
     phase_add("build.alloc_text_pin_ring", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     std::vector<Sample> smp(n);
     std::vector<int> rcodes(n, SKX_OK);
@@ -840,7 +855,7 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
             {
                 std::lock_guard<std::mutex> lk(ring.mu);
                 if (bad) { ring.failed = true; ring.abort = true; }
-                for (auto &r : batch) { ring.free_slots.push_back(r.slot); smp[r.sample].pending--; mark_ready_locked(r.sample); }
+                for (auto &r : batch) { ring.free_slots.push_back(r.slot); smp[r.sample].pending--; ring.up_pending--; mark_ready_locked(r.sample); }
             }
             ring.cv_free.notify_all(); ring.cv_ready.notify_all();
             if (bad) { ring.cv_stream.notify_all(); }
@@ -861,9 +876,9 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
                 {
                     const auto tw = std::chrono::steady_clock::now();
                     std::unique_lock<std::mutex> lk(ring.mu);
-                    // the link keeps up (most of the pinned ring is free) and a raw slot is to be had: this sample goes as it is; otherwise it is
-                    // packed here.  (reads_raw=2: raw whatever the ring says -- then a raw slot is waited for.)
-                    auto want_raw = [&] { return R > 0 && !ring.prefer_packed && (raw_knob == 2 || (!ring.free_raw.empty() && (int)ring.free_slots.size() * 2 >= n_slots)); };
+                    // the link keeps up (few filled pieces of the pinned ring wait for their copy) and a raw slot is to be had: this sample goes as it
+                    // is; otherwise it is packed here.  (reads_raw=2: raw whatever the ring says -- then a raw slot is waited for.)
+                    auto want_raw = [&] { return R > 0 && !ring.prefer_packed && (raw_knob == 2 || (!ring.free_raw.empty() && ring.up_pending * 4 <= n_slots)); };
                     ring.cv_stream.wait(lk, [&] { return ring.abort || (want_raw() ? !ring.free_raw.empty() : !ring.free_stream.empty()); });
                     us_wait_stream += us_since(tw);
                     if (ring.abort) return;
@@ -874,10 +889,10 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
                 }
                 const auto t_files = std::chrono::steady_clock::now();
                 struct Out { int slot = -1; size_t used = 0; uint8_t *dst = nullptr; uint64_t off = 0; } x;
-                x.dst = raw ? raw_pool.p + (uint64_t)sslot * rslot_bytes : packed_pool.p + (uint64_t)sslot * pslot_bytes;
+                x.dst = raw ? raw_slots[(size_t)sslot].p : packed_pool.p + (uint64_t)sslot * pslot_bytes;
                 auto flush = [&]() {
                     if (x.slot < 0) return;
-                    { std::lock_guard<std::mutex> lk(ring.mu); ring.work.push_back({x.slot, x.dst + x.off, x.used, i}); smp[i].pending++; }
+                    { std::lock_guard<std::mutex> lk(ring.mu); ring.work.push_back({x.slot, x.dst + x.off, x.used, i}); smp[i].pending++; ring.up_pending++; }
                     ring.cv_work.notify_one();
                     bytes_up += (long long)x.used;
                     x.off += x.used; x.slot = -1; x.used = 0;
@@ -1017,7 +1032,7 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
             // accepts what is merely unusual -- blank lines between records -- and words the error for what is wrong), and the readers pack the
             // samples that follow: files of one run tend to share their quirks
             int irregular = 0;
-            krc = fastq_frame_planes(ctx, raw_pool.p + (uint64_t)smp[i].slot * rslot_bytes, smp[i].len, smp[i].junction, min_qual_host, (uint64_t *)slot_p, fsc, &positions, &irregular);
+            krc = fastq_frame_planes(ctx, raw_slots[(size_t)smp[i].slot].p, smp[i].len, smp[i].junction, min_qual_host, (uint64_t *)slot_p, fsc, &positions, &irregular);
             if (krc == SKX_OK && irregular) {
                 n_irregular++;
                 { std::lock_guard<std::mutex> lk(ring.mu); ring.prefer_packed = true; }
@@ -1068,7 +1083,8 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     for (int i = 0; i < n; i++) if (rcodes[i] == SKF_OVER_BOUND) return SKF_NOT_TAKEN;
     for (int i = 0; i < n; i++) if (rcodes[i] != SKX_OK) { set_error("%s", errs[i].c_str()); return rcodes[i]; }
     if (done < n) { set_error("internal: read-set pipeline stopped early"); return SKX_EUNSUP; }
-    packed_pool.release(); raw_pool.release(); raw_planes.release();
+    raw_alloc.join();
+    packed_pool.release(); raw_planes.release(); raw_slots.clear();
     const auto t1 = std::chrono::steady_clock::now();
     skx_dictset *d = nullptr;
     int r = reads_words_to_dictset(ctx, wl, wh2, cnt, k, rc, &d);
