@@ -797,7 +797,7 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     // before, 0.25 s of one read for the first time, when sixteen read()s contend for the page cache's LRU lock -- so six slots carried 24 raw
     // samples a second at most and the link idled at 12 GB/s: profiles/r06d_reads_1000.log).  They are allocated one by one by a helper thread
     // while the pipeline already runs on the packed pool: 11 GB taken at once right after another process released its memory cost 1.4-1.9 s.
-    const int R = raw_possible ? (int)std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(2, std::min<uint64_t>((uint64_t)nt + 2, (free_b / 8) / (rslot_bytes + 1)))) : 0;
+    const int R = raw_possible ? (int)std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(2, std::min<uint64_t>(any_gz || raw_knob == 2 ? (uint64_t)nt + 2 : (uint64_t)std::max(1, nt / 8) + 3, (free_b / 8) / (rslot_bytes + 1)))) : 0;
     if (raw_knob == 2) P = 1;
     DevBuf<uint8_t> packed_pool, raw_planes;
     std::vector<DevBuf<uint8_t>> raw_slots((size_t)R);
@@ -811,7 +811,7 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     struct Ring {
         uint8_t *base = nullptr; std::mutex mu; std::condition_variable cv_free, cv_work, cv_stream, cv_ready;
         std::vector<int> free_slots, free_stream, free_raw; struct Req { int slot; uint8_t *dst; size_t bytes; int sample; }; std::deque<Req> work;
-        std::deque<int> ready; int readers_left = 0, up_pending = 0; bool failed = false, abort = false, prefer_packed = false;
+        std::deque<int> ready; int readers_left = 0, up_pending = 0, raw_active = 0; bool failed = false, abort = false, prefer_packed = false;
         ~Ring() { if (base) (void)hipHostFree(base); }
     } ring;
     if (hipHostMalloc((void **)&ring.base, (size_t)n_slots * SLOT, hipHostMallocDefault) != hipSuccess) { ring.base = nullptr; return SKF_NOT_TAKEN; }
@@ -878,7 +878,13 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
                     std::unique_lock<std::mutex> lk(ring.mu);
                     // the link keeps up (few filled pieces of the pinned ring wait for their copy) and a raw slot is to be had: this sample goes as it
                     // is; otherwise it is packed here.  (reads_raw=2: raw whatever the ring says -- then a raw slot is waited for.)
-                    auto want_raw = [&] { return R > 0 && !ring.prefer_packed && (raw_knob == 2 || (!ring.free_raw.empty() && ring.up_pending * 4 <= n_slots)); };
+                    // Measured (profiles/r06e_reads_modes.log, 16 readers): files read before -- packed 124 isolates/s through the pipeline, raw 91 (the link:
+                    // 46 GB/s), and a reader's time is the read() either way (0.10 s of its 0.11 s per isolate: packing is what fits beside it); files
+                    // read for the first time -- 35 isolates/s in every form (sixteen read()s of fresh tmpfs pages share 26 GB/s).  So raw text is
+                    // what relieves a processor that packs slowly or inflates (gzip: every sample raw), and beside fast packers only a sample or two
+                    // at a time travel raw, on bandwidth the link has left.
+                    const int raw_cap = any_gz ? nt : std::max(1, nt / 8);
+                    auto want_raw = [&] { return R > 0 && !ring.prefer_packed && (raw_knob == 2 || (!ring.free_raw.empty() && ring.raw_active < raw_cap && ring.up_pending * 4 <= n_slots)); };
                     ring.cv_stream.wait(lk, [&] { return ring.abort || (want_raw() ? !ring.free_raw.empty() : !ring.free_stream.empty()); });
                     us_wait_stream += us_since(tw);
                     if (ring.abort) return;
@@ -886,6 +892,7 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
                     std::vector<int> &fl = raw ? ring.free_raw : ring.free_stream;
                     sslot = fl.back(); fl.pop_back();
                     smp[i].slot = sslot; smp[i].raw = raw;
+                    if (raw) ring.raw_active++;
                 }
                 const auto t_files = std::chrono::steady_clock::now();
                 struct Out { int slot = -1; size_t used = 0; uint8_t *dst = nullptr; uint64_t off = 0; } x;
@@ -997,6 +1004,7 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
                     sample_len = pk.pos;
                 }
                 if (r == SKX_OK) flush();
+                if (raw) { std::lock_guard<std::mutex> lk(ring.mu); ring.raw_active--; }
                 if (r != SKX_OK) {
                     give_back();
                     if (r != SKF_ABORTED) { rcodes[i] = r; errs[i] = skx_last_error(); }      // (only the failure that started it is reported)
