@@ -11,6 +11,7 @@
 #include <numeric>
 #include <thread>
 #include <unistd.h>
+#include <fcntl.h>
 
 using namespace skx;
 
@@ -217,6 +218,73 @@ extern "C" int skx_array_map(skx_array *a, const char *reference, int ambig_mask
     });
 }
 
+// The compressed bytes of a group of chunks, from the file into pinned memory by a small team of pread()s, a group ahead of the device
+// (round 6).  The loaders used to hand the runtime a pointer into the file's mapping: a pageable copy, one thread taking the page faults --
+// 8 GB/s on a file read before, 2 GB/s on one another process has just written (`ska align x.skf` behind `ska build`, `ska distance`
+// behind `ska merge`: the first touch of fresh tmpfs pages; load.stream_decode_filter 1.76 s of a 2.5 s `ska distance`,
+// profiles/r06d_reads_1000.log -- 0.44 s on the same file read a second time).  SKX_KNOBS=no_load_stager: the mapping, as before.
+namespace {
+struct GroupStager {
+    int fd = -1, nt = 4;
+    uint8_t *pin[2] = {nullptr, nullptr}; size_t cap[2] = {0, 0};
+    std::thread th[2]; bool ok[2] = {true, true};
+    size_t lo[2] = {0, 0}, hi[2] = {0, 0};
+    explicit GroupStager(const char *path)
+    {
+        if (knob("no_load_stager")) return;
+        fd = ::open(path, O_RDONLY);
+        nt = std::max(1, std::min(8, cpu_budget()));
+    }
+    ~GroupStager()
+    {
+        for (int w = 0; w < 2; w++) { if (th[w].joinable()) th[w].join(); if (pin[w]) (void)hipHostFree(pin[w]); }
+        if (fd >= 0) ::close(fd);
+    }
+    bool on() const { return fd >= 0; }
+    // file bytes [a, b) into buffer w (which nothing on the device reads any more)
+    bool start(int w, size_t a, size_t b)
+    {
+        if (th[w].joinable()) th[w].join();
+        const size_t n = b - a;
+        if (n + 512 > cap[w]) {
+            if (pin[w]) (void)hipHostFree(pin[w]);
+            pin[w] = nullptr; cap[w] = 0;
+            const size_t want = n + n / 4 + (1u << 20);
+            if (hipHostMalloc((void **)&pin[w], want, hipHostMallocDefault) != hipSuccess) { pin[w] = nullptr; (void)hipGetLastError(); return false; }
+            cap[w] = want;
+        }
+        lo[w] = a; hi[w] = b; ok[w] = true;
+        uint8_t *dst = pin[w]; const int fdc = fd; const int team = (int)std::max<size_t>(1, std::min<size_t>((size_t)nt, n >> 20));
+        bool *okp = &ok[w];
+        th[w] = std::thread([dst, fdc, a, n, team, okp]() {
+            std::atomic<bool> good{true};
+            auto slice = [&](int t) {
+                size_t p = n * (size_t)t / (size_t)team, e = n * (size_t)(t + 1) / (size_t)team;
+                while (p < e) {
+                    const ssize_t r = ::pread(fdc, dst + p, e - p, (off_t)(a + p));
+                    if (r < 0 && errno == EINTR) continue;
+                    if (r <= 0) { good = false; return; }
+                    p += (size_t)r;
+                }
+            };
+            std::vector<std::thread> helpers;
+            for (int t = 1; t < team; t++) helpers.emplace_back(slice, t);
+            slice(0);
+            for (auto &h : helpers) h.join();
+            *okp = good.load();
+        });
+        return true;
+    }
+    // the bytes [a, b) if buffer w holds (or is being filled with) exactly those; nullptr otherwise
+    const uint8_t *get(int w, size_t a, size_t b)
+    {
+        if (!pin[w] || lo[w] != a || hi[w] != b || a == b) return nullptr;
+        if (th[w].joinable()) th[w].join();
+        return ok[w] ? pin[w] : nullptr;
+    }
+};
+}  // namespace
+
 // ------------------------------------------------------------------------------------------ .skf
 // 64 KB chunks per launch of the device codec (512 MB of CBOR; SKX_SKF_GROUP_CHUNKS overrides, tests use small groups)
 static uint64_t skf_group_chunks()
@@ -375,13 +443,19 @@ extern "C" int skx_array_load(skx_ctx *ctx, const char *path, int want_bits, skx
         std::vector<SnapChunk> tab;
         uint64_t src_cap = 0, row_lo = 0, have_hi = 0;          // rows < row_lo are in the matrix; cells [row_lo * cols, have_hi) wait in the current buffer
         int cur = 0;
-        for (size_t g0 = c0; g0 < c1; g0 += G) {
+        GroupStager stg(path);
+        int sw = 0;
+        for (size_t g0 = c0; g0 < c1; g0 += G, sw ^= 1) {
             const size_t g1 = std::min<size_t>(c1, g0 + G);
             const size_t f_lo = ch[g0].off, f_hi = ch[g1 - 1].off + ch[g1 - 1].len;
             if (f_hi - f_lo + 512 > src_cap) { src_cap = f_hi - f_lo + 512; SKX_TRY(d_src.alloc(src_cap)); }      // + the decoder's read-ahead window
             tab.resize(g1 - g0);
             for (size_t c = g0; c < g1; c++) tab[c - g0] = SnapChunk{ch[c].off - f_lo, ch[c].uoff, (uint32_t)ch[c].len, ch[c].ulen, ch[c].crc, ch[c].compressed ? 1u : 0u};
-            SKX_HIP(hipMemcpyAsync(d_src.p, file + f_lo, f_hi - f_lo, hipMemcpyHostToDevice, st));
+            // this group's bytes: staged by the pread team (started a group ago; now, for the first), or straight from the mapping
+            const uint8_t *src_bytes = nullptr;
+            if (stg.on()) { src_bytes = stg.get(sw, f_lo, f_hi); if (!src_bytes && stg.start(sw, f_lo, f_hi)) src_bytes = stg.get(sw, f_lo, f_hi); }
+            if (stg.on() && g1 < c1) { const size_t n1 = std::min<size_t>(c1, g1 + G); (void)stg.start(sw ^ 1, ch[g1].off, ch[n1 - 1].off + ch[n1 - 1].len); }
+            SKX_HIP(hipMemcpyAsync(d_src.p, src_bytes ? src_bytes : file + f_lo, f_hi - f_lo, hipMemcpyHostToDevice, st));
             SKX_HIP(hipMemcpyAsync(d_chunks.p, tab.data(), tab.size() * sizeof(SnapChunk), hipMemcpyHostToDevice, st));
             const uint64_t base_cell = (row_lo * cols) & ~7ull;
             SKX_TRY(launch_skf_decode_cells(ctx->device, d_src.p, d_chunks.p, (uint32_t)(g1 - g0), upos, uend, d_scratch.p, d_cells[cur].p, base_cell, d_status.p, st));
@@ -543,12 +617,15 @@ extern "C" int skx_array_load_filtered(skx_ctx *ctx, const char *path, const skx
         if (mappable_output_fd(expect_fd, &opos)) a->prealloc = std::make_shared<Preallocator>(expect_fd, opos);
     }
     bool last_group = false;
-    for (size_t g0 = c0; !last_group; ) {
+    GroupStager stg(path);
+    int sw = 0; size_t planned_g1 = 0;                                                      // the group whose bytes the stager is reading ahead ends here (0: none)
+    for (size_t g0 = c0; !last_group; sw ^= 1) {
         // the group's chunks as far as the walker has come (it stays ahead of the device: ~3 M chunks/s against ~2.5 M decoded)
         // (at most gmax chunks: the buffers above are sized for gmax chunks of up to 64 KB each; a file framed in smaller chunks has more
         // chunks than 64 KB pieces and simply takes more groups)
-        (void)sf.wait_chunk(g0 + gmax - 1);
-        size_t g1 = std::min<size_t>(sf.n_chunks(), g0 + gmax);
+        if (!planned_g1) (void)sf.wait_chunk(g0 + gmax - 1);
+        size_t g1 = planned_g1 ? planned_g1 : std::min<size_t>(sf.n_chunks(), g0 + gmax);
+        planned_g1 = 0;
         if (g1 <= g0) {                                                                      // the walk ended before the data section did
             const int wr = sf.walk_result();
             if (wr == SKF_NOT_TAKEN) { a->prealloc.reset(); a.reset(); return load_then_filter(ctx, path, f, out, removed, constant); }
@@ -560,7 +637,16 @@ extern "C" int skx_array_load_filtered(skx_ctx *ctx, const char *path, const skx
         if (f_hi - f_lo + 512 > src_cap) { src_cap = f_hi - f_lo + 512; SKX_TRY(d_src.alloc(src_cap)); }
         tab.resize(g1 - g0);
         for (size_t c = g0; c < g1; c++) tab[c - g0] = SnapChunk{ch[c].off - f_lo, ch[c].uoff, (uint32_t)ch[c].len, ch[c].ulen, ch[c].crc, ch[c].compressed ? 1u : 0u};
-        SKX_HIP(hipMemcpyAsync(d_src.p, file + f_lo, f_hi - f_lo, hipMemcpyHostToDevice, st));
+        // this group's bytes: staged by the pread team (started a group ago; now, for the first), or straight from the mapping; then the next
+        // group as far as the walker has come is planned and its bytes are asked for
+        const uint8_t *src_bytes = nullptr;
+        if (stg.on()) { src_bytes = stg.get(sw, f_lo, f_hi); if (!src_bytes && stg.start(sw, f_lo, f_hi)) src_bytes = stg.get(sw, f_lo, f_hi); }
+        if (stg.on() && !last_group) {
+            size_t n1 = std::min<size_t>(sf.n_chunks(), g1 + gmax);
+            for (size_t c = g1; c < n1; c++) if (ch[c].uoff + ch[c].ulen >= uend) { n1 = c + 1; break; }
+            if (n1 > g1 && stg.start(sw ^ 1, ch[g1].off, ch[n1 - 1].off + ch[n1 - 1].len)) planned_g1 = n1;
+        }
+        SKX_HIP(hipMemcpyAsync(d_src.p, src_bytes ? src_bytes : file + f_lo, f_hi - f_lo, hipMemcpyHostToDevice, st));
         SKX_HIP(hipMemcpyAsync(d_chunks.p, tab.data(), tab.size() * sizeof(SnapChunk), hipMemcpyHostToDevice, st));
         const uint64_t base_cell = (row_lo * S) & ~7ull;
         SKX_TRY(launch_skf_decode_cells(ctx->device, d_src.p, d_chunks.p, (uint32_t)(g1 - g0), upos, uend, d_scratch.p, d_cells[cur].p, base_cell, d_status.p, st));
