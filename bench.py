@@ -9,7 +9,8 @@ the same number of samples (weak scaling); the only collective is one all-gather
 the reduction of the per-row filter statistics (ska.rust_amd/dist.py).
 
 Prints ONE JSON line (rank 0).  `value` is that device-resident rate (inputs in HBM when the clock starts, as the bench
-contract asks).  `roofline` is for the split-k-mer extraction+scatter kernel (HBM bound): algorithmic bytes = 10 B per
+contract asks; the line says so in `value_is`) -- NOT what a user of the executable times: that is `end_to_end.genomes_per_s`,
+~70 x lower (files in and out, not kernels).  `roofline` is for the split-k-mer extraction+scatter kernel (HBM bound): algorithmic bytes = 10 B per
 input base (1 B ASCII read + 9 B (key, middle base) written) over the kernel's launch duration measured with
 HIP events on the engine's stream.
 
@@ -356,7 +357,8 @@ def end_to_end(args, files, td, device=0):
 
 def preflight(args, world):
     """The first contact of a sharded job with a node should not be the timed run: rank 0 runs `ska selftest --gpus N` (one process per GPU,
-    each exchange of the sharded job once over RCCL and once over the host-staged transport; 60 s limit with the stage it stopped in) before
+    each exchange of the sharded job once over RCCL and once over the host-staged transport, then BASELINE config 4's key-table exchange at
+    its size; 60 s + 180 s limits with the stage it stopped in) before
     any rank of the bench opens its device, and the bench stops with that message when it fails."""
     ska = os.path.join(ROOT, "ska.rust_amd", "ska")
     t0 = time.perf_counter()
@@ -369,9 +371,9 @@ def preflight(args, world):
             raise SystemExit(f"bench.py: `ska selftest --gpus {world}` {why}")
         return {"seconds": time.perf_counter() - t0, "failed": why}
     try:
-        r = subprocess.run([ska, "selftest", "--gpus", str(world)], capture_output=True, timeout=180)
+        r = subprocess.run([ska, "selftest", "--gpus", str(world)], capture_output=True, timeout=300)
     except subprocess.TimeoutExpired:
-        return failed("did not finish in 180 s")
+        return failed("did not finish in 300 s")
     except OSError as e:
         return failed(f"could not be started: {e}")
     msg = r.stderr.decode(errors="replace").strip().splitlines()
@@ -710,6 +712,8 @@ def main():
             "value": n_total * steps / dt, "unit": "genomes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64" if args.k <= 31 else "u128", "data": "synthetic",
+            "value_is": "the device-resident step (inputs in HBM when the clock starts, no file in or out: the bench contract's `value`); the metric as a user times it -- "
+                        "FASTA files in, .skf and alignment out, through the ska executable -- is end_to_end.genomes_per_s (N = 1), ~70 x lower: files, not kernels",
             "config": {"workload": f"ska build + ska align, {G} synthetic {args.genome_len} bp assemblies per GPU, k={args.k}, "
                                    f"inputs resident in HBM (BASELINE.json configs[2])",
                        "samples_per_gpu": G, "private_snps": private_snps(n_total), "genome_len": args.genome_len, "k": args.k,

@@ -500,8 +500,38 @@ int skf_read_stream(const char *path, SkfMeta &m, std::vector<skx_key> &keys, st
             // nearly every 64-bit split k-mer is a 9-byte uint (0x1b + 8 bytes): whole runs of those are decoded by the team,
             // anything else one at a time by the generic parser
             uint64_t j = 0;
+            // keys of any width straight from the buffered bytes: a uint of 1 to 9 bytes, or tag 2 + a byte string of up to 16 bytes (what serde
+            // writes for a u128 above 2^64: lib.rs:592-622) -- the forms Reader::key takes, without its per-key calls (128-bit lists went through
+            // those one key at a time: 0.8 s of a 4.1 s `ska merge` of four 5 M-key files, profiles/r06d_reads_1000.log).  Stops at anything
+            // else and 19 bytes before the buffer's end; returns the keys taken.
+            auto inline_keys = [&](uint64_t limit) -> uint64_t {
+                const uint8_t *p = fr.data(); const size_t av = fr.avail(); size_t o = 0; uint64_t got = 0;
+                while (got < limit && o + 19 <= av) {
+                    const uint8_t c = p[o];
+                    uint64_t lo = 0, hi = 0;
+                    if (c == 0x1b) { uint64_t v; memcpy(&v, p + o + 1, 8); lo = __builtin_bswap64(v); o += 9; }
+                    else if (c == 0xC2) {
+                        const uint8_t b = p[o + 1];
+                        if (b < 0x40 || b > 0x50) break;
+                        const size_t len = (size_t)(b - 0x40);
+                        unsigned __int128 x = 0;
+                        for (size_t t = 0; t < len; t++) x = (x << 8) | p[o + 2 + t];
+                        lo = (uint64_t)x; hi = (uint64_t)(x >> 64); o += 2 + len;
+                    }
+                    else if (c < 0x18) { lo = c; o += 1; }
+                    else if (c == 0x18) { lo = p[o + 1]; o += 2; }
+                    else if (c == 0x19) { lo = ((uint64_t)p[o + 1] << 8) | p[o + 2]; o += 3; }
+                    else if (c == 0x1a) { uint32_t v; memcpy(&v, p + o + 1, 4); lo = __builtin_bswap32(v); o += 5; }
+                    else break;
+                    keys[j + got] = skx_key{lo, hi};
+                    got++;
+                }
+                fr.consume(o);
+                return got;
+            };
+            bool wide_list = false;                                                       // a run that was not all 9-byte uints has been seen: no more team passes
             while (j < n && rd.ok) {
-                const uint64_t can = std::min<uint64_t>(n - j, fr.avail() / 9);
+                const uint64_t can = wide_list ? 0 : std::min<uint64_t>(n - j, fr.avail() / 9);
                 if (can >= 4096) {
                     const uint8_t *src = fr.data();
                     const size_t parts = (size_t)std::min<uint64_t>((uint64_t)threads, can / 1024);
@@ -521,11 +551,13 @@ int skf_read_stream(const char *path, SkfMeta &m, std::vector<skx_key> &keys, st
                     });
                     team_s += secs(tq, now());
                     if (!other) { fr.consume(9 * can); j += can; continue; }
-                    for (uint64_t c = 0; c < can && rd.ok; c++) keys[j + c] = rd.key();         // a run with shorter / wider keys in it
-                    j += can;
-                    continue;
+                    wide_list = true;                                                     // a run with shorter / wider keys in it
                 }
-                { const auto tq = now(); keys[j++] = rd.key(); generic_s += secs(tq, now()); generic_n++; }
+                { const auto tq = now();
+                  const uint64_t got = inline_keys(n - j);
+                  j += got;
+                  if (j < n && got == 0) { keys[j++] = rd.key(); generic_n++; }           // near the buffer's end, or a form the inline parser leaves: the generic one (it refills)
+                  generic_s += secs(tq, now()); }
             }
             phase_add("load.dbg_keys_team", team_s); phase_add("load.dbg_keys_generic", generic_s); phase_add("load.dbg_fill", fr.fill_secs);
             if (getenv("SKX_DEBUG")) fprintf(stderr, "[skx] generic keys %llu\n", (unsigned long long)generic_n);
