@@ -1163,6 +1163,32 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
     // the runtime: 64 threads spent 0.28 s each waiting for theirs).  They read() file pieces into the slots of ONE pinned ring;
     // a single uploader issues the copies on one stream and recycles the slots.  The ring is pinned by a helper thread while
     // this one sizes and allocates the device buffers.
+    // The regions' word buffer -- the largest allocation of a build, ~10 bytes per base -- is asked for now, on a thread of its own, and put back
+    // into the allocator's cache, where dictset_build_device finds it: as a box's first GPU process the allocation waits ~1 s for memory the
+    // driver hands out for the first time (build.dictionaries 0.98 s of a 2.46 s `ska build`, profiles/r06f_bench_full.json), and that second
+    // can pass beside the reading of the files.  The size is the one dictset_build_device will compute if the longest sample is as long as
+    // the largest plain file says (headers and line ends make it ~2 % more: the cache hands out a block up to a quarter larger than asked).
+    std::thread warm_thread;
+    struct JoinWarm { std::thread &t; ~JoinWarm() { if (t.joinable()) t.join(); } } join_warm{warm_thread};
+    if (device_parse && !any_pair && n >= 8 && !knob("no_prewarm")) {
+        uint64_t maxlen = 0; bool plain = true;
+        for (int i = 0; i < n && plain; i++) { struct stat sb; if (stat(file1[i], &sb) != 0 || !S_ISREG(sb.st_mode)) plain = false; else maxlen = std::max<uint64_t>(maxlen, (uint64_t)sb.st_size); }
+        for (int i = 0; i < n && plain; i++) { const size_t L = strlen(file1[i]); if (L > 3 && (!strcmp(file1[i] + L - 3, ".gz") || !strcmp(file1[i] + L - 3, ".xz") || !strcmp(file1[i] + L - 4, ".bz2") || !strcmp(file1[i] + L - 4, ".zst"))) plain = false; }
+        if (plain && maxlen > (1u << 20)) {
+            const bool wide_w = k > 31;
+            const uint64_t per_region = wide_w ? 3200 : 4900;
+            const int need = std::max(0, ilog2_ceil((maxlen + per_region - 1) / per_region)), base_logB = wide_w ? 11 : 10;
+            const int logB_w = std::min({need > base_logB ? std::max(base_logB, need - 5) : need, 2 * (k - 1), MAX_LOGB});
+            const uint64_t mean = (maxlen >> logB_w) + 1, cap_w = ((mean + mean / 5 + 256) + 63) / 64 * 64;
+            const uint64_t bytes = (((uint64_t)n << logB_w) * cap_w * (wide_w ? 2 : 1) + 2048) * 8;
+            size_t free_b = 0, total_b = 0;
+            (void)hipSetDevice(ctx->device);
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes < free_b / 2) {
+                const int dev = ctx->device;
+                warm_thread = std::thread([bytes, dev]() { (void)hipSetDevice(dev); hipError_t e = hipSuccess; if (void *p = dev_alloc(bytes, &e)) dev_free(p); });
+            }
+        }
+    }
     constexpr size_t SLOT = 8u << 20;
     // (a thread streaming a FASTQ sample fills a sequence and a quality slot at a time: two per thread and a few in flight)
     const int n_slots = any_pair ? 2 * nt + 8 : std::max(4, std::min(2 * nt, 32));
@@ -1446,6 +1472,7 @@ extern "C" int skx_dictset_build_files(skx_ctx *ctx, const char *const *file1, c
         raw_all.release();
     }
     skx_dictset *d = nullptr;
+    if (warm_thread.joinable()) { PhaseTimer t_w("build.wait_for_word_buffer"); warm_thread.join(); }
     const auto t_dev0 = std::chrono::steady_clock::now();
     int r = skx_dictset_build(ctx, ss.data(), n, 1, k, rc, q, &d);
     phase_add("build.dictionaries", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_dev0).count());
