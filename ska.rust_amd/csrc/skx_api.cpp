@@ -2414,10 +2414,18 @@ int skx::array_host_keys(skx_array *a, std::vector<skx_key> &hk)
     else {
         std::vector<uint64_t> w(2 * K);
         SKX_HIP(hipMemcpy(w.data(), a->keys.p, K * 16, hipMemcpyDeviceToHost));
-        for (uint64_t i = 0; i < K; i++) {
-            const u128 key = hunmix_w((((u128)w[2 * i + 1] << 64) | w[2 * i]) >> 4, a->wh);
-            hk[i].lo = (uint64_t)key; hk[i].hi = (uint64_t)(key >> 64);
-        }
+        // (the hash undone on the host: three rounds of 64-bit multiplies a key -- by a team, 0.16 s of `ska merge`'s save on one thread)
+        const int team = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::min(16, cpu_budget()), K >> 16));
+        std::vector<std::thread> th;
+        auto part = [&](int t) {
+            for (uint64_t i = K * (uint64_t)t / (uint64_t)team, e = K * (uint64_t)(t + 1) / (uint64_t)team; i < e; i++) {
+                const u128 key = hunmix_w((((u128)w[2 * i + 1] << 64) | w[2 * i]) >> 4, a->wh);
+                hk[i].lo = (uint64_t)key; hk[i].hi = (uint64_t)(key >> 64);
+            }
+        };
+        for (int t = 1; t < team; t++) th.emplace_back(part, t);
+        part(0);
+        for (auto &x : th) x.join();
     }
     return SKX_OK;
 }
