@@ -720,6 +720,8 @@ def test_large_assembly_stays_on_the_assembly_kernels(E, k, length, contigs, mon
     for x, y in zip(_sorted_export(ga), want):
         assert np.array_equal(x, y)
     ds.free()
+    if length > 15_000_000:
+        return                 # (the rebuild under the knob once, on the 12 Mbp case)
     set_knob(monkeypatch, "sorted_dicts", "1")
     gs = E.DictSet.build(streams, k, True).merge(["big", "small"])
     assert E.default_context().merge_path().startswith("sorted:")
