@@ -538,6 +538,7 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
     // (128-bit keys: 3 200, so that a region's fixed capacity -- 20 % + 256 above the mean -- stays within the 4 096 words of the wide counting sort
     // and the samples can stay as extracted for the append pass whatever their length)
     uint64_t per_region = wide ? 3200 : 4900;
+    if (knob("per_region") > 0) per_region = (uint64_t)knob("per_region");       // (measurements: 9800 = 2^9 regions for 5 Mbp samples, 2450 = 2^11)
     if (any_qual) return build_reads();
     // Longer samples (round 6): the bucket count stops growing at the 5 Mbp shape (2^10 regions; 2^11 for 128-bit keys) and the regions grow
     // instead -- the extraction kernel's (tile, bucket) chunks stay whole lines (with regions capped at 4 900 words a 20 Mbp sample took 13 ps per
@@ -545,7 +546,7 @@ static int dictset_build_device(skx_ctx *ctx, const std::vector<const uint8_t *>
     // size unsorted (2^(logQ - logB) row blocks per region: up to 32 readers a region), and who asks for sorted dictionaries of such samples
     // gets the flat sorted form (dictset_sort_flat).  Beyond 32 row blocks per region the buckets grow again (to 2^13: ~1.3 Gbp).
     const int need = std::max(0, ilog2_ceil((maxlen + per_region - 1) / per_region));
-    const int base_logB = wide ? 11 : 10;
+    const int base_logB = knob("per_region") > 0 ? std::min(need, MAX_LOGB) : (wide ? 11 : 10);
     const bool grow_regions = !knob("small_regions");
     if ((grow_regions ? need - 5 : need) > MAX_LOGB) return build_reads();
     int logB = std::min({grow_regions && need > base_logB ? std::max(base_logB, need - 5) : need, key_bits_used, MAX_LOGB});
