@@ -180,3 +180,59 @@ def test_ska_build_on_unusual_fastq_takes_the_host_readers_verdict(E, tmp_path):
         r = subprocess.run([SKA, "build", "-f", "list.txt", "-o", "bad", "-k", "31", "--min-count", "2", "--threads", "3"], cwd=wd, capture_output=True, timeout=300,
                            env=dict(os.environ, SKX_KNOBS=knobs))
         assert r.returncode != 0 and b"Invalid FASTA/Q record" in r.stderr, (knobs, r.stderr[-400:])
+
+
+def test_device_framing_fuzz_against_the_host_reader(E, tmp_path):
+    """Seeded mutations of small FASTQ texts -- bytes flipped to '\\n', '\\r', '@', '+' or anything, line ends removed or doubled, pieces cut out or
+    repeated, the text cut short: whatever the device accepts as regular is what the host reader delivers, record for record; whatever the host
+    reader refuses the device calls irregular (the other direction -- texts the host reader accepts by its slower rules -- is the device's
+    right to pass on).  900 texts of 40 to 4 000 bytes, three quality thresholds."""
+    rng = np.random.default_rng(2026)
+    lens = np.array([0, 1, 2, 5, 17, 31, 32, 33, 64, 65, 100, 150])
+    regular = irregular = refused = 0
+    for it in range(900):
+        base = bytearray(_records(rng, int(rng.integers(1, 14)), lens, eol=b"\r\n" if it % 7 == 0 else b"\n",
+                                  header=lambda i: b"@r%d" % i, plus=(lambda i: b"+") if it % 3 else (lambda i: b"+r%d" % i)))
+        for _ in range(int(rng.integers(0, 4))):
+            if not base:
+                break
+            kind = int(rng.integers(0, 7))
+            pos = int(rng.integers(0, len(base)))
+            if kind == 0:
+                base[pos] = int(rng.choice(np.frombuffer(b"\n\r@+ACGTN!I~", np.uint8)))
+            elif kind == 1:
+                base[pos] = int(rng.integers(1, 256))
+            elif kind == 2:
+                nl = [i for i, c in enumerate(base) if c == 10]
+                if nl:
+                    del base[nl[int(rng.integers(0, len(nl)))]]
+            elif kind == 3:
+                base[pos:pos] = b"\n"
+            elif kind == 4:
+                end = min(len(base), pos + int(rng.integers(1, 60)))
+                del base[pos:end]
+            elif kind == 5:
+                end = min(len(base), pos + int(rng.integers(1, 60)))
+                base[pos:pos] = base[pos:end]
+            else:
+                del base[pos:]
+        text = bytes(base)
+        if not text or text[:1] != b"@":                # (the pipeline takes files that begin with '@' only)
+            continue
+        t = text if text.endswith(b"\n") else text + b"\n"
+        mq = (20, 0, 60)[it % 3]
+        irr, ds, dq = _frame(E, t, 0, mq)
+        try:
+            hs, hq = _host(E, tmp_path, text)
+            host_ok = True
+        except E.EngineError:
+            host_ok = False
+        if not irr:
+            assert host_ok, (it, text[:200])
+            assert (ds, dq) == _canon(hs, hq, mq), (it, text[:200])
+            regular += 1
+        elif host_ok:
+            irregular += 1
+        else:
+            refused += 1
+    assert regular > 150 and refused > 100, (regular, irregular, refused)
