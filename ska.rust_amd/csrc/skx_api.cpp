@@ -753,11 +753,13 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
             uint64_t plain = ok ? (uint64_t)sb.st_size : 0;
             if (ok && c0[0] == 0x1f && c0[1] == 0x8b) {
                 // gzip: the reader thread inflates as it goes; the stream's size from the trailer (ISIZE, the last member's length mod 2^32).  A
-                // file whose trailer cannot be its whole text -- several members, 4 GB and more -- is left to the one-shot form, and so is a
-                // batch in which a file turns out longer than its trailer says (SKF_OVER_BOUND below)
+                // batch in which a file turns out longer than that says is left to the one-shot form (SKF_OVER_BOUND below)
                 ok = sb.st_size > 18 && pread(fd, tail, 4, sb.st_size - 4) == 4;
                 plain = (uint64_t)tail[0] | ((uint64_t)tail[1] << 8) | ((uint64_t)tail[2] << 16) | ((uint64_t)tail[3] << 24);
-                ok = ok && plain >= (uint64_t)sb.st_size;
+                // a trailer that cannot be the whole text (shorter than the file itself): several members -- bgzip's 64 KB blocks, files
+                // joined with cat -- or 4 GB and more.  Six times the file's size then stands for the text's length (reads deflate 3-5 x);
+                // a text that turns out longer sends the batch to the one-shot form like any file longer than its bound
+                if (ok && plain < (uint64_t)sb.st_size) plain = 6 * (uint64_t)sb.st_size;
                 any_gz = true;
             } else ok = ok && c0[0] == '@';
             if (fd >= 0) ::close(fd);
