@@ -129,6 +129,13 @@ void top_help(FILE *out)
 
 }  // namespace
 
+// the usage line clap prints under an error of subcommand `cmd` ("ska <cmd> ..."; the top-level one for an unknown name)
+const char *skh_usage_line(const char *cmd)
+{
+    for (auto &c : commands()) if (!strcmp(cmd, c.name)) return c.usage;
+    return "ska [OPTIONS] <COMMAND>";
+}
+
 // 1: the invocation was a help / version request and has been answered (exit code 0); 0: not one; 2: `ska help <unknown>`
 extern "C" int skh_help(int argc, char **argv)
 {

@@ -609,6 +609,25 @@ const char *VALUE_OPTS[] = {"-o", "-k", "-f", "--threads", "--min-count", "--min
                             "--min-freq", "-m", "--filter", "-s", "--skf-file", "--format", "--gpus", nullptr};
 bool takes_value(const std::string &s) { for (int i = 0; VALUE_OPTS[i]; i++) if (s == VALUE_OPTS[i]) return true; return false; }
 int fail(const char *msg) { fprintf(stderr, "error: %s\n", msg); return 2; }
+}
+const char *skh_usage_line(const char *cmd);       // ska_help.cpp
+namespace {
+// clap's wording for what its derive macros refuse (cli.rs: value_parser / value_enum / required): exit code 2, the reason, the hint
+int clap_invalid(const std::string &value, const char *arg, const char *why)
+{
+    fprintf(stderr, "error: invalid value '%s' for '%s': %s\n\nFor more information, try '--help'.\n", value.c_str(), arg, why);
+    return 2;
+}
+int clap_possible(const std::string &value, const char *arg, const char *values)
+{
+    fprintf(stderr, "error: invalid value '%s' for '%s'\n  [possible values: %s]\n\nFor more information, try '--help'.\n", value.c_str(), arg, values);
+    return 2;
+}
+int clap_missing(const char *cmd, const char *args)
+{
+    fprintf(stderr, "error: the following required arguments were not provided:\n  %s\n\nUsage: %s\n\nFor more information, try '--help'.\n", args, skh_usage_line(cmd));
+    return 2;
+}
 int engine_fail() { fprintf(stderr, "error: %s\n", skx_last_error()); return 101; }   // Rust panics exit with 101
 int parse_filter(const std::string &s)
 {
@@ -684,21 +703,22 @@ struct BuildOpts { int k = 31; skx_qual q{5, 20, SKX_QUAL_STRICT}; bool auto_cou
 int parse_build_opts(const Args &a, BuildOpts &o)                                      // cli.rs:27-108 (Build)
 {
     o.k = atoi(a.get("-k", "31").c_str());
-    if (o.k < 5 || o.k > 63 || o.k % 2 == 0) return fail("K-mer must be an odd number between 5 and 63 (inclusive)");   // cli.rs:38-47
+    if (o.k < 5 || o.k > 63 || o.k % 2 == 0) return clap_invalid(a.get("-k", "31"), "-k <K>", "K-mer must be an odd number between 5 and 63 (inclusive)");   // cli.rs:38-47
     if (a.has("--min-count")) {
         const std::string mc = a.get("--min-count");
         if (mc == "auto") o.auto_count = true; else {
         char *end; long v = strtol(mc.c_str(), &end, 10);
-        if (*end || v < 1 || v > 65535) return fail("Minimum kmer count must be >= 1");                           // cli.rs:94-108
+        if (*end || v < 1 || v > 65535) return clap_invalid(mc, "--min-count <MIN_COUNT>", "Minimum kmer count must be >= 1");   // cli.rs:94-108
         o.q.min_count = (uint16_t)v; }
     }
     if (a.has("--min-qual")) o.q.min_qual = (uint8_t)atoi(a.get("--min-qual").c_str());
     if (a.has("--qual-filter")) {
         const std::string f = a.get("--qual-filter");
         o.q.qual_filter = f == "no-filter" ? SKX_QUAL_NOFILTER : f == "middle" ? SKX_QUAL_MIDDLE : f == "strict" ? SKX_QUAL_STRICT : -1;
-        if (o.q.qual_filter < 0) return fail("invalid --qual-filter");
+        if (o.q.qual_filter < 0) return clap_possible(f, "--qual-filter <QUAL_FILTER>", "no-filter, middle, strict");
     }
     o.prop = a.has("--proportion-reads") ? atof(a.get("--proportion-reads").c_str()) : 0.0;
+    if (o.prop < 0.0 || o.prop > 1.0) return clap_invalid(a.get("--proportion-reads"), "--proportion-reads <PROPORTION_READS>", "K-mer must be between 0 and 1 (inclusive)");   // cli.rs:49-58 (the reference's own wording)
     return 0;
 }
 struct Inputs { std::vector<std::string> names, f1, f2; std::vector<const char *> cn, c1, c2; };
@@ -905,6 +925,68 @@ int emit(const std::string &out_path, const char *buf, uint64_t len)            
 }
 }  // namespace
 
+namespace {
+// What clap refuses before lib.rs::main runs (cli.rs: required arguments, the argument groups of build / delete, value_parser and value_enum
+// of every option): the same refusals in clap's wording, before the banner and before a device is touched.  0: the command line stands.
+int validate_cli(const std::string &cmd, const Args &a, bool multi)
+{
+    auto number = [](const std::string &v) { if (v.empty()) return false; char *e; (void)strtod(v.c_str(), &e); return *e == 0; };
+    auto kmer = [&](const char *arg) -> int {
+        if (!a.has("-k")) return 0;
+        const std::string v = a.get("-k");
+        if (!number(v) || v.find_first_not_of("0123456789") != std::string::npos) return clap_invalid(v, arg, ("`" + v + "` isn't a valid k-mer").c_str());
+        const int k = atoi(v.c_str());
+        return (k < 5 || k > 63 || k % 2 == 0) ? clap_invalid(v, arg, "K-mer must be an odd number between 5 and 63 (inclusive)") : 0;
+    };
+    auto freq = [&]() -> int {
+        const std::string v = a.has("--min-freq") ? a.get("--min-freq") : a.has("-m") ? a.get("-m") : "";
+        if (v.empty()) return 0;
+        if (!number(v)) return clap_invalid(v, "--min-freq <MIN_FREQ>", ("`" + v + "` isn't a valid frequency").c_str());
+        const double f = atof(v.c_str());
+        return (f < 0.0 || f > 1.0) ? clap_invalid(v, "--min-freq <MIN_FREQ>", "Frequency must be between 0 and 1 (inclusive)") : 0;
+    };
+    auto filter = [&]() -> int {
+        return a.has("--filter") && parse_filter(a.get("--filter")) < 0 ? clap_possible(a.get("--filter"), "--filter <FILTER>", "no-filter, no-const, no-ambig, no-ambig-or-const") : 0;
+    };
+    if (a.has("--threads")) {
+        const std::string v = a.get("--threads");
+        if (v.find_first_not_of("0123456789") != std::string::npos || v.empty()) return clap_invalid(v, "--threads <THREADS>", ("`" + v + "` isn't a valid number of cores").c_str());
+        if (atoi(v.c_str()) < 1) return clap_invalid(v, "--threads <THREADS>", "Threads must be one or higher");
+    }
+    const bool files_from_build = multi && (cmd == "align" || cmd == "distance");        // (--gpus N: sequence files or -f, and the build options)
+    if (cmd == "build" || files_from_build) {
+        if (cmd == "build" && !a.has("-o")) return clap_missing("build", "-o <OUTPUT>");
+        if (a.pos.empty() && !a.has("-f")) return clap_missing(cmd.c_str(), "<SEQ_FILES|-f <FILE_LIST>>");
+        if (!a.pos.empty() && a.has("-f")) { fprintf(stderr, "error: the argument '[SEQ_FILES]...' cannot be used with '-f <FILE_LIST>'\n\nUsage: %s\n\nFor more information, try '--help'.\n", skh_usage_line("build")); return 2; }
+        BuildOpts bo;
+        if (int e = kmer("-k <K>")) return e;
+        if (int e = parse_build_opts(a, bo)) return e;
+    }
+    if (cmd == "align") { if (!multi && a.pos.empty()) return clap_missing("align", "<INPUT>..."); if (int e = filter()) return e; if (int e = freq()) return e; }
+    else if (cmd == "distance") { if (!multi && a.pos.size() != 1) return a.pos.empty() ? clap_missing("distance", "<SKF_FILE>") : fail("one .skf file required"); if (int e = freq()) return e; }
+    else if (cmd == "nk") { if (a.pos.empty()) return clap_missing("nk", "<SKF_FILE>"); }
+    else if (cmd == "cov") { if (a.pos.size() < 2) return clap_missing("cov", a.pos.empty() ? "<FASTQ_FWD>\n  <FASTQ_REV>" : "<FASTQ_REV>"); if (int e = kmer("-k <K>")) return e; }
+    else if (cmd == "map") {
+        if (a.pos.empty()) return clap_missing("map", "<REFERENCE>");
+        const std::string fmt = a.get("--format", a.has("-f") ? a.get("-f") : "aln");
+        if (fmt != "aln" && fmt != "vcf") return clap_possible(fmt, "--format <FORMAT>", "vcf, aln");
+    }
+    else if (cmd == "merge") { if (!a.has("-o")) return clap_missing("merge", "-o <OUTPUT>"); }
+    else if (cmd == "delete") {
+        if (!a.has("-s") && !a.has("--skf-file")) return clap_missing("delete", "--skf-file <SKF_FILE>");
+        if (a.pos.empty() && !a.has("-f")) return clap_missing("delete", "<-f <FILE_LIST>|NAMES>");
+        if (!a.pos.empty() && a.has("-f")) { fprintf(stderr, "error: the argument '[NAMES]...' cannot be used with '-f <FILE_LIST>'\n\nUsage: %s\n\nFor more information, try '--help'.\n", skh_usage_line("delete")); return 2; }
+    }
+    else if (cmd == "weed") { if (a.pos.empty()) return clap_missing("weed", "<SKF_FILE>"); if (int e = filter()) return e; if (int e = freq()) return e; }
+    else if (cmd == "lo") return fail("`ska lo` is not part of this engine (build, align, map, distance, nk, merge, delete, weed, cov are)");
+    else if (cmd != "build" && cmd != "selftest") {
+        fprintf(stderr, "error: unrecognized subcommand '%s'\n\nUsage: ska [OPTIONS] <COMMAND>\n\nFor more information, try '--help'.\n", cmd.c_str());
+        return 2;
+    }
+    return 0;
+}
+}  // namespace
+
 extern "C" int skh_main(int argc, char **argv)
 {
     const int env_world = getenv("SKX_WORLD") ? atoi(getenv("SKX_WORLD")) : 0, env_rank = getenv("SKX_RANK") ? atoi(getenv("SKX_RANK")) : 0;
@@ -914,7 +996,6 @@ extern "C" int skh_main(int argc, char **argv)
         fprintf(stderr, "Split k-mer analysis\n\nUsage: ska [OPTIONS] <COMMAND>\n\nFor more information, try '--help'.\n");
         return 2;
     }
-    if (env_rank == 0) fprintf(stderr, "SKA: Split K-mer Analysis (the alignment-free aligner)\n");
     const std::string cmd = argv[1];
     Args a;
     for (int i = 2; i < argc; i++) {
@@ -946,6 +1027,8 @@ extern "C" int skh_main(int argc, char **argv)
                         return 2;
                     }
     }
+    if (const int bad = validate_cli(cmd, a, multi)) return bad;
+    if (env_rank == 0) fprintf(stderr, "SKA: Split K-mer Analysis (the alignment-free aligner)\n");      // lib.rs:565: after the arguments stand
     int threads = atoi(a.get("--threads", "1").c_str());
     if (threads < 1) return fail("Threads must be one or higher");
     const auto t_main = std::chrono::steady_clock::now();

@@ -63,3 +63,39 @@ def test_subcommand_help_lists_the_reference_flags(cmd):
         assert f in out, (cmd, f)
     r = _run(cmd, "--version")                          # propagate_version
     assert (r.returncode, r.stdout) == (0, f"ska-{cmd} 0.5.2\n")
+
+
+@pytest.mark.skipif(not os.path.exists(SKA), reason="ska executable not built")
+def test_refusals_in_claps_wording_before_any_device():
+    """What clap refuses for the reference (cli.rs: required arguments, the argument groups of build / delete, value_parser and value_enum
+    of the options) is refused here in the same words, with exit code 2, without the banner and before a device is opened -- so on the CPU."""
+    miss = "error: the following required arguments were not provided:\n  {}\n\nUsage: {}\n\nFor more information, try '--help'.\n"
+    cases = [
+        (["build", "a.fa"], miss.format("-o <OUTPUT>", "ska build [OPTIONS] -o <OUTPUT> <SEQ_FILES|-f <FILE_LIST>>")),
+        (["build", "-o", "x"], miss.format("<SEQ_FILES|-f <FILE_LIST>>", "ska build [OPTIONS] -o <OUTPUT> <SEQ_FILES|-f <FILE_LIST>>")),
+        (["align"], miss.format("<INPUT>...", "ska align [OPTIONS] <INPUT>...")),
+        (["distance"], miss.format("<SKF_FILE>", "ska distance [OPTIONS] <SKF_FILE>")),
+        (["nk"], miss.format("<SKF_FILE>", "ska nk [OPTIONS] <SKF_FILE>")),
+        (["merge", "a.skf", "b.skf"], miss.format("-o <OUTPUT>", "ska merge -o <OUTPUT> [SKF_FILES]...")),
+        (["delete", "name"], miss.format("--skf-file <SKF_FILE>", "ska delete [OPTIONS] --skf-file <SKF_FILE> <-f <FILE_LIST>|NAMES>")),
+        (["weed"], miss.format("<SKF_FILE>", "ska weed [OPTIONS] <SKF_FILE> [WEED_FILE]")),
+        (["map"], miss.format("<REFERENCE>", "ska map [OPTIONS] <REFERENCE> [INPUT]...")),
+        (["cov", "a.fq"], miss.format("<FASTQ_REV>", "ska cov [OPTIONS] <FASTQ_FWD> <FASTQ_REV>")),
+        (["build", "-o", "x", "-k", "4", "a.fa"], "error: invalid value '4' for '-k <K>': K-mer must be an odd number between 5 and 63 (inclusive)\n\nFor more information, try '--help'.\n"),
+        (["build", "-o", "x", "-k", "65", "a.fa"], "error: invalid value '65' for '-k <K>': K-mer must be an odd number between 5 and 63 (inclusive)\n\nFor more information, try '--help'.\n"),
+        (["build", "-o", "x", "-k", "abc", "a.fa"], "error: invalid value 'abc' for '-k <K>': `abc` isn't a valid k-mer\n\nFor more information, try '--help'.\n"),
+        (["build", "-o", "x", "--min-count", "0", "a.fa"], "error: invalid value '0' for '--min-count <MIN_COUNT>': Minimum kmer count must be >= 1\n\nFor more information, try '--help'.\n"),
+        (["build", "-o", "x", "--qual-filter", "soft", "a.fa"], "error: invalid value 'soft' for '--qual-filter <QUAL_FILTER>'\n  [possible values: no-filter, middle, strict]\n\nFor more information, try '--help'.\n"),
+        (["align", "x.skf", "--filter", "none"], "error: invalid value 'none' for '--filter <FILTER>'\n  [possible values: no-filter, no-const, no-ambig, no-ambig-or-const]\n\nFor more information, try '--help'.\n"),
+        (["align", "x.skf", "-m", "1.5"], "error: invalid value '1.5' for '--min-freq <MIN_FREQ>': Frequency must be between 0 and 1 (inclusive)\n\nFor more information, try '--help'.\n"),
+        (["weed", "x.skf", "--min-freq", "-0.1"], "error: invalid value '-0.1' for '--min-freq <MIN_FREQ>': Frequency must be between 0 and 1 (inclusive)\n\nFor more information, try '--help'.\n"),
+        (["map", "ref.fa", "x.skf", "-f", "txt"], "error: invalid value 'txt' for '--format <FORMAT>'\n  [possible values: vcf, aln]\n\nFor more information, try '--help'.\n"),
+        (["align", "x.skf", "--threads", "0"], "error: invalid value '0' for '--threads <THREADS>': Threads must be one or higher\n\nFor more information, try '--help'.\n"),
+        (["frobnicate"], "error: unrecognized subcommand 'frobnicate'\n\nUsage: ska [OPTIONS] <COMMAND>\n\nFor more information, try '--help'.\n"),
+        (["build", "-o", "x", "-f", "list.tsv", "a.fa"], "error: the argument '[SEQ_FILES]...' cannot be used with '-f <FILE_LIST>'\n\nUsage: ska build [OPTIONS] -o <OUTPUT> <SEQ_FILES|-f <FILE_LIST>>\n\nFor more information, try '--help'.\n"),
+    ]
+    for args, want in cases:
+        r = _run(*args)
+        assert (r.returncode, r.stdout, r.stderr) == (2, "", want), (args, r.stderr)
+    r = _run("align", "x.skf", "--bogus")
+    assert r.returncode == 2 and r.stderr.startswith("error: unexpected argument '--bogus' found\n") and "SKA:" not in r.stderr
