@@ -1151,6 +1151,8 @@ extern "C" int skh_main(int argc, char **argv)
     skx_ctx_destroy(ctx);
     skx_phase_add("main.release_device", since() - t_done);
     skx_phase_add("main.total", since());
+    // lib.rs:888-890: what the reference says on stderr when a command has run through
+    if (rank == 0 && rcode == 0 && cmd != "selftest") fprintf(stderr, "SKA done in %llus\n\xE2\xAC\x9B\xE2\xAC\x9C\xE2\xAC\x9B\xE2\xAC\x9C\xE2\xAC\x9B\xE2\xAC\x9C\xE2\xAC\x9B\n\xE2\xAC\x9C\xE2\xAC\x9B\xE2\xAC\x9C\xE2\xAC\x9B\xE2\xAC\x9C\xE2\xAC\x9B\xE2\xAC\x9C\n", (unsigned long long)since());
     if (const char *pp = rank == 0 ? getenv("SKX_PHASES") : nullptr) {                  // phase table of this invocation as JSON (bench.py's end_to_end leg)
         char *js = nullptr; uint64_t jl = 0;
         if (skx_phases_json(&js, &jl, 0) == SKX_OK) { if (FILE *f = fopen(pp, "w")) { fwrite(js, 1, jl, f); fputc('\n', f); fclose(f); } skx_free(js); }
