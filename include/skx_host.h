@@ -84,6 +84,9 @@ int skh_main(int argc, char **argv);
 /* `ska --help | -h | help [cmd] | <cmd> --help | --version | -V` (cli.rs:154 `#[command(author, version, about)]`, propagate_version; per-flag
  * help cli.rs:168-459): 1 = answered on stdout (exit code 0), 0 = not a help / version request, 2 = `ska help <unknown>`.  skh_main calls it first. */
 int skh_help(int argc, char **argv);
+/* a line of the reference's logger (simple_logger: lib.rs:559-563, Warn by default, Info with -v) on stderr: level 1 = WARN, 2 = INFO;
+ * target = the Rust module the reference logs it from ("ska::io_utils" ...) */
+void skh_log(int level, const char *target, const char *message);
 
 #ifdef __cplusplus
 }

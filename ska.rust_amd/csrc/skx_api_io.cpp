@@ -1,6 +1,7 @@
 // skx_api_io.cpp -- the C ABI entry points that move text and files: `ska cov` histogram, `ska map`, .skf save / load.
 // (skx_api.cpp holds the build -> merge -> filter -> distance path.)
 #include "skx_internal.h"
+#include "../../include/skx_host.h"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -67,6 +68,7 @@ extern "C" int skx_array_map(skx_array *a, const char *reference, int ambig_mask
     std::vector<uint64_t> cstart, clen, coff;
     { uint64_t b0 = 0, off = 0; for (uint64_t i = 0; i < L; i++) if (hs.seq[i] == '\n') { cstart.push_back(b0); clen.push_back(i - b0); coff.push_back(off); off += i - b0; b0 = i + 1; } }
     const size_t n_chrom = cstart.size();
+    if (n_chrom > 1 && !format) skh_log(1, "ska::ska_ref", "Reference contained multiple contigs, in the output they will be concatenated");      // ska_ref.rs:641-645 write_aln
     uint64_t total = 0; for (auto l : clen) total += l;
     DevBuf<uint8_t> d_seq; SKX_TRY(d_seq.alloc(L + 16));
     SKX_HIP(hipMemcpyAsync(d_seq.p, hs.seq.data(), L, hipMemcpyHostToDevice, st));

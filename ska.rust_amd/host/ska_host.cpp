@@ -13,6 +13,7 @@
 #include <sstream>
 #include <atomic>
 #include <thread>
+#include <ctime>
 #include <string>
 #include <fcntl.h>
 #include <signal.h>
@@ -611,6 +612,16 @@ bool takes_value(const std::string &s) { for (int i = 0; VALUE_OPTS[i]; i++) if 
 int fail(const char *msg) { fprintf(stderr, "error: %s\n", msg); return 2; }
 }
 const char *skh_usage_line(const char *cmd);       // ska_help.cpp
+// simple_logger's line (lib.rs:559-563: Info with -v, Warn without): "<UTC time> <LEVEL> [<target>] <message>" on stderr
+static bool g_verbose = false;
+extern "C" void skh_log(int level, const char *target, const char *message)         // level: 1 = WARN, 2 = INFO
+{
+    if (level > (g_verbose ? 2 : 1)) return;
+    struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts);
+    struct tm tmv; gmtime_r(&ts.tv_sec, &tmv);
+    char tb[40]; strftime(tb, sizeof tb, "%Y-%m-%dT%H:%M:%S", &tmv);
+    fprintf(stderr, "%s.%03ldZ %-5s [%s] %s\n", tb, ts.tv_nsec / 1000000, level == 1 ? "WARN" : "INFO", target, message);
+}
 namespace {
 // clap's wording for what its derive macros refuse (cli.rs: value_parser / value_enum / required): exit code 2, the reason, the hint
 int clap_invalid(const std::string &value, const char *arg, const char *why)
@@ -1028,7 +1039,24 @@ extern "C" int skh_main(int argc, char **argv)
                     }
     }
     if (const int bad = validate_cli(cmd, a, multi)) return bad;
+    g_verbose = a.has("-v") || a.has("--verbose");
     if (env_rank == 0) fprintf(stderr, "SKA: Split K-mer Analysis (the alignment-free aligner)\n");      // lib.rs:565: after the arguments stand
+    if (env_rank == 0) {
+        char msg[256];
+        // cli.rs:86-91 check_threads (build, align, map, distance: lib.rs:580,634,672,714)
+        const int asked = atoi(a.get("--threads", "1").c_str()), cores = (int)std::thread::hardware_concurrency();
+        if ((cmd == "build" || cmd == "align" || cmd == "map" || cmd == "distance") && cores > 0 && asked > cores) {
+            snprintf(msg, sizeof msg, "%d threads is greater than available cores %d", asked, cores); skh_log(1, "ska::cli", msg);
+        }
+        // io_utils.rs:66-73 load_array: one input = a .skf, where --threads has nothing to do
+        if (!multi && ((cmd == "align" && a.pos.size() == 1) || (cmd == "map" && a.pos.size() == 2)) && asked > 1) skh_log(1, "ska::io_utils", "--threads only used if building skf, setting to 1");
+        // merge_ska_array.rs:298-300 filter
+        if ((cmd == "align" || cmd == "weed") && a.has("--no-gap-only-sites")) {
+            const std::string f = a.get("--filter", cmd == "align" ? "no-const" : "no-filter");
+            if (f == "no-ambig" || f == "no-filter") skh_log(1, "ska::merge_ska_array", "--no-gap-only-sites can only be applied when filtering constant bases");
+        }
+        if (cmd == "build") { const int k = atoi(a.get("-k", "31").c_str()); snprintf(msg, sizeof msg, "k=%d: using %d-bit representation", k, k <= 31 ? 64 : 128); skh_log(2, "ska", msg); }   // lib.rs:592,607
+    }
     int threads = atoi(a.get("--threads", "1").c_str());
     if (threads < 1) return fail("Threads must be one or higher");
     const auto t_main = std::chrono::steady_clock::now();

@@ -71,7 +71,7 @@ skx_array_merge skx_array_delete_samples skx_array_weed skx_keyset_from_fasta sk
 skx_comm_unique_id skx_comm_create skx_comm_create_local skx_comm_destroy skx_comm_rank skx_comm_world skx_comm_bytes_received skx_comm_transport skx_comm_barrier
 skx_comm_allgather skx_comm_allreduce_u32 skx_comm_gather_root skx_shard_range skx_pair_bands skx_keyset_allgather skx_array_reduce_stats skx_array_distance_sharded
 skh_build_sharded skh_align_sharded skh_distance_sharded
-skh_apply_filters skh_align skh_align_fd skh_distance_tsv skh_nk skh_save_skf skh_load_array skh_sample_name skh_main skh_merge skh_delete skh_weed skh_cov skh_cov_fit skh_align_inputs_fd skh_distance_skf_tsv skh_help""".split()
+skh_apply_filters skh_align skh_align_fd skh_distance_tsv skh_nk skh_save_skf skh_load_array skh_sample_name skh_main skh_merge skh_delete skh_weed skh_cov skh_cov_fit skh_align_inputs_fd skh_distance_skf_tsv skh_help skh_log""".split()
 
 _lib = None
 

@@ -99,3 +99,24 @@ def test_refusals_in_claps_wording_before_any_device():
         assert (r.returncode, r.stdout, r.stderr) == (2, "", want), (args, r.stderr)
     r = _run("align", "x.skf", "--bogus")
     assert r.returncode == 2 and r.stderr.startswith("error: unexpected argument '--bogus' found\n") and "SKA:" not in r.stderr
+
+
+@pytest.mark.skipif(not os.path.exists(SKA), reason="ska executable not built")
+def test_the_references_warnings_in_simple_loggers_form():
+    """Warnings the reference logs whatever -v says (simple_logger at Warn: lib.rs:559-563): cli.rs:86-91 (more threads than cores),
+    io_utils.rs:66-73 (--threads with a single .skf), merge_ska_array.rs:298-300 (--no-gap-only-sites without a constant-site filter); -v adds
+    the Info lines.  They come behind the banner and before the device is opened, so they can be read here (the command itself then fails on
+    a box without a GPU)."""
+    import re
+    stamp = r"\d{4}-\d\d-\d\dT\d\d:\d\d:\d\d\.\d{3}Z "
+    r = _run("align", "x.skf", "--threads", "4", "--no-gap-only-sites", "--filter", "no-ambig")
+    lines = r.stderr.splitlines()
+    assert lines[0] == "SKA: Split K-mer Analysis (the alignment-free aligner)"
+    assert re.fullmatch(stamp + r"WARN  \[ska::io_utils\] --threads only used if building skf, setting to 1", lines[1]), lines[:4]
+    assert re.fullmatch(stamp + r"WARN  \[ska::merge_ska_array\] --no-gap-only-sites can only be applied when filtering constant bases", lines[2]), lines[:4]
+    r = _run("build", "-o", "x", "-k", "41", "-v", "--threads", "100000", "a.fa")
+    lines = r.stderr.splitlines()
+    assert re.fullmatch(stamp + r"WARN  \[ska::cli\] 100000 threads is greater than available cores \d+", lines[1]), lines[:4]
+    assert re.fullmatch(stamp + r"INFO  \[ska\] k=41: using 128-bit representation", lines[2]), lines[:4]
+    r = _run("build", "-o", "x", "a.fa")                               # without -v: no Info line
+    assert not any(" INFO " in l for l in r.stderr.splitlines())
