@@ -198,6 +198,7 @@ static int distance_table(skx_array *a, double constant, int filt_ambig, char **
 extern "C" int skh_distance_skf_tsv(skx_ctx *ctx, const char *skf_file, double min_freq, int filt_ambig, char **buf, uint64_t *len)
 {
     return skx_guarded([&]() -> int {
+    skh_log(2, "ska::generic_modes", "Calculating distances");                                            // generic_modes.rs:170
     skx_filter_spec fs{min_freq, 0, SKX_FILTER_NO_CONST, 0, 0, 1};
     skx_array *a = nullptr; int64_t removed = 0, constant = 0;
     int r = skx_array_load_filtered(ctx, skf_file, &fs, &a, &removed, &constant);
@@ -217,11 +218,26 @@ extern "C" int skh_align_inputs_fd(skx_ctx *ctx, const char *const *inputs, int 
         skx_filter_spec fs{min_freq, filter_ambig_as_missing, filter_type, mask_ambig, ignore_const_gaps, 0};
         int64_t removed = 0;
         skx_ctx_expect_output(ctx, fd);                               // the file's pages are allocated while the rows are read
+        skh_log(2, "ska::io_utils", "Single file as input, trying to load as skf 64-bits");                  // io_utils.rs:66-69
         { Phase pl("align.load_filtered"); if ((r = skx_array_load_filtered(ctx, inputs[0], &fs, &a, &removed, nullptr)) != SKX_OK) return r; }
+        {   // generic_modes.rs:121-122, merge_ska_array.rs:385 (here the rows are filtered as they leave the decoder: the lines follow the work)
+            skx_array_info_t info; skx_array_info(a, &info);
+            static const char *const FN[] = {"No filtering", "No constant sites", "No ambiguous sites", "No constant sites or ambiguous bases"};
+            char msg[320];
+            snprintf(msg, sizeof msg, "Applying filters: threshold=%llu constant_site_filter=%s filter_ambig_as_missing=%s ambig_mask=%s no_gap_only_sites=%s",
+                     (unsigned long long)std::ceil((double)info.n_samples * min_freq), FN[filter_type & 3], filter_ambig_as_missing ? "true" : "false", mask_ambig ? "true" : "false",
+                     ignore_const_gaps ? "true" : "false");
+            skh_log(2, "ska::generic_modes", msg);
+            snprintf(msg, sizeof msg, "Filtering removed %lld split k-mers", (long long)removed);
+            skh_log(2, "ska::merge_ska_array", msg);
+        }
+        skh_log(2, "ska::generic_modes", "Writing alignment");                                              // generic_modes.rs:45
         Phase pw("align.write_fasta");
         r = skx_array_write_fasta(a, fd);
     } else {
+        skh_log(2, "ska::io_utils", "Multiple files as input, running ska build with default settings");      // io_utils.rs:76
         if ((r = skh_load_array(ctx, inputs, n_inputs, threads, &a)) != SKX_OK) return r;
+        skh_log(2, "ska::generic_modes", "Writing alignment");
         r = skh_align_fd(a, filter_type, mask_ambig, ignore_const_gaps, min_freq, filter_ambig_as_missing, fd);
     }
     { Phase pf("align.free_array"); skx_array_free(a); }
@@ -1179,8 +1195,9 @@ extern "C" int skh_main(int argc, char **argv)
     skx_ctx_destroy(ctx);
     skx_phase_add("main.release_device", since() - t_done);
     skx_phase_add("main.total", since());
-    // lib.rs:888-890: what the reference says on stderr when a command has run through
+    // lib.rs:888-891: what the reference says on stderr when a command has run through
     if (rank == 0 && rcode == 0 && cmd != "selftest") fprintf(stderr, "SKA done in %llus\n\xE2\xAC\x9B\xE2\xAC\x9C\xE2\xAC\x9B\xE2\xAC\x9C\xE2\xAC\x9B\xE2\xAC\x9C\xE2\xAC\x9B\n\xE2\xAC\x9C\xE2\xAC\x9B\xE2\xAC\x9C\xE2\xAC\x9B\xE2\xAC\x9C\xE2\xAC\x9B\xE2\xAC\x9C\n", (unsigned long long)since());
+    if (rank == 0 && rcode == 0 && cmd != "selftest") skh_log(2, "ska", "Complete");
     if (const char *pp = rank == 0 ? getenv("SKX_PHASES") : nullptr) {                  // phase table of this invocation as JSON (bench.py's end_to_end leg)
         char *js = nullptr; uint64_t jl = 0;
         if (skx_phases_json(&js, &jl, 0) == SKX_OK) { if (FILE *f = fopen(pp, "w")) { fwrite(js, 1, jl, f); fputc('\n', f); fclose(f); } skx_free(js); }
