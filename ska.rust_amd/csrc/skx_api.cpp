@@ -740,7 +740,9 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     if (knob("no_reads_pipeline") || n < 2) return SKF_NOT_TAKEN;
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<uint64_t> bound(n, 0), text_bytes(n, 0);
-    uint64_t slot_bytes = 0, raw_cap = 0;
+    struct GzSizes { uint64_t comp[2] = {0, 0}, hint[2] = {0, 0}; int files = 0, gz_files = 0; };
+    std::vector<GzSizes> gzs(n);                                                // (a sample whose files are all gzip may be inflated on the device)
+    uint64_t slot_bytes = 0, raw_cap = 0, comp_cap = 0;
     bool any_gz = false;
     constexpr int SKF_OVER_BOUND = PlanePacker::OVER_BOUND;
     for (int i = 0; i < n; i++) {
@@ -761,11 +763,15 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
                 // a text that turns out longer sends the batch to the one-shot form like any file longer than its bound
                 if (ok && plain < (uint64_t)sb.st_size) plain = 6 * (uint64_t)sb.st_size;
                 any_gz = true;
+                gzs[i].gz_files++;
             } else ok = ok && c0[0] == '@';
             if (fd >= 0) ::close(fd);
             if (!ok) return SKF_NOT_TAKEN;
+            if (gzs[i].files < 2) { gzs[i].comp[gzs[i].files] = (uint64_t)sb.st_size; gzs[i].hint[gzs[i].files] = plain; }
+            gzs[i].files++;
             bytes += plain;
         }
+        if (gzs[i].gz_files == gzs[i].files) comp_cap = std::max<uint64_t>(comp_cap, ((gzs[i].comp[0] + 64 + 255) & ~255ull) + (gzs[i].files > 1 ? ((gzs[i].comp[1] + 64 + 255) & ~255ull) : 0ull));
         bound[i] = (bytes / 2 + 64 + 255) & ~255ull;                             // plain FASTQ holds at most half its bytes in either stream
         text_bytes[i] = bytes;
         slot_bytes = std::max(slot_bytes, bound[i]);
@@ -787,8 +793,21 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     // isolates/s); a reader takes RAW while the pinned ring has room -- the link is keeping up -- and PACKED when it is filling up, so
     // both are busy.  SKX_KNOBS=reads_raw=1: never raw; =2: always.  The window pass and the rebuild of the passing windows' words read the planes
     // as they are, whoever made them.
+    //   * GZDEV (gzip files) -- the COMPRESSED bytes as read() delivers them, half to a fifth of the text: the reader thread does nothing else, and
+    //     the device inflates (skx_gzdev.hip: block finder, symbolic decode per 64 KB chunk, window maps, text, member lengths and CRCs), frames and
+    //     packs.  A file the device does not vouch for (damaged, unusual header, a stretch that deflates beyond the symbol area) goes through the
+    //     reader threads' inflater on this thread, which accepts it or words the error.  SKX_KNOBS=reads_gz=1: inflate on the reader threads.
     const long raw_knob = knob("reads_raw");
     const bool raw_possible = raw_knob != 1 && raw_cap + 2 < 0xFFFFFF00ull;
+    //     Both inflaters work at once: a few reader threads (gz_feed of them) only feed the device -- a 50x isolate is 0.1-0.3 s of read() for them
+    //     and ~50 ms of the device's inflater -- and the others inflate and hand over text or planes as before (~1.1 s of a thread an isolate);
+    //     all take their samples from the same counter, so the split follows the two rates.  reads_gz=2: the device only.
+    const long gz_knob = knob("reads_gz");
+    const bool gz_device = any_gz && raw_possible && comp_cap > 0 && gz_knob != 1;
+    const int gz_tail = (int)(knob("reads_gz_tail") > 0 ? knob("reads_gz_tail") : 20);
+    const int gz_feed = !gz_device ? 0 : gz_knob == 2 ? 1 << 30 : (int)std::max<long>(1, knob("reads_gz_feed") > 0 ? knob("reads_gz_feed") : 3);
+    int n_gz_samples = 0;
+    for (int i = 0; i < n; i++) if (gz_device && gzs[i].gz_files == gzs[i].files) n_gz_samples++;
     const uint64_t pslot_bytes = ((slot_bytes / 64 + 2) * READ_GROUP_BYTES + 255) & ~255ull;
     const uint64_t rslot_bytes = raw_possible ? ((raw_cap + 2 + 64 + 255) & ~255ull) : 0;
     // Two pools of device slots: packed samples (157 MB each at 50x of 5 Mbp; a reader each and a few waiting for their kernels) and raw ones
@@ -801,29 +820,41 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     // samples a second at most and the link idled at 12 GB/s: profiles/r06d_reads_1000.log).  They are allocated one by one by a helper thread
     // while the pipeline already runs on the packed pool: 11 GB taken at once right after another process released its memory cost 1.4-1.9 s.
     const int R = raw_possible ? (int)std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(2, std::min<uint64_t>(any_gz || raw_knob == 2 ? (uint64_t)nt + 2 : (uint64_t)std::max(1, nt / 8) + 3, (free_b / 8) / (rslot_bytes + 1)))) : 0;
+    // slots for compressed samples: one per reader and a few waiting for the inflater (0.27 GB each at 50x of 5 Mbp); the text the device makes of
+    // a sample lives in ONE buffer (the kernels take a sample at a time)
+    const uint64_t gslot_bytes = gz_device ? comp_cap : 0;
+    const int G = gz_device ? (int)std::min<uint64_t>((uint64_t)n_gz_samples, std::max<uint64_t>(2, std::min<uint64_t>((uint64_t)std::min(gz_feed, nt) + 3, (free_b / 8) / (gslot_bytes + 1)))) : 0;
     if (raw_knob == 2) P = 1;
-    DevBuf<uint8_t> packed_pool, raw_planes;
-    std::vector<DevBuf<uint8_t>> raw_slots((size_t)R);
+    DevBuf<uint8_t> packed_pool, raw_planes, gz_text;
+    std::vector<DevBuf<uint8_t>> raw_slots((size_t)R), gz_slots((size_t)G);
     SKX_TRY(packed_pool.alloc((uint64_t)P * pslot_bytes));
     if (R) { SKX_TRY(raw_planes.alloc(pslot_bytes)); SKX_TRY(raw_slots[0].alloc(rslot_bytes)); }
+    if (G) { SKX_TRY(gz_text.alloc(rslot_bytes)); SKX_TRY(gz_slots[0].alloc(gslot_bytes)); }
     constexpr size_t SLOT = ((8u << 20) / READ_GROUP_BYTES) * READ_GROUP_BYTES;          // whole groups
     constexpr size_t RAW_CHUNK = (SLOT - 1) / 256 * 256;                                 // raw text leaves in pieces that keep their destinations aligned
     const int min_qual_host = q ? (int)q->min_qual : 20;
     const int n_slots = 2 * nt + 8;
-    struct Sample { int slot = -1; int pending = 0; bool read_done = false, queued = false, raw = false; uint64_t len = 0, junction = 0; };
+    struct Sample { int slot = -1; int pending = 0; bool read_done = false, queued = false, raw = false, gzdev = false; uint64_t len = 0, junction = 0, coff[2] = {0, 0}; };
     struct Ring {
         uint8_t *base = nullptr; std::mutex mu; std::condition_variable cv_free, cv_work, cv_stream, cv_ready;
-        std::vector<int> free_slots, free_stream, free_raw; struct Req { int slot; uint8_t *dst; size_t bytes; int sample; }; std::deque<Req> work;
-        std::deque<int> ready; int readers_left = 0, up_pending = 0, raw_active = 0; bool failed = false, abort = false, prefer_packed = false;
+        std::vector<int> free_slots, free_stream, free_raw, free_gz; struct Req { int slot; uint8_t *dst; size_t bytes; int sample; }; std::deque<Req> work;
+        std::deque<int> ready; int readers_left = 0, up_pending = 0, raw_active = 0, gz_active = 0; bool failed = false, abort = false, prefer_packed = false;
         ~Ring() { if (base) (void)hipHostFree(base); }
     } ring;
     if (hipHostMalloc((void **)&ring.base, (size_t)n_slots * SLOT, hipHostMallocDefault) != hipSuccess) { ring.base = nullptr; return SKF_NOT_TAKEN; }
     for (int b = 0; b < n_slots; b++) ring.free_slots.push_back(b);
     for (int p = 0; p < P; p++) ring.free_stream.push_back(p);
     if (R) ring.free_raw.push_back(0);
+    if (G) ring.free_gz.push_back(0);
     ring.readers_left = nt;
     std::thread raw_alloc([&]() {
         (void)hipSetDevice(ctx->device);
+        for (int p = 1; p < G; p++) {
+            { std::lock_guard<std::mutex> lk(ring.mu); if (ring.abort || ring.readers_left == 0) break; }
+            if (gz_slots[(size_t)p].alloc(gslot_bytes) != SKX_OK) break;
+            { std::lock_guard<std::mutex> lk(ring.mu); ring.free_gz.push_back(p); }
+            ring.cv_stream.notify_all();
+        }
         for (int p = 1; p < R; p++) {
             { std::lock_guard<std::mutex> lk(ring.mu); if (ring.abort || ring.readers_left == 0) break; }
             if (raw_slots[(size_t)p].alloc(rslot_bytes) != SKX_OK) break;               // (no room: the pipeline goes on with what there is)
@@ -865,17 +896,22 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
         }
         if (up) (void)hipStreamDestroy(up);
     });
-    std::atomic<long long> us_wait_stream{0}, us_wait_ring{0}, us_files{0}, n_raw{0}, bytes_up{0};      // summed over the reader threads
+    std::atomic<long long> us_wait_stream{0}, us_wait_ring{0}, us_files{0}, n_raw{0}, n_gzdev{0}, bytes_up{0};      // summed over the reader threads
     auto us_since = [](std::chrono::steady_clock::time_point t) { return (long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count(); };
     std::vector<std::thread> pool;
     std::atomic<int> next{0};
     for (int t = 0; t < nt; t++)
-        pool.emplace_back([&]() {
+        pool.emplace_back([&, t]() {
+            const bool feeder = t < gz_feed;                              // (this thread hands gzip samples to the device's inflater)
             struct Leave { Ring &r; ~Leave() { { std::lock_guard<std::mutex> lk(r.mu); r.readers_left--; } r.cv_work.notify_all(); r.cv_ready.notify_all(); } } leave{ring};
             PlanePacker pk;
             pk.min_qual = min_qual_host; pk.gz = any_gz;
-            for (int i; (i = next.fetch_add(1)) < n;) {
-                int sslot = -1; bool raw = false;
+            for (int i;;) {
+                // the batch's last samples are left to the feeders: a thread that starts inflating one now (~1.1 s) would finish after the device has
+                // been through all of them (~50 ms each)
+                if (!feeder && gz_feed > 0 && n_gz_samples == n && n - next.load() < gz_tail) { std::lock_guard<std::mutex> lk(ring.mu); if (!ring.prefer_packed) break; }
+                if ((i = next.fetch_add(1)) >= n) break;
+                int sslot = -1; bool raw = false, gzdev = false;
                 {
                     const auto tw = std::chrono::steady_clock::now();
                     std::unique_lock<std::mutex> lk(ring.mu);
@@ -888,18 +924,23 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
                     // at a time travel raw, on bandwidth the link has left.
                     const int raw_cap = any_gz ? nt : std::max(1, nt / 8);
                     auto want_raw = [&] { return R > 0 && !ring.prefer_packed && (raw_knob == 2 || (!ring.free_raw.empty() && ring.raw_active < raw_cap && ring.up_pending * 4 <= n_slots)); };
-                    ring.cv_stream.wait(lk, [&] { return ring.abort || (want_raw() ? !ring.free_raw.empty() : !ring.free_stream.empty()); });
+                    // a sample of gzip files: its compressed bytes, the device inflates (unless a sample before it turned out irregular: then the
+                    // readers inflate and pack, as they do for plain files)
+                    auto want_gzdev = [&] { return G > 0 && feeder && gzs[i].gz_files == gzs[i].files && !ring.prefer_packed; };
+                    ring.cv_stream.wait(lk, [&] { return ring.abort || (want_gzdev() ? !ring.free_gz.empty() : want_raw() ? !ring.free_raw.empty() : !ring.free_stream.empty()); });
                     us_wait_stream += us_since(tw);
                     if (ring.abort) return;
-                    raw = want_raw();
-                    std::vector<int> &fl = raw ? ring.free_raw : ring.free_stream;
+                    gzdev = want_gzdev();
+                    raw = !gzdev && want_raw();
+                    std::vector<int> &fl = gzdev ? ring.free_gz : raw ? ring.free_raw : ring.free_stream;
                     sslot = fl.back(); fl.pop_back();
-                    smp[i].slot = sslot; smp[i].raw = raw;
+                    smp[i].slot = sslot; smp[i].raw = raw; smp[i].gzdev = gzdev;
                     if (raw) ring.raw_active++;
+                    if (gzdev) ring.gz_active++;
                 }
                 const auto t_files = std::chrono::steady_clock::now();
                 struct Out { int slot = -1; size_t used = 0; uint8_t *dst = nullptr; uint64_t off = 0; } x;
-                x.dst = raw ? raw_slots[(size_t)sslot].p : packed_pool.p + (uint64_t)sslot * pslot_bytes;
+                x.dst = gzdev ? gz_slots[(size_t)sslot].p : raw ? raw_slots[(size_t)sslot].p : packed_pool.p + (uint64_t)sslot * pslot_bytes;
                 auto flush = [&]() {
                     if (x.slot < 0) return;
                     { std::lock_guard<std::mutex> lk(ring.mu); ring.work.push_back({x.slot, x.dst + x.off, x.used, i}); smp[i].pending++; ring.up_pending++; }
@@ -922,7 +963,44 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
                 };
                 int r = SKX_OK;
                 uint64_t sample_len = 0, junction = 0;
-                if (raw) {
+                if (gzdev) {
+                    // the files as they are, each followed by zeros to the next multiple of 256 bytes (at least 64: the inflater's bit reader looks ahead)
+                    n_gzdev++;
+                    uint64_t total = 0;
+                    int fno = 0;
+                    for (const char *f : {file1[i], file2 ? file2[i] : nullptr}) {
+                        if (!f) continue;
+                        const uint64_t want = gzs[i].comp[fno];
+                        smp[i].coff[fno] = total;
+                        const int fd = ::open(f, O_RDONLY);
+                        if (fd < 0) { set_error("Invalid path/file: %s", f); r = SKX_EIO; break; }
+                        struct Close { int fd; ~Close() { ::close(fd); } } cl{fd};
+                        (void)posix_fadvise(fd, 0, 0, POSIX_FADV_NOREUSE);
+                        uint64_t got_file = 0;
+                        while (got_file < want) {
+                            if ((r = take_slot()) != SKX_OK) break;
+                            uint8_t *dstp = ring.base + (size_t)x.slot * SLOT + x.used;
+                            const ssize_t rd = ::read(fd, dstp, std::min<uint64_t>(RAW_CHUNK - x.used, want - got_file));
+                            if (rd < 0 && errno == EINTR) continue;
+                            if (rd < 0) { set_error("Invalid path/file: %s", f); r = SKX_EIO; break; }
+                            if (rd == 0) { r = SKF_OVER_BOUND; break; }              // (the file shrank since it was measured: the one-shot form takes the batch)
+                            x.used += (size_t)rd; got_file += (uint64_t)rd; total += (uint64_t)rd;
+                            if (x.used >= RAW_CHUNK) flush();
+                        }
+                        if (r != SKX_OK) break;
+                        uint64_t zeros = ((want + 64 + 255) & ~255ull) - want;
+                        while (zeros) {
+                            if ((r = take_slot()) != SKX_OK) break;
+                            const size_t c = (size_t)std::min<uint64_t>(zeros, RAW_CHUNK - x.used);
+                            memset(ring.base + (size_t)x.slot * SLOT + x.used, 0, c);
+                            x.used += c; zeros -= c; total += c;
+                            if (x.used >= RAW_CHUNK) flush();
+                        }
+                        if (r != SKX_OK) break;
+                        fno++;
+                    }
+                    sample_len = total;
+                } else if (raw) {
                     // the files' bytes into the pinned ring, nothing else: plain files by read() straight into a slot, gzip files inflated by this
                     // thread's inflater and copied there.  A '\n' is put behind a file that lacks its last one (the device frames lines by their ends)
                     n_raw++;
@@ -1023,22 +1101,125 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     // this thread: a sample's kernels as soon as its text is on the device
     std::vector<DevBuf<uint64_t>> wl(n), wh2(n);
     std::vector<uint64_t> cnt(n, 0);
-    int done = 0, krc = SKX_OK, n_irregular = 0;
-    double t_kernels = 0.0, t_frame = 0.0;
+    int done = 0, krc = SKX_OK, n_irregular = 0, n_gz_host = 0;
+    double t_kernels = 0.0, t_frame = 0.0, t_inflate = 0.0;
     FastqScratch fsc;
+    GzDevWork gzw[2];
+    // a gzip sample's two files are decoded on streams of their own, beside each other AND beside the kernels of the samples the reader threads
+    // inflated (this thread goes on with those while a decode is in flight, one at a time: the inflater's buffers are one set)
+    struct Aux {
+        hipStream_t s[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; GzDevFileInfo *fi = nullptr;
+        ~Aux() { for (auto x : s) if (x) (void)hipStreamDestroy(x); for (auto e : ev) if (e) (void)hipEventDestroy(e); if (fi) (void)hipHostFree(fi); }
+    } aux;
+    if (G) {
+        // (the reader threads are running: a failure here stops the pipeline the way a failed kernel does)
+        const int ar = [&]() -> int {
+            for (int f = 0; f < 2; f++) { SKX_HIP(hipStreamCreateWithFlags(&aux.s[f], hipStreamNonBlocking)); SKX_HIP(hipEventCreateWithFlags(&aux.ev[f], hipEventDisableTiming)); }
+            SKX_HIP(hipHostMalloc((void **)&aux.fi, 2 * sizeof(GzDevFileInfo), hipHostMallocDefault));
+            return SKX_OK;
+        }();
+        if (ar != SKX_OK) { krc = ar; { std::lock_guard<std::mutex> lk(ring.mu); ring.abort = true; } ring.cv_stream.notify_all(); ring.cv_free.notify_all(); }
+    }
+    int inflight = -1;
+    auto gz_start = [&](int i) -> int {
+        const uint8_t *comp = gz_slots[(size_t)smp[i].slot].p;
+        for (int f = 0; f < gzs[i].files; f++) {
+            SKX_TRY(gz_device_decode(ctx, aux.s[f], comp + smp[i].coff[f], gzs[i].comp[f], gzs[i].hint[f], gzw[f]));
+            SKX_HIP(hipMemcpyAsync(&aux.fi[f], gzw[f].finfo.p, sizeof(GzDevFileInfo), hipMemcpyDeviceToHost, aux.s[f]));
+            SKX_HIP(hipEventRecord(aux.ev[f], aux.s[f]));
+        }
+        return SKX_OK;
+    };
+    auto gz_decoded = [&](int i) -> bool { for (int f = 0; f < gzs[i].files; f++) if (hipEventQuery(aux.ev[f]) != hipSuccess) return false; return true; };
+    // a sample through the host reader on this thread: what the device's framing calls irregular, and gzip files the device's inflater does not
+    // vouch for -- the reader accepts what is merely unusual and words the error for what is wrong
+    auto host_planes = [&](int i, uint8_t *slot_p, uint64_t &positions) -> int {
+        std::vector<uint64_t> hp;
+        PlanePacker pk; pk.min_qual = min_qual_host; pk.gz = any_gz; pk.cap = bound[i] - 32;
+        pk.push = [&](const uint64_t *grp) -> int { hp.insert(hp.end(), grp, grp + 5); return SKX_OK; };
+        const std::function<int(int, const uint8_t *, size_t)> emit = [&](int which, const uint8_t *p, size_t nb) -> int { return pk.emit(which, p, nb); };
+        int hr = SKX_OK;
+        for (const char *f : {file1[i], file2 ? file2[i] : nullptr}) {
+            if (!f) continue;
+            hr = stream_fastq_file(f, emit);
+            if (hr == SKF_NOT_TAKEN && !any_gz) { set_error("Invalid FASTA/Q record"); hr = SKX_EIO; }
+            if (hr == SKF_NOT_TAKEN || hr == SKF_OVER_BOUND) hr = SKF_NOT_TAKEN;          // (the one-shot form takes the batch)
+            if (hr != SKX_OK) break;
+        }
+        if (hr == SKX_OK) hr = pk.finish();
+        if (hr == SKX_OK && !hp.empty() && hipMemcpyAsync(slot_p, hp.data(), hp.size() * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) hr = SKX_ENODEV;
+        if (hr == SKX_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) hr = SKX_ENODEV;      // (hp goes)
+        positions = pk.pos;
+        return hr;
+    };
     while (done < n) {
-        int i = -1;
+        int i = -1; bool finish = false;
         {
             std::unique_lock<std::mutex> lk(ring.mu);
-            ring.cv_ready.wait(lk, [&] { return !ring.ready.empty() || ring.abort; });      // (every sample is queued by whoever sees its last piece arrive)
+            ring.cv_ready.wait(lk, [&] { return !ring.ready.empty() || ring.abort || inflight >= 0; });      // (every sample is queued by whoever sees its last piece arrive)
             if (ring.abort) break;
-            i = ring.ready.front(); ring.ready.pop_front();
+            // the sample in the inflater is taken up again when its decode has ended, when nothing else waits, or when the next one needs the inflater
+            if (inflight >= 0 && (ring.ready.empty() || smp[ring.ready.front()].gzdev || gz_decoded(inflight))) finish = true;
+            else { i = ring.ready.front(); ring.ready.pop_front(); }
+        }
+        if (finish) { i = inflight; inflight = -1; }
+        else if (smp[i].gzdev) {
+            krc = gz_start(i);
+            if (krc != SKX_OK) { { std::lock_guard<std::mutex> lk(ring.mu); ring.abort = true; } ring.cv_stream.notify_all(); ring.cv_free.notify_all(); break; }
+            inflight = i;
+            continue;
         }
         const auto tk = std::chrono::steady_clock::now();
         skx_qual qs = q ? *q : skx_qual{5, 20, SKX_QUAL_STRICT};
-        uint8_t *slot_p = smp[i].raw ? raw_planes.p : packed_pool.p + (uint64_t)smp[i].slot * pslot_bytes;      // where the sample's planes are
+        uint8_t *slot_p = smp[i].raw || smp[i].gzdev ? raw_planes.p : packed_pool.p + (uint64_t)smp[i].slot * pslot_bytes;      // where the sample's planes are
         uint64_t positions = smp[i].len;
-        if (smp[i].raw) {
+        if (smp[i].gzdev) {
+            // compressed bytes: both files decoded to symbols side by side, the verdicts and lengths read back, then the text of one behind the
+            // other's (a '\n' behind a file that lacks its last one, as the raw form's readers put it), member CRCs checked, and the device's framing
+            const int nf = gzs[i].files;
+            GzDevFileInfo fi[2] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
+            bool vouched = true;
+            for (int f = 0; f < nf && krc == SKX_OK; f++) {
+                if (hipEventSynchronize(aux.ev[f]) != hipSuccess) krc = SKX_ENODEV;
+                fi[f] = aux.fi[f];
+            }
+            uint64_t junction = 0, len = 0;
+            if (krc == SKX_OK) {
+                for (int f = 0; f < nf; f++) vouched = vouched && fi[f].status == 0 && fi[f].total > 0;
+                if (vouched) {
+                    junction = nf > 1 ? fi[0].total + (fi[0].last != '\n') : 0;
+                    len = (nf > 1 ? junction + fi[1].total + (fi[1].last != '\n') : fi[0].total + (fi[0].last != '\n'));
+                    if (len > text_bytes[i] + 2 || len + 64 > gz_text.n || fi[0].first != '@' || (nf > 1 && fi[1].first != '@')) vouched = false;      // (the host reader decides what it is)
+                }
+            }
+            if (krc == SKX_OK && vouched) {
+                hipStream_t st = ctx->stream;
+                uint64_t at = 0;
+                for (int f = 0; f < nf && krc == SKX_OK; f++) {
+                    krc = gz_device_text(ctx, st, gzw[f], gz_text.p + at, fi[f].total, fi[f].n_members);
+                    at += fi[f].total;
+                    if (krc == SKX_OK && fi[f].last != '\n') { if (hipMemsetAsync(gz_text.p + at, '\n', 1, st) != hipSuccess) krc = SKX_ENODEV; at++; }
+                }
+                for (int f = 0; f < nf && krc == SKX_OK; f++)
+                    if (hipMemcpyAsync(&fi[f], gzw[f].finfo.p, sizeof(GzDevFileInfo), hipMemcpyDeviceToHost, st) != hipSuccess) krc = SKX_ENODEV;
+                t_inflate += std::chrono::duration<double>(std::chrono::steady_clock::now() - tk).count();
+                int irregular = 0;
+                if (krc == SKX_OK) krc = fastq_frame_planes(ctx, gz_text.p, len, junction, min_qual_host, (uint64_t *)slot_p, fsc, &positions, &irregular);      // (returns with the stream idle)
+                for (int f = 0; f < nf; f++) vouched = vouched && fi[f].status == 0;                                                                       // (the members' CRCs)
+                if (krc == SKX_OK && vouched && irregular) {
+                    n_irregular++;
+                    { std::lock_guard<std::mutex> lk(ring.mu); ring.prefer_packed = true; }
+                    krc = host_planes(i, slot_p, positions);
+                }
+            }
+            if (krc == SKX_OK && !vouched) {
+                if (knob("gz_debug"))
+                    fprintf(stderr, "gz on device: sample %d (%s) not vouched for: status %u / %u, text %llu / %llu bytes, first bytes %u / %u\n", i, file1[i], fi[0].status, fi[1].status,
+                            (unsigned long long)fi[0].total, (unsigned long long)fi[1].total, fi[0].first, fi[1].first);
+                n_gz_host++; krc = host_planes(i, slot_p, positions);
+            }
+            t_frame += std::chrono::duration<double>(std::chrono::steady_clock::now() - tk).count();
+        } else if (smp[i].raw) {
             // the device frames the records and makes the planes; a text it calls irregular goes through the host reader here and now (which
             // accepts what is merely unusual -- blank lines between records -- and words the error for what is wrong), and the readers pack the
             // samples that follow: files of one run tend to share their quirks
@@ -1047,29 +1228,14 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
             if (krc == SKX_OK && irregular) {
                 n_irregular++;
                 { std::lock_guard<std::mutex> lk(ring.mu); ring.prefer_packed = true; }
-                std::vector<uint64_t> host_planes;
-                PlanePacker pk; pk.min_qual = min_qual_host; pk.gz = any_gz; pk.cap = bound[i] - 32;
-                pk.push = [&](const uint64_t *grp) -> int { host_planes.insert(host_planes.end(), grp, grp + 5); return SKX_OK; };
-                const std::function<int(int, const uint8_t *, size_t)> emit = [&](int which, const uint8_t *p, size_t nb) -> int { return pk.emit(which, p, nb); };
-                for (const char *f : {file1[i], file2 ? file2[i] : nullptr}) {
-                    if (!f) continue;
-                    krc = stream_fastq_file(f, emit);
-                    if (krc == SKF_NOT_TAKEN && !any_gz) { set_error("Invalid FASTA/Q record"); krc = SKX_EIO; }
-                    if (krc == SKF_NOT_TAKEN || krc == SKF_OVER_BOUND) krc = SKF_NOT_TAKEN;          // (the one-shot form takes the batch)
-                    if (krc != SKX_OK) break;
-                }
-                if (krc == SKX_OK) krc = pk.finish();
-                if (krc == SKX_OK && !host_planes.empty() &&
-                    hipMemcpyAsync(slot_p, host_planes.data(), host_planes.size() * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) krc = SKX_ENODEV;
-                if (krc == SKX_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) krc = SKX_ENODEV;      // (host_planes goes)
-                positions = pk.pos;
+                krc = host_planes(i, slot_p, positions);
             }
             t_frame += std::chrono::duration<double>(std::chrono::steady_clock::now() - tk).count();
         }
         // (the kernels read the packed planes themselves: the two record streams never exist in memory)
         if (krc == SKX_OK) krc = reads_sample_words(ctx, nullptr, nullptr, positions, k, rc, qs, wl[i], wh2[i], &cnt[i], (const uint64_t *)slot_p);      // (returns with the stream idle: the slot is free)
         t_kernels += std::chrono::duration<double>(std::chrono::steady_clock::now() - tk).count();
-        { std::lock_guard<std::mutex> lk(ring.mu); (smp[i].raw ? ring.free_raw : ring.free_stream).push_back(smp[i].slot); if (krc != SKX_OK) ring.abort = true; }
+        { std::lock_guard<std::mutex> lk(ring.mu); (smp[i].gzdev ? ring.free_gz : smp[i].raw ? ring.free_raw : ring.free_stream).push_back(smp[i].slot); if (smp[i].gzdev) ring.gz_active--; if (krc != SKX_OK) ring.abort = true; }
         ring.cv_stream.notify_all();
         if (krc != SKX_OK) { ring.cv_free.notify_all(); break; }
         done++;
@@ -1085,6 +1251,9 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     phase_add("build.readers_wait_pinned_thread_s", us_wait_ring.load() * 1e-6);
     phase_add("build.readers_wait_device_slot_thread_s", us_wait_stream.load() * 1e-6);
     phase_add("build.reads_samples_sent_raw", (double)n_raw.load());
+    phase_add("build.reads_samples_sent_compressed", (double)n_gzdev.load());
+    phase_add("build.reads_samples_inflated_on_host_after_all", (double)n_gz_host);
+    phase_add("build.reads_device_inflate_overlapped", t_inflate);
     phase_add("build.reads_samples_irregular", (double)n_irregular);
     phase_add("build.reads_uploaded_GB", (double)bytes_up.load() * 1e-9);
     if (ring.failed) { set_error("upload of the sequence files failed"); return SKX_ENODEV; }
@@ -1095,7 +1264,8 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     for (int i = 0; i < n; i++) if (rcodes[i] != SKX_OK) { set_error("%s", errs[i].c_str()); return rcodes[i]; }
     if (done < n) { set_error("internal: read-set pipeline stopped early"); return SKX_EUNSUP; }
     raw_alloc.join();
-    packed_pool.release(); raw_planes.release(); raw_slots.clear();
+    packed_pool.release(); raw_planes.release(); raw_slots.clear(); gz_slots.clear(); gz_text.release();
+    for (auto &g : gzw) g = GzDevWork();
     const auto t1 = std::chrono::steady_clock::now();
     skx_dictset *d = nullptr;
     int r = reads_words_to_dictset(ctx, wl, wh2, cnt, k, rc, &d);
@@ -1129,6 +1299,57 @@ extern "C" int skx_debug_fastq_frame(skx_ctx *ctx, const uint8_t *text, uint64_t
     SKX_HIP(hipMemcpyAsync(seq, d_seq.p, *positions, hipMemcpyDeviceToHost, st));
     SKX_HIP(hipMemcpyAsync(qual, d_qual.p, *positions, hipMemcpyDeviceToHost, st));
     SKX_HIP(hipStreamSynchronize(st));
+    SKX_HIP(hipGetLastError());
+    return SKX_OK;
+    });
+}
+
+// Test hook (not part of the drop-in boundary): a gzip file's bytes through the device inflater (skx_gzdev.hip).  status: gzd::Status -- 0: text[0..total)
+// is the members' text, lengths and CRCs checked; otherwise nothing is vouched for (the engine would take the file through the reader threads'
+// inflater).  ms[0..2): device time of the decode kernels and of the text + CRC kernels.
+extern "C" int skx_debug_gz_inflate(skx_ctx *ctx, const uint8_t *gz, uint64_t len, uint64_t text_hint, uint8_t *text, uint64_t cap, uint64_t *total,
+                                    uint32_t *status, uint32_t *n_members, double *ms)
+{
+    return skx_guarded([&]() -> int {
+    if (!ctx || !gz || !text || !total || !status || !n_members) { set_error("bad arguments"); return SKX_EINVAL; }
+    SKX_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevBuf<uint8_t> d_gz, d_text;
+    SKX_TRY(d_gz.alloc(len + 64));
+    SKX_HIP(hipMemsetAsync(d_gz.p + (len & ~3ull), 0, 64 - (len & 3u), st));
+    SKX_HIP(hipMemcpyAsync(d_gz.p, gz, len, hipMemcpyHostToDevice, st));
+    GzDevWork wk;
+    hipEvent_t e0, e1, e2;
+    SKX_HIP(hipEventCreate(&e0)); SKX_HIP(hipEventCreate(&e1)); SKX_HIP(hipEventCreate(&e2));
+    struct Ev { hipEvent_t a, b, c; ~Ev() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipEventDestroy(c); } } ev{e0, e1, e2};
+    int rc2 = SKX_OK;
+    for (int rep = 0; rep < 2 && rc2 == SKX_OK; rep++) {                  // (the second pass is the timed one: buffers exist)
+        SKX_HIP(hipEventRecord(e0, st));
+        rc2 = gz_device_decode(ctx, st, d_gz.p, len, text_hint, wk);
+        SKX_HIP(hipEventRecord(e1, st));
+    }
+    SKX_TRY(rc2);
+    GzDevFileInfo fi;
+    SKX_HIP(hipMemcpyAsync(&fi, wk.finfo.p, sizeof fi, hipMemcpyDeviceToHost, st));
+    SKX_HIP(hipStreamSynchronize(st));
+    float m0 = 0, m1 = 0;
+    (void)hipEventElapsedTime(&m0, e0, e1);
+    if (ms) { ms[0] = m0; ms[1] = 0; }
+    *total = fi.total; *status = fi.status; *n_members = fi.n_members;
+    if (fi.status == 0 && fi.total > cap) { *status = 2; return SKX_OK; }
+    if (fi.status == 0 && fi.total) {
+        SKX_TRY(d_text.alloc(fi.total + 64));
+        SKX_HIP(hipEventRecord(e1, st));
+        SKX_TRY(gz_device_text(ctx, st, wk, d_text.p, fi.total, fi.n_members));
+        SKX_HIP(hipEventRecord(e2, st));
+        SKX_HIP(hipMemcpyAsync(&fi, wk.finfo.p, sizeof fi, hipMemcpyDeviceToHost, st));
+        SKX_HIP(hipMemcpyAsync(text, d_text.p, fi.total, hipMemcpyDeviceToHost, st));
+        SKX_HIP(hipStreamSynchronize(st));
+        (void)hipEventElapsedTime(&m1, e1, e2);
+        *status = fi.status;
+        if (fi.status == 0 && (fi.first != text[0] || fi.last != text[fi.total - 1])) { set_error("internal: first / last byte of the inflated text"); return SKX_EUNSUP; }
+    }
+    if (ms) { ms[0] = m0; ms[1] = m1; }
     SKX_HIP(hipGetLastError());
     return SKX_OK;
     });

@@ -198,6 +198,14 @@ int read_sample_stream(const char *file1, const char *file2, double proportion_r
 // FASTQ text -> the read-set kernels' bit planes on the device (skx_fastq.hip); scratch that lives across a batch's samples
 struct FastqScratch { DevBuf<uint32_t> tile, info, line_end, rec_seq, rec_qual, rec_len, rec_end; };
 int fastq_frame_planes(skx_ctx *ctx, const uint8_t *raw, uint64_t len, uint64_t junction, int min_qual, uint64_t *planes, FastqScratch &sc, uint64_t *positions, int *irregular);
+// `.fastq.gz` inflated on the device (skx_gzdev.hip; logic: gz_device.h): one file's buffers, kept across a batch's samples
+struct GzDevFileInfo { uint64_t total; uint32_t status, n_members, first, last; };      // status: gzd::Status (0: the text is vouched for)
+struct GzDevWork {
+    DevBuf<uint64_t> sync, base, m_end; DevBuf<uint32_t> m_crc, m_acc; DevBuf<uint8_t> cinfo, members, finfo; DevBuf<uint16_t> sym, maps, gwin;
+    const uint8_t *src = nullptr; uint64_t src_bytes = 0; uint32_t n_chunks = 0, n_groups = 0, chunk_bytes = 0, ratio = 0, group = 0, max_members = 0;
+};
+int gz_device_decode(skx_ctx *ctx, hipStream_t st, const uint8_t *src, uint64_t bytes, uint64_t text_hint, GzDevWork &wk);
+int gz_device_text(skx_ctx *ctx, hipStream_t st, GzDevWork &wk, uint8_t *dst, uint64_t total, uint32_t n_members);
 int stream_fastq_file(const char *path, const std::function<int(int which, const uint8_t *p, size_t n)> &emit);
 // gzip members inflated piece by piece into a window of the reader's own (gz_inflate.cpp: the reader threads' inflater).  next(): more text,
 // in place -- the `keep` bytes in front of the last call's end stay in front of it (the caller's unfinished line); *n == 0 at the end of the
