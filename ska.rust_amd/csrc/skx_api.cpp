@@ -819,7 +819,7 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     // before, 0.25 s of one read for the first time, when sixteen read()s contend for the page cache's LRU lock -- so six slots carried 24 raw
     // samples a second at most and the link idled at 12 GB/s: profiles/r06d_reads_1000.log).  They are allocated one by one by a helper thread
     // while the pipeline already runs on the packed pool: 11 GB taken at once right after another process released its memory cost 1.4-1.9 s.
-    const int R = raw_possible ? (int)std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(2, std::min<uint64_t>(any_gz || raw_knob == 2 ? (uint64_t)nt + 2 : (uint64_t)std::max(1, nt / 8) + 3, (free_b / 8) / (rslot_bytes + 1)))) : 0;
+    const int R = raw_possible ? (int)std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(2, std::min<uint64_t>(raw_knob == 2 || (any_gz && !gz_device) ? (uint64_t)nt + 2 : gz_device ? (uint64_t)std::max(1, (nt - std::min(gz_feed, nt)) / 2) + 2 : (uint64_t)std::max(1, nt / 8) + 3, (free_b / 8) / (rslot_bytes + 1)))) : 0;      // (beside the device's inflater: half the inflating readers send text, the others planes)
     // slots for compressed samples: one per reader and a few waiting for the inflater (0.27 GB each at 50x of 5 Mbp); the text the device makes of
     // a sample lives in ONE buffer (the kernels take a sample at a time)
     const uint64_t gslot_bytes = gz_device ? comp_cap : 0;
@@ -1104,33 +1104,36 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     int done = 0, krc = SKX_OK, n_irregular = 0, n_gz_host = 0;
     double t_kernels = 0.0, t_frame = 0.0, t_inflate = 0.0;
     FastqScratch fsc;
-    GzDevWork gzw[2];
+    GzDevWork gzw2[1][2];                                               // (a sample's two files)
     // a gzip sample's two files are decoded on streams of their own, beside each other AND beside the kernels of the samples the reader threads
     // inflated (this thread goes on with those while a decode is in flight, one at a time: the inflater's buffers are one set)
     struct Aux {
-        hipStream_t s[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; GzDevFileInfo *fi = nullptr;
+        hipStream_t s[2] = {nullptr, nullptr}; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; GzDevFileInfo *fi = nullptr;      // (events, verdicts: [file]; ev[2]: a sample's text is made)
         ~Aux() { for (auto x : s) if (x) (void)hipStreamDestroy(x); for (auto e : ev) if (e) (void)hipEventDestroy(e); if (fi) (void)hipHostFree(fi); }
     } aux;
     if (G) {
         // (the reader threads are running: a failure here stops the pipeline the way a failed kernel does)
         const int ar = [&]() -> int {
-            for (int f = 0; f < 2; f++) { SKX_HIP(hipStreamCreateWithFlags(&aux.s[f], hipStreamNonBlocking)); SKX_HIP(hipEventCreateWithFlags(&aux.ev[f], hipEventDisableTiming)); }
-            SKX_HIP(hipHostMalloc((void **)&aux.fi, 2 * sizeof(GzDevFileInfo), hipHostMallocDefault));
+            for (int f = 0; f < 2; f++) SKX_HIP(hipStreamCreateWithFlags(&aux.s[f], hipStreamNonBlocking));
+            for (int e = 0; e < 4; e++) SKX_HIP(hipEventCreateWithFlags(&aux.ev[e], hipEventDisableTiming));
+            SKX_HIP(hipHostMalloc((void **)&aux.fi, 4 * sizeof(GzDevFileInfo), hipHostMallocDefault));
             return SKX_OK;
         }();
         if (ar != SKX_OK) { krc = ar; { std::lock_guard<std::mutex> lk(ring.mu); ring.abort = true; } ring.cv_stream.notify_all(); ring.cv_free.notify_all(); }
     }
-    int inflight = -1;
-    auto gz_start = [&](int i) -> int {
+    int inflight = -1; const int inflight_set = 0, cur_set = 0;
+    auto gz_start = [&](int i, int set) -> int {
         const uint8_t *comp = gz_slots[(size_t)smp[i].slot].p;
         for (int f = 0; f < gzs[i].files; f++) {
-            SKX_TRY(gz_device_decode(ctx, aux.s[f], comp + smp[i].coff[f], gzs[i].comp[f], gzs[i].hint[f], gzw[f]));
-            SKX_HIP(hipMemcpyAsync(&aux.fi[f], gzw[f].finfo.p, sizeof(GzDevFileInfo), hipMemcpyDeviceToHost, aux.s[f]));
-            SKX_HIP(hipEventRecord(aux.ev[f], aux.s[f]));
+            GzDevWork &wk = gzw2[set][f];
+            SKX_TRY(gz_device_decode(ctx, aux.s[f], comp + smp[i].coff[f], gzs[i].comp[f], gzs[i].hint[f], wk));
+            SKX_HIP(hipMemcpyAsync(&aux.fi[set * 2 + f], wk.finfo.p, sizeof(GzDevFileInfo), hipMemcpyDeviceToHost, aux.s[f]));
+            SKX_HIP(hipEventRecord(aux.ev[set * 2 + f], aux.s[f]));
         }
         return SKX_OK;
     };
-    auto gz_decoded = [&](int i) -> bool { for (int f = 0; f < gzs[i].files; f++) if (hipEventQuery(aux.ev[f]) != hipSuccess) return false; return true; };
+    auto gz_decoded = [&](int i, int set) -> bool { for (int f = 0; f < gzs[i].files; f++) if (hipEventQuery(aux.ev[set * 2 + f]) != hipSuccess) return false; return true; };
+    auto stop_pipeline = [&]() { { std::lock_guard<std::mutex> lk(ring.mu); ring.abort = true; } ring.cv_stream.notify_all(); ring.cv_free.notify_all(); };
     // a sample through the host reader on this thread: what the device's framing calls irregular, and gzip files the device's inflater does not
     // vouch for -- the reader accepts what is merely unusual and words the error for what is wrong
     auto host_planes = [&](int i, uint8_t *slot_p, uint64_t &positions) -> int {
@@ -1159,16 +1162,30 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
             ring.cv_ready.wait(lk, [&] { return !ring.ready.empty() || ring.abort || inflight >= 0; });      // (every sample is queued by whoever sees its last piece arrive)
             if (ring.abort) break;
             // the sample in the inflater is taken up again when its decode has ended, when nothing else waits, or when the next one needs the inflater
-            if (inflight >= 0 && (ring.ready.empty() || smp[ring.ready.front()].gzdev || gz_decoded(inflight))) finish = true;
+            if (inflight >= 0 && (ring.ready.empty() || smp[ring.ready.front()].gzdev || gz_decoded(inflight, inflight_set))) finish = true;
             else { i = ring.ready.front(); ring.ready.pop_front(); }
         }
         if (finish) { i = inflight; inflight = -1; }
         else if (smp[i].gzdev) {
-            krc = gz_start(i);
-            if (krc != SKX_OK) { { std::lock_guard<std::mutex> lk(ring.mu); ring.abort = true; } ring.cv_stream.notify_all(); ring.cv_free.notify_all(); break; }
+            krc = gz_start(i, 0);
+            if (krc != SKX_OK) { stop_pipeline(); break; }
             inflight = i;
             continue;
         }
+        // the next gzip sample's decode starts as soon as this one's text is made (the inflater's buffers are free then: the streams wait for that
+        // on the device), beside this one's framing and window kernels
+        auto start_next_gz = [&](bool after_text) -> int {
+            int j = -1;
+            { std::lock_guard<std::mutex> lk(ring.mu); if (!ring.ready.empty() && smp[ring.ready.front()].gzdev) { j = ring.ready.front(); ring.ready.pop_front(); } }
+            if (j < 0) return SKX_OK;
+            if (after_text) {
+                SKX_HIP(hipEventRecord(aux.ev[2], ctx->stream));
+                for (int f = 0; f < 2; f++) SKX_HIP(hipStreamWaitEvent(aux.s[f], aux.ev[2], 0));
+            }
+            SKX_TRY(gz_start(j, 0));
+            inflight = j;
+            return SKX_OK;
+        };
         const auto tk = std::chrono::steady_clock::now();
         skx_qual qs = q ? *q : skx_qual{5, 20, SKX_QUAL_STRICT};
         uint8_t *slot_p = smp[i].raw || smp[i].gzdev ? raw_planes.p : packed_pool.p + (uint64_t)smp[i].slot * pslot_bytes;      // where the sample's planes are
@@ -1179,9 +1196,10 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
             const int nf = gzs[i].files;
             GzDevFileInfo fi[2] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
             bool vouched = true;
+            GzDevWork *gzw = gzw2[cur_set];
             for (int f = 0; f < nf && krc == SKX_OK; f++) {
-                if (hipEventSynchronize(aux.ev[f]) != hipSuccess) krc = SKX_ENODEV;
-                fi[f] = aux.fi[f];
+                if (hipEventSynchronize(aux.ev[cur_set * 2 + f]) != hipSuccess) krc = SKX_ENODEV;
+                fi[f] = aux.fi[cur_set * 2 + f];
             }
             uint64_t junction = 0, len = 0;
             if (krc == SKX_OK) {
@@ -1202,6 +1220,7 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
                 }
                 for (int f = 0; f < nf && krc == SKX_OK; f++)
                     if (hipMemcpyAsync(&fi[f], gzw[f].finfo.p, sizeof(GzDevFileInfo), hipMemcpyDeviceToHost, st) != hipSuccess) krc = SKX_ENODEV;
+                if (krc == SKX_OK) krc = start_next_gz(true);
                 t_inflate += std::chrono::duration<double>(std::chrono::steady_clock::now() - tk).count();
                 int irregular = 0;
                 if (krc == SKX_OK) krc = fastq_frame_planes(ctx, gz_text.p, len, junction, min_qual_host, (uint64_t *)slot_p, fsc, &positions, &irregular);      // (returns with the stream idle)
@@ -1213,6 +1232,7 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
                 }
             }
             if (krc == SKX_OK && !vouched) {
+                if (inflight < 0) krc = start_next_gz(false);
                 if (knob("gz_debug"))
                     fprintf(stderr, "gz on device: sample %d (%s) not vouched for: status %u / %u, text %llu / %llu bytes, first bytes %u / %u\n", i, file1[i], fi[0].status, fi[1].status,
                             (unsigned long long)fi[0].total, (unsigned long long)fi[1].total, fi[0].first, fi[1].first);
@@ -1265,7 +1285,7 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
     if (done < n) { set_error("internal: read-set pipeline stopped early"); return SKX_EUNSUP; }
     raw_alloc.join();
     packed_pool.release(); raw_planes.release(); raw_slots.clear(); gz_slots.clear(); gz_text.release();
-    for (auto &g : gzw) g = GzDevWork();
+    for (auto &st2 : gzw2) for (auto &g : st2) g = GzDevWork();
     const auto t1 = std::chrono::steady_clock::now();
     skx_dictset *d = nullptr;
     int r = reads_words_to_dictset(ctx, wl, wh2, cnt, k, rc, &d);

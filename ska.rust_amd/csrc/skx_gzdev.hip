@@ -1,17 +1,30 @@
-// skx_gzdev.hip -- `.fastq.gz` inflated on the device (round 6): the reader threads only read() the compressed bytes into the pinned ring, and
-// what the read-set kernels are given is made here.  The per-lane logic is gz_device.h (the same functions run on the host in
-// tools/gzdev_host_check.cpp against zlib); the kernels around it:
-//   gzd_find_kernel   : a wavefront per chunk of the compressed file (64 KB) -- the first dynamic block that starts in it: 64 bit positions
-//                       tested at a time (three header bits, the counts, a complete code-length code), the survivors one by one by lane 0
-//                       (complete literal and distance codes, the block decodes to its end-of-block, a block header follows)
-//   gzd_decode_kernel : a wavefront per chunk -- lane 0 walks the blocks from the chunk's start to the next chunk's, Huffman tables in LDS,
-//                       16-bit symbols out: bytes, or references into the 32 KB in front of the chunk that it cannot know
-//   gzd_maps_kernel   : a workgroup per GROUP of chunks -- for every chunk the last 32 KB of text behind it as a map (bytes / references into
-//                       the window in front of the group), one chunk after the other within the group
-//   gzd_groups_kernel : one workgroup -- the windows in front of the groups, one after the other (n_chunks / GROUP steps instead of n_chunks);
-//                       then the chunks' places in the text (scan of their lengths), the members' ends and trailers, the file's verdict
+// skx_gzdev.hip -- `.fastq.gz` inflated on the device (round 6): feeder threads only read() the compressed bytes into the pinned ring, and
+// what the read-set kernels are given is made here.  The format's logic is gz_device.h (bit reader, table builder, block and member walk,
+// the block finder's tests: the same functions run on the host in tools/gzdev_host_check.cpp against zlib, tests/test_gz_device_logic.py);
+// the kernels around it, a file at a time (two files of a sample on two streams):
+//   gzd_find_kernel   : a wavefront per 16 KB chunk of the compressed file -- the first dynamic block that starts in it.  64 bit positions a
+//                       turn, a lane each: three header bits and the two counts (one position in nine fits) -> a queue; 64 queued positions: a
+//                       lane each sums the code-length code's Kraft sum (complete for one in ~70) -> a second queue; 64 of those: a lane
+//                       each decodes the whole header in registers (literal and distance codes exactly complete, an end-of-block code,
+//                       literals that are text).  The first position that passes is the chunk's start; no block is decoded here
+//                       (SKX_KNOBS=gz_verify: it is, and a block header must follow -- 2.8 -> 15 ms a file)
+//   gzd_decode_kernel : a wavefront per chunk walks the blocks from its start to the next chunk's.  Headers by lane 0 (tables into 3.3 KB of
+//                       LDS: zlib's root widths, 9 and 6 bits).  Symbols by LOOK-AHEAD: lane i decodes the token that would start at bit
+//                       i of the next 64 (two table gathers, extra bits, all in its own 64-bit view); the scalar unit hops along the real
+//                       chain (three register reads a token) and pushes tokens into a batch; a batch of 64 is RESOLVED in an LDS buffer:
+//                       literals and copies of settled text in parallel, copies of this batch's own output in order; coalesced stores of
+//                       16-bit symbols: bytes, or references into the 32 KB in front of the chunk that it cannot know
+//   gzd_maps_kernel   : a workgroup per GROUP of 64 chunks -- for every chunk the last 32 KB of text behind it as a map (bytes / references
+//                       into the window in front of the group), one chunk after the other within the group
+//   gzd_groups_kernel : one workgroup -- the windows in front of the groups, one after the other; then the chunks' places in the text (scan of
+//                       their lengths), the members' ends and lengths against their trailers, the file's verdict, its first and last byte
 //   gzd_text_kernel   : every symbol to its byte (through the previous chunk's map and the group's window), text written in place
 //   gzd_crc_kernel / gzd_crc_check_kernel : CRC-32 of every member from 4 KB pieces joined by multiplication mod P, against the trailers
+// Measured (MI355X, one 129 MB file of 150 bp reads at level 1 = 256 MB of text, 72 M tokens; profiles/r06zf, r06zh): find 2.8 ms, decode
+// 15 ms, maps 0.6, groups 1.2, text 0.85, CRC 1.0 ms = 21 ms a file (zlib on one core of the box: 0.78 s).  The decode is bound by instruction
+// issue, not memory: 55 scalar + 33 vector instructions a token (PMC: 4.0 G + 2.4 G a file), one scalar unit a compute unit; the history
+// of its forms -- lane 0 alone 51 ms, a scalar Huffman loop 36 ms, token batches 28 ms, high occupancy 22 ms (and no better however many
+// wavefronts: 180 scalar instructions a token), look-ahead 20 -> 15 ms -- is in NOTEBOOK.md.
 // HBM traffic per text byte: 2 B written + 2 B read of symbols, 1 B of text written, 1 B read by the CRC; the compressed bytes twice.
 #include "skx_internal.h"
 #include "skx_device.h"
@@ -109,7 +122,7 @@ struct WaveBits {
 constexpr uint32_t GZ_BUF = 512;
 constexpr uint32_t TK_LIT = 0, TK_COPY = 1, TK_EOB = 2, TK_ERR = 3;
 template <bool DRY>
-__device__ static int inflate_block_wave(WaveBits &b, const Tables &t, uint16_t *s_buf, uint16_t *out, uint32_t &n_io, uint32_t cap, int32_t floor)
+__device__ static int inflate_block_wave(WaveBits &b, const Tables &t, uint16_t *s_buf, uint32_t *s_tpos, uint16_t *out, uint32_t &n_io, uint32_t cap, int32_t floor)
 {
     const uint32_t lane = threadIdx.x;
     uint32_t n = uni32(n_io), bs = n, tc = 0;
@@ -136,8 +149,32 @@ __device__ static int inflate_block_wave(WaveBits &b, const Tables &t, uint16_t 
                 }
             } else near = true;
         }
+        s_tpos[lane] = lane < tc ? v_pos : 0xFFFFFFFFu;
         __syncthreads();
         uint64_t nm = __ballot(near);
+        if (nm) {
+            // a copy that reads this batch's output, but only what literals and the first round's copies put there, need not wait its turn: the
+            // tokens its source runs over (found by their positions, two binary searches) hold no such copy -- itself included -- then it goes now
+            bool deep = false;
+            if (near) {
+                const uint32_t q0 = src > (int32_t)bs ? (uint32_t)src : bs, q1 = (uint32_t)(src + (int32_t)len - 1);
+                uint32_t a = 0, b2 = 0;
+#pragma unroll
+                for (uint32_t step = 32; step; step >>= 1) {
+                    if (a + step < 64u && s_tpos[a + step] <= q0) a += step;
+                    if (b2 + step < 64u && s_tpos[b2 + step] <= q1) b2 += step;
+                }
+                const uint64_t upto = b2 >= 63u ? ~0ull : (2ull << b2) - 1ull;
+                deep = (nm & upto & ~((1ull << a) - 1ull)) != 0;
+                if (!deep)
+                    for (uint32_t j = 0; j < len; j++) {
+                        const int32_t q = src + (int32_t)j;
+                        s_buf[rel + j] = q < 0 ? (uint16_t)(SYM0 + (uint32_t)(q + (int32_t)WIN)) : q >= (int32_t)bs ? s_buf[(uint32_t)q - bs] : out[q];
+                    }
+            }
+            __syncthreads();
+            nm = __ballot(deep);
+        }
         while (nm) {
             const int k = __ffsll((long long)nm) - 1;
             nm &= nm - 1;
@@ -260,7 +297,7 @@ __device__ static int wave_block_header(const uint32_t *w, uint64_t nwords, uint
 
 // decode_chunk (gz_device.h) by the whole wavefront
 template <bool DRYRUN>
-__device__ static void decode_chunk_wave(const uint32_t *w, uint64_t src_bytes, uint64_t start_bit, uint64_t stop_bit, Tables &t, WaveShared &sh, uint16_t *s_buf, uint16_t *out,
+__device__ static void decode_chunk_wave(const uint32_t *w, uint64_t src_bytes, uint64_t start_bit, uint64_t stop_bit, Tables &t, WaveShared &sh, uint16_t *s_buf, uint32_t *s_tpos, uint16_t *out,
                                          uint64_t cap, ChunkInfo *info, Member *members)
 {
     const uint32_t lane = threadIdx.x;
@@ -297,7 +334,7 @@ __device__ static void decode_chunk_wave(const uint32_t *w, uint64_t src_bytes, 
             if (type == 2 || !fixed_built) { st = wave_block_header(w, nwords, pos, type, false, t, sh, &pos); if (st != OK) break; }
             fixed_built = type == 1;
             b.seek(pos);
-            st = inflate_block_wave<DRYRUN>(b, t, s_buf, out, n, cap32, floor);
+            st = inflate_block_wave<DRYRUN>(b, t, s_buf, s_tpos, out, n, cap32, floor);
             pos = b.pos();
             if (st != OK) break;
         }
@@ -329,7 +366,7 @@ __device__ static bool sync_verify_wave(const uint32_t *w, uint64_t src_bytes, u
     WaveBits b; b.w = w; b.nwords = (uint32_t)nwords;
     b.seek(pos);
     uint32_t n = 0;
-    if (inflate_block_wave<true>(b, t, nullptr, nullptr, n, 0xFFFFFF00u, -(int32_t)WIN) != OK) return false;
+    if (inflate_block_wave<true>(b, t, nullptr, nullptr, nullptr, n, 0xFFFFFF00u, -(int32_t)WIN) != OK) return false;
     pos = b.pos();
     if (n == 0 || pos + 3 > src_bits) return false;
     const uint64_t h = upeek64(w, nwords, pos);
@@ -414,7 +451,7 @@ __global__ void __launch_bounds__(64) gzd_find_kernel(const uint32_t *w, uint64_
 {
     __shared__ Tables t;
     __shared__ WaveShared sh;
-    __shared__ uint64_t s_q[64];
+    __shared__ uint64_t s_q[64], s_p[64];
     const uint32_t c = blockIdx.x + 1, lane = threadIdx.x;
     if (c >= n_chunks) return;
     const uint64_t nwords = (src_bytes + 3) / 4, lo = (uint64_t)c * chunk_bytes * 8;
@@ -423,9 +460,11 @@ __global__ void __launch_bounds__(64) gzd_find_kernel(const uint32_t *w, uint64_
     uint64_t cb = (lo >> 5) & ~63ull;
     uint32_t cw = cb + lane < nwords ? w[cb + lane] : 0u, cw2 = cb + 64 + lane < nwords ? w[cb + 64 + lane] : 0u;
     uint64_t res = NONE;
-    uint32_t qn = 0;
-    // the candidates that passed the cheap test wait in s_q until there are 64 (or the chunk ends): then a lane each checks a header
-    auto drain = [&]() {
+    uint32_t qn = 0, pn = 0;
+    // Two queues, so that every test runs with all lanes busy: positions whose three header bits and two counts fit (one in nine) wait in s_p
+    // until there are 64, then a lane each sums a code-length code (complete for one in ~70); those wait in s_q until there are 64 (or the
+    // chunk ends), then a lane each checks a whole header
+    auto drain_q = [&]() {
         __syncthreads();
         const bool ok = lane < qn && header_ok_lane(w, (uint32_t)nwords, s_q[lane]);
         uint64_t vm = __ballot(ok);
@@ -434,42 +473,54 @@ __global__ void __launch_bounds__(64) gzd_find_kernel(const uint32_t *w, uint64_
             vm &= vm - 1;
             const uint64_t cand = uni64(s_q[l]);
             // VERIFY: the candidate's block is walked to its end-of-block and a header must follow (as much work as decoding the block).  Without:
-            // a header whose three codes are exactly complete is taken at its word -- the chunk before must END exactly there (decode_chunk's
-            // E_SYNC), so a false one is noticed, and the file then goes through the reader threads' inflater
+            // a header whose three codes are exactly complete (and whose literals are text) is taken at its word -- the chunk before must END
+            // exactly there (decode_chunk's E_SYNC), so a false one is noticed, and the file then goes through the reader threads' inflater
             if (!VERIFY || sync_verify_wave(w, src_bytes, cand, t, sh)) { res = cand; break; }
         }
         qn = 0;
+        __syncthreads();
+    };
+    auto drain_p = [&]() {
+        __syncthreads();
+        bool q = false;
+        uint64_t pos = 0;
+        if (lane < pn) {
+            pos = s_p[lane];
+            const uint32_t hclen = ((uint32_t)(peek64(w, nwords, pos) >> 13) & 15u) + 4u;
+            uint64_t vv = peek64(w, nwords, pos + 17);
+            uint32_t kraft = 0;
+            for (uint32_t z = 0; z < hclen; z++) { const uint32_t l = (uint32_t)(vv & 7u); vv >>= 3; if (l) kraft += 128u >> l; }
+            q = kraft == 128u;
+        }
+        pn = 0;
+        const uint64_t m = __ballot(q);
+        if (m) {
+            const uint32_t add = (uint32_t)__popcll(m);
+            if (qn + add > 64) { drain_q(); if (res != NONE) return; }
+            if (q) s_q[qn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = pos;
+            qn += add;
+        }
         __syncthreads();
     };
     for (uint64_t base = lo; base < hi && res == NONE; base += 64) {
         if ((base >> 5) + 6 >= cb + 128) { cw = cw2; cb += 64; cw2 = cb + 64 + lane < nwords ? w[cb + 64 + lane] : 0u; }
         const uint64_t pos = base + lane;
         const uint32_t i = (uint32_t)((pos >> 5) - cb), d = (uint32_t)(pos & 31);
-        uint32_t a[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t x = (uint32_t)__shfl((int)cw, (int)((i + k) & 63), 64), y = (uint32_t)__shfl((int)cw2, (int)((i + k) & 63), 64);
-            a[k] = i + k < 64 ? x : y;
-        }
-        const uint64_t l64 = (uint64_t)a[0] | ((uint64_t)a[1] << 32), h64 = (uint64_t)a[2] | ((uint64_t)a[3] << 32);
-        const uint64_t h = d ? (l64 >> d) | (h64 << (64 - d)) : l64;
-        const uint32_t d2 = d + 17;
-        const uint64_t v = (l64 >> d2) | (h64 << (64 - d2));
-        bool q = pos < hi && (h & 7u) == 4u;
-        if (q) {
-            const uint32_t hlit = (uint32_t)(h >> 3) & 31u, hdist = (uint32_t)(h >> 8) & 31u, hclen = ((uint32_t)(h >> 13) & 15u) + 4u;
-            uint32_t kraft = 0; uint64_t vv = v;
-            for (uint32_t z = 0; z < hclen; z++) { const uint32_t l = (uint32_t)(vv & 7u); vv >>= 3; if (l) kraft += 128u >> l; }
-            q = hlit <= 29u && hdist <= 29u && kraft == 128u;
-        }
+        // the 13 bits at the position: BFINAL 0, BTYPE 10, HLIT and HDIST at most 29
+        const uint32_t x0 = (uint32_t)__shfl((int)cw, (int)(i & 63), 64), y0 = (uint32_t)__shfl((int)cw2, (int)(i & 63), 64);
+        const uint32_t x1 = (uint32_t)__shfl((int)cw, (int)((i + 1) & 63), 64), y1 = (uint32_t)__shfl((int)cw2, (int)((i + 1) & 63), 64);
+        const uint64_t two = (uint64_t)(i < 64 ? x0 : y0) | ((uint64_t)(i + 1 < 64 ? x1 : y1) << 32);
+        const uint32_t h = (uint32_t)(two >> d);
+        const bool q = pos < hi && (h & 7u) == 4u && ((h >> 3) & 31u) <= 29u && ((h >> 8) & 31u) <= 29u;
         const uint64_t m = __ballot(q);
         if (!m) continue;
         const uint32_t add = (uint32_t)__popcll(m);
-        if (qn + add > 64) { drain(); if (res != NONE) break; }
-        if (q) s_q[qn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = pos;
-        qn += add;
+        if (pn + add > 64) { drain_p(); if (res != NONE) break; }
+        if (q) s_p[pn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = pos;
+        pn += add;
     }
-    if (res == NONE && qn) drain();
+    if (res == NONE && pn) drain_p();
+    if (res == NONE && qn) drain_q();
     if (lane == 0) sync[c] = res;
 }
 
@@ -480,6 +531,7 @@ __global__ void __launch_bounds__(64) gzd_decode_kernel(const uint32_t *__restri
     __shared__ Tables t;
     __shared__ WaveShared sh;
     __shared__ uint16_t s_buf[GZ_BUF];
+    __shared__ uint32_t s_tpos[64];
     const uint32_t c = blockIdx.x;
     if (c >= n_chunks) return;
     if (c && sync[c] == NONE) { if (threadIdx.x == 0) { info[c].n_out = 0; info[c].end_bit = 0; info[c].status = OK; info[c].n_members = 0; } return; }
@@ -488,7 +540,7 @@ __global__ void __launch_bounds__(64) gzd_decode_kernel(const uint32_t *__restri
     // (a stretch with no place to start from -- stored or fixed blocks, literals that are not text -- is one wavefront's serial work: beyond
     //  walk_bytes the file is left to the reader threads' inflater)
     if (cap / ratio > walk_bytes) { if (threadIdx.x == 0) { info[c].n_out = 0; info[c].end_bit = 0; info[c].status = E_UNUSUAL; info[c].n_members = 0; } return; }
-    decode_chunk_wave<DRYRUN>(w, src_bytes, start, stop, t, sh, s_buf, sym + uni64(base), uni64(cap), &info[c], members + (size_t)c * MAX_MEMBERS);
+    decode_chunk_wave<DRYRUN>(w, src_bytes, start, stop, t, sh, s_buf, s_tpos, sym + uni64(base), uni64(cap), &info[c], members + (size_t)c * MAX_MEMBERS);
 }
 
 constexpr int GZ_NT = 1024;
@@ -502,8 +554,14 @@ __global__ void __launch_bounds__(GZ_NT) gzd_maps_kernel(const uint64_t *sync, u
         const uint16_t *s = sym + (uint64_t)ratio * (c ? (sync[c] == NONE ? 0 : sync[c] >> 3) : 0);
         const uint16_t *prev = c == c0 ? nullptr : maps + (size_t)(c - 1) * WIN;
         uint16_t *mine = maps + (size_t)c * WIN;
-        for (uint32_t i = threadIdx.x; i < WIN; i += GZ_NT) mine[i] = map_entry(s, n, prev, i);
-        __threadfence();
+        {
+            uint16_t v[WIN / GZ_NT];                                   // (32 entries a thread: their loads overlap)
+#pragma unroll
+            for (uint32_t u = 0; u < WIN / GZ_NT; u++) v[u] = map_entry(s, n, prev, threadIdx.x + u * GZ_NT);
+#pragma unroll
+            for (uint32_t u = 0; u < WIN / GZ_NT; u++) mine[threadIdx.x + u * GZ_NT] = v[u];
+        }
+        __threadfence_block();                                    // (what is written here is read by this workgroup only, at addresses nobody read before: its own L1 serves)
         __syncthreads();
     }
 }
@@ -520,13 +578,19 @@ __global__ void __launch_bounds__(GZ_NT) gzd_groups_kernel(uint32_t n_chunks, ui
     const uint32_t t = threadIdx.x;
     if (t == 0) s_status = OK;
     for (uint32_t i = t; i < WIN; i += GZ_NT) gwin[i] = INVALID;
-    __threadfence();
+    __threadfence_block();                                    // (what is written here is read by this workgroup only, at addresses nobody read before: its own L1 serves)
     __syncthreads();
     for (uint32_t g = 1; g < n_groups; g++) {
         const uint16_t *last = maps + (size_t)(g * group - 1) * WIN, *before = gwin + (size_t)(g - 1) * WIN;
         uint16_t *mine = gwin + (size_t)g * WIN;
-        for (uint32_t i = t; i < WIN; i += GZ_NT) mine[i] = through(before, last[i]);
-        __threadfence();
+        {
+            uint16_t v[WIN / GZ_NT];
+#pragma unroll
+            for (uint32_t u = 0; u < WIN / GZ_NT; u++) v[u] = through(before, last[t + u * GZ_NT]);
+#pragma unroll
+            for (uint32_t u = 0; u < WIN / GZ_NT; u++) mine[t + u * GZ_NT] = v[u];
+        }
+        __threadfence_block();                                    // (what is written here is read by this workgroup only, at addresses nobody read before: its own L1 serves)
         __syncthreads();
     }
     // the chunks' places in the text, the members' ends: every thread a run of chunks
@@ -551,7 +615,7 @@ __global__ void __launch_bounds__(GZ_NT) gzd_groups_kernel(uint32_t n_chunks, ui
             if (nm < max_members) { const Member &mb = members[(size_t)c * MAX_MEMBERS + j]; m_end[nm] = out + mb.end; m_crc[nm] = mb.crc; m_crc[max_members + nm] = mb.isize; }
         out += info[c].n_out;
     }
-    __threadfence();
+    __threadfence_block();                                    // (what is written here is read by this workgroup only, at addresses nobody read before: its own L1 serves)
     __syncthreads();
     const uint32_t total_m = fi->n_members < max_members ? fi->n_members : max_members;
     for (uint32_t i = t; i < total_m; i += GZ_NT) {
@@ -632,15 +696,17 @@ int gz_device_decode(skx_ctx *ctx, hipStream_t st, const uint8_t *src, uint64_t 
 {
     (void)ctx;
     const long kb = knob("gz_chunk_kb"), kr = knob("gz_ratio"), kg = knob("gz_group");
-    wk.chunk_bytes = (uint32_t)(kb > 0 ? kb : 32) << 10;
+    wk.chunk_bytes = (uint32_t)(kb > 0 ? kb : 16) << 10;
     wk.src = src; wk.src_bytes = bytes;
     wk.n_chunks = (uint32_t)((bytes + wk.chunk_bytes - 1) / wk.chunk_bytes);
     if (wk.n_chunks == 0) wk.n_chunks = 1;
-    uint64_t ratio = bytes ? (5 * text_hint / 2 + bytes - 1) / bytes + 2 : 8;
-    ratio = ratio < 8 ? 8 : ratio > 64 ? 64 : ratio;
+    // symbols per compressed byte: half as much again as the file's own ratio (a chunk that deflates better than that is refused: E_OVERFLOW).
+    // Kept tight on purpose: 2 bytes a symbol, and memory another process has just released is slow to get (profiles/r06zg)
+    uint64_t ratio = bytes ? (3 * text_hint / 2 + bytes - 1) / bytes + 1 : 8;
+    ratio = ratio < 4 ? 4 : ratio > 64 ? 64 : ratio;
     if (kr > 0) ratio = (uint64_t)kr;
     wk.ratio = (uint32_t)ratio;
-    wk.group = (uint32_t)(kg > 0 ? kg : 32);
+    wk.group = (uint32_t)(kg > 0 ? kg : 64);
     wk.n_groups = (wk.n_chunks + wk.group - 1) / wk.group;
     wk.max_members = wk.n_chunks * 8 + 64;
     SKX_TRY(ensure(wk.sync, (size_t)wk.n_chunks + 1));

@@ -359,11 +359,20 @@ def test_read_set_pipeline_equals_one_shot(tmp_path):
                         open(dst, "wb").write(gzip.compress(raw, 1))
                     names.append(dst)
                 f.write(f"r{i}\t" + "\t".join(names) + "\n")
-        for knobs in ("", "reads_raw=2", "reads_raw=1"):
+        # (round 6: the device inflates what the feeder threads hand it as compressed bytes -- reads_gz=2: every sample, reads_gz=1: none -- and the
+        #  other readers inflate; a file the device does not vouch for goes through the reader's inflater after all)
+        import json
+        for knobs in ("", "reads_gz=2", "reads_gz=1", "reads_gz=2,gz_chunk_kb=4,gz_group=3", "reads_raw=2", "reads_raw=1"):
+            ph = os.path.join(wd, "ph_gz.json")
             r = subprocess.run([SKA, "build", "-f", f"list_{tag}.txt", "-o", f"{tag}31", "-k", "31", "--min-count", "3", "--threads", "4"], cwd=wd, capture_output=True, timeout=300,
-                               env=dict(os.environ, SKX_KNOBS=knobs))
+                               env=dict(os.environ, SKX_KNOBS=knobs, SKX_PHASES=ph))
             assert r.returncode == 0, r.stderr[-600:]
             assert open(os.path.join(wd, f"{tag}31.skf"), "rb").read() == open(os.path.join(wd, "pipe31.skf"), "rb").read(), (tag, knobs)
+            phases = json.load(open(ph))
+            if knobs.startswith("reads_gz=2") and not two_members:
+                assert phases.get("build.reads_samples_sent_compressed") == len(pairs) and not phases.get("build.reads_samples_inflated_on_host_after_all"), phases
+            if knobs == "reads_gz=1":
+                assert not phases.get("build.reads_samples_sent_compressed"), phases
     # files of many members (bgzip's 64 KB blocks, files joined with cat): their trailers give the last member's length only, so six times the
     # file's size stands for the text's (round 6) and the pipeline takes them as they are -- the phase table says it did
     import json
@@ -376,7 +385,7 @@ def test_read_set_pipeline_equals_one_shot(tmp_path):
                 open(dst, "wb").write(b"".join(gzip.compress(raw[o:o + 60_000], 6) for o in range(0, len(raw), 60_000)) + gzip.compress(b""))
                 names.append(dst)
             f.write(f"r{i}\t" + "\t".join(names) + "\n")
-    for knobs in ("", "reads_raw=2", "reads_raw=1"):
+    for knobs in ("", "reads_gz=2", "reads_gz=1", "reads_raw=2", "reads_raw=1"):
         ph = os.path.join(wd, "ph_bgzf.json")
         r = subprocess.run([SKA, "build", "-f", "list_bgzf.txt", "-o", "bgzf31", "-k", "31", "--min-count", "3", "--threads", "4"], cwd=wd, capture_output=True, timeout=300,
                            env=dict(os.environ, SKX_KNOBS=knobs, SKX_PHASES=ph))
@@ -388,7 +397,7 @@ def test_read_set_pipeline_equals_one_shot(tmp_path):
     open(os.path.join(wd, "cut.fastq.gz"), "wb").write(z[:len(z) * 6 // 10])
     with open(os.path.join(wd, "list_cut.txt"), "w") as f:
         f.write(f"r0\t{pairs[0][0]}.gz.gz\nr4\t{os.path.join(wd, 'cut.fastq.gz')}\nr5\t{pairs[5][0]}.gz.gz\n")
-    for env in ({}, {"SKX_KNOBS": "reads_raw=2"}, {"SKX_KNOBS": "reads_raw=1"}, {"SKX_KNOBS": "no_reads_pipeline=1"}):
+    for env in ({}, {"SKX_KNOBS": "reads_gz=2"}, {"SKX_KNOBS": "reads_gz=1"}, {"SKX_KNOBS": "reads_raw=2"}, {"SKX_KNOBS": "reads_raw=1"}, {"SKX_KNOBS": "no_reads_pipeline=1"}):
         r = subprocess.run([SKA, "build", "-f", "list_cut.txt", "-o", "cut", "-k", "31", "--min-count", "3", "--threads", "3"], cwd=wd, capture_output=True, timeout=300, env=dict(os.environ, **env))
         assert r.returncode != 0 and b"Invalid" in r.stderr, r.stderr[-400:]
     bad = open(pairs[2][0], "rb").read()
