@@ -1121,6 +1121,13 @@ static int build_reads_pipelined(skx_ctx *ctx, const char *const *file1, const c
         }();
         if (ar != SKX_OK) { krc = ar; { std::lock_guard<std::mutex> lk(ring.mu); ring.abort = true; } ring.cv_stream.notify_all(); ring.cv_free.notify_all(); }
     }
+    // the inflater's buffers at the size of the batch's largest file, before the first decode (see gz_device_reserve)
+    if (G && krc == SKX_OK) {
+        for (int i = 0; i < n && krc == SKX_OK; i++)
+            if (gzs[i].gz_files == gzs[i].files)
+                for (int f = 0; f < gzs[i].files && krc == SKX_OK; f++) krc = gz_device_reserve(gzw2[0][f], gzs[i].comp[f], gzs[i].hint[f]);
+        if (krc != SKX_OK) { { std::lock_guard<std::mutex> lk(ring.mu); ring.abort = true; } ring.cv_stream.notify_all(); ring.cv_free.notify_all(); }
+    }
     int inflight = -1; const int inflight_set = 0, cur_set = 0;
     auto gz_start = [&](int i, int set) -> int {
         const uint8_t *comp = gz_slots[(size_t)smp[i].slot].p;

@@ -20,11 +20,11 @@
 //                       their lengths), the members' ends and lengths against their trailers, the file's verdict, its first and last byte
 //   gzd_text_kernel   : every symbol to its byte (through the previous chunk's map and the group's window), text written in place
 //   gzd_crc_kernel / gzd_crc_check_kernel : CRC-32 of every member from 4 KB pieces joined by multiplication mod P, against the trailers
-// Measured (MI355X, one 129 MB file of 150 bp reads at level 1 = 256 MB of text, 72 M tokens; profiles/r06zf, r06zh): find 2.8 ms, decode
-// 15 ms, maps 0.6, groups 1.2, text 0.85, CRC 1.0 ms = 21 ms a file (zlib on one core of the box: 0.78 s).  The decode is bound by instruction
+// Measured (MI355X, one 129 MB file of 150 bp reads at level 1 = 256 MB of text, 72 M tokens; profiles/r06zi): find 2.3 ms, decode
+// 12.2 ms, maps 1.1, groups 1.2, text 0.9, CRC 1.0 ms = 18.7 ms a file (zlib on one core of the box: 0.78 s).  The decode is bound by instruction
 // issue, not memory: 55 scalar + 33 vector instructions a token (PMC: 4.0 G + 2.4 G a file), one scalar unit a compute unit; the history
 // of its forms -- lane 0 alone 51 ms, a scalar Huffman loop 36 ms, token batches 28 ms, high occupancy 22 ms (and no better however many
-// wavefronts: 180 scalar instructions a token), look-ahead 20 -> 15 ms -- is in NOTEBOOK.md.
+// wavefronts: 180 scalar instructions a token), look-ahead 20 -> 15 ms, copies resolved in dependency turns 12 ms -- is in NOTEBOOK.md.
 // HBM traffic per text byte: 2 B written + 2 B read of symbols, 1 B of text written, 1 B read by the CRC; the compressed bytes twice.
 #include "skx_internal.h"
 #include "skx_device.h"
@@ -151,11 +151,12 @@ __device__ static int inflate_block_wave(WaveBits &b, const Tables &t, uint16_t 
         }
         s_tpos[lane] = lane < tc ? v_pos : 0xFFFFFFFFu;
         __syncthreads();
-        uint64_t nm = __ballot(near);
-        if (nm) {
-            // a copy that reads this batch's output, but only what literals and the first round's copies put there, need not wait its turn: the
-            // tokens its source runs over (found by their positions, two binary searches) hold no such copy -- itself included -- then it goes now
-            bool deep = false;
+        uint64_t pend = __ballot(near);
+        if (pend) {
+            // A copy that reads this batch's own output waits for the copies its source runs over (found by their positions: two binary
+            // searches), itself excepted -- its own earlier elements are there when it reads them, element by element.  Every turn, the copies
+            // that wait for nothing pending go, a lane each; the lowest pending one always does.  (Reads of FASTQ: two or three turns a batch.)
+            uint64_t range = 0;
             if (near) {
                 const uint32_t q0 = src > (int32_t)bs ? (uint32_t)src : bs, q1 = (uint32_t)(src + (int32_t)len - 1);
                 uint32_t a = 0, b2 = 0;
@@ -164,32 +165,18 @@ __device__ static int inflate_block_wave(WaveBits &b, const Tables &t, uint16_t 
                     if (a + step < 64u && s_tpos[a + step] <= q0) a += step;
                     if (b2 + step < 64u && s_tpos[b2 + step] <= q1) b2 += step;
                 }
-                const uint64_t upto = b2 >= 63u ? ~0ull : (2ull << b2) - 1ull;
-                deep = (nm & upto & ~((1ull << a) - 1ull)) != 0;
-                if (!deep)
+                range = (b2 >= 63u ? ~0ull : (2ull << b2) - 1ull) & ~((1ull << a) - 1ull) & ~(1ull << lane);
+            }
+            while (pend) {
+                const bool go = near && ((pend >> lane) & 1ull) && (pend & range) == 0;
+                if (go)
                     for (uint32_t j = 0; j < len; j++) {
                         const int32_t q = src + (int32_t)j;
                         s_buf[rel + j] = q < 0 ? (uint16_t)(SYM0 + (uint32_t)(q + (int32_t)WIN)) : q >= (int32_t)bs ? s_buf[(uint32_t)q - bs] : out[q];
                     }
+                __syncthreads();
+                pend &= ~__ballot(go);
             }
-            __syncthreads();
-            nm = __ballot(deep);
-        }
-        while (nm) {
-            const int k = __ffsll((long long)nm) - 1;
-            nm &= nm - 1;
-            const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)v_pos, k) - bs, l = (uint32_t)__builtin_amdgcn_readlane((int)v_meta, k) & 0x1FFu;
-            const int32_t sq = __builtin_amdgcn_readlane((int)v_src, k);
-            const uint32_t d = p + bs - (uint32_t)sq;
-            const bool wraps = d < l;
-            for (uint32_t done = 0; done < l; done += 64) {
-                const uint32_t j = done + lane;
-                if (j < l) {
-                    const int32_t q = sq + (int32_t)(wraps ? j % d : j);
-                    s_buf[p + j] = q < 0 ? (uint16_t)(SYM0 + (uint32_t)(q + (int32_t)WIN)) : q >= (int32_t)bs ? s_buf[(uint32_t)q - bs] : out[q];
-                }
-            }
-            __syncthreads();
         }
         const uint32_t span = n - bs;
         for (uint32_t i = lane; i < span; i += 64) out[bs + i] = s_buf[i];
@@ -690,18 +677,18 @@ __global__ void gzd_crc_check_kernel(const uint32_t *m_acc, const uint32_t *m_cr
 
 template <typename T> static int ensure(DevBuf<T> &b, size_t count) { return b.n >= count ? SKX_OK : b.alloc(count + count / 8); }
 
-// K0..K2 on `st`: src is the file as read (device memory, 4-byte aligned, at least 16 zero bytes behind it).  text_hint: the text's length if the
-// trailer can be believed (sizes the symbol area: `ratio` symbols per compressed byte).  wk.finfo holds the verdict when the stream has run.
-int gz_device_decode(skx_ctx *ctx, hipStream_t st, const uint8_t *src, uint64_t bytes, uint64_t text_hint, GzDevWork &wk)
+// a file's plan (chunks, groups, symbols per compressed byte) and buffers that hold it.  The pipeline reserves for every file of a batch before
+// its first decode: a buffer that had to grow later would be freed under kernels still reading it (the next decode is queued behind the last
+// sample's text kernels, not after them on the host)
+int gz_device_reserve(GzDevWork &wk, uint64_t bytes, uint64_t text_hint)
 {
-    (void)ctx;
     const long kb = knob("gz_chunk_kb"), kr = knob("gz_ratio"), kg = knob("gz_group");
     wk.chunk_bytes = (uint32_t)(kb > 0 ? kb : 16) << 10;
-    wk.src = src; wk.src_bytes = bytes;
+    wk.src_bytes = bytes;
     wk.n_chunks = (uint32_t)((bytes + wk.chunk_bytes - 1) / wk.chunk_bytes);
     if (wk.n_chunks == 0) wk.n_chunks = 1;
     // symbols per compressed byte: half as much again as the file's own ratio (a chunk that deflates better than that is refused: E_OVERFLOW).
-    // Kept tight on purpose: 2 bytes a symbol, and memory another process has just released is slow to get (profiles/r06zg)
+    // Kept tight on purpose: 2 bytes a symbol, and memory another process has just released is slow to get (NOTEBOOK round 6)
     uint64_t ratio = bytes ? (3 * text_hint / 2 + bytes - 1) / bytes + 1 : 8;
     ratio = ratio < 4 ? 4 : ratio > 64 ? 64 : ratio;
     if (kr > 0) ratio = (uint64_t)kr;
@@ -720,6 +707,16 @@ int gz_device_decode(skx_ctx *ctx, hipStream_t st, const uint8_t *src, uint64_t 
     SKX_TRY(ensure(wk.m_crc, (size_t)wk.max_members * 2));
     SKX_TRY(ensure(wk.m_acc, (size_t)wk.max_members));
     SKX_TRY(ensure(wk.finfo, sizeof(GzFileInfoDev)));
+    return SKX_OK;
+}
+
+// K0..K2 on `st`: src is the file as read (device memory, 4-byte aligned, at least 64 zero bytes behind it).  text_hint: the text's length if the
+// trailer can be believed (sizes the symbol area).  wk.finfo holds the verdict when the stream has run.
+int gz_device_decode(skx_ctx *ctx, hipStream_t st, const uint8_t *src, uint64_t bytes, uint64_t text_hint, GzDevWork &wk)
+{
+    (void)ctx;
+    SKX_TRY(gz_device_reserve(wk, bytes, text_hint));
+    wk.src = src;
     const uint32_t *w = reinterpret_cast<const uint32_t *>(src);
     const uint64_t walk = (uint64_t)(knob("gz_walk_kb") > 0 ? knob("gz_walk_kb") : 1024) << 10;
     if (knob("gz_lane0")) {                                           // (the first form: lane 0 does everything, the plain functions of gz_device.h)

@@ -204,6 +204,7 @@ struct GzDevWork {
     DevBuf<uint64_t> sync, base, m_end; DevBuf<uint32_t> m_crc, m_acc; DevBuf<uint8_t> cinfo, members, finfo; DevBuf<uint16_t> sym, maps, gwin;
     const uint8_t *src = nullptr; uint64_t src_bytes = 0; uint32_t n_chunks = 0, n_groups = 0, chunk_bytes = 0, ratio = 0, group = 0, max_members = 0;
 };
+int gz_device_reserve(GzDevWork &wk, uint64_t bytes, uint64_t text_hint);
 int gz_device_decode(skx_ctx *ctx, hipStream_t st, const uint8_t *src, uint64_t bytes, uint64_t text_hint, GzDevWork &wk);
 int gz_device_text(skx_ctx *ctx, hipStream_t st, GzDevWork &wk, uint8_t *dst, uint64_t total, uint32_t n_members);
 int stream_fastq_file(const char *path, const std::function<int(int which, const uint8_t *p, size_t n)> &emit);
