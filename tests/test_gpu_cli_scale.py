@@ -501,3 +501,47 @@ def test_read_set_pipeline_gives_way_to_the_sort_based_form(tmp_path):
     gk, gv, gc = got.export()
     ok, ov, oc = want.export()
     assert len(ok) > 10_000 and np.array_equal(gk, ok) and np.array_equal(gv, ov) and np.array_equal(gc, oc)
+
+
+def test_read_set_pipeline_gzip_samples_of_every_shape(tmp_path):
+    """Round 6: `.fastq.gz` samples reach the device as compressed bytes (skx_gzdev.hip inflates) or as what a reader thread inflated.  A batch
+    whose samples differ -- both files gzip, one gzip and one plain, one file only, a sample four times the others' size (the inflater's buffers
+    are sized for the batch's largest file before the first decode), files deflated at levels 1 / 6 / 9 and as bgzip-like members -- gives the
+    one-shot form's .skf bytes with the device inflating everything it may (reads_gz=2), nothing (reads_gz=1), or sharing (default), on 1, 2 and
+    5 reader threads (with 3 or fewer every thread feeds the device)."""
+    import gzip
+    import json
+    import synth
+    wd = str(tmp_path)
+    anc = synth.ancestor(50_000, seed=11)
+    n = 7
+    with open(os.path.join(wd, "list.txt"), "w") as f:
+        for i in range(n):
+            a, b = synth.write_read_pair(anc, i, n, os.path.join(wd, f"r{i}"), read_len=100, coverage=120.0 if i == 3 else 30.0, seed=11)
+            names = []
+            for j, src in enumerate((a, b)):
+                raw = open(src, "rb").read()
+                if i == 1 and j == 1:
+                    names.append(src)                                   # a plain second file beside a gzip first one
+                    continue
+                if i == 5 and j == 1:
+                    continue                                            # one file only
+                dst = src + ".gz"
+                if i == 4:
+                    open(dst, "wb").write(b"".join(gzip.compress(raw[o:o + 60_000], 6) for o in range(0, len(raw), 60_000)) + gzip.compress(b""))
+                else:
+                    open(dst, "wb").write(gzip.compress(raw, (1, 6, 9)[i % 3]))
+                names.append(dst)
+            f.write(f"r{i}\t" + "\t".join(names) + "\n")
+    want = None
+    for knobs, threads in (("no_reads_pipeline=1", 4), ("reads_gz=2", 5), ("reads_gz=2", 1), ("", 5), ("", 2), ("reads_gz=1", 5), ("reads_gz=2,gz_chunk_kb=4", 3)):
+        ph = os.path.join(wd, "ph.json")
+        r = subprocess.run([SKA, "build", "-f", "list.txt", "-o", "out", "-k", "31", "--min-count", "4", "--threads", str(threads)], cwd=wd, capture_output=True, timeout=300,
+                           env=dict(os.environ, SKX_KNOBS=knobs, SKX_PHASES=ph))
+        assert r.returncode == 0, (knobs, r.stderr[-600:])
+        got = open(os.path.join(wd, "out.skf"), "rb").read()
+        want = want or got
+        assert got == want, (knobs, threads)
+        phases = json.load(open(ph))
+        if knobs.startswith("reads_gz=2"):
+            assert phases.get("build.reads_samples_sent_compressed") == n - 1 and not phases.get("build.reads_samples_inflated_on_host_after_all"), (knobs, phases)
