@@ -20,11 +20,11 @@
 //                       their lengths), the members' ends and lengths against their trailers, the file's verdict, its first and last byte
 //   gzd_text_kernel   : every symbol to its byte (through the previous chunk's map and the group's window), text written in place
 //   gzd_crc_kernel / gzd_crc_check_kernel : CRC-32 of every member from 4 KB pieces joined by multiplication mod P, against the trailers
-// Measured (MI355X, one 129 MB file of 150 bp reads at level 1 = 256 MB of text, 72 M tokens; profiles/r06zi): find 2.3 ms, decode
-// 12.2 ms, maps 1.1, groups 1.2, text 0.9, CRC 1.0 ms = 18.7 ms a file (zlib on one core of the box: 0.78 s).  The decode is bound by instruction
+// Measured (MI355X, one 129 MB file of 150 bp reads at level 1 = 256 MB of text, 72 M tokens; profiles/r06zl): find 2.3 ms, decode
+// 10.6-11.3 ms, maps 1.1, groups 1.2, text 0.9, CRC 1.0 ms = 17-18 ms a file (zlib on one core of the box: 0.78 s).  The decode is bound by instruction
 // issue, not memory: 55 scalar + 33 vector instructions a token (PMC: 4.0 G + 2.4 G a file), one scalar unit a compute unit; the history
 // of its forms -- lane 0 alone 51 ms, a scalar Huffman loop 36 ms, token batches 28 ms, high occupancy 22 ms (and no better however many
-// wavefronts: 180 scalar instructions a token), look-ahead 20 -> 15 ms, copies resolved in dependency turns 12 ms -- is in NOTEBOOK.md.
+// wavefronts: 180 scalar instructions a token), look-ahead 20 -> 15 ms, copies resolved in dependency turns 12 ms, short copies unrolled a lane each and long ones shared 10.6 ms -- is in NOTEBOOK.md.
 // HBM traffic per text byte: 2 B written + 2 B read of symbols, 1 B of text written, 1 B read by the CRC; the compressed bytes twice.
 #include "skx_internal.h"
 #include "skx_device.h"
@@ -133,29 +133,49 @@ __device__ static int inflate_block_wave(WaveBits &b, const Tables &t, uint16_t 
         if (!tc) return;
         const uint32_t len = v_meta & 0x1FFu, rel = v_pos - bs;
         const int32_t src = (int32_t)v_src;
-        bool near = false;
+        // a symbol of the text so far: before the chunk (a reference), in this batch's buffer, or in memory
+        auto sym_at = [&](int32_t q) -> uint16_t { return q < 0 ? (uint16_t)(SYM0 + (uint32_t)(q + (int32_t)WIN)) : q >= (int32_t)bs ? s_buf[(uint32_t)q - bs] : out[q]; };
+        // a long copy (more than SHORT symbols: a read's header, a run), the lanes sharing its elements; one that overlaps itself repeats its first
+        // `d` symbols, which are settled when it starts
+        constexpr uint32_t SHORT = 8;
+        auto copy_long = [&](uint64_t which) {
+            while (which) {
+                const int k = __ffsll((long long)which) - 1;
+                which &= which - 1;
+                const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)v_pos, k) - bs, l = (uint32_t)__builtin_amdgcn_readlane((int)v_meta, k) & 0x1FFu;
+                const int32_t sq = __builtin_amdgcn_readlane((int)v_src, k);
+                const uint32_t d = p + bs - (uint32_t)sq;
+                for (uint32_t done = 0; done < l; done += 64) {
+                    const uint32_t j = done + lane;
+                    if (j < l) s_buf[p + j] = sym_at(sq + (int32_t)(d < l ? j % d : j));
+                }
+            }
+        };
+        bool near = false, far_long = false;
         if (lane < tc) {
             if (v_meta >> 16) s_buf[rel] = (uint16_t)v_src;
             else if (src + (int32_t)len <= (int32_t)bs) {
-                for (uint32_t j = 0; j < len; j += 4) {
-                    uint16_t x[4];
+                if (len <= SHORT) {
 #pragma unroll
-                    for (uint32_t u = 0; u < 4; u++) {
-                        const int32_t q = src + (int32_t)(j + u);
-                        x[u] = j + u < len ? (q < 0 ? (uint16_t)(SYM0 + (uint32_t)(q + (int32_t)WIN)) : out[q]) : (uint16_t)0;
+                    for (uint32_t h = 0; h < SHORT; h += 4) {
+                        uint16_t x[4];
+#pragma unroll
+                        for (uint32_t u = 0; u < 4; u++) x[u] = h + u < len ? sym_at(src + (int32_t)(h + u)) : (uint16_t)0;      // (four loads overlap)
+#pragma unroll
+                        for (uint32_t u = 0; u < 4; u++) if (h + u < len) s_buf[rel + h + u] = x[u];
                     }
-#pragma unroll
-                    for (uint32_t u = 0; u < 4; u++) if (j + u < len) s_buf[rel + j + u] = x[u];
-                }
+                } else far_long = true;
             } else near = true;
         }
         s_tpos[lane] = lane < tc ? v_pos : 0xFFFFFFFFu;
+        copy_long(__ballot(far_long));
         __syncthreads();
         uint64_t pend = __ballot(near);
         if (pend) {
             // A copy that reads this batch's own output waits for the copies its source runs over (found by their positions: two binary
             // searches), itself excepted -- its own earlier elements are there when it reads them, element by element.  Every turn, the copies
-            // that wait for nothing pending go, a lane each; the lowest pending one always does.  (Reads of FASTQ: two or three turns a batch.)
+            // that wait for nothing pending go: the short ones a lane each, the long ones one after the other with all lanes; the lowest
+            // pending one always goes.  (Reads of FASTQ: two or three turns a batch.)
             uint64_t range = 0;
             if (near) {
                 const uint32_t q0 = src > (int32_t)bs ? (uint32_t)src : bs, q1 = (uint32_t)(src + (int32_t)len - 1);
@@ -169,11 +189,11 @@ __device__ static int inflate_block_wave(WaveBits &b, const Tables &t, uint16_t 
             }
             while (pend) {
                 const bool go = near && ((pend >> lane) & 1ull) && (pend & range) == 0;
-                if (go)
-                    for (uint32_t j = 0; j < len; j++) {
-                        const int32_t q = src + (int32_t)j;
-                        s_buf[rel + j] = q < 0 ? (uint16_t)(SYM0 + (uint32_t)(q + (int32_t)WIN)) : q >= (int32_t)bs ? s_buf[(uint32_t)q - bs] : out[q];
-                    }
+                if (go && len <= SHORT) {
+#pragma unroll
+                    for (uint32_t u = 0; u < SHORT; u++) if (u < len) s_buf[rel + u] = sym_at(src + (int32_t)u);      // (in order: it may read its own symbols)
+                }
+                copy_long(__ballot(go && len > SHORT));
                 __syncthreads();
                 pend &= ~__ballot(go);
             }
