@@ -10,7 +10,7 @@ import zlib
 
 import pytest
 
-from test_gz_device_logic import fastq_text, gz
+from test_gz_device_logic import fastq_text, gz, illumina_text
 
 pytestmark = pytest.mark.gpu
 
@@ -45,6 +45,14 @@ def test_levels(E, level, monkeypatch):
         monkeypatch.setenv("SKX_KNOBS", knobs)
         status, members, got, _ = inflate(E, gz(text, level), hint=len(text))
         assert status == 0 and members == 1 and got == text, (level, knobs, status)
+
+
+def test_sequencer_style_reads(E, monkeypatch):
+    monkeypatch.setenv("SKX_KNOBS", "")
+    for level in (1, 5, 9):
+        text = illumina_text(40000, level)
+        status, members, got, _ = inflate(E, gz(text, level), hint=len(text))
+        assert status == 0 and members == 1 and got == text, level
 
 
 def test_block_kinds_members_and_headers(E, monkeypatch):

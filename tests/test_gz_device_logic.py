@@ -40,6 +40,23 @@ def fastq_text(n_reads, seed, read_len=150):
     return b"".join(out)
 
 
+def illumina_text(n_reads, seed):
+    """reads the way a sequencer's software writes them: long headers that differ in a few digits, lengths that vary (trimmed reads), the full
+    quality alphabet falling off along the read, N calls, a comment behind the '+' now and then"""
+    rng = np.random.default_rng(seed)
+    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=300_000)
+    out = []
+    for i in range(n_reads):
+        ln = int(rng.integers(35, 152))
+        p = int(rng.integers(0, len(genome) - ln))
+        seq = genome[p:p + ln].copy()
+        seq[rng.random(ln) < 0.003] = ord("N")
+        q = np.clip(40 - (np.arange(ln) // 12) + rng.integers(-8, 2, size=ln), 2, 41).astype(np.uint8) + 33
+        head = b"@A00%d:%d:HXY%dDSXX:%d:%d:%d:%d %d:N:0:ACGTTGCA+TTGACCGA" % (seed, 17 + seed, seed, 1 + i % 4, 1101 + i // 5000, int(rng.integers(1000, 32000)), int(rng.integers(1000, 37000)), 1 + i % 2)
+        out.append(head + b"\n" + seq.tobytes() + b"\n+" + (head[1:] if i % 97 == 0 else b"") + b"\n" + q.tobytes() + b"\n")
+    return b"".join(out)
+
+
 def gz(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, mem=8):
     c = zlib.compressobj(level, zlib.DEFLATED, 31, mem, strategy)
     return c.compress(data) + c.flush()
@@ -52,6 +69,13 @@ def test_levels_and_chunkings(check, level, chunk, group):
     status, total, members, chunks, synced, got = check(gz(text, level), chunk, 8, group)
     assert status == 0 and got == text and members == 1
     assert chunks < 3 or synced > 0                          # (the finder does find blocks: the chunks are not all walked by the first one)
+
+
+@pytest.mark.parametrize("level", [1, 5, 9])
+def test_sequencer_style_reads(check, level):
+    text = illumina_text(12000, level)
+    status, total, members, chunks, synced, got = check(gz(text, level), 16384, 12, 64)
+    assert status == 0 and got == text and synced > chunks // 4
 
 
 def test_strategies_stored_fixed_and_memlevel(check):
