@@ -665,6 +665,16 @@ __global__ void __launch_bounds__(256) gzd_text_kernel(const uint64_t *sync, uin
 constexpr uint32_t CRC_PIECE = 4096;
 __global__ void __launch_bounds__(256) gzd_crc_kernel(const uint8_t *text, uint64_t total, const uint64_t *m_end, uint32_t n_members, uint32_t *m_acc)
 {
+    // four bytes a step through four tables of 256 words in LDS (made here: 8 shift-and-xor steps an entry, then each table from the one before)
+    __shared__ uint32_t s_t[4][256];
+    {
+        uint32_t v = threadIdx.x;
+        for (int k = 0; k < 8; k++) v = (v >> 1) ^ ((v & 1u) ? 0xEDB88320u : 0u);
+        s_t[0][threadIdx.x] = v;
+        __syncthreads();
+        for (int tb = 1; tb < 4; tb++) { v = (v >> 8) ^ s_t[0][v & 255u]; s_t[tb][threadIdx.x] = v; }
+        __syncthreads();
+    }
     const uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     uint64_t pos = q * CRC_PIECE;
     if (pos >= total) return;
@@ -679,8 +689,7 @@ __global__ void __launch_bounds__(256) gzd_crc_kernel(const uint8_t *text, uint6
         while (p < e && ((uintptr_t)(text + p) & 3u)) state = crc_bytes(state, text + p, 1), p++;
         for (; p + 4 <= e; p += 4) {
             state ^= *reinterpret_cast<const uint32_t *>(text + p);
-#pragma unroll
-            for (int k = 0; k < 32; k++) state = (state >> 1) ^ ((state & 1u) ? 0xEDB88320u : 0u);
+            state = s_t[3][state & 255u] ^ s_t[2][(state >> 8) & 255u] ^ s_t[1][(state >> 16) & 255u] ^ s_t[0][state >> 24];
         }
         if (p < e) state = crc_bytes(state, text + p, e - p);
         const uint32_t piece = state ^ 0xFFFFFFFFu;
