@@ -86,10 +86,8 @@ __global__ void __launch_bounds__(64) gzd_decode_lane0_kernel(const uint32_t *w,
 }
 
 
-// ---- the wave forms.  The decode loop's state (bit buffer, counts, positions) is the same in every lane, so it lives in scalar registers and
-// the loop runs on the scalar unit; the vector lanes carry what is wide: 64 words of the compressed stream (a lane each, refilled by one
-// coalesced load a batch ahead), up to 64 literals waiting for one coalesced store, and a copy's elements (lane j the j-th), whose loads stay
-// in flight while the following symbols are decoded -- they are waited for when the next copy (or the block's end) needs the memory settled.
+// ---- the wave forms.  What every lane agrees on (positions, counts, the stream's words) is kept in scalar registers: values that pass through
+// vector memory or LDS are made uniform again with readfirstlane, so the compiler keeps the control flow on the scalar unit.
 __device__ static inline uint64_t uni64(uint64_t x)
 {
     return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) << 32);
