@@ -231,6 +231,7 @@ struct GroupStager {
     uint8_t *pin[2] = {nullptr, nullptr}; size_t cap[2] = {0, 0};
     std::thread th[2]; bool ok[2] = {true, true};
     size_t lo[2] = {0, 0}, hi[2] = {0, 0};
+    double t_alloc = 0.0; std::atomic<long long> us_pread{0};       // (what pinning the buffers and the team's reads cost: phases load.stager_*)
     explicit GroupStager(const char *path)
     {
         if (knob("no_load_stager")) return;
@@ -240,7 +241,7 @@ struct GroupStager {
     ~GroupStager()
     {
         for (int w = 0; w < 2; w++) { if (th[w].joinable()) th[w].join(); if (pin[w]) (void)hipHostFree(pin[w]); }
-        if (fd >= 0) ::close(fd);
+        if (fd >= 0) { ::close(fd); phase_add("load.stager_pin_alloc", t_alloc); phase_add("load.stager_reads_wall", us_pread.load() * 1e-6); }
     }
     bool on() const { return fd >= 0; }
     // file bytes [a, b) into buffer w (which nothing on the device reads any more)
@@ -252,13 +253,18 @@ struct GroupStager {
             if (pin[w]) (void)hipHostFree(pin[w]);
             pin[w] = nullptr; cap[w] = 0;
             const size_t want = n + n / 4 + (1u << 20);
+            const auto ta = std::chrono::steady_clock::now();
             if (hipHostMalloc((void **)&pin[w], want, hipHostMallocDefault) != hipSuccess) { pin[w] = nullptr; (void)hipGetLastError(); return false; }
+            t_alloc += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
             cap[w] = want;
         }
         lo[w] = a; hi[w] = b; ok[w] = true;
         uint8_t *dst = pin[w]; const int fdc = fd; const int team = (int)std::max<size_t>(1, std::min<size_t>((size_t)nt, n >> 20));
         bool *okp = &ok[w];
-        th[w] = std::thread([dst, fdc, a, n, team, okp]() {
+        std::atomic<long long> *usp = &us_pread;
+        th[w] = std::thread([dst, fdc, a, n, team, okp, usp]() {
+            const auto tr = std::chrono::steady_clock::now();
+            struct Add { std::atomic<long long> *u; std::chrono::steady_clock::time_point t0; ~Add() { *u += (long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); } } add{usp, tr};
             std::atomic<bool> good{true};
             auto slice = [&](int t) {
                 size_t p = n * (size_t)t / (size_t)team, e = n * (size_t)(t + 1) / (size_t)team;

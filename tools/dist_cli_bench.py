@@ -16,7 +16,7 @@ def run(args):
     t = time.perf_counter(); r = subprocess.run([SKA, *args], cwd=td, capture_output=True, env=env); dt = time.perf_counter() - t
     assert r.returncode == 0, r.stderr[-300:]
     return dt, json.load(open(os.path.join(td, "ph.json")))
-run(["build", "-f", "list.txt", "-o", "all", "-k", "31", "--threads", "32"])
+run(["build", "-f", "list.txt", "-o", "all", "-k", os.environ.get("DCB_K", "31"), "--threads", "32"])
 for flags in ([], ["--allow-ambiguous"], ["--min-freq", "0.9"]):
     dt, ph = run(["distance", "all.skf", "-o", "d.tsv", *flags])
     print(n, "samples, ska distance", " ".join(flags), ": %.2f s wall," % dt, "%d pairs," % (n * (n - 1) // 2), "table %.1f MB" % (os.path.getsize(os.path.join(td, "d.tsv")) / 1e6), {k: round(v, 3) for k, v in ph.items()})
