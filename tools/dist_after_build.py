@@ -10,16 +10,16 @@ for i in range(n):
     p = os.path.join(td, f"g{i}.fa"); synth.to_fasta(synth.sample_stream(anc, i, n), p); files.append(p)
 open(os.path.join(td, "list.txt"), "w").write("".join(f"g{i}\t{p}\n" for i, p in enumerate(files)))
 SKA = os.path.join(ROOT, "ska.rust_amd", "ska")
-def run(args, knobs=""):
-    env = dict(os.environ, SKX_PHASES=os.path.join(td, "ph.json"), SKX_KNOBS=knobs)
+def run(args, knobs="", extra=None):
+    env = dict(os.environ, SKX_PHASES=os.path.join(td, "ph.json"), SKX_KNOBS=knobs, **(extra or {}))
     t = time.perf_counter(); r = subprocess.run([SKA, *args], cwd=td, capture_output=True, env=env); dt = time.perf_counter() - t
     assert r.returncode == 0, r.stderr[-300:]
     return dt, json.load(open(os.path.join(td, "ph.json")))
-for k in ("31",):
-    for tag, knobs, pause in (("default", "", 0), ("no_load_stager", "no_load_stager=1", 0), ("default", "", 0), ("pause 0.3 s", "", 0.3), ("default", "", 0)):
-        dt, ph = run(["build", "-f", "list.txt", "-o", "all", "-k", k, "--threads", "32"])
+for k in ("41", "31"):
+    for tag, knobs, pause in (("default", "", 0), ("builder keeps teardown", "", -2), ("default", "", 0), ("builder keeps teardown", "", -2), ("default", "", 0), ("builder keeps teardown", "", -2)):
+        dt, ph = run(["build", "-f", "list.txt", "-o", "all", "-k", k, "--threads", "32"], "", {"SKX_KEEP_TEARDOWN": "1"} if pause == -2 else None)
         if pause > 0: time.sleep(pause)
-        if pause < 0:
+        if pause == -1:
             t = time.perf_counter(); subprocess.run(["cat", os.path.join(td, "all.skf")], stdout=subprocess.DEVNULL); print("  cat all.skf: %.2f s (%.1f GB)" % (time.perf_counter() - t, os.path.getsize(os.path.join(td, "all.skf")) / 1e9))
         d1, p1 = run(["distance", "all.skf", "-o", "d.tsv"], knobs)
         d2, p2 = run(["distance", "all.skf", "-o", "d.tsv"], knobs)
