@@ -115,6 +115,8 @@ void *skx::dev_alloc(size_t bytes, hipError_t *err)
         }
     }
     void *p = nullptr;
+    const auto t_malloc = std::chrono::steady_clock::now();
+    struct Took { std::chrono::steady_clock::time_point t0; ~Took() { skx::phase_add("alloc.hipMalloc_all_threads", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); } } took{t_malloc};      // (what the driver took to hand out memory: the phase table's answer to "where did the seconds go" behind a process that has just released its own)
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {                                // out of memory: drop the cache and retry once
         (void)hipGetLastError();
