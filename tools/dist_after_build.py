@@ -1,3 +1,5 @@
+"""tools/dist_after_build.py: rounds of `ska build` + `ska distance x.skf` + the same distance again (1 000 x 5 Mbp, k = 41 then 31), with the phases that say
+where a slow process lost its seconds: hipMalloc in all threads (memory a process has just released), the loaders' stager (pinning, reads).  NOTEBOOK round 6."""
 import os, subprocess, sys, time, json, tempfile, shutil
 ROOT = "/root/repo"
 sys.path.insert(0, os.path.join(ROOT, "ska.rust_amd"))
