@@ -287,6 +287,9 @@ int  skx_cov_histogram(skx_ctx *ctx, const char *fastq_fwd, const char *fastq_re
  * The text is malloc'd (skx_free).  Errors where the reference panics: "Cannot create reference from FASTQ files",
  * "<file> has no valid sequence" (SKX_EEMPTY), "No split k-mers mapped to reference". */
 int  skx_array_map(skx_array *a, const char *reference_fasta, int ambig_mask, int repeat_mask, int format, int threads, char **buf, uint64_t *len);
+/* the `k` a .skf file states in its first fields, without loading it (0: not found there, or the file cannot be read): lets a caller that
+ * would try 64-bit keys first and 128-bit keys next (lib.rs:635-661) go to the right width at once */
+int  skx_skf_peek_k(const char *path);
 /* the context an array lives on; and a way for host glue above the ABI to leave its message in skx_last_error() */
 skx_ctx *skx_array_ctx(const skx_array *a);
 void skx_set_last_error(const char *msg);

@@ -869,6 +869,25 @@ int skf_write_stream(const char *path, const SkfMeta &m, const std::vector<skx_k
     return SKX_OK;
 }
 
+// the `k` of a file, from its first fields only (0 if the split k-mer list comes first or the file cannot be read): what width its keys need
+// without loading it
+int skf_peek_k(const char *path)
+{
+    FrameReader fr;
+    if (!fr.open(path, 1)) return 0;
+    Reader rd(fr);
+    int mj; uint64_t nf = 0;
+    if (!rd.head(mj, nf) || mj != 5) return 0;
+    for (uint64_t f = 0; f < nf && rd.ok; f++) {
+        const std::string name = rd.text();
+        if (name == "k") { const uint64_t k = rd.uint(); return rd.ok && k < 1000 ? (int)k : 0; }
+        else if (name == "rc") rd.boolean();
+        else if (name == "names") { uint64_t n = rd.array(); for (uint64_t j = 0; j < n && rd.ok; j++) rd.text(); }
+        else return 0;
+    }
+    return 0;
+}
+
 // whole-array forms (small inputs, tests)
 int skf_read(const char *path, SkfData &d)
 {

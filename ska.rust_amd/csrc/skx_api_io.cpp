@@ -409,6 +409,8 @@ extern "C" int skx_array_save(skx_array *a, const char *path)
 
 // MergeSkaArray::load (merge_ska_array.rs:201-204), streamed: row blocks are transposed into the sample-major matrix as
 // they are decoded
+extern "C" int skx_skf_peek_k(const char *path) { return path ? skx::skf_peek_k(path) : 0; }
+
 extern "C" int skx_array_load(skx_ctx *ctx, const char *path, int want_bits, skx_array **out)
 {
     return skx_guarded([&]() -> int {
@@ -422,6 +424,10 @@ extern "C" int skx_array_load(skx_ctx *ctx, const char *path, int want_bits, skx
     auto begin_rows = [&](uint64_t U, uint64_t cols) -> int {
         S = cols;
         if (S == 0 || S > 65535) { set_error("skf: unsupported number of samples"); return SKX_EFORMAT; }
+        // (the split k-mer list comes before the matrix in the file: a list that does not fit the width asked for is refused HERE, before the data
+        //  section is decoded -- `ska merge` of k > 31 files tries 64 bits first, as lib.rs:635-661 does, and was loading its first file twice)
+        if (want_bits == 64)
+            for (auto &kk : keys) if (kk.hi) { set_error("split k-mer does not fit 64 bits"); return SKX_EFORMAT; }
         a->n_rows = U; a->pitch = pitch_for(U);
         { PhaseTimer t_al("load.matrix_alloc"); SKX_TRY(a->matrix.alloc(S * a->pitch)); }
         SKX_HIP(hipMemsetAsync(a->matrix.p, '-', S * a->pitch, st));

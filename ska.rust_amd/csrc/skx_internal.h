@@ -273,6 +273,7 @@ struct SkfData {
     int k = 0, rc = 0, k_bits = 64; std::vector<std::string> names; std::string version;
     std::vector<skx_key> keys; uint64_t n_rows = 0; std::vector<uint8_t> variants; std::vector<uint64_t> counts;
 };
+int skf_peek_k(const char *path);
 int skf_read(const char *path, SkfData &out);
 int skf_write(const char *path, const SkfData &in);
 // streaming forms: the matrix moves in row blocks (row-major [nrows][n_samples]), the snappy chunks are

@@ -314,32 +314,56 @@ extern "C" int skh_merge(skx_ctx *ctx, const char *const *skf_files, int n_files
     if (n_files < 2) { skx_set_error("Need at least two files to merge"); return SKX_EINVAL; }                    // lib.rs:729-731
     std::vector<skx_array *> arrs(n_files, nullptr);
     auto cleanup = [&]() { for (auto p : arrs) if (p) skx_array_free(p); };
-    int bits = 64;
-    if (skx_array_load(ctx, skf_files[0], 64, &arrs[0]) != SKX_OK) {
-        bits = 128;
-        if (skx_array_load(ctx, skf_files[0], 128, &arrs[0]) != SKX_OK) { skx_set_error("Could not read input file: %s", skf_files[0]); return SKX_EIO; }
-    }
-    // the other files by a small team: a load is half host work (the chunk walk, the split k-mer list, the stored counts) and half device
-    // work on the context's one stream, so two or three of them side by side fill each other's gaps (`ska merge` of four 5 M-row files:
-    // loads 1.6 of 3.4 s one after the other, profiles/r06h_reads_1000.log).  SKX_KNOBS=serial_loads: one after the other.
-    {
-        std::vector<int> rc(n_files, SKX_OK);
-        std::atomic<int> next{1};
+    const auto t_m0 = std::chrono::steady_clock::now();
+    auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
+    // The files side by side, a thread each (up to four): a load is half host work (the chunk walk, the split k-mer list, the stored counts)
+    // and half device work on the context's one stream, so they fill each other's gaps (`ska merge` of four 5 M-row files: loads 1.6 of 3.4 s
+    // one after the other, profiles/r06h_reads_1000.log).  The first file's `k` says which key width to ask for; without it (or if the first
+    // file then refuses) the reference's order is followed: the first file as 64-bit keys, then as 128-bit keys, then the others
+    // (lib.rs:635-661, generic_modes.rs:99-100).  SKX_KNOBS=serial_loads: one after the other.
+    const char *kn = getenv("SKX_KNOBS");
+    const bool serial = kn && strstr(kn, "serial_loads");
+    const int k0 = skx_skf_peek_k(skf_files[0]);
+    int bits = k0 > 31 ? 128 : 64;
+    auto load_team = [&](int first, std::vector<int> &rc) {
+        std::atomic<int> next{first};
         auto work = [&]() { for (int i; (i = next.fetch_add(1)) < n_files;) rc[i] = skx_array_load(ctx, skf_files[i], bits, &arrs[i]); };
-        const char *kn = getenv("SKX_KNOBS");
-        const int team = (kn && strstr(kn, "serial_loads")) ? 1 : std::min(3, n_files - 1);
+        const int team = serial ? 1 : std::min(4, n_files - first);
         std::vector<std::thread> th;
         for (int t = 1; t < team; t++) th.emplace_back(work);
         work();
         for (auto &x : th) x.join();
-        for (int i = 1; i < n_files; i++)
-            if (rc[i] != SKX_OK) {                                                                                // generic_modes.rs:99-100
-                cleanup(); skx_set_error("Failed to load input file (inconsistent k-mer lengths?): %s", skf_files[i]); return SKX_EINVAL;
-            }
+    };
+    std::vector<int> rc(n_files, SKX_OK);
+    bool have_first = false;
+    if (k0 > 0) {
+        load_team(0, rc);
+        have_first = rc[0] == SKX_OK;
+        if (!have_first) { cleanup(); for (auto &p : arrs) p = nullptr; }
     }
+    skx_phase_add("merge.first_file_wall", since(t_m0));
+    const auto t_m1 = std::chrono::steady_clock::now();
+    if (!have_first) {
+        bits = 64;
+        if (skx_array_load(ctx, skf_files[0], 64, &arrs[0]) != SKX_OK) {
+            bits = 128;
+            if (skx_array_load(ctx, skf_files[0], 128, &arrs[0]) != SKX_OK) { skx_set_error("Could not read input file: %s", skf_files[0]); return SKX_EIO; }
+        }
+        std::fill(rc.begin(), rc.end(), SKX_OK);
+        load_team(1, rc);
+    }
+    for (int i = 1; i < n_files; i++)
+        if (rc[i] != SKX_OK) {                                                                                // generic_modes.rs:99-100
+            cleanup(); skx_set_error("Failed to load input file (inconsistent k-mer lengths?): %s", skf_files[i]); return SKX_EINVAL;
+        }
+    skx_phase_add("merge.other_files_wall", since(t_m1));
+    const auto t_m2 = std::chrono::steady_clock::now();
     skx_array *m = nullptr;
     int r = skx_array_merge(ctx, arrs.data(), n_files, &m);
+    skx_phase_add("merge.union_scatter_wall", since(t_m2));
+    const auto t_m3 = std::chrono::steady_clock::now();
     cleanup();
+    skx_phase_add("merge.release_inputs_wall", since(t_m3));
     if (r != SKX_OK) return r;
     r = skh_save_skf(m, out_prefix);
     skx_array_free(m);

@@ -67,7 +67,7 @@ skx_keyset_union skx_keyset_union_notes skx_keyset_size skx_keyset_device skx_ke
 skx_array_assemble skx_array_assemble_lazy skx_merge skx_build_and_merge skx_array_free skx_array_save skx_array_load skx_array_from_host
 skx_array_info skx_array_name skx_array_version skx_array_export skx_array_sample_kmers skx_array_pieces_info skx_array_filter
 skx_array_write_fasta skx_array_fasta skx_array_device_matrix skx_array_device_stats skx_array_set_total_samples skx_array_distance skx_free skx_ctx_timings skx_ctx_merge_path
-skx_array_merge skx_array_delete_samples skx_array_weed skx_keyset_from_fasta skx_array_ctx skx_set_last_error skx_array_map skx_cov_histogram skx_phases_json skx_phase_add skx_array_load_filtered skx_ctx_expect_output skx_array_distance_planes skx_planes_distance skx_array_distance_filtered
+skx_array_merge skx_array_delete_samples skx_array_weed skx_keyset_from_fasta skx_array_ctx skx_set_last_error skx_array_map skx_cov_histogram skx_phases_json skx_phase_add skx_skf_peek_k skx_array_load_filtered skx_ctx_expect_output skx_array_distance_planes skx_planes_distance skx_array_distance_filtered
 skx_comm_unique_id skx_comm_create skx_comm_create_local skx_comm_destroy skx_comm_rank skx_comm_world skx_comm_bytes_received skx_comm_transport skx_comm_barrier
 skx_comm_allgather skx_comm_allreduce_u32 skx_comm_gather_root skx_shard_range skx_pair_bands skx_keyset_allgather skx_array_reduce_stats skx_array_distance_sharded
 skh_build_sharded skh_align_sharded skh_distance_sharded
