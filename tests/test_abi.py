@@ -66,3 +66,19 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".cpp", ".h", ".hip", ".inc")) or f == "Makefile":
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "ska_oracle" not in txt and "libska_oracle" not in txt and "import ora" not in txt, os.path.join(dp, f)
+
+
+def test_skf_peek_k_reads_the_first_fields_only():
+    """skx_skf_peek_k (include/skx.h): a file's k without loading it -- what lets `ska merge` ask for the right key width at once (lib.rs:635-661
+    tries u64, then u128).  No device is touched."""
+    import ctypes as C
+    import glob
+    import skx_engine as eng
+    lib = eng.load_library()
+    lib.skx_skf_peek_k.argtypes = [C.c_char_p]
+    lib.skx_skf_peek_k.restype = C.c_int
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    found = {os.path.basename(f): lib.skx_skf_peek_k(f.encode()) for f in glob.glob(os.path.join(root, "**", "*.skf"), recursive=True)}
+    assert found.get("merge_k41.skf") == 41 and found.get("merge_k9.skf") == 9 and found.get("merge.skf") == 17, found
+    assert lib.skx_skf_peek_k(b"/nonexistent/file.skf") == 0
+    assert lib.skx_skf_peek_k(__file__.encode()) == 0                      # not an .skf at all
